@@ -1,0 +1,489 @@
+/*
+ * movi_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * A plain-C, scalar CPU restatement of the reference's PML / count query path
+ * (mohsenzakeri/Movi, modes 6 "regular-thresholds" and 8 "blocked-thresholds").
+ * It exists only so that tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg can check (or time) the HIP path against an independent
+ * statement of the same algorithm.  Nothing under movi_amd/ may import, link or
+ * call it.
+ *
+ * Parity pin: this restatement is checked in tests/test_oracle_golden.py against
+ * the golden vectors the reference's own tests hold for this path
+ * (tests_data/sample.fastq.pmls.sorted on an index of tests_data/ref.fasta,
+ * tests/test_pml.cpp:89-105; index-size known answers 948119 B / 711733 B,
+ * tests/test_build.cpp:37,53; MoveQuery u16 clamp tests/test_basics.cpp:304-315).
+ * The reference itself is NOT buildable in this image (needs sdsl-lite and
+ * hclust-cpp headers, fetched by its CMake from the network), so there is no
+ * oracle/_ref binary; see DESIGN.md.
+ *
+ * Every function cites the reference file:line (relative to /root/reference) it
+ * follows.  Rows are decoded straight from the on-disk bytes of index.movi.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORACLE_OK            0
+#define ORACLE_ERR_FORMAT   -1   /* not a v2 index.movi of mode 6/8            */
+#define ORACLE_ERR_INVARIANT -2  /* a "this should not happen" throw in the ref */
+
+typedef struct {
+    uint8_t  mode;                 /* header.type: 6 or 8 (include/utils.hpp:37) */
+    uint64_t row_bytes;            /* 8 or 6 (include/move_row.hpp:112-117)       */
+    uint64_t length, r, original_r, end_bwt_idx;
+    uint64_t end_thr[4];           /* end_bwt_idx_thresholds (move_structure.hpp:340) */
+    uint64_t alphamap[256];
+    uint64_t alphabet_size;
+    uint8_t  alphabet[16];
+    uint8_t *rows;                 /* r * row_bytes, owned copy                   */
+    uint64_t counts_size;
+    uint64_t counts[16];
+    uint64_t k;                    /* alphabet_size + 1                           */
+    uint64_t last_runs[16], last_offsets[16], first_runs[16], first_offsets[16];
+    uint64_t nblocks;              /* mode 8 only                                 */
+    uint32_t *id_blocks;           /* [alphabet_size][nblocks]                    */
+    uint64_t block_size;
+} oracle_index;
+
+/* alphamap_3: src/utils.cpp:5-8 */
+static const uint32_t alphamap_3[4][4] = {{3, 0, 1, 2},
+                                          {0, 3, 1, 2},
+                                          {0, 1, 3, 2},
+                                          {0, 1, 2, 3}};
+
+/* ---------------------------------------------------------------- index file */
+
+static int rd(const uint8_t *buf, size_t n, size_t *pos, void *dst, size_t len) {
+    if (*pos + len > n) return -1;
+    memcpy(dst, buf + *pos, len);
+    *pos += len;
+    return 0;
+}
+
+/* MoveStructure::deserialize, src/move_structure_io.cpp:471-511:
+ * header (:66-109, struct include/utils.hpp:32-61) | basic data (:145-184) |
+ * main table (:361-397) | overflow tables (:219-254) | counts + base intervals
+ * (:269-287) | id blocks for blocked modes (:305-324). */
+oracle_index *oracle_open(const uint8_t *buf, size_t n) {
+    oracle_index *ix = (oracle_index *)calloc(1, sizeof(oracle_index));
+    size_t p = 0;
+    uint8_t hdr[48];
+    if (!ix || rd(buf, n, &p, hdr, 48)) goto bad;
+    uint32_t magic; memcpy(&magic, hdr, 4);
+    if (magic != 0x4D4F5649u) goto bad;                 /* MOVI_MAGIC utils.hpp:29 */
+    ix->mode = hdr[7];
+    if (ix->mode != 6 && ix->mode != 8) goto bad;
+    ix->row_bytes = ix->mode == 6 ? 8 : 6;
+    memcpy(&ix->length, hdr + 16, 8);
+    memcpy(&ix->r, hdr + 24, 8);
+    memcpy(&ix->original_r, hdr + 32, 8);
+    memcpy(&ix->end_bwt_idx, hdr + 40, 8);
+    uint64_t skip[8];
+    if (rd(buf, n, &p, ix->end_thr, 32)) goto bad;      /* end_bwt_idx_thresholds */
+    if (rd(buf, n, &p, skip, 64)) goto bad;             /* next_down, next_up     */
+    uint64_t amap_size;
+    if (rd(buf, n, &p, &amap_size, 8) || amap_size != 256) goto bad;
+    if (rd(buf, n, &p, ix->alphamap, 256 * 8)) goto bad;
+    if (rd(buf, n, &p, &ix->alphabet_size, 8) || ix->alphabet_size > 8) goto bad;
+    if (rd(buf, n, &p, ix->alphabet, ix->alphabet_size)) goto bad;
+    uint8_t flags[3];                                   /* u16 nt_splitting, bool constant (move_structure.hpp:322-323) */
+    if (rd(buf, n, &p, flags, 3)) goto bad;
+    ix->rows = (uint8_t *)malloc(ix->r * ix->row_bytes + 16);
+    if (!ix->rows || rd(buf, n, &p, ix->rows, ix->r * ix->row_bytes)) goto bad;
+    for (int t = 0; t < 3; t++) {                       /* overflow tables: empty  */
+        uint64_t sz;
+        if (rd(buf, n, &p, &sz, 8)) goto bad;
+        uint64_t per = (t == 2) ? (ix->alphabet_size - 1) * 8 : 8;
+        if (p + sz * per > n) goto bad;
+        p += sz * per;
+    }
+    if (rd(buf, n, &p, &ix->counts_size, 8) || ix->counts_size > 16) goto bad;
+    if (rd(buf, n, &p, ix->counts, ix->counts_size * 8)) goto bad;
+    if (rd(buf, n, &p, &ix->k, 8) || ix->k > 16) goto bad;
+    if (rd(buf, n, &p, ix->last_runs, ix->k * 8)) goto bad;
+    if (rd(buf, n, &p, ix->last_offsets, ix->k * 8)) goto bad;
+    if (rd(buf, n, &p, ix->first_runs, ix->k * 8)) goto bad;
+    if (rd(buf, n, &p, ix->first_offsets, ix->k * 8)) goto bad;
+    if (ix->mode == 8) {
+        if (rd(buf, n, &p, &ix->nblocks, 8)) goto bad;
+        if (ix->nblocks) {
+            size_t bytes = ix->alphabet_size * ix->nblocks * 4;
+            ix->id_blocks = (uint32_t *)malloc(bytes);
+            if (!ix->id_blocks || rd(buf, n, &p, ix->id_blocks, bytes)) goto bad;
+        }
+        ix->block_size = 1048576;                       /* BLOCK_SIZE move_row_configs.hpp:102 */
+        if (p + 8 <= n) rd(buf, n, &p, &ix->block_size, 8);   /* io.cpp:321-323 */
+    }
+    return ix;
+bad:
+    if (ix) { free(ix->rows); free(ix->id_blocks); free(ix); }
+    return NULL;
+}
+
+void oracle_close(oracle_index *ix) {
+    if (!ix) return;
+    free(ix->rows); free(ix->id_blocks); free(ix);
+}
+
+uint64_t oracle_r(const oracle_index *ix) { return ix->r; }
+uint64_t oracle_length(const oracle_index *ix) { return ix->length; }
+uint64_t oracle_end_bwt_idx(const oracle_index *ix) { return ix->end_bwt_idx; }
+int      oracle_mode(const oracle_index *ix) { return ix->mode; }
+
+/* ------------------------------------------------------------------ row decode */
+
+static inline void row16(const oracle_index *ix, uint64_t i, uint16_t w[4]) {
+    memcpy(w, ix->rows + i * ix->row_bytes, ix->row_bytes);
+}
+
+/* MoveRow::get_n, include/move_row.hpp:245-248 (mode 6, 11 bits) / :287-290 (mode 8, 10 bits) */
+static inline uint64_t get_n(const oracle_index *ix, uint64_t i) {
+    uint16_t w[4]; row16(ix, i, w);
+    return ix->mode == 6 ? (w[2] & 0x7FF) : (w[1] & 0x3FF);
+}
+/* MoveRow::get_offset, move_row.hpp:250-253 / :292-295 */
+static inline uint64_t get_offset(const oracle_index *ix, uint64_t i) {
+    uint16_t w[4]; row16(ix, i, w);
+    return ix->mode == 6 ? (w[3] & 0x7FF) : (w[2] & 0x3FF);
+}
+/* MoveRow::get_c, move_row.hpp:255-257 (n >> 13) / :297-299 ((offset >> 10) & 7) */
+static inline uint32_t get_c(const oracle_index *ix, uint64_t i) {
+    uint16_t w[4]; row16(ix, i, w);
+    return ix->mode == 6 ? (uint32_t)(w[2] >> 13) : (uint32_t)((w[2] >> 10) & 7);
+}
+/* MoveRow::get_threshold, move_row.hpp:304-317 (mode 6) / :319-332 (mode 8) */
+static inline uint32_t get_threshold_bit(const oracle_index *ix, uint64_t i, uint32_t k) {
+    uint16_t w[4]; row16(ix, i, w);
+    if (ix->mode == 6) {
+        switch (k) {
+            case 0: return (w[3] >> 11) & 1;
+            case 1: return (w[2] >> 11) & 1;
+            default: return (w[2] >> 12) & 1;
+        }
+    }
+    return (w[2] >> (13 + k)) & 1;
+}
+/* MoveStructure::get_id, src/move_structure.cpp:91-102 with MoveRow::get_id
+ * move_row.hpp:232-243 (mode 6: id32 | (offset>>12)<<32) / :267-285 (mode 8: id16 | (n>>10)<<16) */
+static inline uint64_t get_id(const oracle_index *ix, uint64_t i) {
+    uint16_t w[4]; row16(ix, i, w);
+    if (ix->mode == 6) {
+        uint64_t id = (uint64_t)w[0] | ((uint64_t)w[1] << 16);
+        return id | ((uint64_t)(w[3] >> 12) << 32);
+    }
+    uint64_t bid = (uint64_t)w[0] | ((uint64_t)(w[1] >> 10) << 16);
+    if (i == ix->end_bwt_idx) return bid;
+    uint32_t c = (w[2] >> 10) & 7;
+    return bid + (uint64_t)ix->id_blocks[c * ix->nblocks + i / ix->block_size] + ix->first_runs[c + 1];
+}
+/* MoveStructure::get_thresholds, src/move_structure.cpp:305-309 */
+static inline uint64_t get_thresholds(const oracle_index *ix, uint64_t i, uint32_t k) {
+    return get_threshold_bit(ix, i, k) == 0 ? 0 : get_n(ix, i);
+}
+/* MoveStructure::get_char, src/move_structure.cpp:288-293 */
+static inline int get_char(const oracle_index *ix, uint64_t i) {
+    if (i == ix->end_bwt_idx) return '$';
+    return ix->alphabet[get_c(ix, i)];
+}
+/* MoveStructure::check_alphabet, src/move_structure.cpp:383-397 with
+ * ignore_illegal_chars == 0 and no separators.  Bytes >= 128 index out of the
+ * 256-entry alphamap in the reference (char sign extension); treated as illegal. */
+static inline int check_alphabet(const oracle_index *ix, uint8_t c) {
+    if (c >= 128) return 0;
+    return ix->alphamap[c] != 256;
+}
+
+/* ------------------------------------------------------------------- LF + ff */
+
+/* MoveStructure::fast_forward, src/move_structure.cpp:524-545 */
+static inline uint64_t fast_forward(const oracle_index *ix, uint64_t *offset, uint64_t idx) {
+    uint64_t idx_ = idx;
+    while (idx < ix->r - 1 && *offset >= get_n(ix, idx)) {
+        *offset -= get_n(ix, idx);
+        idx += 1;
+    }
+    return idx - idx_;
+}
+
+/* MoveStructure::LF_move, src/move_structure.cpp:59-87. Returns ff count or <0. */
+static inline int64_t LF_move(const oracle_index *ix, uint64_t *offset, uint64_t *i) {
+    uint64_t idx = get_id(ix, *i);
+    if (idx >= ix->r) return ORACLE_ERR_INVARIANT;                     /* :63-65 */
+    *offset = get_offset(ix, *i) + *offset;
+    uint64_t ff = 0;
+    if (idx < ix->r - 1 && *offset >= get_n(ix, idx)) {
+        ff = fast_forward(ix, offset, idx);
+        idx += ff;
+        if (ff >= 65535) return ORACLE_ERR_INVARIANT;                  /* :72-75 */
+    }
+    *i = idx;
+    return (int64_t)ff;
+}
+
+/* ------------------------------------------------------------- repositioning */
+
+/* MoveStructure::reposition_up, src/move_structure_query.cpp:188-209 */
+static uint64_t reposition_up(const oracle_index *ix, uint64_t idx, uint8_t c, uint64_t *scan) {
+    if (idx == 0) return ix->r;
+    uint8_t row_c = ix->alphabet[get_c(ix, idx)];
+    while (idx > 0 && row_c != c) {
+        *scan += 1;
+        idx -= 1;
+        row_c = ix->alphabet[get_c(ix, idx)];
+    }
+    return row_c == c ? idx : ix->r;
+}
+/* MoveStructure::reposition_down, src/move_structure_query.cpp:211-232 */
+static uint64_t reposition_down(const oracle_index *ix, uint64_t idx, uint8_t c, uint64_t *scan) {
+    if (idx == ix->r - 1) return ix->r;
+    uint8_t row_c = ix->alphabet[get_c(ix, idx)];
+    while (idx < ix->r - 1 && row_c != c) {
+        *scan += 1;
+        idx += 1;
+        row_c = ix->alphabet[get_c(ix, idx)];
+    }
+    return row_c == c ? idx : ix->r;
+}
+
+/* MoveStructure::reposition_thresholds, src/move_structure_query.cpp:513-601
+ * (no-separator branch).  Returns 1 = up, 0 = down, <0 = invariant broken. */
+static int reposition_thresholds(const oracle_index *ix, uint64_t *idx, uint64_t offset,
+                                 uint8_t r_char, uint64_t *scan) {
+    uint64_t saved_idx = *idx;
+    uint64_t alphabet_index = ix->alphamap[r_char];
+    *scan = 0;
+    uint8_t rlbwt_char = ix->alphabet[get_c(ix, *idx)];
+    uint64_t threshold_value;
+    if (*idx == ix->end_bwt_idx) {
+        threshold_value = ix->end_thr[alphabet_index];                 /* :534-535 */
+    } else {
+        alphabet_index = alphamap_3[ix->alphamap[rlbwt_char]][alphabet_index];   /* :556 */
+        if (alphabet_index == 3) return ORACLE_ERR_INVARIANT;          /* :559-561 */
+        threshold_value = get_thresholds(ix, *idx, (uint32_t)alphabet_index);
+    }
+    if (offset >= threshold_value) {                                    /* :575 */
+        *idx = reposition_down(ix, saved_idx, r_char, scan);
+        if (*idx >= ix->r || r_char != ix->alphabet[get_c(ix, *idx)]) return ORACLE_ERR_INVARIANT;
+        return 0;
+    } else {
+        *idx = reposition_up(ix, saved_idx, r_char, scan);
+        if (*idx >= ix->r || r_char != ix->alphabet[get_c(ix, *idx)]) return ORACLE_ERR_INVARIANT;
+        return 1;
+    }
+}
+
+/* ------------------------------------------------------------------------ PML */
+
+typedef struct {            /* Strand, include/read_processor.hpp:9-53 (PML fields) */
+    const uint8_t *R;
+    int64_t  len;
+    int64_t  pos_on_r;
+    uint64_t idx, offset, match_len;
+    uint16_t *out;          /* MoveQuery::matching_lens: emission order = last base first */
+    uint64_t emitted;
+} strand_t;
+
+/* ReadProcessor::reset_process, src/read_processor.cpp:65-96 (start row :69-70,
+ * identical to query_pml src/move_structure_query.cpp:237-238) */
+static inline void strand_reset(const oracle_index *ix, strand_t *s, const uint8_t *R,
+                                int64_t len, uint16_t *out) {
+    s->R = R; s->len = len; s->pos_on_r = len - 1;
+    s->idx = ix->r - 1;
+    s->offset = get_n(ix, s->idx) - 1;
+    s->match_len = 0; s->out = out; s->emitted = 0;
+}
+
+/* ReadProcessor::process_char, src/read_processor.cpp:99-256 (core :100-104,
+ * :188-238); same per-base step as MoveStructure::query_pml
+ * src/move_structure_query.cpp:266-361 with the LF taken before the step. */
+static inline int process_char(const oracle_index *ix, strand_t *s, uint64_t *ff_tot, uint64_t *scan_tot) {
+    if (s->pos_on_r < s->len - 1) {
+        int64_t ff = LF_move(ix, &s->offset, &s->idx);
+        if (ff < 0) return (int)ff;
+        *ff_tot += (uint64_t)ff;
+    }
+    uint8_t row_c = ix->alphabet[get_c(ix, s->idx)];    /* the '$' row decodes as c==0 */
+    uint8_t ch = s->R[s->pos_on_r];
+    uint64_t scan = 0;
+    if (!check_alphabet(ix, ch)) {
+        s->match_len = 0;
+    } else if (row_c == ch) {
+        s->match_len += 1;
+    } else {
+        int up = reposition_thresholds(ix, &s->idx, s->offset, ch, &scan);
+        if (up < 0) return up;
+        s->match_len = 0;
+        s->offset = up ? get_n(ix, s->idx) - 1 : 0;     /* read_processor.cpp:223 */
+    }
+    *scan_tot += scan;
+    /* MoveQuery::add_ml, include/move_query.hpp:26-38: u16 clamp */
+    s->out[s->emitted++] = s->match_len > 65535 ? 65535 : (uint16_t)s->match_len;
+    s->pos_on_r -= 1;
+    return ORACLE_OK;
+}
+
+/* One read, the --no-prefetch answer (MoveStructure::query_pml).  out gets len
+ * values in emission order (last base first), as written to the BPF file. */
+int oracle_pml(const oracle_index *ix, const uint8_t *R, int64_t len, uint16_t *out,
+               uint64_t *ff_tot, uint64_t *scan_tot) {
+    strand_t s;
+    uint64_t ff = 0, sc = 0;
+    if (len <= 0) { if (ff_tot) *ff_tot = 0; if (scan_tot) *scan_tot = 0; return ORACLE_OK; }
+    strand_reset(ix, &s, R, len, out);
+    while (s.pos_on_r > -1) {
+        int rc = process_char(ix, &s, &ff, &sc);
+        if (rc < 0) return rc;
+    }
+    if (ff_tot) *ff_tot = ff;
+    if (scan_tot) *scan_tot = sc;
+    return ORACLE_OK;
+}
+
+/* A batch, scheduled like ReadProcessor::process_latency_hiding
+ * (src/read_processor.cpp:641-730): `strands` reads in flight per thread, one
+ * base each per round, software prefetch of the next row (:719-722); OpenMP team
+ * over groups of reads like src/movi.cpp:274-301.  offs has n_reads+1 entries
+ * into seqs (bytes) and into out (u16 elements).  Used as the CPU baseline. */
+int oracle_pml_batch(const oracle_index *ix, const uint8_t *seqs, const uint64_t *offs,
+                     uint64_t n_reads, uint16_t *out, int threads, int strands,
+                     uint64_t *ff_tot, uint64_t *scan_tot) {
+    if (strands < 1) strands = 1;
+    if (strands > 64) strands = 64;
+    uint64_t n_groups = (n_reads + (uint64_t)strands - 1) / (uint64_t)strands;
+    uint64_t ff_all = 0, sc_all = 0;
+    int err = ORACLE_OK;
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#endif
+    #pragma omp parallel for schedule(dynamic, 4) reduction(+:ff_all, sc_all)
+    for (uint64_t g = 0; g < n_groups; g++) {
+        strand_t st[64];
+        int live[64];
+        uint64_t first = g * (uint64_t)strands;
+        int ns = 0, alive = 0;
+        for (int k = 0; k < strands && first + k < n_reads; k++, ns++) {
+            uint64_t rd_i = first + k;
+            int64_t len = (int64_t)(offs[rd_i + 1] - offs[rd_i]);
+            strand_reset(ix, &st[k], seqs + offs[rd_i], len, out + offs[rd_i]);
+            live[k] = len > 0;
+            alive += live[k];
+        }
+        uint64_t ff = 0, sc = 0;
+        while (alive) {
+            for (int k = 0; k < ns; k++) {
+                if (!live[k]) continue;
+                int rc = process_char(ix, &st[k], &ff, &sc);
+                if (rc < 0) {
+                    #pragma omp atomic write
+                    err = rc;
+                    live[k] = 0; alive--;
+                    continue;
+                }
+                if (st[k].pos_on_r <= -1) { live[k] = 0; alive--; }
+                else __builtin_prefetch(ix->rows + get_id(ix, st[k].idx) * ix->row_bytes, 0, 1);
+            }
+        }
+        ff_all += ff; sc_all += sc;
+    }
+    if (ff_tot) *ff_tot = ff_all;
+    if (scan_tot) *scan_tot = sc_all;
+    return err;
+}
+
+/* ---------------------------------------------------------------------- count */
+
+typedef struct { uint64_t rs, os, re, oe; } interval_t;   /* MoveInterval, include/move_intervals.hpp:10-76 */
+
+/* MoveInterval::is_empty, move_intervals.hpp:43-45 */
+static inline int iv_empty(const interval_t *v) {
+    return !((v->rs < v->re) || (v->rs == v->re && v->os <= v->oe));
+}
+/* MoveInterval::count, move_intervals.hpp:47-58 */
+static uint64_t iv_count(const oracle_index *ix, const interval_t *v) {
+    uint64_t row_count;
+    if (v->rs == v->re) {
+        row_count = v->oe - v->os + 1;
+    } else {
+        row_count = (get_n(ix, v->rs) - v->os) + (v->oe + 1);
+        for (uint64_t k = v->rs + 1; k < v->re; k++) row_count += get_n(ix, k);
+    }
+    return row_count;
+}
+
+/* MoveStructure::update_interval, src/move_structure_search.cpp:48-61 */
+static void update_interval(const oracle_index *ix, interval_t *v, uint8_t next_char) {
+    while (v->rs <= v->re && get_char(ix, v->rs) != next_char) {
+        v->rs += 1;
+        v->os = 0;
+        if (v->rs >= ix->r) break;
+    }
+    while (v->re >= v->rs && get_char(ix, v->re) != next_char) {
+        v->re -= 1;
+        v->oe = get_n(ix, v->re) - 1;
+        if (v->re == 0) break;
+    }
+}
+
+/* MoveStructure::query_backward_search, src/move_structure_search.cpp:340-352, with
+ * initialize_backward_search :261-293 (ftab_k == 0), backward_search :169-201 and
+ * backward_search_step :311-333.  Output as src/utils.cpp:248-256 prints it:
+ * matched = len - pos_on_r, count = rows in the last non-empty interval. */
+int oracle_count(const oracle_index *ix, const uint8_t *R, int64_t len,
+                 uint64_t *matched, uint64_t *count) {
+    if (len <= 0) { *matched = 0; *count = 0; return ORACLE_OK; }
+    int64_t pos_on_r = len - 1;
+    if (!check_alphabet(ix, R[pos_on_r])) {             /* :344-347 */
+        pos_on_r += 1;
+        *matched = (uint64_t)(len - pos_on_r);
+        *count = 0;
+        return ORACLE_OK;
+    }
+    uint64_t ci = ix->alphamap[R[pos_on_r]] + 1;         /* :284-291 */
+    interval_t iv = { ix->first_runs[ci], ix->first_offsets[ci], ix->last_runs[ci], ix->last_offsets[ci] };
+    interval_t prev = iv;
+    while (pos_on_r > 0 && !iv_empty(&iv)) {            /* :176 */
+        prev = iv;
+        if (!check_alphabet(ix, R[pos_on_r - 1])) {     /* :321-324 */
+            iv.rs = 1; iv.os = 0; iv.re = 0; iv.oe = 0; /* make_empty, move_intervals.hpp:36-41 */
+        } else {
+            update_interval(ix, &iv, R[pos_on_r - 1]);
+            if (!iv_empty(&iv)) {
+                if (LF_move(ix, &iv.os, &iv.rs) < 0) return ORACLE_ERR_INVARIANT;
+                if (LF_move(ix, &iv.oe, &iv.re) < 0) return ORACLE_ERR_INVARIANT;
+            }
+        }
+        if (!iv_empty(&iv)) pos_on_r -= 1;
+    }
+    const interval_t *res = iv_empty(&iv) ? &prev : &iv;
+    *matched = (uint64_t)(len - pos_on_r);
+    *count = iv_count(ix, res);
+    return ORACLE_OK;
+}
+
+int oracle_count_batch(const oracle_index *ix, const uint8_t *seqs, const uint64_t *offs,
+                       uint64_t n_reads, uint64_t *matched, uint64_t *count, int threads) {
+    int err = ORACLE_OK;
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#endif
+    #pragma omp parallel for schedule(dynamic, 64)
+    for (uint64_t i = 0; i < n_reads; i++) {
+        int rc = oracle_count(ix, seqs + offs[i], (int64_t)(offs[i + 1] - offs[i]), &matched[i], &count[i]);
+        if (rc < 0) {
+            #pragma omp atomic write
+            err = rc;
+        }
+    }
+    return err;
+}
+
+/* Single LF step exposed for generator / property tests. */
+int oracle_lf(const oracle_index *ix, uint64_t *idx, uint64_t *offset) {
+    int64_t ff = LF_move(ix, offset, idx);
+    return ff < 0 ? (int)ff : ORACLE_OK;
+}
