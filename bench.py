@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""bench.py -- PML query throughput on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the PML hot path (HIP kernel behind the C-ABI) over one
+batch of synthetic reads already resident in HBM.  Default workload = BASELINE
+config[1]: a synthetic ~10 M-row regular-thresholds (mode 6) table and
+1 M x 150 bp reads per GPU.  With N > 1 (launched by torch.distributed.run, one
+rank per GPU) rank 0 builds the index, its row table is broadcast once over
+RCCL/xGMI, every rank queries its own shard of reads, no data-path collective
+("scaling": "weak").
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+
+WORKLOADS = {
+    # name: (rows, mode, n_reads per GPU, read_len, sub_rate)
+    "c2": dict(rows=10_000_000, mode=6, reads=1_000_000, read_len=150, sub=0.01,
+               desc="synthetic 10M-row regular-thresholds table, 1M x 150bp reads per GPU (BASELINE config 2)"),
+    "c3": dict(rows=10_000_000, mode=6, reads=100_000, read_len=10_000, sub=0.08,
+               desc="synthetic 10M-row regular-thresholds table, 100k x 10kbp reads per GPU (BASELINE config 3)"),
+    "c2b": dict(rows=10_000_000, mode=8, reads=1_000_000, read_len=150, sub=0.01,
+                desc="synthetic 10M-row blocked-thresholds table, 1M x 150bp reads per GPU"),
+    "c4": dict(rows=1_000_000_000, mode=6, reads=1_250_000, read_len=150, sub=0.01,
+               desc="synthetic 1B-row regular-thresholds table (8 GB), 1.25M x 150bp reads per GPU (BASELINE config 4 shard)"),
+    "tiny": dict(rows=200_000, mode=6, reads=20_000, read_len=150, sub=0.01,
+                 desc="tiny plumbing workload"),
+}
+SEED = 20260529
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--rows", type=int, default=0)
+    ap.add_argument("--reads", type=int, default=0)
+    ap.add_argument("--read-len", type=int, default=0)
+    ap.add_argument("--variant", type=int, default=-1, help="pml kernel variant (A/B measurement)")
+    ap.add_argument("--block-threads", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-reads", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import movi_amd
+    from movi_amd._lib import IndexDescC
+    from tools import synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    wl = dict(WORKLOADS[args.workload])
+    if args.rows: wl["rows"] = args.rows
+    if args.reads: wl["reads"] = args.reads
+    if args.read_len: wl["read_len"] = args.read_len
+    mode, row_bytes = wl["mode"], (8 if wl["mode"] == 6 else 6)
+
+    # ---- index: every rank derives the same host-side structure from the seed (needed to
+    # draw reads); the DEVICE row table comes from rank 0 through one RCCL broadcast.
+    t0 = time.time()
+    six = synth.synth_index(wl["rows"], mode=mode, seed=SEED)
+    t_index_gen = time.time() - t0
+    t0 = time.time()
+    if rank == 0:
+        img = six.image()
+        _, cdesc, roff, rbytes = movi_amd.parse_index_image(img)
+        rows_host = torch.from_numpy(img[roff: roff + rbytes])
+        id_blocks = (np.ctypeslib.as_array(C.cast(cdesc.id_blocks, C.POINTER(C.c_uint32)),
+                                           shape=(int(cdesc.n_blocks) * 4,)).copy() if mode == 8 else None)
+        meta = [bytes(cdesc), id_blocks, rbytes]
+    else:
+        meta = [None, None, None]
+    if world > 1:
+        dist.broadcast_object_list(meta, src=0)
+    cdesc = IndexDescC.from_buffer_copy(meta[0])
+    id_blocks = meta[1]
+    if id_blocks is not None:
+        cdesc.id_blocks = id_blocks.ctypes.data
+    else:
+        cdesc.id_blocks = None
+    d_rows = torch.empty(meta[2] + 16, dtype=torch.uint8, device=dev)
+    if rank == 0:
+        d_rows[: meta[2]].copy_(rows_host)
+    t_bcast = 0.0
+    if world > 1:
+        torch.cuda.synchronize()
+        tb = time.time()
+        dist.broadcast(d_rows, src=0)                # the one collective of this path
+        torch.cuda.synchronize()
+        t_bcast = time.time() - tb
+    index = movi_amd.MoveIndex.from_device_rows(cdesc, d_rows.data_ptr(), device=local_rank, keepalive=d_rows)
+    if args.variant >= 0:
+        index.set_option("pml_variant", args.variant)
+    if args.block_threads:
+        index.set_option("block_threads", args.block_threads)
+    t_index_upload = time.time() - t0
+
+    # ---- reads: each rank draws its own shard (seed + rank)
+    t0 = time.time()
+    bases, offs = synth.synth_reads(six, wl["reads"], wl["read_len"], seed=SEED + 1 + rank,
+                                    sub_rate=wl["sub"], n_rate=0.001)
+    t_reads_gen = time.time() - t0
+    n_reads, n_bases = wl["reads"], int(bases.size)
+    d_bases = torch.from_numpy(bases).to(dev)
+    d_offs = torch.from_numpy(offs.view(np.int64)).to(dev)
+    d_out = torch.empty(n_bases, dtype=torch.int16, device=dev)
+    d_err = torch.zeros(n_reads, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream()
+
+    def step():
+        index.pml_device(d_bases.data_ptr(), d_offs.data_ptr(), n_reads, n_bases, d_out.data_ptr(),
+                         d_err.data_ptr(), stream.cuda_stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    st = index.last_stats(stream.cuda_stream)
+    if st.errors:
+        raise SystemExit("kernel flagged %d reads with invariant violations" % st.errors)
+
+    # ---- timed region: exactly K steps, barrier + synchronize on both sides
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    for a, b in evs:
+        a.record(stream)
+        step()
+        b.record(stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t_start
+    kern_ms = [a.elapsed_time(b) for a, b in evs]
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        tot = torch.tensor([float(n_bases)], dtype=torch.float64, device=dev)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        total_bases_per_step = float(tot.item())
+    else:
+        total_bases_per_step = float(n_bases)
+
+    f_bar = st.fast_forwards / max(n_bases, 1)
+    s_bar = st.scans / max(n_bases, 1)
+    bytes_per_base = row_bytes * (1.0 + f_bar + s_bar) + 1 + 2
+    avg_kern_s = (sum(kern_ms) / len(kern_ms)) / 1e3
+    achieved_gbs = bytes_per_base * n_bases / avg_kern_s / 1e9
+    value = total_bases_per_step * args.steps / elapsed / 1e9       # Gbases/s, whole job
+
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tf):
+        try:
+            tj = json.load(open(tf))
+            ent = tj.get(args.workload)
+            if ent and ent.get("rows") == wl["rows"] and ent.get("reads") == wl["reads"] \
+                    and ent.get("read_len") == wl["read_len"]:
+                traffic = ent.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    result = {
+        "metric": "PML query Gbases/s on regular-thresholds index" if mode == 6 else
+                  "PML query Gbases/s on blocked-thresholds index",
+        "value": value, "unit": "Gbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u32/u64 integer", "data": "synthetic",
+        "config": {"workload": args.workload, "description": wl["desc"], "rows": wl["rows"], "mode": mode,
+                   "reads_per_gpu": n_reads, "read_len": wl["read_len"], "bases_per_step_per_gpu": n_bases,
+                   "seed": SEED, "parallelism": "reads sharded x%d, index replicated (1 RCCL broadcast)" % world,
+                   "fast_forwards_per_base": round(f_bar, 4), "scans_per_base": round(s_bar, 4),
+                   "reposition_frac": round(st.repositions / max(n_bases, 1), 4),
+                   "algorithmic_bytes_per_base": round(bytes_per_base, 3),
+                   "pml_variant": args.variant, "index_gen_s": round(t_index_gen, 2),
+                   "index_upload_s": round(t_index_upload, 2), "index_broadcast_s": round(t_bcast, 3),
+                   "reads_gen_s": round(t_reads_gen, 2)},
+        "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                     "kernel": "pml_kernel", "kernel_ms_avg": avg_kern_s * 1e3,
+                     "gathers_per_s": (1.0 + f_bar + s_bar) * n_bases / avg_kern_s},
+    }
+
+    # ---- CPU baseline: the oracle restatement (scalar port, 16 strands/thread + prefetch,
+    # OpenMP over read groups) on a bounded sample of the same reads, rank 0, N == 1 only.
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle.oracle import Oracle
+        cores = os.cpu_count() or 1
+        cpu = Oracle(six.image())
+        sample = args.cpu_sample_reads or max(1, min(n_reads, int(30e6 * cores / 8) // max(wl["read_len"], 1)))
+        sb = bases[: int(offs[sample])]
+        so = offs[: sample + 1]
+        cpu.pml_batch(sb[: int(so[min(sample, 64)])], so[: min(sample, 64) + 1], threads=cores)   # warm
+        t0 = time.perf_counter()
+        exp, _, _ = cpu.pml_batch(sb, so, threads=cores, strands=16)
+        dt = time.perf_counter() - t0
+        got = d_out[: sb.size].cpu().numpy().view(np.uint16)
+        result["cpu_baseline"] = {"value": sb.size / dt / 1e9, "unit": "Gbases/s", "cores": cores, "kind": "port",
+                                  "sample": "first %d reads (%d bases) of the same batch, oracle/movi_oracle.c "
+                                            "oracle_pml_batch, %d OpenMP threads x 16 strands, %.2f s"
+                                            % (sample, sb.size, cores, dt)}
+        result["parity_sample_ok"] = bool((got == exp).all())
+        if not result["parity_sample_ok"]:
+            print("PARITY FAILURE on the cpu_baseline sample", file=sys.stderr)
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

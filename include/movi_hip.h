@@ -1,0 +1,154 @@
+/*
+ * movi_hip.h -- C-ABI of libmovi_hip.so, the MI355X (gfx950) query engine.
+ *
+ * The reference (mohsenzakeri/Movi) has no FFI seam: its CLI driver calls C++
+ * members directly.  This header declares, as plain C, exactly the calls a
+ * Movi maintainer would bind in place of those members for the PML / count
+ * query path (see INTEGRATION.md for the reference-side stub):
+ *
+ *   reference member (file:line under /root/reference)           replaced by
+ *   ------------------------------------------------------------------------
+ *   MoveStructure::deserialize      src/move_structure_io.cpp:471-511   movi_index_load / movi_index_create
+ *   std::vector<MoveRow> rlbwt + side tables  include/move_structure.hpp:339-380   movi_index_desc_t
+ *   ReadProcessor::process_latency_hiding (PML)  src/read_processor.cpp:641-730   movi_pml_host / movi_pml_device
+ *   MoveStructure::query_pml        src/move_structure_query.cpp:234-474  movi_pml_host / movi_pml_device
+ *   MoveStructure::query_backward_search  src/move_structure_search.cpp:340-352   movi_count_host / movi_count_device
+ *   ReadProcessor::backward_search + compute_match_count  src/read_processor.cpp:610-620,1096-1175   movi_count_host / movi_count_device
+ *   Classifier::classify (per-read bin maxima)  src/classifier.cpp:99-143   movi_pml_device (bin_max output)
+ *
+ * Conventions: every entry point returns an int status (MOVI_OK == 0) and never
+ * throws; movi_last_error() gives the message for the calling thread.  One
+ * movi_index_t per GPU; calls on one handle are serialised by the caller;
+ * distinct handles may be driven from distinct host threads / processes.
+ * Pointers named d_* are device pointers on the handle's GPU, h_* host pointers.
+ * No torch / C++ types appear in any signature.
+ */
+#ifndef MOVI_HIP_H
+#define MOVI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MOVI_OK              0
+#define MOVI_ERR_ARG        -1   /* bad argument                                        */
+#define MOVI_ERR_FORMAT     -2   /* not a v2 index.movi of mode 6 / 8, or unsupported    */
+#define MOVI_ERR_IO         -3   /* file could not be read                               */
+#define MOVI_ERR_HIP        -4   /* a HIP runtime call failed (message has the code)     */
+#define MOVI_ERR_NO_DEVICE  -5   /* no usable gfx950 device: there is NO CPU fallback    */
+#define MOVI_ERR_INVARIANT  -6   /* a walk hit one of the reference's "this should not
+                                    happen" throws (move_structure.cpp:63-65,72-75;
+                                    move_structure_query.cpp:582-598); per-read flags say which */
+
+#define MOVI_MODE_REGULAR_THRESHOLDS 6   /* 8-byte rows, include/move_row.hpp:131-142 */
+#define MOVI_MODE_BLOCKED_THRESHOLDS 8   /* 6-byte rows, include/move_row.hpp:128-142 */
+
+typedef struct movi_index movi_index_t;
+
+/* The in-memory result of MoveStructure::deserialize for modes 6 / 8: the packed
+ * row table (bytes exactly as stored in index.movi) plus the small side tables. */
+typedef struct movi_index_desc {
+    uint32_t mode;                    /* MOVI_MODE_*                                   */
+    uint32_t alphabet_size;           /* 4 (separators / 5-symbol indexes are rejected) */
+    uint64_t r;                       /* number of move rows                           */
+    uint64_t length;                  /* BWT length n                                  */
+    uint64_t end_bwt_idx;             /* row holding the terminator                    */
+    uint64_t end_bwt_idx_thresholds[4];
+    uint8_t  alphabet[8];             /* code -> ASCII                                 */
+    uint8_t  code_of[256];            /* ASCII -> code 0..3, 0xFF = not in the alphabet */
+    uint64_t first_runs[8], first_offsets[8], last_runs[8], last_offsets[8];  /* k = alphabet_size+1 used */
+    uint64_t n_blocks;                /* mode 8: id_blocks is [alphabet_size][n_blocks] */
+    uint64_t block_size;              /* mode 8                                        */
+    const uint32_t *id_blocks;        /* mode 8, host pointer; NULL for mode 6          */
+} movi_index_desc_t;
+
+/* Per-query statistics (whole batch), for the algorithmic-bytes formula. */
+typedef struct movi_query_stats {
+    uint64_t bases;                   /* sum of read lengths                           */
+    uint64_t fast_forwards;           /* rows stepped over in fast_forward             */
+    uint64_t scans;                   /* rows stepped over in reposition scans / interval shrink */
+    uint64_t repositions;             /* bases that took the mismatch branch           */
+    uint64_t errors;                  /* reads whose error flag is set                 */
+} movi_query_stats_t;
+
+const char *movi_last_error(void);
+int movi_version(void);
+int movi_device_count(int *count);
+
+/* ---- index ------------------------------------------------------------------ */
+
+/* Parse DIR/index.movi (fallback DIR/movi_index.bin, as
+ * src/move_structure_io.cpp:16-32) or the file itself on the host and upload it. */
+int movi_index_load(int device, const char *index_dir_or_file, movi_index_t **out);
+
+/* Parse an index.movi image already in host memory (no upload): fills desc and
+ * the offset/size of the row table inside the image.  Pure host code. */
+int movi_index_parse(const void *h_image, size_t image_bytes, movi_index_desc_t *desc,
+                     size_t *rows_offset, size_t *rows_bytes);
+
+/* Upload host tables.  h_rows = r * row_bytes bytes as in the file. */
+int movi_index_create(int device, const movi_index_desc_t *desc, const void *h_rows,
+                      movi_index_t **out);
+
+/* Adopt a row table that already lives on the device (e.g. received by an RCCL
+ * broadcast into a caller-owned buffer).  The caller keeps ownership of d_rows
+ * and must keep it alive until movi_index_destroy. */
+int movi_index_create_from_device_rows(int device, const movi_index_desc_t *desc,
+                                       const void *d_rows, movi_index_t **out);
+
+int movi_index_destroy(movi_index_t *ix);
+int movi_index_get_desc(const movi_index_t *ix, movi_index_desc_t *desc);   /* id_blocks = NULL */
+/* Device pointer + size of the resident row table (source buffer of the broadcast on rank 0). */
+int movi_index_device_rows(const movi_index_t *ix, const void **d_rows, size_t *bytes);
+
+/* ---- PML -------------------------------------------------------------------- */
+
+/* Reads are the concatenated ASCII bases; offsets has n_reads+1 entries (bytes).
+ * out_pml[offsets[i] + k] = PML of base (len_i - 1 - k) of read i, i.e. emission
+ * order (last base first), the order MoveQuery::matching_lens / the BPF record
+ * hold (include/move_query.hpp:26-38, src/utils.cpp:202-246), u16-clamped.
+ * d_read_err (optional, n_reads bytes): 1 where the walk broke an invariant.
+ * d_bin_max (optional): per-read maxima over bins of `bin_width` PMLs in emission
+ * order, the reduction Classifier::classify needs (src/classifier.cpp:105-118);
+ * d_bin_offsets has n_reads+1 entries into it.  Pass NULL/0 to skip.
+ * Asynchronous on `stream` (a hipStream_t, NULL = the null stream). */
+int movi_pml_device(movi_index_t *ix, const uint8_t *d_bases, const uint64_t *d_offsets,
+                    uint64_t n_reads, uint64_t n_bases, uint16_t *d_out_pml, uint8_t *d_read_err,
+                    void *stream);
+
+/* Same, host buffers in and out; uploads, runs, downloads, synchronises.
+ * stats may be NULL. */
+int movi_pml_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_offsets,
+                  uint64_t n_reads, uint16_t *h_out_pml, uint8_t *h_read_err,
+                  movi_query_stats_t *stats);
+
+/* Device-side counters of the last movi_pml_device / movi_count_device call on
+ * this handle; synchronises `stream` first. */
+int movi_last_stats(movi_index_t *ix, void *stream, movi_query_stats_t *stats);
+
+/* ---- count (backward search) -------------------------------------------------- */
+
+/* Per read: matched = len - pos_on_r and count = rows in the last non-empty
+ * interval, the two numbers src/utils.cpp:248-256 prints (`--no-prefetch`
+ * semantics, src/move_structure_search.cpp:340-352). */
+int movi_count_device(movi_index_t *ix, const uint8_t *d_bases, const uint64_t *d_offsets,
+                      uint64_t n_reads, uint64_t n_bases, uint64_t *d_matched, uint64_t *d_count,
+                      uint8_t *d_read_err, void *stream);
+
+int movi_count_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_offsets,
+                    uint64_t n_reads, uint64_t *h_matched, uint64_t *h_count, uint8_t *h_read_err,
+                    movi_query_stats_t *stats);
+
+/* ---- tuning ------------------------------------------------------------------- */
+
+/* Kernel variant / launch knobs, for A/B measurement (bench.py --variant).
+ * Unknown keys return MOVI_ERR_ARG.  Keys: "pml_variant", "block_threads". */
+int movi_set_option(movi_index_t *ix, const char *key, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOVI_HIP_H */

@@ -1,0 +1,491 @@
+// movi_abi.hip -- the extern "C" boundary of libmovi_hip.so (see include/movi_hip.h).
+// Host-side C++ only: index.movi parsing, device residency, launches, transfers.
+// There is deliberately NO CPU compute path here: without a HIP device every
+// query entry point fails with MOVI_ERR_NO_DEVICE / MOVI_ERR_HIP.
+#include "../../include/movi_hip.h"
+#include "movi_kernels.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include <sys/stat.h>
+
+using namespace movi;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+int fail_hip(hipError_t e, const char *what) {
+    g_err = std::string(what) + ": " + hipGetErrorString(e) + " (hipError " + std::to_string((int)e) + ")";
+    return (e == hipErrorNoDevice || e == hipErrorInvalidDevice) ? MOVI_ERR_NO_DEVICE : MOVI_ERR_HIP;
+}
+#define HIP_TRY(expr)                                            \
+    do {                                                         \
+        hipError_t e_ = (expr);                                  \
+        if (e_ != hipSuccess) return fail_hip(e_, #expr);        \
+    } while (0)
+
+constexpr uint32_t kMoviMagic = 0x4D4F5649u;   // include/utils.hpp:29
+
+struct Reader {
+    const uint8_t *p;
+    size_t n, pos = 0;
+    bool get(void *dst, size_t len) {
+        if (pos + len > n) return false;
+        memcpy(dst, p + pos, len);
+        pos += len;
+        return true;
+    }
+    bool skip(size_t len) {
+        if (pos + len > n) return false;
+        pos += len;
+        return true;
+    }
+};
+
+}  // namespace
+
+struct movi_index {
+    int device = 0;
+    movi_index_desc_t desc{};
+    std::vector<uint32_t> id_blocks_host;
+    uint8_t *d_rows = nullptr;
+    bool owns_rows = false;
+    size_t rows_bytes = 0;
+    uint8_t *d_code_of = nullptr;
+    uint32_t *d_id_blocks = nullptr;
+    uint64_t *d_ckpt = nullptr;      // built lazily by the first count query
+    DevStats *d_stats = nullptr;
+    DevIndex dev{};
+    LaunchCfg cfg;
+};
+
+extern "C" {
+
+const char *movi_last_error(void) { return g_err.c_str(); }
+int movi_version(void) { return 100; }
+
+int movi_device_count(int *count) {
+    if (!count) return fail(MOVI_ERR_ARG, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail_hip(e, "hipGetDeviceCount"); }
+    *count = n;
+    return MOVI_OK;
+}
+
+// MoveStructure::deserialize, src/move_structure_io.cpp:471-511: v2 header
+// (include/utils.hpp:32-61) | end_bwt_idx thresholds / next_down / next_up (3 x 4 x u64,
+// :145-151) | alphamap (:153-157) | alphabet (:159-169) | u16 nt_splitting, bool constant
+// (:171-172) | r rows (:361-397) | three overflow tables (:219-237) | counts and the
+// base intervals (:269-287) | mode 8: id_blocks + block_size (:305-324).
+int movi_index_parse(const void *h_image, size_t image_bytes, movi_index_desc_t *desc,
+                     size_t *rows_offset, size_t *rows_bytes) {
+    if (!h_image || !desc) return fail(MOVI_ERR_ARG, "NULL argument");
+    Reader rd{static_cast<const uint8_t *>(h_image), image_bytes};
+    uint8_t hdr[48];
+    if (!rd.get(hdr, 48)) return fail(MOVI_ERR_FORMAT, "index image shorter than the 48-byte header");
+    uint32_t magic;
+    memcpy(&magic, hdr, 4);
+    if (magic != kMoviMagic)
+        return fail(MOVI_ERR_FORMAT, "invalid magic number in header: not a Movi 2.x index file");
+    memset(desc, 0, sizeof(*desc));
+    desc->mode = hdr[7];
+    if (desc->mode != MOVI_MODE_REGULAR_THRESHOLDS && desc->mode != MOVI_MODE_BLOCKED_THRESHOLDS)
+        return fail(MOVI_ERR_FORMAT, "index mode " + std::to_string(desc->mode) +
+                                         " is not supported (only regular-thresholds=6 and blocked-thresholds=8)");
+    memcpy(&desc->length, hdr + 16, 8);
+    memcpy(&desc->r, hdr + 24, 8);
+    memcpy(&desc->end_bwt_idx, hdr + 40, 8);
+    if (desc->r == 0 || desc->end_bwt_idx >= desc->r) return fail(MOVI_ERR_FORMAT, "corrupt header (r / end_bwt_idx)");
+    if (!rd.get(desc->end_bwt_idx_thresholds, 32) || !rd.skip(64)) return fail(MOVI_ERR_FORMAT, "truncated index (basic data)");
+    uint64_t amap_n = 0;
+    if (!rd.get(&amap_n, 8) || amap_n != 256) return fail(MOVI_ERR_FORMAT, "unexpected alphamap size");
+    uint64_t amap[256];
+    if (!rd.get(amap, sizeof(amap))) return fail(MOVI_ERR_FORMAT, "truncated index (alphamap)");
+    uint64_t asz = 0;
+    if (!rd.get(&asz, 8) || asz == 0 || asz > 8) return fail(MOVI_ERR_FORMAT, "unexpected alphabet size");
+    if (!rd.get(desc->alphabet, asz)) return fail(MOVI_ERR_FORMAT, "truncated index (alphabet)");
+    if (asz > 4)
+        return fail(MOVI_ERR_FORMAT, "alphabet has " + std::to_string(asz) +
+                                         " symbols: separator / non-DNA indexes are not supported by this engine");
+    desc->alphabet_size = (uint32_t)asz;
+    for (int c = 0; c < 256; c++) desc->code_of[c] = (c < 128 && amap[c] < asz) ? (uint8_t)amap[c] : 0xFF;
+    if (!rd.skip(3)) return fail(MOVI_ERR_FORMAT, "truncated index (flags)");
+    const size_t row_b = desc->mode == MOVI_MODE_REGULAR_THRESHOLDS ? 8 : 6;
+    const size_t roff = rd.pos;
+    if (!rd.skip(desc->r * row_b)) return fail(MOVI_ERR_FORMAT, "truncated index (move rows)");
+    for (int t = 0; t < 3; t++) {
+        uint64_t sz = 0;
+        if (!rd.get(&sz, 8)) return fail(MOVI_ERR_FORMAT, "truncated index (overflow tables)");
+        if (sz != 0) return fail(MOVI_ERR_FORMAT, "non-empty overflow table in a mode 6/8 index");
+    }
+    uint64_t csz = 0;
+    if (!rd.get(&csz, 8) || csz > 8 || !rd.skip(csz * 8)) return fail(MOVI_ERR_FORMAT, "truncated index (counts)");
+    uint64_t k = 0;
+    if (!rd.get(&k, 8) || k != asz + 1) return fail(MOVI_ERR_FORMAT, "unexpected base-interval table size");
+    if (!rd.get(desc->last_runs, k * 8) || !rd.get(desc->last_offsets, k * 8) ||
+        !rd.get(desc->first_runs, k * 8) || !rd.get(desc->first_offsets, k * 8))
+        return fail(MOVI_ERR_FORMAT, "truncated index (base intervals)");
+    if (desc->mode == MOVI_MODE_BLOCKED_THRESHOLDS) {
+        if (!rd.get(&desc->n_blocks, 8)) return fail(MOVI_ERR_FORMAT, "truncated index (id blocks)");
+        // the id_blocks payload stays in the image; callers locate it via desc->id_blocks
+        desc->id_blocks = reinterpret_cast<const uint32_t *>(rd.p + rd.pos);
+        if (!rd.skip(desc->n_blocks * asz * 4)) return fail(MOVI_ERR_FORMAT, "truncated index (id blocks)");
+        desc->block_size = 1048576;                        // BLOCK_SIZE, move_row_configs.hpp:102
+        uint64_t bs = 0;
+        if (rd.get(&bs, 8)) desc->block_size = bs;         // move_structure_io.cpp:321-323
+        if (desc->block_size == 0 || desc->n_blocks * desc->block_size < desc->r)
+            return fail(MOVI_ERR_FORMAT, "id blocks do not cover the table");
+    }
+    if (rows_offset) *rows_offset = roff;
+    if (rows_bytes) *rows_bytes = desc->r * row_b;
+    return MOVI_OK;
+}
+
+static int finish_create(movi_index *ix) {
+    const movi_index_desc_t &d = ix->desc;
+    HIP_TRY(hipMalloc(&ix->d_code_of, 256));
+    HIP_TRY(hipMemcpy(ix->d_code_of, d.code_of, 256, hipMemcpyHostToDevice));
+    if (d.mode == MOVI_MODE_BLOCKED_THRESHOLDS) {
+        const size_t nb = (size_t)d.n_blocks * d.alphabet_size;
+        if (nb == 0 || ix->id_blocks_host.size() != nb) return fail(MOVI_ERR_ARG, "mode 8 needs id_blocks");
+        HIP_TRY(hipMalloc(&ix->d_id_blocks, nb * 4));
+        HIP_TRY(hipMemcpy(ix->d_id_blocks, ix->id_blocks_host.data(), nb * 4, hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMalloc(&ix->d_stats, sizeof(DevStats)));
+    HIP_TRY(hipMemset(ix->d_stats, 0, sizeof(DevStats)));
+    DevIndex &v = ix->dev;
+    v.rows = ix->d_rows;
+    v.id_blocks = ix->d_id_blocks;
+    v.code_of = ix->d_code_of;
+    v.row_start_ckpt = nullptr;
+    v.r = d.r;
+    v.end_bwt_idx = d.end_bwt_idx;
+    v.n_blocks = d.n_blocks;
+    v.block_size = d.block_size ? d.block_size : 1;
+    for (int i = 0; i < 4; i++) v.end_thr[i] = d.end_bwt_idx_thresholds[i];
+    for (int i = 0; i < 5; i++) {
+        v.first_runs[i] = d.first_runs[i];
+        v.first_offsets[i] = d.first_offsets[i];
+        v.last_runs[i] = d.last_runs[i];
+        v.last_offsets[i] = d.last_offsets[i];
+    }
+    return MOVI_OK;
+}
+
+static int check_desc(const movi_index_desc_t *desc) {
+    if (!desc) return fail(MOVI_ERR_ARG, "desc is NULL");
+    if (desc->mode != MOVI_MODE_REGULAR_THRESHOLDS && desc->mode != MOVI_MODE_BLOCKED_THRESHOLDS)
+        return fail(MOVI_ERR_ARG, "unsupported mode");
+    if (desc->r == 0 || desc->end_bwt_idx >= desc->r) return fail(MOVI_ERR_ARG, "bad r / end_bwt_idx");
+    if (desc->alphabet_size == 0 || desc->alphabet_size > 4) return fail(MOVI_ERR_ARG, "alphabet_size must be 1..4");
+    return MOVI_OK;
+}
+
+static movi_index *new_handle(int device, const movi_index_desc_t *desc) {
+    movi_index *ix = new movi_index();
+    ix->device = device;
+    ix->desc = *desc;
+    if (desc->mode == MOVI_MODE_BLOCKED_THRESHOLDS && desc->id_blocks)
+        ix->id_blocks_host.assign(desc->id_blocks, desc->id_blocks + (size_t)desc->n_blocks * desc->alphabet_size);
+    ix->desc.id_blocks = nullptr;
+    ix->rows_bytes = (size_t)desc->r * (desc->mode == MOVI_MODE_REGULAR_THRESHOLDS ? 8 : 6);
+    return ix;
+}
+
+int movi_index_create(int device, const movi_index_desc_t *desc, const void *h_rows, movi_index_t **out) {
+    if (!out || !h_rows) return fail(MOVI_ERR_ARG, "NULL argument");
+    *out = nullptr;
+    int rc = check_desc(desc);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(device));
+    movi_index *ix = new_handle(device, desc);
+    hipError_t e = hipMalloc(&ix->d_rows, ix->rows_bytes + 16);
+    if (e == hipSuccess) e = hipMemcpy(ix->d_rows, h_rows, ix->rows_bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { movi_index_destroy(ix); return fail_hip(e, "uploading the move rows"); }
+    ix->owns_rows = true;
+    rc = finish_create(ix);
+    if (rc) { std::string keep = g_err; movi_index_destroy(ix); g_err = keep; return rc; }
+    *out = ix;
+    return MOVI_OK;
+}
+
+int movi_index_create_from_device_rows(int device, const movi_index_desc_t *desc, const void *d_rows,
+                                       movi_index_t **out) {
+    if (!out || !d_rows) return fail(MOVI_ERR_ARG, "NULL argument");
+    *out = nullptr;
+    int rc = check_desc(desc);
+    if (rc) return rc;
+    if ((reinterpret_cast<uintptr_t>(d_rows) & 7u) != 0) return fail(MOVI_ERR_ARG, "d_rows must be 8-byte aligned");
+    HIP_TRY(hipSetDevice(device));
+    movi_index *ix = new_handle(device, desc);
+    ix->d_rows = const_cast<uint8_t *>(static_cast<const uint8_t *>(d_rows));
+    ix->owns_rows = false;
+    rc = finish_create(ix);
+    if (rc) { std::string keep = g_err; movi_index_destroy(ix); g_err = keep; return rc; }
+    *out = ix;
+    return MOVI_OK;
+}
+
+int movi_index_load(int device, const char *path, movi_index_t **out) {
+    if (!path || !out) return fail(MOVI_ERR_ARG, "NULL argument");
+    *out = nullptr;
+    // open_index_read, src/move_structure_io.cpp:16-41: DIR/index.movi, then DIR/movi_index.bin
+    std::string cand[3] = {std::string(path) + "/index.movi", std::string(path) + "/movi_index.bin", std::string(path)};
+    FILE *f = nullptr;
+    for (auto &c : cand) {
+        struct stat sb;
+        if (stat(c.c_str(), &sb) != 0 || !S_ISREG(sb.st_mode)) continue;
+        f = fopen(c.c_str(), "rb");
+        if (f) break;
+    }
+    if (!f) return fail(MOVI_ERR_IO, std::string("Failed to open the index file at: ") + path);
+    fseek(f, 0, SEEK_END);
+    long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    std::vector<uint8_t> img((size_t)sz);
+    if (sz <= 0 || fread(img.data(), 1, (size_t)sz, f) != (size_t)sz) {
+        fclose(f);
+        return fail(MOVI_ERR_IO, std::string("Failed to read the index file at: ") + path);
+    }
+    fclose(f);
+    movi_index_desc_t desc;
+    size_t roff = 0, rbytes = 0;
+    int rc = movi_index_parse(img.data(), img.size(), &desc, &roff, &rbytes);
+    if (rc) return rc;
+    return movi_index_create(device, &desc, img.data() + roff, out);
+}
+
+int movi_index_destroy(movi_index_t *ix) {
+    if (!ix) return MOVI_OK;
+    (void)hipSetDevice(ix->device);
+    if (ix->owns_rows && ix->d_rows) (void)hipFree(ix->d_rows);
+    if (ix->d_code_of) (void)hipFree(ix->d_code_of);
+    if (ix->d_id_blocks) (void)hipFree(ix->d_id_blocks);
+    if (ix->d_ckpt) (void)hipFree(ix->d_ckpt);
+    if (ix->d_stats) (void)hipFree(ix->d_stats);
+    delete ix;
+    return MOVI_OK;
+}
+
+int movi_index_get_desc(const movi_index_t *ix, movi_index_desc_t *desc) {
+    if (!ix || !desc) return fail(MOVI_ERR_ARG, "NULL argument");
+    *desc = ix->desc;
+    desc->id_blocks = nullptr;
+    return MOVI_OK;
+}
+
+int movi_index_device_rows(const movi_index_t *ix, const void **d_rows, size_t *bytes) {
+    if (!ix || !d_rows || !bytes) return fail(MOVI_ERR_ARG, "NULL argument");
+    *d_rows = ix->d_rows;
+    *bytes = ix->rows_bytes;
+    return MOVI_OK;
+}
+
+int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
+    if (!ix || !key) return fail(MOVI_ERR_ARG, "NULL argument");
+    if (!strcmp(key, "pml_variant")) { ix->cfg.pml_variant = (int)value; return MOVI_OK; }
+    if (!strcmp(key, "block_threads")) {
+        if (value < 64 || value > 1024 || (value & 63)) return fail(MOVI_ERR_ARG, "block_threads must be a multiple of 64 in [64,1024]");
+        ix->cfg.block_threads = (int)value;
+        return MOVI_OK;
+    }
+    return fail(MOVI_ERR_ARG, std::string("unknown option: ") + key);
+}
+
+// ---------------------------------------------------------------------------- PML
+
+int movi_pml_device(movi_index_t *ix, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
+                    uint64_t n_bases, uint16_t *d_out_pml, uint8_t *d_read_err, void *stream) {
+    if (!ix) return fail(MOVI_ERR_ARG, "index handle is NULL");
+    if (n_reads == 0) return MOVI_OK;
+    if (!d_offsets || (n_bases && (!d_bases || !d_out_pml))) return fail(MOVI_ERR_ARG, "NULL device buffer");
+    HIP_TRY(hipSetDevice(ix->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemsetAsync(ix->d_stats, 0, sizeof(DevStats), s));
+    HIP_TRY(launch_pml((int)ix->desc.mode, ix->dev, d_bases, d_offsets, n_reads, d_out_pml, d_read_err,
+                       ix->d_stats, ix->cfg, s));
+    return MOVI_OK;
+}
+
+int movi_last_stats(movi_index_t *ix, void *stream, movi_query_stats_t *stats) {
+    if (!ix || !stats) return fail(MOVI_ERR_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(ix->device));
+    HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    DevStats h{};
+    HIP_TRY(hipMemcpy(&h, ix->d_stats, sizeof(h), hipMemcpyDeviceToHost));
+    stats->fast_forwards = h.fast_forwards;
+    stats->scans = h.scans;
+    stats->repositions = h.repositions;
+    stats->errors = h.errors;
+    return MOVI_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+// Reads are cut into chunks of at most kChunkBases bases so that the staging
+// buffers stay bounded whatever the input size.
+constexpr uint64_t kChunkBases = 1ull << 28;
+
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 8); }
+};
+
+template <typename Launch, typename Fetch>
+int run_chunked(movi_index *ix, const uint8_t *h_bases, const uint64_t *h_offsets, uint64_t n_reads,
+                uint8_t *h_read_err, movi_query_stats_t *stats, Launch launch, Fetch fetch) {
+    if (stats) memset(stats, 0, sizeof(*stats));
+    uint64_t first = 0;
+    while (first < n_reads) {
+        uint64_t last = first + 1;
+        while (last < n_reads && h_offsets[last + 1] - h_offsets[first] <= kChunkBases) ++last;
+        const uint64_t nr = last - first;
+        const uint64_t b0 = h_offsets[first], nb = h_offsets[last] - b0;
+        DevBuf d_bases, d_offs, d_err;
+        HIP_TRY(d_bases.alloc(nb));
+        HIP_TRY(d_offs.alloc((nr + 1) * 8));
+        HIP_TRY(d_err.alloc(nr));
+        std::vector<uint64_t> rel(nr + 1);
+        for (uint64_t i = 0; i <= nr; i++) rel[i] = h_offsets[first + i] - b0;
+        if (nb) HIP_TRY(hipMemcpy(d_bases.p, h_bases + b0, nb, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_offs.p, rel.data(), (nr + 1) * 8, hipMemcpyHostToDevice));
+        int rc = launch(static_cast<const uint8_t *>(d_bases.p), static_cast<const uint64_t *>(d_offs.p), nr, nb,
+                        static_cast<uint8_t *>(d_err.p), first, b0);
+        if (rc) return rc;
+        movi_query_stats_t st{};
+        rc = movi_last_stats(ix, nullptr, &st);
+        if (rc) return rc;
+        rc = fetch(first, nr, b0, nb);
+        if (rc) return rc;
+        if (h_read_err) HIP_TRY(hipMemcpy(h_read_err + first, d_err.p, nr, hipMemcpyDeviceToHost));
+        if (stats) {
+            stats->bases += nb;
+            stats->fast_forwards += st.fast_forwards;
+            stats->scans += st.scans;
+            stats->repositions += st.repositions;
+            stats->errors += st.errors;
+        }
+        first = last;
+    }
+    return MOVI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int movi_pml_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_offsets, uint64_t n_reads,
+                  uint16_t *h_out_pml, uint8_t *h_read_err, movi_query_stats_t *stats) {
+    if (!ix) return fail(MOVI_ERR_ARG, "index handle is NULL");
+    if (n_reads == 0) { if (stats) memset(stats, 0, sizeof(*stats)); return MOVI_OK; }
+    if (!h_offsets || (h_offsets[n_reads] != h_offsets[0] && (!h_bases || !h_out_pml)))
+        return fail(MOVI_ERR_ARG, "NULL host buffer");
+    HIP_TRY(hipSetDevice(ix->device));
+    DevBuf d_out;
+    uint64_t out_cap = 0;
+    auto launch = [&](const uint8_t *db, const uint64_t *dof, uint64_t nr, uint64_t nb, uint8_t *derr, uint64_t,
+                      uint64_t) -> int {
+        if (nb > out_cap) {
+            if (d_out.p) { (void)hipFree(d_out.p); d_out.p = nullptr; }
+            HIP_TRY(d_out.alloc(nb * 2));
+            out_cap = nb;
+        }
+        return movi_pml_device(ix, db, dof, nr, nb, static_cast<uint16_t *>(d_out.p), derr, nullptr);
+    };
+    auto fetch = [&](uint64_t, uint64_t, uint64_t b0, uint64_t nb) -> int {
+        if (nb) HIP_TRY(hipMemcpy(h_out_pml + b0, d_out.p, nb * 2, hipMemcpyDeviceToHost));
+        return MOVI_OK;
+    };
+    movi_query_stats_t local{};
+    int rc = run_chunked(ix, h_bases, h_offsets, n_reads, h_read_err, &local, launch, fetch);
+    if (stats) *stats = local;
+    if (rc) return rc;
+    if (local.errors)
+        return fail(MOVI_ERR_INVARIANT, std::to_string(local.errors) +
+                                            " read(s) hit a move-structure invariant violation (corrupt index?)");
+    return MOVI_OK;
+}
+
+// -------------------------------------------------------------------------- count
+
+static int ensure_ckpt(movi_index *ix, hipStream_t s) {
+    if (ix->d_ckpt) return MOVI_OK;
+    const uint64_t n_chunks = (ix->desc.r + (1ull << kPrefixShift) - 1) >> kPrefixShift;
+    HIP_TRY(hipMalloc(&ix->d_ckpt, (n_chunks + 1) * sizeof(uint64_t)));
+    hipError_t e = build_row_start_ckpt((int)ix->desc.mode, ix->d_rows, ix->desc.r, ix->d_ckpt, s);
+    if (e != hipSuccess) {
+        (void)hipFree(ix->d_ckpt);
+        ix->d_ckpt = nullptr;
+        return fail_hip(e, "building the row-start checkpoints");
+    }
+    ix->dev.row_start_ckpt = ix->d_ckpt;
+    return MOVI_OK;
+}
+
+int movi_count_device(movi_index_t *ix, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
+                      uint64_t n_bases, uint64_t *d_matched, uint64_t *d_count, uint8_t *d_read_err,
+                      void *stream) {
+    if (!ix) return fail(MOVI_ERR_ARG, "index handle is NULL");
+    if (n_reads == 0) return MOVI_OK;
+    if (!d_offsets || !d_matched || !d_count || (n_bases && !d_bases)) return fail(MOVI_ERR_ARG, "NULL device buffer");
+    HIP_TRY(hipSetDevice(ix->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int rc = ensure_ckpt(ix, s);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(ix->d_stats, 0, sizeof(DevStats), s));
+    HIP_TRY(launch_count((int)ix->desc.mode, ix->dev, d_bases, d_offsets, n_reads, d_matched, d_count,
+                         d_read_err, ix->d_stats, ix->cfg, s));
+    return MOVI_OK;
+}
+
+int movi_count_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_offsets, uint64_t n_reads,
+                    uint64_t *h_matched, uint64_t *h_count, uint8_t *h_read_err, movi_query_stats_t *stats) {
+    if (!ix) return fail(MOVI_ERR_ARG, "index handle is NULL");
+    if (n_reads == 0) { if (stats) memset(stats, 0, sizeof(*stats)); return MOVI_OK; }
+    if (!h_offsets || !h_matched || !h_count || (h_offsets[n_reads] != h_offsets[0] && !h_bases))
+        return fail(MOVI_ERR_ARG, "NULL host buffer");
+    HIP_TRY(hipSetDevice(ix->device));
+    DevBuf d_m, d_c;
+    uint64_t cap = 0;
+    auto launch = [&](const uint8_t *db, const uint64_t *dof, uint64_t nr, uint64_t nb, uint8_t *derr, uint64_t,
+                      uint64_t) -> int {
+        if (nr > cap) {
+            if (d_m.p) { (void)hipFree(d_m.p); d_m.p = nullptr; }
+            if (d_c.p) { (void)hipFree(d_c.p); d_c.p = nullptr; }
+            HIP_TRY(d_m.alloc(nr * 8));
+            HIP_TRY(d_c.alloc(nr * 8));
+            cap = nr;
+        }
+        return movi_count_device(ix, db, dof, nr, nb, static_cast<uint64_t *>(d_m.p),
+                                 static_cast<uint64_t *>(d_c.p), derr, nullptr);
+    };
+    auto fetch = [&](uint64_t first, uint64_t nr, uint64_t, uint64_t) -> int {
+        HIP_TRY(hipMemcpy(h_matched + first, d_m.p, nr * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(h_count + first, d_c.p, nr * 8, hipMemcpyDeviceToHost));
+        return MOVI_OK;
+    };
+    movi_query_stats_t local{};
+    int rc = run_chunked(ix, h_bases, h_offsets, n_reads, h_read_err, &local, launch, fetch);
+    if (stats) *stats = local;
+    if (rc) return rc;
+    if (local.errors)
+        return fail(MOVI_ERR_INVARIANT, std::to_string(local.errors) +
+                                            " read(s) hit a move-structure invariant violation (corrupt index?)");
+    return MOVI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,363 @@
+// movi_kernels.hip -- gfx950 (CDNA4, wave64) kernels for the PML / count walk.
+//
+// What is computed (reference file:line under /root/reference):
+//   per read, from the last base to the first, one step per base
+//     LF_move        src/move_structure.cpp:59-87     idx = id(row); off += offset(row)
+//     fast_forward   src/move_structure.cpp:524-545   while off >= n(idx): off -= n(idx); idx++
+//     match / reposition_thresholds / reposition_up|down
+//                    src/read_processor.cpp:188-238, src/move_structure_query.cpp:188-232,513-601
+//     add_ml         include/move_query.hpp:26-38     u16 clamp, emitted last base first
+//   count: update_interval src/move_structure_search.cpp:48-61, two LF_moves per base,
+//     MoveInterval::count include/move_intervals.hpp:47-58 (O(1) here via row-start checkpoints).
+//
+// Shape of the work: integer pointer chasing.  One wavefront lane owns one read;
+// every step is one dependent random 8-byte (mode 6) / 6-byte (mode 8) row gather
+// plus a few sequential neighbour rows.  No MFMA: there is no contraction here.
+#include "movi_kernels.hpp"
+
+#include <hipcub/hipcub.hpp>
+
+namespace movi {
+
+// ------------------------------------------------------------------ row decode
+// A row is carried in registers as two dwords.
+//   mode 6 (8 B, include/move_row.hpp:131-142; masks move_row_configs.hpp:34-51):
+//     x = id[31:0]            y = n16 | offset16 << 16
+//     n16:  [10:0] n, [11] thr1, [12] thr2, [15:13] c
+//     off16:[10:0] offset, [11] thr0, [15:12] id[35:32]
+//   mode 8 (6 B, move_row.hpp:128-142; masks move_row_configs.hpp:76-104):
+//     x = id16 | n16 << 16    y = offset16
+//     n16:  [9:0] n, [15:10] id[21:16]
+//     off16:[9:0] offset, [12:10] c, [13] thr0, [14] thr1, [15] thr2
+template <int MODE>
+__device__ __forceinline__ uint2 load_row(const uint8_t *rows, uint64_t i) {
+    if (MODE == 6) {
+        return *reinterpret_cast<const uint2 *>(rows + i * 8);
+    } else {
+        const uint16_t *p = reinterpret_cast<const uint16_t *>(rows + i * 6);
+        uint32_t a = p[0], b = p[1], c = p[2];
+        return make_uint2(a | (b << 16), c);
+    }
+}
+template <int MODE> __device__ __forceinline__ uint32_t row_n(uint2 w) {
+    return MODE == 6 ? (w.y & 0x7FFu) : ((w.x >> 16) & 0x3FFu);
+}
+template <int MODE> __device__ __forceinline__ uint32_t row_off(uint2 w) {
+    return MODE == 6 ? ((w.y >> 16) & 0x7FFu) : (w.y & 0x3FFu);
+}
+template <int MODE> __device__ __forceinline__ uint32_t row_c(uint2 w) {
+    return MODE == 6 ? ((w.y >> 13) & 7u) : ((w.y >> 10) & 7u);
+}
+// threshold bit k in {0,1,2} (MoveRow::get_threshold, move_row.hpp:304-332)
+template <int MODE> __device__ __forceinline__ uint32_t row_thr(uint2 w, uint32_t k) {
+    if (MODE == 6) {
+        // k=0 -> off16 bit 11 (y bit 27); k=1 -> n16 bit 11; k=2 -> n16 bit 12
+        uint32_t sh = (k == 0) ? 27u : (10u + k);
+        return (w.y >> sh) & 1u;
+    } else {
+        return (w.y >> (13u + k)) & 1u;
+    }
+}
+// MoveStructure::get_id, src/move_structure.cpp:91-102
+template <int MODE>
+__device__ __forceinline__ uint64_t row_id(uint2 w, uint64_t idx, const DevIndex &ix) {
+    if (MODE == 6) {
+        return (uint64_t)w.x | ((uint64_t)(w.y >> 28) << 32);
+    } else {
+        uint64_t bid = (uint64_t)(w.x & 0xFFFFu) | ((uint64_t)(w.x >> 26) << 16);
+        if (idx == ix.end_bwt_idx) return bid;
+        uint32_t c = row_c<8>(w);
+        return bid + (uint64_t)ix.id_blocks[(uint64_t)c * ix.n_blocks + idx / ix.block_size] +
+               ix.first_runs[c + 1];
+    }
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s, 64);
+    return v;
+}
+
+// LF_move + fast_forward.  On entry `row` is rows[idx]; on exit it is the row of
+// the new idx.  Returns false when one of the reference's throws would fire.
+template <int MODE>
+__device__ __forceinline__ bool lf_step(const DevIndex &ix, uint64_t &idx, uint32_t &off, uint2 &row,
+                                        uint32_t &ff_total) {
+    uint64_t j = row_id<MODE>(row, idx, ix);
+    if (j >= ix.r) return false;                        // move_structure.cpp:63-65
+    off += row_off<MODE>(row);
+    row = load_row<MODE>(ix.rows, j);                   // THE dependent random gather
+    uint32_t ff = 0;
+    uint32_t n = row_n<MODE>(row);
+    while (j < ix.r - 1 && off >= n) {                  // fast_forward :524-545
+        off -= n;
+        j += 1;
+        ff += 1;
+        row = load_row<MODE>(ix.rows, j);
+        n = row_n<MODE>(row);
+    }
+    if (ff >= 65535u) return false;                     // move_structure.cpp:72-75
+    ff_total += ff;
+    idx = j;
+    return true;
+}
+
+// ------------------------------------------------------------------------- PML
+// Variant 0: one lane per read, straight per-lane loops.
+template <int MODE>
+__global__ __launch_bounds__(256) void pml_kernel_v0(DevIndex ix, const uint8_t *__restrict__ bases,
+                                                     const uint64_t *__restrict__ offs, uint64_t n_reads,
+                                                     uint16_t *__restrict__ out, uint8_t *__restrict__ err,
+                                                     DevStats *stats) {
+    __shared__ uint8_t s_code[256];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = ix.code_of[i];
+    __syncthreads();
+
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t ff_total = 0, scan_total = 0, repo_total = 0, failed = 0;
+    if (t < n_reads) {
+        const uint64_t beg = offs[t];
+        const uint64_t len = offs[t + 1] - beg;
+        const uint8_t *R = bases + beg;
+        uint16_t *O = out + beg;
+        // ReadProcessor::reset_process, src/read_processor.cpp:69-70
+        uint64_t idx = ix.r - 1;
+        uint2 row = load_row<MODE>(ix.rows, idx);
+        uint32_t off = row_n<MODE>(row) - 1;
+        uint32_t ml = 0;
+        uint64_t k = 0;
+        for (; k < len; ++k) {
+            if (k != 0) {
+                if (!lf_step<MODE>(ix, idx, off, row, ff_total)) { failed = 1; break; }
+            }
+            const uint32_t a = s_code[R[len - 1 - k]];
+            const uint32_t rc = row_c<MODE>(row);         // the '$' row decodes as c == 0
+            if (a == 0xFFu) {
+                ml = 0;                                   // check_alphabet failed
+            } else if (rc == a) {
+                ml += 1;
+            } else {
+                // reposition_thresholds, src/move_structure_query.cpp:513-601
+                repo_total += 1;
+                bool down;
+                if (idx == ix.end_bwt_idx) {
+                    down = (uint64_t)off >= ix.end_thr[a];
+                } else {
+                    const uint32_t kk = a - (a > rc ? 1u : 0u);      // alphamap_3[rc][a], utils.cpp:5-8
+                    const uint32_t thr = row_thr<MODE>(row, kk) ? row_n<MODE>(row) : 0u;
+                    down = off >= thr;
+                }
+                bool found = false;
+                if (down) {                               // reposition_down :211-232
+                    if (idx != ix.r - 1) {
+                        uint32_t c = rc;
+                        while (idx < ix.r - 1 && c != a) {
+                            scan_total += 1;
+                            idx += 1;
+                            row = load_row<MODE>(ix.rows, idx);
+                            c = row_c<MODE>(row);
+                        }
+                        found = (c == a);
+                    }
+                    off = 0;
+                } else {                                  // reposition_up :188-209
+                    if (idx != 0) {
+                        uint32_t c = rc;
+                        while (idx > 0 && c != a) {
+                            scan_total += 1;
+                            idx -= 1;
+                            row = load_row<MODE>(ix.rows, idx);
+                            c = row_c<MODE>(row);
+                        }
+                        found = (c == a);
+                    }
+                    off = row_n<MODE>(row) - 1;
+                }
+                if (!found) { failed = 1; break; }        // move_structure_query.cpp:582-598
+                ml = 0;
+            }
+            O[k] = (uint16_t)(ml > 65535u ? 65535u : ml); // MoveQuery::add_ml
+        }
+        if (failed) {
+            for (; k < len; ++k) O[k] = 0;
+        }
+        if (err) err[t] = (uint8_t)failed;
+    }
+    // one atomic per wave per counter
+    const uint32_t ffw = wave_sum(ff_total), scw = wave_sum(scan_total), rpw = wave_sum(repo_total),
+                   erw = wave_sum(failed);
+    if ((threadIdx.x & 63) == 0 && stats) {
+        if (ffw) atomicAdd(&stats->fast_forwards, (unsigned long long)ffw);
+        if (scw) atomicAdd(&stats->scans, (unsigned long long)scw);
+        if (rpw) atomicAdd(&stats->repositions, (unsigned long long)rpw);
+        if (erw) atomicAdd(&stats->errors, (unsigned long long)erw);
+    }
+}
+
+hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets,
+                      uint64_t n_reads, uint16_t *d_out, uint8_t *d_err, DevStats *d_stats,
+                      const LaunchCfg &cfg, hipStream_t stream) {
+    if (n_reads == 0) return hipSuccess;
+    const int bt = cfg.block_threads;
+    const uint64_t blocks = (n_reads + bt - 1) / bt;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    dim3 grid((unsigned)blocks), block((unsigned)bt);
+    if (mode == 6)
+        hipLaunchKernelGGL(pml_kernel_v0<6>, grid, block, 0, stream, ix, d_bases, d_offsets, n_reads, d_out,
+                           d_err, d_stats);
+    else
+        hipLaunchKernelGGL(pml_kernel_v0<8>, grid, block, 0, stream, ix, d_bases, d_offsets, n_reads, d_out,
+                           d_err, d_stats);
+    return hipGetLastError();
+}
+
+// ----------------------------------------------------------------------- count
+
+// BWT position of (row k, offset 0) from the 32-row checkpoints.
+template <int MODE>
+__device__ __forceinline__ uint64_t row_start(const DevIndex &ix, uint64_t k) {
+    uint64_t j = (k >> kPrefixShift) << kPrefixShift;
+    uint64_t p = ix.row_start_ckpt[k >> kPrefixShift];
+    for (; j < k; ++j) p += row_n<MODE>(load_row<MODE>(ix.rows, j));
+    return p;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void count_kernel_v0(DevIndex ix, const uint8_t *__restrict__ bases,
+                                                       const uint64_t *__restrict__ offs, uint64_t n_reads,
+                                                       uint64_t *__restrict__ matched,
+                                                       uint64_t *__restrict__ count, uint8_t *__restrict__ err,
+                                                       DevStats *stats) {
+    __shared__ uint8_t s_code[256];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = ix.code_of[i];
+    __syncthreads();
+
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t ff_total = 0, scan_total = 0, failed = 0;
+    if (t < n_reads) {
+        const uint64_t beg = offs[t];
+        const int64_t len = (int64_t)(offs[t + 1] - beg);
+        const uint8_t *R = bases + beg;
+        uint64_t m_out = 0, c_out = 0;
+        if (len > 0) {
+            int64_t pos = len - 1;
+            uint32_t a = s_code[R[pos]];
+            if (a == 0xFFu) {                            // move_structure_search.cpp:344-347
+                m_out = 0; c_out = 0;
+            } else {
+                // initialize_backward_search :284-291
+                uint64_t rs = ix.first_runs[a + 1], re = ix.last_runs[a + 1];
+                uint32_t os = (uint32_t)ix.first_offsets[a + 1], oe = (uint32_t)ix.last_offsets[a + 1];
+                uint64_t prs = rs, pre = re;
+                uint32_t pos_ = os, poe = oe;
+                bool empty = !((rs < re) || (rs == re && os <= oe));
+                while (pos > 0 && !empty) {              // backward_search :176
+                    prs = rs; pre = re; pos_ = os; poe = oe;
+                    const uint32_t b = s_code[R[pos - 1]];
+                    if (b == 0xFFu) {
+                        empty = true;                     // backward_search_step :321-324
+                    } else {
+                        // update_interval, src/move_structure_search.cpp:48-61 (get_char: '$' never matches)
+                        uint2 rws = load_row<MODE>(ix.rows, rs);
+                        while (rs <= re && (rs == ix.end_bwt_idx || row_c<MODE>(rws) != b)) {
+                            rs += 1; os = 0; scan_total += 1;
+                            if (rs >= ix.r) break;
+                            rws = load_row<MODE>(ix.rows, rs);
+                        }
+                        uint2 rwe = load_row<MODE>(ix.rows, re);
+                        while (re >= rs && (re == ix.end_bwt_idx || row_c<MODE>(rwe) != b)) {
+                            re -= 1; scan_total += 1;
+                            rwe = load_row<MODE>(ix.rows, re);
+                            oe = row_n<MODE>(rwe) - 1;
+                            if (re == 0) break;
+                        }
+                        empty = !((rs < re) || (rs == re && os <= oe));
+                        if (!empty) {
+                            if (!lf_step<MODE>(ix, rs, os, rws, ff_total) ||
+                                !lf_step<MODE>(ix, re, oe, rwe, ff_total)) { failed = 1; break; }
+                            empty = !((rs < re) || (rs == re && os <= oe));
+                        }
+                    }
+                    if (!empty) pos -= 1;
+                }
+                if (empty) { rs = prs; re = pre; os = pos_; oe = poe; }
+                m_out = (uint64_t)(len - pos);
+                // MoveInterval::count, include/move_intervals.hpp:47-58, in O(32) loads
+                if (rs == re) c_out = (uint64_t)oe - os + 1;
+                else c_out = (row_start<MODE>(ix, re) + oe) - (row_start<MODE>(ix, rs) + os) + 1;
+            }
+        }
+        matched[t] = failed ? 0 : m_out;
+        count[t] = failed ? 0 : c_out;
+        if (err) err[t] = (uint8_t)failed;
+    }
+    const uint32_t ffw = wave_sum(ff_total), scw = wave_sum(scan_total), erw = wave_sum(failed);
+    if ((threadIdx.x & 63) == 0 && stats) {
+        if (ffw) atomicAdd(&stats->fast_forwards, (unsigned long long)ffw);
+        if (scw) atomicAdd(&stats->scans, (unsigned long long)scw);
+        if (erw) atomicAdd(&stats->errors, (unsigned long long)erw);
+    }
+}
+
+hipError_t launch_count(int mode, const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets,
+                        uint64_t n_reads, uint64_t *d_matched, uint64_t *d_count, uint8_t *d_err,
+                        DevStats *d_stats, const LaunchCfg &cfg, hipStream_t stream) {
+    if (n_reads == 0) return hipSuccess;
+    const int bt = cfg.block_threads;
+    const uint64_t blocks = (n_reads + bt - 1) / bt;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    dim3 grid((unsigned)blocks), block((unsigned)bt);
+    if (mode == 6)
+        hipLaunchKernelGGL(count_kernel_v0<6>, grid, block, 0, stream, ix, d_bases, d_offsets, n_reads,
+                           d_matched, d_count, d_err, d_stats);
+    else
+        hipLaunchKernelGGL(count_kernel_v0<8>, grid, block, 0, stream, ix, d_bases, d_offsets, n_reads,
+                           d_matched, d_count, d_err, d_stats);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------- row-start checkpoints (setup)
+
+template <int MODE>
+__global__ __launch_bounds__(256) void chunk_sum_kernel(const uint8_t *__restrict__ rows, uint64_t r,
+                                                        uint64_t n_chunks, uint64_t *__restrict__ sums) {
+    // one wave per 64 chunks would coalesce better; this runs once per index load.
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_chunks) return;
+    uint64_t lo = j << kPrefixShift, hi = lo + (1ull << kPrefixShift);
+    if (hi > r) hi = r;
+    uint64_t s = 0;
+    for (uint64_t k = lo; k < hi; ++k) s += row_n<MODE>(load_row<MODE>(rows, k));
+    sums[j] = s;
+}
+
+hipError_t build_row_start_ckpt(int mode, const uint8_t *d_rows, uint64_t r, uint64_t *d_ckpt,
+                                hipStream_t stream) {
+    // d_ckpt has n_chunks + 1 entries; entry j = sum of n over rows [0, 32 j).
+    const uint64_t n_chunks = (r + (1ull << kPrefixShift) - 1) >> kPrefixShift;
+    uint64_t *d_sums = nullptr;
+    hipError_t e = hipMalloc(&d_sums, (n_chunks + 1) * sizeof(uint64_t));
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(d_sums, 0, (n_chunks + 1) * sizeof(uint64_t), stream);
+    if (e != hipSuccess) { (void)hipFree(d_sums); return e; }
+    const unsigned bt = 256;
+    const unsigned blocks = (unsigned)((n_chunks + bt - 1) / bt);
+    if (mode == 6)
+        hipLaunchKernelGGL(chunk_sum_kernel<6>, dim3(blocks), dim3(bt), 0, stream, d_rows, r, n_chunks, d_sums);
+    else
+        hipLaunchKernelGGL(chunk_sum_kernel<8>, dim3(blocks), dim3(bt), 0, stream, d_rows, r, n_chunks, d_sums);
+    e = hipGetLastError();
+    void *d_temp = nullptr;
+    size_t temp_bytes = 0;
+    if (e == hipSuccess)
+        e = hipcub::DeviceScan::ExclusiveSum(nullptr, temp_bytes, d_sums, d_ckpt, (int)(n_chunks + 1), stream);
+    if (e == hipSuccess) e = hipMalloc(&d_temp, temp_bytes ? temp_bytes : 8);
+    if (e == hipSuccess)
+        e = hipcub::DeviceScan::ExclusiveSum(d_temp, temp_bytes, d_sums, d_ckpt, (int)(n_chunks + 1), stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (d_temp) (void)hipFree(d_temp);
+    (void)hipFree(d_sums);
+    return e;
+}
+
+}  // namespace movi

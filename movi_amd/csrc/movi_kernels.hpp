@@ -1,0 +1,50 @@
+// movi_kernels.hpp -- device-side index view shared by the kernels and the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace movi {
+
+constexpr int kPrefixShift = 5;   // one BWT-position checkpoint every 32 rows (count path)
+
+// What every kernel needs of the index, passed by value as a kernel argument
+// (lives in the kernarg segment: scalar loads, no per-lane traffic).
+struct DevIndex {
+    const uint8_t *rows;          // r * row_bytes, packed exactly as in index.movi
+    const uint32_t *id_blocks;    // mode 8: [alphabet][n_blocks]
+    const uint8_t *code_of;       // 256 bytes: ASCII -> code 0..3, 0xFF = illegal
+    const uint64_t *row_start_ckpt; // BWT position of row 32*j (count path), r/32+1 entries
+    uint64_t r;
+    uint64_t end_bwt_idx;
+    uint64_t n_blocks;
+    uint64_t block_size;
+    uint64_t end_thr[4];
+    uint64_t first_runs[5], first_offsets[5], last_runs[5], last_offsets[5];
+};
+
+// Device counters of one query call.
+struct DevStats {
+    unsigned long long fast_forwards;
+    unsigned long long scans;
+    unsigned long long repositions;
+    unsigned long long errors;
+};
+
+struct LaunchCfg {
+    int block_threads = 256;
+    int pml_variant = 0;
+};
+
+hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets,
+                      uint64_t n_reads, uint16_t *d_out, uint8_t *d_err, DevStats *d_stats,
+                      const LaunchCfg &cfg, hipStream_t stream);
+
+hipError_t launch_count(int mode, const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets,
+                        uint64_t n_reads, uint64_t *d_matched, uint64_t *d_count, uint8_t *d_err,
+                        DevStats *d_stats, const LaunchCfg &cfg, hipStream_t stream);
+
+// Fills ckpt[j] = BWT position of row (j << kPrefixShift), j = 0 .. ceil(r/32).
+hipError_t build_row_start_ckpt(int mode, const uint8_t *d_rows, uint64_t r, uint64_t *d_ckpt,
+                                hipStream_t stream);
+
+}  // namespace movi

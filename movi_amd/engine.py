@@ -1,0 +1,179 @@
+"""Host-side mirror of the reference's query interface over the C-ABI.
+
+Reference seam (file:line under /root/reference) -> here:
+  MoveStructure::deserialize          src/move_structure_io.cpp:471-511  -> MoveIndex.load / from_image
+  MoveStructure::query_pml(MoveQuery&) src/move_structure_query.cpp:234   -> MoveIndex.query_pml
+  ReadProcessor::process_latency_hiding src/read_processor.cpp:641        -> MoveIndex.query_pml (batched)
+  MoveStructure::query_backward_search src/move_structure_search.cpp:340  -> MoveIndex.query_count
+
+All compute happens in libmovi_hip.so on the GPU; this file only marshals
+buffers.  Errors are MoviError (the reference throws std::runtime_error).
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import IndexDescC, QueryStatsC, check, lib
+
+
+class IndexDesc:
+    """Python view of movi_index_desc_t."""
+
+    def __init__(self, c):
+        self.mode = int(c.mode)
+        self.alphabet_size = int(c.alphabet_size)
+        self.r = int(c.r)
+        self.length = int(c.length)
+        self.end_bwt_idx = int(c.end_bwt_idx)
+        self.end_bwt_idx_thresholds = list(c.end_bwt_idx_thresholds)
+        self.alphabet = bytes(c.alphabet[: self.alphabet_size])
+        self.code_of = bytes(c.code_of)
+        k = self.alphabet_size + 1
+        self.first_runs = list(c.first_runs[:k])
+        self.first_offsets = list(c.first_offsets[:k])
+        self.last_runs = list(c.last_runs[:k])
+        self.last_offsets = list(c.last_offsets[:k])
+        self.n_blocks = int(c.n_blocks)
+        self.block_size = int(c.block_size)
+        self.row_bytes = 8 if self.mode == 6 else 6
+
+
+def parse_index_image(image):
+    """movi_index_parse: (IndexDesc, raw C desc, rows_offset, rows_bytes).  Host only, no GPU."""
+    buf = np.frombuffer(image, np.uint8)
+    c = IndexDescC()
+    off, nb = C.c_size_t(0), C.c_size_t(0)
+    check(lib().movi_index_parse(buf.ctypes.data, buf.size, C.byref(c), C.byref(off), C.byref(nb)))
+    return IndexDesc(c), c, off.value, nb.value
+
+
+def _pack_reads(reads):
+    """list of bytes -> (uint8 bases, uint64 offsets[n+1])."""
+    lens = np.fromiter((len(r) for r in reads), np.uint64, len(reads))
+    offs = np.zeros(len(reads) + 1, np.uint64)
+    np.cumsum(lens, out=offs[1:])
+    bases = np.frombuffer(b"".join(bytes(r) for r in reads), np.uint8) if len(reads) else np.zeros(0, np.uint8)
+    return np.ascontiguousarray(bases), offs
+
+
+class QueryStats:
+    def __init__(self, c):
+        self.bases = int(c.bases)
+        self.fast_forwards = int(c.fast_forwards)
+        self.scans = int(c.scans)
+        self.repositions = int(c.repositions)
+        self.errors = int(c.errors)
+
+    def __repr__(self):
+        return "QueryStats(bases=%d, ff=%d, scans=%d, repositions=%d, errors=%d)" % (
+            self.bases, self.fast_forwards, self.scans, self.repositions, self.errors)
+
+
+class MoveIndex:
+    """A move-structure index resident on one GPU."""
+
+    def __init__(self, handle, keepalive=None):
+        self._h = handle
+        self._keep = keepalive
+        c = IndexDescC()
+        check(lib().movi_index_get_desc(self._h, C.byref(c)))
+        self.desc = IndexDesc(c)
+
+    # -- construction ---------------------------------------------------------
+    @classmethod
+    def load(cls, index_dir_or_file, device=0):
+        h = C.c_void_p()
+        check(lib().movi_index_load(device, str(index_dir_or_file).encode(), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_image(cls, image, device=0):
+        buf = np.frombuffer(image, np.uint8)
+        _, c, off, _ = parse_index_image(buf)
+        h = C.c_void_p()
+        check(lib().movi_index_create(device, C.byref(c), buf.ctypes.data + off, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_device_rows(cls, cdesc, d_rows_ptr, device=0, keepalive=None):
+        """Adopt a device-resident row table (e.g. an RCCL-broadcast torch tensor)."""
+        h = C.c_void_p()
+        check(lib().movi_index_create_from_device_rows(device, C.byref(cdesc), C.c_void_p(d_rows_ptr), C.byref(h)))
+        return cls(h, keepalive=keepalive)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().movi_index_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def device_rows(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        check(lib().movi_index_device_rows(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def set_option(self, key, value):
+        check(lib().movi_set_option(self._h, key.encode(), int(value)))
+
+    # -- host-buffer queries ----------------------------------------------------
+    def query_pml_packed(self, bases, offs, want_err=False):
+        """bases uint8[n_bases], offs uint64[n+1] -> (u16 PMLs in emission order, QueryStats[, err])."""
+        bases = np.ascontiguousarray(bases, np.uint8)
+        offs = np.ascontiguousarray(offs, np.uint64)
+        n = offs.size - 1
+        out = np.zeros(bases.size, np.uint16)
+        err = np.zeros(max(n, 1), np.uint8)
+        st = QueryStatsC()
+        rc = lib().movi_pml_host(self._h, bases.ctypes.data, offs.ctypes.data, n, out.ctypes.data,
+                                 err.ctypes.data, C.byref(st))
+        if want_err:
+            return out, QueryStats(st), err[:n], rc
+        check(rc)
+        return out, QueryStats(st)
+
+    def query_pml(self, reads):
+        """MoveStructure::query_pml for each read: list of u16 arrays, last base first
+        (MoveQuery::matching_lens order)."""
+        bases, offs = _pack_reads(reads)
+        out, _ = self.query_pml_packed(bases, offs)
+        return [out[int(offs[i]): int(offs[i + 1])] for i in range(len(reads))]
+
+    def query_count_packed(self, bases, offs):
+        bases = np.ascontiguousarray(bases, np.uint8)
+        offs = np.ascontiguousarray(offs, np.uint64)
+        n = offs.size - 1
+        m = np.zeros(max(n, 1), np.uint64)
+        c = np.zeros(max(n, 1), np.uint64)
+        st = QueryStatsC()
+        check(lib().movi_count_host(self._h, bases.ctypes.data, offs.ctypes.data, n, m.ctypes.data,
+                                    c.ctypes.data, None, C.byref(st)))
+        return m[:n], c[:n], QueryStats(st)
+
+    def query_count(self, reads):
+        """query_backward_search per read: list of (matched, count) as printed by
+        output_counts (src/utils.cpp:248-256: `matched/len\\tcount`)."""
+        bases, offs = _pack_reads(reads)
+        m, c, _ = self.query_count_packed(bases, offs)
+        return [(int(m[i]), int(c[i])) for i in range(len(reads))]
+
+    # -- device-pointer queries (bench / torch interop) ---------------------------
+    def pml_device(self, d_bases, d_offs, n_reads, n_bases, d_out, d_err=0, stream=0):
+        check(lib().movi_pml_device(self._h, C.c_void_p(d_bases), C.c_void_p(d_offs), n_reads, n_bases,
+                                    C.c_void_p(d_out), C.c_void_p(d_err) if d_err else None,
+                                    C.c_void_p(stream) if stream else None))
+
+    def count_device(self, d_bases, d_offs, n_reads, n_bases, d_matched, d_count, d_err=0, stream=0):
+        check(lib().movi_count_device(self._h, C.c_void_p(d_bases), C.c_void_p(d_offs), n_reads, n_bases,
+                                      C.c_void_p(d_matched), C.c_void_p(d_count),
+                                      C.c_void_p(d_err) if d_err else None,
+                                      C.c_void_p(stream) if stream else None))
+
+    def last_stats(self, stream=0):
+        st = QueryStatsC()
+        check(lib().movi_last_stats(self._h, C.c_void_p(stream) if stream else None, C.byref(st)))
+        return QueryStats(st)

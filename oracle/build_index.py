@@ -180,7 +180,7 @@ def build_rows(bwt, thr, mode):
             alphabet.append(ch)
             counts.append(cnt)
     sigma = len(alphabet)
-    assert sigma == 4, "only the 4-symbol DNA alphabet is in scope (no separators)"
+    assert 1 <= sigma <= 4, "only DNA alphabets (<= 4 symbols, no separators) are in scope"
     code = np.where(heads == 0, 0, alphamap[heads].astype(np.int64)).astype(np.int64)
     code[heads == 0] = 0                                # set_c: alphamap[0]==256 shifts out
     end_bwt_idx = int(np.flatnonzero(heads == 0)[0])

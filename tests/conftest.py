@@ -1,0 +1,99 @@
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _have_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    if _have_gpu():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def built_lib():
+    """libmovi_hip.so, (re)built if stale.  hipcc cross-compiles without a GPU."""
+    so = os.path.join(ROOT, "movi_amd", "lib", "libmovi_hip.so")
+    srcs = [os.path.join(ROOT, "movi_amd", "csrc", f) for f in
+            ("movi_kernels.hip", "movi_abi.hip", "movi_kernels.hpp")] + [os.path.join(ROOT, "include", "movi_hip.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "movi_amd", "csrc")], stdout=subprocess.DEVNULL)
+    return so
+
+
+@pytest.fixture(scope="session")
+def golden_image():
+    def get(mode):
+        name = {6: "index_regular-thresholds", 8: "index_blocked-thresholds"}[mode]
+        with open(os.path.join(GOLDEN, name, "index.movi"), "rb") as f:
+            return f.read()
+    return get
+
+
+def read_fastx(path):
+    """[(id, seq bytes)] with the reference's id rule (src/batch_loader.cpp:117-119)."""
+    out = []
+    with open(path, "rb") as f:
+        lines = f.read().split(b"\n")
+    if not lines or not lines[0]:
+        return out
+    if lines[0][:1] == b"@":
+        for i in range(0, len(lines) - 3, 4):
+            if lines[i][:1] == b"@":
+                out.append((_read_id(lines[i]), lines[i + 1].rstrip()))
+    else:
+        cur, seq = None, []
+        for ln in lines:
+            if ln[:1] == b">":
+                if cur is not None:
+                    out.append((cur, b"".join(seq)))
+                cur, seq = _read_id(ln), []
+            elif cur is not None:
+                seq.append(ln.rstrip())
+        if cur is not None:
+            out.append((cur, b"".join(seq)))
+    return out
+
+
+def _read_id(header):
+    k = len(header)
+    for i in range(1, len(header)):
+        if header[i:i + 1] in (b" ", b"\t", b"\r"):
+            k = i
+            break
+    return header[1:k + 1] if k < len(header) else header[1:]
+
+
+def golden_sorted_pmls():
+    with open(os.path.join(GOLDEN, "sample.fastq.pmls.sorted")) as f:
+        lines = f.read().split("\n")
+    return sorted(l for l in lines if l and not l.startswith(">")), sorted(l for l in lines if l.startswith(">"))
+
+
+def stdout_line(pml_emission_order):
+    """`--stdout` text of one read: values in read order, each followed by a space
+    (include/move_query.hpp:33-37 + src/utils.cpp:214-219)."""
+    return "".join("%d " % v for v in pml_emission_order[::-1])

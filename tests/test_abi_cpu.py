@@ -1,0 +1,83 @@
+"""CPU suite: the C-ABI library builds, loads, exports every symbol that
+include/movi_hip.h declares, and its host-only entry points behave.  No compute
+call is made here (there is no GPU in the build container)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from oracle.oracle import Oracle
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "movi_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(movi_[a-z_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    from movi_amd._lib import SYMBOLS
+    L = C.CDLL(built_lib)
+    declared = header_functions()
+    assert len(declared) >= 15
+    for name in declared:
+        assert hasattr(L, name), "libmovi_hip.so does not export %s" % name
+    # the ctypes table covers the whole header, nothing more
+    assert sorted(SYMBOLS) == declared
+
+
+def test_parse_golden_index_matches_oracle(built_lib, golden_image):
+    import movi_amd
+    for mode in (6, 8):
+        img = golden_image(mode)
+        desc, _, off, nbytes = movi_amd.parse_index_image(img)
+        o = Oracle(img)
+        assert (desc.mode, desc.r, desc.length, desc.end_bwt_idx) == (mode, o.r, o.length, o.end_bwt_idx)
+        assert desc.r == 118209 and off == 2215
+        assert nbytes == desc.r * (8 if mode == 6 else 6)
+        assert desc.alphabet == b"ACGT"
+        code = np.frombuffer(desc.code_of, np.uint8)
+        assert [int(code[c]) for c in b"ACGT"] == [0, 1, 2, 3]
+        assert (np.delete(code, list(b"ACGT")) == 0xFF).all()
+        if mode == 8:
+            assert desc.n_blocks == 1 and desc.block_size == 1 << 20
+
+
+def test_parse_rejects_bad_images(built_lib, golden_image):
+    import movi_amd
+    img = bytearray(golden_image(6))
+    with pytest.raises(movi_amd.MoviError) as e:
+        movi_amd.parse_index_image(bytes(img[:40]))
+    assert e.value.code == -2
+    bad = bytearray(img); bad[0] ^= 0xFF
+    with pytest.raises(movi_amd.MoviError):
+        movi_amd.parse_index_image(bytes(bad))
+    other_mode = bytearray(img); other_mode[7] = 3          # "regular" (no thresholds): out of scope
+    with pytest.raises(movi_amd.MoviError) as e:
+        movi_amd.parse_index_image(bytes(other_mode))
+    assert "not supported" in str(e.value)
+    with pytest.raises(movi_amd.MoviError):
+        movi_amd.parse_index_image(bytes(img[: len(img) // 2]))
+
+
+def test_no_cpu_fallback(built_lib, golden_image):
+    """Without a GPU the product path must fail loudly, never compute on the host."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import movi_amd
+    with pytest.raises(movi_amd.MoviError) as e:
+        movi_amd.MoveIndex.from_image(golden_image(6))
+    assert e.value.code in (-4, -5)
+
+
+def test_product_does_not_touch_oracle():
+    """Nothing under movi_amd/ or tools/synth.py may reference oracle/."""
+    for base, _, files in os.walk(os.path.join(ROOT, "movi_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h", "Makefile")):
+                assert "oracle" not in open(os.path.join(base, f), errors="replace").read().lower(), f
+    assert "oracle" not in open(os.path.join(ROOT, "tools", "synth.py")).read().replace("oracle/ (this", "")

@@ -1,0 +1,111 @@
+"""CPU suite: pins the oracle (and the index constructor that feeds it) to the
+golden vectors the reference's own tests hold for the PML path."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, golden_sorted_pmls, read_fastx, stdout_line
+from oracle import build_index as B
+from oracle.oracle import Oracle
+
+
+@pytest.fixture(scope="module")
+def ref_bwt():
+    recs = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))
+    t = B.clean_text([s for _, s in recs])
+    return B.bwt_and_thresholds(t)
+
+
+# tests/test_build.cpp:37 and :53 of the reference: index sizes for tests_data/ref.fasta
+@pytest.mark.parametrize("mode,size", [(6, 948119), (8, 711733)])
+def test_index_size_known_answers(ref_bwt, golden_image, mode, size):
+    bwt, thr = ref_bwt
+    f = B.build_rows(bwt, thr, mode)
+    img = B.serialize(f)
+    assert len(img) == size
+    assert f["r"] == 118209 and f["original_r"] == 108629 and f["n"] == 159841
+    # the committed fixture is exactly what the constructor produces
+    assert img == golden_image(mode)
+
+
+# tests/test_pml.cpp:89-105: sample.fastq against sample.fastq.pmls.sorted (sorted multiset)
+@pytest.mark.parametrize("mode", [6, 8])
+def test_oracle_reproduces_golden_pmls(golden_image, mode):
+    o = Oracle(golden_image(mode))
+    reads = read_fastx(os.path.join(GOLDEN, "sample.fastq"))
+    assert len(reads) == 25
+    gold_pml, gold_ids = golden_sorted_pmls()
+    mine = sorted(stdout_line(o.pml(seq)) for _, seq in reads)
+    assert mine == gold_pml
+    assert sorted(">" + i.decode() for i, _ in reads) == gold_ids
+
+
+def test_oracle_batch_equals_single(golden_image):
+    o = Oracle(golden_image(6))
+    reads = [s for _, s in read_fastx(os.path.join(GOLDEN, "sample.fastq"))]
+    bases = np.frombuffer(b"".join(reads), np.uint8)
+    offs = np.concatenate(([0], np.cumsum([len(r) for r in reads]))).astype(np.uint64)
+    out, ff, sc = o.pml_batch(bases, offs, threads=2, strands=4)
+    for i, r in enumerate(reads):
+        assert (out[int(offs[i]):int(offs[i + 1])] == o.pml(r)).all()
+
+
+def test_modes_agree_and_illegal_chars(golden_image):
+    o6, o8 = Oracle(golden_image(6)), Oracle(golden_image(8))
+    rng = np.random.default_rng(7)
+    ref = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))[0][1]
+    for _ in range(40):
+        L = int(rng.integers(1, 400))
+        s = int(rng.integers(0, len(ref) - L))
+        r = bytearray(ref[s:s + L])
+        for k in range(L):
+            u = rng.random()
+            if u < 0.03:
+                r[k] = b"ACGT"[rng.integers(0, 4)]
+            elif u < 0.04:
+                r[k] = ord("N")
+            elif u < 0.05:
+                r[k] = ord("a")
+        p6, p8 = o6.pml(bytes(r)), o8.pml(bytes(r))
+        assert (p6 == p8).all()
+        # illegal characters (N, lower case) give PML 0: check_alphabet, move_structure.cpp:383-397
+        rr = np.frombuffer(bytes(r), np.uint8)[::-1]
+        bad = ~np.isin(rr, np.frombuffer(b"ACGT", np.uint8))
+        assert (p6[bad] == 0).all()
+        assert o6.count(bytes(r)) == o8.count(bytes(r))
+
+
+def test_exact_substrings_match_fully(golden_image):
+    """A substring of the reference matches end to end: PML grows by one per base
+    once it is positive (until a reposition), and count >= 1 with matched == len."""
+    o = Oracle(golden_image(6))
+    ref = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))[0][1]
+    rng = np.random.default_rng(11)
+    for _ in range(30):
+        L = int(rng.integers(20, 300))
+        s = int(rng.integers(0, len(ref) - L))
+        m, c = o.count(ref[s:s + L])
+        assert m == L and c >= 1
+
+
+def test_count_edge_cases(golden_image):
+    o = Oracle(golden_image(6))
+    assert o.count(b"N") == (0, 0)                  # move_structure_search.cpp:344-347
+    assert o.count(b"ACGTN") == (0, 0)
+    m, c = o.count(b"A")
+    assert m == 1 and c > 0
+    m, c = o.count(b"NA")
+    assert m == 1                                   # stops at the illegal base
+    assert o.pml(b"").size == 0
+
+
+def test_add_ml_clamp():
+    """include/move_query.hpp:26-38 (tests/test_basics.cpp:304-315): PML is clamped
+    to 65535 while the counter keeps growing.  A 2-run text A^k makes the walk match
+    forever; check on a synthetic homopolymer index built by the constructor."""
+    img = B.build_index_from_seqs([b"A" * 70000], 6, rc=False)
+    o = Oracle(img)
+    p = o.pml(b"A" * 66000)
+    assert p[0] == 1 and p[65534] == 65535 and p[65535] == 65535 and p[-1] == 65535
+    assert (np.diff(p[:65535].astype(np.int64)) == 1).all()
