@@ -78,32 +78,62 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     return v;
 }
 
+// Per-read error codes (the reference throws in each of these cases).
+enum : uint32_t {
+    kErrNone = 0,
+    kErrIdRange = 1,       // LF destination >= r              (move_structure.cpp:63-65)
+    kErrFastForward = 2,   // >= 65535 fast-forward steps      (move_structure.cpp:72-75)
+    kErrNoRunBelow = 3,    // reposition_down found no run     (move_structure_query.cpp:582-586)
+    kErrNoRunAbove = 4,    // reposition_up found no run       (move_structure_query.cpp:594-598)
+};
+
+// Control-flow note (ROCm 7.2 / gfx950): every data-dependent loop below is written
+// as a WAVE-UNIFORM loop (`while (__any(pred))`) with a predicated body and all
+// loop-carried state in integer VGPRs.  A divergent `while` whose result is consumed
+// as a boolean after the loop (`found = (c == a)`) was miscompiled by hipcc: the exit
+// compare of the LAST iteration (vcc) was reused for lanes that had left the loop
+// earlier.  Uniform loops are also the cheaper form on a 64-wide wavefront.
+__device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
+
 // LF_move + fast_forward.  On entry `row` is rows[idx]; on exit it is the row of
-// the new idx.  Returns false when one of the reference's throws would fire.
+// the new idx.  `live` lanes take the step; returns a kErr* code (0 = ok) per lane.
 template <int MODE>
-__device__ __forceinline__ bool lf_step(const DevIndex &ix, uint64_t &idx, uint32_t &off, uint2 &row,
-                                        uint32_t &ff_total) {
-    uint64_t j = row_id<MODE>(row, idx, ix);
-    if (j >= ix.r) return false;                        // move_structure.cpp:63-65
-    off += row_off<MODE>(row);
-    row = load_row<MODE>(ix.rows, j);                   // THE dependent random gather
-    uint32_t ff = 0;
-    uint32_t n = row_n<MODE>(row);
-    while (j < ix.r - 1 && off >= n) {                  // fast_forward :524-545
-        off -= n;
-        j += 1;
-        ff += 1;
-        row = load_row<MODE>(ix.rows, j);
-        n = row_n<MODE>(row);
+__device__ __forceinline__ uint32_t lf_step(const DevIndex &ix, bool live, uint64_t &idx, uint32_t &off,
+                                            uint2 &row, uint32_t &ff_total) {
+    uint32_t errc = kErrNone;
+    uint64_t j = idx;
+    uint32_t n = 0, ff = 0;
+    uint32_t going = 0;
+    if (live) {
+        j = row_id<MODE>(row, idx, ix);
+        if (j >= ix.r) {                                // move_structure.cpp:63-65
+            errc = kErrIdRange;
+            j = idx;
+        } else {
+            off += row_off<MODE>(row);
+            row = load_row<MODE>(ix.rows, j);           // THE dependent random gather
+            n = row_n<MODE>(row);
+            going = (j < ix.r - 1 && off >= n) ? 1u : 0u;
+        }
     }
-    if (ff >= 65535u) return false;                     // move_structure.cpp:72-75
+    while (wave_any(going != 0u)) {                     // fast_forward :524-545
+        if (going) {
+            off -= n;
+            j += 1;
+            ff += 1;
+            row = load_row<MODE>(ix.rows, j);
+            n = row_n<MODE>(row);
+            going = (j < ix.r - 1 && off >= n && ff < 65535u) ? 1u : 0u;
+        }
+    }
+    if (ff >= 65535u) errc = kErrFastForward;           // move_structure.cpp:72-75
     ff_total += ff;
     idx = j;
-    return true;
+    return errc;
 }
 
 // ------------------------------------------------------------------------- PML
-// Variant 0: one lane per read, straight per-lane loops.
+// Variant 0: one lane per read; wave-uniform step loop, predicated per lane.
 template <int MODE>
 __global__ __launch_bounds__(256) void pml_kernel_v0(DevIndex ix, const uint8_t *__restrict__ bases,
                                                      const uint64_t *__restrict__ offs, uint64_t n_reads,
@@ -115,23 +145,28 @@ __global__ __launch_bounds__(256) void pml_kernel_v0(DevIndex ix, const uint8_t 
 
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t ff_total = 0, scan_total = 0, repo_total = 0, failed = 0;
-    if (t < n_reads) {
-        const uint64_t beg = offs[t];
-        const uint64_t len = offs[t + 1] - beg;
-        const uint8_t *R = bases + beg;
-        uint16_t *O = out + beg;
-        // ReadProcessor::reset_process, src/read_processor.cpp:69-70
-        uint64_t idx = ix.r - 1;
-        uint2 row = load_row<MODE>(ix.rows, idx);
-        uint32_t off = row_n<MODE>(row) - 1;
-        uint32_t ml = 0;
-        uint64_t k = 0;
-        for (; k < len; ++k) {
-            if (k != 0) {
-                if (!lf_step<MODE>(ix, idx, off, row, ff_total)) { failed = 1; break; }
-            }
-            const uint32_t a = s_code[R[len - 1 - k]];
-            const uint32_t rc = row_c<MODE>(row);         // the '$' row decodes as c == 0
+    const bool valid = t < n_reads;
+    const uint64_t beg = valid ? offs[t] : 0;
+    const uint64_t len = valid ? offs[t + 1] - beg : 0;
+    const uint8_t *R = bases + beg;
+    uint16_t *O = out + beg;
+    // ReadProcessor::reset_process, src/read_processor.cpp:69-70
+    uint64_t idx = ix.r - 1;
+    uint2 row = load_row<MODE>(ix.rows, idx);
+    uint32_t off = row_n<MODE>(row) - 1;
+    uint32_t ml = 0;
+    for (uint64_t k = 0; wave_any(k < len && failed == 0u); ++k) {
+        bool live = k < len && failed == 0u;
+        if (k != 0) {
+            const uint32_t e = lf_step<MODE>(ix, live, idx, off, row, ff_total);
+            if (e) { failed = e; live = false; }
+        }
+        uint32_t a = 0xFFu;
+        if (live) a = s_code[R[len - 1 - k]];
+        const uint32_t rc = row_c<MODE>(row);             // the '$' row decodes as c == 0
+        // 0 = no scan, 1 = scanning down, 2 = scanning up
+        uint32_t dir = 0;
+        if (live) {
             if (a == 0xFFu) {
                 ml = 0;                                   // check_alphabet failed
             } else if (rc == a) {
@@ -139,53 +174,53 @@ __global__ __launch_bounds__(256) void pml_kernel_v0(DevIndex ix, const uint8_t 
             } else {
                 // reposition_thresholds, src/move_structure_query.cpp:513-601
                 repo_total += 1;
-                bool down;
+                ml = 0;
+                uint32_t down;
                 if (idx == ix.end_bwt_idx) {
-                    down = (uint64_t)off >= ix.end_thr[a];
+                    // end_bwt_idx_thresholds[a]; a in 1..3 here ('$' row matches 'A')
+                    const uint64_t et = a == 1 ? ix.end_thr[1] : (a == 2 ? ix.end_thr[2] : ix.end_thr[3]);
+                    down = ((uint64_t)off >= et) ? 1u : 0u;
                 } else {
                     const uint32_t kk = a - (a > rc ? 1u : 0u);      // alphamap_3[rc][a], utils.cpp:5-8
                     const uint32_t thr = row_thr<MODE>(row, kk) ? row_n<MODE>(row) : 0u;
-                    down = off >= thr;
+                    down = (off >= thr) ? 1u : 0u;
                 }
-                bool found = false;
-                if (down) {                               // reposition_down :211-232
-                    if (idx != ix.r - 1) {
-                        uint32_t c = rc;
-                        while (idx < ix.r - 1 && c != a) {
-                            scan_total += 1;
-                            idx += 1;
-                            row = load_row<MODE>(ix.rows, idx);
-                            c = row_c<MODE>(row);
-                        }
-                        found = (c == a);
-                    }
-                    off = 0;
-                } else {                                  // reposition_up :188-209
-                    if (idx != 0) {
-                        uint32_t c = rc;
-                        while (idx > 0 && c != a) {
-                            scan_total += 1;
-                            idx -= 1;
-                            row = load_row<MODE>(ix.rows, idx);
-                            c = row_c<MODE>(row);
-                        }
-                        found = (c == a);
-                    }
-                    off = row_n<MODE>(row) - 1;
-                }
-                if (!found) { failed = 1; break; }        // move_structure_query.cpp:582-598
-                ml = 0;
+                dir = down ? 1u : 2u;
+                // reposition_down / reposition_up return r (not found) at the table ends
+                if (down && idx == ix.r - 1) { failed = kErrNoRunBelow; dir = 0; live = false; }
+                if (!down && idx == 0) { failed = kErrNoRunAbove; dir = 0; live = false; }
             }
-            O[k] = (uint16_t)(ml > 65535u ? 65535u : ml); // MoveQuery::add_ml
         }
-        if (failed) {
-            for (; k < len; ++k) O[k] = 0;
+        // reposition_down :211-232 / reposition_up :188-209 as one uniform loop
+        uint32_t scanning = dir;
+        while (wave_any(scanning != 0u)) {
+            if (scanning) {
+                scan_total += 1;
+                idx = (scanning == 1u) ? idx + 1 : idx - 1;
+                row = load_row<MODE>(ix.rows, idx);
+                const uint32_t c = row_c<MODE>(row);
+                if (c == a) {
+                    scanning = 0;
+                } else if (scanning == 1u ? (idx >= ix.r - 1) : (idx == 0)) {
+                    failed = scanning == 1u ? kErrNoRunBelow : kErrNoRunAbove;   // :582-598
+                    scanning = 0;
+                    live = false;
+                }
+            }
         }
-        if (err) err[t] = (uint8_t)failed;
+        if (dir == 1u) off = 0;
+        if (dir == 2u) off = row_n<MODE>(row) - 1;        // read_processor.cpp:223
+        if (live) O[k] = (uint16_t)(ml > 65535u ? 65535u : ml);   // MoveQuery::add_ml
     }
+    // a read that broke an invariant reports all-zero PMLs plus its error code (the
+    // reference aborts the whole run there; the host turns the flag into exit code 1)
+    if (failed) {
+        for (uint64_t k = 0; k < len; ++k) O[k] = 0;
+    }
+    if (valid && err) err[t] = (uint8_t)failed;
     // one atomic per wave per counter
     const uint32_t ffw = wave_sum(ff_total), scw = wave_sum(scan_total), rpw = wave_sum(repo_total),
-                   erw = wave_sum(failed);
+                   erw = wave_sum(failed ? 1u : 0u);
     if ((threadIdx.x & 63) == 0 && stats) {
         if (ffw) atomicAdd(&stats->fast_forwards, (unsigned long long)ffw);
         if (scw) atomicAdd(&stats->scans, (unsigned long long)scw);
@@ -234,64 +269,94 @@ __global__ __launch_bounds__(256) void count_kernel_v0(DevIndex ix, const uint8_
 
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t ff_total = 0, scan_total = 0, failed = 0;
-    if (t < n_reads) {
-        const uint64_t beg = offs[t];
-        const int64_t len = (int64_t)(offs[t + 1] - beg);
-        const uint8_t *R = bases + beg;
-        uint64_t m_out = 0, c_out = 0;
-        if (len > 0) {
-            int64_t pos = len - 1;
-            uint32_t a = s_code[R[pos]];
-            if (a == 0xFFu) {                            // move_structure_search.cpp:344-347
-                m_out = 0; c_out = 0;
-            } else {
-                // initialize_backward_search :284-291
-                uint64_t rs = ix.first_runs[a + 1], re = ix.last_runs[a + 1];
-                uint32_t os = (uint32_t)ix.first_offsets[a + 1], oe = (uint32_t)ix.last_offsets[a + 1];
-                uint64_t prs = rs, pre = re;
-                uint32_t pos_ = os, poe = oe;
-                bool empty = !((rs < re) || (rs == re && os <= oe));
-                while (pos > 0 && !empty) {              // backward_search :176
-                    prs = rs; pre = re; pos_ = os; poe = oe;
-                    const uint32_t b = s_code[R[pos - 1]];
-                    if (b == 0xFFu) {
-                        empty = true;                     // backward_search_step :321-324
-                    } else {
-                        // update_interval, src/move_structure_search.cpp:48-61 (get_char: '$' never matches)
-                        uint2 rws = load_row<MODE>(ix.rows, rs);
-                        while (rs <= re && (rs == ix.end_bwt_idx || row_c<MODE>(rws) != b)) {
-                            rs += 1; os = 0; scan_total += 1;
-                            if (rs >= ix.r) break;
-                            rws = load_row<MODE>(ix.rows, rs);
-                        }
-                        uint2 rwe = load_row<MODE>(ix.rows, re);
-                        while (re >= rs && (re == ix.end_bwt_idx || row_c<MODE>(rwe) != b)) {
-                            re -= 1; scan_total += 1;
-                            rwe = load_row<MODE>(ix.rows, re);
-                            oe = row_n<MODE>(rwe) - 1;
-                            if (re == 0) break;
-                        }
-                        empty = !((rs < re) || (rs == re && os <= oe));
-                        if (!empty) {
-                            if (!lf_step<MODE>(ix, rs, os, rws, ff_total) ||
-                                !lf_step<MODE>(ix, re, oe, rwe, ff_total)) { failed = 1; break; }
-                            empty = !((rs < re) || (rs == re && os <= oe));
-                        }
-                    }
-                    if (!empty) pos -= 1;
+    const bool valid = t < n_reads;
+    const uint64_t beg = valid ? offs[t] : 0;
+    const int64_t len = valid ? (int64_t)(offs[t + 1] - beg) : 0;
+    const uint8_t *R = bases + beg;
+    int64_t pos = len - 1;
+    // interval [rs:os, re:oe] and the previous one (MoveInterval, include/move_intervals.hpp:10-76)
+    uint64_t rs = 0, re = 0, prs = 0, pre = 0;
+    uint32_t os = 0, oe = 0, pos_ = 0, poe = 0;
+    uint32_t run = 0;                 // 1 while the backward search of this lane continues
+    uint32_t have = 0;                // 1 when an interval exists (last base legal)
+    if (len > 0) {
+        const uint32_t a = s_code[R[pos]];
+        if (a != 0xFFu) {             // else: move_structure_search.cpp:344-347 -> "0/len 0"
+            // initialize_backward_search :284-291
+            rs = ix.first_runs[a + 1]; re = ix.last_runs[a + 1];
+            os = (uint32_t)ix.first_offsets[a + 1]; oe = (uint32_t)ix.last_offsets[a + 1];
+            have = 1;
+            run = ((rs < re) || (rs == re && os <= oe)) ? 1u : 0u;
+        }
+    }
+    prs = rs; pre = re; pos_ = os; poe = oe;
+    uint32_t empty = have && !run;
+    while (wave_any(run != 0u && pos > 0)) {             // backward_search :176
+        const bool act = run != 0u && pos > 0;
+        uint32_t b = 0xFFu;
+        if (act) {
+            prs = rs; pre = re; pos_ = os; poe = oe;
+            b = s_code[R[pos - 1]];
+            if (b == 0xFFu) { empty = 1; run = 0; }       // backward_search_step :321-324
+        }
+        const bool legal = act && b != 0xFFu;
+        // update_interval, src/move_structure_search.cpp:48-61 (get_char: '$' never equals a base)
+        uint2 rws = make_uint2(0, 0), rwe = make_uint2(0, 0);
+        uint32_t g = 0;
+        if (legal && rs <= re) {
+            rws = load_row<MODE>(ix.rows, rs);
+            g = (rs == ix.end_bwt_idx || row_c<MODE>(rws) != b) ? 1u : 0u;
+        }
+        while (wave_any(g != 0u)) {
+            if (g) {
+                rs += 1; os = 0; scan_total += 1;
+                if (rs >= ix.r || rs > re) {
+                    g = 0;
+                } else {
+                    rws = load_row<MODE>(ix.rows, rs);
+                    g = (rs == ix.end_bwt_idx || row_c<MODE>(rws) != b) ? 1u : 0u;
                 }
-                if (empty) { rs = prs; re = pre; os = pos_; oe = poe; }
-                m_out = (uint64_t)(len - pos);
-                // MoveInterval::count, include/move_intervals.hpp:47-58, in O(32) loads
-                if (rs == re) c_out = (uint64_t)oe - os + 1;
-                else c_out = (row_start<MODE>(ix, re) + oe) - (row_start<MODE>(ix, rs) + os) + 1;
             }
         }
-        matched[t] = failed ? 0 : m_out;
-        count[t] = failed ? 0 : c_out;
+        g = 0;
+        if (legal && re >= rs) {
+            rwe = load_row<MODE>(ix.rows, re);
+            g = (re == ix.end_bwt_idx || row_c<MODE>(rwe) != b) ? 1u : 0u;
+        }
+        while (wave_any(g != 0u)) {
+            if (g) {
+                re -= 1; scan_total += 1;
+                rwe = load_row<MODE>(ix.rows, re);
+                oe = row_n<MODE>(rwe) - 1;
+                if (re == 0 || re < rs) g = 0;
+                else g = (re == ix.end_bwt_idx || row_c<MODE>(rwe) != b) ? 1u : 0u;
+            }
+        }
+        bool nonempty = legal && ((rs < re) || (rs == re && os <= oe));
+        if (legal && !nonempty) { empty = 1; run = 0; }
+        // backward_search_step :326-330: two LF moves
+        uint32_t e1 = lf_step<MODE>(ix, nonempty, rs, os, rws, ff_total);
+        uint32_t e2 = lf_step<MODE>(ix, nonempty && e1 == 0u, re, oe, rwe, ff_total);
+        if (e1 | e2) { failed = e1 ? e1 : e2; run = 0; nonempty = false; }
+        if (nonempty) {                                   // backward_search :179-182
+            if ((rs < re) || (rs == re && os <= oe)) pos -= 1;
+            else { empty = 1; run = 0; }
+        }
+    }
+    if (valid) {
+        uint64_t m_out = 0, c_out = 0;
+        if (have && !failed) {
+            if (empty) { rs = prs; re = pre; os = pos_; oe = poe; }
+            m_out = (uint64_t)(len - pos);
+            // MoveInterval::count, include/move_intervals.hpp:47-58, via the row-start checkpoints
+            if (rs == re) c_out = (uint64_t)oe - os + 1;
+            else c_out = (row_start<MODE>(ix, re) + oe) - (row_start<MODE>(ix, rs) + os) + 1;
+        }
+        matched[t] = m_out;
+        count[t] = c_out;
         if (err) err[t] = (uint8_t)failed;
     }
-    const uint32_t ffw = wave_sum(ff_total), scw = wave_sum(scan_total), erw = wave_sum(failed);
+    const uint32_t ffw = wave_sum(ff_total), scw = wave_sum(scan_total), erw = wave_sum(failed ? 1u : 0u);
     if ((threadIdx.x & 63) == 0 && stats) {
         if (ffw) atomicAdd(&stats->fast_forwards, (unsigned long long)ffw);
         if (scw) atomicAdd(&stats->scans, (unsigned long long)scw);
