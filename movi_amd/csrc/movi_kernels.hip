@@ -133,9 +133,13 @@ __device__ __forceinline__ uint32_t lf_step(const DevIndex &ix, bool live, uint6
 }
 
 // ------------------------------------------------------------------------- PML
-// Variant 0: one lane per read; wave-uniform step loop, predicated per lane.
-template <int MODE>
-__global__ __launch_bounds__(256) void pml_kernel_v0(DevIndex ix, const uint8_t *__restrict__ bases,
+// One lane per read; wave-uniform step loop, predicated per lane.
+//   VARIANT 0: one byte load and one u16 store per step and lane.
+//   VARIANT 1: packed I/O -- each lane fetches its read 8 bases at a time (one 8-byte load
+//              per 8 steps) and emits PMLs 8 at a time (one 16-byte store per 8 steps), so the
+//              per-step traffic to L2 is the row gather alone.
+template <int MODE, int VARIANT>
+__global__ __launch_bounds__(256) void pml_kernel(DevIndex ix, const uint8_t *__restrict__ bases,
                                                      const uint64_t *__restrict__ offs, uint64_t n_reads,
                                                      uint16_t *__restrict__ out, uint8_t *__restrict__ err,
                                                      DevStats *stats) {
@@ -155,14 +159,28 @@ __global__ __launch_bounds__(256) void pml_kernel_v0(DevIndex ix, const uint8_t 
     uint2 row = load_row<MODE>(ix.rows, idx);
     uint32_t off = row_n<MODE>(row) - 1;
     uint32_t ml = 0;
+    uint64_t rb = 0;                                      // VARIANT 1: 8 bases, byte 7 = current step
+    uint4 pk = make_uint4(0, 0, 0, 0);                    // VARIANT 1: last 8 PMLs, oldest in the low bits
+    const uint64_t packed_end = len & ~7ull;              // steps >= this are stored one by one
     for (uint64_t k = 0; wave_any(k < len && failed == 0u); ++k) {
         bool live = k < len && failed == 0u;
+        if (VARIANT == 1 && (k & 7) == 0) {
+            if (live && k + 8 <= len) {
+                __builtin_memcpy(&rb, R + (len - 8 - k), 8);          // unaligned 8-byte load
+            } else if (live) {
+                rb = 0;
+                for (uint64_t i = 0; i < len - k; ++i) rb |= (uint64_t)R[len - 1 - k - i] << (8 * (7 - i));
+            }
+        }
         if (k != 0) {
             const uint32_t e = lf_step<MODE>(ix, live, idx, off, row, ff_total);
             if (e) { failed = e; live = false; }
         }
         uint32_t a = 0xFFu;
-        if (live) a = s_code[R[len - 1 - k]];
+        if (live) {
+            if (VARIANT == 1) a = s_code[(uint32_t)(rb >> (8 * (7 - (k & 7)))) & 0xFFu];
+            else a = s_code[R[len - 1 - k]];
+        }
         const uint32_t rc = row_c<MODE>(row);             // the '$' row decodes as c == 0
         // 0 = no scan, 1 = scanning down, 2 = scanning up
         uint32_t dir = 0;
@@ -210,7 +228,20 @@ __global__ __launch_bounds__(256) void pml_kernel_v0(DevIndex ix, const uint8_t 
         }
         if (dir == 1u) off = 0;
         if (dir == 2u) off = row_n<MODE>(row) - 1;        // read_processor.cpp:223
-        if (live) O[k] = (uint16_t)(ml > 65535u ? 65535u : ml);   // MoveQuery::add_ml
+        const uint32_t val = ml > 65535u ? 65535u : ml;   // MoveQuery::add_ml
+        if (VARIANT == 1) {
+            if (live && k >= packed_end) {
+                O[k] = (uint16_t)val;
+            } else if (live) {
+                pk.x = (pk.x >> 16) | (pk.y << 16);
+                pk.y = (pk.y >> 16) | (pk.z << 16);
+                pk.z = (pk.z >> 16) | (pk.w << 16);
+                pk.w = (pk.w >> 16) | (val << 16);
+                if ((k & 7) == 7) __builtin_memcpy(O + (k - 7), &pk, 16);   // unaligned 16-byte store
+            }
+        } else if (live) {
+            O[k] = (uint16_t)val;
+        }
     }
     // a read that broke an invariant reports all-zero PMLs plus its error code (the
     // reference aborts the whole run there; the host turns the flag into exit code 1)
@@ -237,12 +268,16 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     const uint64_t blocks = (n_reads + bt - 1) / bt;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     dim3 grid((unsigned)blocks), block((unsigned)bt);
-    if (mode == 6)
-        hipLaunchKernelGGL(pml_kernel_v0<6>, grid, block, 0, stream, ix, d_bases, d_offsets, n_reads, d_out,
-                           d_err, d_stats);
-    else
-        hipLaunchKernelGGL(pml_kernel_v0<8>, grid, block, 0, stream, ix, d_bases, d_offsets, n_reads, d_out,
-                           d_err, d_stats);
+#define MOVI_LAUNCH_PML(M, V)                                                                              \
+    hipLaunchKernelGGL((pml_kernel<M, V>), grid, block, 0, stream, ix, d_bases, d_offsets, n_reads, d_out, \
+                       d_err, d_stats)
+    const int v = cfg.pml_variant;
+    if (mode == 6) {
+        if (v == 0) MOVI_LAUNCH_PML(6, 0); else MOVI_LAUNCH_PML(6, 1);
+    } else {
+        if (v == 0) MOVI_LAUNCH_PML(8, 0); else MOVI_LAUNCH_PML(8, 1);
+    }
+#undef MOVI_LAUNCH_PML
     return hipGetLastError();
 }
 

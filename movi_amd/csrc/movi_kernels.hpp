@@ -32,7 +32,7 @@ struct DevStats {
 
 struct LaunchCfg {
     int block_threads = 256;
-    int pml_variant = 0;
+    int pml_variant = 1;   // see pml_kernel<MODE, VARIANT>
 };
 
 hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets,

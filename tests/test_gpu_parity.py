@@ -85,6 +85,28 @@ def test_pml_ragged_reads_vs_oracle(engines, mode):
 
 
 @pytest.mark.parametrize("mode", [6, 8])
+@pytest.mark.parametrize("variant", [0, 1])
+def test_pml_kernel_variants_vs_oracle(engines, mode, variant):
+    """Every selectable kernel variant is held to the same bit-exact bar, including
+    reads whose length is not a multiple of the 8-step packing and unaligned offsets."""
+    from oracle import build_index as B
+    gpu, cpu = engines[mode]
+    ref = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))[0][1]
+    rng = np.random.default_rng(300 + mode)
+    reads = mutated_reads(rng, ref, 300, 1, 70) + mutated_reads(rng, ref, 300, 100, 200)
+    reads += [b"", b"A", b"AC", b"ACGTACG", b"ACGTACGT", b"ACGTACGTA", b"N" * 9, b"T" * 15, b"G" * 16, b"C" * 17]
+    bases, offs = pack(reads)
+    gpu.set_option("pml_variant", variant)
+    try:
+        out, st = gpu.query_pml_packed(bases, offs)
+    finally:
+        gpu.set_option("pml_variant", 1)
+    exp, ff, sc = cpu.pml_batch(bases, offs, threads=4)
+    assert (out == exp).all()
+    assert (st.fast_forwards, st.scans, st.errors) == (ff, sc, 0)
+
+
+@pytest.mark.parametrize("mode", [6, 8])
 def test_count_vs_oracle(engines, mode):
     from oracle import build_index as B
     gpu, cpu = engines[mode]
