@@ -300,6 +300,11 @@ int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
         ix->cfg.block_threads = (int)value;
         return MOVI_OK;
     }
+    if (!strcmp(key, "waves_per_cu")) {
+        if (value < 0 || value > 32) return fail(MOVI_ERR_ARG, "waves_per_cu must be in [0,32]");
+        ix->cfg.waves_per_cu = (int)value;
+        return MOVI_OK;
+    }
     return fail(MOVI_ERR_ARG, std::string("unknown option: ") + key);
 }
 

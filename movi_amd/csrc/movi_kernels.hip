@@ -260,6 +260,169 @@ __global__ __launch_bounds__(256) void pml_kernel(DevIndex ix, const uint8_t *__
     }
 }
 
+// VARIANT 2 ("lane state machine"): the SIMT-friendly form of the walk.  In variants
+// 0/1 all 64 lanes advance base by base, so every step costs the wave
+// 1 + max_lanes(fast-forwards) + max_lanes(scan rows) dependent memory round trips.
+// Here each lane runs its own little automaton and every iteration of the (wave-uniform)
+// loop issues exactly ONE row load per lane for whatever that lane needs next -- the LF
+// destination, the next fast-forward row, or the next scan row.  A lane that needs three
+// extra rows simply falls three iterations behind its neighbours instead of stalling
+// them; the wave finishes after max_lanes(total row touches) iterations.
+//   states: kInit  first base: row r-1 just loaded, no LF yet
+//           kFF    `need` was reached by LF / fast-forward: keep forwarding or resolve the base
+//           kDown / kUp  repositioning scan in progress (`a` holds the base's code)
+//           kDone
+// I/O is packed as in variant 1; the next 8-base chunk is requested at the end of the
+// iteration that consumes the last base of the current one, so its latency hides behind
+// the next row load (loads return in order).
+template <int MODE>
+__global__ __launch_bounds__(256) void pml_kernel_sm(DevIndex ix, const uint8_t *__restrict__ bases,
+                                                     const uint64_t *__restrict__ offs, uint64_t n_reads,
+                                                     uint16_t *__restrict__ out, uint8_t *__restrict__ err,
+                                                     DevStats *stats) {
+    enum : uint32_t { kInit = 0, kFF = 1, kDown = 2, kUp = 3, kDone = 4 };
+    __shared__ uint8_t s_code[256];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = ix.code_of[i];
+    __syncthreads();
+
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t ff_total = 0, scan_total = 0, repo_total = 0, failed = 0;
+    const bool valid = t < n_reads;
+    const uint64_t beg = valid ? offs[t] : 0;
+    const uint64_t len = valid ? offs[t + 1] - beg : 0;
+    const uint8_t *R = bases + beg;
+    uint16_t *O = out + beg;
+    const uint64_t packed_end = len & ~7ull;              // PMLs of steps >= this are stored one by one
+
+    uint32_t st = len > 0 ? kInit : kDone;
+    uint64_t need = ix.r - 1;                             // ReadProcessor::reset_process :69-70
+    uint64_t idx = need;
+    uint64_t k = 0;                                       // steps done = bases consumed from the end
+    uint32_t off = 0, ml = 0, a = 0xFFu, ff_run = 0;
+    uint64_t rb = 0;                                      // current 8-base chunk (byte 7 = step k with k%8==0)
+    uint4 pk = make_uint4(0, 0, 0, 0);
+    // chunk c holds read positions [len-8(c+1), len-8c); a short final chunk is loaded as the
+    // 8 bytes ending at the chunk's top when that stays inside the buffer (its low bytes are
+    // a neighbour's bases and are never looked at), else byte by byte.
+    auto load_chunk = [&](uint64_t kk) -> uint64_t {
+        uint64_t v = 0;
+        if (beg + len >= kk + 8) {
+            __builtin_memcpy(&v, R + len - kk - 8, 8);    // may start before R: still inside `bases`
+        } else {
+            for (uint64_t i = 0; i < len - kk; ++i) v |= (uint64_t)R[len - 1 - kk - i] << (8 * (7 - i));
+        }
+        return v;
+    };
+    if (st != kDone) rb = load_chunk(0);
+
+    while (wave_any(st != kDone)) {
+        uint2 row = make_uint2(0, 0);
+        if (st != kDone) row = load_row<MODE>(ix.rows, need);
+        bool resolved = false;        // `row` (= rows[need]) is the row base k is compared with
+        bool emit = false;            // base k is finished; `row` at idx = need is its final row
+        if (st == kInit) {
+            off = row_n<MODE>(row) - 1;
+            resolved = true;
+        } else if (st == kFF) {
+            const uint32_t n = row_n<MODE>(row);
+            if (need < ix.r - 1 && off >= n) {            // fast_forward, move_structure.cpp:524-545
+                off -= n;
+                need += 1;
+                ff_run += 1;
+                if (ff_run >= 65535u) { failed = kErrFastForward; st = kDone; }   // :72-75
+            } else {
+                ff_total += ff_run;
+                resolved = true;
+            }
+        } else if (st == kDown || st == kUp) {            // reposition_down :211-232 / _up :188-209
+            scan_total += 1;
+            if (row_c<MODE>(row) == a) {
+                off = (st == kDown) ? 0u : row_n<MODE>(row) - 1;          // read_processor.cpp:223
+                emit = true;
+            } else if (st == kDown ? (need >= ix.r - 1) : (need == 0)) {
+                failed = (st == kDown) ? kErrNoRunBelow : kErrNoRunAbove; // :582-598
+                st = kDone;
+            } else {
+                need = (st == kDown) ? need + 1 : need - 1;
+            }
+        }
+        if (resolved) {
+            idx = need;
+            a = s_code[(uint32_t)(rb >> (8 * (7 - (k & 7)))) & 0xFFu];
+            const uint32_t rc = row_c<MODE>(row);         // the '$' row decodes as c == 0
+            if (a == 0xFFu) {
+                ml = 0;                                   // check_alphabet failed
+                emit = true;
+            } else if (rc == a) {
+                ml += 1;
+                emit = true;
+            } else {
+                // reposition_thresholds, src/move_structure_query.cpp:513-601
+                repo_total += 1;
+                ml = 0;
+                uint32_t down;
+                if (idx == ix.end_bwt_idx) {
+                    const uint64_t et = a == 1 ? ix.end_thr[1] : (a == 2 ? ix.end_thr[2] : ix.end_thr[3]);
+                    down = ((uint64_t)off >= et) ? 1u : 0u;
+                } else {
+                    const uint32_t kk = a - (a > rc ? 1u : 0u);          // alphamap_3[rc][a], utils.cpp:5-8
+                    const uint32_t thr = row_thr<MODE>(row, kk) ? row_n<MODE>(row) : 0u;
+                    down = (off >= thr) ? 1u : 0u;
+                }
+                if (down ? (idx == ix.r - 1) : (idx == 0)) {
+                    failed = down ? kErrNoRunBelow : kErrNoRunAbove;
+                    st = kDone;
+                } else {
+                    st = down ? kDown : kUp;
+                    need = down ? idx + 1 : idx - 1;
+                }
+            }
+        }
+        if (emit) {
+            idx = need;
+            const uint32_t val = ml > 65535u ? 65535u : ml;              // MoveQuery::add_ml
+            if (k >= packed_end) {
+                O[k] = (uint16_t)val;
+            } else {
+                pk.x = (pk.x >> 16) | (pk.y << 16);
+                pk.y = (pk.y >> 16) | (pk.z << 16);
+                pk.z = (pk.z >> 16) | (pk.w << 16);
+                pk.w = (pk.w >> 16) | (val << 16);
+                if ((k & 7) == 7) __builtin_memcpy(O + (k - 7), &pk, 16);
+            }
+            k += 1;
+            if (k == len) {
+                st = kDone;
+            } else {
+                // LF_move, move_structure.cpp:59-67
+                const uint64_t j = row_id<MODE>(row, idx, ix);
+                if (j >= ix.r) {
+                    failed = kErrIdRange;
+                    st = kDone;
+                } else {
+                    off += row_off<MODE>(row);
+                    need = j;
+                    ff_run = 0;
+                    st = kFF;
+                    if ((k & 7) == 0) rb = load_chunk(k);
+                }
+            }
+        }
+    }
+    if (failed) {
+        for (uint64_t i = 0; i < len; ++i) O[i] = 0;
+    }
+    if (valid && err) err[t] = (uint8_t)failed;
+    const uint32_t ffw = wave_sum(ff_total), scw = wave_sum(scan_total), rpw = wave_sum(repo_total),
+                   erw = wave_sum(failed ? 1u : 0u);
+    if ((threadIdx.x & 63) == 0 && stats) {
+        if (ffw) atomicAdd(&stats->fast_forwards, (unsigned long long)ffw);
+        if (scw) atomicAdd(&stats->scans, (unsigned long long)scw);
+        if (rpw) atomicAdd(&stats->repositions, (unsigned long long)rpw);
+        if (erw) atomicAdd(&stats->errors, (unsigned long long)erw);
+    }
+}
+
 hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets,
                       uint64_t n_reads, uint16_t *d_out, uint8_t *d_err, DevStats *d_stats,
                       const LaunchCfg &cfg, hipStream_t stream) {
@@ -268,16 +431,37 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     const uint64_t blocks = (n_reads + bt - 1) / bt;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     dim3 grid((unsigned)blocks), block((unsigned)bt);
-#define MOVI_LAUNCH_PML(M, V)                                                                              \
-    hipLaunchKernelGGL((pml_kernel<M, V>), grid, block, 0, stream, ix, d_bases, d_offsets, n_reads, d_out, \
+    // Occupancy knob: fewer resident walks keep each walk's current cache lines (row
+    // neighbours, its read, its output) alive in L2 between steps.  The cap is enforced by
+    // the dispatcher through the block's LDS allocation (160 KiB per CU); blocks beyond the
+    // cap queue and start as resident ones retire, i.e. hardware does the refill.
+    size_t dyn_lds = 0;
+    if (cfg.waves_per_cu > 0) {
+        int bpc = cfg.waves_per_cu / (bt / 64);
+        if (bpc < 1) bpc = 1;
+        if (bpc < 32) dyn_lds = ((163840u / (unsigned)bpc) & ~1023u) - 1024u;
+    }
+#define MOVI_LAUNCH_PML(M, V)                                                                                  \
+    do {                                                                                                       \
+        if (dyn_lds > 65536) {                                                                                 \
+            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&pml_kernel<M, V>),             \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds);     \
+            if (ea != hipSuccess) return ea;                                                                   \
+        }                                                                                                      \
+        hipLaunchKernelGGL((pml_kernel<M, V>), grid, block, dyn_lds, stream, ix, d_bases, d_offsets, n_reads,  \
+                           d_out, d_err, d_stats);                                                             \
+    } while (0)
+#define MOVI_LAUNCH_SM(M)                                                                                   \
+    hipLaunchKernelGGL((pml_kernel_sm<M>), grid, block, dyn_lds, stream, ix, d_bases, d_offsets, n_reads, d_out, \
                        d_err, d_stats)
     const int v = cfg.pml_variant;
     if (mode == 6) {
-        if (v == 0) MOVI_LAUNCH_PML(6, 0); else MOVI_LAUNCH_PML(6, 1);
+        if (v == 0) MOVI_LAUNCH_PML(6, 0); else if (v == 1) MOVI_LAUNCH_PML(6, 1); else MOVI_LAUNCH_SM(6);
     } else {
-        if (v == 0) MOVI_LAUNCH_PML(8, 0); else MOVI_LAUNCH_PML(8, 1);
+        if (v == 0) MOVI_LAUNCH_PML(8, 0); else if (v == 1) MOVI_LAUNCH_PML(8, 1); else MOVI_LAUNCH_SM(8);
     }
 #undef MOVI_LAUNCH_PML
+#undef MOVI_LAUNCH_SM
     return hipGetLastError();
 }
 

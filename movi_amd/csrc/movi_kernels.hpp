@@ -32,7 +32,8 @@ struct DevStats {
 
 struct LaunchCfg {
     int block_threads = 256;
-    int pml_variant = 1;   // see pml_kernel<MODE, VARIANT>
+    int pml_variant = 2;   // 0/1: pml_kernel<MODE, VARIANT>; 2: pml_kernel_sm (lane state machine)
+    int waves_per_cu = 0;  // 0 = no cap; else cap resident waves per CU by padding the block's LDS allocation
 };
 
 hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets,
