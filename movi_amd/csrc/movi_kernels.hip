@@ -29,9 +29,13 @@ namespace movi {
 //     x = id16 | n16 << 16    y = offset16
 //     n16:  [9:0] n, [15:10] id[21:16]
 //     off16:[9:0] offset, [12:10] c, [13] thr0, [14] thr1, [15] thr2
-template <int MODE>
+template <int MODE, bool NT = false>
 __device__ __forceinline__ uint2 load_row(const uint8_t *rows, uint64_t i) {
     if (MODE == 6) {
+        if (NT) {   // streaming hint for the far gather: the line is not worth keeping in L1
+            const unsigned long long v = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long *>(rows + i * 8));
+            return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+        }
         return *reinterpret_cast<const uint2 *>(rows + i * 8);
     } else {
         const uint16_t *p = reinterpret_cast<const uint16_t *>(rows + i * 6);
@@ -97,7 +101,7 @@ __device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
 
 // LF_move + fast_forward.  On entry `row` is rows[idx]; on exit it is the row of
 // the new idx.  `live` lanes take the step; returns a kErr* code (0 = ok) per lane.
-template <int MODE>
+template <int MODE, bool NT = false>
 __device__ __forceinline__ uint32_t lf_step(const DevIndex &ix, bool live, uint64_t &idx, uint32_t &off,
                                             uint2 &row, uint32_t &ff_total) {
     uint32_t errc = kErrNone;
@@ -111,7 +115,7 @@ __device__ __forceinline__ uint32_t lf_step(const DevIndex &ix, bool live, uint6
             j = idx;
         } else {
             off += row_off<MODE>(row);
-            row = load_row<MODE>(ix.rows, j);           // THE dependent random gather
+            row = load_row<MODE, NT>(ix.rows, j);       // THE dependent random gather
             n = row_n<MODE>(row);
             going = (j < ix.r - 1 && off >= n) ? 1u : 0u;
         }
@@ -164,7 +168,7 @@ __global__ __launch_bounds__(256) void pml_kernel(DevIndex ix, const uint8_t *__
     const uint64_t packed_end = len & ~7ull;              // steps >= this are stored one by one
     for (uint64_t k = 0; wave_any(k < len && failed == 0u); ++k) {
         bool live = k < len && failed == 0u;
-        if (VARIANT == 1 && (k & 7) == 0) {
+        if (VARIANT >= 1 && (k & 7) == 0) {
             if (live && k + 8 <= len) {
                 __builtin_memcpy(&rb, R + (len - 8 - k), 8);          // unaligned 8-byte load
             } else if (live) {
@@ -173,12 +177,12 @@ __global__ __launch_bounds__(256) void pml_kernel(DevIndex ix, const uint8_t *__
             }
         }
         if (k != 0) {
-            const uint32_t e = lf_step<MODE>(ix, live, idx, off, row, ff_total);
+            const uint32_t e = lf_step<MODE, (VARIANT >= 4)>(ix, live, idx, off, row, ff_total);
             if (e) { failed = e; live = false; }
         }
         uint32_t a = 0xFFu;
         if (live) {
-            if (VARIANT == 1) a = s_code[(uint32_t)(rb >> (8 * (7 - (k & 7)))) & 0xFFu];
+            if (VARIANT >= 1) a = s_code[(uint32_t)(rb >> (8 * (7 - (k & 7)))) & 0xFFu];
             else a = s_code[R[len - 1 - k]];
         }
         const uint32_t rc = row_c<MODE>(row);             // the '$' row decodes as c == 0
@@ -229,7 +233,7 @@ __global__ __launch_bounds__(256) void pml_kernel(DevIndex ix, const uint8_t *__
         if (dir == 1u) off = 0;
         if (dir == 2u) off = row_n<MODE>(row) - 1;        // read_processor.cpp:223
         const uint32_t val = ml > 65535u ? 65535u : ml;   // MoveQuery::add_ml
-        if (VARIANT == 1) {
+        if (VARIANT >= 1) {
             if (live && k >= packed_end) {
                 O[k] = (uint16_t)val;
             } else if (live) {
@@ -279,7 +283,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void pml_kernel_sm(DevIndex ix, const uint8_t *__restrict__ bases,
                                                      const uint64_t *__restrict__ offs, uint64_t n_reads,
                                                      uint16_t *__restrict__ out, uint8_t *__restrict__ err,
-                                                     DevStats *stats) {
+                                                     DevStats *stats, int extra_trips) {
     enum : uint32_t { kInit = 0, kFF = 1, kDown = 2, kUp = 3, kDone = 4 };
     __shared__ uint8_t s_code[256];
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = ix.code_of[i];
@@ -316,8 +320,14 @@ __global__ __launch_bounds__(256) void pml_kernel_sm(DevIndex ix, const uint8_t 
     if (st != kDone) rb = load_chunk(0);
 
     while (wave_any(st != kDone)) {
-        uint2 row = make_uint2(0, 0);
-        if (st != kDone) row = load_row<MODE>(ix.rows, need);
+      // Trip 0: every live lane loads the row it needs (for most lanes a far gather).  Trips
+      // 1..extra_trips: only lanes whose NEXT row is an adjacent one (fast-forward / scan in
+      // progress) load again at once -- that neighbour is in the line that just arrived, so the
+      // trip is an L2/L1 hit -- while lanes that finished their base wait for the next trip 0.
+      bool want = st != kDone;
+      for (int trip = 0; trip <= extra_trips && wave_any(want); ++trip) {
+       if (want) {
+        uint2 row = load_row<MODE>(ix.rows, need);
         bool resolved = false;        // `row` (= rows[need]) is the row base k is compared with
         bool emit = false;            // base k is finished; `row` at idx = need is its final row
         if (st == kInit) {
@@ -408,6 +418,9 @@ __global__ __launch_bounds__(256) void pml_kernel_sm(DevIndex ix, const uint8_t 
                 }
             }
         }
+       }
+       want = st == kDown || st == kUp || (st == kFF && ff_run > 0u);
+      }
     }
     if (failed) {
         for (uint64_t i = 0; i < len; ++i) O[i] = 0;
@@ -453,12 +466,20 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     } while (0)
 #define MOVI_LAUNCH_SM(M)                                                                                   \
     hipLaunchKernelGGL((pml_kernel_sm<M>), grid, block, dyn_lds, stream, ix, d_bases, d_offsets, n_reads, d_out, \
-                       d_err, d_stats)
-    const int v = cfg.pml_variant;
+                       d_err, d_stats, extra)
+    // Auto selection (measured on MI355X, profiles/): with plenty of reads (> ~10 waves per CU)
+    // the base-synchronous packed kernel (1) wins because its neighbour loads follow the gather
+    // at once and hit L2; with few reads in flight (long-read batches, small shards) the lane
+    // state machine (2) wins because it needs ~2.3 instead of ~11 dependent trips per base.
+    int v = cfg.pml_variant;
+    if (v < 0) v = (n_reads <= (uint64_t)cfg.num_cus * 64u * 10u) ? 2 : 1;
+    const int extra = v == 2 ? 0 : cfg.extra_trips;       // variant 2 = pure state machine; 3 = with neighbour trips
     if (mode == 6) {
-        if (v == 0) MOVI_LAUNCH_PML(6, 0); else if (v == 1) MOVI_LAUNCH_PML(6, 1); else MOVI_LAUNCH_SM(6);
+        if (v == 0) MOVI_LAUNCH_PML(6, 0); else if (v == 1) MOVI_LAUNCH_PML(6, 1);
+        else if (v == 4) MOVI_LAUNCH_PML(6, 4); else MOVI_LAUNCH_SM(6);
     } else {
-        if (v == 0) MOVI_LAUNCH_PML(8, 0); else if (v == 1) MOVI_LAUNCH_PML(8, 1); else MOVI_LAUNCH_SM(8);
+        if (v == 0) MOVI_LAUNCH_PML(8, 0); else if (v == 1) MOVI_LAUNCH_PML(8, 1);
+        else if (v == 4) MOVI_LAUNCH_PML(8, 4); else MOVI_LAUNCH_SM(8);
     }
 #undef MOVI_LAUNCH_PML
 #undef MOVI_LAUNCH_SM

@@ -32,7 +32,9 @@ struct DevStats {
 
 struct LaunchCfg {
     int block_threads = 256;
-    int pml_variant = 2;   // 0/1: pml_kernel<MODE, VARIANT>; 2: pml_kernel_sm (lane state machine)
+    int pml_variant = -1;  // -1 auto; 0/1/4: pml_kernel<MODE, VARIANT>; 2: lane state machine; 3: + neighbour trips
+    int num_cus = 256;
+    int extra_trips = 2;   // variant 3: immediate adjacent-row trips per iteration
     int waves_per_cu = 0;  // 0 = no cap; else cap resident waves per CU by padding the block's LDS allocation
 };
 

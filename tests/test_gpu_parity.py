@@ -85,7 +85,7 @@ def test_pml_ragged_reads_vs_oracle(engines, mode):
 
 
 @pytest.mark.parametrize("mode", [6, 8])
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 def test_pml_kernel_variants_vs_oracle(engines, mode, variant):
     """Every selectable kernel variant is held to the same bit-exact bar, including
     reads whose length is not a multiple of the 8-step packing and unaligned offsets."""
@@ -100,7 +100,7 @@ def test_pml_kernel_variants_vs_oracle(engines, mode, variant):
     try:
         out, st = gpu.query_pml_packed(bases, offs)
     finally:
-        gpu.set_option("pml_variant", 2)
+        gpu.set_option("pml_variant", -1)
     exp, ff, sc = cpu.pml_batch(bases, offs, threads=4)
     assert (out == exp).all()
     assert (st.fast_forwards, st.scans, st.errors) == (ff, sc, 0)

@@ -52,7 +52,17 @@ __global__ __launch_bounds__(256) void chase(const uint64_t *__restrict__ table,
     uint4 pk = make_uint4(0, 0, 0, 0);
     for (int k = 0; k < steps; ++k) {
         uint64_t v;
-        if (VAR == 0 || VAR >= 5) {
+        if (VAR == 9) {
+            v = __builtin_nontemporal_load(table + idx);
+        } else if (VAR == 10) {
+            asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(table + idx) : "memory");
+        } else if (VAR == 11) {
+            asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(table + idx) : "memory");
+        } else if (VAR == 12) {
+            asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1 nt\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(table + idx) : "memory");
+        } else if (VAR == 13) {
+            asm volatile("global_load_dwordx2 %0, %1, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(table + idx) : "memory");
+        } else if (VAR == 0 || VAR >= 5) {
             v = table[idx];
             if (VAR == 5) {
                 const uint64_t v2 = table[idx + 1 + (uint32_t)(v & 1)];   // issued only after v arrives
@@ -127,20 +137,27 @@ int main(int argc, char **argv) {
     CHECK(hipMalloc(&out, max_lanes * steps * 2 + 64));
     CHECK(hipMalloc(&stream, max_lanes * steps + 64));
     CHECK(hipMemset(stream, 1, max_lanes * steps));
-    const char *names[9] = {"8B row", "16B pair", "32B quad", "64B sector->VGPR", "64B sector->LDS (glds)",
+    const char *names[14] = {"8B row", "16B pair", "32B quad", "64B sector->VGPR", "64B sector->LDS (glds)",
                             "8B row + dependent neighbour", "8B row + 2B store/step", "8B row + 16B store/8 steps",
-                            "8B row + 1B stream load/step"};
-    for (int which = 0; which < 2; which++) {
+                            "8B row + 1B stream load/step", "8B row nt", "8B row sc1", "8B row sc0 sc1",
+                            "8B row sc0 sc1 nt", "8B row sc0"};
+    const char *alloc_names[4] = {"hipMalloc", "hipMalloc", "hipExtMallocWithFlags(Uncached)", "hipExtMallocWithFlags(FineGrained)"};
+    for (int which = 0; which < 4; which++) {
         const int lg = which == 0 ? small_log2 : big_log2;
         const uint64_t n = 1ull << lg;
         uint64_t *table;
-        if (hipMalloc(&table, n * 8 + 64) != hipSuccess) { printf("alloc of %llu rows failed\n", (unsigned long long)n); continue; }
+        hipError_t ea;
+        if (which == 2) ea = hipExtMallocWithFlags((void **)&table, n * 8 + 64, hipDeviceMallocUncached);
+        else if (which == 3) ea = hipExtMallocWithFlags((void **)&table, n * 8 + 64, hipDeviceMallocFinegrained);
+        else ea = hipMalloc(&table, n * 8 + 64);
+        printf("alloc: %s\n", alloc_names[which]);
+        if (ea != hipSuccess) { printf("alloc of %llu rows failed: %s\n", (unsigned long long)n, hipGetErrorString(ea)); continue; }
         hipLaunchKernelGGL(fill_table, dim3(4096), dim3(256), 0, 0, table, n);
         CHECK(hipDeviceSynchronize());
         const uint32_t n_rows = (uint32_t)(n - 8);
         printf("table: 2^%d rows = %.1f MB\n", lg, n * 8 / 1e6);
-        for (uint64_t lanes : {(uint64_t)1 << 17, (uint64_t)1 << 19, (uint64_t)1 << 20}) {
-            double ms[9];
+        for (uint64_t lanes : {(uint64_t)1 << 18, (uint64_t)1 << 20}) {
+            double ms[14];
             ms[0] = run<0>(table, n_rows, steps, lanes, sink, out, stream, 5);
             ms[1] = run<1>(table, n_rows, steps, lanes, sink, out, stream, 5);
             ms[2] = run<2>(table, n_rows, steps, lanes, sink, out, stream, 5);
@@ -150,7 +167,12 @@ int main(int argc, char **argv) {
             ms[6] = run<6>(table, n_rows, steps, lanes, sink, out, stream, 5);
             ms[7] = run<7>(table, n_rows, steps, lanes, sink, out, stream, 5);
             ms[8] = run<8>(table, n_rows, steps, lanes, sink, out, stream, 5);
-            for (int v = 0; v < 9; v++)
+            ms[9] = run<9>(table, n_rows, steps, lanes, sink, out, stream, 5);
+            ms[10] = run<10>(table, n_rows, steps, lanes, sink, out, stream, 5);
+            ms[11] = run<11>(table, n_rows, steps, lanes, sink, out, stream, 5);
+            ms[12] = run<12>(table, n_rows, steps, lanes, sink, out, stream, 5);
+            ms[13] = run<13>(table, n_rows, steps, lanes, sink, out, stream, 5);
+            for (int v = 0; v < 14; v++)
                 printf("  lanes=%8llu  %-32s %8.3f ms  %7.2f Gsteps/s\n", (unsigned long long)lanes, names[v], ms[v],
                        lanes * (double)steps / ms[v] / 1e6);
         }
