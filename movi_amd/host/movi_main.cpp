@@ -1,0 +1,262 @@
+// movi_main.cpp -- the `movi` host binary of the MI355X engine: `movi query` and
+// `movi view` with the reference's command line, input rules and output bytes
+// (driver: src/movi.cpp:221-400 query(), :402-503 view(), :561-748 main()).
+//
+// All query arithmetic happens on the GPU behind the C-ABI of include/movi_hip.h; this
+// file only parses, batches, orders and writes.  One binary serves both index modes (the
+// reference ships one binary per mode and a launcher, src/movi_launcher.cpp:244-254).
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <memory>
+#include <stdexcept>
+#include <thread>
+
+#include "../../include/movi_hip.h"
+#include "options.hpp"
+#include "output.hpp"
+#include "reads.hpp"
+
+using namespace movi_host;
+
+namespace {
+
+struct EngineError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+void check(int rc, const char *what) {
+    if (rc != MOVI_OK) throw EngineError(std::string(what) + ": " + movi_last_error());
+}
+
+const char *index_type_name(uint32_t mode) {                          // program(), src/utils.cpp:10-40
+    return mode == MOVI_MODE_REGULAR_THRESHOLDS ? "regular-thresholds" : "blocked-thresholds";
+}
+
+// Contiguous shards of [0, n) balanced by bases.
+std::vector<size_t> shard_bounds(const ReadSet &rs, int parts) {
+    std::vector<size_t> b(1, 0);
+    const uint64_t total = rs.offsets.back();
+    for (int p = 1; p < parts; p++) {
+        const uint64_t target = total * p / parts;
+        size_t i = std::lower_bound(rs.offsets.begin(), rs.offsets.end(), target) - rs.offsets.begin();
+        b.push_back(std::min(std::max(i, b.back()), rs.size()));
+    }
+    b.push_back(rs.size());
+    return b;
+}
+
+// Rounds the strand scheduler spends on a read in prefetch mode (see reads.hpp).  PML: one
+// round per base.  Count: ReadProcessor::backward_search (src/read_processor.cpp:1096-1175)
+// returns in the round of the last LF when it stops at position 0 or at an illegal base, and
+// one round later when the interval became empty.
+uint64_t count_rounds(const ReadSet &rs, size_t i, uint64_t matched, const uint8_t *code_of) {
+    const uint64_t len = rs.len(i);
+    const uint8_t *R = rs.bases.data() + rs.offsets[i];
+    if (len == 0 || code_of[R[len - 1]] == 0xFF) return 1;
+    if (matched >= len) return std::max<uint64_t>(len - 1, 1);
+    if (code_of[R[len - matched - 1]] == 0xFF) return std::max<uint64_t>(matched - 1, 1);
+    return std::max<uint64_t>(matched, 1);
+}
+
+int run_query(const Options &o) {
+    int n_dev = 0;
+    check(movi_device_count(&n_dev), "no usable GPU");
+    if (n_dev < 1) throw EngineError("no usable GPU: the MI355X engine has no CPU fallback");
+    if (o.device + o.gpus > n_dev)
+        throw EngineError("requested devices " + std::to_string(o.device) + ".." + std::to_string(o.device + o.gpus - 1) +
+                          " but only " + std::to_string(n_dev) + " visible");
+    auto t0 = std::chrono::steady_clock::now();
+    std::vector<movi_index_t *> handles((size_t)o.gpus, nullptr);
+    struct Closer {
+        std::vector<movi_index_t *> &h;
+        ~Closer() { for (auto *x : h) movi_index_destroy(x); }
+    } closer{handles};
+    for (int g = 0; g < o.gpus; g++) check(movi_index_load(o.device + g, o.index_dir.c_str(), &handles[g]), "loading the index");
+    movi_index_desc_t desc;
+    check(movi_index_get_desc(handles[0], &desc), "index description");
+    const std::string index_type = index_type_name(desc.mode);
+    std::cerr << "[movi] The " << index_type << " index is being used (r = " << desc.r << ").\n";
+    std::cerr << "[movi] Time measured for loading the index: "
+              << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << " s\n";
+
+    // input: file or stdin (setup_input_file, src/movi.cpp:106-118)
+    std::ifstream file_in;
+    std::istream *in = &std::cin;
+    if (o.read_file != "-") {
+        file_in.open(o.read_file.c_str());
+        if (!file_in.good()) throw std::runtime_error("The input file " + o.read_file + " does not exist.");
+        in = &file_in;
+    }
+
+    // outputs (open_output_files, src/utils.cpp:319-384)
+    Classifier classifier;
+    std::ofstream report_file, mls_file, matches_file;
+    std::ostream *report = nullptr;
+    if (o.classify) {
+        classifier.load_null_db(o.index_dir, o.verbose);
+        if (!o.filter) {                                              // src/classifier.cpp:39-61
+            if (!o.write_stdout) {
+                const std::string name = o.read_file + "." + index_type + "." + o.query_type() + ".report";
+                std::cerr << "[movi] Report file name: " << name << "\n";
+                report_file.open(name);
+                report = &report_file;
+            } else {
+                report = &std::cout;
+            }
+            classifier.write_report_header(*report);
+        }
+    }
+    const bool open_files = (!o.write_stdout || o.classify) && o.write_output_allowed();
+    if (open_files) {
+        std::string prefix = !o.out_file.empty() ? o.out_file : o.read_file + "." + index_type;
+        prefix += "." + o.query_type();
+        if (o.pml) {
+            mls_file.open(prefix + ".bpf", std::ios::out | std::ios::binary);
+            if (!mls_file.good()) throw std::runtime_error("Failed to open the output file: " + prefix + ".bpf");
+            write_bpf_header(mls_file, 16);
+        } else {
+            matches_file.open(prefix + ".matches");
+            if (!matches_file.good()) throw std::runtime_error("Failed to open the output file: " + prefix + ".matches");
+        }
+    }
+
+    auto t1 = std::chrono::steady_clock::now();
+    BatchReader reader(*in, o.prefetch ? 4 * o.strands : 1);          // src/movi.cpp:283, :326
+    ReadSet rs;
+    const uint64_t chunk_bases = 1ull << 28;
+    uint64_t reads_done = 0, bases_done = 0;
+    std::vector<uint16_t> pml;
+    std::vector<uint64_t> matched, counts;
+    std::vector<uint8_t> err;
+    double gpu_seconds = 0;
+    while (reader.next_chunk(rs, chunk_bases)) {
+        const size_t n = rs.size();
+        if (n == 0) continue;
+        if (o.reverse)                                                // src/read_processor.cpp:49-51
+            for (size_t i = 0; i < n; i++) std::reverse(rs.bases.begin() + rs.offsets[i], rs.bases.begin() + rs.offsets[i + 1]);
+        std::vector<uint8_t> original;                                // --filter echoes the read as given
+        if (o.ignore_illegal_chars == 1) {                            // check_alphabet, src/move_structure.cpp:389-395
+            if (o.filter) original = rs.bases;
+            for (auto &c : rs.bases)
+                if (desc.code_of[c] == 0xFF) c = 'A';
+        }
+        pml.assign(o.pml ? rs.bases.size() : 0, 0);
+        matched.assign(o.count ? n : 0, 0);
+        counts.assign(o.count ? n : 0, 0);
+        err.assign(n, 0);
+        const std::vector<size_t> sb = shard_bounds(rs, o.gpus);
+        std::vector<std::string> errors((size_t)o.gpus);
+        auto tg = std::chrono::steady_clock::now();
+        auto work = [&](int g) {
+            const size_t a = sb[g], b = sb[g + 1];
+            if (a == b) return;
+            int rc;
+            if (o.pml)
+                rc = movi_pml_host(handles[g], rs.bases.data(), rs.offsets.data() + a, b - a, pml.data(), err.data() + a, nullptr);
+            else
+                rc = movi_count_host(handles[g], rs.bases.data(), rs.offsets.data() + a, b - a, matched.data() + a,
+                                     counts.data() + a, err.data() + a, nullptr);
+            if (rc != MOVI_OK) errors[g] = movi_last_error();
+        };
+        if (o.gpus == 1) {
+            work(0);
+        } else {
+            std::vector<std::thread> th;
+            for (int g = 0; g < o.gpus; g++) th.emplace_back(work, g);
+            for (auto &t : th) t.join();
+        }
+        gpu_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - tg).count();
+        for (const auto &e : errors)
+            if (!e.empty()) throw EngineError(e);
+
+        // record order: strand scheduler emulation in prefetch mode, file order otherwise
+        std::vector<uint32_t> order;
+        if (o.prefetch) {
+            std::vector<uint64_t> cost(n);
+            for (size_t i = 0; i < n; i++) cost[i] = o.pml ? rs.len(i) : count_rounds(rs, i, matched[i], desc.code_of);
+            order = strand_order(rs, cost, o.strands);
+        } else {
+            order.resize(n);
+            for (size_t i = 0; i < n; i++) order[i] = (uint32_t)i;
+        }
+        for (uint32_t i : order) {
+            const uint64_t len = rs.len(i);
+            if (o.pml) {
+                const uint16_t *p = pml.data() + rs.offsets[i];
+                if (o.classify) {                                     // write_mls, src/read_processor.cpp:565-578
+                    const bool found = classifier.classify(rs.ids[i], p, len, o.bin_width,
+                                                           o.write_output_allowed() ? report : nullptr);
+                    if (o.filter && !o.no_output && (found != o.invert)) {
+                        const uint8_t *seq = (original.empty() ? rs.bases.data() : original.data()) + rs.offsets[i];
+                        std::cout << ">" << rs.ids[i] << "\n";
+                        std::cout.write(reinterpret_cast<const char *>(seq), (std::streamsize)len);
+                        std::cout << "\n";
+                    }
+                }
+                if (o.write_output_allowed()) {
+                    if (o.write_stdout_enabled()) write_stdout_pmls(std::cout, rs.ids[i], p, len);
+                    else write_bpf_record(mls_file, rs.ids[i], p, len);
+                }
+            } else if (o.write_output_allowed()) {
+                std::ostream &out = o.write_stdout_enabled() ? static_cast<std::ostream &>(std::cout) : matches_file;
+                write_count_line(out, rs.ids[i], len, matched[i], counts[i]);
+            }
+        }
+        reads_done += n;
+        bases_done += rs.bases.size();
+    }
+    const double total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+    std::cerr << "[movi] " << reads_done << " reads are processed.\n";
+    std::cerr << "[movi] Time measured for processing the reads: " << total << " s (" << bases_done << " bases; GPU calls "
+              << gpu_seconds << " s)\n";
+    std::cout.flush();
+    return 0;
+}
+
+// `movi plan`: the host-side batching + record order, without any GPU work.
+int run_plan(const Options &o) {
+    std::ifstream file_in;
+    std::istream *in = &std::cin;
+    if (o.read_file != "-") {
+        file_in.open(o.read_file.c_str());
+        if (!file_in.good()) throw std::runtime_error("The input file " + o.read_file + " does not exist.");
+        in = &file_in;
+    }
+    BatchReader reader(*in, o.prefetch ? 4 * o.strands : 1);
+    ReadSet rs;
+    while (reader.next_chunk(rs, 1ull << 28)) {
+        std::vector<uint64_t> cost(rs.size());
+        for (size_t i = 0; i < rs.size(); i++) cost[i] = rs.len(i);
+        std::vector<uint32_t> order;
+        if (o.prefetch) order = strand_order(rs, cost, o.strands);
+        else for (size_t i = 0; i < rs.size(); i++) order.push_back((uint32_t)i);
+        for (uint32_t i : order) std::cout << rs.batch_of[i] << "\t" << rs.ids[i] << "\t" << rs.len(i) << "\n";
+    }
+    return 0;
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    std::ios::sync_with_stdio(false);
+    try {
+        Options o = parse_args(argc, argv);
+        if (o.command == "help") {
+            std::cerr << usage();
+            return 0;
+        }
+        if (o.command == "view") return view_bpf(o, std::cout);
+        if (o.command == "plan") return run_plan(o);
+        return run_query(o);
+    } catch (const UsageError &e) {
+        std::cerr << "Error parsing command line options: " << e.what() << "\n" << usage();
+        return 1;
+    } catch (const std::exception &e) {                               // src/movi.cpp:744-747
+        std::cerr << "Error: " << e.what() << "\n";
+        return 1;
+    }
+}

@@ -1,0 +1,43 @@
+// output.hpp -- byte-exact writers for everything `movi query` / `movi view` emit.
+//
+//   BPFHeader / output_base_stats / output_binary  include/utils.hpp:64-82, src/utils.cpp:202-246
+//   --stdout PML text   include/move_query.hpp:33-37 + src/utils.cpp:214-219
+//   output_counts       src/utils.cpp:248-256
+//   output_read         src/utils.cpp:291-294 (--filter)
+//   Classifier          src/classifier.cpp:24-63 (header line), :99-143 (classify)
+//   EmpNullDatabase::deserialize  src/emperical_null_database.cpp:105-126
+//   view()              src/movi.cpp:402-503
+#pragma once
+#include <cstdint>
+#include <fstream>
+#include <ostream>
+#include <string>
+#include <vector>
+
+#include "options.hpp"
+
+namespace movi_host {
+
+const uint32_t kBpfMagic = 0x42504600u;      // "BPF\0", include/utils.hpp:26
+
+void write_bpf_header(std::ostream &f, uint8_t entry_size);
+// One record: u16 id_len | id | u64 n | n x u16 (emission order = last base first)
+void write_bpf_record(std::ostream &f, const std::string &id, const uint16_t *pml, uint64_t n);
+// `>id\n` + values in read order, each followed by a space, + `\n`
+void write_stdout_pmls(std::ostream &out, const std::string &id, const uint16_t *pml, uint64_t n);
+void write_count_line(std::ostream &out, const std::string &id, uint64_t query_length, uint64_t matched, uint64_t count);
+
+class Classifier {
+public:
+    // Reads DIR/movi.pml.nulldb; returns max_value_thr = max(percentile, 3) + 1.
+    size_t load_null_db(const std::string &index_dir, bool verbose);
+    void write_report_header(std::ostream &out) const;
+    // Bins of bin_width over the PML vector in emission order; the last bin absorbs a
+    // remainder shorter than bin_width.  Writes the report line unless out == nullptr.
+    bool classify(const std::string &read_name, const uint16_t *pml, uint64_t n, size_t bin_width, std::ostream *out) const;
+    uint16_t max_value_thr = 0;
+};
+
+int view_bpf(const Options &o, std::ostream &out);
+
+}  // namespace movi_host

@@ -1,0 +1,153 @@
+"""CPU suite for the C++ host CLI: argument handling, read parsing / id rule, the
+reference's batch cut and strand-order emulation (checked against an independent
+round-by-round simulation written from src/batch_loader.cpp + src/read_processor.cpp),
+and `movi view` on hand-built BPF bytes.  No GPU work."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+MOVI = os.path.join(ROOT, "movi_amd", "bin", "movi")
+
+
+@pytest.fixture(scope="module")
+def movi_bin(built_lib):
+    if not os.path.exists(MOVI):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "movi_amd", "csrc")], stdout=subprocess.DEVNULL)
+    return MOVI
+
+
+def run(args, **kw):
+    return subprocess.run([MOVI] + args, capture_output=True, **kw)
+
+
+def test_argument_errors(movi_bin):
+    r = run(["query", "-i", "x", "-r", "y", "--pml", "--count"])
+    assert r.returncode == 1 and b"Please only specify count or pml" in r.stderr      # movi_parser.cpp:407-410
+    r = run(["query", "-i", "x"])
+    assert r.returncode == 1 and b"Please include one index directory and one read file." in r.stderr
+    r = run(["query", "-i", "x", "-r", "y", "--zml"])
+    assert r.returncode == 1 and b"not supported" in r.stderr
+    r = run(["build", "-i", "x", "-f", "y"])
+    assert r.returncode == 1
+    r = run(["query", "-i", "x", "-r", "y", "--ignore-illegal-chars", "3"])
+    assert r.returncode == 1 and b"ignore-illegal-chars should be either 1" in r.stderr
+    r = run(["view", "--bpf", "/nonexistent.bpf"])
+    assert r.returncode == 1 and b"Failed to open the MLS file" in r.stderr
+
+
+def reference_schedule(lines, fmt, strands, prefetch):
+    """Independent restatement: loadBatch (batch_loader.cpp:26-89), grabNextRead (:91-143),
+    process_latency_hiding (read_processor.cpp:641-730) simulated one round at a time."""
+    min_reads = 4 * strands if prefetch else 1
+    out, pos, batch_no = [], 0, 0
+    while pos < len(lines):
+        bases = reads = nl = rec = 0
+        batch = []
+        while pos < len(lines) and (bases < 1000 or reads < min_reads):
+            ln = lines[pos]; pos += 1; nl += 1; rec += len(ln)
+            if fmt == "fq":
+                if nl % 4 == 0:
+                    bases += rec // 2; rec = 0; reads += 1
+            elif pos < len(lines) and lines[pos][:1] == b">":
+                bases += rec; rec = 0; reads += 1
+            batch.append(ln)
+        # parse the batch
+        recs, p = [], 0
+        while p < len(batch):
+            h = batch[p]
+            if not h:
+                break
+            k = next((i for i in range(1, len(h)) if h[i:i + 1] in (b" ", b"\t", b"\r")), len(h))
+            rid = h[1:1 + k]
+            p += 1
+            if fmt == "fq":
+                seq = batch[p].rstrip(); p += 3
+            else:
+                seq = b""
+                while p < len(batch) and batch[p][:1] != b">":
+                    seq += batch[p].rstrip(); p += 1
+            recs.append((rid, len(seq)))
+        if not prefetch:
+            out += [(batch_no, r, l) for r, l in recs]
+        else:
+            nxt = 0
+            cur = [None] * strands
+            left = [0] * strands
+            for s in range(strands):
+                if nxt < len(recs):
+                    cur[s], left[s] = recs[nxt], max(recs[nxt][1], 1); nxt += 1
+            while any(c is not None for c in cur):
+                for s in range(strands):
+                    if cur[s] is None:
+                        continue
+                    left[s] -= 1
+                    if left[s] == 0:
+                        out.append((batch_no, cur[s][0], cur[s][1]))
+                        if nxt < len(recs):
+                            cur[s], left[s] = recs[nxt], max(recs[nxt][1], 1); nxt += 1
+                        else:
+                            cur[s] = None
+        batch_no += 1
+    return out
+
+
+def make_reads(rng, n, fmt):
+    lines = []
+    for i in range(n):
+        L = int(rng.integers(1, 400)) if rng.random() < 0.9 else int(rng.integers(400, 3000))
+        seq = bytes(rng.choice(list(b"ACGTN"), size=L).astype(np.uint8))
+        cm = [b"", b" comment here", b"\tx=1", b" "][int(rng.integers(0, 4))]
+        if fmt == "fq":
+            lines += [b"@q%d" % i + cm, seq, b"+", b"I" * L]
+        else:
+            lines.append(b">r%d" % i + cm)
+            w = int(rng.integers(40, 120))
+            lines += [seq[j:j + w] for j in range(0, L, w)]
+    return lines
+
+
+@pytest.mark.parametrize("fmt", ["fa", "fq"])
+@pytest.mark.parametrize("flags,strands,prefetch", [(["-s16"], 16, True), (["-s4"], 4, True), (["-s", "1"], 1, True),
+                                                    (["-n"], 16, False)])
+def test_batching_and_record_order(movi_bin, tmp_path, fmt, flags, strands, prefetch):
+    rng = np.random.default_rng(len(flags) * 7 + strands + (fmt == "fq"))
+    lines = make_reads(rng, 600, fmt)
+    path = tmp_path / ("reads." + fmt)
+    path.write_bytes(b"\n".join(lines) + b"\n")
+    r = run(["plan", "-r", str(path)] + flags)
+    assert r.returncode == 0, r.stderr
+    got = []
+    for l in r.stdout.split(b"\n"):
+        if l:
+            b, rest = l.split(b"\t", 1)          # ids may themselves end in a tab
+            i, ln = rest.rsplit(b"\t", 1)
+            got.append((b, i, ln))
+    exp = reference_schedule(lines, fmt, strands, prefetch)
+    assert len(got) == len(exp) == 600
+    assert [(int(b), i, int(l)) for b, i, l in got] == exp
+    # the id keeps the first whitespace character after the name (batch_loader.cpp:117-119)
+    ids = [i for _, i, _ in got]
+    assert any(i.endswith(b" ") for i in ids) and any(i.endswith(b"\t") for i in ids)
+
+
+def test_view_prints_read_order(movi_bin, tmp_path):
+    """BPF layout: 12-byte header | per read u16 id_len, id, u64 n, n x u16 (last base first);
+    `view` prints each record reversed (src/movi.cpp:454-456)."""
+    recs = [(b"readA ", [0, 1, 2, 65535, 7]), (b"b", []), (b"c\t", [9])]
+    blob = struct.pack("<IBBBBHxx", 0x42504600, 1, 0, 0, 16, 0)
+    for rid, vals in recs:
+        blob += struct.pack("<H", len(rid)) + rid + struct.pack("<Q", len(vals)) + np.asarray(vals, "<u2").tobytes()
+    f = tmp_path / "x.bpf"
+    f.write_bytes(blob)
+    r = run(["view", "--bpf", str(f)])
+    assert r.returncode == 0
+    exp = b"".join(b">" + rid + b"\n" + b"".join(b"%d " % v for v in vals[::-1]) + b"\n" for rid, vals in recs)
+    assert r.stdout == exp
+    bad = tmp_path / "bad.bpf"
+    bad.write_bytes(b"\x00" * 12)
+    assert run(["view", "--bpf", str(bad)]).returncode == 1

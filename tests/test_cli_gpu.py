@@ -1,0 +1,209 @@
+"""GPU suite for the `movi` host binary: the reference's own CLI-level golden test
+(tests/test_pml.cpp:6-55: query --stdout | LC_ALL=C sort | diff golden), BPF bytes,
+`view`, count lines, classification report / filter, --reverse, --ignore-illegal-chars,
+stdin input -- all against the oracle."""
+import os
+import shutil
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, read_fastx, stdout_line
+
+pytestmark = pytest.mark.gpu
+MOVI = os.path.join(ROOT, "movi_amd", "bin", "movi")
+IDX = {6: os.path.join(GOLDEN, "index_regular-thresholds"), 8: os.path.join(GOLDEN, "index_blocked-thresholds")}
+TYPE = {6: "regular-thresholds", 8: "blocked-thresholds"}
+
+
+@pytest.fixture(scope="module")
+def movi_bin(built_lib):
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "movi_amd", "csrc")], stdout=subprocess.DEVNULL)
+    return MOVI
+
+
+@pytest.fixture(scope="module")
+def oracles(golden_image):
+    from oracle.oracle import Oracle
+    return {m: Oracle(golden_image(m)) for m in (6, 8)}
+
+
+def run(args, **kw):
+    return subprocess.run([MOVI] + args, capture_output=True, **kw)
+
+
+def plan_order(reads_path, flags):
+    r = run(["plan", "-r", reads_path] + flags)
+    assert r.returncode == 0
+    out = []
+    for l in r.stdout.split(b"\n"):
+        if l:
+            rest = l.split(b"\t", 1)[1]
+            out.append(rest.rsplit(b"\t", 1)[0])
+    return out
+
+
+# the reference's CLI golden test matrix restricted to the modes in scope (tests/test_pml.cpp:57-105)
+@pytest.mark.parametrize("mode", [6, 8])
+@pytest.mark.parametrize("flags", [["--no-prefetch", "-t1"], ["-s16", "-t1"], ["-s4", "-t4"], ["--no-prefetch", "-t4"]])
+@pytest.mark.parametrize("reads", ["sample.fastq", "sample.fasta"])
+def test_reference_cli_golden(movi_bin, mode, flags, reads):
+    r = run(["query", "--index", IDX[mode], "--read", os.path.join(GOLDEN, reads), "--pml"] + flags + ["--stdout"])
+    assert r.returncode == 0, r.stderr
+    got = b"".join(sorted(r.stdout.splitlines(keepends=True)))          # LC_ALL=C sort
+    assert got == open(os.path.join(GOLDEN, "sample.fastq.pmls.sorted"), "rb").read()
+
+
+def write_mixed_reads(path, rng, ref, n=300):
+    recs = []
+    with open(path, "wb") as f:
+        for i in range(n):
+            L = int(rng.integers(1, 900))
+            s = int(rng.integers(0, len(ref) - L))
+            seq = bytearray(ref[s:s + L])
+            for k in range(L):
+                if rng.random() < 0.02:
+                    seq[k] = b"ACGTNacgt"[rng.integers(0, 9)]
+            hdr = b">m%d" % i + [b"", b" desc", b"\tz"][i % 3]
+            f.write(hdr + b"\n")
+            for j in range(0, L, 70):
+                f.write(bytes(seq[j:j + 70]) + b"\n")
+            rid = hdr[1:] if i % 3 == 0 else hdr[1:hdr.index(b" " if i % 3 == 1 else b"\t") + 1]
+            recs.append((rid, bytes(seq)))
+    return recs
+
+
+@pytest.mark.parametrize("mode", [6, 8])
+def test_bpf_bytes_view_and_order(movi_bin, oracles, tmp_path, mode):
+    from oracle import build_index as B
+    ref = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))[0][1]
+    reads_path = str(tmp_path / "mixed.fa")
+    recs = write_mixed_reads(reads_path, np.random.default_rng(5 + mode), ref)
+    by_id = dict(recs)
+    prefix = str(tmp_path / "out")
+    r = run(["query", "-i", IDX[mode], "-r", reads_path, "-o", prefix, "-s8", "-t1"])
+    assert r.returncode == 0, r.stderr
+    blob = open(prefix + ".pml.bpf", "rb").read()
+    exp = struct.pack("<IBBBBHxx", 0x42504600, 1, 0, 0, 16, 0)
+    for rid in plan_order(reads_path, ["-s8"]):                         # record order = strand scheduler order
+        p = oracles[mode].pml(by_id[rid])
+        exp += struct.pack("<H", len(rid)) + rid + struct.pack("<Q", len(p)) + p.astype("<u2").tobytes()
+    assert blob == exp
+    # default file name: <read_file>.<type>.pml.bpf (src/utils.cpp:346-356)
+    r = run(["query", "-i", IDX[mode], "-r", reads_path, "-n"])
+    assert r.returncode == 0
+    default_name = reads_path + "." + TYPE[mode] + ".pml.bpf"
+    assert os.path.exists(default_name)
+    # view == --stdout (file order with --no-prefetch)
+    v = run(["view", "--bpf", default_name])
+    s = run(["query", "-i", IDX[mode], "-r", reads_path, "-n", "--stdout"])
+    assert v.returncode == 0 and s.returncode == 0 and v.stdout == s.stdout
+    assert s.stdout == b"".join(b">" + rid + b"\n" + stdout_line(oracles[mode].pml(seq)).encode() + b"\n" for rid, seq in recs)
+
+
+@pytest.mark.parametrize("mode", [6, 8])
+def test_count_lines(movi_bin, oracles, tmp_path, mode):
+    from oracle import build_index as B
+    ref = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))[0][1]
+    reads_path = str(tmp_path / "c.fa")
+    recs = write_mixed_reads(reads_path, np.random.default_rng(50 + mode), ref, n=200)
+    r = run(["query", "-i", IDX[mode], "-r", reads_path, "--count", "--no-prefetch", "--stdout"])
+    assert r.returncode == 0, r.stderr
+    exp = b""
+    for rid, seq in recs:
+        m, c = oracles[mode].count(seq)
+        exp += rid + b"\t%d/%d\t%d\n" % (m, len(seq), c)
+    assert r.stdout == exp
+    # file output + prefetch-mode order: same multiset of lines
+    r = run(["query", "-i", IDX[mode], "-r", reads_path, "--count", "-o", str(tmp_path / "cc")])
+    assert r.returncode == 0
+    got = open(str(tmp_path / "cc") + ".count.matches", "rb").read()
+    assert sorted(got.splitlines()) == sorted(exp.splitlines())
+
+
+def classify_py(pml, thr, bin_width=150):
+    n, start, above, below, s, bins = len(pml), 0, 0, 0, 0, 0
+    while start < n:
+        end = start + bin_width if start + bin_width < n else n
+        if n - end < bin_width:
+            end = n
+        mx = int(max(pml[start:end]))
+        above += mx >= thr
+        below += mx < thr
+        s += mx
+        bins += 1
+        start = end
+    found = above / (above + below + 0.0) > 0.5
+    return found, s / bins, above, below
+
+
+def test_classify_report_and_filter(movi_bin, oracles, tmp_path):
+    from oracle import build_index as B
+    ref = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))[0][1]
+    idx = str(tmp_path / "idx")
+    shutil.copytree(IDX[6], idx)
+    # movi.pml.nulldb: u64 num | f64 mean | u64 percentile | u64 stats[num]  (emperical_null_database.cpp:95-126)
+    with open(os.path.join(idx, "movi.pml.nulldb"), "wb") as f:
+        f.write(struct.pack("<QdQ", 3, 4.5, 6) + struct.pack("<3Q", 4, 5, 6))
+    thr = max(6, 3) + 1
+    rng = np.random.default_rng(77)
+    reads_path = str(tmp_path / "cl.fa")
+    recs = []
+    with open(reads_path, "wb") as f:
+        for i in range(60):
+            L = int(rng.integers(100, 1500))
+            if i % 2:
+                s = int(rng.integers(0, len(ref) - L)); seq = ref[s:s + L]
+            else:
+                seq = bytes(rng.choice(list(b"ACGT"), size=L).astype(np.uint8))
+            f.write(b">c%d\n" % i + seq + b"\n")
+            recs.append((b"c%d" % i, seq))
+    r = run(["query", "-i", idx, "-r", reads_path, "--classify", "--stdout", "-n"])
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.decode().split("\n")
+    assert lines[0] == "%-30s%-15s%-19s%-2d%-5s%-12s%-12s" % ("read id:", "status:", "avg max-value (thr=", thr, "):",
+                                                              "above thr:", "below thr:")
+    found_ids = []
+    for (rid, seq), line in zip(recs, lines[1:]):
+        found, avg, above, below = classify_py(oracles[6].pml(seq), thr)
+        exp = "%-30s%-15s%-26s%-12d%-12d" % (rid.decode(), "FOUND" if found else "NOT_PRESENT", "%.3g" % avg, above, below)
+        assert line == exp
+        if found:
+            found_ids.append(rid)
+    assert 0 < len(found_ids) < len(recs)
+    # report file + bpf when not --stdout
+    r = run(["query", "-i", idx, "-r", reads_path, "--classify", "-n"])
+    assert r.returncode == 0
+    rep = open(reads_path + ".regular-thresholds.pml.report").read()
+    assert rep == r"".join(l + "\n" for l in lines[:-1])
+    assert os.path.exists(reads_path + ".regular-thresholds.pml.bpf")
+    # --filter echoes FOUND reads, -v the others (src/read_processor.cpp:569-576, utils.cpp:291-294)
+    r = run(["query", "-i", idx, "-r", reads_path, "--classify", "--filter", "-n"])
+    assert r.stdout == b"".join(b">" + rid + b"\n" + seq + b"\n" for rid, seq in recs if rid in found_ids)
+    r = run(["query", "-i", idx, "-r", reads_path, "--classify", "--filter", "-v", "-n"])
+    assert r.stdout == b"".join(b">" + rid + b"\n" + seq + b"\n" for rid, seq in recs if rid not in found_ids)
+
+
+def test_reverse_illegal_chars_stdin_and_errors(movi_bin, oracles, tmp_path):
+    reads = read_fastx(os.path.join(GOLDEN, "sample.fastq"))
+    r = run(["query", "-i", IDX[6], "-r", os.path.join(GOLDEN, "sample.fastq"), "--reverse", "-n", "--stdout"])
+    assert r.stdout == b"".join(b">" + i + b"\n" + stdout_line(oracles[6].pml(s[::-1])).encode() + b"\n" for i, s in reads)
+    p = tmp_path / "n.fa"
+    p.write_bytes(b">x\nACGTNNACGTacgtACGT\n")
+    r = run(["query", "-i", IDX[6], "-r", str(p), "--ignore-illegal-chars", "1", "-n", "--stdout"])
+    assert r.stdout == b">x\n" + stdout_line(oracles[6].pml(b"ACGTAAACGTAAAAACGT")).encode() + b"\n"
+    data = open(os.path.join(GOLDEN, "sample.fasta"), "rb").read()
+    r = run(["query", "-i", IDX[8], "-r", "-", "-n", "--stdout"], input=data)
+    assert r.returncode == 0
+    assert r.stdout == b"".join(b">" + i + b"\n" + stdout_line(oracles[8].pml(s)).encode() + b"\n" for i, s in reads)
+    r = run(["query", "-i", str(tmp_path / "nope"), "-r", str(p)])
+    assert r.returncode == 1 and b"Failed to open the index file" in r.stderr
+    r = run(["query", "-i", IDX[6], "-r", str(tmp_path / "nope.fa")])
+    assert r.returncode == 1 and b"does not exist" in r.stderr
+    # --no-output: nothing is written, exit code 0
+    q = tmp_path / "q.fa"
+    q.write_bytes(b">x\nACGT\n")
+    r = run(["query", "-i", IDX[6], "-r", str(q), "--no-output"])
+    assert r.returncode == 0 and r.stdout == b"" and not os.path.exists(str(q) + ".regular-thresholds.pml.bpf")
