@@ -191,9 +191,9 @@ def test_reverse_illegal_chars_stdin_and_errors(movi_bin, oracles, tmp_path):
     r = run(["query", "-i", IDX[6], "-r", os.path.join(GOLDEN, "sample.fastq"), "--reverse", "-n", "--stdout"])
     assert r.stdout == b"".join(b">" + i + b"\n" + stdout_line(oracles[6].pml(s[::-1])).encode() + b"\n" for i, s in reads)
     p = tmp_path / "n.fa"
-    p.write_bytes(b">x\nACGTNNACGTacgtACGT\n")
+    p.write_bytes(b">xy\nACGTNNACGTacgtACGT\n")
     r = run(["query", "-i", IDX[6], "-r", str(p), "--ignore-illegal-chars", "1", "-n", "--stdout"])
-    assert r.stdout == b">x\n" + stdout_line(oracles[6].pml(b"ACGTAAACGTAAAAACGT")).encode() + b"\n"
+    assert r.stdout == b">xy\n" + stdout_line(oracles[6].pml(b"ACGTAAACGTAAAAACGT")).encode() + b"\n"
     data = open(os.path.join(GOLDEN, "sample.fasta"), "rb").read()
     r = run(["query", "-i", IDX[8], "-r", "-", "-n", "--stdout"], input=data)
     assert r.returncode == 0
@@ -204,6 +204,6 @@ def test_reverse_illegal_chars_stdin_and_errors(movi_bin, oracles, tmp_path):
     assert r.returncode == 1 and b"does not exist" in r.stderr
     # --no-output: nothing is written, exit code 0
     q = tmp_path / "q.fa"
-    q.write_bytes(b">x\nACGT\n")
+    q.write_bytes(b">xy\nACGT\n")
     r = run(["query", "-i", IDX[6], "-r", str(q), "--no-output"])
     assert r.returncode == 0 and r.stdout == b"" and not os.path.exists(str(q) + ".regular-thresholds.pml.bpf")
