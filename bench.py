@@ -90,33 +90,25 @@ def main():
     six = synth.synth_index(wl["rows"], mode=mode, seed=SEED)
     t_index_gen = time.time() - t0
     t0 = time.time()
+    meta, d_rows = None, None
     if rank == 0:
         img = six.image()
         _, cdesc, roff, rbytes = movi_amd.parse_index_image(img)
-        rows_host = torch.from_numpy(img[roff: roff + rbytes])
         id_blocks = (np.ctypeslib.as_array(C.cast(cdesc.id_blocks, C.POINTER(C.c_uint32)),
                                            shape=(int(cdesc.n_blocks) * 4,)).copy() if mode == 8 else None)
-        meta = [bytes(cdesc), id_blocks, rbytes]
-    else:
-        meta = [None, None, None]
-    if world > 1:
-        dist.broadcast_object_list(meta, src=0)
-    cdesc = IndexDescC.from_buffer_copy(meta[0])
-    id_blocks = meta[1]
-    if id_blocks is not None:
-        cdesc.id_blocks = id_blocks.ctypes.data
-    else:
-        cdesc.id_blocks = None
-    d_rows = torch.empty(meta[2] + 16, dtype=torch.uint8, device=dev)
-    if rank == 0:
-        d_rows[: meta[2]].copy_(rows_host)
+        meta = {"cdesc": bytes(cdesc), "id_blocks": id_blocks}
+        d_rows = torch.from_numpy(img[roff: roff + rbytes]).to(dev)     # rank 0 uploads the table once
     t_bcast = 0.0
     if world > 1:
+        from movi_amd import dist as md
         torch.cuda.synchronize()
         tb = time.time()
-        dist.broadcast(d_rows, src=0)                # the one collective of this path
+        meta, d_rows = md.broadcast_index(meta, d_rows, src=0, device=dev)   # the one collective of this path
         torch.cuda.synchronize()
         t_bcast = time.time() - tb
+    cdesc = IndexDescC.from_buffer_copy(meta["cdesc"])
+    id_blocks = meta["id_blocks"]
+    cdesc.id_blocks = id_blocks.ctypes.data if id_blocks is not None else None
     index = movi_amd.MoveIndex.from_device_rows(cdesc, d_rows.data_ptr(), device=local_rank, keepalive=d_rows)
     if args.variant >= 0:
         index.set_option("pml_variant", args.variant)
@@ -226,14 +218,19 @@ def main():
         sb = bases[: int(offs[sample])]
         so = offs[: sample + 1]
         cpu.pml_batch(sb[: int(so[min(sample, 64)])], so[: min(sample, 64) + 1], threads=cores)   # warm
-        t0 = time.perf_counter()
-        exp, _, _ = cpu.pml_batch(sb, so, threads=cores, strands=16)
-        dt = time.perf_counter() - t0
+        passes, dt, exp = 0, 0.0, None
+        while dt < 10.0 and passes < 64:                # ~10 s of CPU work, bounded
+            t0 = time.perf_counter()
+            exp, _, _ = cpu.pml_batch(sb, so, threads=cores, strands=16)
+            dt += time.perf_counter() - t0
+            passes += 1
         got = d_out[: sb.size].cpu().numpy().view(np.uint16)
-        result["cpu_baseline"] = {"value": sb.size / dt / 1e9, "unit": "Gbases/s", "cores": cores, "kind": "port",
-                                  "sample": "first %d reads (%d bases) of the same batch, oracle/movi_oracle.c "
-                                            "oracle_pml_batch, %d OpenMP threads x 16 strands, %.2f s"
-                                            % (sample, sb.size, cores, dt)}
+        result["cpu_baseline"] = {"value": sb.size * passes / dt / 1e9, "unit": "Gbases/s", "cores": cores,
+                                  "kind": "port",
+                                  "sample": "first %d reads (%d bases) of the same batch x %d passes, "
+                                            "oracle/movi_oracle.c oracle_pml_batch (scalar port of the reference's "
+                                            "strand scheduler: %d OpenMP threads x 16 strands + prefetch), %.2f s"
+                                            % (sample, sb.size, passes, cores, dt)}
         result["parity_sample_ok"] = bool((got == exp).all())
         if not result["parity_sample_ok"]:
             print("PARITY FAILURE on the cpu_baseline sample", file=sys.stderr)
