@@ -14,7 +14,6 @@
  *   MoveStructure::query_pml        src/move_structure_query.cpp:234-474  movi_pml_host / movi_pml_device
  *   MoveStructure::query_backward_search  src/move_structure_search.cpp:340-352   movi_count_host / movi_count_device
  *   ReadProcessor::backward_search + compute_match_count  src/read_processor.cpp:610-620,1096-1175   movi_count_host / movi_count_device
- *   Classifier::classify (per-read bin maxima)  src/classifier.cpp:99-143   movi_pml_device (bin_max output)
  *
  * Conventions: every entry point returns an int status (MOVI_OK == 0) and never
  * throws; movi_last_error() gives the message for the calling thread.  One
@@ -110,10 +109,9 @@ int movi_index_device_rows(const movi_index_t *ix, const void **d_rows, size_t *
  * out_pml[offsets[i] + k] = PML of base (len_i - 1 - k) of read i, i.e. emission
  * order (last base first), the order MoveQuery::matching_lens / the BPF record
  * hold (include/move_query.hpp:26-38, src/utils.cpp:202-246), u16-clamped.
- * d_read_err (optional, n_reads bytes): 1 where the walk broke an invariant.
- * d_bin_max (optional): per-read maxima over bins of `bin_width` PMLs in emission
- * order, the reduction Classifier::classify needs (src/classifier.cpp:105-118);
- * d_bin_offsets has n_reads+1 entries into it.  Pass NULL/0 to skip.
+ * d_read_err (optional, n_reads bytes): 0, or the code of the reference throw the walk
+ * ran into (1 LF destination >= r, 2 >= 65535 fast-forwards, 3/4 no run below/above);
+ * such a read reports all-zero PMLs.
  * Asynchronous on `stream` (a hipStream_t, NULL = the null stream). */
 int movi_pml_device(movi_index_t *ix, const uint8_t *d_bases, const uint64_t *d_offsets,
                     uint64_t n_reads, uint64_t n_bases, uint16_t *d_out_pml, uint8_t *d_read_err,
