@@ -53,7 +53,6 @@ def main():
     ap.add_argument("--variant", type=int, default=-1, help="pml kernel variant (A/B measurement)")
     ap.add_argument("--block-threads", type=int, default=0)
     ap.add_argument("--waves-per-cu", type=int, default=-1)
-    ap.add_argument("--extra-trips", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-reads", type=int, default=0)
     args = ap.parse_args()
@@ -116,8 +115,6 @@ def main():
         index.set_option("block_threads", args.block_threads)
     if args.waves_per_cu >= 0:
         index.set_option("waves_per_cu", args.waves_per_cu)
-    if args.extra_trips >= 0:
-        index.set_option("extra_trips", args.extra_trips)
     t_index_upload = time.time() - t0
 
     # ---- reads: each rank draws its own shard (seed + rank)
@@ -199,7 +196,7 @@ def main():
                    "fast_forwards_per_base": round(f_bar, 4), "scans_per_base": round(s_bar, 4),
                    "reposition_frac": round(st.repositions / max(n_bases, 1), 4),
                    "algorithmic_bytes_per_base": round(bytes_per_base, 3),
-                   "pml_variant": args.variant, "waves_per_cu": args.waves_per_cu, "block_threads": args.block_threads, "extra_trips": args.extra_trips, "index_gen_s": round(t_index_gen, 2),
+                   "pml_variant": args.variant, "waves_per_cu": args.waves_per_cu, "block_threads": args.block_threads, "index_gen_s": round(t_index_gen, 2),
                    "index_upload_s": round(t_index_upload, 2), "index_broadcast_s": round(t_bcast, 3),
                    "reads_gen_s": round(t_reads_gen, 2)},
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",

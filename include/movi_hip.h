@@ -144,7 +144,7 @@ int movi_count_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_
 
 /* Kernel variant / launch knobs, for A/B measurement (bench.py --variant).
  * Unknown keys return MOVI_ERR_ARG.  Keys: "pml_variant", "block_threads",
- * "waves_per_cu" (0 = uncapped), "extra_trips". */
+ * "waves_per_cu" (0 = uncapped). */
 int movi_set_option(movi_index_t *ix, const char *key, int64_t value);
 
 #ifdef __cplusplus

@@ -298,18 +298,13 @@ int movi_index_device_rows(const movi_index_t *ix, const void **d_rows, size_t *
 int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
     if (!ix || !key) return fail(MOVI_ERR_ARG, "NULL argument");
     if (!strcmp(key, "pml_variant")) {
-        if (value < -1 || value > 4) return fail(MOVI_ERR_ARG, "pml_variant must be -1 (auto) or 0..4");
+        if (value < -1 || value > 6) return fail(MOVI_ERR_ARG, "pml_variant must be -1 (auto) or 0..6");
         ix->cfg.pml_variant = (int)value;
         return MOVI_OK;
     }
     if (!strcmp(key, "block_threads")) {
         if (value < 64 || value > 1024 || (value & 63)) return fail(MOVI_ERR_ARG, "block_threads must be a multiple of 64 in [64,1024]");
         ix->cfg.block_threads = (int)value;
-        return MOVI_OK;
-    }
-    if (!strcmp(key, "extra_trips")) {
-        if (value < 0 || value > 64) return fail(MOVI_ERR_ARG, "extra_trips must be in [0,64]");
-        ix->cfg.extra_trips = (int)value;
         return MOVI_OK;
     }
     if (!strcmp(key, "waves_per_cu")) {

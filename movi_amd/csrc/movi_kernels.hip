@@ -29,13 +29,9 @@ namespace movi {
 //     x = id16 | n16 << 16    y = offset16
 //     n16:  [9:0] n, [15:10] id[21:16]
 //     off16:[9:0] offset, [12:10] c, [13] thr0, [14] thr1, [15] thr2
-template <int MODE, bool NT = false>
+template <int MODE>
 __device__ __forceinline__ uint2 load_row(const uint8_t *rows, uint64_t i) {
     if (MODE == 6) {
-        if (NT) {   // streaming hint for the far gather: the line is not worth keeping in L1
-            const unsigned long long v = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long *>(rows + i * 8));
-            return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
-        }
         return *reinterpret_cast<const uint2 *>(rows + i * 8);
     } else {
         const uint16_t *p = reinterpret_cast<const uint16_t *>(rows + i * 6);
@@ -101,7 +97,7 @@ __device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
 
 // LF_move + fast_forward.  On entry `row` is rows[idx]; on exit it is the row of
 // the new idx.  `live` lanes take the step; returns a kErr* code (0 = ok) per lane.
-template <int MODE, bool NT = false>
+template <int MODE, int NB = 1>
 __device__ __forceinline__ uint32_t lf_step(const DevIndex &ix, bool live, uint64_t &idx, uint32_t &off,
                                             uint2 &row, uint32_t &ff_total) {
     uint32_t errc = kErrNone;
@@ -115,19 +111,33 @@ __device__ __forceinline__ uint32_t lf_step(const DevIndex &ix, bool live, uint6
             j = idx;
         } else {
             off += row_off<MODE>(row);
-            row = load_row<MODE, NT>(ix.rows, j);       // THE dependent random gather
+            row = load_row<MODE>(ix.rows, j);           // THE dependent random gather
             n = row_n<MODE>(row);
             going = (j < ix.r - 1 && off >= n) ? 1u : 0u;
         }
     }
-    while (wave_any(going != 0u)) {                     // fast_forward :524-545
+    // fast_forward :524-545.  Each trip fetches the next NB rows at once (they sit in the line
+    // the gather just brought in, so the loads are L2 hits issued back to back) and consumes
+    // them from registers: ceil(ff / NB) dependent round trips instead of ff.
+    while (wave_any(going != 0u)) {
         if (going) {
-            off -= n;
-            j += 1;
-            ff += 1;
-            row = load_row<MODE>(ix.rows, j);
-            n = row_n<MODE>(row);
-            going = (j < ix.r - 1 && off >= n && ff < 65535u) ? 1u : 0u;
+            uint2 w[NB];
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                const uint64_t jj = j + 1 + q;
+                w[q] = load_row<MODE>(ix.rows, jj < ix.r ? jj : ix.r - 1);
+            }
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                if (going) {
+                    off -= n;
+                    j += 1;
+                    ff += 1;
+                    row = w[q];
+                    n = row_n<MODE>(row);
+                    going = (j < ix.r - 1 && off >= n && ff < 65535u) ? 1u : 0u;
+                }
+            }
         }
     }
     if (ff >= 65535u) errc = kErrFastForward;           // move_structure.cpp:72-75
@@ -142,7 +152,8 @@ __device__ __forceinline__ uint32_t lf_step(const DevIndex &ix, bool live, uint6
 //   VARIANT 1: packed I/O -- each lane fetches its read 8 bases at a time (one 8-byte load
 //              per 8 steps) and emits PMLs 8 at a time (one 16-byte store per 8 steps), so the
 //              per-step traffic to L2 is the row gather alone.
-template <int MODE, int VARIANT>
+//   NB: neighbour rows fetched per fast-forward / scan trip.
+template <int MODE, int VARIANT, int NB = 1>
 __global__ __launch_bounds__(256) void pml_kernel(DevIndex ix, const uint8_t *__restrict__ bases,
                                                      const uint64_t *__restrict__ offs, uint64_t n_reads,
                                                      uint16_t *__restrict__ out, uint8_t *__restrict__ err,
@@ -177,7 +188,7 @@ __global__ __launch_bounds__(256) void pml_kernel(DevIndex ix, const uint8_t *__
             }
         }
         if (k != 0) {
-            const uint32_t e = lf_step<MODE, (VARIANT >= 4)>(ix, live, idx, off, row, ff_total);
+            const uint32_t e = lf_step<MODE, NB>(ix, live, idx, off, row, ff_total);
             if (e) { failed = e; live = false; }
         }
         uint32_t a = 0xFFu;
@@ -213,20 +224,33 @@ __global__ __launch_bounds__(256) void pml_kernel(DevIndex ix, const uint8_t *__
                 if (!down && idx == 0) { failed = kErrNoRunAbove; dir = 0; live = false; }
             }
         }
-        // reposition_down :211-232 / reposition_up :188-209 as one uniform loop
+        // reposition_down :211-232 / reposition_up :188-209 as one uniform loop, NB rows per trip
         uint32_t scanning = dir;
         while (wave_any(scanning != 0u)) {
             if (scanning) {
-                scan_total += 1;
-                idx = (scanning == 1u) ? idx + 1 : idx - 1;
-                row = load_row<MODE>(ix.rows, idx);
-                const uint32_t c = row_c<MODE>(row);
-                if (c == a) {
-                    scanning = 0;
-                } else if (scanning == 1u ? (idx >= ix.r - 1) : (idx == 0)) {
-                    failed = scanning == 1u ? kErrNoRunBelow : kErrNoRunAbove;   // :582-598
-                    scanning = 0;
-                    live = false;
+                uint2 w[NB];
+#pragma unroll
+                for (int q = 0; q < NB; ++q) {
+                    uint64_t jj = (scanning == 1u) ? idx + 1 + q : idx - 1 - q;
+                    if (scanning == 1u) { if (jj >= ix.r) jj = ix.r - 1; }
+                    else if (jj > idx) jj = 0;                      // wrapped below row 0
+                    w[q] = load_row<MODE>(ix.rows, jj);
+                }
+#pragma unroll
+                for (int q = 0; q < NB; ++q) {
+                    if (scanning) {
+                        scan_total += 1;
+                        idx = (scanning == 1u) ? idx + 1 : idx - 1;
+                        row = w[q];
+                        const uint32_t c = row_c<MODE>(row);
+                        if (c == a) {
+                            scanning = 0;
+                        } else if (scanning == 1u ? (idx >= ix.r - 1) : (idx == 0)) {
+                            failed = scanning == 1u ? kErrNoRunBelow : kErrNoRunAbove;   // :582-598
+                            scanning = 0;
+                            live = false;
+                        }
+                    }
                 }
             }
         }
@@ -279,11 +303,16 @@ __global__ __launch_bounds__(256) void pml_kernel(DevIndex ix, const uint8_t *__
 // I/O is packed as in variant 1; the next 8-base chunk is requested at the end of the
 // iteration that consumes the last base of the current one, so its latency hides behind
 // the next row load (loads return in order).
-template <int MODE>
+//
+// NB > 1: every iteration fetches a window of NB consecutive rows starting at `need` (downwards
+// for an upward scan) in one go and the automaton consumes them from registers for as long as
+// the row it wants next is the next one of the window.  This kernel runs when few walks are in
+// flight (memory latency, not bandwidth, is the limit), so the speculative neighbours are free.
+template <int MODE, int NB>
 __global__ __launch_bounds__(256) void pml_kernel_sm(DevIndex ix, const uint8_t *__restrict__ bases,
                                                      const uint64_t *__restrict__ offs, uint64_t n_reads,
                                                      uint16_t *__restrict__ out, uint8_t *__restrict__ err,
-                                                     DevStats *stats, int extra_trips) {
+                                                     DevStats *stats) {
     enum : uint32_t { kInit = 0, kFF = 1, kDown = 2, kUp = 3, kDone = 4 };
     __shared__ uint8_t s_code[256];
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = ix.code_of[i];
@@ -320,14 +349,23 @@ __global__ __launch_bounds__(256) void pml_kernel_sm(DevIndex ix, const uint8_t 
     if (st != kDone) rb = load_chunk(0);
 
     while (wave_any(st != kDone)) {
-      // Trip 0: every live lane loads the row it needs (for most lanes a far gather).  Trips
-      // 1..extra_trips: only lanes whose NEXT row is an adjacent one (fast-forward / scan in
-      // progress) load again at once -- that neighbour is in the line that just arrived, so the
-      // trip is an L2/L1 hit -- while lanes that finished their base wait for the next trip 0.
+      const bool up = st == kUp;
+      const uint64_t need0 = need;
+      uint2 w[NB];
+      if (st != kDone) {
+#pragma unroll
+          for (int q = 0; q < NB; ++q) {
+              uint64_t jj = up ? need0 - q : need0 + q;
+              if (up) { if (jj > need0) jj = 0; }                       // wrapped below row 0
+              else if (jj >= ix.r) jj = ix.r - 1;
+              w[q] = load_row<MODE>(ix.rows, jj);
+          }
+      }
       bool want = st != kDone;
-      for (int trip = 0; trip <= extra_trips && wave_any(want); ++trip) {
+#pragma unroll
+      for (int q = 0; q < NB; ++q) {
        if (want) {
-        uint2 row = load_row<MODE>(ix.rows, need);
+        const uint2 row = w[q];
         bool resolved = false;        // `row` (= rows[need]) is the row base k is compared with
         bool emit = false;            // base k is finished; `row` at idx = need is its final row
         if (st == kInit) {
@@ -419,7 +457,9 @@ __global__ __launch_bounds__(256) void pml_kernel_sm(DevIndex ix, const uint8_t 
             }
         }
        }
-       want = st == kDown || st == kUp || (st == kFF && ff_run > 0u);
+       // go on only if the row wanted next is exactly the next row of the window
+       const uint64_t nxt = up ? need0 - (uint64_t)(q + 1) : need0 + (uint64_t)(q + 1);
+       want = st != kDone && need == nxt && (up ? need0 >= (uint64_t)(q + 1) : nxt < ix.r);
       }
     }
     if (failed) {
@@ -454,32 +494,33 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
         if (bpc < 1) bpc = 1;
         if (bpc < 32) dyn_lds = ((163840u / (unsigned)bpc) & ~1023u) - 1024u;
     }
-#define MOVI_LAUNCH_PML(M, V)                                                                                  \
+#define MOVI_LAUNCH_PML(M, V, N)                                                                               \
     do {                                                                                                       \
         if (dyn_lds > 65536) {                                                                                 \
-            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&pml_kernel<M, V>),             \
+            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&pml_kernel<M, V, N>),          \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds);     \
             if (ea != hipSuccess) return ea;                                                                   \
         }                                                                                                      \
-        hipLaunchKernelGGL((pml_kernel<M, V>), grid, block, dyn_lds, stream, ix, d_bases, d_offsets, n_reads,  \
-                           d_out, d_err, d_stats);                                                             \
+        hipLaunchKernelGGL((pml_kernel<M, V, N>), grid, block, dyn_lds, stream, ix, d_bases, d_offsets,        \
+                           n_reads, d_out, d_err, d_stats);                                                    \
     } while (0)
-#define MOVI_LAUNCH_SM(M)                                                                                   \
-    hipLaunchKernelGGL((pml_kernel_sm<M>), grid, block, dyn_lds, stream, ix, d_bases, d_offsets, n_reads, d_out, \
-                       d_err, d_stats, extra)
+#define MOVI_LAUNCH_SM(M, N)                                                                                \
+    hipLaunchKernelGGL((pml_kernel_sm<M, N>), grid, block, dyn_lds, stream, ix, d_bases, d_offsets, n_reads, \
+                       d_out, d_err, d_stats)
     // Auto selection (measured on MI355X, profiles/): with plenty of reads (> ~10 waves per CU)
     // the base-synchronous packed kernel (1) wins because its neighbour loads follow the gather
     // at once and hit L2; with few reads in flight (long-read batches, small shards) the lane
     // state machine (2) wins because it needs ~2.3 instead of ~11 dependent trips per base.
     int v = cfg.pml_variant;
     if (v < 0) v = (n_reads <= (uint64_t)cfg.num_cus * 64u * 10u) ? 2 : 1;
-    const int extra = v == 2 ? 0 : cfg.extra_trips;       // variant 2 = pure state machine; 3 = with neighbour trips
     if (mode == 6) {
-        if (v == 0) MOVI_LAUNCH_PML(6, 0); else if (v == 1) MOVI_LAUNCH_PML(6, 1);
-        else if (v == 4) MOVI_LAUNCH_PML(6, 4); else MOVI_LAUNCH_SM(6);
+        if (v == 0) MOVI_LAUNCH_PML(6, 0, 1); else if (v == 1) MOVI_LAUNCH_PML(6, 1, 1);
+        else if (v == 4) MOVI_LAUNCH_PML(6, 1, 2); else if (v == 5) MOVI_LAUNCH_PML(6, 1, 4);
+        else if (v == 2) MOVI_LAUNCH_SM(6, 1); else if (v == 3) MOVI_LAUNCH_SM(6, 2); else MOVI_LAUNCH_SM(6, 4);
     } else {
-        if (v == 0) MOVI_LAUNCH_PML(8, 0); else if (v == 1) MOVI_LAUNCH_PML(8, 1);
-        else if (v == 4) MOVI_LAUNCH_PML(8, 4); else MOVI_LAUNCH_SM(8);
+        if (v == 0) MOVI_LAUNCH_PML(8, 0, 1); else if (v == 1) MOVI_LAUNCH_PML(8, 1, 1);
+        else if (v == 4) MOVI_LAUNCH_PML(8, 1, 2); else if (v == 5) MOVI_LAUNCH_PML(8, 1, 4);
+        else if (v == 2) MOVI_LAUNCH_SM(8, 1); else if (v == 3) MOVI_LAUNCH_SM(8, 2); else MOVI_LAUNCH_SM(8, 4);
     }
 #undef MOVI_LAUNCH_PML
 #undef MOVI_LAUNCH_SM

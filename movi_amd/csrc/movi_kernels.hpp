@@ -32,9 +32,10 @@ struct DevStats {
 
 struct LaunchCfg {
     int block_threads = 256;
-    int pml_variant = -1;  // -1 auto; 0/1/4: pml_kernel<MODE, VARIANT>; 2: lane state machine; 3: + neighbour trips
+    // -1 auto; base-synchronous pml_kernel: 0 (plain I/O), 1 / 4 / 5 (packed I/O, 1 / 2 / 4 neighbour rows per trip);
+    // lane state machine pml_kernel_sm: 2 / 3 / 6 (1 / 2 / 4-row window per iteration)
+    int pml_variant = -1;
     int num_cus = 256;
-    int extra_trips = 2;   // variant 3: immediate adjacent-row trips per iteration
     int waves_per_cu = 0;  // 0 = no cap; else cap resident waves per CU by padding the block's LDS allocation
 };
 
