@@ -53,6 +53,8 @@ def main():
     ap.add_argument("--variant", type=int, default=-1, help="pml kernel variant (A/B measurement)")
     ap.add_argument("--block-threads", type=int, default=0)
     ap.add_argument("--waves-per-cu", type=int, default=-1)
+    ap.add_argument("--ragged", type=int, default=0, help="1: log-normal read lengths (mean = read_len); "
+                    "2: same, lanes handed out longest-first (d_read_order)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-reads", type=int, default=0)
     args = ap.parse_args()
@@ -119,8 +121,12 @@ def main():
 
     # ---- reads: each rank draws its own shard (seed + rank)
     t0 = time.time()
+    lens = None
+    if args.ragged:
+        g = np.random.default_rng(SEED + 77 + rank)
+        lens = np.clip(g.lognormal(np.log(wl["read_len"]) - 0.08, 0.4, size=wl["reads"]), 20, 5 * wl["read_len"]).astype(np.uint64)
     bases, offs = synth.synth_reads(six, wl["reads"], wl["read_len"], seed=SEED + 1 + rank,
-                                    sub_rate=wl["sub"], n_rate=0.001)
+                                    sub_rate=wl["sub"], n_rate=0.001, lens=lens)
     t_reads_gen = time.time() - t0
     n_reads, n_bases = wl["reads"], int(bases.size)
     d_bases = torch.from_numpy(bases).to(dev)
@@ -128,10 +134,14 @@ def main():
     d_out = torch.empty(n_bases, dtype=torch.int16, device=dev)
     d_err = torch.zeros(n_reads, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream()
+    d_order = 0                                      # uniform read length: no length sort needed
+    if args.ragged == 2:
+        order_t = torch.from_numpy(np.argsort(-(lens.astype(np.int64)), kind="stable").astype(np.uint32).view(np.int32)).to(dev)
+        d_order = order_t.data_ptr()
 
     def step():
         index.pml_device(d_bases.data_ptr(), d_offs.data_ptr(), n_reads, n_bases, d_out.data_ptr(),
-                         d_err.data_ptr(), stream.cuda_stream)
+                         d_err.data_ptr(), stream.cuda_stream, d_order)
 
     for _ in range(args.warmup):
         step()
@@ -196,7 +206,7 @@ def main():
                    "fast_forwards_per_base": round(f_bar, 4), "scans_per_base": round(s_bar, 4),
                    "reposition_frac": round(st.repositions / max(n_bases, 1), 4),
                    "algorithmic_bytes_per_base": round(bytes_per_base, 3),
-                   "pml_variant": args.variant, "waves_per_cu": args.waves_per_cu, "block_threads": args.block_threads, "index_gen_s": round(t_index_gen, 2),
+                   "pml_variant": args.variant, "ragged": args.ragged, "waves_per_cu": args.waves_per_cu, "block_threads": args.block_threads, "index_gen_s": round(t_index_gen, 2),
                    "index_upload_s": round(t_index_upload, 2), "index_broadcast_s": round(t_bcast, 3),
                    "reads_gen_s": round(t_reads_gen, 2)},
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",

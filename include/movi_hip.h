@@ -112,10 +112,14 @@ int movi_index_device_rows(const movi_index_t *ix, const void **d_rows, size_t *
  * d_read_err (optional, n_reads bytes): 0, or the code of the reference throw the walk
  * ran into (1 LF destination >= r, 2 >= 65535 fast-forwards, 3/4 no run below/above);
  * such a read reports all-zero PMLs.
+ * d_read_order (optional, n_reads u32): a permutation of the reads; lane slot t works on read
+ * d_read_order[t].  Results stay indexed by read.  A hook for callers with their own
+ * scheduling; sorting by length measured no gain on MI355X, so the host entry
+ * points pass NULL.  At most 2^32 reads per call.
  * Asynchronous on `stream` (a hipStream_t, NULL = the null stream). */
 int movi_pml_device(movi_index_t *ix, const uint8_t *d_bases, const uint64_t *d_offsets,
                     uint64_t n_reads, uint64_t n_bases, uint16_t *d_out_pml, uint8_t *d_read_err,
-                    void *stream);
+                    const uint32_t *d_read_order, void *stream);
 
 /* Same, host buffers in and out; uploads, runs, downloads, synchronises.
  * stats may be NULL. */
@@ -134,7 +138,7 @@ int movi_last_stats(movi_index_t *ix, void *stream, movi_query_stats_t *stats);
  * semantics, src/move_structure_search.cpp:340-352). */
 int movi_count_device(movi_index_t *ix, const uint8_t *d_bases, const uint64_t *d_offsets,
                       uint64_t n_reads, uint64_t n_bases, uint64_t *d_matched, uint64_t *d_count,
-                      uint8_t *d_read_err, void *stream);
+                      uint8_t *d_read_err, const uint32_t *d_read_order, void *stream);
 
 int movi_count_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_offsets,
                     uint64_t n_reads, uint64_t *h_matched, uint64_t *h_count, uint8_t *h_read_err,

@@ -56,12 +56,12 @@ SYMBOLS = {
     "movi_index_get_desc": (C.c_int, [C.c_void_p, C.POINTER(IndexDescC)]),
     "movi_index_device_rows": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "movi_pml_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p,
-                                  C.c_void_p, C.c_void_p]),
+                                  C.c_void_p, C.c_void_p, C.c_void_p]),
     "movi_pml_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                 C.POINTER(QueryStatsC)]),
     "movi_last_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(QueryStatsC)]),
     "movi_count_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p,
-                                    C.c_void_p, C.c_void_p, C.c_void_p]),
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "movi_count_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.POINTER(QueryStatsC)]),
     "movi_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),

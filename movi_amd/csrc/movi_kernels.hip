@@ -157,7 +157,7 @@ template <int MODE, int VARIANT, int NB = 1>
 __global__ __launch_bounds__(256) void pml_kernel(DevIndex ix, const uint8_t *__restrict__ bases,
                                                      const uint64_t *__restrict__ offs, uint64_t n_reads,
                                                      uint16_t *__restrict__ out, uint8_t *__restrict__ err,
-                                                     DevStats *stats) {
+                                                     DevStats *stats, const uint32_t *__restrict__ order) {
     __shared__ uint8_t s_code[256];
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = ix.code_of[i];
     __syncthreads();
@@ -165,8 +165,11 @@ __global__ __launch_bounds__(256) void pml_kernel(DevIndex ix, const uint8_t *__
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t ff_total = 0, scan_total = 0, repo_total = 0, failed = 0;
     const bool valid = t < n_reads;
-    const uint64_t beg = valid ? offs[t] : 0;
-    const uint64_t len = valid ? offs[t + 1] - beg : 0;
+    // lane slot t works on read rid: the host may pass reads sorted by length so that the 64
+    // lanes of a wave finish together (ragged batches)
+    const uint64_t rid = (valid && order) ? order[t] : t;
+    const uint64_t beg = valid ? offs[rid] : 0;
+    const uint64_t len = valid ? offs[rid + 1] - beg : 0;
     const uint8_t *R = bases + beg;
     uint16_t *O = out + beg;
     // ReadProcessor::reset_process, src/read_processor.cpp:69-70
@@ -276,7 +279,7 @@ __global__ __launch_bounds__(256) void pml_kernel(DevIndex ix, const uint8_t *__
     if (failed) {
         for (uint64_t k = 0; k < len; ++k) O[k] = 0;
     }
-    if (valid && err) err[t] = (uint8_t)failed;
+    if (valid && err) err[rid] = (uint8_t)failed;
     // one atomic per wave per counter
     const uint32_t ffw = wave_sum(ff_total), scw = wave_sum(scan_total), rpw = wave_sum(repo_total),
                    erw = wave_sum(failed ? 1u : 0u);
@@ -312,7 +315,7 @@ template <int MODE, int NB>
 __global__ __launch_bounds__(256) void pml_kernel_sm(DevIndex ix, const uint8_t *__restrict__ bases,
                                                      const uint64_t *__restrict__ offs, uint64_t n_reads,
                                                      uint16_t *__restrict__ out, uint8_t *__restrict__ err,
-                                                     DevStats *stats) {
+                                                     DevStats *stats, const uint32_t *__restrict__ order) {
     enum : uint32_t { kInit = 0, kFF = 1, kDown = 2, kUp = 3, kDone = 4 };
     __shared__ uint8_t s_code[256];
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = ix.code_of[i];
@@ -321,8 +324,11 @@ __global__ __launch_bounds__(256) void pml_kernel_sm(DevIndex ix, const uint8_t 
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t ff_total = 0, scan_total = 0, repo_total = 0, failed = 0;
     const bool valid = t < n_reads;
-    const uint64_t beg = valid ? offs[t] : 0;
-    const uint64_t len = valid ? offs[t + 1] - beg : 0;
+    // lane slot t works on read rid: the host may pass reads sorted by length so that the 64
+    // lanes of a wave finish together (ragged batches)
+    const uint64_t rid = (valid && order) ? order[t] : t;
+    const uint64_t beg = valid ? offs[rid] : 0;
+    const uint64_t len = valid ? offs[rid + 1] - beg : 0;
     const uint8_t *R = bases + beg;
     uint16_t *O = out + beg;
     const uint64_t packed_end = len & ~7ull;              // PMLs of steps >= this are stored one by one
@@ -465,7 +471,7 @@ __global__ __launch_bounds__(256) void pml_kernel_sm(DevIndex ix, const uint8_t 
     if (failed) {
         for (uint64_t i = 0; i < len; ++i) O[i] = 0;
     }
-    if (valid && err) err[t] = (uint8_t)failed;
+    if (valid && err) err[rid] = (uint8_t)failed;
     const uint32_t ffw = wave_sum(ff_total), scw = wave_sum(scan_total), rpw = wave_sum(repo_total),
                    erw = wave_sum(failed ? 1u : 0u);
     if ((threadIdx.x & 63) == 0 && stats) {
@@ -478,7 +484,7 @@ __global__ __launch_bounds__(256) void pml_kernel_sm(DevIndex ix, const uint8_t 
 
 hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets,
                       uint64_t n_reads, uint16_t *d_out, uint8_t *d_err, DevStats *d_stats,
-                      const LaunchCfg &cfg, hipStream_t stream) {
+                      const uint32_t *d_order, const LaunchCfg &cfg, hipStream_t stream) {
     if (n_reads == 0) return hipSuccess;
     const int bt = cfg.block_threads;
     const uint64_t blocks = (n_reads + bt - 1) / bt;
@@ -502,11 +508,11 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
             if (ea != hipSuccess) return ea;                                                                   \
         }                                                                                                      \
         hipLaunchKernelGGL((pml_kernel<M, V, N>), grid, block, dyn_lds, stream, ix, d_bases, d_offsets,        \
-                           n_reads, d_out, d_err, d_stats);                                                    \
+                           n_reads, d_out, d_err, d_stats, d_order);                                           \
     } while (0)
 #define MOVI_LAUNCH_SM(M, N)                                                                                \
     hipLaunchKernelGGL((pml_kernel_sm<M, N>), grid, block, dyn_lds, stream, ix, d_bases, d_offsets, n_reads, \
-                       d_out, d_err, d_stats)
+                       d_out, d_err, d_stats, d_order)
     // Auto selection (measured on MI355X, profiles/): with plenty of reads (> ~10 waves per CU)
     // the base-synchronous packed kernel (1) wins because its neighbour loads follow the gather
     // at once and hit L2; with few reads in flight (long-read batches, small shards) the lane
@@ -543,7 +549,7 @@ __global__ __launch_bounds__(256) void count_kernel_v0(DevIndex ix, const uint8_
                                                        const uint64_t *__restrict__ offs, uint64_t n_reads,
                                                        uint64_t *__restrict__ matched,
                                                        uint64_t *__restrict__ count, uint8_t *__restrict__ err,
-                                                       DevStats *stats) {
+                                                       DevStats *stats, const uint32_t *__restrict__ order) {
     __shared__ uint8_t s_code[256];
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = ix.code_of[i];
     __syncthreads();
@@ -551,8 +557,9 @@ __global__ __launch_bounds__(256) void count_kernel_v0(DevIndex ix, const uint8_
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t ff_total = 0, scan_total = 0, failed = 0;
     const bool valid = t < n_reads;
-    const uint64_t beg = valid ? offs[t] : 0;
-    const int64_t len = valid ? (int64_t)(offs[t + 1] - beg) : 0;
+    const uint64_t rid = (valid && order) ? order[t] : t;
+    const uint64_t beg = valid ? offs[rid] : 0;
+    const int64_t len = valid ? (int64_t)(offs[rid + 1] - beg) : 0;
     const uint8_t *R = bases + beg;
     int64_t pos = len - 1;
     // interval [rs:os, re:oe] and the previous one (MoveInterval, include/move_intervals.hpp:10-76)
@@ -633,9 +640,9 @@ __global__ __launch_bounds__(256) void count_kernel_v0(DevIndex ix, const uint8_
             if (rs == re) c_out = (uint64_t)oe - os + 1;
             else c_out = (row_start<MODE>(ix, re) + oe) - (row_start<MODE>(ix, rs) + os) + 1;
         }
-        matched[t] = m_out;
-        count[t] = c_out;
-        if (err) err[t] = (uint8_t)failed;
+        matched[rid] = m_out;
+        count[rid] = c_out;
+        if (err) err[rid] = (uint8_t)failed;
     }
     const uint32_t ffw = wave_sum(ff_total), scw = wave_sum(scan_total), erw = wave_sum(failed ? 1u : 0u);
     if ((threadIdx.x & 63) == 0 && stats) {
@@ -647,7 +654,7 @@ __global__ __launch_bounds__(256) void count_kernel_v0(DevIndex ix, const uint8_
 
 hipError_t launch_count(int mode, const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets,
                         uint64_t n_reads, uint64_t *d_matched, uint64_t *d_count, uint8_t *d_err,
-                        DevStats *d_stats, const LaunchCfg &cfg, hipStream_t stream) {
+                        DevStats *d_stats, const uint32_t *d_order, const LaunchCfg &cfg, hipStream_t stream) {
     if (n_reads == 0) return hipSuccess;
     const int bt = cfg.block_threads;
     const uint64_t blocks = (n_reads + bt - 1) / bt;
@@ -655,10 +662,10 @@ hipError_t launch_count(int mode, const DevIndex &ix, const uint8_t *d_bases, co
     dim3 grid((unsigned)blocks), block((unsigned)bt);
     if (mode == 6)
         hipLaunchKernelGGL(count_kernel_v0<6>, grid, block, 0, stream, ix, d_bases, d_offsets, n_reads,
-                           d_matched, d_count, d_err, d_stats);
+                           d_matched, d_count, d_err, d_stats, d_order);
     else
         hipLaunchKernelGGL(count_kernel_v0<8>, grid, block, 0, stream, ix, d_bases, d_offsets, n_reads,
-                           d_matched, d_count, d_err, d_stats);
+                           d_matched, d_count, d_err, d_stats, d_order);
     return hipGetLastError();
 }
 

@@ -41,11 +41,11 @@ struct LaunchCfg {
 
 hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets,
                       uint64_t n_reads, uint16_t *d_out, uint8_t *d_err, DevStats *d_stats,
-                      const LaunchCfg &cfg, hipStream_t stream);
+                      const uint32_t *d_order, const LaunchCfg &cfg, hipStream_t stream);
 
 hipError_t launch_count(int mode, const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets,
                         uint64_t n_reads, uint64_t *d_matched, uint64_t *d_count, uint8_t *d_err,
-                        DevStats *d_stats, const LaunchCfg &cfg, hipStream_t stream);
+                        DevStats *d_stats, const uint32_t *d_order, const LaunchCfg &cfg, hipStream_t stream);
 
 // Fills ckpt[j] = BWT position of row (j << kPrefixShift), j = 0 .. ceil(r/32).
 hipError_t build_row_start_ckpt(int mode, const uint8_t *d_rows, uint64_t r, uint64_t *d_ckpt,

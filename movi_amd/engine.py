@@ -162,15 +162,17 @@ class MoveIndex:
         return [(int(m[i]), int(c[i])) for i in range(len(reads))]
 
     # -- device-pointer queries (bench / torch interop) ---------------------------
-    def pml_device(self, d_bases, d_offs, n_reads, n_bases, d_out, d_err=0, stream=0):
+    def pml_device(self, d_bases, d_offs, n_reads, n_bases, d_out, d_err=0, stream=0, d_order=0):
         check(lib().movi_pml_device(self._h, C.c_void_p(d_bases), C.c_void_p(d_offs), n_reads, n_bases,
                                     C.c_void_p(d_out), C.c_void_p(d_err) if d_err else None,
+                                    C.c_void_p(d_order) if d_order else None,
                                     C.c_void_p(stream) if stream else None))
 
-    def count_device(self, d_bases, d_offs, n_reads, n_bases, d_matched, d_count, d_err=0, stream=0):
+    def count_device(self, d_bases, d_offs, n_reads, n_bases, d_matched, d_count, d_err=0, stream=0, d_order=0):
         check(lib().movi_count_device(self._h, C.c_void_p(d_bases), C.c_void_p(d_offs), n_reads, n_bases,
                                       C.c_void_p(d_matched), C.c_void_p(d_count),
                                       C.c_void_p(d_err) if d_err else None,
+                                      C.c_void_p(d_order) if d_order else None,
                                       C.c_void_p(stream) if stream else None))
 
     def last_stats(self, stream=0):
