@@ -55,6 +55,9 @@ def main():
     ap.add_argument("--waves-per-cu", type=int, default=-1)
     ap.add_argument("--ragged", type=int, default=0, help="1: log-normal read lengths (mean = read_len); "
                     "2: same, lanes handed out longest-first (d_read_order)")
+    ap.add_argument("--from-dir", default="", help="use DIR/index.movi + DIR/reads.bin (fixed-length reads, "
+                    "--read-len) written by tools/build_index instead of the synthetic table")
+    ap.add_argument("--reads-file", default="reads.bin")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-reads", type=int, default=0)
     args = ap.parse_args()
@@ -88,12 +91,20 @@ def main():
     # ---- index: every rank derives the same host-side structure from the seed (needed to
     # draw reads); the DEVICE row table comes from rank 0 through one RCCL broadcast.
     t0 = time.time()
-    six = synth.synth_index(wl["rows"], mode=mode, seed=SEED)
+    six, file_img = None, None
+    if args.from_dir:
+        file_img = np.fromfile(os.path.join(args.from_dir, "index.movi"), np.uint8)
+        fdesc = movi_amd.parse_index_image(file_img)[0]
+        mode, row_bytes = fdesc.mode, fdesc.row_bytes
+        wl["rows"], wl["mode"] = fdesc.r, fdesc.mode
+        wl["desc"] = "index + reads from %s (tools/build_index: real BWT of a synthetic pangenome)" % args.from_dir
+    else:
+        six = synth.synth_index(wl["rows"], mode=mode, seed=SEED)
     t_index_gen = time.time() - t0
     t0 = time.time()
     meta, d_rows = None, None
     if rank == 0:
-        img = six.image()
+        img = file_img if file_img is not None else six.image()
         _, cdesc, roff, rbytes = movi_amd.parse_index_image(img)
         id_blocks = (np.ctypeslib.as_array(C.cast(cdesc.id_blocks, C.POINTER(C.c_uint32)),
                                            shape=(int(cdesc.n_blocks) * 4,)).copy() if mode == 8 else None)
@@ -122,11 +133,19 @@ def main():
     # ---- reads: each rank draws its own shard (seed + rank)
     t0 = time.time()
     lens = None
-    if args.ragged:
-        g = np.random.default_rng(SEED + 77 + rank)
-        lens = np.clip(g.lognormal(np.log(wl["read_len"]) - 0.08, 0.4, size=wl["reads"]), 20, 5 * wl["read_len"]).astype(np.uint64)
-    bases, offs = synth.synth_reads(six, wl["reads"], wl["read_len"], seed=SEED + 1 + rank,
-                                    sub_rate=wl["sub"], n_rate=0.001, lens=lens)
+    if args.from_dir:
+        allr = np.fromfile(os.path.join(args.from_dir, args.reads_file), np.uint8)
+        L = wl["read_len"]
+        per = min(wl["reads"], allr.size // L // world)
+        wl["reads"] = per
+        bases = np.ascontiguousarray(allr[rank * per * L: (rank + 1) * per * L])
+        offs = (np.arange(per + 1, dtype=np.uint64) * np.uint64(L))
+    else:
+        if args.ragged:
+            g = np.random.default_rng(SEED + 77 + rank)
+            lens = np.clip(g.lognormal(np.log(wl["read_len"]) - 0.08, 0.4, size=wl["reads"]), 20, 5 * wl["read_len"]).astype(np.uint64)
+        bases, offs = synth.synth_reads(six, wl["reads"], wl["read_len"], seed=SEED + 1 + rank,
+                                        sub_rate=wl["sub"], n_rate=0.001, lens=lens)
     t_reads_gen = time.time() - t0
     n_reads, n_bases = wl["reads"], int(bases.size)
     d_bases = torch.from_numpy(bases).to(dev)
@@ -199,7 +218,7 @@ def main():
                   "PML query Gbases/s on blocked-thresholds index",
         "value": value, "unit": "Gbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "u32/u64 integer", "data": "synthetic",
+        "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": args.workload, "description": wl["desc"], "rows": wl["rows"], "mode": mode,
                    "reads_per_gpu": n_reads, "read_len": wl["read_len"], "bases_per_step_per_gpu": n_bases,
                    "seed": SEED, "parallelism": "reads sharded x%d, index replicated (1 RCCL broadcast)" % world,
@@ -220,7 +239,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle.oracle import Oracle
         cores = os.cpu_count() or 1
-        cpu = Oracle(six.image())
+        cpu = Oracle(file_img if file_img is not None else six.image())
         sample = args.cpu_sample_reads or max(1, min(n_reads, int(30e6 * cores / 8) // max(wl["read_len"], 1)))
         sb = bases[: int(offs[sample])]
         so = offs[: sample + 1]

@@ -1,0 +1,448 @@
+// build_index.cpp -- index constructor for modes 6 / 8 (bench + test tooling; SURVEY section 8(f) "next #2").
+//
+// FASTA (or a synthetic pangenome) -> cleaned text with reverse complements -> suffix array (SA-IS) ->
+// BWT + LCP (Kasai) -> per-run thresholds -> move rows -> `index.movi` bytes.  Linear time, so that
+// the "real-structure" workload of SURVEY section 8(d)(i) -- a 64-genome pangenome with ~10 M runs, 640 Mbp of
+// text -- can be built in minutes.  What is computed follows the reference (file:line under
+// /root/reference):
+//   src/prepare_ref.cpp:39-58            cleaning ("not upper-case ACGT -> 'A'"), reverse complement per record
+//   pfp-thresholds (external, tag `movi`) BWT with terminator byte 0; threshold of a run = leftmost minimum LCP
+//                                         between the end of the previous run of that character and the run start
+//   src/move_structure_build.cpp:328-396 row boundaries: character change, threshold position, MAX_RUN_LENGTH
+//   :74-121, :449-692                    LF of run heads -> (id, offset); :694-731 base intervals
+//   :807-935                             threshold bits (incl. the '$'-row-is-an-'A'-row quirk, :823)
+//   :939-1074                            blocked ids;  src/move_structure_io.cpp:435-469 file layout
+// Checked byte-for-byte against tests/golden/index_*/index.movi (whose sizes are the reference's
+// known answers 948119 / 711733, tests/test_build.cpp:37,53) in tests/test_build_tool.py.
+//
+// usage: build_index fasta <ref.fasta> <mode 6|8> <out_dir>
+//        build_index pangenome <ancestor_len> <n_genomes> <snp_rate> <seed> <mode> <out_dir> [n_reads read_len sub_rate]
+//            [n_reads2 read_len2 sub_rate2]
+//            (also writes <out_dir>/reads.bin (and reads2.bin): fixed-length substrings of the text with substitutions)
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <string>
+#include <sys/stat.h>
+#include <vector>
+
+typedef int32_t sa_t;
+
+// ------------------------------------------------------------------ SA-IS (induced sorting), own implementation
+namespace sais {
+
+template <typename T>
+static void get_counts(const T *s, sa_t *c, sa_t n, sa_t k) {
+    for (sa_t i = 0; i < k; i++) c[i] = 0;
+    for (sa_t i = 0; i < n; i++) c[s[i]]++;
+}
+static void get_buckets(const sa_t *c, sa_t *b, sa_t k, bool end) {
+    sa_t sum = 0;
+    if (end) for (sa_t i = 0; i < k; i++) { sum += c[i]; b[i] = sum; }
+    else for (sa_t i = 0; i < k; i++) { sum += c[i]; b[i] = sum - c[i]; }
+}
+
+template <typename T>
+static void induce(const std::vector<bool> &is_s, sa_t *sa, const T *s, sa_t *c, sa_t *b, sa_t n, sa_t k) {
+    get_buckets(c, b, k, false);                      // L-type, left to right
+    for (sa_t i = 0; i < n; i++) {
+        sa_t j = sa[i] - 1;
+        if (sa[i] > 0 && !is_s[j]) sa[b[s[j]]++] = j;
+    }
+    get_buckets(c, b, k, true);                       // S-type, right to left
+    for (sa_t i = n - 1; i >= 0; i--) {
+        sa_t j = sa[i] - 1;
+        if (sa[i] > 0 && is_s[j]) sa[--b[s[j]]] = j;
+    }
+}
+
+// s[n-1] must be the unique smallest symbol (sentinel).
+template <typename T>
+static void build(const T *s, sa_t *sa, sa_t n, sa_t k) {
+    std::vector<bool> is_s(n);
+    is_s[n - 1] = true;
+    for (sa_t i = n - 2; i >= 0; i--) is_s[i] = s[i] < s[i + 1] || (s[i] == s[i + 1] && is_s[i + 1]);
+    auto is_lms = [&](sa_t i) { return i > 0 && is_s[i] && !is_s[i - 1]; };
+    std::vector<sa_t> c(k), b(k);
+    get_counts(s, c.data(), n, k);
+    // stage 1: sort LMS substrings
+    get_buckets(c.data(), b.data(), k, true);
+    for (sa_t i = 0; i < n; i++) sa[i] = -1;
+    for (sa_t i = 1; i < n; i++) if (is_lms(i)) sa[--b[s[i]]] = i;
+    induce(is_s, sa, s, c.data(), b.data(), n, k);
+    // compact sorted LMS substrings, name them
+    sa_t n1 = 0;
+    for (sa_t i = 0; i < n; i++) if (is_lms(sa[i])) sa[n1++] = sa[i];
+    for (sa_t i = n1; i < n; i++) sa[i] = -1;
+    sa_t name = 0, prev = -1;
+    for (sa_t i = 0; i < n1; i++) {
+        sa_t pos = sa[i];
+        bool diff = false;
+        if (prev < 0) diff = true;
+        else {
+            for (sa_t d = 0;; d++) {
+                if (s[pos + d] != s[prev + d] || is_s[pos + d] != is_s[prev + d]) { diff = true; break; }
+                if (d > 0 && (is_lms(pos + d) || is_lms(prev + d))) break;
+            }
+        }
+        if (diff) { name++; prev = pos; }
+        sa[n1 + pos / 2] = name - 1;
+    }
+    for (sa_t i = n - 1, j = n - 1; i >= n1; i--) if (sa[i] >= 0) sa[j--] = sa[i];
+    // stage 2: solve the reduced problem
+    sa_t *sa1 = sa, *s1 = sa + n - n1;
+    if (name < n1) {
+        build<sa_t>(s1, sa1, n1, name);
+    } else {
+        for (sa_t i = 0; i < n1; i++) sa1[s1[i]] = i;
+    }
+    // stage 3: induce the result
+    get_buckets(c.data(), b.data(), k, true);
+    for (sa_t i = 1, j = 0; i < n; i++) if (is_lms(i)) s1[j++] = i;
+    for (sa_t i = 0; i < n1; i++) sa1[i] = s1[sa1[i]];
+    for (sa_t i = n1; i < n; i++) sa[i] = -1;
+    for (sa_t i = n1 - 1; i >= 0; i--) {
+        sa_t j = sa[i];
+        sa[i] = -1;
+        sa[--b[s[j]]] = j;
+    }
+    induce(is_s, sa, s, c.data(), b.data(), n, k);
+}
+
+}  // namespace sais
+
+// ------------------------------------------------------------------------------------------------ helpers
+static const int alphamap_3[4][4] = {{3, 0, 1, 2}, {0, 3, 1, 2}, {0, 1, 3, 2}, {0, 1, 2, 3}};   // src/utils.cpp:5-8
+
+static uint64_t splitmix64(uint64_t &s) {
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+static void append_clean(std::vector<uint8_t> &text, const std::string &seq) {
+    // src/prepare_ref.cpp:39-58: the test uses the ORIGINAL byte, so lower case also becomes 'A'
+    const size_t a = text.size();
+    for (char ch : seq) text.push_back((ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T') ? (uint8_t)ch : (uint8_t)'A');
+    const size_t b = text.size();
+    for (size_t i = b; i-- > a;) {
+        uint8_t c = text[i];
+        text.push_back(c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : 'A');
+    }
+}
+
+static void put64(std::vector<uint8_t> &o, uint64_t v) { for (int i = 0; i < 8; i++) o.push_back((uint8_t)(v >> (8 * i))); }
+
+// ------------------------------------------------------------------------------- text -> index.movi bytes
+static std::vector<uint8_t> build_index(std::vector<uint8_t> &text, int mode) {
+    text.push_back(0);                                                    // terminator
+    const sa_t n = (sa_t)text.size();
+    if ((uint64_t)text.size() >= (1ull << 31)) { fprintf(stderr, "text too long for 32-bit suffix array\n"); exit(1); }
+    std::vector<sa_t> sa(n);
+    fprintf(stderr, "[build_index] n = %d, building the suffix array...\n", n);
+    sais::build<uint8_t>(text.data(), sa.data(), n, 256);
+    // LCP (Kasai): lcp[i] = lcp(suffix sa[i-1], suffix sa[i])
+    fprintf(stderr, "[build_index] LCP...\n");
+    std::vector<sa_t> rank(n), lcp(n, 0);
+    for (sa_t i = 0; i < n; i++) rank[sa[i]] = i;
+    {
+        sa_t h = 0;
+        for (sa_t i = 0; i < n; i++) {
+            sa_t r = rank[i];
+            if (r > 0) {
+                sa_t j = sa[r - 1];
+                while (i + h < n && j + h < n && text[i + h] == text[j + h]) h++;
+                lcp[r] = h;
+                if (h > 0) h--;
+            } else h = 0;
+        }
+    }
+    std::vector<sa_t>().swap(rank);
+    std::vector<uint8_t> bwt(n);
+    for (sa_t i = 0; i < n; i++) bwt[i] = sa[i] ? text[sa[i] - 1] : 0;
+    std::vector<sa_t>().swap(sa);
+    // thresholds per original run + the split bit vector (fill_bits_by_thresholds :733-746)
+    fprintf(stderr, "[build_index] thresholds + rows...\n");
+    std::vector<bool> hard(n + 1, false);
+    hard[0] = true;
+    std::vector<uint64_t> thr;                                            // per original run
+    {
+        const sa_t INF = 0x7fffffff;
+        sa_t curmin[256], arg[256];
+        bool seen[256];
+        for (int c = 0; c < 256; c++) { curmin[c] = INF; arg[c] = 0; seen[c] = false; }
+        const int syms[5] = {0, 'A', 'C', 'G', 'T'};
+        for (sa_t i = 0; i < n; i++) {
+            if (i > 0) for (int c : syms) if (lcp[i] < curmin[c]) { curmin[c] = lcp[i]; arg[c] = i; }
+            const uint8_t c = bwt[i];
+            if (i == 0 || bwt[i - 1] != c) {
+                hard[i] = true;
+                const uint64_t t = seen[c] ? (uint64_t)arg[c] : 0;
+                thr.push_back(t);
+            }
+            seen[c] = true;
+            curmin[c] = INF;                                              // the range restarts after this position
+        }
+    }
+    for (uint64_t t : thr) hard[t] = true;
+    std::vector<sa_t>().swap(lcp);
+    const uint64_t original_r = thr.size();
+    const uint32_t maxrun = mode == 6 ? 2047 : 1023;                      // move_row_configs.hpp:51,101
+    // rows (:328-396)
+    std::vector<uint64_t> all_p;
+    {
+        uint64_t start = 0;
+        for (uint64_t i = 1; i <= (uint64_t)n; i++) {
+            if (i == (uint64_t)n || hard[i] || i - start == maxrun) { all_p.push_back(start); start = i; }
+        }
+    }
+    const uint64_t r = all_p.size();
+    all_p.push_back((uint64_t)n);
+    // alphabet (build_alphabet :428-447)
+    uint64_t alphamap[256], cnt_all[256] = {0};
+    for (sa_t i = 0; i < n; i++) cnt_all[bwt[i]]++;
+    std::vector<uint8_t> alphabet;
+    std::vector<uint64_t> counts;
+    for (int c = 0; c < 256; c++) alphamap[c] = 256;
+    for (int c = 1; c < 256; c++) if (cnt_all[c]) { alphamap[c] = alphabet.size(); alphabet.push_back((uint8_t)c); counts.push_back(cnt_all[c]); }
+    const size_t sigma = alphabet.size();
+    if (sigma < 1 || sigma > 4) { fprintf(stderr, "only DNA alphabets (<= 4 symbols) are in scope\n"); exit(1); }
+    std::vector<uint8_t> code(r);
+    std::vector<uint16_t> lens(r), doff(r);
+    std::vector<uint64_t> dest(r);
+    uint64_t end_bwt_idx = 0;
+    for (uint64_t i = 0; i < r; i++) {
+        const uint8_t h = bwt[all_p[i]];
+        lens[i] = (uint16_t)(all_p[i + 1] - all_p[i]);
+        if (h == 0) { end_bwt_idx = i; code[i] = 0; }                      // set_c: alphamap[0] == 256 shifts out
+        else code[i] = (uint8_t)alphamap[h];
+    }
+    {   // LF of run heads (LF_heads, src/move_structure.cpp:515-523); destinations are monotone per character
+        uint64_t C[4], rk[4] = {0, 0, 0, 0}, ptr[4] = {0, 0, 0, 0};
+        C[0] = 1;
+        for (size_t a = 1; a < sigma; a++) C[a] = C[a - 1] + counts[a - 1];
+        for (uint64_t i = 0; i < r; i++) {
+            if (i == end_bwt_idx) { dest[i] = 0; doff[i] = 0; continue; }
+            const int a = code[i];
+            const uint64_t lf = C[a] + rk[a];
+            rk[a] += lens[i];
+            uint64_t p = ptr[a];
+            while (all_p[p + 1] <= lf) p++;
+            ptr[a] = p;
+            dest[i] = p;
+            doff[i] = (uint16_t)(lf - all_p[p]);
+        }
+    }
+    // base intervals (:694-731)
+    std::vector<uint64_t> first_runs(1, 0), first_offsets(1, 0), last_runs(1, 0), last_offsets(1, 0);
+    {
+        uint64_t cc = 1;
+        for (size_t a = 0; a < sigma; a++) {
+            const uint64_t lr = last_runs.back(), lo = last_offsets.back();
+            if (lo + 1 >= lens[lr]) { first_runs.push_back(lr + 1); first_offsets.push_back(0); }
+            else { first_runs.push_back(lr); first_offsets.push_back(lo + 1); }
+            cc += counts[a];
+            const uint64_t k = std::lower_bound(all_p.begin(), all_p.begin() + r, cc) - all_p.begin();   // rows starting before cc
+            last_runs.push_back(k - 1);
+            last_offsets.push_back(cc - all_p[k - 1] - 1);
+        }
+    }
+    // threshold bits (:807-935)
+    std::vector<uint8_t> tbits(r, 0);
+    uint64_t end_thr[4] = {0, 0, 0, 0};
+    {
+        std::vector<uint64_t> at(sigma, (uint64_t)n);
+        uint64_t thr_i = original_r - 1;
+        for (uint64_t i = r - 1; i > 0; --i) {
+            const int rc = code[i];                                       // '$' row has c == 0 -> behaves as 'A' (:823)
+            for (size_t j = 0; j < sigma; j++) {
+                if ((int)j == rc) {
+                    at[j] = thr[thr_i];
+                } else {
+                    const uint64_t cur = at[j];
+                    int bit;
+                    uint64_t val;
+                    if (cur >= all_p[i] + lens[i]) { val = lens[i]; bit = 1; }
+                    else if (cur <= all_p[i]) { val = 0; bit = 0; }
+                    else { fprintf(stderr, "threshold strictly inside a row\n"); exit(1); }
+                    if (i == end_bwt_idx) end_thr[j] = val;
+                    else tbits[i] |= (uint8_t)(bit << alphamap_3[rc][j]);
+                }
+            }
+            if (code[i] != code[i - 1] || i == end_bwt_idx || i - 1 == end_bwt_idx) thr_i--;
+        }
+        tbits[0] = 0;
+    }
+    // blocked ids (:939-1074)
+    std::vector<uint32_t> blocked, id_blocks;
+    uint64_t n_blocks = 0, block_size = 1ull << 20, max_allowed = (1ull << 22) - 1;
+    if (mode == 8) {
+        blocked.resize(r);
+        for (;;) {
+            n_blocks = (r + block_size - 1) / block_size;
+            id_blocks.assign(sigma * n_blocks, 0);
+            uint64_t last[4] = {0, 0, 0, 0};
+            bool ok = true;
+            for (uint64_t i = 0; i < r && ok; i++) {
+                if (i % block_size == 0) for (size_t a = 0; a < sigma; a++) id_blocks[a * n_blocks + i / block_size] = (uint32_t)last[a];
+                if (i == end_bwt_idx) { blocked[i] = 0; continue; }
+                const int c = code[i];
+                const uint64_t adj = dest[i] - first_runs[c + 1];
+                const uint64_t b = adj - id_blocks[c * n_blocks + i / block_size];
+                if (b > max_allowed) { ok = false; break; }
+                blocked[i] = (uint32_t)b;
+                last[c] = adj;
+            }
+            if (ok) break;
+            block_size /= 2;
+            max_allowed = ((max_allowed + 1) / 2) - 1;
+        }
+    }
+    // serialize (src/move_structure_io.cpp:435-469)
+    std::vector<uint8_t> o;
+    o.reserve(2215 + r * 8 + 512 + id_blocks.size() * 4);
+    o.resize(48, 0);
+    const uint32_t magic = 0x4D4F5649u;
+    memcpy(&o[0], &magic, 4);
+    o[4] = 2; o[5] = 0; o[6] = 0; o[7] = (uint8_t)mode; o[8] = 0;
+    const uint64_t hdr[4] = {(uint64_t)n, r, original_r, end_bwt_idx};
+    memcpy(&o[16], hdr, 32);
+    for (int i = 0; i < 4; i++) put64(o, end_thr[i]);
+    for (int i = 0; i < 8; i++) put64(o, 0);
+    put64(o, 256);
+    for (int c = 0; c < 256; c++) put64(o, alphamap[c]);
+    put64(o, sigma);
+    for (uint8_t a : alphabet) o.push_back(a);
+    o.push_back(0); o.push_back(0); o.push_back(0);                       // u16 nt_splitting, bool constant
+    for (uint64_t i = 0; i < r; i++) {
+        const uint32_t t = tbits[i];
+        uint16_t w[4];
+        if (mode == 6) {
+            const uint64_t d = dest[i];
+            w[0] = (uint16_t)(d & 0xFFFF);
+            w[1] = (uint16_t)((d >> 16) & 0xFFFF);
+            w[2] = (uint16_t)(lens[i] | (((t >> 1) & 1) << 11) | (((t >> 2) & 1) << 12) | ((uint32_t)code[i] << 13));
+            w[3] = (uint16_t)(doff[i] | ((t & 1) << 11) | ((uint32_t)(d >> 32) << 12));
+            const uint8_t *p = reinterpret_cast<const uint8_t *>(w);
+            o.insert(o.end(), p, p + 8);
+        } else {
+            const uint32_t b = blocked[i];
+            w[0] = (uint16_t)(b & 0xFFFF);
+            w[1] = (uint16_t)(lens[i] | ((b >> 16) << 10));
+            w[2] = (uint16_t)(doff[i] | ((uint32_t)code[i] << 10) | ((t & 1) << 13) | (((t >> 1) & 1) << 14) | (((t >> 2) & 1) << 15));
+            const uint8_t *p = reinterpret_cast<const uint8_t *>(w);
+            o.insert(o.end(), p, p + 6);
+        }
+    }
+    for (int i = 0; i < 3; i++) put64(o, 0);
+    put64(o, counts.size());
+    for (uint64_t c : counts) put64(o, c);
+    put64(o, last_runs.size());
+    for (uint64_t v : last_runs) put64(o, v);
+    for (uint64_t v : last_offsets) put64(o, v);
+    for (uint64_t v : first_runs) put64(o, v);
+    for (uint64_t v : first_offsets) put64(o, v);
+    if (mode == 8) {
+        put64(o, n_blocks);
+        const uint8_t *p = reinterpret_cast<const uint8_t *>(id_blocks.data());
+        o.insert(o.end(), p, p + id_blocks.size() * 4);
+        put64(o, block_size);
+    }
+    fprintf(stderr, "[build_index] n = %d, original_r = %llu, r = %llu, n/r = %.2f, index %zu bytes\n", n,
+            (unsigned long long)original_r, (unsigned long long)r, (double)n / r, o.size());
+    text.pop_back();
+    return o;
+}
+
+static void write_file(const std::string &path, const std::vector<uint8_t> &data) {
+    std::ofstream f(path, std::ios::binary);
+    f.write(reinterpret_cast<const char *>(data.data()), (std::streamsize)data.size());
+    if (!f.good()) { fprintf(stderr, "cannot write %s\n", path.c_str()); exit(1); }
+}
+
+int main(int argc, char **argv) {
+    if (argc < 2) { fprintf(stderr, "usage: see the header of tools/build_index.cpp\n"); return 1; }
+    const std::string cmd = argv[1];
+    std::vector<uint8_t> text;
+    int mode = 6;
+    std::string out_dir;
+    uint64_t n_reads = 0, read_len = 0, seed = 1;
+    double sub_rate = 0;
+    if (cmd == "fasta" && argc >= 5) {
+        std::ifstream in(argv[2]);
+        if (!in.good()) { fprintf(stderr, "cannot open %s\n", argv[2]); return 1; }
+        mode = atoi(argv[3]);
+        out_dir = argv[4];
+        std::string line, seq;
+        bool have = false;
+        while (std::getline(in, line)) {
+            while (!line.empty() && (line.back() == '\r' || line.back() == '\n' || line.back() == ' ')) line.pop_back();
+            if (!line.empty() && line[0] == '>') {
+                if (have) append_clean(text, seq);
+                seq.clear();
+                have = true;
+            } else if (have) seq += line;
+        }
+        if (have) append_clean(text, seq);
+    } else if (cmd == "pangenome" && argc >= 9) {
+        const uint64_t anc_len = strtoull(argv[2], nullptr, 10), n_genomes = strtoull(argv[3], nullptr, 10);
+        const double snp = atof(argv[4]);
+        seed = strtoull(argv[5], nullptr, 10);
+        mode = atoi(argv[6]);
+        out_dir = argv[7];
+        if (argc >= 11) { n_reads = strtoull(argv[8], nullptr, 10); read_len = strtoull(argv[9], nullptr, 10); sub_rate = atof(argv[10]); }
+        uint64_t st = seed * 0x9E3779B97F4A7C15ull + 7;
+        std::string anc(anc_len, 'A');
+        for (auto &c : anc) c = "ACGT"[splitmix64(st) & 3];
+        // a shallow star phylogeny: every genome = ancestor + its own SNPs, plus SNPs shared by a random half
+        for (uint64_t g = 0; g < n_genomes; g++) {
+            std::string s = anc;
+            uint64_t sg = seed * 1315423911ull + g * 2654435761ull;
+            const uint64_t k = (uint64_t)(snp * anc_len);
+            for (uint64_t i = 0; i < k; i++) {
+                const uint64_t pos = splitmix64(sg) % anc_len;
+                s[pos] = "ACGT"[splitmix64(sg) & 3];
+            }
+            uint64_t sh = seed * 77 + 5;                                   // shared variants: same stream for all genomes
+            for (uint64_t i = 0; i < k; i++) {
+                const uint64_t pos = splitmix64(sh) % anc_len;
+                const char alt = "ACGT"[splitmix64(sh) & 3];
+                const uint64_t carriers = splitmix64(sh);
+                if ((carriers >> (g & 63)) & 1) s[pos] = alt;
+            }
+            append_clean(text, s);
+        }
+    } else {
+        fprintf(stderr, "usage: see the header of tools/build_index.cpp\n");
+        return 1;
+    }
+    if (mode != 6 && mode != 8) { fprintf(stderr, "mode must be 6 or 8\n"); return 1; }
+    mkdir(out_dir.c_str(), 0777);
+    for (int set = 0; set < 2; set++) {                                    // optional second read set: argv[11..13] -> reads2.bin
+        if (set == 1) {
+            if (cmd != "pangenome" || argc < 14) break;
+            n_reads = strtoull(argv[11], nullptr, 10); read_len = strtoull(argv[12], nullptr, 10); sub_rate = atof(argv[13]);
+        }
+        if (!n_reads) continue;
+        std::vector<uint8_t> reads(n_reads * read_len);
+        uint64_t sr = seed * 31 + 99 + set;
+        for (uint64_t i = 0; i < n_reads; i++) {
+            const uint64_t pos = splitmix64(sr) % (text.size() - read_len);
+            memcpy(&reads[i * read_len], &text[pos], read_len);
+            for (uint64_t k = 0; k < read_len; k++) {
+                const double u = (double)(splitmix64(sr) >> 11) * (1.0 / 9007199254740992.0);
+                if (u < 0.001) reads[i * read_len + k] = 'N';
+                else if (u < 0.001 + sub_rate) reads[i * read_len + k] = "ACGT"[splitmix64(sr) & 3];
+            }
+        }
+        write_file(out_dir + (set ? "/reads2.bin" : "/reads.bin"), reads);
+    }
+    const std::vector<uint8_t> img = build_index(text, mode);
+    write_file(out_dir + "/index.movi", img);
+    return 0;
+}
