@@ -24,19 +24,59 @@ if ROOT not in sys.path:
 
 import numpy as np
 
+PG = dict(anc=5_000_000, genomes=64, snp=0.001, seed=11)       # 64 x 5 Mbp (+ reverse complements) = 640 Mbp, ~14 M rows
 WORKLOADS = {
-    # name: (rows, mode, n_reads per GPU, read_len, sub_rate)
-    "c2": dict(rows=10_000_000, mode=6, reads=1_000_000, read_len=150, sub=0.01,
-               desc="synthetic 10M-row regular-thresholds table, 1M x 150bp reads per GPU (BASELINE config 2)"),
-    "c3": dict(rows=10_000_000, mode=6, reads=100_000, read_len=10_000, sub=0.08,
-               desc="synthetic 10M-row regular-thresholds table, 100k x 10kbp reads per GPU (BASELINE config 3)"),
-    "c2b": dict(rows=10_000_000, mode=8, reads=1_000_000, read_len=150, sub=0.01,
-                desc="synthetic 10M-row blocked-thresholds table, 1M x 150bp reads per GPU"),
-    "c4": dict(rows=1_000_000_000, mode=6, reads=1_250_000, read_len=150, sub=0.01,
-               desc="synthetic 1B-row regular-thresholds table (8 GB), 1.25M x 150bp reads per GPU (BASELINE config 4 shard)"),
-    "tiny": dict(rows=200_000, mode=6, reads=20_000, read_len=150, sub=0.01,
+    # "pangenome": real BWT of a synthetic 64-genome pangenome built by tools/build_index,
+    # cached under /tmp after the first ~90 s build.  "synth": random move table of tools/synth.c (8(d)(ii)).
+    "c2": dict(kind="pangenome", mode=6, reads=1_000_000, read_len=150, sub=0.01,
+               desc="BASELINE config 2: synthetic 64-genome E. coli-scale pangenome (5 Mbp ancestor, 640 Mbp text, ~14 M "
+                    "rows, real BWT), regular-thresholds, 1M x 150bp reads per GPU (substrings, 1% subst., 0.1% N)"),
+    "c3": dict(kind="pangenome", mode=6, reads=100_000, read_len=10_000, sub=0.08,
+               desc="BASELINE config 3: same pangenome index, 100k x 10kbp reads per GPU (8% subst.)"),
+    "c2b": dict(kind="pangenome", mode=8, reads=1_000_000, read_len=150, sub=0.01,
+                desc="same pangenome as blocked-thresholds (6 B rows), 1M x 150bp reads per GPU"),
+    "c2synth": dict(kind="synth", rows=10_000_000, mode=6, reads=1_000_000, read_len=150, sub=0.01,
+                    desc="random 10M-row regular-thresholds table (worst-case step mix), 1M x 150bp reads per GPU"),
+    "c3synth": dict(kind="synth", rows=10_000_000, mode=6, reads=100_000, read_len=10_000, sub=0.08,
+                    desc="random 10M-row regular-thresholds table, 100k x 10kbp reads per GPU"),
+    "c2bsynth": dict(kind="synth", rows=10_000_000, mode=8, reads=1_000_000, read_len=150, sub=0.01,
+                     desc="random 10M-row blocked-thresholds table, 1M x 150bp reads per GPU"),
+    "c4": dict(kind="synth", rows=1_000_000_000, mode=6, reads=1_250_000, read_len=150, sub=0.01,
+               desc="random 1B-row regular-thresholds table (8 GB), 1.25M x 150bp reads per GPU (BASELINE config 4 shard)"),
+    "tiny": dict(kind="synth", rows=200_000, mode=6, reads=20_000, read_len=150, sub=0.01,
                  desc="tiny plumbing workload"),
 }
+CACHE = os.environ.get("MOVI_BENCH_CACHE", "/tmp/movi_bench_cache")
+
+
+def ensure_pangenome(wl, world, rank, barrier):
+    """Rank 0 builds (once per box) the pangenome index and this workload's reads; returns the directory."""
+    import subprocess
+    tool = os.path.join(ROOT, "tools", "build_index")
+    idx_dir = os.path.join(CACHE, "pg_%d_%d_%g_%d_m%d" % (PG["anc"], PG["genomes"], PG["snp"], PG["seed"], wl["mode"]))
+    reads_file = os.path.join(idx_dir, "reads_%dx%d_%g.bin" % (wl["reads"] * world, wl["read_len"], wl["sub"]))
+    if rank == 0:
+        src = tool + ".cpp"
+        if not os.path.exists(tool) or os.path.getmtime(tool) < os.path.getmtime(src):
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", tool, src])
+        os.makedirs(CACHE, exist_ok=True)
+        if not os.path.exists(os.path.join(idx_dir, ".done")):
+            tmp = idx_dir + ".tmp%d" % os.getpid()
+            subprocess.check_call([tool, "pangenome", str(PG["anc"]), str(PG["genomes"]), str(PG["snp"]), str(PG["seed"]),
+                                   str(wl["mode"]), tmp], stderr=subprocess.DEVNULL)
+            if os.path.exists(idx_dir):
+                import shutil
+                shutil.rmtree(idx_dir)
+            os.rename(tmp, idx_dir)
+            open(os.path.join(idx_dir, ".done"), "w").close()
+        if not os.path.exists(reads_file):
+            subprocess.check_call([tool, "reads", os.path.join(idx_dir, "text.bin"), str(wl["reads"] * world),
+                                   str(wl["read_len"]), str(wl["sub"]), str(PG["seed"]), reads_file + ".tmp"])
+            os.rename(reads_file + ".tmp", reads_file)
+    barrier()
+    return idx_dir, reads_file
+
+
 SEED = 20260529
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
@@ -91,13 +131,19 @@ def main():
     # ---- index: every rank derives the same host-side structure from the seed (needed to
     # draw reads); the DEVICE row table comes from rank 0 through one RCCL broadcast.
     t0 = time.time()
-    six, file_img = None, None
+    six, file_img, reads_path = None, None, None
+    barrier = (lambda: dist.barrier()) if world > 1 else (lambda: None)
     if args.from_dir:
-        file_img = np.fromfile(os.path.join(args.from_dir, "index.movi"), np.uint8)
-        fdesc = movi_amd.parse_index_image(file_img)[0]
-        mode, row_bytes = fdesc.mode, fdesc.row_bytes
-        wl["rows"], wl["mode"] = fdesc.r, fdesc.mode
+        idx_dir, reads_path = args.from_dir, os.path.join(args.from_dir, args.reads_file)
         wl["desc"] = "index + reads from %s (tools/build_index: real BWT of a synthetic pangenome)" % args.from_dir
+    elif wl["kind"] == "pangenome":
+        idx_dir, reads_path = ensure_pangenome(wl, world, rank, barrier)
+    if reads_path:
+        file_img = np.fromfile(os.path.join(idx_dir, "index.movi"), np.uint8) if rank == 0 else None
+        if rank == 0:
+            fdesc = movi_amd.parse_index_image(file_img)[0]
+            mode, row_bytes = fdesc.mode, fdesc.row_bytes
+            wl["rows"], wl["mode"] = fdesc.r, fdesc.mode
     else:
         six = synth.synth_index(wl["rows"], mode=mode, seed=SEED)
     t_index_gen = time.time() - t0
@@ -119,6 +165,8 @@ def main():
         torch.cuda.synchronize()
         t_bcast = time.time() - tb
     cdesc = IndexDescC.from_buffer_copy(meta["cdesc"])
+    mode, row_bytes = int(cdesc.mode), (8 if int(cdesc.mode) == 6 else 6)
+    wl["rows"], wl["mode"] = int(cdesc.r), mode
     id_blocks = meta["id_blocks"]
     cdesc.id_blocks = id_blocks.ctypes.data if id_blocks is not None else None
     index = movi_amd.MoveIndex.from_device_rows(cdesc, d_rows.data_ptr(), device=local_rank, keepalive=d_rows)
@@ -133,12 +181,11 @@ def main():
     # ---- reads: each rank draws its own shard (seed + rank)
     t0 = time.time()
     lens = None
-    if args.from_dir:
-        allr = np.fromfile(os.path.join(args.from_dir, args.reads_file), np.uint8)
+    if reads_path:
         L = wl["read_len"]
-        per = min(wl["reads"], allr.size // L // world)
+        per = min(wl["reads"], os.path.getsize(reads_path) // L // world)
         wl["reads"] = per
-        bases = np.ascontiguousarray(allr[rank * per * L: (rank + 1) * per * L])
+        bases = np.fromfile(reads_path, np.uint8, count=per * L, offset=rank * per * L)
         offs = (np.arange(per + 1, dtype=np.uint64) * np.uint64(L))
     else:
         if args.ragged:

@@ -18,7 +18,9 @@
 // usage: build_index fasta <ref.fasta> <mode 6|8> <out_dir>
 //        build_index pangenome <ancestor_len> <n_genomes> <snp_rate> <seed> <mode> <out_dir> [n_reads read_len sub_rate]
 //            [n_reads2 read_len2 sub_rate2]
-//            (also writes <out_dir>/reads.bin (and reads2.bin): fixed-length substrings of the text with substitutions)
+//            (also writes <out_dir>/text.bin and reads.bin (and reads2.bin): fixed-length substrings of the text
+//            with substitutions)
+//        build_index reads <text.bin> <n_reads> <read_len> <sub_rate> <seed> <out_file>
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
@@ -365,6 +367,20 @@ static void write_file(const std::string &path, const std::vector<uint8_t> &data
     if (!f.good()) { fprintf(stderr, "cannot write %s\n", path.c_str()); exit(1); }
 }
 
+// Fixed-length substrings of the text with substitutions (rate sub_rate) and 0.1 % 'N'.
+static void draw_reads(const std::vector<uint8_t> &text, std::vector<uint8_t> &reads, uint64_t n_reads, uint64_t read_len,
+                       double sub_rate, uint64_t sr) {
+    for (uint64_t i = 0; i < n_reads; i++) {
+        const uint64_t pos = splitmix64(sr) % (text.size() - read_len);
+        memcpy(&reads[i * read_len], &text[pos], read_len);
+        for (uint64_t k = 0; k < read_len; k++) {
+            const double u = (double)(splitmix64(sr) >> 11) * (1.0 / 9007199254740992.0);
+            if (u < 0.001) reads[i * read_len + k] = 'N';
+            else if (u < 0.001 + sub_rate) reads[i * read_len + k] = "ACGT"[splitmix64(sr) & 3];
+        }
+    }
+}
+
 int main(int argc, char **argv) {
     if (argc < 2) { fprintf(stderr, "usage: see the header of tools/build_index.cpp\n"); return 1; }
     const std::string cmd = argv[1];
@@ -389,7 +405,7 @@ int main(int argc, char **argv) {
             } else if (have) seq += line;
         }
         if (have) append_clean(text, seq);
-    } else if (cmd == "pangenome" && argc >= 9) {
+    } else if (cmd == "pangenome" && argc >= 8) {
         const uint64_t anc_len = strtoull(argv[2], nullptr, 10), n_genomes = strtoull(argv[3], nullptr, 10);
         const double snp = atof(argv[4]);
         seed = strtoull(argv[5], nullptr, 10);
@@ -417,12 +433,27 @@ int main(int argc, char **argv) {
             }
             append_clean(text, s);
         }
+    } else if (cmd == "reads" && argc >= 8) {
+        // build_index reads <text.bin> <n_reads> <read_len> <sub_rate> <seed> <out_file>
+        std::ifstream in(argv[2], std::ios::binary);
+        if (!in.good()) { fprintf(stderr, "cannot open %s\n", argv[2]); return 1; }
+        in.seekg(0, std::ios::end);
+        text.resize((size_t)in.tellg());
+        in.seekg(0);
+        in.read(reinterpret_cast<char *>(text.data()), (std::streamsize)text.size());
+        n_reads = strtoull(argv[3], nullptr, 10); read_len = strtoull(argv[4], nullptr, 10); sub_rate = atof(argv[5]);
+        seed = strtoull(argv[6], nullptr, 10);
+        std::vector<uint8_t> reads(n_reads * read_len);
+        draw_reads(text, reads, n_reads, read_len, sub_rate, seed * 31 + 99);
+        write_file(argv[7], reads);
+        return 0;
     } else {
         fprintf(stderr, "usage: see the header of tools/build_index.cpp\n");
         return 1;
     }
     if (mode != 6 && mode != 8) { fprintf(stderr, "mode must be 6 or 8\n"); return 1; }
     mkdir(out_dir.c_str(), 0777);
+    if (cmd == "pangenome") write_file(out_dir + "/text.bin", text);       // lets `reads` draw more reads later
     for (int set = 0; set < 2; set++) {                                    // optional second read set: argv[11..13] -> reads2.bin
         if (set == 1) {
             if (cmd != "pangenome" || argc < 14) break;
@@ -430,16 +461,7 @@ int main(int argc, char **argv) {
         }
         if (!n_reads) continue;
         std::vector<uint8_t> reads(n_reads * read_len);
-        uint64_t sr = seed * 31 + 99 + set;
-        for (uint64_t i = 0; i < n_reads; i++) {
-            const uint64_t pos = splitmix64(sr) % (text.size() - read_len);
-            memcpy(&reads[i * read_len], &text[pos], read_len);
-            for (uint64_t k = 0; k < read_len; k++) {
-                const double u = (double)(splitmix64(sr) >> 11) * (1.0 / 9007199254740992.0);
-                if (u < 0.001) reads[i * read_len + k] = 'N';
-                else if (u < 0.001 + sub_rate) reads[i * read_len + k] = "ACGT"[splitmix64(sr) & 3];
-            }
-        }
+        draw_reads(text, reads, n_reads, read_len, sub_rate, seed * 31 + 99 + set);
         write_file(out_dir + (set ? "/reads2.bin" : "/reads.bin"), reads);
     }
     const std::vector<uint8_t> img = build_index(text, mode);
