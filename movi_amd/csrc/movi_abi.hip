@@ -379,6 +379,8 @@ int run_chunked(movi_index *ix, const uint8_t *h_bases, const uint64_t *h_offset
         // slightly SLOWER (31.1 vs 32.8 Gbases/s, log-normal lengths) -- the walk is bound by the
         // memory system, not by lane occupancy, and the dispatcher already refills whole blocks.
         const uint32_t *order_ptr = nullptr;
+        if (nb) HIP_TRY(hipMemcpy(d_bases.p, h_bases + b0, nb, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_offs.p, rel.data(), (nr + 1) * 8, hipMemcpyHostToDevice));
         int rc = launch(static_cast<const uint8_t *>(d_bases.p), static_cast<const uint64_t *>(d_offs.p), nr, nb,
                         static_cast<uint8_t *>(d_err.p), order_ptr);
         if (rc) return rc;

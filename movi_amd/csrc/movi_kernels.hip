@@ -146,6 +146,51 @@ __device__ __forceinline__ uint32_t lf_step(const DevIndex &ix, bool live, uint6
     return errc;
 }
 
+// Two independent LF_moves (the two ends of a backward-search interval) advanced together:
+// both gathers are issued before either result is needed and the two fast-forwards share one
+// wave-uniform loop, so an interval step costs the trips of ONE walker.
+template <int MODE>
+__device__ __forceinline__ uint32_t lf_step2(const DevIndex &ix, bool live, uint64_t &ia, uint32_t &offa, uint2 &rowa,
+                                             uint64_t &ib, uint32_t &offb, uint2 &rowb, uint32_t &ff_total) {
+    uint32_t errc = kErrNone;
+    uint64_t ja = ia, jb = ib;
+    uint32_t na = 0, nb = 0, ffa = 0, ffb = 0, ga = 0, gb = 0;
+    if (live) {
+        ja = row_id<MODE>(rowa, ia, ix);
+        jb = row_id<MODE>(rowb, ib, ix);
+        if (ja >= ix.r || jb >= ix.r) {                 // move_structure.cpp:63-65
+            errc = kErrIdRange;
+            ja = ia; jb = ib;
+        } else {
+            offa += row_off<MODE>(rowa);
+            offb += row_off<MODE>(rowb);
+            rowa = load_row<MODE>(ix.rows, ja);
+            rowb = load_row<MODE>(ix.rows, jb);
+            na = row_n<MODE>(rowa);
+            nb = row_n<MODE>(rowb);
+            ga = (ja < ix.r - 1 && offa >= na) ? 1u : 0u;
+            gb = (jb < ix.r - 1 && offb >= nb) ? 1u : 0u;
+        }
+    }
+    while (wave_any((ga | gb) != 0u)) {                 // fast_forward :524-545, both walkers
+        uint2 wa = rowa, wb = rowb;
+        if (ga) wa = load_row<MODE>(ix.rows, ja + 1);
+        if (gb) wb = load_row<MODE>(ix.rows, jb + 1);
+        if (ga) {
+            offa -= na; ja += 1; ffa += 1; rowa = wa; na = row_n<MODE>(rowa);
+            ga = (ja < ix.r - 1 && offa >= na && ffa < 65535u) ? 1u : 0u;
+        }
+        if (gb) {
+            offb -= nb; jb += 1; ffb += 1; rowb = wb; nb = row_n<MODE>(rowb);
+            gb = (jb < ix.r - 1 && offb >= nb && ffb < 65535u) ? 1u : 0u;
+        }
+    }
+    if (ffa >= 65535u || ffb >= 65535u) errc = kErrFastForward;   // move_structure.cpp:72-75
+    ff_total += ffa + ffb;
+    ia = ja; ib = jb;
+    return errc;
+}
+
 // ------------------------------------------------------------------------- PML
 // One lane per read; wave-uniform step loop, predicated per lane.
 //   VARIANT 0: one byte load and one u16 store per step and lane.
@@ -589,43 +634,42 @@ __global__ __launch_bounds__(256) void count_kernel_v0(DevIndex ix, const uint8_
         }
         const bool legal = act && b != 0xFFu;
         // update_interval, src/move_structure_search.cpp:48-61 (get_char: '$' never equals a base)
+        // Both ends shrink in ONE wave-uniform loop, one row per end and trip.  When the interval
+        // holds no row of character b the two ends cross instead of rs running all the way past re as
+        // in the reference; either way the interval is empty and the previous one is reported.
         uint2 rws = make_uint2(0, 0), rwe = make_uint2(0, 0);
-        uint32_t g = 0;
+        uint32_t gs = 0, ge = 0;
         if (legal && rs <= re) {
             rws = load_row<MODE>(ix.rows, rs);
-            g = (rs == ix.end_bwt_idx || row_c<MODE>(rws) != b) ? 1u : 0u;
-        }
-        while (wave_any(g != 0u)) {
-            if (g) {
-                rs += 1; os = 0; scan_total += 1;
-                if (rs >= ix.r || rs > re) {
-                    g = 0;
-                } else {
-                    rws = load_row<MODE>(ix.rows, rs);
-                    g = (rs == ix.end_bwt_idx || row_c<MODE>(rws) != b) ? 1u : 0u;
-                }
-            }
-        }
-        g = 0;
-        if (legal && re >= rs) {
             rwe = load_row<MODE>(ix.rows, re);
-            g = (re == ix.end_bwt_idx || row_c<MODE>(rwe) != b) ? 1u : 0u;
+            gs = (rs == ix.end_bwt_idx || row_c<MODE>(rws) != b) ? 1u : 0u;
+            ge = (re == ix.end_bwt_idx || row_c<MODE>(rwe) != b) ? 1u : 0u;
         }
-        while (wave_any(g != 0u)) {
-            if (g) {
-                re -= 1; scan_total += 1;
-                rwe = load_row<MODE>(ix.rows, re);
-                oe = row_n<MODE>(rwe) - 1;
-                if (re == 0 || re < rs) g = 0;
-                else g = (re == ix.end_bwt_idx || row_c<MODE>(rwe) != b) ? 1u : 0u;
+        while (wave_any((gs | ge) != 0u)) {
+            uint2 ws = rws, we = rwe;
+            if (gs && rs + 1 < ix.r) ws = load_row<MODE>(ix.rows, rs + 1);
+            if (ge && re > 0) we = load_row<MODE>(ix.rows, re - 1);
+            if (gs) {
+                rs += 1; os = 0; scan_total += 1;
+                if (rs >= ix.r || rs > re) { gs = 0; ge = 0; }
+                else { rws = ws; gs = (rs == ix.end_bwt_idx || row_c<MODE>(rws) != b) ? 1u : 0u; }
+            }
+            if (ge) {
+                if (re == 0) { ge = 0; gs = 0; rs = 1; }          // nothing above row 0: empty
+                else {
+                    re -= 1; scan_total += 1;
+                    rwe = we;
+                    oe = row_n<MODE>(rwe) - 1;
+                    if (re < rs) { ge = 0; gs = 0; }
+                    else ge = (re == ix.end_bwt_idx || row_c<MODE>(rwe) != b) ? 1u : 0u;
+                }
             }
         }
         bool nonempty = legal && ((rs < re) || (rs == re && os <= oe));
         if (legal && !nonempty) { empty = 1; run = 0; }
         // backward_search_step :326-330: two LF moves
-        uint32_t e1 = lf_step<MODE>(ix, nonempty, rs, os, rws, ff_total);
-        uint32_t e2 = lf_step<MODE>(ix, nonempty && e1 == 0u, re, oe, rwe, ff_total);
-        if (e1 | e2) { failed = e1 ? e1 : e2; run = 0; nonempty = false; }
+        const uint32_t e12 = lf_step2<MODE>(ix, nonempty, rs, os, rws, re, oe, rwe, ff_total);
+        if (e12) { failed = e12; run = 0; nonempty = false; }
         if (nonempty) {                                   // backward_search :179-182
             if ((rs < re) || (rs == re && os <= oe)) pos -= 1;
             else { empty = 1; run = 0; }
