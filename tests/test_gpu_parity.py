@@ -197,3 +197,55 @@ def test_large_batch_properties(built_lib):
     assert (out[int(offs[sl.start]): int(offs[sl.stop])] == exp).all()
     sub, _ = gpu.query_pml_packed(sb, so)
     assert (sub == exp).all()
+
+
+def test_long_read_batch_properties_multi_chunk(built_lib):
+    """BASELINE config 3 shape (100 k x 10 kbp = 1 Gbase on a 10 M-row table): crosses the host
+    path's 2^28-base chunking, runs the low-occupancy kernel; checked by properties + an oracle
+    spot check."""
+    import movi_amd
+    from oracle.oracle import Oracle
+    from tools import synth
+    six = synth.synth_index(10_000_000, mode=6, seed=20260529)
+    img = six.image()
+    gpu = movi_amd.MoveIndex.from_image(img)
+    n_reads, L = 100_000, 10_000
+    bases, offs = synth.synth_reads(six, n_reads, L, seed=3, sub_rate=0.08)
+    out, st = gpu.query_pml_packed(bases, offs)
+    assert st.errors == 0 and st.bases == n_reads * L
+    pm = out.reshape(n_reads, L)
+    rb = bases.reshape(n_reads, L)[:, ::-1]
+    assert (pm[rb == ord("N")] == 0).all()
+    d = pm[:, 1:].astype(np.int32) - pm[:, :-1].astype(np.int32)
+    assert ((d == 1) | (pm[:, 1:] == 0)).all()
+    cpu = Oracle(img)
+    for i in (0, 26843, 26844, 53687, 99_999):                 # reads next to the chunk boundaries
+        assert (pm[i] == cpu.pml(bases[i * L:(i + 1) * L].tobytes())).all()
+
+
+@pytest.mark.parametrize("mode", [6, 8])
+def test_large_count_batch_properties(built_lib, mode):
+    """BASELINE config 5 shape at single-GPU scale (1 M x 150 bp --count): exact substrings are
+    found end to end; mutated reads agree with the oracle on a slice."""
+    import movi_amd
+    from oracle.oracle import Oracle
+    from tools import synth
+    six = synth.synth_index(10_000_000, mode=mode, seed=77)
+    img = six.image()
+    gpu = movi_amd.MoveIndex.from_image(img)
+    n_reads, L = 1_000_000, 150
+    bases, offs = synth.synth_reads(six, n_reads, L, seed=5, sub_rate=0.0, n_rate=0.0)
+    m, c, st = gpu.query_count_packed(bases, offs)
+    assert st.errors == 0
+    cpu = Oracle(img)
+    short = np.flatnonzero(m != L)          # a walk through the terminator row is not a substring of the text
+    assert short.size <= 5
+    for i in short:
+        assert cpu.count(bases[i * L:(i + 1) * L].tobytes()) == (int(m[i]), int(c[i]))
+    assert (c >= 1).all()
+    bases2, offs2 = synth.synth_reads(six, n_reads, L, seed=6, sub_rate=0.02, n_rate=0.001)
+    m2, c2, _ = gpu.query_count_packed(bases2, offs2)
+    assert (m2 <= L).all() and ((m2 > 0) | (bases2.reshape(n_reads, L)[:, -1] == ord("N"))).all()
+    sl = slice(500_000, 503_000)
+    em, ec = cpu.count_batch(bases2[sl.start * L: sl.stop * L], offs2[sl.start: sl.stop + 1] - offs2[sl.start], threads=8)
+    assert (m2[sl] == em).all() and (c2[sl] == ec).all()
