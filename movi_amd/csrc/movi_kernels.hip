@@ -222,13 +222,24 @@ __global__ __launch_bounds__(256) void pml_kernel(DevIndex ix, const uint8_t *__
     uint2 row = load_row<MODE>(ix.rows, idx);
     uint32_t off = row_n<MODE>(row) - 1;
     uint32_t ml = 0;
-    uint64_t rb = 0;                                      // VARIANT 1: 8 bases, byte 7 = current step
-    uint4 pk = make_uint4(0, 0, 0, 0);                    // VARIANT 1: last 8 PMLs, oldest in the low bits
+    uint64_t rb = 0, rb_next = 0;                         // VARIANT 1: 8 bases, byte 7 = current step
+    uint32_t have16 = 0;
+    uint4 pk = make_uint4(0, 0, 0, 0), pk_old = pk;       // VARIANT 1: last 8 PMLs, oldest in the low bits
     const uint64_t packed_end = len & ~7ull;              // steps >= this are stored one by one
     for (uint64_t k = 0; wave_any(k < len && failed == 0u); ++k) {
         bool live = k < len && failed == 0u;
         if (VARIANT >= 1 && (k & 7) == 0) {
-            if (live && k + 8 <= len) {
+            // 16 bases per fetch when they exist (one L2 request per 16 steps), else 8, else bytes
+            if ((k & 8) == 0 && live && k + 16 <= len) {
+                uint64_t two[2];
+                __builtin_memcpy(two, R + (len - 16 - k), 16);        // unaligned 16-byte load
+                rb = two[1];
+                rb_next = two[0];
+                have16 = 1;
+            } else if ((k & 8) != 0 && have16) {
+                rb = rb_next;
+                have16 = 0;
+            } else if (live && k + 8 <= len) {
                 __builtin_memcpy(&rb, R + (len - 8 - k), 8);          // unaligned 8-byte load
             } else if (live) {
                 rb = 0;
@@ -313,7 +324,15 @@ __global__ __launch_bounds__(256) void pml_kernel(DevIndex ix, const uint8_t *__
                 pk.y = (pk.y >> 16) | (pk.z << 16);
                 pk.z = (pk.z >> 16) | (pk.w << 16);
                 pk.w = (pk.w >> 16) | (val << 16);
-                if ((k & 7) == 7) __builtin_memcpy(O + (k - 7), &pk, 16);   // unaligned 16-byte store
+                // 16 PMLs leave together as two adjacent 16-byte stores (one 32-byte span per
+                // 16 steps); an odd group of 8 before the tail goes out on its own
+                if ((k & 15) == 7) {
+                    if (k + 8 < packed_end) pk_old = pk;
+                    else __builtin_memcpy(O + (k - 7), &pk, 16);
+                } else if ((k & 15) == 15) {
+                    __builtin_memcpy(O + (k - 15), &pk_old, 16);      // unaligned 16-byte stores
+                    __builtin_memcpy(O + (k - 7), &pk, 16);
+                }
             }
         } else if (live) {
             O[k] = (uint16_t)val;
@@ -503,6 +522,8 @@ __global__ __launch_bounds__(256) void pml_kernel_sm(DevIndex ix, const uint8_t 
                     need = j;
                     ff_run = 0;
                     st = kFF;
+                    // (16-base fetches / paired stores as in pml_kernel measured SLOWER here: this
+                    // kernel runs latency-bound, every extra instruction per iteration shows)
                     if ((k & 7) == 0) rb = load_chunk(k);
                 }
             }
