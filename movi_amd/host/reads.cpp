@@ -1,20 +1,63 @@
 #include "reads.hpp"
 
+#include <algorithm>
 #include <cctype>
+#include <cstring>
 #include <queue>
 #include <stdexcept>
 
 namespace movi_host {
 
+bool LineSource::fill() {
+    if (drained_) return false;
+    if (pos_ > 0) {
+        std::memmove(buf_.data(), buf_.data() + pos_, end_ - pos_);
+        end_ -= pos_;
+        pos_ = 0;
+    }
+    if (end_ == buf_.size()) buf_.resize(buf_.size() * 2);             // a single line longer than the buffer
+    in_.read(buf_.data() + end_, (std::streamsize)(buf_.size() - end_));
+    const size_t got = (size_t)in_.gcount();
+    end_ += got;
+    if (got == 0) drained_ = true;
+    return got > 0;
+}
+
+int LineSource::peek() {
+    if (pos_ == end_ && !fill()) { eof_ = true; return std::char_traits<char>::eof(); }
+    return (unsigned char)buf_[pos_];
+}
+
+bool LineSource::getline(const char *&p, size_t &n) {
+    for (;;) {
+        const char *base = buf_.data() + pos_;
+        const void *nl = std::memchr(base, '\n', end_ - pos_);
+        if (nl) {
+            n = (size_t)(static_cast<const char *>(nl) - base);
+            p = base;
+            pos_ += n + 1;
+            return true;
+        }
+        if (!fill()) break;
+    }
+    if (pos_ == end_) { eof_ = true; return false; }                   // nothing left: getline fails
+    p = buf_.data() + pos_;                                            // last line without a newline:
+    n = end_ - pos_;                                                   // returned, and eof is set
+    pos_ = end_;
+    eof_ = true;
+    return true;
+}
+
 // One reference batch = the lines loadBatch would put into its stringstream
 // (src/batch_loader.cpp:50-87): lines are read until BOTH >= 1000 "bases" and >= min_reads
 // reads are covered.  FASTQ: a read is counted every 4 lines with (record bytes)/2 bases;
 // FASTA: a read is counted when the NEXT line starts with '>' with (record bytes) bases.
-bool BatchReader::load_batch(std::vector<std::string> &lines) {
-    lines.clear();
+bool BatchReader::load_batch() {
+    arena_.clear();
+    lines_.clear();
     if (format_ < 0) {
-        if (!in_.good()) return false;
-        int c = in_.peek();
+        if (!src_.good()) return false;
+        int c = src_.peek();
         if (c == '>') format_ = 0;
         else if (c == '@') format_ = 1;
         else if (c == std::char_traits<char>::eof()) return false;
@@ -22,71 +65,75 @@ bool BatchReader::load_batch(std::vector<std::string> &lines) {
     }
     size_t bases = 0, reads = 0, nlines = 0, record = 0;
     const size_t num_bases = 1000;
-    std::string buf;
     bool valid = false;
-    while (in_.good() && (bases < num_bases || reads < min_reads_)) {
-        if (!std::getline(in_, buf)) {
-            if (format_ == 1 && nlines % 4 == 0) return valid || !lines.empty();
-            if (format_ == 0 && nlines % 2 == 0) return valid || !lines.empty();
+    while (src_.good() && (bases < num_bases || reads < min_reads_)) {
+        const char *p;
+        size_t n;
+        if (!src_.getline(p, n)) {
+            if (format_ == 1 && nlines % 4 == 0) return valid || !lines_.empty();
+            if (format_ == 0 && nlines % 2 == 0) return valid || !lines_.empty();
             // the reference returns false here and drops the partial batch (:57-63)
-            lines.clear();
+            lines_.clear();
             return false;
         }
         nlines++;
-        record += buf.size();
+        record += n;
         valid = true;
+        lines_.push_back(Span{arena_.size(), n});
+        arena_.append(p, n);
         if (format_ == 1) {
             if (nlines % 4 == 0) { bases += record / 2; record = 0; reads++; }
-        } else if (in_.peek() == '>') {
+        } else if (src_.peek() == '>') {
             bases += record; record = 0; reads++;
         }
-        lines.push_back(buf);
     }
     return valid;
 }
 
-static void strip_trailing_space(std::string &s) {
-    while (!s.empty() && std::isspace(static_cast<unsigned char>(s.back()))) s.pop_back();
+static size_t rstrip_len(const char *p, size_t n) {
+    while (n > 0 && std::isspace(static_cast<unsigned char>(p[n - 1]))) n--;
+    return n;
 }
 
 bool BatchReader::next_chunk(ReadSet &out, uint64_t max_bases) {
     out.ids.clear(); out.bases.clear(); out.offsets.assign(1, 0); out.batch_of.clear();
-    std::vector<std::string> lines;
     bool any = false;
     while (out.bases.size() < max_bases) {
-        if (!load_batch(lines)) break;
+        if (!load_batch()) break;
         any = true;
         const uint32_t b = batch_counter_++;
         // grabNextRead over the batch (src/batch_loader.cpp:91-143)
         size_t p = 0;
-        while (p < lines.size()) {
-            const std::string &hdr = lines[p];
-            if (hdr.empty()) break;                                    // ":99 an empty line" ends the batch
+        const size_t nl = lines_.size();
+        auto line = [&](size_t i) { return arena_.data() + lines_[i].off; };
+        while (p < nl) {
+            const char *hdr = line(p);
+            const size_t hn = lines_[p].len;
+            if (hn == 0) break;                                        // ":99 an empty line" ends the batch
             if (format_ == 1 && hdr[0] != '@')
                 throw std::runtime_error(std::string("Incorrect FASTQ entry, it should start with '@' but found ") + hdr[0]);
             if (format_ == 0 && hdr[0] != '>')
                 throw std::runtime_error(std::string("Incorrect FASTA entry, it should start with '>' but found ") + hdr[0]);
-            if (hdr.size() <= 2) throw std::runtime_error("header line is missing an id. invalid query cannot be processed.");
-            size_t id_len = hdr.find_first_of(" \t\r", 1);
-            if (id_len == std::string::npos) id_len = hdr.size();
-            std::string id = hdr.substr(1, id_len);                    // NB: a length, so the whitespace char is kept
+            if (hn <= 2) throw std::runtime_error("header line is missing an id. invalid query cannot be processed.");
+            size_t id_len = hn;                                        // find_first_of(" \t\r", 1)
+            for (size_t i = 1; i < hn; i++)
+                if (hdr[i] == ' ' || hdr[i] == '\t' || hdr[i] == '\r') { id_len = i; break; }
+            // substr(1, id_len): id_len is used as a LENGTH, so the whitespace char is kept
+            out.ids.emplace_back(hdr + 1, std::min(id_len, hn - 1));
             p++;
-            std::string seq;
             if (format_ == 1) {
-                if (p >= lines.size()) break;
-                seq = lines[p++];
-                strip_trailing_space(seq);
-                if (p + 1 >= lines.size()) break;                      // '+' line and qualities must exist
-                p += 2;
+                if (p >= nl) { out.ids.pop_back(); break; }
+                const size_t sn = rstrip_len(line(p), lines_[p].len);
+                if (p + 2 >= nl) { out.ids.pop_back(); break; }        // '+' line and qualities must exist
+                out.bases.insert(out.bases.end(), line(p), line(p) + sn);
+                p += 3;
             } else {
-                while (p < lines.size() && (lines[p].empty() || lines[p][0] != '>')) {
-                    std::string l = lines[p++];
-                    strip_trailing_space(l);
-                    seq += l;
+                while (p < nl && (lines_[p].len == 0 || line(p)[0] != '>')) {
+                    const size_t sn = rstrip_len(line(p), lines_[p].len);
+                    out.bases.insert(out.bases.end(), line(p), line(p) + sn);
+                    p++;
                 }
             }
-            out.ids.push_back(std::move(id));
-            out.bases.insert(out.bases.end(), seq.begin(), seq.end());
             out.offsets.push_back(out.bases.size());
             out.batch_of.push_back(b);
         }
