@@ -14,6 +14,7 @@
  *   MoveStructure::query_pml        src/move_structure_query.cpp:234-474  movi_pml_host / movi_pml_device
  *   MoveStructure::query_backward_search  src/move_structure_search.cpp:340-352   movi_count_host / movi_count_device
  *   ReadProcessor::backward_search + compute_match_count  src/read_processor.cpp:610-620,1096-1175   movi_count_host / movi_count_device
+ *   Classifier::classify (bins)     src/classifier.cpp:99-143           movi_classify_device / movi_pml_classify_host
  *
  * Conventions: every entry point returns an int status (MOVI_OK == 0) and never
  * throws; movi_last_error() gives the message for the calling thread.  One
@@ -130,6 +131,27 @@ int movi_pml_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_of
 /* Device-side counters of the last movi_pml_device / movi_count_device call on
  * this handle; synchronises `stream` first. */
 int movi_last_stats(movi_index_t *ix, void *stream, movi_query_stats_t *stats);
+
+/* ---- binary classification bins ------------------------------------------------ */
+
+/* The per-read reduction of Classifier::classify (src/classifier.cpp:99-143) over PML vectors
+ * that are already on the device: bins of bin_width PMLs in emission order, the last bin
+ * absorbing a remainder shorter than bin_width; per read the number of bins whose maximum is
+ * >= max_value_thr (bins_above) / below it, and the sum of the bin maxima.  The verdict is
+ * FOUND iff bins_above / (bins_above + bins_below) > 0.5; the report's average is
+ * sum_max / (bins_above + bins_below).  max_value_thr = max(percentile, 3) + 1 from
+ * DIR/movi.pml.nulldb (src/classifier.cpp:30-33). */
+int movi_classify_device(movi_index_t *ix, const uint16_t *d_pml, const uint64_t *d_offsets,
+                         uint64_t n_reads, uint32_t bin_width, uint32_t max_value_thr,
+                         uint32_t *d_bins_above, uint32_t *d_bins_below, uint64_t *d_sum_max,
+                         void *stream);
+
+/* PML query + the reduction above in one call; the PML vectors never leave the GPU (what
+ * `movi query --classify --filter` needs: 16 bytes back per read instead of 2 per base). */
+int movi_pml_classify_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_offsets,
+                           uint64_t n_reads, uint32_t bin_width, uint32_t max_value_thr,
+                           uint32_t *h_bins_above, uint32_t *h_bins_below, uint64_t *h_sum_max,
+                           uint8_t *h_read_err, movi_query_stats_t *stats);
 
 /* ---- count (backward search) -------------------------------------------------- */
 

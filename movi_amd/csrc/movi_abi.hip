@@ -438,6 +438,68 @@ int movi_pml_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_of
     return MOVI_OK;
 }
 
+// ----------------------------------------------------------------- classification
+
+int movi_classify_device(movi_index_t *ix, const uint16_t *d_pml, const uint64_t *d_offsets, uint64_t n_reads,
+                         uint32_t bin_width, uint32_t max_value_thr, uint32_t *d_bins_above, uint32_t *d_bins_below,
+                         uint64_t *d_sum_max, void *stream) {
+    if (!ix) return fail(MOVI_ERR_ARG, "index handle is NULL");
+    if (n_reads == 0) return MOVI_OK;
+    if (!d_pml || !d_offsets || !d_bins_above || !d_bins_below || !d_sum_max) return fail(MOVI_ERR_ARG, "NULL device buffer");
+    if (bin_width == 0) return fail(MOVI_ERR_ARG, "bin_width must be > 0");
+    HIP_TRY(hipSetDevice(ix->device));
+    HIP_TRY(launch_classify(d_pml, d_offsets, n_reads, bin_width, max_value_thr, d_bins_above, d_bins_below, d_sum_max,
+                            static_cast<hipStream_t>(stream)));
+    return MOVI_OK;
+}
+
+int movi_pml_classify_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_offsets, uint64_t n_reads,
+                           uint32_t bin_width, uint32_t max_value_thr, uint32_t *h_bins_above, uint32_t *h_bins_below,
+                           uint64_t *h_sum_max, uint8_t *h_read_err, movi_query_stats_t *stats) {
+    if (!ix) return fail(MOVI_ERR_ARG, "index handle is NULL");
+    if (n_reads == 0) { if (stats) memset(stats, 0, sizeof(*stats)); return MOVI_OK; }
+    if (!h_offsets || !h_bins_above || !h_bins_below || !h_sum_max || (h_offsets[n_reads] != h_offsets[0] && !h_bases))
+        return fail(MOVI_ERR_ARG, "NULL host buffer");
+    if (bin_width == 0) return fail(MOVI_ERR_ARG, "bin_width must be > 0");
+    HIP_TRY(hipSetDevice(ix->device));
+    DevBuf d_out, d_a, d_b, d_s;
+    uint64_t out_cap = 0, cap = 0;
+    auto launch = [&](const uint8_t *db, const uint64_t *dof, uint64_t nr, uint64_t nb, uint8_t *derr,
+                      const uint32_t *dord) -> int {
+        if (nb > out_cap) {
+            if (d_out.p) { (void)hipFree(d_out.p); d_out.p = nullptr; }
+            HIP_TRY(d_out.alloc(nb * 2));
+            out_cap = nb;
+        }
+        if (nr > cap) {
+            for (DevBuf *x : {&d_a, &d_b, &d_s}) if (x->p) { (void)hipFree(x->p); x->p = nullptr; }
+            HIP_TRY(d_a.alloc(nr * 4));
+            HIP_TRY(d_b.alloc(nr * 4));
+            HIP_TRY(d_s.alloc(nr * 8));
+            cap = nr;
+        }
+        int rc = movi_pml_device(ix, db, dof, nr, nb, static_cast<uint16_t *>(d_out.p), derr, dord, nullptr);
+        if (rc) return rc;
+        return movi_classify_device(ix, static_cast<const uint16_t *>(d_out.p), dof, nr, bin_width, max_value_thr,
+                                    static_cast<uint32_t *>(d_a.p), static_cast<uint32_t *>(d_b.p),
+                                    static_cast<uint64_t *>(d_s.p), nullptr);
+    };
+    auto fetch = [&](uint64_t first, uint64_t nr, uint64_t, uint64_t) -> int {     // the PMLs stay on the GPU
+        HIP_TRY(hipMemcpy(h_bins_above + first, d_a.p, nr * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(h_bins_below + first, d_b.p, nr * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(h_sum_max + first, d_s.p, nr * 8, hipMemcpyDeviceToHost));
+        return MOVI_OK;
+    };
+    movi_query_stats_t local{};
+    int rc = run_chunked(ix, h_bases, h_offsets, n_reads, h_read_err, &local, launch, fetch);
+    if (stats) *stats = local;
+    if (rc) return rc;
+    if (local.errors)
+        return fail(MOVI_ERR_INVARIANT, std::to_string(local.errors) +
+                                            " read(s) hit a move-structure invariant violation (corrupt index?)");
+    return MOVI_OK;
+}
+
 // -------------------------------------------------------------------------- count
 
 static int ensure_ckpt(movi_index *ix, hipStream_t s) {

@@ -734,6 +734,62 @@ hipError_t launch_count(int mode, const DevIndex &ix, const uint8_t *d_bases, co
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------ classification bins
+// Classifier::classify, src/classifier.cpp:99-143: the PML vector (emission order) is cut into
+// bins of bin_width, the LAST bin absorbing a remainder shorter than bin_width; per read the
+// number of bins whose maximum is >= thr / < thr and the sum of the bin maxima.  One lane per
+// read, PMLs fetched 8 at a time (16-byte loads; the vector was just written, L2/MALL-warm).
+__global__ __launch_bounds__(256) void classify_kernel(const uint16_t *__restrict__ pml,
+                                                       const uint64_t *__restrict__ offs, uint64_t n_reads,
+                                                       uint32_t bin_width, uint32_t thr,
+                                                       uint32_t *__restrict__ above, uint32_t *__restrict__ below,
+                                                       uint64_t *__restrict__ sum_max) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_reads) return;
+    const uint64_t beg = offs[t], n = offs[t + 1] - beg;
+    const uint16_t *P = pml + beg;
+    uint64_t nb = n / bin_width;                          // bins: [iW, (i+1)W) for i < nb-1, last = [(nb-1)W, n)
+    if (nb == 0) nb = 1;
+    uint32_t a = 0, b = 0, cur = 0;
+    uint64_t sum = 0, bin = 0, next_cut = (nb > 1) ? bin_width : n;
+    uint64_t k = 0;
+    while (k < n) {
+        uint16_t v[8];
+        uint32_t m = 8;
+        if (k + 8 <= n) {
+            __builtin_memcpy(v, P + k, 16);
+        } else {
+            m = (uint32_t)(n - k);
+            for (uint32_t i = 0; i < m; ++i) v[i] = P[k + i];
+        }
+        for (uint32_t i = 0; i < m; ++i) {
+            cur = v[i] > cur ? v[i] : cur;
+            if (k + i + 1 == next_cut) {
+                if (cur >= thr) a += 1; else b += 1;
+                sum += cur;
+                cur = 0;
+                bin += 1;
+                next_cut = (bin + 1 < nb) ? next_cut + bin_width : n;
+            }
+        }
+        k += m;
+    }
+    above[t] = a;
+    below[t] = b;
+    sum_max[t] = sum;
+}
+
+hipError_t launch_classify(const uint16_t *d_pml, const uint64_t *d_offsets, uint64_t n_reads, uint32_t bin_width,
+                           uint32_t thr, uint32_t *d_above, uint32_t *d_below, uint64_t *d_sum, hipStream_t stream) {
+    if (n_reads == 0) return hipSuccess;
+    const unsigned bt = 256;
+    const uint64_t blocks = (n_reads + bt - 1) / bt;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(classify_kernel, dim3((unsigned)blocks), dim3(bt), 0, stream, d_pml, d_offsets, n_reads, bin_width,
+                       thr, d_above, d_below, d_sum);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------- row-start checkpoints (setup)
 
 template <int MODE>

@@ -143,6 +143,20 @@ class MoveIndex:
         out, _ = self.query_pml_packed(bases, offs)
         return [out[int(offs[i]): int(offs[i + 1])] for i in range(len(reads))]
 
+    def classify_packed(self, bases, offs, bin_width, max_value_thr):
+        """PML + Classifier::classify bins on the device: (bins_above, bins_below, sum_max) per read."""
+        bases = np.ascontiguousarray(bases, np.uint8)
+        offs = np.ascontiguousarray(offs, np.uint64)
+        n = offs.size - 1
+        a = np.zeros(max(n, 1), np.uint32)
+        b = np.zeros(max(n, 1), np.uint32)
+        s = np.zeros(max(n, 1), np.uint64)
+        st = QueryStatsC()
+        check(lib().movi_pml_classify_host(self._h, bases.ctypes.data, offs.ctypes.data, n, int(bin_width),
+                                           int(max_value_thr), a.ctypes.data, b.ctypes.data, s.ctypes.data,
+                                           None, C.byref(st)))
+        return a[:n], b[:n], s[:n]
+
     def query_count_packed(self, bases, offs):
         bases = np.ascontiguousarray(bases, np.uint8)
         offs = np.ascontiguousarray(offs, np.uint64)

@@ -144,7 +144,12 @@ int run_query(const Options &o) {
             for (auto &c : rs.bases)
                 if (desc.code_of[c] == 0xFF) c = 'A';
         }
-        pml.assign(o.pml ? rs.bases.size() : 0, 0);
+        // --classify with --filter / --no-output needs verdicts only: the bins are reduced on the
+        // GPU and the PML vectors never cross PCIe
+        const bool verdict_only = o.pml && o.classify && !o.write_output_allowed();
+        std::vector<uint32_t> bins_above(verdict_only ? n : 0), bins_below(verdict_only ? n : 0);
+        std::vector<uint64_t> bins_sum(verdict_only ? n : 0);
+        pml.assign(o.pml && !verdict_only ? rs.bases.size() : 0, 0);
         matched.assign(o.count ? n : 0, 0);
         counts.assign(o.count ? n : 0, 0);
         err.assign(n, 0);
@@ -155,7 +160,11 @@ int run_query(const Options &o) {
             const size_t a = sb[g], b = sb[g + 1];
             if (a == b) return;
             int rc;
-            if (o.pml)
+            if (verdict_only)
+                rc = movi_pml_classify_host(handles[g], rs.bases.data(), rs.offsets.data() + a, b - a, (uint32_t)o.bin_width,
+                                            classifier.max_value_thr, bins_above.data() + a, bins_below.data() + a,
+                                            bins_sum.data() + a, err.data() + a, nullptr);
+            else if (o.pml)
                 rc = movi_pml_host(handles[g], rs.bases.data(), rs.offsets.data() + a, b - a, pml.data(), err.data() + a, nullptr);
             else
                 rc = movi_count_host(handles[g], rs.bases.data(), rs.offsets.data() + a, b - a, matched.data() + a,
@@ -186,10 +195,11 @@ int run_query(const Options &o) {
         for (uint32_t i : order) {
             const uint64_t len = rs.len(i);
             if (o.pml) {
-                const uint16_t *p = pml.data() + rs.offsets[i];
+                const uint16_t *p = verdict_only ? nullptr : pml.data() + rs.offsets[i];
                 if (o.classify) {                                     // write_mls, src/read_processor.cpp:565-578
-                    const bool found = classifier.classify(rs.ids[i], p, len, o.bin_width,
-                                                           o.write_output_allowed() ? report : nullptr);
+                    const bool found = verdict_only
+                        ? (bins_above[i] / (bins_above[i] + bins_below[i] + 0.0) > 0.50)      // classifier.cpp:119
+                        : classifier.classify(rs.ids[i], p, len, o.bin_width, o.write_output_allowed() ? report : nullptr);
                     if (o.filter && !o.no_output && (found != o.invert)) {
                         const uint8_t *seq = (original.empty() ? rs.bases.data() : original.data()) + rs.offsets[i];
                         std::cout << ">" << rs.ids[i] << "\n";

@@ -249,3 +249,29 @@ def test_large_count_batch_properties(built_lib, mode):
     sl = slice(500_000, 503_000)
     em, ec = cpu.count_batch(bases2[sl.start * L: sl.stop * L], offs2[sl.start: sl.stop + 1] - offs2[sl.start], threads=8)
     assert (m2[sl] == em).all() and (c2[sl] == ec).all()
+
+
+@pytest.mark.parametrize("bin_width,thr", [(150, 7), (40, 4), (1, 1), (1000, 20)])
+def test_classification_bins_on_device(engines, bin_width, thr):
+    """movi_pml_classify_host == Classifier::classify's bins (src/classifier.cpp:99-143) applied to the
+    oracle's PML vectors: bins in emission order, last bin absorbs a short remainder."""
+    from oracle import build_index as B
+    gpu, cpu = engines[6]
+    ref = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))[0][1]
+    rng = np.random.default_rng(bin_width + thr)
+    reads = mutated_reads(rng, ref, 400, 1, 1200) + [b"", b"A", ref[:149], ref[:150], ref[:151], ref[:299], ref[:300], ref[:449]]
+    bases, offs = pack(reads)
+    a, b, s = gpu.classify_packed(bases, offs, bin_width, thr)
+    for i, r in enumerate(reads):
+        p = cpu.pml(r)
+        n, start, ea, eb, es = len(p), 0, 0, 0, 0
+        while start < n:
+            end = start + bin_width if start + bin_width < n else n
+            if n - end < bin_width:
+                end = n
+            mx = int(p[start:end].max())
+            ea += mx >= thr
+            eb += mx < thr
+            es += mx
+            start = end
+        assert (int(a[i]), int(b[i]), int(s[i])) == (ea, eb, es), (i, len(r))
