@@ -548,6 +548,140 @@ __global__ __launch_bounds__(256) void pml_kernel_sm(DevIndex ix, const uint8_t 
     }
 }
 
+// VARIANT 7 ("flat state machine"): the same per-lane automaton as pml_kernel_sm, written as
+// straight-line predicated code.  pml_kernel_sm runs latency-bound (1-2 waves per SIMD on long-read
+// batches) and spends ~37 % of its wave cycles issuing ~270 instructions per iteration, many of
+// them exec-mask bookkeeping and phi copies of its nested divergent branches.  Here every state
+// update is a select, the only branches guard memory side effects, and the base code of step k
+// is looked up in LDS when k advances -- the lookup then overlaps the next row gather instead of
+// sitting between the row's arrival and the compare.
+// IdxT = uint32_t when the table has fewer than 2^32 rows (half the index arithmetic).
+template <int MODE, typename IdxT>
+__global__ __launch_bounds__(256) void pml_kernel_flat(DevIndex ix, const uint8_t *__restrict__ bases,
+                                                       const uint64_t *__restrict__ offs, uint64_t n_reads,
+                                                       uint16_t *__restrict__ out, uint8_t *__restrict__ err,
+                                                       DevStats *stats, const uint32_t *__restrict__ order) {
+    enum : uint32_t { sFF = 0, sDown = 1, sUp = 2, sDone = 3 };
+    __shared__ uint8_t s_code[256];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = ix.code_of[i];
+    __syncthreads();
+
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t ff_total = 0, scan_total = 0, repo_total = 0, failed = 0;
+    const bool valid = t < n_reads;
+    const uint64_t rid = (valid && order) ? order[t] : t;
+    const uint64_t beg = valid ? offs[rid] : 0;
+    const uint32_t len = valid ? (uint32_t)(offs[rid + 1] - beg) : 0;   // reads are shorter than 2^32 (checked on the host)
+    const uint8_t *R = bases + beg;
+    uint16_t *O = out + beg;
+    const uint32_t packed_end = len & ~7u;
+    const IdxT r1 = (IdxT)(ix.r - 1), end_row = (IdxT)ix.end_bwt_idx;
+
+    auto load_chunk = [&](uint32_t kk) -> uint64_t {
+        uint64_t v = 0;
+        if (beg + len >= (uint64_t)kk + 8) {
+            __builtin_memcpy(&v, R + len - kk - 8, 8);    // may start before R: still inside `bases`
+        } else {
+            for (uint32_t i = 0; i < len - kk; ++i) v |= (uint64_t)R[len - 1 - kk - i] << (8 * (7 - i));
+        }
+        return v;
+    };
+
+    uint32_t st = len > 0 ? sFF : sDone;
+    IdxT need = r1;                                       // ReadProcessor::reset_process :69-70
+    uint32_t k = 0;
+    uint32_t ml = 0, ff_run = 0;
+    uint32_t off = row_n<MODE>(load_row<MODE>(ix.rows, r1)) - 1;
+    uint64_t rb = st != sDone ? load_chunk(0) : 0;
+    uint32_t a = s_code[(uint32_t)(rb >> 56) & 0xFFu];    // code of the base of step k (k = 0)
+    uint4 pk = make_uint4(0, 0, 0, 0);
+
+    while (wave_any(st != sDone)) {
+        uint2 row = make_uint2(0, 0);
+        if (st != sDone) row = load_row<MODE>(ix.rows, need);
+        const uint32_t n = row_n<MODE>(row), c = row_c<MODE>(row);
+        // predicates as 0/1 integers combined with & | (no short-circuit control flow)
+        const uint32_t isFF = st == sFF, isDown = st == sDown, isUp = st == sUp;
+        // fast_forward, move_structure.cpp:524-545
+        const uint32_t ffm = isFF & (uint32_t)(need < r1) & (uint32_t)(off >= n);
+        const uint32_t ff_over = ffm & (uint32_t)(ff_run + 1 >= 65535u);  // :72-75
+        const uint32_t resolved = isFF & (ffm ^ 1u);
+        // the base of step k against the row (read_processor.cpp:188-238)
+        const uint32_t illegal = a == 0xFFu, match = c == a;
+        const uint32_t mism = resolved & (illegal ^ 1u) & (match ^ 1u);
+        // reposition_thresholds, src/move_structure_query.cpp:513-601
+        const uint32_t kk = (a - (uint32_t)(a > c)) & 3u;                 // alphamap_3[c][a]
+        const uint32_t thr = row_thr<MODE>(row, kk > 2u ? 2u : kk) ? n : 0u;
+        const uint64_t et = a == 1 ? ix.end_thr[1] : (a == 2 ? ix.end_thr[2] : ix.end_thr[3]);
+        const uint32_t down = (need == end_row) ? (uint32_t)((uint64_t)off >= et) : (uint32_t)(off >= thr);
+        const uint32_t at_last = need >= r1, at_first = need == 0;
+        const uint32_t repo_edge = mism & (down ? at_last : at_first);
+        // reposition_down :211-232 / reposition_up :188-209, one row per iteration
+        const uint32_t scanning = isDown | isUp;
+        const uint32_t hit = scanning & match;
+        const uint32_t scan_edge = scanning & (hit ^ 1u) & (isDown ? at_last : at_first);
+        const uint32_t emit = (resolved & (illegal | match)) | hit;
+        const uint32_t errc = ff_over ? kErrFastForward
+                              : (repo_edge ? (down ? kErrNoRunBelow : kErrNoRunAbove)
+                                 : (scan_edge ? (isDown ? kErrNoRunBelow : kErrNoRunAbove) : kErrNone));
+        // ---- state update, all selects
+        ml = resolved ? (match ? ml + 1 : 0u) : ml;
+        ff_total += resolved ? ff_run : 0u;
+        ff_run += ffm;
+        repo_total += mism;
+        scan_total += scanning;
+        off = ffm ? off - n : (hit ? (isDown ? 0u : n - 1) : off);        // read_processor.cpp:223
+        const uint32_t step_fwd = ffm | (mism & down) | (scanning & (hit ^ 1u) & isDown);
+        const uint32_t step_back = (mism & (down ^ 1u)) | (scanning & (hit ^ 1u) & isUp);
+        IdxT need_next = need + step_fwd - step_back;
+        uint32_t st_next = mism ? (down ? sDown : sUp) : st;
+        if (emit) {
+            const uint32_t val = ml > 65535u ? 65535u : ml;               // MoveQuery::add_ml
+            if (k >= packed_end) {
+                O[k] = (uint16_t)val;
+            } else {
+                pk.x = (pk.x >> 16) | (pk.y << 16);
+                pk.y = (pk.y >> 16) | (pk.z << 16);
+                pk.z = (pk.z >> 16) | (pk.w << 16);
+                pk.w = (pk.w >> 16) | (val << 16);
+                if ((k & 7) == 7) __builtin_memcpy(O + (k - 7), &pk, 16);
+            }
+            k += 1;
+            if (k == len) {
+                st_next = sDone;
+            } else {
+                const uint64_t j = row_id<MODE>(row, need, ix);           // LF_move, move_structure.cpp:59-67
+                if (j >= ix.r) {
+                    failed = kErrIdRange;
+                    st_next = sDone;
+                } else {
+                    off += row_off<MODE>(row);
+                    need_next = (IdxT)j;
+                    ff_run = 0;
+                    st_next = sFF;
+                    if ((k & 7) == 0) rb = load_chunk(k);
+                    a = s_code[(uint32_t)(rb >> (8 * (7 - (k & 7)))) & 0xFFu];
+                }
+            }
+        }
+        if (errc) { failed = errc; st_next = sDone; }
+        need = need_next;
+        st = st_next;
+    }
+    if (failed) {
+        for (uint32_t i = 0; i < len; ++i) O[i] = 0;
+    }
+    if (valid && err) err[rid] = (uint8_t)failed;
+    const uint32_t ffw = wave_sum(ff_total), scw = wave_sum(scan_total), rpw = wave_sum(repo_total),
+                   erw = wave_sum(failed ? 1u : 0u);
+    if ((threadIdx.x & 63) == 0 && stats) {
+        if (ffw) atomicAdd(&stats->fast_forwards, (unsigned long long)ffw);
+        if (scw) atomicAdd(&stats->scans, (unsigned long long)scw);
+        if (rpw) atomicAdd(&stats->repositions, (unsigned long long)rpw);
+        if (erw) atomicAdd(&stats->errors, (unsigned long long)erw);
+    }
+}
+
 hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets,
                       uint64_t n_reads, uint16_t *d_out, uint8_t *d_err, DevStats *d_stats,
                       const uint32_t *d_order, const LaunchCfg &cfg, hipStream_t stream) {
@@ -579,23 +713,36 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
 #define MOVI_LAUNCH_SM(M, N)                                                                                \
     hipLaunchKernelGGL((pml_kernel_sm<M, N>), grid, block, dyn_lds, stream, ix, d_bases, d_offsets, n_reads, \
                        d_out, d_err, d_stats, d_order)
+#define MOVI_LAUNCH_FLAT(M)                                                                                 \
+    do {                                                                                                    \
+        if (ix.r < 0xFFFFFFFFull)                                                                           \
+            hipLaunchKernelGGL((pml_kernel_flat<M, uint32_t>), grid, block, dyn_lds, stream, ix, d_bases,   \
+                               d_offsets, n_reads, d_out, d_err, d_stats, d_order);                         \
+        else                                                                                                \
+            hipLaunchKernelGGL((pml_kernel_flat<M, uint64_t>), grid, block, dyn_lds, stream, ix, d_bases,   \
+                               d_offsets, n_reads, d_out, d_err, d_stats, d_order);                         \
+    } while (0)
     // Auto selection (measured on MI355X, profiles/): with plenty of reads (> ~10 waves per CU)
     // the base-synchronous packed kernel (1) wins because its neighbour loads follow the gather
     // at once and hit L2; with few reads in flight (long-read batches, small shards) the lane
-    // state machine (2) wins because it needs ~2.3 instead of ~11 dependent trips per base.
+    // state machine wins because it needs ~2.3 instead of ~11 dependent trips per base -- in its
+    // flat predicated form (7), which is 11-12 % faster than the branchy one (2).
     int v = cfg.pml_variant;
-    if (v < 0) v = (n_reads <= (uint64_t)cfg.num_cus * 64u * 10u) ? 2 : 1;
+    if (v < 0) v = (n_reads <= (uint64_t)cfg.num_cus * 64u * 10u) ? 7 : 1;
     if (mode == 6) {
         if (v == 0) MOVI_LAUNCH_PML(6, 0, 1); else if (v == 1) MOVI_LAUNCH_PML(6, 1, 1);
         else if (v == 4) MOVI_LAUNCH_PML(6, 1, 2); else if (v == 5) MOVI_LAUNCH_PML(6, 1, 4);
-        else if (v == 2) MOVI_LAUNCH_SM(6, 1); else if (v == 3) MOVI_LAUNCH_SM(6, 2); else MOVI_LAUNCH_SM(6, 4);
+        else if (v == 2) MOVI_LAUNCH_SM(6, 1); else if (v == 3) MOVI_LAUNCH_SM(6, 2); else if (v == 6) MOVI_LAUNCH_SM(6, 4);
+        else MOVI_LAUNCH_FLAT(6);
     } else {
         if (v == 0) MOVI_LAUNCH_PML(8, 0, 1); else if (v == 1) MOVI_LAUNCH_PML(8, 1, 1);
         else if (v == 4) MOVI_LAUNCH_PML(8, 1, 2); else if (v == 5) MOVI_LAUNCH_PML(8, 1, 4);
-        else if (v == 2) MOVI_LAUNCH_SM(8, 1); else if (v == 3) MOVI_LAUNCH_SM(8, 2); else MOVI_LAUNCH_SM(8, 4);
+        else if (v == 2) MOVI_LAUNCH_SM(8, 1); else if (v == 3) MOVI_LAUNCH_SM(8, 2); else if (v == 6) MOVI_LAUNCH_SM(8, 4);
+        else MOVI_LAUNCH_FLAT(8);
     }
 #undef MOVI_LAUNCH_PML
 #undef MOVI_LAUNCH_SM
+#undef MOVI_LAUNCH_FLAT
     return hipGetLastError();
 }
 

@@ -33,7 +33,7 @@ struct DevStats {
 struct LaunchCfg {
     int block_threads = 256;
     // -1 auto; base-synchronous pml_kernel: 0 (plain I/O), 1 / 4 / 5 (packed I/O, 1 / 2 / 4 neighbour rows per trip);
-    // lane state machine pml_kernel_sm: 2 / 3 / 6 (1 / 2 / 4-row window per iteration)
+    // lane state machine pml_kernel_sm: 2 / 3 / 6 (1 / 2 / 4-row window per iteration); 7: pml_kernel_flat
     int pml_variant = -1;
     int num_cus = 256;
     int waves_per_cu = 0;  // 0 = no cap; else cap resident waves per CU by padding the block's LDS allocation

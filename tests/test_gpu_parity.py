@@ -85,7 +85,7 @@ def test_pml_ragged_reads_vs_oracle(engines, mode):
 
 
 @pytest.mark.parametrize("mode", [6, 8])
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7])
 def test_pml_kernel_variants_vs_oracle(engines, mode, variant):
     """Every selectable kernel variant is held to the same bit-exact bar, including
     reads whose length is not a multiple of the 8-step packing and unaligned offsets."""
