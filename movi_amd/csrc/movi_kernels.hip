@@ -722,13 +722,13 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
             hipLaunchKernelGGL((pml_kernel_flat<M, uint64_t>), grid, block, dyn_lds, stream, ix, d_bases,   \
                                d_offsets, n_reads, d_out, d_err, d_stats, d_order);                         \
     } while (0)
-    // Auto selection (measured on MI355X, profiles/): with plenty of reads (> ~10 waves per CU)
+    // Auto selection (measured on MI355X, profiles/): with plenty of reads (> ~12 waves per CU)
     // the base-synchronous packed kernel (1) wins because its neighbour loads follow the gather
     // at once and hit L2; with few reads in flight (long-read batches, small shards) the lane
     // state machine wins because it needs ~2.3 instead of ~11 dependent trips per base -- in its
     // flat predicated form (7), which is 11-12 % faster than the branchy one (2).
     int v = cfg.pml_variant;
-    if (v < 0) v = (n_reads <= (uint64_t)cfg.num_cus * 64u * 10u) ? 7 : 1;
+    if (v < 0) v = (n_reads <= (uint64_t)cfg.num_cus * 64u * 12u) ? 7 : 1;   // measured crossover: ~12 waves per CU
     if (mode == 6) {
         if (v == 0) MOVI_LAUNCH_PML(6, 0, 1); else if (v == 1) MOVI_LAUNCH_PML(6, 1, 1);
         else if (v == 4) MOVI_LAUNCH_PML(6, 1, 2); else if (v == 5) MOVI_LAUNCH_PML(6, 1, 4);
