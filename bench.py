@@ -118,11 +118,19 @@ def main():
             print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    # test hook for 1-GPU boxes: MOVI_BENCH_SHARE_GPU=1 runs every rank on cuda:0 over gloo so that the
+    # N>1 code path (index broadcast, per-rank read shards, max-over-ranks timing) can be exercised
+    share_gpu = os.environ.get("MOVI_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     wl = dict(WORKLOADS[args.workload])
     if args.rows: wl["rows"] = args.rows
