@@ -275,3 +275,51 @@ def test_classification_bins_on_device(engines, bin_width, thr):
             es += mx
             start = end
         assert (int(a[i]), int(b[i]), int(s[i])) == (ea, eb, es), (i, len(r))
+
+
+@pytest.mark.parametrize("alphabet", [b"ACGT", b"ACG", b"AT", b"GT", b"C"])
+def test_fuzz_small_indexes(built_lib, tmp_path, alphabet):
+    """Many tiny indexes with awkward structure (reduced alphabets -> shifted codes and a shorter
+    base-interval table, long runs split at MAX_RUN_LENGTH, repeats, the terminator row in odd
+    places), built by tools/build_index; PML + count on the GPU vs the oracle, both modes."""
+    import subprocess
+    import movi_amd
+    from oracle.oracle import Oracle
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "build_index")
+    if not os.path.exists(tool):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", tool, tool + ".cpp"])
+    rng = np.random.default_rng(len(alphabet) * 1000 + alphabet[0])
+    for trial in range(6):
+        recs = []
+        for _ in range(int(rng.integers(1, 4))):
+            unit = bytes(rng.choice(list(alphabet), size=int(rng.integers(5, 400))).astype(np.uint8))
+            s = unit * int(rng.integers(1, 6)) + bytes([alphabet[0]]) * int(rng.integers(0, 3000))
+            recs.append(s)
+        fa = tmp_path / ("f%d.fa" % trial)
+        fa.write_bytes(b"".join(b">s%d\n%s\n" % (i, s) for i, s in enumerate(recs)))
+        text = b"".join(recs)
+        reads = []
+        for _ in range(120):
+            L = int(rng.integers(1, 300))
+            p = int(rng.integers(0, max(1, len(text) - L)))
+            r = bytearray(text[p:p + L])
+            for k in range(len(r)):
+                if rng.random() < 0.05:
+                    r[k] = b"ACGTN"[rng.integers(0, 5)]
+            reads.append(bytes(r))
+        bases, offs = pack(reads)
+        for mode in (6, 8):
+            out_dir = str(tmp_path / ("i%d_%d" % (trial, mode)))
+            subprocess.check_call([tool, "fasta", str(fa), str(mode), out_dir], stderr=subprocess.DEVNULL)
+            img = open(os.path.join(out_dir, "index.movi"), "rb").read()
+            gpu, cpu = movi_amd.MoveIndex.from_image(img), Oracle(img)
+            for variant in (1, 7):
+                gpu.set_option("pml_variant", variant)
+                out, st = gpu.query_pml_packed(bases, offs)
+                exp, ff, sc = cpu.pml_batch(bases, offs, threads=2)
+                assert (out == exp).all(), (alphabet, trial, mode, variant)
+                assert (st.fast_forwards, st.scans, st.errors) == (ff, sc, 0)
+            m, c, _ = gpu.query_count_packed(bases, offs)
+            em, ec = cpu.count_batch(bases, offs, threads=2)
+            assert (m == em).all() and (c == ec).all(), (alphabet, trial, mode)
+            gpu.close()
