@@ -176,6 +176,11 @@ static int finish_create(movi_index *ix) {
     v.end_bwt_idx = d.end_bwt_idx;
     v.n_blocks = d.n_blocks;
     v.block_size = d.block_size ? d.block_size : 1;
+    v.block_shift = 0xFFFFFFFFu;
+    if ((v.block_size & (v.block_size - 1)) == 0) {
+        v.block_shift = 0;
+        while ((1ull << v.block_shift) < v.block_size) v.block_shift++;
+    }
     for (int i = 0; i < 4; i++) v.end_thr[i] = d.end_bwt_idx_thresholds[i];
     for (int i = 0; i < 5; i++) {
         v.first_runs[i] = d.first_runs[i];

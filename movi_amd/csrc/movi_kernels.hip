@@ -67,8 +67,8 @@ __device__ __forceinline__ uint64_t row_id(uint2 w, uint64_t idx, const DevIndex
         uint64_t bid = (uint64_t)(w.x & 0xFFFFu) | ((uint64_t)(w.x >> 26) << 16);
         if (idx == ix.end_bwt_idx) return bid;
         uint32_t c = row_c<8>(w);
-        return bid + (uint64_t)ix.id_blocks[(uint64_t)c * ix.n_blocks + idx / ix.block_size] +
-               ix.first_runs[c + 1];
+        const uint64_t blk = ix.block_shift != 0xFFFFFFFFu ? (idx >> ix.block_shift) : idx / ix.block_size;
+        return bid + (uint64_t)ix.id_blocks[(uint64_t)c * ix.n_blocks + blk] + ix.first_runs[c + 1];
     }
 }
 

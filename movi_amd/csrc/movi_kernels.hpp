@@ -18,6 +18,8 @@ struct DevIndex {
     uint64_t end_bwt_idx;
     uint64_t n_blocks;
     uint64_t block_size;
+    uint32_t block_shift;         // log2(block_size) when it is a power of two (always, in practice), else 0xFFFFFFFF
+    uint32_t pad_;
     uint64_t end_thr[4];
     uint64_t first_runs[5], first_offsets[5], last_runs[5], last_offsets[5];
 };
