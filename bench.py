@@ -43,6 +43,9 @@ WORKLOADS = {
                      desc="random 10M-row blocked-thresholds table, 1M x 150bp reads per GPU"),
     "c4": dict(kind="synth", rows=1_000_000_000, mode=6, reads=1_250_000, read_len=150, sub=0.01,
                desc="random 1B-row regular-thresholds table (8 GB), 1.25M x 150bp reads per GPU (BASELINE config 4 shard)"),
+    "c5": dict(kind="synth", rows=1_000_000_000, mode=8, reads=1_250_000, read_len=150, sub=0.01,
+               desc="random 1B-row blocked-thresholds table (6 GB), 1.25M x 150bp reads per GPU (BASELINE config 5 shard; "
+                    "use with --query count)"),
     "tiny": dict(kind="synth", rows=200_000, mode=6, reads=20_000, read_len=150, sub=0.01,
                  desc="tiny plumbing workload"),
 }

@@ -19,6 +19,8 @@
 
 namespace movi {
 
+constexpr int kIdbLdsEntries = 4096;   // mode-8 id_blocks entries held in LDS (16 KiB)
+
 // ------------------------------------------------------------------ row decode
 // A row is carried in registers as two dwords.
 //   mode 6 (8 B, include/move_row.hpp:131-142; masks move_row_configs.hpp:34-51):
@@ -34,9 +36,13 @@ __device__ __forceinline__ uint2 load_row(const uint8_t *rows, uint64_t i) {
     if (MODE == 6) {
         return *reinterpret_cast<const uint2 *>(rows + i * 8);
     } else {
-        const uint16_t *p = reinterpret_cast<const uint16_t *>(rows + i * 6);
-        uint32_t a = p[0], b = p[1], c = p[2];
-        return make_uint2(a | (b << 16), c);
+        // 6-byte rows: ONE unaligned 8-byte load of the bytes [6i-2, 6i+6) (for row 0: [0, 8)), shifted into
+        // place -- never reads outside the table -- instead of three 2-byte loads
+        const uint32_t lead = i ? 2u : 0u;
+        unsigned long long v;
+        __builtin_memcpy(&v, rows + i * 6 - lead, 8);
+        v >>= 8u * lead;
+        return make_uint2((uint32_t)v, (uint32_t)(v >> 32) & 0xFFFFu);
     }
 }
 template <int MODE> __device__ __forceinline__ uint32_t row_n(uint2 w) {
@@ -60,7 +66,7 @@ template <int MODE> __device__ __forceinline__ uint32_t row_thr(uint2 w, uint32_
 }
 // MoveStructure::get_id, src/move_structure.cpp:91-102
 template <int MODE>
-__device__ __forceinline__ uint64_t row_id(uint2 w, uint64_t idx, const DevIndex &ix) {
+__device__ __forceinline__ uint64_t row_id(uint2 w, uint64_t idx, const DevIndex &ix, const uint32_t *idb_lds = nullptr) {
     if (MODE == 6) {
         return (uint64_t)w.x | ((uint64_t)(w.y >> 28) << 32);
     } else {
@@ -68,7 +74,9 @@ __device__ __forceinline__ uint64_t row_id(uint2 w, uint64_t idx, const DevIndex
         if (idx == ix.end_bwt_idx) return bid;
         uint32_t c = row_c<8>(w);
         const uint64_t blk = ix.block_shift != 0xFFFFFFFFu ? (idx >> ix.block_shift) : idx / ix.block_size;
-        return bid + (uint64_t)ix.id_blocks[(uint64_t)c * ix.n_blocks + blk] + ix.first_runs[c + 1];
+        const uint64_t slot = (uint64_t)c * ix.n_blocks + blk;
+        const uint32_t base = idb_lds ? idb_lds[slot] : ix.id_blocks[slot];     // check point of (character, block)
+        return bid + (uint64_t)base + ix.first_runs[c + 1];
     }
 }
 
@@ -99,13 +107,13 @@ __device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
 // the new idx.  `live` lanes take the step; returns a kErr* code (0 = ok) per lane.
 template <int MODE, int NB = 1>
 __device__ __forceinline__ uint32_t lf_step(const DevIndex &ix, bool live, uint64_t &idx, uint32_t &off,
-                                            uint2 &row, uint32_t &ff_total) {
+                                            uint2 &row, uint32_t &ff_total, const uint32_t *idb_lds = nullptr) {
     uint32_t errc = kErrNone;
     uint64_t j = idx;
     uint32_t n = 0, ff = 0;
     uint32_t going = 0;
     if (live) {
-        j = row_id<MODE>(row, idx, ix);
+        j = row_id<MODE>(row, idx, ix, idb_lds);
         if (j >= ix.r) {                                // move_structure.cpp:63-65
             errc = kErrIdRange;
             j = idx;
@@ -151,13 +159,14 @@ __device__ __forceinline__ uint32_t lf_step(const DevIndex &ix, bool live, uint6
 // wave-uniform loop, so an interval step costs the trips of ONE walker.
 template <int MODE>
 __device__ __forceinline__ uint32_t lf_step2(const DevIndex &ix, bool live, uint64_t &ia, uint32_t &offa, uint2 &rowa,
-                                             uint64_t &ib, uint32_t &offb, uint2 &rowb, uint32_t &ff_total) {
+                                             uint64_t &ib, uint32_t &offb, uint2 &rowb, uint32_t &ff_total,
+                                             const uint32_t *idb_lds = nullptr) {
     uint32_t errc = kErrNone;
     uint64_t ja = ia, jb = ib;
     uint32_t na = 0, nb = 0, ffa = 0, ffb = 0, ga = 0, gb = 0;
     if (live) {
-        ja = row_id<MODE>(rowa, ia, ix);
-        jb = row_id<MODE>(rowb, ib, ix);
+        ja = row_id<MODE>(rowa, ia, ix, idb_lds);
+        jb = row_id<MODE>(rowb, ib, ix, idb_lds);
         if (ja >= ix.r || jb >= ix.r) {                 // move_structure.cpp:63-65
             errc = kErrIdRange;
             ja = ia; jb = ib;
@@ -205,6 +214,14 @@ __global__ __launch_bounds__(256) void pml_kernel(DevIndex ix, const uint8_t *__
                                                      DevStats *stats, const uint32_t *__restrict__ order) {
     __shared__ uint8_t s_code[256];
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = ix.code_of[i];
+    // mode 8: the (character, block) check points of the blocked ids, kept in LDS when they fit
+    // (4 x n_blocks x 4 B = 15 kB for 1 B rows) so that get_id costs no extra global load
+    __shared__ uint32_t s_idb[MODE == 8 ? kIdbLdsEntries : 1];
+    const uint32_t *idb = nullptr;
+    if (MODE == 8 && ix.n_blocks * 4 <= (uint64_t)kIdbLdsEntries) {
+        for (uint32_t i = threadIdx.x; i < (uint32_t)ix.n_blocks * 4; i += blockDim.x) s_idb[i] = ix.id_blocks[i];
+        idb = s_idb;
+    }
     __syncthreads();
 
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -247,7 +264,7 @@ __global__ __launch_bounds__(256) void pml_kernel(DevIndex ix, const uint8_t *__
             }
         }
         if (k != 0) {
-            const uint32_t e = lf_step<MODE, NB>(ix, live, idx, off, row, ff_total);
+            const uint32_t e = lf_step<MODE, NB>(ix, live, idx, off, row, ff_total, idb);
             if (e) { failed = e; live = false; }
         }
         uint32_t a = 0xFFu;
@@ -383,6 +400,14 @@ __global__ __launch_bounds__(256) void pml_kernel_sm(DevIndex ix, const uint8_t 
     enum : uint32_t { kInit = 0, kFF = 1, kDown = 2, kUp = 3, kDone = 4 };
     __shared__ uint8_t s_code[256];
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = ix.code_of[i];
+    // mode 8: the (character, block) check points of the blocked ids, kept in LDS when they fit
+    // (4 x n_blocks x 4 B = 15 kB for 1 B rows) so that get_id costs no extra global load
+    __shared__ uint32_t s_idb[MODE == 8 ? kIdbLdsEntries : 1];
+    const uint32_t *idb = nullptr;
+    if (MODE == 8 && ix.n_blocks * 4 <= (uint64_t)kIdbLdsEntries) {
+        for (uint32_t i = threadIdx.x; i < (uint32_t)ix.n_blocks * 4; i += blockDim.x) s_idb[i] = ix.id_blocks[i];
+        idb = s_idb;
+    }
     __syncthreads();
 
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -513,7 +538,7 @@ __global__ __launch_bounds__(256) void pml_kernel_sm(DevIndex ix, const uint8_t 
                 st = kDone;
             } else {
                 // LF_move, move_structure.cpp:59-67
-                const uint64_t j = row_id<MODE>(row, idx, ix);
+                const uint64_t j = row_id<MODE>(row, idx, ix, idb);
                 if (j >= ix.r) {
                     failed = kErrIdRange;
                     st = kDone;
@@ -564,6 +589,14 @@ __global__ __launch_bounds__(256) void pml_kernel_flat(DevIndex ix, const uint8_
     enum : uint32_t { sFF = 0, sDown = 1, sUp = 2, sDone = 3 };
     __shared__ uint8_t s_code[256];
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = ix.code_of[i];
+    // mode 8: the (character, block) check points of the blocked ids, kept in LDS when they fit
+    // (4 x n_blocks x 4 B = 15 kB for 1 B rows) so that get_id costs no extra global load
+    __shared__ uint32_t s_idb[MODE == 8 ? kIdbLdsEntries : 1];
+    const uint32_t *idb = nullptr;
+    if (MODE == 8 && ix.n_blocks * 4 <= (uint64_t)kIdbLdsEntries) {
+        for (uint32_t i = threadIdx.x; i < (uint32_t)ix.n_blocks * 4; i += blockDim.x) s_idb[i] = ix.id_blocks[i];
+        idb = s_idb;
+    }
     __syncthreads();
 
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -650,7 +683,7 @@ __global__ __launch_bounds__(256) void pml_kernel_flat(DevIndex ix, const uint8_
             if (k == len) {
                 st_next = sDone;
             } else {
-                const uint64_t j = row_id<MODE>(row, need, ix);           // LF_move, move_structure.cpp:59-67
+                const uint64_t j = row_id<MODE>(row, need, ix, idb);      // LF_move, move_structure.cpp:59-67
                 if (j >= ix.r) {
                     failed = kErrIdRange;
                     st_next = sDone;
@@ -765,6 +798,14 @@ __global__ __launch_bounds__(256) void count_kernel_v0(DevIndex ix, const uint8_
                                                        DevStats *stats, const uint32_t *__restrict__ order) {
     __shared__ uint8_t s_code[256];
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = ix.code_of[i];
+    // mode 8: the (character, block) check points of the blocked ids, kept in LDS when they fit
+    // (4 x n_blocks x 4 B = 15 kB for 1 B rows) so that get_id costs no extra global load
+    __shared__ uint32_t s_idb[MODE == 8 ? kIdbLdsEntries : 1];
+    const uint32_t *idb = nullptr;
+    if (MODE == 8 && ix.n_blocks * 4 <= (uint64_t)kIdbLdsEntries) {
+        for (uint32_t i = threadIdx.x; i < (uint32_t)ix.n_blocks * 4; i += blockDim.x) s_idb[i] = ix.id_blocks[i];
+        idb = s_idb;
+    }
     __syncthreads();
 
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -836,7 +877,7 @@ __global__ __launch_bounds__(256) void count_kernel_v0(DevIndex ix, const uint8_
         bool nonempty = legal && ((rs < re) || (rs == re && os <= oe));
         if (legal && !nonempty) { empty = 1; run = 0; }
         // backward_search_step :326-330: two LF moves
-        const uint32_t e12 = lf_step2<MODE>(ix, nonempty, rs, os, rws, re, oe, rwe, ff_total);
+        const uint32_t e12 = lf_step2<MODE>(ix, nonempty, rs, os, rws, re, oe, rwe, ff_total, idb);
         if (e12) { failed = e12; run = 0; nonempty = false; }
         if (nonempty) {                                   // backward_search :179-182
             if ((rs < re) || (rs == re && os <= oe)) pos -= 1;
