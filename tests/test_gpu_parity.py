@@ -323,3 +323,31 @@ def test_fuzz_small_indexes(built_lib, tmp_path, alphabet):
             em, ec = cpu.count_batch(bases, offs, threads=2)
             assert (m == em).all() and (c == ec).all(), (alphabet, trial, mode)
             gpu.close()
+
+
+@pytest.mark.parametrize("mode", [6, 8])
+def test_real_bwt_pangenome_vs_oracle(built_lib, tmp_path, mode):
+    """A real-BWT index of a synthetic 16-genome pangenome (~1 M rows, built by tools/build_index) with
+    20 k substrings + mutations: every PML and every count against the oracle."""
+    import subprocess
+    import movi_amd
+    from oracle.oracle import Oracle
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "build_index")
+    if not os.path.exists(tool):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", tool, tool + ".cpp"])
+    out = str(tmp_path / "pg")
+    subprocess.check_call([tool, "pangenome", "500000", "16", "0.002", "5", str(mode), out, "20000", "150", "0.02"],
+                          stderr=subprocess.DEVNULL)
+    img = open(os.path.join(out, "index.movi"), "rb").read()
+    gpu, cpu = movi_amd.MoveIndex.from_image(img), Oracle(img)
+    assert gpu.desc.r > 500_000
+    bases = np.fromfile(os.path.join(out, "reads.bin"), np.uint8)
+    offs = (np.arange(20001, dtype=np.uint64) * np.uint64(150))
+    exp, ff, sc = cpu.pml_batch(bases, offs, threads=8)
+    for variant in (1, 7):
+        gpu.set_option("pml_variant", variant)
+        got, st = gpu.query_pml_packed(bases, offs)
+        assert (got == exp).all() and (st.fast_forwards, st.scans, st.errors) == (ff, sc, 0)
+    m, c, _ = gpu.query_count_packed(bases, offs)
+    em, ec = cpu.count_batch(bases, offs, threads=8)
+    assert (m == em).all() and (c == ec).all()
