@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iostream>
@@ -66,7 +67,10 @@ int run_query(const Options &o) {
     int n_dev = 0;
     check(movi_device_count(&n_dev), "no usable GPU");
     if (n_dev < 1) throw EngineError("no usable GPU: the MI355X engine has no CPU fallback");
-    if (o.device + o.gpus > n_dev)
+    // test hook for 1-GPU boxes: MOVI_SHARE_GPU=1 puts every logical GPU of --gpus N on --device
+    const bool share_gpu = std::getenv("MOVI_SHARE_GPU") && std::string(std::getenv("MOVI_SHARE_GPU")) == "1";
+    auto dev_of = [&](int g) { return share_gpu ? o.device : o.device + g; };
+    if (!share_gpu && o.device + o.gpus > n_dev)
         throw EngineError("requested devices " + std::to_string(o.device) + ".." + std::to_string(o.device + o.gpus - 1) +
                           " but only " + std::to_string(n_dev) + " visible");
     auto t0 = std::chrono::steady_clock::now();
@@ -75,7 +79,34 @@ int run_query(const Options &o) {
         std::vector<movi_index_t *> &h;
         ~Closer() { for (auto *x : h) movi_index_destroy(x); }
     } closer{handles};
-    for (int g = 0; g < o.gpus; g++) check(movi_index_load(o.device + g, o.index_dir.c_str(), &handles[g]), "loading the index");
+    if (o.gpus == 1) {
+        check(movi_index_load(o.device, o.index_dir.c_str(), &handles[0]), "loading the index");
+    } else {
+        // read and parse the file once, then upload the same host image to every GPU in parallel
+        std::vector<uint8_t> img;
+        for (const std::string &cand : {o.index_dir + "/index.movi", o.index_dir + "/movi_index.bin", o.index_dir}) {
+            std::ifstream f(cand, std::ios::binary | std::ios::ate);
+            if (!f.good() || f.tellg() <= 0) continue;
+            img.resize((size_t)f.tellg());
+            f.seekg(0);
+            f.read(reinterpret_cast<char *>(img.data()), (std::streamsize)img.size());
+            if (f.good()) break;
+            img.clear();
+        }
+        if (img.empty()) throw std::runtime_error("Failed to open the index file at: " + o.index_dir);
+        movi_index_desc_t d0;
+        size_t roff = 0, rbytes = 0;
+        check(movi_index_parse(img.data(), img.size(), &d0, &roff, &rbytes), "parsing the index");
+        std::vector<std::string> errs((size_t)o.gpus);
+        std::vector<std::thread> th;
+        for (int g = 0; g < o.gpus; g++)
+            th.emplace_back([&, g] {
+                if (movi_index_create(dev_of(g), &d0, img.data() + roff, &handles[g]) != MOVI_OK) errs[g] = movi_last_error();
+            });
+        for (auto &t : th) t.join();
+        for (const auto &e : errs)
+            if (!e.empty()) throw EngineError("uploading the index: " + e);
+    }
     movi_index_desc_t desc;
     check(movi_index_get_desc(handles[0], &desc), "index description");
     const std::string index_type = index_type_name(desc.mode);

@@ -207,3 +207,19 @@ def test_reverse_illegal_chars_stdin_and_errors(movi_bin, oracles, tmp_path):
     q.write_bytes(b">xy\nACGT\n")
     r = run(["query", "-i", IDX[6], "-r", str(q), "--no-output"])
     assert r.returncode == 0 and r.stdout == b"" and not os.path.exists(str(q) + ".regular-thresholds.pml.bpf")
+
+
+def test_multi_gpu_sharding_path(movi_bin, tmp_path):
+    """`--gpus N`: the index is read once and uploaded per GPU, each chunk of reads is sharded by bases over
+    N host threads / handles.  On a 1-GPU box MOVI_SHARE_GPU=1 maps every logical GPU to device 0; the
+    output must be byte-identical to the single-GPU run (PML file order and count)."""
+    from oracle import build_index as B
+    ref = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))[0][1]
+    reads_path = str(tmp_path / "mg.fa")
+    write_mixed_reads(reads_path, np.random.default_rng(9), ref, n=500)
+    env = dict(os.environ, MOVI_SHARE_GPU="1")
+    for extra in (["--stdout"], ["--count", "--stdout", "-n"]):
+        one = run(["query", "-i", IDX[8], "-r", reads_path] + extra)
+        many = run(["query", "-i", IDX[8], "-r", reads_path, "--gpus", "3"] + extra, env=env)
+        assert one.returncode == 0 and many.returncode == 0, many.stderr
+        assert one.stdout == many.stdout and len(one.stdout) > 1000
