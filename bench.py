@@ -101,7 +101,7 @@ def main():
     ap.add_argument("--from-dir", default="", help="use DIR/index.movi + DIR/reads.bin (fixed-length reads, "
                     "--read-len) written by tools/build_index instead of the synthetic table")
     ap.add_argument("--reads-file", default="reads.bin")
-    ap.add_argument("--query", default="pml", choices=["pml", "count"], help="count = backward-search count query "
+    ap.add_argument("--query", default="pml", choices=["pml", "count", "zml"], help="count = backward-search count query "
                     "(BASELINE config 5 path); the headline metric is pml")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-reads", type=int, default=0)
@@ -239,6 +239,9 @@ def main():
         if args.query == "count":
             index.count_device(d_bases.data_ptr(), d_offs.data_ptr(), n_reads, n_bases, d_matched.data_ptr(),
                                d_count.data_ptr(), d_err.data_ptr(), stream.cuda_stream, d_order)
+        elif args.query == "zml":
+            index.zml_device(d_bases.data_ptr(), d_offs.data_ptr(), n_reads, n_bases, d_out.data_ptr(),
+                             d_err.data_ptr(), stream.cuda_stream, d_order)
         else:
             index.pml_device(d_bases.data_ptr(), d_offs.data_ptr(), n_reads, n_bases, d_out.data_ptr(),
                              d_err.data_ptr(), stream.cuda_stream, d_order)
@@ -284,6 +287,10 @@ def main():
         work_bases = max(int(d_matched.sum().item()), 1)
         f_bar, s_bar = st.fast_forwards / work_bases / 2.0, st.scans / work_bases
         bytes_per_base = 2 * row_bytes * (1.0 + f_bar) + row_bytes * s_bar + 1
+    if args.query == "zml":
+        # every base: two LF walkers (fast-forwards counted over both) + interval-shrink rows + 1 base in + 2 out
+        f_bar, s_bar = st.fast_forwards / max(n_bases, 1) / 2.0, st.scans / max(n_bases, 1)
+        bytes_per_base = 2 * row_bytes * (1.0 + f_bar) + row_bytes * s_bar + 1 + 2
     avg_kern_s = (sum(kern_ms) / len(kern_ms)) / 1e3
     achieved_gbs = bytes_per_base * work_bases / avg_kern_s / 1e9
     value = total_bases_per_step * args.steps / elapsed / 1e9       # Gbases/s, whole job
@@ -301,7 +308,7 @@ def main():
             traffic = None
 
     result = {
-        "metric": ("PML" if args.query == "pml" else "count") + " query Gbases/s on " +
+        "metric": {"pml": "PML", "count": "count", "zml": "ZML"}[args.query] + " query Gbases/s on " +
                   ("regular-thresholds" if mode == 6 else "blocked-thresholds") + " index",
         "value": value, "unit": "Gbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -317,12 +324,37 @@ def main():
                    "reads_gen_s": round(t_reads_gen, 2)},
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "pml_kernel", "kernel_ms_avg": avg_kern_s * 1e3,
-                     "gathers_per_s": (1.0 + f_bar + s_bar) * n_bases / avg_kern_s},
+                     "kernel": {"pml": "pml_kernel", "count": "count_kernel_v0", "zml": "zml_kernel"}[args.query],
+                     "kernel_ms_avg": avg_kern_s * 1e3,
+                     "gathers_per_s": ((1.0 + f_bar + s_bar) * n_bases if args.query == "pml"
+                                       else (2.0 * (1.0 + f_bar) + s_bar) * work_bases) / avg_kern_s},
     }
 
     # ---- CPU baseline: the oracle restatement (scalar port, 16 strands/thread + prefetch,
     # OpenMP over read groups) on a bounded sample of the same reads, rank 0, N == 1 only.
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.query == "zml":
+        from oracle.oracle import Oracle
+        cores = os.cpu_count() or 1
+        cpu = Oracle(file_img if file_img is not None else six.image())
+        sample = args.cpu_sample_reads or max(1, min(n_reads, int(15e6 * cores / 8) // max(wl["read_len"], 1)))
+        sb = bases[: int(offs[sample])]
+        so = offs[: sample + 1]
+        passes, dt, exp = 0, 0.0, None
+        while dt < 10.0 and passes < 64:
+            t0 = time.perf_counter()
+            exp = cpu.zml_batch(sb, so, threads=cores)
+            dt += time.perf_counter() - t0
+            passes += 1
+        got = d_out[: sb.size].cpu().numpy().view(np.uint16)
+        result["cpu_baseline"] = {"value": sb.size * passes / dt / 1e9, "unit": "Gbases/s", "cores": cores,
+                                  "kind": "port",
+                                  "sample": "first %d reads (%d bases) of the same batch x %d passes, "
+                                            "oracle/movi_oracle.c oracle_zml_batch (scalar port of query_zml, "
+                                            "%d OpenMP threads, no software prefetch), %.2f s"
+                                            % (sample, sb.size, passes, cores, dt)}
+        result["parity_sample_ok"] = bool((got == exp).all())
+        if not result["parity_sample_ok"]:
+            print("PARITY FAILURE on the cpu_baseline sample", file=sys.stderr)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.query == "pml":
         from oracle.oracle import Oracle
         cores = os.cpu_count() or 1

@@ -15,6 +15,7 @@
  *   MoveStructure::query_backward_search  src/move_structure_search.cpp:340-352   movi_count_host / movi_count_device
  *   ReadProcessor::backward_search + compute_match_count  src/read_processor.cpp:610-620,1096-1175   movi_count_host / movi_count_device
  *   Classifier::classify (bins)     src/classifier.cpp:99-143           movi_classify_device / movi_pml_classify_host
+ *   MoveStructure::query_zml        src/move_structure_query.cpp:690-785  movi_zml_host / movi_zml_device
  *
  * Conventions: every entry point returns an int status (MOVI_OK == 0) and never
  * throws; movi_last_error() gives the message for the calling thread.  One
@@ -172,6 +173,24 @@ int movi_count_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_
  * Unknown keys return MOVI_ERR_ARG.  Keys: "pml_variant", "block_threads",
  * "waves_per_cu" (0 = uncapped). */
 int movi_set_option(movi_index_t *ix, const char *key, int64_t value);
+
+/* ---- ZML (Ziv-Merhav cross parse) ---------------------------------------------- */
+
+/* `movi query --zml`: MoveStructure::query_zml (src/move_structure_query.cpp:690-785) without
+ * multi-classify.  Same buffers, layout, error and ordering conventions as movi_pml_device:
+ * out_zml[offsets[i] + k] = match length recorded for base (len_i - 1 - k) of read i = the
+ * number of bases of its greedy backward-search phrase to its right, u16-clamped; illegal
+ * bases give 0 and end the phrase.  These are the values of the reference's --no-prefetch
+ * path; its strand scheduler appends one extra entry to a read whose first base is illegal
+ * (reset_backward_search skips to pos -1, src/read_processor.cpp:1006-1013, and the caller adds
+ * again, :704), which this engine does not reproduce. */
+int movi_zml_device(movi_index_t *ix, const uint8_t *d_bases, const uint64_t *d_offsets,
+                    uint64_t n_reads, uint64_t n_bases, uint16_t *d_out_zml, uint8_t *d_read_err,
+                    const uint32_t *d_read_order, void *stream);
+
+int movi_zml_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_offsets,
+                  uint64_t n_reads, uint16_t *h_out_zml, uint8_t *h_read_err,
+                  movi_query_stats_t *stats);
 
 #ifdef __cplusplus
 }

@@ -322,19 +322,34 @@ int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
 
 // ---------------------------------------------------------------------------- PML
 
-int movi_pml_device(movi_index_t *ix, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
-                    uint64_t n_bases, uint16_t *d_out_pml, uint8_t *d_read_err, const uint32_t *d_read_order,
-                    void *stream) {
+static int ml_device(bool zml, movi_index_t *ix, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
+                     uint64_t n_bases, uint16_t *d_out, uint8_t *d_read_err, const uint32_t *d_read_order, void *stream) {
     if (!ix) return fail(MOVI_ERR_ARG, "index handle is NULL");
     if (n_reads == 0) return MOVI_OK;
-    if (!d_offsets || (n_bases && (!d_bases || !d_out_pml))) return fail(MOVI_ERR_ARG, "NULL device buffer");
+    if (!d_offsets || (n_bases && (!d_bases || !d_out))) return fail(MOVI_ERR_ARG, "NULL device buffer");
     HIP_TRY(hipSetDevice(ix->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     HIP_TRY(hipMemsetAsync(ix->d_stats, 0, sizeof(DevStats), s));
     if (n_reads > 0xFFFFFFFFull) return fail(MOVI_ERR_ARG, "more than 2^32 reads in one call");
-    HIP_TRY(launch_pml((int)ix->desc.mode, ix->dev, d_bases, d_offsets, n_reads, d_out_pml, d_read_err,
-                       ix->d_stats, d_read_order, ix->cfg, s));
+    if (zml)
+        HIP_TRY(launch_zml((int)ix->desc.mode, ix->dev, d_bases, d_offsets, n_reads, d_out, d_read_err, ix->d_stats,
+                           d_read_order, ix->cfg, s));
+    else
+        HIP_TRY(launch_pml((int)ix->desc.mode, ix->dev, d_bases, d_offsets, n_reads, d_out, d_read_err, ix->d_stats,
+                           d_read_order, ix->cfg, s));
     return MOVI_OK;
+}
+
+int movi_pml_device(movi_index_t *ix, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
+                    uint64_t n_bases, uint16_t *d_out_pml, uint8_t *d_read_err, const uint32_t *d_read_order,
+                    void *stream) {
+    return ml_device(false, ix, d_bases, d_offsets, n_reads, n_bases, d_out_pml, d_read_err, d_read_order, stream);
+}
+
+int movi_zml_device(movi_index_t *ix, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
+                    uint64_t n_bases, uint16_t *d_out_zml, uint8_t *d_read_err, const uint32_t *d_read_order,
+                    void *stream) {
+    return ml_device(true, ix, d_bases, d_offsets, n_reads, n_bases, d_out_zml, d_read_err, d_read_order, stream);
 }
 
 int movi_last_stats(movi_index_t *ix, void *stream, movi_query_stats_t *stats) {
@@ -411,7 +426,7 @@ int run_chunked(movi_index *ix, const uint8_t *h_bases, const uint64_t *h_offset
 
 extern "C" {
 
-int movi_pml_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_offsets, uint64_t n_reads,
+static int ml_host(bool zml, movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_offsets, uint64_t n_reads,
                   uint16_t *h_out_pml, uint8_t *h_read_err, movi_query_stats_t *stats) {
     if (!ix) return fail(MOVI_ERR_ARG, "index handle is NULL");
     if (n_reads == 0) { if (stats) memset(stats, 0, sizeof(*stats)); return MOVI_OK; }
@@ -427,7 +442,7 @@ int movi_pml_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_of
             HIP_TRY(d_out.alloc(nb * 2));
             out_cap = nb;
         }
-        return movi_pml_device(ix, db, dof, nr, nb, static_cast<uint16_t *>(d_out.p), derr, dord, nullptr);
+        return ml_device(zml, ix, db, dof, nr, nb, static_cast<uint16_t *>(d_out.p), derr, dord, nullptr);
     };
     auto fetch = [&](uint64_t, uint64_t, uint64_t b0, uint64_t nb) -> int {
         if (nb) HIP_TRY(hipMemcpy(h_out_pml + b0, d_out.p, nb * 2, hipMemcpyDeviceToHost));
@@ -441,6 +456,16 @@ int movi_pml_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_of
         return fail(MOVI_ERR_INVARIANT, std::to_string(local.errors) +
                                             " read(s) hit a move-structure invariant violation (corrupt index?)");
     return MOVI_OK;
+}
+
+int movi_pml_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_offsets, uint64_t n_reads,
+                  uint16_t *h_out_pml, uint8_t *h_read_err, movi_query_stats_t *stats) {
+    return ml_host(false, ix, h_bases, h_offsets, n_reads, h_out_pml, h_read_err, stats);
+}
+
+int movi_zml_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_offsets, uint64_t n_reads,
+                  uint16_t *h_out_zml, uint8_t *h_read_err, movi_query_stats_t *stats) {
+    return ml_host(true, ix, h_bases, h_offsets, n_reads, h_out_zml, h_read_err, stats);
 }
 
 // ----------------------------------------------------------------- classification

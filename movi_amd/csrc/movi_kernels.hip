@@ -922,6 +922,163 @@ hipError_t launch_count(int mode, const DevIndex &ix, const uint8_t *d_bases, co
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------- ZML
+// MoveStructure::query_zml, src/move_structure_query.cpp:690-785 (Ziv-Merhav cross parse): a
+// greedy backward search that restarts at the next base whenever the match cannot be extended.
+// The reference emits, for position pos, match_len BEFORE trying to extend to pos-1; restated
+// per consumed base (emission step k handles base len-1-k):
+//   phrase open  : extend the interval with the base (update_interval + 2 LF); still non-empty
+//                  -> ml += 1, else the phrase ends, ml = 0 and this base opens the next phrase
+//   no phrase    : ml = 0; a legal base opens a phrase (initialize_backward_search :284-291)
+//   emit min(ml, 65535)
+// which produces the same vector (value at a base = bases of its phrase to its right).  Every
+// step consumes exactly one base, so the packed I/O of PML variant 1 carries over: 16 bases per
+// fetch, values leave as paired 16-byte stores.  The walkers are the count query's.
+template <int MODE>
+__global__ __launch_bounds__(256) void zml_kernel(DevIndex ix, const uint8_t *__restrict__ bases,
+                                                  const uint64_t *__restrict__ offs, uint64_t n_reads,
+                                                  uint16_t *__restrict__ out, uint8_t *__restrict__ err,
+                                                  DevStats *stats, const uint32_t *__restrict__ order) {
+    __shared__ uint8_t s_code[256];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = ix.code_of[i];
+    __shared__ uint32_t s_idb[MODE == 8 ? kIdbLdsEntries : 1];
+    const uint32_t *idb = nullptr;
+    if (MODE == 8 && ix.n_blocks * 4 <= (uint64_t)kIdbLdsEntries) {
+        for (uint32_t i = threadIdx.x; i < (uint32_t)ix.n_blocks * 4; i += blockDim.x) s_idb[i] = ix.id_blocks[i];
+        idb = s_idb;
+    }
+    __syncthreads();
+
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t ff_total = 0, scan_total = 0, failed = 0;
+    const bool valid = t < n_reads;
+    const uint64_t rid = (valid && order) ? order[t] : t;
+    const uint64_t beg = valid ? offs[rid] : 0;
+    const uint64_t len = valid ? offs[rid + 1] - beg : 0;
+    const uint8_t *R = bases + beg;
+    uint16_t *O = out + beg;
+    uint64_t rs = 0, re = 0;                              // MoveInterval [rs:os, re:oe]
+    uint32_t os = 0, oe = 0;
+    uint32_t open = 0;                                    // 1 while a phrase (non-empty interval) exists
+    uint32_t ml = 0;
+    uint64_t rb = 0, rb_next = 0;
+    uint32_t have16 = 0;
+    uint4 pk = make_uint4(0, 0, 0, 0), pk_old = pk;
+    const uint64_t packed_end = len & ~7ull;
+    for (uint64_t k = 0; wave_any(k < len && failed == 0u); ++k) {
+        const bool live = k < len && failed == 0u;
+        if ((k & 7) == 0) {                               // base window, as in pml_kernel VARIANT 1
+            if ((k & 8) == 0 && live && k + 16 <= len) {
+                uint64_t two[2];
+                __builtin_memcpy(two, R + (len - 16 - k), 16);
+                rb = two[1];
+                rb_next = two[0];
+                have16 = 1;
+            } else if ((k & 8) != 0 && have16) {
+                rb = rb_next;
+                have16 = 0;
+            } else if (live && k + 8 <= len) {
+                __builtin_memcpy(&rb, R + (len - 8 - k), 8);
+            } else if (live) {
+                rb = 0;
+                for (uint64_t i = 0; i < len - k; ++i) rb |= (uint64_t)R[len - 1 - k - i] << (8 * (7 - i));
+            }
+        }
+        uint32_t b = 0xFFu;
+        if (live) b = s_code[(uint32_t)(rb >> (8 * (7 - (k & 7)))) & 0xFFu];
+        // backward_search_step, src/move_structure_search.cpp:311-333, for lanes with an open phrase
+        const bool ext = live && open != 0u && b != 0xFFu;
+        uint2 rws = make_uint2(0, 0), rwe = make_uint2(0, 0);
+        uint32_t gs = 0, ge = 0;
+        if (ext && rs <= re) {                            // update_interval :48-61, as in count_kernel_v0
+            rws = load_row<MODE>(ix.rows, rs);
+            rwe = load_row<MODE>(ix.rows, re);
+            gs = (rs == ix.end_bwt_idx || row_c<MODE>(rws) != b) ? 1u : 0u;
+            ge = (re == ix.end_bwt_idx || row_c<MODE>(rwe) != b) ? 1u : 0u;
+        }
+        while (wave_any((gs | ge) != 0u)) {
+            uint2 ws = rws, we = rwe;
+            if (gs && rs + 1 < ix.r) ws = load_row<MODE>(ix.rows, rs + 1);
+            if (ge && re > 0) we = load_row<MODE>(ix.rows, re - 1);
+            if (gs) {
+                rs += 1; os = 0; scan_total += 1;
+                if (rs >= ix.r || rs > re) { gs = 0; ge = 0; }
+                else { rws = ws; gs = (rs == ix.end_bwt_idx || row_c<MODE>(rws) != b) ? 1u : 0u; }
+            }
+            if (ge) {
+                if (re == 0) { ge = 0; gs = 0; rs = 1; }
+                else {
+                    re -= 1; scan_total += 1;
+                    rwe = we;
+                    oe = row_n<MODE>(rwe) - 1;
+                    if (re < rs) { ge = 0; gs = 0; }
+                    else ge = (re == ix.end_bwt_idx || row_c<MODE>(rwe) != b) ? 1u : 0u;
+                }
+            }
+        }
+        bool nonempty = ext && ((rs < re) || (rs == re && os <= oe));
+        const uint32_t e12 = lf_step2<MODE>(ix, nonempty, rs, os, rws, re, oe, rwe, ff_total, idb);
+        if (e12) { failed = e12; nonempty = false; }
+        if (nonempty && !((rs < re) || (rs == re && os <= oe))) nonempty = false;   // query_zml :717
+        if (live && failed == 0u) {
+            if (nonempty) {
+                ml += 1;                                  // :718-720
+            } else {
+                ml = 0;                                   // :750-760, or no phrase yet (:696-704)
+                open = 0;
+                if (b != 0xFFu) {                         // this base opens the next phrase
+                    rs = ix.first_runs[b + 1]; re = ix.last_runs[b + 1];
+                    os = (uint32_t)ix.first_offsets[b + 1]; oe = (uint32_t)ix.last_offsets[b + 1];
+                    open = ((rs < re) || (rs == re && os <= oe)) ? 1u : 0u;
+                }
+            }
+        }
+        const uint32_t val = ml > 65535u ? 65535u : ml;   // MoveQuery::add_ml
+        if (live && k >= packed_end) {
+            O[k] = (uint16_t)val;
+        } else if (live) {
+            pk.x = (pk.x >> 16) | (pk.y << 16);
+            pk.y = (pk.y >> 16) | (pk.z << 16);
+            pk.z = (pk.z >> 16) | (pk.w << 16);
+            pk.w = (pk.w >> 16) | (val << 16);
+            if ((k & 15) == 7) {
+                if (k + 8 < packed_end) pk_old = pk;
+                else __builtin_memcpy(O + (k - 7), &pk, 16);
+            } else if ((k & 15) == 15) {
+                __builtin_memcpy(O + (k - 15), &pk_old, 16);
+                __builtin_memcpy(O + (k - 7), &pk, 16);
+            }
+        }
+    }
+    if (failed) {
+        for (uint64_t k = 0; k < len; ++k) O[k] = 0;
+    }
+    if (valid && err) err[rid] = (uint8_t)failed;
+    const uint32_t ffw = wave_sum(ff_total), scw = wave_sum(scan_total), erw = wave_sum(failed ? 1u : 0u);
+    if ((threadIdx.x & 63) == 0 && stats) {
+        if (ffw) atomicAdd(&stats->fast_forwards, (unsigned long long)ffw);
+        if (scw) atomicAdd(&stats->scans, (unsigned long long)scw);
+        if (erw) atomicAdd(&stats->errors, (unsigned long long)erw);
+    }
+}
+
+hipError_t launch_zml(int mode, const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets,
+                      uint64_t n_reads, uint16_t *d_out, uint8_t *d_err, DevStats *d_stats,
+                      const uint32_t *d_order, const LaunchCfg &cfg, hipStream_t stream) {
+    if (n_reads == 0) return hipSuccess;
+    const int bt = cfg.block_threads;
+    const uint64_t blocks = (n_reads + bt - 1) / bt;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    dim3 grid((unsigned)blocks), block((unsigned)bt);
+    if (mode == 6)
+        hipLaunchKernelGGL(zml_kernel<6>, grid, block, 0, stream, ix, d_bases, d_offsets, n_reads, d_out, d_err,
+                           d_stats, d_order);
+    else
+        hipLaunchKernelGGL(zml_kernel<8>, grid, block, 0, stream, ix, d_bases, d_offsets, n_reads, d_out, d_err,
+                           d_stats, d_order);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------ classification bins
 // Classifier::classify, src/classifier.cpp:99-143: the PML vector (emission order) is cut into
 // bins of bin_width, the LAST bin absorbing a remainder shorter than bin_width; per read the

@@ -49,6 +49,10 @@ hipError_t launch_count(int mode, const DevIndex &ix, const uint8_t *d_bases, co
                         uint64_t n_reads, uint64_t *d_matched, uint64_t *d_count, uint8_t *d_err,
                         DevStats *d_stats, const uint32_t *d_order, const LaunchCfg &cfg, hipStream_t stream);
 
+hipError_t launch_zml(int mode, const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets,
+                      uint64_t n_reads, uint16_t *d_out, uint8_t *d_err, DevStats *d_stats,
+                      const uint32_t *d_order, const LaunchCfg &cfg, hipStream_t stream);
+
 hipError_t launch_classify(const uint16_t *d_pml, const uint64_t *d_offsets, uint64_t n_reads, uint32_t bin_width,
                            uint32_t thr, uint32_t *d_above, uint32_t *d_below, uint64_t *d_sum, hipStream_t stream);
 

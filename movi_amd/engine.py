@@ -143,6 +143,23 @@ class MoveIndex:
         out, _ = self.query_pml_packed(bases, offs)
         return [out[int(offs[i]): int(offs[i + 1])] for i in range(len(reads))]
 
+    def query_zml_packed(self, bases, offs):
+        """MoveStructure::query_zml (src/move_structure_query.cpp:690-785) for packed reads:
+        (u16 match lengths in emission order, QueryStats)."""
+        bases = np.ascontiguousarray(bases, np.uint8)
+        offs = np.ascontiguousarray(offs, np.uint64)
+        n = offs.size - 1
+        out = np.zeros(bases.size, np.uint16)
+        st = QueryStatsC()
+        check(lib().movi_zml_host(self._h, bases.ctypes.data, offs.ctypes.data, n, out.ctypes.data, None,
+                                  C.byref(st)))
+        return out, QueryStats(st)
+
+    def query_zml(self, reads):
+        bases, offs = _pack_reads(reads)
+        out, _ = self.query_zml_packed(bases, offs)
+        return [out[int(offs[i]): int(offs[i + 1])] for i in range(len(reads))]
+
     def classify_packed(self, bases, offs, bin_width, max_value_thr):
         """PML + Classifier::classify bins on the device: (bins_above, bins_below, sum_max) per read."""
         bases = np.ascontiguousarray(bases, np.uint8)
@@ -178,6 +195,12 @@ class MoveIndex:
     # -- device-pointer queries (bench / torch interop) ---------------------------
     def pml_device(self, d_bases, d_offs, n_reads, n_bases, d_out, d_err=0, stream=0, d_order=0):
         check(lib().movi_pml_device(self._h, C.c_void_p(d_bases), C.c_void_p(d_offs), n_reads, n_bases,
+                                    C.c_void_p(d_out), C.c_void_p(d_err) if d_err else None,
+                                    C.c_void_p(d_order) if d_order else None,
+                                    C.c_void_p(stream) if stream else None))
+
+    def zml_device(self, d_bases, d_offs, n_reads, n_bases, d_out, d_err=0, stream=0, d_order=0):
+        check(lib().movi_zml_device(self._h, C.c_void_p(d_bases), C.c_void_p(d_offs), n_reads, n_bases,
                                     C.c_void_p(d_out), C.c_void_p(d_err) if d_err else None,
                                     C.c_void_p(d_order) if d_order else None,
                                     C.c_void_p(stream) if stream else None))

@@ -63,6 +63,47 @@ uint64_t count_rounds(const ReadSet &rs, size_t i, uint64_t matched, const uint8
     return std::max<uint64_t>(matched, 1);
 }
 
+// ZML: one round per ReadProcessor::backward_search call (src/read_processor.cpp:1096-1175 driven
+// by :667-714).  A round either extends the phrase by one base (and also ends it there when the
+// next base is illegal or position 0 is reached) or finds the interval empty / the first
+// extension impossible and ends the phrase without moving.  Derived from the match lengths:
+// base p-1 extended the phrase of p iff z[p-1] == z[p] + 1 (or both sit at the u16 clamp).
+uint64_t zml_rounds(const ReadSet &rs, size_t i, const uint16_t *z, const uint8_t *code_of) {
+    const int64_t len = (int64_t)rs.len(i);
+    const uint8_t *R = rs.bases.data() + rs.offsets[i];
+    auto legal = [&](int64_t p) { return code_of[R[p]] != 0xFF; };
+    auto val = [&](int64_t p) { return z[len - 1 - p]; };
+    int64_t pos = len - 1;
+    while (pos >= 0 && !legal(pos)) pos--;                             // reset_backward_search at load
+    if (pos < 0) return 1;
+    uint64_t rounds = 0;
+    bool first = true;
+    for (;;) {
+        rounds++;
+        if (pos == 0) return rounds;                                   // first iteration at position 0 ends the read
+        bool ended = false;
+        if (first && !legal(pos - 1)) ended = true;                    // :1119-1121, no LF in this round
+        first = false;
+        if (!ended) {
+            const bool extended = legal(pos - 1) && (val(pos - 1) == (uint16_t)(val(pos) + 1) ||
+                                                     (val(pos) == 65535 && val(pos - 1) == 65535));
+            if (!extended) {
+                ended = true;                                          // empty interval: :1142-1146
+            } else {
+                pos--;
+                if (pos == 0) return rounds;                           // :1148-1156
+                if (!legal(pos - 1)) ended = true;                     // :1159-1163, same round
+            }
+        }
+        if (ended) {                                                   // :688-700
+            pos--;
+            while (pos >= 0 && !legal(pos)) pos--;
+            if (pos < 0) return rounds + 1;                            // one more round on the empty range
+            first = true;
+        }
+    }
+}
+
 int run_query(const Options &o) {
     int n_dev = 0;
     check(movi_device_count(&n_dev), "no usable GPU");
@@ -128,7 +169,7 @@ int run_query(const Options &o) {
     std::ofstream report_file, mls_file, matches_file;
     std::ostream *report = nullptr;
     if (o.classify) {
-        classifier.load_null_db(o.index_dir, o.verbose);
+        classifier.load_null_db(o.index_dir, o.query_type(), o.verbose);
         if (!o.filter) {                                              // src/classifier.cpp:39-61
             if (!o.write_stdout) {
                 const std::string name = o.read_file + "." + index_type + "." + o.query_type() + ".report";
@@ -145,7 +186,7 @@ int run_query(const Options &o) {
     if (open_files) {
         std::string prefix = !o.out_file.empty() ? o.out_file : o.read_file + "." + index_type;
         prefix += "." + o.query_type();
-        if (o.pml) {
+        if (o.ml()) {
             mls_file.open(prefix + ".bpf", std::ios::out | std::ios::binary);
             if (!mls_file.good()) throw std::runtime_error("Failed to open the output file: " + prefix + ".bpf");
             write_bpf_header(mls_file, 16);
@@ -177,10 +218,10 @@ int run_query(const Options &o) {
         }
         // --classify with --filter / --no-output needs verdicts only: the bins are reduced on the
         // GPU and the PML vectors never cross PCIe
-        const bool verdict_only = o.pml && o.classify && !o.write_output_allowed();
+        const bool verdict_only = o.pml && o.classify && !o.write_output_allowed();   // PML only: ZML takes the host bins
         std::vector<uint32_t> bins_above(verdict_only ? n : 0), bins_below(verdict_only ? n : 0);
         std::vector<uint64_t> bins_sum(verdict_only ? n : 0);
-        pml.assign(o.pml && !verdict_only ? rs.bases.size() : 0, 0);
+        pml.assign(o.ml() && !verdict_only ? rs.bases.size() : 0, 0);
         matched.assign(o.count ? n : 0, 0);
         counts.assign(o.count ? n : 0, 0);
         err.assign(n, 0);
@@ -197,6 +238,8 @@ int run_query(const Options &o) {
                                             bins_sum.data() + a, err.data() + a, nullptr);
             else if (o.pml)
                 rc = movi_pml_host(handles[g], rs.bases.data(), rs.offsets.data() + a, b - a, pml.data(), err.data() + a, nullptr);
+            else if (o.zml)
+                rc = movi_zml_host(handles[g], rs.bases.data(), rs.offsets.data() + a, b - a, pml.data(), err.data() + a, nullptr);
             else
                 rc = movi_count_host(handles[g], rs.bases.data(), rs.offsets.data() + a, b - a, matched.data() + a,
                                      counts.data() + a, err.data() + a, nullptr);
@@ -217,7 +260,10 @@ int run_query(const Options &o) {
         std::vector<uint32_t> order;
         if (o.prefetch) {
             std::vector<uint64_t> cost(n);
-            for (size_t i = 0; i < n; i++) cost[i] = o.pml ? rs.len(i) : count_rounds(rs, i, matched[i], desc.code_of);
+            for (size_t i = 0; i < n; i++)
+                cost[i] = o.pml ? rs.len(i)
+                        : o.zml ? zml_rounds(rs, i, pml.data() + rs.offsets[i], desc.code_of)
+                                : count_rounds(rs, i, matched[i], desc.code_of);
             order = strand_order(rs, cost, o.strands);
         } else {
             order.resize(n);
@@ -225,7 +271,7 @@ int run_query(const Options &o) {
         }
         for (uint32_t i : order) {
             const uint64_t len = rs.len(i);
-            if (o.pml) {
+            if (o.ml()) {
                 const uint16_t *p = verdict_only ? nullptr : pml.data() + rs.offsets[i];
                 if (o.classify) {                                     // write_mls, src/read_processor.cpp:565-578
                     const bool found = verdict_only

@@ -55,7 +55,7 @@ long to_int(const std::string &name, const std::string &v) {
 }  // namespace
 
 std::string usage() {
-    return "movi (MI355X engine): movi query -i DIR -r FILE|- [-o PREFIX] [--pml|--count] [--classify] [--filter [-v]]\n"
+    return "movi (MI355X engine): movi query -i DIR -r FILE|- [-o PREFIX] [--pml|--zml|--count] [--classify] [--filter [-v]]\n"
            "                      [--stdout] [--no-output] [-s N] [-t N] [-n] [--reverse] [--bin-width N]\n"
            "                      [--ignore-illegal-chars 1] [--gpus N] [--device D] [--verbose]\n"
            "       movi view --bpf FILE\n";
@@ -112,17 +112,18 @@ Options parse_args(int argc, char **argv) {
         o.index_dir = val("index");
         o.read_file = val("read");
         if (has("out-file")) o.out_file = val("out-file");
-        for (const char *bad : {"zml", "mem", "rpml", "kmer", "kmer-count", "sa-entries", "multi-classify", "ftab-k",
+        for (const char *bad : {"mem", "rpml", "kmer", "kmer-count", "sa-entries", "multi-classify", "ftab-k",
                                 "multi-ftab", "mmap"})
             if (has(bad))
-                throw UsageError(std::string("--") + bad + " is not supported by the MI355X engine (PML and count queries "
+                throw UsageError(std::string("--") + bad + " is not supported by the MI355X engine (PML, ZML and count queries "
                                  "on regular-thresholds / blocked-thresholds indexes only)");
         if (has("bin-width")) o.bin_width = (size_t)to_int("bin-width", val("bin-width"));
-        if (has("count")) { o.count = true; o.pml = false; }      // set_count(), movi_options.hpp:97
-        if (has("pml")) {                                          // set_pml() :95 -> then :407-410
-            if (o.count) throw UsageError("Please only specify count or pml as the type of queries.");
-            o.pml = true;
-        }
+        // movi_parser.cpp:353-355 applies set_count, set_zml, set_pml in this order and each setter
+        // clears the other query types (movi_options.hpp:108-110), so the last one applied wins
+        // (the "only specify count or pml" check at :407-410 can never fire)
+        if (has("count")) { o.count = true; o.pml = false; o.zml = false; }
+        if (has("zml")) { o.zml = true; o.pml = false; o.count = false; }
+        if (has("pml")) { o.pml = true; o.count = false; o.zml = false; }
         o.classify = has("classify");
         o.filter = has("filter");
         o.invert = has("invert");
@@ -144,7 +145,7 @@ Options parse_args(int argc, char **argv) {
         if (has("gpus")) o.gpus = (int)to_int("gpus", val("gpus"));
         if (has("device")) o.device = (int)to_int("device", val("device"));
         if (o.gpus < 1) throw UsageError("--gpus must be >= 1");
-        if (o.classify && o.count) throw UsageError("--classify needs PML queries");
+        if (o.classify && o.count) throw UsageError("--classify needs PML or ZML queries");
     } else if (o.command == "plan") {
         // host-only helper (no GPU): prints how the reads are batched and in which order
         // their records will be emitted, one `batch<TAB>id<TAB>length` line per read.

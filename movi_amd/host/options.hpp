@@ -17,6 +17,7 @@ struct Options {
     std::string bpf_file;         // view --bpf
     bool pml = true;              // default query type (movi_options.hpp:243)
     bool count = false;
+    bool zml = false;             // --zml: Ziv-Merhav cross parse lengths, same outputs as PML
     bool classify = false;
     bool filter = false;
     bool invert = false;
@@ -37,7 +38,8 @@ struct Options {
     // derived predicates, same names as the reference (movi_options.hpp:57-58)
     bool write_output_allowed() const { return !no_output && !filter; }
     bool write_stdout_enabled() const { return write_stdout && !classify; }
-    std::string query_type() const { return count ? "count" : "pml"; }   // src/utils.cpp:47-67
+    bool ml() const { return pml || zml; }                                // per-base matching lengths
+    std::string query_type() const { return count ? "count" : (zml ? "zml" : "pml"); }   // src/utils.cpp:47-67
 };
 
 struct UsageError : std::runtime_error {

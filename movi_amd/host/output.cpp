@@ -47,8 +47,8 @@ void write_count_line(std::ostream &out, const std::string &id, uint64_t query_l
     out << id << "\t" << matched << "/" << query_length << "\t" << count << "\n";
 }
 
-size_t Classifier::load_null_db(const std::string &index_dir, bool verbose) {
-    const std::string name = index_dir + "/movi.pml.nulldb";
+size_t Classifier::load_null_db(const std::string &index_dir, const std::string &query_type, bool verbose) {
+    const std::string name = index_dir + "/movi." + query_type + ".nulldb";      // emperical_null_database.cpp:107
     std::ifstream in(name, std::ios::in | std::ios::binary);
     if (!in.good()) throw std::runtime_error("Failed to open the null database: " + name);
     uint64_t num_values = 0, percentile_value = 0;

@@ -30,7 +30,7 @@ void write_count_line(std::ostream &out, const std::string &id, uint64_t query_l
 class Classifier {
 public:
     // Reads DIR/movi.pml.nulldb; returns max_value_thr = max(percentile, 3) + 1.
-    size_t load_null_db(const std::string &index_dir, bool verbose);
+    size_t load_null_db(const std::string &index_dir, const std::string &query_type, bool verbose);
     void write_report_header(std::ostream &out) const;
     // Bins of bin_width over the PML vector in emission order; the last bin absorbs a
     // remainder shorter than bin_width.  Writes the report line unless out == nullptr.

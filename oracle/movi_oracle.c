@@ -482,6 +482,72 @@ int oracle_count_batch(const oracle_index *ix, const uint8_t *seqs, const uint64
     return err;
 }
 
+/* ------------------------------------------------------------------ ZML
+ * MoveStructure::query_zml, src/move_structure_query.cpp:690-785 (the Ziv-Merhav cross parse):
+ * greedy backward search from the last base; while the match extends, position pos gets the
+ * number of bases already matched to its right (match_len before the step); when it cannot be
+ * extended the phrase ends, pos gets match_len, and a new search starts at pos-1.  One u16 per
+ * base (MoveQuery::add_ml clamp), emitted last base first like the PMLs.  Multi-classify
+ * (doc_pats) is not restated.
+ * NOT pinned to a reference output (the reference's tests hold no ZML vector): pinned in
+ * tests/ against a brute-force substring search over the fixture text instead. */
+int oracle_zml(const oracle_index *ix, const uint8_t *R, int64_t len, uint16_t *out) {
+    int64_t pos_on_r = len - 1, k = 0;
+    uint64_t match_len = 0;
+    /* :696-704 (the reference tests the character before the bound; same outputs) */
+    while (pos_on_r >= 0 && !check_alphabet(ix, R[pos_on_r])) { out[k++] = 0; pos_on_r -= 1; }
+    if (pos_on_r < 0) return ORACLE_OK;
+    uint64_t ci = ix->alphamap[R[pos_on_r]] + 1;         /* initialize_backward_search :284-291 */
+    interval_t iv = { ix->first_runs[ci], ix->first_offsets[ci], ix->last_runs[ci], ix->last_offsets[ci] };
+    while (pos_on_r > 0) {                               /* :714 */
+        /* backward_search_step(query_seq, pos_on_r, interval), move_structure_search.cpp:311-333 */
+        if (!check_alphabet(ix, R[pos_on_r - 1])) {
+            iv.rs = 1; iv.os = 0; iv.re = 0; iv.oe = 0;
+        } else {
+            update_interval(ix, &iv, R[pos_on_r - 1]);
+            if (!iv_empty(&iv)) {
+                if (LF_move(ix, &iv.os, &iv.rs) < 0) return ORACLE_ERR_INVARIANT;
+                if (LF_move(ix, &iv.oe, &iv.re) < 0) return ORACLE_ERR_INVARIANT;
+            }
+        }
+        if (!iv_empty(&iv)) {                            /* :717-720 */
+            out[k++] = (uint16_t)(match_len < 65535 ? match_len : 65535);
+            pos_on_r -= 1;
+            match_len += 1;
+        } else {                                         /* :750-760 */
+            out[k++] = (uint16_t)(match_len < 65535 ? match_len : 65535);
+            pos_on_r -= 1;
+            match_len = 0;
+            while (!check_alphabet(ix, R[pos_on_r]) && pos_on_r > 0) { out[k++] = 0; pos_on_r -= 1; }
+            if (check_alphabet(ix, R[pos_on_r])) {
+                ci = ix->alphamap[R[pos_on_r]] + 1;
+                iv.rs = ix->first_runs[ci]; iv.os = ix->first_offsets[ci];
+                iv.re = ix->last_runs[ci];  iv.oe = ix->last_offsets[ci];
+            }
+        }
+    }
+    if (iv_empty(&iv)) match_len = 0;                    /* :762-765 */
+    out[k++] = (uint16_t)(match_len < 65535 ? match_len : 65535);
+    return ORACLE_OK;
+}
+
+int oracle_zml_batch(const oracle_index *ix, const uint8_t *seqs, const uint64_t *offs,
+                     uint64_t n_reads, uint16_t *out, int threads) {
+    int err = ORACLE_OK;
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#endif
+    #pragma omp parallel for schedule(dynamic, 64)
+    for (uint64_t i = 0; i < n_reads; i++) {
+        int rc = oracle_zml(ix, seqs + offs[i], (int64_t)(offs[i + 1] - offs[i]), out + offs[i]);
+        if (rc < 0) {
+            #pragma omp atomic write
+            err = rc;
+        }
+    }
+    return err;
+}
+
 /* Single LF step exposed for generator / property tests. */
 int oracle_lf(const oracle_index *ix, uint64_t *idx, uint64_t *offset) {
     int64_t ff = LF_move(ix, offset, idx);

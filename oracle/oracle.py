@@ -42,6 +42,8 @@ def lib():
         L.oracle_count.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         L.oracle_count_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
                                          C.c_void_p, C.c_int]
+        L.oracle_zml.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.oracle_zml_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
         L.oracle_lf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
@@ -118,6 +120,25 @@ class Oracle:
         if rc:
             raise OracleError("oracle_count_batch rc=%d" % rc)
         return m, c
+
+    def zml(self, read):
+        """u16 Ziv-Merhav match lengths in emission order (last base first)."""
+        a = np.frombuffer(bytes(read), np.uint8)
+        out = np.zeros(a.size, np.uint16)
+        rc = lib().oracle_zml(self._h, a.ctypes.data if a.size else None, a.size, out.ctypes.data)
+        if rc:
+            raise OracleError("oracle_zml rc=%d" % rc)
+        return out
+
+    def zml_batch(self, seqs, offs, threads=1):
+        seqs = np.ascontiguousarray(seqs, np.uint8)
+        offs = np.ascontiguousarray(offs, np.uint64)
+        out = np.zeros(seqs.size, np.uint16)
+        rc = lib().oracle_zml_batch(self._h, seqs.ctypes.data, offs.ctypes.data, offs.size - 1,
+                                    out.ctypes.data, threads)
+        if rc:
+            raise OracleError("oracle_zml_batch rc=%d" % rc)
+        return out
 
     def lf(self, idx, offset):
         i, o = C.c_uint64(idx), C.c_uint64(offset)

@@ -26,11 +26,13 @@ def run(args, **kw):
 
 
 def test_argument_errors(movi_bin):
-    r = run(["query", "-i", "x", "-r", "y", "--pml", "--count"])
-    assert r.returncode == 1 and b"Please only specify count or pml" in r.stderr      # movi_parser.cpp:407-410
+    # set_count / set_zml / set_pml are applied in this order and clear each other (movi_parser.cpp:353-355,
+    # movi_options.hpp:108-110): --pml --count is a PML query, not a usage error
+    r = run(["query", "-i", "x", "-r", "y", "--pml", "--count", "--zml"])
+    assert r.returncode == 1 and b"Error parsing command line" not in r.stderr
     r = run(["query", "-i", "x"])
     assert r.returncode == 1 and b"Please include one index directory and one read file." in r.stderr
-    r = run(["query", "-i", "x", "-r", "y", "--zml"])
+    r = run(["query", "-i", "x", "-r", "y", "--mem"])
     assert r.returncode == 1 and b"not supported" in r.stderr
     r = run(["build", "-i", "x", "-f", "y"])
     assert r.returncode == 1

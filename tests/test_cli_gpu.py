@@ -123,6 +123,36 @@ def test_count_lines(movi_bin, oracles, tmp_path, mode):
     assert sorted(got.splitlines()) == sorted(exp.splitlines())
 
 
+@pytest.mark.parametrize("mode", [6, 8])
+def test_zml_cli(movi_bin, oracles, tmp_path, mode):
+    """`movi query --zml`: <prefix>.zml.bpf (src/utils.cpp:346-356, query_type "zml"), --stdout, view."""
+    from oracle import build_index as B
+    ref = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))[0][1]
+    reads_path = str(tmp_path / "z.fa")
+    recs = write_mixed_reads(reads_path, np.random.default_rng(70 + mode), ref, n=200)
+    s = run(["query", "-i", IDX[mode], "-r", reads_path, "--zml", "-n", "--stdout"])
+    assert s.returncode == 0, s.stderr
+    assert s.stdout == b"".join(b">" + rid + b"\n" + stdout_line(oracles[mode].zml(seq)).encode() + b"\n" for rid, seq in recs)
+    r = run(["query", "-i", IDX[mode], "-r", reads_path, "--zml", "-n"])
+    assert r.returncode == 0, r.stderr
+    name = reads_path + "." + TYPE[mode] + ".zml.bpf"
+    blob = open(name, "rb").read()
+    exp = struct.pack("<IBBBBHxx", 0x42504600, 1, 0, 0, 16, 0)
+    for rid, seq in recs:
+        z = oracles[mode].zml(seq)
+        exp += struct.pack("<H", len(rid)) + rid + struct.pack("<Q", len(z)) + z.astype("<u2").tobytes()
+    assert blob == exp
+    v = run(["view", "--bpf", name])
+    assert v.returncode == 0 and v.stdout == s.stdout
+    # prefetch mode: same records, scheduler order (a permutation); --pml given after --zml wins
+    r = run(["query", "-i", IDX[mode], "-r", reads_path, "--zml", "-s8", "-o", str(tmp_path / "zz"), "--gpus", "1"])
+    assert r.returncode == 0, r.stderr
+    v2 = run(["view", "--bpf", str(tmp_path / "zz") + ".zml.bpf"])
+    assert sorted(v2.stdout.split(b">")) == sorted(s.stdout.split(b">"))
+    r = run(["query", "-i", IDX[mode], "-r", reads_path, "--zml", "--pml", "-n", "--stdout"])
+    assert r.stdout == b"".join(b">" + rid + b"\n" + stdout_line(oracles[mode].pml(seq)).encode() + b"\n" for rid, seq in recs)
+
+
 def classify_py(pml, thr, bin_width=150):
     n, start, above, below, s, bins = len(pml), 0, 0, 0, 0, 0
     while start < n:

@@ -122,6 +122,68 @@ def test_count_vs_oracle(engines, mode):
 
 
 @pytest.mark.parametrize("mode", [6, 8])
+def test_zml_vs_oracle(engines, mode):
+    """MoveStructure::query_zml (src/move_structure_query.cpp:690-785): ragged reads with substitutions
+    and illegal characters, the edge cases around illegal first / last bases, every length 0..40
+    (packed-store tails)."""
+    from oracle import build_index as B
+    gpu, cpu = engines[mode]
+    ref = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))[0][1]
+    rng = np.random.default_rng(300 + mode)
+    reads = mutated_reads(rng, ref, 600, 1, 500)
+    reads += [b"", b"A", b"N", b"NN", b"AN", b"NA", b"NAN", b"ACGTN", b"NACGT", b"ACGTNNACGT", b"aACGT", b"ACGTa",
+              b"C" * 40, ref[1000:1300], ref[5:6], ref[2000:2300] + b"N" + ref[7000:7100]]
+    reads += [ref[3000:3000 + L] for L in range(0, 41)]
+    reads += [s for _, s in read_fastx(os.path.join(GOLDEN, "sample.fastq"))]
+    bases, offs = pack(reads)
+    z, st = gpu.query_zml_packed(bases, offs)
+    assert (z == cpu.zml_batch(bases, offs, threads=4)).all()
+    assert st.errors == 0
+    for i in (0, 5, 600, 601, 602, 603, 604, 605, 606):
+        assert (gpu.query_zml([reads[i]])[0] == cpu.zml(reads[i])).all()
+    # an exact substring is one phrase: 0, 1, 2, ...
+    one = gpu.query_zml([ref[1000:1300]])[0]
+    assert (one == np.arange(300)).all()
+
+
+def test_zml_u16_clamp_on_device(built_lib):
+    import movi_amd
+    from oracle import build_index as B
+    img = B.build_index_from_seqs([b"A" * 70000], 6, rc=False)
+    gpu = movi_amd.MoveIndex.from_image(img)
+    z = gpu.query_zml([b"A" * 66000])[0]
+    assert z[0] == 0 and z[65535] == 65535 and z[-1] == 65535
+    assert (np.diff(z[:65536].astype(np.int64)) == 1).all()
+
+
+@pytest.mark.parametrize("mode", [6, 8])
+def test_large_zml_batch_properties(built_lib, mode):
+    """1 M x 150 bp --zml on a 10 M-row table: size-independent properties on everything (values
+    restart at 0 and grow by exactly 1 inside a phrase; exact walks are a single phrase), the oracle
+    on a slice."""
+    import movi_amd
+    from oracle.oracle import Oracle
+    from tools import synth
+    six = synth.synth_index(10_000_000, mode=mode, seed=78)
+    img = six.image()
+    gpu = movi_amd.MoveIndex.from_image(img)
+    n_reads, L = 1_000_000, 150
+    bases, offs = synth.synth_reads(six, n_reads, L, seed=15, sub_rate=0.01, n_rate=0.001)
+    z, st = gpu.query_zml_packed(bases, offs)
+    assert st.errors == 0
+    zz = z.reshape(n_reads, L).astype(np.int32)
+    assert (zz[:, 0] == 0).all()
+    d = np.diff(zz, axis=1)
+    assert ((d == 1) | (zz[:, 1:] == 0)).all()          # either the phrase grows by one or a new one starts
+    illegal = bases.reshape(n_reads, L)[:, ::-1] == ord("N")
+    assert (zz[illegal] == 0).all()
+    cpu = Oracle(img)
+    sl = slice(250_000, 253_000)
+    exp = cpu.zml_batch(bases[sl.start * L: sl.stop * L], offs[sl.start: sl.stop + 1] - offs[sl.start], threads=8)
+    assert (z[sl.start * L: sl.stop * L] == exp).all()
+
+
+@pytest.mark.parametrize("mode", [6, 8])
 def test_synthetic_index_vs_oracle(built_lib, mode):
     """Seeded synthetic table (tools/synth.py) at a size the oracle does in seconds."""
     import movi_amd
@@ -138,6 +200,8 @@ def test_synthetic_index_vs_oracle(built_lib, mode):
     m, c, _ = gpu.query_count_packed(bases, offs)
     em, ec = cpu.count_batch(bases, offs, threads=8)
     assert (m == em).all() and (c == ec).all()
+    z, zst = gpu.query_zml_packed(bases, offs)
+    assert (z == cpu.zml_batch(bases, offs, threads=8)).all() and zst.errors == 0
 
 
 def test_u16_clamp_on_device(built_lib):
@@ -322,6 +386,8 @@ def test_fuzz_small_indexes(built_lib, tmp_path, alphabet):
             m, c, _ = gpu.query_count_packed(bases, offs)
             em, ec = cpu.count_batch(bases, offs, threads=2)
             assert (m == em).all() and (c == ec).all(), (alphabet, trial, mode)
+            z, _ = gpu.query_zml_packed(bases, offs)
+            assert (z == cpu.zml_batch(bases, offs, threads=2)).all(), (alphabet, trial, mode)
             gpu.close()
 
 
@@ -351,3 +417,5 @@ def test_real_bwt_pangenome_vs_oracle(built_lib, tmp_path, mode):
     m, c, _ = gpu.query_count_packed(bases, offs)
     em, ec = cpu.count_batch(bases, offs, threads=8)
     assert (m == em).all() and (c == ec).all()
+    z, zst = gpu.query_zml_packed(bases, offs)
+    assert (z == cpu.zml_batch(bases, offs, threads=8)).all() and zst.errors == 0

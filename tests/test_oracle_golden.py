@@ -109,3 +109,105 @@ def test_add_ml_clamp():
     p = o.pml(b"A" * 66000)
     assert p[0] == 1 and p[65534] == 65535 and p[65535] == 65535 and p[-1] == 65535
     assert (np.diff(p[:65535].astype(np.int64)) == 1).all()
+
+
+# ---------------------------------------------------------------- count / ZML against the text
+# The reference's tests hold no count or ZML vector; these pin the restated interval walkers
+# (update_interval + 2 LF) to an independent brute-force substring search over the fixture text.
+
+def _occurrences(T, P):
+    n, i = 0, T.find(P)
+    while i >= 0:
+        n += 1
+        i = T.find(P, i + 1)
+    return n
+
+
+def _zml_brute(T, R):
+    """Greedy Ziv-Merhav parse from the right with `in T` as the only matching primitive."""
+    legal = set(b"ACGT")
+    out = []
+    pos = len(R) - 1
+    while pos >= 0 and R[pos] not in legal:
+        out.append(0)
+        pos -= 1
+    if pos < 0:
+        return out
+    end, ml, alive = pos, 0, True                   # current phrase = R[pos..end]
+    while pos > 0:
+        if R[pos - 1] in legal and R[pos - 1:end + 1] in T:
+            out.append(ml); pos -= 1; ml += 1
+        else:
+            out.append(ml); pos -= 1; ml = 0
+            alive = False
+            while R[pos] not in legal and pos > 0:
+                out.append(0); pos -= 1
+            if R[pos] in legal:
+                end, alive = pos, True
+    out.append(ml if alive else 0)
+    return out
+
+
+def _mutated_reads(ref, rng, n, lo, hi, sub=0.03, ill=0.01):
+    reads = []
+    for _ in range(n):
+        L = int(rng.integers(lo, hi))
+        s = int(rng.integers(0, len(ref) - L))
+        r = bytearray(ref[s:s + L])
+        for k in range(L):
+            u = rng.random()
+            if u < sub:
+                r[k] = b"ACGT"[rng.integers(0, 4)]
+            elif u < sub + ill:
+                r[k] = b"Na"[rng.integers(0, 2)]
+        reads.append(bytes(r))
+    return reads
+
+
+@pytest.mark.parametrize("mode", [6, 8])
+def test_count_equals_brute_force(golden_image, mode):
+    o = Oracle(golden_image(mode))
+    recs = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))
+    T = bytes(B.clean_text([s for _, s in recs])[:-1])
+    rng = np.random.default_rng(21)
+    reads = _mutated_reads(recs[0][1], rng, 60, 1, 120, sub=0.02, ill=0.005) + [b"A", b"ACGT", b"TTTTTTTT", b"GNAC"]
+    for R in reads:
+        m, c = o.count(R)
+        if R[-1:] not in (b"A", b"C", b"G", b"T"):
+            assert (m, c) == (0, 0)
+            continue
+        # longest suffix of R (ending at the last base, legal characters only) that occurs in T
+        k = 1
+        while k < len(R) and R[len(R) - k - 1:len(R) - k] in (b"A", b"C", b"G", b"T") and R[len(R) - k - 1:] in T:
+            k += 1
+        assert m == k
+        assert c == _occurrences(T, R[len(R) - k:])
+
+
+@pytest.mark.parametrize("mode", [6, 8])
+def test_zml_equals_brute_force(golden_image, mode):
+    o = Oracle(golden_image(mode))
+    recs = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))
+    T = bytes(B.clean_text([s for _, s in recs])[:-1])
+    rng = np.random.default_rng(22)
+    reads = _mutated_reads(recs[0][1], rng, 60, 1, 200)
+    reads += [b"A", b"N", b"NN", b"NA", b"AN", b"NAN", b"ACGTNNACGT", b"aACGT", b"ACGTa", b"NNNNACGTACGTNNN"]
+    reads += [s for _, s in read_fastx(os.path.join(GOLDEN, "sample.fastq"))][:5]
+    for R in reads:
+        z = o.zml(R)
+        assert z.size == len(R)
+        assert z.tolist() == _zml_brute(T, R), R
+
+
+def test_zml_batch_and_clamp(golden_image):
+    o = Oracle(golden_image(6))
+    reads = [s for _, s in read_fastx(os.path.join(GOLDEN, "sample.fastq"))]
+    bases = np.frombuffer(b"".join(reads), np.uint8)
+    offs = np.concatenate(([0], np.cumsum([len(r) for r in reads]))).astype(np.uint64)
+    out = o.zml_batch(bases, offs, threads=2)
+    for i, r in enumerate(reads):
+        assert (out[int(offs[i]):int(offs[i + 1])] == o.zml(r)).all()
+    img = B.build_index_from_seqs([b"A" * 70000], 6, rc=False)
+    z = Oracle(img).zml(b"A" * 66000)               # one phrase: 0, 1, 2, ... clamped at 65535
+    assert z[0] == 0 and z[65535] == 65535 and z[-1] == 65535
+    assert (np.diff(z[:65536].astype(np.int64)) == 1).all()
