@@ -105,7 +105,7 @@ __device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
 
 // LF_move + fast_forward.  On entry `row` is rows[idx]; on exit it is the row of
 // the new idx.  `live` lanes take the step; returns a kErr* code (0 = ok) per lane.
-template <int MODE, int NB = 1>
+template <int MODE>
 __device__ __forceinline__ uint32_t lf_step(const DevIndex &ix, bool live, uint64_t &idx, uint32_t &off,
                                             uint2 &row, uint32_t &ff_total, const uint32_t *idb_lds = nullptr) {
     uint32_t errc = kErrNone;
@@ -124,28 +124,17 @@ __device__ __forceinline__ uint32_t lf_step(const DevIndex &ix, bool live, uint6
             going = (j < ix.r - 1 && off >= n) ? 1u : 0u;
         }
     }
-    // fast_forward :524-545.  Each trip fetches the next NB rows at once (they sit in the line
-    // the gather just brought in, so the loads are L2 hits issued back to back) and consumes
-    // them from registers: ceil(ff / NB) dependent round trips instead of ff.
+    // fast_forward :524-545: the next row sits in the line the gather just brought in (L2 hit)
     while (wave_any(going != 0u)) {
         if (going) {
-            uint2 w[NB];
-#pragma unroll
-            for (int q = 0; q < NB; ++q) {
-                const uint64_t jj = j + 1 + q;
-                w[q] = load_row<MODE>(ix.rows, jj < ix.r ? jj : ix.r - 1);
-            }
-#pragma unroll
-            for (int q = 0; q < NB; ++q) {
-                if (going) {
-                    off -= n;
-                    j += 1;
-                    ff += 1;
-                    row = w[q];
-                    n = row_n<MODE>(row);
-                    going = (j < ix.r - 1 && off >= n && ff < 65535u) ? 1u : 0u;
-                }
-            }
+            const uint64_t jj = j + 1;
+            const uint2 w = load_row<MODE>(ix.rows, jj < ix.r ? jj : ix.r - 1);
+            off -= n;
+            j += 1;
+            ff += 1;
+            row = w;
+            n = row_n<MODE>(row);
+            going = (j < ix.r - 1 && off >= n && ff < 65535u) ? 1u : 0u;
         }
     }
     if (ff >= 65535u) errc = kErrFastForward;           // move_structure.cpp:72-75
@@ -206,8 +195,7 @@ __device__ __forceinline__ uint32_t lf_step2(const DevIndex &ix, bool live, uint
 //   VARIANT 1: packed I/O -- each lane fetches its read 8 bases at a time (one 8-byte load
 //              per 8 steps) and emits PMLs 8 at a time (one 16-byte store per 8 steps), so the
 //              per-step traffic to L2 is the row gather alone.
-//   NB: neighbour rows fetched per fast-forward / scan trip.
-template <int MODE, int VARIANT, int NB = 1>
+template <int MODE, int VARIANT>
 __global__ __launch_bounds__(256) void pml_kernel(DevIndex ix, const uint8_t *__restrict__ bases,
                                                      const uint64_t *__restrict__ offs, uint64_t n_reads,
                                                      uint16_t *__restrict__ out, uint8_t *__restrict__ err,
@@ -264,7 +252,7 @@ __global__ __launch_bounds__(256) void pml_kernel(DevIndex ix, const uint8_t *__
             }
         }
         if (k != 0) {
-            const uint32_t e = lf_step<MODE, NB>(ix, live, idx, off, row, ff_total, idb);
+            const uint32_t e = lf_step<MODE>(ix, live, idx, off, row, ff_total, idb);
             if (e) { failed = e; live = false; }
         }
         uint32_t a = 0xFFu;
@@ -300,33 +288,24 @@ __global__ __launch_bounds__(256) void pml_kernel(DevIndex ix, const uint8_t *__
                 if (!down && idx == 0) { failed = kErrNoRunAbove; dir = 0; live = false; }
             }
         }
-        // reposition_down :211-232 / reposition_up :188-209 as one uniform loop, NB rows per trip
+        // reposition_down :211-232 / reposition_up :188-209 as one uniform loop, one row per trip
         uint32_t scanning = dir;
         while (wave_any(scanning != 0u)) {
             if (scanning) {
-                uint2 w[NB];
-#pragma unroll
-                for (int q = 0; q < NB; ++q) {
-                    uint64_t jj = (scanning == 1u) ? idx + 1 + q : idx - 1 - q;
-                    if (scanning == 1u) { if (jj >= ix.r) jj = ix.r - 1; }
-                    else if (jj > idx) jj = 0;                      // wrapped below row 0
-                    w[q] = load_row<MODE>(ix.rows, jj);
-                }
-#pragma unroll
-                for (int q = 0; q < NB; ++q) {
-                    if (scanning) {
-                        scan_total += 1;
-                        idx = (scanning == 1u) ? idx + 1 : idx - 1;
-                        row = w[q];
-                        const uint32_t c = row_c<MODE>(row);
-                        if (c == a) {
-                            scanning = 0;
-                        } else if (scanning == 1u ? (idx >= ix.r - 1) : (idx == 0)) {
-                            failed = scanning == 1u ? kErrNoRunBelow : kErrNoRunAbove;   // :582-598
-                            scanning = 0;
-                            live = false;
-                        }
-                    }
+                uint64_t jj = (scanning == 1u) ? idx + 1 : idx - 1;
+                if (scanning == 1u) { if (jj >= ix.r) jj = ix.r - 1; }
+                else if (jj > idx) jj = 0;                          // wrapped below row 0
+                const uint2 w = load_row<MODE>(ix.rows, jj);
+                scan_total += 1;
+                idx = (scanning == 1u) ? idx + 1 : idx - 1;
+                row = w;
+                const uint32_t c = row_c<MODE>(row);
+                if (c == a) {
+                    scanning = 0;
+                } else if (scanning == 1u ? (idx >= ix.r - 1) : (idx == 0)) {
+                    failed = scanning == 1u ? kErrNoRunBelow : kErrNoRunAbove;   // :582-598
+                    scanning = 0;
+                    live = false;
                 }
             }
         }
@@ -372,211 +351,16 @@ __global__ __launch_bounds__(256) void pml_kernel(DevIndex ix, const uint8_t *__
     }
 }
 
-// VARIANT 2 ("lane state machine"): the SIMT-friendly form of the walk.  In variants
-// 0/1 all 64 lanes advance base by base, so every step costs the wave
-// 1 + max_lanes(fast-forwards) + max_lanes(scan rows) dependent memory round trips.
-// Here each lane runs its own little automaton and every iteration of the (wave-uniform)
-// loop issues exactly ONE row load per lane for whatever that lane needs next -- the LF
-// destination, the next fast-forward row, or the next scan row.  A lane that needs three
-// extra rows simply falls three iterations behind its neighbours instead of stalling
-// them; the wave finishes after max_lanes(total row touches) iterations.
-//   states: kInit  first base: row r-1 just loaded, no LF yet
-//           kFF    `need` was reached by LF / fast-forward: keep forwarding or resolve the base
-//           kDown / kUp  repositioning scan in progress (`a` holds the base's code)
-//           kDone
-// I/O is packed as in variant 1; the next 8-base chunk is requested at the end of the
-// iteration that consumes the last base of the current one, so its latency hides behind
-// the next row load (loads return in order).
-//
-// NB > 1: every iteration fetches a window of NB consecutive rows starting at `need` (downwards
-// for an upward scan) in one go and the automaton consumes them from registers for as long as
-// the row it wants next is the next one of the window.  This kernel runs when few walks are in
-// flight (memory latency, not bandwidth, is the limit), so the speculative neighbours are free.
-template <int MODE, int NB>
-__global__ __launch_bounds__(256) void pml_kernel_sm(DevIndex ix, const uint8_t *__restrict__ bases,
-                                                     const uint64_t *__restrict__ offs, uint64_t n_reads,
-                                                     uint16_t *__restrict__ out, uint8_t *__restrict__ err,
-                                                     DevStats *stats, const uint32_t *__restrict__ order) {
-    enum : uint32_t { kInit = 0, kFF = 1, kDown = 2, kUp = 3, kDone = 4 };
-    __shared__ uint8_t s_code[256];
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = ix.code_of[i];
-    // mode 8: the (character, block) check points of the blocked ids, kept in LDS when they fit
-    // (4 x n_blocks x 4 B = 15 kB for 1 B rows) so that get_id costs no extra global load
-    __shared__ uint32_t s_idb[MODE == 8 ? kIdbLdsEntries : 1];
-    const uint32_t *idb = nullptr;
-    if (MODE == 8 && ix.n_blocks * 4 <= (uint64_t)kIdbLdsEntries) {
-        for (uint32_t i = threadIdx.x; i < (uint32_t)ix.n_blocks * 4; i += blockDim.x) s_idb[i] = ix.id_blocks[i];
-        idb = s_idb;
-    }
-    __syncthreads();
-
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t ff_total = 0, scan_total = 0, repo_total = 0, failed = 0;
-    const bool valid = t < n_reads;
-    // lane slot t works on read rid: the host may pass reads sorted by length so that the 64
-    // lanes of a wave finish together (ragged batches)
-    const uint64_t rid = (valid && order) ? order[t] : t;
-    const uint64_t beg = valid ? offs[rid] : 0;
-    const uint64_t len = valid ? offs[rid + 1] - beg : 0;
-    const uint8_t *R = bases + beg;
-    uint16_t *O = out + beg;
-    const uint64_t packed_end = len & ~7ull;              // PMLs of steps >= this are stored one by one
-
-    uint32_t st = len > 0 ? kInit : kDone;
-    uint64_t need = ix.r - 1;                             // ReadProcessor::reset_process :69-70
-    uint64_t idx = need;
-    uint64_t k = 0;                                       // steps done = bases consumed from the end
-    uint32_t off = 0, ml = 0, a = 0xFFu, ff_run = 0;
-    uint64_t rb = 0;                                      // current 8-base chunk (byte 7 = step k with k%8==0)
-    uint4 pk = make_uint4(0, 0, 0, 0);
-    // chunk c holds read positions [len-8(c+1), len-8c); a short final chunk is loaded as the
-    // 8 bytes ending at the chunk's top when that stays inside the buffer (its low bytes are
-    // a neighbour's bases and are never looked at), else byte by byte.
-    auto load_chunk = [&](uint64_t kk) -> uint64_t {
-        uint64_t v = 0;
-        if (beg + len >= kk + 8) {
-            __builtin_memcpy(&v, R + len - kk - 8, 8);    // may start before R: still inside `bases`
-        } else {
-            for (uint64_t i = 0; i < len - kk; ++i) v |= (uint64_t)R[len - 1 - kk - i] << (8 * (7 - i));
-        }
-        return v;
-    };
-    if (st != kDone) rb = load_chunk(0);
-
-    while (wave_any(st != kDone)) {
-      const bool up = st == kUp;
-      const uint64_t need0 = need;
-      uint2 w[NB];
-      if (st != kDone) {
-#pragma unroll
-          for (int q = 0; q < NB; ++q) {
-              uint64_t jj = up ? need0 - q : need0 + q;
-              if (up) { if (jj > need0) jj = 0; }                       // wrapped below row 0
-              else if (jj >= ix.r) jj = ix.r - 1;
-              w[q] = load_row<MODE>(ix.rows, jj);
-          }
-      }
-      bool want = st != kDone;
-#pragma unroll
-      for (int q = 0; q < NB; ++q) {
-       if (want) {
-        const uint2 row = w[q];
-        bool resolved = false;        // `row` (= rows[need]) is the row base k is compared with
-        bool emit = false;            // base k is finished; `row` at idx = need is its final row
-        if (st == kInit) {
-            off = row_n<MODE>(row) - 1;
-            resolved = true;
-        } else if (st == kFF) {
-            const uint32_t n = row_n<MODE>(row);
-            if (need < ix.r - 1 && off >= n) {            // fast_forward, move_structure.cpp:524-545
-                off -= n;
-                need += 1;
-                ff_run += 1;
-                if (ff_run >= 65535u) { failed = kErrFastForward; st = kDone; }   // :72-75
-            } else {
-                ff_total += ff_run;
-                resolved = true;
-            }
-        } else if (st == kDown || st == kUp) {            // reposition_down :211-232 / _up :188-209
-            scan_total += 1;
-            if (row_c<MODE>(row) == a) {
-                off = (st == kDown) ? 0u : row_n<MODE>(row) - 1;          // read_processor.cpp:223
-                emit = true;
-            } else if (st == kDown ? (need >= ix.r - 1) : (need == 0)) {
-                failed = (st == kDown) ? kErrNoRunBelow : kErrNoRunAbove; // :582-598
-                st = kDone;
-            } else {
-                need = (st == kDown) ? need + 1 : need - 1;
-            }
-        }
-        if (resolved) {
-            idx = need;
-            a = s_code[(uint32_t)(rb >> (8 * (7 - (k & 7)))) & 0xFFu];
-            const uint32_t rc = row_c<MODE>(row);         // the '$' row decodes as c == 0
-            if (a == 0xFFu) {
-                ml = 0;                                   // check_alphabet failed
-                emit = true;
-            } else if (rc == a) {
-                ml += 1;
-                emit = true;
-            } else {
-                // reposition_thresholds, src/move_structure_query.cpp:513-601
-                repo_total += 1;
-                ml = 0;
-                uint32_t down;
-                if (idx == ix.end_bwt_idx) {
-                    const uint64_t et = a == 1 ? ix.end_thr[1] : (a == 2 ? ix.end_thr[2] : ix.end_thr[3]);
-                    down = ((uint64_t)off >= et) ? 1u : 0u;
-                } else {
-                    const uint32_t kk = a - (a > rc ? 1u : 0u);          // alphamap_3[rc][a], utils.cpp:5-8
-                    const uint32_t thr = row_thr<MODE>(row, kk) ? row_n<MODE>(row) : 0u;
-                    down = (off >= thr) ? 1u : 0u;
-                }
-                if (down ? (idx == ix.r - 1) : (idx == 0)) {
-                    failed = down ? kErrNoRunBelow : kErrNoRunAbove;
-                    st = kDone;
-                } else {
-                    st = down ? kDown : kUp;
-                    need = down ? idx + 1 : idx - 1;
-                }
-            }
-        }
-        if (emit) {
-            idx = need;
-            const uint32_t val = ml > 65535u ? 65535u : ml;              // MoveQuery::add_ml
-            if (k >= packed_end) {
-                O[k] = (uint16_t)val;
-            } else {
-                pk.x = (pk.x >> 16) | (pk.y << 16);
-                pk.y = (pk.y >> 16) | (pk.z << 16);
-                pk.z = (pk.z >> 16) | (pk.w << 16);
-                pk.w = (pk.w >> 16) | (val << 16);
-                if ((k & 7) == 7) __builtin_memcpy(O + (k - 7), &pk, 16);
-            }
-            k += 1;
-            if (k == len) {
-                st = kDone;
-            } else {
-                // LF_move, move_structure.cpp:59-67
-                const uint64_t j = row_id<MODE>(row, idx, ix, idb);
-                if (j >= ix.r) {
-                    failed = kErrIdRange;
-                    st = kDone;
-                } else {
-                    off += row_off<MODE>(row);
-                    need = j;
-                    ff_run = 0;
-                    st = kFF;
-                    // (16-base fetches / paired stores as in pml_kernel measured SLOWER here: this
-                    // kernel runs latency-bound, every extra instruction per iteration shows)
-                    if ((k & 7) == 0) rb = load_chunk(k);
-                }
-            }
-        }
-       }
-       // go on only if the row wanted next is exactly the next row of the window
-       const uint64_t nxt = up ? need0 - (uint64_t)(q + 1) : need0 + (uint64_t)(q + 1);
-       want = st != kDone && need == nxt && (up ? need0 >= (uint64_t)(q + 1) : nxt < ix.r);
-      }
-    }
-    if (failed) {
-        for (uint64_t i = 0; i < len; ++i) O[i] = 0;
-    }
-    if (valid && err) err[rid] = (uint8_t)failed;
-    const uint32_t ffw = wave_sum(ff_total), scw = wave_sum(scan_total), rpw = wave_sum(repo_total),
-                   erw = wave_sum(failed ? 1u : 0u);
-    if ((threadIdx.x & 63) == 0 && stats) {
-        if (ffw) atomicAdd(&stats->fast_forwards, (unsigned long long)ffw);
-        if (scw) atomicAdd(&stats->scans, (unsigned long long)scw);
-        if (rpw) atomicAdd(&stats->repositions, (unsigned long long)rpw);
-        if (erw) atomicAdd(&stats->errors, (unsigned long long)erw);
-    }
-}
-
-// VARIANT 7 ("flat state machine"): the same per-lane automaton as pml_kernel_sm, written as
-// straight-line predicated code.  pml_kernel_sm runs latency-bound (1-2 waves per SIMD on long-read
-// batches) and spends ~37 % of its wave cycles issuing ~270 instructions per iteration, many of
-// them exec-mask bookkeeping and phi copies of its nested divergent branches.  Here every state
+// VARIANT 7 ("flat lane state machine"): the SIMT-friendly form of the walk for batches with few
+// reads.  In variants 0/1 all 64 lanes advance base by base, so every step costs the wave
+// 1 + max_lanes(fast-forwards) + max_lanes(scan rows) dependent memory round trips.  Here each lane
+// runs its own little automaton (states: fast-forwarding to / resolving a base, scanning down,
+// scanning up, done) and every iteration of the wave-uniform loop issues exactly ONE row load per
+// lane for whatever that lane needs next; a lane that needs three extra rows falls three
+// iterations behind its neighbours instead of stalling them.  The first version of this kernel used
+// ordinary nested branches (variant 2, removed: 11-12 % slower -- latency-bound at 1-2 waves per
+// SIMD it spent ~37 % of its wave cycles issuing ~270 instructions per iteration, many of them
+// exec-mask bookkeeping and phi copies); this one is straight-line predicated code: every state
 // update is a select, the only branches guard memory side effects, and the base code of step k
 // is looked up in LDS when k advances -- the lookup then overlaps the next row gather instead of
 // sitting between the row's arrival and the compare.
@@ -715,6 +499,211 @@ __global__ __launch_bounds__(256) void pml_kernel_flat(DevIndex ix, const uint8_
     }
 }
 
+// VARIANT 8 ("flat state machine + aligned row window"): variant 7 fetching, instead of the one row
+// it needs, the aligned 4-row window around it -- the same cache line, so the same single L2 request
+// -- and walking inside the window without further memory round trips: up to HA cheap fast-forward /
+// scan hops, the full automaton step on the row reached, then up to HC more hops for a scan that the
+// step just started.  Measured (100 k x 10 kbp, Gbases/s; variant 7 = 34.3 pangenome / 28.9 random
+// table): (HA, HC) = (1,0) 36.9 / 33.2, (2,0) 36.5 / 33.7 <- shipped, (3,0) 35.9 / 33.4, (2,1) 35.8 /
+// 32.9, (3,3) 31.8 / 29.1: the gather's latency dominates an iteration, so each hop's ~30
+// instructions must pay for themselves in saved (cheap, L2-hit) neighbour trips.
+template <int MODE>
+__device__ __forceinline__ void load_window(const uint8_t *rows, uint64_t wbase, uint2 (&w)[4]) {
+    if (MODE == 6) {
+        uint4 p0, p1;
+        __builtin_memcpy(&p0, rows + wbase * 8, 16);
+        __builtin_memcpy(&p1, rows + wbase * 8 + 16, 16);
+        w[0] = make_uint2(p0.x, p0.y); w[1] = make_uint2(p0.z, p0.w);
+        w[2] = make_uint2(p1.x, p1.y); w[3] = make_uint2(p1.z, p1.w);
+    } else {
+        unsigned long long x0, x1, x2;                    // rows 4m .. 4m+3 = bytes [24m, 24m+24)
+        __builtin_memcpy(&x0, rows + wbase * 6, 8);
+        __builtin_memcpy(&x1, rows + wbase * 6 + 8, 8);
+        __builtin_memcpy(&x2, rows + wbase * 6 + 16, 8);
+        const unsigned long long v1 = (x0 >> 48) | (x1 << 16), v2 = (x1 >> 32) | (x2 << 32), v3 = x2 >> 16;
+        w[0] = make_uint2((uint32_t)x0, (uint32_t)(x0 >> 32) & 0xFFFFu);
+        w[1] = make_uint2((uint32_t)v1, (uint32_t)(v1 >> 32) & 0xFFFFu);
+        w[2] = make_uint2((uint32_t)v2, (uint32_t)(v2 >> 32) & 0xFFFFu);
+        w[3] = make_uint2((uint32_t)v3, (uint32_t)(v3 >> 32) & 0xFFFFu);
+    }
+}
+__device__ __forceinline__ uint2 win_sel(const uint2 (&w)[4], uint32_t q) {
+    const uint2 lo = (q & 1u) ? w[1] : w[0];
+    const uint2 hi = (q & 1u) ? w[3] : w[2];
+    return (q & 2u) ? hi : lo;
+}
+
+template <int MODE, typename IdxT, int HA, int HC>
+__global__ __launch_bounds__(256) void pml_kernel_flatw(DevIndex ix, const uint8_t *__restrict__ bases,
+                                                       const uint64_t *__restrict__ offs, uint64_t n_reads,
+                                                       uint16_t *__restrict__ out, uint8_t *__restrict__ err,
+                                                       DevStats *stats, const uint32_t *__restrict__ order) {
+    enum : uint32_t { sFF = 0, sDown = 1, sUp = 2, sDone = 3 };
+    __shared__ uint8_t s_code[256];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = ix.code_of[i];
+    // mode 8: the (character, block) check points of the blocked ids, kept in LDS when they fit
+    // (4 x n_blocks x 4 B = 15 kB for 1 B rows) so that get_id costs no extra global load
+    __shared__ uint32_t s_idb[MODE == 8 ? kIdbLdsEntries : 1];
+    const uint32_t *idb = nullptr;
+    if (MODE == 8 && ix.n_blocks * 4 <= (uint64_t)kIdbLdsEntries) {
+        for (uint32_t i = threadIdx.x; i < (uint32_t)ix.n_blocks * 4; i += blockDim.x) s_idb[i] = ix.id_blocks[i];
+        idb = s_idb;
+    }
+    __syncthreads();
+
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t ff_total = 0, scan_total = 0, repo_total = 0, failed = 0;
+    const bool valid = t < n_reads;
+    const uint64_t rid = (valid && order) ? order[t] : t;
+    const uint64_t beg = valid ? offs[rid] : 0;
+    const uint32_t len = valid ? (uint32_t)(offs[rid + 1] - beg) : 0;   // reads are shorter than 2^32 (checked on the host)
+    const uint8_t *R = bases + beg;
+    uint16_t *O = out + beg;
+    const uint32_t packed_end = len & ~7u;
+    const IdxT r1 = (IdxT)(ix.r - 1), end_row = (IdxT)ix.end_bwt_idx;
+
+    auto load_chunk = [&](uint32_t kk) -> uint64_t {
+        uint64_t v = 0;
+        if (beg + len >= (uint64_t)kk + 8) {
+            __builtin_memcpy(&v, R + len - kk - 8, 8);    // may start before R: still inside `bases`
+        } else {
+            for (uint32_t i = 0; i < len - kk; ++i) v |= (uint64_t)R[len - 1 - kk - i] << (8 * (7 - i));
+        }
+        return v;
+    };
+
+    uint32_t st = len > 0 ? sFF : sDone;
+    IdxT need = r1;                                       // ReadProcessor::reset_process :69-70
+    uint32_t k = 0;
+    uint32_t ml = 0, ff_run = 0;
+    uint32_t off = row_n<MODE>(load_row<MODE>(ix.rows, r1)) - 1;
+    uint64_t rb = st != sDone ? load_chunk(0) : 0;
+    uint32_t a = s_code[(uint32_t)(rb >> 56) & 0xFFu];    // code of the base of step k (k = 0)
+    uint4 pk = make_uint4(0, 0, 0, 0);
+
+    while (wave_any(st != sDone)) {
+        // the aligned 4-row window that holds `need`: 32 bytes (mode 6, two 16-byte loads) or 24 bytes
+        // (mode 8, three 8-byte loads) of ONE cache line in most cases -- one L2 request like the 8-byte row
+        const IdxT wbase = need & ~(IdxT)3;
+        uint2 w[4] = {make_uint2(0, 0), make_uint2(0, 0), make_uint2(0, 0), make_uint2(0, 0)};
+        const bool act = st != sDone;
+        if (wave_any(act && (uint64_t)wbase + 3 > (uint64_t)r1)) {        // the table's last window: row by row
+            if (act) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint64_t jj = (uint64_t)wbase + q;
+                    w[q] = load_row<MODE>(ix.rows, jj < ix.r ? jj : ix.r - 1);
+                }
+            }
+        } else if (act) {
+            load_window<MODE>(ix.rows, (uint64_t)wbase, w);
+        }
+        // cheap hop: a fast-forward or scan step that only moves on (everything that resolves a base,
+        // starts a scan, ends one or fails is left to the full step below)
+        auto hop = [&]() {
+            const uint32_t inwin = (uint32_t)((need & ~(IdxT)3) == wbase) & (uint32_t)(st != sDone);
+            const uint2 hr = win_sel(w, (uint32_t)need & 3u);
+            const uint32_t hn = row_n<MODE>(hr), hc = row_c<MODE>(hr);
+            const uint32_t ffh = inwin & (uint32_t)(st == sFF) & (uint32_t)(need < r1) & (uint32_t)(off >= hn) &
+                                 (uint32_t)(ff_run + 1 < 65535u);
+            const uint32_t nomatch = hc != a;
+            const uint32_t dnh = inwin & (uint32_t)(st == sDown) & nomatch & (uint32_t)(need < r1);
+            const uint32_t uph = inwin & (uint32_t)(st == sUp) & nomatch & (uint32_t)(need != 0);
+            off = ffh ? off - hn : off;
+            ff_run += ffh;
+            scan_total += dnh | uph;
+            need = need + (IdxT)(ffh + dnh) - (IdxT)uph;
+        };
+#pragma unroll
+        for (int h = 0; h < HA; ++h) hop();
+        const uint32_t inwin = (uint32_t)((need & ~(IdxT)3) == wbase) & (uint32_t)act;
+        const uint2 row = win_sel(w, (uint32_t)need & 3u);
+        const uint32_t n = row_n<MODE>(row), c = row_c<MODE>(row);
+        // predicates as 0/1 integers combined with & | (no short-circuit control flow)
+        const uint32_t isFF = (uint32_t)(st == sFF) & inwin, isDown = (uint32_t)(st == sDown) & inwin,
+                       isUp = (uint32_t)(st == sUp) & inwin;
+        // fast_forward, move_structure.cpp:524-545
+        const uint32_t ffm = isFF & (uint32_t)(need < r1) & (uint32_t)(off >= n);
+        const uint32_t ff_over = ffm & (uint32_t)(ff_run + 1 >= 65535u);  // :72-75
+        const uint32_t resolved = isFF & (ffm ^ 1u);
+        // the base of step k against the row (read_processor.cpp:188-238)
+        const uint32_t illegal = a == 0xFFu, match = c == a;
+        const uint32_t mism = resolved & (illegal ^ 1u) & (match ^ 1u);
+        // reposition_thresholds, src/move_structure_query.cpp:513-601
+        const uint32_t kk = (a - (uint32_t)(a > c)) & 3u;                 // alphamap_3[c][a]
+        const uint32_t thr = row_thr<MODE>(row, kk > 2u ? 2u : kk) ? n : 0u;
+        const uint64_t et = a == 1 ? ix.end_thr[1] : (a == 2 ? ix.end_thr[2] : ix.end_thr[3]);
+        const uint32_t down = (need == end_row) ? (uint32_t)((uint64_t)off >= et) : (uint32_t)(off >= thr);
+        const uint32_t at_last = need >= r1, at_first = need == 0;
+        const uint32_t repo_edge = mism & (down ? at_last : at_first);
+        // reposition_down :211-232 / reposition_up :188-209, one row per iteration
+        const uint32_t scanning = isDown | isUp;
+        const uint32_t hit = scanning & match;
+        const uint32_t scan_edge = scanning & (hit ^ 1u) & (isDown ? at_last : at_first);
+        const uint32_t emit = (resolved & (illegal | match)) | hit;
+        const uint32_t errc = ff_over ? kErrFastForward
+                              : (repo_edge ? (down ? kErrNoRunBelow : kErrNoRunAbove)
+                                 : (scan_edge ? (isDown ? kErrNoRunBelow : kErrNoRunAbove) : kErrNone));
+        // ---- state update, all selects
+        ml = resolved ? (match ? ml + 1 : 0u) : ml;
+        ff_total += resolved ? ff_run : 0u;
+        ff_run += ffm;
+        repo_total += mism;
+        scan_total += scanning;
+        off = ffm ? off - n : (hit ? (isDown ? 0u : n - 1) : off);        // read_processor.cpp:223
+        const uint32_t step_fwd = ffm | (mism & down) | (scanning & (hit ^ 1u) & isDown);
+        const uint32_t step_back = (mism & (down ^ 1u)) | (scanning & (hit ^ 1u) & isUp);
+        IdxT need_next = need + step_fwd - step_back;
+        uint32_t st_next = mism ? (down ? sDown : sUp) : st;
+        if (emit) {
+            const uint32_t val = ml > 65535u ? 65535u : ml;               // MoveQuery::add_ml
+            if (k >= packed_end) {
+                O[k] = (uint16_t)val;
+            } else {
+                pk.x = (pk.x >> 16) | (pk.y << 16);
+                pk.y = (pk.y >> 16) | (pk.z << 16);
+                pk.z = (pk.z >> 16) | (pk.w << 16);
+                pk.w = (pk.w >> 16) | (val << 16);
+                if ((k & 7) == 7) __builtin_memcpy(O + (k - 7), &pk, 16);
+            }
+            k += 1;
+            if (k == len) {
+                st_next = sDone;
+            } else {
+                const uint64_t j = row_id<MODE>(row, need, ix, idb);      // LF_move, move_structure.cpp:59-67
+                if (j >= ix.r) {
+                    failed = kErrIdRange;
+                    st_next = sDone;
+                } else {
+                    off += row_off<MODE>(row);
+                    need_next = (IdxT)j;
+                    ff_run = 0;
+                    st_next = sFF;
+                    if ((k & 7) == 0) rb = load_chunk(k);
+                    a = s_code[(uint32_t)(rb >> (8 * (7 - (k & 7)))) & 0xFFu];
+                }
+            }
+        }
+        if (errc) { failed = errc; st_next = sDone; }
+        need = need_next;
+        st = st_next;
+#pragma unroll
+        for (int h = 0; h < HC; ++h) hop();
+    }
+    if (failed) {
+        for (uint32_t i = 0; i < len; ++i) O[i] = 0;
+    }
+    if (valid && err) err[rid] = (uint8_t)failed;
+    const uint32_t ffw = wave_sum(ff_total), scw = wave_sum(scan_total), rpw = wave_sum(repo_total),
+                   erw = wave_sum(failed ? 1u : 0u);
+    if ((threadIdx.x & 63) == 0 && stats) {
+        if (ffw) atomicAdd(&stats->fast_forwards, (unsigned long long)ffw);
+        if (scw) atomicAdd(&stats->scans, (unsigned long long)scw);
+        if (rpw) atomicAdd(&stats->repositions, (unsigned long long)rpw);
+        if (erw) atomicAdd(&stats->errors, (unsigned long long)erw);
+    }
+}
+
 hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets,
                       uint64_t n_reads, uint16_t *d_out, uint8_t *d_err, DevStats *d_stats,
                       const uint32_t *d_order, const LaunchCfg &cfg, hipStream_t stream) {
@@ -733,19 +722,25 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
         if (bpc < 1) bpc = 1;
         if (bpc < 32) dyn_lds = ((163840u / (unsigned)bpc) & ~1023u) - 1024u;
     }
-#define MOVI_LAUNCH_PML(M, V, N)                                                                               \
-    do {                                                                                                       \
-        if (dyn_lds > 65536) {                                                                                 \
-            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&pml_kernel<M, V, N>),          \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds);     \
-            if (ea != hipSuccess) return ea;                                                                   \
-        }                                                                                                      \
-        hipLaunchKernelGGL((pml_kernel<M, V, N>), grid, block, dyn_lds, stream, ix, d_bases, d_offsets,        \
-                           n_reads, d_out, d_err, d_stats, d_order);                                           \
+#define MOVI_LAUNCH_PML(M, V)                                                                               \
+    do {                                                                                                    \
+        if (dyn_lds > 65536) {                                                                              \
+            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&pml_kernel<M, V>),          \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds);  \
+            if (ea != hipSuccess) return ea;                                                                \
+        }                                                                                                   \
+        hipLaunchKernelGGL((pml_kernel<M, V>), grid, block, dyn_lds, stream, ix, d_bases, d_offsets,        \
+                           n_reads, d_out, d_err, d_stats, d_order);                                        \
     } while (0)
-#define MOVI_LAUNCH_SM(M, N)                                                                                \
-    hipLaunchKernelGGL((pml_kernel_sm<M, N>), grid, block, dyn_lds, stream, ix, d_bases, d_offsets, n_reads, \
-                       d_out, d_err, d_stats, d_order)
+#define MOVI_LAUNCH_FLATW(M, HA, HC)                                                                        \
+    do {                                                                                                    \
+        if (ix.r < 0xFFFFFFFFull)                                                                           \
+            hipLaunchKernelGGL((pml_kernel_flatw<M, uint32_t, HA, HC>), grid, block, dyn_lds, stream, ix,   \
+                               d_bases, d_offsets, n_reads, d_out, d_err, d_stats, d_order);                \
+        else                                                                                                \
+            hipLaunchKernelGGL((pml_kernel_flatw<M, uint64_t, HA, HC>), grid, block, dyn_lds, stream, ix,   \
+                               d_bases, d_offsets, n_reads, d_out, d_err, d_stats, d_order);                \
+    } while (0)
 #define MOVI_LAUNCH_FLAT(M)                                                                                 \
     do {                                                                                                    \
         if (ix.r < 0xFFFFFFFFull)                                                                           \
@@ -755,27 +750,25 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
             hipLaunchKernelGGL((pml_kernel_flat<M, uint64_t>), grid, block, dyn_lds, stream, ix, d_bases,   \
                                d_offsets, n_reads, d_out, d_err, d_stats, d_order);                         \
     } while (0)
+    // Variants: 0 first correct kernel, 1 base-synchronous packed I/O, 7 flat lane state machine,
+    // 8 = 7 + aligned 4-row window.  (2-6 were experiments -- branchy state machine, 2/4-row neighbour
+    // windows -- measured slower and removed; numbers in DESIGN.md section 3.)
     // Auto selection (measured on MI355X, profiles/): with plenty of reads (> ~12 waves per CU)
-    // the base-synchronous packed kernel (1) wins because its neighbour loads follow the gather
-    // at once and hit L2; with few reads in flight (long-read batches, small shards) the lane
-    // state machine wins because it needs ~2.3 instead of ~11 dependent trips per base -- in its
-    // flat predicated form (7), which is 11-12 % faster than the branchy one (2).
+    // variant 1 wins because its neighbour loads follow the gather at once and hit L2; with few
+    // reads in flight (long-read batches, small shards) the lane state machine wins because it
+    // needs ~1.5-2.3 instead of ~11 dependent trips per base.
     int v = cfg.pml_variant;
-    if (v < 0) v = (n_reads <= (uint64_t)cfg.num_cus * 64u * 12u) ? 7 : 1;   // measured crossover: ~12 waves per CU
+    if (v < 0) v = (n_reads <= (uint64_t)cfg.num_cus * 64u * 12u) ? 8 : 1;   // measured crossover: ~12 waves per CU
     if (mode == 6) {
-        if (v == 0) MOVI_LAUNCH_PML(6, 0, 1); else if (v == 1) MOVI_LAUNCH_PML(6, 1, 1);
-        else if (v == 4) MOVI_LAUNCH_PML(6, 1, 2); else if (v == 5) MOVI_LAUNCH_PML(6, 1, 4);
-        else if (v == 2) MOVI_LAUNCH_SM(6, 1); else if (v == 3) MOVI_LAUNCH_SM(6, 2); else if (v == 6) MOVI_LAUNCH_SM(6, 4);
-        else MOVI_LAUNCH_FLAT(6);
+        if (v == 0) MOVI_LAUNCH_PML(6, 0); else if (v == 1) MOVI_LAUNCH_PML(6, 1);
+        else if (v == 7) MOVI_LAUNCH_FLAT(6); else MOVI_LAUNCH_FLATW(6, 2, 0);
     } else {
-        if (v == 0) MOVI_LAUNCH_PML(8, 0, 1); else if (v == 1) MOVI_LAUNCH_PML(8, 1, 1);
-        else if (v == 4) MOVI_LAUNCH_PML(8, 1, 2); else if (v == 5) MOVI_LAUNCH_PML(8, 1, 4);
-        else if (v == 2) MOVI_LAUNCH_SM(8, 1); else if (v == 3) MOVI_LAUNCH_SM(8, 2); else if (v == 6) MOVI_LAUNCH_SM(8, 4);
-        else MOVI_LAUNCH_FLAT(8);
+        if (v == 0) MOVI_LAUNCH_PML(8, 0); else if (v == 1) MOVI_LAUNCH_PML(8, 1);
+        else if (v == 7) MOVI_LAUNCH_FLAT(8); else MOVI_LAUNCH_FLATW(8, 2, 0);
     }
 #undef MOVI_LAUNCH_PML
-#undef MOVI_LAUNCH_SM
 #undef MOVI_LAUNCH_FLAT
+#undef MOVI_LAUNCH_FLATW
     return hipGetLastError();
 }
 
