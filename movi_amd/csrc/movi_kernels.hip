@@ -826,6 +826,13 @@ __global__ __launch_bounds__(256) void count_kernel_v0(DevIndex ix, const uint8_
     }
     prs = rs; pre = re; pos_ = os; poe = oe;
     uint32_t empty = have && !run;
+    // rows[rs], rows[re]: loaded for the first step, afterwards carried over from the LF moves
+    // (lf_step2 leaves the rows of the new ends in rws / rwe), one dependent trip less per base
+    uint2 rws = make_uint2(0, 0), rwe = make_uint2(0, 0);
+    if (run) {
+        rws = load_row<MODE>(ix.rows, rs);
+        rwe = load_row<MODE>(ix.rows, re);
+    }
     while (wave_any(run != 0u && pos > 0)) {             // backward_search :176
         const bool act = run != 0u && pos > 0;
         uint32_t b = 0xFFu;
@@ -839,11 +846,8 @@ __global__ __launch_bounds__(256) void count_kernel_v0(DevIndex ix, const uint8_
         // Both ends shrink in ONE wave-uniform loop, one row per end and trip.  When the interval
         // holds no row of character b the two ends cross instead of rs running all the way past re as
         // in the reference; either way the interval is empty and the previous one is reported.
-        uint2 rws = make_uint2(0, 0), rwe = make_uint2(0, 0);
         uint32_t gs = 0, ge = 0;
         if (legal && rs <= re) {
-            rws = load_row<MODE>(ix.rows, rs);
-            rwe = load_row<MODE>(ix.rows, re);
             gs = (rs == ix.end_bwt_idx || row_c<MODE>(rws) != b) ? 1u : 0u;
             ge = (re == ix.end_bwt_idx || row_c<MODE>(rwe) != b) ? 1u : 0u;
         }
@@ -953,6 +957,7 @@ __global__ __launch_bounds__(256) void zml_kernel(DevIndex ix, const uint8_t *__
     uint64_t rs = 0, re = 0;                              // MoveInterval [rs:os, re:oe]
     uint32_t os = 0, oe = 0;
     uint32_t open = 0;                                    // 1 while a phrase (non-empty interval) exists
+    uint2 rws = make_uint2(0, 0), rwe = make_uint2(0, 0); // rows[rs], rows[re] while a phrase is open
     uint32_t ml = 0;
     uint64_t rb = 0, rb_next = 0;
     uint32_t have16 = 0;
@@ -981,11 +986,8 @@ __global__ __launch_bounds__(256) void zml_kernel(DevIndex ix, const uint8_t *__
         if (live) b = s_code[(uint32_t)(rb >> (8 * (7 - (k & 7)))) & 0xFFu];
         // backward_search_step, src/move_structure_search.cpp:311-333, for lanes with an open phrase
         const bool ext = live && open != 0u && b != 0xFFu;
-        uint2 rws = make_uint2(0, 0), rwe = make_uint2(0, 0);
         uint32_t gs = 0, ge = 0;
         if (ext && rs <= re) {                            // update_interval :48-61, as in count_kernel_v0
-            rws = load_row<MODE>(ix.rows, rs);
-            rwe = load_row<MODE>(ix.rows, re);
             gs = (rs == ix.end_bwt_idx || row_c<MODE>(rws) != b) ? 1u : 0u;
             ge = (re == ix.end_bwt_idx || row_c<MODE>(rwe) != b) ? 1u : 0u;
         }
@@ -1023,6 +1025,10 @@ __global__ __launch_bounds__(256) void zml_kernel(DevIndex ix, const uint8_t *__
                     rs = ix.first_runs[b + 1]; re = ix.last_runs[b + 1];
                     os = (uint32_t)ix.first_offsets[b + 1]; oe = (uint32_t)ix.last_offsets[b + 1];
                     open = ((rs < re) || (rs == re && os <= oe)) ? 1u : 0u;
+                    if (open) {                           // the LF moves carry the rows over from here on
+                        rws = load_row<MODE>(ix.rows, rs);
+                        rwe = load_row<MODE>(ix.rows, re);
+                    }
                 }
             }
         }
