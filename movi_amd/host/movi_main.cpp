@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <fstream>
 #include <iostream>
 #include <memory>
@@ -17,6 +18,7 @@
 #include <thread>
 
 #include "../../include/movi_hip.h"
+#include "nulldb.hpp"
 #include "options.hpp"
 #include "output.hpp"
 #include "reads.hpp"
@@ -304,6 +306,38 @@ int run_query(const Options &o) {
     return 0;
 }
 
+// `movi null`: Classifier::generate_null_statistics (src/classifier.cpp:12-22, driver src/movi.cpp:732-736).
+int run_null(const Options &o) {
+    const std::string pattern_file = o.index_dir + "/null_reads.fasta";
+    if (o.gen_reads) {
+        unsigned seed = (unsigned)std::time(nullptr);                 // srand(time(0)), src/utils.cpp:431
+        if (const char *e = std::getenv("MOVI_NULL_SEED")) seed = (unsigned)std::strtoul(e, nullptr, 10);
+        const size_t n = generate_null_reads(o.ref_file, pattern_file, seed);
+        std::cerr << "[movi] " << n << " null reads written to " << pattern_file << "\n";
+    }
+    movi_index_t *h = nullptr;
+    check(movi_index_load(o.device, o.index_dir.c_str(), &h), "loading the index");
+    struct Closer { movi_index_t *h; ~Closer() { movi_index_destroy(h); } } closer{h};
+    const std::vector<std::string> seqs = read_fasta_sequences(pattern_file);
+    std::vector<uint8_t> bases;
+    std::vector<uint64_t> offsets(1, 0);
+    for (const std::string &s : seqs) {
+        bases.insert(bases.end(), s.begin(), s.end());
+        offsets.push_back(bases.size());
+    }
+    std::vector<uint16_t> ml(bases.size());
+    check(o.zml ? movi_zml_host(h, bases.data(), offsets.data(), seqs.size(), ml.data(), nullptr, nullptr)
+                : movi_pml_host(h, bases.data(), offsets.data(), seqs.size(), ml.data(), nullptr, nullptr),
+          "null statistics");
+    const std::vector<uint64_t> values(ml.begin(), ml.end());        // ml_stats, emission order per read
+    const NullStats st = compute_null_stats(values);
+    const std::string name = o.index_dir + "/movi." + o.query_type() + ".nulldb";
+    write_null_db(name, st, values);
+    std::cerr << "[movi] Null database statistics: mean_null_stat: " << st.mean << " percentile_value: " << st.percentile_value
+              << " (" << st.num_values << " values) -> " << name << "\n";
+    return 0;
+}
+
 // `movi plan`: the host-side batching + record order, without any GPU work.
 int run_plan(const Options &o) {
     std::ifstream file_in;
@@ -338,6 +372,7 @@ int main(int argc, char **argv) {
         }
         if (o.command == "view") return view_bpf(o, std::cout);
         if (o.command == "plan") return run_plan(o);
+        if (o.command == "null") return run_null(o);
         return run_query(o);
     } catch (const UsageError &e) {
         std::cerr << "Error parsing command line options: " << e.what() << "\n" << usage();

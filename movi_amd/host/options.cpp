@@ -26,7 +26,8 @@ const Spec kSpecs[] = {
     {"bpf", 0, true},            {"small-bpf", 0, false},   {"large-bpf", 0, false},
     {"no-header", 0, false},     {"help", 'h', false},      {"gpus", 0, true},
     {"device", 0, true},         {"type", 0, true},         {"debug", 'd', false},
-    {"logs", 0, false},          {"mmap", 0, false},
+    {"logs", 0, false},          {"mmap", 0, false},        {"gen-reads", 0, false},
+    {"fasta", 'f', true},
     // recognised but unsupported query types / features
     {"zml", 0, false},           {"mem", 0, false},         {"rpml", 0, false},
     {"kmer", 0, false},          {"kmer-count", 0, false},  {"sa-entries", 0, false},
@@ -58,7 +59,8 @@ std::string usage() {
     return "movi (MI355X engine): movi query -i DIR -r FILE|- [-o PREFIX] [--pml|--zml|--count] [--classify] [--filter [-v]]\n"
            "                      [--stdout] [--no-output] [-s N] [-t N] [-n] [--reverse] [--bin-width N]\n"
            "                      [--ignore-illegal-chars 1] [--gpus N] [--device D] [--verbose]\n"
-           "       movi view --bpf FILE\n";
+           "       movi view --bpf FILE\n"
+           "       movi null -i DIR [--gen-reads -f REF.fasta] [--pml|--zml]\n";
 }
 
 Options parse_args(int argc, char **argv) {
@@ -126,6 +128,7 @@ Options parse_args(int argc, char **argv) {
         if (has("pml")) { o.pml = true; o.count = false; o.zml = false; }
         o.classify = has("classify");
         o.filter = has("filter");
+        if (o.filter) o.classify = true;                          // set_filter(), movi_options.hpp:122-125
         o.invert = has("invert");
         o.reverse = has("reverse");
         if (has("ignore-illegal-chars")) {
@@ -154,14 +157,26 @@ Options parse_args(int argc, char **argv) {
         if (has("no-prefetch")) o.prefetch = false;
         if (has("strands")) o.strands = (size_t)to_int("strands", val("strands"));
         if (o.strands == 0) o.strands = 1;
+    } else if (o.command == "null") {
+        // src/movi_parser.cpp:524-541
+        if (seen["index"].size() != 1) throw UsageError("Please specify the index directory file.");
+        o.index_dir = val("index");
+        if (has("gen-reads")) {
+            o.gen_reads = true;
+            if (!has("fasta")) throw UsageError("Please specify the reference fasta file.");
+            o.ref_file = val("fasta");
+        }
+        if (has("zml")) { o.zml = true; o.pml = false; }
+        if (has("pml")) { o.pml = true; o.zml = false; }
+        if (has("device")) o.device = (int)to_int("device", val("device"));
     } else if (o.command == "view") {
         if (seen["bpf"].size() != 1) throw UsageError("Please specify one mls file.");
         o.bpf_file = val("bpf");
         o.small_bpf = has("small-bpf");
         o.large_bpf = has("large-bpf");
     } else {
-        throw UsageError("The '" + o.command + "' action is not part of the MI355X engine (query and view only); use the "
-                         "reference movi for build / inspect / color / ftab / null.");
+        throw UsageError("The '" + o.command + "' action is not part of the MI355X engine (query, view and null only); use "
+                         "the reference movi for build / inspect / color / ftab.");
     }
     return o;
 }

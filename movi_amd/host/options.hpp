@@ -10,11 +10,13 @@
 namespace movi_host {
 
 struct Options {
-    std::string command;          // "query" | "view"
+    std::string command;          // "query" | "view" | "null" | "plan"
     std::string index_dir;        // -i / --index
     std::string read_file;        // -r / --read ("-" = stdin)
     std::string out_file;         // -o / --out-file
     std::string bpf_file;         // view --bpf
+    std::string ref_file;         // null --gen-reads -f/--fasta
+    bool gen_reads = false;       // null --gen-reads
     bool pml = true;              // default query type (movi_options.hpp:243)
     bool count = false;
     bool zml = false;             // --zml: Ziv-Merhav cross parse lengths, same outputs as PML

@@ -97,3 +97,20 @@ def stdout_line(pml_emission_order):
     """`--stdout` text of one read: values in read order, each followed by a space
     (include/move_query.hpp:33-37 + src/utils.cpp:214-219)."""
     return "".join("%d " % v for v in pml_emission_order[::-1])
+
+
+def classify_py(pml, thr, bin_width=150):
+    """Classifier::classify, src/classifier.cpp:99-143: (found, avg max, bins above, bins below)."""
+    n, start, above, below, s, bins = len(pml), 0, 0, 0, 0, 0
+    while start < n:
+        end = start + bin_width if start + bin_width < n else n
+        if n - end < bin_width:
+            end = n
+        mx = int(max(pml[start:end]))
+        above += mx >= thr
+        below += mx < thr
+        s += mx
+        bins += 1
+        start = end
+    found = above / (above + below + 0.0) > 0.5
+    return found, s / bins, above, below

@@ -34,6 +34,10 @@ def test_argument_errors(movi_bin):
     assert r.returncode == 1 and b"Please include one index directory and one read file." in r.stderr
     r = run(["query", "-i", "x", "-r", "y", "--mem"])
     assert r.returncode == 1 and b"not supported" in r.stderr
+    r = run(["null"])
+    assert r.returncode == 1 and b"Please specify the index directory file." in r.stderr       # movi_parser.cpp:538-540
+    r = run(["null", "-i", "x", "--gen-reads"])
+    assert r.returncode == 1 and b"Please specify the reference fasta file." in r.stderr       # movi_parser.cpp:531-533
     r = run(["build", "-i", "x", "-f", "y"])
     assert r.returncode == 1
     r = run(["query", "-i", "x", "-r", "y", "--ignore-illegal-chars", "3"])

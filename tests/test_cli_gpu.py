@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, ROOT, read_fastx, stdout_line
+from conftest import GOLDEN, ROOT, classify_py, read_fastx, stdout_line
 
 pytestmark = pytest.mark.gpu
 MOVI = os.path.join(ROOT, "movi_amd", "bin", "movi")
@@ -153,22 +153,6 @@ def test_zml_cli(movi_bin, oracles, tmp_path, mode):
     assert r.stdout == b"".join(b">" + rid + b"\n" + stdout_line(oracles[mode].pml(seq)).encode() + b"\n" for rid, seq in recs)
 
 
-def classify_py(pml, thr, bin_width=150):
-    n, start, above, below, s, bins = len(pml), 0, 0, 0, 0, 0
-    while start < n:
-        end = start + bin_width if start + bin_width < n else n
-        if n - end < bin_width:
-            end = n
-        mx = int(max(pml[start:end]))
-        above += mx >= thr
-        below += mx < thr
-        s += mx
-        bins += 1
-        start = end
-    found = above / (above + below + 0.0) > 0.5
-    return found, s / bins, above, below
-
-
 def test_classify_report_and_filter(movi_bin, oracles, tmp_path):
     from oracle import build_index as B
     ref = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))[0][1]
@@ -214,6 +198,61 @@ def test_classify_report_and_filter(movi_bin, oracles, tmp_path):
     assert r.stdout == b"".join(b">" + rid + b"\n" + seq + b"\n" for rid, seq in recs if rid in found_ids)
     r = run(["query", "-i", idx, "-r", reads_path, "--classify", "--filter", "-v", "-n"])
     assert r.stdout == b"".join(b">" + rid + b"\n" + seq + b"\n" for rid, seq in recs if rid not in found_ids)
+
+
+def null_stats_py(values):
+    """EmpNullDatabase::compute_stats, src/emperical_null_database.cpp:47-92."""
+    v = np.asarray(values, np.uint64)
+    uniq, cnt = np.unique(v, return_counts=True)
+    common = uniq[cnt >= 5]
+    perc = int(common.max()) if common.size else 0
+    return struct.pack("<QdQ", v.size, float(v.astype(np.float64).sum() / v.size), perc) + v.astype("<u8").tobytes(), perc
+
+
+@pytest.mark.parametrize("mode", [6, 8])
+def test_null_database_and_reference_filter_golden(movi_bin, oracles, tmp_path, mode):
+    """`movi null --gen-reads` (parse_null_reads + generate_null_statistics) and the reference's own
+    classification golden: tests/test_classification.cpp:54-100 runs `query --pml --filter --invert --stdout`
+    on sample.fasta and diffs the sorted output against sample.fasta.pmls.filtered_notfound.sorted."""
+    from oracle import build_index as B
+    idx = str(tmp_path / "idx")
+    shutil.copytree(IDX[mode], idx)
+    ref_path = os.path.join(GOLDEN, "ref.fasta")
+    env = dict(os.environ, MOVI_NULL_SEED="7")
+    r = run(["null", "-i", idx, "--gen-reads", "-f", ref_path], env=env)
+    assert r.returncode == 0, r.stderr
+    recs = B.read_fasta(ref_path)
+    nulls = read_fastx(os.path.join(idx, "null_reads.fasta"))
+    assert len(nulls) == 100 * len(recs) and all(len(s) == 150 for _, s in nulls)
+    assert [i for i, _ in nulls] == [b"read_%d" % k for k in range(len(nulls))]
+    raw = open(ref_path, "rb").read().split(b"\n")
+    whole = b"".join(l for l in raw if not l.startswith(b">"))
+    assert all(s[::-1] in whole for _, s in nulls)                  # reversed chunks of the reference
+    vals = np.concatenate([oracles[mode].pml(s) for _, s in nulls])
+    blob, perc = null_stats_py(vals)
+    assert open(os.path.join(idx, "movi.pml.nulldb"), "rb").read() == blob
+    assert 4 <= perc <= 40
+    # same seed -> same reads; ZML database from the existing reads (no --gen-reads)
+    r = run(["null", "-i", idx, "--zml"], env=env)
+    assert r.returncode == 0, r.stderr
+    zvals = np.concatenate([oracles[mode].zml(s) for _, s in nulls])
+    assert open(os.path.join(idx, "movi.zml.nulldb"), "rb").read() == null_stats_py(zvals)[0]
+    # the reference's golden (all 25 simulated reads are foreign to ref.fasta)
+    gold = open(os.path.join(GOLDEN, "sample.fasta.pmls.filtered_notfound.sorted"), "rb").read()
+    for flags in (["-s16", "-t1"], ["--no-prefetch", "-t1"]):
+        q = run(["query", "--index", idx, "--read", os.path.join(GOLDEN, "sample.fasta"), "--pml", "--filter", "--invert"]
+                + flags + ["--stdout"])
+        assert q.returncode == 0, q.stderr
+        assert b"".join(sorted(q.stdout.splitlines(keepends=True))) == gold
+    q = run(["query", "--index", idx, "--read", os.path.join(GOLDEN, "sample.fasta"), "--pml", "--filter", "--stdout"])
+    assert q.returncode == 0 and q.stdout == b""
+    # reads drawn from the reference itself are FOUND; ZML classification uses movi.zml.nulldb
+    own = tmp_path / "own.fa"
+    seq = recs[0][1]
+    own.write_bytes(b"".join(b">o%d\n%s\n" % (k, seq[k * 700:k * 700 + 450]) for k in range(8)))
+    for qt in ("--pml", "--zml"):
+        q = run(["query", "-i", idx, "-r", str(own), qt, "--filter", "--stdout", "-n"])
+        assert q.returncode == 0 and q.stdout == own.read_bytes()
 
 
 def test_reverse_illegal_chars_stdin_and_errors(movi_bin, oracles, tmp_path):

@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, golden_sorted_pmls, read_fastx, stdout_line
+from conftest import GOLDEN, classify_py, golden_sorted_pmls, read_fastx, stdout_line
 from oracle import build_index as B
 from oracle.oracle import Oracle
 
@@ -211,3 +211,27 @@ def test_zml_batch_and_clamp(golden_image):
     z = Oracle(img).zml(b"A" * 66000)               # one phrase: 0, 1, 2, ... clamped at 65535
     assert z[0] == 0 and z[65535] == 65535 and z[-1] == 65535
     assert (np.diff(z[:65536].astype(np.int64)) == 1).all()
+
+
+# tests/test_classification.cpp:54-100 of the reference: `query --pml --filter --invert --stdout` on sample.fasta,
+# sorted, equals sample.fasta.pmls.filtered_notfound.sorted.  The null database is regenerated here the way
+# `movi build` does (reversed random 150-bp chunks of the reference, src/utils.cpp:427-475; statistics
+# src/emperical_null_database.cpp:47-92) -- the reference seeds it with time(0), so its golden holds for any draw.
+@pytest.mark.parametrize("mode", [6, 8])
+@pytest.mark.parametrize("seed", [1, 2])
+def test_reference_filter_invert_golden(golden_image, mode, seed):
+    o = Oracle(golden_image(mode))
+    ref = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))[0][1]
+    rng = np.random.default_rng(seed)
+    vals = []
+    for _ in range(100):
+        at = int(rng.integers(0, len(ref) - 150))
+        vals.append(o.pml(ref[at:at + 150][::-1]))
+    uniq, cnt = np.unique(np.concatenate(vals), return_counts=True)
+    thr = max(int(uniq[cnt >= 5].max()), 3) + 1                     # src/classifier.cpp:32
+    out = []
+    for rid, seq in read_fastx(os.path.join(GOLDEN, "sample.fasta")):
+        found, _, _, _ = classify_py(o.pml(seq), thr)
+        if not found:                                               # --invert: output_read, src/utils.cpp:291-294
+            out += [b">" + rid + b"\n", seq + b"\n"]
+    assert b"".join(sorted(out)) == open(os.path.join(GOLDEN, "sample.fasta.pmls.filtered_notfound.sorted"), "rb").read()
