@@ -93,6 +93,9 @@ def main():
     ap.add_argument("--rows", type=int, default=0)
     ap.add_argument("--reads", type=int, default=0)
     ap.add_argument("--read-len", type=int, default=0)
+    ap.add_argument("--classify", type=int, default=0, choices=[0, 1, 2],
+                    help="PML with Classifier::classify bins fused into the walk (BASELINE config 3 is 'PML + --classify'): "
+                         "1 = PML vectors + bins, 2 = bins only (--classify --filter: no PML vector is written)")
     ap.add_argument("--variant", type=int, default=-1, help="pml kernel variant (A/B measurement)")
     ap.add_argument("--block-threads", type=int, default=0)
     ap.add_argument("--waves-per-cu", type=int, default=-1)
@@ -235,8 +238,18 @@ def main():
         d_matched = torch.zeros(n_reads, dtype=torch.int64, device=dev)
         d_count = torch.zeros(n_reads, dtype=torch.int64, device=dev)
 
+    if args.classify:
+        d_above = torch.zeros(n_reads, dtype=torch.int32, device=dev)
+        d_below = torch.zeros(n_reads, dtype=torch.int32, device=dev)
+        d_summax = torch.zeros(n_reads, dtype=torch.int64, device=dev)
+
     def step():
-        if args.query == "count":
+        if args.classify and args.query == "pml":
+            index.pml_classify_device(d_bases.data_ptr(), d_offs.data_ptr(), n_reads, n_bases, 150, 8,
+                                      d_out.data_ptr() if args.classify == 1 else 0, d_above.data_ptr(),
+                                      d_below.data_ptr(), d_summax.data_ptr(), d_err.data_ptr(), stream.cuda_stream,
+                                      d_order)
+        elif args.query == "count":
             index.count_device(d_bases.data_ptr(), d_offs.data_ptr(), n_reads, n_bases, d_matched.data_ptr(),
                                d_count.data_ptr(), d_err.data_ptr(), stream.cuda_stream, d_order)
         elif args.query == "zml":
@@ -319,7 +332,7 @@ def main():
                    "fast_forwards_per_base": round(f_bar, 4), "scans_per_base": round(s_bar, 4),
                    "reposition_frac": round(st.repositions / max(n_bases, 1), 4),
                    "algorithmic_bytes_per_base": round(bytes_per_base, 3),
-                   "query": args.query, "matched_bases_per_step": work_bases, "pml_variant": args.variant, "ragged": args.ragged, "waves_per_cu": args.waves_per_cu, "block_threads": args.block_threads, "index_gen_s": round(t_index_gen, 2),
+                   "query": args.query, "fused_classify": args.classify, "matched_bases_per_step": work_bases, "pml_variant": args.variant, "ragged": args.ragged, "waves_per_cu": args.waves_per_cu, "block_threads": args.block_threads, "index_gen_s": round(t_index_gen, 2),
                    "index_upload_s": round(t_index_upload, 2), "index_broadcast_s": round(t_bcast, 3),
                    "reads_gen_s": round(t_reads_gen, 2)},
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -355,7 +368,7 @@ def main():
         result["parity_sample_ok"] = bool((got == exp).all())
         if not result["parity_sample_ok"]:
             print("PARITY FAILURE on the cpu_baseline sample", file=sys.stderr)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.query == "pml":
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.query == "pml" and args.classify != 2:
         from oracle.oracle import Oracle
         cores = os.cpu_count() or 1
         cpu = Oracle(file_img if file_img is not None else six.image())

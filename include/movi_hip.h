@@ -14,7 +14,7 @@
  *   MoveStructure::query_pml        src/move_structure_query.cpp:234-474  movi_pml_host / movi_pml_device
  *   MoveStructure::query_backward_search  src/move_structure_search.cpp:340-352   movi_count_host / movi_count_device
  *   ReadProcessor::backward_search + compute_match_count  src/read_processor.cpp:610-620,1096-1175   movi_count_host / movi_count_device
- *   Classifier::classify (bins)     src/classifier.cpp:99-143           movi_classify_device / movi_pml_classify_host
+ *   Classifier::classify (bins)     src/classifier.cpp:99-143           movi_classify_device / movi_pml_classify_device / movi_pml_classify_host
  *   MoveStructure::query_zml        src/move_structure_query.cpp:690-785  movi_zml_host / movi_zml_device
  *
  * Conventions: every entry point returns an int status (MOVI_OK == 0) and never
@@ -147,8 +147,18 @@ int movi_classify_device(movi_index_t *ix, const uint16_t *d_pml, const uint64_t
                          uint32_t *d_bins_above, uint32_t *d_bins_below, uint64_t *d_sum_max,
                          void *stream);
 
-/* PML query + the reduction above in one call; the PML vectors never leave the GPU (what
- * `movi query --classify --filter` needs: 16 bytes back per read instead of 2 per base). */
+/* PML query with the reduction above FUSED into the walk (each lane keeps its running bin maximum
+ * in registers): one kernel, and with d_out_pml == NULL no PML vector is written at all -- what
+ * `movi query --classify --filter / --no-output` needs.  d_out_pml != NULL writes the vectors too
+ * (`--classify` with BPF output).  Other arguments as movi_pml_device / movi_classify_device. */
+int movi_pml_classify_device(movi_index_t *ix, const uint8_t *d_bases, const uint64_t *d_offsets,
+                             uint64_t n_reads, uint64_t n_bases, uint32_t bin_width,
+                             uint32_t max_value_thr, uint16_t *d_out_pml, uint32_t *d_bins_above,
+                             uint32_t *d_bins_below, uint64_t *d_sum_max, uint8_t *d_read_err,
+                             const uint32_t *d_read_order, void *stream);
+
+/* Host buffers in, bins out (16 bytes back per read instead of 2 per base); uses the fused kernel
+ * without a PML vector. */
 int movi_pml_classify_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_offsets,
                            uint64_t n_reads, uint32_t bin_width, uint32_t max_value_thr,
                            uint32_t *h_bins_above, uint32_t *h_bins_below, uint64_t *h_sum_max,

@@ -70,6 +70,9 @@ SYMBOLS = {
                                   C.c_void_p, C.POINTER(QueryStatsC)]),
     "movi_classify_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "movi_pml_classify_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32,
+                                           C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p]),
     "movi_pml_classify_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(QueryStatsC)]),
     "movi_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),

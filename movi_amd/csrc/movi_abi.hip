@@ -324,10 +324,12 @@ int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
 // ---------------------------------------------------------------------------- PML
 
 static int ml_device(bool zml, movi_index_t *ix, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
-                     uint64_t n_bases, uint16_t *d_out, uint8_t *d_read_err, const uint32_t *d_read_order, void *stream) {
+                     uint64_t n_bases, uint16_t *d_out, uint8_t *d_read_err, const uint32_t *d_read_order, void *stream,
+                     const ClsArgs &cls = ClsArgs()) {
     if (!ix) return fail(MOVI_ERR_ARG, "index handle is NULL");
     if (n_reads == 0) return MOVI_OK;
-    if (!d_offsets || (n_bases && (!d_bases || !d_out))) return fail(MOVI_ERR_ARG, "NULL device buffer");
+    const bool bins_only = cls.bin_width != 0 && !d_out;
+    if (!d_offsets || (n_bases && (!d_bases || (!d_out && !bins_only)))) return fail(MOVI_ERR_ARG, "NULL device buffer");
     HIP_TRY(hipSetDevice(ix->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     HIP_TRY(hipMemsetAsync(ix->d_stats, 0, sizeof(DevStats), s));
@@ -337,7 +339,7 @@ static int ml_device(bool zml, movi_index_t *ix, const uint8_t *d_bases, const u
                            d_read_order, ix->cfg, s));
     else
         HIP_TRY(launch_pml((int)ix->desc.mode, ix->dev, d_bases, d_offsets, n_reads, d_out, d_read_err, ix->d_stats,
-                           d_read_order, ix->cfg, s));
+                           d_read_order, ix->cfg, s, cls));
     return MOVI_OK;
 }
 
@@ -484,6 +486,21 @@ int movi_classify_device(movi_index_t *ix, const uint16_t *d_pml, const uint64_t
     return MOVI_OK;
 }
 
+int movi_pml_classify_device(movi_index_t *ix, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
+                             uint64_t n_bases, uint32_t bin_width, uint32_t max_value_thr, uint16_t *d_out_pml,
+                             uint32_t *d_bins_above, uint32_t *d_bins_below, uint64_t *d_sum_max, uint8_t *d_read_err,
+                             const uint32_t *d_read_order, void *stream) {
+    if (bin_width == 0) return fail(MOVI_ERR_ARG, "bin_width must be > 0");
+    if (n_reads && (!d_bins_above || !d_bins_below || !d_sum_max)) return fail(MOVI_ERR_ARG, "NULL device buffer");
+    ClsArgs cls;
+    cls.bin_width = bin_width;
+    cls.thr = max_value_thr;
+    cls.above = d_bins_above;
+    cls.below = d_bins_below;
+    cls.sum_max = d_sum_max;
+    return ml_device(false, ix, d_bases, d_offsets, n_reads, n_bases, d_out_pml, d_read_err, d_read_order, stream, cls);
+}
+
 int movi_pml_classify_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_offsets, uint64_t n_reads,
                            uint32_t bin_width, uint32_t max_value_thr, uint32_t *h_bins_above, uint32_t *h_bins_below,
                            uint64_t *h_sum_max, uint8_t *h_read_err, movi_query_stats_t *stats) {
@@ -493,15 +510,10 @@ int movi_pml_classify_host(movi_index_t *ix, const uint8_t *h_bases, const uint6
         return fail(MOVI_ERR_ARG, "NULL host buffer");
     if (bin_width == 0) return fail(MOVI_ERR_ARG, "bin_width must be > 0");
     HIP_TRY(hipSetDevice(ix->device));
-    DevBuf d_out, d_a, d_b, d_s;
-    uint64_t out_cap = 0, cap = 0;
+    DevBuf d_a, d_b, d_s;
+    uint64_t cap = 0;
     auto launch = [&](const uint8_t *db, const uint64_t *dof, uint64_t nr, uint64_t nb, uint8_t *derr,
                       const uint32_t *dord) -> int {
-        if (nb > out_cap) {
-            if (d_out.p) { (void)hipFree(d_out.p); d_out.p = nullptr; }
-            HIP_TRY(d_out.alloc(nb * 2));
-            out_cap = nb;
-        }
         if (nr > cap) {
             for (DevBuf *x : {&d_a, &d_b, &d_s}) if (x->p) { (void)hipFree(x->p); x->p = nullptr; }
             HIP_TRY(d_a.alloc(nr * 4));
@@ -509,13 +521,12 @@ int movi_pml_classify_host(movi_index_t *ix, const uint8_t *h_bases, const uint6
             HIP_TRY(d_s.alloc(nr * 8));
             cap = nr;
         }
-        int rc = movi_pml_device(ix, db, dof, nr, nb, static_cast<uint16_t *>(d_out.p), derr, dord, nullptr);
-        if (rc) return rc;
-        return movi_classify_device(ix, static_cast<const uint16_t *>(d_out.p), dof, nr, bin_width, max_value_thr,
-                                    static_cast<uint32_t *>(d_a.p), static_cast<uint32_t *>(d_b.p),
-                                    static_cast<uint64_t *>(d_s.p), nullptr);
+        // bins reduced inside the PML kernel; no PML vector is written at all
+        return movi_pml_classify_device(ix, db, dof, nr, nb, bin_width, max_value_thr, nullptr,
+                                        static_cast<uint32_t *>(d_a.p), static_cast<uint32_t *>(d_b.p),
+                                        static_cast<uint64_t *>(d_s.p), derr, dord, nullptr);
     };
-    auto fetch = [&](uint64_t first, uint64_t nr, uint64_t, uint64_t) -> int {     // the PMLs stay on the GPU
+    auto fetch = [&](uint64_t first, uint64_t nr, uint64_t, uint64_t) -> int {
         HIP_TRY(hipMemcpy(h_bins_above + first, d_a.p, nr * 4, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(h_bins_below + first, d_b.p, nr * 4, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(h_sum_max + first, d_s.p, nr * 8, hipMemcpyDeviceToHost));

@@ -189,17 +189,47 @@ __device__ __forceinline__ uint32_t lf_step2(const DevIndex &ix, bool live, uint
     return errc;
 }
 
+// Classifier::classify (src/classifier.cpp:99-143) as a running reduction over the values a lane emits:
+// bins of bin_width in emission order, the last bin absorbing a remainder shorter than bin_width.
+// CLS template parameter of the PML kernels: 0 = PML vector only, 1 = vector + bins, 2 = bins only.
+struct ClsState {
+    uint32_t cur = 0, above = 0, below = 0, bin = 0, nb = 1, next_cut = 0;
+    uint64_t sum = 0;
+    __device__ __forceinline__ void init(uint32_t len, uint32_t w) {
+        nb = w ? len / w : 0;
+        if (nb == 0) nb = 1;
+        next_cut = nb > 1 ? w : len;
+    }
+    __device__ __forceinline__ void add(uint32_t val, uint32_t k, uint32_t len, uint32_t w, uint32_t thr) {
+        cur = val > cur ? val : cur;
+        if (k + 1 == next_cut) {
+            above += cur >= thr ? 1u : 0u;
+            below += cur >= thr ? 0u : 1u;
+            sum += cur;
+            cur = 0;
+            bin += 1;
+            next_cut = (bin + 1 < nb) ? next_cut + w : len;
+        }
+    }
+    __device__ __forceinline__ void store(const ClsArgs &c, uint64_t rid, bool failed) const {
+        c.above[rid] = failed ? 0u : above;
+        c.below[rid] = failed ? 0u : below;
+        c.sum_max[rid] = failed ? 0ull : sum;
+    }
+};
+
 // ------------------------------------------------------------------------- PML
 // One lane per read; wave-uniform step loop, predicated per lane.
 //   VARIANT 0: one byte load and one u16 store per step and lane.
 //   VARIANT 1: packed I/O -- each lane fetches its read 8 bases at a time (one 8-byte load
 //              per 8 steps) and emits PMLs 8 at a time (one 16-byte store per 8 steps), so the
 //              per-step traffic to L2 is the row gather alone.
-template <int MODE, int VARIANT>
+template <int MODE, int VARIANT, int CLS>
 __global__ __launch_bounds__(256) void pml_kernel(DevIndex ix, const uint8_t *__restrict__ bases,
                                                      const uint64_t *__restrict__ offs, uint64_t n_reads,
                                                      uint16_t *__restrict__ out, uint8_t *__restrict__ err,
-                                                     DevStats *stats, const uint32_t *__restrict__ order) {
+                                                     DevStats *stats, const uint32_t *__restrict__ order,
+                                                     ClsArgs cls) {
     __shared__ uint8_t s_code[256];
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = ix.code_of[i];
     // mode 8: the (character, block) check points of the blocked ids, kept in LDS when they fit
@@ -230,6 +260,8 @@ __global__ __launch_bounds__(256) void pml_kernel(DevIndex ix, const uint8_t *__
     uint64_t rb = 0, rb_next = 0;                         // VARIANT 1: 8 bases, byte 7 = current step
     uint32_t have16 = 0;
     uint4 pk = make_uint4(0, 0, 0, 0), pk_old = pk;       // VARIANT 1: last 8 PMLs, oldest in the low bits
+    ClsState cs;
+    if (CLS) cs.init((uint32_t)len, cls.bin_width);
     const uint64_t packed_end = len & ~7ull;              // steps >= this are stored one by one
     for (uint64_t k = 0; wave_any(k < len && failed == 0u); ++k) {
         bool live = k < len && failed == 0u;
@@ -312,7 +344,10 @@ __global__ __launch_bounds__(256) void pml_kernel(DevIndex ix, const uint8_t *__
         if (dir == 1u) off = 0;
         if (dir == 2u) off = row_n<MODE>(row) - 1;        // read_processor.cpp:223
         const uint32_t val = ml > 65535u ? 65535u : ml;   // MoveQuery::add_ml
-        if (VARIANT >= 1) {
+        if (CLS && live) cs.add(val, (uint32_t)k, (uint32_t)len, cls.bin_width, cls.thr);
+        if (CLS == 2) {
+            // verdict bins only: the PML vector is never written
+        } else if (VARIANT >= 1) {
             if (live && k >= packed_end) {
                 O[k] = (uint16_t)val;
             } else if (live) {
@@ -336,9 +371,10 @@ __global__ __launch_bounds__(256) void pml_kernel(DevIndex ix, const uint8_t *__
     }
     // a read that broke an invariant reports all-zero PMLs plus its error code (the
     // reference aborts the whole run there; the host turns the flag into exit code 1)
-    if (failed) {
+    if (failed && CLS != 2) {
         for (uint64_t k = 0; k < len; ++k) O[k] = 0;
     }
+    if (CLS && valid) cs.store(cls, rid, failed != 0u);
     if (valid && err) err[rid] = (uint8_t)failed;
     // one atomic per wave per counter
     const uint32_t ffw = wave_sum(ff_total), scw = wave_sum(scan_total), rpw = wave_sum(repo_total),
@@ -365,11 +401,12 @@ __global__ __launch_bounds__(256) void pml_kernel(DevIndex ix, const uint8_t *__
 // is looked up in LDS when k advances -- the lookup then overlaps the next row gather instead of
 // sitting between the row's arrival and the compare.
 // IdxT = uint32_t when the table has fewer than 2^32 rows (half the index arithmetic).
-template <int MODE, typename IdxT>
+template <int MODE, typename IdxT, int CLS>
 __global__ __launch_bounds__(256) void pml_kernel_flat(DevIndex ix, const uint8_t *__restrict__ bases,
                                                        const uint64_t *__restrict__ offs, uint64_t n_reads,
                                                        uint16_t *__restrict__ out, uint8_t *__restrict__ err,
-                                                       DevStats *stats, const uint32_t *__restrict__ order) {
+                                                       DevStats *stats, const uint32_t *__restrict__ order,
+                                                       ClsArgs cls) {
     enum : uint32_t { sFF = 0, sDown = 1, sUp = 2, sDone = 3 };
     __shared__ uint8_t s_code[256];
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = ix.code_of[i];
@@ -412,6 +449,8 @@ __global__ __launch_bounds__(256) void pml_kernel_flat(DevIndex ix, const uint8_
     uint64_t rb = st != sDone ? load_chunk(0) : 0;
     uint32_t a = s_code[(uint32_t)(rb >> 56) & 0xFFu];    // code of the base of step k (k = 0)
     uint4 pk = make_uint4(0, 0, 0, 0);
+    ClsState cs;
+    if (CLS) cs.init(len, cls.bin_width);
 
     while (wave_any(st != sDone)) {
         uint2 row = make_uint2(0, 0);
@@ -454,7 +493,10 @@ __global__ __launch_bounds__(256) void pml_kernel_flat(DevIndex ix, const uint8_
         uint32_t st_next = mism ? (down ? sDown : sUp) : st;
         if (emit) {
             const uint32_t val = ml > 65535u ? 65535u : ml;               // MoveQuery::add_ml
-            if (k >= packed_end) {
+            if (CLS) cs.add(val, k, len, cls.bin_width, cls.thr);
+            if (CLS == 2) {
+                // verdict bins only
+            } else if (k >= packed_end) {
                 O[k] = (uint16_t)val;
             } else {
                 pk.x = (pk.x >> 16) | (pk.y << 16);
@@ -485,9 +527,10 @@ __global__ __launch_bounds__(256) void pml_kernel_flat(DevIndex ix, const uint8_
         need = need_next;
         st = st_next;
     }
-    if (failed) {
+    if (failed && CLS != 2) {
         for (uint32_t i = 0; i < len; ++i) O[i] = 0;
     }
+    if (CLS && valid) cs.store(cls, rid, failed != 0u);
     if (valid && err) err[rid] = (uint8_t)failed;
     const uint32_t ffw = wave_sum(ff_total), scw = wave_sum(scan_total), rpw = wave_sum(repo_total),
                    erw = wave_sum(failed ? 1u : 0u);
@@ -533,11 +576,12 @@ __device__ __forceinline__ uint2 win_sel(const uint2 (&w)[4], uint32_t q) {
     return (q & 2u) ? hi : lo;
 }
 
-template <int MODE, typename IdxT, int HA, int HC>
+template <int MODE, typename IdxT, int HA, int HC, int CLS>
 __global__ __launch_bounds__(256) void pml_kernel_flatw(DevIndex ix, const uint8_t *__restrict__ bases,
                                                        const uint64_t *__restrict__ offs, uint64_t n_reads,
                                                        uint16_t *__restrict__ out, uint8_t *__restrict__ err,
-                                                       DevStats *stats, const uint32_t *__restrict__ order) {
+                                                       DevStats *stats, const uint32_t *__restrict__ order,
+                                                       ClsArgs cls) {
     enum : uint32_t { sFF = 0, sDown = 1, sUp = 2, sDone = 3 };
     __shared__ uint8_t s_code[256];
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = ix.code_of[i];
@@ -580,6 +624,8 @@ __global__ __launch_bounds__(256) void pml_kernel_flatw(DevIndex ix, const uint8
     uint64_t rb = st != sDone ? load_chunk(0) : 0;
     uint32_t a = s_code[(uint32_t)(rb >> 56) & 0xFFu];    // code of the base of step k (k = 0)
     uint4 pk = make_uint4(0, 0, 0, 0);
+    ClsState cs;
+    if (CLS) cs.init(len, cls.bin_width);
 
     while (wave_any(st != sDone)) {
         // the aligned 4-row window that holds `need`: 32 bytes (mode 6, two 16-byte loads) or 24 bytes
@@ -657,7 +703,10 @@ __global__ __launch_bounds__(256) void pml_kernel_flatw(DevIndex ix, const uint8
         uint32_t st_next = mism ? (down ? sDown : sUp) : st;
         if (emit) {
             const uint32_t val = ml > 65535u ? 65535u : ml;               // MoveQuery::add_ml
-            if (k >= packed_end) {
+            if (CLS) cs.add(val, k, len, cls.bin_width, cls.thr);
+            if (CLS == 2) {
+                // verdict bins only
+            } else if (k >= packed_end) {
                 O[k] = (uint16_t)val;
             } else {
                 pk.x = (pk.x >> 16) | (pk.y << 16);
@@ -690,9 +739,10 @@ __global__ __launch_bounds__(256) void pml_kernel_flatw(DevIndex ix, const uint8
 #pragma unroll
         for (int h = 0; h < HC; ++h) hop();
     }
-    if (failed) {
+    if (failed && CLS != 2) {
         for (uint32_t i = 0; i < len; ++i) O[i] = 0;
     }
+    if (CLS && valid) cs.store(cls, rid, failed != 0u);
     if (valid && err) err[rid] = (uint8_t)failed;
     const uint32_t ffw = wave_sum(ff_total), scw = wave_sum(scan_total), rpw = wave_sum(repo_total),
                    erw = wave_sum(failed ? 1u : 0u);
@@ -706,8 +756,12 @@ __global__ __launch_bounds__(256) void pml_kernel_flatw(DevIndex ix, const uint8
 
 hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets,
                       uint64_t n_reads, uint16_t *d_out, uint8_t *d_err, DevStats *d_stats,
-                      const uint32_t *d_order, const LaunchCfg &cfg, hipStream_t stream) {
+                      const uint32_t *d_order, const LaunchCfg &cfg, hipStream_t stream, const ClsArgs &cls) {
     if (n_reads == 0) return hipSuccess;
+    // 0 = PML vector only, 1 = vector + classification bins, 2 = bins only
+    const int cm = cls.bin_width == 0 ? 0 : (d_out ? 1 : 2);
+    if (cm == 0 && !d_out) return hipErrorInvalidValue;
+    if (cm != 0 && (!cls.above || !cls.below || !cls.sum_max)) return hipErrorInvalidValue;
     const int bt = cfg.block_threads;
     const uint64_t blocks = (n_reads + bt - 1) / bt;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
@@ -722,33 +776,37 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
         if (bpc < 1) bpc = 1;
         if (bpc < 32) dyn_lds = ((163840u / (unsigned)bpc) & ~1023u) - 1024u;
     }
-#define MOVI_LAUNCH_PML(M, V)                                                                               \
+#define MOVI_LAUNCH_PML(M, V, C)                                                                            \
     do {                                                                                                    \
         if (dyn_lds > 65536) {                                                                              \
-            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&pml_kernel<M, V>),          \
+            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&pml_kernel<M, V, C>),       \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds);  \
             if (ea != hipSuccess) return ea;                                                                \
         }                                                                                                   \
-        hipLaunchKernelGGL((pml_kernel<M, V>), grid, block, dyn_lds, stream, ix, d_bases, d_offsets,        \
-                           n_reads, d_out, d_err, d_stats, d_order);                                        \
+        hipLaunchKernelGGL((pml_kernel<M, V, C>), grid, block, dyn_lds, stream, ix, d_bases, d_offsets,     \
+                           n_reads, d_out, d_err, d_stats, d_order, cls);                                   \
     } while (0)
-#define MOVI_LAUNCH_FLATW(M, HA, HC)                                                                        \
+#define MOVI_LAUNCH_FLATW(M, C)                                                                             \
     do {                                                                                                    \
         if (ix.r < 0xFFFFFFFFull)                                                                           \
-            hipLaunchKernelGGL((pml_kernel_flatw<M, uint32_t, HA, HC>), grid, block, dyn_lds, stream, ix,   \
-                               d_bases, d_offsets, n_reads, d_out, d_err, d_stats, d_order);                \
+            hipLaunchKernelGGL((pml_kernel_flatw<M, uint32_t, 2, 0, C>), grid, block, dyn_lds, stream, ix,  \
+                               d_bases, d_offsets, n_reads, d_out, d_err, d_stats, d_order, cls);           \
         else                                                                                                \
-            hipLaunchKernelGGL((pml_kernel_flatw<M, uint64_t, HA, HC>), grid, block, dyn_lds, stream, ix,   \
-                               d_bases, d_offsets, n_reads, d_out, d_err, d_stats, d_order);                \
+            hipLaunchKernelGGL((pml_kernel_flatw<M, uint64_t, 2, 0, C>), grid, block, dyn_lds, stream, ix,  \
+                               d_bases, d_offsets, n_reads, d_out, d_err, d_stats, d_order, cls);           \
     } while (0)
 #define MOVI_LAUNCH_FLAT(M)                                                                                 \
     do {                                                                                                    \
         if (ix.r < 0xFFFFFFFFull)                                                                           \
-            hipLaunchKernelGGL((pml_kernel_flat<M, uint32_t>), grid, block, dyn_lds, stream, ix, d_bases,   \
-                               d_offsets, n_reads, d_out, d_err, d_stats, d_order);                         \
+            hipLaunchKernelGGL((pml_kernel_flat<M, uint32_t, 0>), grid, block, dyn_lds, stream, ix,         \
+                               d_bases, d_offsets, n_reads, d_out, d_err, d_stats, d_order, cls);           \
         else                                                                                                \
-            hipLaunchKernelGGL((pml_kernel_flat<M, uint64_t>), grid, block, dyn_lds, stream, ix, d_bases,   \
-                               d_offsets, n_reads, d_out, d_err, d_stats, d_order);                         \
+            hipLaunchKernelGGL((pml_kernel_flat<M, uint64_t, 0>), grid, block, dyn_lds, stream, ix,         \
+                               d_bases, d_offsets, n_reads, d_out, d_err, d_stats, d_order, cls);           \
+    } while (0)
+#define MOVI_BY_CLS(LAUNCH, ...)                                                                            \
+    do {                                                                                                    \
+        if (cm == 0) LAUNCH(__VA_ARGS__, 0); else if (cm == 1) LAUNCH(__VA_ARGS__, 1); else LAUNCH(__VA_ARGS__, 2); \
     } while (0)
     // Variants: 0 first correct kernel, 1 base-synchronous packed I/O, 7 flat lane state machine,
     // 8 = 7 + aligned 4-row window.  (2-6 were experiments -- branchy state machine, 2/4-row neighbour
@@ -759,16 +817,18 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     // needs ~1.5-2.3 instead of ~11 dependent trips per base.
     int v = cfg.pml_variant;
     if (v < 0) v = (n_reads <= (uint64_t)cfg.num_cus * 64u * 12u) ? 8 : 1;   // measured crossover: ~12 waves per CU
+    if (cm != 0 && (v == 0 || v == 7)) v = (v == 0) ? 1 : 8;                 // the A/B kernels carry no fused bins
     if (mode == 6) {
-        if (v == 0) MOVI_LAUNCH_PML(6, 0); else if (v == 1) MOVI_LAUNCH_PML(6, 1);
-        else if (v == 7) MOVI_LAUNCH_FLAT(6); else MOVI_LAUNCH_FLATW(6, 2, 0);
+        if (v == 0) MOVI_LAUNCH_PML(6, 0, 0); else if (v == 1) MOVI_BY_CLS(MOVI_LAUNCH_PML, 6, 1);
+        else if (v == 7) MOVI_LAUNCH_FLAT(6); else MOVI_BY_CLS(MOVI_LAUNCH_FLATW, 6);
     } else {
-        if (v == 0) MOVI_LAUNCH_PML(8, 0); else if (v == 1) MOVI_LAUNCH_PML(8, 1);
-        else if (v == 7) MOVI_LAUNCH_FLAT(8); else MOVI_LAUNCH_FLATW(8, 2, 0);
+        if (v == 0) MOVI_LAUNCH_PML(8, 0, 0); else if (v == 1) MOVI_BY_CLS(MOVI_LAUNCH_PML, 8, 1);
+        else if (v == 7) MOVI_LAUNCH_FLAT(8); else MOVI_BY_CLS(MOVI_LAUNCH_FLATW, 8);
     }
 #undef MOVI_LAUNCH_PML
 #undef MOVI_LAUNCH_FLAT
 #undef MOVI_LAUNCH_FLATW
+#undef MOVI_BY_CLS
     return hipGetLastError();
 }
 

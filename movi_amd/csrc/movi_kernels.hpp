@@ -34,16 +34,28 @@ struct DevStats {
 
 struct LaunchCfg {
     int block_threads = 256;
-    // -1 auto; base-synchronous pml_kernel: 0 (plain I/O), 1 / 4 / 5 (packed I/O, 1 / 2 / 4 neighbour rows per trip);
-    // lane state machine pml_kernel_sm: 2 / 3 / 6 (1 / 2 / 4-row window per iteration); 7: pml_kernel_flat
+    // -1 auto; 0 first kernel (plain I/O), 1 base-synchronous packed I/O, 7 flat lane state machine,
+    // 8 flat lane state machine + aligned row window
     int pml_variant = -1;
     int num_cus = 256;
     int waves_per_cu = 0;  // 0 = no cap; else cap resident waves per CU by padding the block's LDS allocation
 };
 
+// Classifier::classify bins (src/classifier.cpp:99-143) fused into the PML kernels: per read the number of
+// bins whose maximum is >= thr / < thr and the sum of the bin maxima.
+struct ClsArgs {
+    uint32_t bin_width = 0;                // 0 = no classification
+    uint32_t thr = 0;
+    uint32_t *above = nullptr;
+    uint32_t *below = nullptr;
+    uint64_t *sum_max = nullptr;
+};
+
+// d_out == nullptr is allowed when cls.bin_width != 0: verdict bins only, no PML vector is written.
 hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets,
                       uint64_t n_reads, uint16_t *d_out, uint8_t *d_err, DevStats *d_stats,
-                      const uint32_t *d_order, const LaunchCfg &cfg, hipStream_t stream);
+                      const uint32_t *d_order, const LaunchCfg &cfg, hipStream_t stream,
+                      const ClsArgs &cls = ClsArgs());
 
 hipError_t launch_count(int mode, const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets,
                         uint64_t n_reads, uint64_t *d_matched, uint64_t *d_count, uint8_t *d_err,

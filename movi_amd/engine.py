@@ -199,6 +199,17 @@ class MoveIndex:
                                     C.c_void_p(d_order) if d_order else None,
                                     C.c_void_p(stream) if stream else None))
 
+    def pml_classify_device(self, d_bases, d_offs, n_reads, n_bases, bin_width, max_value_thr, d_out, d_above,
+                            d_below, d_sum, d_err=0, stream=0, d_order=0):
+        """PML walk with Classifier::classify bins fused in; d_out = 0 writes no PML vector."""
+        check(lib().movi_pml_classify_device(self._h, C.c_void_p(d_bases), C.c_void_p(d_offs), n_reads, n_bases,
+                                             int(bin_width), int(max_value_thr),
+                                             C.c_void_p(d_out) if d_out else None, C.c_void_p(d_above),
+                                             C.c_void_p(d_below), C.c_void_p(d_sum),
+                                             C.c_void_p(d_err) if d_err else None,
+                                             C.c_void_p(d_order) if d_order else None,
+                                             C.c_void_p(stream) if stream else None))
+
     def zml_device(self, d_bases, d_offs, n_reads, n_bases, d_out, d_err=0, stream=0, d_order=0):
         check(lib().movi_zml_device(self._h, C.c_void_p(d_bases), C.c_void_p(d_offs), n_reads, n_bases,
                                     C.c_void_p(d_out), C.c_void_p(d_err) if d_err else None,

@@ -341,6 +341,66 @@ def test_classification_bins_on_device(engines, bin_width, thr):
         assert (int(a[i]), int(b[i]), int(s[i])) == (ea, eb, es), (i, len(r))
 
 
+@pytest.mark.parametrize("mode", [6, 8])
+@pytest.mark.parametrize("variant", [1, 8])
+def test_fused_classification_kernels(engines, mode, variant):
+    """movi_pml_classify_device: the bins fused into the PML walk, with and without the PML vector, in both
+    shipped kernels, against the bins of the oracle's PML vectors and against the standalone
+    movi_classify_device reduction over the resident vectors."""
+    import ctypes as C
+    import torch
+    from conftest import classify_py
+    from movi_amd._lib import lib
+    from oracle import build_index as B
+    gpu, cpu = engines[mode]
+    ref = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))[0][1]
+    rng = np.random.default_rng(900 + mode + variant)
+    reads = mutated_reads(rng, ref, 700, 1, 900) + [b"", b"A", ref[:149], ref[:150], ref[:151], ref[:299], ref[:300], ref[:449]]
+    bases, offs = pack(reads)
+    n = len(reads)
+    dev = torch.device("cuda", 0)
+    d_bases = torch.from_numpy(bases.copy()).to(dev)
+    d_offs = torch.from_numpy(offs.view(np.int64).copy()).to(dev)
+    exp_pml, _, _ = cpu.pml_batch(bases, offs, threads=4)
+    gpu.set_option("pml_variant", variant)
+    try:
+        for bin_width, thr in ((150, 7), (40, 3), (1, 1)):
+            exp = [classify_py(exp_pml[int(offs[i]):int(offs[i + 1])], thr, bin_width) if len(r) else None
+                   for i, r in enumerate(reads)]
+            for with_vector in (True, False):
+                d_out = torch.zeros(max(bases.size, 1), dtype=torch.int16, device=dev)
+                d_a = torch.full((n,), -1, dtype=torch.int32, device=dev)
+                d_b = torch.full((n,), -1, dtype=torch.int32, device=dev)
+                d_s = torch.full((n,), -1, dtype=torch.int64, device=dev)
+                gpu.pml_classify_device(d_bases.data_ptr(), d_offs.data_ptr(), n, bases.size, bin_width, thr,
+                                        d_out.data_ptr() if with_vector else 0, d_a.data_ptr(), d_b.data_ptr(),
+                                        d_s.data_ptr())
+                torch.cuda.synchronize()
+                a, b, sm = d_a.cpu().numpy(), d_b.cpu().numpy(), d_s.cpu().numpy()
+                for i, e in enumerate(exp):
+                    if e is None:
+                        assert (a[i], b[i], sm[i]) == (0, 0, 0)
+                    else:
+                        found, avg, ea, eb = e
+                        assert (a[i], b[i]) == (ea, eb) and sm[i] == round(avg * (ea + eb)), (i, len(reads[i]))
+                if with_vector:
+                    assert (d_out.cpu().numpy().view(np.uint16)[:bases.size] == exp_pml).all()
+                    # standalone reduction over the resident vectors agrees
+                    d_a2, d_b2, d_s2 = torch.zeros_like(d_a), torch.zeros_like(d_b), torch.zeros_like(d_s)
+                    rc = lib().movi_classify_device(gpu._h, C.c_void_p(d_out.data_ptr()), C.c_void_p(d_offs.data_ptr()), n,
+                                                    bin_width, thr, C.c_void_p(d_a2.data_ptr()), C.c_void_p(d_b2.data_ptr()),
+                                                    C.c_void_p(d_s2.data_ptr()), None)
+                    assert rc == 0
+                    torch.cuda.synchronize()
+                    nz = np.array([len(r) > 0 for r in reads])
+                    assert (d_a2.cpu().numpy()[nz] == a[nz]).all() and (d_b2.cpu().numpy()[nz] == b[nz]).all()
+                    assert (d_s2.cpu().numpy()[nz] == sm[nz]).all()
+                else:
+                    assert int(d_out.abs().sum().item()) == 0          # nothing was written
+    finally:
+        gpu.set_option("pml_variant", -1)
+
+
 @pytest.mark.parametrize("alphabet", [b"ACGT", b"ACG", b"AT", b"GT", b"C"])
 def test_fuzz_small_indexes(built_lib, tmp_path, alphabet):
     """Many tiny indexes with awkward structure (reduced alphabets -> shifted codes and a shorter
