@@ -398,6 +398,10 @@ int run_chunked(movi_index *ix, const uint8_t *h_bases, const uint64_t *h_offset
         HIP_TRY(d_err.alloc(nr));
         std::vector<uint64_t> rel(nr + 1);
         for (uint64_t i = 0; i <= nr; i++) rel[i] = h_offsets[first + i] - b0;
+        for (uint64_t i = 0; i < nr; i++) {
+            if (rel[i + 1] < rel[i]) return fail(MOVI_ERR_ARG, "read offsets are not non-decreasing");
+            if (rel[i + 1] - rel[i] > 0xFFFFFFFFull) return fail(MOVI_ERR_ARG, "a read is longer than 2^32 - 1 bases");
+        }
         // No length sort here: on ragged batches handing the lanes out longest-first measured
         // slightly SLOWER (31.1 vs 32.8 Gbases/s, log-normal lengths) -- the walk is bound by the
         // memory system, not by lane occupancy, and the dispatcher already refills whole blocks.

@@ -214,6 +214,17 @@ def test_u16_clamp_on_device(built_lib):
     assert p[0] == 1 and p[65534] == 65535 and p[-1] == 65535
 
 
+def test_host_argument_validation(engines):
+    """Bad offsets are refused with MOVI_ERR_ARG (-1), not walked."""
+    from movi_amd._lib import MoviError
+    gpu, _ = engines[6]
+    bases = np.frombuffer(b"ACGTACGTAC", np.uint8)
+    for q in (gpu.query_pml_packed, gpu.query_zml_packed, gpu.query_count_packed):
+        with pytest.raises(MoviError) as e:
+            q(bases, np.array([0, 6, 4, 10], np.uint64))
+        assert e.value.code == -1 and "non-decreasing" in str(e.value)
+
+
 def test_invariant_violation_is_flagged_not_hidden(built_lib, golden_image):
     """A corrupted table must surface as MOVI_ERR_INVARIANT + per-read flags (the
     reference throws, src/move_structure.cpp:63-65)."""
