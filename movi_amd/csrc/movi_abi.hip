@@ -372,9 +372,14 @@ int movi_last_stats(movi_index_t *ix, void *stream, movi_query_stats_t *stats) {
 
 namespace {
 
-// Reads are cut into chunks of at most kChunkBases bases so that the staging
-// buffers stay bounded whatever the input size.
+// Reads are cut into chunks so that the staging buffers stay bounded whatever the input size:
+// about kChunkBases bases per launch -- but never so few READS that the GPU runs empty.  One lane
+// walks one read, so a chunk of long reads (2^28 bases = 27 k reads of 10 kbp) would leave most of
+// the 524 k lane slots idle and the walk latency-bound; such chunks grow until they hold
+// kMinChunkReads reads or kMaxChunkBases bases (3 B of device memory per base, 6 GiB).
 constexpr uint64_t kChunkBases = 1ull << 28;
+constexpr uint64_t kMinChunkReads = 1ull << 18;
+constexpr uint64_t kMaxChunkBases = 1ull << 31;
 
 struct DevBuf {
     void *p = nullptr;
@@ -389,7 +394,11 @@ int run_chunked(movi_index *ix, const uint8_t *h_bases, const uint64_t *h_offset
     uint64_t first = 0;
     while (first < n_reads) {
         uint64_t last = first + 1;
-        while (last < n_reads && h_offsets[last + 1] - h_offsets[first] <= kChunkBases) ++last;
+        while (last < n_reads) {
+            const uint64_t nb_next = h_offsets[last + 1] - h_offsets[first];
+            if (nb_next <= kChunkBases || (last - first < kMinChunkReads && nb_next <= kMaxChunkBases)) ++last;
+            else break;
+        }
         const uint64_t nr = last - first;
         const uint64_t b0 = h_offsets[first], nb = h_offsets[last] - b0;
         DevBuf d_bases, d_offs, d_err;

@@ -7,6 +7,7 @@
 // reference ships one binary per mode and a launcher, src/movi_launcher.cpp:244-254).
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -14,6 +15,7 @@
 #include <fstream>
 #include <iostream>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <thread>
 
@@ -105,6 +107,80 @@ uint64_t zml_rounds(const ReadSet &rs, size_t i, const uint16_t *z, const uint8_
         }
     }
 }
+
+// Parses the next chunk of reads on its own thread while the caller works on the current one
+// (GPU calls + output writing): two ReadSet slots, handed over in order.  A parse error surfaces from
+// next() at the chunk it belongs to, after every earlier chunk has been delivered.
+class ChunkPrefetcher {
+public:
+    ChunkPrefetcher(BatchReader &reader, uint64_t chunk_bases, uint64_t min_reads, uint64_t hard_max)
+        : reader_(reader), worker_([=] { run(chunk_bases, min_reads, hard_max); }) {}
+    ~ChunkPrefetcher() {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        worker_.join();
+    }
+    // nullptr at end of input; the returned set stays valid until the next call
+    ReadSet *next() {
+        std::unique_lock<std::mutex> g(m_);
+        if (held_ >= 0) {                                             // give the previous slot back
+            full_[held_] = false;
+            held_ = -1;
+            cv_.notify_all();
+        }
+        cv_.wait(g, [&] { return full_[take_] || done_; });
+        if (!full_[take_]) {
+            if (error_) std::rethrow_exception(error_);
+            return nullptr;
+        }
+        held_ = take_;
+        take_ ^= 1;
+        return &slot_[held_];
+    }
+
+private:
+    void run(uint64_t chunk_bases, uint64_t min_reads, uint64_t hard_max) {
+        int put = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [&] { return !full_[put] || stop_; });
+                if (stop_) return;
+            }
+            bool more = false;
+            try {
+                more = reader_.next_chunk(slot_[put], chunk_bases, min_reads, hard_max);
+            } catch (...) {
+                std::lock_guard<std::mutex> g(m_);
+                error_ = std::current_exception();
+                done_ = true;
+                cv_.notify_all();
+                return;
+            }
+            std::lock_guard<std::mutex> g(m_);
+            if (!more) {
+                done_ = true;
+                cv_.notify_all();
+                return;
+            }
+            full_[put] = true;
+            put ^= 1;
+            cv_.notify_all();
+        }
+    }
+    BatchReader &reader_;
+    ReadSet slot_[2];
+    bool full_[2] = {false, false};
+    bool done_ = false, stop_ = false;
+    int take_ = 0, held_ = -1;
+    std::exception_ptr error_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::thread worker_;                                              // last: starts when everything above exists
+};
 
 int run_query(const Options &o) {
     int n_dev = 0;
@@ -200,14 +276,17 @@ int run_query(const Options &o) {
 
     auto t1 = std::chrono::steady_clock::now();
     BatchReader reader(*in, o.prefetch ? 4 * o.strands : 1);          // src/movi.cpp:283, :326
-    ReadSet rs;
-    const uint64_t chunk_bases = 1ull << 28;
+    // chunks of >= 2^26 bases and >= 2^18 reads (long reads: up to 2^31 bases): one GPU lane walks one read, so
+    // a chunk needs enough READS to fill the lanes; several chunks per file let parsing overlap the GPU + writing
+    const uint64_t chunk_bases = 1ull << 26;
+    ChunkPrefetcher chunks(reader, chunk_bases, 1ull << 18, 1ull << 31);
     uint64_t reads_done = 0, bases_done = 0;
     std::vector<uint16_t> pml;
     std::vector<uint64_t> matched, counts;
     std::vector<uint8_t> err;
     double gpu_seconds = 0;
-    while (reader.next_chunk(rs, chunk_bases)) {
+    while (ReadSet *chunk = chunks.next()) {
+        ReadSet &rs = *chunk;
         const size_t n = rs.size();
         if (n == 0) continue;
         if (o.reverse)                                                // src/read_processor.cpp:49-51

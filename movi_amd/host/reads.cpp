@@ -95,10 +95,10 @@ static size_t rstrip_len(const char *p, size_t n) {
     return n;
 }
 
-bool BatchReader::next_chunk(ReadSet &out, uint64_t max_bases) {
+bool BatchReader::next_chunk(ReadSet &out, uint64_t max_bases, uint64_t min_reads, uint64_t hard_max_bases) {
     out.ids.clear(); out.bases.clear(); out.offsets.assign(1, 0); out.batch_of.clear();
     bool any = false;
-    while (out.bases.size() < max_bases) {
+    while (out.bases.size() < max_bases || (out.ids.size() < min_reads && out.bases.size() < hard_max_bases)) {
         if (!load_batch()) break;
         any = true;
         const uint32_t b = batch_counter_++;

@@ -47,7 +47,9 @@ private:
 class BatchReader {
 public:
     BatchReader(std::istream &in, size_t min_reads) : src_(in), min_reads_(min_reads) {}
-    bool next_chunk(ReadSet &out, uint64_t max_bases);
+    // Whole reference batches until `max_bases` bases are held -- and, for long reads, until `min_reads`
+    // reads or `hard_max_bases` bases are (one GPU lane walks one read: a chunk needs reads, not bases).
+    bool next_chunk(ReadSet &out, uint64_t max_bases, uint64_t min_reads = 0, uint64_t hard_max_bases = 0);
 
 private:
     struct Span { size_t off, len; };

@@ -274,10 +274,35 @@ def test_large_batch_properties(built_lib):
     assert (sub == exp).all()
 
 
+def test_host_chunk_boundary(built_lib):
+    """The host entry points cut their input into launches of >= 2^28 bases AND >= 2^18 reads (long reads: up to
+    2^31 bases).  300 k x 1 kbp crosses one cut (after read ~268 k): the result must not depend on it."""
+    import movi_amd
+    from oracle.oracle import Oracle
+    from tools import synth
+    six = synth.synth_index(1_000_000, mode=6, seed=4)
+    img = six.image()
+    gpu, cpu = movi_amd.MoveIndex.from_image(img), Oracle(img)
+    n_reads, L = 300_000, 1000
+    bases, offs = synth.synth_reads(six, n_reads, L, seed=8, sub_rate=0.03)
+    out, st = gpu.query_pml_packed(bases, offs)
+    assert st.errors == 0 and st.bases == n_reads * L
+    for lo in (0, 262_000, 268_000, 299_000):               # around 2^18 reads and 2^28 bases
+        hi = lo + 1000
+        exp, _, _ = cpu.pml_batch(bases[lo * L: hi * L], offs[lo: hi + 1] - offs[lo], threads=8)
+        assert (out[lo * L: hi * L] == exp).all()
+    z, _ = gpu.query_zml_packed(bases, offs)
+    lo, hi = 267_500, 269_000
+    assert (z[lo * L: hi * L] == cpu.zml_batch(bases[lo * L: hi * L], offs[lo: hi + 1] - offs[lo], threads=8)).all()
+    m, c, _ = gpu.query_count_packed(bases, offs)
+    em, ec = cpu.count_batch(bases[lo * L: hi * L], offs[lo: hi + 1] - offs[lo], threads=8)
+    assert (m[lo:hi] == em).all() and (c[lo:hi] == ec).all()
+
+
 def test_long_read_batch_properties_multi_chunk(built_lib):
-    """BASELINE config 3 shape (100 k x 10 kbp = 1 Gbase on a 10 M-row table): crosses the host
-    path's 2^28-base chunking, runs the low-occupancy kernel; checked by properties + an oracle
-    spot check."""
+    """BASELINE config 3 shape (100 k x 10 kbp = 1 Gbase on a 10 M-row table): one launch of the host
+    path (long reads extend a chunk until it holds 2^18 reads or 2^31 bases), the low-occupancy
+    kernel; checked by properties + an oracle spot check."""
     import movi_amd
     from oracle.oracle import Oracle
     from tools import synth
