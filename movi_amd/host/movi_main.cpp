@@ -244,7 +244,11 @@ int run_query(const Options &o) {
 
     // outputs (open_output_files, src/utils.cpp:319-384)
     Classifier classifier;
+    // stream buffers first: they must outlive the streams that flush through them on destruction
+    std::vector<char> out_buf(4u << 20), out_buf2(1u << 20);          // 4 MiB: ~80 write(2) calls per 317 MB BPF
     std::ofstream report_file, mls_file, matches_file;
+    mls_file.rdbuf()->pubsetbuf(out_buf.data(), (std::streamsize)out_buf.size());
+    matches_file.rdbuf()->pubsetbuf(out_buf2.data(), (std::streamsize)out_buf2.size());
     std::ostream *report = nullptr;
     if (o.classify) {
         classifier.load_null_db(o.index_dir, o.query_type(), o.verbose);
@@ -281,7 +285,20 @@ int run_query(const Options &o) {
     const uint64_t chunk_bases = 1ull << 26;
     ChunkPrefetcher chunks(reader, chunk_bases, 1ull << 18, 1ull << 31);
     uint64_t reads_done = 0, bases_done = 0;
-    std::vector<uint16_t> pml;
+    // matching lengths of the current chunk: grow-only and never zero-filled (the engine writes every entry)
+    struct MlBuf {
+        uint16_t *p = nullptr;
+        size_t cap = 0;
+        ~MlBuf() { std::free(p); }
+        uint16_t *data() const { return p; }
+        void ensure(size_t n) {
+            if (n <= cap) return;
+            std::free(p);
+            cap = n + (n >> 4);
+            p = static_cast<uint16_t *>(std::malloc(cap * sizeof(uint16_t)));
+            if (!p) throw std::bad_alloc();
+        }
+    } pml;
     std::vector<uint64_t> matched, counts;
     std::vector<uint8_t> err;
     double gpu_seconds = 0;
@@ -302,7 +319,7 @@ int run_query(const Options &o) {
         const bool verdict_only = o.pml && o.classify && !o.write_output_allowed();   // PML only: ZML takes the host bins
         std::vector<uint32_t> bins_above(verdict_only ? n : 0), bins_below(verdict_only ? n : 0);
         std::vector<uint64_t> bins_sum(verdict_only ? n : 0);
-        pml.assign(o.ml() && !verdict_only ? rs.bases.size() : 0, 0);
+        pml.ensure(o.ml() && !verdict_only ? rs.bases.size() : 0);
         matched.assign(o.count ? n : 0, 0);
         counts.assign(o.count ? n : 0, 0);
         err.assign(n, 0);

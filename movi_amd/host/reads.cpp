@@ -97,6 +97,8 @@ static size_t rstrip_len(const char *p, size_t n) {
 
 bool BatchReader::next_chunk(ReadSet &out, uint64_t max_bases, uint64_t min_reads, uint64_t hard_max_bases) {
     out.ids.clear(); out.bases.clear(); out.offsets.assign(1, 0); out.batch_of.clear();
+    // one allocation per slot instead of doubling reallocations (each of which faults its pages in afresh)
+    if (out.bases.capacity() < max_bases + (max_bases >> 4)) out.bases.reserve(max_bases + (max_bases >> 4));
     bool any = false;
     while (out.bases.size() < max_bases || (out.ids.size() < min_reads && out.bases.size() < hard_max_bases)) {
         if (!load_batch()) break;
