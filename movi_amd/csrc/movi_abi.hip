@@ -303,8 +303,8 @@ int movi_index_device_rows(const movi_index_t *ix, const void **d_rows, size_t *
 int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
     if (!ix || !key) return fail(MOVI_ERR_ARG, "NULL argument");
     if (!strcmp(key, "pml_variant")) {
-        if (value != -1 && value != 0 && value != 1 && value != 7 && value != 8)
-            return fail(MOVI_ERR_ARG, "pml_variant must be -1 (auto), 0, 1, 7 or 8");
+        if (value != -1 && value != 0 && value != 1 && (value < 7 || value > 12))
+            return fail(MOVI_ERR_ARG, "pml_variant must be -1 (auto), 0, 1 or 7..12");
         ix->cfg.pml_variant = (int)value;
         return MOVI_OK;
     }

@@ -754,6 +754,192 @@ __global__ __launch_bounds__(256) void pml_kernel_flatw(DevIndex ix, const uint8
     }
 }
 
+// VARIANTS 9 / 10 ("flat state machine + window, software-pipelined"): variant 8 with the two remaining
+// serial memory waits of an iteration taken off the critical path.
+//   * read chunks are double-buffered: the 8 bases after the current chunk are fetched when the current chunk
+//     is entered, so the chunk load (always an L2 miss: the line was evicted long ago) overlaps eight row
+//     gathers instead of stalling the lane once per 8 bases (variant 9, PIPE = 0);
+//   * PIPE = 1 (variant 10): the next window's address is computed from the row alone (all selects) and its
+//     load is issued BEFORE the bookkeeping of the step (PML packing and stores, bins, counters, base decode),
+//     which then runs under the gather's latency.
+template <int MODE, typename IdxT, int HA, int PIPE, int CLS>
+__global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8_t *__restrict__ bases,
+                                                       const uint64_t *__restrict__ offs, uint64_t n_reads,
+                                                       uint16_t *__restrict__ out, uint8_t *__restrict__ err,
+                                                       DevStats *stats, const uint32_t *__restrict__ order,
+                                                       ClsArgs cls) {
+    enum : uint32_t { sFF = 0, sDown = 1, sUp = 2, sDone = 3 };
+    __shared__ uint8_t s_code[256];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = ix.code_of[i];
+    __shared__ uint32_t s_idb[MODE == 8 ? kIdbLdsEntries : 1];
+    const uint32_t *idb = nullptr;
+    if (MODE == 8 && ix.n_blocks * 4 <= (uint64_t)kIdbLdsEntries) {
+        for (uint32_t i = threadIdx.x; i < (uint32_t)ix.n_blocks * 4; i += blockDim.x) s_idb[i] = ix.id_blocks[i];
+        idb = s_idb;
+    }
+    __syncthreads();
+
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t ff_total = 0, scan_total = 0, repo_total = 0, failed = 0;
+    const bool valid = t < n_reads;
+    const uint64_t rid = (valid && order) ? order[t] : t;
+    const uint64_t beg = valid ? offs[rid] : 0;
+    const uint32_t len = valid ? (uint32_t)(offs[rid + 1] - beg) : 0;   // reads are shorter than 2^32 (checked on the host)
+    const uint8_t *R = bases + beg;
+    uint16_t *O = out + beg;
+    const uint32_t packed_end = len & ~7u;
+    const IdxT r1 = (IdxT)(ix.r - 1), end_row = (IdxT)ix.end_bwt_idx;
+
+    auto load_chunk = [&](uint32_t kk) -> uint64_t {
+        uint64_t v = 0;
+        if (beg + len >= (uint64_t)kk + 8) {
+            __builtin_memcpy(&v, R + len - kk - 8, 8);    // may start before R: still inside `bases`
+        } else {
+            for (uint32_t i = 0; i < len - kk; ++i) v |= (uint64_t)R[len - 1 - kk - i] << (8 * (7 - i));
+        }
+        return v;
+    };
+    // The 4-row window that holds row nd: aligned, except that the table's last window is pulled back to
+    // rows [r-4, r) so that the fetch never leaves the table and needs no special case (r >= 4, checked at
+    // launch).  Unpredicated: finished lanes re-read window 0 (a cache hit) instead of branching around the load.
+    const IdxT wb_last = (IdxT)(ix.r - 4);
+    auto win_base = [&](IdxT nd) -> IdxT {
+        const IdxT wb = nd & ~(IdxT)3;
+        return wb < wb_last ? wb : wb_last;
+    };
+    auto fetch = [&](IdxT nd, bool act, uint2 (&w)[4]) {
+        load_window<MODE>(ix.rows, (uint64_t)(act ? win_base(nd) : (IdxT)0), w);
+    };
+
+    uint32_t st = len > 0 ? sFF : sDone;
+    IdxT need = r1;                                       // ReadProcessor::reset_process :69-70
+    uint32_t k = 0;
+    uint32_t ml = 0, ff_run = 0;
+    uint32_t off = row_n<MODE>(load_row<MODE>(ix.rows, r1)) - 1;
+    uint64_t rb = st != sDone ? load_chunk(0) : 0;
+    uint64_t rb_nx = len > 8 ? load_chunk(8) : 0;        // the chunk after the current one, already in flight
+    uint32_t a = s_code[(uint32_t)(rb >> 56) & 0xFFu];    // code of the base of step k (k = 0)
+    uint4 pk = make_uint4(0, 0, 0, 0);
+    ClsState cs;
+    if (CLS) cs.init(len, cls.bin_width);
+    uint2 w[4];
+    if (PIPE) fetch(need, st != sDone, w);
+
+    while (wave_any(st != sDone)) {
+        const bool act = st != sDone;
+        if (!PIPE) fetch(need, act, w);
+        const IdxT wbase = win_base(need);
+        // cheap hop: a fast-forward or scan step that only moves on (see pml_kernel_flatw)
+        auto hop = [&]() {
+            const uint32_t q = (uint32_t)(need - wbase);
+            const uint32_t inwin = (uint32_t)(q < 4u) & (uint32_t)(st != sDone);
+            const uint2 hr = win_sel(w, q);
+            const uint32_t hn = row_n<MODE>(hr), hc = row_c<MODE>(hr);
+            const uint32_t ffh = inwin & (uint32_t)(st == sFF) & (uint32_t)(need < r1) & (uint32_t)(off >= hn) &
+                                 (uint32_t)(ff_run + 1 < 65535u);
+            const uint32_t nomatch = hc != a;
+            const uint32_t dnh = inwin & (uint32_t)(st == sDown) & nomatch & (uint32_t)(need < r1);
+            const uint32_t uph = inwin & (uint32_t)(st == sUp) & nomatch & (uint32_t)(need != 0);
+            off = ffh ? off - hn : off;
+            ff_run += ffh;
+            scan_total += dnh | uph;
+            need = need + (IdxT)(ffh + dnh) - (IdxT)uph;
+        };
+#pragma unroll
+        for (int h = 0; h < HA; ++h) hop();
+        const uint32_t qn = (uint32_t)(need - wbase);
+        const uint32_t inwin = (uint32_t)(qn < 4u) & (uint32_t)act;
+        const uint2 row = win_sel(w, qn);
+        const uint32_t n = row_n<MODE>(row), c = row_c<MODE>(row), roff = row_off<MODE>(row);
+        const uint32_t isFF = (uint32_t)(st == sFF) & inwin, isDown = (uint32_t)(st == sDown) & inwin,
+                       isUp = (uint32_t)(st == sUp) & inwin;
+        // fast_forward, move_structure.cpp:524-545
+        const uint32_t ffm = isFF & (uint32_t)(need < r1) & (uint32_t)(off >= n);
+        const uint32_t ff_over = ffm & (uint32_t)(ff_run + 1 >= 65535u);  // :72-75
+        const uint32_t resolved = isFF & (ffm ^ 1u);
+        // the base of step k against the row (read_processor.cpp:188-238)
+        const uint32_t illegal = a == 0xFFu, match = c == a;
+        const uint32_t mism = resolved & (illegal ^ 1u) & (match ^ 1u);
+        // reposition_thresholds, src/move_structure_query.cpp:513-601
+        const uint32_t kk = (a - (uint32_t)(a > c)) & 3u;                 // alphamap_3[c][a]
+        const uint32_t thr = row_thr<MODE>(row, kk > 2u ? 2u : kk) ? n : 0u;
+        const uint64_t et = a == 1 ? ix.end_thr[1] : (a == 2 ? ix.end_thr[2] : ix.end_thr[3]);
+        const uint32_t down = (need == end_row) ? (uint32_t)((uint64_t)off >= et) : (uint32_t)(off >= thr);
+        const uint32_t at_last = need >= r1, at_first = need == 0;
+        const uint32_t repo_edge = mism & (down ? at_last : at_first);
+        // reposition_down :211-232 / reposition_up :188-209, one row per iteration
+        const uint32_t scanning = isDown | isUp;
+        const uint32_t hit = scanning & match;
+        const uint32_t scan_edge = scanning & (hit ^ 1u) & (isDown ? at_last : at_first);
+        const uint32_t emit = (resolved & (illegal | match)) | hit;
+        // LF_move of the emitted base, move_structure.cpp:59-67 (emit and the error cases are exclusive)
+        const uint32_t lf = emit & (uint32_t)(k + 1 != len);
+        uint64_t j = 0;
+        if (MODE == 6 || lf) j = row_id<MODE>(row, need, ix, idb);
+        const uint32_t lf_bad = lf & (uint32_t)(j >= ix.r);
+        const uint32_t errc = ff_over ? kErrFastForward
+                              : (repo_edge ? (down ? kErrNoRunBelow : kErrNoRunAbove)
+                                 : (scan_edge ? (isDown ? kErrNoRunBelow : kErrNoRunAbove)
+                                    : (lf_bad ? kErrIdRange : kErrNone)));
+        const uint32_t step_fwd = ffm | (mism & down) | (scanning & (hit ^ 1u) & isDown);
+        const uint32_t step_back = (mism & (down ^ 1u)) | (scanning & (hit ^ 1u) & isUp);
+        // (an error freezes the lane where it is: no out-of-table window is ever fetched)
+        const IdxT need_next = errc ? need : (lf ? (IdxT)j : (IdxT)(need + step_fwd - step_back));
+        const uint32_t st_next = (errc != 0u || (emit & (lf ^ 1u))) ? sDone
+                                 : (lf ? sFF : (mism ? (down ? sDown : sUp) : st));
+        // ---- the next gather leaves now; everything below runs under its latency
+        // (`row` is not touched below, so the new window can land in the old one's registers)
+        if (PIPE) fetch(need_next, st_next != sDone, w);
+        // ---- bookkeeping, all selects
+        ml = resolved ? (match ? ml + 1 : 0u) : ml;
+        ff_total += resolved ? ff_run : 0u;
+        ff_run = lf ? 0u : ff_run + ffm;
+        repo_total += mism;
+        scan_total += scanning;
+        off = ffm ? off - n : (hit ? (isDown ? 0u : n - 1) : off);        // read_processor.cpp:223
+        off += lf ? roff : 0u;
+        if (emit) {
+            const uint32_t val = ml > 65535u ? 65535u : ml;               // MoveQuery::add_ml
+            if (CLS) cs.add(val, k, len, cls.bin_width, cls.thr);
+            if (CLS == 2) {
+                // verdict bins only
+            } else if (k >= packed_end) {
+                O[k] = (uint16_t)val;
+            } else {
+                pk.x = (pk.x >> 16) | (pk.y << 16);
+                pk.y = (pk.y >> 16) | (pk.z << 16);
+                pk.z = (pk.z >> 16) | (pk.w << 16);
+                pk.w = (pk.w >> 16) | (val << 16);
+                if ((k & 7) == 7) __builtin_memcpy(O + (k - 7), &pk, 16);
+            }
+            k += 1;
+            if (lf) {
+                if ((k & 7) == 0) {
+                    rb = rb_nx;
+                    if (k + 8 < len) rb_nx = load_chunk(k + 8);
+                }
+                a = s_code[(uint32_t)(rb >> (8 * (7 - (k & 7)))) & 0xFFu];
+            }
+        }
+        if (errc) failed = errc;
+        need = need_next;
+        st = st_next;
+    }
+    if (failed && CLS != 2) {
+        for (uint32_t i = 0; i < len; ++i) O[i] = 0;
+    }
+    if (CLS && valid) cs.store(cls, rid, failed != 0u);
+    if (valid && err) err[rid] = (uint8_t)failed;
+    const uint32_t ffw = wave_sum(ff_total), scw = wave_sum(scan_total), rpw = wave_sum(repo_total),
+                   erw = wave_sum(failed ? 1u : 0u);
+    if ((threadIdx.x & 63) == 0 && stats) {
+        if (ffw) atomicAdd(&stats->fast_forwards, (unsigned long long)ffw);
+        if (scw) atomicAdd(&stats->scans, (unsigned long long)scw);
+        if (rpw) atomicAdd(&stats->repositions, (unsigned long long)rpw);
+        if (erw) atomicAdd(&stats->errors, (unsigned long long)erw);
+    }
+}
+
 hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets,
                       uint64_t n_reads, uint16_t *d_out, uint8_t *d_err, DevStats *d_stats,
                       const uint32_t *d_order, const LaunchCfg &cfg, hipStream_t stream, const ClsArgs &cls) {
@@ -795,6 +981,15 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
             hipLaunchKernelGGL((pml_kernel_flatw<M, uint64_t, 2, 0, C>), grid, block, dyn_lds, stream, ix,  \
                                d_bases, d_offsets, n_reads, d_out, d_err, d_stats, d_order, cls);           \
     } while (0)
+#define MOVI_LAUNCH_FLATP(M, HA, P, C)                                                                      \
+    do {                                                                                                    \
+        if (ix.r < 0xFFFFFFFFull)                                                                           \
+            hipLaunchKernelGGL((pml_kernel_flatp<M, uint32_t, HA, P, C>), grid, block, dyn_lds, stream, ix, \
+                               d_bases, d_offsets, n_reads, d_out, d_err, d_stats, d_order, cls);           \
+        else                                                                                                \
+            hipLaunchKernelGGL((pml_kernel_flatp<M, uint64_t, HA, P, C>), grid, block, dyn_lds, stream, ix, \
+                               d_bases, d_offsets, n_reads, d_out, d_err, d_stats, d_order, cls);           \
+    } while (0)
 #define MOVI_LAUNCH_FLAT(M)                                                                                 \
     do {                                                                                                    \
         if (ix.r < 0xFFFFFFFFull)                                                                           \
@@ -816,18 +1011,24 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     // reads in flight (long-read batches, small shards) the lane state machine wins because it
     // needs ~1.5-2.3 instead of ~11 dependent trips per base.
     int v = cfg.pml_variant;
-    if (v < 0) v = (n_reads <= (uint64_t)cfg.num_cus * 64u * 12u) ? 8 : 1;   // measured crossover: ~12 waves per CU
-    if (cm != 0 && (v == 0 || v == 7)) v = (v == 0) ? 1 : 8;                 // the A/B kernels carry no fused bins
+    if (v < 0) v = (n_reads <= (uint64_t)cfg.num_cus * 64u * 12u) ? 10 : 1;  // measured crossover: ~12 waves per CU
+    if (v >= 9 && ix.r < 8) v = 7;                                           // the clamped window needs >= 4 rows
+    if (cm != 0 && (v == 0 || v == 7 || v == 9 || v == 11 || v == 12)) v = (v == 0) ? 1 : 10;   // the A/B kernels carry no fused bins
     if (mode == 6) {
         if (v == 0) MOVI_LAUNCH_PML(6, 0, 0); else if (v == 1) MOVI_BY_CLS(MOVI_LAUNCH_PML, 6, 1);
-        else if (v == 7) MOVI_LAUNCH_FLAT(6); else MOVI_BY_CLS(MOVI_LAUNCH_FLATW, 6);
+        else if (v == 7) MOVI_LAUNCH_FLAT(6); else if (v == 9) MOVI_LAUNCH_FLATP(6, 2, 0, 0);
+        else if (v == 10) MOVI_BY_CLS(MOVI_LAUNCH_FLATP, 6, 2, 1); else if (v == 11) MOVI_LAUNCH_FLATP(6, 1, 1, 0);
+        else if (v == 12) MOVI_LAUNCH_FLATP(6, 3, 1, 0); else MOVI_BY_CLS(MOVI_LAUNCH_FLATW, 6);
     } else {
         if (v == 0) MOVI_LAUNCH_PML(8, 0, 0); else if (v == 1) MOVI_BY_CLS(MOVI_LAUNCH_PML, 8, 1);
-        else if (v == 7) MOVI_LAUNCH_FLAT(8); else MOVI_BY_CLS(MOVI_LAUNCH_FLATW, 8);
+        else if (v == 7) MOVI_LAUNCH_FLAT(8); else if (v == 9) MOVI_LAUNCH_FLATP(8, 2, 0, 0);
+        else if (v == 10) MOVI_BY_CLS(MOVI_LAUNCH_FLATP, 8, 2, 1); else if (v == 11) MOVI_LAUNCH_FLATP(8, 1, 1, 0);
+        else if (v == 12) MOVI_LAUNCH_FLATP(8, 3, 1, 0); else MOVI_BY_CLS(MOVI_LAUNCH_FLATW, 8);
     }
 #undef MOVI_LAUNCH_PML
 #undef MOVI_LAUNCH_FLAT
 #undef MOVI_LAUNCH_FLATW
+#undef MOVI_LAUNCH_FLATP
 #undef MOVI_BY_CLS
     return hipGetLastError();
 }

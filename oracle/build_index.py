@@ -54,10 +54,15 @@ def read_fasta(path):
     return recs
 
 
-def clean_text(seqs, rc=True):
+SEPARATOR = 37                   # '%', include/commons.hpp:63
+
+
+def clean_text(seqs, rc=True, separators=False):
     """src/prepare_ref.cpp:39-58: anything that is not an upper-case A/C/G/T in
     the input (lower case included -- the test uses the pre-uppercasing byte)
-    becomes 'A'; each record is followed by its reverse complement; no separators.
+    becomes 'A'; each record is followed by its reverse complement.  With
+    `separators` (movi build --separators, prepare_ref.cpp:61-66) every record and
+    every reverse complement is followed by one '%'.
     Returns the text as uint8 with one trailing 0 terminator."""
     comp = np.zeros(256, np.uint8)
     comp[ord("A")], comp[ord("C")], comp[ord("G")], comp[ord("T")] = ord("T"), ord("G"), ord("C"), ord("A")
@@ -67,8 +72,12 @@ def clean_text(seqs, rc=True):
         ok = (a == 65) | (a == 67) | (a == 71) | (a == 84)
         a[~ok] = 65
         parts.append(a)
+        if separators:
+            parts.append(np.full(1, SEPARATOR, np.uint8))
         if rc:
             parts.append(comp[a[::-1]])
+            if separators:
+                parts.append(np.full(1, SEPARATOR, np.uint8))
     parts.append(np.zeros(1, np.uint8))
     return np.concatenate(parts)
 
@@ -180,7 +189,9 @@ def build_rows(bwt, thr, mode):
             alphabet.append(ch)
             counts.append(cnt)
     sigma = len(alphabet)
-    assert 1 <= sigma <= 4, "only DNA alphabets (<= 4 symbols, no separators) are in scope"
+    # MoveStructure::use_separator, src/move_structure.cpp:547-552: a 5-symbol alphabet led by '%'
+    sep = 1 if (sigma == 5 and alphabet[0] == SEPARATOR) else 0
+    assert 1 <= sigma <= 4 or sep, "only DNA alphabets (<= 4 symbols, or '%' + 4 with separators) are in scope"
     code = np.where(heads == 0, 0, alphamap[heads].astype(np.int64)).astype(np.int64)
     code[heads == 0] = 0                                # set_c: alphamap[0]==256 shifts out
     end_bwt_idx = int(np.flatnonzero(heads == 0)[0])
@@ -211,37 +222,55 @@ def build_rows(bwt, thr, mode):
         occ_rank = int(np.searchsorted(all_p, char_count, side="left"))   # rbits(char_count)
         last_runs.append(occ_rank - 1)
         last_offsets.append(char_count - int(all_p[occ_rank - 1]) - 1)
-    # --- compute_thresholds (:807-935), split mode: one bit per (row, other char)
+    # --- compute_thresholds (:807-935), split mode: one bit per (row, other DNA char).  With separators
+    # (:826-831, :836-858, :912-921) no threshold is kept FOR the separator; a row OF the separator -- and
+    # the '$' row, whose character field decodes as the separator -- gets an explicit 4-value entry
+    # in separators_thresholds (appended in descending row order, row 0 last), keyed by row in the map.
     thr_bits = np.zeros((r, 3), np.int64)
     end_thr = [0, 0, 0, 0]
+    sep_thr, sep_map = [], {}
     alphabet_thresholds = [n] * sigma
     thr_i = original_r - 1
     cl, pl, ll, tl = code.tolist(), all_p.tolist(), lens.tolist(), thr.tolist()
     for i in range(r - 1, 0, -1):
-        rc = cl[i]                                      # '$' row has c == 0 -> 'A' (:823)
+        rc = cl[i]                                      # '$' row has c == 0 -> 'A' (:823), '%' with separators
+        if sep and rc == 0:
+            sep_thr.append([0, 0, 0, 0])
+            sep_map[i] = len(sep_thr) - 1
         for j in range(sigma):
             if j == rc:
                 alphabet_thresholds[j] = tl[thr_i]
             else:
+                if sep and j == 0:
+                    continue                            # :849-852
                 cur = alphabet_thresholds[j]
                 if cur >= pl[i] + ll[i]:
                     val, bit = ll[i], 1
                 elif cur <= pl[i]:
                     val, bit = 0, 0
                 else:
-                    raise AssertionError("threshold strictly inside a row: rows must be split at thresholds")
+                    val, bit = cur - pl[i], None        # strictly inside the row (:869-871)
                 if i == end_bwt_idx:
-                    end_thr[j] = val                    # set_threshold_for_one_character :776-779
+                    end_thr[j - sep] = val              # set_threshold_for_one_character :776-779
+                elif sep and rc == 0:
+                    sep_thr[-1][j - 1] = val            # :781-784
                 else:
-                    thr_bits[i, ALPHAMAP_3[rc][j]] = bit
+                    if bit is None:
+                        raise AssertionError("threshold strictly inside a row: rows must be split at thresholds")
+                    thr_bits[i, ALPHAMAP_3[rc - sep][j - sep]] = bit
         if cl[i] != cl[i - 1] or i == end_bwt_idx or i - 1 == end_bwt_idx:
             thr_i -= 1
-    thr_bits[0, :] = 0                                  # :903-911
+    if sep and cl[0] == 0:                              # :917-920
+        sep_thr.append([0, 0, 0, 0])
+        sep_map[0] = len(sep_thr) - 1
+    else:
+        thr_bits[0, :] = 0                              # :903-911, :922-929
     out = dict(mode=mode, n=n, r=r, original_r=original_r, end_bwt_idx=end_bwt_idx,
                alphamap=alphamap, alphabet=bytes(alphabet), counts=counts,
                first_runs=first_runs, first_offsets=first_offsets,
                last_runs=last_runs, last_offsets=last_offsets, end_thr=end_thr,
-               lens=lens, offset=offset, code=code, pp_id=pp_id, thr_bits=thr_bits, all_p=all_p)
+               lens=lens, offset=offset, code=code, pp_id=pp_id, thr_bits=thr_bits, all_p=all_p,
+               sep=sep, sep_thr=sep_thr, sep_map=sep_map)
     if mode == 8:
         out.update(compute_blocked_ids(pp_id, code, end_bwt_idx, first_runs, sigma))
     return out
@@ -317,17 +346,24 @@ def serialize(f):
     if f["mode"] == 8:
         ib = f["id_blocks"]
         out += [u64([ib.shape[1]]), ib.astype("<u4").tobytes(), u64([f["block_size"]])]
+    if f.get("sep"):
+        # write_separators_thresholds, src/move_structure_io.cpp:399-413: u64 count | ThresholdsRow{u16[4]} each |
+        # u64 map size | (u64 row, u64 entry) pairs.  The reference walks an unordered_map (unspecified order);
+        # ascending row order here.
+        st = np.asarray(f["sep_thr"], "<u2").reshape(-1, 4)
+        out += [u64([len(st)]), st.tobytes(), u64([len(f["sep_map"])])]
+        out += [u64([k, v]) for k, v in sorted(f["sep_map"].items())]
     return b"".join(out)
 
 
-def build_index_from_seqs(seqs, mode, rc=True):
-    t = clean_text(seqs, rc=rc)
+def build_index_from_seqs(seqs, mode, rc=True, separators=False):
+    t = clean_text(seqs, rc=rc, separators=separators)
     bwt, thr = bwt_and_thresholds(t)
     return serialize(build_rows(bwt, thr, mode))
 
 
-def build_index_from_fasta(path, mode):
-    return build_index_from_seqs([s for _, s in read_fasta(path)], mode)
+def build_index_from_fasta(path, mode, separators=False):
+    return build_index_from_seqs([s for _, s in read_fasta(path)], mode, separators=separators)
 
 
 if __name__ == "__main__":

@@ -48,7 +48,15 @@ typedef struct {
     uint64_t nblocks;              /* mode 8 only                                 */
     uint32_t *id_blocks;           /* [alphabet_size][nblocks]                    */
     uint64_t block_size;
+    /* separators (movi build --separators): alphabet = '%' + ACGT; explicit thresholds of the
+     * separator rows, move_structure.hpp:344-346, file layout move_structure_io.cpp:399-433 */
+    int      sep;                  /* MoveStructure::use_separator, move_structure.cpp:547-552 */
+    uint64_t n_sep;                /* separators_thresholds_map entries, sorted by row */
+    uint64_t *sep_rows;
+    uint16_t (*sep_vals)[4];
 } oracle_index;
+
+#define ORACLE_SEPARATOR '%'       /* include/commons.hpp:63 */
 
 /* alphamap_3: src/utils.cpp:5-8 */
 static const uint32_t alphamap_3[4][4] = {{3, 0, 1, 2},
@@ -119,15 +127,39 @@ oracle_index *oracle_open(const uint8_t *buf, size_t n) {
         ix->block_size = 1048576;                       /* BLOCK_SIZE move_row_configs.hpp:102 */
         if (p + 8 <= n) rd(buf, n, &p, &ix->block_size, 8);   /* io.cpp:321-323 */
     }
+    ix->sep = ix->alphabet_size == 5 && ix->alphabet[0] == ORACLE_SEPARATOR;
+    if (ix->sep) {                                      /* read_separators_thresholds, io.cpp:415-433 */
+        uint64_t nt, nm;
+        if (rd(buf, n, &p, &nt, 8) || nt > (n - p) / 8) goto bad;
+        uint16_t (*vals)[4] = (uint16_t (*)[4])malloc((nt ? nt : 1) * 8);
+        if (!vals || rd(buf, n, &p, vals, nt * 8)) { free(vals); goto bad; }
+        if (rd(buf, n, &p, &nm, 8) || nm > (n - p) / 16) { free(vals); goto bad; }
+        ix->sep_rows = (uint64_t *)malloc((nm ? nm : 1) * 8);
+        ix->sep_vals = (uint16_t (*)[4])malloc((nm ? nm : 1) * 8);
+        for (uint64_t e = 0; e < nm; e++) {             /* the map, kept sorted by row (insertion sort: few entries) */
+            uint64_t kv[2];
+            if (rd(buf, n, &p, kv, 16) || kv[1] >= nt) { free(vals); goto bad; }
+            uint64_t at = e;
+            while (at > 0 && ix->sep_rows[at - 1] > kv[0]) {
+                ix->sep_rows[at] = ix->sep_rows[at - 1];
+                memcpy(ix->sep_vals[at], ix->sep_vals[at - 1], 8);
+                at--;
+            }
+            ix->sep_rows[at] = kv[0];
+            memcpy(ix->sep_vals[at], vals[kv[1]], 8);
+        }
+        ix->n_sep = nm;
+        free(vals);
+    }
     return ix;
 bad:
-    if (ix) { free(ix->rows); free(ix->id_blocks); free(ix); }
+    if (ix) { free(ix->rows); free(ix->id_blocks); free(ix->sep_rows); free(ix->sep_vals); free(ix); }
     return NULL;
 }
 
 void oracle_close(oracle_index *ix) {
     if (!ix) return;
-    free(ix->rows); free(ix->id_blocks); free(ix);
+    free(ix->rows); free(ix->id_blocks); free(ix->sep_rows); free(ix->sep_vals); free(ix);
 }
 
 uint64_t oracle_r(const oracle_index *ix) { return ix->r; }
@@ -191,10 +223,11 @@ static inline int get_char(const oracle_index *ix, uint64_t i) {
     return ix->alphabet[get_c(ix, i)];
 }
 /* MoveStructure::check_alphabet, src/move_structure.cpp:383-397 with
- * ignore_illegal_chars == 0 and no separators.  Bytes >= 128 index out of the
+ * ignore_illegal_chars == 0.  Bytes >= 128 index out of the
  * 256-entry alphamap in the reference (char sign extension); treated as illegal. */
 static inline int check_alphabet(const oracle_index *ix, uint8_t c) {
     if (c >= 128) return 0;
+    if (ix->sep && c == ORACLE_SEPARATOR) return 0;                    /* :384-388 */
     return ix->alphamap[c] != 256;
 }
 
@@ -250,19 +283,38 @@ static uint64_t reposition_down(const oracle_index *ix, uint64_t idx, uint8_t c,
     return row_c == c ? idx : ix->r;
 }
 
-/* MoveStructure::reposition_thresholds, src/move_structure_query.cpp:513-601
- * (no-separator branch).  Returns 1 = up, 0 = down, <0 = invariant broken. */
+/* separators_thresholds[separators_thresholds_map[idx]] (move_structure_query.cpp:541); an unordered_map
+ * operator[] on a missing key would insert entry 0 -- a row that is a separator always has its key. */
+static const uint16_t *sep_lookup(const oracle_index *ix, uint64_t idx) {
+    uint64_t lo = 0, hi = ix->n_sep;
+    while (lo < hi) {
+        uint64_t mid = (lo + hi) / 2;
+        if (ix->sep_rows[mid] < idx) lo = mid + 1; else hi = mid;
+    }
+    return (lo < ix->n_sep && ix->sep_rows[lo] == idx) ? ix->sep_vals[lo] : NULL;
+}
+
+/* MoveStructure::reposition_thresholds, src/move_structure_query.cpp:513-601.
+ * Returns 1 = up, 0 = down, <0 = invariant broken. */
 static int reposition_thresholds(const oracle_index *ix, uint64_t *idx, uint64_t offset,
                                  uint8_t r_char, uint64_t *scan) {
     uint64_t saved_idx = *idx;
     uint64_t alphabet_index = ix->alphamap[r_char];
+    if (ix->sep) {                                                      /* :518-523 */
+        if (alphabet_index == 0) return ORACLE_ERR_INVARIANT;
+        alphabet_index -= 1;
+    }
     *scan = 0;
     uint8_t rlbwt_char = ix->alphabet[get_c(ix, *idx)];
     uint64_t threshold_value;
     if (*idx == ix->end_bwt_idx) {
         threshold_value = ix->end_thr[alphabet_index];                 /* :534-535 */
+    } else if (ix->sep && rlbwt_char == ORACLE_SEPARATOR) {             /* :540-541 */
+        const uint16_t *v = sep_lookup(ix, *idx);
+        if (!v) return ORACLE_ERR_INVARIANT;
+        threshold_value = v[alphabet_index];
     } else {
-        alphabet_index = alphamap_3[ix->alphamap[rlbwt_char]][alphabet_index];   /* :556 */
+        alphabet_index = alphamap_3[ix->alphamap[rlbwt_char] - (ix->sep ? 1 : 0)][alphabet_index];   /* :545-556 */
         if (alphabet_index == 3) return ORACLE_ERR_INVARIANT;          /* :559-561 */
         threshold_value = get_thresholds(ix, *idx, (uint32_t)alphabet_index);
     }

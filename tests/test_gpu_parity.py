@@ -85,7 +85,7 @@ def test_pml_ragged_reads_vs_oracle(engines, mode):
 
 
 @pytest.mark.parametrize("mode", [6, 8])
-@pytest.mark.parametrize("variant", [0, 1, 7, 8])
+@pytest.mark.parametrize("variant", [0, 1, 7, 8, 9, 10, 11, 12])
 def test_pml_kernel_variants_vs_oracle(engines, mode, variant):
     """Every selectable kernel variant is held to the same bit-exact bar, including
     reads whose length is not a multiple of the 8-step packing and unaligned offsets."""
@@ -378,7 +378,7 @@ def test_classification_bins_on_device(engines, bin_width, thr):
 
 
 @pytest.mark.parametrize("mode", [6, 8])
-@pytest.mark.parametrize("variant", [1, 8])
+@pytest.mark.parametrize("variant", [1, 8, 10])
 def test_fused_classification_kernels(engines, mode, variant):
     """movi_pml_classify_device: the bins fused into the PML walk, with and without the PML vector, in both
     shipped kernels, against the bins of the oracle's PML vectors and against the standalone
@@ -473,7 +473,7 @@ def test_fuzz_small_indexes(built_lib, tmp_path, alphabet):
             subprocess.check_call([tool, "fasta", str(fa), str(mode), out_dir], stderr=subprocess.DEVNULL)
             img = open(os.path.join(out_dir, "index.movi"), "rb").read()
             gpu, cpu = movi_amd.MoveIndex.from_image(img), Oracle(img)
-            for variant in (1, 7, 8):
+            for variant in (1, 7, 8, 9, 10):
                 gpu.set_option("pml_variant", variant)
                 out, st = gpu.query_pml_packed(bases, offs)
                 exp, ff, sc = cpu.pml_batch(bases, offs, threads=2)
@@ -506,7 +506,7 @@ def test_real_bwt_pangenome_vs_oracle(built_lib, tmp_path, mode):
     bases = np.fromfile(os.path.join(out, "reads.bin"), np.uint8)
     offs = (np.arange(20001, dtype=np.uint64) * np.uint64(150))
     exp, ff, sc = cpu.pml_batch(bases, offs, threads=8)
-    for variant in (1, 7, 8):
+    for variant in (1, 7, 8, 9, 10):
         gpu.set_option("pml_variant", variant)
         got, st = gpu.query_pml_packed(bases, offs)
         assert (got == exp).all() and (st.fast_forwards, st.scans, st.errors) == (ff, sc, 0)
