@@ -46,6 +46,7 @@ extern "C" {
 
 #define MOVI_MODE_REGULAR_THRESHOLDS 6   /* 8-byte rows, include/move_row.hpp:131-142 */
 #define MOVI_MODE_BLOCKED_THRESHOLDS 8   /* 6-byte rows, include/move_row.hpp:128-142 */
+#define MOVI_MODE_SAMPLED_THRESHOLDS 7   /* 3-byte rows without ids + sampled id table, move_row.hpp:122-127 */
 
 typedef struct movi_index movi_index_t;
 
@@ -53,17 +54,33 @@ typedef struct movi_index movi_index_t;
  * row table (bytes exactly as stored in index.movi) plus the small side tables. */
 typedef struct movi_index_desc {
     uint32_t mode;                    /* MOVI_MODE_*                                   */
-    uint32_t alphabet_size;           /* 4 (separators / 5-symbol indexes are rejected) */
+    uint32_t alphabet_size;           /* <= 4 DNA symbols, or 5 = '%' + ACGT (movi build --separators) */
     uint64_t r;                       /* number of move rows                           */
     uint64_t length;                  /* BWT length n                                  */
     uint64_t end_bwt_idx;             /* row holding the terminator                    */
     uint64_t end_bwt_idx_thresholds[4];
     uint8_t  alphabet[8];             /* code -> ASCII                                 */
-    uint8_t  code_of[256];            /* ASCII -> code 0..3, 0xFF = not in the alphabet */
+    uint8_t  code_of[256];            /* ASCII -> alphamap code (0..3; 1..4 with separators), 0xFF = illegal in a
+                                         read (not in the alphabet, or the separator: check_alphabet, move_structure.cpp:383-397) */
     uint64_t first_runs[8], first_offsets[8], last_runs[8], last_offsets[8];  /* k = alphabet_size+1 used */
     uint64_t n_blocks;                /* mode 8: id_blocks is [alphabet_size][n_blocks] */
     uint64_t block_size;              /* mode 8                                        */
     const uint32_t *id_blocks;        /* mode 8, host pointer; NULL for mode 6          */
+    /* Separators indexes only (alphabet "%ACGT"): the explicit thresholds of the separator's rows,
+     * MoveStructure::separators_thresholds / separators_thresholds_map (include/move_structure.hpp:344-346)
+     * exactly as read_separators_thresholds (src/move_structure_io.cpp:415-433) finds them in the file.
+     * Host pointers (may be unaligned, into the parsed image); copied by movi_index_create*. */
+    uint64_t n_separator_thresholds;
+    const void *separator_thresholds;     /* n x ThresholdsRow { uint16_t values[4] }       */
+    uint64_t n_separator_map;
+    const void *separator_map;            /* n x { uint64_t row, uint64_t entry }           */
+    /* Sampled-thresholds indexes only (mode 7): MoveStructure::tally_checkpoints / tally_ids
+     * (include/move_structure.hpp:361-363) as read_tally_table (src/move_structure_io.cpp:338-349) finds them:
+     * [alphabet_size][n_tally] 5-byte MoveTally entries (u32 low | u8 high, include/move_row.hpp:13-40). */
+    uint32_t tally_checkpoints;
+    uint32_t reserved_;
+    uint64_t n_tally;
+    const void *tally_ids;                /* host pointer, may be unaligned                 */
 } movi_index_desc_t;
 
 /* Per-query statistics (whole batch), for the algorithmic-bytes formula. */
@@ -181,8 +198,8 @@ int movi_count_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_
 
 /* Kernel variant / launch knobs, for A/B measurement (bench.py --variant).
  * Unknown keys return MOVI_ERR_ARG.  Keys: "pml_variant" (-1 = auto by batch size, 0 = first
- * kernel, 1 = base-synchronous packed I/O, 7 = flat lane state machine, 8 = 7 + aligned row
- * window), "block_threads", "waves_per_cu" (0 = uncapped). */
+ * kernel, 1 = base-synchronous packed I/O, 7 = flat lane state machine, 10 = 7 + row window,
+ * software-pipelined), "block_threads", "waves_per_cu" (0 = uncapped). */
 int movi_set_option(movi_index_t *ix, const char *key, int64_t value);
 
 /* ---- ZML (Ziv-Merhav cross parse) ---------------------------------------------- */

@@ -28,6 +28,14 @@ class IndexDescC(C.Structure):
         ("n_blocks", C.c_uint64),
         ("block_size", C.c_uint64),
         ("id_blocks", C.c_void_p),
+        ("n_separator_thresholds", C.c_uint64),
+        ("separator_thresholds", C.c_void_p),
+        ("n_separator_map", C.c_uint64),
+        ("separator_map", C.c_void_p),
+        ("tally_checkpoints", C.c_uint32),
+        ("reserved_", C.c_uint32),
+        ("n_tally", C.c_uint64),
+        ("tally_ids", C.c_void_p),
     ]
 
 

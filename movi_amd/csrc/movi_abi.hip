@@ -58,6 +58,14 @@ struct movi_index {
     int device = 0;
     movi_index_desc_t desc{};
     std::vector<uint32_t> id_blocks_host;
+    std::vector<uint64_t> sep_rows_host;         // separators indexes: rows of the separator, ascending
+    std::vector<uint64_t> sep_vals_host;         //   their ThresholdsRow (4 x u16 in one u64)
+    std::vector<uint16_t> sep_thr_raw;           //   the file's two tables, kept for movi_index_get_desc-style round trips
+    std::vector<uint64_t> sep_map_raw;
+    uint64_t *d_sep_rows = nullptr;
+    uint64_t *d_sep_vals = nullptr;
+    std::vector<uint64_t> tally_host;            // mode 7: tally_ids widened to u64, [alphabet][n_tally]
+    uint64_t *d_tally = nullptr;
     uint8_t *d_rows = nullptr;
     bool owns_rows = false;
     size_t rows_bytes = 0;
@@ -87,7 +95,8 @@ int movi_device_count(int *count) {
 // (include/utils.hpp:32-61) | end_bwt_idx thresholds / next_down / next_up (3 x 4 x u64,
 // :145-151) | alphamap (:153-157) | alphabet (:159-169) | u16 nt_splitting, bool constant
 // (:171-172) | r rows (:361-397) | three overflow tables (:219-237) | counts and the
-// base intervals (:269-287) | mode 8: id_blocks + block_size (:305-324).
+// base intervals (:269-287) | mode 8: id_blocks + block_size (:305-324) | with separators: their
+// thresholds and the row -> entry map (:415-433).
 int movi_index_parse(const void *h_image, size_t image_bytes, movi_index_desc_t *desc,
                      size_t *rows_offset, size_t *rows_bytes) {
     if (!h_image || !desc) return fail(MOVI_ERR_ARG, "NULL argument");
@@ -100,9 +109,10 @@ int movi_index_parse(const void *h_image, size_t image_bytes, movi_index_desc_t 
         return fail(MOVI_ERR_FORMAT, "invalid magic number in header: not a Movi 2.x index file");
     memset(desc, 0, sizeof(*desc));
     desc->mode = hdr[7];
-    if (desc->mode != MOVI_MODE_REGULAR_THRESHOLDS && desc->mode != MOVI_MODE_BLOCKED_THRESHOLDS)
-        return fail(MOVI_ERR_FORMAT, "index mode " + std::to_string(desc->mode) +
-                                         " is not supported (only regular-thresholds=6 and blocked-thresholds=8)");
+    if (desc->mode != MOVI_MODE_REGULAR_THRESHOLDS && desc->mode != MOVI_MODE_BLOCKED_THRESHOLDS &&
+        desc->mode != MOVI_MODE_SAMPLED_THRESHOLDS)
+        return fail(MOVI_ERR_FORMAT, "index mode " + std::to_string(desc->mode) + " is not supported (only "
+                                         "regular-thresholds=6, sampled-thresholds=7 and blocked-thresholds=8)");
     memcpy(&desc->length, hdr + 16, 8);
     memcpy(&desc->r, hdr + 24, 8);
     memcpy(&desc->end_bwt_idx, hdr + 40, 8);
@@ -115,15 +125,28 @@ int movi_index_parse(const void *h_image, size_t image_bytes, movi_index_desc_t 
     uint64_t asz = 0;
     if (!rd.get(&asz, 8) || asz == 0 || asz > 8) return fail(MOVI_ERR_FORMAT, "unexpected alphabet size");
     if (!rd.get(desc->alphabet, asz)) return fail(MOVI_ERR_FORMAT, "truncated index (alphabet)");
-    if (asz > 4)
+    // MoveStructure::use_separator, src/move_structure.cpp:547-552: five symbols led by '%'
+    const bool sep = asz == 5 && desc->alphabet[0] == '%';
+    if (asz > 4 && !sep)
         return fail(MOVI_ERR_FORMAT, "alphabet has " + std::to_string(asz) +
-                                         " symbols: separator / non-DNA indexes are not supported by this engine");
+                                         " symbols: only DNA (<= 4) and separator ('%' + ACGT) indexes are supported");
     desc->alphabet_size = (uint32_t)asz;
     for (int c = 0; c < 256; c++) desc->code_of[c] = (c < 128 && amap[c] < asz) ? (uint8_t)amap[c] : 0xFF;
+    if (sep) desc->code_of[(int)'%'] = 0xFF;               // check_alphabet, move_structure.cpp:384-388
     if (!rd.skip(3)) return fail(MOVI_ERR_FORMAT, "truncated index (flags)");
-    const size_t row_b = desc->mode == MOVI_MODE_REGULAR_THRESHOLDS ? 8 : 6;
+    const size_t row_b = desc->mode == MOVI_MODE_REGULAR_THRESHOLDS ? 8 : (desc->mode == MOVI_MODE_BLOCKED_THRESHOLDS ? 6 : 3);
     const size_t roff = rd.pos;
     if (!rd.skip(desc->r * row_b)) return fail(MOVI_ERR_FORMAT, "truncated index (move rows)");
+    if (desc->mode == MOVI_MODE_SAMPLED_THRESHOLDS) {      // read_tally_table, move_structure_io.cpp:338-349
+        if (!rd.get(&desc->tally_checkpoints, 4) || desc->tally_checkpoints == 0)
+            return fail(MOVI_ERR_FORMAT, "truncated index (tally checkpoints)");
+        if (!rd.get(&desc->n_tally, 8)) return fail(MOVI_ERR_FORMAT, "truncated index (tally table)");
+        desc->tally_ids = rd.p + rd.pos;
+        if (desc->n_tally > image_bytes / 5 || !rd.skip(desc->n_tally * asz * 5))
+            return fail(MOVI_ERR_FORMAT, "truncated index (tally table)");
+        if (desc->n_tally < desc->r / desc->tally_checkpoints + 2)
+            return fail(MOVI_ERR_FORMAT, "tally table does not cover the rows");
+    }
     for (int t = 0; t < 3; t++) {
         uint64_t sz = 0;
         if (!rd.get(&sz, 8)) return fail(MOVI_ERR_FORMAT, "truncated index (overflow tables)");
@@ -147,6 +170,16 @@ int movi_index_parse(const void *h_image, size_t image_bytes, movi_index_desc_t 
         if (desc->block_size == 0 || desc->n_blocks * desc->block_size < desc->r)
             return fail(MOVI_ERR_FORMAT, "id blocks do not cover the table");
     }
+    if (sep) {                                             // read_separators_thresholds, move_structure_io.cpp:415-433
+        if (!rd.get(&desc->n_separator_thresholds, 8)) return fail(MOVI_ERR_FORMAT, "truncated index (separator thresholds)");
+        desc->separator_thresholds = rd.p + rd.pos;
+        if (desc->n_separator_thresholds > image_bytes / 8 || !rd.skip(desc->n_separator_thresholds * 8))
+            return fail(MOVI_ERR_FORMAT, "truncated index (separator thresholds)");
+        if (!rd.get(&desc->n_separator_map, 8)) return fail(MOVI_ERR_FORMAT, "truncated index (separator map)");
+        desc->separator_map = rd.p + rd.pos;
+        if (desc->n_separator_map > image_bytes / 16 || !rd.skip(desc->n_separator_map * 16))
+            return fail(MOVI_ERR_FORMAT, "truncated index (separator map)");
+    }
     if (rows_offset) *rows_offset = roff;
     if (rows_bytes) *rows_bytes = desc->r * row_b;
     return MOVI_OK;
@@ -161,6 +194,19 @@ static int finish_create(movi_index *ix) {
         if (nb == 0 || ix->id_blocks_host.size() != nb) return fail(MOVI_ERR_ARG, "mode 8 needs id_blocks");
         HIP_TRY(hipMalloc(&ix->d_id_blocks, nb * 4));
         HIP_TRY(hipMemcpy(ix->d_id_blocks, ix->id_blocks_host.data(), nb * 4, hipMemcpyHostToDevice));
+    }
+    const bool sep = d.alphabet_size == 5;
+    if (sep && !ix->sep_rows_host.empty()) {
+        const size_t ns = ix->sep_rows_host.size();
+        HIP_TRY(hipMalloc(&ix->d_sep_rows, ns * 8));
+        HIP_TRY(hipMalloc(&ix->d_sep_vals, ns * 8));
+        HIP_TRY(hipMemcpy(ix->d_sep_rows, ix->sep_rows_host.data(), ns * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ix->d_sep_vals, ix->sep_vals_host.data(), ns * 8, hipMemcpyHostToDevice));
+    }
+    if (d.mode == MOVI_MODE_SAMPLED_THRESHOLDS) {
+        if (ix->tally_host.empty()) return fail(MOVI_ERR_ARG, "mode 7 needs tally_ids");
+        HIP_TRY(hipMalloc(&ix->d_tally, ix->tally_host.size() * 8));
+        HIP_TRY(hipMemcpy(ix->d_tally, ix->tally_host.data(), ix->tally_host.size() * 8, hipMemcpyHostToDevice));
     }
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, ix->device));
@@ -181,8 +227,16 @@ static int finish_create(movi_index *ix) {
         v.block_shift = 0;
         while ((1ull << v.block_shift) < v.block_size) v.block_shift++;
     }
+    v.sigma = d.alphabet_size;
+    v.sep = sep ? 1u : 0u;
+    v.n_sep = (uint32_t)ix->sep_rows_host.size();
+    v.sep_rows = ix->d_sep_rows;
+    v.sep_vals = reinterpret_cast<const uint2 *>(ix->d_sep_vals);
+    v.tally = ix->d_tally;
+    v.tally_len = d.n_tally;
+    v.tally_cp = d.tally_checkpoints ? d.tally_checkpoints : 1;
     for (int i = 0; i < 4; i++) v.end_thr[i] = d.end_bwt_idx_thresholds[i];
-    for (int i = 0; i < 5; i++) {
+    for (int i = 0; i < 6; i++) {
         v.first_runs[i] = d.first_runs[i];
         v.first_offsets[i] = d.first_offsets[i];
         v.last_runs[i] = d.last_runs[i];
@@ -193,10 +247,20 @@ static int finish_create(movi_index *ix) {
 
 static int check_desc(const movi_index_desc_t *desc) {
     if (!desc) return fail(MOVI_ERR_ARG, "desc is NULL");
-    if (desc->mode != MOVI_MODE_REGULAR_THRESHOLDS && desc->mode != MOVI_MODE_BLOCKED_THRESHOLDS)
+    if (desc->mode != MOVI_MODE_REGULAR_THRESHOLDS && desc->mode != MOVI_MODE_BLOCKED_THRESHOLDS &&
+        desc->mode != MOVI_MODE_SAMPLED_THRESHOLDS)
         return fail(MOVI_ERR_ARG, "unsupported mode");
+    if (desc->mode == MOVI_MODE_SAMPLED_THRESHOLDS &&
+        (!desc->tally_ids || desc->tally_checkpoints == 0 || desc->n_tally < desc->r / desc->tally_checkpoints + 2))
+        return fail(MOVI_ERR_ARG, "mode 7 needs tally_checkpoints / tally_ids covering the rows");
     if (desc->r == 0 || desc->end_bwt_idx >= desc->r) return fail(MOVI_ERR_ARG, "bad r / end_bwt_idx");
-    if (desc->alphabet_size == 0 || desc->alphabet_size > 4) return fail(MOVI_ERR_ARG, "alphabet_size must be 1..4");
+    if (desc->alphabet_size == 0 || desc->alphabet_size > 5) return fail(MOVI_ERR_ARG, "alphabet_size must be 1..5");
+    if (desc->alphabet_size == 5) {
+        if (desc->alphabet[0] != '%') return fail(MOVI_ERR_ARG, "a 5-symbol alphabet must be '%' + ACGT (separators)");
+        if ((desc->n_separator_thresholds && !desc->separator_thresholds) || (desc->n_separator_map && !desc->separator_map))
+            return fail(MOVI_ERR_ARG, "separator tables missing");
+        if (desc->n_separator_map > 0xFFFFFFFFull) return fail(MOVI_ERR_ARG, "too many separator rows");
+    }
     return MOVI_OK;
 }
 
@@ -207,7 +271,37 @@ static movi_index *new_handle(int device, const movi_index_desc_t *desc) {
     if (desc->mode == MOVI_MODE_BLOCKED_THRESHOLDS && desc->id_blocks)
         ix->id_blocks_host.assign(desc->id_blocks, desc->id_blocks + (size_t)desc->n_blocks * desc->alphabet_size);
     ix->desc.id_blocks = nullptr;
-    ix->rows_bytes = (size_t)desc->r * (desc->mode == MOVI_MODE_REGULAR_THRESHOLDS ? 8 : 6);
+    if (desc->alphabet_size == 5) {
+        // separators_thresholds[separators_thresholds_map[row]] flattened into two arrays sorted by row
+        const size_t nt = (size_t)desc->n_separator_thresholds, nm = (size_t)desc->n_separator_map;
+        ix->sep_thr_raw.resize(nt * 4);
+        if (nt) memcpy(ix->sep_thr_raw.data(), desc->separator_thresholds, nt * 8);
+        ix->sep_map_raw.resize(nm * 2);
+        if (nm) memcpy(ix->sep_map_raw.data(), desc->separator_map, nm * 16);
+        std::vector<std::pair<uint64_t, uint64_t>> kv(nm);
+        for (size_t e = 0; e < nm; e++) kv[e] = {ix->sep_map_raw[2 * e], ix->sep_map_raw[2 * e + 1]};
+        std::sort(kv.begin(), kv.end());
+        for (const auto &e : kv) {
+            uint64_t packed = 0;                          // a key pointing past the table reads as zeros
+            if (e.second < nt) memcpy(&packed, ix->sep_thr_raw.data() + e.second * 4, 8);
+            ix->sep_rows_host.push_back(e.first);
+            ix->sep_vals_host.push_back(packed);
+        }
+    }
+    ix->desc.separator_thresholds = nullptr;
+    ix->desc.separator_map = nullptr;
+    if (desc->mode == MOVI_MODE_SAMPLED_THRESHOLDS) {
+        const size_t ne = (size_t)desc->n_tally * desc->alphabet_size;
+        const uint8_t *p = static_cast<const uint8_t *>(desc->tally_ids);
+        ix->tally_host.resize(ne);
+        for (size_t e = 0; e < ne; e++) {                 // MoveTally::get, include/move_row.hpp:28-38
+            uint32_t right;
+            memcpy(&right, p + e * 5, 4);
+            ix->tally_host[e] = (uint64_t)right | ((uint64_t)p[e * 5 + 4] << 32);
+        }
+    }
+    ix->desc.tally_ids = nullptr;
+    ix->rows_bytes = (size_t)desc->r * (desc->mode == MOVI_MODE_REGULAR_THRESHOLDS ? 8 : (desc->mode == MOVI_MODE_BLOCKED_THRESHOLDS ? 6 : 3));
     return ix;
 }
 
@@ -280,6 +374,9 @@ int movi_index_destroy(movi_index_t *ix) {
     if (ix->owns_rows && ix->d_rows) (void)hipFree(ix->d_rows);
     if (ix->d_code_of) (void)hipFree(ix->d_code_of);
     if (ix->d_id_blocks) (void)hipFree(ix->d_id_blocks);
+    if (ix->d_sep_rows) (void)hipFree(ix->d_sep_rows);
+    if (ix->d_sep_vals) (void)hipFree(ix->d_sep_vals);
+    if (ix->d_tally) (void)hipFree(ix->d_tally);
     if (ix->d_ckpt) (void)hipFree(ix->d_ckpt);
     if (ix->d_stats) (void)hipFree(ix->d_stats);
     delete ix;
@@ -290,6 +387,9 @@ int movi_index_get_desc(const movi_index_t *ix, movi_index_desc_t *desc) {
     if (!ix || !desc) return fail(MOVI_ERR_ARG, "NULL argument");
     *desc = ix->desc;
     desc->id_blocks = nullptr;
+    desc->separator_thresholds = nullptr;
+    desc->separator_map = nullptr;
+    desc->tally_ids = nullptr;
     return MOVI_OK;
 }
 
@@ -303,8 +403,8 @@ int movi_index_device_rows(const movi_index_t *ix, const void **d_rows, size_t *
 int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
     if (!ix || !key) return fail(MOVI_ERR_ARG, "NULL argument");
     if (!strcmp(key, "pml_variant")) {
-        if (value != -1 && value != 0 && value != 1 && (value < 7 || value > 12))
-            return fail(MOVI_ERR_ARG, "pml_variant must be -1 (auto), 0, 1 or 7..12");
+        if (value != -1 && value != 0 && value != 1 && value != 7 && value != 10)
+            return fail(MOVI_ERR_ARG, "pml_variant must be -1 (auto), 0, 1, 7 or 10");
         ix->cfg.pml_variant = (int)value;
         return MOVI_OK;
     }

@@ -19,7 +19,7 @@
 
 namespace movi {
 
-constexpr int kIdbLdsEntries = 4096;   // mode-8 id_blocks entries held in LDS (16 KiB)
+constexpr int kIdbLdsEntries = 4096;   // mode-8 id_blocks entries held in LDS (16 KiB; 20 KiB cost a block per CU: c2b 46 -> 42.7)
 
 // ------------------------------------------------------------------ row decode
 // A row is carried in registers as two dwords.
@@ -31,11 +31,13 @@ constexpr int kIdbLdsEntries = 4096;   // mode-8 id_blocks entries held in LDS (
 //     x = id16 | n16 << 16    y = offset16
 //     n16:  [9:0] n, [15:10] id[21:16]
 //     off16:[9:0] offset, [12:10] c, [13] thr0, [14] thr1, [15] thr2
+//   mode 7 (3 B, sampled-thresholds; move_row.hpp:122-127, masks move_row_configs.hpp:120-136): no id in the row
+//     x = n8 | offset8 << 8 | cbyte << 16     cbyte: [0] offset bit 8, [1] n bit 8, [4:2] c, [5] thr0, [6] thr1, [7] thr2
 template <int MODE>
 __device__ __forceinline__ uint2 load_row(const uint8_t *rows, uint64_t i) {
     if (MODE == 6) {
         return *reinterpret_cast<const uint2 *>(rows + i * 8);
-    } else {
+    } else if (MODE == 8) {
         // 6-byte rows: ONE unaligned 8-byte load of the bytes [6i-2, 6i+6) (for row 0: [0, 8)), shifted into
         // place -- never reads outside the table -- instead of three 2-byte loads
         const uint32_t lead = i ? 2u : 0u;
@@ -43,30 +45,43 @@ __device__ __forceinline__ uint2 load_row(const uint8_t *rows, uint64_t i) {
         __builtin_memcpy(&v, rows + i * 6 - lead, 8);
         v >>= 8u * lead;
         return make_uint2((uint32_t)v, (uint32_t)(v >> 32) & 0xFFFFu);
+    } else {
+        // 3-byte rows: one unaligned 4-byte load of the bytes [3i-1, 3i+3) (row 0: [0, 4)), same trick
+        const uint32_t lead = i ? 1u : 0u;
+        uint32_t v;
+        __builtin_memcpy(&v, rows + i * 3 - lead, 4);
+        v >>= 8u * lead;
+        return make_uint2(v & 0xFFFFFFu, 0u);
     }
 }
 template <int MODE> __device__ __forceinline__ uint32_t row_n(uint2 w) {
+    if (MODE == 7) return (w.x & 0xFFu) | (((w.x >> 17) & 1u) << 8);
     return MODE == 6 ? (w.y & 0x7FFu) : ((w.x >> 16) & 0x3FFu);
 }
 template <int MODE> __device__ __forceinline__ uint32_t row_off(uint2 w) {
+    if (MODE == 7) return ((w.x >> 8) & 0xFFu) | (((w.x >> 16) & 1u) << 8);
     return MODE == 6 ? ((w.y >> 16) & 0x7FFu) : (w.y & 0x3FFu);
 }
 template <int MODE> __device__ __forceinline__ uint32_t row_c(uint2 w) {
+    if (MODE == 7) return (w.x >> 18) & 7u;
     return MODE == 6 ? ((w.y >> 13) & 7u) : ((w.y >> 10) & 7u);
 }
-// threshold bit k in {0,1,2} (MoveRow::get_threshold, move_row.hpp:304-332)
+// threshold bit k in {0,1,2} (MoveRow::get_threshold, move_row.hpp:304-347)
 template <int MODE> __device__ __forceinline__ uint32_t row_thr(uint2 w, uint32_t k) {
     if (MODE == 6) {
         // k=0 -> off16 bit 11 (y bit 27); k=1 -> n16 bit 11; k=2 -> n16 bit 12
         uint32_t sh = (k == 0) ? 27u : (10u + k);
         return (w.y >> sh) & 1u;
-    } else {
+    } else if (MODE == 8) {
         return (w.y >> (13u + k)) & 1u;
+    } else {
+        return (w.x >> (21u + k)) & 1u;
     }
 }
 // MoveStructure::get_id, src/move_structure.cpp:91-102
 template <int MODE>
 __device__ __forceinline__ uint64_t row_id(uint2 w, uint64_t idx, const DevIndex &ix, const uint32_t *idb_lds = nullptr) {
+    static_assert(MODE == 6 || MODE == 8, "sampled mode 7 has no id in the row: tally_id()");
     if (MODE == 6) {
         return (uint64_t)w.x | ((uint64_t)(w.y >> 28) << 32);
     } else {
@@ -78,6 +93,41 @@ __device__ __forceinline__ uint64_t row_id(uint2 w, uint64_t idx, const DevIndex
         const uint32_t base = idb_lds ? idb_lds[slot] : ix.id_blocks[slot];     // check point of (character, block)
         return bid + (uint64_t)base + ix.first_runs[c + 1];
     }
+}
+
+// ---- reposition_thresholds, src/move_structure_query.cpp:513-601: which threshold applies.
+// Read base code a and row code c are alphamap values: 0..3, or 1..4 on a separators index (code 0 = '%').
+// Slot of a DNA row: alphamap_3[c - sep][a - sep] (src/utils.cpp:5-8) = (a - sep) - (a > c) for a != c.
+__device__ __forceinline__ uint32_t thr_slot(uint32_t sep, uint32_t a, uint32_t c) {
+    return (a - sep - (uint32_t)(a > c)) & 3u;
+}
+// end_bwt_idx_thresholds[a - sep] (:534-535).  The four values are clamped to 32 bits once per kernel (offsets
+// are < 2^11, so `off >= t` is unchanged) and picked with selects: written as a ladder over the kernel-argument
+// array, hipcc turned the pick into an indexed LOAD from the kernarg segment plus `s_waitcnt vmcnt(0)` -- one
+// more memory round trip in every iteration of the latency-bound state machine (c3: 39.6 -> 32.2 Gbases/s).
+struct EndThr { uint32_t e0, e1, e2, e3; };
+__device__ __forceinline__ EndThr end_thresholds(const DevIndex &ix) {
+    auto clamp = [](uint64_t v) { return v > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)v; };
+    return EndThr{clamp(ix.end_thr[0]), clamp(ix.end_thr[1]), clamp(ix.end_thr[2]), clamp(ix.end_thr[3])};
+}
+__device__ __forceinline__ uint32_t end_threshold(uint32_t sep, const EndThr &e, uint32_t a) {
+    const uint32_t k = a - sep;
+    const uint32_t lo = (k & 1u) ? e.e1 : e.e0, hi = (k & 1u) ? e.e3 : e.e2;
+    return (k & 2u) ? hi : lo;
+}
+// separators_thresholds[separators_thresholds_map[idx]].values[a - 1] (:540-541) for a row of the separator;
+// a missing key reads entry 0 of an empty-initialised map in the reference: 0 here.  Rare path: binary search.
+__device__ __forceinline__ uint32_t separator_threshold(const DevIndex &ix, uint64_t idx, uint32_t a) {
+    uint32_t lo = 0, hi = ix.n_sep;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (ix.sep_rows[mid] < idx) lo = mid + 1; else hi = mid;
+    }
+    if (lo >= ix.n_sep || ix.sep_rows[lo] != idx) return 0u;
+    const uint2 v = ix.sep_vals[lo];
+    const uint32_t k = a - 1u;
+    const uint32_t w = (k & 2u) ? v.y : v.x;
+    return (k & 1u) ? (w >> 16) : (w & 0xFFFFu);
 }
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
@@ -103,6 +153,79 @@ enum : uint32_t {
 // earlier.  Uniform loops are also the cheaper form on a 64-wide wavefront.
 __device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
 
+// MoveStructure::get_id for the sampled ("tally") mode 7, src/move_structure.cpp:104-283, forward branch (the
+// reference fixes forward_direciton = true, :146): the row holds no id; every tally_cp rows the id of the latest
+// run of each character is kept.  The id of row idx = the id stored at the next checkpoint for idx's character,
+// walked back over the destination rows by the BWT positions of that character between idx and the stored run.
+// Wave-uniform loops, predicated per lane (see the control-flow note above).  Returns r on the reference's throws.
+__device__ __forceinline__ uint64_t tally_id(const DevIndex &ix, bool live, uint64_t idx, uint2 row) {
+    const uint32_t ci = row_c<7>(row);
+    const uint64_t cp = ix.tally_cp;
+    uint64_t id = 0;
+    uint32_t walk = 0;                                   // 1 while the lane still scans / walks
+    uint64_t i = idx, next_cp = idx;
+    uint64_t rows_until = 0;
+    uint32_t last_n = 0, last_off = 0, last_is_idx = 1;
+    if (live && idx != ix.end_bwt_idx) {                 // '$' goes to row 0 (:106-108)
+        const uint64_t ta = idx / cp;
+        const uint64_t *tl = ix.tally + (uint64_t)ci * ix.tally_len;
+        if (idx == ix.r - 1) id = tl[ix.tally_len - 1];  // :114-117
+        else if (ta * cp == idx) id = tl[ta];            // :121-124
+        else {
+            next_cp = (ta + 1) * cp;
+            if (next_cp >= ix.r) next_cp = ix.r - 1;     // :137-139
+            id = tl[ta + 1];
+            walk = 1;
+        }
+    }
+    // rows of idx's character in [idx, next_cp) (:168-174); row idx itself is one of them
+    uint32_t scan = walk;
+    while (wave_any(scan != 0u)) {
+        if (scan) {
+            const uint2 w = load_row<7>(ix.rows, i);
+            if (i != ix.end_bwt_idx && row_c<7>(w) == ci) {
+                rows_until += row_n<7>(w);
+                last_n = row_n<7>(w);
+                last_off = row_off<7>(w);
+                last_is_idx = (i == idx) ? 1u : 0u;
+            }
+            i += 1;
+            scan = (i < next_cp) ? 1u : 0u;
+        }
+    }
+    uint32_t back = 0;
+    if (walk) {
+        const uint2 wn = load_row<7>(ix.rows, next_cp);
+        const uint32_t same = (next_cp != ix.end_bwt_idx && row_c<7>(wn) == ci) ? 1u : 0u;
+        if (last_is_idx && !same) {
+            walk = 0;                                    // :178-180: the stored id is idx's own
+        } else {
+            uint32_t offset = row_off<7>(wn);
+            if (!same) { rows_until -= last_n; offset = last_off; }       // :194-197
+            if (id >= ix.r) { id = ix.r; walk = 0; }
+            else {
+                const uint32_t nid = row_n<7>(load_row<7>(ix.rows, id));
+                if (offset >= nid) { id = ix.r; walk = 0; }               // :200-203 throws
+                else if ((uint64_t)offset >= rows_until) walk = 0;        // :204-205
+                else { rows_until -= (uint64_t)offset + 1; back = 1; }    // :206-209 (id -= 1 below)
+            }
+        }
+    }
+    if (back) { if (id == 0) { id = ix.r; back = 0; } else id -= 1; }
+    while (wave_any(back != 0u && rows_until != 0)) {   // :211-219
+        if (back && rows_until != 0) {
+            const uint32_t nid = row_n<7>(load_row<7>(ix.rows, id));
+            if (rows_until >= nid) {
+                rows_until -= nid;
+                if (id == 0) { id = ix.r; rows_until = 0; } else id -= 1;
+            } else {
+                rows_until = 0;
+            }
+        }
+    }
+    return id;
+}
+
 // LF_move + fast_forward.  On entry `row` is rows[idx]; on exit it is the row of
 // the new idx.  `live` lanes take the step; returns a kErr* code (0 = ok) per lane.
 template <int MODE>
@@ -112,8 +235,9 @@ __device__ __forceinline__ uint32_t lf_step(const DevIndex &ix, bool live, uint6
     uint64_t j = idx;
     uint32_t n = 0, ff = 0;
     uint32_t going = 0;
+    if constexpr (MODE == 7) j = tally_id(ix, live, idx, row);
     if (live) {
-        j = row_id<MODE>(row, idx, ix, idb_lds);
+        if constexpr (MODE != 7) j = row_id<MODE>(row, idx, ix, idb_lds);
         if (j >= ix.r) {                                // move_structure.cpp:63-65
             errc = kErrIdRange;
             j = idx;
@@ -153,9 +277,15 @@ __device__ __forceinline__ uint32_t lf_step2(const DevIndex &ix, bool live, uint
     uint32_t errc = kErrNone;
     uint64_t ja = ia, jb = ib;
     uint32_t na = 0, nb = 0, ffa = 0, ffb = 0, ga = 0, gb = 0;
+    if constexpr (MODE == 7) {
+        ja = tally_id(ix, live, ia, rowa);
+        jb = tally_id(ix, live, ib, rowb);
+    }
     if (live) {
-        ja = row_id<MODE>(rowa, ia, ix, idb_lds);
-        jb = row_id<MODE>(rowb, ib, ix, idb_lds);
+        if constexpr (MODE != 7) {
+            ja = row_id<MODE>(rowa, ia, ix, idb_lds);
+            jb = row_id<MODE>(rowb, ib, ix, idb_lds);
+        }
         if (ja >= ix.r || jb >= ix.r) {                 // move_structure.cpp:63-65
             errc = kErrIdRange;
             ja = ia; jb = ib;
@@ -236,14 +366,15 @@ __global__ __launch_bounds__(256) void pml_kernel(DevIndex ix, const uint8_t *__
     // (4 x n_blocks x 4 B = 15 kB for 1 B rows) so that get_id costs no extra global load
     __shared__ uint32_t s_idb[MODE == 8 ? kIdbLdsEntries : 1];
     const uint32_t *idb = nullptr;
-    if (MODE == 8 && ix.n_blocks * 4 <= (uint64_t)kIdbLdsEntries) {
-        for (uint32_t i = threadIdx.x; i < (uint32_t)ix.n_blocks * 4; i += blockDim.x) s_idb[i] = ix.id_blocks[i];
+    if (MODE == 8 && ix.n_blocks * ix.sigma <= (uint64_t)kIdbLdsEntries) {
+        for (uint32_t i = threadIdx.x; i < (uint32_t)ix.n_blocks * ix.sigma; i += blockDim.x) s_idb[i] = ix.id_blocks[i];
         idb = s_idb;
     }
     __syncthreads();
 
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t ff_total = 0, scan_total = 0, repo_total = 0, failed = 0;
+    const EndThr ethr = end_thresholds(ix);
     const bool valid = t < n_reads;
     // lane slot t works on read rid: the host may pass reads sorted by length so that the 64
     // lanes of a wave finish together (ragged batches)
@@ -306,12 +437,13 @@ __global__ __launch_bounds__(256) void pml_kernel(DevIndex ix, const uint8_t *__
                 ml = 0;
                 uint32_t down;
                 if (idx == ix.end_bwt_idx) {
-                    // end_bwt_idx_thresholds[a]; a in 1..3 here ('$' row matches 'A')
-                    const uint64_t et = a == 1 ? ix.end_thr[1] : (a == 2 ? ix.end_thr[2] : ix.end_thr[3]);
-                    down = ((uint64_t)off >= et) ? 1u : 0u;
+                    // end_bwt_idx_thresholds (without separators the '$' row matches 'A', so a is 1..3 here)
+                    down = (off >= end_threshold(ix.sep, ethr, a)) ? 1u : 0u;
+                } else if (ix.sep && rc == 0u) {
+                    down = (off >= separator_threshold(ix, idx, a)) ? 1u : 0u;   // a row of the separator
                 } else {
-                    const uint32_t kk = a - (a > rc ? 1u : 0u);      // alphamap_3[rc][a], utils.cpp:5-8
-                    const uint32_t thr = row_thr<MODE>(row, kk) ? row_n<MODE>(row) : 0u;
+                    const uint32_t kk = thr_slot(ix.sep, a, rc);     // alphamap_3, utils.cpp:5-8
+                    const uint32_t thr = row_thr<MODE>(row, kk > 2u ? 2u : kk) ? row_n<MODE>(row) : 0u;
                     down = (off >= thr) ? 1u : 0u;
                 }
                 dir = down ? 1u : 2u;
@@ -414,14 +546,15 @@ __global__ __launch_bounds__(256) void pml_kernel_flat(DevIndex ix, const uint8_
     // (4 x n_blocks x 4 B = 15 kB for 1 B rows) so that get_id costs no extra global load
     __shared__ uint32_t s_idb[MODE == 8 ? kIdbLdsEntries : 1];
     const uint32_t *idb = nullptr;
-    if (MODE == 8 && ix.n_blocks * 4 <= (uint64_t)kIdbLdsEntries) {
-        for (uint32_t i = threadIdx.x; i < (uint32_t)ix.n_blocks * 4; i += blockDim.x) s_idb[i] = ix.id_blocks[i];
+    if (MODE == 8 && ix.n_blocks * ix.sigma <= (uint64_t)kIdbLdsEntries) {
+        for (uint32_t i = threadIdx.x; i < (uint32_t)ix.n_blocks * ix.sigma; i += blockDim.x) s_idb[i] = ix.id_blocks[i];
         idb = s_idb;
     }
     __syncthreads();
 
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t ff_total = 0, scan_total = 0, repo_total = 0, failed = 0;
+    const EndThr ethr = end_thresholds(ix);
     const bool valid = t < n_reads;
     const uint64_t rid = (valid && order) ? order[t] : t;
     const uint64_t beg = valid ? offs[rid] : 0;
@@ -466,10 +599,12 @@ __global__ __launch_bounds__(256) void pml_kernel_flat(DevIndex ix, const uint8_
         const uint32_t illegal = a == 0xFFu, match = c == a;
         const uint32_t mism = resolved & (illegal ^ 1u) & (match ^ 1u);
         // reposition_thresholds, src/move_structure_query.cpp:513-601
-        const uint32_t kk = (a - (uint32_t)(a > c)) & 3u;                 // alphamap_3[c][a]
-        const uint32_t thr = row_thr<MODE>(row, kk > 2u ? 2u : kk) ? n : 0u;
-        const uint64_t et = a == 1 ? ix.end_thr[1] : (a == 2 ? ix.end_thr[2] : ix.end_thr[3]);
-        const uint32_t down = (need == end_row) ? (uint32_t)((uint64_t)off >= et) : (uint32_t)(off >= thr);
+        const uint32_t kk = thr_slot(ix.sep, a, c);                       // alphamap_3[c][a]
+        uint32_t thr = row_thr<MODE>(row, kk > 2u ? 2u : kk) ? n : 0u;
+        if (ix.sep) {                                                     // a row of the separator: side table
+            if (mism & (uint32_t)(c == 0u) & (uint32_t)(need != end_row)) thr = separator_threshold(ix, (uint64_t)need, a);
+        }
+        const uint32_t down = (uint32_t)(off >= ((need == end_row) ? end_threshold(ix.sep, ethr, a) : thr));
         const uint32_t at_last = need >= r1, at_first = need == 0;
         const uint32_t repo_edge = mism & (down ? at_last : at_first);
         // reposition_down :211-232 / reposition_up :188-209, one row per iteration
@@ -542,14 +677,6 @@ __global__ __launch_bounds__(256) void pml_kernel_flat(DevIndex ix, const uint8_
     }
 }
 
-// VARIANT 8 ("flat state machine + aligned row window"): variant 7 fetching, instead of the one row
-// it needs, the aligned 4-row window around it -- the same cache line, so the same single L2 request
-// -- and walking inside the window without further memory round trips: up to HA cheap fast-forward /
-// scan hops, the full automaton step on the row reached, then up to HC more hops for a scan that the
-// step just started.  Measured (100 k x 10 kbp, Gbases/s; variant 7 = 34.3 pangenome / 28.9 random
-// table): (HA, HC) = (1,0) 36.9 / 33.2, (2,0) 36.5 / 33.7 <- shipped, (3,0) 35.9 / 33.4, (2,1) 35.8 /
-// 32.9, (3,3) 31.8 / 29.1: the gather's latency dominates an iteration, so each hop's ~30
-// instructions must pay for themselves in saved (cheap, L2-hit) neighbour trips.
 template <int MODE>
 __device__ __forceinline__ void load_window(const uint8_t *rows, uint64_t wbase, uint2 (&w)[4]) {
     if (MODE == 6) {
@@ -576,193 +703,23 @@ __device__ __forceinline__ uint2 win_sel(const uint2 (&w)[4], uint32_t q) {
     return (q & 2u) ? hi : lo;
 }
 
-template <int MODE, typename IdxT, int HA, int HC, int CLS>
-__global__ __launch_bounds__(256) void pml_kernel_flatw(DevIndex ix, const uint8_t *__restrict__ bases,
-                                                       const uint64_t *__restrict__ offs, uint64_t n_reads,
-                                                       uint16_t *__restrict__ out, uint8_t *__restrict__ err,
-                                                       DevStats *stats, const uint32_t *__restrict__ order,
-                                                       ClsArgs cls) {
-    enum : uint32_t { sFF = 0, sDown = 1, sUp = 2, sDone = 3 };
-    __shared__ uint8_t s_code[256];
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = ix.code_of[i];
-    // mode 8: the (character, block) check points of the blocked ids, kept in LDS when they fit
-    // (4 x n_blocks x 4 B = 15 kB for 1 B rows) so that get_id costs no extra global load
-    __shared__ uint32_t s_idb[MODE == 8 ? kIdbLdsEntries : 1];
-    const uint32_t *idb = nullptr;
-    if (MODE == 8 && ix.n_blocks * 4 <= (uint64_t)kIdbLdsEntries) {
-        for (uint32_t i = threadIdx.x; i < (uint32_t)ix.n_blocks * 4; i += blockDim.x) s_idb[i] = ix.id_blocks[i];
-        idb = s_idb;
-    }
-    __syncthreads();
-
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t ff_total = 0, scan_total = 0, repo_total = 0, failed = 0;
-    const bool valid = t < n_reads;
-    const uint64_t rid = (valid && order) ? order[t] : t;
-    const uint64_t beg = valid ? offs[rid] : 0;
-    const uint32_t len = valid ? (uint32_t)(offs[rid + 1] - beg) : 0;   // reads are shorter than 2^32 (checked on the host)
-    const uint8_t *R = bases + beg;
-    uint16_t *O = out + beg;
-    const uint32_t packed_end = len & ~7u;
-    const IdxT r1 = (IdxT)(ix.r - 1), end_row = (IdxT)ix.end_bwt_idx;
-
-    auto load_chunk = [&](uint32_t kk) -> uint64_t {
-        uint64_t v = 0;
-        if (beg + len >= (uint64_t)kk + 8) {
-            __builtin_memcpy(&v, R + len - kk - 8, 8);    // may start before R: still inside `bases`
-        } else {
-            for (uint32_t i = 0; i < len - kk; ++i) v |= (uint64_t)R[len - 1 - kk - i] << (8 * (7 - i));
-        }
-        return v;
-    };
-
-    uint32_t st = len > 0 ? sFF : sDone;
-    IdxT need = r1;                                       // ReadProcessor::reset_process :69-70
-    uint32_t k = 0;
-    uint32_t ml = 0, ff_run = 0;
-    uint32_t off = row_n<MODE>(load_row<MODE>(ix.rows, r1)) - 1;
-    uint64_t rb = st != sDone ? load_chunk(0) : 0;
-    uint32_t a = s_code[(uint32_t)(rb >> 56) & 0xFFu];    // code of the base of step k (k = 0)
-    uint4 pk = make_uint4(0, 0, 0, 0);
-    ClsState cs;
-    if (CLS) cs.init(len, cls.bin_width);
-
-    while (wave_any(st != sDone)) {
-        // the aligned 4-row window that holds `need`: 32 bytes (mode 6, two 16-byte loads) or 24 bytes
-        // (mode 8, three 8-byte loads) of ONE cache line in most cases -- one L2 request like the 8-byte row
-        const IdxT wbase = need & ~(IdxT)3;
-        uint2 w[4] = {make_uint2(0, 0), make_uint2(0, 0), make_uint2(0, 0), make_uint2(0, 0)};
-        const bool act = st != sDone;
-        if (wave_any(act && (uint64_t)wbase + 3 > (uint64_t)r1)) {        // the table's last window: row by row
-            if (act) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const uint64_t jj = (uint64_t)wbase + q;
-                    w[q] = load_row<MODE>(ix.rows, jj < ix.r ? jj : ix.r - 1);
-                }
-            }
-        } else if (act) {
-            load_window<MODE>(ix.rows, (uint64_t)wbase, w);
-        }
-        // cheap hop: a fast-forward or scan step that only moves on (everything that resolves a base,
-        // starts a scan, ends one or fails is left to the full step below)
-        auto hop = [&]() {
-            const uint32_t inwin = (uint32_t)((need & ~(IdxT)3) == wbase) & (uint32_t)(st != sDone);
-            const uint2 hr = win_sel(w, (uint32_t)need & 3u);
-            const uint32_t hn = row_n<MODE>(hr), hc = row_c<MODE>(hr);
-            const uint32_t ffh = inwin & (uint32_t)(st == sFF) & (uint32_t)(need < r1) & (uint32_t)(off >= hn) &
-                                 (uint32_t)(ff_run + 1 < 65535u);
-            const uint32_t nomatch = hc != a;
-            const uint32_t dnh = inwin & (uint32_t)(st == sDown) & nomatch & (uint32_t)(need < r1);
-            const uint32_t uph = inwin & (uint32_t)(st == sUp) & nomatch & (uint32_t)(need != 0);
-            off = ffh ? off - hn : off;
-            ff_run += ffh;
-            scan_total += dnh | uph;
-            need = need + (IdxT)(ffh + dnh) - (IdxT)uph;
-        };
-#pragma unroll
-        for (int h = 0; h < HA; ++h) hop();
-        const uint32_t inwin = (uint32_t)((need & ~(IdxT)3) == wbase) & (uint32_t)act;
-        const uint2 row = win_sel(w, (uint32_t)need & 3u);
-        const uint32_t n = row_n<MODE>(row), c = row_c<MODE>(row);
-        // predicates as 0/1 integers combined with & | (no short-circuit control flow)
-        const uint32_t isFF = (uint32_t)(st == sFF) & inwin, isDown = (uint32_t)(st == sDown) & inwin,
-                       isUp = (uint32_t)(st == sUp) & inwin;
-        // fast_forward, move_structure.cpp:524-545
-        const uint32_t ffm = isFF & (uint32_t)(need < r1) & (uint32_t)(off >= n);
-        const uint32_t ff_over = ffm & (uint32_t)(ff_run + 1 >= 65535u);  // :72-75
-        const uint32_t resolved = isFF & (ffm ^ 1u);
-        // the base of step k against the row (read_processor.cpp:188-238)
-        const uint32_t illegal = a == 0xFFu, match = c == a;
-        const uint32_t mism = resolved & (illegal ^ 1u) & (match ^ 1u);
-        // reposition_thresholds, src/move_structure_query.cpp:513-601
-        const uint32_t kk = (a - (uint32_t)(a > c)) & 3u;                 // alphamap_3[c][a]
-        const uint32_t thr = row_thr<MODE>(row, kk > 2u ? 2u : kk) ? n : 0u;
-        const uint64_t et = a == 1 ? ix.end_thr[1] : (a == 2 ? ix.end_thr[2] : ix.end_thr[3]);
-        const uint32_t down = (need == end_row) ? (uint32_t)((uint64_t)off >= et) : (uint32_t)(off >= thr);
-        const uint32_t at_last = need >= r1, at_first = need == 0;
-        const uint32_t repo_edge = mism & (down ? at_last : at_first);
-        // reposition_down :211-232 / reposition_up :188-209, one row per iteration
-        const uint32_t scanning = isDown | isUp;
-        const uint32_t hit = scanning & match;
-        const uint32_t scan_edge = scanning & (hit ^ 1u) & (isDown ? at_last : at_first);
-        const uint32_t emit = (resolved & (illegal | match)) | hit;
-        const uint32_t errc = ff_over ? kErrFastForward
-                              : (repo_edge ? (down ? kErrNoRunBelow : kErrNoRunAbove)
-                                 : (scan_edge ? (isDown ? kErrNoRunBelow : kErrNoRunAbove) : kErrNone));
-        // ---- state update, all selects
-        ml = resolved ? (match ? ml + 1 : 0u) : ml;
-        ff_total += resolved ? ff_run : 0u;
-        ff_run += ffm;
-        repo_total += mism;
-        scan_total += scanning;
-        off = ffm ? off - n : (hit ? (isDown ? 0u : n - 1) : off);        // read_processor.cpp:223
-        const uint32_t step_fwd = ffm | (mism & down) | (scanning & (hit ^ 1u) & isDown);
-        const uint32_t step_back = (mism & (down ^ 1u)) | (scanning & (hit ^ 1u) & isUp);
-        IdxT need_next = need + step_fwd - step_back;
-        uint32_t st_next = mism ? (down ? sDown : sUp) : st;
-        if (emit) {
-            const uint32_t val = ml > 65535u ? 65535u : ml;               // MoveQuery::add_ml
-            if (CLS) cs.add(val, k, len, cls.bin_width, cls.thr);
-            if (CLS == 2) {
-                // verdict bins only
-            } else if (k >= packed_end) {
-                O[k] = (uint16_t)val;
-            } else {
-                pk.x = (pk.x >> 16) | (pk.y << 16);
-                pk.y = (pk.y >> 16) | (pk.z << 16);
-                pk.z = (pk.z >> 16) | (pk.w << 16);
-                pk.w = (pk.w >> 16) | (val << 16);
-                if ((k & 7) == 7) __builtin_memcpy(O + (k - 7), &pk, 16);
-            }
-            k += 1;
-            if (k == len) {
-                st_next = sDone;
-            } else {
-                const uint64_t j = row_id<MODE>(row, need, ix, idb);      // LF_move, move_structure.cpp:59-67
-                if (j >= ix.r) {
-                    failed = kErrIdRange;
-                    st_next = sDone;
-                } else {
-                    off += row_off<MODE>(row);
-                    need_next = (IdxT)j;
-                    ff_run = 0;
-                    st_next = sFF;
-                    if ((k & 7) == 0) rb = load_chunk(k);
-                    a = s_code[(uint32_t)(rb >> (8 * (7 - (k & 7)))) & 0xFFu];
-                }
-            }
-        }
-        if (errc) { failed = errc; st_next = sDone; }
-        need = need_next;
-        st = st_next;
-#pragma unroll
-        for (int h = 0; h < HC; ++h) hop();
-    }
-    if (failed && CLS != 2) {
-        for (uint32_t i = 0; i < len; ++i) O[i] = 0;
-    }
-    if (CLS && valid) cs.store(cls, rid, failed != 0u);
-    if (valid && err) err[rid] = (uint8_t)failed;
-    const uint32_t ffw = wave_sum(ff_total), scw = wave_sum(scan_total), rpw = wave_sum(repo_total),
-                   erw = wave_sum(failed ? 1u : 0u);
-    if ((threadIdx.x & 63) == 0 && stats) {
-        if (ffw) atomicAdd(&stats->fast_forwards, (unsigned long long)ffw);
-        if (scw) atomicAdd(&stats->scans, (unsigned long long)scw);
-        if (rpw) atomicAdd(&stats->repositions, (unsigned long long)rpw);
-        if (erw) atomicAdd(&stats->errors, (unsigned long long)erw);
-    }
-}
-
-// VARIANTS 9 / 10 ("flat state machine + window, software-pipelined"): variant 8 with the two remaining
-// serial memory waits of an iteration taken off the critical path.
-//   * read chunks are double-buffered: the 8 bases after the current chunk are fetched when the current chunk
-//     is entered, so the chunk load (always an L2 miss: the line was evicted long ago) overlaps eight row
-//     gathers instead of stalling the lane once per 8 bases (variant 9, PIPE = 0);
-//   * PIPE = 1 (variant 10): the next window's address is computed from the row alone (all selects) and its
-//     load is issued BEFORE the bookkeeping of the step (PML packing and stores, bins, counters, base decode),
-//     which then runs under the gather's latency.
-template <int MODE, typename IdxT, int HA, int PIPE, int CLS>
+// VARIANT 10 ("flat state machine + row window, software-pipelined"; default when <= 12 waves/CU of reads):
+// variant 7 with
+//   * the 4-row WINDOW around the row it needs fetched instead of the row (32 B / 24 B of the same cache line,
+//     the same single L2 request) and up to HA cheap fast-forward / scan hops taken inside it before the full
+//     automaton step, so most neighbour rows cost no memory round trip (+6 % on the pangenome, +16-19 % on
+//     random tables over variant 7);
+//   * the next window's address computed from the row alone (all selects) and its load issued BEFORE the
+//     step's bookkeeping (PML packing and stores, bins, counters, base decode), which then runs under the
+//     gather's latency; the load is unpredicated and branch-free (the table's last window is pulled back to
+//     rows [r-4, r); finished lanes re-read window 0) -- with a predicated two-path fetch hipcc parked a
+//     `s_waitcnt vmcnt(0)` right behind the load and the overlap was gone;
+//   * read chunks double-buffered: the 8 bases after the current chunk are fetched when the chunk is entered, so
+//     the chunk load (always an L2 miss: its line was evicted long ago) overlaps eight row gathers.
+// Measured (100 k x 10 kbp, Gbases/s, pangenome / random table): unpipelined window kernel (variant 8, removed)
+// 36.4 / 33.6; chunk double-buffering alone 35.1 / 32.4; pipelined HA = 1 / 2 / 3: 40.2 / 39.6 / 38.9 (pangenome),
+// 36.3 / 36.6 / 36.2 (random) -> HA = 2 shipped.  Hops after the step (HC > 0) measured slower and are gone.
+template <int MODE, typename IdxT, int HA, int CLS, int SEP>
 __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8_t *__restrict__ bases,
                                                        const uint64_t *__restrict__ offs, uint64_t n_reads,
                                                        uint16_t *__restrict__ out, uint8_t *__restrict__ err,
@@ -773,14 +730,15 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = ix.code_of[i];
     __shared__ uint32_t s_idb[MODE == 8 ? kIdbLdsEntries : 1];
     const uint32_t *idb = nullptr;
-    if (MODE == 8 && ix.n_blocks * 4 <= (uint64_t)kIdbLdsEntries) {
-        for (uint32_t i = threadIdx.x; i < (uint32_t)ix.n_blocks * 4; i += blockDim.x) s_idb[i] = ix.id_blocks[i];
+    if (MODE == 8 && ix.n_blocks * ix.sigma <= (uint64_t)kIdbLdsEntries) {
+        for (uint32_t i = threadIdx.x; i < (uint32_t)ix.n_blocks * ix.sigma; i += blockDim.x) s_idb[i] = ix.id_blocks[i];
         idb = s_idb;
     }
     __syncthreads();
 
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t ff_total = 0, scan_total = 0, repo_total = 0, failed = 0;
+    const EndThr ethr = end_thresholds(ix);
     const bool valid = t < n_reads;
     const uint64_t rid = (valid && order) ? order[t] : t;
     const uint64_t beg = valid ? offs[rid] : 0;
@@ -823,13 +781,13 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
     ClsState cs;
     if (CLS) cs.init(len, cls.bin_width);
     uint2 w[4];
-    if (PIPE) fetch(need, st != sDone, w);
+    fetch(need, st != sDone, w);
 
     while (wave_any(st != sDone)) {
         const bool act = st != sDone;
-        if (!PIPE) fetch(need, act, w);
         const IdxT wbase = win_base(need);
-        // cheap hop: a fast-forward or scan step that only moves on (see pml_kernel_flatw)
+        // cheap hop: a fast-forward or scan step that only moves on (everything that resolves a base,
+        // starts a scan, ends one or fails is left to the full step below)
         auto hop = [&]() {
             const uint32_t q = (uint32_t)(need - wbase);
             const uint32_t inwin = (uint32_t)(q < 4u) & (uint32_t)(st != sDone);
@@ -861,10 +819,14 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
         const uint32_t illegal = a == 0xFFu, match = c == a;
         const uint32_t mism = resolved & (illegal ^ 1u) & (match ^ 1u);
         // reposition_thresholds, src/move_structure_query.cpp:513-601
-        const uint32_t kk = (a - (uint32_t)(a > c)) & 3u;                 // alphamap_3[c][a]
-        const uint32_t thr = row_thr<MODE>(row, kk > 2u ? 2u : kk) ? n : 0u;
-        const uint64_t et = a == 1 ? ix.end_thr[1] : (a == 2 ? ix.end_thr[2] : ix.end_thr[3]);
-        const uint32_t down = (need == end_row) ? (uint32_t)((uint64_t)off >= et) : (uint32_t)(off >= thr);
+        // (SEP is a template parameter here: the separator branch and its selects sit on the critical path
+        // between the window's arrival and the next gather, and cost 4 % on c3 as a run-time flag)
+        const uint32_t kk = thr_slot(SEP, a, c);                          // alphamap_3[c][a]
+        uint32_t thr = row_thr<MODE>(row, kk > 2u ? 2u : kk) ? n : 0u;
+        if (SEP) {                                                        // a row of the separator: side table
+            if (mism & (uint32_t)(c == 0u) & (uint32_t)(need != end_row)) thr = separator_threshold(ix, (uint64_t)need, a);
+        }
+        const uint32_t down = (uint32_t)(off >= ((need == end_row) ? end_threshold(SEP, ethr, a) : thr));
         const uint32_t at_last = need >= r1, at_first = need == 0;
         const uint32_t repo_edge = mism & (down ? at_last : at_first);
         // reposition_down :211-232 / reposition_up :188-209, one row per iteration
@@ -889,7 +851,7 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
                                  : (lf ? sFF : (mism ? (down ? sDown : sUp) : st));
         // ---- the next gather leaves now; everything below runs under its latency
         // (`row` is not touched below, so the new window can land in the old one's registers)
-        if (PIPE) fetch(need_next, st_next != sDone, w);
+        fetch(need_next, st_next != sDone, w);
         // ---- bookkeeping, all selects
         ml = resolved ? (match ? ml + 1 : 0u) : ml;
         ff_total += resolved ? ff_run : 0u;
@@ -972,23 +934,18 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
         hipLaunchKernelGGL((pml_kernel<M, V, C>), grid, block, dyn_lds, stream, ix, d_bases, d_offsets,     \
                            n_reads, d_out, d_err, d_stats, d_order, cls);                                   \
     } while (0)
-#define MOVI_LAUNCH_FLATW(M, C)                                                                             \
+#define MOVI_LAUNCH_FLATP_S(M, C, S)                                                                        \
     do {                                                                                                    \
         if (ix.r < 0xFFFFFFFFull)                                                                           \
-            hipLaunchKernelGGL((pml_kernel_flatw<M, uint32_t, 2, 0, C>), grid, block, dyn_lds, stream, ix,  \
+            hipLaunchKernelGGL((pml_kernel_flatp<M, uint32_t, 2, C, S>), grid, block, dyn_lds, stream, ix,  \
                                d_bases, d_offsets, n_reads, d_out, d_err, d_stats, d_order, cls);           \
         else                                                                                                \
-            hipLaunchKernelGGL((pml_kernel_flatw<M, uint64_t, 2, 0, C>), grid, block, dyn_lds, stream, ix,  \
+            hipLaunchKernelGGL((pml_kernel_flatp<M, uint64_t, 2, C, S>), grid, block, dyn_lds, stream, ix,  \
                                d_bases, d_offsets, n_reads, d_out, d_err, d_stats, d_order, cls);           \
     } while (0)
-#define MOVI_LAUNCH_FLATP(M, HA, P, C)                                                                      \
+#define MOVI_LAUNCH_FLATP(M, C)                                                                             \
     do {                                                                                                    \
-        if (ix.r < 0xFFFFFFFFull)                                                                           \
-            hipLaunchKernelGGL((pml_kernel_flatp<M, uint32_t, HA, P, C>), grid, block, dyn_lds, stream, ix, \
-                               d_bases, d_offsets, n_reads, d_out, d_err, d_stats, d_order, cls);           \
-        else                                                                                                \
-            hipLaunchKernelGGL((pml_kernel_flatp<M, uint64_t, HA, P, C>), grid, block, dyn_lds, stream, ix, \
-                               d_bases, d_offsets, n_reads, d_out, d_err, d_stats, d_order, cls);           \
+        if (ix.sep) MOVI_LAUNCH_FLATP_S(M, C, 1); else MOVI_LAUNCH_FLATP_S(M, C, 0);                        \
     } while (0)
 #define MOVI_LAUNCH_FLAT(M)                                                                                 \
     do {                                                                                                    \
@@ -1004,31 +961,31 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
         if (cm == 0) LAUNCH(__VA_ARGS__, 0); else if (cm == 1) LAUNCH(__VA_ARGS__, 1); else LAUNCH(__VA_ARGS__, 2); \
     } while (0)
     // Variants: 0 first correct kernel, 1 base-synchronous packed I/O, 7 flat lane state machine,
-    // 8 = 7 + aligned 4-row window.  (2-6 were experiments -- branchy state machine, 2/4-row neighbour
-    // windows -- measured slower and removed; numbers in DESIGN.md section 3.)
+    // 10 = 7 + row window + software pipelining.  (2-6, 8, 9, 11, 12 were experiments -- branchy state machine,
+    // 2/4-row neighbour windows, the unpipelined window kernel, other hop counts -- measured slower and
+    // removed; numbers in DESIGN.md section 3.)
     // Auto selection (measured on MI355X, profiles/): with plenty of reads (> ~12 waves per CU)
-    // variant 1 wins because its neighbour loads follow the gather at once and hit L2; with few
-    // reads in flight (long-read batches, small shards) the lane state machine wins because it
-    // needs ~1.5-2.3 instead of ~11 dependent trips per base.
+    // variant 1 wins because its neighbour loads follow the gather at once and hit L2 (400 k x 150 bp: 43.2 vs
+    // 37.4 Gbases/s); with few reads in flight (long-read batches, small shards) the lane state machine wins
+    // because it needs ~1.5-2.3 instead of ~11 dependent trips per base (200 k x 150 bp: 33.8 vs 32.4).
     int v = cfg.pml_variant;
     if (v < 0) v = (n_reads <= (uint64_t)cfg.num_cus * 64u * 12u) ? 10 : 1;  // measured crossover: ~12 waves per CU
-    if (v >= 9 && ix.r < 8) v = 7;                                           // the clamped window needs >= 4 rows
-    if (cm != 0 && (v == 0 || v == 7 || v == 9 || v == 11 || v == 12)) v = (v == 0) ? 1 : 10;   // the A/B kernels carry no fused bins
-    if (mode == 6) {
+    if (v == 10 && ix.r < 8) v = 7;                                          // the clamped window needs >= 4 rows
+    if (cm != 0 && (v == 0 || v == 7)) v = (v == 0) ? 1 : (ix.r < 8 ? 1 : 10);   // the A/B kernels carry no fused bins
+    if (mode == 7) {
+        // sampled-thresholds: 3-byte rows, ids from the checkpoints -- the base-synchronous kernel only
+        MOVI_BY_CLS(MOVI_LAUNCH_PML, 7, 1);
+    } else if (mode == 6) {
         if (v == 0) MOVI_LAUNCH_PML(6, 0, 0); else if (v == 1) MOVI_BY_CLS(MOVI_LAUNCH_PML, 6, 1);
-        else if (v == 7) MOVI_LAUNCH_FLAT(6); else if (v == 9) MOVI_LAUNCH_FLATP(6, 2, 0, 0);
-        else if (v == 10) MOVI_BY_CLS(MOVI_LAUNCH_FLATP, 6, 2, 1); else if (v == 11) MOVI_LAUNCH_FLATP(6, 1, 1, 0);
-        else if (v == 12) MOVI_LAUNCH_FLATP(6, 3, 1, 0); else MOVI_BY_CLS(MOVI_LAUNCH_FLATW, 6);
+        else if (v == 7) MOVI_LAUNCH_FLAT(6); else MOVI_BY_CLS(MOVI_LAUNCH_FLATP, 6);
     } else {
         if (v == 0) MOVI_LAUNCH_PML(8, 0, 0); else if (v == 1) MOVI_BY_CLS(MOVI_LAUNCH_PML, 8, 1);
-        else if (v == 7) MOVI_LAUNCH_FLAT(8); else if (v == 9) MOVI_LAUNCH_FLATP(8, 2, 0, 0);
-        else if (v == 10) MOVI_BY_CLS(MOVI_LAUNCH_FLATP, 8, 2, 1); else if (v == 11) MOVI_LAUNCH_FLATP(8, 1, 1, 0);
-        else if (v == 12) MOVI_LAUNCH_FLATP(8, 3, 1, 0); else MOVI_BY_CLS(MOVI_LAUNCH_FLATW, 8);
+        else if (v == 7) MOVI_LAUNCH_FLAT(8); else MOVI_BY_CLS(MOVI_LAUNCH_FLATP, 8);
     }
 #undef MOVI_LAUNCH_PML
 #undef MOVI_LAUNCH_FLAT
-#undef MOVI_LAUNCH_FLATW
 #undef MOVI_LAUNCH_FLATP
+#undef MOVI_LAUNCH_FLATP_S
 #undef MOVI_BY_CLS
     return hipGetLastError();
 }
@@ -1056,8 +1013,8 @@ __global__ __launch_bounds__(256) void count_kernel_v0(DevIndex ix, const uint8_
     // (4 x n_blocks x 4 B = 15 kB for 1 B rows) so that get_id costs no extra global load
     __shared__ uint32_t s_idb[MODE == 8 ? kIdbLdsEntries : 1];
     const uint32_t *idb = nullptr;
-    if (MODE == 8 && ix.n_blocks * 4 <= (uint64_t)kIdbLdsEntries) {
-        for (uint32_t i = threadIdx.x; i < (uint32_t)ix.n_blocks * 4; i += blockDim.x) s_idb[i] = ix.id_blocks[i];
+    if (MODE == 8 && ix.n_blocks * ix.sigma <= (uint64_t)kIdbLdsEntries) {
+        for (uint32_t i = threadIdx.x; i < (uint32_t)ix.n_blocks * ix.sigma; i += blockDim.x) s_idb[i] = ix.id_blocks[i];
         idb = s_idb;
     }
     __syncthreads();
@@ -1171,7 +1128,10 @@ hipError_t launch_count(int mode, const DevIndex &ix, const uint8_t *d_bases, co
     const uint64_t blocks = (n_reads + bt - 1) / bt;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     dim3 grid((unsigned)blocks), block((unsigned)bt);
-    if (mode == 6)
+    if (mode == 7)
+        hipLaunchKernelGGL(count_kernel_v0<7>, grid, block, 0, stream, ix, d_bases, d_offsets, n_reads,
+                           d_matched, d_count, d_err, d_stats, d_order);
+    else if (mode == 6)
         hipLaunchKernelGGL(count_kernel_v0<6>, grid, block, 0, stream, ix, d_bases, d_offsets, n_reads,
                            d_matched, d_count, d_err, d_stats, d_order);
     else
@@ -1201,8 +1161,8 @@ __global__ __launch_bounds__(256) void zml_kernel(DevIndex ix, const uint8_t *__
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = ix.code_of[i];
     __shared__ uint32_t s_idb[MODE == 8 ? kIdbLdsEntries : 1];
     const uint32_t *idb = nullptr;
-    if (MODE == 8 && ix.n_blocks * 4 <= (uint64_t)kIdbLdsEntries) {
-        for (uint32_t i = threadIdx.x; i < (uint32_t)ix.n_blocks * 4; i += blockDim.x) s_idb[i] = ix.id_blocks[i];
+    if (MODE == 8 && ix.n_blocks * ix.sigma <= (uint64_t)kIdbLdsEntries) {
+        for (uint32_t i = threadIdx.x; i < (uint32_t)ix.n_blocks * ix.sigma; i += blockDim.x) s_idb[i] = ix.id_blocks[i];
         idb = s_idb;
     }
     __syncthreads();
@@ -1330,7 +1290,10 @@ hipError_t launch_zml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     const uint64_t blocks = (n_reads + bt - 1) / bt;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     dim3 grid((unsigned)blocks), block((unsigned)bt);
-    if (mode == 6)
+    if (mode == 7)
+        hipLaunchKernelGGL(zml_kernel<7>, grid, block, 0, stream, ix, d_bases, d_offsets, n_reads, d_out, d_err,
+                           d_stats, d_order);
+    else if (mode == 6)
         hipLaunchKernelGGL(zml_kernel<6>, grid, block, 0, stream, ix, d_bases, d_offsets, n_reads, d_out, d_err,
                            d_stats, d_order);
     else
@@ -1421,7 +1384,9 @@ hipError_t build_row_start_ckpt(int mode, const uint8_t *d_rows, uint64_t r, uin
     if (e != hipSuccess) { (void)hipFree(d_sums); return e; }
     const unsigned bt = 256;
     const unsigned blocks = (unsigned)((n_chunks + bt - 1) / bt);
-    if (mode == 6)
+    if (mode == 7)
+        hipLaunchKernelGGL(chunk_sum_kernel<7>, dim3(blocks), dim3(bt), 0, stream, d_rows, r, n_chunks, d_sums);
+    else if (mode == 6)
         hipLaunchKernelGGL(chunk_sum_kernel<6>, dim3(blocks), dim3(bt), 0, stream, d_rows, r, n_chunks, d_sums);
     else
         hipLaunchKernelGGL(chunk_sum_kernel<8>, dim3(blocks), dim3(bt), 0, stream, d_rows, r, n_chunks, d_sums);

@@ -12,16 +12,28 @@ constexpr int kPrefixShift = 5;   // one BWT-position checkpoint every 32 rows (
 struct DevIndex {
     const uint8_t *rows;          // r * row_bytes, packed exactly as in index.movi
     const uint32_t *id_blocks;    // mode 8: [alphabet][n_blocks]
-    const uint8_t *code_of;       // 256 bytes: ASCII -> code 0..3, 0xFF = illegal
+    const uint8_t *code_of;       // 256 bytes: ASCII -> code 0..3 (1..4 with separators), 0xFF = illegal
     const uint64_t *row_start_ckpt; // BWT position of row 32*j (count path), r/32+1 entries
     uint64_t r;
     uint64_t end_bwt_idx;
     uint64_t n_blocks;
     uint64_t block_size;
     uint32_t block_shift;         // log2(block_size) when it is a power of two (always, in practice), else 0xFFFFFFFF
-    uint32_t pad_;
-    uint64_t end_thr[4];
-    uint64_t first_runs[5], first_offsets[5], last_runs[5], last_offsets[5];
+    uint32_t sigma;               // alphabet size: 4 (ACGT; fewer for reduced test alphabets) or 5 ('%' + ACGT)
+    uint64_t end_thr[4];          // end_bwt_idx_thresholds, by DNA character
+    uint64_t first_runs[6], first_offsets[6], last_runs[6], last_offsets[6];
+    // `movi build --separators` indexes (MoveStructure::use_separator, src/move_structure.cpp:547-552): code 0 is
+    // the separator '%', DNA codes are 1..4, and the rows OF the separator keep explicit thresholds in a side
+    // table (separators_thresholds[separators_thresholds_map[idx]], src/move_structure_query.cpp:540-541) --
+    // here sorted by row: sep_rows[k] <-> sep_vals[k] = 4 x u16 packed as (v0 | v1 << 16, v2 | v3 << 16)
+    uint32_t sep;                 // 0 / 1
+    uint32_t n_sep;
+    const uint64_t *sep_rows;
+    const uint2 *sep_vals;
+    // sampled-thresholds (mode 7): tally_ids[character][checkpoint], widened from the file's 40-bit entries
+    const uint64_t *tally;
+    uint64_t tally_len;
+    uint64_t tally_cp;            // rows between checkpoints (movi build --checkpoint, default 20)
 };
 
 // Device counters of one query call.
@@ -35,7 +47,7 @@ struct DevStats {
 struct LaunchCfg {
     int block_threads = 256;
     // -1 auto; 0 first kernel (plain I/O), 1 base-synchronous packed I/O, 7 flat lane state machine,
-    // 8 flat lane state machine + aligned row window
+    // 10 flat lane state machine + row window, software-pipelined
     int pml_variant = -1;
     int num_cus = 256;
     int waves_per_cu = 0;  // 0 = no cap; else cap resident waves per CU by padding the block's LDS allocation

@@ -30,7 +30,8 @@ Reference code restated (file:line relative to /root/reference):
 import numpy as np
 
 MOVI_MAGIC = 0x4D4F5649          # include/utils.hpp:29
-MAX_RUN = {6: 2047, 8: 1023}     # include/move_row_configs.hpp:51,101
+MAX_RUN = {6: 2047, 8: 1023, 7: 511}   # include/move_row_configs.hpp:51,101,135
+TALLY_CHECKPOINTS = 20           # include/movi_options.hpp:257 (movi build --checkpoint default)
 BLOCK_SIZE = 1 << 20             # include/move_row_configs.hpp:102
 MAX_ALLOWED_BLOCKED_ID = (1 << 22) - 1   # :103
 
@@ -156,7 +157,7 @@ def bwt_and_thresholds(t):
 def build_rows(bwt, thr, mode):
     """Everything MoveStructure::build() derives from ref.bwt + ref.thr_pos.
     Returns a dict of the fields serialize() writes."""
-    assert mode in (6, 8)
+    assert mode in (6, 7, 8)
     n = len(bwt)
     maxrun = MAX_RUN[mode]
     # --- detect_move_row_boundaries (:328-396) + fill_bits_by_thresholds (:733-746)
@@ -273,7 +274,31 @@ def build_rows(bwt, thr, mode):
                sep=sep, sep_thr=sep_thr, sep_map=sep_map)
     if mode == 8:
         out.update(compute_blocked_ids(pp_id, code, end_bwt_idx, first_runs, sigma))
+    if mode == 7:
+        out.update(compute_tally_ids(pp_id, code, end_bwt_idx, sigma))
     return out
+
+
+def compute_tally_ids(pp_id, code, end_bwt_idx, sigma, checkpoints=TALLY_CHECKPOINTS):
+    """Sampled ("tally") modes keep no id in the row: src/move_structure_build.cpp:486-496, :571-596, :677-682.
+    Every `checkpoints` rows the destination id of the latest run of EACH character seen so far is stored
+    (for the checkpoint row's own character that is the row itself); a character not seen yet gets the id
+    of its first run once that shows up; one extra last entry holds the final ids."""
+    r = len(pp_id)
+    n_ck = r // checkpoints + 2
+    tally = np.zeros((sigma, n_ck), np.int64)
+    cur = [r] * sigma
+    ids, cl = pp_id.tolist(), code.tolist()
+    for i in range(r):
+        if i != end_bwt_idx:
+            a = cl[i]
+            if cur[a] == r:
+                tally[a, : i // checkpoints + 1] = ids[i]
+            cur[a] = ids[i]
+        if i % checkpoints == 0:
+            tally[:, i // checkpoints] = cur
+    tally[:, n_ck - 1] = cur
+    return dict(tally_ids=tally, tally_checkpoints=checkpoints)
 
 
 def compute_blocked_ids(raw_ids, code, end_bwt_idx, first_runs, sigma):
@@ -318,6 +343,14 @@ def encode_rows(f):
         rows[:, 1] = (pid >> 16) & 0xFFFF
         rows[:, 2] = n | (t[:, 1] << 11) | (t[:, 2] << 12) | (c << 13)
         rows[:, 3] = off | (t[:, 0] << 11) | ((pid >> 32) << 12)
+    elif mode == 7:
+        # include/move_row.hpp:122-127 + move_row_configs.hpp:120-136: u8 n | u8 offset | u8 c with
+        # bit0 = offset bit 8, bit1 = n bit 8, bits 2-4 = character, bits 5-7 = threshold bits 0-2
+        rows = np.zeros((r, 3), np.uint8)
+        rows[:, 0] = n & 0xFF
+        rows[:, 1] = off & 0xFF
+        rows[:, 2] = (off >> 8) | ((n >> 8) << 1) | (c << 2) | (t[:, 0] << 5) | (t[:, 1] << 6) | (t[:, 2] << 7)
+        return rows.tobytes()
     else:
         rows = np.zeros((r, 3), np.uint16)
         bid = f["blocked_id"]
@@ -338,8 +371,16 @@ def serialize(f):
     out = [bytes(hdr), u64(f["end_thr"]), u64([0] * 4), u64([0] * 4),
            u64([256]), u64(f["alphamap"]), u64([len(f["alphabet"])]), f["alphabet"],
            b"\x00\x00", b"\x00",                       # u16 nt_splitting, bool constant
-           encode_rows(f),
-           u64([0]), u64([0]), u64([0]),               # overflow tables (empty)
+           encode_rows(f)]
+    if f["mode"] == 7:
+        # write_tally_table, src/move_structure_io.cpp:328-336: u32 checkpoints | u64 len | per character len x MoveTally
+        # (40-bit id: u32 low | u8 high, include/move_row.hpp:13-40)
+        tl = f["tally_ids"]
+        packed = np.zeros(tl.shape + (5,), np.uint8)
+        for b in range(5):
+            packed[..., b] = (tl >> (8 * b)) & 0xFF
+        out += [np.uint32(f["tally_checkpoints"]).tobytes(), u64([tl.shape[1]]), packed.tobytes()]
+    out += [u64([0]), u64([0]), u64([0]),               # overflow tables (empty)
            u64([len(f["counts"])]), u64(f["counts"]),
            u64([len(f["last_runs"])]), u64(f["last_runs"]), u64(f["last_offsets"]),
            u64(f["first_runs"]), u64(f["first_offsets"])]

@@ -48,6 +48,10 @@ typedef struct {
     uint64_t nblocks;              /* mode 8 only                                 */
     uint32_t *id_blocks;           /* [alphabet_size][nblocks]                    */
     uint64_t block_size;
+    /* sampled ("tally") mode 7: ids kept only every tally_checkpoints rows, move_structure.hpp:361-363 */
+    uint32_t tally_checkpoints;
+    uint64_t tally_len;
+    uint8_t *tally_ids;            /* [alphabet_size][tally_len] x 5-byte MoveTally (move_row.hpp:13-40) */
     /* separators (movi build --separators): alphabet = '%' + ACGT; explicit thresholds of the
      * separator rows, move_structure.hpp:344-346, file layout move_structure_io.cpp:399-433 */
     int      sep;                  /* MoveStructure::use_separator, move_structure.cpp:547-552 */
@@ -85,8 +89,8 @@ oracle_index *oracle_open(const uint8_t *buf, size_t n) {
     uint32_t magic; memcpy(&magic, hdr, 4);
     if (magic != 0x4D4F5649u) goto bad;                 /* MOVI_MAGIC utils.hpp:29 */
     ix->mode = hdr[7];
-    if (ix->mode != 6 && ix->mode != 8) goto bad;
-    ix->row_bytes = ix->mode == 6 ? 8 : 6;
+    if (ix->mode != 6 && ix->mode != 8 && ix->mode != 7) goto bad;
+    ix->row_bytes = ix->mode == 6 ? 8 : (ix->mode == 8 ? 6 : 3);            /* MoveRow::row_size, move_row.hpp:104-120 */
     memcpy(&ix->length, hdr + 16, 8);
     memcpy(&ix->r, hdr + 24, 8);
     memcpy(&ix->original_r, hdr + 32, 8);
@@ -103,6 +107,13 @@ oracle_index *oracle_open(const uint8_t *buf, size_t n) {
     if (rd(buf, n, &p, flags, 3)) goto bad;
     ix->rows = (uint8_t *)malloc(ix->r * ix->row_bytes + 16);
     if (!ix->rows || rd(buf, n, &p, ix->rows, ix->r * ix->row_bytes)) goto bad;
+    if (ix->mode == 7) {                                /* read_tally_table, io.cpp:338-349 */
+        if (rd(buf, n, &p, &ix->tally_checkpoints, 4) || ix->tally_checkpoints == 0) goto bad;
+        if (rd(buf, n, &p, &ix->tally_len, 8) || ix->tally_len > (n - p) / 5) goto bad;
+        size_t bytes = ix->alphabet_size * ix->tally_len * 5;
+        ix->tally_ids = (uint8_t *)malloc(bytes + 8);
+        if (!ix->tally_ids || rd(buf, n, &p, ix->tally_ids, bytes)) goto bad;
+    }
     for (int t = 0; t < 3; t++) {                       /* overflow tables: empty  */
         uint64_t sz;
         if (rd(buf, n, &p, &sz, 8)) goto bad;
@@ -153,13 +164,13 @@ oracle_index *oracle_open(const uint8_t *buf, size_t n) {
     }
     return ix;
 bad:
-    if (ix) { free(ix->rows); free(ix->id_blocks); free(ix->sep_rows); free(ix->sep_vals); free(ix); }
+    if (ix) { free(ix->rows); free(ix->id_blocks); free(ix->tally_ids); free(ix->sep_rows); free(ix->sep_vals); free(ix); }
     return NULL;
 }
 
 void oracle_close(oracle_index *ix) {
     if (!ix) return;
-    free(ix->rows); free(ix->id_blocks); free(ix->sep_rows); free(ix->sep_vals); free(ix);
+    free(ix->rows); free(ix->id_blocks); free(ix->tally_ids); free(ix->sep_rows); free(ix->sep_vals); free(ix);
 }
 
 uint64_t oracle_r(const oracle_index *ix) { return ix->r; }
@@ -175,21 +186,31 @@ static inline void row16(const oracle_index *ix, uint64_t i, uint16_t w[4]) {
 
 /* MoveRow::get_n, include/move_row.hpp:245-248 (mode 6, 11 bits) / :287-290 (mode 8, 10 bits) */
 static inline uint64_t get_n(const oracle_index *ix, uint64_t i) {
+    if (ix->mode == 7) {                                /* tally rows, move_row.hpp:209-212: n | (c bit 1) << 8 */
+        const uint8_t *b = ix->rows + i * 3;
+        return (uint64_t)b[0] | ((uint64_t)((b[2] >> 1) & 1) << 8);
+    }
     uint16_t w[4]; row16(ix, i, w);
     return ix->mode == 6 ? (w[2] & 0x7FF) : (w[1] & 0x3FF);
 }
 /* MoveRow::get_offset, move_row.hpp:250-253 / :292-295 */
 static inline uint64_t get_offset(const oracle_index *ix, uint64_t i) {
+    if (ix->mode == 7) {                                /* move_row.hpp:214-217: offset | (c bit 0) << 8 */
+        const uint8_t *b = ix->rows + i * 3;
+        return (uint64_t)b[1] | ((uint64_t)(b[2] & 1) << 8);
+    }
     uint16_t w[4]; row16(ix, i, w);
     return ix->mode == 6 ? (w[3] & 0x7FF) : (w[2] & 0x3FF);
 }
 /* MoveRow::get_c, move_row.hpp:255-257 (n >> 13) / :297-299 ((offset >> 10) & 7) */
 static inline uint32_t get_c(const oracle_index *ix, uint64_t i) {
+    if (ix->mode == 7) return (ix->rows[i * 3 + 2] >> 2) & 7;          /* move_row.hpp:219-221, SHIFT_C 2 */
     uint16_t w[4]; row16(ix, i, w);
     return ix->mode == 6 ? (uint32_t)(w[2] >> 13) : (uint32_t)((w[2] >> 10) & 7);
 }
 /* MoveRow::get_threshold, move_row.hpp:304-317 (mode 6) / :319-332 (mode 8) */
 static inline uint32_t get_threshold_bit(const oracle_index *ix, uint64_t i, uint32_t k) {
+    if (ix->mode == 7) return (ix->rows[i * 3 + 2] >> (5 + k)) & 1;    /* move_row.hpp:334-347 */
     uint16_t w[4]; row16(ix, i, w);
     if (ix->mode == 6) {
         switch (k) {
@@ -200,9 +221,53 @@ static inline uint32_t get_threshold_bit(const oracle_index *ix, uint64_t i, uin
     }
     return (w[2] >> (13 + k)) & 1;
 }
+/* MoveStructure::get_char, src/move_structure.cpp:288-293 */
+static inline int get_char(const oracle_index *ix, uint64_t i) {
+    if (i == ix->end_bwt_idx) return '$';
+    return ix->alphabet[get_c(ix, i)];
+}
+/* MoveTally::get, include/move_row.hpp:28-38 */
+static inline uint64_t tally_get(const oracle_index *ix, uint32_t c, uint64_t k) {
+    const uint8_t *b = ix->tally_ids + ((uint64_t)c * ix->tally_len + k) * 5;
+    uint32_t right; memcpy(&right, b, 4);
+    return (uint64_t)right | ((uint64_t)b[4] << 32);
+}
+/* MoveStructure::get_id for the sampled modes, src/move_structure.cpp:104-283 (the forward branch: the
+ * reference fixes forward_direciton = true, :146).  The id of row idx is recovered from the id stored at the
+ * next checkpoint for idx's character: count the BWT positions of that character between idx and that
+ * stored run, then walk the destination rows backwards by that many positions. */
+static uint64_t get_id_tally(const oracle_index *ix, uint64_t idx) {
+    if (idx == ix->end_bwt_idx) return 0;                              /* :106-108 */
+    uint32_t ci = get_c(ix, idx);
+    uint64_t cp = ix->tally_checkpoints, ta = idx / cp;
+    if (idx == ix->r - 1) return tally_get(ix, ci, ix->tally_len - 1); /* :114-117 */
+    if (idx % cp == 0) return tally_get(ix, ci, ta);                   /* :121-124 */
+    uint64_t tb = ta + 1, next_cp = tb * cp;
+    if (next_cp >= ix->r) next_cp = ix->r - 1;                         /* :137-139 */
+    uint64_t id = tally_get(ix, ci, tb), rows_until = 0, last_id = ix->r;
+    for (uint64_t i = idx; i < next_cp; i++)                           /* :168-174 */
+        if (get_char(ix, i) == get_char(ix, idx)) { rows_until += get_n(ix, i); last_id = i; }
+    if (last_id == idx && get_char(ix, idx) != get_char(ix, next_cp)) return id;   /* :178-180 */
+    if (last_id == ix->r) return ix->r;                                /* :181-183 throws */
+    uint64_t offset = get_offset(ix, next_cp);
+    if (get_char(ix, idx) != get_char(ix, next_cp)) {                  /* :194-197 */
+        rows_until -= get_n(ix, last_id);
+        offset = get_offset(ix, last_id);
+    }
+    if (id >= ix->r || offset >= get_n(ix, id)) return ix->r;          /* :200-203 throws */
+    if (offset >= rows_until) return id;                               /* :204-209 */
+    rows_until -= offset + 1;
+    id -= 1;
+    while (rows_until != 0) {                                          /* :211-219 */
+        if (rows_until >= get_n(ix, id)) { rows_until -= get_n(ix, id); id -= 1; }
+        else rows_until = 0;
+    }
+    return id;
+}
 /* MoveStructure::get_id, src/move_structure.cpp:91-102 with MoveRow::get_id
  * move_row.hpp:232-243 (mode 6: id32 | (offset>>12)<<32) / :267-285 (mode 8: id16 | (n>>10)<<16) */
 static inline uint64_t get_id(const oracle_index *ix, uint64_t i) {
+    if (ix->mode == 7) return get_id_tally(ix, i);
     uint16_t w[4]; row16(ix, i, w);
     if (ix->mode == 6) {
         uint64_t id = (uint64_t)w[0] | ((uint64_t)w[1] << 16);
@@ -216,11 +281,6 @@ static inline uint64_t get_id(const oracle_index *ix, uint64_t i) {
 /* MoveStructure::get_thresholds, src/move_structure.cpp:305-309 */
 static inline uint64_t get_thresholds(const oracle_index *ix, uint64_t i, uint32_t k) {
     return get_threshold_bit(ix, i, k) == 0 ? 0 : get_n(ix, i);
-}
-/* MoveStructure::get_char, src/move_structure.cpp:288-293 */
-static inline int get_char(const oracle_index *ix, uint64_t i) {
-    if (i == ix->end_bwt_idx) return '$';
-    return ix->alphabet[get_c(ix, i)];
 }
 /* MoveStructure::check_alphabet, src/move_structure.cpp:383-397 with
  * ignore_illegal_chars == 0.  Bytes >= 128 index out of the

@@ -83,3 +83,46 @@ def test_product_does_not_touch_oracle():
     for f in ("synth.py", "synth.c"):            # the generator feeds the measured path too
         code = open(os.path.join(ROOT, "tools", f)).read()
         assert not re.search(r"^\s*(from|import)\s+oracle|#include.*oracle|libmovi_oracle", code, re.M), f
+
+
+def test_parse_separators_index(built_lib):
+    """A `movi build --separators` image ('%' + ACGT, reference KAT size 948232 B, tests/test_build.cpp:79):
+    parsed, '%' illegal in reads, the two separator tables located; other 5-symbol alphabets rejected."""
+    import movi_amd
+    from conftest import GOLDEN
+    from oracle import build_index as B
+    ref = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))[0][1]
+    for mode, size in ((6, 948232), (8, 711854)):
+        img = B.build_index_from_seqs([ref], mode, separators=True)
+        assert len(img) == size
+        desc, c, off, nbytes = movi_amd.parse_index_image(img)
+        assert desc.alphabet == b"%ACGT" and desc.alphabet_size == 5 and desc.r == 118207
+        code = np.frombuffer(desc.code_of, np.uint8)
+        assert [int(code[x]) for x in b"ACGT"] == [1, 2, 3, 4] and code[ord("%")] == 0xFF
+        assert (int(c.n_separator_thresholds), int(c.n_separator_map)) == (3, 3)
+        assert len(desc.first_runs) == 6
+        o = Oracle(img)
+        assert (o.r, o.end_bwt_idx) == (desc.r, desc.end_bwt_idx)
+        with pytest.raises(movi_amd.MoviError):
+            movi_amd.parse_index_image(img[:-8])                     # truncated separator map
+    bad = bytearray(B.build_index_from_seqs([ref], 6, separators=True))
+    at = bad.index(b"%ACGT")
+    bad[at] = ord("#")
+    with pytest.raises(movi_amd.MoviError) as e:
+        movi_amd.parse_index_image(bytes(bad))
+    assert "separator" in str(e.value)
+
+
+def test_parse_sampled_thresholds_index(built_lib):
+    """Mode 7 (reference KAT 475326 B, tests/test_build.cpp:45-47): 3-byte rows, the tally table located."""
+    import movi_amd
+    from conftest import GOLDEN
+    from oracle import build_index as B
+    ref = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))[0][1]
+    img = B.build_index_from_seqs([ref], 7)
+    assert len(img) == 475326
+    desc, c, off, nbytes = movi_amd.parse_index_image(img)
+    assert (desc.mode, desc.r, desc.row_bytes, nbytes) == (7, 118209, 3, 118209 * 3)
+    assert int(c.tally_checkpoints) == 20 and int(c.n_tally) == 118209 // 20 + 2
+    with pytest.raises(movi_amd.MoviError):
+        movi_amd.parse_index_image(img[: off + nbytes + 100])           # truncated tally table

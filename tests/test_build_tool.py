@@ -49,6 +49,39 @@ def test_matches_numpy_constructor_on_random_multi_record_fasta(tool, tmp_path):
         assert open(os.path.join(out, "index.movi"), "rb").read() == B.build_index_from_seqs(seqs, mode)
 
 
+# tests/test_build.cpp:79 and :95 of the reference: `movi build --separators` index sizes
+@pytest.mark.parametrize("mode,size", [(6, 948232), (8, 711854)])
+def test_separators_known_answers_and_numpy_agreement(tool, tmp_path, mode, size):
+    from oracle import build_index as B
+    out = str(tmp_path / "sep")
+    subprocess.check_call([tool, "fasta", os.path.join(GOLDEN, "ref.fasta"), str(mode), out, "separators"], stderr=subprocess.DEVNULL)
+    img = open(os.path.join(out, "index.movi"), "rb").read()
+    assert len(img) == size
+    ref = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))[0][1]
+    assert img == B.build_index_from_seqs([ref], mode, separators=True)
+    # many records: many rows of the separator
+    rng = np.random.default_rng(9 + mode)
+    seqs = [bytes(rng.choice(list(b"ACGT"), size=int(rng.integers(1, 300))).astype(np.uint8)) for _ in range(40)]
+    fa = tmp_path / "many.fa"
+    fa.write_bytes(b"".join(b">r%d\n%s\n" % (i, s) for i, s in enumerate(seqs)))
+    out2 = str(tmp_path / "sep2")
+    subprocess.check_call([tool, "fasta", str(fa), str(mode), out2, "separators"], stderr=subprocess.DEVNULL)
+    assert open(os.path.join(out2, "index.movi"), "rb").read() == B.build_index_from_seqs(seqs, mode, separators=True)
+
+
+# tests/test_build.cpp:45-47 and :86-88 of the reference: sampled-thresholds index sizes
+@pytest.mark.parametrize("separators,size", [(False, 475326), (True, 505009)])
+def test_sampled_thresholds_known_answers_and_numpy_agreement(tool, tmp_path, separators, size):
+    from oracle import build_index as B
+    out = str(tmp_path / "m7")
+    subprocess.check_call([tool, "fasta", os.path.join(GOLDEN, "ref.fasta"), "7", out] + (["separators"] if separators else []),
+                          stderr=subprocess.DEVNULL)
+    img = open(os.path.join(out, "index.movi"), "rb").read()
+    assert len(img) == size
+    ref = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))[0][1]
+    assert img == B.build_index_from_seqs([ref], 7, separators=separators)
+
+
 def test_pangenome_mode_is_queryable(tool, tmp_path):
     """Synthetic pangenome: substrings of the text are found end to end by the oracle's count query."""
     from oracle.oracle import Oracle

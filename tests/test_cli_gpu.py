@@ -292,3 +292,35 @@ def test_multi_gpu_sharding_path(movi_bin, tmp_path):
         many = run(["query", "-i", IDX[8], "-r", reads_path, "--gpus", "3"] + extra, env=env)
         assert one.returncode == 0 and many.returncode == 0, many.stderr
         assert one.stdout == many.stdout and len(one.stdout) > 1000
+
+
+@pytest.mark.parametrize("mode", [6, 8])
+def test_separators_index_through_the_cli(movi_bin, tmp_path, mode):
+    """`movi query` on a `movi build --separators` index (reference KAT sizes tests/test_build.cpp:79,95):
+    --pml --stdout and --count lines against the oracle; '%' in a read is an illegal character."""
+    from oracle import build_index as B
+    from oracle.oracle import Oracle
+    ref = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))[0][1]
+    img = B.build_index_from_seqs([ref], mode, separators=True)
+    d = tmp_path / "sep_index"
+    d.mkdir()
+    (d / "index.movi").write_bytes(img)
+    cpu = Oracle(img)
+    rng = np.random.default_rng(55 + mode)
+    reads_path = str(tmp_path / "mixed.fa")
+    recs = write_mixed_reads(reads_path, rng, ref, n=120)
+    with open(reads_path, "ab") as f:
+        f.write(b">withsep\nACGTAC%GTACGT\n")
+    recs.append((b"withsep", b"ACGTAC%GTACGT"))
+    r = run(["query", "--index", str(d), "--read", reads_path, "--pml", "--no-prefetch", "-t1", "--stdout"])
+    assert r.returncode == 0, r.stderr
+    assert b"regular-thresholds" in r.stderr or b"blocked-thresholds" in r.stderr
+    exp = b"".join(b">" + rid + b"\n" + stdout_line(cpu.pml(seq)).encode() + b"\n" for rid, seq in recs)
+    assert r.stdout == exp
+    r = run(["query", "--index", str(d), "--read", reads_path, "--count", "--no-prefetch", "-t1", "--stdout"])
+    assert r.returncode == 0, r.stderr
+    exp = b""
+    for rid, seq in recs:
+        m, c = cpu.count(seq)
+        exp += rid + b"\t%d/%d\t%d\n" % (m, len(seq), c)
+    assert r.stdout == exp

@@ -85,7 +85,7 @@ def test_pml_ragged_reads_vs_oracle(engines, mode):
 
 
 @pytest.mark.parametrize("mode", [6, 8])
-@pytest.mark.parametrize("variant", [0, 1, 7, 8, 9, 10, 11, 12])
+@pytest.mark.parametrize("variant", [0, 1, 7, 10])
 def test_pml_kernel_variants_vs_oracle(engines, mode, variant):
     """Every selectable kernel variant is held to the same bit-exact bar, including
     reads whose length is not a multiple of the 8-step packing and unaligned offsets."""
@@ -378,7 +378,7 @@ def test_classification_bins_on_device(engines, bin_width, thr):
 
 
 @pytest.mark.parametrize("mode", [6, 8])
-@pytest.mark.parametrize("variant", [1, 8, 10])
+@pytest.mark.parametrize("variant", [1, 10])
 def test_fused_classification_kernels(engines, mode, variant):
     """movi_pml_classify_device: the bins fused into the PML walk, with and without the PML vector, in both
     shipped kernels, against the bins of the oracle's PML vectors and against the standalone
@@ -473,7 +473,7 @@ def test_fuzz_small_indexes(built_lib, tmp_path, alphabet):
             subprocess.check_call([tool, "fasta", str(fa), str(mode), out_dir], stderr=subprocess.DEVNULL)
             img = open(os.path.join(out_dir, "index.movi"), "rb").read()
             gpu, cpu = movi_amd.MoveIndex.from_image(img), Oracle(img)
-            for variant in (1, 7, 8, 9, 10):
+            for variant in (1, 7, 10):
                 gpu.set_option("pml_variant", variant)
                 out, st = gpu.query_pml_packed(bases, offs)
                 exp, ff, sc = cpu.pml_batch(bases, offs, threads=2)
@@ -506,7 +506,7 @@ def test_real_bwt_pangenome_vs_oracle(built_lib, tmp_path, mode):
     bases = np.fromfile(os.path.join(out, "reads.bin"), np.uint8)
     offs = (np.arange(20001, dtype=np.uint64) * np.uint64(150))
     exp, ff, sc = cpu.pml_batch(bases, offs, threads=8)
-    for variant in (1, 7, 8, 9, 10):
+    for variant in (1, 7, 10):
         gpu.set_option("pml_variant", variant)
         got, st = gpu.query_pml_packed(bases, offs)
         assert (got == exp).all() and (st.fast_forwards, st.scans, st.errors) == (ff, sc, 0)
@@ -515,3 +515,139 @@ def test_real_bwt_pangenome_vs_oracle(built_lib, tmp_path, mode):
     assert (m == em).all() and (c == ec).all()
     z, zst = gpu.query_zml_packed(bases, offs)
     assert (z == cpu.zml_batch(bases, offs, threads=8)).all() and zst.errors == 0
+
+
+# ------------------------------------------------------------------ separators ('%' + ACGT) indexes
+# movi build --separators: reference index-size KATs tests/test_build.cpp:79,95 (pinned on the CPU in
+# tests/test_separators_cpu.py, which also holds the oracle to a BWT-level simulation).
+
+@pytest.mark.parametrize("mode", [6, 8])
+def test_separators_reference_index_vs_oracle(built_lib, mode):
+    import movi_amd
+    from oracle import build_index as B
+    from oracle.oracle import Oracle
+    ref = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))[0][1]
+    img = B.build_index_from_seqs([ref], mode, separators=True)
+    assert len(img) == {6: 948232, 8: 711854}[mode]
+    gpu, cpu = movi_amd.MoveIndex.from_image(img), Oracle(img)
+    assert gpu.desc.alphabet_size == 5
+    rng = np.random.default_rng(70 + mode)
+    reads = mutated_reads(rng, ref, 400, 1, 1500)
+    L = len(ref)
+    clean = bytes(B.clean_text([ref], separators=True)[:L])
+    rc = clean.translate(bytes.maketrans(b"ACGT", b"TGCA"))[::-1]
+    reads += [clean[L - 40:] + rc[:40], clean[L - 5:] + b"%" + rc[:30], rc[-60:], b"%", b"A%C", b"%%ACGT", b"", b"N"]
+    reads += [s for _, s in read_fastx(os.path.join(GOLDEN, "sample.fastq"))]
+    bases, offs = pack(reads)
+    exp, ff, sc = cpu.pml_batch(bases, offs, threads=4)
+    for variant in (0, 1, 7, 10):
+        gpu.set_option("pml_variant", variant)
+        out, st = gpu.query_pml_packed(bases, offs)
+        assert (out == exp).all(), variant
+        assert (st.fast_forwards, st.scans, st.errors) == (ff, sc, 0)
+    m, c, _ = gpu.query_count_packed(bases, offs)
+    em, ec = cpu.count_batch(bases, offs, threads=4)
+    assert (m == em).all() and (c == ec).all()
+    z, _ = gpu.query_zml_packed(bases, offs)
+    assert (z == cpu.zml_batch(bases, offs, threads=4)).all()
+    gpu.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_separators_fuzz_many_sequences(built_lib, seed):
+    """Many short records: many rows of the separator (side-table thresholds), walks that reposition on them."""
+    import movi_amd
+    from oracle import build_index as B
+    from oracle.oracle import Oracle
+    from test_separators_cpu import _multi_sequence_case
+    rng = np.random.default_rng(4100 + seed)
+    seqs, t, reads = _multi_sequence_case(rng, int(rng.integers(2, 60)))
+    reads += [b"", b"%", b"N%N"]
+    bases, offs = pack(reads)
+    bwt, thr = B.bwt_and_thresholds(t)
+    for mode in (6, 8):
+        img = B.serialize(B.build_rows(bwt, thr, mode))
+        gpu, cpu = movi_amd.MoveIndex.from_image(img), Oracle(img)
+        exp, ff, sc = cpu.pml_batch(bases, offs, threads=2)
+        for variant in (0, 1, 7, 10):
+            gpu.set_option("pml_variant", variant)
+            out, st = gpu.query_pml_packed(bases, offs)
+            assert (out == exp).all(), (seed, mode, variant)
+            assert (st.fast_forwards, st.scans, st.errors) == (ff, sc, 0)
+        m, c, _ = gpu.query_count_packed(bases, offs)
+        em, ec = cpu.count_batch(bases, offs, threads=2)
+        assert (m == em).all() and (c == ec).all(), (seed, mode)
+        z, _ = gpu.query_zml_packed(bases, offs)
+        assert (z == cpu.zml_batch(bases, offs, threads=2)).all(), (seed, mode)
+        gpu.close()
+
+
+# ------------------------------------------------------------------ sampled-thresholds (mode 7) indexes
+# 3-byte rows without ids + checkpointed id table (reference KATs tests/test_build.cpp:45-47,86-88; the
+# reference's PML golden test covers this index type too, tests/test_pml.cpp:98-100).
+
+@pytest.mark.parametrize("separators", [False, True])
+def test_sampled_thresholds_index_vs_oracle(built_lib, separators):
+    import movi_amd
+    from oracle import build_index as B
+    from oracle.oracle import Oracle
+    ref = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))[0][1]
+    img = B.build_index_from_seqs([ref], 7, separators=separators)
+    assert len(img) == (505009 if separators else 475326)
+    gpu, cpu = movi_amd.MoveIndex.from_image(img), Oracle(img)
+    assert gpu.desc.mode == 7 and gpu.desc.row_bytes == 3
+    golden_reads = [s for _, s in read_fastx(os.path.join(GOLDEN, "sample.fastq"))]
+    if not separators:
+        gold_pml, _ = golden_sorted_pmls()
+        assert sorted(stdout_line(p) for p in gpu.query_pml(golden_reads)) == gold_pml
+    rng = np.random.default_rng(170 + separators)
+    reads = mutated_reads(rng, ref, 500, 1, 1500) + golden_reads + [b"", b"A", b"N", b"%", b"ACGT" * 200]
+    bases, offs = pack(reads)
+    exp, ff, sc = cpu.pml_batch(bases, offs, threads=4)
+    out, st = gpu.query_pml_packed(bases, offs)
+    assert (out == exp).all()
+    assert (st.fast_forwards, st.scans, st.errors) == (ff, sc, 0)
+    m, c, _ = gpu.query_count_packed(bases, offs)
+    em, ec = cpu.count_batch(bases, offs, threads=4)
+    assert (m == em).all() and (c == ec).all()
+    z, _ = gpu.query_zml_packed(bases, offs)
+    assert (z == cpu.zml_batch(bases, offs, threads=4)).all()
+    gpu.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_sampled_thresholds_fuzz(built_lib, seed):
+    """Small awkward texts (repeats, long runs split at 511, few rows per checkpoint span, the terminator row and
+    the table end inside a span), with and without separators."""
+    import movi_amd
+    from oracle import build_index as B
+    from oracle.oracle import Oracle
+    rng = np.random.default_rng(7100 + seed)
+    seqs = []
+    for _ in range(int(rng.integers(1, 5))):
+        unit = bytes(rng.choice(list(b"ACGT"), size=int(rng.integers(3, 300))).astype(np.uint8))
+        seqs.append(unit * int(rng.integers(1, 8)) + b"A" * int(rng.integers(0, 2500)))
+    text = b"".join(seqs)
+    reads = []
+    for _ in range(150):
+        L = int(rng.integers(1, 300))
+        p = int(rng.integers(0, max(1, len(text) - L)))
+        r = bytearray(text[p:p + L])
+        for k in range(len(r)):
+            if rng.random() < 0.05:
+                r[k] = b"ACGTN"[rng.integers(0, 5)]
+        reads.append(bytes(r))
+    bases, offs = pack(reads)
+    for separators in (False, True):
+        img = B.build_index_from_seqs(seqs, 7, separators=separators)
+        gpu, cpu = movi_amd.MoveIndex.from_image(img), Oracle(img)
+        exp, ff, sc = cpu.pml_batch(bases, offs, threads=2)
+        out, st = gpu.query_pml_packed(bases, offs)
+        assert (out == exp).all(), (seed, separators)
+        assert (st.fast_forwards, st.scans, st.errors) == (ff, sc, 0)
+        m, c, _ = gpu.query_count_packed(bases, offs)
+        em, ec = cpu.count_batch(bases, offs, threads=2)
+        assert (m == em).all() and (c == ec).all(), (seed, separators)
+        z, _ = gpu.query_zml_packed(bases, offs)
+        assert (z == cpu.zml_batch(bases, offs, threads=2)).all(), (seed, separators)
+        gpu.close()

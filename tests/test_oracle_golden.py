@@ -235,3 +235,56 @@ def test_reference_filter_invert_golden(golden_image, mode, seed):
         if not found:                                               # --invert: output_read, src/utils.cpp:291-294
             out += [b">" + rid + b"\n", seq + b"\n"]
     assert b"".join(sorted(out)) == open(os.path.join(GOLDEN, "sample.fasta.pmls.filtered_notfound.sorted"), "rb").read()
+
+
+# ---------------------------------------------------------------- sampled-thresholds (mode 7, 3-byte rows + sampled ids)
+# tests/test_build.cpp:45-47 (475326 B) and :86-88 (505009 B with --separators); tests/test_pml.cpp:98-100 holds the
+# sampled-thresholds index to the same golden file as the other two modes.
+
+@pytest.fixture(scope="module")
+def sampled_image(ref_bwt):
+    bwt, thr = ref_bwt
+    return B.serialize(B.build_rows(bwt, thr, 7))
+
+
+def test_sampled_index_size_known_answers(ref_bwt, sampled_image):
+    assert len(sampled_image) == 475326
+    recs = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))
+    t = B.clean_text([s for _, s in recs], separators=True)
+    assert len(B.serialize(B.build_rows(*B.bwt_and_thresholds(t), 7))) == 505009
+
+
+def test_sampled_oracle_reproduces_golden_pmls(sampled_image):
+    o = Oracle(sampled_image)
+    assert o.r == 118209                            # 511-base rows never split further on this text
+    reads = read_fastx(os.path.join(GOLDEN, "sample.fastq"))
+    gold_pml, _ = golden_sorted_pmls()
+    assert sorted(stdout_line(o.pml(seq)) for _, seq in reads) == gold_pml
+
+
+def test_sampled_lf_equals_regular_lf(sampled_image, golden_image):
+    """get_id from the sampled checkpoints (src/move_structure.cpp:104-283) lands on the row the stored id of the
+    regular index names, for every row: both tables have the same 118209 rows on this text."""
+    o7, o6 = Oracle(sampled_image), Oracle(golden_image(6))
+    rng = np.random.default_rng(3)
+    rows = np.concatenate((np.arange(0, 200), rng.integers(0, o6.r, 4000), [o6.r - 1, o6.end_bwt_idx]))
+    for i in rows.tolist():
+        assert o7.lf(i, 0) == o6.lf(i, 0), i
+
+
+def test_sampled_count_and_zml_equal_brute_force(sampled_image):
+    o = Oracle(sampled_image)
+    recs = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))
+    T = bytes(B.clean_text([s for _, s in recs])[:-1])
+    rng = np.random.default_rng(23)
+    for R in _mutated_reads(recs[0][1], rng, 40, 1, 120, sub=0.02, ill=0.005) + [b"A", b"GNAC"]:
+        m, c = o.count(R)
+        if R[-1:] not in (b"A", b"C", b"G", b"T"):
+            assert (m, c) == (0, 0)
+            continue
+        k = 1
+        while k < len(R) and R[len(R) - k - 1:len(R) - k] in (b"A", b"C", b"G", b"T") and R[len(R) - k - 1:] in T:
+            k += 1
+        assert (m, c) == (k, _occurrences(T, R[len(R) - k:]))
+    for R in _mutated_reads(recs[0][1], rng, 30, 1, 200) + [b"NA", b"ACGTNNACGT"]:
+        assert o.zml(R).tolist() == _zml_brute(T, R), R

@@ -164,3 +164,49 @@ def test_separator_modes_agree(sep_image):
     for _, R in read_fastx(os.path.join(GOLDEN, "sample.fastq")):
         assert (o6.pml(R) == o8.pml(R)).all()
         assert o6.count(R) == o8.count(R)
+
+
+def _multi_sequence_case(rng, n_seqs):
+    """Many short records -> many separator rows, and walks that keep stepping on them."""
+    seqs = []
+    base = bytes(rng.choice(list(b"ACGT"), size=int(rng.integers(30, 200))).astype(np.uint8))
+    for _ in range(n_seqs):
+        s = bytearray(base if rng.random() < 0.5 else
+                      bytes(rng.choice(list(b"ACGT"), size=int(rng.integers(1, 120))).astype(np.uint8)))
+        for k in range(len(s)):
+            if rng.random() < 0.05:
+                s[k] = b"ACGT"[rng.integers(0, 4)]
+        seqs.append(bytes(s))
+    t = B.clean_text(seqs, separators=True)
+    text = bytes(t[:-1])
+    reads = []
+    for _ in range(80):
+        L = int(rng.integers(1, 150))
+        p = int(rng.integers(0, max(1, len(text) - L)))
+        r = bytearray(text[p:p + L])                # may run over '%' (illegal in a read)
+        for k in range(len(r)):
+            if rng.random() < 0.06:
+                r[k] = b"ACGTN"[rng.integers(0, 5)]
+        reads.append(bytes(r))
+    return seqs, t, reads
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_separator_fuzz_many_sequences(seed):
+    rng = np.random.default_rng(4000 + seed)
+    seqs, t, reads = _multi_sequence_case(rng, int(rng.integers(2, 40)))
+    w = BwtWalker(t, sep=1)
+    T = bytes(t[:-1])
+    bwt, thr = B.bwt_and_thresholds(t)
+    for mode in (6, 8):
+        f = B.build_rows(bwt, thr, mode)
+        assert len(f["sep_thr"]) >= 2
+        o = Oracle(B.serialize(f))
+        for R in reads:
+            assert o.pml(R).tolist() == w.pml(R), (seed, mode, R)
+            m, c = o.count(R)
+            if R[-1:] in (b"A", b"C", b"G", b"T"):
+                k = 1
+                while k < len(R) and R[len(R) - k - 1:len(R) - k] in (b"A", b"C", b"G", b"T") and R[len(R) - k - 1:] in T:
+                    k += 1
+                assert (m, c) == (k, _occurrences(T, R[len(R) - k:])), (seed, mode, R)

@@ -1,4 +1,4 @@
-// build_index.cpp -- index constructor for modes 6 / 8 (bench + test tooling; SURVEY section 8(f) "next #2").
+// build_index.cpp -- index constructor for modes 6 / 7 / 8 (bench + test tooling; SURVEY section 8(f) "next #2").
 //
 // FASTA (or a synthetic pangenome) -> cleaned text with reverse complements -> suffix array (SA-IS) ->
 // BWT + LCP (Kasai) -> per-run thresholds -> move rows -> `index.movi` bytes.  Linear time, so that
@@ -15,13 +15,15 @@
 // Checked byte-for-byte against tests/golden/index_*/index.movi (whose sizes are the reference's
 // known answers 948119 / 711733, tests/test_build.cpp:37,53) in tests/test_build_tool.py.
 //
-// usage: build_index fasta <ref.fasta> <mode 6|8> <out_dir>
+// usage: build_index fasta <ref.fasta> <mode 6|7|8> <out_dir> [separators]     ("separators" = movi build --separators:
+//            every record and reverse complement followed by %; sizes 948232 / 711854 B, tests/test_build.cpp:79,95)
 //        build_index pangenome <ancestor_len> <n_genomes> <snp_rate> <seed> <mode> <out_dir> [n_reads read_len sub_rate]
 //            [n_reads2 read_len2 sub_rate2]
 //            (also writes <out_dir>/text.bin and reads.bin (and reads2.bin): fixed-length substrings of the text
 //            with substitutions)
 //        build_index reads <text.bin> <n_reads> <read_len> <sub_rate> <seed> <out_file>
 #include <algorithm>
+#include <array>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -127,15 +129,18 @@ static uint64_t splitmix64(uint64_t &s) {
     return z ^ (z >> 31);
 }
 
-static void append_clean(std::vector<uint8_t> &text, const std::string &seq) {
-    // src/prepare_ref.cpp:39-58: the test uses the ORIGINAL byte, so lower case also becomes 'A'
+static void append_clean(std::vector<uint8_t> &text, const std::string &seq, bool separators = false) {
+    // src/prepare_ref.cpp:39-58: the test uses the ORIGINAL byte, so lower case also becomes 'A';
+    // with separators (:61-66) the record and its reverse complement are each followed by '%'
     const size_t a = text.size();
     for (char ch : seq) text.push_back((ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T') ? (uint8_t)ch : (uint8_t)'A');
     const size_t b = text.size();
+    if (separators) text.push_back('%');
     for (size_t i = b; i-- > a;) {
         uint8_t c = text[i];
         text.push_back(c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : 'A');
     }
+    if (separators) text.push_back('%');
 }
 
 static void put64(std::vector<uint8_t> &o, uint64_t v) { for (int i = 0; i < 8; i++) o.push_back((uint8_t)(v >> (8 * i))); }
@@ -178,7 +183,7 @@ static std::vector<uint8_t> build_index(std::vector<uint8_t> &text, int mode) {
         sa_t curmin[256], arg[256];
         bool seen[256];
         for (int c = 0; c < 256; c++) { curmin[c] = INF; arg[c] = 0; seen[c] = false; }
-        const int syms[5] = {0, 'A', 'C', 'G', 'T'};
+        const int syms[6] = {0, '%', 'A', 'C', 'G', 'T'};
         for (sa_t i = 0; i < n; i++) {
             if (i > 0) for (int c : syms) if (lcp[i] < curmin[c]) { curmin[c] = lcp[i]; arg[c] = i; }
             const uint8_t c = bwt[i];
@@ -194,7 +199,7 @@ static std::vector<uint8_t> build_index(std::vector<uint8_t> &text, int mode) {
     for (uint64_t t : thr) hard[t] = true;
     std::vector<sa_t>().swap(lcp);
     const uint64_t original_r = thr.size();
-    const uint32_t maxrun = mode == 6 ? 2047 : 1023;                      // move_row_configs.hpp:51,101
+    const uint32_t maxrun = mode == 6 ? 2047 : (mode == 8 ? 1023 : 511);  // move_row_configs.hpp:51,101,135
     // rows (:328-396)
     std::vector<uint64_t> all_p;
     {
@@ -213,7 +218,9 @@ static std::vector<uint8_t> build_index(std::vector<uint8_t> &text, int mode) {
     for (int c = 0; c < 256; c++) alphamap[c] = 256;
     for (int c = 1; c < 256; c++) if (cnt_all[c]) { alphamap[c] = alphabet.size(); alphabet.push_back((uint8_t)c); counts.push_back(cnt_all[c]); }
     const size_t sigma = alphabet.size();
-    if (sigma < 1 || sigma > 4) { fprintf(stderr, "only DNA alphabets (<= 4 symbols) are in scope\n"); exit(1); }
+    // MoveStructure::use_separator, src/move_structure.cpp:547-552: five symbols led by '%'
+    const int sep = (sigma == 5 && alphabet[0] == '%') ? 1 : 0;
+    if (sigma < 1 || (sigma > 4 && !sep)) { fprintf(stderr, "only DNA alphabets (<= 4 symbols, or '%%' + ACGT) are in scope\n"); exit(1); }
     std::vector<uint8_t> code(r);
     std::vector<uint16_t> lens(r), doff(r);
     std::vector<uint64_t> dest(r);
@@ -225,7 +232,7 @@ static std::vector<uint8_t> build_index(std::vector<uint8_t> &text, int mode) {
         else code[i] = (uint8_t)alphamap[h];
     }
     {   // LF of run heads (LF_heads, src/move_structure.cpp:515-523); destinations are monotone per character
-        uint64_t C[4], rk[4] = {0, 0, 0, 0}, ptr[4] = {0, 0, 0, 0};
+        uint64_t C[5], rk[5] = {0, 0, 0, 0, 0}, ptr[5] = {0, 0, 0, 0, 0};
         C[0] = 1;
         for (size_t a = 1; a < sigma; a++) C[a] = C[a - 1] + counts[a - 1];
         for (uint64_t i = 0; i < r; i++) {
@@ -254,31 +261,49 @@ static std::vector<uint8_t> build_index(std::vector<uint8_t> &text, int mode) {
             last_offsets.push_back(cc - all_p[k - 1] - 1);
         }
     }
-    // threshold bits (:807-935)
+    // threshold bits (:807-935).  With separators (:826-831, :836-858, :912-921) no threshold is kept FOR the
+    // separator; a row OF the separator (and the '$' row, whose character field decodes as one) gets an explicit
+    // 4-value entry in separators_thresholds, appended in descending row order, row 0 last.
     std::vector<uint8_t> tbits(r, 0);
     uint64_t end_thr[4] = {0, 0, 0, 0};
+    std::vector<std::array<uint16_t, 4>> sep_thr;
+    std::vector<std::pair<uint64_t, uint64_t>> sep_map;
     {
         std::vector<uint64_t> at(sigma, (uint64_t)n);
         uint64_t thr_i = original_r - 1;
         for (uint64_t i = r - 1; i > 0; --i) {
             const int rc = code[i];                                       // '$' row has c == 0 -> behaves as 'A' (:823)
+            if (sep && rc == 0) {
+                sep_thr.push_back({0, 0, 0, 0});
+                sep_map.emplace_back(i, sep_thr.size() - 1);
+            }
             for (size_t j = 0; j < sigma; j++) {
                 if ((int)j == rc) {
                     at[j] = thr[thr_i];
                 } else {
+                    if (sep && j == 0) continue;                          // :849-852
                     const uint64_t cur = at[j];
                     int bit;
                     uint64_t val;
                     if (cur >= all_p[i] + lens[i]) { val = lens[i]; bit = 1; }
                     else if (cur <= all_p[i]) { val = 0; bit = 0; }
-                    else { fprintf(stderr, "threshold strictly inside a row\n"); exit(1); }
-                    if (i == end_bwt_idx) end_thr[j] = val;
-                    else tbits[i] |= (uint8_t)(bit << alphamap_3[rc][j]);
+                    else { val = cur - all_p[i]; bit = -1; }              // strictly inside the row (:869-871)
+                    if (i == end_bwt_idx) end_thr[j - sep] = val;
+                    else if (sep && rc == 0) sep_thr.back()[j - 1] = (uint16_t)val;
+                    else {
+                        if (bit < 0) { fprintf(stderr, "threshold strictly inside a row\n"); exit(1); }
+                        tbits[i] |= (uint8_t)(bit << alphamap_3[rc - sep][j - sep]);
+                    }
                 }
             }
             if (code[i] != code[i - 1] || i == end_bwt_idx || i - 1 == end_bwt_idx) thr_i--;
         }
-        tbits[0] = 0;
+        if (sep && code[0] == 0) {                                        // :917-920
+            sep_thr.push_back({0, 0, 0, 0});
+            sep_map.emplace_back(0, sep_thr.size() - 1);
+        } else {
+            tbits[0] = 0;
+        }
     }
     // blocked ids (:939-1074)
     std::vector<uint32_t> blocked, id_blocks;
@@ -288,7 +313,7 @@ static std::vector<uint8_t> build_index(std::vector<uint8_t> &text, int mode) {
         for (;;) {
             n_blocks = (r + block_size - 1) / block_size;
             id_blocks.assign(sigma * n_blocks, 0);
-            uint64_t last[4] = {0, 0, 0, 0};
+            uint64_t last[5] = {0, 0, 0, 0, 0};
             bool ok = true;
             for (uint64_t i = 0; i < r && ok; i++) {
                 if (i % block_size == 0) for (size_t a = 0; a < sigma; a++) id_blocks[a * n_blocks + i / block_size] = (uint32_t)last[a];
@@ -304,6 +329,25 @@ static std::vector<uint8_t> build_index(std::vector<uint8_t> &text, int mode) {
             block_size /= 2;
             max_allowed = ((max_allowed + 1) / 2) - 1;
         }
+    }
+    // sampled ids (mode 7; src/move_structure_build.cpp:486-496, :571-596, :677-682): every 20 rows the destination id
+    // of the latest run of each character; a character not seen yet gets the id of its first run once it shows up
+    const uint64_t tally_cp = 20;                                         // movi_options.hpp:257
+    std::vector<uint64_t> tally;
+    uint64_t n_tally = 0;
+    if (mode == 7) {
+        n_tally = r / tally_cp + 2;
+        tally.assign(sigma * n_tally, 0);
+        std::vector<uint64_t> cur(sigma, r);
+        for (uint64_t i = 0; i < r; i++) {
+            if (i != end_bwt_idx) {
+                const int a = code[i];
+                if (cur[a] == r) for (uint64_t t = 0; t <= i / tally_cp; t++) tally[a * n_tally + t] = dest[i];
+                cur[a] = dest[i];
+            }
+            if (i % tally_cp == 0) for (size_t a = 0; a < sigma; a++) tally[a * n_tally + i / tally_cp] = cur[a];
+        }
+        for (size_t a = 0; a < sigma; a++) tally[a * n_tally + n_tally - 1] = cur[a];
     }
     // serialize (src/move_structure_io.cpp:435-469)
     std::vector<uint8_t> o;
@@ -332,6 +376,10 @@ static std::vector<uint8_t> build_index(std::vector<uint8_t> &text, int mode) {
             w[3] = (uint16_t)(doff[i] | ((t & 1) << 11) | ((uint32_t)(d >> 32) << 12));
             const uint8_t *p = reinterpret_cast<const uint8_t *>(w);
             o.insert(o.end(), p, p + 8);
+        } else if (mode == 7) {                                            // move_row.hpp:122-127, configs :120-136
+            o.push_back((uint8_t)(lens[i] & 0xFF));
+            o.push_back((uint8_t)(doff[i] & 0xFF));
+            o.push_back((uint8_t)((doff[i] >> 8) | ((lens[i] >> 8) << 1) | ((uint32_t)code[i] << 2) | ((t & 7) << 5)));
         } else {
             const uint32_t b = blocked[i];
             w[0] = (uint16_t)(b & 0xFFFF);
@@ -340,6 +388,12 @@ static std::vector<uint8_t> build_index(std::vector<uint8_t> &text, int mode) {
             const uint8_t *p = reinterpret_cast<const uint8_t *>(w);
             o.insert(o.end(), p, p + 6);
         }
+    }
+    if (mode == 7) {                                                      // write_tally_table, io.cpp:328-336
+        const uint32_t cp32 = (uint32_t)tally_cp;
+        for (int b = 0; b < 4; b++) o.push_back((uint8_t)(cp32 >> (8 * b)));
+        put64(o, n_tally);
+        for (uint64_t v : tally) for (int b = 0; b < 5; b++) o.push_back((uint8_t)(v >> (8 * b)));   // MoveTally: u32 low | u8 high
     }
     for (int i = 0; i < 3; i++) put64(o, 0);
     put64(o, counts.size());
@@ -354,6 +408,13 @@ static std::vector<uint8_t> build_index(std::vector<uint8_t> &text, int mode) {
         const uint8_t *p = reinterpret_cast<const uint8_t *>(id_blocks.data());
         o.insert(o.end(), p, p + id_blocks.size() * 4);
         put64(o, block_size);
+    }
+    if (sep) {                                                            // write_separators_thresholds, io.cpp:399-413
+        put64(o, sep_thr.size());
+        for (const auto &t : sep_thr) for (int k = 0; k < 4; k++) { o.push_back((uint8_t)(t[k] & 0xFF)); o.push_back((uint8_t)(t[k] >> 8)); }
+        std::sort(sep_map.begin(), sep_map.end());                        // the reference walks an unordered_map; ascending rows here
+        put64(o, sep_map.size());
+        for (const auto &kv : sep_map) { put64(o, kv.first); put64(o, kv.second); }
     }
     fprintf(stderr, "[build_index] n = %d, original_r = %llu, r = %llu, n/r = %.2f, index %zu bytes\n", n,
             (unsigned long long)original_r, (unsigned long long)r, (double)n / r, o.size());
@@ -394,17 +455,18 @@ int main(int argc, char **argv) {
         if (!in.good()) { fprintf(stderr, "cannot open %s\n", argv[2]); return 1; }
         mode = atoi(argv[3]);
         out_dir = argv[4];
+        const bool separators = argc >= 6 && std::string(argv[5]) == "separators";   // movi build --separators
         std::string line, seq;
         bool have = false;
         while (std::getline(in, line)) {
             while (!line.empty() && (line.back() == '\r' || line.back() == '\n' || line.back() == ' ')) line.pop_back();
             if (!line.empty() && line[0] == '>') {
-                if (have) append_clean(text, seq);
+                if (have) append_clean(text, seq, separators);
                 seq.clear();
                 have = true;
             } else if (have) seq += line;
         }
-        if (have) append_clean(text, seq);
+        if (have) append_clean(text, seq, separators);
     } else if (cmd == "pangenome" && argc >= 8) {
         const uint64_t anc_len = strtoull(argv[2], nullptr, 10), n_genomes = strtoull(argv[3], nullptr, 10);
         const double snp = atof(argv[4]);
@@ -451,7 +513,7 @@ int main(int argc, char **argv) {
         fprintf(stderr, "usage: see the header of tools/build_index.cpp\n");
         return 1;
     }
-    if (mode != 6 && mode != 8) { fprintf(stderr, "mode must be 6 or 8\n"); return 1; }
+    if (mode != 6 && mode != 7 && mode != 8) { fprintf(stderr, "mode must be 6, 7 or 8\n"); return 1; }
     mkdir(out_dir.c_str(), 0777);
     if (cmd == "pangenome") write_file(out_dir + "/text.bin", text);       // lets `reads` draw more reads later
     for (int set = 0; set < 2; set++) {                                    // optional second read set: argv[11..13] -> reads2.bin
