@@ -35,6 +35,9 @@ WORKLOADS = {
                desc="BASELINE config 3: same pangenome index, 100k x 10kbp reads per GPU (8% subst.)"),
     "c2b": dict(kind="pangenome", mode=8, reads=1_000_000, read_len=150, sub=0.01,
                 desc="same pangenome as blocked-thresholds (6 B rows), 1M x 150bp reads per GPU"),
+    "c2s": dict(kind="pangenome", mode=7, reads=1_000_000, read_len=150, sub=0.01,
+                desc="same pangenome as sampled-thresholds (3 B rows, ids recovered from checkpoints every 20 rows), "
+                     "1M x 150bp reads per GPU"),
     "c2synth": dict(kind="synth", rows=10_000_000, mode=6, reads=1_000_000, read_len=150, sub=0.01,
                     desc="random 10M-row regular-thresholds table (worst-case step mix), 1M x 150bp reads per GPU"),
     "c3synth": dict(kind="synth", rows=10_000_000, mode=6, reads=100_000, read_len=10_000, sub=0.08,
@@ -142,7 +145,8 @@ def main():
     if args.rows: wl["rows"] = args.rows
     if args.reads: wl["reads"] = args.reads
     if args.read_len: wl["read_len"] = args.read_len
-    mode, row_bytes = wl["mode"], (8 if wl["mode"] == 6 else 6)
+    ROW_BYTES = {6: 8, 8: 6, 7: 3}
+    mode, row_bytes = wl["mode"], ROW_BYTES[wl["mode"]]
 
     # ---- index: every rank derives the same host-side structure from the seed (needed to
     # draw reads); the DEVICE row table comes from rank 0 through one RCCL broadcast.
@@ -182,8 +186,10 @@ def main():
         img = file_img if file_img is not None else six.image()
         _, cdesc, roff, rbytes = movi_amd.parse_index_image(img)
         id_blocks = (np.ctypeslib.as_array(C.cast(cdesc.id_blocks, C.POINTER(C.c_uint32)),
-                                           shape=(int(cdesc.n_blocks) * 4,)).copy() if mode == 8 else None)
-        meta = {"cdesc": bytes(cdesc), "id_blocks": id_blocks}
+                                           shape=(int(cdesc.n_blocks) * int(cdesc.alphabet_size),)).copy() if mode == 8 else None)
+        tally = (np.ctypeslib.as_array(C.cast(cdesc.tally_ids, C.POINTER(C.c_uint8)),
+                                       shape=(int(cdesc.n_tally) * int(cdesc.alphabet_size) * 5,)).copy() if mode == 7 else None)
+        meta = {"cdesc": bytes(cdesc), "id_blocks": id_blocks, "tally": tally}
         d_rows = torch.from_numpy(img[roff: roff + rbytes]).to(dev)     # rank 0 uploads the table once
     t_bcast = 0.0
     if world > 1:
@@ -194,10 +200,14 @@ def main():
         torch.cuda.synchronize()
         t_bcast = time.time() - tb
     cdesc = IndexDescC.from_buffer_copy(meta["cdesc"])
-    mode, row_bytes = int(cdesc.mode), (8 if int(cdesc.mode) == 6 else 6)
+    mode, row_bytes = int(cdesc.mode), ROW_BYTES[int(cdesc.mode)]
     wl["rows"], wl["mode"] = int(cdesc.r), mode
     id_blocks = meta["id_blocks"]
     cdesc.id_blocks = id_blocks.ctypes.data if id_blocks is not None else None
+    tally = meta.get("tally")
+    cdesc.tally_ids = tally.ctypes.data if tally is not None else None
+    cdesc.separator_thresholds, cdesc.separator_map = None, None      # the bench workloads carry no separators
+    cdesc.n_separator_thresholds = cdesc.n_separator_map = 0
     index = movi_amd.MoveIndex.from_device_rows(cdesc, d_rows.data_ptr(), device=local_rank, keepalive=d_rows)
     if args.variant >= 0:
         index.set_option("pml_variant", args.variant)
@@ -322,7 +332,7 @@ def main():
 
     result = {
         "metric": {"pml": "PML", "count": "count", "zml": "ZML"}[args.query] + " query Gbases/s on " +
-                  ("regular-thresholds" if mode == 6 else "blocked-thresholds") + " index",
+                  {6: "regular-thresholds", 8: "blocked-thresholds", 7: "sampled-thresholds"}[mode] + " index",
         "value": value, "unit": "Gbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",

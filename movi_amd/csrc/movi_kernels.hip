@@ -161,7 +161,7 @@ __device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
 __device__ __forceinline__ uint64_t tally_id(const DevIndex &ix, bool live, uint64_t idx, uint2 row) {
     const uint32_t ci = row_c<7>(row);
     const uint64_t cp = ix.tally_cp;
-    uint64_t id = 0;
+    uint64_t id = live ? 0 : idx;                        // lanes that take no step keep their row (callers store the result)
     uint32_t walk = 0;                                   // 1 while the lane still scans / walks
     uint64_t i = idx, next_cp = idx;
     uint64_t rows_until = 0;

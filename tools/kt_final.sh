@@ -10,6 +10,8 @@ run c2_pml ""
 run c3_pml "--workload c3 --steps 5"
 run c2_count "--query count"
 run c2_zml "--query zml"
+run c3_classify "--workload c3 --steps 5 --classify 1"
+run c2s_pml "--workload c2s"
 python3 tools/prof_summary.py "$OUT" > "$OUT/summary.txt" 2>&1
 for f in "$OUT"/*.log; do echo "== $f"; tail -1 "$f"; done >> "$OUT/summary.txt"
 find "$OUT" -name "*.db" -delete
