@@ -301,6 +301,15 @@ def main():
     else:
         total_bases_per_step = float(n_bases)
 
+    # which PML kernel launch_pml picked (movi_kernels.hip: state machine for <= 12 waves/CU of reads, mode 6 / 8)
+    n_cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    v_sel = args.variant if args.variant >= 0 else (10 if n_reads <= n_cus * 64 * 12 else 1)
+    if mode == 7 or (args.classify and v_sel == 0):
+        v_sel = 1
+    if args.classify and v_sel == 7:
+        v_sel = 10
+    pml_kernel_name = {0: "pml_kernel<%d,0>" % mode, 1: "pml_kernel<%d,1>" % mode, 7: "pml_kernel_flat<%d>" % mode,
+                       10: "pml_kernel_flatp<%d>" % mode}[v_sel]
     f_bar = st.fast_forwards / max(n_bases, 1)
     s_bar = st.scans / max(n_bases, 1)
     bytes_per_base = row_bytes * (1.0 + f_bar + s_bar) + 1 + 2
@@ -347,7 +356,7 @@ def main():
                    "reads_gen_s": round(t_reads_gen, 2)},
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": {"pml": "pml_kernel", "count": "count_kernel_v0", "zml": "zml_kernel"}[args.query],
+                     "kernel": pml_kernel_name if args.query == "pml" else {"count": "count_kernel_v0", "zml": "zml_kernel"}[args.query],
                      "kernel_ms_avg": avg_kern_s * 1e3,
                      "gathers_per_s": ((1.0 + f_bar + s_bar) * n_bases if args.query == "pml"
                                        else (2.0 * (1.0 + f_bar) + s_bar) * work_bases) / avg_kern_s},

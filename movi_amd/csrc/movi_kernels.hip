@@ -158,6 +158,16 @@ __device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
 // run of each character is kept.  The id of row idx = the id stored at the next checkpoint for idx's character,
 // walked back over the destination rows by the BWT positions of that character between idx and the stored run.
 // Wave-uniform loops, predicated per lane (see the control-flow note above).  Returns r on the reference's throws.
+// Five consecutive 3-byte rows out of one unaligned 16-byte load (bytes [3i, 3i+16)): row t at byte 3t.
+__device__ __forceinline__ uint32_t row5(const uint4 &v, int t) {
+    switch (t) {
+        case 0: return v.x & 0xFFFFFFu;
+        case 1: return ((v.x >> 24) | (v.y << 8)) & 0xFFFFFFu;
+        case 2: return ((v.y >> 16) | (v.z << 16)) & 0xFFFFFFu;
+        case 3: return (v.z >> 8) & 0xFFFFFFu;
+        default: return v.w & 0xFFFFFFu;
+    }
+}
 __device__ __forceinline__ uint64_t tally_id(const DevIndex &ix, bool live, uint64_t idx, uint2 row) {
     const uint32_t ci = row_c<7>(row);
     const uint64_t cp = ix.tally_cp;
@@ -167,7 +177,7 @@ __device__ __forceinline__ uint64_t tally_id(const DevIndex &ix, bool live, uint
     uint64_t rows_until = 0;
     uint32_t last_n = 0, last_off = 0, last_is_idx = 1;
     if (live && idx != ix.end_bwt_idx) {                 // '$' goes to row 0 (:106-108)
-        const uint64_t ta = idx / cp;
+        const uint64_t ta = ix.r < 0xFFFFFFFFull ? (uint64_t)((uint32_t)idx / (uint32_t)cp) : idx / cp;
         const uint64_t *tl = ix.tally + (uint64_t)ci * ix.tally_len;
         if (idx == ix.r - 1) id = tl[ix.tally_len - 1];  // :114-117
         else if (ta * cp == idx) id = tl[ta];            // :121-124
@@ -178,18 +188,37 @@ __device__ __forceinline__ uint64_t tally_id(const DevIndex &ix, bool live, uint
             walk = 1;
         }
     }
-    // rows of idx's character in [idx, next_cp) (:168-174); row idx itself is one of them
+    // rows of idx's character in [idx, next_cp) (:168-174); row idx itself is one of them.  Five rows per
+    // 16-byte load: the scattered row loads of this loop, not their latency, were what bound the kernel
+    // (one load per row: 9.7 Gbases/s on the pangenome).
     uint32_t scan = walk;
     while (wave_any(scan != 0u)) {
         if (scan) {
-            const uint2 w = load_row<7>(ix.rows, i);
-            if (i != ix.end_bwt_idx && row_c<7>(w) == ci) {
-                rows_until += row_n<7>(w);
-                last_n = row_n<7>(w);
-                last_off = row_off<7>(w);
-                last_is_idx = (i == idx) ? 1u : 0u;
+            if (i + 6 <= ix.r) {                         // bytes [3i, 3i+16) lie inside the table
+                uint4 v;
+                __builtin_memcpy(&v, ix.rows + i * 3, 16);
+#pragma unroll
+                for (int t = 0; t < 5; ++t) {
+                    const uint2 w = make_uint2(row5(v, t), 0u);
+                    const uint64_t it = i + (uint64_t)t;
+                    if (it < next_cp && it != ix.end_bwt_idx && row_c<7>(w) == ci) {
+                        rows_until += row_n<7>(w);
+                        last_n = row_n<7>(w);
+                        last_off = row_off<7>(w);
+                        last_is_idx = (it == idx) ? 1u : 0u;
+                    }
+                }
+                i += 5;
+            } else {
+                const uint2 w = load_row<7>(ix.rows, i);
+                if (i != ix.end_bwt_idx && row_c<7>(w) == ci) {
+                    rows_until += row_n<7>(w);
+                    last_n = row_n<7>(w);
+                    last_off = row_off<7>(w);
+                    last_is_idx = (i == idx) ? 1u : 0u;
+                }
+                i += 1;
             }
-            i += 1;
             scan = (i < next_cp) ? 1u : 0u;
         }
     }
@@ -212,14 +241,30 @@ __device__ __forceinline__ uint64_t tally_id(const DevIndex &ix, bool live, uint
         }
     }
     if (back) { if (id == 0) { id = ix.r; back = 0; } else id -= 1; }
-    while (wave_any(back != 0u && rows_until != 0)) {   // :211-219
+    // :211-219: walk the destination rows back, five rows (id-4 .. id) per 16-byte load
+    while (wave_any(back != 0u && rows_until != 0)) {
         if (back && rows_until != 0) {
-            const uint32_t nid = row_n<7>(load_row<7>(ix.rows, id));
-            if (rows_until >= nid) {
-                rows_until -= nid;
-                if (id == 0) { id = ix.r; rows_until = 0; } else id -= 1;
+            if (id >= 4 && id + 2 <= ix.r) {             // bytes [3(id-4), 3(id-4)+16) lie inside the table
+                uint4 v;
+                __builtin_memcpy(&v, ix.rows + (id - 4) * 3, 16);
+                uint32_t took = 0;
+#pragma unroll
+                for (int t = 4; t >= 0; --t) {
+                    const uint32_t nid = row_n<7>(make_uint2(row5(v, t), 0u));
+                    if (rows_until != 0) {
+                        if (rows_until >= nid) { rows_until -= nid; took += 1; }
+                        else rows_until = 0;
+                    }
+                }
+                if (took > id) { id = ix.r; rows_until = 0; } else id -= took;     // took <= 5 <= id + 1
             } else {
-                rows_until = 0;
+                const uint32_t nid = row_n<7>(load_row<7>(ix.rows, id));
+                if (rows_until >= nid) {
+                    rows_until -= nid;
+                    if (id == 0) { id = ix.r; rows_until = 0; } else id -= 1;
+                } else {
+                    rows_until = 0;
+                }
             }
         }
     }
