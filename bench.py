@@ -110,6 +110,8 @@ def main():
     ap.add_argument("--query", default="pml", choices=["pml", "count", "zml"], help="count = backward-search count query "
                     "(BASELINE config 5 path); the headline metric is pml")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-long-reads", action="store_true", help="skip the secondary 100k x 10kbp measurement that the default "
+                    "run (c2, N=1) appends as `long_reads` (north_star: 150 bp and 10 kbp reads)")
     ap.add_argument("--cpu-sample-reads", type=int, default=0)
     args = ap.parse_args()
 
@@ -411,6 +413,43 @@ def main():
         result["parity_sample_ok"] = bool((got == exp).all())
         if not result["parity_sample_ok"]:
             print("PARITY FAILURE on the cpu_baseline sample", file=sys.stderr)
+    # ---- secondary figure, default run only (N == 1, after the timed region, never part of `value`): BASELINE config 3,
+    # 100 k x 10 kbp reads on the same resident index -- the latency-bound shape, served by the lane state machine
+    if (rank == 0 and world == 1 and args.workload == "c2" and args.query == "pml" and not args.classify
+            and not args.no_long_reads and not args.from_dir and reads_path and args.variant < 0):
+        try:
+            import subprocess
+            w3 = WORKLOADS["c3"]
+            rf = os.path.join(idx_dir, "reads_%dx%d_%g.bin" % (w3["reads"], w3["read_len"], w3["sub"]))
+            if not os.path.exists(rf):
+                subprocess.check_call([os.path.join(ROOT, "tools", "build_index"), "reads", os.path.join(idx_dir, "text.bin"),
+                                       str(w3["reads"]), str(w3["read_len"]), str(w3["sub"]), str(PG["seed"]), rf + ".tmp"])
+                os.rename(rf + ".tmp", rf)
+            del d_out, d_bases
+            torch.cuda.empty_cache()
+            L3, n3 = w3["read_len"], w3["reads"]
+            b3 = torch.from_numpy(np.fromfile(rf, np.uint8, count=n3 * L3)).to(dev)
+            o3 = torch.from_numpy((np.arange(n3 + 1, dtype=np.uint64) * np.uint64(L3)).view(np.int64)).to(dev)
+            out3 = torch.empty(n3 * L3, dtype=torch.int16, device=dev)
+            err3 = torch.zeros(n3, dtype=torch.uint8, device=dev)
+            run3 = lambda: index.pml_device(b3.data_ptr(), o3.data_ptr(), n3, n3 * L3, out3.data_ptr(), err3.data_ptr(),
+                                            stream.cuda_stream, 0)
+            run3()
+            torch.cuda.synchronize()
+            st3 = index.last_stats(stream.cuda_stream)
+            k3 = 3
+            t0 = time.perf_counter()
+            for _ in range(k3):
+                run3()
+            torch.cuda.synchronize()
+            dt3 = time.perf_counter() - t0
+            result["long_reads"] = {"workload": "c3", "description": w3["desc"], "value": n3 * L3 * k3 / dt3 / 1e9,
+                                    "unit": "Gbases/s", "steps": k3, "ms_per_step": dt3 / k3 * 1e3, "reads_per_gpu": n3,
+                                    "read_len": L3, "kernel": "pml_kernel_flatp<%d>" % mode,
+                                    "fast_forwards_per_base": round(st3.fast_forwards / (n3 * L3), 4),
+                                    "scans_per_base": round(st3.scans / (n3 * L3), 4), "errors": int(st3.errors)}
+        except Exception as e:                            # noqa: BLE001 -- never lose the headline line to the extra
+            result["long_reads"] = {"error": repr(e)[:200]}
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

@@ -113,13 +113,15 @@ int movi_index_create(int device, const movi_index_desc_t *desc, const void *h_r
 
 /* Adopt a row table that already lives on the device (e.g. received by an RCCL
  * broadcast into a caller-owned buffer).  The caller keeps ownership of d_rows
- * and must keep it alive until movi_index_destroy. */
+ * and must keep it alive until movi_index_destroy (mode 7: the rows are copied
+ * -- widened to 4 bytes each -- so the buffer may be released after the call). */
 int movi_index_create_from_device_rows(int device, const movi_index_desc_t *desc,
                                        const void *d_rows, movi_index_t **out);
 
 int movi_index_destroy(movi_index_t *ix);
 int movi_index_get_desc(const movi_index_t *ix, movi_index_desc_t *desc);   /* id_blocks = NULL */
-/* Device pointer + size of the resident row table (source buffer of the broadcast on rank 0). */
+/* Device pointer + size of the resident row table (source buffer of the broadcast on rank 0).  Modes 6 / 8 only:
+ * mode 7 rows are resident widened to 4 bytes (MOVI_ERR_ARG); broadcast the file bytes for those. */
 int movi_index_device_rows(const movi_index_t *ix, const void **d_rows, size_t *bytes);
 
 /* ---- PML -------------------------------------------------------------------- */

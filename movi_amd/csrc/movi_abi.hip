@@ -305,6 +305,21 @@ static movi_index *new_handle(int device, const movi_index_desc_t *desc) {
     return ix;
 }
 
+// Mode 7: the resident table is the file's 3-byte rows widened to one aligned dword each (kernels: load_row<7>);
+// `packed` is a device buffer with the file bytes.  The handle owns the widened copy.
+static hipError_t adopt_widened(movi_index *ix, const uint8_t *d_packed) {
+    uint32_t *wide = nullptr;
+    hipError_t e = hipMalloc(&wide, (size_t)ix->desc.r * 4 + 16);
+    if (e != hipSuccess) return e;
+    e = hipMemset(wide, 0, (size_t)ix->desc.r * 4 + 16);
+    if (e == hipSuccess) e = widen_rows(d_packed, ix->desc.r, wide, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) { (void)hipFree(wide); return e; }
+    ix->d_rows = reinterpret_cast<uint8_t *>(wide);
+    ix->owns_rows = true;
+    return hipSuccess;
+}
+
 int movi_index_create(int device, const movi_index_desc_t *desc, const void *h_rows, movi_index_t **out) {
     if (!out || !h_rows) return fail(MOVI_ERR_ARG, "NULL argument");
     *out = nullptr;
@@ -316,6 +331,13 @@ int movi_index_create(int device, const movi_index_desc_t *desc, const void *h_r
     if (e == hipSuccess) e = hipMemcpy(ix->d_rows, h_rows, ix->rows_bytes, hipMemcpyHostToDevice);
     if (e != hipSuccess) { movi_index_destroy(ix); return fail_hip(e, "uploading the move rows"); }
     ix->owns_rows = true;
+    if (desc->mode == MOVI_MODE_SAMPLED_THRESHOLDS) {
+        uint8_t *packed = ix->d_rows;
+        ix->d_rows = nullptr;
+        e = adopt_widened(ix, packed);
+        (void)hipFree(packed);
+        if (e != hipSuccess) { movi_index_destroy(ix); return fail_hip(e, "widening the 3-byte rows"); }
+    }
     rc = finish_create(ix);
     if (rc) { std::string keep = g_err; movi_index_destroy(ix); g_err = keep; return rc; }
     *out = ix;
@@ -333,6 +355,11 @@ int movi_index_create_from_device_rows(int device, const movi_index_desc_t *desc
     movi_index *ix = new_handle(device, desc);
     ix->d_rows = const_cast<uint8_t *>(static_cast<const uint8_t *>(d_rows));
     ix->owns_rows = false;
+    if (desc->mode == MOVI_MODE_SAMPLED_THRESHOLDS) {      // widened private copy; the caller's buffer is not kept
+        ix->d_rows = nullptr;
+        hipError_t e = adopt_widened(ix, static_cast<const uint8_t *>(d_rows));
+        if (e != hipSuccess) { movi_index_destroy(ix); return fail_hip(e, "widening the 3-byte rows"); }
+    }
     rc = finish_create(ix);
     if (rc) { std::string keep = g_err; movi_index_destroy(ix); g_err = keep; return rc; }
     *out = ix;
@@ -395,6 +422,8 @@ int movi_index_get_desc(const movi_index_t *ix, movi_index_desc_t *desc) {
 
 int movi_index_device_rows(const movi_index_t *ix, const void **d_rows, size_t *bytes) {
     if (!ix || !d_rows || !bytes) return fail(MOVI_ERR_ARG, "NULL argument");
+    if (ix->desc.mode == MOVI_MODE_SAMPLED_THRESHOLDS)
+        return fail(MOVI_ERR_ARG, "sampled-thresholds rows are resident widened (4 B per row): broadcast the file bytes instead");
     *d_rows = ix->d_rows;
     *bytes = ix->rows_bytes;
     return MOVI_OK;

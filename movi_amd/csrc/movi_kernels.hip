@@ -33,6 +33,7 @@ constexpr int kIdbLdsEntries = 4096;   // mode-8 id_blocks entries held in LDS (
 //     off16:[9:0] offset, [12:10] c, [13] thr0, [14] thr1, [15] thr2
 //   mode 7 (3 B, sampled-thresholds; move_row.hpp:122-127, masks move_row_configs.hpp:120-136): no id in the row
 //     x = n8 | offset8 << 8 | cbyte << 16     cbyte: [0] offset bit 8, [1] n bit 8, [4:2] c, [5] thr0, [6] thr1, [7] thr2
+//     (resident as one dword per row, top byte zero)
 template <int MODE>
 __device__ __forceinline__ uint2 load_row(const uint8_t *rows, uint64_t i) {
     if (MODE == 6) {
@@ -46,12 +47,10 @@ __device__ __forceinline__ uint2 load_row(const uint8_t *rows, uint64_t i) {
         v >>= 8u * lead;
         return make_uint2((uint32_t)v, (uint32_t)(v >> 32) & 0xFFFFu);
     } else {
-        // 3-byte rows: one unaligned 4-byte load of the bytes [3i-1, 3i+3) (row 0: [0, 4)), same trick
-        const uint32_t lead = i ? 1u : 0u;
-        uint32_t v;
-        __builtin_memcpy(&v, rows + i * 3 - lead, 4);
-        v >>= 8u * lead;
-        return make_uint2(v & 0xFFFFFFu, 0u);
+        // 3-byte rows, WIDENED to one aligned dword per row when the index is uploaded (widen_rows_kernel):
+        // unaligned 4- and 16-byte loads of the packed bytes cost the texture addresser 2-5 passes per lane,
+        // and the sampled mode issues many row loads per step (12.3 -> see DESIGN.md section 5)
+        return make_uint2(*reinterpret_cast<const uint32_t *>(rows + i * 4), 0u);
     }
 }
 template <int MODE> __device__ __forceinline__ uint32_t row_n(uint2 w) {
@@ -158,117 +157,107 @@ __device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
 // run of each character is kept.  The id of row idx = the id stored at the next checkpoint for idx's character,
 // walked back over the destination rows by the BWT positions of that character between idx and the stored run.
 // Wave-uniform loops, predicated per lane (see the control-flow note above).  Returns r on the reference's throws.
-// Five consecutive 3-byte rows out of one unaligned 16-byte load (bytes [3i, 3i+16)): row t at byte 3t.
-__device__ __forceinline__ uint32_t row5(const uint4 &v, int t) {
-    switch (t) {
-        case 0: return v.x & 0xFFFFFFu;
-        case 1: return ((v.x >> 24) | (v.y << 8)) & 0xFFFFFFu;
-        case 2: return ((v.y >> 16) | (v.z << 16)) & 0xFFFFFFu;
-        case 3: return (v.z >> 8) & 0xFFFFFFu;
-        default: return v.w & 0xFFFFFFu;
-    }
-}
-__device__ __forceinline__ uint64_t tally_id(const DevIndex &ix, bool live, uint64_t idx, uint2 row) {
+// IdxT = uint32_t when the table has fewer than 2^32 rows.  Rows are read four at a time as the aligned 16-byte
+// group that holds them (the widened table has 16 bytes of slack, so the last group may be read whole).
+template <typename IdxT>
+__device__ __forceinline__ uint64_t tally_id_t(const DevIndex &ix, bool live, uint64_t idx64, uint2 row) {
+    const IdxT idx = (IdxT)idx64, r = (IdxT)ix.r, end_row = (IdxT)ix.end_bwt_idx;
     const uint32_t ci = row_c<7>(row);
-    const uint64_t cp = ix.tally_cp;
-    uint64_t id = live ? 0 : idx;                        // lanes that take no step keep their row (callers store the result)
+    const IdxT cp = (IdxT)ix.tally_cp;
+    IdxT id = live ? 0 : idx;                            // lanes that take no step keep their row (callers store the result)
     uint32_t walk = 0;                                   // 1 while the lane still scans / walks
-    uint64_t i = idx, next_cp = idx;
-    uint64_t rows_until = 0;
+    uint32_t bad = 0;                                    // one of the reference's throws (or an id >= r): returns r
+    IdxT next_cp = idx;
+    uint32_t rows_until = 0;                             // <= tally_cp rows of <= 511 positions
     uint32_t last_n = 0, last_off = 0, last_is_idx = 1;
-    if (live && idx != ix.end_bwt_idx) {                 // '$' goes to row 0 (:106-108)
-        const uint64_t ta = ix.r < 0xFFFFFFFFull ? (uint64_t)((uint32_t)idx / (uint32_t)cp) : idx / cp;
+    if (live && idx != end_row) {                        // '$' goes to row 0 (:106-108)
+        const IdxT ta = idx / cp;
         const uint64_t *tl = ix.tally + (uint64_t)ci * ix.tally_len;
-        if (idx == ix.r - 1) id = tl[ix.tally_len - 1];  // :114-117
-        else if (ta * cp == idx) id = tl[ta];            // :121-124
+        uint64_t raw;
+        if (idx == r - 1) raw = tl[ix.tally_len - 1];    // :114-117
+        else if (ta * cp == idx) raw = tl[ta];           // :121-124
         else {
             next_cp = (ta + 1) * cp;
-            if (next_cp >= ix.r) next_cp = ix.r - 1;     // :137-139
-            id = tl[ta + 1];
+            if (next_cp >= r) next_cp = r - 1;           // :137-139
+            raw = tl[ta + 1];
             walk = 1;
         }
+        id = (IdxT)raw;
+        if (raw >= ix.r) { bad = 1; walk = 0; }          // LF_move throws on it (move_structure.cpp:63-65)
     }
-    // rows of idx's character in [idx, next_cp) (:168-174); row idx itself is one of them.  Five rows per
-    // 16-byte load: the scattered row loads of this loop, not their latency, were what bound the kernel
-    // (one load per row: 9.7 Gbases/s on the pangenome).
+    // rows of idx's character in [idx, next_cp) (:168-174) -- row idx itself is one of them -- and the row at
+    // next_cp, group by group
     uint32_t scan = walk;
+    IdxT g = idx & ~(IdxT)3;
+    uint32_t wn = 0;                                     // the row at next_cp
     while (wave_any(scan != 0u)) {
         if (scan) {
-            if (i + 6 <= ix.r) {                         // bytes [3i, 3i+16) lie inside the table
-                uint4 v;
-                __builtin_memcpy(&v, ix.rows + i * 3, 16);
+            const uint4 v = *reinterpret_cast<const uint4 *>(ix.rows + (uint64_t)g * 4);
+            const uint32_t x[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-                for (int t = 0; t < 5; ++t) {
-                    const uint2 w = make_uint2(row5(v, t), 0u);
-                    const uint64_t it = i + (uint64_t)t;
-                    if (it < next_cp && it != ix.end_bwt_idx && row_c<7>(w) == ci) {
-                        rows_until += row_n<7>(w);
-                        last_n = row_n<7>(w);
-                        last_off = row_off<7>(w);
-                        last_is_idx = (it == idx) ? 1u : 0u;
-                    }
-                }
-                i += 5;
-            } else {
-                const uint2 w = load_row<7>(ix.rows, i);
-                if (i != ix.end_bwt_idx && row_c<7>(w) == ci) {
+            for (int t = 0; t < 4; ++t) {
+                const uint2 w = make_uint2(x[t], 0u);
+                const IdxT it = g + (IdxT)t;
+                if (it >= idx && it < next_cp && it != end_row && row_c<7>(w) == ci) {
                     rows_until += row_n<7>(w);
                     last_n = row_n<7>(w);
                     last_off = row_off<7>(w);
-                    last_is_idx = (i == idx) ? 1u : 0u;
+                    last_is_idx = (it == idx) ? 1u : 0u;
                 }
-                i += 1;
+                wn = (it == next_cp) ? x[t] : wn;
             }
-            scan = (i < next_cp) ? 1u : 0u;
+            g += 4;
+            scan = (g <= next_cp) ? 1u : 0u;
         }
     }
-    uint32_t back = 0;
+    // the stored id is idx's own (:178-180), or the walk starts at row id with `offset` positions to spare (:186-209)
+    uint32_t back = 0, offset = 0;
     if (walk) {
-        const uint2 wn = load_row<7>(ix.rows, next_cp);
-        const uint32_t same = (next_cp != ix.end_bwt_idx && row_c<7>(wn) == ci) ? 1u : 0u;
-        if (last_is_idx && !same) {
-            walk = 0;                                    // :178-180: the stored id is idx's own
-        } else {
-            uint32_t offset = row_off<7>(wn);
+        const uint2 wnr = make_uint2(wn, 0u);
+        const uint32_t same = (next_cp != end_row && row_c<7>(wnr) == ci) ? 1u : 0u;
+        if (!(last_is_idx && !same)) {
+            offset = row_off<7>(wnr);
             if (!same) { rows_until -= last_n; offset = last_off; }       // :194-197
-            if (id >= ix.r) { id = ix.r; walk = 0; }
-            else {
-                const uint32_t nid = row_n<7>(load_row<7>(ix.rows, id));
-                if (offset >= nid) { id = ix.r; walk = 0; }               // :200-203 throws
-                else if ((uint64_t)offset >= rows_until) walk = 0;        // :204-205
-                else { rows_until -= (uint64_t)offset + 1; back = 1; }    // :206-209 (id -= 1 below)
-            }
+            back = 1;
         }
     }
-    if (back) { if (id == 0) { id = ix.r; back = 0; } else id -= 1; }
-    // :211-219: walk the destination rows back, five rows (id-4 .. id) per 16-byte load
-    while (wave_any(back != 0u && rows_until != 0)) {
-        if (back && rows_until != 0) {
-            if (id >= 4 && id + 2 <= ix.r) {             // bytes [3(id-4), 3(id-4)+16) lie inside the table
-                uint4 v;
-                __builtin_memcpy(&v, ix.rows + (id - 4) * 3, 16);
-                uint32_t took = 0;
+    // :200-219: row id first (offset >= n(id) throws; offset >= rows_until: id it is; else rows_until -= offset + 1
+    // and on to id - 1), then `while (rows_until) { rows_until >= n(id) ? (rows_until -= n(id), id--) : rows_until = 0 }`
+    uint32_t first = 1;
+    while (wave_any(back != 0u)) {
+        if (back) {
+            const IdxT gb = id & ~(IdxT)3;
+            const uint4 v = *reinterpret_cast<const uint4 *>(ix.rows + (uint64_t)gb * 4);
+            const uint32_t x[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-                for (int t = 4; t >= 0; --t) {
-                    const uint32_t nid = row_n<7>(make_uint2(row5(v, t), 0u));
-                    if (rows_until != 0) {
-                        if (rows_until >= nid) { rows_until -= nid; took += 1; }
-                        else rows_until = 0;
+            for (int t = 3; t >= 0; --t) {
+                const uint32_t nrow = row_n<7>(make_uint2(x[t], 0u));
+                if (back && (gb + (IdxT)t) == id) {
+                    uint32_t step_down = 0;
+                    if (first) {
+                        first = 0;
+                        if (offset >= nrow) { bad = 1; back = 0; }
+                        else if (offset >= rows_until) back = 0;
+                        else { rows_until -= offset + 1; step_down = 1; }
+                    } else if (rows_until == 0) {
+                        back = 0;
+                    } else if (rows_until >= nrow) {
+                        rows_until -= nrow;
+                        step_down = 1;
+                    } else {
+                        rows_until = 0;
+                        back = 0;
                     }
-                }
-                if (took > id) { id = ix.r; rows_until = 0; } else id -= took;     // took <= 5 <= id + 1
-            } else {
-                const uint32_t nid = row_n<7>(load_row<7>(ix.rows, id));
-                if (rows_until >= nid) {
-                    rows_until -= nid;
-                    if (id == 0) { id = ix.r; rows_until = 0; } else id -= 1;
-                } else {
-                    rows_until = 0;
+                    if (step_down) { if (id == 0) { bad = 1; back = 0; } else id -= 1; }
                 }
             }
         }
     }
-    return id;
+    return bad ? ix.r : (uint64_t)id;
+}
+__device__ __forceinline__ uint64_t tally_id(const DevIndex &ix, bool live, uint64_t idx, uint2 row) {
+    if (ix.r < 0xFFFFFFFFull) return tally_id_t<uint32_t>(ix, live, idx, row);   // wave-uniform choice
+    return tally_id_t<uint64_t>(ix, live, idx, row);
 }
 
 // LF_move + fast_forward.  On entry `row` is rows[idx]; on exit it is the row of
@@ -759,8 +748,9 @@ __device__ __forceinline__ uint2 win_sel(const uint2 (&w)[4], uint32_t q) {
 //     gather's latency; the load is unpredicated and branch-free (the table's last window is pulled back to
 //     rows [r-4, r); finished lanes re-read window 0) -- with a predicated two-path fetch hipcc parked a
 //     `s_waitcnt vmcnt(0)` right behind the load and the overlap was gone;
-//   * read chunks double-buffered: the 8 bases after the current chunk are fetched when the chunk is entered, so
-//     the chunk load (always an L2 miss: its line was evicted long ago) overlaps eight row gathers.
+//   * read chunks double-buffered, 16 bases per fetch: the 16 bases after the current ones are fetched when a
+//     16-group is entered, so the chunk load (always an L2 miss: its line was evicted long ago) overlaps sixteen row
+//     gathers and costs 1/16 instead of 1/8 line per base; PMLs leave as paired 16-byte stores.
 // Measured (100 k x 10 kbp, Gbases/s, pangenome / random table): unpipelined window kernel (variant 8, removed)
 // 36.4 / 33.6; chunk double-buffering alone 35.1 / 32.4; pipelined HA = 1 / 2 / 3: 40.2 / 39.6 / 38.9 (pangenome),
 // 36.3 / 36.6 / 36.2 (random) -> HA = 2 shipped.  Hops after the step (HC > 0) measured slower and are gone.
@@ -802,6 +792,20 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
         }
         return v;
     };
+    // 16 bases per fetch when they exist (every read-chunk fetch is a 128-byte line from the fabric -- its line is
+    // evicted long before the lane comes back -- so 8-base fetches cost 0.125 lines per base, 11 % of all line fetches
+    // on c3): c0 = the 8 bases of steps kk .. kk+7, c1 = steps kk+8 .. kk+15
+    auto load_pair = [&](uint32_t kk, uint64_t &c0, uint64_t &c1) {
+        if ((uint64_t)kk + 16 <= len) {
+            uint64_t two[2];
+            __builtin_memcpy(two, R + len - kk - 16, 16);
+            c0 = two[1];
+            c1 = two[0];
+        } else {
+            c0 = kk < len ? load_chunk(kk) : 0;
+            c1 = kk + 8 < len ? load_chunk(kk + 8) : 0;
+        }
+    };
     // The 4-row window that holds row nd: aligned, except that the table's last window is pulled back to
     // rows [r-4, r) so that the fetch never leaves the table and needs no special case (r >= 4, checked at
     // launch).  Unpredicated: finished lanes re-read window 0 (a cache hit) instead of branching around the load.
@@ -819,10 +823,11 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
     uint32_t k = 0;
     uint32_t ml = 0, ff_run = 0;
     uint32_t off = row_n<MODE>(load_row<MODE>(ix.rows, r1)) - 1;
-    uint64_t rb = st != sDone ? load_chunk(0) : 0;
-    uint64_t rb_nx = len > 8 ? load_chunk(8) : 0;        // the chunk after the current one, already in flight
+    uint64_t rb = 0, rb2 = 0, nx0 = 0, nx1 = 0;           // current 8 bases, the 8 after them, and the next 16 (in flight)
+    if (st != sDone) load_pair(0, rb, rb2);
+    if (len > 16) load_pair(16, nx0, nx1);
     uint32_t a = s_code[(uint32_t)(rb >> 56) & 0xFFu];    // code of the base of step k (k = 0)
-    uint4 pk = make_uint4(0, 0, 0, 0);
+    uint4 pk = make_uint4(0, 0, 0, 0), pk_old = pk;
     ClsState cs;
     if (CLS) cs.init(len, cls.bin_width);
     uint2 w[4];
@@ -917,13 +922,23 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
                 pk.y = (pk.y >> 16) | (pk.z << 16);
                 pk.z = (pk.z >> 16) | (pk.w << 16);
                 pk.w = (pk.w >> 16) | (val << 16);
-                if ((k & 7) == 7) __builtin_memcpy(O + (k - 7), &pk, 16);
+                // 16 PMLs leave together as two adjacent 16-byte stores; an odd group of 8 before the tail on its own
+                if ((k & 15) == 7) {
+                    if (k + 8 < packed_end) pk_old = pk;
+                    else __builtin_memcpy(O + (k - 7), &pk, 16);
+                } else if ((k & 15) == 15) {
+                    __builtin_memcpy(O + (k - 15), &pk_old, 16);
+                    __builtin_memcpy(O + (k - 7), &pk, 16);
+                }
             }
             k += 1;
             if (lf) {
-                if ((k & 7) == 0) {
-                    rb = rb_nx;
-                    if (k + 8 < len) rb_nx = load_chunk(k + 8);
+                if ((k & 15) == 8) {
+                    rb = rb2;
+                } else if ((k & 15) == 0) {
+                    rb = nx0;
+                    rb2 = nx1;
+                    if (k + 16 < len) load_pair(k + 16, nx0, nx1);
                 }
                 a = s_code[(uint32_t)(rb >> (8 * (7 - (k & 7)))) & 0xFFu];
             }
@@ -1416,6 +1431,23 @@ __global__ __launch_bounds__(256) void chunk_sum_kernel(const uint8_t *__restric
     uint64_t s = 0;
     for (uint64_t k = lo; k < hi; ++k) s += row_n<MODE>(load_row<MODE>(rows, k));
     sums[j] = s;
+}
+
+// Mode 7 upload: the file's 3-byte rows -> one aligned dword per row (top byte zero).
+__global__ __launch_bounds__(256) void widen_rows_kernel(const uint8_t *__restrict__ packed, uint64_t r,
+                                                         uint32_t *__restrict__ wide) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= r) return;
+    const uint8_t *p = packed + i * 3;
+    wide[i] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+}
+
+hipError_t widen_rows(const uint8_t *d_packed, uint64_t r, uint32_t *d_wide, hipStream_t stream) {
+    const unsigned bt = 256;
+    const uint64_t blocks = (r + bt - 1) / bt;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(widen_rows_kernel, dim3((unsigned)blocks), dim3(bt), 0, stream, d_packed, r, d_wide);
+    return hipGetLastError();
 }
 
 hipError_t build_row_start_ckpt(int mode, const uint8_t *d_rows, uint64_t r, uint64_t *d_ckpt,

@@ -10,7 +10,7 @@ constexpr int kPrefixShift = 5;   // one BWT-position checkpoint every 32 rows (
 // What every kernel needs of the index, passed by value as a kernel argument
 // (lives in the kernarg segment: scalar loads, no per-lane traffic).
 struct DevIndex {
-    const uint8_t *rows;          // r * row_bytes, packed exactly as in index.movi
+    const uint8_t *rows;          // r * row_bytes, packed exactly as in index.movi (mode 7: widened to 4 B per row)
     const uint32_t *id_blocks;    // mode 8: [alphabet][n_blocks]
     const uint8_t *code_of;       // 256 bytes: ASCII -> code 0..3 (1..4 with separators), 0xFF = illegal
     const uint64_t *row_start_ckpt; // BWT position of row 32*j (count path), r/32+1 entries
@@ -79,6 +79,9 @@ hipError_t launch_zml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
 
 hipError_t launch_classify(const uint16_t *d_pml, const uint64_t *d_offsets, uint64_t n_reads, uint32_t bin_width,
                            uint32_t thr, uint32_t *d_above, uint32_t *d_below, uint64_t *d_sum, hipStream_t stream);
+
+// Mode 7: 3-byte file rows -> one dword per row (d_wide: r * 4 bytes + 16 of slack).
+hipError_t widen_rows(const uint8_t *d_packed, uint64_t r, uint32_t *d_wide, hipStream_t stream);
 
 // Fills ckpt[j] = BWT position of row (j << kPrefixShift), j = 0 .. ceil(r/32).
 hipError_t build_row_start_ckpt(int mode, const uint8_t *d_rows, uint64_t r, uint64_t *d_ckpt,

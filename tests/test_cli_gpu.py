@@ -324,3 +324,25 @@ def test_separators_index_through_the_cli(movi_bin, tmp_path, mode):
         m, c = cpu.count(seq)
         exp += rid + b"\t%d/%d\t%d\n" % (m, len(seq), c)
     assert r.stdout == exp
+
+
+# tests/test_pml.cpp:66-68, :98-100 of the reference: the sampled-thresholds index against the same golden file
+@pytest.mark.parametrize("flags", [["--no-prefetch", "-t1"], ["-s4", "-t1"]])
+def test_reference_cli_golden_sampled_thresholds(movi_bin, tmp_path, flags):
+    from oracle import build_index as B
+    ref = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))[0][1]
+    d = tmp_path / "sampled"
+    d.mkdir()
+    (d / "index.movi").write_bytes(B.build_index_from_seqs([ref], 7))
+    r = run(["query", "--index", str(d), "--read", os.path.join(GOLDEN, "sample.fastq"), "--pml"] + flags + ["--stdout"])
+    assert r.returncode == 0, r.stderr
+    assert b"sampled-thresholds" in r.stderr
+    got = b"".join(sorted(r.stdout.splitlines(keepends=True)))          # LC_ALL=C sort
+    assert got == open(os.path.join(GOLDEN, "sample.fastq.pmls.sorted"), "rb").read()
+    # file outputs carry the index type in their names (src/utils.cpp:348-362)
+    reads = tmp_path / "s.fastq"
+    shutil.copy(os.path.join(GOLDEN, "sample.fastq"), reads)
+    assert run(["query", "--index", str(d), "--read", str(reads), "--pml"]).returncode == 0
+    assert os.path.exists(str(reads) + ".sampled-thresholds.pml.bpf")
+    assert run(["query", "--index", str(d), "--read", str(reads), "--count"]).returncode == 0
+    assert os.path.exists(str(reads) + ".sampled-thresholds.count.matches")
