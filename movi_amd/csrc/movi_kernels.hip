@@ -713,7 +713,11 @@ __global__ __launch_bounds__(256) void pml_kernel_flat(DevIndex ix, const uint8_
 
 template <int MODE>
 __device__ __forceinline__ void load_window(const uint8_t *rows, uint64_t wbase, uint2 (&w)[4]) {
-    if (MODE == 6) {
+    if (MODE == 7) {                                      // widened rows: four dwords
+        uint4 p;
+        __builtin_memcpy(&p, rows + wbase * 4, 16);
+        w[0] = make_uint2(p.x, 0u); w[1] = make_uint2(p.y, 0u); w[2] = make_uint2(p.z, 0u); w[3] = make_uint2(p.w, 0u);
+    } else if (MODE == 6) {
         uint4 p0, p1;
         __builtin_memcpy(&p0, rows + wbase * 8, 16);
         __builtin_memcpy(&p1, rows + wbase * 8 + 16, 16);
@@ -1050,6 +1054,96 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     return hipGetLastError();
 }
 
+// update_interval, src/move_structure_search.cpp:48-61 (get_char: the '$' row never equals a base): move the interval's
+// start down to the first row of character b and its end up to the last one.  If [rs, re] holds such a row both searches
+// find one and start <= end; if it holds none the interval is empty, and that is all the callers use (the reference lets
+// the start run past the end instead).  So the two searches are independent, each bounded by the OTHER end's original row,
+// and each takes the 4-row window around its next row per trip (window base clamped to r - 4: never outside the table)
+// instead of one row: the trips of this loop -- max over the wave's lanes -- were most of a ZML step on divergent reads.
+template <int MODE>
+__device__ __forceinline__ void shrink_interval(const DevIndex &ix, bool act, uint32_t b, uint64_t &rs, uint32_t &os,
+                                                uint2 &rws, uint64_t &re, uint32_t &oe, uint2 &rwe,
+                                                uint32_t &scan_total) {
+    uint32_t gs = 0, ge = 0, dead = 0;
+    if (act) {
+        gs = (rs == ix.end_bwt_idx || row_c<MODE>(rws) != b) ? 1u : 0u;
+        ge = (re == ix.end_bwt_idx || row_c<MODE>(rwe) != b) ? 1u : 0u;
+    }
+    const uint64_t lo = rs, hi = re, wb_last = ix.r - 4;
+    while (wave_any((gs | ge) != 0u)) {
+        if (gs) {
+            if (rs >= hi) { dead = 1; gs = 0; ge = 0; }                  // no row of b in [lo, hi]
+            else {
+                uint64_t wb = (rs + 1) & ~3ull;
+                if (wb > wb_last) wb = wb_last;
+                uint2 w[4];
+                load_window<MODE>(ix.rows, wb, w);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (gs && wb + (uint64_t)t == rs + 1) {
+                        rs += 1;
+                        scan_total += 1;
+                        if (rs != ix.end_bwt_idx && row_c<MODE>(w[t]) == b) { rws = w[t]; gs = 0; }
+                        else if (rs >= hi) { dead = 1; gs = 0; ge = 0; }
+                    }
+                }
+                os = 0;
+            }
+        }
+        if (ge) {
+            if (re <= lo) { dead = 1; gs = 0; ge = 0; }
+            else {
+                uint64_t wb = (re - 1) & ~3ull;
+                if (wb > wb_last) wb = wb_last;
+                uint2 w[4];
+                load_window<MODE>(ix.rows, wb, w);
+#pragma unroll
+                for (int t = 3; t >= 0; --t) {
+                    if (ge && wb + (uint64_t)t + 1 == re) {
+                        re -= 1;
+                        scan_total += 1;
+                        if (re != ix.end_bwt_idx && row_c<MODE>(w[t]) == b) { rwe = w[t]; oe = row_n<MODE>(w[t]) - 1; ge = 0; }
+                        else if (re <= lo) { dead = 1; gs = 0; ge = 0; }
+                    }
+                }
+            }
+        }
+    }
+    if (dead) { rs = 1; re = 0; os = 0; oe = 0; }                        // empty, whatever the rows were
+}
+
+// The same, one row per end and trip (tables too small for a window).
+template <int MODE>
+__device__ __forceinline__ void shrink_interval_rows(const DevIndex &ix, bool act, uint32_t b, uint64_t &rs, uint32_t &os,
+                                                     uint2 &rws, uint64_t &re, uint32_t &oe, uint2 &rwe,
+                                                     uint32_t &scan_total) {
+    uint32_t gs = 0, ge = 0;
+    if (act) {
+        gs = (rs == ix.end_bwt_idx || row_c<MODE>(rws) != b) ? 1u : 0u;
+        ge = (re == ix.end_bwt_idx || row_c<MODE>(rwe) != b) ? 1u : 0u;
+    }
+    while (wave_any((gs | ge) != 0u)) {
+        uint2 ws = rws, we = rwe;
+        if (gs && rs + 1 < ix.r) ws = load_row<MODE>(ix.rows, rs + 1);
+        if (ge && re > 0) we = load_row<MODE>(ix.rows, re - 1);
+        if (gs) {
+            rs += 1; os = 0; scan_total += 1;
+            if (rs >= ix.r || rs > re) { gs = 0; ge = 0; }
+            else { rws = ws; gs = (rs == ix.end_bwt_idx || row_c<MODE>(rws) != b) ? 1u : 0u; }
+        }
+        if (ge) {
+            if (re == 0) { ge = 0; gs = 0; rs = 1; }          // nothing above row 0: empty
+            else {
+                re -= 1; scan_total += 1;
+                rwe = we;
+                oe = row_n<MODE>(rwe) - 1;
+                if (re < rs) { ge = 0; gs = 0; }
+                else ge = (re == ix.end_bwt_idx || row_c<MODE>(rwe) != b) ? 1u : 0u;
+            }
+        }
+    }
+}
+
 // ----------------------------------------------------------------------- count
 
 // BWT position of (row k, offset 0) from the 32-row checkpoints.
@@ -1124,30 +1218,10 @@ __global__ __launch_bounds__(256) void count_kernel_v0(DevIndex ix, const uint8_
         // Both ends shrink in ONE wave-uniform loop, one row per end and trip.  When the interval
         // holds no row of character b the two ends cross instead of rs running all the way past re as
         // in the reference; either way the interval is empty and the previous one is reported.
-        uint32_t gs = 0, ge = 0;
-        if (legal && rs <= re) {
-            gs = (rs == ix.end_bwt_idx || row_c<MODE>(rws) != b) ? 1u : 0u;
-            ge = (re == ix.end_bwt_idx || row_c<MODE>(rwe) != b) ? 1u : 0u;
-        }
-        while (wave_any((gs | ge) != 0u)) {
-            uint2 ws = rws, we = rwe;
-            if (gs && rs + 1 < ix.r) ws = load_row<MODE>(ix.rows, rs + 1);
-            if (ge && re > 0) we = load_row<MODE>(ix.rows, re - 1);
-            if (gs) {
-                rs += 1; os = 0; scan_total += 1;
-                if (rs >= ix.r || rs > re) { gs = 0; ge = 0; }
-                else { rws = ws; gs = (rs == ix.end_bwt_idx || row_c<MODE>(rws) != b) ? 1u : 0u; }
-            }
-            if (ge) {
-                if (re == 0) { ge = 0; gs = 0; rs = 1; }          // nothing above row 0: empty
-                else {
-                    re -= 1; scan_total += 1;
-                    rwe = we;
-                    oe = row_n<MODE>(rwe) - 1;
-                    if (re < rs) { ge = 0; gs = 0; }
-                    else ge = (re == ix.end_bwt_idx || row_c<MODE>(rwe) != b) ? 1u : 0u;
-                }
-            }
+        if (ix.r >= 8) {
+            shrink_interval<MODE>(ix, legal && rs <= re, b, rs, os, rws, re, oe, rwe, scan_total);
+        } else {
+            shrink_interval_rows<MODE>(ix, legal && rs <= re, b, rs, os, rws, re, oe, rwe, scan_total);
         }
         bool nonempty = legal && ((rs < re) || (rs == re && os <= oe));
         if (legal && !nonempty) { empty = 1; run = 0; }
@@ -1267,30 +1341,10 @@ __global__ __launch_bounds__(256) void zml_kernel(DevIndex ix, const uint8_t *__
         if (live) b = s_code[(uint32_t)(rb >> (8 * (7 - (k & 7)))) & 0xFFu];
         // backward_search_step, src/move_structure_search.cpp:311-333, for lanes with an open phrase
         const bool ext = live && open != 0u && b != 0xFFu;
-        uint32_t gs = 0, ge = 0;
-        if (ext && rs <= re) {                            // update_interval :48-61, as in count_kernel_v0
-            gs = (rs == ix.end_bwt_idx || row_c<MODE>(rws) != b) ? 1u : 0u;
-            ge = (re == ix.end_bwt_idx || row_c<MODE>(rwe) != b) ? 1u : 0u;
-        }
-        while (wave_any((gs | ge) != 0u)) {
-            uint2 ws = rws, we = rwe;
-            if (gs && rs + 1 < ix.r) ws = load_row<MODE>(ix.rows, rs + 1);
-            if (ge && re > 0) we = load_row<MODE>(ix.rows, re - 1);
-            if (gs) {
-                rs += 1; os = 0; scan_total += 1;
-                if (rs >= ix.r || rs > re) { gs = 0; ge = 0; }
-                else { rws = ws; gs = (rs == ix.end_bwt_idx || row_c<MODE>(rws) != b) ? 1u : 0u; }
-            }
-            if (ge) {
-                if (re == 0) { ge = 0; gs = 0; rs = 1; }
-                else {
-                    re -= 1; scan_total += 1;
-                    rwe = we;
-                    oe = row_n<MODE>(rwe) - 1;
-                    if (re < rs) { ge = 0; gs = 0; }
-                    else ge = (re == ix.end_bwt_idx || row_c<MODE>(rwe) != b) ? 1u : 0u;
-                }
-            }
+        if (ix.r >= 8) {                     // update_interval :48-61, as in count_kernel_v0
+            shrink_interval<MODE>(ix, ext && rs <= re, b, rs, os, rws, re, oe, rwe, scan_total);
+        } else {
+            shrink_interval_rows<MODE>(ix, ext && rs <= re, b, rs, os, rws, re, oe, rwe, scan_total);
         }
         bool nonempty = ext && ((rs < re) || (rs == re && os <= oe));
         const uint32_t e12 = lf_step2<MODE>(ix, nonempty, rs, os, rws, re, oe, rwe, ff_total, idb);

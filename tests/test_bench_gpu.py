@@ -1,0 +1,47 @@
+"""GPU suite: bench.py's contract line, N = 1 and the N > 1 code path (index broadcast, per-rank read shards, barrier +
+max-over-ranks timing).  A 1-GPU box cannot run two RCCL ranks, so the N = 2 case uses the bench's own test hook
+MOVI_BENCH_SHARE_GPU=1: both ranks on cuda:0, collectives over gloo, everything else as in production."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline")
+
+
+def _line(out):
+    lines = [l for l in out.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_single_gpu_contract():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "tiny", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _line(r.stdout)
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and d["parity_sample_ok"] is True
+
+
+@pytest.mark.parametrize("query", ["pml", "count"])
+def test_bench_two_ranks_share_one_gpu(query):
+    env = dict(os.environ, MOVI_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533" if query == "pml" else "29534", os.path.join(ROOT, "bench.py"), "--gpus", "2",
+           "--workload", "tiny", "--steps", "3", "--warmup", "1", "--query", query]
+    r = subprocess.run(cmd, capture_output=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _line(r.stdout)
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    assert d["config"]["bases_per_step_per_gpu"] == 20000 * 150
+    assert "cpu_baseline" not in d                      # rank 0, N == 1 only
