@@ -235,6 +235,7 @@ static int finish_create(movi_index *ix) {
     v.tally = ix->d_tally;
     v.tally_len = d.n_tally;
     v.tally_cp = d.tally_checkpoints ? d.tally_checkpoints : 1;
+    v.idx32 = d.r < 0xFFFFFFFFull ? 1u : 0u;
     for (int i = 0; i < 4; i++) v.end_thr[i] = d.end_bwt_idx_thresholds[i];
     for (int i = 0; i < 6; i++) {
         v.first_runs[i] = d.first_runs[i];
@@ -435,6 +436,11 @@ int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
         if (value != -1 && value != 0 && value != 1 && value != 7 && value != 10)
             return fail(MOVI_ERR_ARG, "pml_variant must be -1 (auto), 0, 1, 7 or 10");
         ix->cfg.pml_variant = (int)value;
+        return MOVI_OK;
+    }
+    if (!strcmp(key, "idx64")) {                             // test hook: run the 64-bit-index kernel instantiations
+        if (value != 0 && value != 1) return fail(MOVI_ERR_ARG, "idx64 must be 0 or 1");
+        ix->dev.idx32 = (value == 0 && ix->desc.r < 0xFFFFFFFFull) ? 1u : 0u;
         return MOVI_OK;
     }
     if (!strcmp(key, "block_threads")) {

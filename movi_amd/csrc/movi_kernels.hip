@@ -256,7 +256,7 @@ __device__ __forceinline__ uint64_t tally_id_t(const DevIndex &ix, bool live, ui
     return bad ? ix.r : (uint64_t)id;
 }
 __device__ __forceinline__ uint64_t tally_id(const DevIndex &ix, bool live, uint64_t idx, uint2 row) {
-    if (ix.r < 0xFFFFFFFFull) return tally_id_t<uint32_t>(ix, live, idx, row);   // wave-uniform choice
+    if (ix.idx32) return tally_id_t<uint32_t>(ix, live, idx, row);               // wave-uniform choice
     return tally_id_t<uint64_t>(ix, live, idx, row);
 }
 
@@ -1000,7 +1000,7 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     } while (0)
 #define MOVI_LAUNCH_FLATP_S(M, C, S)                                                                        \
     do {                                                                                                    \
-        if (ix.r < 0xFFFFFFFFull)                                                                           \
+        if (ix.idx32)                                                                                       \
             hipLaunchKernelGGL((pml_kernel_flatp<M, uint32_t, 2, C, S>), grid, block, dyn_lds, stream, ix,  \
                                d_bases, d_offsets, n_reads, d_out, d_err, d_stats, d_order, cls);           \
         else                                                                                                \
@@ -1013,7 +1013,7 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     } while (0)
 #define MOVI_LAUNCH_FLAT(M)                                                                                 \
     do {                                                                                                    \
-        if (ix.r < 0xFFFFFFFFull)                                                                           \
+        if (ix.idx32)                                                                                       \
             hipLaunchKernelGGL((pml_kernel_flat<M, uint32_t, 0>), grid, block, dyn_lds, stream, ix,         \
                                d_bases, d_offsets, n_reads, d_out, d_err, d_stats, d_order, cls);           \
         else                                                                                                \

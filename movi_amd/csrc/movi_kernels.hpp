@@ -34,6 +34,10 @@ struct DevIndex {
     const uint64_t *tally;
     uint64_t tally_len;
     uint64_t tally_cp;            // rows between checkpoints (movi build --checkpoint, default 20)
+    // 1: row indexes fit 32 bits (r < 2^32 - 1) -> the kernels' uint32_t instantiations; the "idx64" option clears it so
+    // that tests can run the 64-bit instantiations (tables beyond 4 G rows) on small indexes
+    uint32_t idx32;
+    uint32_t pad_;
 };
 
 // Device counters of one query call.

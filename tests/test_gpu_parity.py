@@ -651,3 +651,33 @@ def test_sampled_thresholds_fuzz(built_lib, seed):
         z, _ = gpu.query_zml_packed(bases, offs)
         assert (z == cpu.zml_batch(bases, offs, threads=2)).all(), (seed, separators)
         gpu.close()
+
+
+@pytest.mark.parametrize("mode", [6, 7, 8])
+def test_64bit_index_instantiations(built_lib, golden_image, mode):
+    """Tables of 2^32 rows and more run the uint64_t instantiations of the state-machine kernels and of the sampled
+    mode's get_id; no test table is that large, so the "idx64" option routes a small index through them."""
+    import movi_amd
+    from oracle import build_index as B
+    from oracle.oracle import Oracle
+    ref = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))[0][1]
+    img = golden_image(mode) if mode != 7 else B.build_index_from_seqs([ref], 7)
+    gpu, cpu = movi_amd.MoveIndex.from_image(img), Oracle(img)
+    rng = np.random.default_rng(640 + mode)
+    reads = mutated_reads(rng, ref, 300, 1, 1200) + [b"", b"A", b"N", b"ACGT" * 100]
+    bases, offs = pack(reads)
+    exp, ff, sc = cpu.pml_batch(bases, offs, threads=4)
+    gpu.set_option("idx64", 1)
+    for variant in ((7, 10) if mode != 7 else (-1,)):
+        gpu.set_option("pml_variant", variant)
+        out, st = gpu.query_pml_packed(bases, offs)
+        assert (out == exp).all(), (mode, variant)
+        assert (st.fast_forwards, st.scans, st.errors) == (ff, sc, 0)
+    m, c, _ = gpu.query_count_packed(bases, offs)
+    em, ec = cpu.count_batch(bases, offs, threads=4)
+    assert (m == em).all() and (c == ec).all()
+    gpu.set_option("idx64", 0)
+    gpu.set_option("pml_variant", -1)
+    out, _ = gpu.query_pml_packed(bases, offs)
+    assert (out == exp).all()
+    gpu.close()
