@@ -36,8 +36,8 @@ WORKLOADS = {
     "c2b": dict(kind="pangenome", mode=8, reads=1_000_000, read_len=150, sub=0.01,
                 desc="same pangenome as blocked-thresholds (6 B rows), 1M x 150bp reads per GPU"),
     "c2s": dict(kind="pangenome", mode=7, reads=1_000_000, read_len=150, sub=0.01,
-                desc="same pangenome as sampled-thresholds (3 B rows, ids recovered from checkpoints every 20 rows), "
-                     "1M x 150bp reads per GPU"),
+                desc="same pangenome as sampled-thresholds (3 B rows + id checkpoints every 20 rows on disk; expanded to "
+                     "regular-thresholds rows on the GPU at upload), 1M x 150bp reads per GPU"),
     "c2synth": dict(kind="synth", rows=10_000_000, mode=6, reads=1_000_000, read_len=150, sub=0.01,
                     desc="random 10M-row regular-thresholds table (worst-case step mix), 1M x 150bp reads per GPU"),
     "c3synth": dict(kind="synth", rows=10_000_000, mode=6, reads=100_000, read_len=10_000, sub=0.08,
@@ -147,7 +147,7 @@ def main():
     if args.rows: wl["rows"] = args.rows
     if args.reads: wl["reads"] = args.reads
     if args.read_len: wl["read_len"] = args.read_len
-    ROW_BYTES = {6: 8, 8: 6, 7: 3}
+    ROW_BYTES = {6: 8, 8: 6, 7: 8}       # resident row bytes: sampled-thresholds rows are expanded to the mode-6 layout at upload
     mode, row_bytes = wl["mode"], ROW_BYTES[wl["mode"]]
 
     # ---- index: every rank derives the same host-side structure from the seed (needed to
@@ -306,12 +306,13 @@ def main():
     # which PML kernel launch_pml picked (movi_kernels.hip: state machine for <= 12 waves/CU of reads, mode 6 / 8)
     n_cus = torch.cuda.get_device_properties(dev).multi_processor_count
     v_sel = args.variant if args.variant >= 0 else (10 if n_reads <= n_cus * 64 * 12 else 1)
-    if mode == 7 or (args.classify and v_sel == 0):
+    if args.classify and v_sel == 0:
         v_sel = 1
     if args.classify and v_sel == 7:
         v_sel = 10
-    pml_kernel_name = {0: "pml_kernel<%d,0>" % mode, 1: "pml_kernel<%d,1>" % mode, 7: "pml_kernel_flat<%d>" % mode,
-                       10: "pml_kernel_flatp<%d>" % mode}[v_sel]
+    kmode = 6 if mode == 7 else mode
+    pml_kernel_name = {0: "pml_kernel<%d,0>" % kmode, 1: "pml_kernel<%d,1>" % kmode, 7: "pml_kernel_flat<%d>" % kmode,
+                       10: "pml_kernel_flatp<%d>" % kmode}[v_sel]
     f_bar = st.fast_forwards / max(n_bases, 1)
     s_bar = st.scans / max(n_bases, 1)
     bytes_per_base = row_bytes * (1.0 + f_bar + s_bar) + 1 + 2

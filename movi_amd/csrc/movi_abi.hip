@@ -74,6 +74,7 @@ struct movi_index {
     uint64_t *d_ckpt = nullptr;      // built lazily by the first count query
     DevStats *d_stats = nullptr;
     DevIndex dev{};
+    int kmode = 0;                   // row layout the kernels run on: desc.mode, except 6 for sampled-thresholds (expanded)
     LaunchCfg cfg;
 };
 
@@ -236,6 +237,26 @@ static int finish_create(movi_index *ix) {
     v.tally_len = d.n_tally;
     v.tally_cp = d.tally_checkpoints ? d.tally_checkpoints : 1;
     v.idx32 = d.r < 0xFFFFFFFFull ? 1u : 0u;
+    ix->kmode = (int)d.mode;
+    if (d.mode == MOVI_MODE_SAMPLED_THRESHOLDS) {
+        // expand to regular-thresholds rows once (movi_kernels.hip, expand_sampled_kernel); the widened rows and the
+        // tally table are only needed for that
+        if (d.r >= (1ull << 36)) return fail(MOVI_ERR_ARG, "sampled-thresholds index with 2^36 rows or more");
+        uint8_t *rows6 = nullptr;
+        HIP_TRY(hipMalloc(&rows6, (size_t)d.r * 8 + 16));
+        hipError_t e = hipMemset(rows6, 0, (size_t)d.r * 8 + 16);
+        if (e == hipSuccess) e = expand_sampled_rows(v, rows6, nullptr);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e != hipSuccess) { (void)hipFree(rows6); return fail_hip(e, "expanding the sampled rows"); }
+        if (ix->owns_rows && ix->d_rows) (void)hipFree(ix->d_rows);
+        (void)hipFree(ix->d_tally);
+        ix->d_tally = nullptr;
+        ix->d_rows = rows6;
+        ix->owns_rows = true;
+        v.rows = rows6;
+        v.tally = nullptr;
+        ix->kmode = MOVI_MODE_REGULAR_THRESHOLDS;
+    }
     for (int i = 0; i < 4; i++) v.end_thr[i] = d.end_bwt_idx_thresholds[i];
     for (int i = 0; i < 6; i++) {
         v.first_runs[i] = d.first_runs[i];
@@ -423,10 +444,9 @@ int movi_index_get_desc(const movi_index_t *ix, movi_index_desc_t *desc) {
 
 int movi_index_device_rows(const movi_index_t *ix, const void **d_rows, size_t *bytes) {
     if (!ix || !d_rows || !bytes) return fail(MOVI_ERR_ARG, "NULL argument");
-    if (ix->desc.mode == MOVI_MODE_SAMPLED_THRESHOLDS)
-        return fail(MOVI_ERR_ARG, "sampled-thresholds rows are resident widened (4 B per row): broadcast the file bytes instead");
     *d_rows = ix->d_rows;
-    *bytes = ix->rows_bytes;
+    // sampled-thresholds: the resident table is the EXPANDED one (r rows of the 8-byte regular-thresholds layout)
+    *bytes = ix->desc.mode == MOVI_MODE_SAMPLED_THRESHOLDS ? (size_t)ix->desc.r * 8 : ix->rows_bytes;
     return MOVI_OK;
 }
 
@@ -470,10 +490,10 @@ static int ml_device(bool zml, movi_index_t *ix, const uint8_t *d_bases, const u
     HIP_TRY(hipMemsetAsync(ix->d_stats, 0, sizeof(DevStats), s));
     if (n_reads > 0xFFFFFFFFull) return fail(MOVI_ERR_ARG, "more than 2^32 reads in one call");
     if (zml)
-        HIP_TRY(launch_zml((int)ix->desc.mode, ix->dev, d_bases, d_offsets, n_reads, d_out, d_read_err, ix->d_stats,
+        HIP_TRY(launch_zml(ix->kmode, ix->dev, d_bases, d_offsets, n_reads, d_out, d_read_err, ix->d_stats,
                            d_read_order, ix->cfg, s));
     else
-        HIP_TRY(launch_pml((int)ix->desc.mode, ix->dev, d_bases, d_offsets, n_reads, d_out, d_read_err, ix->d_stats,
+        HIP_TRY(launch_pml(ix->kmode, ix->dev, d_bases, d_offsets, n_reads, d_out, d_read_err, ix->d_stats,
                            d_read_order, ix->cfg, s, cls));
     return MOVI_OK;
 }
@@ -696,7 +716,7 @@ static int ensure_ckpt(movi_index *ix, hipStream_t s) {
     if (ix->d_ckpt) return MOVI_OK;
     const uint64_t n_chunks = (ix->desc.r + (1ull << kPrefixShift) - 1) >> kPrefixShift;
     HIP_TRY(hipMalloc(&ix->d_ckpt, (n_chunks + 1) * sizeof(uint64_t)));
-    hipError_t e = build_row_start_ckpt((int)ix->desc.mode, ix->d_rows, ix->desc.r, ix->d_ckpt, s);
+    hipError_t e = build_row_start_ckpt(ix->kmode, ix->d_rows, ix->desc.r, ix->d_ckpt, s);
     if (e != hipSuccess) {
         (void)hipFree(ix->d_ckpt);
         ix->d_ckpt = nullptr;
@@ -718,7 +738,7 @@ int movi_count_device(movi_index_t *ix, const uint8_t *d_bases, const uint64_t *
     if (rc) return rc;
     HIP_TRY(hipMemsetAsync(ix->d_stats, 0, sizeof(DevStats), s));
     if (n_reads > 0xFFFFFFFFull) return fail(MOVI_ERR_ARG, "more than 2^32 reads in one call");
-    HIP_TRY(launch_count((int)ix->desc.mode, ix->dev, d_bases, d_offsets, n_reads, d_matched, d_count,
+    HIP_TRY(launch_count(ix->kmode, ix->dev, d_bases, d_offsets, n_reads, d_matched, d_count,
                          d_read_err, ix->d_stats, d_read_order, ix->cfg, s));
     return MOVI_OK;
 }

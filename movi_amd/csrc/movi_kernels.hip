@@ -33,7 +33,7 @@ constexpr int kIdbLdsEntries = 4096;   // mode-8 id_blocks entries held in LDS (
 //     off16:[9:0] offset, [12:10] c, [13] thr0, [14] thr1, [15] thr2
 //   mode 7 (3 B, sampled-thresholds; move_row.hpp:122-127, masks move_row_configs.hpp:120-136): no id in the row
 //     x = n8 | offset8 << 8 | cbyte << 16     cbyte: [0] offset bit 8, [1] n bit 8, [4:2] c, [5] thr0, [6] thr1, [7] thr2
-//     (resident as one dword per row, top byte zero)
+//     (widened to one dword per row at upload, then expanded to mode-6 rows: expand_sampled_kernel)
 template <int MODE>
 __device__ __forceinline__ uint2 load_row(const uint8_t *rows, uint64_t i) {
     if (MODE == 6) {
@@ -47,9 +47,8 @@ __device__ __forceinline__ uint2 load_row(const uint8_t *rows, uint64_t i) {
         v >>= 8u * lead;
         return make_uint2((uint32_t)v, (uint32_t)(v >> 32) & 0xFFFFu);
     } else {
-        // 3-byte rows, WIDENED to one aligned dword per row when the index is uploaded (widen_rows_kernel):
-        // unaligned 4- and 16-byte loads of the packed bytes cost the texture addresser 2-5 passes per lane,
-        // and the sampled mode issues many row loads per step (12.3 -> see DESIGN.md section 5)
+        // 3-byte rows, widened to one aligned dword per row when the index is uploaded (widen_rows_kernel); only
+        // expand_sampled_kernel reads them: queries run on the mode-6 rows it writes
         return make_uint2(*reinterpret_cast<const uint32_t *>(rows + i * 4), 0u);
     }
 }
@@ -713,11 +712,8 @@ __global__ __launch_bounds__(256) void pml_kernel_flat(DevIndex ix, const uint8_
 
 template <int MODE>
 __device__ __forceinline__ void load_window(const uint8_t *rows, uint64_t wbase, uint2 (&w)[4]) {
-    if (MODE == 7) {                                      // widened rows: four dwords
-        uint4 p;
-        __builtin_memcpy(&p, rows + wbase * 4, 16);
-        w[0] = make_uint2(p.x, 0u); w[1] = make_uint2(p.y, 0u); w[2] = make_uint2(p.z, 0u); w[3] = make_uint2(p.w, 0u);
-    } else if (MODE == 6) {
+    static_assert(MODE == 6 || MODE == 8, "queries never run on mode-7 rows (expanded to mode 6 at upload)");
+    if (MODE == 6) {
         uint4 p0, p1;
         __builtin_memcpy(&p0, rows + wbase * 8, 16);
         __builtin_memcpy(&p1, rows + wbase * 8 + 16, 16);
@@ -1036,10 +1032,7 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     if (v < 0) v = (n_reads <= (uint64_t)cfg.num_cus * 64u * 12u) ? 10 : 1;  // measured crossover: ~12 waves per CU
     if (v == 10 && ix.r < 8) v = 7;                                          // the clamped window needs >= 4 rows
     if (cm != 0 && (v == 0 || v == 7)) v = (v == 0) ? 1 : (ix.r < 8 ? 1 : 10);   // the A/B kernels carry no fused bins
-    if (mode == 7) {
-        // sampled-thresholds: 3-byte rows, ids from the checkpoints -- the base-synchronous kernel only
-        MOVI_BY_CLS(MOVI_LAUNCH_PML, 7, 1);
-    } else if (mode == 6) {
+    if (mode == 6) {
         if (v == 0) MOVI_LAUNCH_PML(6, 0, 0); else if (v == 1) MOVI_BY_CLS(MOVI_LAUNCH_PML, 6, 1);
         else if (v == 7) MOVI_LAUNCH_FLAT(6); else MOVI_BY_CLS(MOVI_LAUNCH_FLATP, 6);
     } else {
@@ -1262,10 +1255,7 @@ hipError_t launch_count(int mode, const DevIndex &ix, const uint8_t *d_bases, co
     const uint64_t blocks = (n_reads + bt - 1) / bt;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     dim3 grid((unsigned)blocks), block((unsigned)bt);
-    if (mode == 7)
-        hipLaunchKernelGGL(count_kernel_v0<7>, grid, block, 0, stream, ix, d_bases, d_offsets, n_reads,
-                           d_matched, d_count, d_err, d_stats, d_order);
-    else if (mode == 6)
+    if (mode == 6)
         hipLaunchKernelGGL(count_kernel_v0<6>, grid, block, 0, stream, ix, d_bases, d_offsets, n_reads,
                            d_matched, d_count, d_err, d_stats, d_order);
     else
@@ -1404,10 +1394,7 @@ hipError_t launch_zml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     const uint64_t blocks = (n_reads + bt - 1) / bt;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     dim3 grid((unsigned)blocks), block((unsigned)bt);
-    if (mode == 7)
-        hipLaunchKernelGGL(zml_kernel<7>, grid, block, 0, stream, ix, d_bases, d_offsets, n_reads, d_out, d_err,
-                           d_stats, d_order);
-    else if (mode == 6)
+    if (mode == 6)
         hipLaunchKernelGGL(zml_kernel<6>, grid, block, 0, stream, ix, d_bases, d_offsets, n_reads, d_out, d_err,
                            d_stats, d_order);
     else
@@ -1504,6 +1491,33 @@ hipError_t widen_rows(const uint8_t *d_packed, uint64_t r, uint32_t *d_wide, hip
     return hipGetLastError();
 }
 
+// Sampled-thresholds -> regular-thresholds rows, once per index: the sampled format trades time for space (no id in
+// the row; MoveStructure::get_id scans to the next checkpoint and walks the destination rows back, two dependent
+// misses and ~1300 VALU instructions per LF here), a trade that makes no sense next to 288 GB of HBM.  So the ids are
+// recovered ONCE, on the GPU, by that very get_id (tally_id above), and written out in the 8-byte layout of mode 6
+// (n <= 511, 9-bit offsets, the same three threshold bits and character: everything fits); queries then run the mode-6
+// kernels, state machines included, on identical rows -- identical answers, fast-forward and scan counts included.
+__global__ __launch_bounds__(256) void expand_sampled_kernel(DevIndex ix, uint2 *__restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < ix.r;
+    const uint2 row = live ? load_row<7>(ix.rows, i) : make_uint2(0u, 0u);
+    const uint64_t id = tally_id(ix, live, i, row);                     // r on the reference's throws: LF_move rejects it
+    if (live) {
+        const uint32_t n = row_n<7>(row), off = row_off<7>(row), c = row_c<7>(row);
+        const uint32_t n16 = n | (row_thr<7>(row, 1) << 11) | (row_thr<7>(row, 2) << 12) | (c << 13);
+        const uint32_t off16 = off | (row_thr<7>(row, 0) << 11) | ((uint32_t)((id >> 32) & 0xFu) << 12);
+        out[i] = make_uint2((uint32_t)id, n16 | (off16 << 16));
+    }
+}
+
+hipError_t expand_sampled_rows(const DevIndex &ix, void *d_rows6, hipStream_t stream) {
+    const unsigned bt = 256;
+    const uint64_t blocks = (ix.r + bt - 1) / bt;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(expand_sampled_kernel, dim3((unsigned)blocks), dim3(bt), 0, stream, ix, static_cast<uint2 *>(d_rows6));
+    return hipGetLastError();
+}
+
 hipError_t build_row_start_ckpt(int mode, const uint8_t *d_rows, uint64_t r, uint64_t *d_ckpt,
                                 hipStream_t stream) {
     // d_ckpt has n_chunks + 1 entries; entry j = sum of n over rows [0, 32 j).
@@ -1515,9 +1529,7 @@ hipError_t build_row_start_ckpt(int mode, const uint8_t *d_rows, uint64_t r, uin
     if (e != hipSuccess) { (void)hipFree(d_sums); return e; }
     const unsigned bt = 256;
     const unsigned blocks = (unsigned)((n_chunks + bt - 1) / bt);
-    if (mode == 7)
-        hipLaunchKernelGGL(chunk_sum_kernel<7>, dim3(blocks), dim3(bt), 0, stream, d_rows, r, n_chunks, d_sums);
-    else if (mode == 6)
+    if (mode == 6)
         hipLaunchKernelGGL(chunk_sum_kernel<6>, dim3(blocks), dim3(bt), 0, stream, d_rows, r, n_chunks, d_sums);
     else
         hipLaunchKernelGGL(chunk_sum_kernel<8>, dim3(blocks), dim3(bt), 0, stream, d_rows, r, n_chunks, d_sums);

@@ -681,3 +681,24 @@ def test_64bit_index_instantiations(built_lib, golden_image, mode):
     out, _ = gpu.query_pml_packed(bases, offs)
     assert (out == exp).all()
     gpu.close()
+
+
+def test_sampled_expansion_equals_regular_rows(built_lib, golden_image):
+    """The sampled index is expanded on the GPU to regular-thresholds rows by the reference's get_id.  On ref.fasta the
+    511-base run cap of mode 7 splits nothing further (r = 118209 in both modes), so the expanded table must equal the row
+    table of the KAT-pinned regular-thresholds index byte for byte: every id, offset, length, character and threshold bit."""
+    import ctypes as C
+    import movi_amd
+    from oracle import build_index as B
+    ref = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))[0][1]
+    gpu = movi_amd.MoveIndex.from_image(B.build_index_from_seqs([ref], 7))
+    ptr, n = gpu.device_rows()
+    assert n == 118209 * 8
+    host = np.empty(n, np.uint8)
+    hip = C.CDLL("libamdhip64.so")
+    assert hip.hipMemcpy(C.c_void_p(host.ctypes.data), C.c_void_p(ptr), C.c_size_t(n), C.c_int(2)) == 0   # device -> host
+    img6 = np.frombuffer(golden_image(6), np.uint8)
+    _, _, off, nbytes = movi_amd.parse_index_image(img6)
+    assert nbytes == n
+    assert (host == img6[off: off + nbytes]).all()
+    gpu.close()
