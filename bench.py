@@ -147,7 +147,7 @@ def main():
     if args.rows: wl["rows"] = args.rows
     if args.reads: wl["reads"] = args.reads
     if args.read_len: wl["read_len"] = args.read_len
-    ROW_BYTES = {6: 8, 8: 6, 7: 8}       # resident row bytes: sampled-thresholds rows are expanded to the mode-6 layout at upload
+    ROW_BYTES = {6: 8, 8: 8, 7: 8}       # resident row bytes: blocked- / sampled-thresholds rows are expanded to the mode-6 layout at upload
     mode, row_bytes = wl["mode"], ROW_BYTES[wl["mode"]]
 
     # ---- index: every rank derives the same host-side structure from the seed (needed to
@@ -310,7 +310,7 @@ def main():
         v_sel = 1
     if args.classify and v_sel == 7:
         v_sel = 10
-    kmode = 6 if mode == 7 else mode
+    kmode = 6                                        # one resident row layout (movi_abi.hip: finish_create)
     pml_kernel_name = {0: "pml_kernel<%d,0>" % kmode, 1: "pml_kernel<%d,1>" % kmode, 7: "pml_kernel_flat<%d>" % kmode,
                        10: "pml_kernel_flatp<%d>" % kmode}[v_sel]
     f_bar = st.fast_forwards / max(n_bases, 1)

@@ -45,7 +45,9 @@ extern "C" {
                                     move_structure_query.cpp:582-598); per-read flags say which */
 
 #define MOVI_MODE_REGULAR_THRESHOLDS 6   /* 8-byte rows, include/move_row.hpp:131-142 */
-#define MOVI_MODE_BLOCKED_THRESHOLDS 8   /* 6-byte rows, include/move_row.hpp:128-142 */
+#define MOVI_MODE_BLOCKED_THRESHOLDS 8   /* 6-byte rows, include/move_row.hpp:128-142.  On upload get_id (blocked id + check
+                                            point + first_runs, src/move_structure.cpp:91-102) is evaluated once per row and
+                                            the rows rewritten in the mode-6 layout: one resident layout, one set of kernels */
 #define MOVI_MODE_SAMPLED_THRESHOLDS 7   /* 3-byte rows without ids + sampled id table, move_row.hpp:122-127.  On upload
                                             the ids are recovered once, on the GPU, by MoveStructure::get_id
                                             (src/move_structure.cpp:104-283) and the rows rewritten in the mode-6
@@ -116,7 +118,7 @@ int movi_index_create(int device, const movi_index_desc_t *desc, const void *h_r
 
 /* Adopt a row table that already lives on the device (e.g. received by an RCCL
  * broadcast into a caller-owned buffer).  The caller keeps ownership of d_rows
- * and must keep it alive until movi_index_destroy (mode 7: the rows are copied
+ * and must keep it alive until movi_index_destroy (modes 7 / 8: the rows are copied
  * -- expanded to the regular-thresholds layout, see MOVI_MODE_SAMPLED_THRESHOLDS --
  * so the buffer may be released after the call). */
 int movi_index_create_from_device_rows(int device, const movi_index_desc_t *desc,
@@ -124,9 +126,9 @@ int movi_index_create_from_device_rows(int device, const movi_index_desc_t *desc
 
 int movi_index_destroy(movi_index_t *ix);
 int movi_index_get_desc(const movi_index_t *ix, movi_index_desc_t *desc);   /* id_blocks = NULL */
-/* Device pointer + size of the resident row table (source buffer of the broadcast on rank 0).  Modes 6 / 8: the
- * file's bytes.  Mode 7: the expanded table, r x 8 bytes in the regular-thresholds layout (not what
- * movi_index_create_from_device_rows takes for a mode-7 descriptor: broadcast the file bytes for that). */
+/* Device pointer + size of the resident row table.  Mode 6: the file's bytes.  Modes 7 / 8: the expanded table, r x 8
+ * bytes in the regular-thresholds layout (not what movi_index_create_from_device_rows takes for a mode-7 / 8
+ * descriptor: broadcast the file bytes for that). */
 int movi_index_device_rows(const movi_index_t *ix, const void **d_rows, size_t *bytes);
 
 /* ---- PML -------------------------------------------------------------------- */

@@ -1032,13 +1032,11 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     if (v < 0) v = (n_reads <= (uint64_t)cfg.num_cus * 64u * 12u) ? 10 : 1;  // measured crossover: ~12 waves per CU
     if (v == 10 && ix.r < 8) v = 7;                                          // the clamped window needs >= 4 rows
     if (cm != 0 && (v == 0 || v == 7)) v = (v == 0) ? 1 : (ix.r < 8 ? 1 : 10);   // the A/B kernels carry no fused bins
-    if (mode == 6) {
-        if (v == 0) MOVI_LAUNCH_PML(6, 0, 0); else if (v == 1) MOVI_BY_CLS(MOVI_LAUNCH_PML, 6, 1);
-        else if (v == 7) MOVI_LAUNCH_FLAT(6); else MOVI_BY_CLS(MOVI_LAUNCH_FLATP, 6);
-    } else {
-        if (v == 0) MOVI_LAUNCH_PML(8, 0, 0); else if (v == 1) MOVI_BY_CLS(MOVI_LAUNCH_PML, 8, 1);
-        else if (v == 7) MOVI_LAUNCH_FLAT(8); else MOVI_BY_CLS(MOVI_LAUNCH_FLATP, 8);
-    }
+    // One resident row layout: blocked- and sampled-thresholds tables are expanded to regular-thresholds rows at upload
+    // (expand_blocked_kernel / expand_sampled_kernel), so the query kernels exist for MODE 6 only.
+    if (mode != 6) return hipErrorInvalidValue;
+    if (v == 0) MOVI_LAUNCH_PML(6, 0, 0); else if (v == 1) MOVI_BY_CLS(MOVI_LAUNCH_PML, 6, 1);
+    else if (v == 7) MOVI_LAUNCH_FLAT(6); else MOVI_BY_CLS(MOVI_LAUNCH_FLATP, 6);
 #undef MOVI_LAUNCH_PML
 #undef MOVI_LAUNCH_FLAT
 #undef MOVI_LAUNCH_FLATP
@@ -1255,12 +1253,9 @@ hipError_t launch_count(int mode, const DevIndex &ix, const uint8_t *d_bases, co
     const uint64_t blocks = (n_reads + bt - 1) / bt;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     dim3 grid((unsigned)blocks), block((unsigned)bt);
-    if (mode == 6)
-        hipLaunchKernelGGL(count_kernel_v0<6>, grid, block, 0, stream, ix, d_bases, d_offsets, n_reads,
-                           d_matched, d_count, d_err, d_stats, d_order);
-    else
-        hipLaunchKernelGGL(count_kernel_v0<8>, grid, block, 0, stream, ix, d_bases, d_offsets, n_reads,
-                           d_matched, d_count, d_err, d_stats, d_order);
+    if (mode != 6) return hipErrorInvalidValue;          // see launch_pml
+    hipLaunchKernelGGL(count_kernel_v0<6>, grid, block, 0, stream, ix, d_bases, d_offsets, n_reads,
+                       d_matched, d_count, d_err, d_stats, d_order);
     return hipGetLastError();
 }
 
@@ -1394,12 +1389,9 @@ hipError_t launch_zml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     const uint64_t blocks = (n_reads + bt - 1) / bt;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     dim3 grid((unsigned)blocks), block((unsigned)bt);
-    if (mode == 6)
-        hipLaunchKernelGGL(zml_kernel<6>, grid, block, 0, stream, ix, d_bases, d_offsets, n_reads, d_out, d_err,
-                           d_stats, d_order);
-    else
-        hipLaunchKernelGGL(zml_kernel<8>, grid, block, 0, stream, ix, d_bases, d_offsets, n_reads, d_out, d_err,
-                           d_stats, d_order);
+    if (mode != 6) return hipErrorInvalidValue;          // see launch_pml
+    hipLaunchKernelGGL(zml_kernel<6>, grid, block, 0, stream, ix, d_bases, d_offsets, n_reads, d_out, d_err,
+                       d_stats, d_order);
     return hipGetLastError();
 }
 
@@ -1510,6 +1502,26 @@ __global__ __launch_bounds__(256) void expand_sampled_kernel(DevIndex ix, uint2 
     }
 }
 
+// Blocked-thresholds -> regular-thresholds rows, once per index: get_id = blocked id + the (character, block) check
+// point + first_runs[c + 1] (src/move_structure.cpp:91-102) evaluated for every row, written in the 8-byte layout.
+__global__ __launch_bounds__(256) void expand_blocked_kernel(DevIndex ix, uint2 *__restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ix.r) return;
+    const uint2 row = load_row<8>(ix.rows, i);
+    const uint64_t id = row_id<8>(row, i, ix, nullptr);
+    const uint32_t n16 = row_n<8>(row) | (row_thr<8>(row, 1) << 11) | (row_thr<8>(row, 2) << 12) | (row_c<8>(row) << 13);
+    const uint32_t off16 = row_off<8>(row) | (row_thr<8>(row, 0) << 11) | ((uint32_t)((id >> 32) & 0xFu) << 12);
+    out[i] = make_uint2((uint32_t)id, n16 | (off16 << 16));
+}
+
+hipError_t expand_blocked_rows(const DevIndex &ix, void *d_rows6, hipStream_t stream) {
+    const unsigned bt = 256;
+    const uint64_t blocks = (ix.r + bt - 1) / bt;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(expand_blocked_kernel, dim3((unsigned)blocks), dim3(bt), 0, stream, ix, static_cast<uint2 *>(d_rows6));
+    return hipGetLastError();
+}
+
 hipError_t expand_sampled_rows(const DevIndex &ix, void *d_rows6, hipStream_t stream) {
     const unsigned bt = 256;
     const uint64_t blocks = (ix.r + bt - 1) / bt;
@@ -1529,10 +1541,8 @@ hipError_t build_row_start_ckpt(int mode, const uint8_t *d_rows, uint64_t r, uin
     if (e != hipSuccess) { (void)hipFree(d_sums); return e; }
     const unsigned bt = 256;
     const unsigned blocks = (unsigned)((n_chunks + bt - 1) / bt);
-    if (mode == 6)
-        hipLaunchKernelGGL(chunk_sum_kernel<6>, dim3(blocks), dim3(bt), 0, stream, d_rows, r, n_chunks, d_sums);
-    else
-        hipLaunchKernelGGL(chunk_sum_kernel<8>, dim3(blocks), dim3(bt), 0, stream, d_rows, r, n_chunks, d_sums);
+    if (mode != 6) { (void)hipFree(d_sums); return hipErrorInvalidValue; }
+    hipLaunchKernelGGL(chunk_sum_kernel<6>, dim3(blocks), dim3(bt), 0, stream, d_rows, r, n_chunks, d_sums);
     e = hipGetLastError();
     void *d_temp = nullptr;
     size_t temp_bytes = 0;
