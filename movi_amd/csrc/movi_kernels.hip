@@ -19,7 +19,6 @@
 
 namespace movi {
 
-constexpr int kIdbLdsEntries = 4096;   // mode-8 id_blocks entries held in LDS (16 KiB; 20 KiB cost a block per CU: c2b 46 -> 42.7)
 
 // ------------------------------------------------------------------ row decode
 // A row is carried in registers as two dwords.
@@ -78,7 +77,7 @@ template <int MODE> __device__ __forceinline__ uint32_t row_thr(uint2 w, uint32_
 }
 // MoveStructure::get_id, src/move_structure.cpp:91-102
 template <int MODE>
-__device__ __forceinline__ uint64_t row_id(uint2 w, uint64_t idx, const DevIndex &ix, const uint32_t *idb_lds = nullptr) {
+__device__ __forceinline__ uint64_t row_id(uint2 w, uint64_t idx, const DevIndex &ix) {
     static_assert(MODE == 6 || MODE == 8, "sampled mode 7 has no id in the row: tally_id()");
     if (MODE == 6) {
         return (uint64_t)w.x | ((uint64_t)(w.y >> 28) << 32);
@@ -88,7 +87,7 @@ __device__ __forceinline__ uint64_t row_id(uint2 w, uint64_t idx, const DevIndex
         uint32_t c = row_c<8>(w);
         const uint64_t blk = ix.block_shift != 0xFFFFFFFFu ? (idx >> ix.block_shift) : idx / ix.block_size;
         const uint64_t slot = (uint64_t)c * ix.n_blocks + blk;
-        const uint32_t base = idb_lds ? idb_lds[slot] : ix.id_blocks[slot];     // check point of (character, block)
+        const uint32_t base = ix.id_blocks[slot];                           // check point of (character, block)
         return bid + (uint64_t)base + ix.first_runs[c + 1];
     }
 }
@@ -263,14 +262,14 @@ __device__ __forceinline__ uint64_t tally_id(const DevIndex &ix, bool live, uint
 // the new idx.  `live` lanes take the step; returns a kErr* code (0 = ok) per lane.
 template <int MODE>
 __device__ __forceinline__ uint32_t lf_step(const DevIndex &ix, bool live, uint64_t &idx, uint32_t &off,
-                                            uint2 &row, uint32_t &ff_total, const uint32_t *idb_lds = nullptr) {
+                                            uint2 &row, uint32_t &ff_total) {
     uint32_t errc = kErrNone;
     uint64_t j = idx;
     uint32_t n = 0, ff = 0;
     uint32_t going = 0;
     if constexpr (MODE == 7) j = tally_id(ix, live, idx, row);
     if (live) {
-        if constexpr (MODE != 7) j = row_id<MODE>(row, idx, ix, idb_lds);
+        if constexpr (MODE != 7) j = row_id<MODE>(row, idx, ix);
         if (j >= ix.r) {                                // move_structure.cpp:63-65
             errc = kErrIdRange;
             j = idx;
@@ -305,8 +304,7 @@ __device__ __forceinline__ uint32_t lf_step(const DevIndex &ix, bool live, uint6
 // wave-uniform loop, so an interval step costs the trips of ONE walker.
 template <int MODE>
 __device__ __forceinline__ uint32_t lf_step2(const DevIndex &ix, bool live, uint64_t &ia, uint32_t &offa, uint2 &rowa,
-                                             uint64_t &ib, uint32_t &offb, uint2 &rowb, uint32_t &ff_total,
-                                             const uint32_t *idb_lds = nullptr) {
+                                             uint64_t &ib, uint32_t &offb, uint2 &rowb, uint32_t &ff_total) {
     uint32_t errc = kErrNone;
     uint64_t ja = ia, jb = ib;
     uint32_t na = 0, nb = 0, ffa = 0, ffb = 0, ga = 0, gb = 0;
@@ -316,8 +314,8 @@ __device__ __forceinline__ uint32_t lf_step2(const DevIndex &ix, bool live, uint
     }
     if (live) {
         if constexpr (MODE != 7) {
-            ja = row_id<MODE>(rowa, ia, ix, idb_lds);
-            jb = row_id<MODE>(rowb, ib, ix, idb_lds);
+            ja = row_id<MODE>(rowa, ia, ix);
+            jb = row_id<MODE>(rowb, ib, ix);
         }
         if (ja >= ix.r || jb >= ix.r) {                 // move_structure.cpp:63-65
             errc = kErrIdRange;
@@ -395,14 +393,6 @@ __global__ __launch_bounds__(256) void pml_kernel(DevIndex ix, const uint8_t *__
                                                      ClsArgs cls) {
     __shared__ uint8_t s_code[256];
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = ix.code_of[i];
-    // mode 8: the (character, block) check points of the blocked ids, kept in LDS when they fit
-    // (4 x n_blocks x 4 B = 15 kB for 1 B rows) so that get_id costs no extra global load
-    __shared__ uint32_t s_idb[MODE == 8 ? kIdbLdsEntries : 1];
-    const uint32_t *idb = nullptr;
-    if (MODE == 8 && ix.n_blocks * ix.sigma <= (uint64_t)kIdbLdsEntries) {
-        for (uint32_t i = threadIdx.x; i < (uint32_t)ix.n_blocks * ix.sigma; i += blockDim.x) s_idb[i] = ix.id_blocks[i];
-        idb = s_idb;
-    }
     __syncthreads();
 
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -448,7 +438,7 @@ __global__ __launch_bounds__(256) void pml_kernel(DevIndex ix, const uint8_t *__
             }
         }
         if (k != 0) {
-            const uint32_t e = lf_step<MODE>(ix, live, idx, off, row, ff_total, idb);
+            const uint32_t e = lf_step<MODE>(ix, live, idx, off, row, ff_total);
             if (e) { failed = e; live = false; }
         }
         uint32_t a = 0xFFu;
@@ -575,14 +565,6 @@ __global__ __launch_bounds__(256) void pml_kernel_flat(DevIndex ix, const uint8_
     enum : uint32_t { sFF = 0, sDown = 1, sUp = 2, sDone = 3 };
     __shared__ uint8_t s_code[256];
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = ix.code_of[i];
-    // mode 8: the (character, block) check points of the blocked ids, kept in LDS when they fit
-    // (4 x n_blocks x 4 B = 15 kB for 1 B rows) so that get_id costs no extra global load
-    __shared__ uint32_t s_idb[MODE == 8 ? kIdbLdsEntries : 1];
-    const uint32_t *idb = nullptr;
-    if (MODE == 8 && ix.n_blocks * ix.sigma <= (uint64_t)kIdbLdsEntries) {
-        for (uint32_t i = threadIdx.x; i < (uint32_t)ix.n_blocks * ix.sigma; i += blockDim.x) s_idb[i] = ix.id_blocks[i];
-        idb = s_idb;
-    }
     __syncthreads();
 
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -677,7 +659,7 @@ __global__ __launch_bounds__(256) void pml_kernel_flat(DevIndex ix, const uint8_
             if (k == len) {
                 st_next = sDone;
             } else {
-                const uint64_t j = row_id<MODE>(row, need, ix, idb);      // LF_move, move_structure.cpp:59-67
+                const uint64_t j = row_id<MODE>(row, need, ix);      // LF_move, move_structure.cpp:59-67
                 if (j >= ix.r) {
                     failed = kErrIdRange;
                     st_next = sDone;
@@ -712,24 +694,12 @@ __global__ __launch_bounds__(256) void pml_kernel_flat(DevIndex ix, const uint8_
 
 template <int MODE>
 __device__ __forceinline__ void load_window(const uint8_t *rows, uint64_t wbase, uint2 (&w)[4]) {
-    static_assert(MODE == 6 || MODE == 8, "queries never run on mode-7 rows (expanded to mode 6 at upload)");
-    if (MODE == 6) {
-        uint4 p0, p1;
-        __builtin_memcpy(&p0, rows + wbase * 8, 16);
-        __builtin_memcpy(&p1, rows + wbase * 8 + 16, 16);
-        w[0] = make_uint2(p0.x, p0.y); w[1] = make_uint2(p0.z, p0.w);
-        w[2] = make_uint2(p1.x, p1.y); w[3] = make_uint2(p1.z, p1.w);
-    } else {
-        unsigned long long x0, x1, x2;                    // rows 4m .. 4m+3 = bytes [24m, 24m+24)
-        __builtin_memcpy(&x0, rows + wbase * 6, 8);
-        __builtin_memcpy(&x1, rows + wbase * 6 + 8, 8);
-        __builtin_memcpy(&x2, rows + wbase * 6 + 16, 8);
-        const unsigned long long v1 = (x0 >> 48) | (x1 << 16), v2 = (x1 >> 32) | (x2 << 32), v3 = x2 >> 16;
-        w[0] = make_uint2((uint32_t)x0, (uint32_t)(x0 >> 32) & 0xFFFFu);
-        w[1] = make_uint2((uint32_t)v1, (uint32_t)(v1 >> 32) & 0xFFFFu);
-        w[2] = make_uint2((uint32_t)v2, (uint32_t)(v2 >> 32) & 0xFFFFu);
-        w[3] = make_uint2((uint32_t)v3, (uint32_t)(v3 >> 32) & 0xFFFFu);
-    }
+    static_assert(MODE == 6, "queries run on regular-thresholds rows only (modes 7 / 8 are expanded at upload)");
+    uint4 p0, p1;
+    __builtin_memcpy(&p0, rows + wbase * 8, 16);
+    __builtin_memcpy(&p1, rows + wbase * 8 + 16, 16);
+    w[0] = make_uint2(p0.x, p0.y); w[1] = make_uint2(p0.z, p0.w);
+    w[2] = make_uint2(p1.x, p1.y); w[3] = make_uint2(p1.z, p1.w);
 }
 __device__ __forceinline__ uint2 win_sel(const uint2 (&w)[4], uint32_t q) {
     const uint2 lo = (q & 1u) ? w[1] : w[0];
@@ -763,12 +733,6 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
     enum : uint32_t { sFF = 0, sDown = 1, sUp = 2, sDone = 3 };
     __shared__ uint8_t s_code[256];
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = ix.code_of[i];
-    __shared__ uint32_t s_idb[MODE == 8 ? kIdbLdsEntries : 1];
-    const uint32_t *idb = nullptr;
-    if (MODE == 8 && ix.n_blocks * ix.sigma <= (uint64_t)kIdbLdsEntries) {
-        for (uint32_t i = threadIdx.x; i < (uint32_t)ix.n_blocks * ix.sigma; i += blockDim.x) s_idb[i] = ix.id_blocks[i];
-        idb = s_idb;
-    }
     __syncthreads();
 
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -887,7 +851,7 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
         // LF_move of the emitted base, move_structure.cpp:59-67 (emit and the error cases are exclusive)
         const uint32_t lf = emit & (uint32_t)(k + 1 != len);
         uint64_t j = 0;
-        if (MODE == 6 || lf) j = row_id<MODE>(row, need, ix, idb);
+        if (MODE == 6 || lf) j = row_id<MODE>(row, need, ix);
         const uint32_t lf_bad = lf & (uint32_t)(j >= ix.r);
         const uint32_t errc = ff_over ? kErrFastForward
                               : (repo_edge ? (down ? kErrNoRunBelow : kErrNoRunAbove)
@@ -1154,14 +1118,6 @@ __global__ __launch_bounds__(256) void count_kernel_v0(DevIndex ix, const uint8_
                                                        DevStats *stats, const uint32_t *__restrict__ order) {
     __shared__ uint8_t s_code[256];
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = ix.code_of[i];
-    // mode 8: the (character, block) check points of the blocked ids, kept in LDS when they fit
-    // (4 x n_blocks x 4 B = 15 kB for 1 B rows) so that get_id costs no extra global load
-    __shared__ uint32_t s_idb[MODE == 8 ? kIdbLdsEntries : 1];
-    const uint32_t *idb = nullptr;
-    if (MODE == 8 && ix.n_blocks * ix.sigma <= (uint64_t)kIdbLdsEntries) {
-        for (uint32_t i = threadIdx.x; i < (uint32_t)ix.n_blocks * ix.sigma; i += blockDim.x) s_idb[i] = ix.id_blocks[i];
-        idb = s_idb;
-    }
     __syncthreads();
 
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1217,7 +1173,7 @@ __global__ __launch_bounds__(256) void count_kernel_v0(DevIndex ix, const uint8_
         bool nonempty = legal && ((rs < re) || (rs == re && os <= oe));
         if (legal && !nonempty) { empty = 1; run = 0; }
         // backward_search_step :326-330: two LF moves
-        const uint32_t e12 = lf_step2<MODE>(ix, nonempty, rs, os, rws, re, oe, rwe, ff_total, idb);
+        const uint32_t e12 = lf_step2<MODE>(ix, nonempty, rs, os, rws, re, oe, rwe, ff_total);
         if (e12) { failed = e12; run = 0; nonempty = false; }
         if (nonempty) {                                   // backward_search :179-182
             if ((rs < re) || (rs == re && os <= oe)) pos -= 1;
@@ -1278,12 +1234,6 @@ __global__ __launch_bounds__(256) void zml_kernel(DevIndex ix, const uint8_t *__
                                                   DevStats *stats, const uint32_t *__restrict__ order) {
     __shared__ uint8_t s_code[256];
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = ix.code_of[i];
-    __shared__ uint32_t s_idb[MODE == 8 ? kIdbLdsEntries : 1];
-    const uint32_t *idb = nullptr;
-    if (MODE == 8 && ix.n_blocks * ix.sigma <= (uint64_t)kIdbLdsEntries) {
-        for (uint32_t i = threadIdx.x; i < (uint32_t)ix.n_blocks * ix.sigma; i += blockDim.x) s_idb[i] = ix.id_blocks[i];
-        idb = s_idb;
-    }
     __syncthreads();
 
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1332,7 +1282,7 @@ __global__ __launch_bounds__(256) void zml_kernel(DevIndex ix, const uint8_t *__
             shrink_interval_rows<MODE>(ix, ext && rs <= re, b, rs, os, rws, re, oe, rwe, scan_total);
         }
         bool nonempty = ext && ((rs < re) || (rs == re && os <= oe));
-        const uint32_t e12 = lf_step2<MODE>(ix, nonempty, rs, os, rws, re, oe, rwe, ff_total, idb);
+        const uint32_t e12 = lf_step2<MODE>(ix, nonempty, rs, os, rws, re, oe, rwe, ff_total);
         if (e12) { failed = e12; nonempty = false; }
         if (nonempty && !((rs < re) || (rs == re && os <= oe))) nonempty = false;   // query_zml :717
         if (live && failed == 0u) {
@@ -1508,7 +1458,7 @@ __global__ __launch_bounds__(256) void expand_blocked_kernel(DevIndex ix, uint2 
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ix.r) return;
     const uint2 row = load_row<8>(ix.rows, i);
-    const uint64_t id = row_id<8>(row, i, ix, nullptr);
+    const uint64_t id = row_id<8>(row, i, ix);
     const uint32_t n16 = row_n<8>(row) | (row_thr<8>(row, 1) << 11) | (row_thr<8>(row, 2) << 12) | (row_c<8>(row) << 13);
     const uint32_t off16 = row_off<8>(row) | (row_thr<8>(row, 0) << 11) | ((uint32_t)((id >> 32) & 0xFu) << 12);
     out[i] = make_uint2((uint32_t)id, n16 | (off16 << 16));
