@@ -36,7 +36,7 @@ extern "C" {
 
 #define MOVI_OK              0
 #define MOVI_ERR_ARG        -1   /* bad argument                                        */
-#define MOVI_ERR_FORMAT     -2   /* not a v2 index.movi of mode 6 / 8, or unsupported    */
+#define MOVI_ERR_FORMAT     -2   /* not a v2 index.movi of mode 5 / 6 / 7 / 8, or unsupported */
 #define MOVI_ERR_IO         -3   /* file could not be read                               */
 #define MOVI_ERR_HIP        -4   /* a HIP runtime call failed (message has the code)     */
 #define MOVI_ERR_NO_DEVICE  -5   /* no usable gfx950 device: there is NO CPU fallback    */
@@ -52,6 +52,10 @@ extern "C" {
                                             the ids are recovered once, on the GPU, by MoveStructure::get_id
                                             (src/move_structure.cpp:104-283) and the rows rewritten in the mode-6
                                             layout: queries run the regular-thresholds kernels on identical rows */
+
+#define MOVI_MODE_SAMPLED 5              /* like 7 without thresholds (10-bit lengths, move_row_configs.hpp:107-118).  Count and
+                                            ZML queries only: PML on an index without thresholds repositions RANDOMLY in the
+                                            reference (reposition_randomly) and is refused (MOVI_ERR_ARG) */
 
 typedef struct movi_index movi_index_t;
 

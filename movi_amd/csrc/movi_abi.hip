@@ -111,8 +111,8 @@ int movi_index_parse(const void *h_image, size_t image_bytes, movi_index_desc_t 
     memset(desc, 0, sizeof(*desc));
     desc->mode = hdr[7];
     if (desc->mode != MOVI_MODE_REGULAR_THRESHOLDS && desc->mode != MOVI_MODE_BLOCKED_THRESHOLDS &&
-        desc->mode != MOVI_MODE_SAMPLED_THRESHOLDS)
-        return fail(MOVI_ERR_FORMAT, "index mode " + std::to_string(desc->mode) + " is not supported (only "
+        desc->mode != MOVI_MODE_SAMPLED_THRESHOLDS && desc->mode != MOVI_MODE_SAMPLED)
+        return fail(MOVI_ERR_FORMAT, "index mode " + std::to_string(desc->mode) + " is not supported (only sampled=5, "
                                          "regular-thresholds=6, sampled-thresholds=7 and blocked-thresholds=8)");
     memcpy(&desc->length, hdr + 16, 8);
     memcpy(&desc->r, hdr + 24, 8);
@@ -138,7 +138,8 @@ int movi_index_parse(const void *h_image, size_t image_bytes, movi_index_desc_t 
     const size_t row_b = desc->mode == MOVI_MODE_REGULAR_THRESHOLDS ? 8 : (desc->mode == MOVI_MODE_BLOCKED_THRESHOLDS ? 6 : 3);
     const size_t roff = rd.pos;
     if (!rd.skip(desc->r * row_b)) return fail(MOVI_ERR_FORMAT, "truncated index (move rows)");
-    if (desc->mode == MOVI_MODE_SAMPLED_THRESHOLDS) {      // read_tally_table, move_structure_io.cpp:338-349
+    const bool sampled = desc->mode == MOVI_MODE_SAMPLED_THRESHOLDS || desc->mode == MOVI_MODE_SAMPLED;
+    if (sampled) {                                         // read_tally_table, move_structure_io.cpp:338-349
         if (!rd.get(&desc->tally_checkpoints, 4) || desc->tally_checkpoints == 0)
             return fail(MOVI_ERR_FORMAT, "truncated index (tally checkpoints)");
         if (!rd.get(&desc->n_tally, 8)) return fail(MOVI_ERR_FORMAT, "truncated index (tally table)");
@@ -171,7 +172,7 @@ int movi_index_parse(const void *h_image, size_t image_bytes, movi_index_desc_t 
         if (desc->block_size == 0 || desc->n_blocks * desc->block_size < desc->r)
             return fail(MOVI_ERR_FORMAT, "id blocks do not cover the table");
     }
-    if (sep) {                                             // read_separators_thresholds, move_structure_io.cpp:415-433
+    if (sep && desc->mode != MOVI_MODE_SAMPLED) {          // read_separators_thresholds, move_structure_io.cpp:415-433 (USE_THRESHOLDS)
         if (!rd.get(&desc->n_separator_thresholds, 8)) return fail(MOVI_ERR_FORMAT, "truncated index (separator thresholds)");
         desc->separator_thresholds = rd.p + rd.pos;
         if (desc->n_separator_thresholds > image_bytes / 8 || !rd.skip(desc->n_separator_thresholds * 8))
@@ -204,8 +205,8 @@ static int finish_create(movi_index *ix) {
         HIP_TRY(hipMemcpy(ix->d_sep_rows, ix->sep_rows_host.data(), ns * 8, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(ix->d_sep_vals, ix->sep_vals_host.data(), ns * 8, hipMemcpyHostToDevice));
     }
-    if (d.mode == MOVI_MODE_SAMPLED_THRESHOLDS) {
-        if (ix->tally_host.empty()) return fail(MOVI_ERR_ARG, "mode 7 needs tally_ids");
+    if (d.mode == MOVI_MODE_SAMPLED_THRESHOLDS || d.mode == MOVI_MODE_SAMPLED) {
+        if (ix->tally_host.empty()) return fail(MOVI_ERR_ARG, "the sampled modes need tally_ids");
         HIP_TRY(hipMalloc(&ix->d_tally, ix->tally_host.size() * 8));
         HIP_TRY(hipMemcpy(ix->d_tally, ix->tally_host.data(), ix->tally_host.size() * 8, hipMemcpyHostToDevice));
     }
@@ -262,14 +263,14 @@ static int finish_create(movi_index *ix) {
         v.rows = rows6;
         ix->kmode = MOVI_MODE_REGULAR_THRESHOLDS;
     }
-    if (d.mode == MOVI_MODE_SAMPLED_THRESHOLDS) {
+    if (d.mode == MOVI_MODE_SAMPLED_THRESHOLDS || d.mode == MOVI_MODE_SAMPLED) {
         // expand to regular-thresholds rows once (movi_kernels.hip, expand_sampled_kernel); the widened rows and the
         // tally table are only needed for that
         if (d.r >= (1ull << 36)) return fail(MOVI_ERR_ARG, "sampled-thresholds index with 2^36 rows or more");
         uint8_t *rows6 = nullptr;
         HIP_TRY(hipMalloc(&rows6, (size_t)d.r * 8 + 16));
         hipError_t e = hipMemset(rows6, 0, (size_t)d.r * 8 + 16);
-        if (e == hipSuccess) e = expand_sampled_rows(v, rows6, nullptr);
+        if (e == hipSuccess) e = expand_sampled_rows((int)d.mode, v, rows6, nullptr);
         if (e == hipSuccess) e = hipDeviceSynchronize();
         if (e != hipSuccess) { (void)hipFree(rows6); return fail_hip(e, "expanding the sampled rows"); }
         if (ix->owns_rows && ix->d_rows) (void)hipFree(ix->d_rows);
@@ -287,9 +288,9 @@ static int finish_create(movi_index *ix) {
 static int check_desc(const movi_index_desc_t *desc) {
     if (!desc) return fail(MOVI_ERR_ARG, "desc is NULL");
     if (desc->mode != MOVI_MODE_REGULAR_THRESHOLDS && desc->mode != MOVI_MODE_BLOCKED_THRESHOLDS &&
-        desc->mode != MOVI_MODE_SAMPLED_THRESHOLDS)
+        desc->mode != MOVI_MODE_SAMPLED_THRESHOLDS && desc->mode != MOVI_MODE_SAMPLED)
         return fail(MOVI_ERR_ARG, "unsupported mode");
-    if (desc->mode == MOVI_MODE_SAMPLED_THRESHOLDS &&
+    if ((desc->mode == MOVI_MODE_SAMPLED_THRESHOLDS || desc->mode == MOVI_MODE_SAMPLED) &&
         (!desc->tally_ids || desc->tally_checkpoints == 0 || desc->n_tally < desc->r / desc->tally_checkpoints + 2))
         return fail(MOVI_ERR_ARG, "mode 7 needs tally_checkpoints / tally_ids covering the rows");
     if (desc->r == 0 || desc->end_bwt_idx >= desc->r) return fail(MOVI_ERR_ARG, "bad r / end_bwt_idx");
@@ -329,7 +330,7 @@ static movi_index *new_handle(int device, const movi_index_desc_t *desc) {
     }
     ix->desc.separator_thresholds = nullptr;
     ix->desc.separator_map = nullptr;
-    if (desc->mode == MOVI_MODE_SAMPLED_THRESHOLDS) {
+    if (desc->mode == MOVI_MODE_SAMPLED_THRESHOLDS || desc->mode == MOVI_MODE_SAMPLED) {
         const size_t ne = (size_t)desc->n_tally * desc->alphabet_size;
         const uint8_t *p = static_cast<const uint8_t *>(desc->tally_ids);
         ix->tally_host.resize(ne);
@@ -370,7 +371,7 @@ int movi_index_create(int device, const movi_index_desc_t *desc, const void *h_r
     if (e == hipSuccess) e = hipMemcpy(ix->d_rows, h_rows, ix->rows_bytes, hipMemcpyHostToDevice);
     if (e != hipSuccess) { movi_index_destroy(ix); return fail_hip(e, "uploading the move rows"); }
     ix->owns_rows = true;
-    if (desc->mode == MOVI_MODE_SAMPLED_THRESHOLDS) {
+    if (desc->mode == MOVI_MODE_SAMPLED_THRESHOLDS || desc->mode == MOVI_MODE_SAMPLED) {
         uint8_t *packed = ix->d_rows;
         ix->d_rows = nullptr;
         e = adopt_widened(ix, packed);
@@ -394,7 +395,7 @@ int movi_index_create_from_device_rows(int device, const movi_index_desc_t *desc
     movi_index *ix = new_handle(device, desc);
     ix->d_rows = const_cast<uint8_t *>(static_cast<const uint8_t *>(d_rows));
     ix->owns_rows = false;
-    if (desc->mode == MOVI_MODE_SAMPLED_THRESHOLDS) {      // widened private copy; the caller's buffer is not kept
+    if (desc->mode == MOVI_MODE_SAMPLED_THRESHOLDS || desc->mode == MOVI_MODE_SAMPLED) {   // private copy; the caller's buffer is not kept
         ix->d_rows = nullptr;
         hipError_t e = adopt_widened(ix, static_cast<const uint8_t *>(d_rows));
         if (e != hipSuccess) { movi_index_destroy(ix); return fail_hip(e, "widening the 3-byte rows"); }
@@ -499,6 +500,10 @@ static int ml_device(bool zml, movi_index_t *ix, const uint8_t *d_bases, const u
                      uint64_t n_bases, uint16_t *d_out, uint8_t *d_read_err, const uint32_t *d_read_order, void *stream,
                      const ClsArgs &cls = ClsArgs()) {
     if (!ix) return fail(MOVI_ERR_ARG, "index handle is NULL");
+    if (!zml && ix->desc.mode == MOVI_MODE_SAMPLED)
+        return fail(MOVI_ERR_ARG, "PML needs thresholds: on a `sampled` index the reference repositions randomly "
+                                  "(reposition_randomly), which cannot be reproduced; use --zml or --count, or a "
+                                  "sampled-thresholds index");
     if (n_reads == 0) return MOVI_OK;
     const bool bins_only = cls.bin_width != 0 && !d_out;
     if (!d_offsets || (n_bases && (!d_bases || (!d_out && !bins_only)))) return fail(MOVI_ERR_ARG, "NULL device buffer");

@@ -52,19 +52,23 @@ __device__ __forceinline__ uint2 load_row(const uint8_t *rows, uint64_t i) {
     }
 }
 template <int MODE> __device__ __forceinline__ uint32_t row_n(uint2 w) {
+    if (MODE == 5) return (w.x & 0xFFu) | (((w.x >> 18) & 3u) << 8);      // sampled, no thresholds: configs :107-118
     if (MODE == 7) return (w.x & 0xFFu) | (((w.x >> 17) & 1u) << 8);
     return MODE == 6 ? (w.y & 0x7FFu) : ((w.x >> 16) & 0x3FFu);
 }
 template <int MODE> __device__ __forceinline__ uint32_t row_off(uint2 w) {
+    if (MODE == 5) return ((w.x >> 8) & 0xFFu) | (((w.x >> 16) & 3u) << 8);
     if (MODE == 7) return ((w.x >> 8) & 0xFFu) | (((w.x >> 16) & 1u) << 8);
     return MODE == 6 ? ((w.y >> 16) & 0x7FFu) : (w.y & 0x3FFu);
 }
 template <int MODE> __device__ __forceinline__ uint32_t row_c(uint2 w) {
+    if (MODE == 5) return (w.x >> 20) & 15u;
     if (MODE == 7) return (w.x >> 18) & 7u;
     return MODE == 6 ? ((w.y >> 13) & 7u) : ((w.y >> 10) & 7u);
 }
 // threshold bit k in {0,1,2} (MoveRow::get_threshold, move_row.hpp:304-347)
 template <int MODE> __device__ __forceinline__ uint32_t row_thr(uint2 w, uint32_t k) {
+    if (MODE == 5) return 0u;                             // no thresholds in this index type
     if (MODE == 6) {
         // k=0 -> off16 bit 11 (y bit 27); k=1 -> n16 bit 11; k=2 -> n16 bit 12
         uint32_t sh = (k == 0) ? 27u : (10u + k);
@@ -78,7 +82,7 @@ template <int MODE> __device__ __forceinline__ uint32_t row_thr(uint2 w, uint32_
 // MoveStructure::get_id, src/move_structure.cpp:91-102
 template <int MODE>
 __device__ __forceinline__ uint64_t row_id(uint2 w, uint64_t idx, const DevIndex &ix) {
-    static_assert(MODE == 6 || MODE == 8, "sampled mode 7 has no id in the row: tally_id()");
+    static_assert(MODE == 6 || MODE == 8, "the sampled modes have no id in the row: tally_id()");
     if (MODE == 6) {
         return (uint64_t)w.x | ((uint64_t)(w.y >> 28) << 32);
     } else {
@@ -157,10 +161,10 @@ __device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
 // Wave-uniform loops, predicated per lane (see the control-flow note above).  Returns r on the reference's throws.
 // IdxT = uint32_t when the table has fewer than 2^32 rows.  Rows are read four at a time as the aligned 16-byte
 // group that holds them (the widened table has 16 bytes of slack, so the last group may be read whole).
-template <typename IdxT>
+template <int TM, typename IdxT>                          // TM: 7 = sampled-thresholds rows, 5 = sampled rows
 __device__ __forceinline__ uint64_t tally_id_t(const DevIndex &ix, bool live, uint64_t idx64, uint2 row) {
     const IdxT idx = (IdxT)idx64, r = (IdxT)ix.r, end_row = (IdxT)ix.end_bwt_idx;
-    const uint32_t ci = row_c<7>(row);
+    const uint32_t ci = row_c<TM>(row);
     const IdxT cp = (IdxT)ix.tally_cp;
     IdxT id = live ? 0 : idx;                            // lanes that take no step keep their row (callers store the result)
     uint32_t walk = 0;                                   // 1 while the lane still scans / walks
@@ -196,10 +200,10 @@ __device__ __forceinline__ uint64_t tally_id_t(const DevIndex &ix, bool live, ui
             for (int t = 0; t < 4; ++t) {
                 const uint2 w = make_uint2(x[t], 0u);
                 const IdxT it = g + (IdxT)t;
-                if (it >= idx && it < next_cp && it != end_row && row_c<7>(w) == ci) {
-                    rows_until += row_n<7>(w);
-                    last_n = row_n<7>(w);
-                    last_off = row_off<7>(w);
+                if (it >= idx && it < next_cp && it != end_row && row_c<TM>(w) == ci) {
+                    rows_until += row_n<TM>(w);
+                    last_n = row_n<TM>(w);
+                    last_off = row_off<TM>(w);
                     last_is_idx = (it == idx) ? 1u : 0u;
                 }
                 wn = (it == next_cp) ? x[t] : wn;
@@ -212,9 +216,9 @@ __device__ __forceinline__ uint64_t tally_id_t(const DevIndex &ix, bool live, ui
     uint32_t back = 0, offset = 0;
     if (walk) {
         const uint2 wnr = make_uint2(wn, 0u);
-        const uint32_t same = (next_cp != end_row && row_c<7>(wnr) == ci) ? 1u : 0u;
+        const uint32_t same = (next_cp != end_row && row_c<TM>(wnr) == ci) ? 1u : 0u;
         if (!(last_is_idx && !same)) {
-            offset = row_off<7>(wnr);
+            offset = row_off<TM>(wnr);
             if (!same) { rows_until -= last_n; offset = last_off; }       // :194-197
             back = 1;
         }
@@ -229,7 +233,7 @@ __device__ __forceinline__ uint64_t tally_id_t(const DevIndex &ix, bool live, ui
             const uint32_t x[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int t = 3; t >= 0; --t) {
-                const uint32_t nrow = row_n<7>(make_uint2(x[t], 0u));
+                const uint32_t nrow = row_n<TM>(make_uint2(x[t], 0u));
                 if (back && (gb + (IdxT)t) == id) {
                     uint32_t step_down = 0;
                     if (first) {
@@ -253,9 +257,10 @@ __device__ __forceinline__ uint64_t tally_id_t(const DevIndex &ix, bool live, ui
     }
     return bad ? ix.r : (uint64_t)id;
 }
+template <int TM>
 __device__ __forceinline__ uint64_t tally_id(const DevIndex &ix, bool live, uint64_t idx, uint2 row) {
-    if (ix.idx32) return tally_id_t<uint32_t>(ix, live, idx, row);               // wave-uniform choice
-    return tally_id_t<uint64_t>(ix, live, idx, row);
+    if (ix.idx32) return tally_id_t<TM, uint32_t>(ix, live, idx, row);           // wave-uniform choice
+    return tally_id_t<TM, uint64_t>(ix, live, idx, row);
 }
 
 // LF_move + fast_forward.  On entry `row` is rows[idx]; on exit it is the row of
@@ -267,9 +272,8 @@ __device__ __forceinline__ uint32_t lf_step(const DevIndex &ix, bool live, uint6
     uint64_t j = idx;
     uint32_t n = 0, ff = 0;
     uint32_t going = 0;
-    if constexpr (MODE == 7) j = tally_id(ix, live, idx, row);
     if (live) {
-        if constexpr (MODE != 7) j = row_id<MODE>(row, idx, ix);
+        j = row_id<MODE>(row, idx, ix);
         if (j >= ix.r) {                                // move_structure.cpp:63-65
             errc = kErrIdRange;
             j = idx;
@@ -308,15 +312,9 @@ __device__ __forceinline__ uint32_t lf_step2(const DevIndex &ix, bool live, uint
     uint32_t errc = kErrNone;
     uint64_t ja = ia, jb = ib;
     uint32_t na = 0, nb = 0, ffa = 0, ffb = 0, ga = 0, gb = 0;
-    if constexpr (MODE == 7) {
-        ja = tally_id(ix, live, ia, rowa);
-        jb = tally_id(ix, live, ib, rowb);
-    }
     if (live) {
-        if constexpr (MODE != 7) {
-            ja = row_id<MODE>(rowa, ia, ix);
-            jb = row_id<MODE>(rowb, ib, ix);
-        }
+        ja = row_id<MODE>(rowa, ia, ix);
+        jb = row_id<MODE>(rowb, ib, ix);
         if (ja >= ix.r || jb >= ix.r) {                 // move_structure.cpp:63-65
             errc = kErrIdRange;
             ja = ia; jb = ib;
@@ -1439,15 +1437,17 @@ hipError_t widen_rows(const uint8_t *d_packed, uint64_t r, uint32_t *d_wide, hip
 // recovered ONCE, on the GPU, by that very get_id (tally_id above), and written out in the 8-byte layout of mode 6
 // (n <= 511, 9-bit offsets, the same three threshold bits and character: everything fits); queries then run the mode-6
 // kernels, state machines included, on identical rows -- identical answers, fast-forward and scan counts included.
+// TM = 7: sampled-thresholds rows; TM = 5: sampled rows (no thresholds, 10-bit lengths: count / ZML queries only).
+template <int TM>
 __global__ __launch_bounds__(256) void expand_sampled_kernel(DevIndex ix, uint2 *__restrict__ out) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < ix.r;
-    const uint2 row = live ? load_row<7>(ix.rows, i) : make_uint2(0u, 0u);
-    const uint64_t id = tally_id(ix, live, i, row);                     // r on the reference's throws: LF_move rejects it
+    const uint2 row = live ? load_row<TM>(ix.rows, i) : make_uint2(0u, 0u);
+    const uint64_t id = tally_id<TM>(ix, live, i, row);                 // r on the reference's throws: LF_move rejects it
     if (live) {
-        const uint32_t n = row_n<7>(row), off = row_off<7>(row), c = row_c<7>(row);
-        const uint32_t n16 = n | (row_thr<7>(row, 1) << 11) | (row_thr<7>(row, 2) << 12) | (c << 13);
-        const uint32_t off16 = off | (row_thr<7>(row, 0) << 11) | ((uint32_t)((id >> 32) & 0xFu) << 12);
+        const uint32_t n = row_n<TM>(row), off = row_off<TM>(row), c = row_c<TM>(row);
+        const uint32_t n16 = n | (row_thr<TM>(row, 1) << 11) | (row_thr<TM>(row, 2) << 12) | (c << 13);
+        const uint32_t off16 = off | (row_thr<TM>(row, 0) << 11) | ((uint32_t)((id >> 32) & 0xFu) << 12);
         out[i] = make_uint2((uint32_t)id, n16 | (off16 << 16));
     }
 }
@@ -1472,11 +1472,14 @@ hipError_t expand_blocked_rows(const DevIndex &ix, void *d_rows6, hipStream_t st
     return hipGetLastError();
 }
 
-hipError_t expand_sampled_rows(const DevIndex &ix, void *d_rows6, hipStream_t stream) {
+hipError_t expand_sampled_rows(int mode, const DevIndex &ix, void *d_rows6, hipStream_t stream) {
     const unsigned bt = 256;
     const uint64_t blocks = (ix.r + bt - 1) / bt;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(expand_sampled_kernel, dim3((unsigned)blocks), dim3(bt), 0, stream, ix, static_cast<uint2 *>(d_rows6));
+    if (mode == 7)
+        hipLaunchKernelGGL(expand_sampled_kernel<7>, dim3((unsigned)blocks), dim3(bt), 0, stream, ix, static_cast<uint2 *>(d_rows6));
+    else
+        hipLaunchKernelGGL(expand_sampled_kernel<5>, dim3((unsigned)blocks), dim3(bt), 0, stream, ix, static_cast<uint2 *>(d_rows6));
     return hipGetLastError();
 }
 

@@ -85,7 +85,7 @@ hipError_t launch_classify(const uint16_t *d_pml, const uint64_t *d_offsets, uin
                            uint32_t thr, uint32_t *d_above, uint32_t *d_below, uint64_t *d_sum, hipStream_t stream);
 
 // Mode 7: ix = a mode-7 view (widened rows + tally table); writes r mode-6 rows (8 bytes each) with the ids recovered by get_id.
-hipError_t expand_sampled_rows(const DevIndex &ix, void *d_rows6, hipStream_t stream);
+hipError_t expand_sampled_rows(int mode, const DevIndex &ix, void *d_rows6, hipStream_t stream);   // mode 7 or 5
 // Mode 8: ix = a mode-8 view (raw 6-byte rows + id_blocks); writes r mode-6 rows with the ids get_id reconstructs.
 hipError_t expand_blocked_rows(const DevIndex &ix, void *d_rows6, hipStream_t stream);
 

@@ -30,7 +30,8 @@ Reference code restated (file:line relative to /root/reference):
 import numpy as np
 
 MOVI_MAGIC = 0x4D4F5649          # include/utils.hpp:29
-MAX_RUN = {6: 2047, 8: 1023, 7: 511}   # include/move_row_configs.hpp:51,101,135
+MAX_RUN = {6: 2047, 8: 1023, 7: 511, 5: 1023}   # include/move_row_configs.hpp:51,101,135,117
+THRESHOLD_MODES = (6, 7, 8)      # include/utils.hpp:146 (USE_THRESHOLDS); mode 5 "sampled" keeps none
 TALLY_CHECKPOINTS = 20           # include/movi_options.hpp:257 (movi build --checkpoint default)
 BLOCK_SIZE = 1 << 20             # include/move_row_configs.hpp:102
 MAX_ALLOWED_BLOCKED_ID = (1 << 22) - 1   # :103
@@ -157,7 +158,7 @@ def bwt_and_thresholds(t):
 def build_rows(bwt, thr, mode):
     """Everything MoveStructure::build() derives from ref.bwt + ref.thr_pos.
     Returns a dict of the fields serialize() writes."""
-    assert mode in (6, 7, 8)
+    assert mode in (5, 6, 7, 8)
     n = len(bwt)
     maxrun = MAX_RUN[mode]
     # --- detect_move_row_boundaries (:328-396) + fill_bits_by_thresholds (:733-746)
@@ -167,7 +168,8 @@ def build_rows(bwt, thr, mode):
     orig_starts = np.flatnonzero(hard[:n])
     original_r = len(orig_starts)
     assert len(thr) == original_r
-    hard[thr] = True                                    # bits[thresholds[i]] = 1
+    if mode in THRESHOLD_MODES:
+        hard[thr] = True                                # bits[thresholds[i]] = 1 (rows split at thresholds, :733-746)
     seg = np.flatnonzero(hard[:n])
     seg_len = np.diff(np.concatenate((seg, [n])))
     # split every segment into pieces of MAX_RUN_LENGTH (:380-385: a new row starts
@@ -233,7 +235,7 @@ def build_rows(bwt, thr, mode):
     alphabet_thresholds = [n] * sigma
     thr_i = original_r - 1
     cl, pl, ll, tl = code.tolist(), all_p.tolist(), lens.tolist(), thr.tolist()
-    for i in range(r - 1, 0, -1):
+    for i in range(r - 1, 0, -1) if mode in THRESHOLD_MODES else ():
         rc = cl[i]                                      # '$' row has c == 0 -> 'A' (:823), '%' with separators
         if sep and rc == 0:
             sep_thr.append([0, 0, 0, 0])
@@ -261,7 +263,9 @@ def build_rows(bwt, thr, mode):
                     thr_bits[i, ALPHAMAP_3[rc - sep][j - sep]] = bit
         if cl[i] != cl[i - 1] or i == end_bwt_idx or i - 1 == end_bwt_idx:
             thr_i -= 1
-    if sep and cl[0] == 0:                              # :917-920
+    if mode not in THRESHOLD_MODES:
+        pass                                            # no thresholds of any kind (write_separators_thresholds is under USE_THRESHOLDS too)
+    elif sep and cl[0] == 0:                            # :917-920
         sep_thr.append([0, 0, 0, 0])
         sep_map[0] = len(sep_thr) - 1
     else:
@@ -274,7 +278,7 @@ def build_rows(bwt, thr, mode):
                sep=sep, sep_thr=sep_thr, sep_map=sep_map)
     if mode == 8:
         out.update(compute_blocked_ids(pp_id, code, end_bwt_idx, first_runs, sigma))
-    if mode == 7:
+    if mode in (5, 7):
         out.update(compute_tally_ids(pp_id, code, end_bwt_idx, sigma))
     return out
 
@@ -343,6 +347,14 @@ def encode_rows(f):
         rows[:, 1] = (pid >> 16) & 0xFFFF
         rows[:, 2] = n | (t[:, 1] << 11) | (t[:, 2] << 12) | (c << 13)
         rows[:, 3] = off | (t[:, 0] << 11) | ((pid >> 32) << 12)
+    elif mode == 5:
+        # sampled, no thresholds (move_row_configs.hpp:107-118): u8 n | u8 offset | u8 c with bits 0-1 = offset bits 8-9,
+        # bits 2-3 = n bits 8-9, bits 4-7 = character
+        rows = np.zeros((r, 3), np.uint8)
+        rows[:, 0] = n & 0xFF
+        rows[:, 1] = off & 0xFF
+        rows[:, 2] = (off >> 8) | ((n >> 8) << 2) | (c << 4)
+        return rows.tobytes()
     elif mode == 7:
         # include/move_row.hpp:122-127 + move_row_configs.hpp:120-136: u8 n | u8 offset | u8 c with
         # bit0 = offset bit 8, bit1 = n bit 8, bits 2-4 = character, bits 5-7 = threshold bits 0-2
@@ -372,7 +384,7 @@ def serialize(f):
            u64([256]), u64(f["alphamap"]), u64([len(f["alphabet"])]), f["alphabet"],
            b"\x00\x00", b"\x00",                       # u16 nt_splitting, bool constant
            encode_rows(f)]
-    if f["mode"] == 7:
+    if f["mode"] in (5, 7):
         # write_tally_table, src/move_structure_io.cpp:328-336: u32 checkpoints | u64 len | per character len x MoveTally
         # (40-bit id: u32 low | u8 high, include/move_row.hpp:13-40)
         tl = f["tally_ids"]
@@ -387,7 +399,7 @@ def serialize(f):
     if f["mode"] == 8:
         ib = f["id_blocks"]
         out += [u64([ib.shape[1]]), ib.astype("<u4").tobytes(), u64([f["block_size"]])]
-    if f.get("sep"):
+    if f.get("sep") and f["mode"] in THRESHOLD_MODES:
         # write_separators_thresholds, src/move_structure_io.cpp:399-413: u64 count | ThresholdsRow{u16[4]} each |
         # u64 map size | (u64 row, u64 entry) pairs.  The reference walks an unordered_map (unspecified order);
         # ascending row order here.

@@ -89,7 +89,7 @@ oracle_index *oracle_open(const uint8_t *buf, size_t n) {
     uint32_t magic; memcpy(&magic, hdr, 4);
     if (magic != 0x4D4F5649u) goto bad;                 /* MOVI_MAGIC utils.hpp:29 */
     ix->mode = hdr[7];
-    if (ix->mode != 6 && ix->mode != 8 && ix->mode != 7) goto bad;
+    if (ix->mode != 6 && ix->mode != 8 && ix->mode != 7 && ix->mode != 5) goto bad;
     ix->row_bytes = ix->mode == 6 ? 8 : (ix->mode == 8 ? 6 : 3);            /* MoveRow::row_size, move_row.hpp:104-120 */
     memcpy(&ix->length, hdr + 16, 8);
     memcpy(&ix->r, hdr + 24, 8);
@@ -107,7 +107,7 @@ oracle_index *oracle_open(const uint8_t *buf, size_t n) {
     if (rd(buf, n, &p, flags, 3)) goto bad;
     ix->rows = (uint8_t *)malloc(ix->r * ix->row_bytes + 16);
     if (!ix->rows || rd(buf, n, &p, ix->rows, ix->r * ix->row_bytes)) goto bad;
-    if (ix->mode == 7) {                                /* read_tally_table, io.cpp:338-349 */
+    if (ix->mode == 7 || ix->mode == 5) {               /* read_tally_table, io.cpp:338-349 */
         if (rd(buf, n, &p, &ix->tally_checkpoints, 4) || ix->tally_checkpoints == 0) goto bad;
         if (rd(buf, n, &p, &ix->tally_len, 8) || ix->tally_len > (n - p) / 5) goto bad;
         size_t bytes = ix->alphabet_size * ix->tally_len * 5;
@@ -139,7 +139,7 @@ oracle_index *oracle_open(const uint8_t *buf, size_t n) {
         if (p + 8 <= n) rd(buf, n, &p, &ix->block_size, 8);   /* io.cpp:321-323 */
     }
     ix->sep = ix->alphabet_size == 5 && ix->alphabet[0] == ORACLE_SEPARATOR;
-    if (ix->sep) {                                      /* read_separators_thresholds, io.cpp:415-433 */
+    if (ix->sep && ix->mode != 5) {                     /* read_separators_thresholds, io.cpp:415-433 (USE_THRESHOLDS only) */
         uint64_t nt, nm;
         if (rd(buf, n, &p, &nt, 8) || nt > (n - p) / 8) goto bad;
         uint16_t (*vals)[4] = (uint16_t (*)[4])malloc((nt ? nt : 1) * 8);
@@ -190,6 +190,10 @@ static inline uint64_t get_n(const oracle_index *ix, uint64_t i) {
         const uint8_t *b = ix->rows + i * 3;
         return (uint64_t)b[0] | ((uint64_t)((b[2] >> 1) & 1) << 8);
     }
+    if (ix->mode == 5) {                                /* sampled, no thresholds: SHIFT_N 2, 2 bits (configs :107-118) */
+        const uint8_t *b = ix->rows + i * 3;
+        return (uint64_t)b[0] | ((uint64_t)((b[2] >> 2) & 3) << 8);
+    }
     uint16_t w[4]; row16(ix, i, w);
     return ix->mode == 6 ? (w[2] & 0x7FF) : (w[1] & 0x3FF);
 }
@@ -199,12 +203,17 @@ static inline uint64_t get_offset(const oracle_index *ix, uint64_t i) {
         const uint8_t *b = ix->rows + i * 3;
         return (uint64_t)b[1] | ((uint64_t)(b[2] & 1) << 8);
     }
+    if (ix->mode == 5) {                                /* SHIFT_OFFSET 0, 2 bits */
+        const uint8_t *b = ix->rows + i * 3;
+        return (uint64_t)b[1] | ((uint64_t)(b[2] & 3) << 8);
+    }
     uint16_t w[4]; row16(ix, i, w);
     return ix->mode == 6 ? (w[3] & 0x7FF) : (w[2] & 0x3FF);
 }
 /* MoveRow::get_c, move_row.hpp:255-257 (n >> 13) / :297-299 ((offset >> 10) & 7) */
 static inline uint32_t get_c(const oracle_index *ix, uint64_t i) {
     if (ix->mode == 7) return (ix->rows[i * 3 + 2] >> 2) & 7;          /* move_row.hpp:219-221, SHIFT_C 2 */
+    if (ix->mode == 5) return (ix->rows[i * 3 + 2] >> 4) & 15;         /* SHIFT_C 4, 4 bits */
     uint16_t w[4]; row16(ix, i, w);
     return ix->mode == 6 ? (uint32_t)(w[2] >> 13) : (uint32_t)((w[2] >> 10) & 7);
 }
@@ -267,7 +276,7 @@ static uint64_t get_id_tally(const oracle_index *ix, uint64_t idx) {
 /* MoveStructure::get_id, src/move_structure.cpp:91-102 with MoveRow::get_id
  * move_row.hpp:232-243 (mode 6: id32 | (offset>>12)<<32) / :267-285 (mode 8: id16 | (n>>10)<<16) */
 static inline uint64_t get_id(const oracle_index *ix, uint64_t i) {
-    if (ix->mode == 7) return get_id_tally(ix, i);
+    if (ix->mode == 7 || ix->mode == 5) return get_id_tally(ix, i);
     uint16_t w[4]; row16(ix, i, w);
     if (ix->mode == 6) {
         uint64_t id = (uint64_t)w[0] | ((uint64_t)w[1] << 16);
@@ -445,6 +454,9 @@ int oracle_pml(const oracle_index *ix, const uint8_t *R, int64_t len, uint16_t *
                uint64_t *ff_tot, uint64_t *scan_tot) {
     strand_t s;
     uint64_t ff = 0, sc = 0;
+    /* an index without thresholds repositions RANDOMLY in the reference (reposition_randomly,
+     * src/move_structure_query.cpp:603-): its PMLs are not reproducible, so there is nothing to restate */
+    if (ix->mode == 5) return ORACLE_ERR_FORMAT;
     if (len <= 0) { if (ff_tot) *ff_tot = 0; if (scan_tot) *scan_tot = 0; return ORACLE_OK; }
     strand_reset(ix, &s, R, len, out);
     while (s.pos_on_r > -1) {
@@ -464,6 +476,7 @@ int oracle_pml(const oracle_index *ix, const uint8_t *R, int64_t len, uint16_t *
 int oracle_pml_batch(const oracle_index *ix, const uint8_t *seqs, const uint64_t *offs,
                      uint64_t n_reads, uint16_t *out, int threads, int strands,
                      uint64_t *ff_tot, uint64_t *scan_tot) {
+    if (ix->mode == 5) return ORACLE_ERR_FORMAT;        /* no thresholds: see oracle_pml */
     if (strands < 1) strands = 1;
     if (strands > 64) strands = 64;
     uint64_t n_groups = (n_reads + (uint64_t)strands - 1) / (uint64_t)strands;
@@ -661,6 +674,17 @@ int oracle_zml_batch(const oracle_index *ix, const uint8_t *seqs, const uint64_t
 }
 
 /* Single LF step exposed for generator / property tests. */
+/* MoveStructure::get_id of every row (ids[i] = r where the reference throws).  For the sampled modes this is the
+ * checkpoint scan + walk-back, INCLUDING what it does when r is a multiple of tally_checkpoints: the builder stores the
+ * final ids at entry r / cp + 1 (src/move_structure_build.cpp:677-682) but rows of the last span look at entry
+ * r / cp (src/move_structure.cpp:127, :151), which nothing ever wrote -- such LFs throw or go astray in the reference. */
+void oracle_get_ids(const oracle_index *ix, uint64_t *ids) {
+    for (uint64_t i = 0; i < ix->r; i++) {
+        uint64_t id = get_id(ix, i);
+        ids[i] = id >= ix->r ? ix->r : id;
+    }
+}
+
 int oracle_lf(const oracle_index *ix, uint64_t *idx, uint64_t *offset) {
     int64_t ff = LF_move(ix, offset, idx);
     return ff < 0 ? (int)ff : ORACLE_OK;

@@ -45,6 +45,8 @@ def lib():
         L.oracle_zml.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.oracle_zml_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
         L.oracle_lf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_get_ids.argtypes = [C.c_void_p, C.c_void_p]
+        L.oracle_get_ids.restype = None
         _lib = L
     return _lib
 
@@ -139,6 +141,12 @@ class Oracle:
         if rc:
             raise OracleError("oracle_zml_batch rc=%d" % rc)
         return out
+
+    def get_ids(self):
+        """MoveStructure::get_id of every row; r where the reference throws."""
+        ids = np.zeros(self.r, np.uint64)
+        lib().oracle_get_ids(self._h, ids.ctypes.data)
+        return ids
 
     def lf(self, idx, offset):
         i, o = C.c_uint64(idx), C.c_uint64(offset)

@@ -126,3 +126,17 @@ def test_parse_sampled_thresholds_index(built_lib):
     assert int(c.tally_checkpoints) == 20 and int(c.n_tally) == 118209 // 20 + 2
     with pytest.raises(movi_amd.MoviError):
         movi_amd.parse_index_image(img[: off + nbytes + 100])           # truncated tally table
+
+
+def test_parse_sampled_index(built_lib):
+    """Mode 5 (reference KAT 437006 B, tests/test_build.cpp:41-43): accepted; with separators there is no threshold section."""
+    import movi_amd
+    from conftest import GOLDEN
+    from oracle import build_index as B
+    ref = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))[0][1]
+    for sep, size in ((False, 437006), (True, 464203)):
+        img = B.build_index_from_seqs([ref], 5, separators=sep)
+        assert len(img) == size
+        desc, c, off, nbytes = movi_amd.parse_index_image(img)
+        assert (desc.mode, desc.row_bytes, nbytes) == (5, 3, desc.r * 3)
+        assert int(c.tally_checkpoints) == 20 and int(c.n_separator_thresholds) == 0

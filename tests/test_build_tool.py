@@ -82,6 +82,19 @@ def test_sampled_thresholds_known_answers_and_numpy_agreement(tool, tmp_path, se
     assert img == B.build_index_from_seqs([ref], 7, separators=separators)
 
 
+# tests/test_build.cpp:41-43 and :82-84 of the reference: sampled (no thresholds) index sizes
+@pytest.mark.parametrize("separators,size", [(False, 437006), (True, 464203)])
+def test_sampled_known_answers_and_numpy_agreement(tool, tmp_path, separators, size):
+    from oracle import build_index as B
+    out = str(tmp_path / "m5")
+    subprocess.check_call([tool, "fasta", os.path.join(GOLDEN, "ref.fasta"), "5", out] + (["separators"] if separators else []),
+                          stderr=subprocess.DEVNULL)
+    img = open(os.path.join(out, "index.movi"), "rb").read()
+    assert len(img) == size
+    ref = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))[0][1]
+    assert img == B.build_index_from_seqs([ref], 5, separators=separators)
+
+
 def test_pangenome_mode_is_queryable(tool, tmp_path):
     """Synthetic pangenome: substrings of the text are found end to end by the oracle's count query."""
     from oracle.oracle import Oracle

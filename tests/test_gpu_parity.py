@@ -702,3 +702,68 @@ def test_sampled_expansion_equals_regular_rows(built_lib, golden_image):
     assert nbytes == n
     assert (host == img6[off: off + nbytes]).all()
     gpu.close()
+
+
+@pytest.mark.parametrize("separators", [False, True])
+def test_sampled_no_thresholds_index(built_lib, separators):
+    """Mode 5: count and ZML against the oracle; PML refused (the reference repositions randomly without thresholds); the
+    table expanded on the GPU equals the same rows encoded in the regular-thresholds layout by the numpy constructor."""
+    import ctypes as C
+    import movi_amd
+    from oracle import build_index as B
+    from oracle.oracle import Oracle
+    ref = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))[0][1]
+    t = B.clean_text([ref], separators=separators)
+    f = B.build_rows(*B.bwt_and_thresholds(t), 5)
+    img = B.serialize(f)
+    assert len(img) == (464203 if separators else 437006)
+    gpu, cpu = movi_amd.MoveIndex.from_image(img), Oracle(img)
+    assert gpu.desc.mode == 5
+    rng = np.random.default_rng(500 + separators)
+    reads = mutated_reads(rng, ref, 400, 1, 1200) + [b"", b"A", b"N", b"%", b"ACGT" * 100]
+    bases, offs = pack(reads)
+    m, c, _ = gpu.query_count_packed(bases, offs)
+    em, ec = cpu.count_batch(bases, offs, threads=4)
+    assert (m == em).all() and (c == ec).all()
+    z, _ = gpu.query_zml_packed(bases, offs)
+    assert (z == cpu.zml_batch(bases, offs, threads=4)).all()
+    with pytest.raises(movi_amd.MoviError) as e:
+        gpu.query_pml_packed(bases, offs)
+    assert e.value.code == -1 and "thresholds" in str(e.value)
+    ptr, n = gpu.device_rows()
+    host = np.empty(n, np.uint8)
+    assert C.CDLL("libamdhip64.so").hipMemcpy(C.c_void_p(host.ctypes.data), C.c_void_p(ptr), C.c_size_t(n), C.c_int(2)) == 0
+    assert host.tobytes() == B.encode_rows(dict(f, mode=6))
+    gpu.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_sampled_expansion_equals_oracle_get_id_fuzz(built_lib, seed):
+    """get_id on the GPU for every row of awkward multi-record texts (modes 7 and 5, with and without separators): the
+    expanded table holds the oracle's get_id of every row (the reference's algorithm, its blind spot when r is a multiple
+    of the checkpoint distance included -- seed 2 has r = 600) next to the constructor's offset / length / character /
+    threshold bits; wherever the reference's get_id works it is the constructor's own id."""
+    import ctypes as C
+    import movi_amd
+    from oracle import build_index as B
+    from oracle.oracle import Oracle
+    rng = np.random.default_rng(8100 + seed)
+    seqs = []
+    for _ in range(int(rng.integers(1, 6))):
+        unit = bytes(rng.choice(list(b"ACGT"), size=int(rng.integers(3, 200))).astype(np.uint8))
+        seqs.append(unit * int(rng.integers(1, 8)) + b"T" * int(rng.integers(0, 3000)))
+    hip = C.CDLL("libamdhip64.so")
+    for separators in (False, True):
+        bwt, thr = B.bwt_and_thresholds(B.clean_text(seqs, separators=separators))
+        for mode in (7, 5):
+            f = B.build_rows(bwt, thr, mode)
+            img = B.serialize(f)
+            gpu = movi_amd.MoveIndex.from_image(img)
+            ptr, n = gpu.device_rows()
+            host = np.empty(n, np.uint8)
+            assert hip.hipMemcpy(C.c_void_p(host.ctypes.data), C.c_void_p(ptr), C.c_size_t(n), C.c_int(2)) == 0
+            ids = Oracle(img).get_ids().astype(np.int64)
+            if f["r"] % 20:                                    # the reference's get_id is sound: it is the constructor's id
+                assert (ids == f["pp_id"]).all(), (seed, separators, mode)
+            assert host.tobytes() == B.encode_rows(dict(f, mode=6, pp_id=ids)), (seed, separators, mode)
+            gpu.close()

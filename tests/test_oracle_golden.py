@@ -288,3 +288,33 @@ def test_sampled_count_and_zml_equal_brute_force(sampled_image):
         assert (m, c) == (k, _occurrences(T, R[len(R) - k:]))
     for R in _mutated_reads(recs[0][1], rng, 30, 1, 200) + [b"NA", b"ACGTNNACGT"]:
         assert o.zml(R).tolist() == _zml_brute(T, R), R
+
+
+# ---------------------------------------------------------------- sampled (mode 5: the sampled layout without thresholds)
+# tests/test_build.cpp:41-43 (437006 B) and :82-84 (464203 B with --separators).  PML on an index without thresholds
+# repositions randomly in the reference (reposition_randomly): count and ZML are the reproducible queries.
+
+def test_sampled_no_thresholds_known_answers_and_queries(ref_bwt):
+    bwt, thr = ref_bwt
+    f = B.build_rows(bwt, thr, 5)
+    img = B.serialize(f)
+    assert len(img) == 437006 and f["r"] == f["original_r"] == 108629      # rows = BWT runs: no threshold splits
+    recs = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))
+    t = B.clean_text([s for _, s in recs], separators=True)
+    assert len(B.serialize(B.build_rows(*B.bwt_and_thresholds(t), 5))) == 464203
+    o = Oracle(img)
+    with pytest.raises(Exception):
+        o.pml(b"ACGT")
+    T = bytes(B.clean_text([s for _, s in recs])[:-1])
+    rng = np.random.default_rng(25)
+    for R in _mutated_reads(recs[0][1], rng, 40, 1, 120, sub=0.02, ill=0.005) + [b"A", b"GNAC"]:
+        m, c = o.count(R)
+        if R[-1:] not in (b"A", b"C", b"G", b"T"):
+            assert (m, c) == (0, 0)
+            continue
+        k = 1
+        while k < len(R) and R[len(R) - k - 1:len(R) - k] in (b"A", b"C", b"G", b"T") and R[len(R) - k - 1:] in T:
+            k += 1
+        assert (m, c) == (k, _occurrences(T, R[len(R) - k:]))
+    for R in _mutated_reads(recs[0][1], rng, 30, 1, 200) + [b"NA", b"ACGTNNACGT"]:
+        assert o.zml(R).tolist() == _zml_brute(T, R), R

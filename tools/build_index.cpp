@@ -1,4 +1,4 @@
-// build_index.cpp -- index constructor for modes 6 / 7 / 8 (bench + test tooling; SURVEY section 8(f) "next #2").
+// build_index.cpp -- index constructor for modes 5 / 6 / 7 / 8 (bench + test tooling; SURVEY section 8(f) "next #2").
 //
 // FASTA (or a synthetic pangenome) -> cleaned text with reverse complements -> suffix array (SA-IS) ->
 // BWT + LCP (Kasai) -> per-run thresholds -> move rows -> `index.movi` bytes.  Linear time, so that
@@ -15,7 +15,7 @@
 // Checked byte-for-byte against tests/golden/index_*/index.movi (whose sizes are the reference's
 // known answers 948119 / 711733, tests/test_build.cpp:37,53) in tests/test_build_tool.py.
 //
-// usage: build_index fasta <ref.fasta> <mode 6|7|8> <out_dir> [separators]     ("separators" = movi build --separators:
+// usage: build_index fasta <ref.fasta> <mode 5|6|7|8> <out_dir> [separators]     ("separators" = movi build --separators:
 //            every record and reverse complement followed by %; sizes 948232 / 711854 B, tests/test_build.cpp:79,95)
 //        build_index pangenome <ancestor_len> <n_genomes> <snp_rate> <seed> <mode> <out_dir> [n_reads read_len sub_rate]
 //            [n_reads2 read_len2 sub_rate2]
@@ -147,6 +147,7 @@ static void put64(std::vector<uint8_t> &o, uint64_t v) { for (int i = 0; i < 8; 
 
 // ------------------------------------------------------------------------------- text -> index.movi bytes
 static std::vector<uint8_t> build_index(std::vector<uint8_t> &text, int mode) {
+    const bool with_thresholds = mode != 5;                               // mode 5 "sampled": USE_THRESHOLDS is off
     text.push_back(0);                                                    // terminator
     const sa_t n = (sa_t)text.size();
     if ((uint64_t)text.size() >= (1ull << 31)) { fprintf(stderr, "text too long for 32-bit suffix array\n"); exit(1); }
@@ -196,10 +197,10 @@ static std::vector<uint8_t> build_index(std::vector<uint8_t> &text, int mode) {
             curmin[c] = INF;                                              // the range restarts after this position
         }
     }
-    for (uint64_t t : thr) hard[t] = true;
+    if (with_thresholds) for (uint64_t t : thr) hard[t] = true;           // rows split at thresholds (:733-746)
     std::vector<sa_t>().swap(lcp);
     const uint64_t original_r = thr.size();
-    const uint32_t maxrun = mode == 6 ? 2047 : (mode == 8 ? 1023 : 511);  // move_row_configs.hpp:51,101,135
+    const uint32_t maxrun = mode == 6 ? 2047 : (mode == 7 ? 511 : 1023);  // move_row_configs.hpp:51,101,135,117
     // rows (:328-396)
     std::vector<uint64_t> all_p;
     {
@@ -271,7 +272,7 @@ static std::vector<uint8_t> build_index(std::vector<uint8_t> &text, int mode) {
     {
         std::vector<uint64_t> at(sigma, (uint64_t)n);
         uint64_t thr_i = original_r - 1;
-        for (uint64_t i = r - 1; i > 0; --i) {
+        for (uint64_t i = r - 1; with_thresholds && i > 0; --i) {
             const int rc = code[i];                                       // '$' row has c == 0 -> behaves as 'A' (:823)
             if (sep && rc == 0) {
                 sep_thr.push_back({0, 0, 0, 0});
@@ -298,7 +299,9 @@ static std::vector<uint8_t> build_index(std::vector<uint8_t> &text, int mode) {
             }
             if (code[i] != code[i - 1] || i == end_bwt_idx || i - 1 == end_bwt_idx) thr_i--;
         }
-        if (sep && code[0] == 0) {                                        // :917-920
+        if (!with_thresholds) {
+            // no thresholds of any kind
+        } else if (sep && code[0] == 0) {                                 // :917-920
             sep_thr.push_back({0, 0, 0, 0});
             sep_map.emplace_back(0, sep_thr.size() - 1);
         } else {
@@ -335,7 +338,7 @@ static std::vector<uint8_t> build_index(std::vector<uint8_t> &text, int mode) {
     const uint64_t tally_cp = 20;                                         // movi_options.hpp:257
     std::vector<uint64_t> tally;
     uint64_t n_tally = 0;
-    if (mode == 7) {
+    if (mode == 7 || mode == 5) {
         n_tally = r / tally_cp + 2;
         tally.assign(sigma * n_tally, 0);
         std::vector<uint64_t> cur(sigma, r);
@@ -376,6 +379,10 @@ static std::vector<uint8_t> build_index(std::vector<uint8_t> &text, int mode) {
             w[3] = (uint16_t)(doff[i] | ((t & 1) << 11) | ((uint32_t)(d >> 32) << 12));
             const uint8_t *p = reinterpret_cast<const uint8_t *>(w);
             o.insert(o.end(), p, p + 8);
+        } else if (mode == 5) {                                            // sampled, no thresholds: configs :107-118
+            o.push_back((uint8_t)(lens[i] & 0xFF));
+            o.push_back((uint8_t)(doff[i] & 0xFF));
+            o.push_back((uint8_t)((doff[i] >> 8) | ((lens[i] >> 8) << 2) | ((uint32_t)code[i] << 4)));
         } else if (mode == 7) {                                            // move_row.hpp:122-127, configs :120-136
             o.push_back((uint8_t)(lens[i] & 0xFF));
             o.push_back((uint8_t)(doff[i] & 0xFF));
@@ -389,7 +396,7 @@ static std::vector<uint8_t> build_index(std::vector<uint8_t> &text, int mode) {
             o.insert(o.end(), p, p + 6);
         }
     }
-    if (mode == 7) {                                                      // write_tally_table, io.cpp:328-336
+    if (mode == 7 || mode == 5) {                                         // write_tally_table, io.cpp:328-336
         const uint32_t cp32 = (uint32_t)tally_cp;
         for (int b = 0; b < 4; b++) o.push_back((uint8_t)(cp32 >> (8 * b)));
         put64(o, n_tally);
@@ -409,7 +416,7 @@ static std::vector<uint8_t> build_index(std::vector<uint8_t> &text, int mode) {
         o.insert(o.end(), p, p + id_blocks.size() * 4);
         put64(o, block_size);
     }
-    if (sep) {                                                            // write_separators_thresholds, io.cpp:399-413
+    if (sep && with_thresholds) {                                         // write_separators_thresholds, io.cpp:399-413
         put64(o, sep_thr.size());
         for (const auto &t : sep_thr) for (int k = 0; k < 4; k++) { o.push_back((uint8_t)(t[k] & 0xFF)); o.push_back((uint8_t)(t[k] >> 8)); }
         std::sort(sep_map.begin(), sep_map.end());                        // the reference walks an unordered_map; ascending rows here
@@ -513,7 +520,7 @@ int main(int argc, char **argv) {
         fprintf(stderr, "usage: see the header of tools/build_index.cpp\n");
         return 1;
     }
-    if (mode != 6 && mode != 7 && mode != 8) { fprintf(stderr, "mode must be 6, 7 or 8\n"); return 1; }
+    if (mode != 5 && mode != 6 && mode != 7 && mode != 8) { fprintf(stderr, "mode must be 5, 6, 7 or 8\n"); return 1; }
     mkdir(out_dir.c_str(), 0777);
     if (cmd == "pangenome") write_file(out_dir + "/text.bin", text);       // lets `reads` draw more reads later
     for (int set = 0; set < 2; set++) {                                    // optional second read set: argv[11..13] -> reads2.bin
