@@ -487,10 +487,11 @@ def test_fuzz_small_indexes(built_lib, tmp_path, alphabet):
             gpu.close()
 
 
-@pytest.mark.parametrize("mode", [6, 8])
+@pytest.mark.parametrize("mode", [6, 8, 7])
 def test_real_bwt_pangenome_vs_oracle(built_lib, tmp_path, mode):
     """A real-BWT index of a synthetic 16-genome pangenome (~1 M rows, built by tools/build_index) with
-    20 k substrings + mutations: every PML and every count against the oracle."""
+    20 k substrings + mutations: every PML and every count against the oracle (which walks the index type as
+    stored: blocked ids, sampled ids through get_id per step), on the GPU through the expanded table."""
     import subprocess
     import movi_amd
     from oracle.oracle import Oracle
