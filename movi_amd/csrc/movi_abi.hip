@@ -245,36 +245,22 @@ static int finish_create(movi_index *ix) {
         v.last_runs[i] = d.last_runs[i];
         v.last_offsets[i] = d.last_offsets[i];
     }
-    // ---- resident row layout (needs the complete device view above: get_id reads first_runs / id_blocks / tally)
+    // ---- resident row layout: ONE for every index type.  Blocked- and sampled-* tables are expanded to regular-thresholds
+    // rows once, on the GPU, by the reference's get_id (needs the complete device view above: get_id reads first_runs /
+    // id_blocks / tally).  Blocked: aligned 8-byte rows with the id inside instead of 2-byte-aligned 6-byte rows + a
+    // check-point lookup per LF (count +7-10 %, ZML +28 %, PML +2-4 %, measured); sampled: see expand_sampled_kernel.
     ix->kmode = (int)d.mode;
-    if (d.mode == MOVI_MODE_BLOCKED_THRESHOLDS) {
-        // expand to regular-thresholds rows once (expand_blocked_kernel): aligned 8-byte rows with the id inside instead of
-        // 2-byte-aligned 6-byte rows + a check-point lookup per LF (count +7-10 %, ZML +28 %, PML +2-4 %, measured)
-        if (d.r >= (1ull << 36)) return fail(MOVI_ERR_ARG, "blocked-thresholds index with 2^36 rows or more");
+    if (d.mode != MOVI_MODE_REGULAR_THRESHOLDS) {
+        if (d.r >= (1ull << 36)) return fail(MOVI_ERR_ARG, "2^36 rows or more do not fit the resident row layout");
+        const bool blocked = d.mode == MOVI_MODE_BLOCKED_THRESHOLDS;
         uint8_t *rows6 = nullptr;
         HIP_TRY(hipMalloc(&rows6, (size_t)d.r * 8 + 16));
         hipError_t e = hipMemset(rows6, 0, (size_t)d.r * 8 + 16);
-        if (e == hipSuccess) e = expand_blocked_rows(v, rows6, nullptr);
+        if (e == hipSuccess) e = blocked ? expand_blocked_rows(v, rows6, nullptr) : expand_sampled_rows((int)d.mode, v, rows6, nullptr);
         if (e == hipSuccess) e = hipDeviceSynchronize();
-        if (e != hipSuccess) { (void)hipFree(rows6); return fail_hip(e, "expanding the blocked rows"); }
-        if (ix->owns_rows && ix->d_rows) (void)hipFree(ix->d_rows);
-        ix->d_rows = rows6;
-        ix->owns_rows = true;
-        v.rows = rows6;
-        ix->kmode = MOVI_MODE_REGULAR_THRESHOLDS;
-    }
-    if (d.mode == MOVI_MODE_SAMPLED_THRESHOLDS || d.mode == MOVI_MODE_SAMPLED) {
-        // expand to regular-thresholds rows once (movi_kernels.hip, expand_sampled_kernel); the widened rows and the
-        // tally table are only needed for that
-        if (d.r >= (1ull << 36)) return fail(MOVI_ERR_ARG, "sampled-thresholds index with 2^36 rows or more");
-        uint8_t *rows6 = nullptr;
-        HIP_TRY(hipMalloc(&rows6, (size_t)d.r * 8 + 16));
-        hipError_t e = hipMemset(rows6, 0, (size_t)d.r * 8 + 16);
-        if (e == hipSuccess) e = expand_sampled_rows((int)d.mode, v, rows6, nullptr);
-        if (e == hipSuccess) e = hipDeviceSynchronize();
-        if (e != hipSuccess) { (void)hipFree(rows6); return fail_hip(e, "expanding the sampled rows"); }
-        if (ix->owns_rows && ix->d_rows) (void)hipFree(ix->d_rows);
-        (void)hipFree(ix->d_tally);
+        if (e != hipSuccess) { (void)hipFree(rows6); return fail_hip(e, "expanding the rows to the resident layout"); }
+        if (ix->owns_rows && ix->d_rows) (void)hipFree(ix->d_rows);       // the file-format copy (an adopted buffer stays the caller's)
+        if (ix->d_tally) (void)hipFree(ix->d_tally);                      // sampled: only get_id needed the checkpoints
         ix->d_tally = nullptr;
         ix->d_rows = rows6;
         ix->owns_rows = true;
