@@ -451,10 +451,17 @@ def main():
                                     "scans_per_base": round(st3.scans / (n3 * L3), 4), "errors": int(st3.errors)}
         except Exception as e:                            # noqa: BLE001 -- never lose the headline line to the extra
             result["long_reads"] = {"error": repr(e)[:200]}
+    parity_failed = rank == 0 and result.get("parity_sample_ok") is False
+    if parity_failed:
+        # a kernel that disagrees with the oracle has no throughput: the record keeps the measurement under
+        # another name, `value` is nulled and the process fails
+        result["value_unverified"], result["value"] = result["value"], None
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
+    if parity_failed:
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

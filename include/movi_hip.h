@@ -212,7 +212,7 @@ int movi_count_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_
 /* Kernel variant / launch knobs, for A/B measurement (bench.py --variant).
  * Unknown keys return MOVI_ERR_ARG.  Keys: "pml_variant" (-1 = auto by batch size, 0 = first
  * kernel, 1 = base-synchronous packed I/O, 7 = flat lane state machine, 10 = 7 + row window,
- * software-pipelined), "block_threads", "waves_per_cu" (0 = uncapped), "idx64" (1 = run the kernel
+ * software-pipelined), "block_threads" (64, 128, 192 or 256: the kernels' launch bound), "waves_per_cu" (0 = uncapped), "idx64" (1 = run the kernel
  * instantiations for tables of 2^32 rows and more, whatever the size: a test hook). */
 int movi_set_option(movi_index_t *ix, const char *key, int64_t value);
 

@@ -39,14 +39,15 @@ constexpr uint32_t kMoviMagic = 0x4D4F5649u;   // include/utils.hpp:29
 struct Reader {
     const uint8_t *p;
     size_t n, pos = 0;
+    // overflow-safe: `len` comes from file fields and may be anything
     bool get(void *dst, size_t len) {
-        if (pos + len > n) return false;
+        if (len > n - pos) return false;
         memcpy(dst, p + pos, len);
         pos += len;
         return true;
     }
     bool skip(size_t len) {
-        if (pos + len > n) return false;
+        if (len > n - pos) return false;
         pos += len;
         return true;
     }
@@ -117,7 +118,10 @@ int movi_index_parse(const void *h_image, size_t image_bytes, movi_index_desc_t 
     memcpy(&desc->length, hdr + 16, 8);
     memcpy(&desc->r, hdr + 24, 8);
     memcpy(&desc->end_bwt_idx, hdr + 40, 8);
-    if (desc->r == 0 || desc->end_bwt_idx >= desc->r) return fail(MOVI_ERR_FORMAT, "corrupt header (r / end_bwt_idx)");
+    // ids are 36 bits in every supported row layout (move_row_configs.hpp:34-51), so r < 2^36 -- which also keeps
+    // every product of r below with a row size far from wrapping a u64
+    if (desc->r == 0 || desc->r >= (1ull << 36) || desc->end_bwt_idx >= desc->r)
+        return fail(MOVI_ERR_FORMAT, "corrupt header (r / end_bwt_idx)");
     if (!rd.get(desc->end_bwt_idx_thresholds, 32) || !rd.skip(64)) return fail(MOVI_ERR_FORMAT, "truncated index (basic data)");
     uint64_t amap_n = 0;
     if (!rd.get(&amap_n, 8) || amap_n != 256) return fail(MOVI_ERR_FORMAT, "unexpected alphamap size");
@@ -137,14 +141,15 @@ int movi_index_parse(const void *h_image, size_t image_bytes, movi_index_desc_t 
     if (!rd.skip(3)) return fail(MOVI_ERR_FORMAT, "truncated index (flags)");
     const size_t row_b = desc->mode == MOVI_MODE_REGULAR_THRESHOLDS ? 8 : (desc->mode == MOVI_MODE_BLOCKED_THRESHOLDS ? 6 : 3);
     const size_t roff = rd.pos;
-    if (!rd.skip(desc->r * row_b)) return fail(MOVI_ERR_FORMAT, "truncated index (move rows)");
+    if (desc->r > (image_bytes - rd.pos) / row_b || !rd.skip(desc->r * row_b))
+        return fail(MOVI_ERR_FORMAT, "truncated index (move rows)");
     const bool sampled = desc->mode == MOVI_MODE_SAMPLED_THRESHOLDS || desc->mode == MOVI_MODE_SAMPLED;
     if (sampled) {                                         // read_tally_table, move_structure_io.cpp:338-349
         if (!rd.get(&desc->tally_checkpoints, 4) || desc->tally_checkpoints == 0)
             return fail(MOVI_ERR_FORMAT, "truncated index (tally checkpoints)");
         if (!rd.get(&desc->n_tally, 8)) return fail(MOVI_ERR_FORMAT, "truncated index (tally table)");
         desc->tally_ids = rd.p + rd.pos;
-        if (desc->n_tally > image_bytes / 5 || !rd.skip(desc->n_tally * asz * 5))
+        if (desc->n_tally > image_bytes / (asz * 5) || !rd.skip(desc->n_tally * asz * 5))
             return fail(MOVI_ERR_FORMAT, "truncated index (tally table)");
         if (desc->n_tally < desc->r / desc->tally_checkpoints + 2)
             return fail(MOVI_ERR_FORMAT, "tally table does not cover the rows");
@@ -165,11 +170,13 @@ int movi_index_parse(const void *h_image, size_t image_bytes, movi_index_desc_t 
         if (!rd.get(&desc->n_blocks, 8)) return fail(MOVI_ERR_FORMAT, "truncated index (id blocks)");
         // the id_blocks payload stays in the image; callers locate it via desc->id_blocks
         desc->id_blocks = reinterpret_cast<const uint32_t *>(rd.p + rd.pos);
-        if (!rd.skip(desc->n_blocks * asz * 4)) return fail(MOVI_ERR_FORMAT, "truncated index (id blocks)");
+        if (desc->n_blocks > image_bytes / (asz * 4) || !rd.skip(desc->n_blocks * asz * 4))
+            return fail(MOVI_ERR_FORMAT, "truncated index (id blocks)");
         desc->block_size = 1048576;                        // BLOCK_SIZE, move_row_configs.hpp:102
         uint64_t bs = 0;
         if (rd.get(&bs, 8)) desc->block_size = bs;         // move_structure_io.cpp:321-323
-        if (desc->block_size == 0 || desc->n_blocks * desc->block_size < desc->r)
+        // n_blocks * block_size >= r without the product (either factor is a file field)
+        if (desc->block_size == 0 || desc->n_blocks == 0 || (desc->r - 1) / desc->block_size >= desc->n_blocks)
             return fail(MOVI_ERR_FORMAT, "id blocks do not cover the table");
     }
     if (sep && desc->mode != MOVI_MODE_SAMPLED) {          // read_separators_thresholds, move_structure_io.cpp:415-433 (USE_THRESHOLDS)
@@ -251,7 +258,6 @@ static int finish_create(movi_index *ix) {
     // check-point lookup per LF (count +7-10 %, ZML +28 %, PML +2-4 %, measured); sampled: see expand_sampled_kernel.
     ix->kmode = (int)d.mode;
     if (d.mode != MOVI_MODE_REGULAR_THRESHOLDS) {
-        if (d.r >= (1ull << 36)) return fail(MOVI_ERR_ARG, "2^36 rows or more do not fit the resident row layout");
         const bool blocked = d.mode == MOVI_MODE_BLOCKED_THRESHOLDS;
         uint8_t *rows6 = nullptr;
         HIP_TRY(hipMalloc(&rows6, (size_t)d.r * 8 + 16));
@@ -280,6 +286,11 @@ static int check_desc(const movi_index_desc_t *desc) {
         (!desc->tally_ids || desc->tally_checkpoints == 0 || desc->n_tally < desc->r / desc->tally_checkpoints + 2))
         return fail(MOVI_ERR_ARG, "mode 7 needs tally_checkpoints / tally_ids covering the rows");
     if (desc->r == 0 || desc->end_bwt_idx >= desc->r) return fail(MOVI_ERR_ARG, "bad r / end_bwt_idx");
+    if (desc->r >= (1ull << 36)) return fail(MOVI_ERR_ARG, "2^36 rows or more: ids are 36 bits in every row layout");
+    if (desc->mode == MOVI_MODE_BLOCKED_THRESHOLDS &&
+        (desc->block_size == 0 || desc->n_blocks == 0 || (desc->r - 1) / desc->block_size >= desc->n_blocks ||
+         desc->n_blocks > (1ull << 36)))
+        return fail(MOVI_ERR_ARG, "id blocks do not cover the table");
     if (desc->alphabet_size == 0 || desc->alphabet_size > 5) return fail(MOVI_ERR_ARG, "alphabet_size must be 1..5");
     if (desc->alphabet_size == 5) {
         if (desc->alphabet[0] != '%') return fail(MOVI_ERR_ARG, "a 5-symbol alphabet must be '%' + ACGT (separators)");
@@ -468,7 +479,9 @@ int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
         return MOVI_OK;
     }
     if (!strcmp(key, "block_threads")) {
-        if (value < 64 || value > 1024 || (value & 63)) return fail(MOVI_ERR_ARG, "block_threads must be a multiple of 64 in [64,1024]");
+        // every query kernel is compiled with __launch_bounds__(256)
+        if (value != 64 && value != 128 && value != 192 && value != 256)
+            return fail(MOVI_ERR_ARG, "block_threads must be 64, 128, 192 or 256");
         ix->cfg.block_threads = (int)value;
         return MOVI_OK;
     }
@@ -524,6 +537,7 @@ int movi_last_stats(movi_index_t *ix, void *stream, movi_query_stats_t *stats) {
     HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
     DevStats h{};
     HIP_TRY(hipMemcpy(&h, ix->d_stats, sizeof(h), hipMemcpyDeviceToHost));
+    stats->bases = 0;                      // not tracked on the device: the *_host entry points fill it in
     stats->fast_forwards = h.fast_forwards;
     stats->scans = h.scans;
     stats->repositions = h.repositions;
@@ -550,6 +564,16 @@ struct DevBuf {
     hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 8); }
 };
 
+// The offsets are the caller's: every *_host entry point validates them all before they size a chunk, an
+// allocation or a copy (and before the device is touched, so the check is testable without one).
+int check_offsets(const uint64_t *h_offsets, uint64_t n_reads) {
+    for (uint64_t i = 0; i < n_reads; i++) {
+        if (h_offsets[i + 1] < h_offsets[i]) return fail(MOVI_ERR_ARG, "read offsets are not non-decreasing");
+        if (h_offsets[i + 1] - h_offsets[i] > 0xFFFFFFFFull) return fail(MOVI_ERR_ARG, "a read is longer than 2^32 - 1 bases");
+    }
+    return MOVI_OK;
+}
+
 template <typename Launch, typename Fetch>
 int run_chunked(movi_index *ix, const uint8_t *h_bases, const uint64_t *h_offsets, uint64_t n_reads,
                 uint8_t *h_read_err, movi_query_stats_t *stats, Launch launch, Fetch fetch) {
@@ -570,10 +594,6 @@ int run_chunked(movi_index *ix, const uint8_t *h_bases, const uint64_t *h_offset
         HIP_TRY(d_err.alloc(nr));
         std::vector<uint64_t> rel(nr + 1);
         for (uint64_t i = 0; i <= nr; i++) rel[i] = h_offsets[first + i] - b0;
-        for (uint64_t i = 0; i < nr; i++) {
-            if (rel[i + 1] < rel[i]) return fail(MOVI_ERR_ARG, "read offsets are not non-decreasing");
-            if (rel[i + 1] - rel[i] > 0xFFFFFFFFull) return fail(MOVI_ERR_ARG, "a read is longer than 2^32 - 1 bases");
-        }
         // No length sort here: on ragged batches handing the lanes out longest-first measured
         // slightly SLOWER (31.1 vs 32.8 Gbases/s, log-normal lengths) -- the walk is bound by the
         // memory system, not by lane occupancy, and the dispatcher already refills whole blocks.
@@ -611,6 +631,7 @@ static int ml_host(bool zml, movi_index_t *ix, const uint8_t *h_bases, const uin
     if (n_reads == 0) { if (stats) memset(stats, 0, sizeof(*stats)); return MOVI_OK; }
     if (!h_offsets || (h_offsets[n_reads] != h_offsets[0] && (!h_bases || !h_out_pml)))
         return fail(MOVI_ERR_ARG, "NULL host buffer");
+    if (int rc0 = check_offsets(h_offsets, n_reads)) return rc0;
     HIP_TRY(hipSetDevice(ix->device));
     DevBuf d_out;
     uint64_t out_cap = 0;
@@ -684,6 +705,7 @@ int movi_pml_classify_host(movi_index_t *ix, const uint8_t *h_bases, const uint6
     if (n_reads == 0) { if (stats) memset(stats, 0, sizeof(*stats)); return MOVI_OK; }
     if (!h_offsets || !h_bins_above || !h_bins_below || !h_sum_max || (h_offsets[n_reads] != h_offsets[0] && !h_bases))
         return fail(MOVI_ERR_ARG, "NULL host buffer");
+    if (int rc0 = check_offsets(h_offsets, n_reads)) return rc0;
     if (bin_width == 0) return fail(MOVI_ERR_ARG, "bin_width must be > 0");
     HIP_TRY(hipSetDevice(ix->device));
     DevBuf d_a, d_b, d_s;
@@ -757,6 +779,7 @@ int movi_count_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_
     if (n_reads == 0) { if (stats) memset(stats, 0, sizeof(*stats)); return MOVI_OK; }
     if (!h_offsets || !h_matched || !h_count || (h_offsets[n_reads] != h_offsets[0] && !h_bases))
         return fail(MOVI_ERR_ARG, "NULL host buffer");
+    if (int rc0 = check_offsets(h_offsets, n_reads)) return rc0;
     HIP_TRY(hipSetDevice(ix->device));
     DevBuf d_m, d_c;
     uint64_t cap = 0;

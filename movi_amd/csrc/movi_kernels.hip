@@ -946,24 +946,22 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
         if (bpc < 1) bpc = 1;
         if (bpc < 32) dyn_lds = ((163840u / (unsigned)bpc) & ~1023u) - 1024u;
     }
-#define MOVI_LAUNCH_PML(M, V, C)                                                                            \
+    // every kernel that is handed more than 64 KiB of dynamic LDS must opt in first
+#define MOVI_LAUNCH_K(...)                                                                                  \
     do {                                                                                                    \
         if (dyn_lds > 65536) {                                                                              \
-            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&pml_kernel<M, V, C>),       \
+            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&__VA_ARGS__),               \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds);  \
             if (ea != hipSuccess) return ea;                                                                \
         }                                                                                                   \
-        hipLaunchKernelGGL((pml_kernel<M, V, C>), grid, block, dyn_lds, stream, ix, d_bases, d_offsets,     \
-                           n_reads, d_out, d_err, d_stats, d_order, cls);                                   \
+        hipLaunchKernelGGL((__VA_ARGS__), grid, block, dyn_lds, stream, ix, d_bases, d_offsets, n_reads,    \
+                           d_out, d_err, d_stats, d_order, cls);                                            \
     } while (0)
+#define MOVI_LAUNCH_PML(M, V, C) MOVI_LAUNCH_K(pml_kernel<M, V, C>)
 #define MOVI_LAUNCH_FLATP_S(M, C, S)                                                                        \
     do {                                                                                                    \
-        if (ix.idx32)                                                                                       \
-            hipLaunchKernelGGL((pml_kernel_flatp<M, uint32_t, 2, C, S>), grid, block, dyn_lds, stream, ix,  \
-                               d_bases, d_offsets, n_reads, d_out, d_err, d_stats, d_order, cls);           \
-        else                                                                                                \
-            hipLaunchKernelGGL((pml_kernel_flatp<M, uint64_t, 2, C, S>), grid, block, dyn_lds, stream, ix,  \
-                               d_bases, d_offsets, n_reads, d_out, d_err, d_stats, d_order, cls);           \
+        if (ix.idx32) MOVI_LAUNCH_K(pml_kernel_flatp<M, uint32_t, 2, C, S>);                                \
+        else MOVI_LAUNCH_K(pml_kernel_flatp<M, uint64_t, 2, C, S>);                                         \
     } while (0)
 #define MOVI_LAUNCH_FLATP(M, C)                                                                             \
     do {                                                                                                    \
@@ -971,12 +969,8 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     } while (0)
 #define MOVI_LAUNCH_FLAT(M)                                                                                 \
     do {                                                                                                    \
-        if (ix.idx32)                                                                                       \
-            hipLaunchKernelGGL((pml_kernel_flat<M, uint32_t, 0>), grid, block, dyn_lds, stream, ix,         \
-                               d_bases, d_offsets, n_reads, d_out, d_err, d_stats, d_order, cls);           \
-        else                                                                                                \
-            hipLaunchKernelGGL((pml_kernel_flat<M, uint64_t, 0>), grid, block, dyn_lds, stream, ix,         \
-                               d_bases, d_offsets, n_reads, d_out, d_err, d_stats, d_order, cls);           \
+        if (ix.idx32) MOVI_LAUNCH_K(pml_kernel_flat<M, uint32_t, 0>);                                       \
+        else MOVI_LAUNCH_K(pml_kernel_flat<M, uint64_t, 0>);                                                \
     } while (0)
 #define MOVI_BY_CLS(LAUNCH, ...)                                                                            \
     do {                                                                                                    \
@@ -1000,6 +994,7 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     if (v == 0) MOVI_LAUNCH_PML(6, 0, 0); else if (v == 1) MOVI_BY_CLS(MOVI_LAUNCH_PML, 6, 1);
     else if (v == 7) MOVI_LAUNCH_FLAT(6); else MOVI_BY_CLS(MOVI_LAUNCH_FLATP, 6);
 #undef MOVI_LAUNCH_PML
+#undef MOVI_LAUNCH_K
 #undef MOVI_LAUNCH_FLAT
 #undef MOVI_LAUNCH_FLATP
 #undef MOVI_LAUNCH_FLATP_S

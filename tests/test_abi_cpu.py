@@ -61,6 +61,27 @@ def test_parse_rejects_bad_images(built_lib, golden_image):
     assert "not supported" in str(e.value)
     with pytest.raises(movi_amd.MoviError):
         movi_amd.parse_index_image(bytes(img[: len(img) // 2]))
+    # u64 wrap-around: r + 2^61 makes r * 8 wrap to the true table size, so a naive `pos + r * 8 <= n` accepts it
+    import struct
+    for mode, row_b in ((6, 8), (8, 6)):
+        gi = bytearray(golden_image(mode))
+        (r,) = struct.unpack_from("<Q", gi, 24)
+        for bogus in (r + (1 << 61), r + (1 << 63), (1 << 64) - 1, 1 << 36):
+            w = bytearray(gi)
+            struct.pack_into("<Q", w, 24, bogus)
+            with pytest.raises(movi_amd.MoviError) as e:
+                movi_amd.parse_index_image(bytes(w))
+            assert e.value.code == -2, (mode, bogus)
+    # blocked: n_blocks / block_size whose product wraps must not pass the coverage check
+    gi = bytearray(golden_image(8))
+    desc, c, off, nbytes = movi_amd.parse_index_image(bytes(gi))
+    at = len(gi) - 8                                          # trailing u64 block_size (move_structure_io.cpp:321-323)
+    assert struct.unpack_from("<Q", gi, at)[0] == 1 << 20
+    for bogus in (0, 1, 1 << 10):                             # 1 block of 1 / 1024 rows does not cover 118209 rows
+        w = bytearray(gi)
+        struct.pack_into("<Q", w, at, bogus)
+        with pytest.raises(movi_amd.MoviError):
+            movi_amd.parse_index_image(bytes(w))
 
 
 def test_no_cpu_fallback(built_lib, golden_image):

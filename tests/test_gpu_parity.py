@@ -223,6 +223,42 @@ def test_host_argument_validation(engines):
         with pytest.raises(MoviError) as e:
             q(bases, np.array([0, 6, 4, 10], np.uint64))
         assert e.value.code == -1 and "non-decreasing" in str(e.value)
+        # a decreasing pair that would underflow the chunk's byte count: refused before anything is allocated
+        with pytest.raises(MoviError) as e:
+            q(bases, np.array([100, 0], np.uint64))
+        assert e.value.code == -1 and "non-decreasing" in str(e.value)
+    with pytest.raises(MoviError) as e:
+        gpu.classify_packed(bases, np.array([100, 0], np.uint64), 150, 8)
+    assert e.value.code == -1
+
+
+def test_launch_options_are_bounded(engines):
+    """block_threads beyond the kernels' __launch_bounds__(256) is refused; the occupancy cap (dynamic LDS padding
+    above 64 KiB needs an opt-in per kernel) works with every selectable PML kernel."""
+    from movi_amd._lib import MoviError
+    from oracle import build_index as B
+    gpu, cpu = engines[6]
+    for bad in (0, 32, 100, 512, 1024):
+        with pytest.raises(MoviError) as e:
+            gpu.set_option("block_threads", bad)
+        assert e.value.code == -1
+    ref = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))[0][1]
+    reads = mutated_reads(np.random.default_rng(77), ref, 400, 1, 200)
+    bases, offs = pack(reads)
+    exp, _, _ = cpu.pml_batch(bases, offs, threads=4)
+    try:
+        for bt in (64, 128, 256):
+            gpu.set_option("block_threads", bt)
+            for wpc in (1, 2, 4):                             # 159 KiB / 79 KiB / 39 KiB of dynamic LDS per block of 64
+                gpu.set_option("waves_per_cu", wpc)
+                for variant in (1, 7, 10):
+                    gpu.set_option("pml_variant", variant)
+                    out, st = gpu.query_pml_packed(bases, offs)
+                    assert (out == exp).all() and st.errors == 0, (bt, wpc, variant)
+    finally:
+        gpu.set_option("pml_variant", -1)
+        gpu.set_option("waves_per_cu", 0)
+        gpu.set_option("block_threads", 256)
 
 
 def test_invariant_violation_is_flagged_not_hidden(built_lib, golden_image):

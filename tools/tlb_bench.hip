@@ -1,0 +1,140 @@
+// tlb_bench.hip -- does the ALLOCATION flavour change the random-gather ceiling on a table far larger than the TLB reach?
+//
+// The PML walk on a 1 B-row (8 GB) table misses the per-CU TLB on 70 % of its lookups (profiles/r01_c4_*), and the pure
+// gather rate drops from ~65 G/s (64 MB table) to ~49 G/s (8 GB).  This tool repeats the dependent 8-byte gather of
+// tools/gather_bench.hip (and its 16 B / 32 B / neighbour forms) over tables obtained from
+//   hipMalloc | hipExtMallocWithFlags(hipDeviceMallocContiguous) | hipMemCreate + hipMemMap (one physical handle)
+// at several sizes, to see whether physically contiguous memory (larger page-table fragments) buys TLB reach.
+//
+// build: hipcc -O3 --offload-arch=gfx950 -o tlb_bench tlb_bench.hip ; run: ./tlb_bench [log2 rows ...]
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+__device__ __forceinline__ uint64_t mix(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ void fill_table(uint64_t *t, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) t[i] = mix(i + 0x9E3779B97F4A7C15ull);
+}
+__device__ __forceinline__ uint32_t next_idx(uint64_t v, uint32_t n_rows) {
+    return __umulhi((uint32_t)(v ^ (v >> 32)), n_rows);
+}
+
+// VAR 0: 8 B row; 1: aligned 16 B pair; 2: aligned 32 B quad (2 x 16 B); 3: 8 B row + dependent neighbour row
+template <int VAR>
+__global__ __launch_bounds__(256) void chase(const uint64_t *__restrict__ table, uint32_t n_rows, int steps,
+                                             uint64_t n_lanes, uint64_t *__restrict__ sink) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_lanes) return;
+    uint32_t idx = next_idx(mix(t), n_rows);
+    uint64_t acc = 0;
+    for (int k = 0; k < steps; ++k) {
+        uint64_t v;
+        if (VAR == 0 || VAR == 3) {
+            v = table[idx];
+            if (VAR == 3) v ^= table[idx + 1 + (uint32_t)(v & 1)] >> 7;
+        } else if (VAR == 1) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(table + (idx & ~1u));
+            v = (idx & 1) ? ((uint64_t)q.w << 32 | q.z) : ((uint64_t)q.y << 32 | q.x);
+            acc += q.x ^ q.z;
+        } else {
+            const uint4 *p = reinterpret_cast<const uint4 *>(table + (idx & ~3u));
+            const uint4 q0 = p[0], q1 = p[1];
+            const uint4 q = (idx & 2) ? q1 : q0;
+            v = (idx & 1) ? ((uint64_t)q.w << 32 | q.z) : ((uint64_t)q.y << 32 | q.x);
+            acc += q0.x ^ q1.z;
+        }
+        acc ^= v;
+        idx = next_idx(v + k, n_rows);
+    }
+    if (acc == 0x1234567ull) sink[0] = acc;
+}
+
+template <int VAR>
+double run(const uint64_t *table, uint32_t n_rows, int steps, uint64_t lanes, uint64_t *sink, int reps) {
+    dim3 block(256), grid((unsigned)((lanes + 255) / 256));
+    hipEvent_t a, b;
+    CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+    hipLaunchKernelGGL(chase<VAR>, grid, block, 0, 0, table, n_rows, steps, lanes, sink);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(a));
+    for (int i = 0; i < reps; i++) hipLaunchKernelGGL(chase<VAR>, grid, block, 0, 0, table, n_rows, steps, lanes, sink);
+    CHECK(hipEventRecord(b));
+    CHECK(hipEventSynchronize(b));
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, a, b));
+    return (double)ms / reps;
+}
+
+int main(int argc, char **argv) {
+    int sizes[8], ns = 0;
+    for (int i = 1; i < argc && ns < 8; i++) sizes[ns++] = atoi(argv[i]);
+    if (ns == 0) { sizes[0] = 24; sizes[1] = 27; sizes[2] = 30; ns = 3; }
+    const int steps = 150;
+    uint64_t *sink;
+    CHECK(hipMalloc(&sink, 64));
+    const char *alloc_names[3] = {"hipMalloc", "hipExtMallocWithFlags(hipDeviceMallocContiguous)", "hipMemCreate+hipMemMap (one handle)"};
+    const char *names[4] = {"8B row", "16B pair", "32B quad", "8B row + dependent neighbour"};
+    for (int si = 0; si < ns; si++) {
+        const uint64_t n = 1ull << sizes[si];
+        for (int which = 0; which < 3; which++) {
+            uint64_t *table = nullptr;
+            hipMemGenericAllocationHandle_t handle{};
+            size_t vm_bytes = 0;
+            hipError_t ea = hipSuccess;
+            if (which == 0) ea = hipMalloc(&table, n * 8 + 64);
+            else if (which == 1) ea = hipExtMallocWithFlags((void **)&table, n * 8 + 64, hipDeviceMallocContiguous);
+            else {
+                hipMemAllocationProp prop{};
+                prop.type = hipMemAllocationTypePinned;
+                prop.location.type = hipMemLocationTypeDevice;
+                prop.location.id = 0;
+                size_t gran = 0;
+                ea = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended);
+                if (ea == hipSuccess) {
+                    printf("  (VMM recommended granularity: %zu bytes)\n", gran);
+                    vm_bytes = ((n * 8 + 64 + gran - 1) / gran) * gran;
+                    ea = hipMemCreate(&handle, vm_bytes, &prop, 0);
+                }
+                if (ea == hipSuccess) ea = hipMemAddressReserve((void **)&table, vm_bytes, 1ull << 30, nullptr, 0);
+                if (ea == hipSuccess) ea = hipMemMap(table, vm_bytes, 0, handle, 0);
+                if (ea == hipSuccess) {
+                    hipMemAccessDesc acc{};
+                    acc.location.type = hipMemLocationTypeDevice;
+                    acc.location.id = 0;
+                    acc.flags = hipMemAccessFlagsProtReadWrite;
+                    ea = hipMemSetAccess(table, vm_bytes, &acc, 1);
+                }
+            }
+            printf("table 2^%d rows = %.1f MB, alloc: %s, ptr %p\n", sizes[si], n * 8 / 1e6, alloc_names[which], (void *)table);
+            if (ea != hipSuccess) { printf("  allocation failed: %s\n", hipGetErrorString(ea)); (void)hipGetLastError(); continue; }
+            hipLaunchKernelGGL(fill_table, dim3(4096), dim3(256), 0, 0, table, n);
+            CHECK(hipDeviceSynchronize());
+            const uint32_t n_rows = (uint32_t)(n - 8);
+            for (uint64_t lanes : {(uint64_t)1 << 19, (uint64_t)1 << 20}) {
+                double ms[4];
+                ms[0] = run<0>(table, n_rows, steps, lanes, sink, 4);
+                ms[1] = run<1>(table, n_rows, steps, lanes, sink, 4);
+                ms[2] = run<2>(table, n_rows, steps, lanes, sink, 4);
+                ms[3] = run<3>(table, n_rows, steps, lanes, sink, 4);
+                for (int v = 0; v < 4; v++)
+                    printf("  lanes=%8llu  %-30s %8.3f ms  %7.2f Gsteps/s\n", (unsigned long long)lanes, names[v], ms[v],
+                           lanes * (double)steps / ms[v] / 1e6);
+            }
+            if (which == 2) {
+                (void)hipMemUnmap(table, vm_bytes);
+                (void)hipMemRelease(handle);
+                (void)hipMemAddressFree(table, vm_bytes);
+            } else CHECK(hipFree(table));
+        }
+    }
+    return 0;
+}
