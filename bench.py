@@ -305,14 +305,17 @@ def main():
 
     # which PML kernel launch_pml picked (movi_kernels.hip: state machine for <= 12 waves/CU of reads, mode 6 / 8)
     n_cus = torch.cuda.get_device_properties(dev).multi_processor_count
-    v_sel = args.variant if args.variant >= 0 else (10 if n_reads <= n_cus * 64 * 12 else 1)
+    v_sel = args.variant if args.variant >= 0 else 10     # launch_pml: variant 10, capped at 9 waves per CU on big batches
     if args.classify and v_sel == 0:
         v_sel = 1
     if args.classify and v_sel == 7:
         v_sel = 10
+    wpc_refill = args.waves_per_cu if args.waves_per_cu > 0 else 9          # kRefillWaves, movi_kernels.hpp
+    if v_sel == 13 and (d_order or n_reads <= n_cus * 64 * wpc_refill):
+        v_sel = 10
     kmode = 6                                        # one resident row layout (movi_abi.hip: finish_create)
     pml_kernel_name = {0: "pml_kernel<%d,0>" % kmode, 1: "pml_kernel<%d,1>" % kmode, 7: "pml_kernel_flat<%d>" % kmode,
-                       10: "pml_kernel_flatp<%d>" % kmode}[v_sel]
+                       10: "pml_kernel_flatp<%d,refill=0>" % kmode, 13: "pml_kernel_flatp<%d,refill=1>" % kmode}[v_sel]
     f_bar = st.fast_forwards / max(n_bases, 1)
     s_bar = st.scans / max(n_bases, 1)
     bytes_per_base = row_bytes * (1.0 + f_bar + s_bar) + 1 + 2
@@ -353,6 +356,8 @@ def main():
                    "seed": SEED, "parallelism": "reads sharded x%d, index replicated (1 RCCL broadcast)" % world,
                    "fast_forwards_per_base": round(f_bar, 4), "scans_per_base": round(s_bar, 4),
                    "reposition_frac": round(st.repositions / max(n_bases, 1), 4),
+                   "simt_efficiency": round(st.lane_steps / (64.0 * st.wave_steps), 4) if st.wave_steps else None,
+                   "iterations_per_base": round(st.lane_steps / max(n_bases, 1), 4) if st.wave_steps else None,
                    "algorithmic_bytes_per_base": round(bytes_per_base, 3),
                    "query": args.query, "fused_classify": args.classify, "matched_bases_per_step": work_bases, "pml_variant": args.variant, "ragged": args.ragged, "waves_per_cu": args.waves_per_cu, "block_threads": args.block_threads, "index_gen_s": round(t_index_gen, 2),
                    "index_upload_s": round(t_index_upload, 2), "index_broadcast_s": round(t_bcast, 3),

@@ -99,6 +99,9 @@ typedef struct movi_query_stats {
     uint64_t scans;                   /* rows stepped over in reposition scans / interval shrink */
     uint64_t repositions;             /* bases that took the mismatch branch           */
     uint64_t errors;                  /* reads whose error flag is set                 */
+    uint64_t lane_steps;              /* lane state machines only: iterations in which a lane had work ...   */
+    uint64_t wave_steps;              /* ... and iterations run by its wavefront: SIMT efficiency =
+                                       * lane_steps / (64 * wave_steps); 0 / 0 from the other kernels        */
 } movi_query_stats_t;
 
 const char *movi_last_error(void);
@@ -212,8 +215,11 @@ int movi_count_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_
 /* Kernel variant / launch knobs, for A/B measurement (bench.py --variant).
  * Unknown keys return MOVI_ERR_ARG.  Keys: "pml_variant" (-1 = auto by batch size, 0 = first
  * kernel, 1 = base-synchronous packed I/O, 7 = flat lane state machine, 10 = 7 + row window,
- * software-pipelined), "block_threads" (64, 128, 192 or 256: the kernels' launch bound), "waves_per_cu" (0 = uncapped), "idx64" (1 = run the kernel
- * instantiations for tables of 2^32 rows and more, whatever the size: a test hook). */
+ * software-pipelined, 13 = 10 as a persistent grid whose lanes take a new read when they finish one),
+ * "refill_blocks" (variant 13: wavefronts in the persistent grid, 0 = CUs x waves per CU),
+ * "block_threads" (0 = auto, 64, 128, 192 or 256: the kernels' launch bound), "waves_per_cu"
+ * (0 = uncapped; variant 13: 0 = its default of 9), "idx64" (1 = run the kernel instantiations for
+ * tables of 2^32 rows and more, whatever the size: a test hook). */
 int movi_set_option(movi_index_t *ix, const char *key, int64_t value);
 
 /* ---- ZML (Ziv-Merhav cross parse) ---------------------------------------------- */

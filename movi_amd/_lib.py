@@ -46,6 +46,8 @@ class QueryStatsC(C.Structure):
         ("scans", C.c_uint64),
         ("repositions", C.c_uint64),
         ("errors", C.c_uint64),
+        ("lane_steps", C.c_uint64),
+        ("wave_steps", C.c_uint64),
     ]
 
 

@@ -468,8 +468,8 @@ int movi_index_device_rows(const movi_index_t *ix, const void **d_rows, size_t *
 int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
     if (!ix || !key) return fail(MOVI_ERR_ARG, "NULL argument");
     if (!strcmp(key, "pml_variant")) {
-        if (value != -1 && value != 0 && value != 1 && value != 7 && value != 10)
-            return fail(MOVI_ERR_ARG, "pml_variant must be -1 (auto), 0, 1, 7 or 10");
+        if (value != -1 && value != 0 && value != 1 && value != 7 && value != 10 && value != 13)
+            return fail(MOVI_ERR_ARG, "pml_variant must be -1 (auto), 0, 1, 7, 10 or 13");
         ix->cfg.pml_variant = (int)value;
         return MOVI_OK;
     }
@@ -480,9 +480,14 @@ int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
     }
     if (!strcmp(key, "block_threads")) {
         // every query kernel is compiled with __launch_bounds__(256)
-        if (value != 64 && value != 128 && value != 192 && value != 256)
-            return fail(MOVI_ERR_ARG, "block_threads must be 64, 128, 192 or 256");
+        if (value != 0 && value != 64 && value != 128 && value != 192 && value != 256)
+            return fail(MOVI_ERR_ARG, "block_threads must be 0 (auto), 64, 128, 192 or 256");
         ix->cfg.block_threads = (int)value;
+        return MOVI_OK;
+    }
+    if (!strcmp(key, "refill_blocks")) {                     // test hook / tuning: persistent grid of the lane-refill kernel
+        if (value < 0 || value > (1 << 20)) return fail(MOVI_ERR_ARG, "refill_blocks must be in [0, 2^20]");
+        ix->cfg.refill_blocks = (int)value;
         return MOVI_OK;
     }
     if (!strcmp(key, "waves_per_cu")) {
@@ -514,7 +519,7 @@ static int ml_device(bool zml, movi_index_t *ix, const uint8_t *d_bases, const u
         HIP_TRY(launch_zml(ix->kmode, ix->dev, d_bases, d_offsets, n_reads, d_out, d_read_err, ix->d_stats,
                            d_read_order, ix->cfg, s));
     else
-        HIP_TRY(launch_pml(ix->kmode, ix->dev, d_bases, d_offsets, n_reads, d_out, d_read_err, ix->d_stats,
+        HIP_TRY(launch_pml(ix->kmode, ix->dev, d_bases, d_offsets, n_reads, n_bases, d_out, d_read_err, ix->d_stats,
                            d_read_order, ix->cfg, s, cls));
     return MOVI_OK;
 }
@@ -542,6 +547,8 @@ int movi_last_stats(movi_index_t *ix, void *stream, movi_query_stats_t *stats) {
     stats->scans = h.scans;
     stats->repositions = h.repositions;
     stats->errors = h.errors;
+    stats->lane_steps = h.lane_steps;
+    stats->wave_steps = h.wave_steps;
     return MOVI_OK;
 }
 
@@ -615,6 +622,8 @@ int run_chunked(movi_index *ix, const uint8_t *h_bases, const uint64_t *h_offset
             stats->scans += st.scans;
             stats->repositions += st.repositions;
             stats->errors += st.errors;
+            stats->lane_steps += st.lane_steps;
+            stats->wave_steps += st.wave_steps;
         }
         first = last;
     }

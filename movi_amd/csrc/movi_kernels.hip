@@ -722,50 +722,74 @@ __device__ __forceinline__ uint2 win_sel(const uint2 (&w)[4], uint32_t q) {
 // Measured (100 k x 10 kbp, Gbases/s, pangenome / random table): unpipelined window kernel (variant 8, removed)
 // 36.4 / 33.6; chunk double-buffering alone 35.1 / 32.4; pipelined HA = 1 / 2 / 3: 40.2 / 39.6 / 38.9 (pangenome),
 // 36.3 / 36.6 / 36.2 (random) -> HA = 2 shipped.  Hops after the step (HC > 0) measured slower and are gone.
-template <int MODE, typename IdxT, int HA, int CLS, int SEP>
+// REFILL = 1 ("lane refill", variant 13, the default whenever there are more reads than resident lanes): the same
+// automaton as a PERSISTENT grid of num_cus x waves_per_cu wavefronts whose lanes take a new read the moment they
+// finish one.  Without it a wavefront runs until its slowest lane is done: on 1 M x 150 bp only 80 % of the lane
+// iterations did work (reads differ in fast-forward / scan iterations), on log-normal read lengths 43 %.
+//   * Tickets are wave-local and need no atomics: wave v's t-th read is rid_of(t) -- chunks of 16 consecutive reads
+//     dealt round-robin to the waves -- so a refill is integer arithmetic on a wave-uniform counter (ballot + mbcnt).
+//     Across waves the split is static (each wave walks ~n_reads / n_waves reads, so length differences average out);
+//     inside a wave it is dynamic.  The launcher sizes the grid so that all of it is resident.
+//   * A refill never waits on memory and never makes the compiler wait: when a lane starts read X it also takes the
+//     ticket of its next read and issues the loads of that read's offsets, which are looked at only when X ends.  The
+//     switch is register moves in the bookkeeping half of the iteration in which X ends, under the gather's latency; it
+//     issues the loads of the new read's first 32 bases and parks the lane in `sLoad` for ONE iteration (the bases
+//     land with that iteration's row window, which for a parked lane is the window of row r-1, where every read
+//     starts).  Prefetching those bases as well (so that the lane loses no iteration at all) was tried first: two
+//     blocks that each load into registers the other one reads made hipcc put `s_waitcnt vmcnt(0)` into both --
+//     right behind the row gather -- and the kernel ran 6 % SLOWER than variant 10 despite 92 % instead of 80 %
+//     busy lanes; one parked iteration in ~190 is the cheaper price.
+//   * Results of a read (error byte, bins, zero-fill on failure) are written when it ends, not after the loop.
+// `order` is not supported (longest-first ordering is what refill replaces).
+template <int MODE, typename IdxT, int HA, int CLS, int SEP, int REFILL>
 __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8_t *__restrict__ bases,
                                                        const uint64_t *__restrict__ offs, uint64_t n_reads,
                                                        uint16_t *__restrict__ out, uint8_t *__restrict__ err,
                                                        DevStats *stats, const uint32_t *__restrict__ order,
                                                        ClsArgs cls) {
-    enum : uint32_t { sFF = 0, sDown = 1, sUp = 2, sDone = 3 };
+    enum : uint32_t { sFF = 0, sDown = 1, sUp = 2, sDone = 3, sLoad = 4 };   // sLoad (REFILL): first bases of a new read in flight
     __shared__ uint8_t s_code[256];
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = ix.code_of[i];
     __syncthreads();
 
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t ff_total = 0, scan_total = 0, repo_total = 0, failed = 0;
+    uint32_t ff_total = 0, scan_total = 0, repo_total = 0, failed = 0, err_total = 0;
     const EndThr ethr = end_thresholds(ix);
-    const bool valid = t < n_reads;
-    const uint64_t rid = (valid && order) ? order[t] : t;
-    const uint64_t beg = valid ? offs[rid] : 0;
-    const uint32_t len = valid ? (uint32_t)(offs[rid + 1] - beg) : 0;   // reads are shorter than 2^32 (checked on the host)
-    const uint8_t *R = bases + beg;
-    uint16_t *O = out + beg;
-    const uint32_t packed_end = len & ~7u;
     const IdxT r1 = (IdxT)(ix.r - 1), end_row = (IdxT)ix.end_bwt_idx;
+    const uint2 row_r1 = load_row<MODE>(ix.rows, r1);       // ReadProcessor::reset_process :69-70: every read starts here
+    const uint32_t off0 = row_n<MODE>(row_r1) - 1;
 
-    auto load_chunk = [&](uint32_t kk) -> uint64_t {
-        uint64_t v = 0;
-        if (beg + len >= (uint64_t)kk + 8) {
-            __builtin_memcpy(&v, R + len - kk - 8, 8);    // may start before R: still inside `bases`
-        } else {
-            for (uint32_t i = 0; i < len - kk; ++i) v |= (uint64_t)R[len - 1 - kk - i] << (8 * (7 - i));
-        }
-        return v;
+    // ---- the lane's current read
+    const bool valid = !REFILL && t < n_reads;
+    uint64_t rid = (valid && order) ? order[t] : t;
+    uint64_t beg = valid ? offs[rid] : 0;
+    uint32_t len = valid ? (uint32_t)(offs[rid + 1] - beg) : 0;   // reads are shorter than 2^32 (checked on the host)
+    uint32_t packed_end = len & ~7u;
+
+    // The 16 bases of steps kk .. kk+15 of the read (b, l) are the bytes [b + l - kk - 16, b + l - kk) of `bases`, last
+    // step first: ONE unconditional 16-byte load -- c0 = steps kk .. kk+7 (step kk in the top byte), c1 = steps kk+8 ..
+    // kk+15.  Bytes that belong to steps >= l are never looked at, so a read's last, partial group needs no special
+    // case; it merely reaches back into the previous read.  Only a read that starts in the first 16 bytes of the
+    // batch can reach back past the buffer: its address is clamped to 0 and fix_pair() shifts the bytes into place
+    // WHEN THEY ARE USED.  (Every read-chunk fetch is a 128-byte line from the fabric -- its line is evicted long
+    // before the lane comes back -- so 8-base fetches cost 0.125 lines per base, 11 % of all line fetches on c3.)
+    // No branch, no select and no zero-fill may touch c0 / c1 at the load: the prefetched groups are consumed 16 steps later,
+    // and anything that reads or overwrites the registers of a load in flight makes hipcc park an `s_waitcnt vmcnt(0)`
+    // behind it -- i.e. behind the row gather issued just before -- which un-pipelines the iteration (the byte-wise
+    // tail variants of the first version did exactly that once per read and lane: every third iteration of a wave).
+    // The launcher guarantees >= 16 bytes of bases in the batch.
+    // (e = b + l - kk: one past the byte of step kk)
+    auto load_pair_at = [&](uint64_t e, uint64_t &c0, uint64_t &c1) {
+        uint64_t two[2];
+        __builtin_memcpy(two, bases + (e >= 16 ? e - 16 : 0), 16);
+        c0 = two[1];
+        c1 = two[0];
     };
-    // 16 bases per fetch when they exist (every read-chunk fetch is a 128-byte line from the fabric -- its line is
-    // evicted long before the lane comes back -- so 8-base fetches cost 0.125 lines per base, 11 % of all line fetches
-    // on c3): c0 = the 8 bases of steps kk .. kk+7, c1 = steps kk+8 .. kk+15
-    auto load_pair = [&](uint32_t kk, uint64_t &c0, uint64_t &c1) {
-        if ((uint64_t)kk + 16 <= len) {
-            uint64_t two[2];
-            __builtin_memcpy(two, R + len - kk - 16, 16);
-            c0 = two[1];
-            c1 = two[0];
-        } else {
-            c0 = kk < len ? load_chunk(kk) : 0;
-            c1 = kk + 8 < len ? load_chunk(kk + 8) : 0;
+    auto fix_pair = [&](uint64_t e, uint64_t &c0, uint64_t &c1) {
+        if (e < 16) {                                     // the 128-bit value (c0:c1) << 8 * (16 - e); e >= 1
+            const uint32_t sh = 8u * (uint32_t)(16 - e);  // 8 .. 120
+            if (sh >= 64) { c0 = c1 << (sh - 64); c1 = 0; }
+            else { c0 = (c0 << sh) | (c1 >> (64 - sh)); c1 <<= sh; }
         }
     };
     // The 4-row window that holds row nd: aligned, except that the table's last window is pulled back to
@@ -779,30 +803,65 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
     auto fetch = [&](IdxT nd, bool act, uint2 (&w)[4]) {
         load_window<MODE>(ix.rows, (uint64_t)(act ? win_base(nd) : (IdxT)0), w);
     };
+    // end of a read: what the reference's exception / output paths do with it
+    ClsState cs;
+    auto finish_read = [&]() {
+        if (failed && CLS != 2) {
+            for (uint32_t i = 0; i < len; ++i) out[beg + i] = 0;
+        }
+        if (CLS) cs.store(cls, rid, failed != 0u);
+        if (err) err[rid] = (uint8_t)failed;
+        err_total += failed ? 1u : 0u;
+    };
 
     uint32_t st = len > 0 ? sFF : sDone;
-    IdxT need = r1;                                       // ReadProcessor::reset_process :69-70
+    IdxT need = r1;
     uint32_t k = 0;
     uint32_t ml = 0, ff_run = 0;
-    uint32_t off = row_n<MODE>(load_row<MODE>(ix.rows, r1)) - 1;
+    uint32_t off = off0;
     uint64_t rb = 0, rb2 = 0, nx0 = 0, nx1 = 0;           // current 8 bases, the 8 after them, and the next 16 (in flight)
-    if (st != sDone) load_pair(0, rb, rb2);
-    if (len > 16) load_pair(16, nx0, nx1);
+    if (st != sDone) {
+        load_pair_at(beg + len, rb, rb2);
+        fix_pair(beg + len, rb, rb2);
+    }
+    if (len > 16) load_pair_at(beg + len - 16, nx0, nx1);
     uint32_t a = s_code[(uint32_t)(rb >> 56) & 0xFFu];    // code of the base of step k (k = 0)
     uint4 pk = make_uint4(0, 0, 0, 0), pk_old = pk;
-    ClsState cs;
     if (CLS) cs.init(len, cls.bin_width);
     uint2 w[4];
     fetch(need, st != sDone, w);
 
-    while (wave_any(st != sDone)) {
-        const bool act = st != sDone;
+    // ---- lane refill: wave-local tickets and the prefetched next read
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t wave = t >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    auto rid_of = [&](uint32_t tk) -> uint64_t {
+        return (uint64_t)(tk >> 4) * (n_waves << 4) + (wave << 4) + (uint64_t)(tk & 15u);
+    };
+    uint32_t tnext = 64, has_next = 0, nend_lo = 0;
+    uint64_t rid_n = 0, nbeg = 0;
+    // the offsets of the lane's next read: an 8-byte and a 4-byte load (reads are shorter than 2^32), NOT one 16-byte
+    // load -- hipcc reused the dead top dword of that tuple for another variable and waited for the load to do so
+    auto load_next_offsets = [&]() {
+        nbeg = offs[rid_n];
+        nend_lo = *reinterpret_cast<const uint32_t *>(offs + rid_n + 1);
+    };
+    if (REFILL) {
+        rid_n = rid_of(lane);
+        has_next = rid_n < n_reads;
+        if (has_next) load_next_offsets();
+    }
+
+    uint32_t lane_steps = 0, wave_steps = 0;
+    while (wave_any(st != sDone || (REFILL && has_next))) {
+        const bool act = st < sDone;
+        lane_steps += (uint32_t)act;
+        wave_steps += 1;
         const IdxT wbase = win_base(need);
         // cheap hop: a fast-forward or scan step that only moves on (everything that resolves a base,
         // starts a scan, ends one or fails is left to the full step below)
         auto hop = [&]() {
             const uint32_t q = (uint32_t)(need - wbase);
-            const uint32_t inwin = (uint32_t)(q < 4u) & (uint32_t)(st != sDone);
+            const uint32_t inwin = (uint32_t)(q < 4u) & (uint32_t)(st < sDone);
             const uint2 hr = win_sel(w, q);
             const uint32_t hn = row_n<MODE>(hr), hc = row_c<MODE>(hr);
             const uint32_t ffh = inwin & (uint32_t)(st == sFF) & (uint32_t)(need < r1) & (uint32_t)(off >= hn) &
@@ -865,6 +924,8 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
         // (`row` is not touched below, so the new window can land in the old one's registers)
         fetch(need_next, st_next != sDone, w);
         // ---- bookkeeping, all selects
+        uint32_t want_nx = 0;                             // this lane asks for the 16 bases that end at byte nx_e
+        uint64_t nx_e = 0;
         ml = resolved ? (match ? ml + 1 : 0u) : ml;
         ff_total += resolved ? ff_run : 0u;
         ff_run = lf ? 0u : ff_run + ffm;
@@ -874,6 +935,7 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
         off += lf ? roff : 0u;
         if (emit) {
             const uint32_t val = ml > 65535u ? 65535u : ml;               // MoveQuery::add_ml
+            uint16_t *O = out + beg;
             if (CLS) cs.add(val, k, len, cls.bin_width, cls.thr);
             if (CLS == 2) {
                 // verdict bins only
@@ -900,7 +962,8 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
                 } else if ((k & 15) == 0) {
                     rb = nx0;
                     rb2 = nx1;
-                    if (k + 16 < len) load_pair(k + 16, nx0, nx1);
+                    fix_pair(beg + len - k, rb, rb2);
+                    if (k + 16 < len) { want_nx = 1; nx_e = beg + len - k - 16; }
                 }
                 a = s_code[(uint32_t)(rb >> (8 * (7 - (k & 7)))) & 0xFFu];
             }
@@ -908,41 +971,122 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
         if (errc) failed = errc;
         need = need_next;
         st = st_next;
+        if (REFILL) {
+            // ---- lane refill, all of it under the gather's latency.  Order matters for the waits hipcc inserts: every
+            // block reads its registers BEFORE any block below it issues a load into them.
+            // (A) parked lanes: the first bases arrived with this iteration's window
+            if (wave_any(st == sLoad)) {
+                if (st == sLoad) {
+                    fix_pair(beg + len, rb, rb2);
+                    a = s_code[(uint32_t)(rb >> 56) & 0xFFu];
+                    st = sFF;
+                }
+            }
+            // (B) reads that ended in this iteration
+            const uint32_t fin = (uint32_t)act & (uint32_t)(st == sDone);
+            if (wave_any(fin != 0u)) {
+                if (fin) finish_read();
+            }
+            // (C) idle lanes with a next read switch to it
+            const uint32_t sw = (uint32_t)(st == sDone) & has_next;
+            const uint64_t swm = __ballot(sw != 0u);
+            if (swm != 0ull) {
+                if (sw) {
+                    rid = rid_n; beg = nbeg; len = nend_lo - (uint32_t)nbeg; packed_end = len & ~7u;
+                    k = 0; ml = 0; ff_run = 0; off = off0; need = r1; failed = 0;
+                    if (CLS) { cs = ClsState(); cs.init(len, cls.bin_width); }
+                    if (len > 0) {
+                        load_pair_at(beg + len, rb, rb2);
+                        if (len > 16) { want_nx = 1; nx_e = beg + len - 16; }
+                        st = sLoad;
+                    } else {
+                        finish_read();
+                    }
+                    const uint32_t tk = tnext + __builtin_amdgcn_mbcnt_hi((uint32_t)(swm >> 32),
+                                                                         __builtin_amdgcn_mbcnt_lo((uint32_t)swm, 0u));
+                    rid_n = rid_of(tk);
+                    has_next = rid_n < n_reads;
+                    if (has_next) load_next_offsets();
+                }
+                tnext += (uint32_t)__popcll(swm);
+            }
+        }
+        // ONE load site per prefetch register set and iteration, behind every read of those registers: a second site (or
+        // a temporary that the register allocator parks in them where they are dead) costs an `s_waitcnt` on a load
+        // in flight, i.e. on the row gather issued above
+        if (want_nx) load_pair_at(nx_e, nx0, nx1);
     }
-    if (failed && CLS != 2) {
-        for (uint32_t i = 0; i < len; ++i) O[i] = 0;
-    }
-    if (CLS && valid) cs.store(cls, rid, failed != 0u);
-    if (valid && err) err[rid] = (uint8_t)failed;
+    if (!REFILL && valid) finish_read();
     const uint32_t ffw = wave_sum(ff_total), scw = wave_sum(scan_total), rpw = wave_sum(repo_total),
-                   erw = wave_sum(failed ? 1u : 0u);
+                   erw = wave_sum(err_total);
     if ((threadIdx.x & 63) == 0 && stats) {
         if (ffw) atomicAdd(&stats->fast_forwards, (unsigned long long)ffw);
         if (scw) atomicAdd(&stats->scans, (unsigned long long)scw);
         if (rpw) atomicAdd(&stats->repositions, (unsigned long long)rpw);
         if (erw) atomicAdd(&stats->errors, (unsigned long long)erw);
     }
+    const uint32_t lsw = wave_sum(lane_steps);
+    if ((threadIdx.x & 63) == 0 && stats) {
+        atomicAdd(&stats->lane_steps, (unsigned long long)lsw);
+        atomicAdd(&stats->wave_steps, (unsigned long long)wave_steps);
+    }
 }
 
 hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets,
-                      uint64_t n_reads, uint16_t *d_out, uint8_t *d_err, DevStats *d_stats,
+                      uint64_t n_reads, uint64_t n_bases, uint16_t *d_out, uint8_t *d_err, DevStats *d_stats,
                       const uint32_t *d_order, const LaunchCfg &cfg, hipStream_t stream, const ClsArgs &cls) {
     if (n_reads == 0) return hipSuccess;
     // 0 = PML vector only, 1 = vector + classification bins, 2 = bins only
     const int cm = cls.bin_width == 0 ? 0 : (d_out ? 1 : 2);
     if (cm == 0 && !d_out) return hipErrorInvalidValue;
     if (cm != 0 && (!cls.above || !cls.below || !cls.sum_max)) return hipErrorInvalidValue;
-    const int bt = cfg.block_threads;
-    const uint64_t blocks = (n_reads + bt - 1) / bt;
+    // One resident row layout: blocked- and sampled-thresholds tables are expanded to regular-thresholds rows at upload
+    // (expand_blocked_kernel / expand_sampled_kernel), so the query kernels exist for MODE 6 only.
+    if (mode != 6) return hipErrorInvalidValue;
+    // Variants: 0 first correct kernel, 1 base-synchronous packed I/O, 7 flat lane state machine,
+    // 10 = 7 + row window + software pipelining, 13 = 10 as a persistent grid with lane refill.  (2-6, 8, 9, 11, 12 were
+    // experiments -- branchy state machine, 2/4-row neighbour windows, the unpipelined window kernel, other hop counts --
+    // measured slower and removed; numbers in DESIGN.md section 3.)
+    // Auto selection (measured on MI355X, profiles/r02_*): variant 10 in blocks of ONE wavefront, and -- when there are
+    // more reads than ~12 waves per CU -- at most kCapWaves wavefronts resident per CU.  Why a cap: between two
+    // iterations of a lane its cache lines (the row window's neighbours, its read, its output) must survive in the
+    // 4 MiB L2 of its XCD; with all 32 wave slots of a CU walking, 8 MiB of lines are in flight per XCD and neighbour
+    // rows are refetched from the fabric.  1 M x 150 bp, Gbases/s, variant 10 uncapped / capped at 8-10 waves per CU /
+    // variant 1 (base-synchronous: its neighbour loads follow the gather at once, so it wants all the occupancy it can
+    // get): pangenome 14 M rows 43.2 / 48.2 / 46.4; random tables of 10 M rows 40.0 / 47.5 / 43.6, 60 M 35.7 / 40.8 /
+    // 36.3, 250 M (2 GB) 29.1 / 32.8 / 29.2, 500 M 27.9 / 30.3 / 27.7, 1 B (8 GB) 27.4 / 27.7 / 28.3.
+    // Variant 13 (lane refill) lifts the share of busy lanes from 80 % to 92 % but runs every rare-per-lane block
+    // (chunk fetch, PML stores, refill) in every iteration because its lanes are never in step: 46.1 on the pangenome
+    // (variant 10 capped: 47.7), 43.5 on the random table; on log-normal read lengths 36.5 against 35.8.  Selectable,
+    // not the default.
+    int v = cfg.pml_variant;
+    const bool big_batch = n_reads > (uint64_t)cfg.num_cus * 64u * 12u;
+    if (v < 0) v = 10;
+    const int wpc_refill = cfg.waves_per_cu > 0 ? cfg.waves_per_cu : kCapWaves;
+    uint64_t refill_blocks = cfg.refill_blocks > 0 ? (uint64_t)cfg.refill_blocks
+                                                   : (uint64_t)cfg.num_cus * (uint64_t)wpc_refill;   // in wavefronts (blocks of 64)
+    if (v == 13 && (d_order || n_reads <= refill_blocks * 64u)) v = 10;      // nothing to refill
+    if ((v == 10 || v == 13) && (ix.r < 8 || n_bases < 16)) v = 7;           // the clamped window needs >= 4 rows, the
+                                                                             // 16-base fetches >= 16 bytes of bases
+    if (cm != 0 && (v == 0 || v == 7)) v = (v == 0 || ix.r < 8 || n_bases < 16) ? 1 : 10;   // the A/B kernels carry no fused bins
+    const int bt = cfg.block_threads > 0 ? cfg.block_threads : 64;           // one wavefront per block: finest dispatch grain
+    uint64_t blocks = (n_reads + bt - 1) / bt;
+    int wpc = cfg.waves_per_cu;
+    if (wpc < 0) wpc = 0;
+    if (cfg.waves_per_cu == 0 && cfg.pml_variant < 0 && v == 10 && big_batch) wpc = kCapWaves;   // the auto policy above
+    if (v == 13) {
+        wpc = wpc_refill;
+        const uint64_t resident = (refill_blocks * 64u + bt - 1) / bt;
+        if (blocks > resident) blocks = resident;
+    }
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     dim3 grid((unsigned)blocks), block((unsigned)bt);
-    // Occupancy knob: fewer resident walks keep each walk's current cache lines (row
-    // neighbours, its read, its output) alive in L2 between steps.  The cap is enforced by
-    // the dispatcher through the block's LDS allocation (160 KiB per CU); blocks beyond the
-    // cap queue and start as resident ones retire, i.e. hardware does the refill.
+    // Occupancy cap: enforced by the dispatcher through the block's LDS allocation (160 KiB per CU); blocks beyond
+    // the cap queue and start as resident ones retire.  For the persistent grid of variant 13 the same padding makes
+    // the dispatcher spread the blocks evenly: exactly wpc wavefronts on every CU.
     size_t dyn_lds = 0;
-    if (cfg.waves_per_cu > 0) {
-        int bpc = cfg.waves_per_cu / (bt / 64);
+    if (wpc > 0) {
+        int bpc = wpc / (bt / 64);
         if (bpc < 1) bpc = 1;
         if (bpc < 32) dyn_lds = ((163840u / (unsigned)bpc) & ~1023u) - 1024u;
     }
@@ -954,14 +1098,25 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds);  \
             if (ea != hipSuccess) return ea;                                                                \
         }                                                                                                   \
+        if (v == 13 && cfg.refill_blocks == 0) {                                                            \
+            /* the persistent grid must be resident as a whole: reads are dealt to its waves statically */   \
+            int mb = 0;                                                                                     \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&mb, __VA_ARGS__, bt, dyn_lds) == hipSuccess && \
+                mb > 0 && (uint64_t)grid.x > (uint64_t)mb * (uint64_t)cfg.num_cus)                          \
+                grid.x = (unsigned)((uint64_t)mb * (uint64_t)cfg.num_cus);                                  \
+        }                                                                                                   \
         hipLaunchKernelGGL((__VA_ARGS__), grid, block, dyn_lds, stream, ix, d_bases, d_offsets, n_reads,    \
                            d_out, d_err, d_stats, d_order, cls);                                            \
     } while (0)
 #define MOVI_LAUNCH_PML(M, V, C) MOVI_LAUNCH_K(pml_kernel<M, V, C>)
+#define MOVI_LAUNCH_FLATP_R(M, C, S, R)                                                                     \
+    do {                                                                                                    \
+        if (ix.idx32) MOVI_LAUNCH_K(pml_kernel_flatp<M, uint32_t, 2, C, S, R>);                             \
+        else MOVI_LAUNCH_K(pml_kernel_flatp<M, uint64_t, 2, C, S, R>);                                      \
+    } while (0)
 #define MOVI_LAUNCH_FLATP_S(M, C, S)                                                                        \
     do {                                                                                                    \
-        if (ix.idx32) MOVI_LAUNCH_K(pml_kernel_flatp<M, uint32_t, 2, C, S>);                                \
-        else MOVI_LAUNCH_K(pml_kernel_flatp<M, uint64_t, 2, C, S>);                                         \
+        if (v == 13) MOVI_LAUNCH_FLATP_R(M, C, S, 1); else MOVI_LAUNCH_FLATP_R(M, C, S, 0);                 \
     } while (0)
 #define MOVI_LAUNCH_FLATP(M, C)                                                                             \
     do {                                                                                                    \
@@ -976,21 +1131,6 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     do {                                                                                                    \
         if (cm == 0) LAUNCH(__VA_ARGS__, 0); else if (cm == 1) LAUNCH(__VA_ARGS__, 1); else LAUNCH(__VA_ARGS__, 2); \
     } while (0)
-    // Variants: 0 first correct kernel, 1 base-synchronous packed I/O, 7 flat lane state machine,
-    // 10 = 7 + row window + software pipelining.  (2-6, 8, 9, 11, 12 were experiments -- branchy state machine,
-    // 2/4-row neighbour windows, the unpipelined window kernel, other hop counts -- measured slower and
-    // removed; numbers in DESIGN.md section 3.)
-    // Auto selection (measured on MI355X, profiles/): with plenty of reads (> ~12 waves per CU)
-    // variant 1 wins because its neighbour loads follow the gather at once and hit L2 (400 k x 150 bp: 43.2 vs
-    // 37.4 Gbases/s); with few reads in flight (long-read batches, small shards) the lane state machine wins
-    // because it needs ~1.5-2.3 instead of ~11 dependent trips per base (200 k x 150 bp: 33.8 vs 32.4).
-    int v = cfg.pml_variant;
-    if (v < 0) v = (n_reads <= (uint64_t)cfg.num_cus * 64u * 12u) ? 10 : 1;  // measured crossover: ~12 waves per CU
-    if (v == 10 && ix.r < 8) v = 7;                                          // the clamped window needs >= 4 rows
-    if (cm != 0 && (v == 0 || v == 7)) v = (v == 0) ? 1 : (ix.r < 8 ? 1 : 10);   // the A/B kernels carry no fused bins
-    // One resident row layout: blocked- and sampled-thresholds tables are expanded to regular-thresholds rows at upload
-    // (expand_blocked_kernel / expand_sampled_kernel), so the query kernels exist for MODE 6 only.
-    if (mode != 6) return hipErrorInvalidValue;
     if (v == 0) MOVI_LAUNCH_PML(6, 0, 0); else if (v == 1) MOVI_BY_CLS(MOVI_LAUNCH_PML, 6, 1);
     else if (v == 7) MOVI_LAUNCH_FLAT(6); else MOVI_BY_CLS(MOVI_LAUNCH_FLATP, 6);
 #undef MOVI_LAUNCH_PML
@@ -998,6 +1138,7 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
 #undef MOVI_LAUNCH_FLAT
 #undef MOVI_LAUNCH_FLATP
 #undef MOVI_LAUNCH_FLATP_S
+#undef MOVI_LAUNCH_FLATP_R
 #undef MOVI_BY_CLS
     return hipGetLastError();
 }
@@ -1198,7 +1339,7 @@ hipError_t launch_count(int mode, const DevIndex &ix, const uint8_t *d_bases, co
                         uint64_t n_reads, uint64_t *d_matched, uint64_t *d_count, uint8_t *d_err,
                         DevStats *d_stats, const uint32_t *d_order, const LaunchCfg &cfg, hipStream_t stream) {
     if (n_reads == 0) return hipSuccess;
-    const int bt = cfg.block_threads;
+    const int bt = cfg.block_threads > 0 ? cfg.block_threads : 256;
     const uint64_t blocks = (n_reads + bt - 1) / bt;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     dim3 grid((unsigned)blocks), block((unsigned)bt);
@@ -1328,7 +1469,7 @@ hipError_t launch_zml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
                       uint64_t n_reads, uint16_t *d_out, uint8_t *d_err, DevStats *d_stats,
                       const uint32_t *d_order, const LaunchCfg &cfg, hipStream_t stream) {
     if (n_reads == 0) return hipSuccess;
-    const int bt = cfg.block_threads;
+    const int bt = cfg.block_threads > 0 ? cfg.block_threads : 256;
     const uint64_t blocks = (n_reads + bt - 1) / bt;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     dim3 grid((unsigned)blocks), block((unsigned)bt);

@@ -46,15 +46,24 @@ struct DevStats {
     unsigned long long scans;
     unsigned long long repositions;
     unsigned long long errors;
+    // SIMT efficiency of the lane state machines: iterations in which a lane had work / 64 x wave iterations
+    unsigned long long lane_steps;
+    unsigned long long wave_steps;
+    unsigned long long ticket;         // next unassigned read of the lane-refill kernels (zeroed with the counters)
+    unsigned long long pad_;
 };
 
+constexpr int kCapWaves = 9;   // resident wavefronts per CU of the lane state machine on big batches (measured optimum: 8-10)
+
 struct LaunchCfg {
-    int block_threads = 256;
+    int block_threads = 0;   // 0 = auto: 64 for the PML kernels (finest dispatch grain), 256 for count / ZML
     // -1 auto; 0 first kernel (plain I/O), 1 base-synchronous packed I/O, 7 flat lane state machine,
-    // 10 flat lane state machine + row window, software-pipelined
+    // 10 flat lane state machine + row window, software-pipelined, 13 = 10 as a persistent grid with lane refill
     int pml_variant = -1;
     int num_cus = 256;
-    int waves_per_cu = 0;  // 0 = no cap; else cap resident waves per CU by padding the block's LDS allocation
+    int waves_per_cu = 0;  // 0 = auto (variant 10 on big batches and variant 13: kCapWaves; else no cap); else cap resident waves per CU by padding the block's LDS allocation
+    int refill_blocks = 0; // variant 13: size of the persistent grid in blocks; 0 = num_cus x waves per CU (tests shrink it
+                           // so that a few hundred reads already go through many refills per lane)
 };
 
 // Classifier::classify bins (src/classifier.cpp:99-143) fused into the PML kernels: per read the number of
@@ -69,7 +78,7 @@ struct ClsArgs {
 
 // d_out == nullptr is allowed when cls.bin_width != 0: verdict bins only, no PML vector is written.
 hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets,
-                      uint64_t n_reads, uint16_t *d_out, uint8_t *d_err, DevStats *d_stats,
+                      uint64_t n_reads, uint64_t n_bases, uint16_t *d_out, uint8_t *d_err, DevStats *d_stats,
                       const uint32_t *d_order, const LaunchCfg &cfg, hipStream_t stream,
                       const ClsArgs &cls = ClsArgs());
 

@@ -63,6 +63,8 @@ class QueryStats:
         self.scans = int(c.scans)
         self.repositions = int(c.repositions)
         self.errors = int(c.errors)
+        self.lane_steps = int(c.lane_steps)
+        self.wave_steps = int(c.wave_steps)
 
     def __repr__(self):
         return "QueryStats(bases=%d, ff=%d, scans=%d, repositions=%d, errors=%d)" % (

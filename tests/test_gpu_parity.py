@@ -85,7 +85,7 @@ def test_pml_ragged_reads_vs_oracle(engines, mode):
 
 
 @pytest.mark.parametrize("mode", [6, 8])
-@pytest.mark.parametrize("variant", [0, 1, 7, 10])
+@pytest.mark.parametrize("variant", [0, 1, 7, 10, 13])
 def test_pml_kernel_variants_vs_oracle(engines, mode, variant):
     """Every selectable kernel variant is held to the same bit-exact bar, including
     reads whose length is not a multiple of the 8-step packing and unaligned offsets."""
@@ -97,11 +97,41 @@ def test_pml_kernel_variants_vs_oracle(engines, mode, variant):
     reads += [b"", b"A", b"AC", b"ACGTACG", b"ACGTACGT", b"ACGTACGTA", b"N" * 9, b"T" * 15, b"G" * 16, b"C" * 17]
     bases, offs = pack(reads)
     gpu.set_option("pml_variant", variant)
+    gpu.set_option("refill_blocks", 2)            # variant 13: 128 lanes for 610 reads, i.e. ~5 refills per lane
     try:
         out, st = gpu.query_pml_packed(bases, offs)
     finally:
         gpu.set_option("pml_variant", -1)
+        gpu.set_option("refill_blocks", 0)
     exp, ff, sc = cpu.pml_batch(bases, offs, threads=4)
+    assert (out == exp).all()
+    assert (st.fast_forwards, st.scans, st.errors) == (ff, sc, 0)
+    if variant == 13:                             # the refill path really ran: 2 wavefronts did all the work
+        assert st.wave_steps > 0 and st.lane_steps > 0.5 * 64 * st.wave_steps
+
+
+@pytest.mark.parametrize("blocks", [1, 3, 7])
+def test_lane_refill_ragged_batches_vs_oracle(engines, blocks):
+    """The lane-refill kernel (variant 13) on batches built to stress the refill: empty reads between long ones, a run of
+    empty reads longer than a wavefront, one-base reads, fewer reads than lanes in the last round, illegal bases."""
+    from oracle import build_index as B
+    gpu, cpu = engines[6]
+    ref = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))[0][1]
+    rng = np.random.default_rng(1300 + blocks)
+    reads = mutated_reads(rng, ref, 500, 1, 40) + [b""] * 150 + mutated_reads(rng, ref, 300, 150, 400)
+    reads += [b"A", b"", b"N", b"", b"ACGTN" * 7] * 20 + mutated_reads(rng, ref, 30, 1500, 2500)
+    order = rng.permutation(len(reads))
+    reads = [reads[i] for i in order[:900]] + [b""] * 70 + [reads[i] for i in order[900:]]
+    bases, offs = pack(reads)
+    exp, ff, sc = cpu.pml_batch(bases, offs, threads=4)
+    gpu.set_option("pml_variant", 13)
+    gpu.set_option("refill_blocks", blocks)
+    try:
+        out, st, err, rc = gpu.query_pml_packed(bases, offs, want_err=True)
+    finally:
+        gpu.set_option("pml_variant", -1)
+        gpu.set_option("refill_blocks", 0)
+    assert rc == 0 and not err.any()
     assert (out == exp).all()
     assert (st.fast_forwards, st.scans, st.errors) == (ff, sc, 0)
 
@@ -238,7 +268,7 @@ def test_launch_options_are_bounded(engines):
     from movi_amd._lib import MoviError
     from oracle import build_index as B
     gpu, cpu = engines[6]
-    for bad in (0, 32, 100, 512, 1024):
+    for bad in (-64, 32, 100, 512, 1024):
         with pytest.raises(MoviError) as e:
             gpu.set_option("block_threads", bad)
         assert e.value.code == -1
@@ -258,7 +288,7 @@ def test_launch_options_are_bounded(engines):
     finally:
         gpu.set_option("pml_variant", -1)
         gpu.set_option("waves_per_cu", 0)
-        gpu.set_option("block_threads", 256)
+        gpu.set_option("block_threads", 0)
 
 
 def test_invariant_violation_is_flagged_not_hidden(built_lib, golden_image):
@@ -414,7 +444,7 @@ def test_classification_bins_on_device(engines, bin_width, thr):
 
 
 @pytest.mark.parametrize("mode", [6, 8])
-@pytest.mark.parametrize("variant", [1, 10])
+@pytest.mark.parametrize("variant", [1, 10, 13])
 def test_fused_classification_kernels(engines, mode, variant):
     """movi_pml_classify_device: the bins fused into the PML walk, with and without the PML vector, in both
     shipped kernels, against the bins of the oracle's PML vectors and against the standalone
@@ -435,6 +465,7 @@ def test_fused_classification_kernels(engines, mode, variant):
     d_offs = torch.from_numpy(offs.view(np.int64).copy()).to(dev)
     exp_pml, _, _ = cpu.pml_batch(bases, offs, threads=4)
     gpu.set_option("pml_variant", variant)
+    gpu.set_option("refill_blocks", 3)
     try:
         for bin_width, thr in ((150, 7), (40, 3), (1, 1)):
             exp = [classify_py(exp_pml[int(offs[i]):int(offs[i + 1])], thr, bin_width) if len(r) else None
@@ -471,6 +502,7 @@ def test_fused_classification_kernels(engines, mode, variant):
                     assert int(d_out.abs().sum().item()) == 0          # nothing was written
     finally:
         gpu.set_option("pml_variant", -1)
+        gpu.set_option("refill_blocks", 0)
 
 
 @pytest.mark.parametrize("alphabet", [b"ACGT", b"ACG", b"AT", b"GT", b"C"])

@@ -52,7 +52,7 @@ def main():
             print("  KERNEL %-90s calls=%-4d avg=%10.2f us total=%12.2f us %6.2f%%"
                   % (k["name"][:90], k["calls"], k["avg_us"], k["total_us"], k["pct"]))
         for c in r["counters"]:
-            if c["kernel"].startswith("void movi::") or "movi" in c["kernel"]:
+            if c["kernel"].startswith("void movi::") or "movi" in c["kernel"] or "chase" in c["kernel"]:
                 print("  PMC %-60s %-22s n=%-3d avg=%.6g min=%.6g max=%.6g avg_dur=%.1f us vgpr=%s sgpr=%s lds=%s grid=%s wg=%s"
                       % (c["kernel"][:60], c["counter"], c["n"], c["avg"], c["min"], c["max"],
                          c["avg_duration_ns"] / 1e3, c["vgpr"], c["sgpr"], c["lds"], c["grid"], c["wg"]))

@@ -85,7 +85,9 @@ int main(int argc, char **argv) {
     const char *names[4] = {"8B row", "16B pair", "32B quad", "8B row + dependent neighbour"};
     for (int si = 0; si < ns; si++) {
         const uint64_t n = 1ull << sizes[si];
+        const char *only = getenv("TLB_ALLOC");             // e.g. TLB_ALLOC=0: hipMalloc only (profiling runs)
         for (int which = 0; which < 3; which++) {
+            if (only && atoi(only) != which) continue;
             uint64_t *table = nullptr;
             hipMemGenericAllocationHandle_t handle{};
             size_t vm_bytes = 0;
