@@ -57,6 +57,11 @@ extern "C" {
                                             ZML queries only: PML on an index without thresholds repositions RANDOMLY in the
                                             reference (reposition_randomly) and is refused (MOVI_ERR_ARG) */
 
+#define MOVI_MODE_REGULAR 3              /* 8-byte rows like 6 with 12-bit lengths and no thresholds (move_row_configs.hpp:21-32):
+                                            resident as stored.  Count and ZML only, as for MOVI_MODE_SAMPLED */
+#define MOVI_MODE_BLOCKED 2              /* 6-byte rows like 8 with a 24-bit blocked id and no thresholds (:54-75); expanded at
+                                            upload to the MOVI_MODE_REGULAR layout.  Count and ZML only */
+
 typedef struct movi_index movi_index_t;
 
 /* The in-memory result of MoveStructure::deserialize for modes 6 / 8: the packed

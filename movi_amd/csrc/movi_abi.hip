@@ -36,6 +36,20 @@ int fail_hip(hipError_t e, const char *what) {
 
 constexpr uint32_t kMoviMagic = 0x4D4F5649u;   // include/utils.hpp:29
 
+bool mode_supported(uint32_t m) {
+    return m == MOVI_MODE_REGULAR_THRESHOLDS || m == MOVI_MODE_BLOCKED_THRESHOLDS || m == MOVI_MODE_SAMPLED_THRESHOLDS ||
+           m == MOVI_MODE_SAMPLED || m == MOVI_MODE_REGULAR || m == MOVI_MODE_BLOCKED;
+}
+bool mode_blocked(uint32_t m) { return m == MOVI_MODE_BLOCKED_THRESHOLDS || m == MOVI_MODE_BLOCKED; }
+bool mode_sampled(uint32_t m) { return m == MOVI_MODE_SAMPLED_THRESHOLDS || m == MOVI_MODE_SAMPLED; }
+// USE_THRESHOLDS, include/utils.hpp:145
+bool mode_has_thresholds(uint32_t m) {
+    return m == MOVI_MODE_REGULAR_THRESHOLDS || m == MOVI_MODE_BLOCKED_THRESHOLDS || m == MOVI_MODE_SAMPLED_THRESHOLDS;
+}
+size_t mode_row_bytes(uint32_t m) {             // MoveRow::row_size, include/move_row.hpp:104-120
+    return (m == MOVI_MODE_REGULAR_THRESHOLDS || m == MOVI_MODE_REGULAR) ? 8 : (mode_blocked(m) ? 6 : 3);
+}
+
 struct Reader {
     const uint8_t *p;
     size_t n, pos = 0;
@@ -111,10 +125,10 @@ int movi_index_parse(const void *h_image, size_t image_bytes, movi_index_desc_t 
         return fail(MOVI_ERR_FORMAT, "invalid magic number in header: not a Movi 2.x index file");
     memset(desc, 0, sizeof(*desc));
     desc->mode = hdr[7];
-    if (desc->mode != MOVI_MODE_REGULAR_THRESHOLDS && desc->mode != MOVI_MODE_BLOCKED_THRESHOLDS &&
-        desc->mode != MOVI_MODE_SAMPLED_THRESHOLDS && desc->mode != MOVI_MODE_SAMPLED)
-        return fail(MOVI_ERR_FORMAT, "index mode " + std::to_string(desc->mode) + " is not supported (only sampled=5, "
-                                         "regular-thresholds=6, sampled-thresholds=7 and blocked-thresholds=8)");
+    if (!mode_supported(desc->mode))
+        return fail(MOVI_ERR_FORMAT, "index mode " + std::to_string(desc->mode) + " is not supported (only blocked=2, regular=3, "
+                                         "sampled=5, regular-thresholds=6, sampled-thresholds=7 and blocked-thresholds=8; the "
+                                         "Movi-1 style types large / constant / split are not)");
     memcpy(&desc->length, hdr + 16, 8);
     memcpy(&desc->r, hdr + 24, 8);
     memcpy(&desc->end_bwt_idx, hdr + 40, 8);
@@ -139,11 +153,11 @@ int movi_index_parse(const void *h_image, size_t image_bytes, movi_index_desc_t 
     for (int c = 0; c < 256; c++) desc->code_of[c] = (c < 128 && amap[c] < asz) ? (uint8_t)amap[c] : 0xFF;
     if (sep) desc->code_of[(int)'%'] = 0xFF;               // check_alphabet, move_structure.cpp:384-388
     if (!rd.skip(3)) return fail(MOVI_ERR_FORMAT, "truncated index (flags)");
-    const size_t row_b = desc->mode == MOVI_MODE_REGULAR_THRESHOLDS ? 8 : (desc->mode == MOVI_MODE_BLOCKED_THRESHOLDS ? 6 : 3);
+    const size_t row_b = mode_row_bytes(desc->mode);
     const size_t roff = rd.pos;
     if (desc->r > (image_bytes - rd.pos) / row_b || !rd.skip(desc->r * row_b))
         return fail(MOVI_ERR_FORMAT, "truncated index (move rows)");
-    const bool sampled = desc->mode == MOVI_MODE_SAMPLED_THRESHOLDS || desc->mode == MOVI_MODE_SAMPLED;
+    const bool sampled = mode_sampled(desc->mode);
     if (sampled) {                                         // read_tally_table, move_structure_io.cpp:338-349
         if (!rd.get(&desc->tally_checkpoints, 4) || desc->tally_checkpoints == 0)
             return fail(MOVI_ERR_FORMAT, "truncated index (tally checkpoints)");
@@ -166,20 +180,20 @@ int movi_index_parse(const void *h_image, size_t image_bytes, movi_index_desc_t 
     if (!rd.get(desc->last_runs, k * 8) || !rd.get(desc->last_offsets, k * 8) ||
         !rd.get(desc->first_runs, k * 8) || !rd.get(desc->first_offsets, k * 8))
         return fail(MOVI_ERR_FORMAT, "truncated index (base intervals)");
-    if (desc->mode == MOVI_MODE_BLOCKED_THRESHOLDS) {
+    if (mode_blocked(desc->mode)) {
         if (!rd.get(&desc->n_blocks, 8)) return fail(MOVI_ERR_FORMAT, "truncated index (id blocks)");
         // the id_blocks payload stays in the image; callers locate it via desc->id_blocks
         desc->id_blocks = reinterpret_cast<const uint32_t *>(rd.p + rd.pos);
         if (desc->n_blocks > image_bytes / (asz * 4) || !rd.skip(desc->n_blocks * asz * 4))
             return fail(MOVI_ERR_FORMAT, "truncated index (id blocks)");
-        desc->block_size = 1048576;                        // BLOCK_SIZE, move_row_configs.hpp:102
+        desc->block_size = desc->mode == MOVI_MODE_BLOCKED ? 4194304 : 1048576;   // BLOCK_SIZE, move_row_configs.hpp:73 / :102
         uint64_t bs = 0;
         if (rd.get(&bs, 8)) desc->block_size = bs;         // move_structure_io.cpp:321-323
         // n_blocks * block_size >= r without the product (either factor is a file field)
         if (desc->block_size == 0 || desc->n_blocks == 0 || (desc->r - 1) / desc->block_size >= desc->n_blocks)
             return fail(MOVI_ERR_FORMAT, "id blocks do not cover the table");
     }
-    if (sep && desc->mode != MOVI_MODE_SAMPLED) {          // read_separators_thresholds, move_structure_io.cpp:415-433 (USE_THRESHOLDS)
+    if (sep && mode_has_thresholds(desc->mode)) {          // read_separators_thresholds, move_structure_io.cpp:415-433 (USE_THRESHOLDS)
         if (!rd.get(&desc->n_separator_thresholds, 8)) return fail(MOVI_ERR_FORMAT, "truncated index (separator thresholds)");
         desc->separator_thresholds = rd.p + rd.pos;
         if (desc->n_separator_thresholds > image_bytes / 8 || !rd.skip(desc->n_separator_thresholds * 8))
@@ -198,9 +212,9 @@ static int finish_create(movi_index *ix) {
     const movi_index_desc_t &d = ix->desc;
     HIP_TRY(hipMalloc(&ix->d_code_of, 256));
     HIP_TRY(hipMemcpy(ix->d_code_of, d.code_of, 256, hipMemcpyHostToDevice));
-    if (d.mode == MOVI_MODE_BLOCKED_THRESHOLDS) {
+    if (mode_blocked(d.mode)) {
         const size_t nb = (size_t)d.n_blocks * d.alphabet_size;
-        if (nb == 0 || ix->id_blocks_host.size() != nb) return fail(MOVI_ERR_ARG, "mode 8 needs id_blocks");
+        if (nb == 0 || ix->id_blocks_host.size() != nb) return fail(MOVI_ERR_ARG, "the blocked modes need id_blocks");
         HIP_TRY(hipMalloc(&ix->d_id_blocks, nb * 4));
         HIP_TRY(hipMemcpy(ix->d_id_blocks, ix->id_blocks_host.data(), nb * 4, hipMemcpyHostToDevice));
     }
@@ -212,7 +226,7 @@ static int finish_create(movi_index *ix) {
         HIP_TRY(hipMemcpy(ix->d_sep_rows, ix->sep_rows_host.data(), ns * 8, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(ix->d_sep_vals, ix->sep_vals_host.data(), ns * 8, hipMemcpyHostToDevice));
     }
-    if (d.mode == MOVI_MODE_SAMPLED_THRESHOLDS || d.mode == MOVI_MODE_SAMPLED) {
+    if (mode_sampled(d.mode)) {
         if (ix->tally_host.empty()) return fail(MOVI_ERR_ARG, "the sampled modes need tally_ids");
         HIP_TRY(hipMalloc(&ix->d_tally, ix->tally_host.size() * 8));
         HIP_TRY(hipMemcpy(ix->d_tally, ix->tally_host.data(), ix->tally_host.size() * 8, hipMemcpyHostToDevice));
@@ -256,13 +270,14 @@ static int finish_create(movi_index *ix) {
     // rows once, on the GPU, by the reference's get_id (needs the complete device view above: get_id reads first_runs /
     // id_blocks / tally).  Blocked: aligned 8-byte rows with the id inside instead of 2-byte-aligned 6-byte rows + a
     // check-point lookup per LF (count +7-10 %, ZML +28 %, PML +2-4 %, measured); sampled: see expand_sampled_kernel.
+    // (the threshold-less `regular` / `blocked` types keep 12-bit lengths: their resident layout is the `regular` one, kmode 3)
     ix->kmode = (int)d.mode;
-    if (d.mode != MOVI_MODE_REGULAR_THRESHOLDS) {
-        const bool blocked = d.mode == MOVI_MODE_BLOCKED_THRESHOLDS;
+    if (d.mode != MOVI_MODE_REGULAR_THRESHOLDS && d.mode != MOVI_MODE_REGULAR) {
+        const bool blocked = mode_blocked(d.mode);
         uint8_t *rows6 = nullptr;
         HIP_TRY(hipMalloc(&rows6, (size_t)d.r * 8 + 16));
         hipError_t e = hipMemset(rows6, 0, (size_t)d.r * 8 + 16);
-        if (e == hipSuccess) e = blocked ? expand_blocked_rows(v, rows6, nullptr) : expand_sampled_rows((int)d.mode, v, rows6, nullptr);
+        if (e == hipSuccess) e = blocked ? expand_blocked_rows((int)d.mode, v, rows6, nullptr) : expand_sampled_rows((int)d.mode, v, rows6, nullptr);
         if (e == hipSuccess) e = hipDeviceSynchronize();
         if (e != hipSuccess) { (void)hipFree(rows6); return fail_hip(e, "expanding the rows to the resident layout"); }
         if (ix->owns_rows && ix->d_rows) (void)hipFree(ix->d_rows);       // the file-format copy (an adopted buffer stays the caller's)
@@ -272,22 +287,20 @@ static int finish_create(movi_index *ix) {
         ix->owns_rows = true;
         v.rows = rows6;
         v.tally = nullptr;
-        ix->kmode = MOVI_MODE_REGULAR_THRESHOLDS;
+        ix->kmode = d.mode == MOVI_MODE_BLOCKED ? MOVI_MODE_REGULAR : MOVI_MODE_REGULAR_THRESHOLDS;
     }
     return MOVI_OK;
 }
 
 static int check_desc(const movi_index_desc_t *desc) {
     if (!desc) return fail(MOVI_ERR_ARG, "desc is NULL");
-    if (desc->mode != MOVI_MODE_REGULAR_THRESHOLDS && desc->mode != MOVI_MODE_BLOCKED_THRESHOLDS &&
-        desc->mode != MOVI_MODE_SAMPLED_THRESHOLDS && desc->mode != MOVI_MODE_SAMPLED)
-        return fail(MOVI_ERR_ARG, "unsupported mode");
-    if ((desc->mode == MOVI_MODE_SAMPLED_THRESHOLDS || desc->mode == MOVI_MODE_SAMPLED) &&
+    if (!mode_supported(desc->mode)) return fail(MOVI_ERR_ARG, "unsupported mode");
+    if (mode_sampled(desc->mode) &&
         (!desc->tally_ids || desc->tally_checkpoints == 0 || desc->n_tally < desc->r / desc->tally_checkpoints + 2))
         return fail(MOVI_ERR_ARG, "mode 7 needs tally_checkpoints / tally_ids covering the rows");
     if (desc->r == 0 || desc->end_bwt_idx >= desc->r) return fail(MOVI_ERR_ARG, "bad r / end_bwt_idx");
     if (desc->r >= (1ull << 36)) return fail(MOVI_ERR_ARG, "2^36 rows or more: ids are 36 bits in every row layout");
-    if (desc->mode == MOVI_MODE_BLOCKED_THRESHOLDS &&
+    if (mode_blocked(desc->mode) &&
         (desc->block_size == 0 || desc->n_blocks == 0 || (desc->r - 1) / desc->block_size >= desc->n_blocks ||
          desc->n_blocks > (1ull << 36)))
         return fail(MOVI_ERR_ARG, "id blocks do not cover the table");
@@ -305,7 +318,7 @@ static movi_index *new_handle(int device, const movi_index_desc_t *desc) {
     movi_index *ix = new movi_index();
     ix->device = device;
     ix->desc = *desc;
-    if (desc->mode == MOVI_MODE_BLOCKED_THRESHOLDS && desc->id_blocks)
+    if (mode_blocked(desc->mode) && desc->id_blocks)
         ix->id_blocks_host.assign(desc->id_blocks, desc->id_blocks + (size_t)desc->n_blocks * desc->alphabet_size);
     ix->desc.id_blocks = nullptr;
     if (desc->alphabet_size == 5) {
@@ -327,7 +340,7 @@ static movi_index *new_handle(int device, const movi_index_desc_t *desc) {
     }
     ix->desc.separator_thresholds = nullptr;
     ix->desc.separator_map = nullptr;
-    if (desc->mode == MOVI_MODE_SAMPLED_THRESHOLDS || desc->mode == MOVI_MODE_SAMPLED) {
+    if (mode_sampled(desc->mode)) {
         const size_t ne = (size_t)desc->n_tally * desc->alphabet_size;
         const uint8_t *p = static_cast<const uint8_t *>(desc->tally_ids);
         ix->tally_host.resize(ne);
@@ -338,7 +351,7 @@ static movi_index *new_handle(int device, const movi_index_desc_t *desc) {
         }
     }
     ix->desc.tally_ids = nullptr;
-    ix->rows_bytes = (size_t)desc->r * (desc->mode == MOVI_MODE_REGULAR_THRESHOLDS ? 8 : (desc->mode == MOVI_MODE_BLOCKED_THRESHOLDS ? 6 : 3));
+    ix->rows_bytes = (size_t)desc->r * mode_row_bytes(desc->mode);
     return ix;
 }
 
@@ -368,7 +381,7 @@ int movi_index_create(int device, const movi_index_desc_t *desc, const void *h_r
     if (e == hipSuccess) e = hipMemcpy(ix->d_rows, h_rows, ix->rows_bytes, hipMemcpyHostToDevice);
     if (e != hipSuccess) { movi_index_destroy(ix); return fail_hip(e, "uploading the move rows"); }
     ix->owns_rows = true;
-    if (desc->mode == MOVI_MODE_SAMPLED_THRESHOLDS || desc->mode == MOVI_MODE_SAMPLED) {
+    if (mode_sampled(desc->mode)) {
         uint8_t *packed = ix->d_rows;
         ix->d_rows = nullptr;
         e = adopt_widened(ix, packed);
@@ -392,7 +405,7 @@ int movi_index_create_from_device_rows(int device, const movi_index_desc_t *desc
     movi_index *ix = new_handle(device, desc);
     ix->d_rows = const_cast<uint8_t *>(static_cast<const uint8_t *>(d_rows));
     ix->owns_rows = false;
-    if (desc->mode == MOVI_MODE_SAMPLED_THRESHOLDS || desc->mode == MOVI_MODE_SAMPLED) {   // private copy; the caller's buffer is not kept
+    if (mode_sampled(desc->mode)) {   // private copy; the caller's buffer is not kept
         ix->d_rows = nullptr;
         hipError_t e = adopt_widened(ix, static_cast<const uint8_t *>(d_rows));
         if (e != hipSuccess) { movi_index_destroy(ix); return fail_hip(e, "widening the 3-byte rows"); }
@@ -504,10 +517,10 @@ static int ml_device(bool zml, movi_index_t *ix, const uint8_t *d_bases, const u
                      uint64_t n_bases, uint16_t *d_out, uint8_t *d_read_err, const uint32_t *d_read_order, void *stream,
                      const ClsArgs &cls = ClsArgs()) {
     if (!ix) return fail(MOVI_ERR_ARG, "index handle is NULL");
-    if (!zml && ix->desc.mode == MOVI_MODE_SAMPLED)
-        return fail(MOVI_ERR_ARG, "PML needs thresholds: on a `sampled` index the reference repositions randomly "
-                                  "(reposition_randomly), which cannot be reproduced; use --zml or --count, or a "
-                                  "sampled-thresholds index");
+    if (!zml && !mode_has_thresholds(ix->desc.mode))
+        return fail(MOVI_ERR_ARG, "PML needs thresholds: on a `regular`, `blocked` or `sampled` index the reference repositions "
+                                  "randomly (reposition_randomly), which cannot be reproduced; use --zml or --count, or a "
+                                  "*-thresholds index");
     if (n_reads == 0) return MOVI_OK;
     const bool bins_only = cls.bin_width != 0 && !d_out;
     if (!d_offsets || (n_bases && (!d_bases || (!d_out && !bins_only)))) return fail(MOVI_ERR_ARG, "NULL device buffer");

@@ -35,9 +35,9 @@ namespace movi {
 //     (widened to one dword per row at upload, then expanded to mode-6 rows: expand_sampled_kernel)
 template <int MODE>
 __device__ __forceinline__ uint2 load_row(const uint8_t *rows, uint64_t i) {
-    if (MODE == 6) {
+    if (MODE == 6 || MODE == 3) {
         return *reinterpret_cast<const uint2 *>(rows + i * 8);
-    } else if (MODE == 8) {
+    } else if (MODE == 8 || MODE == 2) {
         // 6-byte rows: ONE unaligned 8-byte load of the bytes [6i-2, 6i+6) (for row 0: [0, 8)), shifted into
         // place -- never reads outside the table -- instead of three 2-byte loads
         const uint32_t lead = i ? 2u : 0u;
@@ -54,21 +54,23 @@ __device__ __forceinline__ uint2 load_row(const uint8_t *rows, uint64_t i) {
 template <int MODE> __device__ __forceinline__ uint32_t row_n(uint2 w) {
     if (MODE == 5) return (w.x & 0xFFu) | (((w.x >> 18) & 3u) << 8);      // sampled, no thresholds: configs :107-118
     if (MODE == 7) return (w.x & 0xFFu) | (((w.x >> 17) & 1u) << 8);
-    return MODE == 6 ? (w.y & 0x7FFu) : ((w.x >> 16) & 0x3FFu);
+    if (MODE == 3) return w.y & 0xFFFu;                                    // regular, no thresholds: 12 bits (configs :21-32)
+    return MODE == 6 ? (w.y & 0x7FFu) : ((w.x >> 16) & 0x3FFu);           // modes 8 and 2: 10 bits
 }
 template <int MODE> __device__ __forceinline__ uint32_t row_off(uint2 w) {
     if (MODE == 5) return ((w.x >> 8) & 0xFFu) | (((w.x >> 16) & 3u) << 8);
     if (MODE == 7) return ((w.x >> 8) & 0xFFu) | (((w.x >> 16) & 1u) << 8);
+    if (MODE == 3) return (w.y >> 16) & 0xFFFu;
     return MODE == 6 ? ((w.y >> 16) & 0x7FFu) : (w.y & 0x3FFu);
 }
 template <int MODE> __device__ __forceinline__ uint32_t row_c(uint2 w) {
     if (MODE == 5) return (w.x >> 20) & 15u;
     if (MODE == 7) return (w.x >> 18) & 7u;
-    return MODE == 6 ? ((w.y >> 13) & 7u) : ((w.y >> 10) & 7u);
+    return (MODE == 6 || MODE == 3) ? ((w.y >> 13) & 7u) : ((w.y >> 10) & 7u);
 }
 // threshold bit k in {0,1,2} (MoveRow::get_threshold, move_row.hpp:304-347)
 template <int MODE> __device__ __forceinline__ uint32_t row_thr(uint2 w, uint32_t k) {
-    if (MODE == 5) return 0u;                             // no thresholds in this index type
+    if (MODE == 5 || MODE == 3 || MODE == 2) return 0u;   // no thresholds in these index types
     if (MODE == 6) {
         // k=0 -> off16 bit 11 (y bit 27); k=1 -> n16 bit 11; k=2 -> n16 bit 12
         uint32_t sh = (k == 0) ? 27u : (10u + k);
@@ -82,13 +84,14 @@ template <int MODE> __device__ __forceinline__ uint32_t row_thr(uint2 w, uint32_
 // MoveStructure::get_id, src/move_structure.cpp:91-102
 template <int MODE>
 __device__ __forceinline__ uint64_t row_id(uint2 w, uint64_t idx, const DevIndex &ix) {
-    static_assert(MODE == 6 || MODE == 8, "the sampled modes have no id in the row: tally_id()");
-    if (MODE == 6) {
+    static_assert(MODE == 6 || MODE == 8 || MODE == 3 || MODE == 2, "the sampled modes have no id in the row: tally_id()");
+    if (MODE == 6 || MODE == 3) {
         return (uint64_t)w.x | ((uint64_t)(w.y >> 28) << 32);
     } else {
         uint64_t bid = (uint64_t)(w.x & 0xFFFFu) | ((uint64_t)(w.x >> 26) << 16);
+        if (MODE == 2) bid |= (uint64_t)((w.y >> 14) & 3u) << 22;          // two more id bits in `offset` (move_row.hpp:274-280)
         if (idx == ix.end_bwt_idx) return bid;
-        uint32_t c = row_c<8>(w);
+        uint32_t c = row_c<MODE>(w);
         const uint64_t blk = ix.block_shift != 0xFFFFFFFFu ? (idx >> ix.block_shift) : idx / ix.block_size;
         const uint64_t slot = (uint64_t)c * ix.n_blocks + blk;
         const uint32_t base = ix.id_blocks[slot];                           // check point of (character, block)
@@ -692,7 +695,7 @@ __global__ __launch_bounds__(256) void pml_kernel_flat(DevIndex ix, const uint8_
 
 template <int MODE>
 __device__ __forceinline__ void load_window(const uint8_t *rows, uint64_t wbase, uint2 (&w)[4]) {
-    static_assert(MODE == 6, "queries run on regular-thresholds rows only (modes 7 / 8 are expanded at upload)");
+    static_assert(MODE == 6 || MODE == 3, "queries run on 8-byte regular(-thresholds) rows only (the other types are expanded at upload)");
     uint4 p0, p1;
     __builtin_memcpy(&p0, rows + wbase * 8, 16);
     __builtin_memcpy(&p1, rows + wbase * 8 + 16, 16);
@@ -1109,10 +1112,13 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
                            d_out, d_err, d_stats, d_order, cls);                                            \
     } while (0)
 #define MOVI_LAUNCH_PML(M, V, C) MOVI_LAUNCH_K(pml_kernel<M, V, C>)
+#ifndef MOVI_HA
+#define MOVI_HA 2
+#endif
 #define MOVI_LAUNCH_FLATP_R(M, C, S, R)                                                                     \
     do {                                                                                                    \
-        if (ix.idx32) MOVI_LAUNCH_K(pml_kernel_flatp<M, uint32_t, 2, C, S, R>);                             \
-        else MOVI_LAUNCH_K(pml_kernel_flatp<M, uint64_t, 2, C, S, R>);                                      \
+        if (ix.idx32) MOVI_LAUNCH_K(pml_kernel_flatp<M, uint32_t, MOVI_HA, C, S, R>);                             \
+        else MOVI_LAUNCH_K(pml_kernel_flatp<M, uint64_t, MOVI_HA, C, S, R>);                                      \
     } while (0)
 #define MOVI_LAUNCH_FLATP_S(M, C, S)                                                                        \
     do {                                                                                                    \
@@ -1343,9 +1349,14 @@ hipError_t launch_count(int mode, const DevIndex &ix, const uint8_t *d_bases, co
     const uint64_t blocks = (n_reads + bt - 1) / bt;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     dim3 grid((unsigned)blocks), block((unsigned)bt);
-    if (mode != 6) return hipErrorInvalidValue;          // see launch_pml
-    hipLaunchKernelGGL(count_kernel_v0<6>, grid, block, 0, stream, ix, d_bases, d_offsets, n_reads,
-                       d_matched, d_count, d_err, d_stats, d_order);
+    // resident layouts: 6 = regular-thresholds rows, 3 = regular rows (threshold-less types: 12-bit lengths)
+    if (mode == 6)
+        hipLaunchKernelGGL(count_kernel_v0<6>, grid, block, 0, stream, ix, d_bases, d_offsets, n_reads,
+                           d_matched, d_count, d_err, d_stats, d_order);
+    else if (mode == 3)
+        hipLaunchKernelGGL(count_kernel_v0<3>, grid, block, 0, stream, ix, d_bases, d_offsets, n_reads,
+                           d_matched, d_count, d_err, d_stats, d_order);
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
@@ -1473,9 +1484,13 @@ hipError_t launch_zml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     const uint64_t blocks = (n_reads + bt - 1) / bt;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     dim3 grid((unsigned)blocks), block((unsigned)bt);
-    if (mode != 6) return hipErrorInvalidValue;          // see launch_pml
-    hipLaunchKernelGGL(zml_kernel<6>, grid, block, 0, stream, ix, d_bases, d_offsets, n_reads, d_out, d_err,
-                       d_stats, d_order);
+    if (mode == 6)
+        hipLaunchKernelGGL(zml_kernel<6>, grid, block, 0, stream, ix, d_bases, d_offsets, n_reads, d_out, d_err,
+                           d_stats, d_order);
+    else if (mode == 3)
+        hipLaunchKernelGGL(zml_kernel<3>, grid, block, 0, stream, ix, d_bases, d_offsets, n_reads, d_out, d_err,
+                           d_stats, d_order);
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
@@ -1588,23 +1603,29 @@ __global__ __launch_bounds__(256) void expand_sampled_kernel(DevIndex ix, uint2 
     }
 }
 
-// Blocked-thresholds -> regular-thresholds rows, once per index: get_id = blocked id + the (character, block) check
+// Blocked(-thresholds) -> regular(-thresholds) rows, once per index: get_id = blocked id + the (character, block) check
 // point + first_runs[c + 1] (src/move_structure.cpp:91-102) evaluated for every row, written in the 8-byte layout.
+// SM = 8: blocked-thresholds -> the regular-thresholds layout; SM = 2: blocked -> the regular layout (12-bit fields, no
+// threshold bits; count / ZML queries only).
+template <int SM>
 __global__ __launch_bounds__(256) void expand_blocked_kernel(DevIndex ix, uint2 *__restrict__ out) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ix.r) return;
-    const uint2 row = load_row<8>(ix.rows, i);
-    const uint64_t id = row_id<8>(row, i, ix);
-    const uint32_t n16 = row_n<8>(row) | (row_thr<8>(row, 1) << 11) | (row_thr<8>(row, 2) << 12) | (row_c<8>(row) << 13);
-    const uint32_t off16 = row_off<8>(row) | (row_thr<8>(row, 0) << 11) | ((uint32_t)((id >> 32) & 0xFu) << 12);
+    const uint2 row = load_row<SM>(ix.rows, i);
+    const uint64_t id = row_id<SM>(row, i, ix);
+    const uint32_t n16 = row_n<SM>(row) | (row_thr<SM>(row, 1) << 11) | (row_thr<SM>(row, 2) << 12) | (row_c<SM>(row) << 13);
+    const uint32_t off16 = row_off<SM>(row) | (row_thr<SM>(row, 0) << 11) | ((uint32_t)((id >> 32) & 0xFu) << 12);
     out[i] = make_uint2((uint32_t)id, n16 | (off16 << 16));
 }
 
-hipError_t expand_blocked_rows(const DevIndex &ix, void *d_rows6, hipStream_t stream) {
+hipError_t expand_blocked_rows(int mode, const DevIndex &ix, void *d_rows6, hipStream_t stream) {
     const unsigned bt = 256;
     const uint64_t blocks = (ix.r + bt - 1) / bt;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(expand_blocked_kernel, dim3((unsigned)blocks), dim3(bt), 0, stream, ix, static_cast<uint2 *>(d_rows6));
+    if (mode == 8)
+        hipLaunchKernelGGL(expand_blocked_kernel<8>, dim3((unsigned)blocks), dim3(bt), 0, stream, ix, static_cast<uint2 *>(d_rows6));
+    else
+        hipLaunchKernelGGL(expand_blocked_kernel<2>, dim3((unsigned)blocks), dim3(bt), 0, stream, ix, static_cast<uint2 *>(d_rows6));
     return hipGetLastError();
 }
 
@@ -1630,8 +1651,9 @@ hipError_t build_row_start_ckpt(int mode, const uint8_t *d_rows, uint64_t r, uin
     if (e != hipSuccess) { (void)hipFree(d_sums); return e; }
     const unsigned bt = 256;
     const unsigned blocks = (unsigned)((n_chunks + bt - 1) / bt);
-    if (mode != 6) { (void)hipFree(d_sums); return hipErrorInvalidValue; }
-    hipLaunchKernelGGL(chunk_sum_kernel<6>, dim3(blocks), dim3(bt), 0, stream, d_rows, r, n_chunks, d_sums);
+    if (mode == 6) hipLaunchKernelGGL(chunk_sum_kernel<6>, dim3(blocks), dim3(bt), 0, stream, d_rows, r, n_chunks, d_sums);
+    else if (mode == 3) hipLaunchKernelGGL(chunk_sum_kernel<3>, dim3(blocks), dim3(bt), 0, stream, d_rows, r, n_chunks, d_sums);
+    else { (void)hipFree(d_sums); return hipErrorInvalidValue; }
     e = hipGetLastError();
     void *d_temp = nullptr;
     size_t temp_bytes = 0;

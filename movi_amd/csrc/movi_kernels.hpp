@@ -95,8 +95,9 @@ hipError_t launch_classify(const uint16_t *d_pml, const uint64_t *d_offsets, uin
 
 // Mode 7: ix = a mode-7 view (widened rows + tally table); writes r mode-6 rows (8 bytes each) with the ids recovered by get_id.
 hipError_t expand_sampled_rows(int mode, const DevIndex &ix, void *d_rows6, hipStream_t stream);   // mode 7 or 5
-// Mode 8: ix = a mode-8 view (raw 6-byte rows + id_blocks); writes r mode-6 rows with the ids get_id reconstructs.
-hipError_t expand_blocked_rows(const DevIndex &ix, void *d_rows6, hipStream_t stream);
+// Modes 8 / 2: ix = a blocked view (raw 6-byte rows + id_blocks); writes r 8-byte rows (regular-thresholds / regular
+// layout) with the ids get_id reconstructs.
+hipError_t expand_blocked_rows(int mode, const DevIndex &ix, void *d_rows6, hipStream_t stream);
 
 // Mode 7: 3-byte file rows -> one dword per row (d_wide: r * 4 bytes + 16 of slack).
 hipError_t widen_rows(const uint8_t *d_packed, uint64_t r, uint32_t *d_wide, hipStream_t stream);

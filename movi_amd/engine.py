@@ -35,7 +35,7 @@ class IndexDesc:
         self.last_offsets = list(c.last_offsets[:k])
         self.n_blocks = int(c.n_blocks)
         self.block_size = int(c.block_size)
-        self.row_bytes = {6: 8, 8: 6, 7: 3, 5: 3}[self.mode]
+        self.row_bytes = {6: 8, 8: 6, 7: 3, 5: 3, 3: 8, 2: 6}[self.mode]
 
 
 def parse_index_image(image):

@@ -40,7 +40,9 @@ void check(int rc, const char *what) {
 const char *index_type_name(uint32_t mode) {                          // program(), src/utils.cpp:10-40
     return mode == MOVI_MODE_REGULAR_THRESHOLDS ? "regular-thresholds"
            : mode == MOVI_MODE_SAMPLED_THRESHOLDS ? "sampled-thresholds"
-           : mode == MOVI_MODE_SAMPLED ? "sampled" : "blocked-thresholds";
+           : mode == MOVI_MODE_SAMPLED ? "sampled"
+           : mode == MOVI_MODE_REGULAR ? "regular"
+           : mode == MOVI_MODE_BLOCKED ? "blocked" : "blocked-thresholds";
 }
 
 // Contiguous shards of [0, n) balanced by bases.

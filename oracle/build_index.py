@@ -30,11 +30,11 @@ Reference code restated (file:line relative to /root/reference):
 import numpy as np
 
 MOVI_MAGIC = 0x4D4F5649          # include/utils.hpp:29
-MAX_RUN = {6: 2047, 8: 1023, 7: 511, 5: 1023}   # include/move_row_configs.hpp:51,101,135,117
+MAX_RUN = {6: 2047, 8: 1023, 7: 511, 5: 1023, 3: 4095, 2: 1023}   # include/move_row_configs.hpp:51,101,135,117,31,72
 THRESHOLD_MODES = (6, 7, 8)      # include/utils.hpp:146 (USE_THRESHOLDS); mode 5 "sampled" keeps none
 TALLY_CHECKPOINTS = 20           # include/movi_options.hpp:257 (movi build --checkpoint default)
-BLOCK_SIZE = 1 << 20             # include/move_row_configs.hpp:102
-MAX_ALLOWED_BLOCKED_ID = (1 << 22) - 1   # :103
+BLOCK_SIZE = {8: 1 << 20, 2: 1 << 22}                      # include/move_row_configs.hpp:102 / :73
+MAX_ALLOWED_BLOCKED_ID = {8: (1 << 22) - 1, 2: (1 << 24) - 1}   # :103 / :74
 
 ALPHAMAP_3 = np.array([[3, 0, 1, 2], [0, 3, 1, 2], [0, 1, 3, 2], [0, 1, 2, 3]])  # src/utils.cpp:5-8
 
@@ -158,7 +158,7 @@ def bwt_and_thresholds(t):
 def build_rows(bwt, thr, mode):
     """Everything MoveStructure::build() derives from ref.bwt + ref.thr_pos.
     Returns a dict of the fields serialize() writes."""
-    assert mode in (5, 6, 7, 8)
+    assert mode in (2, 3, 5, 6, 7, 8)
     n = len(bwt)
     maxrun = MAX_RUN[mode]
     # --- detect_move_row_boundaries (:328-396) + fill_bits_by_thresholds (:733-746)
@@ -276,8 +276,8 @@ def build_rows(bwt, thr, mode):
                last_runs=last_runs, last_offsets=last_offsets, end_thr=end_thr,
                lens=lens, offset=offset, code=code, pp_id=pp_id, thr_bits=thr_bits, all_p=all_p,
                sep=sep, sep_thr=sep_thr, sep_map=sep_map)
-    if mode == 8:
-        out.update(compute_blocked_ids(pp_id, code, end_bwt_idx, first_runs, sigma))
+    if mode in (8, 2):
+        out.update(compute_blocked_ids(pp_id, code, end_bwt_idx, first_runs, sigma, mode))
     if mode in (5, 7):
         out.update(compute_tally_ids(pp_id, code, end_bwt_idx, sigma))
     return out
@@ -305,14 +305,14 @@ def compute_tally_ids(pp_id, code, end_bwt_idx, sigma, checkpoints=TALLY_CHECKPO
     return dict(tally_ids=tally, tally_checkpoints=checkpoints)
 
 
-def compute_blocked_ids(raw_ids, code, end_bwt_idx, first_runs, sigma):
+def compute_blocked_ids(raw_ids, code, end_bwt_idx, first_runs, sigma, mode=8):
     """src/move_structure_build.cpp:939-1074: per block and character keep the
     last destination id (relative to first_runs[c+1]) seen before the block; rows
     store the distance from that check point; halve the block size until the
     distance fits MAX_ALLOWED_BLOCKED_ID."""
     r = len(raw_ids)
     fr = np.asarray(first_runs, np.int64)
-    block_size, max_allowed = BLOCK_SIZE, MAX_ALLOWED_BLOCKED_ID
+    block_size, max_allowed = BLOCK_SIZE[mode], MAX_ALLOWED_BLOCKED_ID[mode]
     adj = raw_ids - fr[code + 1]
     not_end = np.arange(r) != end_bwt_idx
     while True:
@@ -347,6 +347,22 @@ def encode_rows(f):
         rows[:, 1] = (pid >> 16) & 0xFFFF
         rows[:, 2] = n | (t[:, 1] << 11) | (t[:, 2] << 12) | (c << 13)
         rows[:, 3] = off | (t[:, 0] << 11) | ((pid >> 32) << 12)
+    elif mode == 3:
+        # regular, no thresholds (move_row_configs.hpp:21-32): the mode-6 fields with 12-bit n / offset and no threshold bits
+        rows = np.zeros((r, 4), np.uint16)
+        pid = f["pp_id"]
+        rows[:, 0] = pid & 0xFFFF
+        rows[:, 1] = (pid >> 16) & 0xFFFF
+        rows[:, 2] = n | (c << 13)
+        rows[:, 3] = off | ((pid >> 32) << 12)
+    elif mode == 2:
+        # blocked, no thresholds (move_row_configs.hpp:54-75, MoveRow::set_id src/move_row.cpp:213-225): 24-bit blocked id =
+        # id16 | 6 bits in n | 2 bits in offset[15:14]
+        rows = np.zeros((r, 3), np.uint16)
+        bid = f["blocked_id"]
+        rows[:, 0] = bid & 0xFFFF
+        rows[:, 1] = n | (((bid >> 16) & 0x3F) << 10)
+        rows[:, 2] = off | (c << 10) | ((bid >> 22) << 14)
     elif mode == 5:
         # sampled, no thresholds (move_row_configs.hpp:107-118): u8 n | u8 offset | u8 c with bits 0-1 = offset bits 8-9,
         # bits 2-3 = n bits 8-9, bits 4-7 = character
@@ -396,7 +412,7 @@ def serialize(f):
            u64([len(f["counts"])]), u64(f["counts"]),
            u64([len(f["last_runs"])]), u64(f["last_runs"]), u64(f["last_offsets"]),
            u64(f["first_runs"]), u64(f["first_offsets"])]
-    if f["mode"] == 8:
+    if f["mode"] in (8, 2):
         ib = f["id_blocks"]
         out += [u64([ib.shape[1]]), ib.astype("<u4").tobytes(), u64([f["block_size"]])]
     if f.get("sep") and f["mode"] in THRESHOLD_MODES:

@@ -89,8 +89,8 @@ oracle_index *oracle_open(const uint8_t *buf, size_t n) {
     uint32_t magic; memcpy(&magic, hdr, 4);
     if (magic != 0x4D4F5649u) goto bad;                 /* MOVI_MAGIC utils.hpp:29 */
     ix->mode = hdr[7];
-    if (ix->mode != 6 && ix->mode != 8 && ix->mode != 7 && ix->mode != 5) goto bad;
-    ix->row_bytes = ix->mode == 6 ? 8 : (ix->mode == 8 ? 6 : 3);            /* MoveRow::row_size, move_row.hpp:104-120 */
+    if (ix->mode != 6 && ix->mode != 8 && ix->mode != 7 && ix->mode != 5 && ix->mode != 3 && ix->mode != 2) goto bad;
+    ix->row_bytes = (ix->mode == 6 || ix->mode == 3) ? 8 : ((ix->mode == 8 || ix->mode == 2) ? 6 : 3);   /* MoveRow::row_size, move_row.hpp:104-120 */
     memcpy(&ix->length, hdr + 16, 8);
     memcpy(&ix->r, hdr + 24, 8);
     memcpy(&ix->original_r, hdr + 32, 8);
@@ -128,18 +128,18 @@ oracle_index *oracle_open(const uint8_t *buf, size_t n) {
     if (rd(buf, n, &p, ix->last_offsets, ix->k * 8)) goto bad;
     if (rd(buf, n, &p, ix->first_runs, ix->k * 8)) goto bad;
     if (rd(buf, n, &p, ix->first_offsets, ix->k * 8)) goto bad;
-    if (ix->mode == 8) {
+    if (ix->mode == 8 || ix->mode == 2) {
         if (rd(buf, n, &p, &ix->nblocks, 8)) goto bad;
         if (ix->nblocks) {
             size_t bytes = ix->alphabet_size * ix->nblocks * 4;
             ix->id_blocks = (uint32_t *)malloc(bytes);
             if (!ix->id_blocks || rd(buf, n, &p, ix->id_blocks, bytes)) goto bad;
         }
-        ix->block_size = 1048576;                       /* BLOCK_SIZE move_row_configs.hpp:102 */
+        ix->block_size = ix->mode == 8 ? 1048576 : 4194304;   /* BLOCK_SIZE move_row_configs.hpp:102 / :73 */
         if (p + 8 <= n) rd(buf, n, &p, &ix->block_size, 8);   /* io.cpp:321-323 */
     }
     ix->sep = ix->alphabet_size == 5 && ix->alphabet[0] == ORACLE_SEPARATOR;
-    if (ix->sep && ix->mode != 5) {                     /* read_separators_thresholds, io.cpp:415-433 (USE_THRESHOLDS only) */
+    if (ix->sep && ix->mode != 5 && ix->mode != 3 && ix->mode != 2) {   /* read_separators_thresholds, io.cpp:415-433 (USE_THRESHOLDS only) */
         uint64_t nt, nm;
         if (rd(buf, n, &p, &nt, 8) || nt > (n - p) / 8) goto bad;
         uint16_t (*vals)[4] = (uint16_t (*)[4])malloc((nt ? nt : 1) * 8);
@@ -195,7 +195,8 @@ static inline uint64_t get_n(const oracle_index *ix, uint64_t i) {
         return (uint64_t)b[0] | ((uint64_t)((b[2] >> 2) & 3) << 8);
     }
     uint16_t w[4]; row16(ix, i, w);
-    return ix->mode == 6 ? (w[2] & 0x7FF) : (w[1] & 0x3FF);
+    if (ix->mode == 3) return w[2] & 0xFFF;             /* regular, no thresholds: LENGTH_BITS 12 (configs :21-32) */
+    return ix->mode == 6 ? (w[2] & 0x7FF) : (w[1] & 0x3FF);             /* modes 8 and 2: 10 bits */
 }
 /* MoveRow::get_offset, move_row.hpp:250-253 / :292-295 */
 static inline uint64_t get_offset(const oracle_index *ix, uint64_t i) {
@@ -208,6 +209,7 @@ static inline uint64_t get_offset(const oracle_index *ix, uint64_t i) {
         return (uint64_t)b[1] | ((uint64_t)(b[2] & 3) << 8);
     }
     uint16_t w[4]; row16(ix, i, w);
+    if (ix->mode == 3) return w[3] & 0xFFF;
     return ix->mode == 6 ? (w[3] & 0x7FF) : (w[2] & 0x3FF);
 }
 /* MoveRow::get_c, move_row.hpp:255-257 (n >> 13) / :297-299 ((offset >> 10) & 7) */
@@ -215,7 +217,7 @@ static inline uint32_t get_c(const oracle_index *ix, uint64_t i) {
     if (ix->mode == 7) return (ix->rows[i * 3 + 2] >> 2) & 7;          /* move_row.hpp:219-221, SHIFT_C 2 */
     if (ix->mode == 5) return (ix->rows[i * 3 + 2] >> 4) & 15;         /* SHIFT_C 4, 4 bits */
     uint16_t w[4]; row16(ix, i, w);
-    return ix->mode == 6 ? (uint32_t)(w[2] >> 13) : (uint32_t)((w[2] >> 10) & 7);
+    return (ix->mode == 6 || ix->mode == 3) ? (uint32_t)(w[2] >> 13) : (uint32_t)((w[2] >> 10) & 7);
 }
 /* MoveRow::get_threshold, move_row.hpp:304-317 (mode 6) / :319-332 (mode 8) */
 static inline uint32_t get_threshold_bit(const oracle_index *ix, uint64_t i, uint32_t k) {
@@ -278,11 +280,12 @@ static uint64_t get_id_tally(const oracle_index *ix, uint64_t idx) {
 static inline uint64_t get_id(const oracle_index *ix, uint64_t i) {
     if (ix->mode == 7 || ix->mode == 5) return get_id_tally(ix, i);
     uint16_t w[4]; row16(ix, i, w);
-    if (ix->mode == 6) {
+    if (ix->mode == 6 || ix->mode == 3) {
         uint64_t id = (uint64_t)w[0] | ((uint64_t)w[1] << 16);
         return id | ((uint64_t)(w[3] >> 12) << 32);
     }
     uint64_t bid = (uint64_t)w[0] | ((uint64_t)(w[1] >> 10) << 16);
+    if (ix->mode == 2) bid |= (uint64_t)(w[2] >> 14) << 22;            /* move_row.hpp:274-280: two more id bits in `offset` */
     if (i == ix->end_bwt_idx) return bid;
     uint32_t c = (w[2] >> 10) & 7;
     return bid + (uint64_t)ix->id_blocks[c * ix->nblocks + i / ix->block_size] + ix->first_runs[c + 1];
@@ -456,7 +459,7 @@ int oracle_pml(const oracle_index *ix, const uint8_t *R, int64_t len, uint16_t *
     uint64_t ff = 0, sc = 0;
     /* an index without thresholds repositions RANDOMLY in the reference (reposition_randomly,
      * src/move_structure_query.cpp:603-): its PMLs are not reproducible, so there is nothing to restate */
-    if (ix->mode == 5) return ORACLE_ERR_FORMAT;
+    if (ix->mode == 5 || ix->mode == 3 || ix->mode == 2) return ORACLE_ERR_FORMAT;
     if (len <= 0) { if (ff_tot) *ff_tot = 0; if (scan_tot) *scan_tot = 0; return ORACLE_OK; }
     strand_reset(ix, &s, R, len, out);
     while (s.pos_on_r > -1) {
@@ -476,7 +479,7 @@ int oracle_pml(const oracle_index *ix, const uint8_t *R, int64_t len, uint16_t *
 int oracle_pml_batch(const oracle_index *ix, const uint8_t *seqs, const uint64_t *offs,
                      uint64_t n_reads, uint16_t *out, int threads, int strands,
                      uint64_t *ff_tot, uint64_t *scan_tot) {
-    if (ix->mode == 5) return ORACLE_ERR_FORMAT;        /* no thresholds: see oracle_pml */
+    if (ix->mode == 5 || ix->mode == 3 || ix->mode == 2) return ORACLE_ERR_FORMAT;        /* no thresholds: see oracle_pml */
     if (strands < 1) strands = 1;
     if (strands > 64) strands = 64;
     uint64_t n_groups = (n_reads + (uint64_t)strands - 1) / (uint64_t)strands;

@@ -62,7 +62,7 @@ class Oracle:
         buf = np.frombuffer(bytes(index_bytes), np.uint8)
         self._h = lib().oracle_open(buf.ctypes.data, buf.size)
         if not self._h:
-            raise OracleError("not a mode-6/8 v2 index.movi image")
+            raise OracleError("not a v2 index.movi image of a supported type (modes 2, 3, 5, 6, 7, 8)")
         self.r = lib().oracle_r(self._h)
         self.length = lib().oracle_length(self._h)
         self.end_bwt_idx = lib().oracle_end_bwt_idx(self._h)

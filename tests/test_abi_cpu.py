@@ -55,10 +55,11 @@ def test_parse_rejects_bad_images(built_lib, golden_image):
     bad = bytearray(img); bad[0] ^= 0xFF
     with pytest.raises(movi_amd.MoviError):
         movi_amd.parse_index_image(bytes(bad))
-    other_mode = bytearray(img); other_mode[7] = 3          # "regular" (no thresholds): out of scope
-    with pytest.raises(movi_amd.MoviError) as e:
-        movi_amd.parse_index_image(bytes(other_mode))
-    assert "not supported" in str(e.value)
+    for legacy in (0, 1, 4):                                  # large / constant / split: Movi-1 style rows, out of scope
+        other_mode = bytearray(img); other_mode[7] = legacy
+        with pytest.raises(movi_amd.MoviError) as e:
+            movi_amd.parse_index_image(bytes(other_mode))
+        assert "not supported" in str(e.value)
     with pytest.raises(movi_amd.MoviError):
         movi_amd.parse_index_image(bytes(img[: len(img) // 2]))
     # u64 wrap-around: r + 2^61 makes r * 8 wrap to the true table size, so a naive `pos + r * 8 <= n` accepts it
@@ -161,3 +162,22 @@ def test_parse_sampled_index(built_lib):
         desc, c, off, nbytes = movi_amd.parse_index_image(img)
         assert (desc.mode, desc.row_bytes, nbytes) == (5, 3, desc.r * 3)
         assert int(c.tally_checkpoints) == 20 and int(c.n_separator_thresholds) == 0
+
+
+def test_parse_regular_and_blocked_indexes(built_lib):
+    """Modes 3 / 2 (reference KATs 871479 / 654253 B, tests/test_build.cpp:33,49): accepted; with separators there is no
+    threshold section (USE_THRESHOLDS is off); blocked: id blocks located, default block size 2^22."""
+    import movi_amd
+    from conftest import GOLDEN
+    from oracle import build_index as B
+    ref = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))[0][1]
+    for mode, sep, size in ((3, False, 871479), (3, True, 871496), (2, False, 654253), (2, True, 654280)):
+        img = B.build_index_from_seqs([ref], mode, separators=sep)
+        assert len(img) == size
+        desc, c, off, nbytes = movi_amd.parse_index_image(img)
+        assert (desc.mode, desc.row_bytes, nbytes) == (mode, 8 if mode == 3 else 6, desc.r * (8 if mode == 3 else 6))
+        assert int(c.n_separator_thresholds) == 0 and desc.alphabet == (b"%ACGT" if sep else b"ACGT")
+        if mode == 2:
+            assert desc.n_blocks == 1 and desc.block_size == 1 << 22
+            with pytest.raises(movi_amd.MoviError):
+                movi_amd.parse_index_image(img[:-12])                   # truncated id blocks

@@ -95,6 +95,19 @@ def test_sampled_known_answers_and_numpy_agreement(tool, tmp_path, separators, s
     assert img == B.build_index_from_seqs([ref], 5, separators=separators)
 
 
+# tests/test_build.cpp:33,49 and :76,92 of the reference: regular / blocked (no thresholds) index sizes
+@pytest.mark.parametrize("mode,separators,size", [(3, False, 871479), (3, True, 871496), (2, False, 654253), (2, True, 654280)])
+def test_regular_and_blocked_known_answers_and_numpy_agreement(tool, tmp_path, mode, separators, size):
+    from oracle import build_index as B
+    out = str(tmp_path / "m")
+    subprocess.check_call([tool, "fasta", os.path.join(GOLDEN, "ref.fasta"), str(mode), out] + (["separators"] if separators else []),
+                          stderr=subprocess.DEVNULL)
+    img = open(os.path.join(out, "index.movi"), "rb").read()
+    assert len(img) == size
+    ref = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))[0][1]
+    assert img == B.build_index_from_seqs([ref], mode, separators=separators)
+
+
 def test_pangenome_mode_is_queryable(tool, tmp_path):
     """Synthetic pangenome: substrings of the text are found end to end by the oracle's count query."""
     from oracle.oracle import Oracle

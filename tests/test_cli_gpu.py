@@ -346,3 +346,31 @@ def test_reference_cli_golden_sampled_thresholds(movi_bin, tmp_path, flags):
     assert os.path.exists(str(reads) + ".sampled-thresholds.pml.bpf")
     assert run(["query", "--index", str(d), "--read", str(reads), "--count"]).returncode == 0
     assert os.path.exists(str(reads) + ".sampled-thresholds.count.matches")
+
+
+@pytest.mark.parametrize("mode,name", [(3, "regular"), (2, "blocked")])
+def test_cli_regular_and_blocked_indexes(movi_bin, tmp_path, mode, name):
+    """`movi query` on the threshold-less index types: --count and --zml served (file names carry the type, src/utils.cpp:20-28),
+    --pml refused with the reason (the reference would reposition randomly)."""
+    from oracle import build_index as B
+    from oracle.oracle import Oracle
+    ref = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))[0][1]
+    d = tmp_path / name
+    d.mkdir()
+    img = B.build_index_from_seqs([ref], mode)
+    (d / "index.movi").write_bytes(img)
+    reads = tmp_path / "s.fastq"
+    shutil.copy(os.path.join(GOLDEN, "sample.fastq"), reads)
+    r = run(["query", "--index", str(d), "--read", str(reads), "--count", "--no-prefetch", "--stdout"])
+    assert r.returncode == 0, r.stderr
+    assert (b"The " + name.encode() + b" index") in r.stderr
+    cpu = Oracle(img)
+    exp = b""
+    for rid, seq in read_fastx(str(reads)):
+        m, c = cpu.count(seq)
+        exp += rid + b"\t%d/%d\t%d\n" % (m, len(seq), c)
+    assert r.stdout == exp
+    assert run(["query", "--index", str(d), "--read", str(reads), "--zml"]).returncode == 0
+    assert os.path.exists(str(reads) + "." + name + ".zml.bpf")
+    r = run(["query", "--index", str(d), "--read", str(reads), "--pml"])
+    assert r.returncode == 1 and b"thresholds" in r.stderr

@@ -836,3 +836,73 @@ def test_sampled_expansion_equals_oracle_get_id_fuzz(built_lib, seed):
                 assert (ids == f["pp_id"]).all(), (seed, separators, mode)
             assert host.tobytes() == B.encode_rows(dict(f, mode=6, pp_id=ids)), (seed, separators, mode)
             gpu.close()
+
+
+@pytest.mark.parametrize("mode", [3, 2])
+@pytest.mark.parametrize("separators", [False, True])
+def test_no_threshold_regular_and_blocked_indexes(built_lib, mode, separators):
+    """`regular` (mode 3) and `blocked` (mode 2) indexes -- the reference's threshold-less 8- and 6-byte row types, KAT sizes
+    871479 / 654253 B (tests/test_build.cpp:33,49): count and ZML against the oracle (itself pinned to those KATs and to the
+    brute-force search); PML refused; the resident table equals the rows in the `regular` layout (blocked: every id
+    reconstructed by get_id on the GPU)."""
+    import ctypes as C
+    import movi_amd
+    from oracle import build_index as B
+    from oracle.oracle import Oracle
+    ref = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))[0][1]
+    t = B.clean_text([ref], separators=separators)
+    f = B.build_rows(*B.bwt_and_thresholds(t), mode)
+    img = B.serialize(f)
+    assert len(img) == {(3, False): 871479, (3, True): 871496, (2, False): 654253, (2, True): 654280}[(mode, separators)]
+    gpu, cpu = movi_amd.MoveIndex.from_image(img), Oracle(img)
+    assert gpu.desc.mode == mode
+    rng = np.random.default_rng(700 + mode + separators)
+    reads = mutated_reads(rng, ref, 500, 1, 1200) + [b"", b"A", b"N", b"%", b"ACGT" * 100]
+    bases, offs = pack(reads)
+    m, c, _ = gpu.query_count_packed(bases, offs)
+    em, ec = cpu.count_batch(bases, offs, threads=4)
+    assert (m == em).all() and (c == ec).all()
+    z, _ = gpu.query_zml_packed(bases, offs)
+    assert (z == cpu.zml_batch(bases, offs, threads=4)).all()
+    with pytest.raises(movi_amd.MoviError) as e:
+        gpu.query_pml_packed(bases, offs)
+    assert e.value.code == -1 and "thresholds" in str(e.value)
+    with pytest.raises(movi_amd.MoviError):
+        gpu.classify_packed(bases, offs, 150, 8)
+    ptr, n = gpu.device_rows()
+    assert n == f["r"] * 8
+    host = np.empty(n, np.uint8)
+    assert C.CDLL("libamdhip64.so").hipMemcpy(C.c_void_p(host.ctypes.data), C.c_void_p(ptr), C.c_size_t(n), C.c_int(2)) == 0
+    assert host.tobytes() == B.encode_rows(dict(f, mode=3))
+    gpu.set_option("idx64", 1)                               # the 64-bit-index instantiations of the same kernels
+    m2, c2, _ = gpu.query_count_packed(bases, offs)
+    assert (m2 == em).all() and (c2 == ec).all()
+    gpu.close()
+
+
+def test_blocked_index_with_many_blocks(built_lib, tmp_path):
+    """A `blocked` table whose rows span several id blocks (block size forced down by shrinking BLOCK_SIZE in the numpy
+    constructor): the check-point lookup of get_id is exercised for every (character, block) pair."""
+    import movi_amd
+    from oracle import build_index as B
+    from oracle.oracle import Oracle
+    rng = np.random.default_rng(4242)
+    anc = rng.choice(np.frombuffer(b"ACGT", np.uint8), 60000).tobytes()
+    old = dict(B.BLOCK_SIZE)
+    try:
+        B.BLOCK_SIZE[2] = 1 << 12
+        B.BLOCK_SIZE[8] = 1 << 12
+        for mode in (2, 8):
+            img = B.build_index_from_seqs([anc], mode)
+            gpu, cpu = movi_amd.MoveIndex.from_image(img), Oracle(img)
+            assert gpu.desc.n_blocks > 4 and gpu.desc.block_size == 1 << 12
+            reads = mutated_reads(rng, anc, 300, 1, 400)
+            bases, offs = pack(reads)
+            m, c, _ = gpu.query_count_packed(bases, offs)
+            em, ec = cpu.count_batch(bases, offs, threads=4)
+            assert (m == em).all() and (c == ec).all()
+            z, _ = gpu.query_zml_packed(bases, offs)
+            assert (z == cpu.zml_batch(bases, offs, threads=4)).all()
+            gpu.close()
+    finally:
+        B.BLOCK_SIZE.update(old)

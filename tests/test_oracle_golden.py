@@ -318,3 +318,43 @@ def test_sampled_no_thresholds_known_answers_and_queries(ref_bwt):
         assert (m, c) == (k, _occurrences(T, R[len(R) - k:]))
     for R in _mutated_reads(recs[0][1], rng, 30, 1, 200) + [b"NA", b"ACGTNNACGT"]:
         assert o.zml(R).tolist() == _zml_brute(T, R), R
+
+
+# ---- `regular` (mode 3) and `blocked` (mode 2): the threshold-less siblings of modes 6 / 8 (count and ZML only:
+# without thresholds the reference's PML repositions randomly).  Pinned to the reference's index-size known answers
+# 871479 / 654253 B plain and 871496 / 654280 B with --separators (tests/test_build.cpp:33,49,76,92), to the stored ids
+# of the KAT-pinned regular-thresholds index (same LF, rows merged where that index splits at thresholds) and to the
+# brute-force count / ZML.
+@pytest.mark.parametrize("mode,size,sep_size", [(3, 871479, 871496), (2, 654253, 654280)])
+def test_no_threshold_modes_known_answers_and_queries(ref_bwt, golden_image, mode, size, sep_size):
+    bwt, thr = ref_bwt
+    f = B.build_rows(bwt, thr, mode)
+    img = B.serialize(f)
+    assert len(img) == size and f["r"] == f["original_r"] == 108629        # rows = BWT runs: no threshold splits
+    recs = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))
+    t = B.clean_text([s for _, s in recs], separators=True)
+    assert len(B.serialize(B.build_rows(*B.bwt_and_thresholds(t), mode))) == sep_size
+    o = Oracle(img)
+    assert (o.mode, o.r) == (mode, 108629)
+    with pytest.raises(Exception):
+        o.pml(b"ACGT")
+    # every row's LF destination = the BWT position the constructor derived (pp_id is what get_id must return)
+    assert (o.get_ids().astype(np.int64) == f["pp_id"]).all()
+    T = bytes(B.clean_text([s for _, s in recs])[:-1])
+    rng = np.random.default_rng(30 + mode)
+    for R in _mutated_reads(recs[0][1], rng, 40, 1, 120, sub=0.02, ill=0.005) + [b"A", b"GNAC"]:
+        m, c = o.count(R)
+        if R[-1:] not in (b"A", b"C", b"G", b"T"):
+            assert (m, c) == (0, 0)
+            continue
+        k = 1
+        while k < len(R) and R[len(R) - k - 1:len(R) - k] in (b"A", b"C", b"G", b"T") and R[len(R) - k - 1:] in T:
+            k += 1
+        assert (m, c) == (k, _occurrences(T, R[len(R) - k:]))
+    for R in _mutated_reads(recs[0][1], rng, 30, 1, 200) + [b"NA", b"ACGTNNACGT"]:
+        assert o.zml(R).tolist() == _zml_brute(T, R), R
+    # the same queries on the KAT- and golden-pinned regular-thresholds index give the same answers
+    o6 = Oracle(golden_image(6))
+    reads = _mutated_reads(recs[0][1], rng, 50, 1, 300)
+    for R in reads:
+        assert o.count(R) == o6.count(R) and o.zml(R).tolist() == o6.zml(R).tolist()

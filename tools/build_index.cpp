@@ -1,4 +1,4 @@
-// build_index.cpp -- index constructor for modes 5 / 6 / 7 / 8 (bench + test tooling; SURVEY section 8(f) "next #2").
+// build_index.cpp -- index constructor for modes 2 / 3 / 5 / 6 / 7 / 8 (bench + test tooling; SURVEY section 8(f) "next #2").
 //
 // FASTA (or a synthetic pangenome) -> cleaned text with reverse complements -> suffix array (SA-IS) ->
 // BWT + LCP (Kasai) -> per-run thresholds -> move rows -> `index.movi` bytes.  Linear time, so that
@@ -15,7 +15,7 @@
 // Checked byte-for-byte against tests/golden/index_*/index.movi (whose sizes are the reference's
 // known answers 948119 / 711733, tests/test_build.cpp:37,53) in tests/test_build_tool.py.
 //
-// usage: build_index fasta <ref.fasta> <mode 5|6|7|8> <out_dir> [separators]     ("separators" = movi build --separators:
+// usage: build_index fasta <ref.fasta> <mode 2|3|5|6|7|8> <out_dir> [separators]     ("separators" = movi build --separators:
 //            every record and reverse complement followed by %; sizes 948232 / 711854 B, tests/test_build.cpp:79,95)
 //        build_index pangenome <ancestor_len> <n_genomes> <snp_rate> <seed> <mode> <out_dir> [n_reads read_len sub_rate]
 //            [n_reads2 read_len2 sub_rate2]
@@ -147,7 +147,7 @@ static void put64(std::vector<uint8_t> &o, uint64_t v) { for (int i = 0; i < 8; 
 
 // ------------------------------------------------------------------------------- text -> index.movi bytes
 static std::vector<uint8_t> build_index(std::vector<uint8_t> &text, int mode) {
-    const bool with_thresholds = mode != 5;                               // mode 5 "sampled": USE_THRESHOLDS is off
+    const bool with_thresholds = mode != 5 && mode != 3 && mode != 2;     // sampled / regular / blocked: USE_THRESHOLDS is off
     text.push_back(0);                                                    // terminator
     const sa_t n = (sa_t)text.size();
     if ((uint64_t)text.size() >= (1ull << 31)) { fprintf(stderr, "text too long for 32-bit suffix array\n"); exit(1); }
@@ -200,7 +200,7 @@ static std::vector<uint8_t> build_index(std::vector<uint8_t> &text, int mode) {
     if (with_thresholds) for (uint64_t t : thr) hard[t] = true;           // rows split at thresholds (:733-746)
     std::vector<sa_t>().swap(lcp);
     const uint64_t original_r = thr.size();
-    const uint32_t maxrun = mode == 6 ? 2047 : (mode == 7 ? 511 : 1023);  // move_row_configs.hpp:51,101,135,117
+    const uint32_t maxrun = mode == 6 ? 2047 : (mode == 7 ? 511 : (mode == 3 ? 4095 : 1023));   // move_row_configs.hpp:51,101,135,117,31,72
     // rows (:328-396)
     std::vector<uint64_t> all_p;
     {
@@ -310,8 +310,9 @@ static std::vector<uint8_t> build_index(std::vector<uint8_t> &text, int mode) {
     }
     // blocked ids (:939-1074)
     std::vector<uint32_t> blocked, id_blocks;
-    uint64_t n_blocks = 0, block_size = 1ull << 20, max_allowed = (1ull << 22) - 1;
-    if (mode == 8) {
+    uint64_t n_blocks = 0, block_size = mode == 2 ? 1ull << 22 : 1ull << 20;   // move_row_configs.hpp:73 / :102
+    uint64_t max_allowed = mode == 2 ? (1ull << 24) - 1 : (1ull << 22) - 1;     // :74 / :103
+    if (mode == 8 || mode == 2) {
         blocked.resize(r);
         for (;;) {
             n_blocks = (r + block_size - 1) / block_size;
@@ -371,7 +372,7 @@ static std::vector<uint8_t> build_index(std::vector<uint8_t> &text, int mode) {
     for (uint64_t i = 0; i < r; i++) {
         const uint32_t t = tbits[i];
         uint16_t w[4];
-        if (mode == 6) {
+        if (mode == 6 || mode == 3) {                                      // mode 3: 12-bit n / offset, no threshold bits (t == 0)
             const uint64_t d = dest[i];
             w[0] = (uint16_t)(d & 0xFFFF);
             w[1] = (uint16_t)((d >> 16) & 0xFFFF);
@@ -379,6 +380,13 @@ static std::vector<uint8_t> build_index(std::vector<uint8_t> &text, int mode) {
             w[3] = (uint16_t)(doff[i] | ((t & 1) << 11) | ((uint32_t)(d >> 32) << 12));
             const uint8_t *p = reinterpret_cast<const uint8_t *>(w);
             o.insert(o.end(), p, p + 8);
+        } else if (mode == 2) {                                            // blocked: 24-bit id, MoveRow::set_id src/move_row.cpp:213-225
+            const uint32_t b = blocked[i];
+            w[0] = (uint16_t)(b & 0xFFFF);
+            w[1] = (uint16_t)(lens[i] | (((b >> 16) & 0x3F) << 10));
+            w[2] = (uint16_t)(doff[i] | ((uint32_t)code[i] << 10) | ((b >> 22) << 14));
+            const uint8_t *p = reinterpret_cast<const uint8_t *>(w);
+            o.insert(o.end(), p, p + 6);
         } else if (mode == 5) {                                            // sampled, no thresholds: configs :107-118
             o.push_back((uint8_t)(lens[i] & 0xFF));
             o.push_back((uint8_t)(doff[i] & 0xFF));
@@ -410,7 +418,7 @@ static std::vector<uint8_t> build_index(std::vector<uint8_t> &text, int mode) {
     for (uint64_t v : last_offsets) put64(o, v);
     for (uint64_t v : first_runs) put64(o, v);
     for (uint64_t v : first_offsets) put64(o, v);
-    if (mode == 8) {
+    if (mode == 8 || mode == 2) {
         put64(o, n_blocks);
         const uint8_t *p = reinterpret_cast<const uint8_t *>(id_blocks.data());
         o.insert(o.end(), p, p + id_blocks.size() * 4);
@@ -520,7 +528,7 @@ int main(int argc, char **argv) {
         fprintf(stderr, "usage: see the header of tools/build_index.cpp\n");
         return 1;
     }
-    if (mode != 5 && mode != 6 && mode != 7 && mode != 8) { fprintf(stderr, "mode must be 5, 6, 7 or 8\n"); return 1; }
+    if (mode != 2 && mode != 3 && mode != 5 && mode != 6 && mode != 7 && mode != 8) { fprintf(stderr, "mode must be 2, 3, 5, 6, 7 or 8\n"); return 1; }
     mkdir(out_dir.c_str(), 0777);
     if (cmd == "pangenome") write_file(out_dir + "/text.bin", text);       // lets `reads` draw more reads later
     for (int set = 0; set < 2; set++) {                                    // optional second read set: argv[11..13] -> reads2.bin
