@@ -100,6 +100,7 @@ def main():
                     help="PML with Classifier::classify bins fused into the walk (BASELINE config 3 is 'PML + --classify'): "
                          "1 = PML vectors + bins, 2 = bins only (--classify --filter: no PML vector is written)")
     ap.add_argument("--variant", type=int, default=-1, help="pml kernel variant (A/B measurement)")
+    ap.add_argument("--zml-variant", type=int, default=-1, help="ZML kernel: 0 base-synchronous, 1 lane state machine (A/B)")
     ap.add_argument("--block-threads", type=int, default=0)
     ap.add_argument("--waves-per-cu", type=int, default=-1)
     ap.add_argument("--ragged", type=int, default=0, help="1: log-normal read lengths (mean = read_len); "
@@ -213,6 +214,8 @@ def main():
     index = movi_amd.MoveIndex.from_device_rows(cdesc, d_rows.data_ptr(), device=local_rank, keepalive=d_rows)
     if args.variant >= 0:
         index.set_option("pml_variant", args.variant)
+    if args.zml_variant >= 0:
+        index.set_option("zml_variant", args.zml_variant)
     if args.block_threads:
         index.set_option("block_threads", args.block_threads)
     if args.waves_per_cu >= 0:

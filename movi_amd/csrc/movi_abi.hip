@@ -486,6 +486,11 @@ int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
         ix->cfg.pml_variant = (int)value;
         return MOVI_OK;
     }
+    if (!strcmp(key, "zml_variant")) {
+        if (value < -1 || value > 1) return fail(MOVI_ERR_ARG, "zml_variant must be -1 (auto), 0 or 1");
+        ix->cfg.zml_variant = (int)value;
+        return MOVI_OK;
+    }
     if (!strcmp(key, "idx64")) {                             // test hook: run the 64-bit-index kernel instantiations
         if (value != 0 && value != 1) return fail(MOVI_ERR_ARG, "idx64 must be 0 or 1");
         ix->dev.idx32 = (value == 0 && ix->desc.r < 0xFFFFFFFFull) ? 1u : 0u;
@@ -529,7 +534,7 @@ static int ml_device(bool zml, movi_index_t *ix, const uint8_t *d_bases, const u
     HIP_TRY(hipMemsetAsync(ix->d_stats, 0, sizeof(DevStats), s));
     if (n_reads > 0xFFFFFFFFull) return fail(MOVI_ERR_ARG, "more than 2^32 reads in one call");
     if (zml)
-        HIP_TRY(launch_zml(ix->kmode, ix->dev, d_bases, d_offsets, n_reads, d_out, d_read_err, ix->d_stats,
+        HIP_TRY(launch_zml(ix->kmode, ix->dev, d_bases, d_offsets, n_reads, n_bases, d_out, d_read_err, ix->d_stats,
                            d_read_order, ix->cfg, s));
     else
         HIP_TRY(launch_pml(ix->kmode, ix->dev, d_bases, d_offsets, n_reads, n_bases, d_out, d_read_err, ix->d_stats,

@@ -1476,21 +1476,292 @@ __global__ __launch_bounds__(256) void zml_kernel(DevIndex ix, const uint8_t *__
     }
 }
 
+// ZML as a LANE STATE MACHINE ("zml_kernel_flat", selectable with the "zml_variant" option; NOT the default: see
+// launch_zml for the numbers): the base-synchronous kernel above costs a wave, per base, max-over-lanes(shrink trips)
+// + 1 + max-over-lanes(fast-forward trips) dependent round trips.  Here every lane runs the per-base micro-steps
+//   M0 start base k: phrase open and base legal -> which ends must scan (update_interval)      else FAIL
+//   M1 scans done:   interval still non-empty   -> the two LF jumps; both ends fast-forward      else FAIL
+//   M2 jumps done:   interval still non-empty   -> ml += 1, emit, next base (M0 in the same iteration)   else FAIL
+//   FAIL             ml = 0, the base opens the next phrase (rows of its interval's ends are fetched), emit 0, next base
+// on its own clock.  Each iteration a lane consumes ONE 4-row window per interval end -- the window around the next row
+// that end needs, whatever the reason (scan step, LF target, fast-forward neighbour, first rows of a new phrase) --
+// walks as far as that window reaches, then runs the micro-steps as far as they go without new rows (typically
+// M2 -> M0 -> M1: one iteration per matched base), and issues the two fetches of the next iteration before its
+// bookkeeping (emission, base decode) -- the software pipelining of pml_kernel_flatp, and its read-chunk handling.
+// The end-by-end order inside an iteration (start end first, whole window; then the end end) is the order of
+// shrink_interval's trips, so answers AND scan / fast-forward counts equal the base-synchronous kernel's.
+template <int MODE, typename IdxT>
+__global__ __launch_bounds__(256) void zml_kernel_flat(DevIndex ix, const uint8_t *__restrict__ bases,
+                                                       const uint64_t *__restrict__ offs, uint64_t n_reads,
+                                                       uint16_t *__restrict__ out, uint8_t *__restrict__ err,
+                                                       DevStats *stats, const uint32_t *__restrict__ order) {
+    enum : uint32_t { phStart = 0, phScan = 1, phLF = 2, phInit = 3, phDone = 4 };
+    enum : uint32_t { pNone = 0, pScan = 1, pFF = 2 };       // what an interval end is waiting for
+    __shared__ uint8_t s_code[256];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = ix.code_of[i];
+    __syncthreads();
+
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t ff_total = 0, scan_total = 0, failed = 0;
+    const bool valid = t < n_reads;
+    const uint64_t rid = (valid && order) ? order[t] : t;
+    const uint64_t beg = valid ? offs[rid] : 0;
+    const uint32_t len = valid ? (uint32_t)(offs[rid + 1] - beg) : 0;
+    uint16_t *O = out + beg;
+    const uint32_t packed_end = len & ~7u;
+    const IdxT r1 = (IdxT)(ix.r - 1), end_row = (IdxT)ix.end_bwt_idx, wb_last = (IdxT)(ix.r - 4);
+
+    auto load_pair_at = [&](uint64_t e, uint64_t &c0, uint64_t &c1) {      // see pml_kernel_flatp
+        uint64_t two[2];
+        __builtin_memcpy(two, bases + (e >= 16 ? e - 16 : 0), 16);
+        c0 = two[1];
+        c1 = two[0];
+    };
+    auto fix_pair = [&](uint64_t e, uint64_t &c0, uint64_t &c1) {
+        if (e < 16) {
+            const uint32_t sh = 8u * (uint32_t)(16 - e);
+            if (sh >= 64) { c0 = c1 << (sh - 64); c1 = 0; }
+            else { c0 = (c0 << sh) | (c1 >> (64 - sh)); c1 <<= sh; }
+        }
+    };
+    auto win_base = [&](IdxT nd) -> IdxT {
+        const IdxT wb = nd & ~(IdxT)3;
+        return wb < wb_last ? wb : wb_last;
+    };
+
+    // interval [rs:os, re:oe] (MoveInterval), the rows of its ends, and what each end waits for
+    IdxT rs = 0, re = 0, lo = 0, hi = 0;
+    uint32_t os = 0, oe = 0, open = 0, dead = 0;
+    uint2 rws = make_uint2(0, 0), rwe = make_uint2(0, 0);
+    uint32_t ps = pNone, pe = pNone, ffs = 0, ffe = 0;
+    uint32_t ph = len > 0 ? phStart : phDone;
+    uint32_t k = 0, ml = 0;
+    uint64_t rb = 0, rb2 = 0, nx0 = 0, nx1 = 0;
+    if (len > 0) {
+        load_pair_at(beg + len, rb, rb2);
+        fix_pair(beg + len, rb, rb2);
+    }
+    if (len > 16) load_pair_at(beg + len - 16, nx0, nx1);
+    // b = code of the base of step k, bn = of step k + 1: M2 -> M0 chains two bases inside one iteration, so the next
+    // base must be decoded one step ahead (rb always holds the 8-group of step k + 1)
+    uint32_t b = s_code[(uint32_t)(rb >> 56) & 0xFFu];
+    uint32_t bn = len > 1 ? s_code[(uint32_t)(rb >> 48) & 0xFFu] : 0xFFu;
+    uint4 pk = make_uint4(0, 0, 0, 0), pk_old = pk;
+    uint2 ws[4], we[4];
+    load_window<MODE>(ix.rows, 0, ws);
+    load_window<MODE>(ix.rows, 0, we);
+    IdxT wbs = 0, wbe = 0;                                   // bases of the two windows in flight
+
+    uint32_t lane_steps = 0, wave_steps = 0;
+    while (wave_any(ph != phDone)) {
+        const bool act = ph != phDone;
+        lane_steps += (uint32_t)act;
+        wave_steps += 1;
+        // ---- 1. walk each end as far as its window reaches (start end first: shrink_interval's order)
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            if (ps == pScan) {                               // update_interval: start moves down to the next row of b
+                if (rs >= hi) { dead = 1; ps = pNone; pe = pNone; }
+                else {
+                    const uint32_t q = (uint32_t)((IdxT)(rs + 1) - wbs);
+                    if (q < 4u) {
+                        const uint2 w = win_sel(ws, q);
+                        rs += 1;
+                        os = 0;
+                        scan_total += 1;
+                        if (rs != end_row && row_c<MODE>(w) == b) { rws = w; ps = pNone; }
+                        else if (rs >= hi) { dead = 1; ps = pNone; pe = pNone; }
+                    }
+                }
+            } else if (ps == pFF) {                          // fast_forward of the start walker (also: first row of a phrase)
+                const uint32_t q = (uint32_t)(rs - wbs);
+                if (q < 4u) {
+                    const uint2 w = win_sel(ws, q);
+                    const uint32_t n = row_n<MODE>(w);
+                    if (rs < r1 && os >= n && ffs < 65535u) { os -= n; rs += 1; ffs += 1; }
+                    else { rws = w; ps = pNone; }
+                }
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            if (pe == pScan) {                               // the end moves up to the previous row of b
+                if (re <= lo) { dead = 1; ps = pNone; pe = pNone; }
+                else {
+                    const uint32_t q = (uint32_t)((IdxT)(re - 1) - wbe);
+                    if (q < 4u) {
+                        const uint2 w = win_sel(we, q);
+                        re -= 1;
+                        scan_total += 1;
+                        if (re != end_row && row_c<MODE>(w) == b) { rwe = w; oe = row_n<MODE>(w) - 1; pe = pNone; }
+                        else if (re <= lo) { dead = 1; ps = pNone; pe = pNone; }
+                    }
+                }
+            } else if (pe == pFF) {
+                const uint32_t q = (uint32_t)(re - wbe);
+                if (q < 4u) {
+                    const uint2 w = win_sel(we, q);
+                    const uint32_t n = row_n<MODE>(w);
+                    if (re < r1 && oe >= n && ffe < 65535u) { oe -= n; re += 1; ffe += 1; }
+                    else { rwe = w; pe = pNone; }
+                }
+            }
+        }
+        // ---- 2. micro-steps, as far as they go without new rows
+        const bool ready = act && ps == pNone && pe == pNone;
+        uint32_t fail = 0, do_emit = 0, ek = 0, errc = kErrNone;
+        if (ready && ph == phLF) {                           // M2: both jumps and their fast-forwards are done
+            ff_total += ffs + ffe;
+            if (ffs >= 65535u || ffe >= 65535u) errc = kErrFastForward;   // move_structure.cpp:72-75
+            else if ((rs < re) || (rs == re && os <= oe)) {  // query_zml :717-720
+                ml += 1;
+                do_emit = 1; ek = k;
+                k += 1;
+                b = bn;
+                ph = k == len ? phDone : phStart;
+            } else fail = 1;
+        } else if (ready && ph == phInit) {                  // the rows of a new phrase's ends have arrived
+            ph = phStart;
+        }
+        if (ph == phStart && do_emit == 0 && act && b == 0xFFu) fail = 1;       // illegal base: no phrase
+        if (ph == phStart && do_emit == 0 && act && open == 0u) fail = 1;       // no phrase to extend
+        if (ph == phStart && act && fail == 0u && open != 0u && b != 0xFFu) {   // M0: update_interval begins
+            ps = (rs == end_row || row_c<MODE>(rws) != b) ? pScan : pNone;
+            pe = (re == end_row || row_c<MODE>(rwe) != b) ? pScan : pNone;
+            lo = rs; hi = re; dead = 0;
+            ph = phScan;
+        }
+        if (ph == phScan && act && ps == pNone && pe == pNone && errc == kErrNone) {   // M1: scans done (or none needed)
+            if (dead == 0u && ((rs < re) || (rs == re && os <= oe))) {
+                const uint64_t ja = row_id<MODE>(rws, (uint64_t)rs, ix), jb = row_id<MODE>(rwe, (uint64_t)re, ix);
+                if (ja >= ix.r || jb >= ix.r) errc = kErrIdRange;       // move_structure.cpp:63-65
+                else {
+                    os += row_off<MODE>(rws);
+                    oe += row_off<MODE>(rwe);
+                    rs = (IdxT)ja; re = (IdxT)jb;
+                    ps = pFF; pe = pFF; ffs = 0; ffe = 0;
+                    ph = phLF;
+                }
+            } else if (do_emit == 0u) {
+                fail = 1;                                    // (with an emission already made in this iteration: decided again
+            }                                                // in the next one -- ph stays phScan)
+        }
+        if (fail) {                                          // :750-760 / :696-704: the base opens the next phrase
+            ml = 0;
+            open = 0;
+            ph = phStart;
+            if (b != 0xFFu) {                                // initialize_backward_search :284-291
+                rs = (IdxT)ix.first_runs[b + 1]; re = (IdxT)ix.last_runs[b + 1];
+                os = (uint32_t)ix.first_offsets[b + 1]; oe = (uint32_t)ix.last_offsets[b + 1];
+                open = ((rs < re) || (rs == re && os <= oe)) ? 1u : 0u;
+                if (open) { ps = pFF; pe = pFF; ffs = 65535u; ffe = 65535u; ph = phInit; }   // rows only: no fast-forward
+            }
+            do_emit = 1; ek = k;
+            k += 1;
+            b = bn;
+            if (k == len) ph = phDone;
+        }
+        if (errc) { failed = errc; ph = phDone; ps = pNone; pe = pNone; }
+        // ---- 3. the next two windows leave now; everything below runs under their latency
+        {
+            const IdxT ns = ps == pScan ? (IdxT)(rs + 1) : rs, ne = pe == pScan ? (IdxT)(re - (re > 0 ? 1 : 0)) : re;
+            wbs = ps != pNone ? win_base(ns) : (IdxT)0;
+            wbe = pe != pNone ? win_base(ne) : (IdxT)0;
+            load_window<MODE>(ix.rows, (uint64_t)wbs, ws);
+            load_window<MODE>(ix.rows, (uint64_t)wbe, we);
+        }
+        // ---- 4. bookkeeping: emission and the next base
+        uint32_t want_nx = 0;
+        uint64_t nx_e = 0;
+        if (do_emit) {
+            const uint32_t val = ml > 65535u ? 65535u : ml;               // MoveQuery::add_ml
+            if (ek >= packed_end) {
+                O[ek] = (uint16_t)val;
+            } else {
+                pk.x = (pk.x >> 16) | (pk.y << 16);
+                pk.y = (pk.y >> 16) | (pk.z << 16);
+                pk.z = (pk.z >> 16) | (pk.w << 16);
+                pk.w = (pk.w >> 16) | (val << 16);
+                if ((ek & 15) == 7) {
+                    if (ek + 8 < packed_end) pk_old = pk;
+                    else __builtin_memcpy(O + (ek - 7), &pk, 16);
+                } else if ((ek & 15) == 15) {
+                    __builtin_memcpy(O + (ek - 15), &pk_old, 16);
+                    __builtin_memcpy(O + (ek - 7), &pk, 16);
+                }
+            }
+            const uint32_t j = k + 1;                        // k = ek + 1 is decoded already: look one step further
+            if (j < len) {
+                if ((j & 15) == 8) {
+                    rb = rb2;
+                } else if ((j & 15) == 0) {
+                    rb = nx0;
+                    rb2 = nx1;
+                    fix_pair(beg + len - j, rb, rb2);
+                    if (j + 16 < len) { want_nx = 1; nx_e = beg + len - j - 16; }
+                }
+                bn = s_code[(uint32_t)(rb >> (8 * (7 - (j & 7)))) & 0xFFu];
+            }
+        }
+        if (want_nx) load_pair_at(nx_e, nx0, nx1);
+    }
+    if (failed) {
+        for (uint32_t i = 0; i < len; ++i) O[i] = 0;
+    }
+    if (valid && err) err[rid] = (uint8_t)failed;
+    const uint32_t ffw = wave_sum(ff_total), scw = wave_sum(scan_total), erw = wave_sum(failed ? 1u : 0u);
+    if ((threadIdx.x & 63) == 0 && stats) {
+        if (ffw) atomicAdd(&stats->fast_forwards, (unsigned long long)ffw);
+        if (scw) atomicAdd(&stats->scans, (unsigned long long)scw);
+        if (erw) atomicAdd(&stats->errors, (unsigned long long)erw);
+    }
+    const uint32_t lsw = wave_sum(lane_steps);
+    if ((threadIdx.x & 63) == 0 && stats) {
+        atomicAdd(&stats->lane_steps, (unsigned long long)lsw);
+        atomicAdd(&stats->wave_steps, (unsigned long long)wave_steps);
+    }
+}
+
 hipError_t launch_zml(int mode, const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets,
-                      uint64_t n_reads, uint16_t *d_out, uint8_t *d_err, DevStats *d_stats,
+                      uint64_t n_reads, uint64_t n_bases, uint16_t *d_out, uint8_t *d_err, DevStats *d_stats,
                       const uint32_t *d_order, const LaunchCfg &cfg, hipStream_t stream) {
     if (n_reads == 0) return hipSuccess;
-    const int bt = cfg.block_threads > 0 ? cfg.block_threads : 256;
+    // 0 = base-synchronous kernel (default), 1 = lane state machine.  Measured (profiles/r02_zml_state_machine.txt),
+    // Gbases/s, kernel 0 / 1: 100 k x 10 kbp 12.1 / 12.4 (pangenome), 12.2 / 11.2 (random table); 1 M x 150 bp 36.5 /
+    // 32.6 and 33.9 / 32.1 -- unlike PML the state machine buys nothing here: a ZML base touches ~5 rows in two
+    // dependent stages (interval shrink, then the two jumps), so it needs 2.2 iterations per base with ~500
+    // instructions each (two 4-row windows, eight in-window hops), and on divergent reads every ~12th base opens a new
+    // phrase (one more iteration for the rows of its interval's ends).  Kept selectable ("zml_variant") and tested.
+    int v = cfg.zml_variant;
+    if (v < 0) v = 0;
+    if (v == 1 && (ix.r < 8 || n_bases < 16)) v = 0;     // the clamped windows need >= 4 rows, the 16-base fetches 16 bytes
+    const int bt = cfg.block_threads > 0 ? cfg.block_threads : (v == 1 ? 64 : 256);
     const uint64_t blocks = (n_reads + bt - 1) / bt;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     dim3 grid((unsigned)blocks), block((unsigned)bt);
-    if (mode == 6)
-        hipLaunchKernelGGL(zml_kernel<6>, grid, block, 0, stream, ix, d_bases, d_offsets, n_reads, d_out, d_err,
-                           d_stats, d_order);
-    else if (mode == 3)
-        hipLaunchKernelGGL(zml_kernel<3>, grid, block, 0, stream, ix, d_bases, d_offsets, n_reads, d_out, d_err,
-                           d_stats, d_order);
+    size_t dyn_lds = 0;                                  // occupancy cap by LDS padding, as in launch_pml (<= 64 KiB here)
+    if (cfg.waves_per_cu > 0) {
+        int bpc = cfg.waves_per_cu / (bt / 64);
+        if (bpc < 3) bpc = 3;
+        if (bpc < 32) dyn_lds = ((163840u / (unsigned)bpc) & ~1023u) - 1024u;
+    }
+#define MOVI_LAUNCH_ZML(M)                                                                                     \
+    do {                                                                                                       \
+        if (v == 0)                                                                                            \
+            hipLaunchKernelGGL(zml_kernel<M>, grid, block, dyn_lds, stream, ix, d_bases, d_offsets, n_reads,   \
+                               d_out, d_err, d_stats, d_order);                                                \
+        else if (ix.idx32)                                                                                     \
+            hipLaunchKernelGGL((zml_kernel_flat<M, uint32_t>), grid, block, dyn_lds, stream, ix, d_bases,      \
+                               d_offsets, n_reads, d_out, d_err, d_stats, d_order);                            \
+        else                                                                                                   \
+            hipLaunchKernelGGL((zml_kernel_flat<M, uint64_t>), grid, block, dyn_lds, stream, ix, d_bases,      \
+                               d_offsets, n_reads, d_out, d_err, d_stats, d_order);                            \
+    } while (0)
+    // resident layouts: 6 = regular-thresholds rows, 3 = regular rows (threshold-less types: 12-bit lengths)
+    if (mode == 6) MOVI_LAUNCH_ZML(6);
+    else if (mode == 3) MOVI_LAUNCH_ZML(3);
     else return hipErrorInvalidValue;
+#undef MOVI_LAUNCH_ZML
     return hipGetLastError();
 }
 

@@ -60,6 +60,7 @@ struct LaunchCfg {
     // -1 auto; 0 first kernel (plain I/O), 1 base-synchronous packed I/O, 7 flat lane state machine,
     // 10 flat lane state machine + row window, software-pipelined, 13 = 10 as a persistent grid with lane refill
     int pml_variant = -1;
+    int zml_variant = -1;  // -1 auto; 0 base-synchronous kernel, 1 lane state machine
     int num_cus = 256;
     int waves_per_cu = 0;  // 0 = auto (variant 10 on big batches and variant 13: kCapWaves; else no cap); else cap resident waves per CU by padding the block's LDS allocation
     int refill_blocks = 0; // variant 13: size of the persistent grid in blocks; 0 = num_cus x waves per CU (tests shrink it
@@ -87,7 +88,7 @@ hipError_t launch_count(int mode, const DevIndex &ix, const uint8_t *d_bases, co
                         DevStats *d_stats, const uint32_t *d_order, const LaunchCfg &cfg, hipStream_t stream);
 
 hipError_t launch_zml(int mode, const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets,
-                      uint64_t n_reads, uint16_t *d_out, uint8_t *d_err, DevStats *d_stats,
+                      uint64_t n_reads, uint64_t n_bases, uint16_t *d_out, uint8_t *d_err, DevStats *d_stats,
                       const uint32_t *d_order, const LaunchCfg &cfg, hipStream_t stream);
 
 hipError_t launch_classify(const uint16_t *d_pml, const uint64_t *d_offsets, uint64_t n_reads, uint32_t bin_width,

@@ -152,7 +152,8 @@ def test_count_vs_oracle(engines, mode):
 
 
 @pytest.mark.parametrize("mode", [6, 8])
-def test_zml_vs_oracle(engines, mode):
+@pytest.mark.parametrize("variant", [0, 1])
+def test_zml_vs_oracle(engines, mode, variant):
     """MoveStructure::query_zml (src/move_structure_query.cpp:690-785): ragged reads with substitutions
     and illegal characters, the edge cases around illegal first / last bases, every length 0..40
     (packed-store tails)."""
@@ -166,14 +167,22 @@ def test_zml_vs_oracle(engines, mode):
     reads += [ref[3000:3000 + L] for L in range(0, 41)]
     reads += [s for _, s in read_fastx(os.path.join(GOLDEN, "sample.fastq"))]
     bases, offs = pack(reads)
-    z, st = gpu.query_zml_packed(bases, offs)
-    assert (z == cpu.zml_batch(bases, offs, threads=4)).all()
-    assert st.errors == 0
-    for i in (0, 5, 600, 601, 602, 603, 604, 605, 606):
-        assert (gpu.query_zml([reads[i]])[0] == cpu.zml(reads[i])).all()
-    # an exact substring is one phrase: 0, 1, 2, ...
-    one = gpu.query_zml([ref[1000:1300]])[0]
-    assert (one == np.arange(300)).all()
+    gpu.set_option("zml_variant", variant)                   # 0 = base-synchronous kernel, 1 = lane state machine
+    try:
+        z, st = gpu.query_zml_packed(bases, offs)
+        assert (z == cpu.zml_batch(bases, offs, threads=4)).all()
+        assert st.errors == 0
+        for i in (0, 5, 600, 601, 602, 603, 604, 605, 606):
+            assert (gpu.query_zml([reads[i]])[0] == cpu.zml(reads[i])).all()
+        # an exact substring is one phrase: 0, 1, 2, ...
+        one = gpu.query_zml([ref[1000:1300]])[0]
+        assert (one == np.arange(300)).all()
+        # the two kernels walk the same rows: identical fast-forward and scan counts
+        gpu.set_option("zml_variant", 1 - variant)
+        z2, st2 = gpu.query_zml_packed(bases, offs)
+        assert (z2 == z).all() and (st2.fast_forwards, st2.scans) == (st.fast_forwards, st.scans)
+    finally:
+        gpu.set_option("zml_variant", -1)
 
 
 def test_zml_u16_clamp_on_device(built_lib):
