@@ -913,16 +913,21 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
         uint64_t j = 0;
         if (MODE == 6 || lf) j = row_id<MODE>(row, need, ix);
         const uint32_t lf_bad = lf & (uint32_t)(j >= ix.r);
-        const uint32_t errc = ff_over ? kErrFastForward
-                              : (repo_edge ? (down ? kErrNoRunBelow : kErrNoRunAbove)
-                                 : (scan_edge ? (isDown ? kErrNoRunBelow : kErrNoRunAbove)
-                                    : (lf_bad ? kErrIdRange : kErrNone)));
         const uint32_t step_fwd = ffm | (mism & down) | (scanning & (hit ^ 1u) & isDown);
         const uint32_t step_back = (mism & (down ^ 1u)) | (scanning & (hit ^ 1u) & isUp);
-        // (an error freezes the lane where it is: no out-of-table window is ever fetched)
-        const IdxT need_next = errc ? need : (lf ? (IdxT)j : (IdxT)(need + step_fwd - step_back));
-        const uint32_t st_next = (errc != 0u || (emit & (lf ^ 1u))) ? sDone
-                                 : (lf ? sFF : (mism ? (down ? sDown : sUp) : st));
+        IdxT need_next = lf ? (IdxT)j : (IdxT)(need + step_fwd - step_back);
+        uint32_t st_next = (emit & (lf ^ 1u)) ? sDone : (lf ? sFF : (mism ? (down ? sDown : sUp) : st));
+        // The reference's throws: practically never, so which one it was is sorted out off the common path (as one
+        // select ladder over need_next / st_next it cost ~45 instructions between a window's arrival and the next
+        // gather's issue in every iteration).  An error freezes the lane where it is: no out-of-table window is fetched.
+        uint32_t errc = kErrNone;
+        if (wave_any((ff_over | repo_edge | scan_edge | lf_bad) != 0u)) {
+            errc = ff_over ? kErrFastForward
+                           : (repo_edge ? (down ? kErrNoRunBelow : kErrNoRunAbove)
+                              : (scan_edge ? (isDown ? kErrNoRunBelow : kErrNoRunAbove)
+                                 : (lf_bad ? kErrIdRange : kErrNone)));
+            if (errc) { need_next = need; st_next = sDone; }
+        }
         // ---- the next gather leaves now; everything below runs under its latency
         // (`row` is not touched below, so the new window can land in the old one's registers)
         fetch(need_next, st_next != sDone, w);
