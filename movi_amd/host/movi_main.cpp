@@ -19,6 +19,11 @@
 #include <stdexcept>
 #include <thread>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include "../../include/movi_hip.h"
 #include "nulldb.hpp"
 #include "options.hpp"
@@ -112,79 +117,88 @@ uint64_t zml_rounds(const ReadSet &rs, size_t i, const uint16_t *z, const uint8_
     }
 }
 
-// Parses the next chunk of reads on its own thread while the caller works on the current one
-// (GPU calls + output writing): two ReadSet slots, handed over in order.  A parse error surfaces from
-// next() at the chunk it belongs to, after every earlier chunk has been delivered.
-class ChunkPrefetcher {
-public:
-    ChunkPrefetcher(BatchReader &reader, uint64_t chunk_bases, uint64_t min_reads, uint64_t hard_max)
-        : reader_(reader), worker_([=] { run(chunk_bases, min_reads, hard_max); }) {}
-    ~ChunkPrefetcher() {
-        {
-            std::lock_guard<std::mutex> g(m_);
-            stop_ = true;
-        }
-        cv_.notify_all();
-        worker_.join();
+// ---- the three-stage host pipeline of `movi query`: parse (thread) -> GPU calls (caller) -> order + write (thread).
+// Three Jobs circulate; each carries a chunk of reads and everything the engine returns for it, so the parser can fill
+// chunk k+1 and the writer can drain chunk k-1 while the GPU works on chunk k.  Record order is untouched: chunks are
+// parsed, processed and written strictly in input order.
+struct MlBuf {                                                        // grow-only, never zero-filled (the engine writes every entry)
+    uint16_t *p = nullptr;
+    size_t cap = 0;
+    ~MlBuf() { std::free(p); }
+    uint16_t *data() const { return p; }
+    void ensure(size_t n) {
+        if (n <= cap) return;
+        std::free(p);
+        cap = n + (n >> 4);
+        p = static_cast<uint16_t *>(std::malloc(cap * sizeof(uint16_t)));
+        if (!p) throw std::bad_alloc();
     }
-    // nullptr at end of input; the returned set stays valid until the next call
-    ReadSet *next() {
+};
+
+struct Job {
+    ReadSet rs;
+    MlBuf pml;                                                        // PML / ZML values, emission order per read
+    std::vector<uint64_t> matched, counts;                            // --count
+    std::vector<uint8_t> err;                                         // per-read error byte
+    RawBytes original;                                                // reads as given (--filter after --ignore-illegal-chars 1)
+    std::vector<uint32_t> bins_above, bins_below;                     // verdict-only classification
+    std::vector<uint64_t> bins_sum;
+    bool verdict_only = false;
+};
+
+template <typename T>
+class HandOff {                                                       // unbounded FIFO between two pipeline stages
+public:
+    void push(T v) {
+        { std::lock_guard<std::mutex> g(m_); q_.push_back(v); }
+        cv_.notify_all();
+    }
+    // false once close() was called and the queue is drained -- or at once after abandon()
+    bool pop(T &v) {
         std::unique_lock<std::mutex> g(m_);
-        if (held_ >= 0) {                                             // give the previous slot back
-            full_[held_] = false;
-            held_ = -1;
-            cv_.notify_all();
-        }
-        cv_.wait(g, [&] { return full_[take_] || done_; });
-        if (!full_[take_]) {
-            if (error_) std::rethrow_exception(error_);
-            return nullptr;
-        }
-        held_ = take_;
-        take_ ^= 1;
-        return &slot_[held_];
+        cv_.wait(g, [&] { return !q_.empty() || closed_ || abandoned_; });
+        if (abandoned_ || q_.empty()) return false;
+        v = q_.front();
+        q_.erase(q_.begin());
+        return true;
+    }
+    void close() {
+        { std::lock_guard<std::mutex> g(m_); closed_ = true; }
+        cv_.notify_all();
+    }
+    void abandon() {
+        { std::lock_guard<std::mutex> g(m_); abandoned_ = true; }
+        cv_.notify_all();
     }
 
 private:
-    void run(uint64_t chunk_bases, uint64_t min_reads, uint64_t hard_max) {
-        int put = 0;
-        for (;;) {
-            {
-                std::unique_lock<std::mutex> g(m_);
-                cv_.wait(g, [&] { return !full_[put] || stop_; });
-                if (stop_) return;
-            }
-            bool more = false;
-            try {
-                more = reader_.next_chunk(slot_[put], chunk_bases, min_reads, hard_max);
-            } catch (...) {
-                std::lock_guard<std::mutex> g(m_);
-                error_ = std::current_exception();
-                done_ = true;
-                cv_.notify_all();
-                return;
-            }
-            std::lock_guard<std::mutex> g(m_);
-            if (!more) {
-                done_ = true;
-                cv_.notify_all();
-                return;
-            }
-            full_[put] = true;
-            put ^= 1;
-            cv_.notify_all();
-        }
-    }
-    BatchReader &reader_;
-    ReadSet slot_[2];
-    bool full_[2] = {false, false};
-    bool done_ = false, stop_ = false;
-    int take_ = 0, held_ = -1;
-    std::exception_ptr error_;
     std::mutex m_;
     std::condition_variable cv_;
-    std::thread worker_;                                              // last: starts when everything above exists
+    std::vector<T> q_;
+    bool closed_ = false, abandoned_ = false;
 };
+
+// A regular read file is memory-mapped: the parser then cuts lines and batches without copying a byte, and its worker
+// threads copy the sequences straight from the page cache into the chunk; pipes and stdin go through the stream.
+struct InputMapping {
+    void *p = MAP_FAILED;
+    size_t n = 0;
+    ~InputMapping() { if (p != MAP_FAILED) munmap(p, n); }
+};
+std::unique_ptr<BatchReader> open_reader(const std::string &path, std::istream &in, size_t min_reads, InputMapping &map) {
+    if (path != "-" && !std::getenv("MOVI_NO_MMAP")) {
+        const int fd = open(path.c_str(), O_RDONLY);
+        struct stat sb;
+        if (fd >= 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0) {
+            map.n = (size_t)sb.st_size;
+            map.p = mmap(nullptr, map.n, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (map.p != MAP_FAILED) madvise(map.p, map.n, MADV_SEQUENTIAL);
+        }
+        if (fd >= 0) close(fd);
+    }
+    if (map.p != MAP_FAILED) return std::unique_ptr<BatchReader>(new BatchReader(static_cast<const char *>(map.p), map.n, min_reads));
+    return std::unique_ptr<BatchReader>(new BatchReader(in, min_reads));
+}
 
 int run_query(const Options &o) {
     int n_dev = 0;
@@ -249,9 +263,9 @@ int run_query(const Options &o) {
     // outputs (open_output_files, src/utils.cpp:319-384)
     Classifier classifier;
     // stream buffers first: they must outlive the streams that flush through them on destruction
-    std::vector<char> out_buf(4u << 20), out_buf2(1u << 20);          // 4 MiB: ~80 write(2) calls per 317 MB BPF
-    std::ofstream report_file, mls_file, matches_file;
-    mls_file.rdbuf()->pubsetbuf(out_buf.data(), (std::streamsize)out_buf.size());
+    std::vector<char> out_buf2(1u << 20);
+    std::ofstream report_file, matches_file;
+    BpfWriter mls_file;
     matches_file.rdbuf()->pubsetbuf(out_buf2.data(), (std::streamsize)out_buf2.size());
     std::ostream *report = nullptr;
     if (o.classify) {
@@ -273,9 +287,7 @@ int run_query(const Options &o) {
         std::string prefix = !o.out_file.empty() ? o.out_file : o.read_file + "." + index_type;
         prefix += "." + o.query_type();
         if (o.ml()) {
-            mls_file.open(prefix + ".bpf", std::ios::out | std::ios::binary);
-            if (!mls_file.good()) throw std::runtime_error("Failed to open the output file: " + prefix + ".bpf");
-            write_bpf_header(mls_file, 16);
+            mls_file.open(prefix + ".bpf", 16);
         } else {
             matches_file.open(prefix + ".matches");
             if (!matches_file.good()) throw std::runtime_error("Failed to open the output file: " + prefix + ".matches");
@@ -283,50 +295,140 @@ int run_query(const Options &o) {
     }
 
     auto t1 = std::chrono::steady_clock::now();
-    BatchReader reader(*in, o.prefetch ? 4 * o.strands : 1);          // src/movi.cpp:283, :326
-    // chunks of >= 2^26 bases and >= 2^18 reads (long reads: up to 2^31 bases): one GPU lane walks one read, so
-    // a chunk needs enough READS to fill the lanes; several chunks per file let parsing overlap the GPU + writing
-    const uint64_t chunk_bases = 1ull << 26;
-    ChunkPrefetcher chunks(reader, chunk_bases, 1ull << 18, 1ull << 31);
+    InputMapping map;
+    std::unique_ptr<BatchReader> reader_ptr = open_reader(o.read_file, *in, o.prefetch ? 4 * o.strands : 1, map);   // src/movi.cpp:283, :326
+    BatchReader &reader = *reader_ptr;
+    // chunks of >= 2^25 bases and >= 2^15 reads (long reads: up to 2^30 bases): one GPU lane walks one read, so a chunk needs
+    // READS to fill the lanes (2^25 bases of 150 bp reads = 224 k reads: more than the 147 k lanes the PML kernel keeps
+    // resident) -- but the host stages (text parsing ~1.4 GB/s, BPF writing) are what bounds the command, and they only overlap
+    // the GPU calls and each other across chunks: better several half-filled launches than one full one
+    const uint64_t chunk_bases = 1ull << 25, chunk_min_reads = 1ull << 15, chunk_hard_max = 1ull << 30;
     uint64_t reads_done = 0, bases_done = 0;
-    // matching lengths of the current chunk: grow-only and never zero-filled (the engine writes every entry)
-    struct MlBuf {
-        uint16_t *p = nullptr;
-        size_t cap = 0;
-        ~MlBuf() { std::free(p); }
-        uint16_t *data() const { return p; }
-        void ensure(size_t n) {
-            if (n <= cap) return;
-            std::free(p);
-            cap = n + (n >> 4);
-            p = static_cast<uint16_t *>(std::malloc(cap * sizeof(uint16_t)));
-            if (!p) throw std::bad_alloc();
-        }
-    } pml;
-    std::vector<uint64_t> matched, counts;
-    std::vector<uint8_t> err;
     double gpu_seconds = 0;
-    while (ReadSet *chunk = chunks.next()) {
-        ReadSet &rs = *chunk;
+
+    Job jobs[3];
+    HandOff<Job *> free_q, parsed_q, done_q;
+    for (Job &j : jobs) free_q.push(&j);
+    std::exception_ptr parse_error, write_error;
+    std::mutex err_m;
+
+    // ---- stage 1: parse
+    std::thread parser([&] {
+        try {
+            Job *j = nullptr;
+            while (free_q.pop(j)) {
+                if (!reader.next_chunk(j->rs, chunk_bases, chunk_min_reads, chunk_hard_max)) break;
+                parsed_q.push(j);
+            }
+        } catch (...) {
+            std::lock_guard<std::mutex> g(err_m);
+            parse_error = std::current_exception();
+        }
+        parsed_q.close();
+    });
+
+    // ---- stage 3: record order + writers (everything that touches the output streams lives on this thread)
+    auto write_job = [&](Job &job) {
+        ReadSet &rs = job.rs;
         const size_t n = rs.size();
-        if (n == 0) continue;
+        const bool verdict_only = job.verdict_only;
+        // record order: strand scheduler emulation in prefetch mode, file order otherwise
+        std::vector<uint32_t> order;
+        if (o.prefetch) {
+            std::vector<uint64_t> cost(n);
+            for (size_t i = 0; i < n; i++)
+                cost[i] = o.pml ? rs.len(i)
+                        : o.zml ? zml_rounds(rs, i, job.pml.data() + rs.offsets[i], desc.code_of)
+                                : count_rounds(rs, i, job.matched[i], desc.code_of);
+            order = strand_order(rs, cost, o.strands);
+        } else {
+            order.resize(n);
+            for (size_t i = 0; i < n; i++) order[i] = (uint32_t)i;
+        }
+        std::vector<BpfWriter::Record> bpf;                           // the chunk's records, in emission order
+        const bool to_bpf = o.ml() && o.write_output_allowed() && !o.write_stdout_enabled();
+        if (to_bpf) bpf.reserve(n);
+        for (uint32_t i : order) {
+            const uint64_t len = rs.len(i);
+            if (o.ml()) {
+                const uint16_t *p = verdict_only ? nullptr : job.pml.data() + rs.offsets[i];
+                if (o.classify) {                                     // write_mls, src/read_processor.cpp:565-578
+                    const bool found = verdict_only
+                        ? (job.bins_above[i] / (job.bins_above[i] + job.bins_below[i] + 0.0) > 0.50)      // classifier.cpp:119
+                        : classifier.classify(rs.ids[i], p, len, o.bin_width, o.write_output_allowed() ? report : nullptr);
+                    if (o.filter && !o.no_output && (found != o.invert)) {
+                        const uint8_t *seq = (job.original.empty() ? rs.bases.data() : job.original.data()) + rs.offsets[i];
+                        std::cout << ">" << rs.ids[i] << "\n";
+                        std::cout.write(reinterpret_cast<const char *>(seq), (std::streamsize)len);
+                        std::cout << "\n";
+                    }
+                }
+                if (o.write_output_allowed()) {
+                    if (o.write_stdout_enabled()) write_stdout_pmls(std::cout, rs.ids[i], p, len);
+                    else bpf.push_back(BpfWriter::Record{&rs.ids[i], p, len});
+                }
+            } else if (o.write_output_allowed()) {
+                std::ostream &out = o.write_stdout_enabled() ? static_cast<std::ostream &>(std::cout) : matches_file;
+                write_count_line(out, rs.ids[i], len, job.matched[i], job.counts[i]);
+            }
+        }
+        if (to_bpf) mls_file.append(bpf);
+    };
+    std::thread writer([&] {
+        Job *j = nullptr;
+        while (done_q.pop(j)) {
+            bool failed;
+            { std::lock_guard<std::mutex> g(err_m); failed = write_error != nullptr; }
+            if (!failed) {
+                try {
+                    write_job(*j);
+                } catch (...) {
+                    std::lock_guard<std::mutex> g(err_m);
+                    write_error = std::current_exception();
+                }
+            }
+            free_q.push(j);
+        }
+    });
+    // whatever happens below, the two threads are released and joined before the streams and jobs go away
+    struct Joiner {
+        HandOff<Job *> &free_q, &done_q;
+        std::thread &parser, &writer;
+        ~Joiner() {
+            free_q.abandon();                                         // parser: stop taking jobs
+            done_q.close();                                           // writer: drain what was handed over, then stop
+            if (parser.joinable()) parser.join();
+            if (writer.joinable()) writer.join();
+        }
+    } joiner{free_q, done_q, parser, writer};
+
+    // ---- stage 2: the GPU calls, in input order
+    Job *jp = nullptr;
+    while (parsed_q.pop(jp)) {
+        Job &job = *jp;
+        ReadSet &rs = job.rs;
+        const size_t n = rs.size();
+        { std::lock_guard<std::mutex> g(err_m); if (write_error) std::rethrow_exception(write_error); }
+        if (n == 0) { free_q.push(jp); continue; }
         if (o.reverse)                                                // src/read_processor.cpp:49-51
             for (size_t i = 0; i < n; i++) std::reverse(rs.bases.begin() + rs.offsets[i], rs.bases.begin() + rs.offsets[i + 1]);
-        std::vector<uint8_t> original;                                // --filter echoes the read as given
+        job.original.clear();                                         // --filter echoes the read as given
         if (o.ignore_illegal_chars == 1) {                            // check_alphabet, src/move_structure.cpp:389-395
-            if (o.filter) original = rs.bases;
+            if (o.filter) job.original.assign(rs.bases);
             for (auto &c : rs.bases)
                 if (desc.code_of[c] == 0xFF) c = 'A';
         }
         // --classify with --filter / --no-output needs verdicts only: the bins are reduced on the
         // GPU and the PML vectors never cross PCIe
         const bool verdict_only = o.pml && o.classify && !o.write_output_allowed();   // PML only: ZML takes the host bins
-        std::vector<uint32_t> bins_above(verdict_only ? n : 0), bins_below(verdict_only ? n : 0);
-        std::vector<uint64_t> bins_sum(verdict_only ? n : 0);
-        pml.ensure(o.ml() && !verdict_only ? rs.bases.size() : 0);
-        matched.assign(o.count ? n : 0, 0);
-        counts.assign(o.count ? n : 0, 0);
-        err.assign(n, 0);
+        job.verdict_only = verdict_only;
+        job.bins_above.assign(verdict_only ? n : 0, 0);
+        job.bins_below.assign(verdict_only ? n : 0, 0);
+        job.bins_sum.assign(verdict_only ? n : 0, 0);
+        job.pml.ensure(o.ml() && !verdict_only ? rs.bases.size() : 0);
+        job.matched.assign(o.count ? n : 0, 0);
+        job.counts.assign(o.count ? n : 0, 0);
+        job.err.assign(n, 0);
         const std::vector<size_t> sb = shard_bounds(rs, o.gpus);
         std::vector<std::string> errors((size_t)o.gpus);
         auto tg = std::chrono::steady_clock::now();
@@ -336,15 +438,15 @@ int run_query(const Options &o) {
             int rc;
             if (verdict_only)
                 rc = movi_pml_classify_host(handles[g], rs.bases.data(), rs.offsets.data() + a, b - a, (uint32_t)o.bin_width,
-                                            classifier.max_value_thr, bins_above.data() + a, bins_below.data() + a,
-                                            bins_sum.data() + a, err.data() + a, nullptr);
+                                            classifier.max_value_thr, job.bins_above.data() + a, job.bins_below.data() + a,
+                                            job.bins_sum.data() + a, job.err.data() + a, nullptr);
             else if (o.pml)
-                rc = movi_pml_host(handles[g], rs.bases.data(), rs.offsets.data() + a, b - a, pml.data(), err.data() + a, nullptr);
+                rc = movi_pml_host(handles[g], rs.bases.data(), rs.offsets.data() + a, b - a, job.pml.data(), job.err.data() + a, nullptr);
             else if (o.zml)
-                rc = movi_zml_host(handles[g], rs.bases.data(), rs.offsets.data() + a, b - a, pml.data(), err.data() + a, nullptr);
+                rc = movi_zml_host(handles[g], rs.bases.data(), rs.offsets.data() + a, b - a, job.pml.data(), job.err.data() + a, nullptr);
             else
-                rc = movi_count_host(handles[g], rs.bases.data(), rs.offsets.data() + a, b - a, matched.data() + a,
-                                     counts.data() + a, err.data() + a, nullptr);
+                rc = movi_count_host(handles[g], rs.bases.data(), rs.offsets.data() + a, b - a, job.matched.data() + a,
+                                     job.counts.data() + a, job.err.data() + a, nullptr);
             if (rc != MOVI_OK) errors[g] = movi_last_error();
         };
         if (o.gpus == 1) {
@@ -357,47 +459,18 @@ int run_query(const Options &o) {
         gpu_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - tg).count();
         for (const auto &e : errors)
             if (!e.empty()) throw EngineError(e);
-
-        // record order: strand scheduler emulation in prefetch mode, file order otherwise
-        std::vector<uint32_t> order;
-        if (o.prefetch) {
-            std::vector<uint64_t> cost(n);
-            for (size_t i = 0; i < n; i++)
-                cost[i] = o.pml ? rs.len(i)
-                        : o.zml ? zml_rounds(rs, i, pml.data() + rs.offsets[i], desc.code_of)
-                                : count_rounds(rs, i, matched[i], desc.code_of);
-            order = strand_order(rs, cost, o.strands);
-        } else {
-            order.resize(n);
-            for (size_t i = 0; i < n; i++) order[i] = (uint32_t)i;
-        }
-        for (uint32_t i : order) {
-            const uint64_t len = rs.len(i);
-            if (o.ml()) {
-                const uint16_t *p = verdict_only ? nullptr : pml.data() + rs.offsets[i];
-                if (o.classify) {                                     // write_mls, src/read_processor.cpp:565-578
-                    const bool found = verdict_only
-                        ? (bins_above[i] / (bins_above[i] + bins_below[i] + 0.0) > 0.50)      // classifier.cpp:119
-                        : classifier.classify(rs.ids[i], p, len, o.bin_width, o.write_output_allowed() ? report : nullptr);
-                    if (o.filter && !o.no_output && (found != o.invert)) {
-                        const uint8_t *seq = (original.empty() ? rs.bases.data() : original.data()) + rs.offsets[i];
-                        std::cout << ">" << rs.ids[i] << "\n";
-                        std::cout.write(reinterpret_cast<const char *>(seq), (std::streamsize)len);
-                        std::cout << "\n";
-                    }
-                }
-                if (o.write_output_allowed()) {
-                    if (o.write_stdout_enabled()) write_stdout_pmls(std::cout, rs.ids[i], p, len);
-                    else write_bpf_record(mls_file, rs.ids[i], p, len);
-                }
-            } else if (o.write_output_allowed()) {
-                std::ostream &out = o.write_stdout_enabled() ? static_cast<std::ostream &>(std::cout) : matches_file;
-                write_count_line(out, rs.ids[i], len, matched[i], counts[i]);
-            }
-        }
         reads_done += n;
         bases_done += rs.bases.size();
+        done_q.push(jp);
     }
+    // end of input (or a parse error, which surfaces after every earlier chunk has been written)
+    done_q.close();
+    writer.join();
+    free_q.abandon();
+    parser.join();
+    if (write_error) std::rethrow_exception(write_error);
+    if (parse_error) std::rethrow_exception(parse_error);
+    mls_file.close();
     const double total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
     std::cerr << "[movi] " << reads_done << " reads are processed.\n";
     std::cerr << "[movi] Time measured for processing the reads: " << total << " s (" << bases_done << " bases; GPU calls "
@@ -447,7 +520,9 @@ int run_plan(const Options &o) {
         if (!file_in.good()) throw std::runtime_error("The input file " + o.read_file + " does not exist.");
         in = &file_in;
     }
-    BatchReader reader(*in, o.prefetch ? 4 * o.strands : 1);
+    InputMapping map;
+    std::unique_ptr<BatchReader> reader_ptr = open_reader(o.read_file, *in, o.prefetch ? 4 * o.strands : 1, map);
+    BatchReader &reader = *reader_ptr;
     ReadSet rs;
     while (reader.next_chunk(rs, 1ull << 28)) {
         std::vector<uint64_t> cost(rs.size());

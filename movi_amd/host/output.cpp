@@ -6,25 +6,71 @@
 #include <iostream>
 #include <stdexcept>
 
+#include <fcntl.h>
+#include <unistd.h>
+
 namespace movi_host {
 
-void write_bpf_header(std::ostream &f, uint8_t entry_size) {
-    // struct BPFHeader {u32 magic; u8 major, minor, patch; u8 entry_size; u16 reserved;} is
-    // written with sizeof == 12: bytes 10-11 are struct padding (uninitialised in the reference,
-    // zero here).  include/utils.hpp:64-82, version numbers include/version.hpp:12-14.
+BpfWriter::~BpfWriter() {
+    if (fd_ >= 0) ::close(fd_);
+}
+
+void BpfWriter::open(const std::string &path, uint8_t entry_size) {
+    path_ = path;
+    fd_ = ::open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
+    if (fd_ < 0) throw std::runtime_error("Failed to open the output file: " + path);
+    // struct BPFHeader {u32 magic; u8 major, minor, patch; u8 entry_size; u16 reserved;} is written with sizeof == 12:
+    // bytes 10-11 are struct padding (uninitialised in the reference, zero here).  include/utils.hpp:64-82, version
+    // numbers include/version.hpp:12-14.
     uint8_t h[12] = {0};
     std::memcpy(h, &kBpfMagic, 4);
     h[4] = 1; h[5] = 0; h[6] = 0;
     h[7] = entry_size;
-    f.write(reinterpret_cast<const char *>(h), 12);
+    if (::write(fd_, h, 12) != 12) throw std::runtime_error("Failed to write the output file: " + path);
+    pos_ = 12;
 }
 
-void write_bpf_record(std::ostream &f, const std::string &id, const uint16_t *pml, uint64_t n) {
-    uint16_t st_length = static_cast<uint16_t>(id.length());          // src/utils.cpp:222
-    f.write(reinterpret_cast<const char *>(&st_length), 2);
-    f.write(id.data(), st_length);
-    f.write(reinterpret_cast<const char *>(&n), 8);                   // output_binary :204-210
-    f.write(reinterpret_cast<const char *>(pml), (std::streamsize)(n * 2));
+void BpfWriter::close() {
+    if (fd_ >= 0 && ::close(fd_) != 0) { fd_ = -1; throw std::runtime_error("Failed to write the output file: " + path_); }
+    fd_ = -1;
+}
+
+// Measured on the GPU box (2 GB of PMLs for 100 k x 10 kbp reads / 317 MB for 1 M x 150 bp; processing time of the whole
+// command, +-10 % run to run): records gathered in a multi-MiB buffer and written with few large write()s 0.60 / 0.11 s;
+// pwritev of (head, payload) iovec pairs from 8 threads 0.55 / 0.16 s (buffered writes to ONE file serialise on the inode
+// lock, and 2 M small iovecs cost more than copying them); one write() per 20 KB payload 0.77 / 0.10 s (system calls are
+// expensive there); T threads copying into a MAP_SHARED mapping of the grown file 1.40 / 0.22 s (page faults on the file
+// mapping are slow there).  Kept: one thread, an 8 MiB buffer, only payloads of 1 MiB and more written straight from the
+// result array.
+void BpfWriter::append(const std::vector<Record> &records) {
+    if (buf_.empty()) buf_.resize(8u << 20);
+    size_t fill = 0;
+    auto write_all = [&](const void *p, size_t len) {
+        const uint8_t *q = static_cast<const uint8_t *>(p);
+        while (len) {
+            const ssize_t w = ::write(fd_, q, len);
+            if (w < 0) throw std::runtime_error("Failed to write the output file: " + path_);
+            q += w;
+            len -= (size_t)w;
+        }
+    };
+    auto flush = [&] { if (fill) { write_all(buf_.data(), fill); fill = 0; } };
+    auto put = [&](const void *p, size_t len) {
+        if (len > buf_.size() - fill) flush();
+        std::memcpy(buf_.data() + fill, p, len);
+        fill += len;
+    };
+    for (const Record &r : records) {
+        const uint16_t idl = static_cast<uint16_t>(r.id->length());      // src/utils.cpp:222
+        put(&idl, 2);
+        put(r.id->data(), idl);
+        put(&r.n, 8);                                                    // output_binary :204-210
+        const size_t bytes = r.n * 2;
+        if (bytes >= (1u << 20)) { flush(); write_all(r.pml, bytes); }
+        else if (bytes) put(r.pml, bytes);
+        pos_ += 10u + idl + bytes;
+    }
+    flush();
 }
 
 void write_stdout_pmls(std::ostream &out, const std::string &id, const uint16_t *pml, uint64_t n) {

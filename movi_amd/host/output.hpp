@@ -20,9 +20,28 @@ namespace movi_host {
 
 const uint32_t kBpfMagic = 0x42504600u;      // "BPF\0", include/utils.hpp:26
 
-void write_bpf_header(std::ostream &f, uint8_t entry_size);
-// One record: u16 id_len | id | u64 n | n x u16 (emission order = last base first)
-void write_bpf_record(std::ostream &f, const std::string &id, const uint16_t *pml, uint64_t n);
+// BPF file: 12-byte header, then per read u16 id_len | id | u64 n | n x u16 (emission order = last base first).
+// The BPF file of one query, written through a raw descriptor: records are appended a chunk at a time (see append()
+// in output.cpp for what was measured).
+class BpfWriter {
+public:
+    BpfWriter() = default;
+    BpfWriter(const BpfWriter &) = delete;
+    BpfWriter &operator=(const BpfWriter &) = delete;
+    ~BpfWriter();
+    void open(const std::string &path, uint8_t entry_size);           // creates / truncates, writes the header
+    bool is_open() const { return fd_ >= 0; }
+    struct Record { const std::string *id; const uint16_t *pml; uint64_t n; };
+    void append(const std::vector<Record> &records);                  // in the given order
+    void close();
+
+private:
+    int fd_ = -1;
+    uint64_t pos_ = 0;
+    std::string path_;
+    std::vector<uint8_t> buf_;
+};
+
 // `>id\n` + values in read order, each followed by a space, + `\n`
 void write_stdout_pmls(std::ostream &out, const std::string &id, const uint16_t *pml, uint64_t n);
 void write_count_line(std::ostream &out, const std::string &id, uint64_t query_length, uint64_t matched, uint64_t count);

@@ -5,6 +5,7 @@
 #include <cstring>
 #include <queue>
 #include <stdexcept>
+#include <thread>
 
 namespace movi_host {
 
@@ -16,8 +17,8 @@ bool LineSource::fill() {
         pos_ = 0;
     }
     if (end_ == buf_.size()) buf_.resize(buf_.size() * 2);             // a single line longer than the buffer
-    in_.read(buf_.data() + end_, (std::streamsize)(buf_.size() - end_));
-    const size_t got = (size_t)in_.gcount();
+    in_->read(buf_.data() + end_, (std::streamsize)(buf_.size() - end_));
+    const size_t got = (size_t)in_->gcount();
     end_ += got;
     if (got == 0) drained_ = true;
     return got > 0;
@@ -25,12 +26,12 @@ bool LineSource::fill() {
 
 int LineSource::peek() {
     if (pos_ == end_ && !fill()) { eof_ = true; return std::char_traits<char>::eof(); }
-    return (unsigned char)buf_[pos_];
+    return (unsigned char)data()[pos_];
 }
 
 bool LineSource::getline(const char *&p, size_t &n) {
     for (;;) {
-        const char *base = buf_.data() + pos_;
+        const char *base = data() + pos_;
         const void *nl = std::memchr(base, '\n', end_ - pos_);
         if (nl) {
             n = (size_t)(static_cast<const char *>(nl) - base);
@@ -41,7 +42,7 @@ bool LineSource::getline(const char *&p, size_t &n) {
         if (!fill()) break;
     }
     if (pos_ == end_) { eof_ = true; return false; }                   // nothing left: getline fails
-    p = buf_.data() + pos_;                                            // last line without a newline:
+    p = data() + pos_;                                                 // last line without a newline:
     n = end_ - pos_;                                                   // returned, and eof is set
     pos_ = end_;
     eof_ = true;
@@ -52,9 +53,9 @@ bool LineSource::getline(const char *&p, size_t &n) {
 // (src/batch_loader.cpp:50-87): lines are read until BOTH >= 1000 "bases" and >= min_reads
 // reads are covered.  FASTQ: a read is counted every 4 lines with (record bytes)/2 bases;
 // FASTA: a read is counted when the NEXT line starts with '>' with (record bytes) bases.
-bool BatchReader::load_batch() {
-    arena_.clear();
-    lines_.clear();
+// The batch's lines are appended to lines_ from index first_line on.
+bool BatchReader::load_batch(size_t &first_line) {
+    first_line = lines_.size();
     if (format_ < 0) {
         if (!src_.good()) return false;
         int c = src_.peek();
@@ -70,17 +71,21 @@ bool BatchReader::load_batch() {
         const char *p;
         size_t n;
         if (!src_.getline(p, n)) {
-            if (format_ == 1 && nlines % 4 == 0) return valid || !lines_.empty();
-            if (format_ == 0 && nlines % 2 == 0) return valid || !lines_.empty();
+            if (format_ == 1 && nlines % 4 == 0) return valid || lines_.size() > first_line;
+            if (format_ == 0 && nlines % 2 == 0) return valid || lines_.size() > first_line;
             // the reference returns false here and drops the partial batch (:57-63)
-            lines_.clear();
+            lines_.resize(first_line);
             return false;
         }
         nlines++;
         record += n;
         valid = true;
-        lines_.push_back(Span{arena_.size(), n});
-        arena_.append(p, n);
+        if (mem_) {
+            lines_.push_back(Span{(size_t)(p - mem_), n});
+        } else {
+            lines_.push_back(Span{arena_.size(), n});
+            arena_.append(p, n);
+        }
         if (format_ == 1) {
             if (nlines % 4 == 0) { bases += record / 2; record = 0; reads++; }
         } else if (src_.peek() == '>') {
@@ -97,17 +102,19 @@ static size_t rstrip_len(const char *p, size_t n) {
 
 bool BatchReader::next_chunk(ReadSet &out, uint64_t max_bases, uint64_t min_reads, uint64_t hard_max_bases) {
     out.ids.clear(); out.bases.clear(); out.offsets.assign(1, 0); out.batch_of.clear();
-    // one allocation per slot instead of doubling reallocations (each of which faults its pages in afresh)
-    if (out.bases.capacity() < max_bases + (max_bases >> 4)) out.bases.reserve(max_bases + (max_bases >> 4));
+    arena_.clear();
+    lines_.clear();
+    recs_.clear();
+    // ---- phase 1 (sequential): batches, headers, where each read's sequence lines are
     bool any = false;
-    while (out.bases.size() < max_bases || (out.ids.size() < min_reads && out.bases.size() < hard_max_bases)) {
-        if (!load_batch()) break;
+    uint64_t approx_bases = 0;                                         // sequence-line bytes, trailing whitespace included
+    while (approx_bases < max_bases || (recs_.size() < min_reads && approx_bases < hard_max_bases)) {
+        size_t p = 0;
+        if (!load_batch(p)) break;
         any = true;
         const uint32_t b = batch_counter_++;
         // grabNextRead over the batch (src/batch_loader.cpp:91-143)
-        size_t p = 0;
         const size_t nl = lines_.size();
-        auto line = [&](size_t i) { return arena_.data() + lines_[i].off; };
         while (p < nl) {
             const char *hdr = line(p);
             const size_t hn = lines_[p].len;
@@ -117,30 +124,70 @@ bool BatchReader::next_chunk(ReadSet &out, uint64_t max_bases, uint64_t min_read
             if (format_ == 0 && hdr[0] != '>')
                 throw std::runtime_error(std::string("Incorrect FASTA entry, it should start with '>' but found ") + hdr[0]);
             if (hn <= 2) throw std::runtime_error("header line is missing an id. invalid query cannot be processed.");
-            size_t id_len = hn;                                        // find_first_of(" \t\r", 1)
-            for (size_t i = 1; i < hn; i++)
-                if (hdr[i] == ' ' || hdr[i] == '\t' || hdr[i] == '\r') { id_len = i; break; }
-            // substr(1, id_len): id_len is used as a LENGTH, so the whitespace char is kept
-            out.ids.emplace_back(hdr + 1, std::min(id_len, hn - 1));
+            Rec r{p, p + 1, p + 1, b};
             p++;
             if (format_ == 1) {
-                if (p >= nl) { out.ids.pop_back(); break; }
-                const size_t sn = rstrip_len(line(p), lines_[p].len);
-                if (p + 2 >= nl) { out.ids.pop_back(); break; }        // '+' line and qualities must exist
-                out.bases.insert(out.bases.end(), line(p), line(p) + sn);
+                if (p >= nl) break;
+                if (p + 2 >= nl) break;                                // '+' line and qualities must exist
+                r.seq_end = p + 1;
+                approx_bases += lines_[p].len;
                 p += 3;
             } else {
                 while (p < nl && (lines_[p].len == 0 || line(p)[0] != '>')) {
-                    const size_t sn = rstrip_len(line(p), lines_[p].len);
-                    out.bases.insert(out.bases.end(), line(p), line(p) + sn);
+                    approx_bases += lines_[p].len;
                     p++;
                 }
+                r.seq_end = p;
             }
-            out.offsets.push_back(out.bases.size());
-            out.batch_of.push_back(b);
+            recs_.push_back(r);
         }
     }
-    return any;
+    if (!any) return false;
+    // ---- phase 2 (parallel): ids, stripped lengths, then the bases at their final offsets
+    const size_t n = recs_.size();
+    out.ids.resize(n);
+    out.batch_of.resize(n);
+    out.offsets.assign(n + 1, 0);
+    unsigned T = threads_ ? threads_ : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (approx_bases < (1u << 22) || n < 64) T = 1;                    // not worth a thread launch
+    auto for_ranges = [&](auto &&fn) {
+        if (T == 1) { fn(0, n); return; }
+        std::vector<std::thread> th;
+        // ranges balanced by sequence bytes, not by read count: line offsets are monotone in the input
+        for (unsigned t = 0; t < T; t++) th.emplace_back([&, t] { fn(n * t / T, n * (t + 1) / T); });
+        for (auto &x : th) x.join();
+    };
+    for_ranges([&](size_t a, size_t b) {
+        for (size_t i = a; i < b; i++) {
+            const Rec &r = recs_[i];
+            const char *hdr = line(r.hdr);
+            const size_t hn = lines_[r.hdr].len;
+            size_t id_len = hn;                                        // find_first_of(" \t\r", 1)
+            for (size_t k = 1; k < hn; k++)
+                if (hdr[k] == ' ' || hdr[k] == '\t' || hdr[k] == '\r') { id_len = k; break; }
+            // substr(1, id_len): id_len is used as a LENGTH, so the whitespace char is kept
+            out.ids[i].assign(hdr + 1, std::min(id_len, hn - 1));
+            out.batch_of[i] = r.batch;
+            uint64_t len = 0;
+            for (size_t l = r.seq_first; l < r.seq_end; l++) len += rstrip_len(line(l), lines_[l].len);
+            out.offsets[i + 1] = len;
+        }
+    });
+    for (size_t i = 0; i < n; i++) out.offsets[i + 1] += out.offsets[i];
+    const uint64_t total = out.offsets[n];
+    out.bases.resize_uninitialized(total);                             // first touched by the workers below, in parallel
+    for_ranges([&](size_t a, size_t b) {
+        for (size_t i = a; i < b; i++) {
+            const Rec &r = recs_[i];
+            uint8_t *dst = out.bases.data() + out.offsets[i];
+            for (size_t l = r.seq_first; l < r.seq_end; l++) {
+                const size_t sn = rstrip_len(line(l), lines_[l].len);
+                std::memcpy(dst, line(l), sn);
+                dst += sn;
+            }
+        }
+    });
+    return true;
 }
 
 std::vector<uint32_t> strand_order(const ReadSet &rs, const std::vector<uint64_t> &cost, size_t strands) {

@@ -141,6 +141,36 @@ def test_batching_and_record_order(movi_bin, tmp_path, fmt, flags, strands, pref
     assert any(i.endswith(b" ") for i in ids) and any(i.endswith(b"\t") for i in ids)
 
 
+@pytest.mark.parametrize("fmt", ["fa", "fq"])
+def test_parallel_mmap_parser_equals_stream_parser(movi_bin, tmp_path, fmt):
+    """A read file big enough for the parser's worker threads (> 4 MB of sequence), with comment headers, multi-line
+    FASTA records, CRLF line ends and a last line without a newline: the memory-mapped parallel path, the stream path
+    (MOVI_NO_MMAP=1) and stdin give the same batches, ids, lengths and order -- and the reference's schedule."""
+    rng = np.random.default_rng(77 + (fmt == "fq"))
+    lines = make_reads(rng, 14000, fmt)
+    for k in range(0, len(lines), 97):                        # sprinkle CRLF line ends (stripped by the reader, kept in ids)
+        if not lines[k].startswith((b">", b"@", b"+")):
+            lines[k] = lines[k] + b"\r"
+    path = tmp_path / ("big." + fmt)
+    path.write_bytes(b"\n".join(lines))                       # no trailing newline
+    assert path.stat().st_size > (4 << 20)
+    a = run(["plan", "-r", str(path), "-s16"])
+    b = run(["plan", "-r", str(path), "-s16"], env=dict(os.environ, MOVI_NO_MMAP="1"))
+    c = run(["plan", "-r", "-", "-s16"], input=path.read_bytes())
+    assert a.returncode == b.returncode == c.returncode == 0, (a.stderr, b.stderr, c.stderr)
+    assert a.stdout == b.stdout == c.stdout and a.stdout.count(b"\n") == 14000
+    clean = [l[:-1] if l.endswith(b"\r") and not l.startswith((b">", b"@")) else l for l in lines]
+    exp = reference_schedule(clean, fmt, 16, True)
+    got = []
+    for l in a.stdout.split(b"\n"):
+        if l:
+            bb, rest = l.split(b"\t", 1)
+            i, ln = rest.rsplit(b"\t", 1)
+            got.append((int(bb), i, int(ln)))
+    assert [(x, z) for x, _, z in got] == [(x, z) for x, _, z in exp]     # batches and lengths in the reference's order
+    assert [y for _, y, _ in got] == [y for _, y, _ in exp]
+
+
 def test_view_prints_read_order(movi_bin, tmp_path):
     """BPF layout: 12-byte header | per read u16 id_len, id, u64 n, n x u16 (last base first);
     `view` prints each record reversed (src/movi.cpp:454-456)."""
