@@ -224,7 +224,8 @@ int movi_count_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_
  * "refill_blocks" (variant 13: wavefronts in the persistent grid, 0 = CUs x waves per CU),
  * "block_threads" (0 = auto, 64, 128, 192 or 256: the kernels' launch bound), "waves_per_cu"
  * (0 = uncapped; variant 13: 0 = its default of 9), "idx64" (1 = run the kernel instantiations for
- * tables of 2^32 rows and more, whatever the size: a test hook). */
+ * tables of 2^32 rows and more, whatever the size: a test hook), "release_scratch" (any value: frees the
+ * device staging buffers that the *_host entry points keep, grow-only, across calls). */
 int movi_set_option(movi_index_t *ix, const char *key, int64_t value);
 
 /* ---- ZML (Ziv-Merhav cross parse) ---------------------------------------------- */

@@ -91,7 +91,14 @@ struct movi_index {
     DevIndex dev{};
     int kmode = 0;                   // row layout the kernels run on: desc.mode, except 6 for sampled-thresholds (expanded)
     LaunchCfg cfg;
+    // device staging of the *_host entry points: grow-only, kept across calls (a hipMalloc / hipFree pair per call and
+    // buffer cost more than the copies themselves); released by movi_index_destroy or movi_set_option("release_scratch")
+    enum { kBases = 0, kOffs, kErr, kOut, kA, kB, kS, kScratchSlots };
+    void *scratch[kScratchSlots] = {};
+    size_t scratch_cap[kScratchSlots] = {};
 };
+
+static void release_scratch(movi_index *ix);
 
 extern "C" {
 
@@ -456,6 +463,7 @@ int movi_index_destroy(movi_index_t *ix) {
     if (ix->d_tally) (void)hipFree(ix->d_tally);
     if (ix->d_ckpt) (void)hipFree(ix->d_ckpt);
     if (ix->d_stats) (void)hipFree(ix->d_stats);
+    release_scratch(ix);
     delete ix;
     return MOVI_OK;
 }
@@ -506,6 +514,11 @@ int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
     if (!strcmp(key, "refill_blocks")) {                     // test hook / tuning: persistent grid of the lane-refill kernel
         if (value < 0 || value > (1 << 20)) return fail(MOVI_ERR_ARG, "refill_blocks must be in [0, 2^20]");
         ix->cfg.refill_blocks = (int)value;
+        return MOVI_OK;
+    }
+    if (!strcmp(key, "release_scratch")) {                   // give back the device staging the *_host entry points keep
+        (void)hipSetDevice(ix->device);
+        release_scratch(ix);
         return MOVI_OK;
     }
     if (!strcmp(key, "waves_per_cu")) {
@@ -583,11 +596,32 @@ constexpr uint64_t kChunkBases = 1ull << 28;
 constexpr uint64_t kMinChunkReads = 1ull << 18;
 constexpr uint64_t kMaxChunkBases = 1ull << 31;
 
-struct DevBuf {
-    void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 8); }
-};
+// Slot `slot` of the handle's device staging, at least `bytes` large.
+hipError_t scratch(movi_index *ix, int slot, size_t bytes, void **out) {
+    if (bytes < 8) bytes = 8;
+    if (ix->scratch_cap[slot] < bytes) {
+        if (ix->scratch[slot]) (void)hipFree(ix->scratch[slot]);
+        ix->scratch[slot] = nullptr;
+        ix->scratch_cap[slot] = 0;
+        const size_t want = bytes + (bytes >> 3);
+        hipError_t e = hipMalloc(&ix->scratch[slot], want);
+        if (e != hipSuccess) return e;
+        ix->scratch_cap[slot] = want;
+    }
+    *out = ix->scratch[slot];
+    return hipSuccess;
+}
+}  // namespace
+
+static void release_scratch(movi_index *ix) {
+    for (int k = 0; k < movi_index::kScratchSlots; k++) {
+        if (ix->scratch[k]) (void)hipFree(ix->scratch[k]);
+        ix->scratch[k] = nullptr;
+        ix->scratch_cap[k] = 0;
+    }
+}
+
+namespace {
 
 // The offsets are the caller's: every *_host entry point validates them all before they size a chunk, an
 // allocation or a copy (and before the device is touched, so the check is testable without one).
@@ -613,10 +647,10 @@ int run_chunked(movi_index *ix, const uint8_t *h_bases, const uint64_t *h_offset
         }
         const uint64_t nr = last - first;
         const uint64_t b0 = h_offsets[first], nb = h_offsets[last] - b0;
-        DevBuf d_bases, d_offs, d_err;
-        HIP_TRY(d_bases.alloc(nb));
-        HIP_TRY(d_offs.alloc((nr + 1) * 8));
-        HIP_TRY(d_err.alloc(nr));
+        struct { void *p; } d_bases{}, d_offs{}, d_err{};
+        HIP_TRY(scratch(ix, movi_index::kBases, nb, &d_bases.p));
+        HIP_TRY(scratch(ix, movi_index::kOffs, (nr + 1) * 8, &d_offs.p));
+        HIP_TRY(scratch(ix, movi_index::kErr, nr, &d_err.p));
         std::vector<uint64_t> rel(nr + 1);
         for (uint64_t i = 0; i <= nr; i++) rel[i] = h_offsets[first + i] - b0;
         // No length sort here: on ragged batches handing the lanes out longest-first measured
@@ -660,15 +694,10 @@ static int ml_host(bool zml, movi_index_t *ix, const uint8_t *h_bases, const uin
         return fail(MOVI_ERR_ARG, "NULL host buffer");
     if (int rc0 = check_offsets(h_offsets, n_reads)) return rc0;
     HIP_TRY(hipSetDevice(ix->device));
-    DevBuf d_out;
-    uint64_t out_cap = 0;
+    struct { void *p; } d_out{};
     auto launch = [&](const uint8_t *db, const uint64_t *dof, uint64_t nr, uint64_t nb, uint8_t *derr,
                       const uint32_t *dord) -> int {
-        if (nb > out_cap) {
-            if (d_out.p) { (void)hipFree(d_out.p); d_out.p = nullptr; }
-            HIP_TRY(d_out.alloc(nb * 2));
-            out_cap = nb;
-        }
+        HIP_TRY(scratch(ix, movi_index::kOut, nb * 2, &d_out.p));
         return ml_device(zml, ix, db, dof, nr, nb, static_cast<uint16_t *>(d_out.p), derr, dord, nullptr);
     };
     auto fetch = [&](uint64_t, uint64_t, uint64_t b0, uint64_t nb) -> int {
@@ -735,17 +764,12 @@ int movi_pml_classify_host(movi_index_t *ix, const uint8_t *h_bases, const uint6
     if (int rc0 = check_offsets(h_offsets, n_reads)) return rc0;
     if (bin_width == 0) return fail(MOVI_ERR_ARG, "bin_width must be > 0");
     HIP_TRY(hipSetDevice(ix->device));
-    DevBuf d_a, d_b, d_s;
-    uint64_t cap = 0;
+    struct { void *p; } d_a{}, d_b{}, d_s{};
     auto launch = [&](const uint8_t *db, const uint64_t *dof, uint64_t nr, uint64_t nb, uint8_t *derr,
                       const uint32_t *dord) -> int {
-        if (nr > cap) {
-            for (DevBuf *x : {&d_a, &d_b, &d_s}) if (x->p) { (void)hipFree(x->p); x->p = nullptr; }
-            HIP_TRY(d_a.alloc(nr * 4));
-            HIP_TRY(d_b.alloc(nr * 4));
-            HIP_TRY(d_s.alloc(nr * 8));
-            cap = nr;
-        }
+        HIP_TRY(scratch(ix, movi_index::kA, nr * 4, &d_a.p));
+        HIP_TRY(scratch(ix, movi_index::kB, nr * 4, &d_b.p));
+        HIP_TRY(scratch(ix, movi_index::kS, nr * 8, &d_s.p));
         // bins reduced inside the PML kernel; no PML vector is written at all
         return movi_pml_classify_device(ix, db, dof, nr, nb, bin_width, max_value_thr, nullptr,
                                         static_cast<uint32_t *>(d_a.p), static_cast<uint32_t *>(d_b.p),
@@ -808,17 +832,11 @@ int movi_count_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_
         return fail(MOVI_ERR_ARG, "NULL host buffer");
     if (int rc0 = check_offsets(h_offsets, n_reads)) return rc0;
     HIP_TRY(hipSetDevice(ix->device));
-    DevBuf d_m, d_c;
-    uint64_t cap = 0;
+    struct { void *p; } d_m{}, d_c{};
     auto launch = [&](const uint8_t *db, const uint64_t *dof, uint64_t nr, uint64_t nb, uint8_t *derr,
                       const uint32_t *dord) -> int {
-        if (nr > cap) {
-            if (d_m.p) { (void)hipFree(d_m.p); d_m.p = nullptr; }
-            if (d_c.p) { (void)hipFree(d_c.p); d_c.p = nullptr; }
-            HIP_TRY(d_m.alloc(nr * 8));
-            HIP_TRY(d_c.alloc(nr * 8));
-            cap = nr;
-        }
+        HIP_TRY(scratch(ix, movi_index::kA, nr * 8, &d_m.p));
+        HIP_TRY(scratch(ix, movi_index::kS, nr * 8, &d_c.p));
         return movi_count_device(ix, db, dof, nr, nb, static_cast<uint64_t *>(d_m.p),
                                  static_cast<uint64_t *>(d_c.p), derr, dord, nullptr);
     };
