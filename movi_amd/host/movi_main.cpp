@@ -567,6 +567,7 @@ int main(int argc, char **argv) {
         if (o.command == "view") return view_bpf(o, std::cout);
         if (o.command == "plan") return run_plan(o);
         if (o.command == "null") return run_null(o);
+        if (o.command == "build") return run_build(o);
         return run_query(o);
     } catch (const UsageError &e) {
         std::cerr << "Error parsing command line options: " << e.what() << "\n" << usage();

@@ -27,7 +27,7 @@ const Spec kSpecs[] = {
     {"no-header", 0, false},     {"help", 'h', false},      {"gpus", 0, true},
     {"device", 0, true},         {"type", 0, true},         {"debug", 'd', false},
     {"logs", 0, false},          {"mmap", 0, false},        {"gen-reads", 0, false},
-    {"fasta", 'f', true},
+    {"fasta", 'f', true},          {"separators", 0, false},
     // recognised but unsupported query types / features
     {"zml", 0, false},           {"mem", 0, false},         {"rpml", 0, false},
     {"kmer", 0, false},          {"kmer-count", 0, false},  {"sa-entries", 0, false},
@@ -60,7 +60,9 @@ std::string usage() {
            "                      [--stdout] [--no-output] [-s N] [-t N] [-n] [--reverse] [--bin-width N]\n"
            "                      [--ignore-illegal-chars 1] [--gpus N] [--device D] [--verbose]\n"
            "       movi view --bpf FILE\n"
-           "       movi null -i DIR [--gen-reads -f REF.fasta] [--pml|--zml]\n";
+           "       movi null -i DIR [--gen-reads -f REF.fasta] [--pml|--zml]\n"
+           "       movi build -i DIR -f REF.fasta [--type regular-thresholds|blocked-thresholds|sampled-thresholds|regular|blocked|sampled]\n"
+           "                  [--separators]\n";
 }
 
 Options parse_args(int argc, char **argv) {
@@ -169,14 +171,22 @@ Options parse_args(int argc, char **argv) {
         if (has("zml")) { o.zml = true; o.pml = false; }
         if (has("pml")) { o.pml = true; o.zml = false; }
         if (has("device")) o.device = (int)to_int("device", val("device"));
+    } else if (o.command == "build") {
+        // src/movi_parser.cpp:441-470: one index directory and one reference
+        if (seen["index"].size() != 1) throw UsageError("Please specify the index directory file.");
+        if (seen["fasta"].size() != 1) throw UsageError("Please specify the reference fasta file.");
+        o.index_dir = val("index");
+        o.ref_file = val("fasta");
+        if (has("type")) o.index_type = val("type");
+        o.separators = has("separators");
     } else if (o.command == "view") {
         if (seen["bpf"].size() != 1) throw UsageError("Please specify one mls file.");
         o.bpf_file = val("bpf");
         o.small_bpf = has("small-bpf");
         o.large_bpf = has("large-bpf");
     } else {
-        throw UsageError("The '" + o.command + "' action is not part of the MI355X engine (query, view and null only); use "
-                         "the reference movi for build / inspect / color / ftab.");
+        throw UsageError("The '" + o.command + "' action is not part of the MI355X engine (query, view, null and build only); use "
+                         "the reference movi for inspect / color / ftab.");
     }
     return o;
 }

@@ -15,7 +15,9 @@ struct Options {
     std::string read_file;        // -r / --read ("-" = stdin)
     std::string out_file;         // -o / --out-file
     std::string bpf_file;         // view --bpf
-    std::string ref_file;         // null --gen-reads -f/--fasta
+    std::string ref_file;         // null --gen-reads -f/--fasta; build -f/--fasta
+    std::string index_type = "regular-thresholds";   // build --type (DEFAULT_INDEX_TYPE, src/movi_launcher.cpp:17)
+    bool separators = false;      // build --separators
     bool gen_reads = false;       // null --gen-reads
     bool pml = true;              // default query type (movi_options.hpp:243)
     bool count = false;
@@ -51,5 +53,6 @@ struct UsageError : std::runtime_error {
 // Throws UsageError with the reference's message texts where they exist.
 Options parse_args(int argc, char **argv);
 std::string usage();
+int run_build(const Options &o);  // build_cmd.cpp
 
 }  // namespace movi_host

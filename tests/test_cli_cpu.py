@@ -187,3 +187,33 @@ def test_view_prints_read_order(movi_bin, tmp_path):
     bad = tmp_path / "bad.bpf"
     bad.write_bytes(b"\x00" * 12)
     assert run(["view", "--bpf", str(bad)]).returncode == 1
+
+
+@pytest.mark.parametrize("type_name,mode,separators,size", [
+    ("regular-thresholds", 6, False, 948119), ("blocked-thresholds", 8, False, 711733), ("sampled-thresholds", 7, False, 475326),
+    ("regular", 3, False, 871479), ("blocked", 2, False, 654253), ("sampled", 5, False, 437006),
+    ("regular-thresholds", 6, True, 948232), ("blocked", 2, True, 654280)])
+def test_movi_build_reproduces_reference_index_sizes(movi_bin, tmp_path, type_name, mode, separators, size):
+    """`movi build -i DIR -f ref.fasta --type T [--separators]`: the in-memory constructor behind the host CLI reproduces the
+    reference's index-size known answers (tests/test_build.cpp:33-95) and the numpy constructor byte for byte."""
+    from conftest import GOLDEN
+    from oracle import build_index as B
+    d = tmp_path / "ix"
+    r = run(["build", "-i", str(d), "-f", os.path.join(GOLDEN, "ref.fasta"), "--type", type_name] + (["--separators"] if separators else []))
+    assert r.returncode == 0, r.stderr
+    img = (d / "index.movi").read_bytes()
+    assert len(img) == size
+    ref = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))[0][1]
+    assert img == B.build_index_from_seqs([ref], mode, separators=separators)
+
+
+def test_movi_build_argument_errors(movi_bin, tmp_path):
+    from conftest import GOLDEN
+    r = run(["build", "-f", os.path.join(GOLDEN, "ref.fasta")])
+    assert r.returncode == 1 and b"Please specify the index directory file." in r.stderr
+    r = run(["build", "-i", str(tmp_path / "x")])
+    assert r.returncode == 1 and b"Please specify the reference fasta file." in r.stderr
+    r = run(["build", "-i", str(tmp_path / "x"), "-f", os.path.join(GOLDEN, "ref.fasta"), "--type", "constant"])
+    assert r.returncode == 1 and b"not supported" in r.stderr
+    r = run(["build", "-i", str(tmp_path / "x"), "-f", str(tmp_path / "missing.fa")])
+    assert r.returncode == 1 and b"cannot open" in r.stderr

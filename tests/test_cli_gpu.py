@@ -374,3 +374,14 @@ def test_cli_regular_and_blocked_indexes(movi_bin, tmp_path, mode, name):
     assert os.path.exists(str(reads) + "." + name + ".zml.bpf")
     r = run(["query", "--index", str(d), "--read", str(reads), "--pml"])
     assert r.returncode == 1 and b"thresholds" in r.stderr
+
+
+def test_movi_build_then_query_reproduces_golden(movi_bin, tmp_path):
+    """End to end inside this CLI: `movi build` from the reference's ref.fasta, then `movi query --pml --stdout` on its
+    sample.fastq reproduces the reference's golden PML file (tests/test_pml.cpp:89-105)."""
+    d = tmp_path / "built"
+    assert run(["build", "-i", str(d), "-f", os.path.join(GOLDEN, "ref.fasta")]).returncode == 0
+    r = run(["query", "--index", str(d), "--read", os.path.join(GOLDEN, "sample.fastq"), "--pml", "--no-prefetch", "--stdout"])
+    assert r.returncode == 0, r.stderr
+    got = b"".join(sorted(r.stdout.splitlines(keepends=True)))          # LC_ALL=C sort
+    assert got == open(os.path.join(GOLDEN, "sample.fastq.pmls.sorted"), "rb").read()

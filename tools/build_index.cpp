@@ -437,14 +437,14 @@ static std::vector<uint8_t> build_index(std::vector<uint8_t> &text, int mode) {
     return o;
 }
 
-static void write_file(const std::string &path, const std::vector<uint8_t> &data) {
+[[maybe_unused]] static void write_file(const std::string &path, const std::vector<uint8_t> &data) {
     std::ofstream f(path, std::ios::binary);
     f.write(reinterpret_cast<const char *>(data.data()), (std::streamsize)data.size());
     if (!f.good()) { fprintf(stderr, "cannot write %s\n", path.c_str()); exit(1); }
 }
 
 // Fixed-length substrings of the text with substitutions (rate sub_rate) and 0.1 % 'N'.
-static void draw_reads(const std::vector<uint8_t> &text, std::vector<uint8_t> &reads, uint64_t n_reads, uint64_t read_len,
+[[maybe_unused]] static void draw_reads(const std::vector<uint8_t> &text, std::vector<uint8_t> &reads, uint64_t n_reads, uint64_t read_len,
                        double sub_rate, uint64_t sr) {
     for (uint64_t i = 0; i < n_reads; i++) {
         const uint64_t pos = splitmix64(sr) % (text.size() - read_len);
@@ -457,6 +457,42 @@ static void draw_reads(const std::vector<uint8_t> &text, std::vector<uint8_t> &r
     }
 }
 
+// FASTA -> the indexed text (prepare_ref: every record forward + reverse complement, cleaned; with `separators` a '%'
+// after every sequence).  Returns false when the file cannot be read.
+static bool text_from_fasta(const std::string &path, bool separators, std::vector<uint8_t> &text) {
+    std::ifstream in(path);
+    if (!in.good()) return false;
+    std::string line, seq;
+    bool have = false;
+    while (std::getline(in, line)) {
+        while (!line.empty() && (line.back() == '\r' || line.back() == '\n' || line.back() == ' ')) line.pop_back();
+        if (!line.empty() && line[0] == '>') {
+            if (have) append_clean(text, seq, separators);
+            seq.clear();
+            have = true;
+        } else if (have) seq += line;
+    }
+    if (have) append_clean(text, seq, separators);
+    return true;
+}
+
+// `movi build` of the host CLI (movi_amd/host/build_cmd.cpp includes this file with MOVI_BUILD_INDEX_NO_MAIN):
+// FASTA file -> OUT_DIR/index.movi of the given type.  Returns a message on failure, "" on success.
+std::string movi_build_index_from_fasta(const std::string &fasta, int mode, const std::string &out_dir, bool separators) {
+    std::vector<uint8_t> text;
+    if (!text_from_fasta(fasta, separators, text)) return "cannot open " + fasta;
+    if (text.empty()) return "no sequence in " + fasta;
+    if ((uint64_t)text.size() + 1 >= (1ull << 31)) return "text too long for the in-memory constructor (2^31 characters, reverse complements included)";
+    mkdir(out_dir.c_str(), 0777);
+    const std::vector<uint8_t> img = build_index(text, mode);
+    std::ofstream f(out_dir + "/index.movi", std::ios::binary);
+    f.write(reinterpret_cast<const char *>(img.data()), (std::streamsize)img.size());
+    f.close();
+    if (!f.good()) return "cannot write " + out_dir + "/index.movi";
+    return "";
+}
+
+#ifndef MOVI_BUILD_INDEX_NO_MAIN
 int main(int argc, char **argv) {
     if (argc < 2) { fprintf(stderr, "usage: see the header of tools/build_index.cpp\n"); return 1; }
     const std::string cmd = argv[1];
@@ -466,22 +502,10 @@ int main(int argc, char **argv) {
     uint64_t n_reads = 0, read_len = 0, seed = 1;
     double sub_rate = 0;
     if (cmd == "fasta" && argc >= 5) {
-        std::ifstream in(argv[2]);
-        if (!in.good()) { fprintf(stderr, "cannot open %s\n", argv[2]); return 1; }
         mode = atoi(argv[3]);
         out_dir = argv[4];
         const bool separators = argc >= 6 && std::string(argv[5]) == "separators";   // movi build --separators
-        std::string line, seq;
-        bool have = false;
-        while (std::getline(in, line)) {
-            while (!line.empty() && (line.back() == '\r' || line.back() == '\n' || line.back() == ' ')) line.pop_back();
-            if (!line.empty() && line[0] == '>') {
-                if (have) append_clean(text, seq, separators);
-                seq.clear();
-                have = true;
-            } else if (have) seq += line;
-        }
-        if (have) append_clean(text, seq, separators);
+        if (!text_from_fasta(argv[2], separators, text)) { fprintf(stderr, "cannot open %s\n", argv[2]); return 1; }
     } else if (cmd == "pangenome" && argc >= 8) {
         const uint64_t anc_len = strtoull(argv[2], nullptr, 10), n_genomes = strtoull(argv[3], nullptr, 10);
         const double snp = atof(argv[4]);
@@ -545,3 +569,4 @@ int main(int argc, char **argv) {
     write_file(out_dir + "/index.movi", img);
     return 0;
 }
+#endif  // MOVI_BUILD_INDEX_NO_MAIN
