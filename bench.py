@@ -308,7 +308,7 @@ def main():
 
     # which PML kernel launch_pml picked (movi_kernels.hip: state machine for <= 12 waves/CU of reads, mode 6 / 8)
     n_cus = torch.cuda.get_device_properties(dev).multi_processor_count
-    v_sel = args.variant if args.variant >= 0 else 10     # launch_pml: variant 10, capped at 9 waves per CU on big batches
+    v_sel = args.variant if args.variant >= 0 else 14     # launch_pml: the window-parallel lane state machine, capped at 9 waves per CU on big batches
     if args.classify and v_sel == 0:
         v_sel = 1
     if args.classify and v_sel == 7:
@@ -318,7 +318,8 @@ def main():
         v_sel = 10
     kmode = 6                                        # one resident row layout (movi_abi.hip: finish_create)
     pml_kernel_name = {0: "pml_kernel<%d,0>" % kmode, 1: "pml_kernel<%d,1>" % kmode, 7: "pml_kernel_flat<%d>" % kmode,
-                       10: "pml_kernel_flatp<%d,refill=0>" % kmode, 13: "pml_kernel_flatp<%d,refill=1>" % kmode}[v_sel]
+                       10: "pml_kernel_flatp<%d,refill=0>" % kmode, 13: "pml_kernel_flatp<%d,refill=1>" % kmode,
+                       14: "pml_kernel_flatp<%d,window-parallel>" % kmode}[v_sel]
     f_bar = st.fast_forwards / max(n_bases, 1)
     s_bar = st.scans / max(n_bases, 1)
     bytes_per_base = row_bytes * (1.0 + f_bar + s_bar) + 1 + 2
@@ -454,7 +455,7 @@ def main():
             dt3 = time.perf_counter() - t0
             result["long_reads"] = {"workload": "c3", "description": w3["desc"], "value": n3 * L3 * k3 / dt3 / 1e9,
                                     "unit": "Gbases/s", "steps": k3, "ms_per_step": dt3 / k3 * 1e3, "reads_per_gpu": n3,
-                                    "read_len": L3, "kernel": "pml_kernel_flatp<%d>" % mode,
+                                    "read_len": L3, "kernel": "pml_kernel_flatp<%d,window-parallel>" % mode,
                                     "fast_forwards_per_base": round(st3.fast_forwards / (n3 * L3), 4),
                                     "scans_per_base": round(st3.scans / (n3 * L3), 4), "errors": int(st3.errors)}
         except Exception as e:                            # noqa: BLE001 -- never lose the headline line to the extra

@@ -220,7 +220,8 @@ int movi_count_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_
 /* Kernel variant / launch knobs, for A/B measurement (bench.py --variant).
  * Unknown keys return MOVI_ERR_ARG.  Keys: "pml_variant" (-1 = auto by batch size, 0 = first
  * kernel, 1 = base-synchronous packed I/O, 7 = flat lane state machine, 10 = 7 + row window,
- * software-pipelined, 13 = 10 as a persistent grid whose lanes take a new read when they finish one),
+ * software-pipelined, 13 = 10 as a persistent grid whose lanes take a new read when they finish one, 14 = 10 with all
+ * in-window fast-forward / scan steps resolved at once: what auto selects),
  * "refill_blocks" (variant 13: wavefronts in the persistent grid, 0 = CUs x waves per CU),
  * "block_threads" (0 = auto, 64, 128, 192 or 256: the kernels' launch bound), "waves_per_cu"
  * (0 = uncapped; variant 13: 0 = its default of 9), "idx64" (1 = run the kernel instantiations for

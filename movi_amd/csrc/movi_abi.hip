@@ -489,8 +489,8 @@ int movi_index_device_rows(const movi_index_t *ix, const void **d_rows, size_t *
 int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
     if (!ix || !key) return fail(MOVI_ERR_ARG, "NULL argument");
     if (!strcmp(key, "pml_variant")) {
-        if (value != -1 && value != 0 && value != 1 && value != 7 && value != 10 && value != 13)
-            return fail(MOVI_ERR_ARG, "pml_variant must be -1 (auto), 0, 1, 7, 10 or 13");
+        if (value != -1 && value != 0 && value != 1 && value != 7 && value != 10 && value != 13 && value != 14)
+            return fail(MOVI_ERR_ARG, "pml_variant must be -1 (auto), 0, 1, 7, 10, 13 or 14");
         ix->cfg.pml_variant = (int)value;
         return MOVI_OK;
     }

@@ -877,8 +877,46 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
             scan_total += dnh | uph;
             need = need + (IdxT)(ffh + dnh) - (IdxT)uph;
         };
+        // HA < 0 ("window-parallel", variant 14): everything the hops could do inside this window, in closed form instead
+        // of one dependent select-compare-update round per hop.  A fast-forward passes row i iff off >= the running sum of
+        // the lengths up to and including i (monotone, so the number of rows passed is a sum of four compares); a scan
+        // passes the leading run of non-matching rows from its position (a 4-bit mask and a count-trailing / leading-ones).
+        // Same state afterwards as four hop() calls -- identical answers and counts -- at a third of the dependency depth.
+        auto window_advance = [&]() {
+            const uint32_t q0 = (uint32_t)(need - wbase);
+            const uint32_t inwin = (uint32_t)(q0 < 4u) & (uint32_t)(st < sDone);
+            const uint32_t n0 = row_n<MODE>(w[0]), n1 = row_n<MODE>(w[1]), n2 = row_n<MODE>(w[2]), n3 = row_n<MODE>(w[3]);
+            const uint32_t last_win = (uint32_t)(wbase + 3 == r1);         // the table ends inside (at the end of) this window
+            const uint32_t first_win = (uint32_t)(wbase == 0);
+            // ---- fast-forward: rows q0 .. 3 (need < r1 can only fail at index 3 of the last window)
+            const uint32_t m0 = q0 == 0u, m1 = q0 <= 1u, m2 = q0 <= 2u;   // row i takes part (i >= q0); row 3 always does
+            const uint32_t t1 = m0 ? n0 : 0u, t2 = t1 + (m1 ? n1 : 0u), t3 = t2 + (m2 ? n2 : 0u), t4 = t3 + n3;
+            const uint32_t isff = inwin & (uint32_t)(st == sFF);
+            const uint32_t p0 = isff & m0 & (uint32_t)(off >= t1), p1 = isff & m1 & (uint32_t)(off >= t2),
+                           p2 = isff & m2 & (uint32_t)(off >= t3), p3 = isff & (uint32_t)(off >= t4) & (last_win ^ 1u);
+            const uint32_t cf = p0 + p1 + p2 + p3;
+            off -= (p3 ? t4 : (p2 ? t3 : (p1 ? t2 : (p0 ? t1 : 0u))));
+            ff_run += cf;
+            // ---- scans: bit i of nm = row i does not hold the base
+            const uint32_t nm = (uint32_t)(row_c<MODE>(w[0]) != a) | ((uint32_t)(row_c<MODE>(w[1]) != a) << 1) |
+                                ((uint32_t)(row_c<MODE>(w[2]) != a) << 2) | ((uint32_t)(row_c<MODE>(w[3]) != a) << 3);
+            // down: leading run of 1s from bit q0 upwards; row r-1 is never passed (need < r1)
+            const uint32_t dmask = (nm & (last_win ? 7u : 15u)) >> (q0 & 3u);
+            const uint32_t cd = (inwin & (uint32_t)(st == sDown)) ? (uint32_t)__builtin_ctz(~dmask | 16u) : 0u;
+            // up: leading run of 1s from bit q0 downwards; row 0 is never passed (need != 0)
+            const uint32_t umask = ((nm & (first_win ? 14u : 15u)) << (3u - (q0 & 3u))) & 15u;
+            const uint32_t cu = (inwin & (uint32_t)(st == sUp)) ? (uint32_t)__builtin_clz(((~umask) & 15u) << 28 | 0x08000000u) : 0u;
+            scan_total += cd + cu;
+            need = need + (IdxT)(cf + cd) - (IdxT)cu;
+        };
+        if (HA >= 0) {
 #pragma unroll
-        for (int h = 0; h < HA; ++h) hop();
+            for (int h = 0; h < (HA >= 0 ? HA : 0); ++h) hop();
+        } else if (wave_any(st == sFF && ff_run >= 65520u)) {
+            for (int h = 0; h < 4; ++h) hop();                       // near the reference's fast-forward limit: step by step
+        } else {
+            window_advance();
+        }
         const uint32_t qn = (uint32_t)(need - wbase);
         const uint32_t inwin = (uint32_t)(qn < 4u) & (uint32_t)act;
         const uint2 row = win_sel(w, qn);
@@ -1052,7 +1090,8 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     // (expand_blocked_kernel / expand_sampled_kernel), so the query kernels exist for MODE 6 only.
     if (mode != 6) return hipErrorInvalidValue;
     // Variants: 0 first correct kernel, 1 base-synchronous packed I/O, 7 flat lane state machine,
-    // 10 = 7 + row window + software pipelining, 13 = 10 as a persistent grid with lane refill.  (2-6, 8, 9, 11, 12 were
+    // 10 = 7 + row window + software pipelining, 13 = 10 as a persistent grid with lane refill, 14 = 10 with every in-window
+    // fast-forward / scan step resolved in closed form (window_advance; the default).  (2-6, 8, 9, 11, 12 were
     // experiments -- branchy state machine, 2/4-row neighbour windows, the unpipelined window kernel, other hop counts --
     // measured slower and removed; numbers in DESIGN.md section 3.)
     // Auto selection (measured on MI355X, profiles/r02_*): variant 10 in blocks of ONE wavefront, and -- when there are
@@ -1069,7 +1108,11 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     // not the default.
     int v = cfg.pml_variant;
     const bool big_batch = n_reads > (uint64_t)cfg.num_cus * 64u * 12u;
-    if (v < 0) v = 10;
+    if (v < 0) v = 14;
+    // variant 14 = variant 10 with the window-parallel advance instead of two sequential hops: +2.5 % on long reads,
+    // +5.5 % on the 8 GB table, neutral on the fabric-bound big batches (profiles/r02_window_parallel.txt) -> the default
+    const bool wp = v == 14;
+    if (wp) v = 10;
     const int wpc_refill = cfg.waves_per_cu > 0 ? cfg.waves_per_cu : kCapWaves;
     uint64_t refill_blocks = cfg.refill_blocks > 0 ? (uint64_t)cfg.refill_blocks
                                                    : (uint64_t)cfg.num_cus * (uint64_t)wpc_refill;   // in wavefronts (blocks of 64)
@@ -1081,7 +1124,7 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     uint64_t blocks = (n_reads + bt - 1) / bt;
     int wpc = cfg.waves_per_cu;
     if (wpc < 0) wpc = 0;
-    if (cfg.waves_per_cu == 0 && cfg.pml_variant < 0 && v == 10 && big_batch) wpc = kCapWaves;   // the auto policy above
+    if (cfg.waves_per_cu == 0 && (cfg.pml_variant < 0 || cfg.pml_variant == 14) && v == 10 && big_batch) wpc = kCapWaves;   // the auto policy above
     if (v == 13) {
         wpc = wpc_refill;
         const uint64_t resident = (refill_blocks * 64u + bt - 1) / bt;
@@ -1120,10 +1163,14 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
 #ifndef MOVI_HA
 #define MOVI_HA 2
 #endif
+#define MOVI_LAUNCH_FLATP_H(M, H, C, S, R)                                                                  \
+    do {                                                                                                    \
+        if (ix.idx32) MOVI_LAUNCH_K(pml_kernel_flatp<M, uint32_t, H, C, S, R>);                             \
+        else MOVI_LAUNCH_K(pml_kernel_flatp<M, uint64_t, H, C, S, R>);                                      \
+    } while (0)
 #define MOVI_LAUNCH_FLATP_R(M, C, S, R)                                                                     \
     do {                                                                                                    \
-        if (ix.idx32) MOVI_LAUNCH_K(pml_kernel_flatp<M, uint32_t, MOVI_HA, C, S, R>);                             \
-        else MOVI_LAUNCH_K(pml_kernel_flatp<M, uint64_t, MOVI_HA, C, S, R>);                                      \
+        if (wp) MOVI_LAUNCH_FLATP_H(M, -1, C, S, R); else MOVI_LAUNCH_FLATP_H(M, MOVI_HA, C, S, R);         \
     } while (0)
 #define MOVI_LAUNCH_FLATP_S(M, C, S)                                                                        \
     do {                                                                                                    \
@@ -1150,6 +1197,7 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
 #undef MOVI_LAUNCH_FLATP
 #undef MOVI_LAUNCH_FLATP_S
 #undef MOVI_LAUNCH_FLATP_R
+#undef MOVI_LAUNCH_FLATP_H
 #undef MOVI_BY_CLS
     return hipGetLastError();
 }

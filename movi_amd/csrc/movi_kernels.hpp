@@ -58,7 +58,8 @@ constexpr int kCapWaves = 9;   // resident wavefronts per CU of the lane state m
 struct LaunchCfg {
     int block_threads = 0;   // 0 = auto: 64 for the PML kernels (finest dispatch grain), 256 for count / ZML
     // -1 auto; 0 first kernel (plain I/O), 1 base-synchronous packed I/O, 7 flat lane state machine,
-    // 10 flat lane state machine + row window, software-pipelined, 13 = 10 as a persistent grid with lane refill
+    // 10 flat lane state machine + row window, software-pipelined, 13 = 10 as a persistent grid with lane refill,
+    // 14 = 10 with the window-parallel advance (what auto picks)
     int pml_variant = -1;
     int zml_variant = -1;  // -1 auto; 0 base-synchronous kernel, 1 lane state machine
     int num_cus = 256;

@@ -85,7 +85,7 @@ def test_pml_ragged_reads_vs_oracle(engines, mode):
 
 
 @pytest.mark.parametrize("mode", [6, 8])
-@pytest.mark.parametrize("variant", [0, 1, 7, 10, 13])
+@pytest.mark.parametrize("variant", [0, 1, 7, 10, 13, 14])
 def test_pml_kernel_variants_vs_oracle(engines, mode, variant):
     """Every selectable kernel variant is held to the same bit-exact bar, including
     reads whose length is not a multiple of the 8-step packing and unaligned offsets."""
@@ -290,7 +290,7 @@ def test_launch_options_are_bounded(engines):
             gpu.set_option("block_threads", bt)
             for wpc in (1, 2, 4):                             # 159 KiB / 79 KiB / 39 KiB of dynamic LDS per block of 64
                 gpu.set_option("waves_per_cu", wpc)
-                for variant in (1, 7, 10):
+                for variant in (1, 7, 10, 14):
                     gpu.set_option("pml_variant", variant)
                     out, st = gpu.query_pml_packed(bases, offs)
                     assert (out == exp).all() and st.errors == 0, (bt, wpc, variant)
@@ -453,7 +453,7 @@ def test_classification_bins_on_device(engines, bin_width, thr):
 
 
 @pytest.mark.parametrize("mode", [6, 8])
-@pytest.mark.parametrize("variant", [1, 10, 13])
+@pytest.mark.parametrize("variant", [1, 10, 13, 14])
 def test_fused_classification_kernels(engines, mode, variant):
     """movi_pml_classify_device: the bins fused into the PML walk, with and without the PML vector, in both
     shipped kernels, against the bins of the oracle's PML vectors and against the standalone
@@ -550,7 +550,7 @@ def test_fuzz_small_indexes(built_lib, tmp_path, alphabet):
             subprocess.check_call([tool, "fasta", str(fa), str(mode), out_dir], stderr=subprocess.DEVNULL)
             img = open(os.path.join(out_dir, "index.movi"), "rb").read()
             gpu, cpu = movi_amd.MoveIndex.from_image(img), Oracle(img)
-            for variant in (1, 7, 10):
+            for variant in (1, 7, 10, 14):
                 gpu.set_option("pml_variant", variant)
                 out, st = gpu.query_pml_packed(bases, offs)
                 exp, ff, sc = cpu.pml_batch(bases, offs, threads=2)
@@ -584,7 +584,7 @@ def test_real_bwt_pangenome_vs_oracle(built_lib, tmp_path, mode):
     bases = np.fromfile(os.path.join(out, "reads.bin"), np.uint8)
     offs = (np.arange(20001, dtype=np.uint64) * np.uint64(150))
     exp, ff, sc = cpu.pml_batch(bases, offs, threads=8)
-    for variant in (1, 7, 10):
+    for variant in (1, 7, 10, 14):
         gpu.set_option("pml_variant", variant)
         got, st = gpu.query_pml_packed(bases, offs)
         assert (got == exp).all() and (st.fast_forwards, st.scans, st.errors) == (ff, sc, 0)
@@ -618,7 +618,7 @@ def test_separators_reference_index_vs_oracle(built_lib, mode):
     reads += [s for _, s in read_fastx(os.path.join(GOLDEN, "sample.fastq"))]
     bases, offs = pack(reads)
     exp, ff, sc = cpu.pml_batch(bases, offs, threads=4)
-    for variant in (0, 1, 7, 10):
+    for variant in (0, 1, 7, 10, 14):
         gpu.set_option("pml_variant", variant)
         out, st = gpu.query_pml_packed(bases, offs)
         assert (out == exp).all(), variant
@@ -647,7 +647,7 @@ def test_separators_fuzz_many_sequences(built_lib, seed):
         img = B.serialize(B.build_rows(bwt, thr, mode))
         gpu, cpu = movi_amd.MoveIndex.from_image(img), Oracle(img)
         exp, ff, sc = cpu.pml_batch(bases, offs, threads=2)
-        for variant in (0, 1, 7, 10):
+        for variant in (0, 1, 7, 10, 14):
             gpu.set_option("pml_variant", variant)
             out, st = gpu.query_pml_packed(bases, offs)
             assert (out == exp).all(), (seed, mode, variant)
@@ -746,7 +746,7 @@ def test_64bit_index_instantiations(built_lib, golden_image, mode):
     bases, offs = pack(reads)
     exp, ff, sc = cpu.pml_batch(bases, offs, threads=4)
     gpu.set_option("idx64", 1)
-    for variant in ((7, 10) if mode != 7 else (-1,)):
+    for variant in ((7, 10, 14) if mode != 7 else (-1,)):
         gpu.set_option("pml_variant", variant)
         out, st = gpu.query_pml_packed(bases, offs)
         assert (out == exp).all(), (mode, variant)
