@@ -368,7 +368,7 @@ def main():
                    "reads_gen_s": round(t_reads_gen, 2)},
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": pml_kernel_name if args.query == "pml" else {"count": "count_kernel_v0", "zml": "zml_kernel"}[args.query],
+                     "kernel": pml_kernel_name if args.query == "pml" else {"count": "count_kernel_v0", "zml": ("zml_kernel" if (args.zml_variant == 0 or (args.zml_variant < 0 and wl["rows"] > (3 << 30) // 8)) else "zml_kernel_flat")}[args.query],
                      "kernel_ms_avg": avg_kern_s * 1e3,
                      "gathers_per_s": ((1.0 + f_bar + s_bar) * n_bases if args.query == "pml"
                                        else (2.0 * (1.0 + f_bar) + s_bar) * work_bases) / avg_kern_s},

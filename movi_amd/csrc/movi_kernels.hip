@@ -1529,9 +1529,9 @@ __global__ __launch_bounds__(256) void zml_kernel(DevIndex ix, const uint8_t *__
     }
 }
 
-// ZML as a LANE STATE MACHINE ("zml_kernel_flat", selectable with the "zml_variant" option; NOT the default: see
-// launch_zml for the numbers): the base-synchronous kernel above costs a wave, per base, max-over-lanes(shrink trips)
-// + 1 + max-over-lanes(fast-forward trips) dependent round trips.  Here every lane runs the per-base micro-steps
+// ZML as a LANE STATE MACHINE ("zml_kernel_flat", "zml_variant" 1; the default for tables up to 3 GB: see launch_zml
+// for the numbers): the base-synchronous kernel above costs a wave, per base, max-over-lanes(shrink trips) + 1 +
+// max-over-lanes(fast-forward trips) dependent round trips.  Here every lane runs the per-base micro-steps
 //   M0 start base k: phrase open and base legal -> which ends must scan (update_interval)      else FAIL
 //   M1 scans done:   interval still non-empty   -> the two LF jumps; both ends fast-forward      else FAIL
 //   M2 jumps done:   interval still non-empty   -> ml += 1, emit, next base (M0 in the same iteration)   else FAIL
@@ -1610,53 +1610,83 @@ __global__ __launch_bounds__(256) void zml_kernel_flat(DevIndex ix, const uint8_
         const bool act = ph != phDone;
         lane_steps += (uint32_t)act;
         wave_steps += 1;
-        // ---- 1. walk each end as far as its window reaches (start end first: shrink_interval's order)
-#pragma unroll
-        for (int h = 0; h < 4; ++h) {
+        // ---- 1. walk each end as far as its window reaches (start end first: shrink_interval's order), in closed form as
+        // pml_kernel_flatp's window_advance: a fast-forward passes row i iff the offset covers the running sum of the
+        // lengths up to i; a scan passes the leading run of rows that are not its target (a 4-bit mask + count zeros).
+        {
+            const uint32_t cb0 = row_c<MODE>(ws[0]) == b, cb1 = row_c<MODE>(ws[1]) == b, cb2 = row_c<MODE>(ws[2]) == b,
+                           cb3 = row_c<MODE>(ws[3]) == b;
+            const uint32_t eq = (uint32_t)(end_row - wbs);                 // window index of the '$' row: never a target
+            const uint32_t hitm = (cb0 | (cb1 << 1) | (cb2 << 2) | (cb3 << 3)) & ~(eq < 4u ? (1u << eq) : 0u);
             if (ps == pScan) {                               // update_interval: start moves down to the next row of b
                 if (rs >= hi) { dead = 1; ps = pNone; pe = pNone; }
                 else {
-                    const uint32_t q = (uint32_t)((IdxT)(rs + 1) - wbs);
-                    if (q < 4u) {
-                        const uint2 w = win_sel(ws, q);
-                        rs += 1;
+                    const uint32_t qf = (uint32_t)((IdxT)(rs + 1) - wbs);  // first candidate; candidates are qf .. min(3, hi - wbs)
+                    if (qf < 4u) {
+                        const uint32_t last = (uint32_t)(hi - wbs) < 3u ? (uint32_t)(hi - wbs) : 3u;
+                        const uint32_t cand = (hitm >> qf) << qf & ((2u << last) - 1u);
+                        const uint32_t h = cand ? (uint32_t)__builtin_ctz(cand) : last;
+                        scan_total += h - qf + 1;
+                        rs = wbs + (IdxT)h;
                         os = 0;
-                        scan_total += 1;
-                        if (rs != end_row && row_c<MODE>(w) == b) { rws = w; ps = pNone; }
+                        if (cand) { rws = win_sel(ws, h); ps = pNone; }
                         else if (rs >= hi) { dead = 1; ps = pNone; pe = pNone; }
                     }
                 }
             } else if (ps == pFF) {                          // fast_forward of the start walker (also: first row of a phrase)
-                const uint32_t q = (uint32_t)(rs - wbs);
-                if (q < 4u) {
-                    const uint2 w = win_sel(ws, q);
-                    const uint32_t n = row_n<MODE>(w);
-                    if (rs < r1 && os >= n && ffs < 65535u) { os -= n; rs += 1; ffs += 1; }
-                    else { rws = w; ps = pNone; }
+                const uint32_t q0 = (uint32_t)(rs - wbs);
+                if (q0 < 4u) {
+                    const uint32_t n0 = row_n<MODE>(ws[0]), n1 = row_n<MODE>(ws[1]), n2 = row_n<MODE>(ws[2]), n3 = row_n<MODE>(ws[3]);
+                    const uint32_t m0 = q0 == 0u, m1 = q0 <= 1u, m2 = q0 <= 2u;
+                    const uint32_t t1 = m0 ? n0 : 0u, t2 = t1 + (m1 ? n1 : 0u), t3 = t2 + (m2 ? n2 : 0u), t4 = t3 + n3;
+                    const uint32_t lastw = (uint32_t)(wbs + 3 == r1);
+                    uint32_t cnt = (m0 & (uint32_t)(os >= t1)) + (m1 & (uint32_t)(os >= t2)) + (m2 & (uint32_t)(os >= t3)) +
+                                   ((uint32_t)(os >= t4) & (lastw ^ 1u));
+                    const uint32_t room = 65535u - (ffs < 65535u ? ffs : 65535u);
+                    cnt = cnt < room ? cnt : room;
+                    const uint32_t q = q0 + cnt;             // where the walker stands now
+                    os -= (q == 0u ? 0u : (q == 1u ? t1 : (q == 2u ? t2 : (q == 3u ? t3 : t4))));
+                    ffs += cnt;
+                    rs += (IdxT)cnt;
+                    if (q < 4u) { rws = win_sel(ws, q); ps = pNone; }
                 }
             }
         }
-#pragma unroll
-        for (int h = 0; h < 4; ++h) {
+        {
+            const uint32_t cb0 = row_c<MODE>(we[0]) == b, cb1 = row_c<MODE>(we[1]) == b, cb2 = row_c<MODE>(we[2]) == b,
+                           cb3 = row_c<MODE>(we[3]) == b;
+            const uint32_t eq = (uint32_t)(end_row - wbe);
+            const uint32_t hitm = (cb0 | (cb1 << 1) | (cb2 << 2) | (cb3 << 3)) & ~(eq < 4u ? (1u << eq) : 0u);
             if (pe == pScan) {                               // the end moves up to the previous row of b
                 if (re <= lo) { dead = 1; ps = pNone; pe = pNone; }
                 else {
-                    const uint32_t q = (uint32_t)((IdxT)(re - 1) - wbe);
-                    if (q < 4u) {
-                        const uint2 w = win_sel(we, q);
-                        re -= 1;
-                        scan_total += 1;
-                        if (re != end_row && row_c<MODE>(w) == b) { rwe = w; oe = row_n<MODE>(w) - 1; pe = pNone; }
+                    const uint32_t qf = (uint32_t)((IdxT)(re - 1) - wbe);  // first candidate; candidates are qf down to max(0, lo - wbe)
+                    if (qf < 4u) {
+                        const uint32_t first = lo > wbe ? (uint32_t)(lo - wbe) : 0u;
+                        const uint32_t cand = (hitm & ((2u << qf) - 1u)) >> first << first;
+                        const uint32_t h = cand ? 31u - (uint32_t)__builtin_clz(cand) : first;
+                        scan_total += qf - h + 1;
+                        re = wbe + (IdxT)h;
+                        if (cand) { rwe = win_sel(we, h); oe = row_n<MODE>(rwe) - 1; pe = pNone; }
                         else if (re <= lo) { dead = 1; ps = pNone; pe = pNone; }
                     }
                 }
             } else if (pe == pFF) {
-                const uint32_t q = (uint32_t)(re - wbe);
-                if (q < 4u) {
-                    const uint2 w = win_sel(we, q);
-                    const uint32_t n = row_n<MODE>(w);
-                    if (re < r1 && oe >= n && ffe < 65535u) { oe -= n; re += 1; ffe += 1; }
-                    else { rwe = w; pe = pNone; }
+                const uint32_t q0 = (uint32_t)(re - wbe);
+                if (q0 < 4u) {
+                    const uint32_t n0 = row_n<MODE>(we[0]), n1 = row_n<MODE>(we[1]), n2 = row_n<MODE>(we[2]), n3 = row_n<MODE>(we[3]);
+                    const uint32_t m0 = q0 == 0u, m1 = q0 <= 1u, m2 = q0 <= 2u;
+                    const uint32_t t1 = m0 ? n0 : 0u, t2 = t1 + (m1 ? n1 : 0u), t3 = t2 + (m2 ? n2 : 0u), t4 = t3 + n3;
+                    const uint32_t lastw = (uint32_t)(wbe + 3 == r1);
+                    uint32_t cnt = (m0 & (uint32_t)(oe >= t1)) + (m1 & (uint32_t)(oe >= t2)) + (m2 & (uint32_t)(oe >= t3)) +
+                                   ((uint32_t)(oe >= t4) & (lastw ^ 1u));
+                    const uint32_t room = 65535u - (ffe < 65535u ? ffe : 65535u);
+                    cnt = cnt < room ? cnt : room;
+                    const uint32_t q = q0 + cnt;
+                    oe -= (q == 0u ? 0u : (q == 1u ? t1 : (q == 2u ? t2 : (q == 3u ? t3 : t4))));
+                    ffe += cnt;
+                    re += (IdxT)cnt;
+                    if (q < 4u) { rwe = win_sel(we, q); pe = pNone; }
                 }
             }
         }
@@ -1779,14 +1809,15 @@ hipError_t launch_zml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
                       uint64_t n_reads, uint64_t n_bases, uint16_t *d_out, uint8_t *d_err, DevStats *d_stats,
                       const uint32_t *d_order, const LaunchCfg &cfg, hipStream_t stream) {
     if (n_reads == 0) return hipSuccess;
-    // 0 = base-synchronous kernel (default), 1 = lane state machine.  Measured (profiles/r02_zml_state_machine.txt),
-    // Gbases/s, kernel 0 / 1: 100 k x 10 kbp 12.1 / 12.4 (pangenome), 12.2 / 11.2 (random table); 1 M x 150 bp 36.5 /
-    // 32.6 and 33.9 / 32.1 -- unlike PML the state machine buys nothing here: a ZML base touches ~5 rows in two
-    // dependent stages (interval shrink, then the two jumps), so it needs 2.2 iterations per base with ~500
-    // instructions each (two 4-row windows, eight in-window hops), and on divergent reads every ~12th base opens a new
-    // phrase (one more iteration for the rows of its interval's ends).  Kept selectable ("zml_variant") and tested.
+    // 0 = base-synchronous kernel, 1 = lane state machine.  Measured (profiles/r02_zml_state_machine.txt), Gbases/s,
+    // kernel 0 / 1: 100 k x 10 kbp 12.1 / 19.1 (pangenome), 12.2 / 18.2 (random 10 M rows); 1 M x 150 bp 36.8 / 39.2 and
+    // 34.1 / 36.8; random tables of 120 M rows 24.6 / 28.3, 250 M (2 GB) 23.4 / 26.6, 500 M (4 GB) 21.3 / 16.6, 1 B (8 GB)
+    // 17.0 / 13.8.  The state machine fetches two 4-row windows (four 16-byte loads, i.e. ~8 TLB lookups) per iteration:
+    // beyond the ~1.7 GB reach of a CU's TLB that costs more than the base-synchronous kernel's dependent trips, so auto
+    // picks it for tables up to 3 GB.  (Its first form walked the windows with eight sequential hops and was no faster
+    // than kernel 0 anywhere: 12.4 on the long reads, 32.6 on the short ones; the closed-form window walk made it.)
     int v = cfg.zml_variant;
-    if (v < 0) v = 0;
+    if (v < 0) v = ix.r <= (3ull << 30) / 8 ? 1 : 0;
     if (v == 1 && (ix.r < 8 || n_bases < 16)) v = 0;     // the clamped windows need >= 4 rows, the 16-base fetches 16 bytes
     const int bt = cfg.block_threads > 0 ? cfg.block_threads : (v == 1 ? 64 : 256);
     const uint64_t blocks = (n_reads + bt - 1) / bt;
