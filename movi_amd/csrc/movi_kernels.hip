@@ -1107,7 +1107,10 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     // (variant 10 capped: 47.7), 43.5 on the random table; on log-normal read lengths 36.5 against 35.8.  Selectable,
     // not the default.
     int v = cfg.pml_variant;
-    const bool big_batch = n_reads > (uint64_t)cfg.num_cus * 64u * 12u;
+    // (batches of up to ~18 waves per CU run in ONE round, uncapped: with the cap, 224 k reads = 13.7 waves per CU run as
+    // a full round of 9 and a half-empty one -- 38.3 against 39.2 Gbases/s; 300 k reads: 38.2 against 41.2; from 400 k
+    // reads on the cap wins: 43.9 against 41.7.  profiles/r02_occupancy_cap_sweeps.txt)
+    const bool big_batch = n_reads > (uint64_t)cfg.num_cus * 64u * 18u;
     if (v < 0) v = 14;
     // variant 14 = variant 10 with the window-parallel advance instead of two sequential hops: +2.5 % on long reads,
     // +5.5 % on the 8 GB table, neutral on the fabric-bound big batches (profiles/r02_window_parallel.txt) -> the default
