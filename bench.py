@@ -306,7 +306,7 @@ def main():
     else:
         total_bases_per_step = float(n_bases)
 
-    # which PML kernel launch_pml picked (movi_kernels.hip: state machine for <= 12 waves/CU of reads, mode 6 / 8)
+    # which PML kernel launch_pml picked (movi_kernels.hip: the lane state machine everywhere)
     n_cus = torch.cuda.get_device_properties(dev).multi_processor_count
     v_sel = args.variant if args.variant >= 0 else 14     # launch_pml: the window-parallel lane state machine, capped at 9 waves per CU on big batches
     if args.classify and v_sel == 0:

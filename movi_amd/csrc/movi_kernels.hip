@@ -708,7 +708,7 @@ __device__ __forceinline__ uint2 win_sel(const uint2 (&w)[4], uint32_t q) {
     return (q & 2u) ? hi : lo;
 }
 
-// VARIANT 10 ("flat state machine + row window, software-pipelined"; default when <= 12 waves/CU of reads):
+// VARIANT 10 ("flat state machine + row window, software-pipelined"; with HA < 0 = variant 14, the default everywhere):
 // variant 7 with
 //   * the 4-row WINDOW around the row it needs fetched instead of the row (32 B / 24 B of the same cache line,
 //     the same single L2 request) and up to HA cheap fast-forward / scan hops taken inside it before the full
@@ -1095,7 +1095,7 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     // experiments -- branchy state machine, 2/4-row neighbour windows, the unpipelined window kernel, other hop counts --
     // measured slower and removed; numbers in DESIGN.md section 3.)
     // Auto selection (measured on MI355X, profiles/r02_*): variant 10 in blocks of ONE wavefront, and -- when there are
-    // more reads than ~12 waves per CU -- at most kCapWaves wavefronts resident per CU.  Why a cap: between two
+    // more reads than ~18 waves per CU -- at most kCapWaves wavefronts resident per CU.  Why a cap: between two
     // iterations of a lane its cache lines (the row window's neighbours, its read, its output) must survive in the
     // 4 MiB L2 of its XCD; with all 32 wave slots of a CU walking, 8 MiB of lines are in flight per XCD and neighbour
     // rows are refetched from the fabric.  1 M x 150 bp, Gbases/s, variant 10 uncapped / capped at 8-10 waves per CU /
