@@ -217,3 +217,24 @@ def test_movi_build_argument_errors(movi_bin, tmp_path):
     assert r.returncode == 1 and b"not supported" in r.stderr
     r = run(["build", "-i", str(tmp_path / "x"), "-f", str(tmp_path / "missing.fa")])
     assert r.returncode == 1 and b"cannot open" in r.stderr
+
+
+@pytest.mark.parametrize("content,message", [
+    (b">ab\nACGT\n>b\nAC\n", b"header line is missing an id"),                 # a 2-character header (batch_loader.cpp:108-110)
+    (b"ACGT\n", b"unrecognized input query file type"),
+    (b">\nACGT\n", b"header line is missing an id"),
+    (b"@q1\nACGT\n+\nIIII\nq2x\nAC\n+\nII\n", b"Incorrect FASTQ entry"),
+    (b">r1\nACGT\n>r2\nAC\n" * 3 + b"@r3\nAC\n", None)])                     # '@' line inside FASTA = sequence text, as in the reference
+def test_malformed_inputs_fail_the_same_way_on_both_parser_paths(movi_bin, tmp_path, content, message):
+    path = tmp_path / "bad.fx"
+    path.write_bytes(content)
+    a = run(["plan", "-r", str(path), "-n"])
+    b = run(["plan", "-r", str(path), "-n"], env=dict(os.environ, MOVI_NO_MMAP="1"))
+    assert (a.returncode, a.stdout, a.stderr) == (b.returncode, b.stdout, b.stderr)
+    if message is None:
+        assert a.returncode == 0
+    else:
+        assert a.returncode == 1 and message in a.stderr
+    empty = tmp_path / "empty.fa"
+    empty.write_bytes(b"")
+    assert run(["plan", "-r", str(empty)]).returncode == 0
