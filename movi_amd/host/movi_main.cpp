@@ -367,6 +367,30 @@ int run_query(const Options &o) {
         std::vector<BpfWriter::Record> bpf;                           // the chunk's records, in emission order
         const bool to_bpf = o.ml() && o.write_output_allowed() && !o.write_stdout_enabled();
         if (to_bpf) bpf.reserve(n);
+        if (o.ml() && !o.classify && o.write_output_allowed() && o.write_stdout_enabled() && rs.bases.size() >= (1u << 22)) {
+            // plain `--stdout`: the text of a chunk is formatted by worker threads (ranges balanced by bases), written in order
+            const unsigned T = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+            std::vector<std::string> txt(T);
+            std::vector<size_t> cut(T + 1, n);
+            cut[0] = 0;
+            uint64_t acc = 0;
+            unsigned t = 1;
+            for (size_t k = 0; k < n && t < T; k++) {
+                acc += rs.len(order[k]);
+                while (t < T && acc >= rs.bases.size() * (uint64_t)t / T) cut[t++] = k + 1;
+            }
+            std::vector<std::thread> th;
+            for (unsigned u = 0; u < T; u++)
+                th.emplace_back([&, u] {
+                    for (size_t k = cut[u]; k < cut[u + 1]; k++) {
+                        const uint32_t i = order[k];
+                        append_stdout_pmls(txt[u], rs.ids[i], job.pml.data() + rs.offsets[i], rs.len(i));
+                    }
+                });
+            for (auto &x : th) x.join();
+            for (unsigned u = 0; u < T; u++) std::cout.write(txt[u].data(), (std::streamsize)txt[u].size());
+            return;
+        }
         for (uint32_t i : order) {
             const uint64_t len = rs.len(i);
             if (o.ml()) {

@@ -44,6 +44,7 @@ private:
 
 // `>id\n` + values in read order, each followed by a space, + `\n`
 void write_stdout_pmls(std::ostream &out, const std::string &id, const uint16_t *pml, uint64_t n);
+void append_stdout_pmls(std::string &txt, const std::string &id, const uint16_t *pml, uint64_t n);   // the same text, appended
 void write_count_line(std::ostream &out, const std::string &id, uint64_t query_length, uint64_t matched, uint64_t count);
 
 class Classifier {

@@ -189,6 +189,32 @@ def test_view_prints_read_order(movi_bin, tmp_path):
     assert run(["view", "--bpf", str(bad)]).returncode == 1
 
 
+@pytest.mark.parametrize("entry_bits", [16, 32, 64])
+def test_view_large_file_parallel_path(movi_bin, tmp_path, entry_bits):
+    """A BPF file big enough for `view`'s worker threads (several batches of 32 M values would be too slow to check in
+    Python: 3 M values here, which still crosses the 1 M-value threshold of the parallel path), ragged record sizes, an
+    empty record, a name with an embedded NUL, every entry size of the reference (16 / 32 / 64 bits); and a truncated
+    copy, which must fall back to the record-by-record reader and print the complete records."""
+    rng = np.random.default_rng(entry_bits)
+    dt = {16: "<u2", 32: "<u4", 64: "<u8"}[entry_bits]
+    blob = [struct.pack("<IBBBBHxx", 0x42504600, 1, 0, 0, entry_bits, 0)]
+    exp = []
+    for i in range(1500):
+        n = int(rng.integers(0, 4000)) if i != 7 else 0
+        vals = rng.integers(0, 70000 if entry_bits > 16 else 65536, n).astype(dt)
+        rid = b"r%d " % i if i != 11 else b"nul\x00tail"
+        blob.append(struct.pack("<H", len(rid)) + rid + struct.pack("<Q", n) + vals.tobytes())
+        exp.append(b">" + rid.split(b"\x00")[0] + b"\n" + b"".join(b"%d " % v for v in vals[::-1].tolist()) + b"\n")
+    f = tmp_path / "big.bpf"
+    f.write_bytes(b"".join(blob))
+    r = run(["view", "--bpf", str(f)])
+    assert r.returncode == 0 and r.stdout == b"".join(exp)
+    cut = tmp_path / "cut.bpf"
+    cut.write_bytes(b"".join(blob)[:-5])
+    r2 = run(["view", "--bpf", str(cut)])
+    assert r2.returncode == 0 and r2.stdout.startswith(b"".join(exp[:-1]))
+
+
 @pytest.mark.parametrize("type_name,mode,separators,size", [
     ("regular-thresholds", 6, False, 948119), ("blocked-thresholds", 8, False, 711733), ("sampled-thresholds", 7, False, 475326),
     ("regular", 3, False, 871479), ("blocked", 2, False, 654253), ("sampled", 5, False, 437006),

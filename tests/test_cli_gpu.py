@@ -385,3 +385,33 @@ def test_movi_build_then_query_reproduces_golden(movi_bin, tmp_path):
     assert r.returncode == 0, r.stderr
     got = b"".join(sorted(r.stdout.splitlines(keepends=True)))          # LC_ALL=C sort
     assert got == open(os.path.join(GOLDEN, "sample.fastq.pmls.sorted"), "rb").read()
+
+
+def test_stdout_and_view_on_a_multi_chunk_file(movi_bin, tmp_path):
+    """40 k x 150 bp reads (6 Mbases: past the 4 Mbase threshold of the threaded `--stdout` formatter) with mixed-length
+    stragglers: `query --stdout` (prefetch order and file order), `query` + `view` of the BPF file and the oracle agree."""
+    from oracle import build_index as B
+    from oracle.oracle import Oracle
+    ref = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))[0][1]
+    rng = np.random.default_rng(8)
+    lines, reads = [], []
+    for i in range(40000):
+        L = 150 if i % 50 else int(rng.integers(1, 600))
+        st = int(rng.integers(0, len(ref) - L))
+        r = bytearray(ref[st:st + L])
+        for k in rng.integers(0, L, max(1, L // 70)):
+            r[k] = b"ACGTN"[rng.integers(0, 5)]
+        reads.append(bytes(r))
+        lines += [b">q%d" % i, bytes(r)]
+    path = tmp_path / "many.fa"
+    path.write_bytes(b"\n".join(lines) + b"\n")
+    cpu = Oracle(open(os.path.join(IDX[6], "index.movi"), "rb").read())
+    exp = {b"q%d" % i: stdout_line(cpu.pml(r)).encode() for i, r in enumerate(reads)}
+    file_order = b"".join(b">q%d\n" % i + exp[b"q%d" % i] + b"\n" for i in range(len(reads)))
+    a = run(["query", "-i", IDX[6], "-r", str(path), "-n", "--stdout"])
+    assert a.returncode == 0 and a.stdout == file_order
+    b = run(["query", "-i", IDX[6], "-r", str(path), "--stdout"])                 # strand-scheduler order: a permutation
+    assert b.returncode == 0 and sorted(b.stdout.split(b">")) == sorted(file_order.split(b">"))
+    assert run(["query", "-i", IDX[6], "-r", str(path), "-n", "-o", str(tmp_path / "o")]).returncode == 0
+    v = run(["view", "--bpf", str(tmp_path / "o.pml.bpf")])
+    assert v.returncode == 0 and v.stdout == file_order
