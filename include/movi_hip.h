@@ -162,7 +162,11 @@ int movi_pml_device(movi_index_t *ix, const uint8_t *d_bases, const uint64_t *d_
                     const uint32_t *d_read_order, void *stream);
 
 /* Same, host buffers in and out; uploads, runs, downloads, synchronises.
- * stats may be NULL. */
+ * stats may be NULL.  With h_bases and h_out_pml in PAGE-LOCKED memory (movi_host_alloc /
+ * movi_host_register below) the call is overlapped: the reads are cut into chunks, up to four of
+ * them in flight on their own streams, so that the upload of one, the walks of the next and the
+ * download of the last run at the same time (results are identical; DESIGN.md has the rates).  Pageable
+ * buffers take the synchronous path. */
 int movi_pml_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_offsets,
                   uint64_t n_reads, uint16_t *h_out_pml, uint8_t *h_read_err,
                   movi_query_stats_t *stats);
@@ -215,6 +219,20 @@ int movi_count_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_
                     uint64_t n_reads, uint64_t *h_matched, uint64_t *h_count, uint8_t *h_read_err,
                     movi_query_stats_t *stats);
 
+/* ---- page-locked host memory --------------------------------------------------- */
+
+/* The reference keeps reads and results in std::string / std::vector of its MoveQuery objects
+ * (include/move_query.hpp:14-60); a caller that wants the *_host entry points to overlap their
+ * transfers with the walk keeps them in page-locked memory instead: either allocated here
+ * (hipHostMalloc) or its own buffers registered once (hipHostRegister) and reused across calls.
+ * The *_host entry points detect it per call (movi_pml_host / movi_zml_host: h_bases and the
+ * result vector; movi_count_host / movi_pml_classify_host: h_bases -- their per-read results are
+ * small and may stay pageable). */
+int movi_host_alloc(size_t bytes, void **out);
+int movi_host_free(void *p);
+int movi_host_register(void *p, size_t bytes);
+int movi_host_unregister(void *p);
+
 /* ---- tuning ------------------------------------------------------------------- */
 
 /* Kernel variant / launch knobs, for A/B measurement (bench.py --variant).
@@ -226,7 +244,8 @@ int movi_count_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_
  * "block_threads" (0 = auto, 64, 128, 192 or 256: the kernels' launch bound), "waves_per_cu"
  * (0 = uncapped; variant 13: 0 = its default of 9), "idx64" (1 = run the kernel instantiations for
  * tables of 2^32 rows and more, whatever the size: a test hook), "release_scratch" (any value: frees the
- * device staging buffers that the *_host entry points keep, grow-only, across calls). */
+ * device staging buffers that the *_host entry points keep, grow-only, across calls), "pipe_chunk_bases"
+ * (bases per chunk of the overlapped host path, 0 = its own policy: a test hook). */
 int movi_set_option(movi_index_t *ix, const char *key, int64_t value);
 
 /* ---- ZML (Ziv-Merhav cross parse) ---------------------------------------------- */

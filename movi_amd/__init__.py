@@ -7,6 +7,6 @@ binding used by the tests and by bench.py -- it contains no compute and no CPU
 fallback: without the built library every entry point raises.
 """
 from ._lib import MoviError, lib, lib_path  # noqa: F401
-from .engine import MoveIndex, IndexDesc, parse_index_image  # noqa: F401
+from .engine import MoveIndex, IndexDesc, parse_index_image, pinned_empty  # noqa: F401
 
-__all__ = ["MoviError", "MoveIndex", "IndexDesc", "parse_index_image", "lib", "lib_path"]
+__all__ = ["MoviError", "MoveIndex", "IndexDesc", "parse_index_image", "pinned_empty", "lib", "lib_path"]

@@ -86,6 +86,10 @@ SYMBOLS = {
     "movi_pml_classify_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(QueryStatsC)]),
     "movi_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
+    "movi_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "movi_host_free": (C.c_int, [C.c_void_p]),
+    "movi_host_register": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "movi_host_unregister": (C.c_int, [C.c_void_p]),
 }
 
 

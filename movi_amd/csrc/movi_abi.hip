@@ -96,6 +96,23 @@ struct movi_index {
     enum { kBases = 0, kOffs, kErr, kOut, kA, kB, kS, kScratchSlots };
     void *scratch[kScratchSlots] = {};
     size_t scratch_cap[kScratchSlots] = {};
+    // the overlapped form of the *_host entry points (page-locked caller buffers, movi_host_alloc): kPipeSlots chunks in
+    // flight, each on its own stream with its own device staging, counters and a small page-locked block for what
+    // travels with a chunk (relative offsets up; error bytes, per-read results and counters down)
+    struct PipeSlot {
+        hipStream_t s = nullptr;
+        hipEvent_t ev = nullptr;                 // the slot's walk has finished
+        hipEvent_t ev_up = nullptr;              // the slot's chunk has arrived
+        void *d[kScratchSlots] = {};
+        size_t cap[kScratchSlots] = {};
+        DevStats *d_stats = nullptr;
+        uint8_t *h = nullptr;
+        size_t h_cap = 0;
+    };
+    enum { kPipeSlots = 6, kPipeAhead = 3 };   // slots; chunks going up or being walked while one comes down
+    PipeSlot pipe[kPipeSlots];
+    hipStream_t pipe_up = nullptr;   // every chunk's upload, in order (uploads on separate streams share the link and all arrive late)
+    uint64_t pipe_chunk_bases = 0;   // test hook ("pipe_chunk_bases"): chunk size of the overlapped path, 0 = its policy
 };
 
 static void release_scratch(movi_index *ix);
@@ -521,6 +538,11 @@ int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
         release_scratch(ix);
         return MOVI_OK;
     }
+    if (!strcmp(key, "pipe_chunk_bases")) {                  // test hook: many small chunks through the overlapped host path
+        if (value < 0) return fail(MOVI_ERR_ARG, "pipe_chunk_bases must be >= 0");
+        ix->pipe_chunk_bases = (uint64_t)value;
+        return MOVI_OK;
+    }
     if (!strcmp(key, "waves_per_cu")) {
         if (value < 0 || value > 32) return fail(MOVI_ERR_ARG, "waves_per_cu must be in [0,32]");
         ix->cfg.waves_per_cu = (int)value;
@@ -533,8 +555,9 @@ int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
 
 static int ml_device(bool zml, movi_index_t *ix, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
                      uint64_t n_bases, uint16_t *d_out, uint8_t *d_read_err, const uint32_t *d_read_order, void *stream,
-                     const ClsArgs &cls = ClsArgs()) {
+                     const ClsArgs &cls = ClsArgs(), DevStats *d_stats = nullptr) {
     if (!ix) return fail(MOVI_ERR_ARG, "index handle is NULL");
+    if (!d_stats) d_stats = ix->d_stats;                     // (the pipelined host path counts per chunk in flight)
     if (!zml && !mode_has_thresholds(ix->desc.mode))
         return fail(MOVI_ERR_ARG, "PML needs thresholds: on a `regular`, `blocked` or `sampled` index the reference repositions "
                                   "randomly (reposition_randomly), which cannot be reproduced; use --zml or --count, or a "
@@ -544,13 +567,13 @@ static int ml_device(bool zml, movi_index_t *ix, const uint8_t *d_bases, const u
     if (!d_offsets || (n_bases && (!d_bases || (!d_out && !bins_only)))) return fail(MOVI_ERR_ARG, "NULL device buffer");
     HIP_TRY(hipSetDevice(ix->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    HIP_TRY(hipMemsetAsync(ix->d_stats, 0, sizeof(DevStats), s));
+    HIP_TRY(hipMemsetAsync(d_stats, 0, sizeof(DevStats), s));
     if (n_reads > 0xFFFFFFFFull) return fail(MOVI_ERR_ARG, "more than 2^32 reads in one call");
     if (zml)
-        HIP_TRY(launch_zml(ix->kmode, ix->dev, d_bases, d_offsets, n_reads, n_bases, d_out, d_read_err, ix->d_stats,
+        HIP_TRY(launch_zml(ix->kmode, ix->dev, d_bases, d_offsets, n_reads, n_bases, d_out, d_read_err, d_stats,
                            d_read_order, ix->cfg, s));
     else
-        HIP_TRY(launch_pml(ix->kmode, ix->dev, d_bases, d_offsets, n_reads, n_bases, d_out, d_read_err, ix->d_stats,
+        HIP_TRY(launch_pml(ix->kmode, ix->dev, d_bases, d_offsets, n_reads, n_bases, d_out, d_read_err, d_stats,
                            d_read_order, ix->cfg, s, cls));
     return MOVI_OK;
 }
@@ -595,22 +618,69 @@ namespace {
 constexpr uint64_t kChunkBases = 1ull << 28;
 constexpr uint64_t kMinChunkReads = 1ull << 18;
 constexpr uint64_t kMaxChunkBases = 1ull << 31;
+// The overlapped path (page-locked caller buffers) wants several chunks per call -- chunk i+1 goes up and chunk i-1 comes
+// down while chunk i is walked, and the kernels of neighbouring chunks share the GPU -- so it cuts finer: about an
+// eighth of the call, between 2^22 and 2^28 bases, and at least 2^15 reads (a download can only start when a walk
+// has finished, so chunks must be short; the lanes in flight are those of the kPipeAhead chunks being walked, and a
+// read takes as long as it takes however few lanes walk beside it -- long reads are best cut into just those
+// kPipeAhead chunks: 100 k x 10 kbp as 3 x 33 k reads 57 ms, as 8 x 12.5 k reads 85 ms, synchronous 74 ms).
+constexpr uint64_t kPipeMinBases = 1ull << 22;
+constexpr uint64_t kPipeMinReads = 1ull << 15;
+constexpr uint64_t kPipeTargetChunks = 8;
 
-// Slot `slot` of the handle's device staging, at least `bytes` large.
-hipError_t scratch(movi_index *ix, int slot, size_t bytes, void **out) {
+hipError_t grow(void **p, size_t *cap, size_t bytes) {
     if (bytes < 8) bytes = 8;
-    if (ix->scratch_cap[slot] < bytes) {
-        if (ix->scratch[slot]) (void)hipFree(ix->scratch[slot]);
-        ix->scratch[slot] = nullptr;
-        ix->scratch_cap[slot] = 0;
+    if (*cap < bytes) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+        *cap = 0;
         const size_t want = bytes + (bytes >> 3);
-        hipError_t e = hipMalloc(&ix->scratch[slot], want);
+        hipError_t e = hipMalloc(p, want);
         if (e != hipSuccess) return e;
-        ix->scratch_cap[slot] = want;
+        *cap = want;
     }
-    *out = ix->scratch[slot];
     return hipSuccess;
 }
+
+// Where one chunk of a *_host call lives: the stream it runs on, its counters, its device staging (the handle's in the
+// synchronous path, a pipeline slot's in the overlapped one) and, overlapped only, page-locked room for per-read results.
+struct ChunkCtx {
+    movi_index *ix = nullptr;
+    hipStream_t s = nullptr;
+    DevStats *d_stats = nullptr;
+    void **d = nullptr;
+    size_t *cap = nullptr;
+    uint8_t *h_small = nullptr;
+    bool async = false;
+    hipError_t alloc(int slot, size_t bytes, void **out) {
+        hipError_t e = grow(&d[slot], &cap[slot], bytes);
+        *out = d[slot];
+        return e;
+    }
+    // device -> host: straight into the caller's buffer (synchronous path, or a page-locked destination) ...
+    hipError_t down(void *h_dst, const void *d_src, size_t bytes) {
+        if (!bytes) return hipSuccess;
+        return async ? hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, s)
+                     : hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost);
+    }
+    // ... or, overlapped path with a destination that may be pageable (a copy into pageable memory would hold the host
+    // until the kernel is done): into the slot's page-locked block at `small_off`; harvest() moves it on
+    hipError_t down_small(void *h_dst, size_t small_off, const void *d_src, size_t bytes) {
+        return down(async ? static_cast<void *>(h_small + small_off) : h_dst, d_src, bytes);
+    }
+};
+
+// Page-locked (hipHostMalloc / hipHostRegister) host memory?  Pageable pointers are unknown to the runtime.
+bool is_pinned(const void *p) {
+    if (!p) return false;
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return at.type == hipMemoryTypeHost;
+}
+
 }  // namespace
 
 static void release_scratch(movi_index *ix) {
@@ -619,6 +689,30 @@ static void release_scratch(movi_index *ix) {
         ix->scratch[k] = nullptr;
         ix->scratch_cap[k] = 0;
     }
+    if (ix->pipe_up) {
+        (void)hipStreamSynchronize(ix->pipe_up);
+        (void)hipStreamDestroy(ix->pipe_up);
+        ix->pipe_up = nullptr;
+    }
+    for (auto &sl : ix->pipe) {
+        if (sl.s) (void)hipStreamSynchronize(sl.s);
+        for (int k = 0; k < movi_index::kScratchSlots; k++) {
+            if (sl.d[k]) (void)hipFree(sl.d[k]);
+            sl.d[k] = nullptr;
+            sl.cap[k] = 0;
+        }
+        if (sl.d_stats) (void)hipFree(sl.d_stats);
+        sl.d_stats = nullptr;
+        if (sl.h) (void)hipHostFree(sl.h);
+        sl.h = nullptr;
+        sl.h_cap = 0;
+        if (sl.ev) (void)hipEventDestroy(sl.ev);
+        sl.ev = nullptr;
+        if (sl.ev_up) (void)hipEventDestroy(sl.ev_up);
+        sl.ev_up = nullptr;
+        if (sl.s) (void)hipStreamDestroy(sl.s);
+        sl.s = nullptr;
+    }
 }
 
 namespace {
@@ -626,6 +720,11 @@ namespace {
 // The offsets are the caller's: every *_host entry point validates them all before they size a chunk, an
 // allocation or a copy (and before the device is touched, so the check is testable without one).
 int check_offsets(const uint64_t *h_offsets, uint64_t n_reads) {
+    // one branch-free pass (a decreasing pair wraps to >= 2^63, an overlong read is >= 2^32: either way high bits);
+    // the slow pass below only runs to name the first offender
+    uint64_t bad = 0;
+    for (uint64_t i = 0; i < n_reads; i++) bad |= (h_offsets[i + 1] - h_offsets[i]) >> 32;
+    if (!bad) return MOVI_OK;
     for (uint64_t i = 0; i < n_reads; i++) {
         if (h_offsets[i + 1] < h_offsets[i]) return fail(MOVI_ERR_ARG, "read offsets are not non-decreasing");
         if (h_offsets[i + 1] - h_offsets[i] > 0xFFFFFFFFull) return fail(MOVI_ERR_ARG, "a read is longer than 2^32 - 1 bases");
@@ -633,10 +732,31 @@ int check_offsets(const uint64_t *h_offsets, uint64_t n_reads) {
     return MOVI_OK;
 }
 
-template <typename Launch, typename Fetch>
+void add_stats(movi_query_stats_t *acc, uint64_t nb, const DevStats &h) {
+    acc->bases += nb;
+    acc->fast_forwards += h.fast_forwards;
+    acc->scans += h.scans;
+    acc->repositions += h.repositions;
+    acc->errors += h.errors;
+    acc->lane_steps += h.lane_steps;
+    acc->wave_steps += h.wave_steps;
+}
+
+// One kind of query behind a *_host entry point:
+//   launch(ctx, d_bases, d_offs, nr, nb, d_err)  allocates the chunk's result staging from ctx and enqueues the kernel;
+//   fetch(ctx, first, nr, b0, nb)                enqueues the results' way back (ctx.down / ctx.down_small);
+//   harvest(h_small, first, nr)                  overlapped path only, after the chunk's stream has drained: per-read
+//                                                results from the page-locked block to the caller's arrays;
+//   small_bytes                                  page-locked bytes per read that fetch / harvest use.
+template <typename Launch, typename Fetch, typename Harvest>
 int run_chunked(movi_index *ix, const uint8_t *h_bases, const uint64_t *h_offsets, uint64_t n_reads,
-                uint8_t *h_read_err, movi_query_stats_t *stats, Launch launch, Fetch fetch) {
+                uint8_t *h_read_err, movi_query_stats_t *stats, Launch launch, Fetch fetch, Harvest, size_t) {
     if (stats) memset(stats, 0, sizeof(*stats));
+    ChunkCtx ctx;
+    ctx.ix = ix;
+    ctx.d_stats = ix->d_stats;
+    ctx.d = ix->scratch;
+    ctx.cap = ix->scratch_cap;
     uint64_t first = 0;
     while (first < n_reads) {
         uint64_t last = first + 1;
@@ -648,24 +768,23 @@ int run_chunked(movi_index *ix, const uint8_t *h_bases, const uint64_t *h_offset
         const uint64_t nr = last - first;
         const uint64_t b0 = h_offsets[first], nb = h_offsets[last] - b0;
         struct { void *p; } d_bases{}, d_offs{}, d_err{};
-        HIP_TRY(scratch(ix, movi_index::kBases, nb, &d_bases.p));
-        HIP_TRY(scratch(ix, movi_index::kOffs, (nr + 1) * 8, &d_offs.p));
-        HIP_TRY(scratch(ix, movi_index::kErr, nr, &d_err.p));
+        HIP_TRY(ctx.alloc(movi_index::kBases, nb, &d_bases.p));
+        HIP_TRY(ctx.alloc(movi_index::kOffs, (nr + 1) * 8, &d_offs.p));
+        HIP_TRY(ctx.alloc(movi_index::kErr, nr, &d_err.p));
         std::vector<uint64_t> rel(nr + 1);
         for (uint64_t i = 0; i <= nr; i++) rel[i] = h_offsets[first + i] - b0;
         // No length sort here: on ragged batches handing the lanes out longest-first measured
         // slightly SLOWER (31.1 vs 32.8 Gbases/s, log-normal lengths) -- the walk is bound by the
         // memory system, not by lane occupancy, and the dispatcher already refills whole blocks.
-        const uint32_t *order_ptr = nullptr;
         if (nb) HIP_TRY(hipMemcpy(d_bases.p, h_bases + b0, nb, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(d_offs.p, rel.data(), (nr + 1) * 8, hipMemcpyHostToDevice));
-        int rc = launch(static_cast<const uint8_t *>(d_bases.p), static_cast<const uint64_t *>(d_offs.p), nr, nb,
-                        static_cast<uint8_t *>(d_err.p), order_ptr);
+        int rc = launch(ctx, static_cast<const uint8_t *>(d_bases.p), static_cast<const uint64_t *>(d_offs.p), nr, nb,
+                        static_cast<uint8_t *>(d_err.p));
         if (rc) return rc;
         movi_query_stats_t st{};
         rc = movi_last_stats(ix, nullptr, &st);
         if (rc) return rc;
-        rc = fetch(first, nr, b0, nb);
+        rc = fetch(ctx, first, nr, b0, nb);
         if (rc) return rc;
         if (h_read_err) HIP_TRY(hipMemcpy(h_read_err + first, d_err.p, nr, hipMemcpyDeviceToHost));
         if (stats) {
@@ -682,9 +801,204 @@ int run_chunked(movi_index *ix, const uint8_t *h_bases, const uint64_t *h_offset
     return MOVI_OK;
 }
 
+// The same call with the caller's bases (and, for PML / ZML, result vector) in page-locked memory: kPipeSlots chunks in
+// flight, each on its own stream -- upload, walk, download -- so that the three overlap across chunks: the call then
+// costs about what its slowest leg does (2 B per base coming down: ~28 Gbases/s on a 56 GB/s link) instead of the
+// sum of the three.
+// A chunk's download is enqueued only once its walk HAS finished (the host waits on an event), never behind it as a
+// dependent copy: a copy that waits for a kernel sits in its SDMA ring as a poll packet and holds up every copy queued
+// after it -- the next chunk's upload included.  Enqueued that way (the first version) the timeline was strictly serial,
+// chunk after chunk (rocprofv3 --memory-copy-trace), and the call no faster than the synchronous one.
+template <typename Launch, typename Fetch, typename Harvest>
+int run_pipelined(movi_index *ix, const uint8_t *h_bases, const uint64_t *h_offsets, uint64_t n_reads,
+                  uint8_t *h_read_err, movi_query_stats_t *stats, Launch launch, Fetch fetch, Harvest harvest,
+                  size_t small_bytes) {
+    if (stats) memset(stats, 0, sizeof(*stats));
+    movi_query_stats_t acc{};
+    const uint64_t total = h_offsets[n_reads] - h_offsets[0];
+    uint64_t target = total / kPipeTargetChunks;
+    target = target < kPipeMinBases ? kPipeMinBases : (target > kChunkBases ? kChunkBases : target);
+    uint64_t min_reads = kPipeMinReads;
+    if (ix->pipe_chunk_bases) { target = ix->pipe_chunk_bases; min_reads = 1; }
+    struct Chunk { uint64_t first, nr, b0, nb; };
+    std::vector<Chunk> chunks;
+    for (uint64_t first = 0; first < n_reads;) {
+        // the longest run of reads from `first` with at most `target` bases (the offsets are non-decreasing: checked) --
+        // at least one read, at least min_reads of them if that stays below kMaxChunkBases
+        const uint64_t *lo = h_offsets + first + 1, *end = h_offsets + n_reads + 1;
+        // (the first download can only start when the first walk is over: the first two chunks are a quarter and
+        // half the size)
+        uint64_t tgt = target;
+        if (!ix->pipe_chunk_bases && chunks.size() < 2 && (target >> (2 - chunks.size())) >= kPipeMinBases) tgt = target >> (2 - chunks.size());
+        uint64_t last = (uint64_t)(std::upper_bound(lo, end, h_offsets[first] + tgt) - h_offsets) - 1;
+        if (last - first < min_reads) {
+            const uint64_t cap = (uint64_t)(std::upper_bound(lo, end, h_offsets[first] + kMaxChunkBases) - h_offsets) - 1;
+            last = std::min(first + min_reads, cap);
+        }
+        if (last <= first) last = first + 1;
+        if (last > n_reads) last = n_reads;
+        chunks.push_back({first, last - first, h_offsets[first], h_offsets[last] - h_offsets[first]});
+        first = last;
+    }
+    constexpr int S = movi_index::kPipeSlots;
+    struct InFlight { int stage = 0; Chunk c{}; } fl[S];       // 0 free, 1 walking (upload + kernel enqueued), 2 coming down
+    // layout of a slot's page-locked block
+    auto off_err = [](uint64_t nr) { return (size_t)(nr + 1) * 8; };
+    auto off_small = [&](uint64_t nr) { return (off_err(nr) + (size_t)nr + 15) & ~(size_t)15; };
+    auto off_stats = [&](uint64_t nr) { return (off_small(nr) + (size_t)nr * small_bytes + 15) & ~(size_t)15; };
+    auto ctx_of = [&](int k, uint64_t nr) {
+        movi_index::PipeSlot &sl = ix->pipe[k];
+        ChunkCtx ctx;
+        ctx.ix = ix;
+        ctx.s = sl.s;
+        ctx.d_stats = sl.d_stats;
+        ctx.d = sl.d;
+        ctx.cap = sl.cap;
+        ctx.h_small = sl.h + off_small(nr);
+        ctx.async = true;
+        return ctx;
+    };
+    // a chunk's stream has drained: counters, error bytes, per-read results
+    auto finish = [&](int k) -> int {
+        movi_index::PipeSlot &sl = ix->pipe[k];
+        InFlight &f = fl[k];
+        if (f.stage == 0) return MOVI_OK;
+        f.stage = 0;
+        HIP_TRY(hipStreamSynchronize(sl.s));
+        DevStats h;
+        memcpy(&h, sl.h + off_stats(f.c.nr), sizeof(h));
+        add_stats(&acc, f.c.nb, h);
+        if (h_read_err) memcpy(h_read_err + f.c.first, sl.h + off_err(f.c.nr), f.c.nr);
+        harvest(sl.h + off_small(f.c.nr), f.c.first, f.c.nr);
+        return MOVI_OK;
+    };
+    // chunk c goes up into slot k and is walked
+    auto up = [&](const Chunk &c, int k) -> int {
+        movi_index::PipeSlot &sl = ix->pipe[k];
+        if (int rc = finish(k)) return rc;
+        if (!sl.s) HIP_TRY(hipStreamCreateWithFlags(&sl.s, hipStreamNonBlocking));
+        if (!sl.ev) HIP_TRY(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+        if (!sl.ev_up) HIP_TRY(hipEventCreateWithFlags(&sl.ev_up, hipEventDisableTiming));
+        if (!ix->pipe_up) HIP_TRY(hipStreamCreateWithFlags(&ix->pipe_up, hipStreamNonBlocking));
+        if (!sl.d_stats) HIP_TRY(hipMalloc(&sl.d_stats, sizeof(DevStats)));
+        const size_t hb = off_stats(c.nr) + sizeof(DevStats);
+        if (sl.h_cap < hb) {
+            if (sl.h) (void)hipHostFree(sl.h);
+            sl.h = nullptr;
+            sl.h_cap = 0;
+            const size_t want = hb + (hb >> 2);
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sl.h), want, hipHostMallocDefault));
+            sl.h_cap = want;
+        }
+        ChunkCtx ctx = ctx_of(k, c.nr);
+        struct { void *p; } d_bases{}, d_offs{}, d_err{};
+        HIP_TRY(ctx.alloc(movi_index::kBases, c.nb, &d_bases.p));
+        HIP_TRY(ctx.alloc(movi_index::kOffs, (c.nr + 1) * 8, &d_offs.p));
+        HIP_TRY(ctx.alloc(movi_index::kErr, c.nr, &d_err.p));
+        uint64_t *rel = reinterpret_cast<uint64_t *>(sl.h);
+        for (uint64_t i = 0; i <= c.nr; i++) rel[i] = h_offsets[c.first + i] - c.b0;
+        fl[k].c = c;
+        fl[k].stage = 1;                                     // from here on the streams hold work that touches caller memory
+        if (c.nb) HIP_TRY(hipMemcpyAsync(d_bases.p, h_bases + c.b0, c.nb, hipMemcpyHostToDevice, ix->pipe_up));
+        HIP_TRY(hipMemcpyAsync(d_offs.p, rel, (c.nr + 1) * 8, hipMemcpyHostToDevice, ix->pipe_up));
+        HIP_TRY(hipEventRecord(sl.ev_up, ix->pipe_up));
+        HIP_TRY(hipStreamWaitEvent(sl.s, sl.ev_up, 0));
+        if (int rc = launch(ctx, static_cast<const uint8_t *>(d_bases.p), static_cast<const uint64_t *>(d_offs.p), c.nr, c.nb,
+                            static_cast<uint8_t *>(d_err.p)))
+            return rc;
+        HIP_TRY(hipEventRecord(sl.ev, sl.s));
+        return MOVI_OK;
+    };
+    // slot k's walk is over: its results start their way down
+    auto down = [&](int k) -> int {
+        movi_index::PipeSlot &sl = ix->pipe[k];
+        const Chunk &c = fl[k].c;
+        HIP_TRY(hipEventSynchronize(sl.ev));
+        ChunkCtx ctx = ctx_of(k, c.nr);
+        if (int rc = fetch(ctx, c.first, c.nr, c.b0, c.nb)) return rc;
+        HIP_TRY(hipMemcpyAsync(sl.h + off_err(c.nr), sl.d[movi_index::kErr], c.nr, hipMemcpyDeviceToHost, sl.s));
+        HIP_TRY(hipMemcpyAsync(sl.h + off_stats(c.nr), sl.d_stats, sizeof(DevStats), hipMemcpyDeviceToHost, sl.s));
+        fl[k].stage = 2;
+        return MOVI_OK;
+    };
+    // kPipeAhead chunks going up or being walked (their kernels share the GPU: the lanes in flight are the sum of
+    // theirs) while one comes down; twice as many slots, so that a slot's previous chunk has long arrived on the host
+    // when the slot is reused (with kPipeAhead + 1 slots every upload waited for the download issued just before it,
+    // and the downloads did not queue back to back)
+    int rc = MOVI_OK;
+    const size_t n = chunks.size();
+    size_t next_up = 0;
+    for (size_t i = 0; i < n && rc == MOVI_OK; i++) {
+        for (; next_up < n && next_up < i + (size_t)movi_index::kPipeAhead && rc == MOVI_OK; next_up++) rc = up(chunks[next_up], (int)(next_up % S));
+        if (rc == MOVI_OK) rc = down((int)(i % S));
+    }
+    for (size_t j = 0; j < (size_t)S && rc == MOVI_OK; j++) rc = finish((int)((n + j) % S));   // oldest first
+    if (rc != MOVI_OK) {
+        // whatever happened, nothing may still be reading or writing the caller's buffers when the call returns
+        const std::string keep = g_err;
+        if (ix->pipe_up) (void)hipStreamSynchronize(ix->pipe_up);
+        for (int k = 0; k < S; k++)
+            if (ix->pipe[k].s) (void)hipStreamSynchronize(ix->pipe[k].s);
+        g_err = keep;
+    }
+    if (stats) *stats = acc;
+    return rc;
+}
+
+// Queries with per-read results (count, bins) only have their upload to hide.  A read takes as long as it takes: with
+// long reads the last chunk's walk starts when the last byte has arrived and lasts as long as the whole batch's would
+// (100 k x 10 kbp, bins: 43 ms overlapped, 38 ms synchronous); with short reads the walks are short against the
+// transfers and overlapping pays (1 M x 150 bp: count 20.6 -> 25.1, bins 21.8 -> 28.8 Gbases/s).
+bool worth_overlapping_small_results(const uint64_t *h_offsets, uint64_t n_reads) {
+    const uint64_t total = h_offsets[n_reads] - h_offsets[0];
+    return total != 0 && total / n_reads <= 2048;
+}
+
+template <typename Launch, typename Fetch, typename Harvest>
+int run_host(bool overlapped, movi_index *ix, const uint8_t *h_bases, const uint64_t *h_offsets, uint64_t n_reads,
+             uint8_t *h_read_err, movi_query_stats_t *stats, Launch launch, Fetch fetch, Harvest harvest,
+             size_t small_bytes) {
+    movi_query_stats_t local{};
+    int rc = overlapped ? run_pipelined(ix, h_bases, h_offsets, n_reads, h_read_err, &local, launch, fetch, harvest, small_bytes)
+                        : run_chunked(ix, h_bases, h_offsets, n_reads, h_read_err, &local, launch, fetch, harvest, small_bytes);
+    if (stats) *stats = local;
+    if (rc) return rc;
+    if (local.errors)
+        return fail(MOVI_ERR_INVARIANT, std::to_string(local.errors) +
+                                            " read(s) hit a move-structure invariant violation (corrupt index?)");
+    return MOVI_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
+// ------------------------------------------------------------- page-locked host memory
+
+int movi_host_alloc(size_t bytes, void **out) {
+    if (!out) return fail(MOVI_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    HIP_TRY(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return MOVI_OK;
+}
+
+int movi_host_free(void *p) {
+    if (!p) return MOVI_OK;
+    HIP_TRY(hipHostFree(p));
+    return MOVI_OK;
+}
+
+int movi_host_register(void *p, size_t bytes) {
+    if (!p || !bytes) return fail(MOVI_ERR_ARG, "NULL or empty range");
+    HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    return MOVI_OK;
+}
+
+int movi_host_unregister(void *p) {
+    if (!p) return MOVI_OK;
+    HIP_TRY(hipHostUnregister(p));
+    return MOVI_OK;
+}
 
 static int ml_host(bool zml, movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_offsets, uint64_t n_reads,
                   uint16_t *h_out_pml, uint8_t *h_read_err, movi_query_stats_t *stats) {
@@ -695,23 +1009,19 @@ static int ml_host(bool zml, movi_index_t *ix, const uint8_t *h_bases, const uin
     if (int rc0 = check_offsets(h_offsets, n_reads)) return rc0;
     HIP_TRY(hipSetDevice(ix->device));
     struct { void *p; } d_out{};
-    auto launch = [&](const uint8_t *db, const uint64_t *dof, uint64_t nr, uint64_t nb, uint8_t *derr,
-                      const uint32_t *dord) -> int {
-        HIP_TRY(scratch(ix, movi_index::kOut, nb * 2, &d_out.p));
-        return ml_device(zml, ix, db, dof, nr, nb, static_cast<uint16_t *>(d_out.p), derr, dord, nullptr);
+    auto launch = [&](ChunkCtx &c, const uint8_t *db, const uint64_t *dof, uint64_t nr, uint64_t nb, uint8_t *derr) -> int {
+        HIP_TRY(c.alloc(movi_index::kOut, nb * 2, &d_out.p));
+        return ml_device(zml, ix, db, dof, nr, nb, static_cast<uint16_t *>(d_out.p), derr, nullptr, c.s, ClsArgs(), c.d_stats);
     };
-    auto fetch = [&](uint64_t, uint64_t, uint64_t b0, uint64_t nb) -> int {
-        if (nb) HIP_TRY(hipMemcpy(h_out_pml + b0, d_out.p, nb * 2, hipMemcpyDeviceToHost));
+    // (the results are found through the chunk's own staging: with chunks in flight, launch() of the next chunk has
+    // run before fetch() of this one)
+    auto fetch = [&](ChunkCtx &c, uint64_t, uint64_t, uint64_t b0, uint64_t nb) -> int {
+        HIP_TRY(c.down(h_out_pml + b0, c.d[movi_index::kOut], nb * 2));
         return MOVI_OK;
     };
-    movi_query_stats_t local{};
-    int rc = run_chunked(ix, h_bases, h_offsets, n_reads, h_read_err, &local, launch, fetch);
-    if (stats) *stats = local;
-    if (rc) return rc;
-    if (local.errors)
-        return fail(MOVI_ERR_INVARIANT, std::to_string(local.errors) +
-                                            " read(s) hit a move-structure invariant violation (corrupt index?)");
-    return MOVI_OK;
+    auto harvest = [](const uint8_t *, uint64_t, uint64_t) {};
+    const bool overlapped = h_offsets[n_reads] != h_offsets[0] && is_pinned(h_bases) && is_pinned(h_out_pml);
+    return run_host(overlapped, ix, h_bases, h_offsets, n_reads, h_read_err, stats, launch, fetch, harvest, 0);
 }
 
 int movi_pml_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_offsets, uint64_t n_reads,
@@ -739,10 +1049,10 @@ int movi_classify_device(movi_index_t *ix, const uint16_t *d_pml, const uint64_t
     return MOVI_OK;
 }
 
-int movi_pml_classify_device(movi_index_t *ix, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
-                             uint64_t n_bases, uint32_t bin_width, uint32_t max_value_thr, uint16_t *d_out_pml,
-                             uint32_t *d_bins_above, uint32_t *d_bins_below, uint64_t *d_sum_max, uint8_t *d_read_err,
-                             const uint32_t *d_read_order, void *stream) {
+static int pml_classify_device(movi_index_t *ix, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
+                               uint64_t n_bases, uint32_t bin_width, uint32_t max_value_thr, uint16_t *d_out_pml,
+                               uint32_t *d_bins_above, uint32_t *d_bins_below, uint64_t *d_sum_max, uint8_t *d_read_err,
+                               const uint32_t *d_read_order, void *stream, DevStats *d_stats) {
     if (bin_width == 0) return fail(MOVI_ERR_ARG, "bin_width must be > 0");
     if (n_reads && (!d_bins_above || !d_bins_below || !d_sum_max)) return fail(MOVI_ERR_ARG, "NULL device buffer");
     ClsArgs cls;
@@ -751,7 +1061,15 @@ int movi_pml_classify_device(movi_index_t *ix, const uint8_t *d_bases, const uin
     cls.above = d_bins_above;
     cls.below = d_bins_below;
     cls.sum_max = d_sum_max;
-    return ml_device(false, ix, d_bases, d_offsets, n_reads, n_bases, d_out_pml, d_read_err, d_read_order, stream, cls);
+    return ml_device(false, ix, d_bases, d_offsets, n_reads, n_bases, d_out_pml, d_read_err, d_read_order, stream, cls, d_stats);
+}
+
+int movi_pml_classify_device(movi_index_t *ix, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
+                             uint64_t n_bases, uint32_t bin_width, uint32_t max_value_thr, uint16_t *d_out_pml,
+                             uint32_t *d_bins_above, uint32_t *d_bins_below, uint64_t *d_sum_max, uint8_t *d_read_err,
+                             const uint32_t *d_read_order, void *stream) {
+    return pml_classify_device(ix, d_bases, d_offsets, n_reads, n_bases, bin_width, max_value_thr, d_out_pml, d_bins_above,
+                               d_bins_below, d_sum_max, d_read_err, d_read_order, stream, nullptr);
 }
 
 int movi_pml_classify_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_offsets, uint64_t n_reads,
@@ -765,30 +1083,29 @@ int movi_pml_classify_host(movi_index_t *ix, const uint8_t *h_bases, const uint6
     if (bin_width == 0) return fail(MOVI_ERR_ARG, "bin_width must be > 0");
     HIP_TRY(hipSetDevice(ix->device));
     struct { void *p; } d_a{}, d_b{}, d_s{};
-    auto launch = [&](const uint8_t *db, const uint64_t *dof, uint64_t nr, uint64_t nb, uint8_t *derr,
-                      const uint32_t *dord) -> int {
-        HIP_TRY(scratch(ix, movi_index::kA, nr * 4, &d_a.p));
-        HIP_TRY(scratch(ix, movi_index::kB, nr * 4, &d_b.p));
-        HIP_TRY(scratch(ix, movi_index::kS, nr * 8, &d_s.p));
+    auto launch = [&](ChunkCtx &c, const uint8_t *db, const uint64_t *dof, uint64_t nr, uint64_t nb, uint8_t *derr) -> int {
+        HIP_TRY(c.alloc(movi_index::kA, nr * 4, &d_a.p));
+        HIP_TRY(c.alloc(movi_index::kB, nr * 4, &d_b.p));
+        HIP_TRY(c.alloc(movi_index::kS, nr * 8, &d_s.p));
         // bins reduced inside the PML kernel; no PML vector is written at all
-        return movi_pml_classify_device(ix, db, dof, nr, nb, bin_width, max_value_thr, nullptr,
-                                        static_cast<uint32_t *>(d_a.p), static_cast<uint32_t *>(d_b.p),
-                                        static_cast<uint64_t *>(d_s.p), derr, dord, nullptr);
+        return pml_classify_device(ix, db, dof, nr, nb, bin_width, max_value_thr, nullptr, static_cast<uint32_t *>(d_a.p),
+                                   static_cast<uint32_t *>(d_b.p), static_cast<uint64_t *>(d_s.p), derr, nullptr, c.s,
+                                   c.d_stats);
     };
-    auto fetch = [&](uint64_t first, uint64_t nr, uint64_t, uint64_t) -> int {
-        HIP_TRY(hipMemcpy(h_bins_above + first, d_a.p, nr * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(h_bins_below + first, d_b.p, nr * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(h_sum_max + first, d_s.p, nr * 8, hipMemcpyDeviceToHost));
+    // page-locked block of a chunk in flight: sum_max[nr] | above[nr] | below[nr]
+    auto fetch = [&](ChunkCtx &c, uint64_t first, uint64_t nr, uint64_t, uint64_t) -> int {
+        HIP_TRY(c.down_small(h_sum_max + first, 0, c.d[movi_index::kS], nr * 8));
+        HIP_TRY(c.down_small(h_bins_above + first, nr * 8, c.d[movi_index::kA], nr * 4));
+        HIP_TRY(c.down_small(h_bins_below + first, nr * 12, c.d[movi_index::kB], nr * 4));
         return MOVI_OK;
     };
-    movi_query_stats_t local{};
-    int rc = run_chunked(ix, h_bases, h_offsets, n_reads, h_read_err, &local, launch, fetch);
-    if (stats) *stats = local;
-    if (rc) return rc;
-    if (local.errors)
-        return fail(MOVI_ERR_INVARIANT, std::to_string(local.errors) +
-                                            " read(s) hit a move-structure invariant violation (corrupt index?)");
-    return MOVI_OK;
+    auto harvest = [&](const uint8_t *h, uint64_t first, uint64_t nr) {
+        memcpy(h_sum_max + first, h, nr * 8);
+        memcpy(h_bins_above + first, h + nr * 8, nr * 4);
+        memcpy(h_bins_below + first, h + nr * 12, nr * 4);
+    };
+    const bool overlapped = worth_overlapping_small_results(h_offsets, n_reads) && is_pinned(h_bases);
+    return run_host(overlapped, ix, h_bases, h_offsets, n_reads, h_read_err, stats, launch, fetch, harvest, 16);
 }
 
 // -------------------------------------------------------------------------- count
@@ -798,6 +1115,7 @@ static int ensure_ckpt(movi_index *ix, hipStream_t s) {
     const uint64_t n_chunks = (ix->desc.r + (1ull << kPrefixShift) - 1) >> kPrefixShift;
     HIP_TRY(hipMalloc(&ix->d_ckpt, (n_chunks + 1) * sizeof(uint64_t)));
     hipError_t e = build_row_start_ckpt(ix->kmode, ix->d_rows, ix->desc.r, ix->d_ckpt, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);        // other streams (the overlapped host path) may use it next
     if (e != hipSuccess) {
         (void)hipFree(ix->d_ckpt);
         ix->d_ckpt = nullptr;
@@ -807,21 +1125,29 @@ static int ensure_ckpt(movi_index *ix, hipStream_t s) {
     return MOVI_OK;
 }
 
-int movi_count_device(movi_index_t *ix, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
-                      uint64_t n_bases, uint64_t *d_matched, uint64_t *d_count, uint8_t *d_read_err,
-                      const uint32_t *d_read_order, void *stream) {
+static int count_device(movi_index_t *ix, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
+                        uint64_t n_bases, uint64_t *d_matched, uint64_t *d_count, uint8_t *d_read_err,
+                        const uint32_t *d_read_order, void *stream, DevStats *d_stats) {
     if (!ix) return fail(MOVI_ERR_ARG, "index handle is NULL");
     if (n_reads == 0) return MOVI_OK;
     if (!d_offsets || !d_matched || !d_count || (n_bases && !d_bases)) return fail(MOVI_ERR_ARG, "NULL device buffer");
+    if (!d_stats) d_stats = ix->d_stats;
     HIP_TRY(hipSetDevice(ix->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     int rc = ensure_ckpt(ix, s);
     if (rc) return rc;
-    HIP_TRY(hipMemsetAsync(ix->d_stats, 0, sizeof(DevStats), s));
+    HIP_TRY(hipMemsetAsync(d_stats, 0, sizeof(DevStats), s));
     if (n_reads > 0xFFFFFFFFull) return fail(MOVI_ERR_ARG, "more than 2^32 reads in one call");
     HIP_TRY(launch_count(ix->kmode, ix->dev, d_bases, d_offsets, n_reads, d_matched, d_count,
-                         d_read_err, ix->d_stats, d_read_order, ix->cfg, s));
+                         d_read_err, d_stats, d_read_order, ix->cfg, s));
     return MOVI_OK;
+}
+
+int movi_count_device(movi_index_t *ix, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
+                      uint64_t n_bases, uint64_t *d_matched, uint64_t *d_count, uint8_t *d_read_err,
+                      const uint32_t *d_read_order, void *stream) {
+    return count_device(ix, d_bases, d_offsets, n_reads, n_bases, d_matched, d_count, d_read_err, d_read_order, stream,
+                        nullptr);
 }
 
 int movi_count_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_offsets, uint64_t n_reads,
@@ -833,26 +1159,24 @@ int movi_count_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_
     if (int rc0 = check_offsets(h_offsets, n_reads)) return rc0;
     HIP_TRY(hipSetDevice(ix->device));
     struct { void *p; } d_m{}, d_c{};
-    auto launch = [&](const uint8_t *db, const uint64_t *dof, uint64_t nr, uint64_t nb, uint8_t *derr,
-                      const uint32_t *dord) -> int {
-        HIP_TRY(scratch(ix, movi_index::kA, nr * 8, &d_m.p));
-        HIP_TRY(scratch(ix, movi_index::kS, nr * 8, &d_c.p));
-        return movi_count_device(ix, db, dof, nr, nb, static_cast<uint64_t *>(d_m.p),
-                                 static_cast<uint64_t *>(d_c.p), derr, dord, nullptr);
+    auto launch = [&](ChunkCtx &c, const uint8_t *db, const uint64_t *dof, uint64_t nr, uint64_t nb, uint8_t *derr) -> int {
+        HIP_TRY(c.alloc(movi_index::kA, nr * 8, &d_m.p));
+        HIP_TRY(c.alloc(movi_index::kS, nr * 8, &d_c.p));
+        return count_device(ix, db, dof, nr, nb, static_cast<uint64_t *>(d_m.p), static_cast<uint64_t *>(d_c.p), derr,
+                            nullptr, c.s, c.d_stats);
     };
-    auto fetch = [&](uint64_t first, uint64_t nr, uint64_t, uint64_t) -> int {
-        HIP_TRY(hipMemcpy(h_matched + first, d_m.p, nr * 8, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(h_count + first, d_c.p, nr * 8, hipMemcpyDeviceToHost));
+    // page-locked block of a chunk in flight: matched[nr] | count[nr]
+    auto fetch = [&](ChunkCtx &c, uint64_t first, uint64_t nr, uint64_t, uint64_t) -> int {
+        HIP_TRY(c.down_small(h_matched + first, 0, c.d[movi_index::kA], nr * 8));
+        HIP_TRY(c.down_small(h_count + first, nr * 8, c.d[movi_index::kS], nr * 8));
         return MOVI_OK;
     };
-    movi_query_stats_t local{};
-    int rc = run_chunked(ix, h_bases, h_offsets, n_reads, h_read_err, &local, launch, fetch);
-    if (stats) *stats = local;
-    if (rc) return rc;
-    if (local.errors)
-        return fail(MOVI_ERR_INVARIANT, std::to_string(local.errors) +
-                                            " read(s) hit a move-structure invariant violation (corrupt index?)");
-    return MOVI_OK;
+    auto harvest = [&](const uint8_t *h, uint64_t first, uint64_t nr) {
+        memcpy(h_matched + first, h, nr * 8);
+        memcpy(h_count + first, h + nr * 8, nr * 8);
+    };
+    const bool overlapped = worth_overlapping_small_results(h_offsets, n_reads) && is_pinned(h_bases);
+    return run_host(overlapped, ix, h_bases, h_offsets, n_reads, h_read_err, stats, launch, fetch, harvest, 16);
 }
 
 }  // extern "C"

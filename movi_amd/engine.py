@@ -56,6 +56,32 @@ def _pack_reads(reads):
     return np.ascontiguousarray(bases), offs
 
 
+class _PinnedBlock:
+    """Page-locked host bytes (movi_host_alloc); numpy views keep it alive through __array_interface__."""
+
+    def __init__(self, nbytes):
+        p = C.c_void_p()
+        check(lib().movi_host_alloc(nbytes, C.byref(p)))
+        self.ptr, self.nbytes = p.value, nbytes
+        self.__array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (self.ptr, False), "version": 3}
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib().movi_host_free(C.c_void_p(self.ptr))
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def pinned_empty(n, dtype):
+    """A numpy array of n elements in page-locked host memory (movi_host_alloc): with the reads and the result
+    vector in such arrays the *_host entry points overlap upload, walk and download (include/movi_hip.h)."""
+    dt = np.dtype(dtype)
+    blk = _PinnedBlock(max(int(n) * dt.itemsize, 1))
+    return np.asarray(blk)[: int(n) * dt.itemsize].view(dt)
+
+
 class QueryStats:
     def __init__(self, c):
         self.bases = int(c.bases)
@@ -123,12 +149,15 @@ class MoveIndex:
         check(lib().movi_set_option(self._h, key.encode(), int(value)))
 
     # -- host-buffer queries ----------------------------------------------------
-    def query_pml_packed(self, bases, offs, want_err=False):
-        """bases uint8[n_bases], offs uint64[n+1] -> (u16 PMLs in emission order, QueryStats[, err])."""
+    def query_pml_packed(self, bases, offs, want_err=False, out=None):
+        """bases uint8[n_bases], offs uint64[n+1] -> (u16 PMLs in emission order, QueryStats[, err]).
+        `out`: the caller's result array (e.g. pinned_empty(n_bases, np.uint16) next to pinned bases: overlapped path)."""
         bases = np.ascontiguousarray(bases, np.uint8)
         offs = np.ascontiguousarray(offs, np.uint64)
         n = offs.size - 1
-        out = np.zeros(bases.size, np.uint16)
+        if out is None:
+            out = np.zeros(bases.size, np.uint16)
+        assert out.dtype == np.uint16 and out.size == bases.size and out.flags.c_contiguous
         err = np.zeros(max(n, 1), np.uint8)
         st = QueryStatsC()
         rc = lib().movi_pml_host(self._h, bases.ctypes.data, offs.ctypes.data, n, out.ctypes.data,
@@ -145,13 +174,15 @@ class MoveIndex:
         out, _ = self.query_pml_packed(bases, offs)
         return [out[int(offs[i]): int(offs[i + 1])] for i in range(len(reads))]
 
-    def query_zml_packed(self, bases, offs):
+    def query_zml_packed(self, bases, offs, out=None):
         """MoveStructure::query_zml (src/move_structure_query.cpp:690-785) for packed reads:
         (u16 match lengths in emission order, QueryStats)."""
         bases = np.ascontiguousarray(bases, np.uint8)
         offs = np.ascontiguousarray(offs, np.uint64)
         n = offs.size - 1
-        out = np.zeros(bases.size, np.uint16)
+        if out is None:
+            out = np.zeros(bases.size, np.uint16)
+        assert out.dtype == np.uint16 and out.size == bases.size and out.flags.c_contiguous
         st = QueryStatsC()
         check(lib().movi_zml_host(self._h, bases.ctypes.data, offs.ctypes.data, n, out.ctypes.data, None,
                                   C.byref(st)))

@@ -915,3 +915,93 @@ def test_blocked_index_with_many_blocks(built_lib, tmp_path):
             gpu.close()
     finally:
         B.BLOCK_SIZE.update(old)
+
+
+# ---------------------------------------------------------------- overlapped host path (page-locked caller buffers)
+
+def _pinned_copy(a):
+    import movi_amd
+    p = movi_amd.pinned_empty(a.size, a.dtype)
+    p[:] = a
+    return p
+
+
+@pytest.mark.parametrize("mode", [6, 8])
+@pytest.mark.parametrize("chunk_bases", [0, 1, 3000, 100_000])
+def test_overlapped_host_path_equals_synchronous(engines, mode, chunk_bases):
+    """movi_*_host with the reads (and the PML / ZML vector) in page-locked memory run as chunks in flight on three
+    streams; answers, error bytes and counters must be those of the synchronous path and of the oracle, whatever the cut
+    (chunk_bases 1 = one read per chunk: every slot is reused many times)."""
+    import movi_amd
+    from oracle import build_index as B
+    gpu, cpu = engines[mode]
+    ref = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))[0][1]
+    rng = np.random.default_rng(4200 + mode)
+    reads = mutated_reads(rng, ref, 300, 1, 1500) + [b"", b"", b"N", b"ACGT" * 100, b""] + mutated_reads(rng, ref, 200, 100, 200)
+    if chunk_bases == 1:
+        reads = reads[:120]
+    bases, offs = pack(reads)
+    exp_out, exp_st = gpu.query_pml_packed(bases, offs)                       # pageable: synchronous path
+    exp_z, exp_zst = gpu.query_zml_packed(bases, offs)
+    exp_m, exp_c, exp_cst = gpu.query_count_packed(bases, offs)
+    exp_cls = gpu.classify_packed(bases, offs, 150, 8)
+    ora, ff, sc = cpu.pml_batch(bases, offs, threads=4)
+    assert (exp_out == ora).all()
+    pb = _pinned_copy(bases)
+    gpu.set_option("pipe_chunk_bases", chunk_bases)
+    try:
+        for rep in range(2):                                                  # second pass: staging reused
+            out = movi_amd.pinned_empty(bases.size, np.uint16)
+            out[:] = 0xABCD
+            got, st, err, rc = gpu.query_pml_packed(pb, offs, want_err=True, out=out)
+            assert rc == 0 and got is out and (out == exp_out).all() and not err.any()
+            assert (st.bases, st.fast_forwards, st.scans, st.repositions, st.errors) == \
+                   (exp_st.bases, exp_st.fast_forwards, exp_st.scans, exp_st.repositions, 0)
+            assert (st.fast_forwards, st.scans) == (ff, sc)
+            zout = movi_amd.pinned_empty(bases.size, np.uint16)
+            zout[:] = 0xABCD
+            _, zst = gpu.query_zml_packed(pb, offs, out=zout)
+            assert (zout == exp_z).all() and (zst.fast_forwards, zst.scans) == (exp_zst.fast_forwards, exp_zst.scans)
+            m, c, cst = gpu.query_count_packed(pb, offs)                      # per-read results stay pageable
+            assert (m == exp_m).all() and (c == exp_c).all()
+            assert (cst.fast_forwards, cst.scans) == (exp_cst.fast_forwards, exp_cst.scans)
+            cls = gpu.classify_packed(pb, offs, 150, 8)
+            assert all((x == y).all() for x, y in zip(cls, exp_cls))
+    finally:
+        gpu.set_option("pipe_chunk_bases", 0)
+    # page-locked reads with a pageable result vector: PML / ZML fall back to the synchronous path, same answers
+    out2, _ = gpu.query_pml_packed(pb, offs)
+    assert (out2 == exp_out).all()
+
+
+def test_overlapped_host_path_reports_invariant_violations(built_lib, golden_image):
+    """Error bytes and MOVI_ERR_INVARIANT come back from chunks in flight exactly as from the synchronous path."""
+    import movi_amd
+    img = bytearray(golden_image(6))
+    _, _, off, _ = movi_amd.parse_index_image(bytes(img))
+    rows = np.frombuffer(img, np.uint8, count=118209 * 8, offset=off).reshape(-1, 8).copy()
+    rows[:, 0:4] = 0xFF                                   # every destination id >= r
+    img[off: off + rows.size] = rows.tobytes()
+    gpu = movi_amd.MoveIndex.from_image(bytes(img))
+    bases, offs = pack([b"ACGTACGT", b"A", b"", b"GG", b"T"] * 7)
+    exp, est, eerr, erc = gpu.query_pml_packed(bases, offs, want_err=True)
+    assert erc == -6 and est.errors == 14 and list(eerr) == [1, 0, 0, 1, 0] * 7
+    gpu.set_option("pipe_chunk_bases", 9)
+    pb = _pinned_copy(bases)
+    out = movi_amd.pinned_empty(bases.size, np.uint16)
+    _, st, err, rc = gpu.query_pml_packed(pb, offs, want_err=True, out=out)
+    assert rc == -6 and st.errors == 14 and list(err) == list(eerr) and (out == exp).all()
+
+
+def test_overlapped_host_path_large(built_lib):
+    """1 M x 150 bp through the overlapped path with its own chunk policy (several chunks of >= 2^25 bases)."""
+    import movi_amd
+    from tools import synth
+    six = synth.synth_index(2_000_000, mode=6, seed=5)
+    gpu = movi_amd.MoveIndex.from_image(six.image())
+    bases, offs = synth.synth_reads(six, 1_000_000, 150, seed=6, sub_rate=0.01, n_rate=0.001)
+    exp, est = gpu.query_pml_packed(bases, offs)
+    pb, out = _pinned_copy(bases), movi_amd.pinned_empty(bases.size, np.uint16)
+    got, st = gpu.query_pml_packed(pb, offs, out=out)
+    assert (out == exp).all()
+    assert (st.bases, st.fast_forwards, st.scans, st.repositions) == (est.bases, est.fast_forwards, est.scans, est.repositions)
