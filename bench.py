@@ -83,6 +83,26 @@ def ensure_pangenome(wl, world, rank, barrier):
     return idx_dir, reads_file
 
 
+def usable_cores():
+    """Host threads this process can really run: the CPU affinity mask capped by the cgroup CPU quota (the GPU boxes
+    show 256 logical CPUs but grant 16 CPUs of quota: 256 OpenMP threads then run at 0.15-0.2 Gbases/s, 16 at 0.39;
+    tools/cpu_threads_sweep.py, profiles/r02_cpu_port_thread_sweep.txt)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]                  # cgroup v2
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())             # cgroup v1
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return max(1, n)
+
+
 SEED = 20260529
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
@@ -378,7 +398,7 @@ def main():
     # OpenMP over read groups) on a bounded sample of the same reads, rank 0, N == 1 only.
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.query == "zml":
         from oracle.oracle import Oracle
-        cores = os.cpu_count() or 1
+        cores = usable_cores()
         cpu = Oracle(file_img if file_img is not None else six.image())
         sample = args.cpu_sample_reads or max(1, min(n_reads, int(15e6 * cores / 8) // max(wl["read_len"], 1)))
         sb = bases[: int(offs[sample])]
@@ -401,7 +421,7 @@ def main():
             print("PARITY FAILURE on the cpu_baseline sample", file=sys.stderr)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.query == "pml" and args.classify != 2:
         from oracle.oracle import Oracle
-        cores = os.cpu_count() or 1
+        cores = usable_cores()
         cpu = Oracle(file_img if file_img is not None else six.image())
         sample = args.cpu_sample_reads or max(1, min(n_reads, int(30e6 * cores / 8) // max(wl["read_len"], 1)))
         sb = bases[: int(offs[sample])]
