@@ -394,6 +394,7 @@ def main():
                                        else (2.0 * (1.0 + f_bar) + s_bar) * work_bases) / avg_kern_s},
     }
 
+    oracle_sample = None
     # ---- CPU baseline: the oracle restatement (scalar port, 16 strands/thread + prefetch,
     # OpenMP over read groups) on a bounded sample of the same reads, rank 0, N == 1 only.
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.query == "zml":
@@ -441,6 +442,7 @@ def main():
                                             "strand scheduler: %d OpenMP threads x 16 strands + prefetch), %.2f s"
                                             % (sample, sb.size, passes, cores, dt)}
         result["parity_sample_ok"] = bool((got == exp).all())
+        oracle_sample = exp
         if not result["parity_sample_ok"]:
             print("PARITY FAILURE on the cpu_baseline sample", file=sys.stderr)
     # ---- secondary figure, default run only (N == 1, after the timed region, never part of `value`): BASELINE config 3,
@@ -480,6 +482,41 @@ def main():
                                     "scans_per_base": round(st3.scans / (n3 * L3), 4), "errors": int(st3.errors)}
         except Exception as e:                            # noqa: BLE001 -- never lose the headline line to the extra
             result["long_reads"] = {"error": repr(e)[:200]}
+    # ---- PCIe-inclusive rate of the boundary's host entry point ("pre-parsed reads in pinned host memory to
+    # PMLs in pinned host memory"), default run only, after the timed region, never part of `value`: the same batch
+    # through movi_pml_host from pageable buffers (synchronous path) and from page-locked ones (overlapped path)
+    if (rank == 0 and world == 1 and args.workload == "c2" and args.query == "pml" and not args.classify
+            and args.variant < 0 and not args.no_cpu_baseline):
+        try:
+            from movi_amd._lib import QueryStatsC, check, lib
+            hp = {"unit": "Gbases/s", "note": "movi_pml_host, host buffers in and out (1 B up + 2 B down per base over PCIe), "
+                                              "best of 3 calls after a warm-up call; the two paths checked against each other and against "
+                                              "the cpu_baseline's oracle sample"}
+            h_offs = np.ascontiguousarray(offs, np.uint64)
+            stq = QueryStatsC()
+            torch.cuda.synchronize()
+            ref_out = None
+            for name, mk in (("pageable", lambda n, dt: np.empty(n, dt)), ("page_locked", movi_amd.pinned_empty)):
+                hb, ho = mk(n_bases, np.uint8), mk(n_bases, np.uint16)
+                hb[:] = bases
+                ho[:] = 0xFFFF
+                ts = []
+                for _ in range(4):
+                    t0 = time.perf_counter()
+                    check(lib().movi_pml_host(index._h, hb.ctypes.data, h_offs.ctypes.data, n_reads, ho.ctypes.data, None,
+                                              C.byref(stq)))
+                    ts.append(time.perf_counter() - t0)
+                if ref_out is None:
+                    ref_out = ho.copy()
+                hp[name] = round(n_bases / min(ts[1:]) / 1e9, 2)
+                ok = bool((ho == ref_out).all())
+                if oracle_sample is not None:
+                    ok = ok and bool((ho[: oracle_sample.size] == oracle_sample).all())
+                hp[name + "_ok"] = ok
+                del hb, ho
+            result["host_path"] = hp
+        except Exception as e:                            # noqa: BLE001 -- an extra, never worth the headline line
+            result["host_path"] = {"error": repr(e)[:200]}
     parity_failed = rank == 0 and result.get("parity_sample_ok") is False
     if parity_failed:
         # a kernel that disagrees with the oracle has no throughput: the record keeps the measurement under

@@ -96,6 +96,23 @@ def test_no_cpu_fallback(built_lib, golden_image):
     assert e.value.code in (-4, -5)
 
 
+def test_host_memory_entry_points_without_gpu(built_lib):
+    """movi_host_alloc / movi_host_register fail with a status and a message (no device here), never crash; NULL frees are no-ops."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from movi_amd._lib import lib
+    p = C.c_void_p()
+    assert lib().movi_host_alloc(1024, C.byref(p)) in (-4, -5) and not p.value and lib().movi_last_error()
+    assert lib().movi_host_alloc(1024, None) == -1
+    a = np.zeros(4096, np.uint8)
+    assert lib().movi_host_register(a.ctypes.data, a.nbytes) in (-4, -5)
+    assert lib().movi_host_register(None, 16) == -1 and lib().movi_host_register(a.ctypes.data, 0) == -1
+    assert lib().movi_host_free(None) == 0 and lib().movi_host_unregister(None) == 0
+
+
 def test_product_does_not_touch_oracle():
     """Nothing under movi_amd/ or tools/synth.py may reference oracle/."""
     for base, _, files in os.walk(os.path.join(ROOT, "movi_amd")):
