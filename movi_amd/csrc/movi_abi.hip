@@ -12,7 +12,11 @@
 #include <string>
 #include <vector>
 
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
+#include <thread>
+#include <unistd.h>
 
 using namespace movi;
 
@@ -394,7 +398,39 @@ static hipError_t adopt_widened(movi_index *ix, const uint8_t *d_packed) {
     return hipSuccess;
 }
 
-int movi_index_create(int device, const movi_index_desc_t *desc, const void *h_rows, movi_index_t **out) {
+// Rows that sit in a fresh file mapping (movi_index_load): every page the copy reads is a minor fault away, and a
+// pageable hipMemcpy takes those faults one by one on the calling thread.  So the rows go up in 64 MiB pieces while a
+// few helper threads touch the pages of the next piece.
+static hipError_t upload_from_mapping(uint8_t *d_rows, const uint8_t *h_rows, size_t bytes) {
+    constexpr size_t kPiece = 64ull << 20;
+    constexpr unsigned kTouchers = 4;
+    auto touch = [&](size_t a, size_t b) {
+        std::vector<std::thread> th;
+        const size_t span = (b - a + kTouchers - 1) / kTouchers;
+        for (unsigned t = 0; t < kTouchers; t++) {
+            const size_t lo = a + t * span, hi = std::min(b, lo + span);
+            if (lo >= hi) break;
+            th.emplace_back([=]() {
+                volatile uint8_t sink = 0;
+                for (size_t o = lo; o < hi; o += 4096) sink = sink + h_rows[o];
+                (void)sink;
+            });
+        }
+        for (auto &x : th) x.join();
+    };
+    touch(0, std::min(bytes, kPiece));
+    for (size_t off = 0; off < bytes; off += kPiece) {
+        const size_t n = std::min(kPiece, bytes - off), next = off + kPiece;
+        std::thread ahead;
+        if (next < bytes) ahead = std::thread([&, next]() { touch(next, std::min(bytes, next + kPiece)); });
+        hipError_t e = hipMemcpy(d_rows + off, h_rows + off, n, hipMemcpyHostToDevice);
+        if (ahead.joinable()) ahead.join();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+static int index_create(int device, const movi_index_desc_t *desc, const void *h_rows, movi_index_t **out, bool from_mapping) {
     if (!out || !h_rows) return fail(MOVI_ERR_ARG, "NULL argument");
     *out = nullptr;
     int rc = check_desc(desc);
@@ -402,7 +438,9 @@ int movi_index_create(int device, const movi_index_desc_t *desc, const void *h_r
     HIP_TRY(hipSetDevice(device));
     movi_index *ix = new_handle(device, desc);
     hipError_t e = hipMalloc(&ix->d_rows, ix->rows_bytes + 16);
-    if (e == hipSuccess) e = hipMemcpy(ix->d_rows, h_rows, ix->rows_bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = from_mapping ? upload_from_mapping(ix->d_rows, static_cast<const uint8_t *>(h_rows), ix->rows_bytes)
+                         : hipMemcpy(ix->d_rows, h_rows, ix->rows_bytes, hipMemcpyHostToDevice);
     if (e != hipSuccess) { movi_index_destroy(ix); return fail_hip(e, "uploading the move rows"); }
     ix->owns_rows = true;
     if (mode_sampled(desc->mode)) {
@@ -416,6 +454,10 @@ int movi_index_create(int device, const movi_index_desc_t *desc, const void *h_r
     if (rc) { std::string keep = g_err; movi_index_destroy(ix); g_err = keep; return rc; }
     *out = ix;
     return MOVI_OK;
+}
+
+int movi_index_create(int device, const movi_index_desc_t *desc, const void *h_rows, movi_index_t **out) {
+    return index_create(device, desc, h_rows, out, false);
 }
 
 int movi_index_create_from_device_rows(int device, const movi_index_desc_t *desc, const void *d_rows,
@@ -445,28 +487,31 @@ int movi_index_load(int device, const char *path, movi_index_t **out) {
     *out = nullptr;
     // open_index_read, src/move_structure_io.cpp:16-41: DIR/index.movi, then DIR/movi_index.bin
     std::string cand[3] = {std::string(path) + "/index.movi", std::string(path) + "/movi_index.bin", std::string(path)};
-    FILE *f = nullptr;
+    // The file is mapped, not read: the header and side tables are parsed in place and the row table -- all but a few
+    // kB of the file -- goes from the page cache to the GPU without a copy into a process buffer (the reference's
+    // --mmap; an 8 GB index no longer passes through an 8 GB std::vector first).
+    int fd = -1;
+    struct stat sb{};
     for (auto &c : cand) {
-        struct stat sb;
         if (stat(c.c_str(), &sb) != 0 || !S_ISREG(sb.st_mode)) continue;
-        f = fopen(c.c_str(), "rb");
-        if (f) break;
+        fd = open(c.c_str(), O_RDONLY | O_CLOEXEC);
+        if (fd >= 0) break;
     }
-    if (!f) return fail(MOVI_ERR_IO, std::string("Failed to open the index file at: ") + path);
-    fseek(f, 0, SEEK_END);
-    long sz = ftell(f);
-    fseek(f, 0, SEEK_SET);
-    std::vector<uint8_t> img((size_t)sz);
-    if (sz <= 0 || fread(img.data(), 1, (size_t)sz, f) != (size_t)sz) {
-        fclose(f);
-        return fail(MOVI_ERR_IO, std::string("Failed to read the index file at: ") + path);
-    }
-    fclose(f);
+    if (fd < 0) return fail(MOVI_ERR_IO, std::string("Failed to open the index file at: ") + path);
+    const size_t sz = (size_t)sb.st_size;
+    if (sz == 0) { close(fd); return fail(MOVI_ERR_IO, std::string("Failed to read the index file at: ") + path); }
+    void *map = mmap(nullptr, sz, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (map == MAP_FAILED) return fail(MOVI_ERR_IO, std::string("Failed to read the index file at: ") + path);
+    (void)madvise(map, sz, MADV_WILLNEED);
     movi_index_desc_t desc;
     size_t roff = 0, rbytes = 0;
-    int rc = movi_index_parse(img.data(), img.size(), &desc, &roff, &rbytes);
-    if (rc) return rc;
-    return movi_index_create(device, &desc, img.data() + roff, out);
+    int rc = movi_index_parse(map, sz, &desc, &roff, &rbytes);
+    if (rc == MOVI_OK) rc = index_create(device, &desc, static_cast<const uint8_t *>(map) + roff, out, true);
+    const std::string keep = g_err;
+    munmap(map, sz);
+    g_err = keep;
+    return rc;
 }
 
 int movi_index_destroy(movi_index_t *ix) {

@@ -117,11 +117,13 @@ Options parse_args(int argc, char **argv) {
         o.read_file = val("read");
         if (has("out-file")) o.out_file = val("out-file");
         for (const char *bad : {"mem", "rpml", "kmer", "kmer-count", "sa-entries", "multi-classify", "ftab-k",
-                                "multi-ftab", "mmap"})
+                                "multi-ftab"})
             if (has(bad))
                 throw UsageError(std::string("--") + bad + " is not supported by the MI355X engine (PML, ZML and count queries "
                                  "on regular-thresholds / blocked-thresholds indexes only)");
-        if (has("bin-width")) o.bin_width = (size_t)to_int("bin-width", val("bin-width"));
+        // --mmap (src/movi_parser.cpp: "Use memory mapping to read the index") is accepted and implied: movi_index_load
+        // always maps the file and uploads the rows straight from the page cache
+                if (has("bin-width")) o.bin_width = (size_t)to_int("bin-width", val("bin-width"));
         // movi_parser.cpp:353-355 applies set_count, set_zml, set_pml in this order and each setter
         // clears the other query types (movi_options.hpp:108-110), so the last one applied wins
         // (the "only specify count or pml" check at :407-410 can never fire)

@@ -415,3 +415,12 @@ def test_stdout_and_view_on_a_multi_chunk_file(movi_bin, tmp_path):
     assert run(["query", "-i", IDX[6], "-r", str(path), "-n", "-o", str(tmp_path / "o")]).returncode == 0
     v = run(["view", "--bpf", str(tmp_path / "o.pml.bpf")])
     assert v.returncode == 0 and v.stdout == file_order
+
+
+def test_cli_accepts_mmap_flag(movi_bin):
+    """`movi query --mmap` (the reference's "use memory mapping to read the index"): accepted, same bytes -- the index file
+    is always mapped and its rows uploaded from the page cache (movi_index_load)."""
+    base = ["query", "--index", IDX[6], "--read", os.path.join(GOLDEN, "sample.fastq"), "--pml", "--no-prefetch", "--stdout"]
+    a, b = run(base), run(base + ["--mmap"])
+    assert a.returncode == 0 and b.returncode == 0, (a.stderr, b.stderr)
+    assert a.stdout == b.stdout and len(a.stdout) > 0

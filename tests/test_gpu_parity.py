@@ -1005,3 +1005,34 @@ def test_overlapped_host_path_large(built_lib):
     got, st = gpu.query_pml_packed(pb, offs, out=out)
     assert (out == exp).all()
     assert (st.bases, st.fast_forwards, st.scans, st.repositions) == (est.bases, est.fast_forwards, est.scans, est.repositions)
+
+
+def test_index_load_maps_the_file(built_lib, golden_image, tmp_path):
+    """movi_index_load maps the index file and uploads the rows in pieces from the mapping: a table of several pieces
+    (200 MB: four 64 MiB pieces, the last one partial) must arrive byte for byte, and truncated / empty files fail cleanly."""
+    import torch
+    import movi_amd
+    from tools import synth
+    six = synth.synth_index(25_000_000, mode=6, seed=77)
+    img = six.image()
+    d = tmp_path / "idx"
+    d.mkdir()
+    np.asarray(img).tofile(str(d / "index.movi"))
+    ix = movi_amd.MoveIndex.load(str(d))
+    _, _, off, nb = movi_amd.parse_index_image(img)
+    ptr, n = ix.device_rows()
+    assert n == nb == 25_000_000 * 8
+    got = torch.empty(n, dtype=torch.uint8, device="cuda")
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    assert hip.hipMemcpy(C.c_void_p(got.data_ptr()), C.c_void_p(ptr), C.c_size_t(n), 3) == 0     # device to device
+    assert (got.cpu().numpy() == np.frombuffer(img, np.uint8, count=nb, offset=off)).all()
+    ix.close()
+    (d / "index.movi").write_bytes(bytes(np.asarray(img)[: off + 1000]))
+    with pytest.raises(movi_amd.MoviError) as e:
+        movi_amd.MoveIndex.load(str(d))
+    assert e.value.code == -2
+    (d / "index.movi").write_bytes(b"")
+    with pytest.raises(movi_amd.MoviError) as e:
+        movi_amd.MoveIndex.load(str(d))
+    assert e.value.code == -3
