@@ -107,6 +107,8 @@ typedef struct movi_query_stats {
     uint64_t lane_steps;              /* lane state machines only: iterations in which a lane had work ...   */
     uint64_t wave_steps;              /* ... and iterations run by its wavefront: SIMT efficiency =
                                        * lane_steps / (64 * wave_steps); 0 / 0 from the other kernels        */
+    uint64_t segments;                /* PML, segment-parallel path ("seg_len"): segments the reads were cut into (0: path not taken) */
+    uint64_t rewalked;                /* ... and reads walked again from end to end because a boundary did not fall into step       */
 } movi_query_stats_t;
 
 const char *movi_last_error(void);
@@ -245,7 +247,10 @@ int movi_host_unregister(void *p);
  * (0 = uncapped; variant 13: 0 = its default of 9), "idx64" (1 = run the kernel instantiations for
  * tables of 2^32 rows and more, whatever the size: a test hook), "release_scratch" (any value: frees the
  * device staging buffers that the *_host entry points keep, grow-only, across calls), "pipe_chunk_bases"
- * (bases per chunk of the overlapped host path, 0 = its own policy: a test hook). */
+ * (bases per chunk of the overlapped host path, 0 = its own policy: a test hook), "seg_len" (PML: batches whose mean
+ * read length is at least twice this many bases are walked segment-parallel -- every read cut into segments of about
+ * seg_len bases walked by their own lanes, stitched where the walks fall into step, reads that do not walked again:
+ * identical results; default 2048, 0 = off, else a multiple of 32). */
 int movi_set_option(movi_index_t *ix, const char *key, int64_t value);
 
 /* ---- ZML (Ziv-Merhav cross parse) ---------------------------------------------- */

@@ -48,6 +48,8 @@ class QueryStatsC(C.Structure):
         ("errors", C.c_uint64),
         ("lane_steps", C.c_uint64),
         ("wave_steps", C.c_uint64),
+        ("segments", C.c_uint64),
+        ("rewalked", C.c_uint64),
     ]
 
 

@@ -100,6 +100,7 @@ struct movi_index {
     enum { kBases = 0, kOffs, kErr, kOut, kA, kB, kS, kScratchSlots };
     void *scratch[kScratchSlots] = {};
     size_t scratch_cap[kScratchSlots] = {};
+    SegWorkspace seg_ws;             // segment-parallel long reads (launch_pml): device workspace of the handle's own calls
     // the overlapped form of the *_host entry points (page-locked caller buffers, movi_host_alloc): kPipeSlots chunks in
     // flight, each on its own stream with its own device staging, counters and a small page-locked block for what
     // travels with a chunk (relative offsets up; error bytes, per-read results and counters down)
@@ -110,6 +111,7 @@ struct movi_index {
         void *d[kScratchSlots] = {};
         size_t cap[kScratchSlots] = {};
         DevStats *d_stats = nullptr;
+        SegWorkspace seg_ws;                     // segment-parallel long reads: this slot's device workspace
         uint8_t *h = nullptr;
         size_t h_cap = 0;
     };
@@ -588,6 +590,12 @@ int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
         ix->pipe_chunk_bases = (uint64_t)value;
         return MOVI_OK;
     }
+    if (!strcmp(key, "seg_len")) {                           // segment-parallel long reads (PML): 0 = off
+        if (value != 0 && (value < 32 || value > (1 << 24) || (value & 31) != 0))
+            return fail(MOVI_ERR_ARG, "seg_len must be 0 (off) or a multiple of 32 in [32, 2^24]");
+        ix->cfg.seg_len = (int)value;
+        return MOVI_OK;
+    }
     if (!strcmp(key, "waves_per_cu")) {
         if (value < 0 || value > 32) return fail(MOVI_ERR_ARG, "waves_per_cu must be in [0,32]");
         ix->cfg.waves_per_cu = (int)value;
@@ -600,9 +608,10 @@ int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
 
 static int ml_device(bool zml, movi_index_t *ix, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
                      uint64_t n_bases, uint16_t *d_out, uint8_t *d_read_err, const uint32_t *d_read_order, void *stream,
-                     const ClsArgs &cls = ClsArgs(), DevStats *d_stats = nullptr) {
+                     const ClsArgs &cls = ClsArgs(), DevStats *d_stats = nullptr, SegWorkspace *seg_ws = nullptr) {
     if (!ix) return fail(MOVI_ERR_ARG, "index handle is NULL");
-    if (!d_stats) d_stats = ix->d_stats;                     // (the pipelined host path counts per chunk in flight)
+    if (!d_stats) d_stats = ix->d_stats;                     // (the pipelined host path counts per chunk in flight ...
+    if (!seg_ws) seg_ws = &ix->seg_ws;                       //  ... and keeps a segment workspace per chunk in flight)
     if (!zml && !mode_has_thresholds(ix->desc.mode))
         return fail(MOVI_ERR_ARG, "PML needs thresholds: on a `regular`, `blocked` or `sampled` index the reference repositions "
                                   "randomly (reposition_randomly), which cannot be reproduced; use --zml or --count, or a "
@@ -619,7 +628,7 @@ static int ml_device(bool zml, movi_index_t *ix, const uint8_t *d_bases, const u
                            d_read_order, ix->cfg, s));
     else
         HIP_TRY(launch_pml(ix->kmode, ix->dev, d_bases, d_offsets, n_reads, n_bases, d_out, d_read_err, d_stats,
-                           d_read_order, ix->cfg, s, cls));
+                           d_read_order, ix->cfg, s, cls, seg_ws));
     return MOVI_OK;
 }
 
@@ -648,6 +657,8 @@ int movi_last_stats(movi_index_t *ix, void *stream, movi_query_stats_t *stats) {
     stats->errors = h.errors;
     stats->lane_steps = h.lane_steps;
     stats->wave_steps = h.wave_steps;
+    stats->segments = h.segments;
+    stats->rewalked = h.rewalked;
     return MOVI_OK;
 }
 
@@ -696,6 +707,7 @@ struct ChunkCtx {
     void **d = nullptr;
     size_t *cap = nullptr;
     uint8_t *h_small = nullptr;
+    SegWorkspace *seg_ws = nullptr;
     bool async = false;
     hipError_t alloc(int slot, size_t bytes, void **out) {
         hipError_t e = grow(&d[slot], &cap[slot], bytes);
@@ -739,8 +751,12 @@ static void release_scratch(movi_index *ix) {
         (void)hipStreamDestroy(ix->pipe_up);
         ix->pipe_up = nullptr;
     }
+    if (ix->seg_ws.buf) (void)hipFree(ix->seg_ws.buf);
+    ix->seg_ws = SegWorkspace();
     for (auto &sl : ix->pipe) {
         if (sl.s) (void)hipStreamSynchronize(sl.s);
+        if (sl.seg_ws.buf) (void)hipFree(sl.seg_ws.buf);
+        sl.seg_ws = SegWorkspace();
         for (int k = 0; k < movi_index::kScratchSlots; k++) {
             if (sl.d[k]) (void)hipFree(sl.d[k]);
             sl.d[k] = nullptr;
@@ -785,6 +801,8 @@ void add_stats(movi_query_stats_t *acc, uint64_t nb, const DevStats &h) {
     acc->errors += h.errors;
     acc->lane_steps += h.lane_steps;
     acc->wave_steps += h.wave_steps;
+    acc->segments += h.segments;
+    acc->rewalked += h.rewalked;
 }
 
 // One kind of query behind a *_host entry point:
@@ -802,6 +820,7 @@ int run_chunked(movi_index *ix, const uint8_t *h_bases, const uint64_t *h_offset
     ctx.d_stats = ix->d_stats;
     ctx.d = ix->scratch;
     ctx.cap = ix->scratch_cap;
+    ctx.seg_ws = &ix->seg_ws;
     uint64_t first = 0;
     while (first < n_reads) {
         uint64_t last = first + 1;
@@ -840,6 +859,8 @@ int run_chunked(movi_index *ix, const uint8_t *h_bases, const uint64_t *h_offset
             stats->errors += st.errors;
             stats->lane_steps += st.lane_steps;
             stats->wave_steps += st.wave_steps;
+            stats->segments += st.segments;
+            stats->rewalked += st.rewalked;
         }
         first = last;
     }
@@ -900,6 +921,7 @@ int run_pipelined(movi_index *ix, const uint8_t *h_bases, const uint64_t *h_offs
         ctx.d = sl.d;
         ctx.cap = sl.cap;
         ctx.h_small = sl.h + off_small(nr);
+        ctx.seg_ws = &sl.seg_ws;
         ctx.async = true;
         return ctx;
     };
@@ -1056,7 +1078,8 @@ static int ml_host(bool zml, movi_index_t *ix, const uint8_t *h_bases, const uin
     struct { void *p; } d_out{};
     auto launch = [&](ChunkCtx &c, const uint8_t *db, const uint64_t *dof, uint64_t nr, uint64_t nb, uint8_t *derr) -> int {
         HIP_TRY(c.alloc(movi_index::kOut, nb * 2, &d_out.p));
-        return ml_device(zml, ix, db, dof, nr, nb, static_cast<uint16_t *>(d_out.p), derr, nullptr, c.s, ClsArgs(), c.d_stats);
+        return ml_device(zml, ix, db, dof, nr, nb, static_cast<uint16_t *>(d_out.p), derr, nullptr, c.s, ClsArgs(), c.d_stats,
+                         c.seg_ws);
     };
     // (the results are found through the chunk's own staging: with chunks in flight, launch() of the next chunk has
     // run before fetch() of this one)

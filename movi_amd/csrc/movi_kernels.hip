@@ -744,12 +744,19 @@ __device__ __forceinline__ uint2 win_sel(const uint2 (&w)[4], uint32_t q) {
 //     busy lanes; one parked iteration in ~190 is the cheaper price.
 //   * Results of a read (error byte, bins, zero-fill on failure) are written when it ends, not after the loop.
 // `order` is not supported (longest-first ordering is what refill replaces).
-template <int MODE, typename IdxT, int HA, int CLS, int SEP, int REFILL>
+// SEG (segment-parallel long reads, movi_kernels.hpp): 0 = a lane walks a read; 1 = a lane walks one SEGMENT of a read
+// from the state every read starts in (K1: its "read" is the segment -- bases at seg_in, PMLs to seg_out --, it leaves a
+// checkpoint of its state and counters every 32 bases and its final state, reports an invariant violation in its
+// segment's flag instead of err[] / zero-filling, and adds nothing to the global fast-forward / scan counters: which
+// part of its work belongs to the read's real walk is only known after K2); 2 = whole reads again, but only those in
+// seg.read_fail (K3).
+template <int MODE, typename IdxT, int HA, int CLS, int SEP, int REFILL, int SEG = 0>
 __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8_t *__restrict__ bases,
                                                        const uint64_t *__restrict__ offs, uint64_t n_reads,
                                                        uint16_t *__restrict__ out, uint8_t *__restrict__ err,
                                                        DevStats *stats, const uint32_t *__restrict__ order,
-                                                       ClsArgs cls) {
+                                                       ClsArgs cls, SegArgs seg) {
+    static_assert(SEG == 0 || (CLS == 0 && REFILL == 0), "segments: plain PML, no refill");
     enum : uint32_t { sFF = 0, sDown = 1, sUp = 2, sDone = 3, sLoad = 4 };   // sLoad (REFILL): first bases of a new read in flight
     __shared__ uint8_t s_code[256];
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = ix.code_of[i];
@@ -763,10 +770,11 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
     const uint32_t off0 = row_n<MODE>(row_r1) - 1;
 
     // ---- the lane's current read
-    const bool valid = !REFILL && t < n_reads;
-    uint64_t rid = (valid && order) ? order[t] : t;
-    uint64_t beg = valid ? offs[rid] : 0;
-    uint32_t len = valid ? (uint32_t)(offs[rid + 1] - beg) : 0;   // reads are shorter than 2^32 (checked on the host)
+    const bool valid = !REFILL && (SEG == 1 ? t < *seg.n_seg : (t < n_reads && (SEG != 2 || seg.read_fail[t] != 0)));
+    uint64_t rid = (valid && order && SEG == 0) ? order[t] : t;
+    uint64_t beg = valid ? (SEG == 1 ? seg.seg_in[rid] : offs[rid]) : 0;
+    uint32_t len = valid ? (SEG == 1 ? seg.seg_len[rid] : (uint32_t)(offs[rid + 1] - beg)) : 0;   // reads are shorter than 2^32 (checked on the host)
+    uint64_t obeg = (SEG == 1 && valid) ? seg.seg_out[rid] : beg;   // where the read's (segment's) PMLs go
     uint32_t packed_end = len & ~7u;
 
     // The 16 bases of steps kk .. kk+15 of the read (b, l) are the bytes [b + l - kk - 16, b + l - kk) of `bases`, last
@@ -809,8 +817,14 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
     // end of a read: what the reference's exception / output paths do with it
     ClsState cs;
     auto finish_read = [&]() {
+        if (SEG == 1) {                                   // K1: the segment's counters and how its walk ended
+            SegTot tt;
+            tt.ff = ff_total; tt.scan = scan_total; tt.repo = repo_total; tt.flag = failed;
+            seg.tot[rid] = tt;
+            return;
+        }
         if (failed && CLS != 2) {
-            for (uint32_t i = 0; i < len; ++i) out[beg + i] = 0;
+            for (uint32_t i = 0; i < len; ++i) out[obeg + i] = 0;
         }
         if (CLS) cs.store(cls, rid, failed != 0u);
         if (err) err[rid] = (uint8_t)failed;
@@ -978,10 +992,24 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
         repo_total += mism;
         scan_total += scanning;
         off = ffm ? off - n : (hit ? (isDown ? 0u : n - 1) : off);        // read_processor.cpp:223
+        const uint32_t off_pre = off;                                     // (before the LF to the next base: what K1 records)
         off += lf ? roff : 0u;
         if (emit) {
             const uint32_t val = ml > 65535u ? 65535u : ml;               // MoveQuery::add_ml
-            uint16_t *O = out + beg;
+            uint16_t *O = out + obeg;
+            if (SEG == 1) {
+                if ((k & 31u) == 31u) {
+                    SegCkpt ck;
+                    ck.idx = (uint64_t)need; ck.off = off_pre; ck.ml = ml;
+                    ck.ff = ff_total; ck.scan = scan_total; ck.repo = repo_total; ck.pad_ = 0;
+                    seg.ckpt[(obeg + k) >> 5] = ck;
+                }
+                if (k + 1 == len) {
+                    SegFin fn;
+                    fn.idx = (uint64_t)need; fn.off = off_pre; fn.ml = ml;
+                    seg.fin[rid] = fn;
+                }
+            }
             if (CLS) cs.add(val, k, len, cls.bin_width, cls.thr);
             if (CLS == 2) {
                 // verdict bins only
@@ -1038,7 +1066,7 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
             const uint64_t swm = __ballot(sw != 0u);
             if (swm != 0ull) {
                 if (sw) {
-                    rid = rid_n; beg = nbeg; len = nend_lo - (uint32_t)nbeg; packed_end = len & ~7u;
+                    rid = rid_n; beg = nbeg; obeg = nbeg; len = nend_lo - (uint32_t)nbeg; packed_end = len & ~7u;
                     k = 0; ml = 0; ff_run = 0; off = off0; need = r1; failed = 0;
                     if (CLS) { cs = ClsState(); cs.init(len, cls.bin_width); }
                     if (len > 0) {
@@ -1063,13 +1091,15 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
         if (want_nx) load_pair_at(nx_e, nx0, nx1);
     }
     if (!REFILL && valid) finish_read();
-    const uint32_t ffw = wave_sum(ff_total), scw = wave_sum(scan_total), rpw = wave_sum(repo_total),
-                   erw = wave_sum(err_total);
-    if ((threadIdx.x & 63) == 0 && stats) {
-        if (ffw) atomicAdd(&stats->fast_forwards, (unsigned long long)ffw);
-        if (scw) atomicAdd(&stats->scans, (unsigned long long)scw);
-        if (rpw) atomicAdd(&stats->repositions, (unsigned long long)rpw);
-        if (erw) atomicAdd(&stats->errors, (unsigned long long)erw);
+    if (SEG != 1) {
+        const uint32_t ffw = wave_sum(ff_total), scw = wave_sum(scan_total), rpw = wave_sum(repo_total),
+                       erw = wave_sum(err_total);
+        if ((threadIdx.x & 63) == 0 && stats) {
+            if (ffw) atomicAdd(&stats->fast_forwards, (unsigned long long)ffw);
+            if (scw) atomicAdd(&stats->scans, (unsigned long long)scw);
+            if (rpw) atomicAdd(&stats->repositions, (unsigned long long)rpw);
+            if (erw) atomicAdd(&stats->errors, (unsigned long long)erw);
+        }
     }
     const uint32_t lsw = wave_sum(lane_steps);
     if ((threadIdx.x & 63) == 0 && stats) {
@@ -1078,9 +1108,297 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
     }
 }
 
+// ------------------------------------------------------------- segment-parallel long reads (movi_kernels.hpp)
+
+// Segments of a read of `len` bases: n = len / seg_len of them (1 below 2 x seg_len), each T bases -- a multiple of
+// 32, so that every checkpoint sits at an emission index k with k % 32 == 31 in the read's as in the segment's count --
+// the last one whatever is left.
+__device__ __forceinline__ void seg_shape(uint64_t len, uint32_t seg_len, uint64_t &n, uint64_t &T) {
+    n = len >= 2ull * seg_len ? len / seg_len : 1;
+    T = (((len + n - 1) / n) + 31) & ~31ull;
+    if (T == 0) T = 32;
+    n = len ? (len + T - 1) / T : 1;
+}
+
+__global__ __launch_bounds__(256) void seg_count_kernel(const uint64_t *__restrict__ offs, uint64_t n_reads, uint32_t seg_len,
+                                                       uint64_t *__restrict__ n_of) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > n_reads) return;
+    uint64_t n = 0, T = 0;
+    if (t < n_reads) seg_shape(offs[t + 1] - offs[t], seg_len, n, T);
+    n_of[t] = n;                                          // entry n_reads = 0: its exclusive sum is the total
+}
+
+// Segment j of read t covers the emission indexes [j T, min(len, (j + 1) T)): the bases [len - k_end, len - k_begin) of
+// the read, PMLs to offs[t] + k_begin.
+__global__ __launch_bounds__(256) void seg_fill_kernel(const uint64_t *__restrict__ offs, uint64_t n_reads, uint32_t seg_len,
+                                                      const uint64_t *__restrict__ first, uint64_t *__restrict__ seg_in,
+                                                      uint64_t *__restrict__ seg_out, uint32_t *__restrict__ seg_l,
+                                                      uint32_t *__restrict__ seg_j) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_reads) return;
+    const uint64_t beg = offs[t], len = offs[t + 1] - beg;
+    uint64_t n = 0, T = 0;
+    seg_shape(len, seg_len, n, T);
+    const uint64_t s0 = first[t];
+    for (uint64_t j = 0; j < n; ++j) {
+        const uint64_t k0 = j * T, k1 = (k0 + T < len) ? k0 + T : len;
+        seg_in[s0 + j] = beg + len - k1;
+        seg_out[s0 + j] = beg + k0;
+        seg_l[s0 + j] = (uint32_t)(k1 - k0);
+        seg_j[s0 + j] = (uint32_t)(j > 0xFFFFFFFFull ? 0xFFFFFFFFull : j);
+    }
+}
+
+// K2: one lane per segment that is not the first of its read.  It takes up the walk where the segment before left it
+// (that segment's final state is the read's real state there IF its own boundary fell into step -- K3 checks the
+// chain), walks into this segment base by base -- the plain base-synchronous automaton of pml_kernel<MODE, 0> --
+// overwriting the speculative PMLs, and stops at the first checkpoint (every 32 bases, and the segment's end) where its
+// row, offset and match length equal what the speculative lane recorded: the rest of the segment is then exact as it
+// stands.  What it counted up to there plus what the speculative lane counted after is the segment's share of the
+// read's fast-forwards / scans / repositions.  No meeting point before the segment ends: flag 0, the read is walked again.
+template <int MODE>
+__global__ __launch_bounds__(256) void seg_stitch_kernel(DevIndex ix, const uint8_t *__restrict__ bases, SegArgs seg,
+                                                        const uint32_t *__restrict__ seg_j, uint16_t *__restrict__ out,
+                                                        SegTot *__restrict__ true_tot, uint8_t *__restrict__ in_step) {
+    __shared__ uint8_t s_code[256];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = ix.code_of[i];
+    __syncthreads();
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool mine = s < *seg.n_seg && seg_j[s] != 0;
+    const EndThr ethr = end_thresholds(ix);
+    uint32_t ff_total = 0, scan_total = 0, repo_total = 0, failed = 0, met = 0;
+    bool live0 = mine;
+    SegTot spec{};
+    if (mine) {
+        spec = seg.tot[s];
+        if (spec.flag != 0u || seg.tot[s - 1].flag != 0u) live0 = false;     // a speculative walk broke an invariant: K3 decides
+    }
+    const uint64_t len = live0 ? (uint64_t)seg.seg_len[s] : 0;
+    const uint8_t *R = bases + (live0 ? seg.seg_in[s] : 0);
+    const uint64_t obeg = live0 ? seg.seg_out[s] : 0;
+    uint16_t *O = out + obeg;
+    uint64_t idx = 0;
+    uint32_t off = 0, ml = 0;
+    if (live0) {
+        const SegFin f = seg.fin[s - 1];
+        idx = f.idx; off = f.off; ml = f.ml;
+    }
+    uint2 row = load_row<MODE>(ix.rows, idx);
+    for (uint64_t k = 0; wave_any(k < len && failed == 0u && met == 0u); ++k) {
+        bool live = k < len && failed == 0u && met == 0u;
+        {
+            const uint32_t e = lf_step<MODE>(ix, live, idx, off, row, ff_total);
+            if (e) { failed = e; live = false; }
+        }
+        uint32_t a = 0xFFu;
+        if (live) a = s_code[R[len - 1 - k]];
+        const uint32_t rc = row_c<MODE>(row);
+        uint32_t dir = 0;
+        if (live) {
+            if (a == 0xFFu) {
+                ml = 0;
+            } else if (rc == a) {
+                ml += 1;
+            } else {                                      // reposition_thresholds, as in pml_kernel
+                repo_total += 1;
+                ml = 0;
+                uint32_t down;
+                if (idx == ix.end_bwt_idx) {
+                    down = (off >= end_threshold(ix.sep, ethr, a)) ? 1u : 0u;
+                } else if (ix.sep && rc == 0u) {
+                    down = (off >= separator_threshold(ix, idx, a)) ? 1u : 0u;
+                } else {
+                    const uint32_t kk = thr_slot(ix.sep, a, rc);
+                    const uint32_t thr = row_thr<MODE>(row, kk > 2u ? 2u : kk) ? row_n<MODE>(row) : 0u;
+                    down = (off >= thr) ? 1u : 0u;
+                }
+                dir = down ? 1u : 2u;
+                if (down && idx == ix.r - 1) { failed = kErrNoRunBelow; dir = 0; live = false; }
+                if (!down && idx == 0) { failed = kErrNoRunAbove; dir = 0; live = false; }
+            }
+        }
+        uint32_t scanning = dir;
+        while (wave_any(scanning != 0u)) {
+            if (scanning) {
+                uint64_t jj = (scanning == 1u) ? idx + 1 : idx - 1;
+                if (scanning == 1u) { if (jj >= ix.r) jj = ix.r - 1; }
+                else if (jj > idx) jj = 0;
+                const uint2 w = load_row<MODE>(ix.rows, jj);
+                scan_total += 1;
+                idx = (scanning == 1u) ? idx + 1 : idx - 1;
+                row = w;
+                const uint32_t c = row_c<MODE>(row);
+                if (c == a) {
+                    scanning = 0;
+                } else if (scanning == 1u ? (idx >= ix.r - 1) : (idx == 0)) {
+                    failed = scanning == 1u ? kErrNoRunBelow : kErrNoRunAbove;
+                    scanning = 0;
+                    live = false;
+                }
+            }
+        }
+        if (dir == 1u) off = 0;
+        if (dir == 2u) off = row_n<MODE>(row) - 1;
+        if (live) {
+            O[k] = (uint16_t)(ml > 65535u ? 65535u : ml);
+            const bool at_ck = (k & 31ull) == 31ull, at_end = k + 1 == len;
+            if (at_ck || at_end) {
+                uint64_t cidx; uint32_t coff, cml, cff, cscan, crepo;
+                if (at_ck) {
+                    const SegCkpt c = seg.ckpt[(obeg + k) >> 5];
+                    cidx = c.idx; coff = c.off; cml = c.ml; cff = c.ff; cscan = c.scan; crepo = c.repo;
+                } else {
+                    const SegFin f = seg.fin[s];
+                    cidx = f.idx; coff = f.off; cml = f.ml; cff = spec.ff; cscan = spec.scan; crepo = spec.repo;
+                }
+                if (cidx == idx && coff == off && cml == ml) {
+                    met = 1;
+                    SegTot tt;
+                    tt.ff = ff_total + (spec.ff - cff); tt.scan = scan_total + (spec.scan - cscan);
+                    tt.repo = repo_total + (spec.repo - crepo); tt.flag = 0;
+                    true_tot[s] = tt;
+                }
+            }
+        }
+    }
+    if (mine) in_step[s] = (uint8_t)met;
+}
+
+// K3, first half: one lane per read.  All of its boundaries in step and no invariant violation in any segment: the PMLs
+// stand, the read's counters are its first segment's plus every later segment's real share, err = 0.  Otherwise the read
+// goes on the list of pml_kernel_flatp<..., SEG = 2>, which walks it from end to end (and reports its error, if any).
+__global__ __launch_bounds__(256) void seg_finalize_kernel(const uint64_t *__restrict__ first, uint64_t n_reads,
+                                                          const SegTot *__restrict__ tot, const SegTot *__restrict__ true_tot,
+                                                          const uint8_t *__restrict__ in_step, uint8_t *__restrict__ read_fail,
+                                                          uint8_t *__restrict__ err, DevStats *stats) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t ff = 0, scan = 0, repo = 0, nseg = 0, nbad = 0;
+    if (t < n_reads) {
+        const uint64_t s0 = first[t], s1 = first[t + 1];
+        uint32_t bad = tot[s0].flag != 0u;
+        ff = tot[s0].ff; scan = tot[s0].scan; repo = tot[s0].repo;
+        for (uint64_t s = s0 + 1; s < s1; ++s) {
+            bad |= (uint32_t)(in_step[s] == 0);
+            const SegTot tt = true_tot[s];
+            ff += tt.ff; scan += tt.scan; repo += tt.repo;
+        }
+        read_fail[t] = (uint8_t)bad;
+        if (bad) { ff = 0; scan = 0; repo = 0; }
+        else if (err) err[t] = 0;
+        nseg = (uint32_t)(s1 - s0);
+        nbad = bad;
+    }
+    const uint32_t ffw = wave_sum(ff), scw = wave_sum(scan), rpw = wave_sum(repo), sgw = wave_sum(nseg), bdw = wave_sum(nbad);
+    if ((threadIdx.x & 63) == 0 && stats) {
+        if (ffw) atomicAdd(&stats->fast_forwards, (unsigned long long)ffw);
+        if (scw) atomicAdd(&stats->scans, (unsigned long long)scw);
+        if (rpw) atomicAdd(&stats->repositions, (unsigned long long)rpw);
+        if (sgw) atomicAdd(&stats->segments, (unsigned long long)sgw);
+        if (bdw) atomicAdd(&stats->rewalked, (unsigned long long)bdw);
+    }
+}
+
+namespace {
+size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+}
+
+// The segmented PML path: plan (count, scan, fill), K1, K2, K3.  Everything on `stream`, nothing read back: the grids are
+// sized for the most segments the batch could have (n_reads + n_bases / seg_len) and surplus lanes leave at once.
+static hipError_t launch_pml_segmented(const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
+                                       uint64_t n_bases, uint16_t *d_out, uint8_t *d_err, DevStats *d_stats,
+                                       const LaunchCfg &cfg, hipStream_t stream, SegWorkspace *ws, bool big_batch_cap) {
+    const uint32_t S = (uint32_t)cfg.seg_len;
+    const uint64_t max_seg = n_reads + n_bases / S + 1;
+    if (max_seg > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    const uint64_t n_ck = (n_bases >> 5) + 2;
+    size_t temp_bytes = 0;
+    hipError_t e = hipcub::DeviceScan::ExclusiveSum(nullptr, temp_bytes, (uint64_t *)nullptr, (uint64_t *)nullptr,
+                                                    (int)(n_reads + 1), stream);
+    if (e != hipSuccess) return e;
+    // carve the workspace
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += align_up(bytes ? bytes : 8); return o; };
+    const size_t o_nof = take((n_reads + 1) * 8), o_first = take((n_reads + 1) * 8), o_temp = take(temp_bytes),
+                 o_in = take(max_seg * 8), o_out = take(max_seg * 8), o_len = take(max_seg * 4), o_j = take(max_seg * 4),
+                 o_fin = take(max_seg * sizeof(SegFin)), o_tot = take(max_seg * sizeof(SegTot)),
+                 o_true = take(max_seg * sizeof(SegTot)), o_step = take(max_seg), o_fail = take(n_reads),
+                 o_ck = take(n_ck * sizeof(SegCkpt));
+    if (ws->cap < off) {
+        if (ws->buf) (void)hipFree(ws->buf);
+        ws->buf = nullptr;
+        ws->cap = 0;
+        const size_t want = off + (off >> 3);
+        e = hipMalloc(&ws->buf, want);
+        if (e != hipSuccess) return e;
+        ws->cap = want;
+    }
+    uint8_t *B = static_cast<uint8_t *>(ws->buf);
+    uint64_t *n_of = reinterpret_cast<uint64_t *>(B + o_nof), *first = reinterpret_cast<uint64_t *>(B + o_first);
+    uint64_t *seg_in = reinterpret_cast<uint64_t *>(B + o_in), *seg_out = reinterpret_cast<uint64_t *>(B + o_out);
+    uint32_t *seg_l = reinterpret_cast<uint32_t *>(B + o_len), *seg_j = reinterpret_cast<uint32_t *>(B + o_j);
+    SegTot *true_tot = reinterpret_cast<SegTot *>(B + o_true);
+    uint8_t *in_step = B + o_step, *read_fail = B + o_fail;
+    SegArgs seg;
+    seg.seg_in = seg_in; seg.seg_out = seg_out; seg.seg_len = seg_l; seg.n_seg = first + n_reads;
+    seg.ckpt = reinterpret_cast<SegCkpt *>(B + o_ck);
+    seg.fin = reinterpret_cast<SegFin *>(B + o_fin);
+    seg.tot = reinterpret_cast<SegTot *>(B + o_tot);
+    seg.read_fail = read_fail;
+    const unsigned bt256 = 256;
+    hipLaunchKernelGGL(seg_count_kernel, dim3((unsigned)((n_reads + 1 + bt256 - 1) / bt256)), dim3(bt256), 0, stream, d_offsets,
+                       n_reads, S, n_of);
+    e = hipcub::DeviceScan::ExclusiveSum(B + o_temp, temp_bytes, n_of, first, (int)(n_reads + 1), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(seg_fill_kernel, dim3((unsigned)((n_reads + bt256 - 1) / bt256)), dim3(bt256), 0, stream, d_offsets,
+                       n_reads, S, first, seg_in, seg_out, seg_l, seg_j);
+    // K1 and K3b: the window-parallel lane state machine in blocks of one wavefront, capped like any big batch
+    const int bt = 64;
+    auto lds_for = [&](uint64_t lanes) -> size_t {
+        int wpc = cfg.waves_per_cu;
+        if (wpc < 0) wpc = 0;
+        if (cfg.waves_per_cu == 0 && big_batch_cap && lanes > (uint64_t)cfg.num_cus * 64u * 18u) wpc = kCapWaves;
+        if (wpc > 0 && wpc < 32) return ((163840u / (unsigned)wpc) & ~1023u) - 1024u;
+        return 0;
+    };
+    const ClsArgs cls;
+    const uint32_t *d_order = nullptr;
+#define MOVI_LAUNCH_SEG(SEGV, LANES, ...)                                                                             \
+    do {                                                                                                              \
+        const size_t dyn_lds = lds_for(LANES);                                                                        \
+        if (dyn_lds > 65536) {                                                                                        \
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&__VA_ARGS__),                                     \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds);                        \
+            if (e != hipSuccess) return e;                                                                            \
+        }                                                                                                             \
+        hipLaunchKernelGGL((__VA_ARGS__), dim3((unsigned)(((LANES) + bt - 1) / bt)), dim3(bt), dyn_lds, stream, ix,   \
+                           d_bases, d_offsets, (uint64_t)(LANES), d_out, d_err, d_stats, d_order, cls, seg);          \
+    } while (0)
+#define MOVI_LAUNCH_SEG_T(SEGV, LANES)                                                                                \
+    do {                                                                                                              \
+        if (ix.idx32) {                                                                                               \
+            if (ix.sep) MOVI_LAUNCH_SEG(SEGV, LANES, pml_kernel_flatp<6, uint32_t, -1, 0, 1, 0, SEGV>);               \
+            else MOVI_LAUNCH_SEG(SEGV, LANES, pml_kernel_flatp<6, uint32_t, -1, 0, 0, 0, SEGV>);                      \
+        } else {                                                                                                      \
+            if (ix.sep) MOVI_LAUNCH_SEG(SEGV, LANES, pml_kernel_flatp<6, uint64_t, -1, 0, 1, 0, SEGV>);               \
+            else MOVI_LAUNCH_SEG(SEGV, LANES, pml_kernel_flatp<6, uint64_t, -1, 0, 0, 0, SEGV>);                      \
+        }                                                                                                             \
+    } while (0)
+    MOVI_LAUNCH_SEG_T(1, max_seg);
+    hipLaunchKernelGGL(seg_stitch_kernel<6>, dim3((unsigned)((max_seg + bt256 - 1) / bt256)), dim3(bt256), 0, stream, ix, d_bases,
+                       seg, seg_j, d_out, true_tot, in_step);
+    hipLaunchKernelGGL(seg_finalize_kernel, dim3((unsigned)((n_reads + bt256 - 1) / bt256)), dim3(bt256), 0, stream, first, n_reads,
+                       seg.tot, true_tot, in_step, read_fail, d_err, d_stats);
+    MOVI_LAUNCH_SEG_T(2, n_reads);
+#undef MOVI_LAUNCH_SEG_T
+#undef MOVI_LAUNCH_SEG
+    return hipGetLastError();
+}
+
 hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets,
                       uint64_t n_reads, uint64_t n_bases, uint16_t *d_out, uint8_t *d_err, DevStats *d_stats,
-                      const uint32_t *d_order, const LaunchCfg &cfg, hipStream_t stream, const ClsArgs &cls) {
+                      const uint32_t *d_order, const LaunchCfg &cfg, hipStream_t stream, const ClsArgs &cls,
+                      SegWorkspace *seg_ws) {
     if (n_reads == 0) return hipSuccess;
     // 0 = PML vector only, 1 = vector + classification bins, 2 = bins only
     const int cm = cls.bin_width == 0 ? 0 : (d_out ? 1 : 2);
@@ -1123,6 +1441,13 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     if ((v == 10 || v == 13) && (ix.r < 8 || n_bases < 16)) v = 7;           // the clamped window needs >= 4 rows, the
                                                                              // 16-base fetches >= 16 bytes of bases
     if (cm != 0 && (v == 0 || v == 7)) v = (v == 0 || ix.r < 8 || n_bases < 16) ? 1 : 10;   // the A/B kernels carry no fused bins
+    // Batches of long reads: segment-parallel (plain PML through the default kernel only).  One lane per read leaves the
+    // GPU short of walks -- 100 k reads are 6 wavefronts per CU, and a single 1 Mbp read holds its lane for 2 s --;
+    // cut into segments the same batch fills it like a batch of short reads.
+    if (seg_ws && cfg.seg_len >= 32 && cm == 0 && !d_order && wp && v == 10 && cfg.block_threads <= 64 &&
+        n_bases / n_reads >= 2ull * (uint64_t)cfg.seg_len && n_reads + n_bases / (uint64_t)cfg.seg_len < 0x7FFFFFF0ull)
+        return launch_pml_segmented(ix, d_bases, d_offsets, n_reads, n_bases, d_out, d_err, d_stats, cfg, stream, seg_ws,
+                                    cfg.pml_variant < 0 || cfg.pml_variant == 14);
     const int bt = cfg.block_threads > 0 ? cfg.block_threads : 64;           // one wavefront per block: finest dispatch grain
     uint64_t blocks = (n_reads + bt - 1) / bt;
     int wpc = cfg.waves_per_cu;
@@ -1144,8 +1469,12 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
         if (bpc < 1) bpc = 1;
         if (bpc < 32) dyn_lds = ((163840u / (unsigned)bpc) & ~1023u) - 1024u;
     }
+    const SegArgs no_seg;
     // every kernel that is handed more than 64 KiB of dynamic LDS must opt in first
-#define MOVI_LAUNCH_K(...)                                                                                  \
+#define MOVI_SEG_0
+#define MOVI_SEG_1 , no_seg
+#define MOVI_LAUNCH_K(...) MOVI_LAUNCH_KX(0, __VA_ARGS__)
+#define MOVI_LAUNCH_KX(X, ...)                                                                              \
     do {                                                                                                    \
         if (dyn_lds > 65536) {                                                                              \
             hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&__VA_ARGS__),               \
@@ -1160,7 +1489,7 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
                 grid.x = (unsigned)((uint64_t)mb * (uint64_t)cfg.num_cus);                                  \
         }                                                                                                   \
         hipLaunchKernelGGL((__VA_ARGS__), grid, block, dyn_lds, stream, ix, d_bases, d_offsets, n_reads,    \
-                           d_out, d_err, d_stats, d_order, cls);                                            \
+                           d_out, d_err, d_stats, d_order, cls MOVI_SEG_##X);                               \
     } while (0)
 #define MOVI_LAUNCH_PML(M, V, C) MOVI_LAUNCH_K(pml_kernel<M, V, C>)
 #ifndef MOVI_HA
@@ -1168,8 +1497,8 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
 #endif
 #define MOVI_LAUNCH_FLATP_H(M, H, C, S, R)                                                                  \
     do {                                                                                                    \
-        if (ix.idx32) MOVI_LAUNCH_K(pml_kernel_flatp<M, uint32_t, H, C, S, R>);                             \
-        else MOVI_LAUNCH_K(pml_kernel_flatp<M, uint64_t, H, C, S, R>);                                      \
+        if (ix.idx32) MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint32_t, H, C, S, R>);                         \
+        else MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint64_t, H, C, S, R>);                                  \
     } while (0)
 #define MOVI_LAUNCH_FLATP_R(M, C, S, R)                                                                     \
     do {                                                                                                    \
@@ -1196,6 +1525,9 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     else if (v == 7) MOVI_LAUNCH_FLAT(6); else MOVI_BY_CLS(MOVI_LAUNCH_FLATP, 6);
 #undef MOVI_LAUNCH_PML
 #undef MOVI_LAUNCH_K
+#undef MOVI_LAUNCH_KX
+#undef MOVI_SEG_0
+#undef MOVI_SEG_1
 #undef MOVI_LAUNCH_FLAT
 #undef MOVI_LAUNCH_FLATP
 #undef MOVI_LAUNCH_FLATP_S

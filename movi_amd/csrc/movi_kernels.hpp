@@ -50,6 +50,8 @@ struct DevStats {
     unsigned long long lane_steps;
     unsigned long long wave_steps;
     unsigned long long ticket;         // next unassigned read of the lane-refill kernels (zeroed with the counters)
+    unsigned long long segments;       // segment-parallel PML: segments walked, reads walked again
+    unsigned long long rewalked;
     unsigned long long pad_;
 };
 
@@ -64,6 +66,7 @@ struct LaunchCfg {
     int zml_variant = -1;  // -1 auto; 0 base-synchronous kernel, 1 lane state machine
     int num_cus = 256;
     int waves_per_cu = 0;  // 0 = auto (variant 10 on big batches and variant 13: kCapWaves; else no cap); else cap resident waves per CU by padding the block's LDS allocation
+    int seg_len = 2048;    // PML: batches whose mean read length is >= 2 x seg_len are walked segment-parallel (0 = never)
     int refill_blocks = 0; // variant 13: size of the persistent grid in blocks; 0 = num_cus x waves per CU (tests shrink it
                            // so that a few hundred reads already go through many refills per lane)
 };
@@ -78,11 +81,40 @@ struct ClsArgs {
     uint64_t *sum_max = nullptr;
 };
 
+// ---- segment-parallel long reads (PML) -------------------------------------------------------------------------
+// A long read is cut into segments of about seg_len bases, every segment walked by its own lane from the state every
+// read starts in (K1); then one lane per segment BOUNDARY continues the walk of the segment before across the
+// boundary until it is in step -- same row, offset and match length at one of the checkpoints the speculative lane
+// left every 32 bases -- with what that lane did (K2): from there on the two walks are the same walk.  A read all of
+// whose boundaries fell into step is exact; any other is walked again from end to end (K3).  tools/sync_study.py: on
+// 10 kbp reads with 8 % / 1 % / 0.1 % substitutions a walk started mid-read is in step after a median of 11 / 80 / 607
+// bases (maximum 107 / 665 / 4540).
+struct SegCkpt { uint64_t idx; uint32_t off, ml, ff, scan, repo, pad_; };   // state after a base (before the LF to the next) + the segment's counters so far
+struct SegFin { uint64_t idx; uint32_t off, ml; };                           // state after a segment's last base
+struct SegTot { uint32_t ff, scan, repo, flag; };                            // a segment's counters; flag = kErr* of the speculative walk
+struct SegArgs {
+    const uint64_t *seg_in = nullptr;     // per segment: byte offset of its bases ...
+    const uint64_t *seg_out = nullptr;    //   ... element offset of its first PML (emission order) ...
+    const uint32_t *seg_len = nullptr;    //   ... and its length
+    const uint64_t *n_seg = nullptr;      // device: number of segments
+    SegCkpt *ckpt = nullptr;              // [(seg_out + k) >> 5] for every k of a segment with k % 32 == 31
+    SegFin *fin = nullptr;
+    SegTot *tot = nullptr;
+    const uint8_t *read_fail = nullptr;   // K3: reads to walk again
+};
+
+// Device workspace of the segmented path, owned by whoever owns the stream (the handle; a pipeline slot): grow-only.
+struct SegWorkspace {
+    void *buf = nullptr;
+    size_t cap = 0;
+};
+
 // d_out == nullptr is allowed when cls.bin_width != 0: verdict bins only, no PML vector is written.
+// seg_ws != nullptr allows the segment-parallel path for batches of long reads (cfg.seg_len).
 hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets,
                       uint64_t n_reads, uint64_t n_bases, uint16_t *d_out, uint8_t *d_err, DevStats *d_stats,
                       const uint32_t *d_order, const LaunchCfg &cfg, hipStream_t stream,
-                      const ClsArgs &cls = ClsArgs());
+                      const ClsArgs &cls = ClsArgs(), SegWorkspace *seg_ws = nullptr);
 
 hipError_t launch_count(int mode, const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets,
                         uint64_t n_reads, uint64_t *d_matched, uint64_t *d_count, uint8_t *d_err,

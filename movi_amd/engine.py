@@ -91,6 +91,8 @@ class QueryStats:
         self.errors = int(c.errors)
         self.lane_steps = int(c.lane_steps)
         self.wave_steps = int(c.wave_steps)
+        self.segments = int(c.segments)
+        self.rewalked = int(c.rewalked)
 
     def __repr__(self):
         return "QueryStats(bases=%d, ff=%d, scans=%d, repositions=%d, errors=%d)" % (

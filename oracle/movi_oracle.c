@@ -471,6 +471,24 @@ int oracle_pml(const oracle_index *ix, const uint8_t *R, int64_t len, uint16_t *
     return ORACLE_OK;
 }
 
+/* oracle_pml that also records the walker's position (row, offset) after every base: for studies of
+ * how quickly walks started at different places of a read fall into step (tools/sync_study.py). */
+int oracle_pml_trace(const oracle_index *ix, const uint8_t *R, int64_t len, uint16_t *out,
+                     uint64_t *idx_out, uint32_t *off_out) {
+    strand_t s;
+    uint64_t ff = 0, sc = 0;
+    if (ix->mode == 5 || ix->mode == 3 || ix->mode == 2) return ORACLE_ERR_FORMAT;
+    if (len <= 0) return ORACLE_OK;
+    strand_reset(ix, &s, R, len, out);
+    while (s.pos_on_r > -1) {
+        int rc = process_char(ix, &s, &ff, &sc);
+        if (rc < 0) return rc;
+        idx_out[s.emitted - 1] = s.idx;
+        off_out[s.emitted - 1] = (uint32_t)s.offset;
+    }
+    return ORACLE_OK;
+}
+
 /* A batch, scheduled like ReadProcessor::process_latency_hiding
  * (src/read_processor.cpp:641-730): `strands` reads in flight per thread, one
  * base each per round, software prefetch of the next row (:719-722); OpenMP team

@@ -1036,3 +1036,95 @@ def test_index_load_maps_the_file(built_lib, golden_image, tmp_path):
     with pytest.raises(movi_amd.MoviError) as e:
         movi_amd.MoveIndex.load(str(d))
     assert e.value.code == -3
+
+
+# ---------------------------------------------------------------- segment-parallel long reads ("seg_len")
+
+@pytest.mark.parametrize("mode", [6, 8])
+@pytest.mark.parametrize("seg_len", [32, 64, 256, 1024])
+def test_segment_parallel_pml_vs_oracle(engines, mode, seg_len):
+    """Batches of long reads are cut into segments walked by their own lanes and stitched where the walks fall into step
+    (K1 / K2 / K3 of movi_kernels.hpp).  PMLs, error bytes and the fast-forward / scan / reposition counters must be
+    exactly those of the oracle and of the one-lane-per-read path, whatever the segment length; noisy reads stitch,
+    exact substrings mostly do not and go through the walk-again path."""
+    from oracle import build_index as B
+    gpu, cpu = engines[mode]
+    ref = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))[0][1]
+    rng = np.random.default_rng(7000 + mode + seg_len)
+    noisy = mutated_reads(rng, ref, 150, max(800, 3 * seg_len), max(3000, 6 * seg_len))
+    for trial, reads in enumerate((
+            noisy + [b"", b"A", b"ACGT" * 5] + mutated_reads(rng, ref, 40, 1, 300),                  # mixed with short / empty reads
+            [bytes(ref[s:s + L]) for s, L in zip(rng.integers(0, len(ref) - 4000, 60), rng.integers(1500, 4000, 60))],   # exact
+            [b"N" * 2500, b"ACGT" * 700, bytes(ref[:3000]), b"T" * 4097])):
+        bases, offs = pack(reads)
+        gpu.set_option("seg_len", 0)
+        ref_out, ref_st = gpu.query_pml_packed(bases, offs)
+        exp, ff, sc = cpu.pml_batch(bases, offs, threads=4)
+        assert (ref_out == exp).all() and ref_st.segments == 0
+        gpu.set_option("seg_len", seg_len)
+        try:
+            for idx64 in (0, 1):
+                gpu.set_option("idx64", idx64)
+                out, st, err, rc = gpu.query_pml_packed(bases, offs, want_err=True)
+                assert rc == 0 and not err.any()
+                assert st.segments > len(reads), (trial, st.segments)             # the segmented path really ran
+                bad = np.flatnonzero(out != exp)
+                assert bad.size == 0, (trial, seg_len, bad[:10], st.segments, st.rewalked)
+                assert (st.fast_forwards, st.scans, st.repositions, st.errors) == \
+                       (ref_st.fast_forwards, ref_st.scans, ref_st.repositions, 0), (trial, st.rewalked)
+                assert (st.fast_forwards, st.scans) == (ff, sc)
+                if trial == 0 and seg_len == 1024:
+                    assert st.rewalked < len(reads) // 4                           # noisy reads stitch within a segment this long
+        finally:
+            gpu.set_option("idx64", 0)
+            gpu.set_option("seg_len", 2048)
+
+
+def test_segment_parallel_default_policy(engines):
+    """Default seg_len (2048): a batch of 10 kbp reads takes the segmented path, a batch of short reads does not; the
+    overlapped host path carries its own segment workspace per chunk in flight."""
+    import movi_amd
+    from oracle import build_index as B
+    gpu, cpu = engines[6]
+    ref = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))[0][1]
+    rng = np.random.default_rng(7100)
+    reads = mutated_reads(rng, ref, 64, 9000, 12000)
+    bases, offs = pack(reads)
+    out, st = gpu.query_pml_packed(bases, offs)
+    exp, ff, sc = cpu.pml_batch(bases, offs, threads=4)
+    assert (out == exp).all() and (st.fast_forwards, st.scans) == (ff, sc)
+    assert st.segments >= 4 * len(reads)
+    sb, so = pack(mutated_reads(rng, ref, 300, 100, 200))
+    _, st2 = gpu.query_pml_packed(sb, so)
+    assert st2.segments == 0
+    pb = movi_amd.pinned_empty(bases.size, np.uint8)
+    pb[:] = bases
+    po = movi_amd.pinned_empty(bases.size, np.uint16)
+    gpu.set_option("pipe_chunk_bases", 100_000)
+    try:
+        _, st3 = gpu.query_pml_packed(pb, offs, out=po)
+    finally:
+        gpu.set_option("pipe_chunk_bases", 0)
+    assert (po == exp).all() and (st3.fast_forwards, st3.scans) == (ff, sc) and st3.segments >= 4 * len(reads)
+
+
+def test_segment_parallel_reports_invariant_violations(built_lib, golden_image):
+    """A corrupted table under the segmented path: the reads are walked again end to end and flagged exactly as without it."""
+    import movi_amd
+    from oracle import build_index as B
+    img = bytearray(golden_image(6))
+    _, _, off, _ = movi_amd.parse_index_image(bytes(img))
+    rows = np.frombuffer(img, np.uint8, count=118209 * 8, offset=off).reshape(-1, 8).copy()
+    rows[1000:60000, 0:4] = 0xFF                          # many destination ids >= r
+    img[off: off + rows.size] = rows.tobytes()
+    gpu = movi_amd.MoveIndex.from_image(bytes(img))
+    ref = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))[0][1]
+    rng = np.random.default_rng(7200)
+    bases, offs = pack(mutated_reads(rng, ref, 80, 500, 1500))
+    gpu.set_option("seg_len", 0)
+    exp, est, eerr, erc = gpu.query_pml_packed(bases, offs, want_err=True)
+    assert erc == -6 and est.errors > 0
+    gpu.set_option("seg_len", 64)
+    out, st, err, rc = gpu.query_pml_packed(bases, offs, want_err=True)
+    assert rc == -6 and st.segments > 80
+    assert (err == eerr).all() and (out == exp).all() and st.errors == est.errors
