@@ -121,6 +121,8 @@ def main():
                          "1 = PML vectors + bins, 2 = bins only (--classify --filter: no PML vector is written)")
     ap.add_argument("--variant", type=int, default=-1, help="pml kernel variant (A/B measurement)")
     ap.add_argument("--zml-variant", type=int, default=-1, help="ZML kernel: 0 base-synchronous, 1 lane state machine (A/B)")
+    ap.add_argument("--seg-len", type=int, default=-1, help="PML: segment length of the segment-parallel long-read path "
+                    "(-1 = the engine's default of 2048, 0 = off)")
     ap.add_argument("--block-threads", type=int, default=0)
     ap.add_argument("--waves-per-cu", type=int, default=-1)
     ap.add_argument("--ragged", type=int, default=0, help="1: log-normal read lengths (mean = read_len); "
@@ -236,6 +238,8 @@ def main():
         index.set_option("pml_variant", args.variant)
     if args.zml_variant >= 0:
         index.set_option("zml_variant", args.zml_variant)
+    if args.seg_len >= 0:
+        index.set_option("seg_len", args.seg_len)
     if args.block_threads:
         index.set_option("block_threads", args.block_threads)
     if args.waves_per_cu >= 0:
@@ -383,6 +387,7 @@ def main():
                    "simt_efficiency": round(st.lane_steps / (64.0 * st.wave_steps), 4) if st.wave_steps else None,
                    "iterations_per_base": round(st.lane_steps / max(n_bases, 1), 4) if st.wave_steps else None,
                    "algorithmic_bytes_per_base": round(bytes_per_base, 3),
+                   "segments": int(st.segments), "rewalked_reads": int(st.rewalked), "seg_len": args.seg_len,
                    "query": args.query, "fused_classify": args.classify, "matched_bases_per_step": work_bases, "pml_variant": args.variant, "ragged": args.ragged, "waves_per_cu": args.waves_per_cu, "block_threads": args.block_threads, "index_gen_s": round(t_index_gen, 2),
                    "index_upload_s": round(t_index_upload, 2), "index_broadcast_s": round(t_bcast, 3),
                    "reads_gen_s": round(t_reads_gen, 2)},
@@ -477,9 +482,10 @@ def main():
             dt3 = time.perf_counter() - t0
             result["long_reads"] = {"workload": "c3", "description": w3["desc"], "value": n3 * L3 * k3 / dt3 / 1e9,
                                     "unit": "Gbases/s", "steps": k3, "ms_per_step": dt3 / k3 * 1e3, "reads_per_gpu": n3,
-                                    "read_len": L3, "kernel": "pml_kernel_flatp<%d,window-parallel>" % mode,
+                                    "read_len": L3, "kernel": "pml_kernel_flatp<%d,window-parallel>, segment-parallel" % mode,
                                     "fast_forwards_per_base": round(st3.fast_forwards / (n3 * L3), 4),
-                                    "scans_per_base": round(st3.scans / (n3 * L3), 4), "errors": int(st3.errors)}
+                                    "scans_per_base": round(st3.scans / (n3 * L3), 4), "errors": int(st3.errors),
+                                    "segments": int(st3.segments), "rewalked_reads": int(st3.rewalked)}
         except Exception as e:                            # noqa: BLE001 -- never lose the headline line to the extra
             result["long_reads"] = {"error": repr(e)[:200]}
     # ---- PCIe-inclusive rate of the boundary's host entry point ("pre-parsed reads in pinned host memory to

@@ -17,6 +17,8 @@
 
 #include <hipcub/hipcub.hpp>
 
+#include <algorithm>
+
 namespace movi {
 
 
@@ -1130,11 +1132,11 @@ __global__ __launch_bounds__(256) void seg_count_kernel(const uint64_t *__restri
 }
 
 // Segment j of read t covers the emission indexes [j T, min(len, (j + 1) T)): the bases [len - k_end, len - k_begin) of
-// the read, PMLs to offs[t] + k_begin.
+// the read, PMLs to offs[t] + k_begin; seg_rem = the bases from its first one to the end of the walk (the read's first base).
 __global__ __launch_bounds__(256) void seg_fill_kernel(const uint64_t *__restrict__ offs, uint64_t n_reads, uint32_t seg_len,
                                                       const uint64_t *__restrict__ first, uint64_t *__restrict__ seg_in,
                                                       uint64_t *__restrict__ seg_out, uint32_t *__restrict__ seg_l,
-                                                      uint32_t *__restrict__ seg_j) {
+                                                      uint32_t *__restrict__ seg_j, uint32_t *__restrict__ seg_rem) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_reads) return;
     const uint64_t beg = offs[t], len = offs[t + 1] - beg;
@@ -1147,52 +1149,66 @@ __global__ __launch_bounds__(256) void seg_fill_kernel(const uint64_t *__restric
         seg_out[s0 + j] = beg + k0;
         seg_l[s0 + j] = (uint32_t)(k1 - k0);
         seg_j[s0 + j] = (uint32_t)(j > 0xFFFFFFFFull ? 0xFFFFFFFFull : j);
+        seg_rem[s0 + j] = (uint32_t)(len - k0);
     }
 }
 
+// What a boundary lane found (K2).
+struct SegJoin {
+    uint32_t ff, scan, repo;     // the real walk's counters from this boundary to the meeting point, plus the speculative lane's after it
+    uint32_t kend;               // last emission index (from this segment's first base) this lane walked
+    uint32_t segs;               // segments it reached into beyond its own (0: met inside its own segment)
+    uint32_t how;                // 0 unresolved (an invariant violation, or no meeting point within `max_over` bases), 1 met, 2 walked to the read's end
+};
+
 // K2: one lane per segment that is not the first of its read.  It takes up the walk where the segment before left it
-// (that segment's final state is the read's real state there IF its own boundary fell into step -- K3 checks the
-// chain), walks into this segment base by base -- the plain base-synchronous automaton of pml_kernel<MODE, 0> --
-// overwriting the speculative PMLs, and stops at the first checkpoint (every 32 bases, and the segment's end) where its
-// row, offset and match length equal what the speculative lane recorded: the rest of the segment is then exact as it
-// stands.  What it counted up to there plus what the speculative lane counted after is the segment's share of the
-// read's fast-forwards / scans / repositions.  No meeting point before the segment ends: flag 0, the read is walked again.
-template <int MODE>
+// (that segment's final state is the read's real state there IF the chain of boundaries before it holds -- K3 checks
+// that), walks on base by base -- the plain base-synchronous automaton of pml_kernel<MODE, 0> -- and stops at the first
+// checkpoint (every 32 bases) where its row, offset and match length equal what the speculative lane of that stretch
+// recorded: from there on the speculative PMLs are the real ones.  Usually that is a few dozen bases in; if not, it
+// walks on into the following segments (up to max_over bases: those segments' own boundary lanes are then void).
+// What it counted up to the meeting point plus what the speculative lane counted after it is this stretch's share of the
+// read's fast-forwards / scans / repositions.  It runs twice: PASS 0 only looks for the meeting point and writes no PML
+// -- a lane whose start state turns out not to be real would write rubbish over a stretch that belongs to another --;
+// once K3 has followed the chains, PASS 1 walks the stretches of the lanes that count again (a few dozen bases each, as
+// a rule) and writes their PMLs: those stretches are disjoint.
+template <int MODE, int PASS>
 __global__ __launch_bounds__(256) void seg_stitch_kernel(DevIndex ix, const uint8_t *__restrict__ bases, SegArgs seg,
-                                                        const uint32_t *__restrict__ seg_j, uint16_t *__restrict__ out,
-                                                        SegTot *__restrict__ true_tot, uint8_t *__restrict__ in_step) {
+                                                        const uint32_t *__restrict__ seg_j, const uint32_t *__restrict__ seg_rem,
+                                                        uint32_t max_over, const uint8_t *__restrict__ on_chain,
+                                                        uint16_t *__restrict__ out, SegJoin *__restrict__ join) {
     __shared__ uint8_t s_code[256];
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = ix.code_of[i];
     __syncthreads();
     const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool mine = s < *seg.n_seg && seg_j[s] != 0;
+    const bool mine = s < *seg.n_seg && seg_j[s] != 0 && (PASS == 0 || on_chain[s] != 0);
     const EndThr ethr = end_thresholds(ix);
-    uint32_t ff_total = 0, scan_total = 0, repo_total = 0, failed = 0, met = 0;
+    uint32_t ff_total = 0, scan_total = 0, repo_total = 0, failed = 0, how = 0;
     bool live0 = mine;
-    SegTot spec{};
-    if (mine) {
-        spec = seg.tot[s];
-        if (spec.flag != 0u || seg.tot[s - 1].flag != 0u) live0 = false;     // a speculative walk broke an invariant: K3 decides
-    }
-    const uint64_t len = live0 ? (uint64_t)seg.seg_len[s] : 0;
-    const uint8_t *R = bases + (live0 ? seg.seg_in[s] : 0);
+    if (PASS == 0 && mine && (seg.tot[s].flag != 0u || seg.tot[s - 1].flag != 0u)) live0 = false;   // a speculative walk broke an invariant: K3 decides
+    const uint32_t T = live0 ? seg.seg_len[s] : 1u;      // (every segment of a read but its last has this length)
+    const uint32_t rem = live0 ? seg_rem[s] : 0u;
+    const uint32_t over = PASS == 0 ? (rem < max_over ? rem : max_over) : (live0 ? join[s].kend + 1u : 0u);
+    const uint64_t len = over;
+    const uint8_t *R = bases + (live0 ? seg.seg_in[s] + T : 0);          // one past this segment's first base
     const uint64_t obeg = live0 ? seg.seg_out[s] : 0;
     uint16_t *O = out + obeg;
     uint64_t idx = 0;
-    uint32_t off = 0, ml = 0;
+    uint32_t off = 0, ml = 0, kend = 0;
+    SegJoin res{};
     if (live0) {
         const SegFin f = seg.fin[s - 1];
         idx = f.idx; off = f.off; ml = f.ml;
     }
     uint2 row = load_row<MODE>(ix.rows, idx);
-    for (uint64_t k = 0; wave_any(k < len && failed == 0u && met == 0u); ++k) {
-        bool live = k < len && failed == 0u && met == 0u;
+    for (uint64_t k = 0; wave_any(k < len && failed == 0u && how == 0u); ++k) {
+        bool live = k < len && failed == 0u && how == 0u;
         {
             const uint32_t e = lf_step<MODE>(ix, live, idx, off, row, ff_total);
             if (e) { failed = e; live = false; }
         }
         uint32_t a = 0xFFu;
-        if (live) a = s_code[R[len - 1 - k]];
+        if (live) a = s_code[*(R - 1 - (int64_t)k)];
         const uint32_t rc = row_c<MODE>(row);
         uint32_t dir = 0;
         if (live) {
@@ -1240,49 +1256,65 @@ __global__ __launch_bounds__(256) void seg_stitch_kernel(DevIndex ix, const uint
         }
         if (dir == 1u) off = 0;
         if (dir == 2u) off = row_n<MODE>(row) - 1;
-        if (live) {
-            O[k] = (uint16_t)(ml > 65535u ? 65535u : ml);
-            const bool at_ck = (k & 31ull) == 31ull, at_end = k + 1 == len;
-            if (at_ck || at_end) {
-                uint64_t cidx; uint32_t coff, cml, cff, cscan, crepo;
-                if (at_ck) {
-                    const SegCkpt c = seg.ckpt[(obeg + k) >> 5];
-                    cidx = c.idx; coff = c.off; cml = c.ml; cff = c.ff; cscan = c.scan; crepo = c.repo;
-                } else {
-                    const SegFin f = seg.fin[s];
-                    cidx = f.idx; coff = f.off; cml = f.ml; cff = spec.ff; cscan = spec.scan; crepo = spec.repo;
+        if (PASS == 1) {
+            if (live) O[k] = (uint16_t)(ml > 65535u ? 65535u : ml);
+        } else if (live) {
+            kend = (uint32_t)k;
+            if ((k & 31ull) == 31ull) {
+                const SegCkpt c = seg.ckpt[(obeg + k) >> 5];
+                if (c.idx == idx && c.off == off && c.ml == ml) {
+                    const uint32_t ds = (uint32_t)(k / T);                // the segment the meeting point lies in
+                    const SegTot spec = seg.tot[s + ds];
+                    how = spec.flag == 0u ? 1u : 0u;
+                    if (spec.flag != 0u) failed = spec.flag;             // (that speculative lane's records are not to be trusted)
+                    res.ff = ff_total + (spec.ff - c.ff); res.scan = scan_total + (spec.scan - c.scan);
+                    res.repo = repo_total + (spec.repo - c.repo); res.segs = ds;
                 }
-                if (cidx == idx && coff == off && cml == ml) {
-                    met = 1;
-                    SegTot tt;
-                    tt.ff = ff_total + (spec.ff - cff); tt.scan = scan_total + (spec.scan - cscan);
-                    tt.repo = repo_total + (spec.repo - crepo); tt.flag = 0;
-                    true_tot[s] = tt;
-                }
+            }
+            if (how == 0u && failed == 0u && k + 1 == rem) {             // the read's first base: nothing left to meet
+                how = 2u;
+                res.ff = ff_total; res.scan = scan_total; res.repo = repo_total; res.segs = (uint32_t)(k / T);
             }
         }
     }
-    if (mine) in_step[s] = (uint8_t)met;
+    if (PASS == 0 && mine) {
+        res.kend = kend;
+        res.how = how;
+        join[s] = res;
+    }
 }
 
-// K3, first half: one lane per read.  All of its boundaries in step and no invariant violation in any segment: the PMLs
-// stand, the read's counters are its first segment's plus every later segment's real share, err = 0.  Otherwise the read
-// goes on the list of pml_kernel_flatp<..., SEG = 2>, which walks it from end to end (and reports its error, if any).
+// K3, first half: one lane per read follows the chain of its boundaries.  The first segment is real by construction;
+// the lane of the boundary behind a real stretch started from the real state, so what it found holds: it met the
+// speculative walk `segs` segments on (the boundaries in between are void) or walked to the read's end.  The lanes on
+// the chain are marked for the writing pass of K2, their counters added up.  A chain that breaks -- an invariant violation anywhere in the
+// read, no meeting point within reach -- puts the read on the list of pml_kernel_flatp<..., SEG = 2>, which walks it
+// from end to end (and reports its error, if any).
 __global__ __launch_bounds__(256) void seg_finalize_kernel(const uint64_t *__restrict__ first, uint64_t n_reads,
-                                                          const SegTot *__restrict__ tot, const SegTot *__restrict__ true_tot,
-                                                          const uint8_t *__restrict__ in_step, uint8_t *__restrict__ read_fail,
+                                                          const SegTot *__restrict__ tot, const SegJoin *__restrict__ join,
+                                                          uint8_t *__restrict__ on_chain, uint8_t *__restrict__ read_fail,
                                                           uint8_t *__restrict__ err, DevStats *stats) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t ff = 0, scan = 0, repo = 0, nseg = 0, nbad = 0;
     if (t < n_reads) {
         const uint64_t s0 = first[t], s1 = first[t + 1];
-        uint32_t bad = tot[s0].flag != 0u;
-        ff = tot[s0].ff; scan = tot[s0].scan; repo = tot[s0].repo;
-        for (uint64_t s = s0 + 1; s < s1; ++s) {
-            bad |= (uint32_t)(in_step[s] == 0);
-            const SegTot tt = true_tot[s];
-            ff += tt.ff; scan += tt.scan; repo += tt.repo;
+        uint32_t bad = 0;
+        for (uint64_t s = s0; s < s1; ++s) {
+            bad |= (uint32_t)(tot[s].flag != 0u);
+            on_chain[s] = 0;
         }
+        ff = tot[s0].ff; scan = tot[s0].scan; repo = tot[s0].repo;
+        uint64_t s = s0 + 1;
+        while (!bad && s < s1) {
+            const SegJoin j = join[s];
+            if (j.how == 0u) { bad = 1; break; }
+            ff += j.ff; scan += j.scan; repo += j.repo;
+            on_chain[s] = 1;
+            if (j.how == 2u) break;
+            s += (uint64_t)j.segs + 1;
+        }
+        if (bad)
+            for (uint64_t q = s0 + 1; q < s1; ++q) on_chain[q] = 0;
         read_fail[t] = (uint8_t)bad;
         if (bad) { ff = 0; scan = 0; repo = 0; }
         else if (err) err[t] = 0;
@@ -1301,6 +1333,7 @@ __global__ __launch_bounds__(256) void seg_finalize_kernel(const uint64_t *__res
 
 namespace {
 size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+constexpr int kSegOverrun = 4;   // a boundary lane looks for its meeting point over at most this many seg_len of bases
 }
 
 // The segmented PML path: plan (count, scan, fill), K1, K2, K3.  Everything on `stream`, nothing read back: the grids are
@@ -1321,8 +1354,8 @@ static hipError_t launch_pml_segmented(const DevIndex &ix, const uint8_t *d_base
     auto take = [&](size_t bytes) { const size_t o = off; off += align_up(bytes ? bytes : 8); return o; };
     const size_t o_nof = take((n_reads + 1) * 8), o_first = take((n_reads + 1) * 8), o_temp = take(temp_bytes),
                  o_in = take(max_seg * 8), o_out = take(max_seg * 8), o_len = take(max_seg * 4), o_j = take(max_seg * 4),
-                 o_fin = take(max_seg * sizeof(SegFin)), o_tot = take(max_seg * sizeof(SegTot)),
-                 o_true = take(max_seg * sizeof(SegTot)), o_step = take(max_seg), o_fail = take(n_reads),
+                 o_rem = take(max_seg * 4), o_fin = take(max_seg * sizeof(SegFin)), o_tot = take(max_seg * sizeof(SegTot)),
+                 o_join = take(max_seg * sizeof(SegJoin)), o_chain = take(max_seg), o_fail = take(n_reads),
                  o_ck = take(n_ck * sizeof(SegCkpt));
     if (ws->cap < off) {
         if (ws->buf) (void)hipFree(ws->buf);
@@ -1336,9 +1369,10 @@ static hipError_t launch_pml_segmented(const DevIndex &ix, const uint8_t *d_base
     uint8_t *B = static_cast<uint8_t *>(ws->buf);
     uint64_t *n_of = reinterpret_cast<uint64_t *>(B + o_nof), *first = reinterpret_cast<uint64_t *>(B + o_first);
     uint64_t *seg_in = reinterpret_cast<uint64_t *>(B + o_in), *seg_out = reinterpret_cast<uint64_t *>(B + o_out);
-    uint32_t *seg_l = reinterpret_cast<uint32_t *>(B + o_len), *seg_j = reinterpret_cast<uint32_t *>(B + o_j);
-    SegTot *true_tot = reinterpret_cast<SegTot *>(B + o_true);
-    uint8_t *in_step = B + o_step, *read_fail = B + o_fail;
+    uint32_t *seg_l = reinterpret_cast<uint32_t *>(B + o_len), *seg_j = reinterpret_cast<uint32_t *>(B + o_j),
+             *seg_rem = reinterpret_cast<uint32_t *>(B + o_rem);
+    SegJoin *join = reinterpret_cast<SegJoin *>(B + o_join);
+    uint8_t *on_chain = B + o_chain, *read_fail = B + o_fail;
     SegArgs seg;
     seg.seg_in = seg_in; seg.seg_out = seg_out; seg.seg_len = seg_l; seg.n_seg = first + n_reads;
     seg.ckpt = reinterpret_cast<SegCkpt *>(B + o_ck);
@@ -1351,7 +1385,7 @@ static hipError_t launch_pml_segmented(const DevIndex &ix, const uint8_t *d_base
     e = hipcub::DeviceScan::ExclusiveSum(B + o_temp, temp_bytes, n_of, first, (int)(n_reads + 1), stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(seg_fill_kernel, dim3((unsigned)((n_reads + bt256 - 1) / bt256)), dim3(bt256), 0, stream, d_offsets,
-                       n_reads, S, first, seg_in, seg_out, seg_l, seg_j);
+                       n_reads, S, first, seg_in, seg_out, seg_l, seg_j, seg_rem);
     // K1 and K3b: the window-parallel lane state machine in blocks of one wavefront, capped like any big batch
     const int bt = 64;
     auto lds_for = [&](uint64_t lanes) -> size_t {
@@ -1385,10 +1419,14 @@ static hipError_t launch_pml_segmented(const DevIndex &ix, const uint8_t *d_base
         }                                                                                                             \
     } while (0)
     MOVI_LAUNCH_SEG_T(1, max_seg);
-    hipLaunchKernelGGL(seg_stitch_kernel<6>, dim3((unsigned)((max_seg + bt256 - 1) / bt256)), dim3(bt256), 0, stream, ix, d_bases,
-                       seg, seg_j, d_out, true_tot, in_step);
+    // (blocks of one wavefront: a boundary lane that has to walk far holds up only the 63 beside it)
+    const uint32_t max_over = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, (uint64_t)S * (uint64_t)kSegOverrun);
+    hipLaunchKernelGGL((seg_stitch_kernel<6, 0>), dim3((unsigned)((max_seg + 63) / 64)), dim3(64), 0, stream, ix, d_bases, seg,
+                       seg_j, seg_rem, max_over, on_chain, d_out, join);
     hipLaunchKernelGGL(seg_finalize_kernel, dim3((unsigned)((n_reads + bt256 - 1) / bt256)), dim3(bt256), 0, stream, first, n_reads,
-                       seg.tot, true_tot, in_step, read_fail, d_err, d_stats);
+                       seg.tot, join, on_chain, read_fail, d_err, d_stats);
+    hipLaunchKernelGGL((seg_stitch_kernel<6, 1>), dim3((unsigned)((max_seg + 63) / 64)), dim3(64), 0, stream, ix, d_bases, seg,
+                       seg_j, seg_rem, max_over, on_chain, d_out, join);
     MOVI_LAUNCH_SEG_T(2, n_reads);
 #undef MOVI_LAUNCH_SEG_T
 #undef MOVI_LAUNCH_SEG
