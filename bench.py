@@ -116,6 +116,7 @@ def main():
     ap.add_argument("--rows", type=int, default=0)
     ap.add_argument("--reads", type=int, default=0)
     ap.add_argument("--read-len", type=int, default=0)
+    ap.add_argument("--sub-rate", type=float, default=-1.0, help="substitution rate of the synthetic reads (synth workloads)")
     ap.add_argument("--classify", type=int, default=0, choices=[0, 1, 2],
                     help="PML with Classifier::classify bins fused into the walk (BASELINE config 3 is 'PML + --classify'): "
                          "1 = PML vectors + bins, 2 = bins only (--classify --filter: no PML vector is written)")
@@ -170,6 +171,7 @@ def main():
     if args.rows: wl["rows"] = args.rows
     if args.reads: wl["reads"] = args.reads
     if args.read_len: wl["read_len"] = args.read_len
+    if args.sub_rate >= 0: wl["sub"] = args.sub_rate
     ROW_BYTES = {6: 8, 8: 8, 7: 8}       # resident row bytes: blocked- / sampled-thresholds rows are expanded to the mode-6 layout at upload
     mode, row_bytes = wl["mode"], ROW_BYTES[wl["mode"]]
 

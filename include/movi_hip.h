@@ -250,7 +250,10 @@ int movi_host_unregister(void *p);
  * (bases per chunk of the overlapped host path, 0 = its own policy: a test hook), "seg_len" (PML: batches whose mean
  * read length is at least twice this many bases are walked segment-parallel -- every read cut into segments of about
  * seg_len bases walked by their own lanes, stitched where the walks fall into step, reads that do not walked again:
- * identical results; default 2048, 0 = off, else a multiple of 32). */
+ * identical results; default 2048, 0 = off, else a multiple of 32), "seg_probe" (1, the default: an eligible batch
+ * is cut into segments only if a probe of some of its reads finds that walks started mid-read fall into step within a
+ * few hundred bases -- noisy long reads do, reads with 0.1 % errors and less do not and are better off with one lane
+ * per read --; 0 = cut whatever the probe would say: a test hook). */
 int movi_set_option(movi_index_t *ix, const char *key, int64_t value);
 
 /* ---- ZML (Ziv-Merhav cross parse) ---------------------------------------------- */

@@ -596,6 +596,11 @@ int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
         ix->cfg.seg_len = (int)value;
         return MOVI_OK;
     }
+    if (!strcmp(key, "seg_probe")) {                         // 0: segment eligible batches whatever the probe would say (tests)
+        if (value != 0 && value != 1) return fail(MOVI_ERR_ARG, "seg_probe must be 0 or 1");
+        ix->cfg.seg_probe = (int)value;
+        return MOVI_OK;
+    }
     if (!strcmp(key, "waves_per_cu")) {
         if (value < 0 || value > 32) return fail(MOVI_ERR_ARG, "waves_per_cu must be in [0,32]");
         ix->cfg.waves_per_cu = (int)value;

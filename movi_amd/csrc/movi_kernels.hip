@@ -772,7 +772,7 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
     const uint32_t off0 = row_n<MODE>(row_r1) - 1;
 
     // ---- the lane's current read
-    const bool valid = !REFILL && (SEG == 1 ? t < *seg.n_seg : (t < n_reads && (SEG != 2 || seg.read_fail[t] != 0)));
+    const bool valid = !REFILL && (SEG == 1 ? (*seg.go != 0u && t < *seg.n_seg) : (t < n_reads && (SEG != 2 || seg.read_fail[t] != 0)));
     uint64_t rid = (valid && order && SEG == 0) ? order[t] : t;
     uint64_t beg = valid ? (SEG == 1 ? seg.seg_in[rid] : offs[rid]) : 0;
     uint32_t len = valid ? (SEG == 1 ? seg.seg_len[rid] : (uint32_t)(offs[rid + 1] - beg)) : 0;   // reads are shorter than 2^32 (checked on the host)
@@ -1112,6 +1112,112 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
 
 // ------------------------------------------------------------- segment-parallel long reads (movi_kernels.hpp)
 
+// One base of the plain base-synchronous automaton (pml_kernel<MODE, 0>) for the lanes with `live`: the LF from the
+// base before (unless this is the walk's first base), then match / illegal / reposition_thresholds + scan against base
+// code `a`.  Wave-uniform loops inside: every lane of the wavefront must make the call.  Returns a kErr* code.
+template <int MODE>
+__device__ __forceinline__ uint32_t walk_base(const DevIndex &ix, const EndThr &ethr, bool live, bool lf, uint32_t a, uint64_t &idx,
+                                              uint32_t &off, uint2 &row, uint32_t &ml, uint32_t &ff_total, uint32_t &scan_total,
+                                              uint32_t &repo_total) {
+    uint32_t failed = lf_step<MODE>(ix, live && lf, idx, off, row, ff_total);
+    if (failed) live = false;
+    const uint32_t rc = row_c<MODE>(row);
+    uint32_t dir = 0;
+    if (live) {
+        if (a == 0xFFu) {
+            ml = 0;
+        } else if (rc == a) {
+            ml += 1;
+        } else {                                          // reposition_thresholds, as in pml_kernel
+            repo_total += 1;
+            ml = 0;
+            uint32_t down;
+            if (idx == ix.end_bwt_idx) {
+                down = (off >= end_threshold(ix.sep, ethr, a)) ? 1u : 0u;
+            } else if (ix.sep && rc == 0u) {
+                down = (off >= separator_threshold(ix, idx, a)) ? 1u : 0u;
+            } else {
+                const uint32_t kk = thr_slot(ix.sep, a, rc);
+                const uint32_t thr = row_thr<MODE>(row, kk > 2u ? 2u : kk) ? row_n<MODE>(row) : 0u;
+                down = (off >= thr) ? 1u : 0u;
+            }
+            dir = down ? 1u : 2u;
+            if (down && idx == ix.r - 1) { failed = kErrNoRunBelow; dir = 0; }
+            if (!down && idx == 0) { failed = kErrNoRunAbove; dir = 0; }
+        }
+    }
+    uint32_t scanning = dir;
+    while (wave_any(scanning != 0u)) {
+        if (scanning) {
+            uint64_t jj = (scanning == 1u) ? idx + 1 : idx - 1;
+            if (scanning == 1u) { if (jj >= ix.r) jj = ix.r - 1; }
+            else if (jj > idx) jj = 0;
+            const uint2 w = load_row<MODE>(ix.rows, jj);
+            scan_total += 1;
+            idx = (scanning == 1u) ? idx + 1 : idx - 1;
+            row = w;
+            const uint32_t c = row_c<MODE>(row);
+            if (c == a) {
+                scanning = 0;
+            } else if (scanning == 1u ? (idx >= ix.r - 1) : (idx == 0)) {
+                failed = scanning == 1u ? kErrNoRunBelow : kErrNoRunAbove;
+                scanning = 0;
+            }
+        }
+    }
+    if (failed == 0u && dir == 1u) off = 0;
+    if (failed == 0u && dir == 2u) off = row_n<MODE>(row) - 1;
+    return failed;
+}
+
+// The probe of the segmented path: does a walk started in the middle of a read fall into step quickly ON THIS BATCH?
+// (Noisy long reads: within a few dozen bases.  Clean ones -- 0.1 % errors and below -- need a mismatch to meet at, i.e.
+// hundreds to thousands of bases: cut into segments such a batch runs 1.5 - 2.3 x SLOWER than one lane per read.)
+// Truth is not available before the walk, but two speculative walks are as good a witness: up to 1024 lanes each take
+// a read, start walker B `lead` bases before the read's middle and walker A at the middle, and report whether the two
+// are in the same state -- row, offset, match length -- within `reach` bases.
+template <int MODE>
+__global__ __launch_bounds__(256) void seg_probe_kernel(DevIndex ix, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ offs,
+                                                       uint64_t n_reads, uint32_t lead, uint32_t reach, uint32_t *__restrict__ tally) {
+    __shared__ uint8_t s_code[256];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = ix.code_of[i];
+    __syncthreads();
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, n_lanes = (uint64_t)gridDim.x * blockDim.x;
+    const EndThr ethr = end_thresholds(ix);
+    // many reads: every stride-th one, probed at its middle; fewer reads than lanes: `per` probes spread along each read
+    const uint64_t stride = n_reads > n_lanes ? n_reads / n_lanes : 1, per = n_reads < n_lanes ? n_lanes / n_reads : 1;
+    const uint64_t rid = per > 1 ? t % n_reads : t * stride, slot = per > 1 ? t / n_reads : 0;
+    bool valid = rid < n_reads && slot < per;
+    const uint64_t beg = valid ? offs[rid] : 0, len = valid ? offs[rid + 1] - beg : 0;
+    const uint64_t mid = len * (2 * slot + 1) / (2 * per);   // walker A starts just below this byte of the read
+    valid = valid && mid >= reach && mid + lead <= len;
+    const uint8_t *R = bases + beg + mid + lead;            // one past walker B's first base; walker A's is `lead` bases on
+    const uint64_t r1 = ix.r - 1;
+    const uint2 row0 = load_row<MODE>(ix.rows, r1);
+    uint64_t ia = r1, ib = r1;
+    uint32_t oa = row_n<MODE>(row0) - 1, ob = oa, ma = 0, mb = 0, ffx = 0, scx = 0, rpx = 0, failed = 0, met = 0;
+    uint2 ra = row0, rb = row0;
+    for (uint32_t k = 0; wave_any(valid && k < lead + reach && failed == 0u && met == 0u); ++k) {
+        const bool live = valid && k < lead + reach && failed == 0u && met == 0u;
+        uint32_t a = 0xFFu;
+        if (live) a = s_code[*(R - 1 - (int64_t)k)];
+        uint32_t e = walk_base<MODE>(ix, ethr, live, k != 0, a, ib, ob, rb, mb, ffx, scx, rpx);
+        const uint32_t e2 = walk_base<MODE>(ix, ethr, live && k >= lead, k > lead, a, ia, oa, ra, ma, ffx, scx, rpx);
+        if (e | e2) failed = 1;
+        if (live && failed == 0u && k >= lead && ia == ib && oa == ob && ma == mb) met = 1;
+    }
+    const uint32_t nv = wave_sum(valid ? 1u : 0u), nm = wave_sum(met);
+    if ((threadIdx.x & 63) == 0) {
+        if (nv) atomicAdd(&tally[0], nv);
+        if (nm) atomicAdd(&tally[1], nm);
+    }
+}
+
+// go = at least 8 probes, 9 in 10 of them in step within reach (or no probing asked for)
+__global__ void seg_decide_kernel(const uint32_t *__restrict__ tally, uint32_t probe, uint32_t *__restrict__ go) {
+    *go = probe ? (uint32_t)(tally[0] >= 8u && (uint64_t)tally[1] * 10ull >= (uint64_t)tally[0] * 9ull) : 1u;
+}
+
 // Segments of a read of `len` bases: n = len / seg_len of them (1 below 2 x seg_len), each T bases -- a multiple of
 // 32, so that every checkpoint sits at an emission index k with k % 32 == 31 in the read's as in the segment's count --
 // the last one whatever is left.
@@ -1181,7 +1287,7 @@ __global__ __launch_bounds__(256) void seg_stitch_kernel(DevIndex ix, const uint
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = ix.code_of[i];
     __syncthreads();
     const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool mine = s < *seg.n_seg && seg_j[s] != 0 && (PASS == 0 || on_chain[s] != 0);
+    const bool mine = *seg.go != 0u && s < *seg.n_seg && seg_j[s] != 0 && (PASS == 0 || on_chain[s] != 0);
     const EndThr ethr = end_thresholds(ix);
     uint32_t ff_total = 0, scan_total = 0, repo_total = 0, failed = 0, how = 0;
     bool live0 = mine;
@@ -1203,59 +1309,10 @@ __global__ __launch_bounds__(256) void seg_stitch_kernel(DevIndex ix, const uint
     uint2 row = load_row<MODE>(ix.rows, idx);
     for (uint64_t k = 0; wave_any(k < len && failed == 0u && how == 0u); ++k) {
         bool live = k < len && failed == 0u && how == 0u;
-        {
-            const uint32_t e = lf_step<MODE>(ix, live, idx, off, row, ff_total);
-            if (e) { failed = e; live = false; }
-        }
         uint32_t a = 0xFFu;
         if (live) a = s_code[*(R - 1 - (int64_t)k)];
-        const uint32_t rc = row_c<MODE>(row);
-        uint32_t dir = 0;
-        if (live) {
-            if (a == 0xFFu) {
-                ml = 0;
-            } else if (rc == a) {
-                ml += 1;
-            } else {                                      // reposition_thresholds, as in pml_kernel
-                repo_total += 1;
-                ml = 0;
-                uint32_t down;
-                if (idx == ix.end_bwt_idx) {
-                    down = (off >= end_threshold(ix.sep, ethr, a)) ? 1u : 0u;
-                } else if (ix.sep && rc == 0u) {
-                    down = (off >= separator_threshold(ix, idx, a)) ? 1u : 0u;
-                } else {
-                    const uint32_t kk = thr_slot(ix.sep, a, rc);
-                    const uint32_t thr = row_thr<MODE>(row, kk > 2u ? 2u : kk) ? row_n<MODE>(row) : 0u;
-                    down = (off >= thr) ? 1u : 0u;
-                }
-                dir = down ? 1u : 2u;
-                if (down && idx == ix.r - 1) { failed = kErrNoRunBelow; dir = 0; live = false; }
-                if (!down && idx == 0) { failed = kErrNoRunAbove; dir = 0; live = false; }
-            }
-        }
-        uint32_t scanning = dir;
-        while (wave_any(scanning != 0u)) {
-            if (scanning) {
-                uint64_t jj = (scanning == 1u) ? idx + 1 : idx - 1;
-                if (scanning == 1u) { if (jj >= ix.r) jj = ix.r - 1; }
-                else if (jj > idx) jj = 0;
-                const uint2 w = load_row<MODE>(ix.rows, jj);
-                scan_total += 1;
-                idx = (scanning == 1u) ? idx + 1 : idx - 1;
-                row = w;
-                const uint32_t c = row_c<MODE>(row);
-                if (c == a) {
-                    scanning = 0;
-                } else if (scanning == 1u ? (idx >= ix.r - 1) : (idx == 0)) {
-                    failed = scanning == 1u ? kErrNoRunBelow : kErrNoRunAbove;
-                    scanning = 0;
-                    live = false;
-                }
-            }
-        }
-        if (dir == 1u) off = 0;
-        if (dir == 2u) off = row_n<MODE>(row) - 1;
+        const uint32_t e = walk_base<MODE>(ix, ethr, live, true, a, idx, off, row, ml, ff_total, scan_total, repo_total);
+        if (e) { failed = e; live = false; }
         if (PASS == 1) {
             if (live) O[k] = (uint16_t)(ml > 65535u ? 65535u : ml);
         } else if (live) {
@@ -1290,13 +1347,16 @@ __global__ __launch_bounds__(256) void seg_stitch_kernel(DevIndex ix, const uint
 // the chain are marked for the writing pass of K2, their counters added up.  A chain that breaks -- an invariant violation anywhere in the
 // read, no meeting point within reach -- puts the read on the list of pml_kernel_flatp<..., SEG = 2>, which walks it
 // from end to end (and reports its error, if any).
-__global__ __launch_bounds__(256) void seg_finalize_kernel(const uint64_t *__restrict__ first, uint64_t n_reads,
-                                                          const SegTot *__restrict__ tot, const SegJoin *__restrict__ join,
+__global__ __launch_bounds__(256) void seg_finalize_kernel(const uint32_t *__restrict__ go, const uint64_t *__restrict__ first,
+                                                          uint64_t n_reads, const SegTot *__restrict__ tot,
+                                                          const SegJoin *__restrict__ join,
                                                           uint8_t *__restrict__ on_chain, uint8_t *__restrict__ read_fail,
                                                           uint8_t *__restrict__ err, DevStats *stats) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t ff = 0, scan = 0, repo = 0, nseg = 0, nbad = 0;
-    if (t < n_reads) {
+    if (t < n_reads && *go == 0u) {
+        read_fail[t] = 1;                                 // the probe advised against segments: every read is walked by one lane
+    } else if (t < n_reads) {
         const uint64_t s0 = first[t], s1 = first[t + 1];
         uint32_t bad = 0;
         for (uint64_t s = s0; s < s1; ++s) {
@@ -1356,7 +1416,7 @@ static hipError_t launch_pml_segmented(const DevIndex &ix, const uint8_t *d_base
                  o_in = take(max_seg * 8), o_out = take(max_seg * 8), o_len = take(max_seg * 4), o_j = take(max_seg * 4),
                  o_rem = take(max_seg * 4), o_fin = take(max_seg * sizeof(SegFin)), o_tot = take(max_seg * sizeof(SegTot)),
                  o_join = take(max_seg * sizeof(SegJoin)), o_chain = take(max_seg), o_fail = take(n_reads),
-                 o_ck = take(n_ck * sizeof(SegCkpt));
+                 o_ck = take(n_ck * sizeof(SegCkpt)), o_go = take(16);
     if (ws->cap < off) {
         if (ws->buf) (void)hipFree(ws->buf);
         ws->buf = nullptr;
@@ -1379,7 +1439,15 @@ static hipError_t launch_pml_segmented(const DevIndex &ix, const uint8_t *d_base
     seg.fin = reinterpret_cast<SegFin *>(B + o_fin);
     seg.tot = reinterpret_cast<SegTot *>(B + o_tot);
     seg.read_fail = read_fail;
+    uint32_t *go = reinterpret_cast<uint32_t *>(B + o_go);               // go | probes | probes in step
+    seg.go = go;
     const unsigned bt256 = 256;
+    // the probe: is this a batch whose walks fall into step quickly?
+    e = hipMemsetAsync(go, 0, 16, stream);
+    if (e != hipSuccess) return e;
+    if (cfg.seg_probe)
+        hipLaunchKernelGGL(seg_probe_kernel<6>, dim3(16), dim3(64), 0, stream, ix, d_bases, d_offsets, n_reads, 128u, 384u, go + 1);
+    hipLaunchKernelGGL(seg_decide_kernel, dim3(1), dim3(1), 0, stream, go + 1, (uint32_t)(cfg.seg_probe != 0), go);
     hipLaunchKernelGGL(seg_count_kernel, dim3((unsigned)((n_reads + 1 + bt256 - 1) / bt256)), dim3(bt256), 0, stream, d_offsets,
                        n_reads, S, n_of);
     e = hipcub::DeviceScan::ExclusiveSum(B + o_temp, temp_bytes, n_of, first, (int)(n_reads + 1), stream);
@@ -1423,7 +1491,7 @@ static hipError_t launch_pml_segmented(const DevIndex &ix, const uint8_t *d_base
     const uint32_t max_over = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, (uint64_t)S * (uint64_t)kSegOverrun);
     hipLaunchKernelGGL((seg_stitch_kernel<6, 0>), dim3((unsigned)((max_seg + 63) / 64)), dim3(64), 0, stream, ix, d_bases, seg,
                        seg_j, seg_rem, max_over, on_chain, d_out, join);
-    hipLaunchKernelGGL(seg_finalize_kernel, dim3((unsigned)((n_reads + bt256 - 1) / bt256)), dim3(bt256), 0, stream, first, n_reads,
+    hipLaunchKernelGGL(seg_finalize_kernel, dim3((unsigned)((n_reads + bt256 - 1) / bt256)), dim3(bt256), 0, stream, go, first, n_reads,
                        seg.tot, join, on_chain, read_fail, d_err, d_stats);
     hipLaunchKernelGGL((seg_stitch_kernel<6, 1>), dim3((unsigned)((max_seg + 63) / 64)), dim3(64), 0, stream, ix, d_bases, seg,
                        seg_j, seg_rem, max_over, on_chain, d_out, join);

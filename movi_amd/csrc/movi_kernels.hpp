@@ -66,7 +66,8 @@ struct LaunchCfg {
     int zml_variant = -1;  // -1 auto; 0 base-synchronous kernel, 1 lane state machine
     int num_cus = 256;
     int waves_per_cu = 0;  // 0 = auto (variant 10 on big batches and variant 13: kCapWaves; else no cap); else cap resident waves per CU by padding the block's LDS allocation
-    int seg_len = 2048;    // PML: batches whose mean read length is >= 2 x seg_len are walked segment-parallel (0 = never)
+    int seg_len = 2048;    // PML: batches whose mean read length is >= 2 x seg_len are walked segment-parallel (0 = never) ...
+    int seg_probe = 1;     // ... if a probe of the batch finds that walks started mid-read fall into step quickly (0 = always: tests)
     int refill_blocks = 0; // variant 13: size of the persistent grid in blocks; 0 = num_cus x waves per CU (tests shrink it
                            // so that a few hundred reads already go through many refills per lane)
 };
@@ -101,6 +102,7 @@ struct SegArgs {
     SegFin *fin = nullptr;
     SegTot *tot = nullptr;
     const uint8_t *read_fail = nullptr;   // K3: reads to walk again
+    const uint32_t *go = nullptr;         // device: 1 = walk the segments; 0 = the probe advised against it: every read goes to K3
 };
 
 // Device workspace of the segmented path, owned by whoever owns the stream (the handle; a pipeline slot): grow-only.

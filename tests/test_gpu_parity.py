@@ -1062,6 +1062,7 @@ def test_segment_parallel_pml_vs_oracle(engines, mode, seg_len):
         exp, ff, sc = cpu.pml_batch(bases, offs, threads=4)
         assert (ref_out == exp).all() and ref_st.segments == 0
         gpu.set_option("seg_len", seg_len)
+        gpu.set_option("seg_probe", 0)                     # segments whatever the batch looks like
         try:
             for idx64 in (0, 1):
                 gpu.set_option("idx64", idx64)
@@ -1078,6 +1079,7 @@ def test_segment_parallel_pml_vs_oracle(engines, mode, seg_len):
         finally:
             gpu.set_option("idx64", 0)
             gpu.set_option("seg_len", 2048)
+            gpu.set_option("seg_probe", 1)
 
 
 def test_segment_parallel_default_policy(engines):
@@ -1125,6 +1127,25 @@ def test_segment_parallel_reports_invariant_violations(built_lib, golden_image):
     exp, est, eerr, erc = gpu.query_pml_packed(bases, offs, want_err=True)
     assert erc == -6 and est.errors > 0
     gpu.set_option("seg_len", 64)
+    gpu.set_option("seg_probe", 0)
     out, st, err, rc = gpu.query_pml_packed(bases, offs, want_err=True)
     assert rc == -6 and st.segments > 80
     assert (err == eerr).all() and (out == exp).all() and st.errors == est.errors
+
+
+def test_segment_parallel_probe_decides(engines):
+    """The probe (two speculative walks per sampled read, started 128 bases apart): noisy long reads fall into step
+    quickly and are cut into segments; exact substrings of the reference have no mismatch to meet at, and a batch of those
+    stays on one lane per read.  Either way the answers are the oracle's."""
+    from oracle import build_index as B
+    gpu, cpu = engines[6]
+    ref = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))[0][1]
+    rng = np.random.default_rng(7300)
+    noisy = mutated_reads(rng, ref, 100, 5000, 8000)
+    exact = [bytes(ref[s:s + L]) for s, L in zip(rng.integers(0, len(ref) - 8000, 100), rng.integers(5000, 8000, 100))]
+    for reads, want_segments in ((noisy, True), (exact, False)):
+        bases, offs = pack(reads)
+        out, st = gpu.query_pml_packed(bases, offs)
+        exp, ff, sc = cpu.pml_batch(bases, offs, threads=4)
+        assert (out == exp).all() and (st.fast_forwards, st.scans, st.errors) == (ff, sc, 0)
+        assert (st.segments > 0) == want_segments, (want_segments, st.segments, st.rewalked)

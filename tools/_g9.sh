@@ -5,12 +5,14 @@ d=json.loads(sys.stdin.read()); c=d['config']; r=d['roofline']
 print('%.2f Gbases/s | %.3f ms | f=%.3f s=%.3f | segs=%s rewalked=%s | simt=%s it/base=%s' % (d['value'], r['kernel_ms_avg'], c['fast_forwards_per_base'], c['scans_per_base'], c.get('segments'), c.get('rewalked_reads'), c.get('simt_efficiency'), c.get('iterations_per_base')))"; }
 {
 for sl in 0 2048 1024; do
+run "c3synth 100k x 10kbp seg $sl" "--workload c3synth --seg-len $sl"
 run "c3synth 25k x 10kbp seg $sl" "--workload c3synth --reads 25000 --seg-len $sl"
-run "c3synth 10k x 10kbp seg $sl" "--workload c3synth --reads 10000 --seg-len $sl"
-run "c3synth 2k x 100kbp seg $sl" "--workload c3synth --reads 2000 --read-len 100000 --seg-len $sl"
 run "c3synth 200 x 1Mbp seg $sl" "--workload c3synth --reads 200 --read-len 1000000 --seg-len $sl"
-run "c3synth ragged (log-normal, mean 10 kbp) 100k seg $sl" "--workload c3synth --ragged 1 --seg-len $sl"
-run "c3synth ragged 20k seg $sl" "--workload c3synth --ragged 1 --reads 20000 --seg-len $sl"
+run "c3synth ragged 100k seg $sl" "--workload c3synth --ragged 1 --seg-len $sl"
+run "c3synth 1% subst 25k x 10kbp seg $sl" "--workload c3synth --reads 25000 --sub-rate 0.01 --seg-len $sl"
+run "c3synth 0.1% subst 25k x 10kbp seg $sl" "--workload c3synth --reads 25000 --sub-rate 0.001 --seg-len $sl"
+run "c3synth 0% subst 25k x 10kbp seg $sl" "--workload c3synth --reads 25000 --sub-rate 0.0 --seg-len $sl"
+run "c3synth 0.1% subst 100k x 10kbp seg $sl" "--workload c3synth --sub-rate 0.001 --seg-len $sl"
 done
-} > gpurun_out/r3j/seg2.txt 2>&1
-cat gpurun_out/r3j/seg2.txt
+} > gpurun_out/r3j/seg3.txt 2>&1
+cat gpurun_out/r3j/seg3.txt
