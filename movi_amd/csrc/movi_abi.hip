@@ -613,7 +613,8 @@ int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
 
 static int ml_device(bool zml, movi_index_t *ix, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
                      uint64_t n_bases, uint16_t *d_out, uint8_t *d_read_err, const uint32_t *d_read_order, void *stream,
-                     const ClsArgs &cls = ClsArgs(), DevStats *d_stats = nullptr, SegWorkspace *seg_ws = nullptr) {
+                     const ClsArgs &cls = ClsArgs(), DevStats *d_stats = nullptr, SegWorkspace *seg_ws = nullptr,
+                     int ragged_hint = -1) {
     if (!ix) return fail(MOVI_ERR_ARG, "index handle is NULL");
     if (!d_stats) d_stats = ix->d_stats;                     // (the pipelined host path counts per chunk in flight ...
     if (!seg_ws) seg_ws = &ix->seg_ws;                       //  ... and keeps a segment workspace per chunk in flight)
@@ -633,7 +634,7 @@ static int ml_device(bool zml, movi_index_t *ix, const uint8_t *d_bases, const u
                            d_read_order, ix->cfg, s));
     else
         HIP_TRY(launch_pml(ix->kmode, ix->dev, d_bases, d_offsets, n_reads, n_bases, d_out, d_read_err, d_stats,
-                           d_read_order, ix->cfg, s, cls, seg_ws));
+                           d_read_order, ix->cfg, s, cls, seg_ws, ragged_hint));
     return MOVI_OK;
 }
 
@@ -713,6 +714,7 @@ struct ChunkCtx {
     size_t *cap = nullptr;
     uint8_t *h_small = nullptr;
     SegWorkspace *seg_ws = nullptr;
+    int ragged_hint = -1;            // the chunk's longest read is (1) / is not (0) more than 1.5 x its mean: launch_pml's segment policy
     bool async = false;
     hipError_t alloc(int slot, size_t bytes, void **out) {
         hipError_t e = grow(&d[slot], &cap[slot], bytes);
@@ -841,7 +843,12 @@ int run_chunked(movi_index *ix, const uint8_t *h_bases, const uint64_t *h_offset
         HIP_TRY(ctx.alloc(movi_index::kOffs, (nr + 1) * 8, &d_offs.p));
         HIP_TRY(ctx.alloc(movi_index::kErr, nr, &d_err.p));
         std::vector<uint64_t> rel(nr + 1);
-        for (uint64_t i = 0; i <= nr; i++) rel[i] = h_offsets[first + i] - b0;
+        uint64_t longest = 0;
+        for (uint64_t i = 0; i <= nr; i++) {
+            rel[i] = h_offsets[first + i] - b0;
+            if (i && rel[i] - rel[i - 1] > longest) longest = rel[i] - rel[i - 1];
+        }
+        ctx.ragged_hint = (nr && longest * 2 > (nb / nr) * 3) ? 1 : 0;
         // No length sort here: on ragged batches handing the lanes out longest-first measured
         // slightly SLOWER (31.1 vs 32.8 Gbases/s, log-normal lengths) -- the walk is bound by the
         // memory system, not by lane occupancy, and the dispatcher already refills whole blocks.
@@ -968,7 +975,12 @@ int run_pipelined(movi_index *ix, const uint8_t *h_bases, const uint64_t *h_offs
         HIP_TRY(ctx.alloc(movi_index::kOffs, (c.nr + 1) * 8, &d_offs.p));
         HIP_TRY(ctx.alloc(movi_index::kErr, c.nr, &d_err.p));
         uint64_t *rel = reinterpret_cast<uint64_t *>(sl.h);
-        for (uint64_t i = 0; i <= c.nr; i++) rel[i] = h_offsets[c.first + i] - c.b0;
+        uint64_t longest = 0;
+        for (uint64_t i = 0; i <= c.nr; i++) {
+            rel[i] = h_offsets[c.first + i] - c.b0;
+            if (i && rel[i] - rel[i - 1] > longest) longest = rel[i] - rel[i - 1];
+        }
+        ctx.ragged_hint = (c.nr && longest * 2 > (c.nb / c.nr) * 3) ? 1 : 0;
         fl[k].c = c;
         fl[k].stage = 1;                                     // from here on the streams hold work that touches caller memory
         if (c.nb) HIP_TRY(hipMemcpyAsync(d_bases.p, h_bases + c.b0, c.nb, hipMemcpyHostToDevice, ix->pipe_up));
@@ -1084,7 +1096,7 @@ static int ml_host(bool zml, movi_index_t *ix, const uint8_t *h_bases, const uin
     auto launch = [&](ChunkCtx &c, const uint8_t *db, const uint64_t *dof, uint64_t nr, uint64_t nb, uint8_t *derr) -> int {
         HIP_TRY(c.alloc(movi_index::kOut, nb * 2, &d_out.p));
         return ml_device(zml, ix, db, dof, nr, nb, static_cast<uint16_t *>(d_out.p), derr, nullptr, c.s, ClsArgs(), c.d_stats,
-                         c.seg_ws);
+                         c.seg_ws, c.ragged_hint);
     };
     // (the results are found through the chunk's own staging: with chunks in flight, launch() of the next chunk has
     // run before fetch() of this one)

@@ -1201,9 +1201,14 @@ __global__ __launch_bounds__(256) void seg_probe_kernel(DevIndex ix, const uint8
         const bool live = valid && k < lead + reach && failed == 0u && met == 0u;
         uint32_t a = 0xFFu;
         if (live) a = s_code[*(R - 1 - (int64_t)k)];
-        uint32_t e = walk_base<MODE>(ix, ethr, live, k != 0, a, ib, ob, rb, mb, ffx, scx, rpx);
-        const uint32_t e2 = walk_base<MODE>(ix, ethr, live && k >= lead, k > lead, a, ia, oa, ra, ma, ffx, scx, rpx);
-        if (e | e2) failed = 1;
+        // (the two LF moves go out together once both walkers are under way: half the round trips)
+        uint32_t e0 = 0;
+        if (k > lead) e0 = lf_step2<MODE>(ix, live, ia, oa, ra, ib, ob, rb, ffx);
+        else e0 = lf_step<MODE>(ix, live && k != 0, ib, ob, rb, ffx);
+        const bool l2 = live && e0 == 0u;
+        const uint32_t e = walk_base<MODE>(ix, ethr, l2, false, a, ib, ob, rb, mb, ffx, scx, rpx);
+        const uint32_t e2 = walk_base<MODE>(ix, ethr, l2 && k >= lead, false, a, ia, oa, ra, ma, ffx, scx, rpx);
+        if (e0 | e | e2) failed = 1;
         if (live && failed == 0u && k >= lead && ia == ib && oa == ob && ma == mb) met = 1;
     }
     const uint32_t nv = wave_sum(valid ? 1u : 0u), nm = wave_sum(met);
@@ -1235,6 +1240,14 @@ __global__ __launch_bounds__(256) void seg_count_kernel(const uint64_t *__restri
     uint64_t n = 0, T = 0;
     if (t < n_reads) seg_shape(offs[t + 1] - offs[t], seg_len, n, T);
     n_of[t] = n;                                          // entry n_reads = 0: its exclusive sum is the total
+}
+
+__global__ __launch_bounds__(256) void seg_maxlen_kernel(const uint64_t *__restrict__ offs, uint64_t n_reads,
+                                                        uint32_t *__restrict__ max_len) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t m = t < n_reads ? (uint32_t)(offs[t + 1] - offs[t]) : 0u;   // (reads are shorter than 2^32)
+    for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(m, d); m = o > m ? o : m; }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(max_len, m);
 }
 
 // Segment j of read t covers the emission indexes [j T, min(len, (j + 1) T)): the bases [len - k_end, len - k_begin) of
@@ -1398,10 +1411,40 @@ constexpr int kSegOverrun = 4;   // a boundary lane looks for its meeting point 
 
 // The segmented PML path: plan (count, scan, fill), K1, K2, K3.  Everything on `stream`, nothing read back: the grids are
 // sized for the most segments the batch could have (n_reads + n_bases / seg_len) and surplus lanes leave at once.
+// Is there anything to gain?  One lane per read already fills the GPU when there are enough reads of about the same
+// length (100 k x 10 kbp: 40.5 Gbases/s either way); segments pay when lanes are scarce -- fewer than 4 wavefronts of reads
+// per CU: 60 k x 10 kbp 28.6 -> 34.3, 25 k 12.1 -> 31.4, 200 x 1 Mbp 0.11 -> 27 Gbases/s -- or when the batch is ragged
+// (its longest read holds a lane long after the others are done; log-normal lengths around 10 kbp: 12.2 -> 32.3).
+// *declined = true: nothing was launched, the caller goes on with one lane per read.  `ragged_hint`: 1 / 0 when the
+// caller knows the lengths (the *_host entry points), -1 when only the device does: then a big batch costs one
+// reduction kernel and a 4-byte read-back -- this call waits for `stream` there.
 static hipError_t launch_pml_segmented(const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
                                        uint64_t n_bases, uint16_t *d_out, uint8_t *d_err, DevStats *d_stats,
-                                       const LaunchCfg &cfg, hipStream_t stream, SegWorkspace *ws, bool big_batch_cap) {
+                                       const LaunchCfg &cfg, hipStream_t stream, SegWorkspace *ws, bool big_batch_cap,
+                                       int ragged_hint, bool *declined) {
+    *declined = false;
     const uint32_t S = (uint32_t)cfg.seg_len;
+    if (cfg.seg_probe && n_reads >= (uint64_t)cfg.num_cus * 64ull * 4ull) {
+        if (ragged_hint == 0) { *declined = true; return hipSuccess; }
+        if (ragged_hint < 0) {
+            if (ws->cap < 64) {
+                if (ws->buf) (void)hipFree(ws->buf);
+                ws->buf = nullptr;
+                ws->cap = 0;
+                hipError_t ea = hipMalloc(&ws->buf, 4096);
+                if (ea != hipSuccess) return ea;
+                ws->cap = 4096;
+            }
+            uint32_t *d_max = static_cast<uint32_t *>(ws->buf), h_max = 0;
+            hipError_t ea = hipMemsetAsync(d_max, 0, 4, stream);
+            if (ea != hipSuccess) return ea;
+            hipLaunchKernelGGL(seg_maxlen_kernel, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, stream, d_offsets, n_reads, d_max);
+            ea = hipMemcpyAsync(&h_max, d_max, 4, hipMemcpyDeviceToHost, stream);
+            if (ea == hipSuccess) ea = hipStreamSynchronize(stream);
+            if (ea != hipSuccess) return ea;
+            if ((uint64_t)h_max * 2ull <= (n_bases / n_reads) * 3ull) { *declined = true; return hipSuccess; }   // longest read <= 1.5 x the mean
+        }
+    }
     const uint64_t max_seg = n_reads + n_bases / S + 1;
     if (max_seg > 0x7FFFFFFFull) return hipErrorInvalidValue;
     const uint64_t n_ck = (n_bases >> 5) + 2;
@@ -1416,7 +1459,7 @@ static hipError_t launch_pml_segmented(const DevIndex &ix, const uint8_t *d_base
                  o_in = take(max_seg * 8), o_out = take(max_seg * 8), o_len = take(max_seg * 4), o_j = take(max_seg * 4),
                  o_rem = take(max_seg * 4), o_fin = take(max_seg * sizeof(SegFin)), o_tot = take(max_seg * sizeof(SegTot)),
                  o_join = take(max_seg * sizeof(SegJoin)), o_chain = take(max_seg), o_fail = take(n_reads),
-                 o_ck = take(n_ck * sizeof(SegCkpt)), o_go = take(16);
+                 o_ck = take(n_ck * sizeof(SegCkpt)), o_go = take(32);
     if (ws->cap < off) {
         if (ws->buf) (void)hipFree(ws->buf);
         ws->buf = nullptr;
@@ -1443,10 +1486,10 @@ static hipError_t launch_pml_segmented(const DevIndex &ix, const uint8_t *d_base
     seg.go = go;
     const unsigned bt256 = 256;
     // the probe: is this a batch whose walks fall into step quickly?
-    e = hipMemsetAsync(go, 0, 16, stream);
+    e = hipMemsetAsync(go, 0, 32, stream);
     if (e != hipSuccess) return e;
     if (cfg.seg_probe)
-        hipLaunchKernelGGL(seg_probe_kernel<6>, dim3(16), dim3(64), 0, stream, ix, d_bases, d_offsets, n_reads, 128u, 384u, go + 1);
+        hipLaunchKernelGGL(seg_probe_kernel<6>, dim3(16), dim3(64), 0, stream, ix, d_bases, d_offsets, n_reads, 32u, 384u, go + 1);
     hipLaunchKernelGGL(seg_decide_kernel, dim3(1), dim3(1), 0, stream, go + 1, (uint32_t)(cfg.seg_probe != 0), go);
     hipLaunchKernelGGL(seg_count_kernel, dim3((unsigned)((n_reads + 1 + bt256 - 1) / bt256)), dim3(bt256), 0, stream, d_offsets,
                        n_reads, S, n_of);
@@ -1504,7 +1547,7 @@ static hipError_t launch_pml_segmented(const DevIndex &ix, const uint8_t *d_base
 hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets,
                       uint64_t n_reads, uint64_t n_bases, uint16_t *d_out, uint8_t *d_err, DevStats *d_stats,
                       const uint32_t *d_order, const LaunchCfg &cfg, hipStream_t stream, const ClsArgs &cls,
-                      SegWorkspace *seg_ws) {
+                      SegWorkspace *seg_ws, int ragged_hint) {
     if (n_reads == 0) return hipSuccess;
     // 0 = PML vector only, 1 = vector + classification bins, 2 = bins only
     const int cm = cls.bin_width == 0 ? 0 : (d_out ? 1 : 2);
@@ -1551,9 +1594,12 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     // GPU short of walks -- 100 k reads are 6 wavefronts per CU, and a single 1 Mbp read holds its lane for 2 s --;
     // cut into segments the same batch fills it like a batch of short reads.
     if (seg_ws && cfg.seg_len >= 32 && cm == 0 && !d_order && wp && v == 10 && cfg.block_threads <= 64 &&
-        n_bases / n_reads >= 2ull * (uint64_t)cfg.seg_len && n_reads + n_bases / (uint64_t)cfg.seg_len < 0x7FFFFFF0ull)
-        return launch_pml_segmented(ix, d_bases, d_offsets, n_reads, n_bases, d_out, d_err, d_stats, cfg, stream, seg_ws,
-                                    cfg.pml_variant < 0 || cfg.pml_variant == 14);
+        n_bases / n_reads >= 2ull * (uint64_t)cfg.seg_len && n_reads + n_bases / (uint64_t)cfg.seg_len < 0x7FFFFFF0ull) {
+        bool declined = false;
+        const hipError_t es = launch_pml_segmented(ix, d_bases, d_offsets, n_reads, n_bases, d_out, d_err, d_stats, cfg, stream,
+                                                   seg_ws, cfg.pml_variant < 0 || cfg.pml_variant == 14, ragged_hint, &declined);
+        if (es != hipSuccess || !declined) return es;
+    }
     const int bt = cfg.block_threads > 0 ? cfg.block_threads : 64;           // one wavefront per block: finest dispatch grain
     uint64_t blocks = (n_reads + bt - 1) / bt;
     int wpc = cfg.waves_per_cu;

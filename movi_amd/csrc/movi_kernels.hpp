@@ -112,11 +112,12 @@ struct SegWorkspace {
 };
 
 // d_out == nullptr is allowed when cls.bin_width != 0: verdict bins only, no PML vector is written.
-// seg_ws != nullptr allows the segment-parallel path for batches of long reads (cfg.seg_len).
+// seg_ws != nullptr allows the segment-parallel path for batches of long reads (cfg.seg_len); ragged_hint: 1 / 0 = the
+// caller knows that the longest read is / is not more than 1.5 x the mean, -1 = it does not know (device offsets only).
 hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets,
                       uint64_t n_reads, uint64_t n_bases, uint16_t *d_out, uint8_t *d_err, DevStats *d_stats,
                       const uint32_t *d_order, const LaunchCfg &cfg, hipStream_t stream,
-                      const ClsArgs &cls = ClsArgs(), SegWorkspace *seg_ws = nullptr);
+                      const ClsArgs &cls = ClsArgs(), SegWorkspace *seg_ws = nullptr, int ragged_hint = -1);
 
 hipError_t launch_count(int mode, const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets,
                         uint64_t n_reads, uint64_t *d_matched, uint64_t *d_count, uint8_t *d_err,
