@@ -484,7 +484,7 @@ def main():
             dt3 = time.perf_counter() - t0
             result["long_reads"] = {"workload": "c3", "description": w3["desc"], "value": n3 * L3 * k3 / dt3 / 1e9,
                                     "unit": "Gbases/s", "steps": k3, "ms_per_step": dt3 / k3 * 1e3, "reads_per_gpu": n3,
-                                    "read_len": L3, "kernel": "pml_kernel_flatp<%d,window-parallel>, segment-parallel" % mode,
+                                    "read_len": L3, "kernel": "pml_kernel_flatp<%d,window-parallel>" % mode + (", segment-parallel" if st3.segments else ""),
                                     "fast_forwards_per_base": round(st3.fast_forwards / (n3 * L3), 4),
                                     "scans_per_base": round(st3.scans / (n3 * L3), 4), "errors": int(st3.errors),
                                     "segments": int(st3.segments), "rewalked_reads": int(st3.rewalked)}
