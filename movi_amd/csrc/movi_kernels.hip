@@ -1421,7 +1421,10 @@ constexpr int kSegOverrun = 4;   // a boundary lane looks for its meeting point 
 static hipError_t launch_pml_segmented(const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
                                        uint64_t n_bases, uint16_t *d_out, uint8_t *d_err, DevStats *d_stats,
                                        const LaunchCfg &cfg, hipStream_t stream, SegWorkspace *ws, bool big_batch_cap,
-                                       int ragged_hint, bool *declined) {
+                                       int ragged_hint, bool *declined, const ClsArgs &bins) {
+    // Classification bins (bins.bin_width != 0): not fused into this walk -- a bin spans segments -- but reduced from the
+    // resident PML vector afterwards (classify_kernel: 2 B per base, streaming); without a caller's vector (d_out == NULL:
+    // verdicts only) the PMLs go to the workspace.
     *declined = false;
     const uint32_t S = (uint32_t)cfg.seg_len;
     if (cfg.seg_probe && n_reads >= (uint64_t)cfg.num_cus * 64ull * 4ull) {
@@ -1459,7 +1462,8 @@ static hipError_t launch_pml_segmented(const DevIndex &ix, const uint8_t *d_base
                  o_in = take(max_seg * 8), o_out = take(max_seg * 8), o_len = take(max_seg * 4), o_j = take(max_seg * 4),
                  o_rem = take(max_seg * 4), o_fin = take(max_seg * sizeof(SegFin)), o_tot = take(max_seg * sizeof(SegTot)),
                  o_join = take(max_seg * sizeof(SegJoin)), o_chain = take(max_seg), o_fail = take(n_reads),
-                 o_ck = take(n_ck * sizeof(SegCkpt)), o_go = take(32);
+                 o_ck = take(n_ck * sizeof(SegCkpt)), o_go = take(32),
+                 o_pml = take((bins.bin_width && !d_out) ? n_bases * 2 : 0), o_err = take((bins.bin_width && !d_err) ? n_reads : 0);
     if (ws->cap < off) {
         if (ws->buf) (void)hipFree(ws->buf);
         ws->buf = nullptr;
@@ -1470,6 +1474,8 @@ static hipError_t launch_pml_segmented(const DevIndex &ix, const uint8_t *d_base
         ws->cap = want;
     }
     uint8_t *B = static_cast<uint8_t *>(ws->buf);
+    if (bins.bin_width && !d_out) d_out = reinterpret_cast<uint16_t *>(B + o_pml);
+    if (bins.bin_width && !d_err) d_err = B + o_err;
     uint64_t *n_of = reinterpret_cast<uint64_t *>(B + o_nof), *first = reinterpret_cast<uint64_t *>(B + o_first);
     uint64_t *seg_in = reinterpret_cast<uint64_t *>(B + o_in), *seg_out = reinterpret_cast<uint64_t *>(B + o_out);
     uint32_t *seg_l = reinterpret_cast<uint32_t *>(B + o_len), *seg_j = reinterpret_cast<uint32_t *>(B + o_j),
@@ -1541,7 +1547,10 @@ static hipError_t launch_pml_segmented(const DevIndex &ix, const uint8_t *d_base
     MOVI_LAUNCH_SEG_T(2, n_reads);
 #undef MOVI_LAUNCH_SEG_T
 #undef MOVI_LAUNCH_SEG
-    return hipGetLastError();
+    e = hipGetLastError();
+    if (e == hipSuccess && bins.bin_width)
+        e = launch_classify(d_out, d_offsets, n_reads, bins.bin_width, bins.thr, bins.above, bins.below, bins.sum_max, stream, d_err);
+    return e;
 }
 
 hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets,
@@ -1593,11 +1602,11 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     // Batches of long reads: segment-parallel (plain PML through the default kernel only).  One lane per read leaves the
     // GPU short of walks -- 100 k reads are 6 wavefronts per CU, and a single 1 Mbp read holds its lane for 2 s --;
     // cut into segments the same batch fills it like a batch of short reads.
-    if (seg_ws && cfg.seg_len >= 32 && cm == 0 && !d_order && wp && v == 10 && cfg.block_threads <= 64 &&
+    if (seg_ws && cfg.seg_len >= 32 && !d_order && wp && v == 10 && cfg.block_threads <= 64 &&
         n_bases / n_reads >= 2ull * (uint64_t)cfg.seg_len && n_reads + n_bases / (uint64_t)cfg.seg_len < 0x7FFFFFF0ull) {
         bool declined = false;
         const hipError_t es = launch_pml_segmented(ix, d_bases, d_offsets, n_reads, n_bases, d_out, d_err, d_stats, cfg, stream,
-                                                   seg_ws, cfg.pml_variant < 0 || cfg.pml_variant == 14, ragged_hint, &declined);
+                                                   seg_ws, cfg.pml_variant < 0 || cfg.pml_variant == 14, ragged_hint, &declined, cls);
         if (es != hipSuccess || !declined) return es;
     }
     const int bt = cfg.block_threads > 0 ? cfg.block_threads : 64;           // one wavefront per block: finest dispatch grain
@@ -2345,9 +2354,13 @@ __global__ __launch_bounds__(256) void classify_kernel(const uint16_t *__restric
                                                        const uint64_t *__restrict__ offs, uint64_t n_reads,
                                                        uint32_t bin_width, uint32_t thr,
                                                        uint32_t *__restrict__ above, uint32_t *__restrict__ below,
-                                                       uint64_t *__restrict__ sum_max) {
+                                                       uint64_t *__restrict__ sum_max, const uint8_t *__restrict__ err) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_reads) return;
+    if (err && err[t]) {                                  // a read that broke an invariant reports no bins (ClsState::store)
+        above[t] = 0; below[t] = 0; sum_max[t] = 0;
+        return;
+    }
     const uint64_t beg = offs[t], n = offs[t + 1] - beg;
     const uint16_t *P = pml + beg;
     uint64_t nb = n / bin_width;                          // bins: [iW, (i+1)W) for i < nb-1, last = [(nb-1)W, n)
@@ -2382,13 +2395,14 @@ __global__ __launch_bounds__(256) void classify_kernel(const uint16_t *__restric
 }
 
 hipError_t launch_classify(const uint16_t *d_pml, const uint64_t *d_offsets, uint64_t n_reads, uint32_t bin_width,
-                           uint32_t thr, uint32_t *d_above, uint32_t *d_below, uint64_t *d_sum, hipStream_t stream) {
+                           uint32_t thr, uint32_t *d_above, uint32_t *d_below, uint64_t *d_sum, hipStream_t stream,
+                           const uint8_t *d_err) {
     if (n_reads == 0) return hipSuccess;
     const unsigned bt = 256;
     const uint64_t blocks = (n_reads + bt - 1) / bt;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     hipLaunchKernelGGL(classify_kernel, dim3((unsigned)blocks), dim3(bt), 0, stream, d_pml, d_offsets, n_reads, bin_width,
-                       thr, d_above, d_below, d_sum);
+                       thr, d_above, d_below, d_sum, d_err);
     return hipGetLastError();
 }
 

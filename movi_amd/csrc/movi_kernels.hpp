@@ -127,8 +127,10 @@ hipError_t launch_zml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
                       uint64_t n_reads, uint64_t n_bases, uint16_t *d_out, uint8_t *d_err, DevStats *d_stats,
                       const uint32_t *d_order, const LaunchCfg &cfg, hipStream_t stream);
 
+// d_err (optional): reads flagged there report no bins (0, 0, 0), like the fused kernels.
 hipError_t launch_classify(const uint16_t *d_pml, const uint64_t *d_offsets, uint64_t n_reads, uint32_t bin_width,
-                           uint32_t thr, uint32_t *d_above, uint32_t *d_below, uint64_t *d_sum, hipStream_t stream);
+                           uint32_t thr, uint32_t *d_above, uint32_t *d_below, uint64_t *d_sum, hipStream_t stream,
+                           const uint8_t *d_err = nullptr);
 
 // Mode 7: ix = a mode-7 view (widened rows + tally table); writes r mode-6 rows (8 bytes each) with the ids recovered by get_id.
 hipError_t expand_sampled_rows(int mode, const DevIndex &ix, void *d_rows6, hipStream_t stream);   // mode 7 or 5

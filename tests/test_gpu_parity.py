@@ -1149,3 +1149,47 @@ def test_segment_parallel_probe_decides(engines):
         exp, ff, sc = cpu.pml_batch(bases, offs, threads=4)
         assert (out == exp).all() and (st.fast_forwards, st.scans, st.errors) == (ff, sc, 0)
         assert (st.segments > 0) == want_segments, (want_segments, st.segments, st.rewalked)
+
+
+def test_segment_parallel_with_classification_bins(engines):
+    """--classify on a batch that is walked segment-parallel: the bins are reduced from the resident PML vector after the
+    walk instead of inside it (a bin spans segments); verdict-only calls keep the vector in the workspace.  Same bins as
+    the fused one-lane-per-read kernels, with and without the caller's PML vector."""
+    import torch
+    from oracle import build_index as B
+    gpu, cpu = engines[6]
+    ref = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))[0][1]
+    rng = np.random.default_rng(7400)
+    reads = mutated_reads(rng, ref, 120, 600, 2500) + [b"", b"ACGT" * 40, bytes(ref[:1000])]
+    bases, offs = pack(reads)
+    n = len(reads)
+    gpu.set_option("seg_len", 0)
+    exp_bins = gpu.classify_packed(bases, offs, 150, 8)
+    exp_pml, _, _ = cpu.pml_batch(bases, offs, threads=4)
+    dev = torch.device("cuda", 0)
+    d_bases = torch.from_numpy(bases.copy()).to(dev)
+    d_offs = torch.from_numpy(offs.view(np.int64).copy()).to(dev)
+    gpu.set_option("seg_len", 64)
+    gpu.set_option("seg_probe", 0)
+    try:
+        got = gpu.classify_packed(bases, offs, 150, 8)                       # verdicts only (movi_pml_classify_host)
+        assert all((x == y).all() for x, y in zip(got, exp_bins))
+        for with_vector in (True, False):
+            d_out = torch.zeros(bases.size, dtype=torch.int16, device=dev)
+            d_a = torch.full((n,), -1, dtype=torch.int32, device=dev)
+            d_b = torch.full((n,), -1, dtype=torch.int32, device=dev)
+            d_s = torch.full((n,), -1, dtype=torch.int64, device=dev)
+            gpu.pml_classify_device(d_bases.data_ptr(), d_offs.data_ptr(), n, bases.size, 150, 8,
+                                    d_out.data_ptr() if with_vector else 0, d_a.data_ptr(), d_b.data_ptr(), d_s.data_ptr())
+            torch.cuda.synchronize()
+            st = gpu.last_stats()
+            assert st.segments > n
+            assert (d_a.cpu().numpy().view(np.uint32) == exp_bins[0]).all() and (d_b.cpu().numpy().view(np.uint32) == exp_bins[1]).all()
+            assert (d_s.cpu().numpy().view(np.uint64) == exp_bins[2]).all()
+            if with_vector:
+                assert (d_out.cpu().numpy().view(np.uint16) == exp_pml).all()
+            else:
+                assert int(d_out.abs().sum().item()) == 0
+    finally:
+        gpu.set_option("seg_len", 2048)
+        gpu.set_option("seg_probe", 1)
