@@ -263,6 +263,8 @@ int run_query(const Options &o) {
         for (const auto &e : errs)
             if (!e.empty()) throw EngineError("uploading the index: " + e);
     }
+    if (o.seg_len >= 0)
+        for (auto *hd : handles) check(movi_set_option(hd, "seg_len", o.seg_len), "--seg-len");
     movi_index_desc_t desc;
     check(movi_index_get_desc(handles[0], &desc), "index description");
     const std::string index_type = index_type_name(desc.mode);

@@ -38,6 +38,7 @@ struct Options {
     size_t bin_width = 150;
     int gpus = 1;                 // extension: --gpus N shards the reads across N devices
     int device = 0;               // extension: --device D
+    long seg_len = -1;            // extension: --seg-len N: segment length of the segment-parallel long-read walk (0 = off; default: the engine's)
 
     // derived predicates, same names as the reference (movi_options.hpp:57-58)
     bool write_output_allowed() const { return !no_output && !filter; }
