@@ -158,7 +158,9 @@ int movi_index_device_rows(const movi_index_t *ix, const void **d_rows, size_t *
  * d_read_order[t].  Results stay indexed by read.  A hook for callers with their own
  * scheduling; sorting by length measured no gain on MI355X, so the host entry
  * points pass NULL.  At most 2^32 reads per call, each shorter than 2^32 bases.
- * Asynchronous on `stream` (a hipStream_t, NULL = the null stream). */
+ * Asynchronous on `stream` (a hipStream_t, NULL = the null stream) -- except that a batch of long reads that
+ * qualifies for the segment-parallel walk ("seg_len" below) makes the call wait for a short probe of the batch
+ * (under a millisecond) before it enqueues the walk. */
 int movi_pml_device(movi_index_t *ix, const uint8_t *d_bases, const uint64_t *d_offsets,
                     uint64_t n_reads, uint64_t n_bases, uint16_t *d_out_pml, uint8_t *d_read_err,
                     const uint32_t *d_read_order, void *stream);
