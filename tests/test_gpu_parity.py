@@ -49,6 +49,22 @@ def test_index_load_from_directory(built_lib):
     assert e.value.code == -3
 
 
+def check_segmented(gpu, bases, offs, exp, ff, sc, tag=None):
+    """The same batch through the segment-parallel path (32-base segments, whatever the probe would say): same PMLs, same counters."""
+    gpu.set_option("pml_variant", -1)
+    gpu.set_option("seg_len", 32)
+    gpu.set_option("seg_probe", 0)
+    try:
+        out, st = gpu.query_pml_packed(bases, offs)
+        if bases.size >= 64 * (offs.size - 1):
+            assert st.segments > 0, tag
+        assert (out == exp).all(), tag
+        assert (st.fast_forwards, st.scans, st.errors) == (ff, sc, 0), (tag, st.segments, st.rewalked)
+    finally:
+        gpu.set_option("seg_len", 2048)
+        gpu.set_option("seg_probe", 1)
+
+
 def mutated_reads(rng, ref, n, lo, hi):
     reads = []
     for _ in range(n):
@@ -556,6 +572,7 @@ def test_fuzz_small_indexes(built_lib, tmp_path, alphabet):
                 exp, ff, sc = cpu.pml_batch(bases, offs, threads=2)
                 assert (out == exp).all(), (alphabet, trial, mode, variant)
                 assert (st.fast_forwards, st.scans, st.errors) == (ff, sc, 0)
+            check_segmented(gpu, bases, offs, exp, ff, sc, (alphabet, trial, mode))
             m, c, _ = gpu.query_count_packed(bases, offs)
             em, ec = cpu.count_batch(bases, offs, threads=2)
             assert (m == em).all() and (c == ec).all(), (alphabet, trial, mode)
@@ -623,6 +640,7 @@ def test_separators_reference_index_vs_oracle(built_lib, mode):
         out, st = gpu.query_pml_packed(bases, offs)
         assert (out == exp).all(), variant
         assert (st.fast_forwards, st.scans, st.errors) == (ff, sc, 0)
+    check_segmented(gpu, bases, offs, exp, ff, sc, "separators")
     m, c, _ = gpu.query_count_packed(bases, offs)
     em, ec = cpu.count_batch(bases, offs, threads=4)
     assert (m == em).all() and (c == ec).all()
@@ -652,6 +670,7 @@ def test_separators_fuzz_many_sequences(built_lib, seed):
             out, st = gpu.query_pml_packed(bases, offs)
             assert (out == exp).all(), (seed, mode, variant)
             assert (st.fast_forwards, st.scans, st.errors) == (ff, sc, 0)
+        check_segmented(gpu, bases, offs, exp, ff, sc, (seed, mode))
         m, c, _ = gpu.query_count_packed(bases, offs)
         em, ec = cpu.count_batch(bases, offs, threads=2)
         assert (m == em).all() and (c == ec).all(), (seed, mode)
