@@ -631,7 +631,7 @@ static int ml_device(bool zml, movi_index_t *ix, const uint8_t *d_bases, const u
     if (n_reads > 0xFFFFFFFFull) return fail(MOVI_ERR_ARG, "more than 2^32 reads in one call");
     if (zml)
         HIP_TRY(launch_zml(ix->kmode, ix->dev, d_bases, d_offsets, n_reads, n_bases, d_out, d_read_err, d_stats,
-                           d_read_order, ix->cfg, s));
+                           d_read_order, ix->cfg, s, seg_ws, ragged_hint));
     else
         HIP_TRY(launch_pml(ix->kmode, ix->dev, d_bases, d_offsets, n_reads, n_bases, d_out, d_read_err, d_stats,
                            d_read_order, ix->cfg, s, cls, seg_ws, ragged_hint));

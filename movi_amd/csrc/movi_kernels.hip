@@ -1934,23 +1934,67 @@ hipError_t launch_count(int mode, const DevIndex &ix, const uint8_t *d_bases, co
 // which produces the same vector (value at a base = bases of its phrase to its right).  Every
 // step consumes exactly one base, so the packed I/O of PML variant 1 carries over: 16 bases per
 // fetch, values leave as paired 16-byte stores.  The walkers are the count query's.
+// One base of query_zml (src/move_structure_query.cpp:690-785) for the lanes with `live`: a base either extends the open
+// phrase (update_interval + two LF moves, ml += 1) or ends it (ml = 0) and opens the next one from the first / last run
+// tables.  State: the interval [rs:os, re:oe] with the rows of its two ends, `open`, ml.  Wave-uniform loops inside:
+// every lane of the wavefront must make the call.  Returns a kErr* code.
 template <int MODE>
+__device__ __forceinline__ uint32_t zml_base(const DevIndex &ix, bool live, uint32_t b, uint32_t &open, uint64_t &rs, uint32_t &os,
+                                             uint2 &rws, uint64_t &re, uint32_t &oe, uint2 &rwe, uint32_t &ml, uint32_t &ff_total,
+                                             uint32_t &scan_total) {
+    uint32_t failed = 0;
+    // backward_search_step, src/move_structure_search.cpp:311-333, for lanes with an open phrase
+    const bool ext = live && open != 0u && b != 0xFFu;
+    if (ix.r >= 8) {                     // update_interval :48-61, as in count_kernel_v0
+        shrink_interval<MODE>(ix, ext && rs <= re, b, rs, os, rws, re, oe, rwe, scan_total);
+    } else {
+        shrink_interval_rows<MODE>(ix, ext && rs <= re, b, rs, os, rws, re, oe, rwe, scan_total);
+    }
+    bool nonempty = ext && ((rs < re) || (rs == re && os <= oe));
+    const uint32_t e12 = lf_step2<MODE>(ix, nonempty, rs, os, rws, re, oe, rwe, ff_total);
+    if (e12) { failed = e12; nonempty = false; }
+    if (nonempty && !((rs < re) || (rs == re && os <= oe))) nonempty = false;   // query_zml :717
+    if (live && failed == 0u) {
+        if (nonempty) {
+            ml += 1;                                  // :718-720
+        } else {
+            ml = 0;                                   // :750-760, or no phrase yet (:696-704)
+            open = 0;
+            if (b != 0xFFu) {                         // this base opens the next phrase
+                rs = ix.first_runs[b + 1]; re = ix.last_runs[b + 1];
+                os = (uint32_t)ix.first_offsets[b + 1]; oe = (uint32_t)ix.last_offsets[b + 1];
+                open = ((rs < re) || (rs == re && os <= oe)) ? 1u : 0u;
+                if (open) {                           // the LF moves carry the rows over from here on
+                    rws = load_row<MODE>(ix.rows, rs);
+                    rwe = load_row<MODE>(ix.rows, re);
+                }
+            }
+        }
+    }
+    return failed;
+}
+
+// SEG (segment-parallel long reads, as for PML): 0 = a lane parses a read; 1 = a lane parses one SEGMENT of a read from
+// the state every read starts in, leaves a checkpoint of its state every 32 bases and its final state, and reports
+// through its segment's record instead of err[] / the global counters; 2 = whole reads again, only those in read_fail.
+template <int MODE, int SEG = 0>
 __global__ __launch_bounds__(256) void zml_kernel(DevIndex ix, const uint8_t *__restrict__ bases,
                                                   const uint64_t *__restrict__ offs, uint64_t n_reads,
                                                   uint16_t *__restrict__ out, uint8_t *__restrict__ err,
-                                                  DevStats *stats, const uint32_t *__restrict__ order) {
+                                                  DevStats *stats, const uint32_t *__restrict__ order, ZSegArgs seg) {
     __shared__ uint8_t s_code[256];
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = ix.code_of[i];
     __syncthreads();
 
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t ff_total = 0, scan_total = 0, failed = 0;
-    const bool valid = t < n_reads;
-    const uint64_t rid = (valid && order) ? order[t] : t;
-    const uint64_t beg = valid ? offs[rid] : 0;
-    const uint64_t len = valid ? offs[rid + 1] - beg : 0;
+    const bool valid = SEG == 1 ? t < *seg.n_seg : (t < n_reads && (SEG != 2 || seg.read_fail[t] != 0));
+    const uint64_t rid = (valid && order && SEG == 0) ? order[t] : t;
+    const uint64_t beg = valid ? (SEG == 1 ? seg.seg_in[rid] : offs[rid]) : 0;
+    const uint64_t len = valid ? (SEG == 1 ? (uint64_t)seg.seg_len[rid] : offs[rid + 1] - beg) : 0;
+    const uint64_t obeg = (SEG == 1 && valid) ? seg.seg_out[rid] : beg;
     const uint8_t *R = bases + beg;
-    uint16_t *O = out + beg;
+    uint16_t *O = out + obeg;
     uint64_t rs = 0, re = 0;                              // MoveInterval [rs:os, re:oe]
     uint32_t os = 0, oe = 0;
     uint32_t open = 0;                                    // 1 while a phrase (non-empty interval) exists
@@ -1981,32 +2025,20 @@ __global__ __launch_bounds__(256) void zml_kernel(DevIndex ix, const uint8_t *__
         }
         uint32_t b = 0xFFu;
         if (live) b = s_code[(uint32_t)(rb >> (8 * (7 - (k & 7)))) & 0xFFu];
-        // backward_search_step, src/move_structure_search.cpp:311-333, for lanes with an open phrase
-        const bool ext = live && open != 0u && b != 0xFFu;
-        if (ix.r >= 8) {                     // update_interval :48-61, as in count_kernel_v0
-            shrink_interval<MODE>(ix, ext && rs <= re, b, rs, os, rws, re, oe, rwe, scan_total);
-        } else {
-            shrink_interval_rows<MODE>(ix, ext && rs <= re, b, rs, os, rws, re, oe, rwe, scan_total);
+        {
+            const uint32_t ez = zml_base<MODE>(ix, live, b, open, rs, os, rws, re, oe, rwe, ml, ff_total, scan_total);
+            if (ez) failed = ez;
         }
-        bool nonempty = ext && ((rs < re) || (rs == re && os <= oe));
-        const uint32_t e12 = lf_step2<MODE>(ix, nonempty, rs, os, rws, re, oe, rwe, ff_total);
-        if (e12) { failed = e12; nonempty = false; }
-        if (nonempty && !((rs < re) || (rs == re && os <= oe))) nonempty = false;   // query_zml :717
-        if (live && failed == 0u) {
-            if (nonempty) {
-                ml += 1;                                  // :718-720
-            } else {
-                ml = 0;                                   // :750-760, or no phrase yet (:696-704)
-                open = 0;
-                if (b != 0xFFu) {                         // this base opens the next phrase
-                    rs = ix.first_runs[b + 1]; re = ix.last_runs[b + 1];
-                    os = (uint32_t)ix.first_offsets[b + 1]; oe = (uint32_t)ix.last_offsets[b + 1];
-                    open = ((rs < re) || (rs == re && os <= oe)) ? 1u : 0u;
-                    if (open) {                           // the LF moves carry the rows over from here on
-                        rws = load_row<MODE>(ix.rows, rs);
-                        rwe = load_row<MODE>(ix.rows, re);
-                    }
-                }
+        if (SEG == 1 && live && failed == 0u) {
+            if ((k & 31ull) == 31ull) {
+                ZSegCkpt ck;
+                ck.rs = rs; ck.re = re; ck.os = os; ck.oe = oe; ck.ml = ml; ck.open = open; ck.ff = ff_total; ck.scan = scan_total;
+                seg.ckpt[(obeg + k) >> 5] = ck;
+            }
+            if (k + 1 == len) {
+                ZSegFin fn;
+                fn.rs = rs; fn.re = re; fn.os = os; fn.oe = oe; fn.ml = ml; fn.open = open;
+                seg.fin[rid] = fn;
             }
         }
         const uint32_t val = ml > 65535u ? 65535u : ml;   // MoveQuery::add_ml
@@ -2026,6 +2058,14 @@ __global__ __launch_bounds__(256) void zml_kernel(DevIndex ix, const uint8_t *__
             }
         }
     }
+    if (SEG == 1) {
+        if (valid) {
+            SegTot tt;
+            tt.ff = ff_total; tt.scan = scan_total; tt.repo = 0; tt.flag = failed;
+            seg.tot[rid] = tt;
+        }
+        return;
+    }
     if (failed) {
         for (uint64_t k = 0; k < len; ++k) O[k] = 0;
     }
@@ -2035,6 +2075,113 @@ __global__ __launch_bounds__(256) void zml_kernel(DevIndex ix, const uint8_t *__
         if (ffw) atomicAdd(&stats->fast_forwards, (unsigned long long)ffw);
         if (scw) atomicAdd(&stats->scans, (unsigned long long)scw);
         if (erw) atomicAdd(&stats->errors, (unsigned long long)erw);
+    }
+}
+
+// K2 of the segmented ZML parse: one lane per segment boundary continues the parse of the segment before until its state
+// -- interval, open flag, match length -- equals a checkpoint of the speculative parse (usually at the first phrase both
+// open at the same base).  PASS 0 finds the meeting point, PASS 1 writes the stretches of the lanes on a chain
+// (seg_stitch_kernel has the reasoning).
+template <int MODE, int PASS>
+__global__ __launch_bounds__(256) void zml_stitch_kernel(DevIndex ix, const uint8_t *__restrict__ bases, ZSegArgs seg,
+                                                        const uint32_t *__restrict__ seg_j, const uint32_t *__restrict__ seg_rem,
+                                                        uint32_t max_over, const uint8_t *__restrict__ on_chain,
+                                                        uint16_t *__restrict__ out, SegJoin *__restrict__ join) {
+    __shared__ uint8_t s_code[256];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = ix.code_of[i];
+    __syncthreads();
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool mine = s < *seg.n_seg && seg_j[s] != 0 && (PASS == 0 || on_chain[s] != 0);
+    uint32_t ff_total = 0, scan_total = 0, failed = 0, how = 0;
+    bool live0 = mine;
+    if (PASS == 0 && mine && (seg.tot[s].flag != 0u || seg.tot[s - 1].flag != 0u)) live0 = false;
+    const uint32_t T = live0 ? seg.seg_len[s] : 1u;
+    const uint32_t rem = live0 ? seg_rem[s] : 0u;
+    const uint64_t len = PASS == 0 ? (rem < max_over ? rem : max_over) : (live0 ? join[s].kend + 1u : 0u);
+    const uint8_t *R = bases + (live0 ? seg.seg_in[s] + T : 0);          // one past this segment's first base
+    const uint64_t obeg = live0 ? seg.seg_out[s] : 0;
+    uint16_t *O = out + obeg;
+    uint64_t rs = 0, re = 0;
+    uint32_t os = 0, oe = 0, ml = 0, open = 0, kend = 0;
+    uint2 rws = make_uint2(0, 0), rwe = make_uint2(0, 0);
+    SegJoin res{};
+    if (live0) {
+        const ZSegFin f = seg.fin[s - 1];
+        rs = f.rs; re = f.re; os = f.os; oe = f.oe; ml = f.ml; open = f.open;
+        if (open) {
+            rws = load_row<MODE>(ix.rows, rs);
+            rwe = load_row<MODE>(ix.rows, re);
+        }
+    }
+    for (uint64_t k = 0; wave_any(k < len && failed == 0u && how == 0u); ++k) {
+        const bool live = k < len && failed == 0u && how == 0u;
+        uint32_t b = 0xFFu;
+        if (live) b = s_code[*(R - 1 - (int64_t)k)];
+        const uint32_t ez = zml_base<MODE>(ix, live, b, open, rs, os, rws, re, oe, rwe, ml, ff_total, scan_total);
+        if (ez) failed = ez;
+        if (PASS == 1) {
+            if (live && failed == 0u) O[k] = (uint16_t)(ml > 65535u ? 65535u : ml);
+        } else if (live && failed == 0u) {
+            kend = (uint32_t)k;
+            if ((k & 31ull) == 31ull) {
+                const ZSegCkpt c = seg.ckpt[(obeg + k) >> 5];
+                // (an interval is only compared while a phrase is open: a closed one holds stale rows)
+                if (c.ml == ml && c.open == open && (open == 0u || (c.rs == rs && c.re == re && c.os == os && c.oe == oe))) {
+                    const uint32_t ds = (uint32_t)(k / T);
+                    const SegTot spec = seg.tot[s + ds];
+                    how = spec.flag == 0u ? 1u : 0u;
+                    if (spec.flag != 0u) failed = spec.flag;
+                    res.ff = ff_total + (spec.ff - c.ff); res.scan = scan_total + (spec.scan - c.scan); res.repo = 0; res.segs = ds;
+                }
+            }
+            if (how == 0u && failed == 0u && k + 1 == rem) {
+                how = 2u;
+                res.ff = ff_total; res.scan = scan_total; res.repo = 0; res.segs = (uint32_t)(k / T);
+            }
+        }
+    }
+    if (PASS == 0 && mine) {
+        res.kend = kend;
+        res.how = how;
+        join[s] = res;
+    }
+}
+
+// The probe of the segmented ZML parse: two speculative parses per sampled position, `lead` bases apart (seg_probe_kernel).
+template <int MODE>
+__global__ __launch_bounds__(256) void zml_probe_kernel(DevIndex ix, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ offs,
+                                                       uint64_t n_reads, uint32_t lead, uint32_t reach, uint32_t *__restrict__ tally) {
+    __shared__ uint8_t s_code[256];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = ix.code_of[i];
+    __syncthreads();
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, n_lanes = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t stride = n_reads > n_lanes ? n_reads / n_lanes : 1, per = n_reads < n_lanes ? n_lanes / n_reads : 1;
+    const uint64_t rid = per > 1 ? t % n_reads : t * stride, slot = per > 1 ? t / n_reads : 0;
+    bool valid = rid < n_reads && slot < per;
+    const uint64_t beg = valid ? offs[rid] : 0, len = valid ? offs[rid + 1] - beg : 0;
+    const uint64_t mid = len * (2 * slot + 1) / (2 * per);
+    valid = valid && mid >= reach && mid + lead <= len;
+    const uint8_t *R = bases + beg + mid + lead;
+    uint64_t ars = 0, are = 0, brs = 0, bre = 0;
+    uint32_t aos = 0, aoe = 0, bos = 0, boe = 0, aml = 0, bml = 0, aop = 0, bop = 0, ffx = 0, scx = 0, failed = 0, met = 0;
+    uint2 arws = make_uint2(0, 0), arwe = arws, brws = arws, brwe = arws;
+    for (uint32_t k = 0; wave_any(valid && k < lead + reach && failed == 0u && met == 0u); ++k) {
+        const bool live = valid && k < lead + reach && failed == 0u && met == 0u;
+        uint32_t b = 0xFFu;
+        if (live) b = s_code[*(R - 1 - (int64_t)k)];
+        const uint32_t e1 = zml_base<MODE>(ix, live, b, bop, brs, bos, brws, bre, boe, brwe, bml, ffx, scx);
+        const uint32_t e2 = zml_base<MODE>(ix, live && k >= lead, b, aop, ars, aos, arws, are, aoe, arwe, aml, ffx, scx);
+        if (e1 | e2) failed = 1;
+        if (live && failed == 0u && k >= lead && aml == bml && aop == bop &&
+            (aop == 0u || (ars == brs && are == bre && aos == bos && aoe == boe)))
+            met = 1;
+        if (k == lead + reach / 2 && 2 * __popcll(__ballot(met != 0u)) < __popcll(__ballot(valid))) break;
+        if (k == lead + reach / 6 && 10 * __popcll(__ballot(met != 0u)) < __popcll(__ballot(valid))) break;
+    }
+    const uint32_t nv = wave_sum(valid ? 1u : 0u), nm = wave_sum(met);
+    if ((threadIdx.x & 63) == 0) {
+        if (nv) atomicAdd(&tally[0], nv);
+        if (nm) atomicAdd(&tally[1], nm);
     }
 }
 
@@ -2314,10 +2461,123 @@ __global__ __launch_bounds__(256) void zml_kernel_flat(DevIndex ix, const uint8_
     }
 }
 
+// The segmented ZML parse (the PML one, launch_pml_segmented, has the reasoning): plan, probe (verdict read back), K1 =
+// zml_kernel<MODE, 1> over the segments, K2 = zml_stitch_kernel find + write, K3 = seg_finalize_kernel + zml_kernel<MODE, 2>.
+// Unlike the PML walk the ZML parse is latency-bound even on a full batch of long reads (100 k x 10 kbp: 19 Gbases/s), so
+// there is something to gain up to 8 wavefronts of reads per CU.
+template <int MODE>
+static hipError_t launch_zml_segmented(const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
+                                       uint64_t n_bases, uint16_t *d_out, uint8_t *d_err, DevStats *d_stats, const LaunchCfg &cfg,
+                                       hipStream_t stream, SegWorkspace *ws, int ragged_hint, bool *declined) {
+    *declined = false;
+    const uint32_t S = (uint32_t)cfg.seg_len;
+    hipError_t e = hipSuccess;
+    if (cfg.seg_probe && n_reads >= (uint64_t)cfg.num_cus * 64ull * 8ull) {
+        if (ragged_hint == 0) { *declined = true; return hipSuccess; }
+        if (ragged_hint < 0) {
+            if (ws->cap < 64) {
+                if (ws->buf) (void)hipFree(ws->buf);
+                ws->buf = nullptr;
+                ws->cap = 0;
+                e = hipMalloc(&ws->buf, 4096);
+                if (e != hipSuccess) return e;
+                ws->cap = 4096;
+            }
+            uint32_t *d_max = static_cast<uint32_t *>(ws->buf), h_max = 0;
+            e = hipMemsetAsync(d_max, 0, 4, stream);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(seg_maxlen_kernel, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, stream, d_offsets, n_reads, d_max);
+            e = hipMemcpyAsync(&h_max, d_max, 4, hipMemcpyDeviceToHost, stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(stream);
+            if (e != hipSuccess) return e;
+            if ((uint64_t)h_max * 2ull <= (n_bases / n_reads) * 3ull) { *declined = true; return hipSuccess; }
+        }
+    }
+    const uint64_t max_seg = n_reads + n_bases / S + 1;
+    if (max_seg > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    const uint64_t n_ck = (n_bases >> 5) + 2;
+    size_t temp_bytes = 0;
+    e = hipcub::DeviceScan::ExclusiveSum(nullptr, temp_bytes, (uint64_t *)nullptr, (uint64_t *)nullptr, (int)(n_reads + 1), stream);
+    if (e != hipSuccess) return e;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += align_up(bytes ? bytes : 8); return o; };
+    const size_t o_nof = take((n_reads + 1) * 8), o_first = take((n_reads + 1) * 8), o_temp = take(temp_bytes),
+                 o_in = take(max_seg * 8), o_out = take(max_seg * 8), o_len = take(max_seg * 4), o_j = take(max_seg * 4),
+                 o_rem = take(max_seg * 4), o_fin = take(max_seg * sizeof(ZSegFin)), o_tot = take(max_seg * sizeof(SegTot)),
+                 o_join = take(max_seg * sizeof(SegJoin)), o_chain = take(max_seg), o_fail = take(n_reads),
+                 o_ck = take(n_ck * sizeof(ZSegCkpt)), o_go = take(32);
+    if (ws->cap < off) {
+        if (ws->buf) (void)hipFree(ws->buf);
+        ws->buf = nullptr;
+        ws->cap = 0;
+        const size_t want = off + (off >> 3);
+        e = hipMalloc(&ws->buf, want);
+        if (e != hipSuccess) return e;
+        ws->cap = want;
+    }
+    uint8_t *B = static_cast<uint8_t *>(ws->buf);
+    uint64_t *n_of = reinterpret_cast<uint64_t *>(B + o_nof), *first = reinterpret_cast<uint64_t *>(B + o_first);
+    uint64_t *seg_in = reinterpret_cast<uint64_t *>(B + o_in), *seg_out = reinterpret_cast<uint64_t *>(B + o_out);
+    uint32_t *seg_l = reinterpret_cast<uint32_t *>(B + o_len), *seg_j = reinterpret_cast<uint32_t *>(B + o_j),
+             *seg_rem = reinterpret_cast<uint32_t *>(B + o_rem);
+    SegJoin *join = reinterpret_cast<SegJoin *>(B + o_join);
+    uint8_t *on_chain = B + o_chain, *read_fail = B + o_fail;
+    ZSegArgs seg;
+    seg.seg_in = seg_in; seg.seg_out = seg_out; seg.seg_len = seg_l; seg.n_seg = first + n_reads;
+    seg.ckpt = reinterpret_cast<ZSegCkpt *>(B + o_ck);
+    seg.fin = reinterpret_cast<ZSegFin *>(B + o_fin);
+    seg.tot = reinterpret_cast<SegTot *>(B + o_tot);
+    seg.read_fail = read_fail;
+    uint32_t *go = reinterpret_cast<uint32_t *>(B + o_go);               // go | probes | probes in step
+    const unsigned bt256 = 256;
+    e = hipMemsetAsync(go, 0, 32, stream);
+    if (e != hipSuccess) return e;
+    if (cfg.seg_probe)
+        hipLaunchKernelGGL(zml_probe_kernel<MODE>, dim3(16), dim3(64), 0, stream, ix, d_bases, d_offsets, n_reads, 32u, 384u, go + 1);
+    hipLaunchKernelGGL(seg_decide_kernel, dim3(1), dim3(1), 0, stream, go + 1, (uint32_t)(cfg.seg_probe != 0), go);
+    if (cfg.seg_probe) {
+        uint32_t h_go = 0;
+        e = hipMemcpyAsync(&h_go, go, 4, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) return e;
+        if (!h_go) { *declined = true; return hipSuccess; }
+    }
+    hipLaunchKernelGGL(seg_count_kernel, dim3((unsigned)((n_reads + 1 + bt256 - 1) / bt256)), dim3(bt256), 0, stream, d_offsets,
+                       n_reads, S, n_of);
+    e = hipcub::DeviceScan::ExclusiveSum(B + o_temp, temp_bytes, n_of, first, (int)(n_reads + 1), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(seg_fill_kernel, dim3((unsigned)((n_reads + bt256 - 1) / bt256)), dim3(bt256), 0, stream, d_offsets,
+                       n_reads, S, first, seg_in, seg_out, seg_l, seg_j, seg_rem);
+    const uint32_t *d_order = nullptr;
+    hipLaunchKernelGGL((zml_kernel<MODE, 1>), dim3((unsigned)((max_seg + bt256 - 1) / bt256)), dim3(bt256), 0, stream, ix, d_bases,
+                       d_offsets, max_seg, d_out, d_err, d_stats, d_order, seg);
+    const uint32_t max_over = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, (uint64_t)S * (uint64_t)kSegOverrun);
+    hipLaunchKernelGGL((zml_stitch_kernel<MODE, 0>), dim3((unsigned)((max_seg + 63) / 64)), dim3(64), 0, stream, ix, d_bases, seg,
+                       seg_j, seg_rem, max_over, on_chain, d_out, join);
+    hipLaunchKernelGGL(seg_finalize_kernel, dim3((unsigned)((n_reads + bt256 - 1) / bt256)), dim3(bt256), 0, stream, go, first, n_reads,
+                       seg.tot, join, on_chain, read_fail, d_err, d_stats);
+    hipLaunchKernelGGL((zml_stitch_kernel<MODE, 1>), dim3((unsigned)((max_seg + 63) / 64)), dim3(64), 0, stream, ix, d_bases, seg,
+                       seg_j, seg_rem, max_over, on_chain, d_out, join);
+    hipLaunchKernelGGL((zml_kernel<MODE, 2>), dim3((unsigned)((n_reads + bt256 - 1) / bt256)), dim3(bt256), 0, stream, ix, d_bases,
+                       d_offsets, n_reads, d_out, d_err, d_stats, d_order, seg);
+    return hipGetLastError();
+}
+
 hipError_t launch_zml(int mode, const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets,
                       uint64_t n_reads, uint64_t n_bases, uint16_t *d_out, uint8_t *d_err, DevStats *d_stats,
-                      const uint32_t *d_order, const LaunchCfg &cfg, hipStream_t stream) {
+                      const uint32_t *d_order, const LaunchCfg &cfg, hipStream_t stream, SegWorkspace *seg_ws,
+                      int ragged_hint) {
     if (n_reads == 0) return hipSuccess;
+    if (seg_ws && cfg.seg_len >= 32 && !d_order && cfg.zml_variant < 0 && cfg.block_threads == 0 && cfg.waves_per_cu <= 0 &&
+        n_bases / n_reads >= 2ull * (uint64_t)cfg.seg_len && n_reads + n_bases / (uint64_t)cfg.seg_len < 0x7FFFFFF0ull &&
+        (mode == 6 || mode == 3)) {
+        bool declined = false;
+        const hipError_t es = mode == 6 ? launch_zml_segmented<6>(ix, d_bases, d_offsets, n_reads, n_bases, d_out, d_err, d_stats, cfg,
+                                                                  stream, seg_ws, ragged_hint, &declined)
+                                        : launch_zml_segmented<3>(ix, d_bases, d_offsets, n_reads, n_bases, d_out, d_err, d_stats, cfg,
+                                                                  stream, seg_ws, ragged_hint, &declined);
+        if (es != hipSuccess || !declined) return es;
+    }
     // 0 = base-synchronous kernel, 1 = lane state machine.  Measured (profiles/r02_zml_state_machine.txt), Gbases/s,
     // kernel 0 / 1: 100 k x 10 kbp 12.1 / 19.1 (pangenome), 12.2 / 18.2 (random 10 M rows); 1 M x 150 bp 36.8 / 39.2 and
     // 34.1 / 36.8; random tables of 120 M rows 24.6 / 28.3, 250 M (2 GB) 23.4 / 26.6, 500 M (4 GB) 21.3 / 16.6, 1 B (8 GB)
@@ -2342,7 +2602,7 @@ hipError_t launch_zml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     do {                                                                                                       \
         if (v == 0)                                                                                            \
             hipLaunchKernelGGL(zml_kernel<M>, grid, block, dyn_lds, stream, ix, d_bases, d_offsets, n_reads,   \
-                               d_out, d_err, d_stats, d_order);                                                \
+                               d_out, d_err, d_stats, d_order, ZSegArgs());                                    \
         else if (ix.idx32)                                                                                     \
             hipLaunchKernelGGL((zml_kernel_flat<M, uint32_t>), grid, block, dyn_lds, stream, ix, d_bases,      \
                                d_offsets, n_reads, d_out, d_err, d_stats, d_order);                            \

@@ -105,6 +105,20 @@ struct SegArgs {
     const uint32_t *go = nullptr;         // device: 1 = walk the segments; 0 = the probe advised against it: every read goes to K3
 };
 
+// The same for ZML (launch_zml_segmented): the state is the backward-search interval, its `open` flag and the match length.
+struct ZSegCkpt { uint64_t rs, re; uint32_t os, oe, ml, open, ff, scan; };
+struct ZSegFin { uint64_t rs, re; uint32_t os, oe, ml, open; };
+struct ZSegArgs {
+    const uint64_t *seg_in = nullptr;
+    const uint64_t *seg_out = nullptr;
+    const uint32_t *seg_len = nullptr;
+    const uint64_t *n_seg = nullptr;
+    ZSegCkpt *ckpt = nullptr;
+    ZSegFin *fin = nullptr;
+    SegTot *tot = nullptr;
+    const uint8_t *read_fail = nullptr;
+};
+
 // Device workspace of the segmented path, owned by whoever owns the stream (the handle; a pipeline slot): grow-only.
 struct SegWorkspace {
     void *buf = nullptr;
@@ -125,7 +139,8 @@ hipError_t launch_count(int mode, const DevIndex &ix, const uint8_t *d_bases, co
 
 hipError_t launch_zml(int mode, const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets,
                       uint64_t n_reads, uint64_t n_bases, uint16_t *d_out, uint8_t *d_err, DevStats *d_stats,
-                      const uint32_t *d_order, const LaunchCfg &cfg, hipStream_t stream);
+                      const uint32_t *d_order, const LaunchCfg &cfg, hipStream_t stream,
+                      SegWorkspace *seg_ws = nullptr, int ragged_hint = -1);
 
 // d_err (optional): reads flagged there report no bins (0, 0, 0), like the fused kernels.
 hipError_t launch_classify(const uint16_t *d_pml, const uint64_t *d_offsets, uint64_t n_reads, uint32_t bin_width,

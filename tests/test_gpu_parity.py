@@ -1212,3 +1212,52 @@ def test_segment_parallel_with_classification_bins(engines):
     finally:
         gpu.set_option("seg_len", 2048)
         gpu.set_option("seg_probe", 1)
+
+
+@pytest.mark.parametrize("mode", [6, 8, 3])
+@pytest.mark.parametrize("seg_len", [32, 64, 1024])
+def test_segment_parallel_zml_vs_oracle(engines, built_lib, mode, seg_len):
+    """The ZML parse of long reads cut into segments (zml_kernel<.., 1> / zml_stitch_kernel / seg_finalize_kernel): values,
+    error bytes and the fast-forward / scan counters equal the oracle's and the one-lane-per-read kernels', on the
+    thresholds types and on a threshold-less `regular` index."""
+    import movi_amd
+    from oracle import build_index as B
+    from oracle.oracle import Oracle
+    ref = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))[0][1]
+    if mode == 3:
+        img = B.build_index_from_seqs([ref], 3)
+        gpu, cpu = movi_amd.MoveIndex.from_image(img), Oracle(img)
+    else:
+        gpu, cpu = engines[mode]
+    rng = np.random.default_rng(7500 + mode + seg_len)
+    noisy = mutated_reads(rng, ref, 120, max(800, 3 * seg_len), max(3000, 6 * seg_len))
+    for trial, reads in enumerate((
+            noisy + [b"", b"A", b"ACGT" * 5] + mutated_reads(rng, ref, 40, 1, 300),
+            [bytes(ref[s:s + L]) for s, L in zip(rng.integers(0, len(ref) - 4000, 40), rng.integers(1500, 4000, 40))],
+            [b"N" * 2500, b"ACGT" * 700, bytes(ref[:3000]), b"T" * 4097, b"ACGTN" * 500])):
+        bases, offs = pack(reads)
+        exp = cpu.zml_batch(bases, offs, threads=4)
+        gpu.set_option("seg_len", 0)
+        ref_out, ref_st = gpu.query_zml_packed(bases, offs)
+        assert (ref_out == exp).all() and ref_st.segments == 0
+        gpu.set_option("seg_len", seg_len)
+        gpu.set_option("seg_probe", 0)
+        try:
+            out, st = gpu.query_zml_packed(bases, offs)
+            assert st.segments > len(reads), (trial, st.segments)
+            bad = np.flatnonzero(out != exp)
+            assert bad.size == 0, (trial, seg_len, bad[:10], st.segments, st.rewalked)
+            assert (st.fast_forwards, st.scans, st.errors) == (ref_st.fast_forwards, ref_st.scans, 0), (trial, st.rewalked)
+        finally:
+            gpu.set_option("seg_len", 2048)
+            gpu.set_option("seg_probe", 1)
+    # default policy with the probe: noisy 10 kbp reads are cut, exact ones are not; same values either way
+    long_noisy = mutated_reads(rng, ref, 64, 9000, 12000)
+    long_exact = [bytes(ref[s:s + 9000]) for s in rng.integers(0, len(ref) - 9000, 64)]
+    for reads, want in ((long_noisy, True), (long_exact, False)):
+        bases, offs = pack(reads)
+        out, st = gpu.query_zml_packed(bases, offs)
+        assert (out == cpu.zml_batch(bases, offs, threads=4)).all()
+        assert (st.segments > 0) == want, (want, st.segments)
+    if mode == 3:
+        gpu.close()
