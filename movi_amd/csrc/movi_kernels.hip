@@ -1411,6 +1411,16 @@ __global__ __launch_bounds__(256) void seg_finalize_kernel(const uint32_t *__res
 namespace {
 size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 constexpr int kSegOverrun = 4;   // a boundary lane looks for its meeting point over at most this many seg_len of bases
+// The segment length of one call: cfg.seg_len, or shorter (down to 512) when the batch is so small that even then the
+// segments would not fill the GPU: `waves` wavefronts of segments per CU are aimed at.  The ZML parse is latency-bound
+// and wants many (24: 25 k x 10 kbp 13.4 -> 17.2 Gbases/s, 5 k 1.0 uncut -> 6.9, 1 %-error reads 7.7 uncut -> 15.1); the
+// PML walk pays more per boundary than it gains from lanes beyond ~8 per CU (with 24: 5 k x 10 kbp 7.5 -> 18.2, but
+// 200 x 1 Mbp 27.5 -> 20.5 and 1 %-error reads 25.3 -> 20.4).  A full batch (100 k x 10 kbp) keeps cfg.seg_len.
+uint32_t call_seg_len(const LaunchCfg &cfg, uint64_t n_bases, uint64_t waves) {
+    const uint64_t want = (n_bases / ((uint64_t)cfg.num_cus * 64ull * waves)) & ~31ull;
+    const uint64_t lo = cfg.seg_len < 512 ? (uint64_t)cfg.seg_len : 512ull;
+    return (uint32_t)(want < lo ? lo : (want > (uint64_t)cfg.seg_len ? (uint64_t)cfg.seg_len : want));
+}
 }
 
 // The segmented PML path: plan (count, scan, fill), K1, K2, K3.  Everything on `stream`, nothing read back: the grids are
@@ -1430,7 +1440,7 @@ static hipError_t launch_pml_segmented(const DevIndex &ix, const uint8_t *d_base
     // resident PML vector afterwards (classify_kernel: 2 B per base, streaming); without a caller's vector (d_out == NULL:
     // verdicts only) the PMLs go to the workspace.
     *declined = false;
-    const uint32_t S = (uint32_t)cfg.seg_len;
+    const uint32_t S = call_seg_len(cfg, n_bases, 8);
     if (cfg.seg_probe && n_reads >= (uint64_t)cfg.num_cus * 64ull * 4ull) {
         if (ragged_hint == 0) { *declined = true; return hipSuccess; }
         if (ragged_hint < 0) {
@@ -1550,7 +1560,7 @@ static hipError_t launch_pml_segmented(const DevIndex &ix, const uint8_t *d_base
     } while (0)
     MOVI_LAUNCH_SEG_T(1, max_seg);
     // (blocks of one wavefront: a boundary lane that has to walk far holds up only the 63 beside it)
-    const uint32_t max_over = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, (uint64_t)S * (uint64_t)kSegOverrun);
+    const uint32_t max_over = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, (uint64_t)cfg.seg_len * (uint64_t)kSegOverrun);
     hipLaunchKernelGGL((seg_stitch_kernel<6, 0>), dim3((unsigned)((max_seg + 63) / 64)), dim3(64), 0, stream, ix, d_bases, seg,
                        seg_j, seg_rem, max_over, on_chain, d_out, join);
     hipLaunchKernelGGL(seg_finalize_kernel, dim3((unsigned)((n_reads + bt256 - 1) / bt256)), dim3(bt256), 0, stream, go, first, n_reads,
@@ -2199,11 +2209,12 @@ __global__ __launch_bounds__(256) void zml_probe_kernel(DevIndex ix, const uint8
 // bookkeeping (emission, base decode) -- the software pipelining of pml_kernel_flatp, and its read-chunk handling.
 // The end-by-end order inside an iteration (start end first, whole window; then the end end) is the order of
 // shrink_interval's trips, so answers AND scan / fast-forward counts equal the base-synchronous kernel's.
-template <int MODE, typename IdxT>
+// SEG = 1: a lane parses one SEGMENT of a read (K1 of launch_zml_segmented), as zml_kernel<MODE, 1>.
+template <int MODE, typename IdxT, int SEG = 0>
 __global__ __launch_bounds__(256) void zml_kernel_flat(DevIndex ix, const uint8_t *__restrict__ bases,
                                                        const uint64_t *__restrict__ offs, uint64_t n_reads,
                                                        uint16_t *__restrict__ out, uint8_t *__restrict__ err,
-                                                       DevStats *stats, const uint32_t *__restrict__ order) {
+                                                       DevStats *stats, const uint32_t *__restrict__ order, ZSegArgs seg) {
     enum : uint32_t { phStart = 0, phScan = 1, phLF = 2, phInit = 3, phDone = 4 };
     enum : uint32_t { pNone = 0, pScan = 1, pFF = 2 };       // what an interval end is waiting for
     __shared__ uint8_t s_code[256];
@@ -2212,13 +2223,18 @@ __global__ __launch_bounds__(256) void zml_kernel_flat(DevIndex ix, const uint8_
 
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t ff_total = 0, scan_total = 0, failed = 0;
-    const bool valid = t < n_reads;
-    const uint64_t rid = (valid && order) ? order[t] : t;
-    const uint64_t beg = valid ? offs[rid] : 0;
-    const uint32_t len = valid ? (uint32_t)(offs[rid + 1] - beg) : 0;
-    uint16_t *O = out + beg;
+    const bool valid = SEG == 1 ? t < *seg.n_seg : t < n_reads;
+    const uint64_t rid = (valid && order && SEG == 0) ? order[t] : t;
+    const uint64_t beg = valid ? (SEG == 1 ? seg.seg_in[rid] : offs[rid]) : 0;
+    const uint32_t len = valid ? (SEG == 1 ? seg.seg_len[rid] : (uint32_t)(offs[rid + 1] - beg)) : 0;
+    const uint64_t obeg = (SEG == 1 && valid) ? seg.seg_out[rid] : beg;
+    uint16_t *O = out + obeg;
     const uint32_t packed_end = len & ~7u;
     const IdxT r1 = (IdxT)(ix.r - 1), end_row = (IdxT)ix.end_bwt_idx, wb_last = (IdxT)(ix.r - 4);
+    // K1: the state right after the base just emitted (the machine may already be moving on to the next base when the
+    // emission is booked)
+    IdxT cap_rs = 0, cap_re = 0;
+    uint32_t cap_os = 0, cap_oe = 0, cap_ml = 0, cap_open = 0, cap_ff = 0, cap_scan = 0;
 
     auto load_pair_at = [&](uint64_t e, uint64_t &c0, uint64_t &c1) {      // see pml_kernel_flatp
         uint64_t two[2];
@@ -2355,6 +2371,7 @@ __global__ __launch_bounds__(256) void zml_kernel_flat(DevIndex ix, const uint8_
             else if ((rs < re) || (rs == re && os <= oe)) {  // query_zml :717-720
                 ml += 1;
                 do_emit = 1; ek = k;
+                if (SEG == 1) { cap_rs = rs; cap_re = re; cap_os = os; cap_oe = oe; cap_ml = ml; cap_open = open; cap_ff = ff_total; cap_scan = scan_total; }
                 k += 1;
                 b = bn;
                 ph = k == len ? phDone : phStart;
@@ -2396,6 +2413,7 @@ __global__ __launch_bounds__(256) void zml_kernel_flat(DevIndex ix, const uint8_
                 if (open) { ps = pFF; pe = pFF; ffs = 65535u; ffe = 65535u; ph = phInit; }   // rows only: no fast-forward
             }
             do_emit = 1; ek = k;
+            if (SEG == 1) { cap_rs = rs; cap_re = re; cap_os = os; cap_oe = oe; cap_ml = ml; cap_open = open; cap_ff = ff_total; cap_scan = scan_total; }
             k += 1;
             b = bn;
             if (k == len) ph = phDone;
@@ -2414,6 +2432,19 @@ __global__ __launch_bounds__(256) void zml_kernel_flat(DevIndex ix, const uint8_
         uint64_t nx_e = 0;
         if (do_emit) {
             const uint32_t val = ml > 65535u ? 65535u : ml;               // MoveQuery::add_ml
+            if (SEG == 1) {
+                if ((ek & 31u) == 31u) {
+                    ZSegCkpt ck;
+                    ck.rs = (uint64_t)cap_rs; ck.re = (uint64_t)cap_re; ck.os = cap_os; ck.oe = cap_oe; ck.ml = cap_ml; ck.open = cap_open;
+                    ck.ff = cap_ff; ck.scan = cap_scan;
+                    seg.ckpt[(obeg + ek) >> 5] = ck;
+                }
+                if (ek + 1 == len) {
+                    ZSegFin fn;
+                    fn.rs = (uint64_t)cap_rs; fn.re = (uint64_t)cap_re; fn.os = cap_os; fn.oe = cap_oe; fn.ml = cap_ml; fn.open = cap_open;
+                    seg.fin[rid] = fn;
+                }
+            }
             if (ek >= packed_end) {
                 O[ek] = (uint16_t)val;
             } else {
@@ -2444,15 +2475,23 @@ __global__ __launch_bounds__(256) void zml_kernel_flat(DevIndex ix, const uint8_
         }
         if (want_nx) load_pair_at(nx_e, nx0, nx1);
     }
-    if (failed) {
-        for (uint32_t i = 0; i < len; ++i) O[i] = 0;
-    }
-    if (valid && err) err[rid] = (uint8_t)failed;
-    const uint32_t ffw = wave_sum(ff_total), scw = wave_sum(scan_total), erw = wave_sum(failed ? 1u : 0u);
-    if ((threadIdx.x & 63) == 0 && stats) {
-        if (ffw) atomicAdd(&stats->fast_forwards, (unsigned long long)ffw);
-        if (scw) atomicAdd(&stats->scans, (unsigned long long)scw);
-        if (erw) atomicAdd(&stats->errors, (unsigned long long)erw);
+    if (SEG == 1) {
+        if (valid) {
+            SegTot tt;
+            tt.ff = ff_total; tt.scan = scan_total; tt.repo = 0; tt.flag = failed;
+            seg.tot[rid] = tt;
+        }
+    } else {
+        if (failed) {
+            for (uint32_t i = 0; i < len; ++i) O[i] = 0;
+        }
+        if (valid && err) err[rid] = (uint8_t)failed;
+        const uint32_t ffw = wave_sum(ff_total), scw = wave_sum(scan_total), erw = wave_sum(failed ? 1u : 0u);
+        if ((threadIdx.x & 63) == 0 && stats) {
+            if (ffw) atomicAdd(&stats->fast_forwards, (unsigned long long)ffw);
+            if (scw) atomicAdd(&stats->scans, (unsigned long long)scw);
+            if (erw) atomicAdd(&stats->errors, (unsigned long long)erw);
+        }
     }
     const uint32_t lsw = wave_sum(lane_steps);
     if ((threadIdx.x & 63) == 0 && stats) {
@@ -2470,7 +2509,7 @@ static hipError_t launch_zml_segmented(const DevIndex &ix, const uint8_t *d_base
                                        uint64_t n_bases, uint16_t *d_out, uint8_t *d_err, DevStats *d_stats, const LaunchCfg &cfg,
                                        hipStream_t stream, SegWorkspace *ws, int ragged_hint, bool *declined) {
     *declined = false;
-    const uint32_t S = (uint32_t)cfg.seg_len;
+    const uint32_t S = call_seg_len(cfg, n_bases, 24);
     hipError_t e = hipSuccess;
     if (cfg.seg_probe && n_reads >= (uint64_t)cfg.num_cus * 64ull * 8ull) {
         if (ragged_hint == 0) { *declined = true; return hipSuccess; }
@@ -2549,9 +2588,19 @@ static hipError_t launch_zml_segmented(const DevIndex &ix, const uint8_t *d_base
     hipLaunchKernelGGL(seg_fill_kernel, dim3((unsigned)((n_reads + bt256 - 1) / bt256)), dim3(bt256), 0, stream, d_offsets,
                        n_reads, S, first, seg_in, seg_out, seg_l, seg_j, seg_rem);
     const uint32_t *d_order = nullptr;
-    hipLaunchKernelGGL((zml_kernel<MODE, 1>), dim3((unsigned)((max_seg + bt256 - 1) / bt256)), dim3(bt256), 0, stream, ix, d_bases,
-                       d_offsets, max_seg, d_out, d_err, d_stats, d_order, seg);
-    const uint32_t max_over = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, (uint64_t)S * (uint64_t)kSegOverrun);
+    // K1: the lane state machine where the plain query would use it (tables up to 3 GB), else the base-synchronous kernel
+    if (ix.r <= (3ull << 30) / 8 && ix.r >= 8 && n_bases >= 16) {
+        if (ix.idx32)
+            hipLaunchKernelGGL((zml_kernel_flat<MODE, uint32_t, 1>), dim3((unsigned)((max_seg + 63) / 64)), dim3(64), 0, stream, ix,
+                               d_bases, d_offsets, max_seg, d_out, d_err, d_stats, d_order, seg);
+        else
+            hipLaunchKernelGGL((zml_kernel_flat<MODE, uint64_t, 1>), dim3((unsigned)((max_seg + 63) / 64)), dim3(64), 0, stream, ix,
+                               d_bases, d_offsets, max_seg, d_out, d_err, d_stats, d_order, seg);
+    } else {
+        hipLaunchKernelGGL((zml_kernel<MODE, 1>), dim3((unsigned)((max_seg + bt256 - 1) / bt256)), dim3(bt256), 0, stream, ix, d_bases,
+                           d_offsets, max_seg, d_out, d_err, d_stats, d_order, seg);
+    }
+    const uint32_t max_over = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, (uint64_t)cfg.seg_len * (uint64_t)kSegOverrun);
     hipLaunchKernelGGL((zml_stitch_kernel<MODE, 0>), dim3((unsigned)((max_seg + 63) / 64)), dim3(64), 0, stream, ix, d_bases, seg,
                        seg_j, seg_rem, max_over, on_chain, d_out, join);
     hipLaunchKernelGGL(seg_finalize_kernel, dim3((unsigned)((n_reads + bt256 - 1) / bt256)), dim3(bt256), 0, stream, go, first, n_reads,
@@ -2605,10 +2654,10 @@ hipError_t launch_zml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
                                d_out, d_err, d_stats, d_order, ZSegArgs());                                    \
         else if (ix.idx32)                                                                                     \
             hipLaunchKernelGGL((zml_kernel_flat<M, uint32_t>), grid, block, dyn_lds, stream, ix, d_bases,      \
-                               d_offsets, n_reads, d_out, d_err, d_stats, d_order);                            \
+                               d_offsets, n_reads, d_out, d_err, d_stats, d_order, ZSegArgs());                \
         else                                                                                                   \
             hipLaunchKernelGGL((zml_kernel_flat<M, uint64_t>), grid, block, dyn_lds, stream, ix, d_bases,      \
-                               d_offsets, n_reads, d_out, d_err, d_stats, d_order);                            \
+                               d_offsets, n_reads, d_out, d_err, d_stats, d_order, ZSegArgs());                \
     } while (0)
     // resident layouts: 6 = regular-thresholds rows, 3 = regular rows (threshold-less types: 12-bit lengths)
     if (mode == 6) MOVI_LAUNCH_ZML(6);

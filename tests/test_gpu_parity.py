@@ -1243,12 +1243,15 @@ def test_segment_parallel_zml_vs_oracle(engines, built_lib, mode, seg_len):
         gpu.set_option("seg_len", seg_len)
         gpu.set_option("seg_probe", 0)
         try:
-            out, st = gpu.query_zml_packed(bases, offs)
-            assert st.segments > len(reads), (trial, st.segments)
-            bad = np.flatnonzero(out != exp)
-            assert bad.size == 0, (trial, seg_len, bad[:10], st.segments, st.rewalked)
-            assert (st.fast_forwards, st.scans, st.errors) == (ref_st.fast_forwards, ref_st.scans, 0), (trial, st.rewalked)
+            for idx64 in (0, 1):
+                gpu.set_option("idx64", idx64)
+                out, st = gpu.query_zml_packed(bases, offs)
+                assert st.segments > len(reads), (trial, st.segments)
+                bad = np.flatnonzero(out != exp)
+                assert bad.size == 0, (trial, seg_len, idx64, bad[:10], st.segments, st.rewalked)
+                assert (st.fast_forwards, st.scans, st.errors) == (ref_st.fast_forwards, ref_st.scans, 0), (trial, st.rewalked)
         finally:
+            gpu.set_option("idx64", 0)
             gpu.set_option("seg_len", 2048)
             gpu.set_option("seg_probe", 1)
     # default policy with the probe: noisy 10 kbp reads are cut, exact ones are not; same values either way
