@@ -488,6 +488,30 @@ def main():
                                     "fast_forwards_per_base": round(st3.fast_forwards / (n3 * L3), 4),
                                     "scans_per_base": round(st3.scans / (n3 * L3), 4), "errors": int(st3.errors),
                                     "segments": int(st3.segments), "rewalked_reads": int(st3.rewalked)}
+            # the same reads, a quarter of them: too few walks to fill the GPU with one lane per read -- the shape the
+            # segment-parallel walk is for; both ways, same launch otherwise
+            n4 = n3 // 4
+            few = {"workload": "first %d of the c3 reads" % n4, "unit": "Gbases/s"}
+            for name, sl in (("one_lane_per_read", 0), ("segment_parallel", 2048)):
+                index.set_option("seg_len", sl)
+                run4 = lambda: index.pml_device(b3.data_ptr(), o3.data_ptr(), n4, n4 * L3, out3.data_ptr(), err3.data_ptr(),
+                                                stream.cuda_stream, 0)
+                run4()
+                torch.cuda.synchronize()
+                st4 = index.last_stats(stream.cuda_stream)
+                t0 = time.perf_counter()
+                for _ in range(k3):
+                    run4()
+                torch.cuda.synchronize()
+                few[name] = round(n4 * L3 * k3 / (time.perf_counter() - t0) / 1e9, 2)
+                few[name + "_segments"] = int(st4.segments)
+                if sl == 0:
+                    keep4 = out3[: n4 * L3].clone()
+                else:
+                    few["identical"] = bool(torch.equal(keep4, out3[: n4 * L3]))
+                    del keep4
+            index.set_option("seg_len", 2048 if args.seg_len < 0 else args.seg_len)
+            result["few_long_reads"] = few
         except Exception as e:                            # noqa: BLE001 -- never lose the headline line to the extra
             result["long_reads"] = {"error": repr(e)[:200]}
     # ---- PCIe-inclusive rate of the boundary's host entry point ("pre-parsed reads in pinned host memory to
