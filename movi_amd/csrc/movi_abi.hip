@@ -119,6 +119,7 @@ struct movi_index {
     PipeSlot pipe[kPipeSlots];
     hipStream_t pipe_up = nullptr;   // every chunk's upload, in order (uploads on separate streams share the link and all arrive late)
     uint64_t pipe_chunk_bases = 0;   // test hook ("pipe_chunk_bases"): chunk size of the overlapped path, 0 = its policy
+    bool seg_seen = false;           // the last PML / ZML host call on long reads was walked segment-parallel (chunk policy below)
 };
 
 static void release_scratch(movi_index *ix);
@@ -614,7 +615,7 @@ int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
 static int ml_device(bool zml, movi_index_t *ix, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
                      uint64_t n_bases, uint16_t *d_out, uint8_t *d_read_err, const uint32_t *d_read_order, void *stream,
                      const ClsArgs &cls = ClsArgs(), DevStats *d_stats = nullptr, SegWorkspace *seg_ws = nullptr,
-                     int ragged_hint = -1) {
+                     int ragged_hint = -1, int *seg_verdict = nullptr) {
     if (!ix) return fail(MOVI_ERR_ARG, "index handle is NULL");
     if (!d_stats) d_stats = ix->d_stats;                     // (the pipelined host path counts per chunk in flight ...
     if (!seg_ws) seg_ws = &ix->seg_ws;                       //  ... and keeps a segment workspace per chunk in flight)
@@ -631,10 +632,10 @@ static int ml_device(bool zml, movi_index_t *ix, const uint8_t *d_bases, const u
     if (n_reads > 0xFFFFFFFFull) return fail(MOVI_ERR_ARG, "more than 2^32 reads in one call");
     if (zml)
         HIP_TRY(launch_zml(ix->kmode, ix->dev, d_bases, d_offsets, n_reads, n_bases, d_out, d_read_err, d_stats,
-                           d_read_order, ix->cfg, s, seg_ws, ragged_hint));
+                           d_read_order, ix->cfg, s, seg_ws, ragged_hint, seg_verdict));
     else
         HIP_TRY(launch_pml(ix->kmode, ix->dev, d_bases, d_offsets, n_reads, n_bases, d_out, d_read_err, d_stats,
-                           d_read_order, ix->cfg, s, cls, seg_ws, ragged_hint));
+                           d_read_order, ix->cfg, s, cls, seg_ws, ragged_hint, seg_verdict));
     return MOVI_OK;
 }
 
@@ -715,6 +716,7 @@ struct ChunkCtx {
     uint8_t *h_small = nullptr;
     SegWorkspace *seg_ws = nullptr;
     int ragged_hint = -1;            // the chunk's longest read is (1) / is not (0) more than 1.5 x its mean: launch_pml's segment policy
+    int *seg_verdict = nullptr;      // one probe per call: the first chunk's verdict serves the others (launch_pml_segmented)
     bool async = false;
     hipError_t alloc(int slot, size_t bytes, void **out) {
         hipError_t e = grow(&d[slot], &cap[slot], bytes);
@@ -822,8 +824,10 @@ template <typename Launch, typename Fetch, typename Harvest>
 int run_chunked(movi_index *ix, const uint8_t *h_bases, const uint64_t *h_offsets, uint64_t n_reads,
                 uint8_t *h_read_err, movi_query_stats_t *stats, Launch launch, Fetch fetch, Harvest, size_t) {
     if (stats) memset(stats, 0, sizeof(*stats));
+    int seg_verdict = -1;
     ChunkCtx ctx;
     ctx.ix = ix;
+    ctx.seg_verdict = &seg_verdict;
     ctx.d_stats = ix->d_stats;
     ctx.d = ix->scratch;
     ctx.cap = ix->scratch_cap;
@@ -897,6 +901,10 @@ int run_pipelined(movi_index *ix, const uint8_t *h_bases, const uint64_t *h_offs
     uint64_t target = total / kPipeTargetChunks;
     target = target < kPipeMinBases ? kPipeMinBases : (target > kChunkBases ? kChunkBases : target);
     uint64_t min_reads = kPipeMinReads;
+    // Long reads are cut into few, big chunks because a read takes its time however few lanes walk beside it -- unless the
+    // reads are walked segment-parallel, which the host only knows afterwards: a caller whose last call was (a stream of
+    // batches of the same kind of reads) gets chunks of >= 2^12 reads from then on, whose downloads start earlier.
+    if (ix->seg_seen && ix->cfg.seg_len > 0 && total / n_reads >= 2ull * (uint64_t)ix->cfg.seg_len) min_reads = 1ull << 12;
     if (ix->pipe_chunk_bases) { target = ix->pipe_chunk_bases; min_reads = 1; }
     struct Chunk { uint64_t first, nr, b0, nb; };
     std::vector<Chunk> chunks;
@@ -924,10 +932,12 @@ int run_pipelined(movi_index *ix, const uint8_t *h_bases, const uint64_t *h_offs
     auto off_err = [](uint64_t nr) { return (size_t)(nr + 1) * 8; };
     auto off_small = [&](uint64_t nr) { return (off_err(nr) + (size_t)nr + 15) & ~(size_t)15; };
     auto off_stats = [&](uint64_t nr) { return (off_small(nr) + (size_t)nr * small_bytes + 15) & ~(size_t)15; };
+    int seg_verdict = -1;
     auto ctx_of = [&](int k, uint64_t nr) {
         movi_index::PipeSlot &sl = ix->pipe[k];
         ChunkCtx ctx;
         ctx.ix = ix;
+        ctx.seg_verdict = &seg_verdict;
         ctx.s = sl.s;
         ctx.d_stats = sl.d_stats;
         ctx.d = sl.d;
@@ -1026,6 +1036,7 @@ int run_pipelined(movi_index *ix, const uint8_t *h_bases, const uint64_t *h_offs
         g_err = keep;
     }
     if (stats) *stats = acc;
+    if (rc == MOVI_OK && total / n_reads >= 2ull * (uint64_t)(ix->cfg.seg_len > 0 ? ix->cfg.seg_len : 1)) ix->seg_seen = acc.segments != 0;
     return rc;
 }
 
@@ -1096,7 +1107,7 @@ static int ml_host(bool zml, movi_index_t *ix, const uint8_t *h_bases, const uin
     auto launch = [&](ChunkCtx &c, const uint8_t *db, const uint64_t *dof, uint64_t nr, uint64_t nb, uint8_t *derr) -> int {
         HIP_TRY(c.alloc(movi_index::kOut, nb * 2, &d_out.p));
         return ml_device(zml, ix, db, dof, nr, nb, static_cast<uint16_t *>(d_out.p), derr, nullptr, c.s, ClsArgs(), c.d_stats,
-                         c.seg_ws, c.ragged_hint);
+                         c.seg_ws, c.ragged_hint, c.seg_verdict);
     };
     // (the results are found through the chunk's own staging: with chunks in flight, launch() of the next chunk has
     // run before fetch() of this one)

@@ -1435,7 +1435,12 @@ uint32_t call_seg_len(const LaunchCfg &cfg, uint64_t n_bases, uint64_t waves) {
 static hipError_t launch_pml_segmented(const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
                                        uint64_t n_bases, uint16_t *d_out, uint8_t *d_err, DevStats *d_stats,
                                        const LaunchCfg &cfg, hipStream_t stream, SegWorkspace *ws, bool big_batch_cap,
-                                       int ragged_hint, bool *declined, const ClsArgs &bins) {
+                                       int ragged_hint, bool *declined, const ClsArgs &bins, int *verdict) {
+    // `verdict` (optional, in / out): a caller that cuts one batch into several launches (the overlapped host path) lets
+    // the first one probe and hands its verdict to the others -- 1: cut without probing (no read-back, the launch stays
+    // asynchronous), 0: do not cut; -1 on entry: not decided yet.
+    if (verdict && *verdict == 0) { *declined = true; return hipSuccess; }
+    const bool probe = cfg.seg_probe != 0 && !(verdict && *verdict == 1);
     // Classification bins (bins.bin_width != 0): not fused into this walk -- a bin spans segments -- but reduced from the
     // resident PML vector afterwards (classify_kernel: 2 B per base, streaming); without a caller's vector (d_out == NULL:
     // verdicts only) the PMLs go to the workspace.
@@ -1508,16 +1513,17 @@ static hipError_t launch_pml_segmented(const DevIndex &ix, const uint8_t *d_base
     // the probe: is this a batch whose walks fall into step quickly?
     e = hipMemsetAsync(go, 0, 32, stream);
     if (e != hipSuccess) return e;
-    if (cfg.seg_probe)
+    if (probe)
         hipLaunchKernelGGL(seg_probe_kernel<6>, dim3(16), dim3(64), 0, stream, ix, d_bases, d_offsets, n_reads, 32u, 384u, go + 1);
-    hipLaunchKernelGGL(seg_decide_kernel, dim3(1), dim3(1), 0, stream, go + 1, (uint32_t)(cfg.seg_probe != 0), go);
-    if (cfg.seg_probe) {
+    hipLaunchKernelGGL(seg_decide_kernel, dim3(1), dim3(1), 0, stream, go + 1, (uint32_t)probe, go);
+    if (probe) {
         // The verdict is read back (this call waits for the probe): a batch it advises against then takes exactly the
         // one-lane-per-read path -- fused bins included -- instead of a dozen kernels that find out one by one.
         uint32_t h_go = 0;
         e = hipMemcpyAsync(&h_go, go, 4, hipMemcpyDeviceToHost, stream);
         if (e == hipSuccess) e = hipStreamSynchronize(stream);
         if (e != hipSuccess) return e;
+        if (verdict) *verdict = h_go ? 1 : 0;
         if (!h_go) { *declined = true; return hipSuccess; }
     }
     hipLaunchKernelGGL(seg_count_kernel, dim3((unsigned)((n_reads + 1 + bt256 - 1) / bt256)), dim3(bt256), 0, stream, d_offsets,
@@ -1579,7 +1585,7 @@ static hipError_t launch_pml_segmented(const DevIndex &ix, const uint8_t *d_base
 hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets,
                       uint64_t n_reads, uint64_t n_bases, uint16_t *d_out, uint8_t *d_err, DevStats *d_stats,
                       const uint32_t *d_order, const LaunchCfg &cfg, hipStream_t stream, const ClsArgs &cls,
-                      SegWorkspace *seg_ws, int ragged_hint) {
+                      SegWorkspace *seg_ws, int ragged_hint, int *seg_verdict) {
     if (n_reads == 0) return hipSuccess;
     // 0 = PML vector only, 1 = vector + classification bins, 2 = bins only
     const int cm = cls.bin_width == 0 ? 0 : (d_out ? 1 : 2);
@@ -1629,7 +1635,8 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
         n_bases / n_reads >= 2ull * (uint64_t)cfg.seg_len && n_reads + n_bases / (uint64_t)cfg.seg_len < 0x7FFFFFF0ull) {
         bool declined = false;
         const hipError_t es = launch_pml_segmented(ix, d_bases, d_offsets, n_reads, n_bases, d_out, d_err, d_stats, cfg, stream,
-                                                   seg_ws, cfg.pml_variant < 0 || cfg.pml_variant == 14, ragged_hint, &declined, cls);
+                                                   seg_ws, cfg.pml_variant < 0 || cfg.pml_variant == 14, ragged_hint, &declined, cls,
+                                                   seg_verdict);
         if (es != hipSuccess || !declined) return es;
     }
     const int bt = cfg.block_threads > 0 ? cfg.block_threads : 64;           // one wavefront per block: finest dispatch grain
@@ -2507,8 +2514,10 @@ __global__ __launch_bounds__(256) void zml_kernel_flat(DevIndex ix, const uint8_
 template <int MODE>
 static hipError_t launch_zml_segmented(const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
                                        uint64_t n_bases, uint16_t *d_out, uint8_t *d_err, DevStats *d_stats, const LaunchCfg &cfg,
-                                       hipStream_t stream, SegWorkspace *ws, int ragged_hint, bool *declined) {
+                                       hipStream_t stream, SegWorkspace *ws, int ragged_hint, bool *declined, int *verdict) {
     *declined = false;
+    if (verdict && *verdict == 0) { *declined = true; return hipSuccess; }
+    const bool probe = cfg.seg_probe != 0 && !(verdict && *verdict == 1);
     const uint32_t S = call_seg_len(cfg, n_bases, 24);
     hipError_t e = hipSuccess;
     if (cfg.seg_probe && n_reads >= (uint64_t)cfg.num_cus * 64ull * 8ull) {
@@ -2571,14 +2580,15 @@ static hipError_t launch_zml_segmented(const DevIndex &ix, const uint8_t *d_base
     const unsigned bt256 = 256;
     e = hipMemsetAsync(go, 0, 32, stream);
     if (e != hipSuccess) return e;
-    if (cfg.seg_probe)
+    if (probe)
         hipLaunchKernelGGL(zml_probe_kernel<MODE>, dim3(16), dim3(64), 0, stream, ix, d_bases, d_offsets, n_reads, 32u, 384u, go + 1);
-    hipLaunchKernelGGL(seg_decide_kernel, dim3(1), dim3(1), 0, stream, go + 1, (uint32_t)(cfg.seg_probe != 0), go);
-    if (cfg.seg_probe) {
+    hipLaunchKernelGGL(seg_decide_kernel, dim3(1), dim3(1), 0, stream, go + 1, (uint32_t)probe, go);
+    if (probe) {
         uint32_t h_go = 0;
         e = hipMemcpyAsync(&h_go, go, 4, hipMemcpyDeviceToHost, stream);
         if (e == hipSuccess) e = hipStreamSynchronize(stream);
         if (e != hipSuccess) return e;
+        if (verdict) *verdict = h_go ? 1 : 0;
         if (!h_go) { *declined = true; return hipSuccess; }
     }
     hipLaunchKernelGGL(seg_count_kernel, dim3((unsigned)((n_reads + 1 + bt256 - 1) / bt256)), dim3(bt256), 0, stream, d_offsets,
@@ -2615,16 +2625,16 @@ static hipError_t launch_zml_segmented(const DevIndex &ix, const uint8_t *d_base
 hipError_t launch_zml(int mode, const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets,
                       uint64_t n_reads, uint64_t n_bases, uint16_t *d_out, uint8_t *d_err, DevStats *d_stats,
                       const uint32_t *d_order, const LaunchCfg &cfg, hipStream_t stream, SegWorkspace *seg_ws,
-                      int ragged_hint) {
+                      int ragged_hint, int *seg_verdict) {
     if (n_reads == 0) return hipSuccess;
     if (seg_ws && cfg.seg_len >= 32 && !d_order && cfg.zml_variant < 0 && cfg.block_threads == 0 && cfg.waves_per_cu <= 0 &&
         n_bases / n_reads >= 2ull * (uint64_t)cfg.seg_len && n_reads + n_bases / (uint64_t)cfg.seg_len < 0x7FFFFFF0ull &&
         (mode == 6 || mode == 3)) {
         bool declined = false;
         const hipError_t es = mode == 6 ? launch_zml_segmented<6>(ix, d_bases, d_offsets, n_reads, n_bases, d_out, d_err, d_stats, cfg,
-                                                                  stream, seg_ws, ragged_hint, &declined)
+                                                                  stream, seg_ws, ragged_hint, &declined, seg_verdict)
                                         : launch_zml_segmented<3>(ix, d_bases, d_offsets, n_reads, n_bases, d_out, d_err, d_stats, cfg,
-                                                                  stream, seg_ws, ragged_hint, &declined);
+                                                                  stream, seg_ws, ragged_hint, &declined, seg_verdict);
         if (es != hipSuccess || !declined) return es;
     }
     // 0 = base-synchronous kernel, 1 = lane state machine.  Measured (profiles/r02_zml_state_machine.txt), Gbases/s,

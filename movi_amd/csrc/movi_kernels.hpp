@@ -131,7 +131,8 @@ struct SegWorkspace {
 hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets,
                       uint64_t n_reads, uint64_t n_bases, uint16_t *d_out, uint8_t *d_err, DevStats *d_stats,
                       const uint32_t *d_order, const LaunchCfg &cfg, hipStream_t stream,
-                      const ClsArgs &cls = ClsArgs(), SegWorkspace *seg_ws = nullptr, int ragged_hint = -1);
+                      const ClsArgs &cls = ClsArgs(), SegWorkspace *seg_ws = nullptr, int ragged_hint = -1,
+                      int *seg_verdict = nullptr);
 
 hipError_t launch_count(int mode, const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets,
                         uint64_t n_reads, uint64_t *d_matched, uint64_t *d_count, uint8_t *d_err,
@@ -140,7 +141,7 @@ hipError_t launch_count(int mode, const DevIndex &ix, const uint8_t *d_bases, co
 hipError_t launch_zml(int mode, const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets,
                       uint64_t n_reads, uint64_t n_bases, uint16_t *d_out, uint8_t *d_err, DevStats *d_stats,
                       const uint32_t *d_order, const LaunchCfg &cfg, hipStream_t stream,
-                      SegWorkspace *seg_ws = nullptr, int ragged_hint = -1);
+                      SegWorkspace *seg_ws = nullptr, int ragged_hint = -1, int *seg_verdict = nullptr);
 
 // d_err (optional): reads flagged there report no bins (0, 0, 0), like the fused kernels.
 hipError_t launch_classify(const uint16_t *d_pml, const uint64_t *d_offsets, uint64_t n_reads, uint32_t bin_width,

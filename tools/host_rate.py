@@ -21,7 +21,7 @@ def best(fn, reps=5):
 
 
 for n, L in ((1_000_000, 150), (100_000, 10_000)):
-    bases, offs = synth.synth_reads(six, n, L, seed=2, sub_rate=0.01, n_rate=0.001)
+    bases, offs = synth.synth_reads(six, n, L, seed=2, sub_rate=0.01 if L < 1000 else 0.08, n_rate=0.001)   # BASELINE configs 2 / 3
     out = np.ones(bases.size, np.uint16)                     # touched
     err = np.zeros(n, np.uint8)
     m, c = np.zeros(n, np.uint64), np.zeros(n, np.uint64)
