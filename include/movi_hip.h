@@ -252,7 +252,8 @@ int movi_host_unregister(void *p);
  * (bases per chunk of the overlapped host path, 0 = its own policy: a test hook), "seg_len" (PML: batches whose mean
  * read length is at least twice this many bases are walked segment-parallel -- every read cut into segments of about
  * seg_len bases walked by their own lanes, stitched where the walks fall into step, reads that do not walked again:
- * identical results; default 2048, 0 = off, else a multiple of 32), "seg_probe" (1, the default: an eligible batch
+ * identical results; ZML parses likewise; default 2048, 0 = off, else a multiple of 32; batches too small to fill the GPU
+ * even so get shorter segments, down to 512), "seg_probe" (1, the default: an eligible batch
  * is cut into segments only if a probe of some of its reads finds that walks started mid-read fall into step within a
  * few hundred bases -- noisy long reads do, reads with 0.1 % errors and less do not and are better off with one lane
  * per read --; 0 = cut whatever the probe would say: a test hook). */
@@ -267,7 +268,8 @@ int movi_set_option(movi_index_t *ix, const char *key, int64_t value);
  * bases give 0 and end the phrase.  These are the values of the reference's --no-prefetch
  * path; its strand scheduler appends one extra entry to a read whose first base is illegal
  * (reset_backward_search skips to pos -1, src/read_processor.cpp:1006-1013, and the caller adds
- * again, :704), which this engine does not reproduce. */
+ * again, :704), which this engine does not reproduce.  Batches of long reads are parsed segment-parallel like PML walks
+ * ("seg_len"; the call then waits for a short probe of the batch before it enqueues the parse). */
 int movi_zml_device(movi_index_t *ix, const uint8_t *d_bases, const uint64_t *d_offsets,
                     uint64_t n_reads, uint64_t n_bases, uint16_t *d_out_zml, uint8_t *d_read_err,
                     const uint32_t *d_read_order, void *stream);
