@@ -1304,7 +1304,7 @@ __global__ __launch_bounds__(256) void seg_stitch_kernel(DevIndex ix, const uint
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = ix.code_of[i];
     __syncthreads();
     const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool mine = *seg.go != 0u && s < *seg.n_seg && seg_j[s] != 0 && (PASS == 0 || on_chain[s] != 0);
+    const bool mine = *seg.go != 0u && s < *seg.n_seg && seg_j[s] != 0 && (PASS == 0 || on_chain[s] == 2);
     const EndThr ethr = end_thresholds(ix);
     uint32_t ff_total = 0, scan_total = 0, repo_total = 0, failed = 0, how = 0;
     bool live0 = mine;
@@ -1333,6 +1333,7 @@ __global__ __launch_bounds__(256) void seg_stitch_kernel(DevIndex ix, const uint
         if (PASS == 1) {
             if (live) O[k] = (uint16_t)(ml > 65535u ? 65535u : ml);
         } else if (live) {
+            if (k < T) O[k] = (uint16_t)(ml > 65535u ? 65535u : ml);     // inside its own segment: no other lane writes there now
             kend = (uint32_t)k;
             if ((k & 31ull) == 31ull) {
                 const SegCkpt c = seg.ckpt[(obeg + k) >> 5];
@@ -1366,7 +1367,8 @@ __global__ __launch_bounds__(256) void seg_stitch_kernel(DevIndex ix, const uint
 // from end to end (and reports its error, if any).
 __global__ __launch_bounds__(256) void seg_finalize_kernel(const uint32_t *__restrict__ go, const uint64_t *__restrict__ first,
                                                           uint64_t n_reads, const SegTot *__restrict__ tot,
-                                                          const SegJoin *__restrict__ join,
+                                                          SegJoin *__restrict__ join, const uint32_t *__restrict__ seg_len,
+                                                          const uint32_t *__restrict__ seg_rem,
                                                           uint8_t *__restrict__ on_chain, uint8_t *__restrict__ read_fail,
                                                           uint8_t *__restrict__ err, DevStats *stats) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1387,6 +1389,20 @@ __global__ __launch_bounds__(256) void seg_finalize_kernel(const uint32_t *__res
             if (j.how == 0u) { bad = 1; break; }
             ff += j.ff; scan += j.scan; repo += j.repo;
             on_chain[s] = 1;
+            // The find pass wrote this lane's PMLs as far as its own segment goes; so did the lanes of the boundaries it
+            // walked past, from states that were not the read's: it walks again (write pass) over everything they touched.
+            const uint64_t T = seg_len[s], last_void = j.how == 2u ? s1 - 1 : s + (uint64_t)j.segs;
+            if (last_void > s || (uint64_t)j.kend >= T) {
+                uint64_t extent = j.kend;
+                for (uint64_t q = s + 1; q <= last_void; ++q) {
+                    const uint64_t tq = seg_len[q], kq = join[q].kend < tq ? join[q].kend : tq - 1;
+                    const uint64_t reach = (q - s) * T + kq;
+                    extent = reach > extent ? reach : extent;
+                }
+                const uint64_t rem = seg_rem[s];
+                join[s].kend = (uint32_t)(extent < rem ? extent : rem - 1);
+                on_chain[s] = 2;
+            }
             if (j.how == 2u) break;
             s += (uint64_t)j.segs + 1;
         }
@@ -1570,7 +1586,7 @@ static hipError_t launch_pml_segmented(const DevIndex &ix, const uint8_t *d_base
     hipLaunchKernelGGL((seg_stitch_kernel<6, 0>), dim3((unsigned)((max_seg + 63) / 64)), dim3(64), 0, stream, ix, d_bases, seg,
                        seg_j, seg_rem, max_over, on_chain, d_out, join);
     hipLaunchKernelGGL(seg_finalize_kernel, dim3((unsigned)((n_reads + bt256 - 1) / bt256)), dim3(bt256), 0, stream, go, first, n_reads,
-                       seg.tot, join, on_chain, read_fail, d_err, d_stats);
+                       seg.tot, join, seg_l, seg_rem, on_chain, read_fail, d_err, d_stats);
     hipLaunchKernelGGL((seg_stitch_kernel<6, 1>), dim3((unsigned)((max_seg + 63) / 64)), dim3(64), 0, stream, ix, d_bases, seg,
                        seg_j, seg_rem, max_over, on_chain, d_out, join);
     MOVI_LAUNCH_SEG_T(2, n_reads);
@@ -2108,7 +2124,7 @@ __global__ __launch_bounds__(256) void zml_stitch_kernel(DevIndex ix, const uint
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = ix.code_of[i];
     __syncthreads();
     const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool mine = s < *seg.n_seg && seg_j[s] != 0 && (PASS == 0 || on_chain[s] != 0);
+    const bool mine = s < *seg.n_seg && seg_j[s] != 0 && (PASS == 0 || on_chain[s] == 2);
     uint32_t ff_total = 0, scan_total = 0, failed = 0, how = 0;
     bool live0 = mine;
     if (PASS == 0 && mine && (seg.tot[s].flag != 0u || seg.tot[s - 1].flag != 0u)) live0 = false;
@@ -2139,6 +2155,7 @@ __global__ __launch_bounds__(256) void zml_stitch_kernel(DevIndex ix, const uint
         if (PASS == 1) {
             if (live && failed == 0u) O[k] = (uint16_t)(ml > 65535u ? 65535u : ml);
         } else if (live && failed == 0u) {
+            if (k < T) O[k] = (uint16_t)(ml > 65535u ? 65535u : ml);
             kend = (uint32_t)k;
             if ((k & 31ull) == 31ull) {
                 const ZSegCkpt c = seg.ckpt[(obeg + k) >> 5];
@@ -2614,7 +2631,7 @@ static hipError_t launch_zml_segmented(const DevIndex &ix, const uint8_t *d_base
     hipLaunchKernelGGL((zml_stitch_kernel<MODE, 0>), dim3((unsigned)((max_seg + 63) / 64)), dim3(64), 0, stream, ix, d_bases, seg,
                        seg_j, seg_rem, max_over, on_chain, d_out, join);
     hipLaunchKernelGGL(seg_finalize_kernel, dim3((unsigned)((n_reads + bt256 - 1) / bt256)), dim3(bt256), 0, stream, go, first, n_reads,
-                       seg.tot, join, on_chain, read_fail, d_err, d_stats);
+                       seg.tot, join, seg_l, seg_rem, on_chain, read_fail, d_err, d_stats);
     hipLaunchKernelGGL((zml_stitch_kernel<MODE, 1>), dim3((unsigned)((max_seg + 63) / 64)), dim3(64), 0, stream, ix, d_bases, seg,
                        seg_j, seg_rem, max_over, on_chain, d_out, join);
     hipLaunchKernelGGL((zml_kernel<MODE, 2>), dim3((unsigned)((n_reads + bt256 - 1) / bt256)), dim3(bt256), 0, stream, ix, d_bases,
