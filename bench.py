@@ -86,7 +86,7 @@ def ensure_pangenome(wl, world, rank, barrier):
 def usable_cores():
     """Host threads this process can really run: the CPU affinity mask capped by the cgroup CPU quota (the GPU boxes
     show 256 logical CPUs but grant 16 CPUs of quota: 256 OpenMP threads then run at 0.15-0.2 Gbases/s, 16 at 0.39;
-    tools/cpu_threads_sweep.py, profiles/r02_cpu_port_thread_sweep.txt)."""
+    tests/cpu_threads_sweep.py, profiles/r02_cpu_port_thread_sweep.txt)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:
         q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]                  # cgroup v2

@@ -87,7 +87,7 @@ struct ClsArgs {
 // read starts in (K1); then one lane per segment BOUNDARY continues the walk of the segment before across the
 // boundary until it is in step -- same row, offset and match length at one of the checkpoints the speculative lane
 // left every 32 bases -- with what that lane did (K2): from there on the two walks are the same walk.  A read all of
-// whose boundaries fell into step is exact; any other is walked again from end to end (K3).  tools/sync_study.py: on
+// whose boundaries fell into step is exact; any other is walked again from end to end (K3).  tests/sync_study.py: on
 // 10 kbp reads with 8 % / 1 % / 0.1 % substitutions a walk started mid-read is in step after a median of 11 / 80 / 607
 // bases (maximum 107 / 665 / 4540).
 struct SegCkpt { uint64_t idx; uint32_t off, ml, ff, scan, repo, pad_; };   // state after a base (before the LF to the next) + the segment's counters so far

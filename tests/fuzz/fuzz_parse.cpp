@@ -4,7 +4,7 @@
 // a sanitizer report, and whatever the parser ACCEPTS must be self-consistent (rows and side tables inside the image).
 // build + run: tools/fuzz_parse.sh [iterations per image]   (test: tests/test_abi_cpu.py::test_parse_fuzz_sanitized)
 // usage: fuzz_parse <iterations> image.movi [...]
-#include "../include/movi_hip.h"
+#include "../../include/movi_hip.h"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>

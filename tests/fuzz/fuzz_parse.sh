@@ -1,9 +1,9 @@
 #!/bin/bash
-# Builds tools/fuzz_parse.cpp + the ABI with ASan / UBSan (host code) and fuzzes movi_index_parse on one small index per type.
-# usage: tools/fuzz_parse.sh [iterations per image = 20000] [work dir = /tmp/movi_fuzz]
+# Builds tests/fuzz/fuzz_parse.cpp + the ABI with ASan / UBSan (host code) and fuzzes movi_index_parse on one small index per type.
+# usage: tests/fuzz/fuzz_parse.sh [iterations per image = 20000] [work dir = /tmp/movi_fuzz]
 set -e
 IT=${1:-20000}; W=${2:-/tmp/movi_fuzz}
-ROOT=$(cd "$(dirname "$0")/.." && pwd)
+ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 mkdir -p "$W"
 python3 - "$ROOT" "$W" <<'PY'
 import sys
@@ -16,5 +16,5 @@ for mode in (2, 3, 5, 6, 7, 8):
         open("%s/m%d%s.movi" % (w, mode, "s" if sep else ""), "wb").write(B.build_index_from_seqs([ref], mode, separators=sep))
 PY
 /opt/rocm/bin/hipcc -O1 -g -std=c++17 -fsanitize=address,undefined -fno-omit-frame-pointer --offload-arch=gfx950 \
-    -o "$W/fuzz_parse" "$ROOT/tools/fuzz_parse.cpp" "$ROOT/movi_amd/csrc/movi_abi.hip" "$ROOT/movi_amd/csrc/movi_kernels.hip"
+    -o "$W/fuzz_parse" "$ROOT/tests/fuzz/fuzz_parse.cpp" "$ROOT/movi_amd/csrc/movi_abi.hip" "$ROOT/movi_amd/csrc/movi_kernels.hip"
 ASAN_OPTIONS=detect_leaks=0 "$W/fuzz_parse" "$IT" "$W"/m*.movi

@@ -10,7 +10,7 @@ d = sys.argv[1]
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
 sub = float(sys.argv[3]) if len(sys.argv) > 3 else 0.08
 n = int(sys.argv[4]) if len(sys.argv) > 4 else 300
-tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "build_index")
+tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "build_index")
 rf = "/tmp/sync_reads_%d_%g.bin" % (L, sub)
 subprocess.check_call([tool, "reads", os.path.join(d, "text.bin"), str(n), str(L), str(sub), "5", rf], stderr=subprocess.DEVNULL)
 reads = np.fromfile(rf, np.uint8).reshape(n, L)

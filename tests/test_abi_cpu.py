@@ -202,11 +202,11 @@ def test_parse_regular_and_blocked_indexes(built_lib):
 
 def test_parse_fuzz_sanitized(tmp_path):
     """movi_index_parse under AddressSanitizer + UBSan (CPU build of the ABI's host code): truncations and field smashing of
-    one small index per type; no sanitizer report, and every accepted image is self-consistent (tools/fuzz_parse.cpp)."""
+    one small index per type; no sanitizer report, and every accepted image is self-consistent (tests/fuzz/fuzz_parse.cpp)."""
     import subprocess
-    script = os.path.join(ROOT, "tools", "fuzz_parse.sh")
+    script = os.path.join(ROOT, "tests", "fuzz", "fuzz_parse.sh")
     if not os.path.exists(script):
-        pytest.skip("tools/fuzz_parse.sh is CPU-container tooling (.gpurunignore keeps it off the GPU box)")
+        pytest.skip("tests/fuzz/fuzz_parse.sh is CPU-container tooling (.gpurunignore keeps it off the GPU box)")
     r = subprocess.run([script, "1500", str(tmp_path)], capture_output=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
     assert b"fuzz ok" in r.stdout and b"no sanitizer report" in r.stdout
