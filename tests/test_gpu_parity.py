@@ -1264,3 +1264,39 @@ def test_segment_parallel_zml_vs_oracle(engines, built_lib, mode, seg_len):
         assert (st.segments > 0) == want, (want, st.segments)
     if mode == 3:
         gpu.close()
+
+
+@pytest.mark.parametrize("seg_len", [32, 64, 96])
+def test_segment_parallel_length_edges(engines, seg_len):
+    """Read lengths around every boundary of the segment plan (2 S - 1, 2 S, 2 S + 1, multiples of 32 +- 1, one base more
+    than a whole number of segments ...), PML and ZML, cut against uncut on the GPU and against the oracle."""
+    from oracle import build_index as B
+    gpu, cpu = engines[6]
+    ref = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))[0][1]
+    rng = np.random.default_rng(7600 + seg_len)
+    lens = sorted(set([2 * seg_len + d for d in (-1, 0, 1, 31, 32, 33)] + [k * seg_len + d for k in (3, 4, 7) for d in (-33, -32, -31, -1, 0, 1, 31, 32, 33)] +
+                      [5 * seg_len + 17, 1000, 1023, 1024, 1025, 2047, 2049]))
+    reads = []
+    for L in lens:
+        for _ in range(3):
+            s = int(rng.integers(0, len(ref) - L))
+            r = bytearray(ref[s:s + L])
+            for k in np.flatnonzero(rng.random(L) < 0.06):
+                r[k] = b"ACGTN"[int(rng.integers(0, 5))]
+            reads.append(bytes(r))
+    bases, offs = pack(reads)
+    exp, ff, sc = cpu.pml_batch(bases, offs, threads=4)
+    zexp = cpu.zml_batch(bases, offs, threads=4)
+    gpu.set_option("seg_len", seg_len)
+    gpu.set_option("seg_probe", 0)
+    try:
+        out, st = gpu.query_pml_packed(bases, offs)
+        bad = np.flatnonzero(out != exp)
+        assert st.segments > len(reads) and bad.size == 0, (bad[:10], st.segments, st.rewalked)
+        assert (st.fast_forwards, st.scans, st.errors) == (ff, sc, 0)
+        zout, zst = gpu.query_zml_packed(bases, offs)
+        zbad = np.flatnonzero(zout != zexp)
+        assert zst.segments > len(reads) and zbad.size == 0, (zbad[:10], zst.segments, zst.rewalked)
+    finally:
+        gpu.set_option("seg_len", 2048)
+        gpu.set_option("seg_probe", 1)
