@@ -1214,6 +1214,8 @@ __global__ __launch_bounds__(256) void seg_probe_kernel(DevIndex ix, const uint8
         // (a batch of clean reads otherwise walks every probe to the end: 1.2 ms instead of 0.4)
         if (k == lead + reach / 2 && 2 * __popcll(__ballot(met != 0u)) < __popcll(__ballot(valid))) break;
         if (k == lead + reach / 6 && 10 * __popcll(__ballot(met != 0u)) < __popcll(__ballot(valid))) break;   // (nor with < 10 % after a sixth)
+        // ... and with 19 in 20 in step already the verdict of this wavefront is in (checked every 16 bases)
+        if (k > lead && (k & 15u) == 15u && 20 * __popcll(__ballot(met != 0u)) >= 19 * __popcll(__ballot(valid))) break;
     }
     const uint32_t nv = wave_sum(valid ? 1u : 0u), nm = wave_sum(met);
     if ((threadIdx.x & 63) == 0) {
@@ -2211,6 +2213,7 @@ __global__ __launch_bounds__(256) void zml_probe_kernel(DevIndex ix, const uint8
             met = 1;
         if (k == lead + reach / 2 && 2 * __popcll(__ballot(met != 0u)) < __popcll(__ballot(valid))) break;
         if (k == lead + reach / 6 && 10 * __popcll(__ballot(met != 0u)) < __popcll(__ballot(valid))) break;
+        if (k > lead && (k & 15u) == 15u && 20 * __popcll(__ballot(met != 0u)) >= 19 * __popcll(__ballot(valid))) break;
     }
     const uint32_t nv = wave_sum(valid ? 1u : 0u), nm = wave_sum(met);
     if ((threadIdx.x & 63) == 0) {
