@@ -44,6 +44,11 @@ def test_argument_errors(movi_bin):
     assert r.returncode == 1 and b"ignore-illegal-chars should be either 1" in r.stderr
     r = run(["view", "--bpf", "/nonexistent.bpf"])
     assert r.returncode == 1 and b"Failed to open the MLS file" in r.stderr
+    # engine extensions and flags that are accepted and implied: parsed before any device is touched
+    r = run(["query", "-i", "x", "-r", "y", "--seg-len", "abc"])
+    assert r.returncode == 1 and b"failed to parse for option 'seg-len'" in r.stderr
+    r = run(["query", "-i", "x", "-r", "y", "--mmap", "--seg-len", "64"])
+    assert r.returncode == 1 and b"not supported" not in r.stderr and b"Error parsing command line" not in r.stderr
 
 
 def reference_schedule(lines, fmt, strands, prefetch):
