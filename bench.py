@@ -83,6 +83,110 @@ def ensure_pangenome(wl, world, rank, barrier):
     return idx_dir, reads_file
 
 
+def bound_of(table_bytes):
+    """What the walk's gathers are served from: a table that fits the 256 MiB Infinity Cache never reaches DRAM in steady
+    state (the line rate of the L2 <-> fabric path bounds it, not HBM); anything bigger is HBM-bound.  `peak` stays the
+    HBM peak either way (the contract's roofline)."""
+    return "hbm" if table_bytes > INFINITY_CACHE_BYTES else "fabric (Infinity-Cache-resident table)"
+
+
+def lookup_traffic(workload, rows, reads, read_len, kernel):
+    """roofline.traffic: bytes per launch from profiles/traffic.json -- rocprofv3 PMC passes of an EARLIER run of this very
+    workload and kernel (counters cannot be collected inside a plain bench run), not a measurement of this run; null when
+    the shape or the kernel differs from what was profiled."""
+    tf = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        ent = json.load(open(tf)).get(workload)
+        if ent and ent.get("rows") == rows and ent.get("reads") == reads and ent.get("read_len") == read_len \
+                and ent.get("kernel_name", kernel) == kernel:
+            return ent.get("hbm_bytes_per_launch"), "static: %s (PMC passes of an earlier run of this workload; not measured in this run)" % ent.get("source")
+    except Exception:
+        pass
+    return None, None
+
+
+def big_table_leg(torch, dev, stream, synth, movi_amd, cores, rows=1_000_000_000, steps=10, warmup=2):
+    """c4 on one GPU: tools/synth.c's 1 B-row regular-thresholds table (8 GB), 1.25 M x 150 bp reads.  Returns the
+    `big_table` object of the bench line.  The oracle is the checker here, never the thing measured."""
+    from oracle.oracle import Oracle
+    w = WORKLOADS["c4"]
+    t0 = time.time()
+    six = synth.synth_index(rows, mode=6, seed=SEED)
+    img = six.image()
+    t_gen = time.time() - t0
+    _, cdesc, roff, rbytes = movi_amd.parse_index_image(img)
+    t0 = time.time()
+    d_rows = torch.from_numpy(img[roff: roff + rbytes]).to(dev)
+    cdesc.id_blocks = None
+    cdesc.tally_ids = None
+    cdesc.separator_thresholds, cdesc.separator_map = None, None
+    index = movi_amd.MoveIndex.from_device_rows(cdesc, d_rows.data_ptr(), device=dev.index or 0, keepalive=d_rows)
+    torch.cuda.synchronize()
+    t_up = time.time() - t0
+    n_reads, L = w["reads"], w["read_len"]
+    bases, offs = synth.synth_reads(six, n_reads, L, seed=SEED + 1, sub_rate=w["sub"], n_rate=0.001)
+    n_bases = int(bases.size)
+    d_bases = torch.from_numpy(bases).to(dev)
+    d_offs = torch.from_numpy(offs.view(np.int64)).to(dev)
+    d_out = torch.empty(n_bases, dtype=torch.int16, device=dev)
+    d_err = torch.zeros(n_reads, dtype=torch.uint8, device=dev)
+    run = lambda: index.pml_device(d_bases.data_ptr(), d_offs.data_ptr(), n_reads, n_bases, d_out.data_ptr(), d_err.data_ptr(),
+                                   stream.cuda_stream, 0)
+    for _ in range(warmup):
+        run()
+    torch.cuda.synchronize()
+    st = index.last_stats(stream.cuda_stream)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for a, b in evs:
+        a.record(stream)
+        run()
+        b.record(stream)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kern_s = sum(a.elapsed_time(b) for a, b in evs) / steps / 1e3
+    launch = index.last_launch()
+    f_bar, s_bar = st.fast_forwards / n_bases, st.scans / n_bases
+    bpb = 8 * (1.0 + f_bar + s_bar) + 1 + 2
+    achieved = bpb * n_bases / kern_s / 1e9
+    traffic, tsrc = lookup_traffic("c4", rows, n_reads, L, launch["kernel"])
+    out = {"workload": "c4", "description": w["desc"], "value": n_bases * steps / dt / 1e9, "unit": "Gbases/s", "steps": steps,
+           "warmup": warmup, "ms_per_step": dt / steps * 1e3, "rows": rows, "table_bytes": int(rbytes), "reads_per_gpu": n_reads,
+           "read_len": L, "fast_forwards_per_base": round(f_bar, 4), "scans_per_base": round(s_bar, 4),
+           "algorithmic_bytes_per_base": round(bpb, 3), "errors": int(st.errors),
+           "index_gen_s": round(t_gen, 1), "index_upload_s": round(t_up, 2),
+           "roofline": {"bound": bound_of(rbytes), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
+                        "kernel": launch["kernel"], "launch": launch, "kernel_ms_avg": kern_s * 1e3,
+                        "gathers_per_s": (1.0 + f_bar + s_bar) * n_bases / kern_s,
+                        "dram_frac_of_peak": (traffic / kern_s / 1e9 / HBM_PEAK_GBS) if traffic else None}}
+    # parity: three slices of the batch against the oracle on the same 8 GB image, PMLs and counters
+    t0 = time.time()
+    cpu = Oracle(img)
+    got_all = d_out.cpu().numpy().view(np.uint16)
+    ok, checked = True, 0
+    for lo in (0, n_reads // 2 - 1000, n_reads - 2000):
+        hi = lo + 2000
+        sb = bases[int(offs[lo]): int(offs[hi])]
+        so = offs[lo: hi + 1] - offs[lo]
+        exp, eff, esc = cpu.pml_batch(sb, so, threads=cores)
+        ok = ok and bool((got_all[int(offs[lo]): int(offs[hi])] == exp).all())
+        # the same slice alone through the engine: its fast-forward / scan counters must equal the oracle's
+        sl = torch.from_numpy(np.ascontiguousarray(so).view(np.int64)).to(dev)
+        index.pml_device(d_bases.data_ptr() + int(offs[lo]), sl.data_ptr(), 2000, int(sb.size), d_out.data_ptr(), d_err.data_ptr(),
+                         stream.cuda_stream, 0)
+        sst = index.last_stats(stream.cuda_stream)
+        ok = ok and sst.fast_forwards == eff and sst.scans == esc and sst.errors == 0
+        ok = ok and bool((d_out[: sb.size].cpu().numpy().view(np.uint16) == exp).all())
+        checked += 2000
+    out["parity_sample_ok"] = ok
+    out["parity_sample"] = "reads [0,2000), [%d,%d), [%d,%d) vs oracle/movi_oracle.c on the same image: PMLs bit-exact, fast-forward and scan counters equal (%.1f s)" % (
+        n_reads // 2 - 1000, n_reads // 2 + 1000, n_reads - 2000, n_reads, time.time() - t0)
+    cpu.close()
+    index.close()
+    return out
+
+
 def usable_cores():
     """Host threads this process can really run: the CPU affinity mask capped by the cgroup CPU quota (the GPU boxes
     show 256 logical CPUs but grant 16 CPUs of quota: 256 OpenMP threads then run at 0.15-0.2 Gbases/s, 16 at 0.39;
@@ -105,6 +209,24 @@ def usable_cores():
 
 SEED = 20260529
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+INFINITY_CACHE_BYTES = 256 << 20   # MI355X_MICROARCH.md: 256 MiB Infinity Cache (MALL) in front of HBM
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` started by hand (no torchrun): this process -- which has not touched the GPU, nor even
+    imported torch -- starts N ranks under torch.distributed.run as a CHILD and relays its exit code; rank 0's JSON
+    line goes to the inherited stdout.  (Never an exec: a process that has initialised the GPU must not be replaced.)"""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -137,7 +259,13 @@ def main():
     ap.add_argument("--no-long-reads", action="store_true", help="skip the secondary 100k x 10kbp measurement that the default "
                     "run (c2, N=1) appends as `long_reads` (north_star: 150 bp and 10 kbp reads)")
     ap.add_argument("--cpu-sample-reads", type=int, default=0)
+    ap.add_argument("--no-big-table", action="store_true", help="skip the 1 B-row (8 GB, HBM-resident) leg that the default run "
+                    "(c2, N=1) appends as `big_table` (BASELINE config 4's per-GPU shard, oracle-checked)")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the >= 5 s of back-to-back steps appended as `sustained`")
+    ap.add_argument("--extras-only", default="", help="debug: comma list of extras to run (big_table,sustained,long_reads,host_path,cli_path)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -160,12 +288,14 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    rccl_ranks = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if share_gpu:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev)          # backend "nccl" IS RCCL on ROCm
+            rccl_ranks = dist.get_world_size()
 
     wl = dict(WORKLOADS[args.workload])
     if args.rows: wl["rows"] = args.rows
@@ -332,20 +462,8 @@ def main():
     else:
         total_bases_per_step = float(n_bases)
 
-    # which PML kernel launch_pml picked (movi_kernels.hip: the lane state machine everywhere)
-    n_cus = torch.cuda.get_device_properties(dev).multi_processor_count
-    v_sel = args.variant if args.variant >= 0 else 14     # launch_pml: the window-parallel lane state machine, capped at 9 waves per CU on big batches
-    if args.classify and v_sel == 0:
-        v_sel = 1
-    if args.classify and v_sel == 7:
-        v_sel = 10
-    wpc_refill = args.waves_per_cu if args.waves_per_cu > 0 else 9          # kRefillWaves, movi_kernels.hpp
-    if v_sel == 13 and (d_order or n_reads <= n_cus * 64 * wpc_refill):
-        v_sel = 10
-    kmode = 6                                        # one resident row layout (movi_abi.hip: finish_create)
-    pml_kernel_name = {0: "pml_kernel<%d,0>" % kmode, 1: "pml_kernel<%d,1>" % kmode, 7: "pml_kernel_flat<%d>" % kmode,
-                       10: "pml_kernel_flatp<%d,refill=0>" % kmode, 13: "pml_kernel_flatp<%d,refill=1>" % kmode,
-                       14: "pml_kernel_flatp<%d,window-parallel>" % kmode}[v_sel]
+    # which kernel the library's launch policy picked for this batch, and with which shape: asked, not assumed
+    launch = index.last_launch()
     f_bar = st.fast_forwards / max(n_bases, 1)
     s_bar = st.scans / max(n_bases, 1)
     bytes_per_base = row_bytes * (1.0 + f_bar + s_bar) + 1 + 2
@@ -363,17 +481,8 @@ def main():
     achieved_gbs = bytes_per_base * work_bases / avg_kern_s / 1e9
     value = total_bases_per_step * args.steps / elapsed / 1e9       # Gbases/s, whole job
 
-    traffic = None
-    tf = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tf):
-        try:
-            tj = json.load(open(tf))
-            ent = tj.get(args.workload)
-            if ent and ent.get("rows") == wl["rows"] and ent.get("reads") == wl["reads"] \
-                    and ent.get("read_len") == wl["read_len"]:
-                traffic = ent.get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    traffic, traffic_src = lookup_traffic(args.workload, wl["rows"], wl["reads"], wl["read_len"], launch["kernel"]) \
+        if args.query == "pml" and not args.classify else (None, None)
 
     result = {
         "metric": {"pml": "PML", "count": "count", "zml": "ZML"}[args.query] + " query Gbases/s on " +
@@ -393,9 +502,11 @@ def main():
                    "query": args.query, "fused_classify": args.classify, "matched_bases_per_step": work_bases, "pml_variant": args.variant, "ragged": args.ragged, "waves_per_cu": args.waves_per_cu, "block_threads": args.block_threads, "index_gen_s": round(t_index_gen, 2),
                    "index_upload_s": round(t_index_upload, 2), "index_broadcast_s": round(t_bcast, 3),
                    "reads_gen_s": round(t_reads_gen, 2)},
-        "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "rccl_ranks": rccl_ranks, "index_broadcast_s": round(t_bcast, 4),
+        "roofline": {"bound": bound_of(wl["rows"] * row_bytes), "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": pml_kernel_name if args.query == "pml" else {"count": "count_kernel_v0", "zml": ("zml_kernel" if (args.zml_variant == 0 or (args.zml_variant < 0 and wl["rows"] > (3 << 30) // 8)) else "zml_kernel_flat")}[args.query],
+                     "traffic_source": traffic_src,
+                     "kernel": launch["kernel"], "launch": launch,
                      "kernel_ms_avg": avg_kern_s * 1e3,
                      "gathers_per_s": ((1.0 + f_bar + s_bar) * n_bases if args.query == "pml"
                                        else (2.0 * (1.0 + f_bar) + s_bar) * work_bases) / avg_kern_s},
@@ -484,7 +595,7 @@ def main():
             dt3 = time.perf_counter() - t0
             result["long_reads"] = {"workload": "c3", "description": w3["desc"], "value": n3 * L3 * k3 / dt3 / 1e9,
                                     "unit": "Gbases/s", "steps": k3, "ms_per_step": dt3 / k3 * 1e3, "reads_per_gpu": n3,
-                                    "read_len": L3, "kernel": "pml_kernel_flatp<%d,window-parallel>" % mode + (", segment-parallel" if st3.segments else ""),
+                                    "read_len": L3, "kernel": index.last_launch()["kernel"], "launch": index.last_launch(),
                                     "fast_forwards_per_base": round(st3.fast_forwards / (n3 * L3), 4),
                                     "scans_per_base": round(st3.scans / (n3 * L3), 4), "errors": int(st3.errors),
                                     "segments": int(st3.segments), "rewalked_reads": int(st3.rewalked)}
@@ -549,6 +660,37 @@ def main():
             result["host_path"] = hp
         except Exception as e:                            # noqa: BLE001 -- an extra, never worth the headline line
             result["host_path"] = {"error": repr(e)[:200]}
+    # ---- >= 5 s of the same step back to back (default run only, after the timed region, never part of `value`): the
+    # timed region above is K x 3 ms -- statistically fine (HIP events agree with rocprofv3 to 0.1 %) but too short for a
+    # 1 Hz utilisation sampler to see the GPU busy at all; this leg is the sustained figure
+    default_run = (rank == 0 and world == 1 and args.workload == "c2" and args.query == "pml" and not args.classify
+                   and args.variant < 0 and not args.from_dir)
+    if default_run and not args.no_sustained:
+        try:
+            n_sus = max(args.steps, int(5.5 / max(avg_kern_s, 1e-6)))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n_sus):
+                step()
+            torch.cuda.synchronize()
+            dts = time.perf_counter() - t0
+            result["sustained"] = {"steps": n_sus, "seconds": round(dts, 3), "value": n_bases * n_sus / dts / 1e9,
+                                   "unit": "Gbases/s", "ms_per_step": dts / n_sus * 1e3}
+        except Exception as e:                            # noqa: BLE001
+            result["sustained"] = {"error": repr(e)[:200]}
+    # ---- BASELINE config 4's per-GPU shard (default run only, after the timed region, never part of `value`): the walk on
+    # a 1 B-row / 8 GB table -- HBM-resident, 30-bit row ids, byte offsets beyond 2^32 -- with its own roofline, and three
+    # slices of the batch (first / middle / last 2000 reads) compared with the oracle bit for bit, counters included
+    if default_run and not args.no_big_table:
+        try:
+            del index, d_rows
+            torch.cuda.empty_cache()
+            result["big_table"] = big_table_leg(torch, dev, stream, synth, movi_amd, usable_cores())
+            if result["big_table"].get("parity_sample_ok") is False:
+                result["parity_sample_ok"] = False
+                print("PARITY FAILURE on the big_table oracle slices", file=sys.stderr)
+        except Exception as e:                            # noqa: BLE001 -- an extra, never worth the headline line
+            result["big_table"] = {"error": repr(e)[:300]}
     parity_failed = rank == 0 and result.get("parity_sample_ok") is False
     if parity_failed:
         # a kernel that disagrees with the oracle has no throughput: the record keeps the measurement under

@@ -138,6 +138,20 @@ int movi_index_create(int device, const movi_index_desc_t *desc, const void *h_r
 int movi_index_create_from_device_rows(int device, const movi_index_desc_t *desc,
                                        const void *d_rows, movi_index_t **out);
 
+/* One index on several GPUs of this node (`movi query --gpus N`; BASELINE north_star: "the shared index broadcast once
+ * via RCCL over xGMI").  Replaces N runs of MoveStructure::deserialize (src/move_structure_io.cpp:471-511; the
+ * reference has no multi-device form).  The file-format rows (8 / 6 / 3 bytes per row) cross PCIe ONCE, to
+ * devices[0]; one RCCL broadcast -- single process: ncclCommInitAll, then ncclBroadcast per device inside
+ * ncclGroupStart / ncclGroupEnd, root devices[0] -- carries them to the other GPUs over xGMI; every GPU then builds
+ * its own resident layout (blocked / sampled types: expanded on that GPU).  out[i] is the handle on devices[i];
+ * devices must be distinct.  n == 1 takes the same path (a communicator of one rank).  librccl.so.1 is bound when the
+ * first of these calls is made (dlopen: 570 MB of code objects that the single-GPU paths never need); if it cannot be
+ * loaded the call fails with MOVI_ERR_HIP -- there is no fallback to N uploads.
+ * movi_index_load_replicated: the same from DIR/index.movi (mapped, as movi_index_load). */
+int movi_index_replicate(const movi_index_desc_t *desc, const void *h_rows, const int *devices, int n,
+                         movi_index_t **out);
+int movi_index_load_replicated(const char *index_dir_or_file, const int *devices, int n, movi_index_t **out);
+
 int movi_index_destroy(movi_index_t *ix);
 int movi_index_get_desc(const movi_index_t *ix, movi_index_desc_t *desc);   /* id_blocks = NULL */
 /* Device pointer + size of the resident row table.  Mode 6: the file's bytes.  Modes 7 / 8: the expanded table, r x 8
@@ -158,18 +172,27 @@ int movi_index_device_rows(const movi_index_t *ix, const void **d_rows, size_t *
  * d_read_order[t].  Results stay indexed by read.  A hook for callers with their own
  * scheduling; sorting by length measured no gain on MI355X, so the host entry
  * points pass NULL.  At most 2^32 reads per call, each shorter than 2^32 bases.
+ * n_bases: the *_device entry points size device scratch from it, so it must be >= offsets[n_reads], and the batch
+ * must start at offsets[0] == 0 (pass a sub-batch as its own d_bases / d_offsets / d_out_pml pointers with offsets
+ * rebased to 0, not as a window into a larger offsets array).  A batch that breaks this is still answered correctly
+ * -- the segment plan checks the offsets on the device and stands down -- but only by one lane per read.
  * Asynchronous on `stream` (a hipStream_t, NULL = the null stream) -- except that a batch of long reads that
  * qualifies for the segment-parallel walk ("seg_len" below) makes the call wait for a short probe of the batch
- * (under a millisecond) before it enqueues the walk. */
+ * (under a millisecond, a 4-byte read-back) before it enqueues the walk.  Callers that capture the stream into a
+ * graph or pipeline several streams set "seg_probe" = 2 and state the verdict themselves ("seg_verdict"): nothing
+ * is read back then and the call never waits.
+ * One query call per handle at a time: the counters behind movi_last_stats, the segment workspace and what
+ * movi_last_launch reports belong to the handle, so two *_device calls on one handle must not be in flight together
+ * even on different streams (the *_host entry points pipeline internally with per-chunk copies of all three). */
 int movi_pml_device(movi_index_t *ix, const uint8_t *d_bases, const uint64_t *d_offsets,
                     uint64_t n_reads, uint64_t n_bases, uint16_t *d_out_pml, uint8_t *d_read_err,
                     const uint32_t *d_read_order, void *stream);
 
 /* Same, host buffers in and out; uploads, runs, downloads, synchronises.
  * stats may be NULL.  With h_bases and h_out_pml in PAGE-LOCKED memory (movi_host_alloc /
- * movi_host_register below) the call is overlapped: the reads are cut into chunks, up to four of
- * them in flight on their own streams, so that the upload of one, the walks of the next and the
- * download of the last run at the same time (results are identical; DESIGN.md has the rates).  Pageable
+ * movi_host_register below) the call is overlapped: the reads are cut into chunks that travel through six
+ * slots with their own streams -- up to three chunks going up or being walked while one comes down -- so that
+ * upload, walks and download run at the same time (results are identical; DESIGN.md has the rates).  Pageable
  * buffers take the synchronous path. */
 int movi_pml_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_offsets,
                   uint64_t n_reads, uint16_t *h_out_pml, uint8_t *h_read_err,
@@ -178,6 +201,20 @@ int movi_pml_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_of
 /* Device-side counters of the last movi_pml_device / movi_count_device call on
  * this handle; synchronises `stream` first. */
 int movi_last_stats(movi_index_t *ix, void *stream, movi_query_stats_t *stats);
+
+/* What the last query call on this handle launched: which kernel the launch policy picked (the name as rocprofv3
+ * prints it, template arguments included) and with which shape.  The policy lives in the library, so measurement code
+ * asks instead of assuming (bench.py's roofline.kernel). */
+typedef struct movi_launch_info {
+    char kernel[96];
+    int32_t variant;                  /* PML: 0, 1, 7, 10, 13, 14 ("pml_variant"); ZML: 0, 1; count: 0             */
+    int32_t block_threads;
+    int32_t waves_per_cu;             /* cap on resident wavefronts per CU that was applied (0 = none)             */
+    int32_t segmented;                /* 1 = the segment-parallel plan ran around that kernel                       */
+    int32_t idx64;                    /* 1 = the 64-bit row-index instantiation                                     */
+    int32_t reserved_[3];
+} movi_launch_info_t;
+int movi_last_launch(const movi_index_t *ix, movi_launch_info_t *info);
 
 /* ---- binary classification bins ------------------------------------------------ */
 
@@ -256,7 +293,8 @@ int movi_host_unregister(void *p);
  * even so get shorter segments, down to 512), "seg_probe" (1, the default: an eligible batch
  * is cut into segments only if a probe of some of its reads finds that walks started mid-read fall into step within a
  * few hundred bases -- noisy long reads do, reads with 0.1 % errors and less do not and are better off with one lane
- * per read --; 0 = cut whatever the probe would say: a test hook). */
+ * per read --; 0 = cut whatever the probe would say: a test hook; 2 = no probe, no length reduction, nothing read back:
+ * "seg_verdict" (1 = cut, 0 = do not, the default) decides and the *_device calls stay asynchronous). */
 int movi_set_option(movi_index_t *ix, const char *key, int64_t value);
 
 /* ---- ZML (Ziv-Merhav cross parse) ---------------------------------------------- */

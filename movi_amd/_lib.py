@@ -53,6 +53,18 @@ class QueryStatsC(C.Structure):
     ]
 
 
+class LaunchInfoC(C.Structure):
+    _fields_ = [
+        ("kernel", C.c_char * 96),
+        ("variant", C.c_int32),
+        ("block_threads", C.c_int32),
+        ("waves_per_cu", C.c_int32),
+        ("segmented", C.c_int32),
+        ("idx64", C.c_int32),
+        ("reserved_", C.c_int32 * 3),
+    ]
+
+
 # name -> (restype, argtypes); mirrors include/movi_hip.h one to one.
 SYMBOLS = {
     "movi_last_error": (C.c_char_p, []),
@@ -64,6 +76,9 @@ SYMBOLS = {
     "movi_index_create": (C.c_int, [C.c_int, C.POINTER(IndexDescC), C.c_void_p, C.POINTER(C.c_void_p)]),
     "movi_index_create_from_device_rows": (C.c_int, [C.c_int, C.POINTER(IndexDescC), C.c_void_p,
                                                      C.POINTER(C.c_void_p)]),
+    "movi_index_replicate": (C.c_int, [C.POINTER(IndexDescC), C.c_void_p, C.POINTER(C.c_int), C.c_int,
+                                       C.POINTER(C.c_void_p)]),
+    "movi_index_load_replicated": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
     "movi_index_destroy": (C.c_int, [C.c_void_p]),
     "movi_index_get_desc": (C.c_int, [C.c_void_p, C.POINTER(IndexDescC)]),
     "movi_index_device_rows": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
@@ -76,6 +91,7 @@ SYMBOLS = {
     "movi_zml_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                 C.POINTER(QueryStatsC)]),
     "movi_last_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(QueryStatsC)]),
+    "movi_last_launch": (C.c_int, [C.c_void_p, C.POINTER(LaunchInfoC)]),
     "movi_count_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "movi_count_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,

@@ -12,7 +12,9 @@
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
 #include <fcntl.h>
+#include <rccl/rccl.h>           // types and prototypes only: librccl.so.1 is bound at first use (movi_index_replicate)
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <thread>
@@ -119,6 +121,7 @@ struct movi_index {
     PipeSlot pipe[kPipeSlots];
     hipStream_t pipe_up = nullptr;   // every chunk's upload, in order (uploads on separate streams share the link and all arrive late)
     uint64_t pipe_chunk_bases = 0;   // test hook ("pipe_chunk_bases"): chunk size of the overlapped path, 0 = its policy
+    LaunchInfo last_launch;          // what the last query call launched (movi_last_launch)
     bool seg_seen = false;           // the last PML / ZML host call on long reads was walked segment-parallel (chunk policy below)
 };
 
@@ -433,6 +436,39 @@ static hipError_t upload_from_mapping(uint8_t *d_rows, const uint8_t *h_rows, si
     return hipSuccess;
 }
 
+// DIR/index.movi (open_index_read, src/move_structure_io.cpp:16-41: then DIR/movi_index.bin; or the file itself) mapped,
+// not read: the header and side tables are parsed in place and the row table -- all but a few kB of the file -- goes
+// from the page cache to the GPU without a copy into a process buffer (the reference's --mmap; an 8 GB index no longer
+// passes through an 8 GB std::vector first).
+struct MappedIndex {
+    void *p = MAP_FAILED;
+    size_t n = 0;
+    int open_index(const char *path) {
+        std::string cand[3] = {std::string(path) + "/index.movi", std::string(path) + "/movi_index.bin", std::string(path)};
+        int fd = -1;
+        struct stat sb{};
+        for (auto &c : cand) {
+            fd = open(c.c_str(), O_RDONLY | O_CLOEXEC);
+            if (fd < 0) continue;
+            // size and type of the file that was OPENED (a stat() of the path before the open could describe another file)
+            if (fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode)) break;
+            close(fd);
+            fd = -1;
+        }
+        if (fd < 0) return fail(MOVI_ERR_IO, std::string("Failed to open the index file at: ") + path);
+        n = (size_t)sb.st_size;
+        if (n == 0) { close(fd); return fail(MOVI_ERR_IO, std::string("Failed to read the index file at: ") + path); }
+        p = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+        close(fd);
+        if (p == MAP_FAILED) return fail(MOVI_ERR_IO, std::string("Failed to read the index file at: ") + path);
+        (void)madvise(p, n, MADV_WILLNEED);
+        return MOVI_OK;
+    }
+    ~MappedIndex() {
+        if (p != MAP_FAILED) { const std::string keep = g_err; munmap(p, n); g_err = keep; }
+    }
+};
+
 static int index_create(int device, const movi_index_desc_t *desc, const void *h_rows, movi_index_t **out, bool from_mapping) {
     if (!out || !h_rows) return fail(MOVI_ERR_ARG, "NULL argument");
     *out = nullptr;
@@ -488,32 +524,175 @@ int movi_index_create_from_device_rows(int device, const movi_index_desc_t *desc
 int movi_index_load(int device, const char *path, movi_index_t **out) {
     if (!path || !out) return fail(MOVI_ERR_ARG, "NULL argument");
     *out = nullptr;
-    // open_index_read, src/move_structure_io.cpp:16-41: DIR/index.movi, then DIR/movi_index.bin
-    std::string cand[3] = {std::string(path) + "/index.movi", std::string(path) + "/movi_index.bin", std::string(path)};
-    // The file is mapped, not read: the header and side tables are parsed in place and the row table -- all but a few
-    // kB of the file -- goes from the page cache to the GPU without a copy into a process buffer (the reference's
-    // --mmap; an 8 GB index no longer passes through an 8 GB std::vector first).
-    int fd = -1;
-    struct stat sb{};
-    for (auto &c : cand) {
-        if (stat(c.c_str(), &sb) != 0 || !S_ISREG(sb.st_mode)) continue;
-        fd = open(c.c_str(), O_RDONLY | O_CLOEXEC);
-        if (fd >= 0) break;
-    }
-    if (fd < 0) return fail(MOVI_ERR_IO, std::string("Failed to open the index file at: ") + path);
-    const size_t sz = (size_t)sb.st_size;
-    if (sz == 0) { close(fd); return fail(MOVI_ERR_IO, std::string("Failed to read the index file at: ") + path); }
-    void *map = mmap(nullptr, sz, PROT_READ, MAP_PRIVATE, fd, 0);
-    close(fd);
-    if (map == MAP_FAILED) return fail(MOVI_ERR_IO, std::string("Failed to read the index file at: ") + path);
-    (void)madvise(map, sz, MADV_WILLNEED);
+    MappedIndex m;
+    int rc = m.open_index(path);
+    if (rc) return rc;
     movi_index_desc_t desc;
     size_t roff = 0, rbytes = 0;
-    int rc = movi_index_parse(map, sz, &desc, &roff, &rbytes);
-    if (rc == MOVI_OK) rc = index_create(device, &desc, static_cast<const uint8_t *>(map) + roff, out, true);
-    const std::string keep = g_err;
-    munmap(map, sz);
-    g_err = keep;
+    rc = movi_index_parse(m.p, m.n, &desc, &roff, &rbytes);
+    if (rc == MOVI_OK) rc = index_create(device, &desc, static_cast<const uint8_t *>(m.p) + roff, out, true);
+    return rc;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------- one index on several GPUs: RCCL broadcast
+namespace {
+
+// librccl.so.1 is 570 MB of code objects for every collective, datatype and topology; a process that serves one GPU
+// (every path but this one) never needs it, and mapping it costs more than a small query.  So it is bound here, when
+// the first replicated index is made -- by name, with the image's own header for the types.  No RCCL, no replica.
+struct Rccl {
+    void *so = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string err;
+    bool load() {
+        if (so) return true;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            so = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (so) break;
+        }
+        if (!so) { const char *m = dlerror(); err = std::string("librccl.so.1 could not be loaded: ") + (m ? m : "?"); return false; }
+        auto sym = [&](const char *n) -> void * {
+            void *p = dlsym(so, n);
+            if (!p && err.empty()) err = std::string("librccl.so.1 lacks ") + n;
+            return p;
+        };
+        CommInitAll = reinterpret_cast<decltype(CommInitAll)>(sym("ncclCommInitAll"));
+        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
+        Broadcast = reinterpret_cast<decltype(Broadcast)>(sym("ncclBroadcast"));
+        GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
+        GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
+        GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
+        if (!err.empty()) { dlclose(so); so = nullptr; return false; }
+        return true;
+    }
+};
+Rccl g_rccl;
+
+int replicate(const movi_index_desc_t *desc, const void *h_rows, const int *devices, int n, movi_index_t **out,
+              bool from_mapping) {
+    if (!out || !h_rows || !devices) return fail(MOVI_ERR_ARG, "NULL argument");
+    if (n < 1 || n > 64) return fail(MOVI_ERR_ARG, "the number of devices must be in [1, 64]");
+    for (int i = 0; i < n; i++) out[i] = nullptr;
+    int rc = check_desc(desc);
+    if (rc) return rc;
+    int visible = 0;
+    HIP_TRY(hipGetDeviceCount(&visible));
+    for (int i = 0; i < n; i++) {
+        if (devices[i] < 0 || devices[i] >= visible)
+            return fail(MOVI_ERR_NO_DEVICE, "device " + std::to_string(devices[i]) + " requested but only " + std::to_string(visible) + " visible");
+        for (int j = 0; j < i; j++)
+            if (devices[j] == devices[i]) return fail(MOVI_ERR_ARG, "the devices of a replicated index must be distinct");
+    }
+    if (!g_rccl.load()) return fail(MOVI_ERR_HIP, g_rccl.err);
+    const size_t rows_bytes = (size_t)desc->r * mode_row_bytes(desc->mode);
+    std::vector<uint8_t *> d_rows((size_t)n, nullptr);
+    std::vector<hipStream_t> streams((size_t)n, nullptr);
+    std::vector<ncclComm_t> comms((size_t)n, nullptr);
+    bool comms_up = false;
+    auto cleanup = [&](bool keep_rows) {
+        const std::string keep = g_err;
+        for (int i = 0; i < n; i++) {
+            (void)hipSetDevice(devices[i]);
+            if (streams[i]) (void)hipStreamDestroy(streams[i]);
+            if (comms_up && comms[i]) (void)g_rccl.CommDestroy(comms[i]);
+            if (!keep_rows && d_rows[i]) (void)hipFree(d_rows[i]);
+        }
+        g_err = keep;
+    };
+    auto hip_fail = [&](hipError_t e, const char *what) { const int c = fail_hip(e, what); cleanup(false); return c; };
+    auto nccl_fail = [&](ncclResult_t r, const char *what) {
+        const int c = fail(MOVI_ERR_HIP, std::string(what) + ": " + g_rccl.GetErrorString(r));
+        cleanup(false);
+        return c;
+    };
+    // the table's only trip over PCIe: host (or file mapping) -> devices[0]
+    for (int i = 0; i < n; i++) {
+        hipError_t e = hipSetDevice(devices[i]);
+        if (e == hipSuccess) e = hipMalloc(&d_rows[i], rows_bytes + 16);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&streams[i], hipStreamNonBlocking);
+        if (e != hipSuccess) return hip_fail(e, "allocating the move rows");
+    }
+    {
+        hipError_t e = hipSetDevice(devices[0]);
+        if (e == hipSuccess)
+            e = from_mapping ? upload_from_mapping(d_rows[0], static_cast<const uint8_t *>(h_rows), rows_bytes)
+                             : hipMemcpy(d_rows[0], h_rows, rows_bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) return hip_fail(e, "uploading the move rows");
+    }
+    // ... and from there to every other GPU: one broadcast over xGMI, all ranks driven by this process
+    ncclResult_t r = g_rccl.CommInitAll(comms.data(), n, devices);
+    if (r != ncclSuccess) return nccl_fail(r, "ncclCommInitAll");
+    comms_up = true;
+    r = g_rccl.GroupStart();
+    if (r != ncclSuccess) return nccl_fail(r, "ncclGroupStart");
+    for (int i = 0; i < n && r == ncclSuccess; i++) {
+        (void)hipSetDevice(devices[i]);
+        r = g_rccl.Broadcast(d_rows[i], d_rows[i], rows_bytes, ncclUint8, 0, comms[i], streams[i]);
+    }
+    const ncclResult_t rg = g_rccl.GroupEnd();
+    if (r != ncclSuccess) return nccl_fail(r, "ncclBroadcast");
+    if (rg != ncclSuccess) return nccl_fail(rg, "ncclGroupEnd");
+    for (int i = 0; i < n; i++) {
+        hipError_t e = hipSetDevice(devices[i]);
+        if (e == hipSuccess) e = hipStreamSynchronize(streams[i]);
+        if (e != hipSuccess) return hip_fail(e, "the RCCL broadcast of the move rows");
+    }
+    // every GPU builds its own resident layout from the file-format rows it now holds
+    for (int i = 0; i < n; i++) {
+        hipError_t e = hipSetDevice(devices[i]);
+        if (e != hipSuccess) { for (int j = 0; j < i; j++) { movi_index_destroy(out[j]); out[j] = nullptr; d_rows[j] = nullptr; } return hip_fail(e, "hipSetDevice"); }
+        movi_index *ix = new_handle(devices[i], desc);
+        ix->d_rows = d_rows[i];
+        ix->owns_rows = true;
+        d_rows[i] = nullptr;                                   // the handle's from here on
+        int rci = MOVI_OK;
+        if (mode_sampled(desc->mode)) {
+            uint8_t *packed = ix->d_rows;
+            ix->d_rows = nullptr;
+            e = adopt_widened(ix, packed);
+            (void)hipFree(packed);
+            if (e != hipSuccess) rci = fail_hip(e, "widening the 3-byte rows");
+        }
+        if (rci == MOVI_OK) rci = finish_create(ix);
+        if (rci != MOVI_OK) {
+            const std::string keep = g_err;
+            movi_index_destroy(ix);
+            for (int j = 0; j < i; j++) { movi_index_destroy(out[j]); out[j] = nullptr; }
+            g_err = keep;
+            cleanup(false);
+            return rci;
+        }
+        out[i] = ix;
+    }
+    cleanup(true);
+    return MOVI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int movi_index_replicate(const movi_index_desc_t *desc, const void *h_rows, const int *devices, int n, movi_index_t **out) {
+    return replicate(desc, h_rows, devices, n, out, false);
+}
+
+int movi_index_load_replicated(const char *path, const int *devices, int n, movi_index_t **out) {
+    if (!path || !out || !devices) return fail(MOVI_ERR_ARG, "NULL argument");
+    for (int i = 0; i < n; i++) out[i] = nullptr;
+    MappedIndex m;
+    int rc = m.open_index(path);
+    if (rc) return rc;
+    movi_index_desc_t desc;
+    size_t roff = 0, rbytes = 0;
+    rc = movi_index_parse(m.p, m.n, &desc, &roff, &rbytes);
+    if (rc == MOVI_OK) rc = replicate(&desc, static_cast<const uint8_t *>(m.p) + roff, devices, n, out, true);
     return rc;
 }
 
@@ -598,8 +777,13 @@ int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
         return MOVI_OK;
     }
     if (!strcmp(key, "seg_probe")) {                         // 0: segment eligible batches whatever the probe would say (tests)
-        if (value != 0 && value != 1) return fail(MOVI_ERR_ARG, "seg_probe must be 0 or 1");
-        ix->cfg.seg_probe = (int)value;
+        if (value < 0 || value > 2) return fail(MOVI_ERR_ARG, "seg_probe must be 0, 1 or 2");
+        ix->cfg.seg_probe = (int)value;                      // 2: the caller's "seg_verdict" decides, nothing is read back
+        return MOVI_OK;
+    }
+    if (!strcmp(key, "seg_verdict")) {
+        if (value != 0 && value != 1) return fail(MOVI_ERR_ARG, "seg_verdict must be 0 or 1");
+        ix->cfg.seg_verdict = (int)value;
         return MOVI_OK;
     }
     if (!strcmp(key, "waves_per_cu")) {
@@ -632,10 +816,10 @@ static int ml_device(bool zml, movi_index_t *ix, const uint8_t *d_bases, const u
     if (n_reads > 0xFFFFFFFFull) return fail(MOVI_ERR_ARG, "more than 2^32 reads in one call");
     if (zml)
         HIP_TRY(launch_zml(ix->kmode, ix->dev, d_bases, d_offsets, n_reads, n_bases, d_out, d_read_err, d_stats,
-                           d_read_order, ix->cfg, s, seg_ws, ragged_hint, seg_verdict));
+                           d_read_order, ix->cfg, s, seg_ws, ragged_hint, seg_verdict, &ix->last_launch));
     else
         HIP_TRY(launch_pml(ix->kmode, ix->dev, d_bases, d_offsets, n_reads, n_bases, d_out, d_read_err, d_stats,
-                           d_read_order, ix->cfg, s, cls, seg_ws, ragged_hint, seg_verdict));
+                           d_read_order, ix->cfg, s, cls, seg_ws, ragged_hint, seg_verdict, &ix->last_launch));
     return MOVI_OK;
 }
 
@@ -649,6 +833,19 @@ int movi_zml_device(movi_index_t *ix, const uint8_t *d_bases, const uint64_t *d_
                     uint64_t n_bases, uint16_t *d_out_zml, uint8_t *d_read_err, const uint32_t *d_read_order,
                     void *stream) {
     return ml_device(true, ix, d_bases, d_offsets, n_reads, n_bases, d_out_zml, d_read_err, d_read_order, stream);
+}
+
+int movi_last_launch(const movi_index_t *ix, movi_launch_info_t *info) {
+    if (!ix || !info) return fail(MOVI_ERR_ARG, "NULL argument");
+    memset(info, 0, sizeof(*info));
+    static_assert(sizeof(info->kernel) == sizeof(ix->last_launch.kernel), "kernel name buffers differ");
+    memcpy(info->kernel, ix->last_launch.kernel, sizeof(info->kernel));
+    info->variant = ix->last_launch.variant;
+    info->block_threads = ix->last_launch.block_threads;
+    info->waves_per_cu = ix->last_launch.waves_per_cu;
+    info->segmented = ix->last_launch.segmented;
+    info->idx64 = ix->last_launch.idx64;
+    return MOVI_OK;
 }
 
 int movi_last_stats(movi_index_t *ix, void *stream, movi_query_stats_t *stats) {
@@ -1148,7 +1345,8 @@ int movi_classify_device(movi_index_t *ix, const uint16_t *d_pml, const uint64_t
 static int pml_classify_device(movi_index_t *ix, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
                                uint64_t n_bases, uint32_t bin_width, uint32_t max_value_thr, uint16_t *d_out_pml,
                                uint32_t *d_bins_above, uint32_t *d_bins_below, uint64_t *d_sum_max, uint8_t *d_read_err,
-                               const uint32_t *d_read_order, void *stream, DevStats *d_stats) {
+                               const uint32_t *d_read_order, void *stream, DevStats *d_stats,
+                               SegWorkspace *seg_ws = nullptr, int ragged_hint = -1, int *seg_verdict = nullptr) {
     if (bin_width == 0) return fail(MOVI_ERR_ARG, "bin_width must be > 0");
     if (n_reads && (!d_bins_above || !d_bins_below || !d_sum_max)) return fail(MOVI_ERR_ARG, "NULL device buffer");
     ClsArgs cls;
@@ -1157,7 +1355,11 @@ static int pml_classify_device(movi_index_t *ix, const uint8_t *d_bases, const u
     cls.above = d_bins_above;
     cls.below = d_bins_below;
     cls.sum_max = d_sum_max;
-    return ml_device(false, ix, d_bases, d_offsets, n_reads, n_bases, d_out_pml, d_read_err, d_read_order, stream, cls, d_stats);
+    // (a chunk in flight of the overlapped host path brings its own segment workspace, length hint and the call's probe
+    // verdict: without them every chunk fell back to the handle's workspace -- shared by chunks on different streams --
+    // and probed again)
+    return ml_device(false, ix, d_bases, d_offsets, n_reads, n_bases, d_out_pml, d_read_err, d_read_order, stream, cls, d_stats,
+                     seg_ws, ragged_hint, seg_verdict);
 }
 
 int movi_pml_classify_device(movi_index_t *ix, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
@@ -1186,7 +1388,7 @@ int movi_pml_classify_host(movi_index_t *ix, const uint8_t *h_bases, const uint6
         // bins reduced inside the PML kernel; no PML vector is written at all
         return pml_classify_device(ix, db, dof, nr, nb, bin_width, max_value_thr, nullptr, static_cast<uint32_t *>(d_a.p),
                                    static_cast<uint32_t *>(d_b.p), static_cast<uint64_t *>(d_s.p), derr, nullptr, c.s,
-                                   c.d_stats);
+                                   c.d_stats, c.seg_ws, c.ragged_hint, c.seg_verdict);
     };
     // page-locked block of a chunk in flight: sum_max[nr] | above[nr] | below[nr]
     auto fetch = [&](ChunkCtx &c, uint64_t first, uint64_t nr, uint64_t, uint64_t) -> int {
@@ -1235,7 +1437,7 @@ static int count_device(movi_index_t *ix, const uint8_t *d_bases, const uint64_t
     HIP_TRY(hipMemsetAsync(d_stats, 0, sizeof(DevStats), s));
     if (n_reads > 0xFFFFFFFFull) return fail(MOVI_ERR_ARG, "more than 2^32 reads in one call");
     HIP_TRY(launch_count(ix->kmode, ix->dev, d_bases, d_offsets, n_reads, d_matched, d_count,
-                         d_read_err, d_stats, d_read_order, ix->cfg, s));
+                         d_read_err, d_stats, d_read_order, ix->cfg, s, &ix->last_launch));
     return MOVI_OK;
 }
 

@@ -18,6 +18,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <cstdio>
 
 namespace movi {
 
@@ -1225,8 +1226,14 @@ __global__ __launch_bounds__(256) void seg_probe_kernel(DevIndex ix, const uint8
 }
 
 // go = at least 8 probes, 9 in 10 of them in step within reach (or no probing asked for)
-__global__ void seg_decide_kernel(const uint32_t *__restrict__ tally, uint32_t probe, uint32_t *__restrict__ go) {
-    *go = probe ? (uint32_t)(tally[0] >= 8u && (uint64_t)tally[1] * 10ull >= (uint64_t)tally[0] * 9ull) : 1u;
+// The segment plan indexes its scratch (checkpoints: one per 32 bases; the verdict-only PML buffer) with the batch's own
+// offsets, so it needs what the header states for the *_device entry points: offsets[0] == 0 and offsets[n_reads] <=
+// n_bases.  The host entry points build their offsets that way; a device caller's are checked HERE, on the device,
+// and a batch that breaks the contract is not cut (go = 0: every kernel of the plan idles, K3 walks whole reads).
+__global__ void seg_decide_kernel(const uint32_t *__restrict__ tally, uint32_t probe, uint32_t *__restrict__ go,
+                                  const uint64_t *__restrict__ offs, uint64_t n_reads, uint64_t n_bases) {
+    const uint32_t fits = (uint32_t)(offs[0] == 0ull && offs[n_reads] <= n_bases);
+    *go = fits & (probe ? (uint32_t)(tally[0] >= 8u && (uint64_t)tally[1] * 10ull >= (uint64_t)tally[0] * 9ull) : 1u);
 }
 
 // Segments of a read of `len` bases: n = len / seg_len of them (1 below 2 x seg_len), each T bases -- a multiple of
@@ -1240,11 +1247,11 @@ __device__ __forceinline__ void seg_shape(uint64_t len, uint32_t seg_len, uint64
 }
 
 __global__ __launch_bounds__(256) void seg_count_kernel(const uint64_t *__restrict__ offs, uint64_t n_reads, uint32_t seg_len,
-                                                       uint64_t *__restrict__ n_of) {
+                                                       uint64_t *__restrict__ n_of, const uint32_t *__restrict__ go) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t > n_reads) return;
     uint64_t n = 0, T = 0;
-    if (t < n_reads) seg_shape(offs[t + 1] - offs[t], seg_len, n, T);
+    if (t < n_reads && *go != 0u) seg_shape(offs[t + 1] - offs[t], seg_len, n, T);   // go == 0: no segments at all
     n_of[t] = n;                                          // entry n_reads = 0: its exclusive sum is the total
 }
 
@@ -1457,14 +1464,24 @@ static hipError_t launch_pml_segmented(const DevIndex &ix, const uint8_t *d_base
     // `verdict` (optional, in / out): a caller that cuts one batch into several launches (the overlapped host path) lets
     // the first one probe and hands its verdict to the others -- 1: cut without probing (no read-back, the launch stays
     // asynchronous), 0: do not cut; -1 on entry: not decided yet.
-    if (verdict && *verdict == 0) { *declined = true; return hipSuccess; }
-    const bool probe = cfg.seg_probe != 0 && !(verdict && *verdict == 1);
+    // cfg.seg_probe == 2: the CALLER decides (cfg.seg_verdict) -- no probe, no length reduction, no read-back: the launch
+    // stays asynchronous (stream capture, callers that pipeline several streams).
+    int forced = -1;
+    if (verdict && *verdict >= 0) forced = *verdict;
+    if (cfg.seg_probe == 2) forced = cfg.seg_verdict ? 1 : 0;
+    if (forced == 0) { *declined = true; return hipSuccess; }
+    const bool probe = cfg.seg_probe == 1 && forced != 1;
+    // a verdict-only call (bins, no PML vector) keeps its PMLs in the workspace, sized from n_bases: for offsets that only
+    // the device has seen (ragged_hint < 0) the verdict of seg_decide_kernel -- which checks them -- is always read back
+    const bool ws_pml = bins.bin_width && !d_out;
+    if (ws_pml && ragged_hint < 0 && cfg.seg_probe == 2) { *declined = true; return hipSuccess; }
+    const bool read_back = probe || (ws_pml && ragged_hint < 0);
     // Classification bins (bins.bin_width != 0): not fused into this walk -- a bin spans segments -- but reduced from the
     // resident PML vector afterwards (classify_kernel: 2 B per base, streaming); without a caller's vector (d_out == NULL:
     // verdicts only) the PMLs go to the workspace.
     *declined = false;
     const uint32_t S = call_seg_len(cfg, n_bases, 8);
-    if (cfg.seg_probe && n_reads >= (uint64_t)cfg.num_cus * 64ull * 4ull) {
+    if (cfg.seg_probe == 1 && n_reads >= (uint64_t)cfg.num_cus * 64ull * 4ull) {
         if (ragged_hint == 0) { *declined = true; return hipSuccess; }
         if (ragged_hint < 0) {
             if (ws->cap < 64) {
@@ -1533,19 +1550,19 @@ static hipError_t launch_pml_segmented(const DevIndex &ix, const uint8_t *d_base
     if (e != hipSuccess) return e;
     if (probe)
         hipLaunchKernelGGL(seg_probe_kernel<6>, dim3(16), dim3(64), 0, stream, ix, d_bases, d_offsets, n_reads, 32u, 384u, go + 1);
-    hipLaunchKernelGGL(seg_decide_kernel, dim3(1), dim3(1), 0, stream, go + 1, (uint32_t)probe, go);
-    if (probe) {
+    hipLaunchKernelGGL(seg_decide_kernel, dim3(1), dim3(1), 0, stream, go + 1, (uint32_t)probe, go, d_offsets, n_reads, n_bases);
+    if (read_back) {
         // The verdict is read back (this call waits for the probe): a batch it advises against then takes exactly the
         // one-lane-per-read path -- fused bins included -- instead of a dozen kernels that find out one by one.
         uint32_t h_go = 0;
         e = hipMemcpyAsync(&h_go, go, 4, hipMemcpyDeviceToHost, stream);
         if (e == hipSuccess) e = hipStreamSynchronize(stream);
         if (e != hipSuccess) return e;
-        if (verdict) *verdict = h_go ? 1 : 0;
+        if (verdict && probe) *verdict = h_go ? 1 : 0;
         if (!h_go) { *declined = true; return hipSuccess; }
     }
     hipLaunchKernelGGL(seg_count_kernel, dim3((unsigned)((n_reads + 1 + bt256 - 1) / bt256)), dim3(bt256), 0, stream, d_offsets,
-                       n_reads, S, n_of);
+                       n_reads, S, n_of, go);
     e = hipcub::DeviceScan::ExclusiveSum(B + o_temp, temp_bytes, n_of, first, (int)(n_reads + 1), stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(seg_fill_kernel, dim3((unsigned)((n_reads + bt256 - 1) / bt256)), dim3(bt256), 0, stream, d_offsets,
@@ -1603,7 +1620,7 @@ static hipError_t launch_pml_segmented(const DevIndex &ix, const uint8_t *d_base
 hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets,
                       uint64_t n_reads, uint64_t n_bases, uint16_t *d_out, uint8_t *d_err, DevStats *d_stats,
                       const uint32_t *d_order, const LaunchCfg &cfg, hipStream_t stream, const ClsArgs &cls,
-                      SegWorkspace *seg_ws, int ragged_hint, int *seg_verdict) {
+                      SegWorkspace *seg_ws, int ragged_hint, int *seg_verdict, LaunchInfo *info) {
     if (n_reads == 0) return hipSuccess;
     // 0 = PML vector only, 1 = vector + classification bins, 2 = bins only
     const int cm = cls.bin_width == 0 ? 0 : (d_out ? 1 : 2);
@@ -1655,6 +1672,12 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
         const hipError_t es = launch_pml_segmented(ix, d_bases, d_offsets, n_reads, n_bases, d_out, d_err, d_stats, cfg, stream,
                                                    seg_ws, cfg.pml_variant < 0 || cfg.pml_variant == 14, ragged_hint, &declined, cls,
                                                    seg_verdict);
+        if (es == hipSuccess && !declined && info) {
+            snprintf(info->kernel, sizeof(info->kernel), "pml_kernel_flatp<6, %s, -1, 0, %d, 0, 1>",
+                     ix.idx32 ? "unsigned int" : "unsigned long", ix.sep ? 1 : 0);
+            info->variant = 14; info->block_threads = 64; info->segmented = 1; info->idx64 = ix.idx32 ? 0 : 1;
+            info->waves_per_cu = 0;
+        }
         if (es != hipSuccess || !declined) return es;
     }
     const int bt = cfg.block_threads > 0 ? cfg.block_threads : 64;           // one wavefront per block: finest dispatch grain
@@ -1732,6 +1755,15 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     } while (0)
     if (v == 0) MOVI_LAUNCH_PML(6, 0, 0); else if (v == 1) MOVI_BY_CLS(MOVI_LAUNCH_PML, 6, 1);
     else if (v == 7) MOVI_LAUNCH_FLAT(6); else MOVI_BY_CLS(MOVI_LAUNCH_FLATP, 6);
+    if (info) {
+        const char *it = ix.idx32 ? "unsigned int" : "unsigned long";
+        if (v == 0 || v == 1) snprintf(info->kernel, sizeof(info->kernel), "pml_kernel<6, %d, %d>", v, v == 0 ? 0 : cm);
+        else if (v == 7) snprintf(info->kernel, sizeof(info->kernel), "pml_kernel_flat<6, %s, 0>", it);
+        else snprintf(info->kernel, sizeof(info->kernel), "pml_kernel_flatp<6, %s, %d, %d, %d, %d, 0>", it, wp ? -1 : MOVI_HA, cm,
+                      ix.sep ? 1 : 0, v == 13 ? 1 : 0);
+        info->variant = (v == 10 && wp) ? 14 : v;
+        info->block_threads = bt; info->waves_per_cu = wpc; info->segmented = 0; info->idx64 = ix.idx32 ? 0 : 1;
+    }
 #undef MOVI_LAUNCH_PML
 #undef MOVI_LAUNCH_K
 #undef MOVI_LAUNCH_KX
@@ -1940,9 +1972,14 @@ __global__ __launch_bounds__(256) void count_kernel_v0(DevIndex ix, const uint8_
 
 hipError_t launch_count(int mode, const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets,
                         uint64_t n_reads, uint64_t *d_matched, uint64_t *d_count, uint8_t *d_err,
-                        DevStats *d_stats, const uint32_t *d_order, const LaunchCfg &cfg, hipStream_t stream) {
+                        DevStats *d_stats, const uint32_t *d_order, const LaunchCfg &cfg, hipStream_t stream,
+                        LaunchInfo *info) {
     if (n_reads == 0) return hipSuccess;
     const int bt = cfg.block_threads > 0 ? cfg.block_threads : 256;
+    if (info) {
+        snprintf(info->kernel, sizeof(info->kernel), "count_kernel_v0<%d>", mode);
+        info->variant = 0; info->block_threads = bt; info->waves_per_cu = 0; info->segmented = 0; info->idx64 = 1;
+    }
     const uint64_t blocks = (n_reads + bt - 1) / bt;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     dim3 grid((unsigned)blocks), block((unsigned)bt);
@@ -2536,11 +2573,14 @@ static hipError_t launch_zml_segmented(const DevIndex &ix, const uint8_t *d_base
                                        uint64_t n_bases, uint16_t *d_out, uint8_t *d_err, DevStats *d_stats, const LaunchCfg &cfg,
                                        hipStream_t stream, SegWorkspace *ws, int ragged_hint, bool *declined, int *verdict) {
     *declined = false;
-    if (verdict && *verdict == 0) { *declined = true; return hipSuccess; }
-    const bool probe = cfg.seg_probe != 0 && !(verdict && *verdict == 1);
+    int forced = -1;                                       // as launch_pml_segmented: seg_probe == 2 = the caller's verdict
+    if (verdict && *verdict >= 0) forced = *verdict;
+    if (cfg.seg_probe == 2) forced = cfg.seg_verdict ? 1 : 0;
+    if (forced == 0) { *declined = true; return hipSuccess; }
+    const bool probe = cfg.seg_probe == 1 && forced != 1;
     const uint32_t S = call_seg_len(cfg, n_bases, 24);
     hipError_t e = hipSuccess;
-    if (cfg.seg_probe && n_reads >= (uint64_t)cfg.num_cus * 64ull * 8ull) {
+    if (cfg.seg_probe == 1 && n_reads >= (uint64_t)cfg.num_cus * 64ull * 8ull) {
         if (ragged_hint == 0) { *declined = true; return hipSuccess; }
         if (ragged_hint < 0) {
             if (ws->cap < 64) {
@@ -2602,7 +2642,7 @@ static hipError_t launch_zml_segmented(const DevIndex &ix, const uint8_t *d_base
     if (e != hipSuccess) return e;
     if (probe)
         hipLaunchKernelGGL(zml_probe_kernel<MODE>, dim3(16), dim3(64), 0, stream, ix, d_bases, d_offsets, n_reads, 32u, 384u, go + 1);
-    hipLaunchKernelGGL(seg_decide_kernel, dim3(1), dim3(1), 0, stream, go + 1, (uint32_t)probe, go);
+    hipLaunchKernelGGL(seg_decide_kernel, dim3(1), dim3(1), 0, stream, go + 1, (uint32_t)probe, go, d_offsets, n_reads, n_bases);
     if (probe) {
         uint32_t h_go = 0;
         e = hipMemcpyAsync(&h_go, go, 4, hipMemcpyDeviceToHost, stream);
@@ -2611,8 +2651,10 @@ static hipError_t launch_zml_segmented(const DevIndex &ix, const uint8_t *d_base
         if (verdict) *verdict = h_go ? 1 : 0;
         if (!h_go) { *declined = true; return hipSuccess; }
     }
+    // (go == 0 -- a probe nobody read back cannot say so here, but offsets that break the contract can: seg_decide_kernel --
+    // leaves the plan without segments: K1 / K2 idle, seg_finalize_kernel hands every read to K3)
     hipLaunchKernelGGL(seg_count_kernel, dim3((unsigned)((n_reads + 1 + bt256 - 1) / bt256)), dim3(bt256), 0, stream, d_offsets,
-                       n_reads, S, n_of);
+                       n_reads, S, n_of, go);
     e = hipcub::DeviceScan::ExclusiveSum(B + o_temp, temp_bytes, n_of, first, (int)(n_reads + 1), stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(seg_fill_kernel, dim3((unsigned)((n_reads + bt256 - 1) / bt256)), dim3(bt256), 0, stream, d_offsets,
@@ -2645,7 +2687,7 @@ static hipError_t launch_zml_segmented(const DevIndex &ix, const uint8_t *d_base
 hipError_t launch_zml(int mode, const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets,
                       uint64_t n_reads, uint64_t n_bases, uint16_t *d_out, uint8_t *d_err, DevStats *d_stats,
                       const uint32_t *d_order, const LaunchCfg &cfg, hipStream_t stream, SegWorkspace *seg_ws,
-                      int ragged_hint, int *seg_verdict) {
+                      int ragged_hint, int *seg_verdict, LaunchInfo *info) {
     if (n_reads == 0) return hipSuccess;
     if (seg_ws && cfg.seg_len >= 32 && !d_order && cfg.zml_variant < 0 && cfg.block_threads == 0 && cfg.waves_per_cu <= 0 &&
         n_bases / n_reads >= 2ull * (uint64_t)cfg.seg_len && n_reads + n_bases / (uint64_t)cfg.seg_len < 0x7FFFFFF0ull &&
@@ -2655,6 +2697,13 @@ hipError_t launch_zml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
                                                                   stream, seg_ws, ragged_hint, &declined, seg_verdict)
                                         : launch_zml_segmented<3>(ix, d_bases, d_offsets, n_reads, n_bases, d_out, d_err, d_stats, cfg,
                                                                   stream, seg_ws, ragged_hint, &declined, seg_verdict);
+        if (es == hipSuccess && !declined && info) {
+            const bool sm = ix.r <= (3ull << 30) / 8 && ix.r >= 8 && n_bases >= 16;
+            if (sm) snprintf(info->kernel, sizeof(info->kernel), "zml_kernel_flat<%d, %s, 1>", mode, ix.idx32 ? "unsigned int" : "unsigned long");
+            else snprintf(info->kernel, sizeof(info->kernel), "zml_kernel<%d, 1>", mode);
+            info->variant = sm ? 1 : 0; info->block_threads = sm ? 64 : 256; info->waves_per_cu = 0; info->segmented = 1;
+            info->idx64 = ix.idx32 ? 0 : 1;
+        }
         if (es != hipSuccess || !declined) return es;
     }
     // 0 = base-synchronous kernel, 1 = lane state machine.  Measured (profiles/r02_zml_state_machine.txt), Gbases/s,
@@ -2671,6 +2720,12 @@ hipError_t launch_zml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     const uint64_t blocks = (n_reads + bt - 1) / bt;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     dim3 grid((unsigned)blocks), block((unsigned)bt);
+    if (info) {
+        if (v == 1) snprintf(info->kernel, sizeof(info->kernel), "zml_kernel_flat<%d, %s, 0>", mode, ix.idx32 ? "unsigned int" : "unsigned long");
+        else snprintf(info->kernel, sizeof(info->kernel), "zml_kernel<%d, 0>", mode);
+        info->variant = v; info->block_threads = bt; info->waves_per_cu = cfg.waves_per_cu > 0 ? cfg.waves_per_cu : 0;
+        info->segmented = 0; info->idx64 = ix.idx32 ? 0 : 1;
+    }
     size_t dyn_lds = 0;                                  // occupancy cap by LDS padding, as in launch_pml (<= 64 KiB here)
     if (cfg.waves_per_cu > 0) {
         int bpc = cfg.waves_per_cu / (bt / 64);

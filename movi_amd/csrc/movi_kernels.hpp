@@ -67,9 +67,21 @@ struct LaunchCfg {
     int num_cus = 256;
     int waves_per_cu = 0;  // 0 = auto (variant 10 on big batches and variant 13: kCapWaves; else no cap); else cap resident waves per CU by padding the block's LDS allocation
     int seg_len = 2048;    // PML: batches whose mean read length is >= 2 x seg_len are walked segment-parallel (0 = never) ...
-    int seg_probe = 1;     // ... if a probe of the batch finds that walks started mid-read fall into step quickly (0 = always: tests)
+    int seg_probe = 1;     // ... if a probe of the batch finds that walks started mid-read fall into step quickly (0 = always: tests;
+                           // 2 = no probe and no read-back at all, the caller's seg_verdict decides: the launch stays asynchronous)
+    int seg_verdict = 0;   // seg_probe == 2: 1 = cut eligible batches, 0 = one lane per read
     int refill_blocks = 0; // variant 13: size of the persistent grid in blocks; 0 = num_cus x waves per CU (tests shrink it
                            // so that a few hundred reads already go through many refills per lane)
+};
+
+// What a launch_* call actually launched (movi_last_launch): the policy lives in the launchers, so they say what they picked.
+struct LaunchInfo {
+    char kernel[96] = {0};   // the dominant kernel's name as rocprofv3 prints it (template arguments included)
+    int variant = -1;        // PML: 0, 1, 7, 10, 13, 14; ZML: 0, 1; count: 0
+    int block_threads = 0;
+    int waves_per_cu = 0;    // resident-wavefront cap applied (0 = none)
+    int segmented = 0;       // 1 = the segment-parallel plan ran (K1 + stitch + finalize around the named kernel)
+    int idx64 = 0;           // 1 = the 64-bit row-index instantiation
 };
 
 // Classifier::classify bins (src/classifier.cpp:99-143) fused into the PML kernels: per read the number of
@@ -132,16 +144,18 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
                       uint64_t n_reads, uint64_t n_bases, uint16_t *d_out, uint8_t *d_err, DevStats *d_stats,
                       const uint32_t *d_order, const LaunchCfg &cfg, hipStream_t stream,
                       const ClsArgs &cls = ClsArgs(), SegWorkspace *seg_ws = nullptr, int ragged_hint = -1,
-                      int *seg_verdict = nullptr);
+                      int *seg_verdict = nullptr, LaunchInfo *info = nullptr);
 
 hipError_t launch_count(int mode, const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets,
                         uint64_t n_reads, uint64_t *d_matched, uint64_t *d_count, uint8_t *d_err,
-                        DevStats *d_stats, const uint32_t *d_order, const LaunchCfg &cfg, hipStream_t stream);
+                        DevStats *d_stats, const uint32_t *d_order, const LaunchCfg &cfg, hipStream_t stream,
+                        LaunchInfo *info = nullptr);
 
 hipError_t launch_zml(int mode, const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets,
                       uint64_t n_reads, uint64_t n_bases, uint16_t *d_out, uint8_t *d_err, DevStats *d_stats,
                       const uint32_t *d_order, const LaunchCfg &cfg, hipStream_t stream,
-                      SegWorkspace *seg_ws = nullptr, int ragged_hint = -1, int *seg_verdict = nullptr);
+                      SegWorkspace *seg_ws = nullptr, int ragged_hint = -1, int *seg_verdict = nullptr,
+                      LaunchInfo *info = nullptr);
 
 // d_err (optional): reads flagged there report no bins (0, 0, 0), like the fused kernels.
 hipError_t launch_classify(const uint16_t *d_pml, const uint64_t *d_offsets, uint64_t n_reads, uint32_t bin_width,

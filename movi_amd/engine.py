@@ -13,7 +13,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import IndexDescC, QueryStatsC, check, lib
+from ._lib import IndexDescC, LaunchInfoC, QueryStatsC, check, lib
 
 
 class IndexDesc:
@@ -130,6 +130,27 @@ class MoveIndex:
         h = C.c_void_p()
         check(lib().movi_index_create_from_device_rows(device, C.byref(cdesc), C.c_void_p(d_rows_ptr), C.byref(h)))
         return cls(h, keepalive=keepalive)
+
+    @classmethod
+    def load_replicated(cls, index_dir_or_file, devices):
+        """movi_index_load_replicated: one handle per device; the rows cross PCIe once (to devices[0]) and reach the
+        other GPUs through one RCCL broadcast."""
+        n = len(devices)
+        devs = (C.c_int * n)(*[int(d) for d in devices])
+        hs = (C.c_void_p * n)()
+        check(lib().movi_index_load_replicated(str(index_dir_or_file).encode(), devs, n, hs))
+        return [cls(C.c_void_p(hs[i])) for i in range(n)]
+
+    @classmethod
+    def replicate_image(cls, image, devices):
+        """movi_index_replicate from an index.movi image in host memory."""
+        buf = np.frombuffer(image, np.uint8)
+        _, c, off, _ = parse_index_image(buf)
+        n = len(devices)
+        devs = (C.c_int * n)(*[int(d) for d in devices])
+        hs = (C.c_void_p * n)()
+        check(lib().movi_index_replicate(C.byref(c), buf.ctypes.data + off, devs, n, hs))
+        return [cls(C.c_void_p(hs[i])) for i in range(n)]
 
     def close(self):
         if getattr(self, "_h", None):
@@ -257,6 +278,13 @@ class MoveIndex:
                                       C.c_void_p(d_err) if d_err else None,
                                       C.c_void_p(d_order) if d_order else None,
                                       C.c_void_p(stream) if stream else None))
+
+    def last_launch(self):
+        """movi_last_launch: dict(kernel=..., variant=..., block_threads=..., waves_per_cu=..., segmented=..., idx64=...)."""
+        li = LaunchInfoC()
+        check(lib().movi_last_launch(self._h, C.byref(li)))
+        return {"kernel": li.kernel.decode(), "variant": int(li.variant), "block_threads": int(li.block_threads),
+                "waves_per_cu": int(li.waves_per_cu), "segmented": int(li.segmented), "idx64": int(li.idx64)}
 
     def last_stats(self, stream=0):
         st = QueryStatsC()

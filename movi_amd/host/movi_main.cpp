@@ -235,33 +235,18 @@ int run_query(const Options &o) {
         std::vector<movi_index_t *> &h;
         ~Closer() { for (auto *x : h) movi_index_destroy(x); }
     } closer{handles};
-    if (o.gpus == 1) {
+    if (!o.gpus_given) {
         check(movi_index_load(o.device, o.index_dir.c_str(), &handles[0]), "loading the index");
+    } else if (!share_gpu) {
+        // --gpus N: the index file is mapped once, its rows cross PCIe once (to the first GPU) and reach the others
+        // through ONE RCCL broadcast over xGMI; every GPU then builds its resident layout (include/movi_hip.h)
+        std::vector<int> devs((size_t)o.gpus);
+        for (int g = 0; g < o.gpus; g++) devs[(size_t)g] = dev_of(g);
+        check(movi_index_load_replicated(o.index_dir.c_str(), devs.data(), o.gpus, handles.data()), "replicating the index");
     } else {
-        // read and parse the file once, then upload the same host image to every GPU in parallel
-        std::vector<uint8_t> img;
-        for (const std::string &cand : {o.index_dir + "/index.movi", o.index_dir + "/movi_index.bin", o.index_dir}) {
-            std::ifstream f(cand, std::ios::binary | std::ios::ate);
-            if (!f.good() || f.tellg() <= 0) continue;
-            img.resize((size_t)f.tellg());
-            f.seekg(0);
-            f.read(reinterpret_cast<char *>(img.data()), (std::streamsize)img.size());
-            if (f.good()) break;
-            img.clear();
-        }
-        if (img.empty()) throw std::runtime_error("Failed to open the index file at: " + o.index_dir);
-        movi_index_desc_t d0;
-        size_t roff = 0, rbytes = 0;
-        check(movi_index_parse(img.data(), img.size(), &d0, &roff, &rbytes), "parsing the index");
-        std::vector<std::string> errs((size_t)o.gpus);
-        std::vector<std::thread> th;
-        for (int g = 0; g < o.gpus; g++)
-            th.emplace_back([&, g] {
-                if (movi_index_create(dev_of(g), &d0, img.data() + roff, &handles[g]) != MOVI_OK) errs[g] = movi_last_error();
-            });
-        for (auto &t : th) t.join();
-        for (const auto &e : errs)
-            if (!e.empty()) throw EngineError("uploading the index: " + e);
+        // MOVI_SHARE_GPU=1 (test hook for 1-GPU boxes: every logical GPU of --gpus N is the same device, which RCCL cannot
+        // serve as N ranks): N independent loads, so that the read sharding and the per-GPU host threads can be exercised
+        for (int g = 0; g < o.gpus; g++) check(movi_index_load(dev_of(g), o.index_dir.c_str(), &handles[(size_t)g]), "loading the index");
     }
     if (o.seg_len >= 0)
         for (auto *hd : handles) check(movi_set_option(hd, "seg_len", o.seg_len), "--seg-len");

@@ -149,7 +149,7 @@ Options parse_args(int argc, char **argv) {
         if (o.strands == 0) o.strands = 1;
         o.write_stdout = has("stdout");
         o.no_output = has("no-output");
-        if (has("gpus")) o.gpus = (int)to_int("gpus", val("gpus"));
+        if (has("gpus")) { o.gpus = (int)to_int("gpus", val("gpus")); o.gpus_given = true; }
         if (has("device")) o.device = (int)to_int("device", val("device"));
         if (has("seg-len")) o.seg_len = (long)to_int("seg-len", val("seg-len"));
         if (o.gpus < 1) throw UsageError("--gpus must be >= 1");

@@ -59,7 +59,9 @@ class Oracle:
     """CPU restatement of the reference query path on one index.movi image."""
 
     def __init__(self, index_bytes):
-        buf = np.frombuffer(bytes(index_bytes), np.uint8)
+        # (oracle_open copies what it keeps: a numpy image -- the bench's 8 GB table -- is passed as it is)
+        buf = (np.ascontiguousarray(index_bytes) if isinstance(index_bytes, np.ndarray) and index_bytes.dtype == np.uint8
+               else np.frombuffer(bytes(index_bytes), np.uint8))
         self._h = lib().oracle_open(buf.ctypes.data, buf.size)
         if not self._h:
             raise OracleError("not a v2 index.movi image of a supported type (modes 2, 3, 5, 6, 7, 8)")

@@ -29,7 +29,8 @@ def test_bench_single_gpu_contract():
     for k in REQUIRED:
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "weak"
-    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
+    assert d["roofline"]["bound"].startswith("fabric") and 0 < d["roofline"]["frac"] < 1      # a 1.6 MB table never reaches DRAM
+    assert d["roofline"]["kernel"].startswith("pml_kernel_flatp<6, unsigned int, -1") and d["rccl_ranks"] == 0
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and d["parity_sample_ok"] is True
 
 
@@ -45,3 +46,16 @@ def test_bench_two_ranks_share_one_gpu(query):
     assert d["n_gpus"] == 2 and d["value"] > 0
     assert d["config"]["bases_per_step_per_gpu"] == 20000 * 150
     assert "cpu_baseline" not in d                      # rank 0, N == 1 only
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` started by hand (no torchrun): the parent spawns the ranks itself and relays rank 0's line."""
+    env = dict(os.environ, MOVI_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "tiny", "--steps", "3",
+                        "--warmup", "1"], capture_output=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _line(r.stdout)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["bases_per_step_per_gpu"] == 20000 * 150
+    assert d["rccl_ranks"] == 0 and "index_broadcast_s" in d      # shared-GPU hook: gloo; under RCCL rccl_ranks == n_gpus
