@@ -246,6 +246,7 @@ def main():
     ap.add_argument("--zml-variant", type=int, default=-1, help="ZML kernel: 0 base-synchronous, 1 lane state machine (A/B)")
     ap.add_argument("--seg-len", type=int, default=-1, help="PML: segment length of the segment-parallel long-read path "
                     "(-1 = the engine's default of 2048, 0 = off)")
+    ap.add_argument("--kmer-k", type=int, default=-1, help="top-of-walk table: first K bases of every read by one lookup (A/B; -1 = the engine's default)")
     ap.add_argument("--block-threads", type=int, default=0)
     ap.add_argument("--waves-per-cu", type=int, default=-1)
     ap.add_argument("--ragged", type=int, default=0, help="1: log-normal read lengths (mean = read_len); "
@@ -262,8 +263,10 @@ def main():
     ap.add_argument("--no-big-table", action="store_true", help="skip the 1 B-row (8 GB, HBM-resident) leg that the default run "
                     "(c2, N=1) appends as `big_table` (BASELINE config 4's per-GPU shard, oracle-checked)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 5 s of back-to-back steps appended as `sustained`")
-    ap.add_argument("--extras-only", default="", help="debug: comma list of extras to run (big_table,sustained,long_reads,host_path,cli_path)")
+    ap.add_argument("--quick", action="store_true", help="the timed region only: no cpu_baseline, long_reads, host_path, sustained, big_table (A/B sweeps)")
     args = ap.parse_args()
+    if args.quick:
+        args.no_cpu_baseline = args.no_long_reads = args.no_big_table = args.no_sustained = True
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args.gpus))
 
@@ -372,6 +375,8 @@ def main():
         index.set_option("zml_variant", args.zml_variant)
     if args.seg_len >= 0:
         index.set_option("seg_len", args.seg_len)
+    if args.kmer_k >= 0:
+        index.set_option("kmer_k", args.kmer_k)
     if args.block_threads:
         index.set_option("block_threads", args.block_threads)
     if args.waves_per_cu >= 0:
@@ -480,6 +485,25 @@ def main():
     avg_kern_s = (sum(kern_ms) / len(kern_ms)) / 1e3
     achieved_gbs = bytes_per_base * work_bases / avg_kern_s / 1e9
     value = total_bases_per_step * args.steps / elapsed / 1e9       # Gbases/s, whole job
+    # ---- >= 5 s of the same step back to back (default run only, after the timed region, never part of `value`): the
+    # timed region above is K x 3 ms -- statistically fine (HIP events agree with rocprofv3 to 0.1 %) but too short for a
+    # 1 Hz utilisation sampler to see the GPU busy at all; this leg is the sustained figure
+    sustained = None
+    default_run = (rank == 0 and world == 1 and args.workload == "c2" and args.query == "pml" and not args.classify
+                   and args.variant < 0 and not args.from_dir)
+    if default_run and not args.no_sustained:
+        try:
+            n_sus = max(args.steps, int(5.5 / max(avg_kern_s, 1e-6)))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n_sus):
+                step()
+            torch.cuda.synchronize()
+            dts = time.perf_counter() - t0
+            sustained = {"steps": n_sus, "seconds": round(dts, 3), "value": n_bases * n_sus / dts / 1e9,
+                                   "unit": "Gbases/s", "ms_per_step": dts / n_sus * 1e3}
+        except Exception as e:                            # noqa: BLE001
+            sustained = {"error": repr(e)[:200]}
 
     traffic, traffic_src = lookup_traffic(args.workload, wl["rows"], wl["reads"], wl["read_len"], launch["kernel"]) \
         if args.query == "pml" and not args.classify else (None, None)
@@ -499,7 +523,7 @@ def main():
                    "iterations_per_base": round(st.lane_steps / max(n_bases, 1), 4) if st.wave_steps else None,
                    "algorithmic_bytes_per_base": round(bytes_per_base, 3),
                    "segments": int(st.segments), "rewalked_reads": int(st.rewalked), "seg_len": args.seg_len,
-                   "query": args.query, "fused_classify": args.classify, "matched_bases_per_step": work_bases, "pml_variant": args.variant, "ragged": args.ragged, "waves_per_cu": args.waves_per_cu, "block_threads": args.block_threads, "index_gen_s": round(t_index_gen, 2),
+                   "query": args.query, "fused_classify": args.classify, "matched_bases_per_step": work_bases, "pml_variant": args.variant, "kmer_k": args.kmer_k, "ragged": args.ragged, "waves_per_cu": args.waves_per_cu, "block_threads": args.block_threads, "index_gen_s": round(t_index_gen, 2),
                    "index_upload_s": round(t_index_upload, 2), "index_broadcast_s": round(t_bcast, 3),
                    "reads_gen_s": round(t_reads_gen, 2)},
         "rccl_ranks": rccl_ranks, "index_broadcast_s": round(t_bcast, 4),
@@ -512,6 +536,8 @@ def main():
                                        else (2.0 * (1.0 + f_bar) + s_bar) * work_bases) / avg_kern_s},
     }
 
+    if sustained is not None:
+        result["sustained"] = sustained
     oracle_sample = None
     # ---- CPU baseline: the oracle restatement (scalar port, 16 strands/thread + prefetch,
     # OpenMP over read groups) on a bounded sample of the same reads, rank 0, N == 1 only.
@@ -660,24 +686,8 @@ def main():
             result["host_path"] = hp
         except Exception as e:                            # noqa: BLE001 -- an extra, never worth the headline line
             result["host_path"] = {"error": repr(e)[:200]}
-    # ---- >= 5 s of the same step back to back (default run only, after the timed region, never part of `value`): the
-    # timed region above is K x 3 ms -- statistically fine (HIP events agree with rocprofv3 to 0.1 %) but too short for a
-    # 1 Hz utilisation sampler to see the GPU busy at all; this leg is the sustained figure
     default_run = (rank == 0 and world == 1 and args.workload == "c2" and args.query == "pml" and not args.classify
                    and args.variant < 0 and not args.from_dir)
-    if default_run and not args.no_sustained:
-        try:
-            n_sus = max(args.steps, int(5.5 / max(avg_kern_s, 1e-6)))
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(n_sus):
-                step()
-            torch.cuda.synchronize()
-            dts = time.perf_counter() - t0
-            result["sustained"] = {"steps": n_sus, "seconds": round(dts, 3), "value": n_bases * n_sus / dts / 1e9,
-                                   "unit": "Gbases/s", "ms_per_step": dts / n_sus * 1e3}
-        except Exception as e:                            # noqa: BLE001
-            result["sustained"] = {"error": repr(e)[:200]}
     # ---- BASELINE config 4's per-GPU shard (default run only, after the timed region, never part of `value`): the walk on
     # a 1 B-row / 8 GB table -- HBM-resident, 30-bit row ids, byte offsets beyond 2^32 -- with its own roofline, and three
     # slices of the batch (first / middle / last 2000 reads) compared with the oracle bit for bit, counters included

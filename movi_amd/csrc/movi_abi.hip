@@ -93,6 +93,7 @@ struct movi_index {
     uint8_t *d_code_of = nullptr;
     uint32_t *d_id_blocks = nullptr;
     uint64_t *d_ckpt = nullptr;      // built lazily by the first count query
+    uint4 *d_kmer = nullptr;         // top-of-walk table ("kmer_k" option), 16 << 2K bytes
     DevStats *d_stats = nullptr;
     DevIndex dev{};
     int kmode = 0;                   // row layout the kernels run on: desc.mode, except 6 for sampled-thresholds (expanded)
@@ -706,6 +707,7 @@ int movi_index_destroy(movi_index_t *ix) {
     if (ix->d_sep_vals) (void)hipFree(ix->d_sep_vals);
     if (ix->d_tally) (void)hipFree(ix->d_tally);
     if (ix->d_ckpt) (void)hipFree(ix->d_ckpt);
+    if (ix->d_kmer) (void)hipFree(ix->d_kmer);
     if (ix->d_stats) (void)hipFree(ix->d_stats);
     release_scratch(ix);
     delete ix;
@@ -784,6 +786,26 @@ int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
     if (!strcmp(key, "seg_verdict")) {
         if (value != 0 && value != 1) return fail(MOVI_ERR_ARG, "seg_verdict must be 0 or 1");
         ix->cfg.seg_verdict = (int)value;
+        return MOVI_OK;
+    }
+    if (!strcmp(key, "kmer_k")) {                            // top-of-walk table: 0 = none, else K in [1, 12]
+        if (value < 0 || value > 12) return fail(MOVI_ERR_ARG, "kmer_k must be in [0, 12]");
+        HIP_TRY(hipSetDevice(ix->device));
+        HIP_TRY(hipDeviceSynchronize());                     // no walk may be reading the table that goes away
+        ix->dev.kmer_k = 0;
+        ix->dev.kmer = nullptr;
+        if (ix->d_kmer) (void)hipFree(ix->d_kmer);
+        ix->d_kmer = nullptr;
+        if (value == 0) return MOVI_OK;
+        if (ix->kmode != MOVI_MODE_REGULAR_THRESHOLDS || ix->dev.sigma - ix->dev.sep != 4 || ix->desc.r < 8)
+            return fail(MOVI_ERR_ARG, "the top-of-walk table serves PML walks on DNA (ACGT) *-thresholds indexes only");
+        const size_t bytes = (size_t)16 << (2 * value);
+        HIP_TRY(hipMalloc(&ix->d_kmer, bytes));
+        hipError_t e = build_kmer_table(ix->dev, (uint32_t)value, ix->d_kmer, nullptr);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e != hipSuccess) { (void)hipFree(ix->d_kmer); ix->d_kmer = nullptr; return fail_hip(e, "building the top-of-walk table"); }
+        ix->dev.kmer = ix->d_kmer;
+        ix->dev.kmer_k = (uint32_t)value;
         return MOVI_OK;
     }
     if (!strcmp(key, "waves_per_cu")) {

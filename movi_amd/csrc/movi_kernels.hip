@@ -848,6 +848,53 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
     uint32_t a = s_code[(uint32_t)(rb >> 56) & 0xFFu];    // code of the base of step k (k = 0)
     uint4 pk = make_uint4(0, 0, 0, 0), pk_old = pk;
     if (CLS) cs.init(len, cls.bin_width);
+    // ---- top of the walk (DevIndex::kmer): the first K bases of the read (segment) by ONE table lookup.  Reads with an
+    // illegal base among them, reads of K bases or fewer and K-mers whose walk throws take the ordinary walk.
+    if (!REFILL && ix.kmer_k != 0u) {                     // wave-uniform
+        const uint32_t K = ix.kmer_k;
+        uint32_t kidx = 0, bad = 0;
+        for (uint32_t i = 0; i < K; ++i) {
+            const uint64_t src = i < 8u ? rb : rb2;
+            const uint32_t cc = (uint32_t)s_code[(uint32_t)(src >> (8u * (7u - (i & 7u)))) & 0xFFu] - (uint32_t)SEP;
+            bad |= (uint32_t)(cc > 3u);
+            kidx |= (cc & 3u) << (2u * i);
+        }
+        uint32_t use = (uint32_t)(st != sDone) & (uint32_t)(len > K) & (bad ^ 1u);
+        uint4 e4 = make_uint4(0, 0, 0, 0);
+        if (use) e4 = ix.kmer[kidx];
+        use &= e4.y >> 31;
+        if (use) {
+            const uint32_t mask = (e4.y >> 16) & 0xFFFu;
+            uint16_t *O = out + obeg;
+            uint32_t run = 0;
+            for (uint32_t i = 0; i < K; ++i) {            // the K PMLs, through the same packing as the loop's emissions
+                run = ((mask >> i) & 1u) ? run + 1u : 0u;
+                if (CLS) cs.add(run, k, len, cls.bin_width, cls.thr);
+                if (CLS == 2) {
+                } else if (k >= packed_end) {
+                    O[k] = (uint16_t)run;
+                } else {
+                    pk.x = (pk.x >> 16) | (pk.y << 16);
+                    pk.y = (pk.y >> 16) | (pk.z << 16);
+                    pk.z = (pk.z >> 16) | (pk.w << 16);
+                    pk.w = (pk.w >> 16) | (run << 16);
+                    if ((k & 15) == 7) {
+                        if (k + 8 < packed_end) pk_old = pk;
+                        else __builtin_memcpy(O + (k - 7), &pk, 16);
+                    }
+                }
+                k += 1;
+            }
+            ml = run;
+            need = (IdxT)((uint64_t)e4.x | ((uint64_t)(e4.y & 15u) << 32));
+            off = (e4.y >> 4) & 0xFFFu;
+            ff_total = e4.z;
+            scan_total = e4.w;
+            repo_total = K - (uint32_t)__popc(mask);
+            if (K >= 8u) rb = rb2;
+            a = s_code[(uint32_t)(rb >> (8u * (7u - (K & 7u)))) & 0xFFu];
+        }
+    }
     uint2 w[4];
     fetch(need, st != sDone, w);
 
@@ -1169,6 +1216,46 @@ __device__ __forceinline__ uint32_t walk_base(const DevIndex &ix, const EndThr &
     if (failed == 0u && dir == 1u) off = 0;
     if (failed == 0u && dir == 2u) off = row_n<MODE>(row) - 1;
     return failed;
+}
+
+// Top-of-walk table (DevIndex::kmer): lane t walks the K-mer whose step-i base has code (t >> 2 i) & 3 (+ 1 on a
+// separators index) from the state every read starts in -- exactly pml_kernel<MODE, 0>'s automaton -- and records where
+// it stands after the LF towards base K.
+template <int MODE>
+__global__ __launch_bounds__(256) void kmer_table_kernel(DevIndex ix, uint32_t K, uint4 *__restrict__ table) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, n = 1ull << (2 * K);
+    const bool valid = t < n;
+    const EndThr ethr = end_thresholds(ix);
+    const uint64_t r1 = ix.r - 1;
+    uint2 row = load_row<MODE>(ix.rows, r1);
+    uint64_t idx = r1;
+    uint32_t off = row_n<MODE>(row) - 1, ml = 0, ff = 0, scan = 0, repo = 0, failed = 0, mask = 0;
+    for (uint32_t i = 0; i < K; ++i) {                    // K is wave-uniform
+        const bool live = valid && failed == 0u;
+        const uint32_t a = (uint32_t)((t >> (2 * i)) & 3u) + ix.sep;
+        const uint32_t before = ml;
+        const uint32_t e = walk_base<MODE>(ix, ethr, live, i != 0, a, idx, off, row, ml, ff, scan, repo);
+        if (e) failed = e;
+        mask |= (uint32_t)(live && e == 0u && ml == before + 1u) << i;
+    }
+    if (!valid) return;
+    const uint64_t j = row_id<MODE>(row, idx, ix);        // LF_move of base K - 1: destination and offset, no fast-forward yet
+    const uint32_t off2 = off + row_off<MODE>(row);
+    const uint32_t ok = (uint32_t)(failed == 0u && j < ix.r && off2 < 4096u);
+    uint4 e4;
+    e4.x = (uint32_t)j;
+    e4.y = (uint32_t)(j >> 32) | (off2 << 4) | (mask << 16) | (ok << 31);
+    e4.z = ff;
+    e4.w = scan;
+    if (!ok) e4 = make_uint4(0, 0, 0, 0);
+    table[t] = e4;
+}
+
+hipError_t build_kmer_table(const DevIndex &ix, uint32_t K, uint4 *d_table, hipStream_t stream) {
+    if (K < 1 || K > 12 || !d_table || ix.sigma - ix.sep != 4) return hipErrorInvalidValue;
+    const uint64_t n = 1ull << (2 * K);
+    hipLaunchKernelGGL(kmer_table_kernel<6>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, ix, K, d_table);
+    return hipGetLastError();
 }
 
 // The probe of the segmented path: does a walk started in the middle of a read fall into step quickly ON THIS BATCH?

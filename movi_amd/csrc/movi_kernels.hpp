@@ -37,7 +37,15 @@ struct DevIndex {
     // 1: row indexes fit 32 bits (r < 2^32 - 1) -> the kernels' uint32_t instantiations; the "idx64" option clears it so
     // that tests can run the 64-bit instantiations (tables beyond 4 G rows) on small indexes
     uint32_t idx32;
-    uint32_t pad_;
+    // Top-of-walk table ("kmer_k" option; 0 = none): every walk starts in the same state (row r-1), so its state after
+    // the last K bases of the read depends on those K bases alone.  kmer[code of the K-mer] = that state (after the LF
+    // towards base K, before its fast-forward), which of the K bases matched (their PMLs follow from that) and the
+    // fast-forwards / scan rows the K steps took: one 16-byte lookup instead of K dependent row gathers.  The reference's
+    // analogue is the ftab of its k-mer queries (src/move_structure_search.cpp:66-167, 203-259), there for intervals.
+    uint32_t kmer_k;
+    const uint4 *kmer;            // 4^K entries: x = row[31:0]; y = row[35:32] | off << 4 (12 bits) | match mask << 16 (K bits) |
+                                  // valid << 31; z = fast-forwards; w = scan rows.  valid = 0: one of the K steps hit one of the
+                                  // reference's throws -- such reads take the ordinary walk and report it
 };
 
 // Device counters of one query call.
@@ -170,6 +178,10 @@ hipError_t expand_blocked_rows(int mode, const DevIndex &ix, void *d_rows6, hipS
 
 // Mode 7: 3-byte file rows -> one dword per row (d_wide: r * 4 bytes + 16 of slack).
 hipError_t widen_rows(const uint8_t *d_packed, uint64_t r, uint32_t *d_wide, hipStream_t stream);
+
+// Fills the 4^K entries of the top-of-walk table (DevIndex::kmer) by walking every K-mer from the start state with the
+// plain base-synchronous automaton.  ix.kmer / ix.kmer_k of `ix` are ignored; K in [1, 12]; thresholds types (kmode 6) only.
+hipError_t build_kmer_table(const DevIndex &ix, uint32_t K, uint4 *d_table, hipStream_t stream);
 
 // Fills ckpt[j] = BWT position of row (j << kPrefixShift), j = 0 .. ceil(r/32).
 hipError_t build_row_start_ckpt(int mode, const uint8_t *d_rows, uint64_t r, uint64_t *d_ckpt,

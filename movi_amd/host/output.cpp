@@ -1,5 +1,8 @@
 #include "output.hpp"
 
+#include <cerrno>
+#include <cstdio>
+
 #include <algorithm>
 #include <cstring>
 #include <iomanip>
@@ -15,7 +18,9 @@
 namespace movi_host {
 
 BpfWriter::~BpfWriter() {
-    if (fd_ >= 0) ::close(fd_);
+    // reached with the descriptor still open only when an exception is unwinding past the writer (close() is the normal
+    // way out and throws on error); a close() error here cannot be thrown, so it is at least said
+    if (fd_ >= 0 && ::close(fd_) != 0) std::fprintf(stderr, "[movi] Failed to write the output file: %s\n", path_.c_str());
 }
 
 void BpfWriter::open(const std::string &path, uint8_t entry_size) {
@@ -29,8 +34,9 @@ void BpfWriter::open(const std::string &path, uint8_t entry_size) {
     std::memcpy(h, &kBpfMagic, 4);
     h[4] = 1; h[5] = 0; h[6] = 0;
     h[7] = entry_size;
-    if (::write(fd_, h, 12) != 12) throw std::runtime_error("Failed to write the output file: " + path);
-    pos_ = 12;
+    ssize_t w;
+    do { w = ::write(fd_, h, 12); } while (w < 0 && errno == EINTR);
+    if (w != 12) throw std::runtime_error("Failed to write the output file: " + path);
 }
 
 void BpfWriter::close() {
@@ -52,6 +58,7 @@ void BpfWriter::append(const std::vector<Record> &records) {
         const uint8_t *q = static_cast<const uint8_t *>(p);
         while (len) {
             const ssize_t w = ::write(fd_, q, len);
+            if (w < 0 && errno == EINTR) continue;                       // a signal, not an error: the ofstream this replaced retried too
             if (w < 0) throw std::runtime_error("Failed to write the output file: " + path_);
             q += w;
             len -= (size_t)w;
@@ -71,7 +78,6 @@ void BpfWriter::append(const std::vector<Record> &records) {
         const size_t bytes = r.n * 2;
         if (bytes >= (1u << 20)) { flush(); write_all(r.pml, bytes); }
         else if (bytes) put(r.pml, bytes);
-        pos_ += 10u + idl + bytes;
     }
     flush();
 }

@@ -37,7 +37,6 @@ public:
 
 private:
     int fd_ = -1;
-    uint64_t pos_ = 0;
     std::string path_;
     std::vector<uint8_t> buf_;
 };

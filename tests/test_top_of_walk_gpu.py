@@ -1,0 +1,137 @@
+"""GPU suite (-m gpu): the top-of-walk table ("kmer_k" option) -- the first K bases of every read (segment) served by one
+table lookup instead of K row gathers (the analogue of the reference's ftab, src/move_structure_search.cpp:66-167).
+Answers, error bytes and the fast-forward / scan / reposition counters must be those of the oracle for every K, on every
+index type, for reads shorter than, as long as and longer than K, with illegal bases inside and outside the K-mer, with
+fused classification bins and on the segment-parallel path."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from test_gpu_parity import mutated_reads, pack
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref():
+    from oracle import build_index as B
+    return B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))[0][1]
+
+
+def _edge_reads(ref, rng, K):
+    reads = mutated_reads(rng, ref, 300, 1, 400)
+    base = bytes(ref[5000:5400])
+    for L in (0, 1, K - 1, K, K + 1, K + 2, 15, 16, 17, 31, 32, 33):
+        if L >= 0:
+            reads.append(base[:L])
+    for pos in (1, K - 1, K, K + 1, 7, 8, 9):                    # an N / a lowercase base at distance `pos` from the read's end
+        for bad in (b"N", b"a"):
+            r = bytearray(base[:60])
+            if 0 < pos <= len(r):
+                r[len(r) - pos: len(r) - pos + 1] = bad
+            reads.append(bytes(r))
+    reads += [b"ACGT" * 30, b"T" * 50, b"GGGGGGGGGGGGGGGGGGGGGGGGC"]
+    return reads
+
+
+@pytest.mark.parametrize("mode", [6, 8, 7])
+@pytest.mark.parametrize("K", [1, 3, 8, 11, 12])
+def test_top_of_walk_vs_oracle(built_lib, golden_image, mode, K):
+    import movi_amd
+    from oracle import build_index as B
+    from oracle.oracle import Oracle
+    ref = _ref()
+    img = golden_image(mode) if mode != 7 else B.build_index_from_seqs([ref], 7)
+    gpu, cpu = movi_amd.MoveIndex.from_image(img), Oracle(img)
+    reads = _edge_reads(ref, np.random.default_rng(8800 + K), K)
+    bases, offs = pack(reads)
+    exp, ff, sc = cpu.pml_batch(bases, offs, threads=4)
+    base_out, base_st = gpu.query_pml_packed(bases, offs)
+    assert (base_out == exp).all()
+    gpu.set_option("kmer_k", K)
+    for variant in (-1, 10):                                      # window-parallel (default) and the two-hop pipeline
+        gpu.set_option("pml_variant", variant)
+        out, st = gpu.query_pml_packed(bases, offs)
+        assert (out == exp).all(), (mode, K, variant)
+        assert (st.fast_forwards, st.scans, st.repositions, st.errors) == (ff, sc, base_st.repositions, 0), (mode, K, variant)
+    gpu.set_option("pml_variant", -1)
+    # fewer iterations than without the table (the point of it)
+    assert st.lane_steps < base_st.lane_steps
+    # fused bins, with and without the PML vector
+    exp_bins = None
+    gpu.set_option("kmer_k", 0)
+    exp_bins = gpu.classify_packed(bases, offs, 40, 4)
+    gpu.set_option("kmer_k", K)
+    got = gpu.classify_packed(bases, offs, 40, 4)
+    assert all((x == y).all() for x, y in zip(got, exp_bins))
+    # segment-parallel: every segment starts from the state every read starts in, so the table serves segments too
+    long_reads = mutated_reads(np.random.default_rng(8900 + K), ref, 40, 700, 3000)
+    lb, lo = pack(long_reads)
+    lexp, lff, lsc = cpu.pml_batch(lb, lo, threads=4)
+    gpu.set_option("seg_len", 64)
+    gpu.set_option("seg_probe", 0)
+    lout, lst = gpu.query_pml_packed(lb, lo)
+    assert lst.segments > len(long_reads)
+    assert (lout == lexp).all() and (lst.fast_forwards, lst.scans, lst.errors) == (lff, lsc, 0)
+    # the table goes away again
+    gpu.set_option("kmer_k", 0)
+    gpu.set_option("seg_len", 2048)
+    gpu.set_option("seg_probe", 1)
+    out, st = gpu.query_pml_packed(bases, offs)
+    assert (out == exp).all() and st.lane_steps == base_st.lane_steps
+    gpu.close()
+
+
+def test_top_of_walk_on_a_separators_index(built_lib):
+    """`movi build --separators`: codes 1..4, code 0 = '%' (illegal in a read); the table is indexed by code - 1."""
+    import movi_amd
+    from oracle import build_index as B
+    from oracle.oracle import Oracle
+    ref = _ref()
+    seqs = [ref[:40000], ref[40000:90000], ref[90000:]]
+    img = B.build_index_from_seqs(seqs, 6, separators=True)
+    gpu, cpu = movi_amd.MoveIndex.from_image(img), Oracle(img)
+    reads = _edge_reads(ref, np.random.default_rng(8700), 9) + [bytes(ref[39950:40050]), b"ACG%TACGTACGTACGT", b"ACGTACGTACGTAC%T"]
+    bases, offs = pack(reads)
+    exp, ff, sc = cpu.pml_batch(bases, offs, threads=4)
+    gpu.set_option("kmer_k", 9)
+    out, st = gpu.query_pml_packed(bases, offs)
+    assert (out == exp).all() and (st.fast_forwards, st.scans, st.errors) == (ff, sc, 0)
+    gpu.close()
+
+
+def test_top_of_walk_refuses_what_it_cannot_serve(built_lib):
+    import movi_amd
+    from oracle import build_index as B
+    img = B.build_index_from_seqs([b"ACGGCAGCAGGACGACGGCAGCAGCGACGAGCGAGCGACGGCAGAC" * 20], 6)    # no T: 3-symbol alphabet
+    gpu = movi_amd.MoveIndex.from_image(img)
+    with pytest.raises(movi_amd.MoviError):
+        gpu.set_option("kmer_k", 8)
+    with pytest.raises(movi_amd.MoviError):
+        gpu.set_option("kmer_k", 13)
+    out, _ = gpu.query_pml_packed(*pack([b"ACGGCAGCAG"]))
+    assert out.size == 10
+    gpu.close()
+
+
+def test_top_of_walk_with_corrupt_rows(built_lib, golden_image):
+    """K-mers whose walk runs into one of the reference's throws have no entry: those reads take the ordinary walk and
+    report the error exactly as without the table."""
+    import movi_amd
+    img = bytearray(golden_image(6))
+    _, _, off, _ = movi_amd.parse_index_image(bytes(img))
+    rows = np.frombuffer(img, np.uint8, count=118209 * 8, offset=off).reshape(-1, 8).copy()
+    rng = np.random.default_rng(8600)
+    hit = rng.choice(118209, 30000, replace=False)
+    rows[hit, 0:4] = 0xFF                                  # a quarter of the rows point past the table
+    img[off: off + rows.size] = rows.tobytes()
+    gpu = movi_amd.MoveIndex.from_image(bytes(img))
+    reads = mutated_reads(rng, _ref(), 400, 5, 300)
+    bases, offs = pack(reads)
+    e_out, e_st, e_err, e_rc = gpu.query_pml_packed(bases, offs, want_err=True)
+    assert e_rc == -6 and e_st.errors > 50
+    gpu.set_option("kmer_k", 6)
+    out, st, err, rc = gpu.query_pml_packed(bases, offs, want_err=True)
+    assert rc == -6 and (out == e_out).all() and (err == e_err).all() and st.errors == e_st.errors
+    gpu.close()

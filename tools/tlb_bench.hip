@@ -28,7 +28,9 @@ __device__ __forceinline__ uint32_t next_idx(uint64_t v, uint32_t n_rows) {
     return __umulhi((uint32_t)(v ^ (v >> 32)), n_rows);
 }
 
-// VAR 0: 8 B row; 1: aligned 16 B pair; 2: aligned 32 B quad (2 x 16 B); 3: 8 B row + dependent neighbour row
+// VAR 0: 8 B row; 1: aligned 16 B pair; 2: aligned 32 B quad (2 x 16 B); 3: 8 B row + dependent neighbour row;
+// 4: the pair as two 8-byte loads; 5: the quad as four 8-byte loads (round 3: how many address translations a wide
+// divergent load costs against the same bytes fetched by 8-byte loads)
 template <int VAR>
 __global__ __launch_bounds__(256) void chase(const uint64_t *__restrict__ table, uint32_t n_rows, int steps,
                                              uint64_t n_lanes, uint64_t *__restrict__ sink) {
@@ -45,6 +47,24 @@ __global__ __launch_bounds__(256) void chase(const uint64_t *__restrict__ table,
             const uint4 q = *reinterpret_cast<const uint4 *>(table + (idx & ~1u));
             v = (idx & 1) ? ((uint64_t)q.w << 32 | q.z) : ((uint64_t)q.y << 32 | q.x);
             acc += q.x ^ q.z;
+        } else if (VAR == 4) {
+            // the aligned pair as TWO independent 8-byte loads of one line (explicit: the compiler would merge them)
+            const uint64_t *p = table + (idx & ~1u);
+            uint64_t a0, a1;
+            asm volatile("global_load_dwordx2 %0, %2, off\n\tglobal_load_dwordx2 %1, %2, off offset:8\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(a0), "=&v"(a1) : "v"(p) : "memory");
+            v = (idx & 1) ? a1 : a0;
+            acc += (uint32_t)a0 ^ (uint32_t)a1;
+        } else if (VAR == 5) {
+            // the aligned quad as FOUR independent 8-byte loads
+            const uint64_t *p = table + (idx & ~3u);
+            uint64_t a0, a1, a2, a3;
+            asm volatile("global_load_dwordx2 %0, %4, off\n\tglobal_load_dwordx2 %1, %4, off offset:8\n\t"
+                         "global_load_dwordx2 %2, %4, off offset:16\n\tglobal_load_dwordx2 %3, %4, off offset:24\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3) : "v"(p) : "memory");
+            const uint64_t lo = (idx & 1) ? a1 : a0, hi = (idx & 1) ? a3 : a2;
+            v = (idx & 2) ? hi : lo;
+            acc += (uint32_t)a0 ^ (uint32_t)a2;
         } else {
             const uint4 *p = reinterpret_cast<const uint4 *>(table + (idx & ~3u));
             const uint4 q0 = p[0], q1 = p[1];
@@ -82,7 +102,8 @@ int main(int argc, char **argv) {
     uint64_t *sink;
     CHECK(hipMalloc(&sink, 64));
     const char *alloc_names[3] = {"hipMalloc", "hipExtMallocWithFlags(hipDeviceMallocContiguous)", "hipMemCreate+hipMemMap (one handle)"};
-    const char *names[4] = {"8B row", "16B pair", "32B quad", "8B row + dependent neighbour"};
+    const char *names[6] = {"8B row", "16B pair", "32B quad", "8B row + dependent neighbour", "pair as 2 x 8B loads", "quad as 4 x 8B loads"};
+    const char *only_var = getenv("TLB_VAR");               // e.g. TLB_VAR=4: that variant only (PMC passes)
     for (int si = 0; si < ns; si++) {
         const uint64_t n = 1ull << sizes[si];
         const char *only = getenv("TLB_ALLOC");             // e.g. TLB_ALLOC=0: hipMalloc only (profiling runs)
@@ -122,14 +143,18 @@ int main(int argc, char **argv) {
             CHECK(hipDeviceSynchronize());
             const uint32_t n_rows = (uint32_t)(n - 8);
             for (uint64_t lanes : {(uint64_t)1 << 19, (uint64_t)1 << 20}) {
-                double ms[4];
-                ms[0] = run<0>(table, n_rows, steps, lanes, sink, 4);
-                ms[1] = run<1>(table, n_rows, steps, lanes, sink, 4);
-                ms[2] = run<2>(table, n_rows, steps, lanes, sink, 4);
-                ms[3] = run<3>(table, n_rows, steps, lanes, sink, 4);
-                for (int v = 0; v < 4; v++)
-                    printf("  lanes=%8llu  %-30s %8.3f ms  %7.2f Gsteps/s\n", (unsigned long long)lanes, names[v], ms[v],
-                           lanes * (double)steps / ms[v] / 1e6);
+                double ms[6] = {0, 0, 0, 0, 0, 0};
+                auto want = [&](int v) { return !only_var || atoi(only_var) == v; };
+                if (want(0)) ms[0] = run<0>(table, n_rows, steps, lanes, sink, 4);
+                if (want(1)) ms[1] = run<1>(table, n_rows, steps, lanes, sink, 4);
+                if (want(2)) ms[2] = run<2>(table, n_rows, steps, lanes, sink, 4);
+                if (want(3)) ms[3] = run<3>(table, n_rows, steps, lanes, sink, 4);
+                if (want(4)) ms[4] = run<4>(table, n_rows, steps, lanes, sink, 4);
+                if (want(5)) ms[5] = run<5>(table, n_rows, steps, lanes, sink, 4);
+                for (int v = 0; v < 6; v++)
+                    if (want(v))
+                        printf("  lanes=%8llu  %-30s %8.3f ms  %7.2f Gsteps/s\n", (unsigned long long)lanes, names[v], ms[v],
+                               lanes * (double)steps / ms[v] / 1e6);
             }
             if (which == 2) {
                 (void)hipMemUnmap(table, vm_bytes);
