@@ -187,6 +187,62 @@ def big_table_leg(torch, dev, stream, synth, movi_amd, cores, rows=1_000_000_000
     return out
 
 
+def write_fasta(path, reads2d):
+    """reads2d: uint8 [n, L] -> FASTA with fixed-width ids (>r0000000), written in one piece."""
+    n, L = reads2d.shape
+    rec = np.empty((n, 10 + L + 1), np.uint8)
+    rec[:, 0] = ord(">")
+    rec[:, 1] = ord("r")
+    idx = np.arange(n)
+    for k in range(7):
+        rec[:, 8 - k] = ord("0") + (idx // 10 ** k) % 10
+    rec[:, 9] = ord("\n")
+    rec[:, 10: 10 + L] = reads2d
+    rec[:, 10 + L] = ord("\n")
+    rec.tofile(path)
+
+
+def cli_path_leg(idx_dir, reads_150, reads_10k):
+    """The drop-in a user touches: the `movi query` binary end to end on FASTA files of the same reads (page cache warm),
+    --no-output and with the BPF file; rates exclude process start and index load (the command's own "processing the
+    reads" clock, src/movi.cpp:387-389 prints the same), `wall_s` includes them."""
+    import re
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "movi_amd", "bin", "movi")
+    out = {"unit": "Gbases/s", "note": "movi query on FASTA input, best of 2 runs; value = bases / the command's own read-processing time "
+                                       "(parse + GPU calls + order + write, pipelined); wall_s adds process start, HIP init and index load"}
+    tmp = tempfile.mkdtemp(prefix="movi_cli_")
+    try:
+        for name, (arr, L) in (("short_1Mx150", reads_150), ("long_100kx10k", reads_10k)):
+            if arr is None:
+                continue
+            fa = os.path.join(tmp, name + ".fa")
+            write_fasta(fa, arr.reshape(-1, L))
+            for mode, flags in (("no_output", ["--no-output"]), ("bpf", ["-o", os.path.join(tmp, name)])):
+                best, wall = None, None
+                for _ in range(2):
+                    t0 = time.perf_counter()
+                    r = subprocess.run([exe, "query", "-i", idx_dir, "-r", fa, "--verbose"] + flags, capture_output=True, timeout=600)
+                    w = time.perf_counter() - t0
+                    if r.returncode != 0:
+                        raise RuntimeError(r.stderr.decode()[-300:])
+                    m = re.search(r"processing the reads: ([0-9.e+-]+) s \((\d+) bases; GPU calls ([0-9.e+-]+) s", r.stderr.decode())
+                    sec, nb = float(m.group(1)), int(m.group(2))
+                    if best is None or sec < best[0]:
+                        st = re.search(r"Stage times: parse ([0-9.e+-]+) s, GPU calls ([0-9.e+-]+) s, order \+ write ([0-9.e+-]+) s", r.stderr.decode())
+                        best = (sec, nb, float(m.group(3)), st.groups() if st else None)
+                        wall = w
+                out[name + "_" + mode] = {"value": round(best[1] / best[0] / 1e9, 3), "seconds": round(best[0], 4), "gpu_calls_s": round(best[2], 4),
+                                          "stage_s": {"parse": float(best[3][0]), "gpu": float(best[3][1]), "write": float(best[3][2])} if best[3] else None,
+                                          "wall_s": round(wall, 3)}
+            os.remove(fa)
+    finally:
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
 def usable_cores():
     """Host threads this process can really run: the CPU affinity mask capped by the cgroup CPU quota (the GPU boxes
     show 256 logical CPUs but grant 16 CPUs of quota: 256 OpenMP threads then run at 0.15-0.2 Gbases/s, 16 at 0.39;
@@ -247,6 +303,7 @@ def main():
     ap.add_argument("--seg-len", type=int, default=-1, help="PML: segment length of the segment-parallel long-read path "
                     "(-1 = the engine's default of 2048, 0 = off)")
     ap.add_argument("--kmer-k", type=int, default=-1, help="top-of-walk table: first K bases of every read by one lookup (A/B; -1 = the engine's default)")
+    ap.add_argument("--stage-reads", type=int, default=-1, help="reads staged through LDS for short-read wavefronts (A/B: 0 off, 1 on; -1 = default)")
     ap.add_argument("--block-threads", type=int, default=0)
     ap.add_argument("--waves-per-cu", type=int, default=-1)
     ap.add_argument("--ragged", type=int, default=0, help="1: log-normal read lengths (mean = read_len); "
@@ -377,6 +434,8 @@ def main():
         index.set_option("seg_len", args.seg_len)
     if args.kmer_k >= 0:
         index.set_option("kmer_k", args.kmer_k)
+    if args.stage_reads >= 0:
+        index.set_option("stage_reads", args.stage_reads)
     if args.block_threads:
         index.set_option("block_threads", args.block_threads)
     if args.waves_per_cu >= 0:
@@ -688,6 +747,15 @@ def main():
             result["host_path"] = {"error": repr(e)[:200]}
     default_run = (rank == 0 and world == 1 and args.workload == "c2" and args.query == "pml" and not args.classify
                    and args.variant < 0 and not args.from_dir)
+    # ---- the command-line drop-in end to end (default run only, after the timed region, never part of `value`)
+    if default_run and not args.no_cpu_baseline and reads_path:
+        try:
+            w3 = WORKLOADS["c3"]
+            rf = os.path.join(idx_dir, "reads_%dx%d_%g.bin" % (w3["reads"], w3["read_len"], w3["sub"]))
+            r10k = (np.fromfile(rf, np.uint8, count=w3["reads"] * w3["read_len"]), w3["read_len"]) if os.path.exists(rf) else (None, 0)
+            result["cli_path"] = cli_path_leg(idx_dir, (bases, wl["read_len"]), r10k)
+        except Exception as e:                            # noqa: BLE001
+            result["cli_path"] = {"error": repr(e)[:300]}
     # ---- BASELINE config 4's per-GPU shard (default run only, after the timed region, never part of `value`): the walk on
     # a 1 B-row / 8 GB table -- HBM-resident, 30-bit row ids, byte offsets beyond 2^32 -- with its own roofline, and three
     # slices of the batch (first / middle / last 2000 reads) compared with the oracle bit for bit, counters included

@@ -193,7 +193,8 @@ int movi_pml_device(movi_index_t *ix, const uint8_t *d_bases, const uint64_t *d_
  * movi_host_register below) the call is overlapped: the reads are cut into chunks that travel through six
  * slots with their own streams -- up to three chunks going up or being walked while one comes down -- so that
  * upload, walks and download run at the same time (results are identical; DESIGN.md has the rates).  Pageable
- * buffers take the synchronous path. */
+ * buffers take the synchronous path.  h_out_pml == NULL: the walk runs and its error bytes and counters come back,
+ * but no vector crosses PCIe (`movi query --no-output`: the reference computes and discards, src/movi.cpp:268-389). */
 int movi_pml_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_offsets,
                   uint64_t n_reads, uint16_t *h_out_pml, uint8_t *h_read_err,
                   movi_query_stats_t *stats);
@@ -212,7 +213,8 @@ typedef struct movi_launch_info {
     int32_t waves_per_cu;             /* cap on resident wavefronts per CU that was applied (0 = none)             */
     int32_t segmented;                /* 1 = the segment-parallel plan ran around that kernel                       */
     int32_t idx64;                    /* 1 = the 64-bit row-index instantiation                                     */
-    int32_t reserved_[3];
+    int32_t staged;                   /* 1 = short-read wavefronts copy their reads into LDS once ("stage_reads")    */
+    int32_t reserved_[2];
 } movi_launch_info_t;
 int movi_last_launch(const movi_index_t *ix, movi_launch_info_t *info);
 

@@ -61,7 +61,8 @@ class LaunchInfoC(C.Structure):
         ("waves_per_cu", C.c_int32),
         ("segmented", C.c_int32),
         ("idx64", C.c_int32),
-        ("reserved_", C.c_int32 * 3),
+        ("staged", C.c_int32),
+        ("reserved_", C.c_int32 * 2),
     ]
 
 

@@ -788,6 +788,11 @@ int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
         ix->cfg.seg_verdict = (int)value;
         return MOVI_OK;
     }
+    if (!strcmp(key, "stage_reads")) {                       // A/B: reads of short-read wavefronts staged through LDS
+        if (value != 0 && value != 1) return fail(MOVI_ERR_ARG, "stage_reads must be 0 or 1");
+        ix->cfg.stage_reads = (int)value;
+        return MOVI_OK;
+    }
     if (!strcmp(key, "kmer_k")) {                            // top-of-walk table: 0 = none, else K in [1, 12]
         if (value < 0 || value > 12) return fail(MOVI_ERR_ARG, "kmer_k must be in [0, 12]");
         HIP_TRY(hipSetDevice(ix->device));
@@ -867,6 +872,7 @@ int movi_last_launch(const movi_index_t *ix, movi_launch_info_t *info) {
     info->waves_per_cu = ix->last_launch.waves_per_cu;
     info->segmented = ix->last_launch.segmented;
     info->idx64 = ix->last_launch.idx64;
+    info->staged = ix->last_launch.staged;
     return MOVI_OK;
 }
 
@@ -1318,8 +1324,9 @@ static int ml_host(bool zml, movi_index_t *ix, const uint8_t *h_bases, const uin
                   uint16_t *h_out_pml, uint8_t *h_read_err, movi_query_stats_t *stats) {
     if (!ix) return fail(MOVI_ERR_ARG, "index handle is NULL");
     if (n_reads == 0) { if (stats) memset(stats, 0, sizeof(*stats)); return MOVI_OK; }
-    if (!h_offsets || (h_offsets[n_reads] != h_offsets[0] && (!h_bases || !h_out_pml)))
-        return fail(MOVI_ERR_ARG, "NULL host buffer");
+    // h_out_pml == NULL: the walk runs, error bytes and counters come back, the vectors stay on the device and are dropped
+    // (`movi query --no-output`: the reference computes and discards)
+    if (!h_offsets || (h_offsets[n_reads] != h_offsets[0] && !h_bases)) return fail(MOVI_ERR_ARG, "NULL host buffer");
     if (int rc0 = check_offsets(h_offsets, n_reads)) return rc0;
     HIP_TRY(hipSetDevice(ix->device));
     struct { void *p; } d_out{};
@@ -1331,11 +1338,11 @@ static int ml_host(bool zml, movi_index_t *ix, const uint8_t *h_bases, const uin
     // (the results are found through the chunk's own staging: with chunks in flight, launch() of the next chunk has
     // run before fetch() of this one)
     auto fetch = [&](ChunkCtx &c, uint64_t, uint64_t, uint64_t b0, uint64_t nb) -> int {
-        HIP_TRY(c.down(h_out_pml + b0, c.d[movi_index::kOut], nb * 2));
+        if (h_out_pml) HIP_TRY(c.down(h_out_pml + b0, c.d[movi_index::kOut], nb * 2));
         return MOVI_OK;
     };
     auto harvest = [](const uint8_t *, uint64_t, uint64_t) {};
-    const bool overlapped = h_offsets[n_reads] != h_offsets[0] && is_pinned(h_bases) && is_pinned(h_out_pml);
+    const bool overlapped = h_offsets[n_reads] != h_offsets[0] && is_pinned(h_bases) && (!h_out_pml || is_pinned(h_out_pml));
     return run_host(overlapped, ix, h_bases, h_offsets, n_reads, h_read_err, stats, launch, fetch, harvest, 0);
 }
 

@@ -848,6 +848,37 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
     uint32_t a = s_code[(uint32_t)(rb >> 56) & 0xFFu];    // code of the base of step k (k = 0)
     uint4 pk = make_uint4(0, 0, 0, 0), pk_old = pk;
     if (CLS) cs.init(len, cls.bin_width);
+    // ---- reads staged through LDS (ix.stage_lds: the launcher found the block's dynamic LDS -- the occupancy cap's
+    // padding, 16 KiB per one-wavefront block -- big enough): a wavefront whose reads all have at most 256 bases copies
+    // them into LDS once, at the start -- each lane its own read, 16 bytes per load from the read's end backwards, so the
+    // 64 x 150 contiguous bytes of the wavefront's reads come in as whole cache lines, each fetched ONCE (the lines stay in
+    // the CU's L1 over these back-to-back loads) -- and takes every base from there.  The walk's other way to its bases,
+    // 16 at a time from global memory (below), re-fetches a read's cache line for every 16 bases: its line is evicted
+    // long before the lane comes back (0.0625 lines per base, 6 % of all line fetches of a big batch).  Layout: step k of
+    // lane l at byte (k / 4) * 256 + 4 l + k % 4 -- lanes in step read consecutive banks.  Wavefronts with a longer read
+    // (and segments, and refilled lanes) keep the global path: the choice is wave-uniform.
+    extern __shared__ __align__(16) uint8_t s_stage[];
+    bool staged = false;
+    if (!REFILL && SEG != 1 && ix.stage_lds != 0u) {
+        staged = !wave_any(len > 256u);
+        if (staged) {
+            uint32_t *S = reinterpret_cast<uint32_t *>(s_stage);
+            const uint32_t sl = threadIdx.x & 63u;
+            for (uint32_t g = 0; wave_any(16u * g < len); ++g) {
+                if (16u * g < len) {
+                    const uint64_t e = beg + len - 16u * g;
+                    uint64_t c0, c1;
+                    load_pair_at(e, c0, c1);
+                    fix_pair(e, c0, c1);
+                    const uint64_t r0 = __builtin_bswap64(c0), r1 = __builtin_bswap64(c1);   // step 16 g in the low byte
+                    S[(4u * g + 0u) * 64u + sl] = (uint32_t)r0;
+                    S[(4u * g + 1u) * 64u + sl] = (uint32_t)(r0 >> 32);
+                    S[(4u * g + 2u) * 64u + sl] = (uint32_t)r1;
+                    S[(4u * g + 3u) * 64u + sl] = (uint32_t)(r1 >> 32);
+                }
+            }
+        }
+    }
     // ---- top of the walk (DevIndex::kmer): the first K bases of the read (segment) by ONE table lookup.  Reads with an
     // illegal base among them, reads of K bases or fewer and K-mers whose walk throws take the ordinary walk.
     if (!REFILL && ix.kmer_k != 0u) {                     // wave-uniform
@@ -1081,15 +1112,19 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
             }
             k += 1;
             if (lf) {
-                if ((k & 15) == 8) {
-                    rb = rb2;
-                } else if ((k & 15) == 0) {
-                    rb = nx0;
-                    rb2 = nx1;
-                    fix_pair(beg + len - k, rb, rb2);
-                    if (k + 16 < len) { want_nx = 1; nx_e = beg + len - k - 16; }
+                if (staged) {                             // wave-uniform
+                    a = s_code[s_stage[(k >> 2) * 256u + (threadIdx.x & 63u) * 4u + (k & 3u)]];
+                } else {
+                    if ((k & 15) == 8) {
+                        rb = rb2;
+                    } else if ((k & 15) == 0) {
+                        rb = nx0;
+                        rb2 = nx1;
+                        fix_pair(beg + len - k, rb, rb2);
+                        if (k + 16 < len) { want_nx = 1; nx_e = beg + len - k - 16; }
+                    }
+                    a = s_code[(uint32_t)(rb >> (8 * (7 - (k & 7)))) & 0xFFu];
                 }
-                a = s_code[(uint32_t)(rb >> (8 * (7 - (k & 7)))) & 0xFFu];
             }
         }
         if (errc) failed = errc;
@@ -1788,6 +1823,10 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
         if (bpc < 1) bpc = 1;
         if (bpc < 32) dyn_lds = ((163840u / (unsigned)bpc) & ~1023u) - 1024u;
     }
+    // reads staged through LDS (pml_kernel_flatp): needs 256 bytes per lane of the one-wavefront block -- what the occupancy
+    // cap's padding provides for caps of up to 9 wavefronts per CU.  cfg.stage_reads: 1 = when it fits (default), 0 = never
+    DevIndex ixl = ix;
+    ixl.stage_lds = (cfg.stage_reads != 0 && bt == 64 && dyn_lds >= 16384 && v == 10) ? 256u : 0u;
     const SegArgs no_seg;
     // every kernel that is handed more than 64 KiB of dynamic LDS must opt in first
 #define MOVI_SEG_0
@@ -1807,7 +1846,7 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
                 mb > 0 && (uint64_t)grid.x > (uint64_t)mb * (uint64_t)cfg.num_cus)                          \
                 grid.x = (unsigned)((uint64_t)mb * (uint64_t)cfg.num_cus);                                  \
         }                                                                                                   \
-        hipLaunchKernelGGL((__VA_ARGS__), grid, block, dyn_lds, stream, ix, d_bases, d_offsets, n_reads,    \
+        hipLaunchKernelGGL((__VA_ARGS__), grid, block, dyn_lds, stream, ixl, d_bases, d_offsets, n_reads,   \
                            d_out, d_err, d_stats, d_order, cls MOVI_SEG_##X);                               \
     } while (0)
 #define MOVI_LAUNCH_PML(M, V, C) MOVI_LAUNCH_K(pml_kernel<M, V, C>)
@@ -1850,6 +1889,7 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
                       ix.sep ? 1 : 0, v == 13 ? 1 : 0);
         info->variant = (v == 10 && wp) ? 14 : v;
         info->block_threads = bt; info->waves_per_cu = wpc; info->segmented = 0; info->idx64 = ix.idx32 ? 0 : 1;
+        info->staged = ixl.stage_lds ? 1 : 0;
     }
 #undef MOVI_LAUNCH_PML
 #undef MOVI_LAUNCH_K

@@ -42,6 +42,7 @@ struct DevIndex {
     // towards base K, before its fast-forward), which of the K bases matched (their PMLs follow from that) and the
     // fast-forwards / scan rows the K steps took: one 16-byte lookup instead of K dependent row gathers.  The reference's
     // analogue is the ftab of its k-mer queries (src/move_structure_search.cpp:66-167, 203-259), there for intervals.
+    uint32_t stage_lds;           // set per launch by launch_pml: bytes of dynamic LDS per lane for read staging (0 = none, 256)
     uint32_t kmer_k;
     const uint4 *kmer;            // 4^K entries: x = row[31:0]; y = row[35:32] | off << 4 (12 bits) | match mask << 16 (K bits) |
                                   // valid << 31; z = fast-forwards; w = scan rows.  valid = 0: one of the K steps hit one of the
@@ -78,6 +79,7 @@ struct LaunchCfg {
     int seg_probe = 1;     // ... if a probe of the batch finds that walks started mid-read fall into step quickly (0 = always: tests;
                            // 2 = no probe and no read-back at all, the caller's seg_verdict decides: the launch stays asynchronous)
     int seg_verdict = 0;   // seg_probe == 2: 1 = cut eligible batches, 0 = one lane per read
+    int stage_reads = 1;   // big batches of short reads: reads staged through LDS (0 = off: A/B)
     int refill_blocks = 0; // variant 13: size of the persistent grid in blocks; 0 = num_cus x waves per CU (tests shrink it
                            // so that a few hundred reads already go through many refills per lane)
 };
@@ -90,6 +92,7 @@ struct LaunchInfo {
     int waves_per_cu = 0;    // resident-wavefront cap applied (0 = none)
     int segmented = 0;       // 1 = the segment-parallel plan ran (K1 + stitch + finalize around the named kernel)
     int idx64 = 0;           // 1 = the 64-bit row-index instantiation
+    int staged = 0;          // 1 = wavefronts of short reads copy their reads into LDS once (pml_kernel_flatp)
 };
 
 // Classifier::classify bins (src/classifier.cpp:99-143) fused into the PML kernels: per read the number of

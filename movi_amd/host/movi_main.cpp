@@ -128,15 +128,26 @@ uint64_t zml_rounds(const ReadSet &rs, size_t i, const uint16_t *z, const uint8_
 struct MlBuf {
     uint16_t *p = nullptr;
     size_t cap = 0;
-    ~MlBuf() { std::free(p); }
-    uint16_t *data() const { return p; }
-    void ensure(size_t n) {
-        if (n <= cap) return;
-        std::free(p);
+    bool pinned = false;                                              // page-locked (movi_host_alloc): the engine overlaps its transfers
+    ~MlBuf() { release(); }
+    void release() {
+        if (p) { if (pinned) movi_host_free(p); else std::free(p); }
         p = nullptr;
+        cap = 0;
+    }
+    uint16_t *data() const { return p; }
+    void ensure(size_t n, bool want_pinned) {
+        if (n <= cap) return;
+        release();
         cap = n + (n >> 4);
         const size_t bytes = ((cap * sizeof(uint16_t) + (2u << 20) - 1) >> 21) << 21;
         void *q = nullptr;
+        if (want_pinned && movi_host_alloc(bytes, &q) == MOVI_OK && q) {   // resident and pinned as it comes
+            p = static_cast<uint16_t *>(q);
+            pinned = true;
+            return;
+        }
+        pinned = false;
         if (posix_memalign(&q, 2u << 20, bytes) != 0 || !q) { cap = 0; throw std::bad_alloc(); }
         p = static_cast<uint16_t *>(q);
         madvise(q, bytes, MADV_HUGEPAGE);                              // fewer, larger faults where THP is on
@@ -153,6 +164,12 @@ struct MlBuf {
         }
     }
 };
+
+void *pinned_alloc(size_t bytes) {
+    void *q = nullptr;
+    return movi_host_alloc(bytes, &q) == MOVI_OK ? q : nullptr;
+}
+void pinned_free(void *q) { movi_host_free(q); }
 
 struct Job {
     ReadSet rs;
@@ -312,9 +329,22 @@ int run_query(const Options &o) {
     uint64_t reads_done = 0, bases_done = 0;
     double gpu_seconds = 0;
 
+    // Page-locked chunk buffers: with the reads and the result vector in page-locked memory the engine's *_host entry
+    // points cut a chunk into pieces whose upload, walk and download overlap (include/movi_hip.h).  Page-locking costs
+    // ~40 us per MB, once per buffer (three jobs circulate, grow-only): always worth it for the 2^25-base chunks of short
+    // reads (~100 MB per job), and for the GB-sized chunks of long reads when the input holds several of them.
+    uint64_t input_bytes = 0;
+    if (map.p != MAP_FAILED) input_bytes = map.n;
+    const bool pin_buffers = !std::getenv("MOVI_NO_PINNED") && (input_bytes == 0 || input_bytes >= (64ull << 20));
+    auto pin_this_chunk = [&](uint64_t chunk_bytes) {
+        return pin_buffers && (chunk_bytes <= (256ull << 20) || input_bytes >= 4 * chunk_bytes);
+    };
     Job jobs[3];
     HandOff<Job *> free_q, parsed_q, done_q;
+    if (pin_buffers && input_bytes && input_bytes / 3 <= (1ull << 30))   // short-read sized chunks: pinned from the start
+        for (Job &j : jobs) j.rs.bases.set_allocator(pinned_alloc, pinned_free);
     for (Job &j : jobs) free_q.push(&j);
+    double parse_seconds = 0, write_seconds = 0;
     std::exception_ptr parse_error, write_error;
     std::mutex err_m;
 
@@ -323,7 +353,10 @@ int run_query(const Options &o) {
         try {
             Job *j = nullptr;
             while (free_q.pop(j)) {
-                if (!reader.next_chunk(j->rs, chunk_bases, chunk_min_reads, chunk_hard_max)) break;
+                const auto tp = std::chrono::steady_clock::now();
+                const bool more = reader.next_chunk(j->rs, chunk_bases, chunk_min_reads, chunk_hard_max);
+                parse_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - tp).count();
+                if (!more) break;
                 parsed_q.push(j);
             }
         } catch (...) {
@@ -338,6 +371,8 @@ int run_query(const Options &o) {
         ReadSet &rs = job.rs;
         const size_t n = rs.size();
         const bool verdict_only = job.verdict_only;
+        // nothing to write for this chunk (`--no-output` without a report or a filter): no record order needed either
+        if (!o.write_output_allowed() && !(o.classify && (o.filter || report))) return;
         // record order: strand scheduler emulation in prefetch mode, file order otherwise
         std::vector<uint32_t> order;
         if (o.prefetch) {
@@ -371,7 +406,7 @@ int run_query(const Options &o) {
                 th.emplace_back([&, u] {
                     for (size_t k = cut[u]; k < cut[u + 1]; k++) {
                         const uint32_t i = order[k];
-                        append_stdout_pmls(txt[u], rs.ids[i], job.pml.data() + rs.offsets[i], rs.len(i));
+                        append_stdout_pmls(txt[u], rs.id(i), job.pml.data() + rs.offsets[i], rs.len(i));
                     }
                 });
             for (auto &x : th) x.join();
@@ -385,21 +420,21 @@ int run_query(const Options &o) {
                 if (o.classify) {                                     // write_mls, src/read_processor.cpp:565-578
                     const bool found = verdict_only
                         ? (job.bins_above[i] / (job.bins_above[i] + job.bins_below[i] + 0.0) > 0.50)      // classifier.cpp:119
-                        : classifier.classify(rs.ids[i], p, len, o.bin_width, o.write_output_allowed() ? report : nullptr);
+                        : classifier.classify(rs.id(i), p, len, o.bin_width, o.write_output_allowed() ? report : nullptr);
                     if (o.filter && !o.no_output && (found != o.invert)) {
                         const uint8_t *seq = (job.original.empty() ? rs.bases.data() : job.original.data()) + rs.offsets[i];
-                        std::cout << ">" << rs.ids[i] << "\n";
+                        std::cout << ">" << rs.id(i) << "\n";
                         std::cout.write(reinterpret_cast<const char *>(seq), (std::streamsize)len);
                         std::cout << "\n";
                     }
                 }
                 if (o.write_output_allowed()) {
-                    if (o.write_stdout_enabled()) write_stdout_pmls(std::cout, rs.ids[i], p, len);
-                    else bpf.push_back(BpfWriter::Record{&rs.ids[i], p, len});
+                    if (o.write_stdout_enabled()) write_stdout_pmls(std::cout, rs.id(i), p, len);
+                    else bpf.push_back(BpfWriter::Record{rs.id(i), p, len});
                 }
             } else if (o.write_output_allowed()) {
                 std::ostream &out = o.write_stdout_enabled() ? static_cast<std::ostream &>(std::cout) : matches_file;
-                write_count_line(out, rs.ids[i], len, job.matched[i], job.counts[i]);
+                write_count_line(out, rs.id(i), len, job.matched[i], job.counts[i]);
             }
         }
         if (to_bpf) mls_file.append(bpf);
@@ -411,7 +446,9 @@ int run_query(const Options &o) {
             { std::lock_guard<std::mutex> g(err_m); failed = write_error != nullptr; }
             if (!failed) {
                 try {
+                    const auto tw = std::chrono::steady_clock::now();
                     write_job(*j);
+                    write_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
                 } catch (...) {
                     std::lock_guard<std::mutex> g(err_m);
                     write_error = std::current_exception();
@@ -455,7 +492,9 @@ int run_query(const Options &o) {
         job.bins_above.assign(verdict_only ? n : 0, 0);
         job.bins_below.assign(verdict_only ? n : 0, 0);
         job.bins_sum.assign(verdict_only ? n : 0, 0);
-        job.pml.ensure(o.ml() && !verdict_only ? rs.bases.size() : 0);
+        // `--no-output` without classification: the walk runs, nothing comes back (movi_pml_host with a NULL vector)
+        const bool walk_only = o.ml() && !o.classify && !o.write_output_allowed();
+        job.pml.ensure(o.ml() && !verdict_only && !walk_only ? rs.bases.size() : 0, pin_this_chunk(rs.bases.size() * 2));
         job.matched.assign(o.count ? n : 0, 0);
         job.counts.assign(o.count ? n : 0, 0);
         job.err.assign(n, 0);
@@ -471,9 +510,11 @@ int run_query(const Options &o) {
                                             classifier.max_value_thr, job.bins_above.data() + a, job.bins_below.data() + a,
                                             job.bins_sum.data() + a, job.err.data() + a, nullptr);
             else if (o.pml)
-                rc = movi_pml_host(handles[g], rs.bases.data(), rs.offsets.data() + a, b - a, job.pml.data(), job.err.data() + a, nullptr);
+                rc = movi_pml_host(handles[g], rs.bases.data(), rs.offsets.data() + a, b - a, walk_only ? nullptr : job.pml.data(),
+                                   job.err.data() + a, nullptr);
             else if (o.zml)
-                rc = movi_zml_host(handles[g], rs.bases.data(), rs.offsets.data() + a, b - a, job.pml.data(), job.err.data() + a, nullptr);
+                rc = movi_zml_host(handles[g], rs.bases.data(), rs.offsets.data() + a, b - a, walk_only ? nullptr : job.pml.data(),
+                                   job.err.data() + a, nullptr);
             else
                 rc = movi_count_host(handles[g], rs.bases.data(), rs.offsets.data() + a, b - a, job.matched.data() + a,
                                      job.counts.data() + a, job.err.data() + a, nullptr);
@@ -505,6 +546,9 @@ int run_query(const Options &o) {
     std::cerr << "[movi] " << reads_done << " reads are processed.\n";
     std::cerr << "[movi] Time measured for processing the reads: " << total << " s (" << bases_done << " bases; GPU calls "
               << gpu_seconds << " s)\n";
+    if (o.verbose)                                                     // the three pipeline stages run side by side: the slowest one bounds the command
+        std::cerr << "[movi] Stage times: parse " << parse_seconds << " s, GPU calls " << gpu_seconds << " s, order + write "
+                  << write_seconds << " s (page-locked chunk buffers: " << (pin_buffers ? "yes" : "no") << ")\n";
     std::cout.flush();
     return 0;
 }
@@ -560,7 +604,7 @@ int run_plan(const Options &o) {
         std::vector<uint32_t> order;
         if (o.prefetch) order = strand_order(rs, cost, o.strands);
         else for (size_t i = 0; i < rs.size(); i++) order.push_back((uint32_t)i);
-        for (uint32_t i : order) std::cout << rs.batch_of[i] << "\t" << rs.ids[i] << "\t" << rs.len(i) << "\n";
+        for (uint32_t i : order) std::cout << rs.batch_of[i] << "\t" << rs.id(i) << "\t" << rs.len(i) << "\n";
     }
     return 0;
 }

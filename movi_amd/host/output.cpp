@@ -71,9 +71,9 @@ void BpfWriter::append(const std::vector<Record> &records) {
         fill += len;
     };
     for (const Record &r : records) {
-        const uint16_t idl = static_cast<uint16_t>(r.id->length());      // src/utils.cpp:222
+        const uint16_t idl = static_cast<uint16_t>(r.id.length());      // src/utils.cpp:222
         put(&idl, 2);
-        put(r.id->data(), idl);
+        put(r.id.data(), idl);
         put(&r.n, 8);                                                    // output_binary :204-210
         const size_t bytes = r.n * 2;
         if (bytes >= (1u << 20)) { flush(); write_all(r.pml, bytes); }
@@ -82,7 +82,7 @@ void BpfWriter::append(const std::vector<Record> &records) {
     flush();
 }
 
-void append_stdout_pmls(std::string &txt, const std::string &id, const uint16_t *pml, uint64_t n) {
+void append_stdout_pmls(std::string &txt, std::string_view id, const uint16_t *pml, uint64_t n) {
     // add_ml appends " " + reversed digits per value and the whole string is reversed once at the
     // end: the net effect is the values in read order, each followed by one space.
     txt.push_back('>');
@@ -99,14 +99,14 @@ void append_stdout_pmls(std::string &txt, const std::string &id, const uint16_t 
     txt.push_back('\n');
 }
 
-void write_stdout_pmls(std::ostream &out, const std::string &id, const uint16_t *pml, uint64_t n) {
+void write_stdout_pmls(std::ostream &out, std::string_view id, const uint16_t *pml, uint64_t n) {
     std::string line;
     line.reserve(id.size() + n * 3 + 3);
     append_stdout_pmls(line, id, pml, n);
     out << line;
 }
 
-void write_count_line(std::ostream &out, const std::string &id, uint64_t query_length, uint64_t matched, uint64_t count) {
+void write_count_line(std::ostream &out, std::string_view id, uint64_t query_length, uint64_t matched, uint64_t count) {
     out << id << "\t" << matched << "/" << query_length << "\t" << count << "\n";
 }
 
@@ -139,7 +139,7 @@ void Classifier::write_report_header(std::ostream &out) const {      // src/clas
         << std::setw(12) << std::left << "below thr:" << std::endl;
 }
 
-bool Classifier::classify(const std::string &read_name, const uint16_t *pml, uint64_t n, size_t bin_width,
+bool Classifier::classify(std::string_view read_name, const uint16_t *pml, uint64_t n, size_t bin_width,
                           std::ostream *out) const {                  // src/classifier.cpp:99-143
     size_t sum_max_bin_values = 0, bins = 0;
     size_t bins_above = 0, bins_below = 0;

@@ -12,6 +12,7 @@
 #include <fstream>
 #include <ostream>
 #include <string>
+#include <string_view>
 #include <vector>
 
 #include "options.hpp"
@@ -31,7 +32,7 @@ public:
     ~BpfWriter();
     void open(const std::string &path, uint8_t entry_size);           // creates / truncates, writes the header
     bool is_open() const { return fd_ >= 0; }
-    struct Record { const std::string *id; const uint16_t *pml; uint64_t n; };
+    struct Record { std::string_view id; const uint16_t *pml; uint64_t n; };
     void append(const std::vector<Record> &records);                  // in the given order
     void close();
 
@@ -42,9 +43,9 @@ private:
 };
 
 // `>id\n` + values in read order, each followed by a space, + `\n`
-void write_stdout_pmls(std::ostream &out, const std::string &id, const uint16_t *pml, uint64_t n);
-void append_stdout_pmls(std::string &txt, const std::string &id, const uint16_t *pml, uint64_t n);   // the same text, appended
-void write_count_line(std::ostream &out, const std::string &id, uint64_t query_length, uint64_t matched, uint64_t count);
+void write_stdout_pmls(std::ostream &out, std::string_view id, const uint16_t *pml, uint64_t n);
+void append_stdout_pmls(std::string &txt, std::string_view id, const uint16_t *pml, uint64_t n);   // the same text, appended
+void write_count_line(std::ostream &out, std::string_view id, uint64_t query_length, uint64_t matched, uint64_t count);
 
 class Classifier {
 public:
@@ -53,7 +54,7 @@ public:
     void write_report_header(std::ostream &out) const;
     // Bins of bin_width over the PML vector in emission order; the last bin absorbs a
     // remainder shorter than bin_width.  Writes the report line unless out == nullptr.
-    bool classify(const std::string &read_name, const uint16_t *pml, uint64_t n, size_t bin_width, std::ostream *out) const;
+    bool classify(std::string_view read_name, const uint16_t *pml, uint64_t n, size_t bin_width, std::ostream *out) const;
     uint16_t max_value_thr = 0;
 };
 

@@ -9,6 +9,75 @@
 
 namespace movi_host {
 
+WorkerPool::WorkerPool(unsigned threads) {
+    for (unsigned t = 1; t < threads; t++) th_.emplace_back([this] { loop(); });
+}
+
+WorkerPool::~WorkerPool() {
+    { std::lock_guard<std::mutex> g(m_); stop_ = true; }
+    cv_.notify_all();
+    for (auto &t : th_) t.join();
+}
+
+void WorkerPool::loop() {
+    uint64_t seen = 0;
+    std::unique_lock<std::mutex> g(m_);
+    for (;;) {
+        cv_.wait(g, [&] { return stop_ || (gen_ != seen && next_ < parts_); });
+        if (stop_) return;
+        seen = gen_;
+        while (next_ < parts_) {
+            const unsigned k = next_++;
+            g.unlock();
+            (*fn_)(k);
+            g.lock();
+            if (--pending_ == 0) done_cv_.notify_all();
+        }
+    }
+}
+
+void WorkerPool::run(unsigned parts, const std::function<void(unsigned)> &fn) {
+    if (parts == 0) return;
+    if (parts == 1 || th_.empty()) { for (unsigned k = 0; k < parts; k++) fn(k); return; }
+    std::unique_lock<std::mutex> g(m_);
+    fn_ = &fn; parts_ = parts; next_ = 0; pending_ = parts; gen_++;
+    cv_.notify_all();
+    while (next_ < parts_) {                                           // the caller takes parts too
+        const unsigned k = next_++;
+        g.unlock();
+        fn(k);
+        g.lock();
+        --pending_;
+    }
+    done_cv_.wait(g, [&] { return pending_ == 0; });
+    fn_ = nullptr;
+}
+
+void LineSource::prescan(size_t bytes, WorkerPool &pool) {
+    if (!mem_) return;
+    if (nl_i_ == nl_.size()) { nl_.clear(); nl_i_ = 0; }
+    size_t from = nl_.empty() ? pos_ : nl_to_;
+    if (from < pos_) from = pos_;
+    const size_t to = std::min(end_, pos_ + bytes);
+    if (to <= from) return;
+    const unsigned T = (to - from) >= (1u << 22) ? pool.size() : 1;
+    std::vector<std::vector<size_t>> part(T);
+    pool.run(T, [&](unsigned t) {
+        const size_t a = from + (to - from) * t / T, b = from + (to - from) * (t + 1) / T;
+        std::vector<size_t> &v = part[t];
+        v.reserve((b - a) / 64 + 16);
+        const char *p = mem_ + a, *e = mem_ + b;
+        while (p < e) {
+            const void *q = std::memchr(p, '\n', (size_t)(e - p));
+            if (!q) break;
+            v.push_back((size_t)(static_cast<const char *>(q) - mem_));
+            p = static_cast<const char *>(q) + 1;
+        }
+    });
+    for (auto &v : part) nl_.insert(nl_.end(), v.begin(), v.end());
+    nl_to_ = to;
+}
+
 bool LineSource::fill() {
     if (drained_) return false;
     if (pos_ > 0) {
@@ -30,6 +99,13 @@ int LineSource::peek() {
 }
 
 bool LineSource::getline(const char *&p, size_t &n) {
+    if (nl_i_ < nl_.size()) {                                          // a newline found by prescan()
+        const size_t at = nl_[nl_i_++];
+        p = mem_ + pos_;
+        n = at - pos_;
+        pos_ = at + 1;
+        return true;
+    }
     for (;;) {
         const char *base = data() + pos_;
         const void *nl = std::memchr(base, '\n', end_ - pos_);
@@ -101,10 +177,14 @@ static size_t rstrip_len(const char *p, size_t n) {
 }
 
 bool BatchReader::next_chunk(ReadSet &out, uint64_t max_bases, uint64_t min_reads, uint64_t hard_max_bases) {
-    out.ids.clear(); out.bases.clear(); out.offsets.assign(1, 0); out.batch_of.clear();
+    out.id_bytes.clear(); out.id_off.assign(1, 0); out.bases.clear(); out.offsets.assign(1, 0); out.batch_of.clear();
     arena_.clear();
     lines_.clear();
     recs_.clear();
+    if (!pool_) pool_.reset(new WorkerPool(threads_ ? threads_ : std::min(16u, std::max(1u, std::thread::hardware_concurrency()))));
+    // the newlines of about a chunk's worth of input, found by all workers at once (the rest, if the chunk turns out
+    // longer, line by line as before)
+    if (mem_) src_.prescan((size_t)std::min<uint64_t>(max_bases + (max_bases >> 2) + (1u << 20), 1ull << 32), *pool_);
     // ---- phase 1 (sequential): batches, headers, where each read's sequence lines are
     bool any = false;
     uint64_t approx_bases = 0;                                         // sequence-line bytes, trailing whitespace included
@@ -143,19 +223,16 @@ bool BatchReader::next_chunk(ReadSet &out, uint64_t max_bases, uint64_t min_read
         }
     }
     if (!any) return false;
-    // ---- phase 2 (parallel): ids, stripped lengths, then the bases at their final offsets
+    // ---- phase 2 (parallel): id and stripped sequence lengths, then ids and bases copied to their final offsets
     const size_t n = recs_.size();
-    out.ids.resize(n);
     out.batch_of.resize(n);
     out.offsets.assign(n + 1, 0);
-    unsigned T = threads_ ? threads_ : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
-    if (approx_bases < (1u << 22) || n < 64) T = 1;                    // not worth a thread launch
-    auto for_ranges = [&](auto &&fn) {
-        if (T == 1) { fn(0, n); return; }
-        std::vector<std::thread> th;
-        // ranges balanced by sequence bytes, not by read count: line offsets are monotone in the input
-        for (unsigned t = 0; t < T; t++) th.emplace_back([&, t] { fn(n * t / T, n * (t + 1) / T); });
-        for (auto &x : th) x.join();
+    out.id_off.assign(n + 1, 0);
+    unsigned T = pool_->size();
+    if (approx_bases < (1u << 22) || n < 64) T = 1;                    // not worth waking the workers
+    auto for_ranges = [&](const std::function<void(size_t, size_t)> &fn) {
+        // ranges of equal read counts: line offsets are monotone in the input, so the ranges are balanced by bytes too
+        pool_->run(T, [&](unsigned t) { fn(n * t / T, n * (t + 1) / T); });
     };
     for_ranges([&](size_t a, size_t b) {
         for (size_t i = a; i < b; i++) {
@@ -166,19 +243,21 @@ bool BatchReader::next_chunk(ReadSet &out, uint64_t max_bases, uint64_t min_read
             for (size_t k = 1; k < hn; k++)
                 if (hdr[k] == ' ' || hdr[k] == '\t' || hdr[k] == '\r') { id_len = k; break; }
             // substr(1, id_len): id_len is used as a LENGTH, so the whitespace char is kept
-            out.ids[i].assign(hdr + 1, std::min(id_len, hn - 1));
+            out.id_off[i + 1] = std::min(id_len, hn - 1);
             out.batch_of[i] = r.batch;
             uint64_t len = 0;
             for (size_t l = r.seq_first; l < r.seq_end; l++) len += rstrip_len(line(l), lines_[l].len);
             out.offsets[i + 1] = len;
         }
     });
-    for (size_t i = 0; i < n; i++) out.offsets[i + 1] += out.offsets[i];
+    for (size_t i = 0; i < n; i++) { out.offsets[i + 1] += out.offsets[i]; out.id_off[i + 1] += out.id_off[i]; }
     const uint64_t total = out.offsets[n];
     out.bases.resize_uninitialized(total);                             // first touched by the workers below, in parallel
+    out.id_bytes.resize_uninitialized(out.id_off[n]);
     for_ranges([&](size_t a, size_t b) {
         for (size_t i = a; i < b; i++) {
             const Rec &r = recs_[i];
+            std::memcpy(out.id_bytes.data() + out.id_off[i], line(r.hdr) + 1, (size_t)(out.id_off[i + 1] - out.id_off[i]));
             uint8_t *dst = out.bases.data() + out.offsets[i];
             for (size_t l = r.seq_first; l < r.seq_end; l++) {
                 const size_t sn = rstrip_len(line(l), lines_[l].len);

@@ -10,20 +10,31 @@
 #include <cstdlib>
 #include <cstring>
 #include <istream>
+#include <memory>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <new>
 #include <string>
+#include <string_view>
+#include <thread>
 #include <vector>
 
 namespace movi_host {
 
 // A byte buffer that can grow WITHOUT initialising its bytes (std::vector value-initialises on resize: for a 1 GB chunk
 // that is one single-threaded pass of page faults before the parallel fill even starts).  Grow-only capacity.
+// The memory comes from malloc unless set_allocator() names another source -- `movi query` hands the chunk buffers
+// page-locked memory (movi_host_alloc) so that the engine's host entry points overlap their transfers with the walk.
 class RawBytes {
 public:
+    typedef void *(*AllocFn)(size_t);
+    typedef void (*FreeFn)(void *);
     RawBytes() = default;
     RawBytes(const RawBytes &) = delete;
     RawBytes &operator=(const RawBytes &) = delete;
-    ~RawBytes() { std::free(p_); }
+    ~RawBytes() { release(); }
+    void set_allocator(AllocFn a, FreeFn f) { release(); alloc_ = a; free_ = f; }   // drops what is held
     uint8_t *data() { return p_; }
     const uint8_t *data() const { return p_; }
     size_t size() const { return n_; }
@@ -33,9 +44,9 @@ public:
     void clear() { n_ = 0; }
     void resize_uninitialized(size_t n) {                   // contents are NOT kept across a growth
         if (n > cap_) {
-            std::free(p_);
+            release();
             cap_ = n + (n >> 4) + 64;
-            p_ = static_cast<uint8_t *>(std::malloc(cap_));
+            p_ = static_cast<uint8_t *>(alloc_ ? alloc_(cap_) : std::malloc(cap_));
             if (!p_) { cap_ = 0; n_ = 0; throw std::bad_alloc(); }
         }
         n_ = n;
@@ -46,17 +57,49 @@ public:
     }
 
 private:
+    void release() {
+        if (p_) { if (free_) free_(p_); else std::free(p_); }
+        p_ = nullptr;
+        n_ = cap_ = 0;
+    }
     uint8_t *p_ = nullptr;
     size_t n_ = 0, cap_ = 0;
+    AllocFn alloc_ = nullptr;
+    FreeFn free_ = nullptr;
 };
 
+// One chunk of reads.  Ids and bases are two byte arenas with offsets: no per-read allocation (a million std::strings
+// per chunk were a quarter of the parser's time, and ids longer than 15 characters -- every SRR id -- an allocation each).
 struct ReadSet {
-    std::vector<std::string> ids;       // header.substr(1, pos of first " \t\r"): keeps that whitespace char
+    RawBytes id_bytes;                  // the ids back to back: header.substr(1, pos of first " \t\r") keeps that whitespace char
+    std::vector<uint64_t> id_off;       // n+1
     RawBytes bases;                     // concatenated sequences
     std::vector<uint64_t> offsets;      // n+1
     std::vector<uint32_t> batch_of;     // reference batch index of each read
-    size_t size() const { return ids.size(); }
+    size_t size() const { return batch_of.size(); }
     uint64_t len(size_t i) const { return offsets[i + 1] - offsets[i]; }
+    std::string_view id(size_t i) const {
+        return std::string_view(reinterpret_cast<const char *>(id_bytes.data()) + id_off[i], (size_t)(id_off[i + 1] - id_off[i]));
+    }
+};
+
+// A few worker threads that stay around between chunks (two thread launches per phase and chunk were ~2 ms of a 10 ms chunk).
+class WorkerPool {
+public:
+    explicit WorkerPool(unsigned threads);
+    ~WorkerPool();
+    unsigned size() const { return (unsigned)th_.size() + 1; }
+    void run(unsigned parts, const std::function<void(unsigned)> &fn);   // fn(0 .. parts-1), the caller works too; returns when all are done
+
+private:
+    void loop();
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_, done_cv_;
+    const std::function<void(unsigned)> *fn_ = nullptr;
+    unsigned parts_ = 0, next_ = 0, pending_ = 0;
+    uint64_t gen_ = 0;
+    bool stop_ = false;
 };
 
 // Line source with std::istream's good()/peek()/getline() state semantics (the batch cut of the reference depends
@@ -70,6 +113,9 @@ public:
     bool good() const { return !eof_; }
     int peek();                                            // EOF sets the eof state, like istream::peek
     bool getline(const char *&p, size_t &n);
+    // memory form only: find the newlines of the next `bytes` bytes with `pool` (slices scanned in parallel); getline()
+    // then takes them from the list instead of running memchr line by line
+    void prescan(size_t bytes, WorkerPool &pool);
 
 private:
     const char *data() const { return mem_ ? mem_ : buf_.data(); }
@@ -79,6 +125,8 @@ private:
     std::vector<char> buf_;
     size_t pos_ = 0, end_ = 0;
     bool eof_ = false, drained_ = false;
+    std::vector<size_t> nl_;            // newline offsets in [nl_from_, nl_to_), ascending; nl_i_ = next unused
+    size_t nl_i_ = 0, nl_to_ = 0;
 };
 
 // Reads whole reference batches (BatchLoader::loadBatch) until a chunk is full.  Returns false when the input is
@@ -111,6 +159,7 @@ private:
     size_t min_reads_;
     uint64_t size_hint_ = 0;
     unsigned threads_ = 0;              // 0 = hardware concurrency (at most 16)
+    std::unique_ptr<WorkerPool> pool_;
     int format_ = -1;                   // -1 unknown, 0 FASTA, 1 FASTQ
     uint32_t batch_counter_ = 0;
 };

@@ -135,3 +135,51 @@ def test_top_of_walk_with_corrupt_rows(built_lib, golden_image):
     out, st, err, rc = gpu.query_pml_packed(bases, offs, want_err=True)
     assert rc == -6 and (out == e_out).all() and (err == e_err).all() and st.errors == e_st.errors
     gpu.close()
+
+
+@pytest.mark.parametrize("mode", [6, 8])
+def test_reads_staged_through_lds_vs_oracle(built_lib, golden_image, mode):
+    """Big batches (more reads than ~18 wavefronts per CU) run capped at 9 wavefronts per CU, and the LDS that enforces the
+    cap holds the reads: a wavefront whose 64 reads all have at most 256 bases copies them into LDS once and takes every
+    base from there; wavefronts with a longer read keep fetching 16 bases at a time from global memory.  Both kinds in one
+    launch, every length from 0 to 256 and beyond, with and without the top-of-walk table, fused bins included: PMLs, error
+    bytes and counters equal the oracle's and those of the unstaged launch."""
+    import movi_amd
+    from oracle.oracle import Oracle
+    img = golden_image(mode)
+    gpu, cpu = movi_amd.MoveIndex.from_image(img), Oracle(img)
+    ref = _ref()
+    rng = np.random.default_rng(8500 + mode)
+    n = 300_000                                           # > 256 CUs x 64 lanes x 18 wavefronts
+    lens = rng.integers(0, 257, n).astype(np.uint64)
+    lens[rng.choice(n, 40, replace=False)] = rng.integers(257, 2000, 40)      # a few wavefronts that cannot stage
+    lens[:64] = 256                                      # one wavefront of reads that fill the staging area exactly
+    lens[64:128] = 0
+    starts = rng.integers(0, len(ref) - 2000, n)
+    offs = np.zeros(n + 1, np.uint64)
+    np.cumsum(lens, out=offs[1:])
+    refa = np.frombuffer(ref, np.uint8)
+    idx = np.repeat(starts.astype(np.int64) - offs[:-1].astype(np.int64), lens.astype(np.int64)) + np.arange(int(offs[-1]), dtype=np.int64)
+    bases = refa[idx].copy()
+    mut = rng.random(bases.size)
+    bases[mut < 0.02] = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, int((mut < 0.02).sum()))]
+    bases[(mut >= 0.02) & (mut < 0.023)] = ord("N")
+    exp, ff, sc = cpu.pml_batch(bases, offs, threads=8)
+    gpu.set_option("stage_reads", 0)
+    out0, st0 = gpu.query_pml_packed(bases, offs)
+    assert gpu.last_launch()["staged"] == 0 and gpu.last_launch()["waves_per_cu"] == 9
+    assert (out0 == exp).all() and (st0.fast_forwards, st0.scans, st0.errors) == (ff, sc, 0)
+    bins0 = gpu.classify_packed(bases, offs, 40, 4)
+    gpu.set_option("stage_reads", 1)
+    for K in (0, 10):
+        gpu.set_option("kmer_k", K)
+        for variant in (-1, 10):
+            gpu.set_option("pml_variant", variant)
+            out, st = gpu.query_pml_packed(bases, offs)
+            assert gpu.last_launch()["staged"] == 1, (K, variant)
+            assert (out == exp).all(), (K, variant)
+            assert (st.fast_forwards, st.scans, st.repositions, st.errors) == (ff, sc, st0.repositions, 0), (K, variant)
+        gpu.set_option("pml_variant", -1)
+        bins = gpu.classify_packed(bases, offs, 40, 4)
+        assert all((x == y).all() for x, y in zip(bins, bins0)), K
+    gpu.close()
