@@ -199,6 +199,17 @@ int movi_pml_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_of
                   uint64_t n_reads, uint16_t *h_out_pml, uint8_t *h_read_err,
                   movi_query_stats_t *stats);
 
+/* `movi query --logs` (src/movi_parser.cpp:95; MoveQuery::add_fastforward / add_scan, include/move_query.hpp:51-53, collected
+ * by ReadProcessor::process_char src/read_processor.cpp:99-121 and written by output_logs src/utils.cpp:268-289): the PML
+ * query with two more u16 values per base, in emission order like the PMLs -- h_fastforwards[offsets[i] + k] = rows the
+ * LF from base k to base k + 1 fast-forwarded over (the read's last entry repeats the one before it, as the reference's
+ * strand does when it writes the read out; a read of one base: 0), h_scans[offsets[i] + k] = rows base k's reposition
+ * scanned.  Runs the first, base-synchronous kernel: a diagnostic path, not a fast one.  (The third file of --logs, the
+ * per-base wall-clock costs of a CPU strand, has no counterpart on a GPU lane; the CLI writes zeros.) */
+int movi_pml_logs_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_offsets, uint64_t n_reads,
+                       uint16_t *h_out_pml, uint16_t *h_fastforwards, uint16_t *h_scans, uint8_t *h_read_err,
+                       movi_query_stats_t *stats);
+
 /* Device-side counters of the last movi_pml_device / movi_count_device call on
  * this handle; synchronises `stream` first. */
 int movi_last_stats(movi_index_t *ix, void *stream, movi_query_stats_t *stats);

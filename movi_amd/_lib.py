@@ -87,6 +87,8 @@ SYMBOLS = {
                                   C.c_void_p, C.c_void_p, C.c_void_p]),
     "movi_pml_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                 C.POINTER(QueryStatsC)]),
+    "movi_pml_logs_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.POINTER(QueryStatsC)]),
     "movi_zml_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p]),
     "movi_zml_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,

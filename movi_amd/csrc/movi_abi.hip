@@ -1351,6 +1351,39 @@ int movi_pml_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_of
     return ml_host(false, ix, h_bases, h_offsets, n_reads, h_out_pml, h_read_err, stats);
 }
 
+// `movi query --logs`: PMLs plus, per base, the fast-forwards and scan rows MoveQuery::add_fastforward / add_scan
+// collect (ClsArgs::log_ff / log_scan).  Synchronous path, first kernel.
+int movi_pml_logs_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_offsets, uint64_t n_reads,
+                       uint16_t *h_out_pml, uint16_t *h_fastforwards, uint16_t *h_scans, uint8_t *h_read_err,
+                       movi_query_stats_t *stats) {
+    if (!ix) return fail(MOVI_ERR_ARG, "index handle is NULL");
+    if (n_reads == 0) { if (stats) memset(stats, 0, sizeof(*stats)); return MOVI_OK; }
+    if (!h_offsets || !h_fastforwards || !h_scans || (h_offsets[n_reads] != h_offsets[0] && (!h_bases || !h_out_pml)))
+        return fail(MOVI_ERR_ARG, "NULL host buffer");
+    if (int rc0 = check_offsets(h_offsets, n_reads)) return rc0;
+    HIP_TRY(hipSetDevice(ix->device));
+    struct { void *p; } d_out{}, d_ff{}, d_sc{};
+    auto launch = [&](ChunkCtx &c, const uint8_t *db, const uint64_t *dof, uint64_t nr, uint64_t nb, uint8_t *derr) -> int {
+        HIP_TRY(c.alloc(movi_index::kOut, nb * 2, &d_out.p));
+        HIP_TRY(c.alloc(movi_index::kA, nb * 2, &d_ff.p));
+        HIP_TRY(c.alloc(movi_index::kS, nb * 2, &d_sc.p));
+        HIP_TRY(hipMemsetAsync(d_ff.p, 0, nb * 2, c.s));               // a read of one base has no LF: its entry stays 0
+        HIP_TRY(hipMemsetAsync(d_sc.p, 0, nb * 2, c.s));
+        ClsArgs logs;
+        logs.log_ff = static_cast<uint16_t *>(d_ff.p);
+        logs.log_scan = static_cast<uint16_t *>(d_sc.p);
+        return ml_device(false, ix, db, dof, nr, nb, static_cast<uint16_t *>(d_out.p), derr, nullptr, c.s, logs, c.d_stats);
+    };
+    auto fetch = [&](ChunkCtx &c, uint64_t, uint64_t, uint64_t b0, uint64_t nb) -> int {
+        HIP_TRY(c.down(h_out_pml + b0, c.d[movi_index::kOut], nb * 2));
+        HIP_TRY(c.down(h_fastforwards + b0, c.d[movi_index::kA], nb * 2));
+        HIP_TRY(c.down(h_scans + b0, c.d[movi_index::kS], nb * 2));
+        return MOVI_OK;
+    };
+    auto harvest = [](const uint8_t *, uint64_t, uint64_t) {};
+    return run_host(false, ix, h_bases, h_offsets, n_reads, h_read_err, stats, launch, fetch, harvest, 0);
+}
+
 int movi_zml_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_offsets, uint64_t n_reads,
                   uint16_t *h_out_zml, uint8_t *h_read_err, movi_query_stats_t *stats) {
     return ml_host(true, ix, h_bases, h_offsets, n_reads, h_out_zml, h_read_err, stats);

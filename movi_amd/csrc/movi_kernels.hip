@@ -442,9 +442,15 @@ __global__ __launch_bounds__(256) void pml_kernel(DevIndex ix, const uint8_t *__
             }
         }
         if (k != 0) {
+            const uint32_t ff_before = ff_total;
             const uint32_t e = lf_step<MODE>(ix, live, idx, off, row, ff_total);
+            if (VARIANT == 0 && cls.log_ff && live) {     // --logs: this LF's fast-forwards (entry k - 1; the last one twice)
+                cls.log_ff[beg + k - 1] = (uint16_t)(ff_total - ff_before);
+                if (k + 1 == len) cls.log_ff[beg + k] = (uint16_t)(ff_total - ff_before);
+            }
             if (e) { failed = e; live = false; }
         }
+        const uint32_t scan_before = scan_total;
         uint32_t a = 0xFFu;
         if (live) {
             if (VARIANT >= 1) a = s_code[(uint32_t)(rb >> (8 * (7 - (k & 7)))) & 0xFFu];
@@ -502,6 +508,7 @@ __global__ __launch_bounds__(256) void pml_kernel(DevIndex ix, const uint8_t *__
         }
         if (dir == 1u) off = 0;
         if (dir == 2u) off = row_n<MODE>(row) - 1;        // read_processor.cpp:223
+        if (VARIANT == 0 && cls.log_scan && k < len) cls.log_scan[beg + k] = (uint16_t)(scan_total - scan_before);
         const uint32_t val = ml > 65535u ? 65535u : ml;   // MoveQuery::add_ml
         if (CLS && live) cs.add(val, (uint32_t)k, (uint32_t)len, cls.bin_width, cls.thr);
         if (CLS == 2) {
@@ -1782,6 +1789,7 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     // (variant 10 capped: 47.7), 43.5 on the random table; on log-normal read lengths 36.5 against 35.8.  Selectable,
     // not the default.
     int v = cfg.pml_variant;
+    const bool logging = cls.log_ff != nullptr || cls.log_scan != nullptr;
     // (batches of up to ~18 waves per CU run in ONE round, uncapped: with the cap, 224 k reads = 13.7 waves per CU run as
     // a full round of 9 and a half-empty one -- 38.3 against 39.2 Gbases/s; 300 k reads: 38.2 against 41.2; from 400 k
     // reads on the cap wins: 43.9 against 41.7.  profiles/r02_occupancy_cap_sweeps.txt)
@@ -1798,10 +1806,14 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     if ((v == 10 || v == 13) && (ix.r < 8 || n_bases < 16)) v = 7;           // the clamped window needs >= 4 rows, the
                                                                              // 16-base fetches >= 16 bytes of bases
     if (cm != 0 && (v == 0 || v == 7)) v = (v == 0 || ix.r < 8 || n_bases < 16) ? 1 : 10;   // the A/B kernels carry no fused bins
+    if (logging) {                                                           // per-base logs: the first kernel keeps them
+        if (cm != 0) return hipErrorInvalidValue;
+        v = 0;
+    }
     // Batches of long reads: segment-parallel (plain PML through the default kernel only).  One lane per read leaves the
     // GPU short of walks -- 100 k reads are 6 wavefronts per CU, and a single 1 Mbp read holds its lane for 2 s --;
     // cut into segments the same batch fills it like a batch of short reads.
-    if (seg_ws && cfg.seg_len >= 32 && !d_order && wp && v == 10 && cfg.block_threads <= 64 &&
+    if (seg_ws && !logging && cfg.seg_len >= 32 && !d_order && wp && v == 10 && cfg.block_threads <= 64 &&
         n_bases / n_reads >= 2ull * (uint64_t)cfg.seg_len && n_reads + n_bases / (uint64_t)cfg.seg_len < 0x7FFFFFF0ull) {
         bool declined = false;
         const hipError_t es = launch_pml_segmented(ix, d_bases, d_offsets, n_reads, n_bases, d_out, d_err, d_stats, cfg, stream,

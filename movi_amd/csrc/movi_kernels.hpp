@@ -103,6 +103,12 @@ struct ClsArgs {
     uint32_t *above = nullptr;
     uint32_t *below = nullptr;
     uint64_t *sum_max = nullptr;
+    // `movi query --logs` (src/read_processor.cpp:99-121,586-596, src/utils.cpp:268-289): per base, in emission order, the
+    // fast-forwards of the LF that led to the NEXT base (entry k = LF into base k + 1; the last entry repeats the one before
+    // it, as the reference's strand does when it writes the read out) and the rows the base's reposition scanned.
+    // u16, truncated like MoveQuery's vectors.  Non-null: the first, base-synchronous kernel runs (pml_kernel<6, 0>).
+    uint16_t *log_ff = nullptr;
+    uint16_t *log_scan = nullptr;
 };
 
 // ---- segment-parallel long reads (PML) -------------------------------------------------------------------------

@@ -190,6 +190,18 @@ class MoveIndex:
         check(rc)
         return out, QueryStats(st)
 
+    def query_pml_logs_packed(self, bases, offs):
+        """movi_pml_logs_host: (PMLs, per-base fast-forwards, per-base scan rows, QueryStats), all in emission order."""
+        bases = np.ascontiguousarray(bases, np.uint8)
+        offs = np.ascontiguousarray(offs, np.uint64)
+        out = np.zeros(bases.size, np.uint16)
+        ff = np.zeros(bases.size, np.uint16)
+        sc = np.zeros(bases.size, np.uint16)
+        st = QueryStatsC()
+        check(lib().movi_pml_logs_host(self._h, bases.ctypes.data, offs.ctypes.data, offs.size - 1, out.ctypes.data,
+                                       ff.ctypes.data, sc.ctypes.data, None, C.byref(st)))
+        return out, ff, sc, QueryStats(st)
+
     def query_pml(self, reads):
         """MoveStructure::query_pml for each read: list of u16 arrays, last base first
         (MoveQuery::matching_lens order)."""

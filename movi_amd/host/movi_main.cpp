@@ -174,6 +174,7 @@ void pinned_free(void *q) { movi_host_free(q); }
 struct Job {
     ReadSet rs;
     MlBuf pml;                                                        // PML / ZML values, emission order per read
+    std::vector<uint16_t> log_ff, log_scan;                           // --logs: per-base fast-forwards / scan rows
     std::vector<uint64_t> matched, counts;                            // --count
     std::vector<uint8_t> err;                                         // per-read error byte
     RawBytes original;                                                // reads as given (--filter after --ignore-illegal-chars 1)
@@ -317,6 +318,19 @@ int run_query(const Options &o) {
         }
     }
 
+    // --logs (src/utils.cpp:376-382: opened with the other output files, written by output_logs :268-289 per read)
+    const bool logs = o.logs && o.pml && open_files;
+    std::ofstream costs_file, scans_file, ff_file;
+    if (logs) {
+        std::string prefix = (!o.out_file.empty() ? o.out_file : o.read_file + "." + index_type) + "." + o.query_type();
+        costs_file.open(prefix + ".costs");
+        scans_file.open(prefix + ".scans");
+        ff_file.open(prefix + ".fastforwards");
+        if (!costs_file.good() || !scans_file.good() || !ff_file.good()) throw std::runtime_error("Failed to open the log files: " + prefix + ".costs/.scans/.fastforwards");
+    } else if (o.logs) {
+        std::cerr << "[movi] --logs is only collected for PML queries that write their output to files; ignored here.\n";
+    }
+
     auto t1 = std::chrono::steady_clock::now();
     InputMapping map;
     std::unique_ptr<BatchReader> reader_ptr = open_reader(o.read_file, *in, o.prefetch ? 4 * o.strands : 1, map);   // src/movi.cpp:283, :326
@@ -431,6 +445,20 @@ int run_query(const Options &o) {
                 if (o.write_output_allowed()) {
                     if (o.write_stdout_enabled()) write_stdout_pmls(std::cout, rs.id(i), p, len);
                     else bpf.push_back(BpfWriter::Record{rs.id(i), p, len});
+                    if (logs) {                                       // output_logs, src/utils.cpp:268-289
+                        // costs: the wall-clock nanoseconds a CPU strand spent per base -- nothing a GPU lane has; zeros
+                        std::string tc, ts, tf;
+                        for (std::string *t : {&tc, &ts, &tf}) { t->push_back('>'); t->append(rs.id(i)); t->push_back('\n'); }
+                        const uint16_t *sc = job.log_scan.data() + rs.offsets[i], *ff = job.log_ff.data() + rs.offsets[i];
+                        for (uint64_t k = 0; k < len; k++) {
+                            tc += "0 ";
+                            ts += std::to_string(sc[k]); ts.push_back(' ');
+                            tf += std::to_string(ff[k]); tf.push_back(' ');
+                        }
+                        costs_file << tc << "\n";
+                        scans_file << ts << "\n";
+                        ff_file << tf << "\n";
+                    }
                 }
             } else if (o.write_output_allowed()) {
                 std::ostream &out = o.write_stdout_enabled() ? static_cast<std::ostream &>(std::cout) : matches_file;
@@ -495,6 +523,7 @@ int run_query(const Options &o) {
         // `--no-output` without classification: the walk runs, nothing comes back (movi_pml_host with a NULL vector)
         const bool walk_only = o.ml() && !o.classify && !o.write_output_allowed();
         job.pml.ensure(o.ml() && !verdict_only && !walk_only ? rs.bases.size() : 0, pin_this_chunk(rs.bases.size() * 2));
+        if (logs) { job.log_ff.resize(rs.bases.size()); job.log_scan.resize(rs.bases.size()); }
         job.matched.assign(o.count ? n : 0, 0);
         job.counts.assign(o.count ? n : 0, 0);
         job.err.assign(n, 0);
@@ -509,6 +538,9 @@ int run_query(const Options &o) {
                 rc = movi_pml_classify_host(handles[g], rs.bases.data(), rs.offsets.data() + a, b - a, (uint32_t)o.bin_width,
                                             classifier.max_value_thr, job.bins_above.data() + a, job.bins_below.data() + a,
                                             job.bins_sum.data() + a, job.err.data() + a, nullptr);
+            else if (o.pml && logs)
+                rc = movi_pml_logs_host(handles[g], rs.bases.data(), rs.offsets.data() + a, b - a, job.pml.data(), job.log_ff.data(),
+                                        job.log_scan.data(), job.err.data() + a, nullptr);
             else if (o.pml)
                 rc = movi_pml_host(handles[g], rs.bases.data(), rs.offsets.data() + a, b - a, walk_only ? nullptr : job.pml.data(),
                                    job.err.data() + a, nullptr);

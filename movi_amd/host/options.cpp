@@ -108,6 +108,7 @@ Options parse_args(int argc, char **argv) {
     if (has("help") || positional.empty()) { o.command = "help"; return o; }
     o.command = positional[0];
     o.verbose = has("verbose");
+    o.logs = has("logs");
     o.no_header = has("no-header");
     if (o.command == "query") {
         // src/movi_parser.cpp:341, :431-434

@@ -37,6 +37,7 @@ struct Options {
     size_t threads = 1;
     size_t bin_width = 150;
     int gpus = 1;                 // extension: --gpus N shards the reads across N devices
+    bool logs = false;            // --logs: <prefix>.costs / .scans / .fastforwards next to the PML output (src/utils.cpp:376-382)
     bool gpus_given = false;      //   (given explicitly, N == 1 included: the index goes through the RCCL replication path)
     int device = 0;               // extension: --device D
     long seg_len = -1;            // extension: --seg-len N: segment length of the segment-parallel long-read walk (0 = off; default: the engine's)

@@ -471,6 +471,33 @@ int oracle_pml(const oracle_index *ix, const uint8_t *R, int64_t len, uint16_t *
     return ORACLE_OK;
 }
 
+/* `movi query --logs`, prefetch mode: what MoveQuery::add_fastforward / add_scan collect for one read
+ * (ReadProcessor::process_char src/read_processor.cpp:99-121: after the LF into a base, the LF's fast-forward count and the
+ * scan count of the base BEFORE it; ReadProcessor::write_mls :586-596: once more when the read is written out -- the last
+ * LF's count again, and the last base's scans).  So, in emission order: scans[k] = rows base k's reposition scanned,
+ * fastforwards[k] = fast-forwards of the LF from base k to base k + 1, the last entry repeating the one before it
+ * (0 for a read of one base: the reference leaves the strand's previous value there).  Values are truncated to u16 like
+ * MoveQuery's vectors (include/move_query.hpp:84-85). */
+int oracle_pml_logs(const oracle_index *ix, const uint8_t *R, int64_t len, uint16_t *out, uint16_t *ff_out, uint16_t *scan_out) {
+    strand_t s;
+    uint64_t ff = 0, sc = 0;
+    if (ix->mode == 5 || ix->mode == 3 || ix->mode == 2) return ORACLE_ERR_FORMAT;
+    if (len <= 0) return ORACLE_OK;
+    strand_reset(ix, &s, R, len, out);
+    int64_t k = 0;
+    ff_out[0] = 0;
+    while (s.pos_on_r > -1) {
+        const uint64_t ff0 = ff, sc0 = sc;
+        int rc = process_char(ix, &s, &ff, &sc);
+        if (rc < 0) return rc;
+        if (k > 0) ff_out[k - 1] = (uint16_t)(ff - ff0);
+        if (k > 0 && k == len - 1) ff_out[k] = (uint16_t)(ff - ff0);
+        scan_out[k] = (uint16_t)(sc - sc0);
+        k++;
+    }
+    return ORACLE_OK;
+}
+
 /* oracle_pml that also records the walker's position (row, offset) after every base: for studies of
  * how quickly walks started at different places of a read fall into step (tools/sync_study.py). */
 int oracle_pml_trace(const oracle_index *ix, const uint8_t *R, int64_t len, uint16_t *out,

@@ -39,6 +39,7 @@ def lib():
         L.oracle_pml.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_pml_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
                                        C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.oracle_pml_logs.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_count.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         L.oracle_count_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
                                          C.c_void_p, C.c_int]
@@ -91,6 +92,16 @@ class Oracle:
         if rc:
             raise OracleError("oracle_pml rc=%d" % rc)
         return (out, ff.value, sc.value) if stats else out
+
+    def pml_logs(self, read):
+        """(PMLs, per-base fast-forwards, per-base scan rows) as `movi query --logs` collects them, emission order."""
+        a = np.frombuffer(bytes(read), np.uint8)
+        out, ff, sc = np.zeros(a.size, np.uint16), np.zeros(a.size, np.uint16), np.zeros(a.size, np.uint16)
+        rc = lib().oracle_pml_logs(self._h, a.ctypes.data if a.size else None, a.size, out.ctypes.data, ff.ctypes.data,
+                                   sc.ctypes.data)
+        if rc:
+            raise OracleError("oracle_pml_logs rc=%d" % rc)
+        return out, ff, sc
 
     def pml_batch(self, seqs, offs, threads=1, strands=16):
         """seqs: uint8 concatenated bases; offs: uint64[n+1].  Returns (out, ff, scan)."""

@@ -295,6 +295,55 @@ def test_multi_gpu_sharding_path(movi_bin, tmp_path):
 
 
 @pytest.mark.parametrize("mode", [6, 8])
+def test_explicit_gpus_flag_replicates_through_rccl(movi_bin, tmp_path, mode):
+    """`--gpus N` given explicitly (N = 1 on this box): the index goes through movi_index_load_replicated -- one upload,
+    one RCCL broadcast (a communicator of one rank here), per-GPU expansion -- instead of movi_index_load.  Same bytes out;
+    asking for more GPUs than there are is an error, not a silent fallback; --no-output walks without fetching anything."""
+    from oracle import build_index as B
+    ref = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))[0][1]
+    reads_path = str(tmp_path / "rg.fa")
+    write_mixed_reads(reads_path, np.random.default_rng(19), ref, n=400)
+    one = run(["query", "-i", IDX[mode], "-r", reads_path, "-o", str(tmp_path / "a")])
+    rep = run(["query", "-i", IDX[mode], "-r", reads_path, "-o", str(tmp_path / "b"), "--gpus", "1"])
+    assert one.returncode == 0 and rep.returncode == 0, rep.stderr
+    a = open(str(tmp_path / "a") + ".pml.bpf", "rb").read()
+    assert a == open(str(tmp_path / "b") + ".pml.bpf", "rb").read() and len(a) > 100000
+    import torch
+    too_many = run(["query", "-i", IDX[mode], "-r", reads_path, "--no-output", "--gpus", str(torch.cuda.device_count() + 1)])
+    assert too_many.returncode == 1 and b"visible" in too_many.stderr
+    quiet = run(["query", "-i", IDX[mode], "-r", reads_path, "--no-output", "--verbose"])
+    assert quiet.returncode == 0 and quiet.stdout == b"" and b"400 reads are processed" in quiet.stderr
+    assert b"Stage times: parse" in quiet.stderr
+
+
+def test_logs_files(movi_bin, oracles, tmp_path):
+    """`movi query --logs`: <prefix>.scans / .fastforwards hold one `>id` line and one line of space-terminated per-base values
+    per read (output_logs, src/utils.cpp:268-289), in the BPF file's record order; .costs (a CPU strand's nanoseconds) is
+    written as zeros."""
+    from oracle import build_index as B
+    ref = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))[0][1]
+    reads_path = str(tmp_path / "lg.fa")
+    recs = dict(write_mixed_reads(reads_path, np.random.default_rng(23), ref, n=120))
+    prefix = str(tmp_path / "lg")
+    r = run(["query", "-i", IDX[6], "-r", reads_path, "-o", prefix, "--logs", "-s8", "-t1"])
+    assert r.returncode == 0, r.stderr
+    order = plan_order(reads_path, ["-s8", "-t1"])
+    files = {k: open(prefix + ".pml." + k, "rb").read().split(b"\n") for k in ("costs", "scans", "fastforwards")}
+    for k, lines in files.items():
+        assert lines[-1] == b"" and len(lines) == 2 * len(order) + 1, k
+        assert [l[1:] for l in lines[0:-1:2]] == order, k
+    for j, rid in enumerate(order):
+        eo, ef, es = oracles[6].pml_logs(recs[rid])
+        assert files["scans"][2 * j + 1] == b"".join(b"%d " % v for v in es)
+        assert files["fastforwards"][2 * j + 1] == b"".join(b"%d " % v for v in ef)
+        assert files["costs"][2 * j + 1] == b"0 " * len(eo)
+    # the PML file of a --logs run is the ordinary one
+    plain = run(["query", "-i", IDX[6], "-r", reads_path, "-o", str(tmp_path / "pl"), "-s8", "-t1"])
+    assert plain.returncode == 0
+    assert open(prefix + ".pml.bpf", "rb").read() == open(str(tmp_path / "pl") + ".pml.bpf", "rb").read()
+
+
+@pytest.mark.parametrize("mode", [6, 8])
 def test_separators_index_through_the_cli(movi_bin, tmp_path, mode):
     """`movi query` on a `movi build --separators` index (reference KAT sizes tests/test_build.cpp:79,95):
     --pml --stdout and --count lines against the oracle; '%' in a read is an illegal character."""

@@ -209,3 +209,26 @@ def test_replicated_index_through_rccl(built_lib, golden_image, tmp_path, mode):
     with pytest.raises(movi_amd.MoviError) as e:
         movi_amd.MoveIndex.replicate_image(img, [n_dev])
     assert e.value.code == -5
+
+
+@pytest.mark.parametrize("mode", [6, 8])
+def test_logs_per_base_fastforwards_and_scans(built_lib, golden_image, mode):
+    """movi_pml_logs_host (`movi query --logs`): per base, the fast-forwards of the LF to the next base and the rows the
+    base's reposition scanned, as MoveQuery::add_fastforward / add_scan collect them in the reference's strand scheduler
+    (src/read_processor.cpp:99-121, 586-596) -- against the oracle's restatement, read by read; their sums are the batch
+    counters of the ordinary query."""
+    import movi_amd
+    from oracle.oracle import Oracle
+    img = golden_image(mode)
+    gpu, cpu = movi_amd.MoveIndex.from_image(img), Oracle(img)
+    reads = mutated_reads(np.random.default_rng(9500 + mode), _ref(), 300, 1, 500) + [b"", b"A", b"N", b"AC", b"ACGTN" * 30]
+    bases, offs = pack(reads)
+    out, ff, sc, st = gpu.query_pml_logs_packed(bases, offs)
+    assert gpu.last_launch()["kernel"] == "pml_kernel<6, 0, 0>"
+    for i, r in enumerate(reads):
+        eo, ef, es = cpu.pml_logs(r)
+        a, b = int(offs[i]), int(offs[i + 1])
+        assert (out[a:b] == eo).all() and (ff[a:b] == ef).all() and (sc[a:b] == es).all(), i
+    plain, pst = gpu.query_pml_packed(bases, offs)
+    assert (plain == out).all() and st.scans == pst.scans == int(sc.astype(np.uint64).sum())
+    gpu.close()
