@@ -627,8 +627,19 @@ int replicate(const movi_index_desc_t *desc, const void *h_rows, const int *devi
                              : hipMemcpy(d_rows[0], h_rows, rows_bytes, hipMemcpyHostToDevice);
         if (e != hipSuccess) return hip_fail(e, "uploading the move rows");
     }
-    // ... and from there to every other GPU: one broadcast over xGMI, all ranks driven by this process
-    ncclResult_t r = g_rccl.CommInitAll(comms.data(), n, devices);
+    // ... and from there to every other GPU: one broadcast over xGMI, all ranks driven by this process.
+    // (librccl prints a version banner with printf when the first communicator comes up; the caller's stdout may be the
+    // query's output -- `movi query --stdout` -- so stdout points at stderr while RCCL initialises)
+    struct StdoutToStderr {
+        int saved = -1;
+        StdoutToStderr() { fflush(stdout); saved = dup(1); if (saved >= 0) dup2(2, 1); }
+        ~StdoutToStderr() { fflush(stdout); if (saved >= 0) { dup2(saved, 1); close(saved); } }
+    };
+    ncclResult_t r;
+    {
+        StdoutToStderr quiet;
+        r = g_rccl.CommInitAll(comms.data(), n, devices);
+    }
     if (r != ncclSuccess) return nccl_fail(r, "ncclCommInitAll");
     comms_up = true;
     r = g_rccl.GroupStart();

@@ -773,13 +773,14 @@ __device__ __forceinline__ uint2 win_sel(const uint2 (&w)[4], uint32_t q) {
 // segment's flag instead of err[] / zero-filling, and adds nothing to the global fast-forward / scan counters: which
 // part of its work belongs to the read's real walk is only known after K2); 2 = whole reads again, but only those in
 // seg.read_fail (K3).
-template <int MODE, typename IdxT, int HA, int CLS, int SEP, int REFILL, int SEG = 0>
+template <int MODE, typename IdxT, int HA, int CLS, int SEP, int REFILL, int SEG = 0, int STG = 0>
 __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8_t *__restrict__ bases,
                                                        const uint64_t *__restrict__ offs, uint64_t n_reads,
                                                        uint16_t *__restrict__ out, uint8_t *__restrict__ err,
                                                        DevStats *stats, const uint32_t *__restrict__ order,
                                                        ClsArgs cls, SegArgs seg) {
     static_assert(SEG == 0 || (CLS == 0 && REFILL == 0), "segments: plain PML, no refill");
+    static_assert(STG == 0 || (SEG == 0 && REFILL == 0), "reads staged through LDS: whole reads, no refill");
     enum : uint32_t { sFF = 0, sDown = 1, sUp = 2, sDone = 3, sLoad = 4 };   // sLoad (REFILL): first bases of a new read in flight
     __shared__ uint8_t s_code[256];
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = ix.code_of[i];
@@ -876,10 +877,12 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
     // 16 at a time from global memory (below), re-fetches a read's cache line for every 16 bases: its line is evicted
     // long before the lane comes back (0.0625 lines per base, 6 % of all line fetches of a big batch).  Layout: step k of
     // lane l at byte (k / 4) * 256 + 4 l + k % 4 -- lanes in step read consecutive banks.  Wavefronts with a longer read
-    // (and segments, and refilled lanes) keep the global path: the choice is wave-uniform.
+    // (and segments, and refilled lanes) keep the global path: the choice is wave-uniform.  STG is a template parameter
+    // so that launches that never stage -- long reads, small batches -- run exactly the loop they ran before (as a
+    // run-time flag alone the extra branch cost the 100 k x 10 kbp shape 2 %).
     extern __shared__ __align__(16) uint8_t s_stage[];
     bool staged = false;
-    if (!REFILL && SEG != 1 && ix.stage_lds != 0u) {
+    if (STG && ix.stage_lds != 0u) {
         staged = !wave_any(len > 256u);
         if (staged) {
             uint32_t *S = reinterpret_cast<uint32_t *>(s_stage);
@@ -1132,7 +1135,7 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
             }
             k += 1;
             if (lf) {
-                if (staged) {                             // wave-uniform
+                if (STG && staged) {                      // wave-uniform
                     a = s_code[s_stage[(k >> 2) * 256u + (threadIdx.x & 63u) * 4u + (k & 3u)]];
                 } else {
                     if ((k & 15) == 8) {
@@ -1820,7 +1823,7 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
                                                    seg_ws, cfg.pml_variant < 0 || cfg.pml_variant == 14, ragged_hint, &declined, cls,
                                                    seg_verdict);
         if (es == hipSuccess && !declined && info) {
-            snprintf(info->kernel, sizeof(info->kernel), "pml_kernel_flatp<6, %s, -1, 0, %d, 0, 1>",
+            snprintf(info->kernel, sizeof(info->kernel), "pml_kernel_flatp<6, %s, -1, 0, %d, 0, 1, 0>",
                      ix.idx32 ? "unsigned int" : "unsigned long", ix.sep ? 1 : 0);
             info->variant = 14; info->block_threads = 64; info->segmented = 1; info->idx64 = ix.idx32 ? 0 : 1;
             info->waves_per_cu = 0;
@@ -1851,7 +1854,7 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     // reads staged through LDS (pml_kernel_flatp): needs 256 bytes per lane of the one-wavefront block -- what the occupancy
     // cap's padding provides for caps of up to 9 wavefronts per CU.  cfg.stage_reads: 1 = when it fits (default), 0 = never
     DevIndex ixl = ix;
-    ixl.stage_lds = (cfg.stage_reads != 0 && bt == 64 && dyn_lds >= 16384 && v == 10) ? 256u : 0u;
+    ixl.stage_lds = (cfg.stage_reads != 0 && bt == 64 && dyn_lds >= 16384 && v == 10 && wp) ? 256u : 0u;
     const SegArgs no_seg;
     // every kernel that is handed more than 64 KiB of dynamic LDS must opt in first
 #define MOVI_SEG_0
@@ -1883,9 +1886,15 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
         if (ix.idx32) MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint32_t, H, C, S, R>);                         \
         else MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint64_t, H, C, S, R>);                                  \
     } while (0)
+#define MOVI_LAUNCH_FLATP_STG(M, C, S)                                                                      \
+    do {                                                                                                    \
+        if (ix.idx32) MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint32_t, -1, C, S, 0, 0, 1>);                  \
+        else MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint64_t, -1, C, S, 0, 0, 1>);                           \
+    } while (0)
 #define MOVI_LAUNCH_FLATP_R(M, C, S, R)                                                                     \
     do {                                                                                                    \
-        if (wp) MOVI_LAUNCH_FLATP_H(M, -1, C, S, R); else MOVI_LAUNCH_FLATP_H(M, MOVI_HA, C, S, R);         \
+        if (wp && R == 0 && ixl.stage_lds) MOVI_LAUNCH_FLATP_STG(M, C, S);                                  \
+        else if (wp) MOVI_LAUNCH_FLATP_H(M, -1, C, S, R); else MOVI_LAUNCH_FLATP_H(M, MOVI_HA, C, S, R);    \
     } while (0)
 #define MOVI_LAUNCH_FLATP_S(M, C, S)                                                                        \
     do {                                                                                                    \
@@ -1910,8 +1919,8 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
         const char *it = ix.idx32 ? "unsigned int" : "unsigned long";
         if (v == 0 || v == 1) snprintf(info->kernel, sizeof(info->kernel), "pml_kernel<6, %d, %d>", v, v == 0 ? 0 : cm);
         else if (v == 7) snprintf(info->kernel, sizeof(info->kernel), "pml_kernel_flat<6, %s, 0>", it);
-        else snprintf(info->kernel, sizeof(info->kernel), "pml_kernel_flatp<6, %s, %d, %d, %d, %d, 0>", it, wp ? -1 : MOVI_HA, cm,
-                      ix.sep ? 1 : 0, v == 13 ? 1 : 0);
+        else snprintf(info->kernel, sizeof(info->kernel), "pml_kernel_flatp<6, %s, %d, %d, %d, %d, 0, %d>", it, wp ? -1 : MOVI_HA, cm,
+                      ix.sep ? 1 : 0, v == 13 ? 1 : 0, (v == 10 && ixl.stage_lds) ? 1 : 0);
         info->variant = (v == 10 && wp) ? 14 : v;
         info->block_threads = bt; info->waves_per_cu = wpc; info->segmented = 0; info->idx64 = ix.idx32 ? 0 : 1;
         info->staged = ixl.stage_lds ? 1 : 0;
@@ -1925,6 +1934,7 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
 #undef MOVI_LAUNCH_FLATP
 #undef MOVI_LAUNCH_FLATP_S
 #undef MOVI_LAUNCH_FLATP_R
+#undef MOVI_LAUNCH_FLATP_STG
 #undef MOVI_LAUNCH_FLATP_H
 #undef MOVI_BY_CLS
     return hipGetLastError();

@@ -343,19 +343,21 @@ int run_query(const Options &o) {
     uint64_t reads_done = 0, bases_done = 0;
     double gpu_seconds = 0;
 
-    // Page-locked chunk buffers: with the reads and the result vector in page-locked memory the engine's *_host entry
-    // points cut a chunk into pieces whose upload, walk and download overlap (include/movi_hip.h).  Page-locking costs
-    // ~40 us per MB, once per buffer (three jobs circulate, grow-only): always worth it for the 2^25-base chunks of short
-    // reads (~100 MB per job), and for the GB-sized chunks of long reads when the input holds several of them.
+    // Page-locked chunk buffers (MOVI_PINNED=1): with the reads and the result vector in page-locked memory the engine's
+    // *_host entry points cut a call into pieces whose upload, walk and download overlap (include/movi_hip.h).  Measured
+    // in this command and NOT the default (profiles/r03_cli_path.txt): its chunks (2^25 bases of short reads, 2^15 long
+    // reads) are a quarter of what the overlapped path needs to pay -- each piece must still fill the GPU -- and a run makes
+    // a handful of calls, so the path's one-time set-up (six streams with staging) is never earned back: GPU calls of
+    // 1 M x 150 bp 0.021 s pageable, 0.084 s page-locked; 100 k x 10 kbp 0.15 s / 0.31 s.  The command's own pipeline
+    // (parse | GPU calls | order + write, three chunks in flight) already overlaps the transfers with the other stages.
     uint64_t input_bytes = 0;
     if (map.p != MAP_FAILED) input_bytes = map.n;
-    const bool pin_buffers = !std::getenv("MOVI_NO_PINNED") && (input_bytes == 0 || input_bytes >= (64ull << 20));
-    auto pin_this_chunk = [&](uint64_t chunk_bytes) {
-        return pin_buffers && (chunk_bytes <= (256ull << 20) || input_bytes >= 4 * chunk_bytes);
-    };
+    const bool pin_buffers = std::getenv("MOVI_PINNED") && std::string(std::getenv("MOVI_PINNED")) == "1";
+    auto pin_this_chunk = [&](uint64_t) { return pin_buffers; };
     Job jobs[3];
     HandOff<Job *> free_q, parsed_q, done_q;
-    if (pin_buffers && input_bytes && input_bytes / 3 <= (1ull << 30))   // short-read sized chunks: pinned from the start
+    (void)input_bytes;
+    if (pin_buffers)
         for (Job &j : jobs) j.rs.bases.set_allocator(pinned_alloc, pinned_free);
     for (Job &j : jobs) free_q.push(&j);
     double parse_seconds = 0, write_seconds = 0;
@@ -578,6 +580,11 @@ int run_query(const Options &o) {
     std::cerr << "[movi] " << reads_done << " reads are processed.\n";
     std::cerr << "[movi] Time measured for processing the reads: " << total << " s (" << bases_done << " bases; GPU calls "
               << gpu_seconds << " s)\n";
+    if (o.verbose) {
+        const BatchReader::PhaseTimes &pt = reader.phase_times();
+        std::cerr << "[movi] Parser phases: newline scan " << pt.prescan << " s, batch cut " << pt.cut << " s, lengths " << pt.lengths
+                  << " s, copy " << pt.copy << " s\n";
+    }
     if (o.verbose)                                                     // the three pipeline stages run side by side: the slowest one bounds the command
         std::cerr << "[movi] Stage times: parse " << parse_seconds << " s, GPU calls " << gpu_seconds << " s, order + write "
                   << write_seconds << " s (page-locked chunk buffers: " << (pin_buffers ? "yes" : "no") << ")\n";

@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <cctype>
+#include <chrono>
 #include <cstring>
 #include <queue>
 #include <stdexcept>
@@ -93,19 +94,12 @@ bool LineSource::fill() {
     return got > 0;
 }
 
-int LineSource::peek() {
+int LineSource::peek_slow() {
     if (pos_ == end_ && !fill()) { eof_ = true; return std::char_traits<char>::eof(); }
     return (unsigned char)data()[pos_];
 }
 
-bool LineSource::getline(const char *&p, size_t &n) {
-    if (nl_i_ < nl_.size()) {                                          // a newline found by prescan()
-        const size_t at = nl_[nl_i_++];
-        p = mem_ + pos_;
-        n = at - pos_;
-        pos_ = at + 1;
-        return true;
-    }
+bool LineSource::getline_slow(const char *&p, size_t &n) {
     for (;;) {
         const char *base = data() + pos_;
         const void *nl = std::memchr(base, '\n', end_ - pos_);
@@ -181,10 +175,16 @@ bool BatchReader::next_chunk(ReadSet &out, uint64_t max_bases, uint64_t min_read
     arena_.clear();
     lines_.clear();
     recs_.clear();
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now();
     if (!pool_) pool_.reset(new WorkerPool(threads_ ? threads_ : std::min(16u, std::max(1u, std::thread::hardware_concurrency()))));
     // the newlines of about a chunk's worth of input, found by all workers at once (the rest, if the chunk turns out
     // longer, line by line as before)
     if (mem_) src_.prescan((size_t)std::min<uint64_t>(max_bases + (max_bases >> 2) + (1u << 20), 1ull << 32), *pool_);
+    const double t_scanned = now();
+    times_.prescan += t_scanned - t_begin;
+    lines_.reserve(src_.prescanned_lines() + 1024);
+    recs_.reserve(src_.prescanned_lines() / 2 + 1024);
     // ---- phase 1 (sequential): batches, headers, where each read's sequence lines are
     bool any = false;
     uint64_t approx_bases = 0;                                         // sequence-line bytes, trailing whitespace included
@@ -222,6 +222,8 @@ bool BatchReader::next_chunk(ReadSet &out, uint64_t max_bases, uint64_t min_read
             recs_.push_back(r);
         }
     }
+    const double t_cut = now();
+    times_.cut += t_cut - t_scanned;
     if (!any) return false;
     // ---- phase 2 (parallel): id and stripped sequence lengths, then ids and bases copied to their final offsets
     const size_t n = recs_.size();
@@ -251,6 +253,8 @@ bool BatchReader::next_chunk(ReadSet &out, uint64_t max_bases, uint64_t min_read
         }
     });
     for (size_t i = 0; i < n; i++) { out.offsets[i + 1] += out.offsets[i]; out.id_off[i + 1] += out.id_off[i]; }
+    const double t_len = now();
+    times_.lengths += t_len - t_cut;
     const uint64_t total = out.offsets[n];
     out.bases.resize_uninitialized(total);                             // first touched by the workers below, in parallel
     out.id_bytes.resize_uninitialized(out.id_off[n]);
@@ -266,6 +270,7 @@ bool BatchReader::next_chunk(ReadSet &out, uint64_t max_bases, uint64_t min_read
             }
         }
     });
+    times_.copy += now() - t_len;
     return true;
 }
 

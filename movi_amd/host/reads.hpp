@@ -111,8 +111,21 @@ public:
     LineSource(const char *mem, size_t bytes) : mem_(mem), end_(bytes), drained_(true) {}
     bool stable() const { return mem_ != nullptr; }         // spans outlive the next call
     bool good() const { return !eof_; }
-    int peek();                                            // EOF sets the eof state, like istream::peek
-    bool getline(const char *&p, size_t &n);
+    int peek() {                                           // EOF sets the eof state, like istream::peek
+        if (pos_ < end_) return (unsigned char)data()[pos_];
+        return peek_slow();
+    }
+    bool getline(const char *&p, size_t &n) {
+        if (nl_i_ < nl_.size()) {                          // a newline found by prescan()
+            const size_t at = nl_[nl_i_++];
+            p = mem_ + pos_;
+            n = at - pos_;
+            pos_ = at + 1;
+            return true;
+        }
+        return getline_slow(p, n);
+    }
+    size_t prescanned_lines() const { return nl_.size() - nl_i_; }
     // memory form only: find the newlines of the next `bytes` bytes with `pool` (slices scanned in parallel); getline()
     // then takes them from the list instead of running memchr line by line
     void prescan(size_t bytes, WorkerPool &pool);
@@ -120,6 +133,8 @@ public:
 private:
     const char *data() const { return mem_ ? mem_ : buf_.data(); }
     bool fill();
+    int peek_slow();
+    bool getline_slow(const char *&p, size_t &n);
     std::istream *in_ = nullptr;
     const char *mem_ = nullptr;
     std::vector<char> buf_;
@@ -145,6 +160,9 @@ public:
     // Whole reference batches until `max_bases` bases are held -- and, for long reads, until `min_reads`
     // reads or `hard_max_bases` bases are (one GPU lane walks one read: a chunk needs reads, not bases).
     bool next_chunk(ReadSet &out, uint64_t max_bases, uint64_t min_reads = 0, uint64_t hard_max_bases = 0);
+    // seconds spent in the parser's phases so far (movi query --verbose, tools/parse_bench.cpp)
+    struct PhaseTimes { double prescan = 0, cut = 0, lengths = 0, copy = 0; };
+    const PhaseTimes &phase_times() const { return times_; }
 
 private:
     struct Span { size_t off, len; };
@@ -160,6 +178,7 @@ private:
     uint64_t size_hint_ = 0;
     unsigned threads_ = 0;              // 0 = hardware concurrency (at most 16)
     std::unique_ptr<WorkerPool> pool_;
+    PhaseTimes times_;
     int format_ = -1;                   // -1 unknown, 0 FASTA, 1 FASTQ
     uint32_t batch_counter_ = 0;
 };
