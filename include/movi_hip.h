@@ -307,7 +307,12 @@ int movi_host_unregister(void *p);
  * is cut into segments only if a probe of some of its reads finds that walks started mid-read fall into step within a
  * few hundred bases -- noisy long reads do, reads with 0.1 % errors and less do not and are better off with one lane
  * per read --; 0 = cut whatever the probe would say: a test hook; 2 = no probe, no length reduction, nothing read back:
- * "seg_verdict" (1 = cut, 0 = do not, the default) decides and the *_device calls stay asynchronous). */
+ * "seg_verdict" (1 = cut, 0 = do not, the default) decides and the *_device calls stay asynchronous), "kmer_k"
+ * (top-of-walk table: every walk starts in the same state, so its state after the last K bases of a read is a function
+ * of those K bases -- one 16-byte table lookup replaces the first K row gathers of every read and segment; left alone the
+ * first PML query on a DNA *-thresholds index builds the K = 12 table (256 MB, a few ms: that one call waits for it);
+ * 0 = no table, 1..12 = build that one now), "stage_reads" (1, the default: in big batches a wavefront whose reads
+ * all have at most 256 bases copies them into LDS once instead of re-fetching them 16 bases at a time; 0 = off: A/B). */
 int movi_set_option(movi_index_t *ix, const char *key, int64_t value);
 
 /* ---- ZML (Ziv-Merhav cross parse) ---------------------------------------------- */

@@ -115,8 +115,7 @@ SYMBOLS = {
 
 
 def lib_path():
-    # MOVI_HIP_LIB: an A/B build of the library (movi_amd/csrc/Makefile, target `split`); measurement only
-    return os.environ.get("MOVI_HIP_LIB") or os.path.join(_HERE, "lib", "libmovi_hip.so")
+    return os.path.join(_HERE, "lib", "libmovi_hip.so")
 
 
 _lib = None

@@ -94,6 +94,7 @@ struct movi_index {
     uint32_t *d_id_blocks = nullptr;
     uint64_t *d_ckpt = nullptr;      // built lazily by the first count query
     uint4 *d_kmer = nullptr;         // top-of-walk table ("kmer_k" option), 16 << 2K bytes
+    int kmer_auto = 12;              // K of the table the first PML query builds by itself (0 = none: "kmer_k" 0)
     DevStats *d_stats = nullptr;
     DevIndex dev{};
     int kmode = 0;                   // row layout the kernels run on: desc.mode, except 6 for sampled-thresholds (expanded)
@@ -725,6 +726,26 @@ int movi_index_destroy(movi_index_t *ix) {
     return MOVI_OK;
 }
 
+}  // extern "C"
+
+// Top-of-walk table (DevIndex::kmer): 16 << 2K bytes, filled by one kernel; the call waits for it -- chunks of the
+// overlapped host path walk on other streams.
+static bool kmer_eligible(const movi_index *ix) {
+    return ix->kmode == MOVI_MODE_REGULAR_THRESHOLDS && ix->dev.sigma - ix->dev.sep == 4 && ix->desc.r >= 8;
+}
+static int build_kmer(movi_index *ix, uint32_t K, hipStream_t s) {
+    const size_t bytes = (size_t)16 << (2 * K);
+    HIP_TRY(hipMalloc(&ix->d_kmer, bytes));
+    hipError_t e = build_kmer_table(ix->dev, K, ix->d_kmer, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { (void)hipFree(ix->d_kmer); ix->d_kmer = nullptr; return fail_hip(e, "building the top-of-walk table"); }
+    ix->dev.kmer = ix->d_kmer;
+    ix->dev.kmer_k = K;
+    return MOVI_OK;
+}
+
+extern "C" {
+
 int movi_index_get_desc(const movi_index_t *ix, movi_index_desc_t *desc) {
     if (!ix || !desc) return fail(MOVI_ERR_ARG, "NULL argument");
     *desc = ix->desc;
@@ -804,7 +825,7 @@ int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
         ix->cfg.stage_reads = (int)value;
         return MOVI_OK;
     }
-    if (!strcmp(key, "kmer_k")) {                            // top-of-walk table: 0 = none, else K in [1, 12]
+    if (!strcmp(key, "kmer_k")) {                            // top-of-walk table: 0 = none, K in [1, 12] = build it now
         if (value < 0 || value > 12) return fail(MOVI_ERR_ARG, "kmer_k must be in [0, 12]");
         HIP_TRY(hipSetDevice(ix->device));
         HIP_TRY(hipDeviceSynchronize());                     // no walk may be reading the table that goes away
@@ -812,17 +833,11 @@ int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
         ix->dev.kmer = nullptr;
         if (ix->d_kmer) (void)hipFree(ix->d_kmer);
         ix->d_kmer = nullptr;
+        ix->kmer_auto = 0;                                   // the caller's choice from here on
         if (value == 0) return MOVI_OK;
-        if (ix->kmode != MOVI_MODE_REGULAR_THRESHOLDS || ix->dev.sigma - ix->dev.sep != 4 || ix->desc.r < 8)
+        if (!kmer_eligible(ix))
             return fail(MOVI_ERR_ARG, "the top-of-walk table serves PML walks on DNA (ACGT) *-thresholds indexes only");
-        const size_t bytes = (size_t)16 << (2 * value);
-        HIP_TRY(hipMalloc(&ix->d_kmer, bytes));
-        hipError_t e = build_kmer_table(ix->dev, (uint32_t)value, ix->d_kmer, nullptr);
-        if (e == hipSuccess) e = hipDeviceSynchronize();
-        if (e != hipSuccess) { (void)hipFree(ix->d_kmer); ix->d_kmer = nullptr; return fail_hip(e, "building the top-of-walk table"); }
-        ix->dev.kmer = ix->d_kmer;
-        ix->dev.kmer_k = (uint32_t)value;
-        return MOVI_OK;
+        return build_kmer(ix, (uint32_t)value, nullptr);
     }
     if (!strcmp(key, "waves_per_cu")) {
         if (value < 0 || value > 32) return fail(MOVI_ERR_ARG, "waves_per_cu must be in [0,32]");
@@ -852,6 +867,10 @@ static int ml_device(bool zml, movi_index_t *ix, const uint8_t *d_bases, const u
     hipStream_t s = static_cast<hipStream_t>(stream);
     HIP_TRY(hipMemsetAsync(d_stats, 0, sizeof(DevStats), s));
     if (n_reads > 0xFFFFFFFFull) return fail(MOVI_ERR_ARG, "more than 2^32 reads in one call");
+    // the first PML query on an index that can have one builds the top-of-walk table (256 MB at K = 12, a few ms)
+    if (!zml && ix->kmer_auto > 0 && !ix->d_kmer && kmer_eligible(ix) && cls.log_ff == nullptr) {
+        if (int rck = build_kmer(ix, (uint32_t)ix->kmer_auto, s)) return rck;
+    }
     if (zml)
         HIP_TRY(launch_zml(ix->kmode, ix->dev, d_bases, d_offsets, n_reads, n_bases, d_out, d_read_err, d_stats,
                            d_read_order, ix->cfg, s, seg_ws, ragged_hint, seg_verdict, &ix->last_launch));

@@ -706,24 +706,11 @@ __global__ __launch_bounds__(256) void pml_kernel_flat(DevIndex ix, const uint8_
 template <int MODE>
 __device__ __forceinline__ void load_window(const uint8_t *rows, uint64_t wbase, uint2 (&w)[4]) {
     static_assert(MODE == 6 || MODE == 3, "queries run on 8-byte regular(-thresholds) rows only (the other types are expanded at upload)");
-#if defined(MOVI_SPLIT_WINDOW) && MOVI_SPLIT_WINDOW
-    // A/B build (make SPLIT=1): the window as FOUR 8-byte loads instead of two 16-byte ones.  The addresses are laundered
-    // through empty asm statements so that the compiler cannot prove them adjacent and merge the loads again.
-    uint64_t o1 = wbase * 8 + 8, o2 = wbase * 8 + 16, o3 = wbase * 8 + 24;   // (offsets, not pointers: those would lose their address space)
-    asm volatile("" : "+v"(o1));
-    asm volatile("" : "+v"(o2));
-    asm volatile("" : "+v"(o3));
-    w[0] = *reinterpret_cast<const uint2 *>(rows + wbase * 8);
-    w[1] = *reinterpret_cast<const uint2 *>(rows + o1);
-    w[2] = *reinterpret_cast<const uint2 *>(rows + o2);
-    w[3] = *reinterpret_cast<const uint2 *>(rows + o3);
-#else
     uint4 p0, p1;
     __builtin_memcpy(&p0, rows + wbase * 8, 16);
     __builtin_memcpy(&p1, rows + wbase * 8 + 16, 16);
     w[0] = make_uint2(p0.x, p0.y); w[1] = make_uint2(p0.z, p0.w);
     w[2] = make_uint2(p1.x, p1.y); w[3] = make_uint2(p1.z, p1.w);
-#endif
 }
 __device__ __forceinline__ uint2 win_sel(const uint2 (&w)[4], uint32_t q) {
     const uint2 lo = (q & 1u) ? w[1] : w[0];

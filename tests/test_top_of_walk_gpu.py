@@ -47,6 +47,7 @@ def test_top_of_walk_vs_oracle(built_lib, golden_image, mode, K):
     reads = _edge_reads(ref, np.random.default_rng(8800 + K), K)
     bases, offs = pack(reads)
     exp, ff, sc = cpu.pml_batch(bases, offs, threads=4)
+    gpu.set_option("kmer_k", 0)                                   # (left alone, the first PML query builds the K = 12 table)
     base_out, base_st = gpu.query_pml_packed(bases, offs)
     assert (base_out == exp).all()
     gpu.set_option("kmer_k", K)
@@ -129,6 +130,7 @@ def test_top_of_walk_with_corrupt_rows(built_lib, golden_image):
     gpu = movi_amd.MoveIndex.from_image(bytes(img))
     reads = mutated_reads(rng, _ref(), 400, 5, 300)
     bases, offs = pack(reads)
+    gpu.set_option("kmer_k", 0)
     e_out, e_st, e_err, e_rc = gpu.query_pml_packed(bases, offs, want_err=True)
     assert e_rc == -6 and e_st.errors > 50
     gpu.set_option("kmer_k", 6)
@@ -166,6 +168,7 @@ def test_reads_staged_through_lds_vs_oracle(built_lib, golden_image, mode):
     bases[(mut >= 0.02) & (mut < 0.023)] = ord("N")
     exp, ff, sc = cpu.pml_batch(bases, offs, threads=8)
     gpu.set_option("stage_reads", 0)
+    gpu.set_option("kmer_k", 0)
     out0, st0 = gpu.query_pml_packed(bases, offs)
     assert gpu.last_launch()["staged"] == 0 and gpu.last_launch()["waves_per_cu"] == 9
     assert (out0 == exp).all() and (st0.fast_forwards, st0.scans, st0.errors) == (ff, sc, 0)
@@ -182,4 +185,22 @@ def test_reads_staged_through_lds_vs_oracle(built_lib, golden_image, mode):
         gpu.set_option("pml_variant", -1)
         bins = gpu.classify_packed(bases, offs, 40, 4)
         assert all((x == y).all() for x, y in zip(bins, bins0)), K
+    gpu.close()
+
+
+def test_top_of_walk_table_is_the_default(built_lib, golden_image):
+    """Left alone, the first PML query on a DNA *-thresholds index builds the K = 12 table: fewer iterations, same answers;
+    count and ZML queries never build it."""
+    import movi_amd
+    from oracle.oracle import Oracle
+    img = golden_image(6)
+    gpu, cpu = movi_amd.MoveIndex.from_image(img), Oracle(img)
+    reads = mutated_reads(np.random.default_rng(8400), _ref(), 500, 30, 300)
+    bases, offs = pack(reads)
+    exp, ff, sc = cpu.pml_batch(bases, offs, threads=4)
+    out, st = gpu.query_pml_packed(bases, offs)
+    assert (out == exp).all() and (st.fast_forwards, st.scans, st.errors) == (ff, sc, 0)
+    gpu.set_option("kmer_k", 0)
+    out0, st0 = gpu.query_pml_packed(bases, offs)
+    assert (out0 == exp).all() and st.lane_steps < st0.lane_steps - 8 * len(reads)
     gpu.close()
