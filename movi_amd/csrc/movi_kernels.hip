@@ -857,7 +857,7 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
     uint4 pk = make_uint4(0, 0, 0, 0), pk_old = pk;
     if (CLS) cs.init(len, cls.bin_width);
     // ---- reads staged through LDS (ix.stage_lds: the launcher found the block's dynamic LDS -- the occupancy cap's
-    // padding, 16 KiB per one-wavefront block -- big enough): a wavefront whose reads all have at most 256 bases copies
+    // padding, 16 KiB per one-wavefront block -- big enough): a wavefront whose reads all have at most ix.stage_lds (256) bases copies
     // them into LDS once, at the start -- each lane its own read, 16 bytes per load from the read's end backwards, so the
     // 64 x 150 contiguous bytes of the wavefront's reads come in as whole cache lines, each fetched ONCE (the lines stay in
     // the CU's L1 over these back-to-back loads) -- and takes every base from there.  The walk's other way to its bases,
@@ -870,7 +870,7 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
     extern __shared__ __align__(16) uint8_t s_stage[];
     bool staged = false;
     if (STG && ix.stage_lds != 0u) {
-        staged = !wave_any(len > 256u);
+        staged = !wave_any(len > ix.stage_lds);
         if (staged) {
             uint32_t *S = reinterpret_cast<uint32_t *>(s_stage);
             const uint32_t sl = threadIdx.x & 63u;
@@ -1841,7 +1841,10 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     // reads staged through LDS (pml_kernel_flatp): needs 256 bytes per lane of the one-wavefront block -- what the occupancy
     // cap's padding provides for caps of up to 9 wavefronts per CU.  cfg.stage_reads: 1 = when it fits (default), 0 = never
     DevIndex ixl = ix;
-    ixl.stage_lds = (cfg.stage_reads != 0 && bt == 64 && dyn_lds >= 16384 && v == 10 && wp) ? 256u : 0u;
+    // (capacity per lane = what the padding leaves, a multiple of 16 up to 256 bases: a cap of 9 wavefronts per CU pads
+    // with exactly 16 KiB = 256 bases per lane, a cap of 12 with 12 KiB = 192)
+    const uint32_t stage_cap = (uint32_t)std::min<size_t>(256, (dyn_lds / 64) & ~(size_t)15);
+    ixl.stage_lds = (cfg.stage_reads != 0 && bt == 64 && stage_cap >= 128 && v == 10 && wp) ? stage_cap : 0u;
     const SegArgs no_seg;
     // every kernel that is handed more than 64 KiB of dynamic LDS must opt in first
 #define MOVI_SEG_0
