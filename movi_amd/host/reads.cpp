@@ -56,26 +56,33 @@ void WorkerPool::run(unsigned parts, const std::function<void(unsigned)> &fn) {
 
 void LineSource::prescan(size_t bytes, WorkerPool &pool) {
     if (!mem_) return;
-    if (nl_i_ == nl_.size()) { nl_.clear(); nl_i_ = 0; }
+    if (nl_i_ == nl_.size()) { nl_.clear(); nl_first_.clear(); nl_i_ = 0; }
     size_t from = nl_.empty() ? pos_ : nl_to_;
     if (from < pos_) from = pos_;
     const size_t to = std::min(end_, pos_ + bytes);
     if (to <= from) return;
     const unsigned T = (to - from) >= (1u << 22) ? pool.size() : 1;
     std::vector<std::vector<size_t>> part(T);
+    std::vector<std::vector<uint8_t>> part_first(T);
     pool.run(T, [&](unsigned t) {
         const size_t a = from + (to - from) * t / T, b = from + (to - from) * (t + 1) / T;
         std::vector<size_t> &v = part[t];
+        std::vector<uint8_t> &f = part_first[t];
         v.reserve((b - a) / 64 + 16);
-        const char *p = mem_ + a, *e = mem_ + b;
+        f.reserve((b - a) / 64 + 16);
+        const char *p = mem_ + a, *e = mem_ + b, *fin = mem_ + end_;
         while (p < e) {
             const void *q = std::memchr(p, '\n', (size_t)(e - p));
             if (!q) break;
-            v.push_back((size_t)(static_cast<const char *>(q) - mem_));
             p = static_cast<const char *>(q) + 1;
+            v.push_back((size_t)(p - 1 - mem_));
+            f.push_back(p < fin ? (uint8_t)*p : (uint8_t)0);
         }
     });
-    for (auto &v : part) nl_.insert(nl_.end(), v.begin(), v.end());
+    for (unsigned t = 0; t < T; t++) {
+        nl_.insert(nl_.end(), part[t].begin(), part[t].end());
+        nl_first_.insert(nl_first_.end(), part_first[t].begin(), part_first[t].end());
+    }
     nl_to_ = to;
 }
 
@@ -140,6 +147,7 @@ bool BatchReader::load_batch(size_t &first_line) {
     while (src_.good() && (bases < num_bases || reads < min_reads_)) {
         const char *p;
         size_t n;
+        const int first = src_.peek_first();               // this line's first character (EOF state untouched by the fast path)
         if (!src_.getline(p, n)) {
             if (format_ == 1 && nlines % 4 == 0) return valid || lines_.size() > first_line;
             if (format_ == 0 && nlines % 2 == 0) return valid || lines_.size() > first_line;
@@ -150,15 +158,18 @@ bool BatchReader::load_batch(size_t &first_line) {
         nlines++;
         record += n;
         valid = true;
+        const uint8_t fc = n ? (uint8_t)(first >= 0 ? first : p[0]) : (uint8_t)0;
+        if (n > 0xFFFFFFFFull) throw std::runtime_error("a line of the query file is longer than 4 GiB");
+        if (lines_.size() >= 0xFFFFFFF0ull) throw std::runtime_error("more than 2^32 lines in one chunk of the query file");
         if (mem_) {
-            lines_.push_back(Span{(size_t)(p - mem_), n});
+            lines_.push_back(Span{(uint64_t)(p - mem_), (uint32_t)n, fc});
         } else {
-            lines_.push_back(Span{arena_.size(), n});
+            lines_.push_back(Span{(uint64_t)arena_.size(), (uint32_t)n, fc});
             arena_.append(p, n);
         }
         if (format_ == 1) {
             if (nlines % 4 == 0) { bases += record / 2; record = 0; reads++; }
-        } else if (src_.peek() == '>') {
+        } else if (src_.peek_first() == '>') {
             bases += record; record = 0; reads++;
         }
     }
@@ -196,28 +207,28 @@ bool BatchReader::next_chunk(ReadSet &out, uint64_t max_bases, uint64_t min_read
         // grabNextRead over the batch (src/batch_loader.cpp:91-143)
         const size_t nl = lines_.size();
         while (p < nl) {
-            const char *hdr = line(p);
             const size_t hn = lines_[p].len;
+            const char h0 = (char)lines_[p].first;
             if (hn == 0) break;                                        // ":99 an empty line" ends the batch
-            if (format_ == 1 && hdr[0] != '@')
-                throw std::runtime_error(std::string("Incorrect FASTQ entry, it should start with '@' but found ") + hdr[0]);
-            if (format_ == 0 && hdr[0] != '>')
-                throw std::runtime_error(std::string("Incorrect FASTA entry, it should start with '>' but found ") + hdr[0]);
+            if (format_ == 1 && h0 != '@')
+                throw std::runtime_error(std::string("Incorrect FASTQ entry, it should start with '@' but found ") + h0);
+            if (format_ == 0 && h0 != '>')
+                throw std::runtime_error(std::string("Incorrect FASTA entry, it should start with '>' but found ") + h0);
             if (hn <= 2) throw std::runtime_error("header line is missing an id. invalid query cannot be processed.");
-            Rec r{p, p + 1, p + 1, b};
+            Rec r{(uint32_t)p, (uint32_t)(p + 1), (uint32_t)(p + 1), b};
             p++;
             if (format_ == 1) {
                 if (p >= nl) break;
                 if (p + 2 >= nl) break;                                // '+' line and qualities must exist
-                r.seq_end = p + 1;
+                r.seq_end = (uint32_t)(p + 1);
                 approx_bases += lines_[p].len;
                 p += 3;
             } else {
-                while (p < nl && (lines_[p].len == 0 || line(p)[0] != '>')) {
+                while (p < nl && (lines_[p].len == 0 || lines_[p].first != '>')) {
                     approx_bases += lines_[p].len;
                     p++;
                 }
-                r.seq_end = p;
+                r.seq_end = (uint32_t)p;
             }
             recs_.push_back(r);
         }

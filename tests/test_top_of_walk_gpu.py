@@ -105,13 +105,13 @@ def test_top_of_walk_on_a_separators_index(built_lib):
 def test_top_of_walk_refuses_what_it_cannot_serve(built_lib):
     import movi_amd
     from oracle import build_index as B
-    img = B.build_index_from_seqs([b"ACGGCAGCAGGACGACGGCAGCAGCGACGAGCGAGCGACGGCAGAC" * 20], 6)    # no T: 3-symbol alphabet
+    img = B.build_index_from_seqs([b"ATTATAATTTATATAATATTTAATAATTATATTTAAT" * 20], 6)    # A and T only (its reverse complement too): 2 symbols
     gpu = movi_amd.MoveIndex.from_image(img)
     with pytest.raises(movi_amd.MoviError):
         gpu.set_option("kmer_k", 8)
     with pytest.raises(movi_amd.MoviError):
         gpu.set_option("kmer_k", 13)
-    out, _ = gpu.query_pml_packed(*pack([b"ACGGCAGCAG"]))
+    out, _ = gpu.query_pml_packed(*pack([b"ATTATAATTT"]))
     assert out.size == 10
     gpu.close()
 
