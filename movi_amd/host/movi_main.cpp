@@ -519,9 +519,11 @@ int run_query(const Options &o) {
         // GPU and the PML vectors never cross PCIe
         const bool verdict_only = o.pml && o.classify && !o.write_output_allowed();   // PML only: ZML takes the host bins
         job.verdict_only = verdict_only;
-        job.bins_above.assign(verdict_only ? n : 0, 0);
-        job.bins_below.assign(verdict_only ? n : 0, 0);
-        job.bins_sum.assign(verdict_only ? n : 0, 0);
+        // (`--no-output` PML without classification borrows the verdict-only kernel: it walks and writes no vector at all)
+        const bool bins_scratch = verdict_only || (o.pml && !o.classify && !o.write_output_allowed());
+        job.bins_above.assign(bins_scratch ? n : 0, 0);
+        job.bins_below.assign(bins_scratch ? n : 0, 0);
+        job.bins_sum.assign(bins_scratch ? n : 0, 0);
         // `--no-output` without classification: the walk runs, nothing comes back (movi_pml_host with a NULL vector)
         const bool walk_only = o.ml() && !o.classify && !o.write_output_allowed();
         job.pml.ensure(o.ml() && !verdict_only && !walk_only ? rs.bases.size() : 0, pin_this_chunk(rs.bases.size() * 2));
@@ -536,9 +538,10 @@ int run_query(const Options &o) {
             const size_t a = sb[g], b = sb[g + 1];
             if (a == b) return;
             int rc;
-            if (verdict_only)
-                rc = movi_pml_classify_host(handles[g], rs.bases.data(), rs.offsets.data() + a, b - a, (uint32_t)o.bin_width,
-                                            classifier.max_value_thr, job.bins_above.data() + a, job.bins_below.data() + a,
+            if (verdict_only || (walk_only && o.pml))
+                rc = movi_pml_classify_host(handles[g], rs.bases.data(), rs.offsets.data() + a, b - a,
+                                            (uint32_t)(o.bin_width > 0 ? o.bin_width : 150), verdict_only ? classifier.max_value_thr : 1u,
+                                            job.bins_above.data() + a, job.bins_below.data() + a,
                                             job.bins_sum.data() + a, job.err.data() + a, nullptr);
             else if (o.pml && logs)
                 rc = movi_pml_logs_host(handles[g], rs.bases.data(), rs.offsets.data() + a, b - a, job.pml.data(), job.log_ff.data(),

@@ -2,6 +2,10 @@
 
 #include <algorithm>
 #include <cctype>
+#include <cstdio>
+#include <cstdlib>
+#include <pthread.h>
+#include <sched.h>
 #include <chrono>
 #include <cstring>
 #include <queue>
@@ -10,8 +14,51 @@
 
 namespace movi_host {
 
+// The hardware threads that share a last-level cache with the calling thread, from sysfs ("0-7,128-135"); empty if unknown.
+static std::vector<int> llc_siblings() {
+    std::vector<int> cpus;
+    const int cpu = sched_getcpu();
+    if (cpu < 0) return cpus;
+    char path[128];
+    snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu);
+    FILE *f = fopen(path, "r");
+    if (!f) return cpus;
+    char buf[4096];
+    if (fgets(buf, sizeof(buf), f)) {
+        for (char *p = buf; *p;) {
+            char *e;
+            long a = strtol(p, &e, 10), b = a;
+            if (e == p) break;
+            if (*e == '-') { p = e + 1; b = strtol(p, &e, 10); }
+            for (long c = a; c <= b && c < CPU_SETSIZE; c++) cpus.push_back((int)c);
+            p = (*e == ',') ? e + 1 : e;
+            if (*e != ',' ) break;
+        }
+    }
+    fclose(f);
+    return cpus;
+}
+
+// The pool's threads and the thread that owns it are kept on ONE last-level-cache domain.  The parser's sequential phase
+// writes the line and record tables that the workers read in the parallel phases and rewrites them for the next chunk:
+// with the workers spread over the sockets of a 2 x 64-core host every one of those rewrites first had to pull its cache
+// line back from another chiplet or socket, and the sequential phase ran 2 x slower with workers than without
+// (profiles/r03_cli_path.txt).  MOVI_NO_AFFINITY=1 leaves the threads where the scheduler puts them.
 WorkerPool::WorkerPool(unsigned threads) {
-    for (unsigned t = 1; t < threads; t++) th_.emplace_back([this] { loop(); });
+    std::vector<int> cpus;
+    if (threads > 1 && !getenv("MOVI_NO_AFFINITY")) cpus = llc_siblings();
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    for (int c : cpus) CPU_SET(c, &set);
+    const bool pin = cpus.size() >= 2;
+    if (pin) {
+        (void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
+        if (threads > cpus.size()) threads = (unsigned)cpus.size();
+    }
+    for (unsigned t = 1; t < threads; t++) {
+        th_.emplace_back([this] { loop(); });
+        if (pin) (void)pthread_setaffinity_np(th_.back().native_handle(), sizeof(set), &set);
+    }
 }
 
 WorkerPool::~WorkerPool() {
