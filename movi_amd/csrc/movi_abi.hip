@@ -869,7 +869,10 @@ static int ml_device(bool zml, movi_index_t *ix, const uint8_t *d_bases, const u
     if (n_reads > 0xFFFFFFFFull) return fail(MOVI_ERR_ARG, "more than 2^32 reads in one call");
     // the first PML query on an index that can have one builds the top-of-walk table (256 MB at K = 12, a few ms)
     if (!zml && ix->kmer_auto > 0 && !ix->d_kmer && kmer_eligible(ix) && cls.log_ff == nullptr) {
-        if (int rck = build_kmer(ix, (uint32_t)ix->kmer_auto, s)) return rck;
+        if (build_kmer(ix, (uint32_t)ix->kmer_auto, s) != MOVI_OK) {   // no room for it (or the device is in trouble, which the
+            (void)hipGetLastError();                                  // walk's own launch will report): walk without a table
+            ix->kmer_auto = 0;
+        }
     }
     if (zml)
         HIP_TRY(launch_zml(ix->kmode, ix->dev, d_bases, d_offsets, n_reads, n_bases, d_out, d_read_err, d_stats,

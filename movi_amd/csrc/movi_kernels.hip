@@ -1839,7 +1839,7 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
         if (bpc < 32) dyn_lds = ((163840u / (unsigned)bpc) & ~1023u) - 1024u;
     }
     // reads staged through LDS (pml_kernel_flatp): needs 256 bytes per lane of the one-wavefront block -- what the occupancy
-    // cap's padding provides for caps of up to 9 wavefronts per CU.  cfg.stage_reads: 1 = when it fits (default), 0 = never
+    // cap's padding provides for caps of up to 9 wavefronts per CU (the default cap is kCapWaves = 7).  cfg.stage_reads: 1 = when it fits (default), 0 = never
     DevIndex ixl = ix;
     // (capacity per lane = what the padding leaves, a multiple of 16 up to 256 bases: a cap of 9 wavefronts per CU pads
     // with exactly 16 KiB = 256 bases per lane, a cap of 12 with 12 KiB = 192)

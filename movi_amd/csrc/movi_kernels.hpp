@@ -64,7 +64,7 @@ struct DevStats {
     unsigned long long pad_;
 };
 
-constexpr int kCapWaves = 9;   // resident wavefronts per CU of the lane state machine on big batches (measured optimum: 8-10)
+constexpr int kCapWaves = 7;   // resident wavefronts per CU of the lane state machine on big batches (round 2: 9, optimum 8-10; round 3, with the reads staged in LDS and the top-of-walk table: 6-8, profiles/r03_occupancy_sweep.txt)
 
 struct LaunchCfg {
     int block_threads = 0;   // 0 = auto: 64 for the PML kernels (finest dispatch grain), 256 for count / ZML

@@ -59,7 +59,7 @@ def test_one_billion_row_table_vs_oracle(built_lib, mode):
     out, st = gpu.query_pml_packed(bases, offs)
     assert st.errors == 0 and st.bases == bases.size
     li = gpu.last_launch()
-    assert li["kernel"].startswith("pml_kernel_flatp<6, unsigned int") and li["idx64"] == 0 and li["waves_per_cu"] == 9
+    assert li["kernel"].startswith("pml_kernel_flatp<6, unsigned int") and li["idx64"] == 0 and li["waves_per_cu"] == 7
     # ---- count: the config-5 query
     m, c, cst = gpu.query_count_packed(bases, offs)
     assert cst.errors == 0

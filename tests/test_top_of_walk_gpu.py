@@ -170,7 +170,7 @@ def test_reads_staged_through_lds_vs_oracle(built_lib, golden_image, mode):
     gpu.set_option("stage_reads", 0)
     gpu.set_option("kmer_k", 0)
     out0, st0 = gpu.query_pml_packed(bases, offs)
-    assert gpu.last_launch()["staged"] == 0 and gpu.last_launch()["waves_per_cu"] == 9
+    assert gpu.last_launch()["staged"] == 0 and gpu.last_launch()["waves_per_cu"] == 7
     assert (out0 == exp).all() and (st0.fast_forwards, st0.scans, st0.errors) == (ff, sc, 0)
     bins0 = gpu.classify_packed(bases, offs, 40, 4)
     gpu.set_option("stage_reads", 1)

@@ -19,7 +19,7 @@ for R in /tmp/reads150.fa /tmp/reads10k.fa; do
   ls -la $R
   for flags in "--no-output" "-o /tmp/out_a" "-o /tmp/out_b -n" "--count -o /tmp/out_c"; do
     echo "== movi query -r $R $flags"
-    ( time ./movi_amd/bin/movi query -i $D -r $R --verbose $flags ) 2>&1 | grep -E "Time measured for processing|Stage times|real|Error"
+    ( time ./movi_amd/bin/movi query -i $D -r $R --verbose $flags ) 2>&1 | grep -E "Time measured for processing|Stage times|Parser phases|real|Error"
   done
 done
 ls -la /tmp/out_a.pml.bpf
