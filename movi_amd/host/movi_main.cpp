@@ -339,7 +339,11 @@ int run_query(const Options &o) {
     // READS to fill the lanes (2^25 bases of 150 bp reads = 224 k reads: more than the 147 k lanes the PML kernel keeps
     // resident) -- but the host stages (text parsing ~1.4 GB/s, BPF writing) are what bounds the command, and they only overlap
     // the GPU calls and each other across chunks: better several half-filled launches than one full one
-    const uint64_t chunk_bases = 1ull << 25, chunk_min_reads = 1ull << 15, chunk_hard_max = 1ull << 30;
+    uint64_t chunk_bases = 1ull << 25, chunk_min_reads = 1ull << 15, chunk_hard_max = 1ull << 30;
+    if (const char *e = std::getenv("MOVI_CHUNK_BASES")) {             // test hook: many small chunks
+        chunk_bases = std::max<uint64_t>(1, std::strtoull(e, nullptr, 10));
+        chunk_min_reads = 1;
+    }
     uint64_t reads_done = 0, bases_done = 0;
     double gpu_seconds = 0;
 
@@ -640,7 +644,9 @@ int run_plan(const Options &o) {
     std::unique_ptr<BatchReader> reader_ptr = open_reader(o.read_file, *in, o.prefetch ? 4 * o.strands : 1, map);
     BatchReader &reader = *reader_ptr;
     ReadSet rs;
-    while (reader.next_chunk(rs, 1ull << 28)) {
+    uint64_t plan_chunk = 1ull << 28;
+    if (const char *e = std::getenv("MOVI_CHUNK_BASES")) plan_chunk = std::max<uint64_t>(1, std::strtoull(e, nullptr, 10));   // test hook
+    while (reader.next_chunk(rs, plan_chunk)) {
         std::vector<uint64_t> cost(rs.size());
         for (size_t i = 0; i < rs.size(); i++) cost[i] = rs.len(i);
         std::vector<uint32_t> order;

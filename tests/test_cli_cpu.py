@@ -164,6 +164,11 @@ def test_parallel_mmap_parser_equals_stream_parser(movi_bin, tmp_path, fmt):
     c = run(["plan", "-r", "-", "-s16"], input=path.read_bytes())
     assert a.returncode == b.returncode == c.returncode == 0, (a.stderr, b.stderr, c.stderr)
     assert a.stdout == b.stdout == c.stdout and a.stdout.count(b"\n") == 14000
+    # the same file cut into many small chunks: the parallel newline scan then covers ~1 MB windows, so chunks, reference
+    # batches and lines straddle its windows (lines beyond a window are found the slow way) -- same plan, worker count or not
+    for env in (dict(MOVI_CHUNK_BASES="50000"), dict(MOVI_CHUNK_BASES="50000", MOVI_NO_AFFINITY="1"), dict(MOVI_CHUNK_BASES="7")):
+        d = run(["plan", "-r", str(path), "-s16"], env=dict(os.environ, **env))
+        assert d.returncode == 0 and d.stdout == a.stdout, env
     clean = [l[:-1] if l.endswith(b"\r") and not l.startswith((b">", b"@")) else l for l in lines]
     exp = reference_schedule(clean, fmt, 16, True)
     got = []
@@ -269,3 +274,18 @@ def test_malformed_inputs_fail_the_same_way_on_both_parser_paths(movi_bin, tmp_p
     empty = tmp_path / "empty.fa"
     empty.write_bytes(b"")
     assert run(["plan", "-r", str(empty)]).returncode == 0
+
+
+def test_lines_longer_than_the_newline_scan_window(movi_bin, tmp_path):
+    """A FASTA whose sequence lines are longer than the parser's scan-ahead window (2.5 MB single-line records between short
+    ones, chunks of 1000 bases): ids, lengths and order as the stream parser and as written."""
+    rng = np.random.default_rng(5)
+    lens = [10, 2_500_000, 33, 1_200_000, 1, 70, 3_000_001, 5]
+    recs = [(b"x%d" % i, bytes(rng.choice(list(b"ACGT"), size=L).astype(np.uint8))) for i, L in enumerate(lens)]
+    path = tmp_path / "long_lines.fa"
+    path.write_bytes(b"".join(b">" + i + b" c\n" + s + b"\n" for i, s in recs))
+    a = run(["plan", "-r", str(path), "-n"], env=dict(os.environ, MOVI_CHUNK_BASES="1000"))
+    b = run(["plan", "-r", str(path), "-n"], env=dict(os.environ, MOVI_NO_MMAP="1"))
+    assert a.returncode == 0 and a.stdout == b.stdout
+    got = [(l.split(b"\t")[1], int(l.rsplit(b"\t", 1)[1])) for l in a.stdout.split(b"\n") if l]
+    assert got == [(i + b" ", len(s)) for i, s in recs]
