@@ -95,6 +95,8 @@ struct movi_index {
     uint64_t *d_ckpt = nullptr;      // built lazily by the first count query
     uint4 *d_kmer = nullptr;         // top-of-walk table ("kmer_k" option), 16 << 2K bytes
     int kmer_auto = 12;              // K of the table the first PML query builds by itself (0 = none: "kmer_k" 0)
+    uint4 *d_ftab = nullptr;         // the count query's interval table ("ftab_k" option), 16 << 2K bytes
+    int ftab_auto = 12;              // K of the table the first count query builds by itself (0 = none)
     DevStats *d_stats = nullptr;
     DevIndex dev{};
     int kmode = 0;                   // row layout the kernels run on: desc.mode, except 6 for sampled-thresholds (expanded)
@@ -720,6 +722,7 @@ int movi_index_destroy(movi_index_t *ix) {
     if (ix->d_tally) (void)hipFree(ix->d_tally);
     if (ix->d_ckpt) (void)hipFree(ix->d_ckpt);
     if (ix->d_kmer) (void)hipFree(ix->d_kmer);
+    if (ix->d_ftab) (void)hipFree(ix->d_ftab);
     if (ix->d_stats) (void)hipFree(ix->d_stats);
     release_scratch(ix);
     delete ix;
@@ -741,6 +744,21 @@ static int build_kmer(movi_index *ix, uint32_t K, hipStream_t s) {
     if (e != hipSuccess) { (void)hipFree(ix->d_kmer); ix->d_kmer = nullptr; return fail_hip(e, "building the top-of-walk table"); }
     ix->dev.kmer = ix->d_kmer;
     ix->dev.kmer_k = K;
+    return MOVI_OK;
+}
+
+// The count query's interval table (DevIndex::ftab): any DNA index, thresholds or not.
+static bool ftab_eligible(const movi_index *ix) {
+    return (ix->kmode == MOVI_MODE_REGULAR_THRESHOLDS || ix->kmode == MOVI_MODE_REGULAR) && ix->dev.sigma - ix->dev.sep == 4;
+}
+static int build_ftab_table(movi_index *ix, uint32_t K, hipStream_t s) {
+    const size_t bytes = (size_t)16 << (2 * K);
+    HIP_TRY(hipMalloc(&ix->d_ftab, bytes));
+    hipError_t e = build_ftab(ix->kmode, ix->dev, K, ix->d_ftab, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { (void)hipFree(ix->d_ftab); ix->d_ftab = nullptr; return fail_hip(e, "building the count query's interval table"); }
+    ix->dev.ftab = ix->d_ftab;
+    ix->dev.ftab_k = K;
     return MOVI_OK;
 }
 
@@ -838,6 +856,19 @@ int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
         if (!kmer_eligible(ix))
             return fail(MOVI_ERR_ARG, "the top-of-walk table serves PML walks on DNA (ACGT) *-thresholds indexes only");
         return build_kmer(ix, (uint32_t)value, nullptr);
+    }
+    if (!strcmp(key, "ftab_k")) {                            // count query's interval table: 0 = none, K in [1, 12] = build it now
+        if (value < 0 || value > 12) return fail(MOVI_ERR_ARG, "ftab_k must be in [0, 12]");
+        HIP_TRY(hipSetDevice(ix->device));
+        HIP_TRY(hipDeviceSynchronize());
+        ix->dev.ftab_k = 0;
+        ix->dev.ftab = nullptr;
+        if (ix->d_ftab) (void)hipFree(ix->d_ftab);
+        ix->d_ftab = nullptr;
+        ix->ftab_auto = 0;
+        if (value == 0) return MOVI_OK;
+        if (!ftab_eligible(ix)) return fail(MOVI_ERR_ARG, "the count query's interval table serves DNA (ACGT) indexes only");
+        return build_ftab_table(ix, (uint32_t)value, nullptr);
     }
     if (!strcmp(key, "waves_per_cu")) {
         if (value < 0 || value > 32) return fail(MOVI_ERR_ARG, "waves_per_cu must be in [0,32]");
@@ -1529,6 +1560,9 @@ static int count_device(movi_index_t *ix, const uint8_t *d_bases, const uint64_t
     hipStream_t s = static_cast<hipStream_t>(stream);
     int rc = ensure_ckpt(ix, s);
     if (rc) return rc;
+    if (ix->ftab_auto > 0 && !ix->d_ftab && ftab_eligible(ix)) {       // the first count query builds the interval table
+        if (build_ftab_table(ix, (uint32_t)ix->ftab_auto, s) != MOVI_OK) { (void)hipGetLastError(); ix->ftab_auto = 0; }
+    }
     HIP_TRY(hipMemsetAsync(d_stats, 0, sizeof(DevStats), s));
     if (n_reads > 0xFFFFFFFFull) return fail(MOVI_ERR_ARG, "more than 2^32 reads in one call");
     HIP_TRY(launch_count(ix->kmode, ix->dev, d_bases, d_offsets, n_reads, d_matched, d_count,

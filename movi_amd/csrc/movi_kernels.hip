@@ -2031,6 +2031,56 @@ __device__ __forceinline__ uint64_t row_start(const DevIndex &ix, uint64_t k) {
     return p;
 }
 
+// Interval table of the count query (DevIndex::ftab): lane t runs the backward search of the K-mer whose i-th consumed base
+// (i = 0: the read's last base) has code (t >> 2 i) & 3 (+ 1 on a separators index) -- exactly count_kernel_v0's steps -- and
+// records the interval after K bases, if it is still non-empty.
+template <int MODE>
+__global__ __launch_bounds__(256) void ftab_kernel(DevIndex ix, uint32_t K, uint4 *__restrict__ table) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, n = 1ull << (2 * K);
+    const bool valid = t < n;
+    uint32_t ff_total = 0, scan_total = 0, failed = 0;
+    const uint32_t a = (uint32_t)(t & 3u) + ix.sep;
+    uint64_t rs = ix.first_runs[a + 1], re = ix.last_runs[a + 1];
+    uint32_t os = (uint32_t)ix.first_offsets[a + 1], oe = (uint32_t)ix.last_offsets[a + 1];
+    uint32_t run = (valid && ((rs < re) || (rs == re && os <= oe))) ? 1u : 0u;
+    uint2 rws = make_uint2(0, 0), rwe = make_uint2(0, 0);
+    if (run) {
+        rws = load_row<MODE>(ix.rows, rs);
+        rwe = load_row<MODE>(ix.rows, re);
+    }
+    for (uint32_t i = 1; i < K; ++i) {                    // K is wave-uniform
+        const bool act = run != 0u;
+        const uint32_t b = (uint32_t)((t >> (2 * i)) & 3u) + ix.sep;
+        if (ix.r >= 8) shrink_interval<MODE>(ix, act && rs <= re, b, rs, os, rws, re, oe, rwe, scan_total);
+        else shrink_interval_rows<MODE>(ix, act && rs <= re, b, rs, os, rws, re, oe, rwe, scan_total);
+        bool nonempty = act && ((rs < re) || (rs == re && os <= oe));
+        if (act && !nonempty) run = 0;
+        const uint32_t e12 = lf_step2<MODE>(ix, nonempty, rs, os, rws, re, oe, rwe, ff_total);
+        if (e12) { failed = e12; run = 0; nonempty = false; }
+        if (nonempty && !((rs < re) || (rs == re && os <= oe))) run = 0;
+    }
+    if (!valid) return;
+    const uint32_t ok = (uint32_t)(run != 0u && failed == 0u && ff_total < (1u << 15) && scan_total < (1u << 16) && os < 4096u && oe < 4096u);
+    uint4 e4 = make_uint4(0, 0, 0, 0);
+    if (ok) {
+        e4.x = (uint32_t)rs;
+        e4.y = (uint32_t)re;
+        e4.z = (uint32_t)(rs >> 32) | ((uint32_t)(re >> 32) << 4) | (os << 8) | (oe << 20);
+        e4.w = ff_total | (scan_total << 15) | (1u << 31);
+    }
+    table[t] = e4;
+}
+
+hipError_t build_ftab(int mode, const DevIndex &ix, uint32_t K, uint4 *d_table, hipStream_t stream) {
+    if (K < 1 || K > 12 || !d_table || ix.sigma - ix.sep != 4) return hipErrorInvalidValue;
+    const uint64_t n = 1ull << (2 * K);
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    if (mode == 6) hipLaunchKernelGGL(ftab_kernel<6>, grid, block, 0, stream, ix, K, d_table);
+    else if (mode == 3) hipLaunchKernelGGL(ftab_kernel<3>, grid, block, 0, stream, ix, K, d_table);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void count_kernel_v0(DevIndex ix, const uint8_t *__restrict__ bases,
                                                        const uint64_t *__restrict__ offs, uint64_t n_reads,
@@ -2062,6 +2112,30 @@ __global__ __launch_bounds__(256) void count_kernel_v0(DevIndex ix, const uint8_
             os = (uint32_t)ix.first_offsets[a + 1]; oe = (uint32_t)ix.last_offsets[a + 1];
             have = 1;
             run = ((rs < re) || (rs == re && os <= oe)) ? 1u : 0u;
+        }
+    }
+    // ---- interval table (DevIndex::ftab): the first K bases of the search by one lookup, when all K are legal and the
+    // K-mer occurs; anything else starts the ordinary way
+    if (ix.ftab_k != 0u) {                                // wave-uniform
+        const uint32_t K = ix.ftab_k;
+        uint32_t kidx = 0, bad = (uint32_t)(len < (int64_t)K);
+        for (uint32_t i = 0; i < K; ++i) {
+            const uint32_t cc = (bad ? 0xFFu : (uint32_t)s_code[R[len - 1 - (int64_t)i]]) - ix.sep;
+            bad |= (uint32_t)(cc > 3u);
+            kidx |= (cc & 3u) << (2u * i);
+        }
+        uint4 e4 = make_uint4(0, 0, 0, 0);
+        if (!bad) e4 = ix.ftab[kidx];
+        if (e4.w >> 31) {
+            rs = (uint64_t)e4.x | ((uint64_t)(e4.z & 15u) << 32);
+            re = (uint64_t)e4.y | ((uint64_t)((e4.z >> 4) & 15u) << 32);
+            os = (e4.z >> 8) & 0xFFFu;
+            oe = e4.z >> 20;
+            ff_total = e4.w & 0x7FFFu;
+            scan_total = (e4.w >> 15) & 0xFFFFu;
+            pos = len - (int64_t)K;
+            have = 1;
+            run = 1;
         }
     }
     prs = rs; pre = re; pos_ = os; poe = oe;

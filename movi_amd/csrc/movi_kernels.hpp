@@ -42,6 +42,14 @@ struct DevIndex {
     // towards base K, before its fast-forward), which of the K bases matched (their PMLs follow from that) and the
     // fast-forwards / scan rows the K steps took: one 16-byte lookup instead of K dependent row gathers.  The reference's
     // analogue is the ftab of its k-mer queries (src/move_structure_search.cpp:66-167, 203-259), there for intervals.
+    // The same idea for the count query (the reference's own ftab, src/move_structure_search.cpp:66-167, 203-259): the
+    // backward-search interval after the last K bases of a read is a function of those K bases.  ftab[code of the K-mer]:
+    // x = run_start[31:0]; y = run_end[31:0]; z = run_start[35:32] | run_end[35:32] << 4 | offset_start << 8 | offset_end << 20
+    // (12 bits each); w = fast-forwards (15 bits) | scan rows << 15 (16 bits) | valid << 31.  valid = 0: the interval of this K-mer
+    // is empty before K bases are consumed (or a step throws): such reads take the ordinary search from their last base.
+    uint32_t ftab_k;
+    uint32_t pad2_;
+    const uint4 *ftab;
     uint32_t stage_lds;           // set per launch by launch_pml: bytes of dynamic LDS per lane for read staging (0 = none, 256)
     uint32_t kmer_k;
     const uint4 *kmer;            // 4^K entries: x = row[31:0]; y = row[35:32] | off << 4 (12 bits) | match mask << 16 (K bits) |
@@ -191,6 +199,9 @@ hipError_t widen_rows(const uint8_t *d_packed, uint64_t r, uint32_t *d_wide, hip
 // Fills the 4^K entries of the top-of-walk table (DevIndex::kmer) by walking every K-mer from the start state with the
 // plain base-synchronous automaton.  ix.kmer / ix.kmer_k of `ix` are ignored; K in [1, 12]; thresholds types (kmode 6) only.
 hipError_t build_kmer_table(const DevIndex &ix, uint32_t K, uint4 *d_table, hipStream_t stream);
+
+// Fills the 4^K entries of the count query's interval table (DevIndex::ftab); mode = resident layout (6 or 3).
+hipError_t build_ftab(int mode, const DevIndex &ix, uint32_t K, uint4 *d_table, hipStream_t stream);
 
 // Fills ckpt[j] = BWT position of row (j << kPrefixShift), j = 0 .. ceil(r/32).
 hipError_t build_row_start_ckpt(int mode, const uint8_t *d_rows, uint64_t r, uint64_t *d_ckpt,

@@ -204,3 +204,50 @@ def test_top_of_walk_table_is_the_default(built_lib, golden_image):
     out0, st0 = gpu.query_pml_packed(bases, offs)
     assert (out0 == exp).all() and st.lane_steps < st0.lane_steps - 8 * len(reads)
     gpu.close()
+
+
+@pytest.mark.parametrize("mode", [6, 8, 3, 2])
+@pytest.mark.parametrize("K", [1, 5, 12])
+def test_count_interval_table_vs_oracle(built_lib, golden_image, mode, K):
+    """The count query's interval table ("ftab_k"; the reference's ftab, src/move_structure_search.cpp:66-167): the
+    backward-search interval after the last K bases of a read by one lookup.  matched / count and the fast-forward / scan
+    counters equal the oracle's for every K, with and without thresholds, for reads shorter than K, K-mers that do not
+    occur and illegal bases inside the K-mer."""
+    import movi_amd
+    from oracle import build_index as B
+    from oracle.oracle import Oracle
+    ref = _ref()
+    img = golden_image(mode) if mode in (6, 8) else B.build_index_from_seqs([ref], mode)
+    gpu, cpu = movi_amd.MoveIndex.from_image(img), Oracle(img)
+    rng = np.random.default_rng(8300 + 10 * mode + K)
+    reads = _edge_reads(ref, rng, K) + [bytes(rng.choice(list(b"ACGT"), size=40).astype(np.uint8)) for _ in range(200)]   # random 40-mers: mostly absent
+    bases, offs = pack(reads)
+    em, ec = cpu.count_batch(bases, offs, threads=4)
+    gpu.set_option("ftab_k", 0)
+    m0, c0, st0 = gpu.query_count_packed(bases, offs)
+    assert (m0 == em).all() and (c0 == ec).all()
+    gpu.set_option("ftab_k", K)
+    m, c, st = gpu.query_count_packed(bases, offs)
+    assert (m == em).all() and (c == ec).all(), (mode, K)
+    assert (st.fast_forwards, st.scans, st.errors) == (st0.fast_forwards, st0.scans, 0), (mode, K)
+    gpu.close()
+
+
+def test_count_interval_table_is_the_default_and_optional(built_lib):
+    import movi_amd
+    from oracle import build_index as B
+    from oracle.oracle import Oracle
+    ref = _ref()
+    img = B.build_index_from_seqs([ref[:50000], ref[50000:]], 6, separators=True)
+    gpu, cpu = movi_amd.MoveIndex.from_image(img), Oracle(img)
+    reads = mutated_reads(np.random.default_rng(8200), ref, 400, 5, 300) + [b"ACGT%ACGTACGTACGTACGT", bytes(ref[49990:50010])]
+    bases, offs = pack(reads)
+    em, ec = cpu.count_batch(bases, offs, threads=4)
+    m, c, _ = gpu.query_count_packed(bases, offs)           # left alone: the first count query builds the K = 12 table
+    assert (m == em).all() and (c == ec).all()
+    small = movi_amd.MoveIndex.from_image(B.build_index_from_seqs([b"ATTATAATTTATATAATATTTAATAATTATATTTAAT" * 20], 6))
+    with pytest.raises(movi_amd.MoviError):
+        small.set_option("ftab_k", 8)                       # two-symbol alphabet: no table
+    assert small.query_count([b"ATTATA"])[0][0] == 6
+    small.close()
+    gpu.close()
