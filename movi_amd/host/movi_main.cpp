@@ -221,13 +221,7 @@ private:
 struct InputMapping {
     void *p = MAP_FAILED;
     size_t n = 0;
-    std::thread ahead;                  // maps the file's pages into this process ahead of the parser (see open_reader)
-    std::atomic<bool> stop{false};
-    ~InputMapping() {
-        stop = true;
-        if (ahead.joinable()) ahead.join();
-        if (p != MAP_FAILED) munmap(p, n);
-    }
+    ~InputMapping() { if (p != MAP_FAILED) munmap(p, n); }
 };
 std::unique_ptr<BatchReader> open_reader(const std::string &path, std::istream &in, size_t min_reads, InputMapping &map) {
     if (path != "-" && !std::getenv("MOVI_NO_MMAP")) {
@@ -236,18 +230,9 @@ std::unique_ptr<BatchReader> open_reader(const std::string &path, std::istream &
         if (fd >= 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0) {
             map.n = (size_t)sb.st_size;
             map.p = mmap(nullptr, map.n, PROT_READ, MAP_PRIVATE, fd, 0);
-            if (map.p != MAP_FAILED) {
-                madvise(map.p, map.n, MADV_SEQUENTIAL);
-                // A fresh mapping costs the parser a minor fault per 64 KB it scans (half of its newline-scan time on a
-                // 160 MB file); one helper thread populates the page tables 16 MB at a time ahead of it instead.
-#ifdef MADV_POPULATE_READ
-                map.ahead = std::thread([&map] {
-                    const size_t step = 16u << 20;
-                    for (size_t off = 0; off < map.n && !map.stop; off += step)
-                        if (madvise(static_cast<char *>(map.p) + off, std::min(step, map.n - off), MADV_POPULATE_READ) != 0) break;
-                });
-#endif
-            }
+            // (populating the mapping ahead of the parser from a helper thread -- MADV_POPULATE_READ, 16 MB at a time -- was
+            // measured and dropped: it contends with the parser's own faults for the address-space lock; scan 14 -> 23 ms)
+            if (map.p != MAP_FAILED) madvise(map.p, map.n, MADV_SEQUENTIAL);
         }
         if (fd >= 0) close(fd);
     }
@@ -520,6 +505,27 @@ int run_query(const Options &o) {
             if (writer.joinable()) writer.join();
         }
     } joiner{free_q, done_q, parser, writer};
+
+    // ---- warm-up, while the parser works on the first chunk: a one-read query of the same kind on every handle, so that what
+    // a handle does once -- building the top-of-walk / interval table (256 MB, ~4 ms), the row-start checkpoints, loading the
+    // kernels' code objects, the first staging allocations -- is not paid inside the first chunk's call (1 M x 150 bp: 24 ms
+    // of the command's 30 ms of GPU calls were that first call; a steady-state call on a 2^25-base chunk takes 1.8 - 2.9 ms)
+    {
+        const uint8_t wb[32] = {'A','C','G','T','A','C','G','T','A','C','G','T','A','C','G','T','A','C','G','T','A','C','G','T','A','C','G','T','A','C','G','T'};
+        const uint64_t wo[2] = {0, 32};
+        uint16_t wp[32];
+        uint64_t wm = 0, wc = 0;
+        uint32_t wa = 0, wbl = 0;
+        uint64_t wsum = 0;
+        uint8_t we = 0;
+        for (auto *hd : handles) {                                     // (errors here are not the query's: the real calls report)
+            if (o.pml && o.classify && !o.write_output_allowed())
+                (void)movi_pml_classify_host(hd, wb, wo, 1, (uint32_t)o.bin_width, classifier.max_value_thr, &wa, &wbl, &wsum, &we, nullptr);
+            else if (o.pml) (void)movi_pml_host(hd, wb, wo, 1, wp, &we, nullptr);
+            else if (o.zml) (void)movi_zml_host(hd, wb, wo, 1, wp, &we, nullptr);
+            else (void)movi_count_host(hd, wb, wo, 1, &wm, &wc, &we, nullptr);
+        }
+    }
 
     // ---- stage 2: the GPU calls, in input order
     Job *jp = nullptr;
