@@ -312,7 +312,10 @@ int movi_host_unregister(void *p);
  * of those K bases -- one 16-byte table lookup replaces the first K row gathers of every read and segment; left alone the
  * first PML query on a DNA *-thresholds index builds the K = 12 table (256 MB, a few ms: that one call waits for it);
  * 0 = no table, 1..12 = build that one now), "stage_reads" (1, the default: in big batches a wavefront whose reads
- * all have at most 256 bases copies them into LDS once instead of re-fetching them 16 bases at a time; 0 = off: A/B). */
+ * all have at most 256 bases copies them into LDS once instead of re-fetching them 16 bases at a time; 0 = off: A/B),
+ * "ftab_k" (the count query's interval table -- the backward-search interval after the last K bases of a read by one lookup,
+ * the reference's own ftab (src/move_structure_search.cpp:66-167) put to work for --count; left alone the first count query
+ * on a DNA index builds the K = 12 table (256 MB); 0 = none, 1..12 = build that one now). */
 int movi_set_option(movi_index_t *ix, const char *key, int64_t value);
 
 /* ---- ZML (Ziv-Merhav cross parse) ---------------------------------------------- */
