@@ -179,8 +179,31 @@ def big_table_leg(torch, dev, stream, synth, movi_amd, cores, rows=1_000_000_000
         ok = ok and sst.fast_forwards == eff and sst.scans == esc and sst.errors == 0
         ok = ok and bool((d_out[: sb.size].cpu().numpy().view(np.uint16) == exp).all())
         checked += 2000
+    # BASELINE config 5's query on the same resident rows (a blocked-thresholds file of this table expands to exactly them at
+    # upload: tests/test_big_table_gpu.py runs that form): --count, timed and checked on the same three slices
+    d_m = torch.zeros(n_reads, dtype=torch.int64, device=dev)
+    d_c = torch.zeros(n_reads, dtype=torch.int64, device=dev)
+    runc = lambda: index.count_device(d_bases.data_ptr(), d_offs.data_ptr(), n_reads, n_bases, d_m.data_ptr(), d_c.data_ptr(),
+                                      d_err.data_ptr(), stream.cuda_stream, 0)
+    runc()
+    torch.cuda.synchronize()
+    tc0 = time.perf_counter()
+    for _ in range(5):
+        runc()
+    torch.cuda.synchronize()
+    dtc = time.perf_counter() - tc0
+    gm, gc = d_m.cpu().numpy().view(np.uint64), d_c.cpu().numpy().view(np.uint64)
+    cok = True
+    for lo in (0, n_reads // 2 - 1000, n_reads - 2000):
+        hi = lo + 2000
+        em, ec = cpu.count_batch(bases[int(offs[lo]): int(offs[hi])], offs[lo: hi + 1] - offs[lo], threads=cores)
+        cok = cok and bool((gm[lo:hi] == em).all() and (gc[lo:hi] == ec).all())
+    out["count"] = {"value": n_bases * 5 / dtc / 1e9, "unit": "Gbases/s (read bases)", "steps": 5, "ms_per_step": dtc / 5 * 1e3,
+                    "kernel": index.last_launch()["kernel"], "matched_bases_per_read": round(float(gm.mean()), 2),
+                    "parity_sample_ok": cok}
+    ok = ok and cok
     out["parity_sample_ok"] = ok
-    out["parity_sample"] = "reads [0,2000), [%d,%d), [%d,%d) vs oracle/movi_oracle.c on the same image: PMLs bit-exact, fast-forward and scan counters equal (%.1f s)" % (
+    out["parity_sample"] = "reads [0,2000), [%d,%d), [%d,%d) vs oracle/movi_oracle.c on the same image: PMLs bit-exact, fast-forward and scan counters equal; count: matched lengths and counts equal (%.1f s)" % (
         n_reads // 2 - 1000, n_reads // 2 + 1000, n_reads - 2000, n_reads, time.time() - t0)
     cpu.close()
     index.close()
