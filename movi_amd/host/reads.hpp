@@ -116,9 +116,9 @@ public:
         return peek_slow();
     }
     bool getline(const char *&p, size_t &n) {
-        if (nl_i_ < nl_.size()) {                          // a newline found by prescan()
-            const size_t at = nl_[nl_i_];
-            next_first_ = nl_first_[nl_i_++];              // ... and the byte behind it: the next line's first character
+        if (nl_i_ < cur_.nl.size() || next_window()) {     // a newline found by the scan-ahead
+            const size_t at = cur_.nl[nl_i_];
+            next_first_ = cur_.first[nl_i_++];             // ... and the byte behind it: the next line's first character
             p = mem_ + pos_;
             n = at - pos_;
             pos_ = at + 1;
@@ -128,14 +128,17 @@ public:
         have_next_first_ = false;
         return getline_slow(p, n);
     }
-    // first character of the line at the cursor without touching the input, when the prescan knows it (else peek())
+    // first character of the line at the cursor without touching the input, when the scan knows it (else peek())
     int peek_first() {
         if (have_next_first_ && pos_ < end_) return next_first_;
         return peek();
     }
-    size_t prescanned_lines() const { return nl_.size() - nl_i_; }
-    // memory form only: find the newlines of the next `bytes` bytes with `pool` (slices scanned in parallel); getline()
-    // then takes them from the list instead of running memchr line by line
+    size_t prescanned_lines() const { return cur_.nl.size() - nl_i_; }
+    ~LineSource();
+    // memory form only: newlines are found ahead of the parser, a window of `bytes` bytes at a time -- the first window by
+    // all workers of `pool` at once, every later one by a helper thread while the parser cuts, measures and copies the chunk
+    // before it (the helper also takes the page faults of a fresh file mapping off the parser's path); getline() then takes
+    // the line ends from the list instead of running memchr line by line
     void prescan(size_t bytes, WorkerPool &pool);
 
 private:
@@ -148,13 +151,19 @@ private:
     std::vector<char> buf_;
     size_t pos_ = 0, end_ = 0;
     bool eof_ = false, drained_ = false;
-    std::vector<size_t> nl_;            // newline offsets in [nl_from_, nl_to_), ascending; nl_i_ = next unused
-    std::vector<uint8_t> nl_first_;     // the byte after each of them (0 at the end of the input): the sequential batch
-                                        // cut then never touches the input itself -- reading one byte per line streamed
-                                        // most of the file through one core (15 ms per 160 MB)
+    // A scanned window of the input: newline offsets in [from, to), ascending, and the byte after each of them (0 at the end
+    // of the input): with those the sequential batch cut never touches the input itself -- reading one byte per line
+    // streamed most of the file through one core (15 ms per 160 MB).
+    struct Window { std::vector<size_t> nl; std::vector<uint8_t> first; size_t from = 0, to = 0; };
+    bool next_window();                 // cur_ is used up: adopt the window scanned ahead (waits for it), scan the one after
+    void scan_ahead();
+    Window cur_, next_;
+    std::thread scan_thread_;
+    bool next_pending_ = false;
+    size_t window_bytes_ = 0;
+    size_t nl_i_ = 0;                   // next unused entry of cur_
     uint8_t next_first_ = 0;
     bool have_next_first_ = false;
-    size_t nl_i_ = 0, nl_to_ = 0;
 };
 
 // Reads whole reference batches (BatchLoader::loadBatch) until a chunk is full.  Returns false when the input is
