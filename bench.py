@@ -326,7 +326,6 @@ def main():
     ap.add_argument("--seg-len", type=int, default=-1, help="PML: segment length of the segment-parallel long-read path "
                     "(-1 = the engine's default of 2048, 0 = off)")
     ap.add_argument("--kmer-k", type=int, default=-1, help="top-of-walk table: first K bases of every read by one lookup (A/B; -1 = the engine's default)")
-    ap.add_argument("--window-rows", type=int, default=-1, help="rows per window fetch of the PML kernel (A/B: 4 quad, 2 forward pair, 0 by table size)")
     ap.add_argument("--ftab-k", type=int, default=-1, help="count query's interval table: first K bases of the backward search by one lookup (A/B; -1 = the engine's default)")
     ap.add_argument("--stage-reads", type=int, default=-1, help="reads staged through LDS for short-read wavefronts (A/B: 0 off, 1 on; -1 = default)")
     ap.add_argument("--block-threads", type=int, default=0)
@@ -463,8 +462,6 @@ def main():
         index.set_option("stage_reads", args.stage_reads)
     if args.ftab_k >= 0:
         index.set_option("ftab_k", args.ftab_k)
-    if args.window_rows >= 0:
-        index.set_option("window_rows", args.window_rows)
     if args.block_threads:
         index.set_option("block_threads", args.block_threads)
     if args.waves_per_cu >= 0:

@@ -838,11 +838,6 @@ int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
         ix->cfg.seg_verdict = (int)value;
         return MOVI_OK;
     }
-    if (!strcmp(key, "window_rows")) {                       // A/B: 4 = quad window, 2 = forward pair, 0 = by table size
-        if (value != 0 && value != 2 && value != 4) return fail(MOVI_ERR_ARG, "window_rows must be 0, 2 or 4");
-        ix->cfg.window_rows = (int)value;
-        return MOVI_OK;
-    }
     if (!strcmp(key, "stage_reads")) {                       // A/B: reads of short-read wavefronts staged through LDS
         if (value != 0 && value != 1) return fail(MOVI_ERR_ARG, "stage_reads must be 0 or 1");
         ix->cfg.stage_reads = (int)value;

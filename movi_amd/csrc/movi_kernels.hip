@@ -760,7 +760,7 @@ __device__ __forceinline__ uint2 win_sel(const uint2 (&w)[4], uint32_t q) {
 // segment's flag instead of err[] / zero-filling, and adds nothing to the global fast-forward / scan counters: which
 // part of its work belongs to the read's real walk is only known after K2); 2 = whole reads again, but only those in
 // seg.read_fail (K3).
-template <int MODE, typename IdxT, int HA, int CLS, int SEP, int REFILL, int SEG = 0, int STG = 0, int WR = 4>
+template <int MODE, typename IdxT, int HA, int CLS, int SEP, int REFILL, int SEG = 0, int STG = 0>
 __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8_t *__restrict__ bases,
                                                        const uint64_t *__restrict__ offs, uint64_t n_reads,
                                                        uint16_t *__restrict__ out, uint8_t *__restrict__ err,
@@ -768,11 +768,6 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
                                                        ClsArgs cls, SegArgs seg) {
     static_assert(SEG == 0 || (CLS == 0 && REFILL == 0), "segments: plain PML, no refill");
     static_assert(STG == 0 || (SEG == 0 && REFILL == 0), "reads staged through LDS: whole reads, no refill");
-    // WR = rows per window.  4: the aligned quad, two 16-byte loads (the default).  2 ("pair window", tables far beyond the TLB
-    // reach): the row and the one after it, two 8-byte loads -- on an 8 GB table a 16-byte gather costs three address
-    // translations and an 8-byte one a single one, and the L2 TLB's request rate is what bounds the walk there
-    // (profiles/r03_c4_tlb.txt); fast-forwards only go forwards, so the pair starts AT the row.
-    static_assert(WR == 4 || (WR == 2 && HA < 0 && SEG == 0 && REFILL == 0), "the pair window: window-parallel whole-read walks");
     enum : uint32_t { sFF = 0, sDown = 1, sUp = 2, sDone = 3, sLoad = 4 };   // sLoad (REFILL): first bases of a new read in flight
     __shared__ uint8_t s_code[256];
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = ix.code_of[i];
@@ -822,25 +817,13 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
     // The 4-row window that holds row nd: aligned, except that the table's last window is pulled back to
     // rows [r-4, r) so that the fetch never leaves the table and needs no special case (r >= 4, checked at
     // launch).  Unpredicated: finished lanes re-read window 0 (a cache hit) instead of branching around the load.
-    const IdxT wb_last = (IdxT)(ix.r - WR);
+    const IdxT wb_last = (IdxT)(ix.r - 4);
     auto win_base = [&](IdxT nd) -> IdxT {
-        const IdxT wb = WR == 4 ? (nd & ~(IdxT)3) : nd;
+        const IdxT wb = nd & ~(IdxT)3;
         return wb < wb_last ? wb : wb_last;
     };
     auto fetch = [&](IdxT nd, bool act, uint2 (&w)[4]) {
-        if (WR == 4) {
-            load_window<MODE>(ix.rows, (uint64_t)(act ? win_base(nd) : (IdxT)0), w);
-        } else {
-            // two 8-byte loads; the second address goes through an empty asm statement so that the compiler cannot prove the
-            // two adjacent and merge them into one 16-byte load again
-            const uint64_t o0 = (uint64_t)(act ? win_base(nd) : (IdxT)0) * 8;
-            uint64_t o1 = o0 + 8;
-            asm volatile("" : "+v"(o1));
-            w[0] = *reinterpret_cast<const uint2 *>(ix.rows + o0);
-            w[1] = *reinterpret_cast<const uint2 *>(ix.rows + o1);
-            w[2] = w[0];
-            w[3] = w[0];
-        }
+        load_window<MODE>(ix.rows, (uint64_t)(act ? win_base(nd) : (IdxT)0), w);
     };
     // end of a read: what the reference's exception / output paths do with it
     ClsState cs;
@@ -986,7 +969,7 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
         // starts a scan, ends one or fails is left to the full step below)
         auto hop = [&]() {
             const uint32_t q = (uint32_t)(need - wbase);
-            const uint32_t inwin = (uint32_t)(q < (uint32_t)WR) & (uint32_t)(st < sDone);
+            const uint32_t inwin = (uint32_t)(q < 4u) & (uint32_t)(st < sDone);
             const uint2 hr = win_sel(w, q);
             const uint32_t hn = row_n<MODE>(hr), hc = row_c<MODE>(hr);
             const uint32_t ffh = inwin & (uint32_t)(st == sFF) & (uint32_t)(need < r1) & (uint32_t)(off >= hn) &
@@ -1005,30 +988,6 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
         // passes the leading run of non-matching rows from its position (a 4-bit mask and a count-trailing / leading-ones).
         // Same state afterwards as four hop() calls -- identical answers and counts -- at a third of the dependency depth.
         auto window_advance = [&]() {
-            if (WR == 2) {
-                // the same closed forms over two rows: q0 is 0 except in the table's last pair (pulled back to rows [r-2, r))
-                const uint32_t q0 = (uint32_t)(need - wbase);
-                const uint32_t inwin = (uint32_t)(q0 < 2u) & (uint32_t)(st < sDone);
-                const uint32_t n0 = row_n<MODE>(w[0]), n1 = row_n<MODE>(w[1]);
-                const uint32_t last_win = (uint32_t)(wbase + 1 == r1), first_win = (uint32_t)(wbase == 0);
-                const uint32_t m0 = q0 == 0u;
-                const uint32_t t1 = m0 ? n0 : 0u, t2 = t1 + n1;
-                const uint32_t isff = inwin & (uint32_t)(st == sFF);
-                const uint32_t p0 = isff & m0 & (uint32_t)(off >= t1), p1 = isff & (uint32_t)(off >= t2) & (last_win ^ 1u);
-                const uint32_t cf = p0 + p1;
-                off -= (p1 ? t2 : (p0 ? t1 : 0u));
-                ff_run += cf;
-                const uint32_t nm = (uint32_t)(row_c<MODE>(w[0]) != a) | ((uint32_t)(row_c<MODE>(w[1]) != a) << 1);
-                // down: leading run of non-matching rows from q0 upwards; row r-1 is never passed
-                const uint32_t dmask = (nm & (last_win ? 1u : 3u)) >> (q0 & 1u);
-                const uint32_t cd = (inwin & (uint32_t)(st == sDown)) ? (uint32_t)__builtin_ctz(~dmask | 4u) : 0u;
-                // up: from q0 downwards; row 0 is never passed (q0 = 1 only in the last pair)
-                const uint32_t um = nm & (first_win ? 2u : 3u);
-                const uint32_t cu = (inwin & (uint32_t)(st == sUp)) ? (q0 ? (((um >> 1) & 1u) ? 1u + (um & 1u) : 0u) : (um & 1u)) : 0u;
-                scan_total += cd + cu;
-                need = need + (IdxT)(cf + cd) - (IdxT)cu;
-                return;
-            }
             const uint32_t q0 = (uint32_t)(need - wbase);
             const uint32_t inwin = (uint32_t)(q0 < 4u) & (uint32_t)(st < sDone);
             const uint32_t n0 = row_n<MODE>(w[0]), n1 = row_n<MODE>(w[1]), n2 = row_n<MODE>(w[2]), n3 = row_n<MODE>(w[3]);
@@ -1064,7 +1023,7 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
             window_advance();
         }
         const uint32_t qn = (uint32_t)(need - wbase);
-        const uint32_t inwin = (uint32_t)(qn < (uint32_t)WR) & (uint32_t)act;
+        const uint32_t inwin = (uint32_t)(qn < 4u) & (uint32_t)act;
         const uint2 row = win_sel(w, qn);
         const uint32_t n = row_n<MODE>(row), c = row_c<MODE>(row), roff = row_off<MODE>(row);
         const uint32_t isFF = (uint32_t)(st == sFF) & inwin, isDown = (uint32_t)(st == sDown) & inwin,
@@ -1851,7 +1810,7 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
                                                    seg_ws, cfg.pml_variant < 0 || cfg.pml_variant == 14, ragged_hint, &declined, cls,
                                                    seg_verdict);
         if (es == hipSuccess && !declined && info) {
-            snprintf(info->kernel, sizeof(info->kernel), "pml_kernel_flatp<6, %s, -1, 0, %d, 0, 1, 0, 4>",
+            snprintf(info->kernel, sizeof(info->kernel), "pml_kernel_flatp<6, %s, -1, 0, %d, 0, 1, 0>",
                      ix.idx32 ? "unsigned int" : "unsigned long", ix.sep ? 1 : 0);
             info->variant = 14; info->block_threads = 64; info->segmented = 1; info->idx64 = ix.idx32 ? 0 : 1;
             info->waves_per_cu = 0;
@@ -1886,9 +1845,6 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     // with exactly 16 KiB = 256 bases per lane, a cap of 12 with 12 KiB = 192)
     const uint32_t stage_cap = (uint32_t)std::min<size_t>(256, (dyn_lds / 64) & ~(size_t)15);
     ixl.stage_lds = (cfg.stage_reads != 0 && bt == 64 && stage_cap >= 128 && v == 10 && wp) ? stage_cap : 0u;
-    // pair window (WR = 2): cfg.window_rows 2 = always, 4 = never, 0 = auto (tables beyond kPairWindowBytes)
-    const bool pair_window = v == 10 && wp && !ix.sep && ix.r >= 8 &&
-                             (cfg.window_rows == 2 || (cfg.window_rows == 0 && ix.r * 8ull > kPairWindowBytes));
     const SegArgs no_seg;
     // every kernel that is handed more than 64 KiB of dynamic LDS must opt in first
 #define MOVI_SEG_0
@@ -1925,20 +1881,9 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
         if (ix.idx32) MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint32_t, -1, C, S, 0, 0, 1>);                  \
         else MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint64_t, -1, C, S, 0, 0, 1>);                           \
     } while (0)
-#define MOVI_LAUNCH_FLATP_W2(M, C)                                                                          \
-    do {                                                                                                    \
-        if (ixl.stage_lds) {                                                                                \
-            if (ix.idx32) MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint32_t, -1, C, 0, 0, 0, 1, 2>);           \
-            else MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint64_t, -1, C, 0, 0, 0, 1, 2>);                    \
-        } else {                                                                                            \
-            if (ix.idx32) MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint32_t, -1, C, 0, 0, 0, 0, 2>);           \
-            else MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint64_t, -1, C, 0, 0, 0, 0, 2>);                    \
-        }                                                                                                   \
-    } while (0)
 #define MOVI_LAUNCH_FLATP_R(M, C, S, R)                                                                     \
     do {                                                                                                    \
-        if (wp && R == 0 && S == 0 && pair_window) MOVI_LAUNCH_FLATP_W2(M, C);                              \
-        else if (wp && R == 0 && ixl.stage_lds) MOVI_LAUNCH_FLATP_STG(M, C, S);                             \
+        if (wp && R == 0 && ixl.stage_lds) MOVI_LAUNCH_FLATP_STG(M, C, S);                                  \
         else if (wp) MOVI_LAUNCH_FLATP_H(M, -1, C, S, R); else MOVI_LAUNCH_FLATP_H(M, MOVI_HA, C, S, R);    \
     } while (0)
 #define MOVI_LAUNCH_FLATP_S(M, C, S)                                                                        \
@@ -1964,8 +1909,8 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
         const char *it = ix.idx32 ? "unsigned int" : "unsigned long";
         if (v == 0 || v == 1) snprintf(info->kernel, sizeof(info->kernel), "pml_kernel<6, %d, %d>", v, v == 0 ? 0 : cm);
         else if (v == 7) snprintf(info->kernel, sizeof(info->kernel), "pml_kernel_flat<6, %s, 0>", it);
-        else snprintf(info->kernel, sizeof(info->kernel), "pml_kernel_flatp<6, %s, %d, %d, %d, %d, 0, %d, %d>", it, wp ? -1 : MOVI_HA, cm,
-                      ix.sep ? 1 : 0, v == 13 ? 1 : 0, (v == 10 && wp && ixl.stage_lds) ? 1 : 0, pair_window ? 2 : 4);
+        else snprintf(info->kernel, sizeof(info->kernel), "pml_kernel_flatp<6, %s, %d, %d, %d, %d, 0, %d>", it, wp ? -1 : MOVI_HA, cm,
+                      ix.sep ? 1 : 0, v == 13 ? 1 : 0, (v == 10 && ixl.stage_lds) ? 1 : 0);
         info->variant = (v == 10 && wp) ? 14 : v;
         info->block_threads = bt; info->waves_per_cu = wpc; info->segmented = 0; info->idx64 = ix.idx32 ? 0 : 1;
         info->staged = ixl.stage_lds ? 1 : 0;
@@ -1980,7 +1925,6 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
 #undef MOVI_LAUNCH_FLATP_S
 #undef MOVI_LAUNCH_FLATP_R
 #undef MOVI_LAUNCH_FLATP_STG
-#undef MOVI_LAUNCH_FLATP_W2
 #undef MOVI_LAUNCH_FLATP_H
 #undef MOVI_BY_CLS
     return hipGetLastError();

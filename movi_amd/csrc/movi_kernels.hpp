@@ -72,7 +72,6 @@ struct DevStats {
     unsigned long long pad_;
 };
 
-constexpr unsigned long long kPairWindowBytes = 1ull << 62;   // auto policy for the pair window: never (until measured)
 constexpr int kCapWaves = 7;   // resident wavefronts per CU of the lane state machine on big batches (round 2: 9, optimum 8-10; round 3, with the reads staged in LDS and the top-of-walk table: 6-8, profiles/r03_occupancy_sweep.txt)
 
 struct LaunchCfg {
@@ -89,8 +88,6 @@ struct LaunchCfg {
                            // 2 = no probe and no read-back at all, the caller's seg_verdict decides: the launch stays asynchronous)
     int seg_verdict = 0;   // seg_probe == 2: 1 = cut eligible batches, 0 = one lane per read
     int stage_reads = 1;   // big batches of short reads: reads staged through LDS (0 = off: A/B)
-    int window_rows = 4;   // rows per fetch of the lane state machine: 4 = aligned quad (two 16-byte loads), 2 = forward pair (two
-                           // 8-byte loads: fewer address translations on tables far beyond the TLB reach), 0 = by table size
     int refill_blocks = 0; // variant 13: size of the persistent grid in blocks; 0 = num_cus x waves per CU (tests shrink it
                            // so that a few hundred reads already go through many refills per lane)
 };

@@ -251,75 +251,3 @@ def test_count_interval_table_is_the_default_and_optional(built_lib):
     assert small.query_count([b"ATTATA"])[0][0] == 6
     small.close()
     gpu.close()
-
-
-@pytest.mark.parametrize("mode", [6, 8, 7])
-def test_pair_window_vs_oracle(built_lib, golden_image, mode):
-    """"window_rows" = 2: the lane state machine fetches the row and the one after it as two 8-byte loads instead of the aligned
-    quad as two 16-byte loads (fewer address translations on tables far beyond the TLB reach).  Same PMLs, error bytes and
-    counters as the oracle: small batches, a big staged batch, with and without the top-of-walk table, fused bins, the 64-bit
-    row-index kernels, reads that end at the table's first and last rows."""
-    import movi_amd
-    from oracle import build_index as B
-    from oracle.oracle import Oracle
-    ref = _ref()
-    img = golden_image(mode) if mode != 7 else B.build_index_from_seqs([ref], 7)
-    gpu, cpu = movi_amd.MoveIndex.from_image(img), Oracle(img)
-    rng = np.random.default_rng(8100 + mode)
-    reads = _edge_reads(ref, rng, 12) + mutated_reads(rng, ref, 300, 1, 600) + [b"A" * 300, b"T" * 300, b"ACGT" * 100, b"$", b"TTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTN"]
-    bases, offs = pack(reads)
-    exp, ff, sc = cpu.pml_batch(bases, offs, threads=4)
-    gpu.set_option("kmer_k", 0)
-    gpu.set_option("window_rows", 4)
-    out4, st4 = gpu.query_pml_packed(bases, offs)
-    bins4 = gpu.classify_packed(bases, offs, 40, 4)
-    assert (out4 == exp).all()
-    gpu.set_option("window_rows", 2)
-    for K in (0, 12):
-        gpu.set_option("kmer_k", K)
-        for idx64 in (0, 1):
-            gpu.set_option("idx64", idx64)
-            out, st = gpu.query_pml_packed(bases, offs)
-            assert gpu.last_launch()["kernel"].endswith(", 2>"), gpu.last_launch()
-            assert (out == exp).all(), (mode, K, idx64)
-            assert (st.fast_forwards, st.scans, st.repositions, st.errors) == (ff, sc, st4.repositions, 0), (mode, K, idx64)
-        gpu.set_option("idx64", 0)
-        bins = gpu.classify_packed(bases, offs, 40, 4)
-        assert all((x == y).all() for x, y in zip(bins, bins4)), K
-    # more iterations than with the quad (that is the price), fewer wide loads
-    assert st.lane_steps >= st4.lane_steps - 13 * len(reads)
-    # a big batch: capped launch, reads staged through LDS, pair window
-    n = 300_000
-    lens = rng.integers(0, 200, n).astype(np.uint64)
-    starts = rng.integers(0, len(ref) - 300, n)
-    o2 = np.zeros(n + 1, np.uint64)
-    np.cumsum(lens, out=o2[1:])
-    refa = np.frombuffer(ref, np.uint8)
-    idx = np.repeat(starts.astype(np.int64) - o2[:-1].astype(np.int64), lens.astype(np.int64)) + np.arange(int(o2[-1]), dtype=np.int64)
-    b2 = refa[idx].copy()
-    mut = rng.random(b2.size)
-    b2[mut < 0.03] = np.frombuffer(b"ACGTN", np.uint8)[rng.integers(0, 5, int((mut < 0.03).sum()))]
-    e2, f2, s2 = cpu.pml_batch(b2, o2, threads=8)
-    got, st2 = gpu.query_pml_packed(b2, o2)
-    li = gpu.last_launch()
-    assert li["staged"] == 1 and li["kernel"].endswith(", 1, 2>")
-    assert (got == e2).all() and (st2.fast_forwards, st2.scans, st2.errors) == (f2, s2, 0)
-    gpu.close()
-
-
-def test_pair_window_with_corrupt_rows(built_lib, golden_image):
-    import movi_amd
-    img = bytearray(golden_image(6))
-    _, _, off, _ = movi_amd.parse_index_image(bytes(img))
-    rows = np.frombuffer(img, np.uint8, count=118209 * 8, offset=off).reshape(-1, 8).copy()
-    rng = np.random.default_rng(8000)
-    rows[rng.choice(118209, 20000, replace=False), 0:4] = 0xFF
-    img[off: off + rows.size] = rows.tobytes()
-    gpu = movi_amd.MoveIndex.from_image(bytes(img))
-    bases, offs = pack(mutated_reads(rng, _ref(), 400, 5, 300))
-    gpu.set_option("window_rows", 4)
-    e_out, e_st, e_err, e_rc = gpu.query_pml_packed(bases, offs, want_err=True)
-    gpu.set_option("window_rows", 2)
-    out, st, err, rc = gpu.query_pml_packed(bases, offs, want_err=True)
-    assert rc == e_rc == -6 and (out == e_out).all() and (err == e_err).all() and st.errors == e_st.errors
-    gpu.close()
