@@ -2202,19 +2202,26 @@ hipError_t launch_count(int mode, const DevIndex &ix, const uint8_t *d_bases, co
                         LaunchInfo *info) {
     if (n_reads == 0) return hipSuccess;
     const int bt = cfg.block_threads > 0 ? cfg.block_threads : 256;
+    // occupancy cap by LDS padding, as in launch_pml (cfg.waves_per_cu; 0 = none)
+    size_t dyn_lds = 0;
+    if (cfg.waves_per_cu > 0) {
+        int bpc = cfg.waves_per_cu / (bt / 64);
+        if (bpc < 1) bpc = 1;
+        if (bpc < 32) dyn_lds = std::min<size_t>(65536 - 1024, ((163840u / (unsigned)bpc) & ~1023u) - 1024u);
+    }
     if (info) {
         snprintf(info->kernel, sizeof(info->kernel), "count_kernel_v0<%d>", mode);
-        info->variant = 0; info->block_threads = bt; info->waves_per_cu = 0; info->segmented = 0; info->idx64 = 1;
+        info->variant = 0; info->block_threads = bt; info->waves_per_cu = cfg.waves_per_cu > 0 ? cfg.waves_per_cu : 0; info->segmented = 0; info->idx64 = 1;
     }
     const uint64_t blocks = (n_reads + bt - 1) / bt;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     dim3 grid((unsigned)blocks), block((unsigned)bt);
     // resident layouts: 6 = regular-thresholds rows, 3 = regular rows (threshold-less types: 12-bit lengths)
     if (mode == 6)
-        hipLaunchKernelGGL(count_kernel_v0<6>, grid, block, 0, stream, ix, d_bases, d_offsets, n_reads,
+        hipLaunchKernelGGL(count_kernel_v0<6>, grid, block, dyn_lds, stream, ix, d_bases, d_offsets, n_reads,
                            d_matched, d_count, d_err, d_stats, d_order);
     else if (mode == 3)
-        hipLaunchKernelGGL(count_kernel_v0<3>, grid, block, 0, stream, ix, d_bases, d_offsets, n_reads,
+        hipLaunchKernelGGL(count_kernel_v0<3>, grid, block, dyn_lds, stream, ix, d_bases, d_offsets, n_reads,
                            d_matched, d_count, d_err, d_stats, d_order);
     else return hipErrorInvalidValue;
     return hipGetLastError();
