@@ -2201,17 +2201,23 @@ hipError_t launch_count(int mode, const DevIndex &ix, const uint8_t *d_bases, co
                         DevStats *d_stats, const uint32_t *d_order, const LaunchCfg &cfg, hipStream_t stream,
                         LaunchInfo *info) {
     if (n_reads == 0) return hipSuccess;
-    const int bt = cfg.block_threads > 0 ? cfg.block_threads : 256;
-    // occupancy cap by LDS padding, as in launch_pml (cfg.waves_per_cu; 0 = none)
+    // Blocks of one wavefront; on a cache-resident table (up to the 256 MiB of the Infinity Cache) and a batch of more than
+    // ~24 wavefronts of reads per CU at most kCountCapWaves wavefronts resident per CU -- the same L2-retention effect as in
+    // launch_pml: the search's neighbour rows (interval shrink, fast-forwards) must survive between a lane's steps.
+    // profiles/r03_count_ftab.txt: pangenome 61.2 -> 67.5 Gbases/s (cap 15 - 16; 14: 66.2, 17: 64.2, 20: 62.5), random 80 MB
+    // table 52.4 -> 54.6; HBM-resident tables lose with any cap (1.6 GB: 47.3 uncapped, 43.2 at 16) or are indifferent (8 GB).
+    const int bt = cfg.block_threads > 0 ? cfg.block_threads : 64;
+    int wpc = cfg.waves_per_cu > 0 ? cfg.waves_per_cu : 0;
+    if (cfg.waves_per_cu == 0 && ix.r * 8ull <= (256ull << 20) && n_reads > (uint64_t)cfg.num_cus * 64ull * 24ull) wpc = kCountCapWaves;
     size_t dyn_lds = 0;
-    if (cfg.waves_per_cu > 0) {
-        int bpc = cfg.waves_per_cu / (bt / 64);
+    if (wpc > 0) {
+        int bpc = wpc / (bt / 64);
         if (bpc < 1) bpc = 1;
         if (bpc < 32) dyn_lds = std::min<size_t>(65536 - 1024, ((163840u / (unsigned)bpc) & ~1023u) - 1024u);
     }
     if (info) {
         snprintf(info->kernel, sizeof(info->kernel), "count_kernel_v0<%d>", mode);
-        info->variant = 0; info->block_threads = bt; info->waves_per_cu = cfg.waves_per_cu > 0 ? cfg.waves_per_cu : 0; info->segmented = 0; info->idx64 = 1;
+        info->variant = 0; info->block_threads = bt; info->waves_per_cu = wpc; info->segmented = 0; info->idx64 = 1;
     }
     const uint64_t blocks = (n_reads + bt - 1) / bt;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;

@@ -72,10 +72,11 @@ struct DevStats {
     unsigned long long pad_;
 };
 
+constexpr int kCountCapWaves = 16;   // the count kernel's cap on cache-resident tables (launch_count)
 constexpr int kCapWaves = 7;   // resident wavefronts per CU of the lane state machine on big batches (round 2: 9, optimum 8-10; round 3, with the reads staged in LDS and the top-of-walk table: 6-8, profiles/r03_occupancy_sweep.txt)
 
 struct LaunchCfg {
-    int block_threads = 0;   // 0 = auto: 64 for the PML kernels (finest dispatch grain), 256 for count / ZML
+    int block_threads = 0;   // 0 = auto: 64 for the PML and count kernels and the ZML state machine (finest dispatch grain), 256 for the base-synchronous ZML kernel
     // -1 auto; 0 first kernel (plain I/O), 1 base-synchronous packed I/O, 7 flat lane state machine,
     // 10 flat lane state machine + row window, software-pipelined, 13 = 10 as a persistent grid with lane refill,
     // 14 = 10 with the window-parallel advance (what auto picks)
