@@ -750,7 +750,11 @@ def main():
             stq = QueryStatsC()
             torch.cuda.synchronize()
             ref_out = None
-            for name, mk in (("pageable", lambda n, dt: np.empty(n, dt)), ("page_locked", movi_amd.pinned_empty)):
+            for name, mk in (("pageable_synchronous", lambda n, dt: np.empty(n, dt)), ("pageable", lambda n, dt: np.empty(n, dt)),
+                             ("page_locked", movi_amd.pinned_empty)):
+                # pageable_synchronous: "host_autopin" 0 = upload, walk, download one after the other; pageable: the default --
+                # a big call page-locks the caller's buffers for its duration and overlaps the three
+                index.set_option("host_autopin", 0 if name == "pageable_synchronous" else 1)
                 hb, ho = mk(n_bases, np.uint8), mk(n_bases, np.uint16)
                 hb[:] = bases
                 ho[:] = 0xFFFF

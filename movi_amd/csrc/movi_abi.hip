@@ -126,6 +126,7 @@ struct movi_index {
     hipStream_t pipe_up = nullptr;   // every chunk's upload, in order (uploads on separate streams share the link and all arrive late)
     uint64_t pipe_chunk_bases = 0;   // test hook ("pipe_chunk_bases"): chunk size of the overlapped path, 0 = its policy
     LaunchInfo last_launch;          // what the last query call launched (movi_last_launch)
+    bool host_autopin = true;        // big *_host calls on pageable buffers page-lock them for the call ("host_autopin")
     bool seg_seen = false;           // the last PML / ZML host call on long reads was walked segment-parallel (chunk policy below)
 };
 
@@ -838,6 +839,11 @@ int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
         ix->cfg.seg_verdict = (int)value;
         return MOVI_OK;
     }
+    if (!strcmp(key, "host_autopin")) {                      // 0: pageable buffers always take the synchronous path (A/B)
+        if (value != 0 && value != 1) return fail(MOVI_ERR_ARG, "host_autopin must be 0 or 1");
+        ix->host_autopin = value != 0;
+        return MOVI_OK;
+    }
     if (!strcmp(key, "stage_reads")) {                       // A/B: reads of short-read wavefronts staged through LDS
         if (value != 0 && value != 1) return fail(MOVI_ERR_ARG, "stage_reads must be 0 or 1");
         ix->cfg.stage_reads = (int)value;
@@ -1406,8 +1412,36 @@ static int ml_host(bool zml, movi_index_t *ix, const uint8_t *h_bases, const uin
         return MOVI_OK;
     };
     auto harvest = [](const uint8_t *, uint64_t, uint64_t) {};
-    const bool overlapped = h_offsets[n_reads] != h_offsets[0] && is_pinned(h_bases) && (!h_out_pml || is_pinned(h_out_pml));
-    return run_host(overlapped, ix, h_bases, h_offsets, n_reads, h_read_err, stats, launch, fetch, harvest, 0);
+    bool overlapped = h_offsets[n_reads] != h_offsets[0] && is_pinned(h_bases) && (!h_out_pml || is_pinned(h_out_pml));
+    // A big call on PAGEABLE buffers (what a std::vector-holding caller passes: INTEGRATION.md's stub): page-lock them for the
+    // duration of the call and take the overlapped path.  Registering touched memory runs at hundreds of GB/s (DESIGN.md section
+    // 5), so on >= 2^27 bases it is paid back several times over (the synchronous path: 12.4 Gbases/s PCIe-inclusive).
+    // "host_autopin" 0 turns it off; anything that fails here falls back to the synchronous path.
+    const uint64_t span = h_offsets[n_reads] - h_offsets[0];
+    void *reg_bases = nullptr, *reg_out = nullptr;
+    if (!overlapped && ix->host_autopin && span >= (1ull << 27) && n_reads >= (1ull << 18)) {
+        uint8_t *b0 = const_cast<uint8_t *>(h_bases) + h_offsets[0];
+        bool ok = true;
+        if (!is_pinned(b0)) {
+            ok = hipHostRegister(b0, span, hipHostRegisterDefault) == hipSuccess;
+            if (ok) reg_bases = b0;
+        }
+        if (ok && h_out_pml && !is_pinned(h_out_pml + h_offsets[0])) {
+            ok = hipHostRegister(h_out_pml + h_offsets[0], span * 2, hipHostRegisterDefault) == hipSuccess;
+            if (ok) reg_out = h_out_pml + h_offsets[0];
+        }
+        (void)hipGetLastError();
+        overlapped = ok;
+    }
+    const int rc = run_host(overlapped, ix, h_bases, h_offsets, n_reads, h_read_err, stats, launch, fetch, harvest, 0);
+    if (reg_out || reg_bases) {
+        const std::string keep = g_err;
+        if (reg_out) (void)hipHostUnregister(reg_out);
+        if (reg_bases) (void)hipHostUnregister(reg_bases);
+        (void)hipGetLastError();
+        g_err = keep;
+    }
+    return rc;
 }
 
 int movi_pml_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_offsets, uint64_t n_reads,

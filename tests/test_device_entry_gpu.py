@@ -232,3 +232,29 @@ def test_logs_per_base_fastforwards_and_scans(built_lib, golden_image, mode):
     plain, pst = gpu.query_pml_packed(bases, offs)
     assert (plain == out).all() and st.scans == pst.scans == int(sc.astype(np.uint64).sum())
     gpu.close()
+
+
+def test_big_pageable_host_call_page_locks_its_buffers(built_lib):
+    """movi_pml_host / movi_zml_host on PAGEABLE buffers of >= 2^27 bases: the call page-locks the caller's buffers for its
+    duration and takes the overlapped path ("host_autopin", on by default).  Same PMLs, error bytes and counters as the
+    synchronous path; the buffers are ordinary pageable memory again afterwards (a second call, and one with the option
+    off, work the same)."""
+    import movi_amd
+    from tools import synth
+    six = synth.synth_index(2_000_000, mode=6, seed=15)
+    gpu = movi_amd.MoveIndex.from_image(six.image())
+    bases, offs = synth.synth_reads(six, 1_000_000, 150, seed=16, sub_rate=0.01, n_rate=0.001)
+    assert bases.size >= 1 << 27
+    gpu.set_option("host_autopin", 0)
+    exp, est = gpu.query_pml_packed(bases, offs)
+    expz, _ = gpu.query_zml_packed(bases, offs)
+    gpu.set_option("host_autopin", 1)
+    for rep in range(2):
+        out = np.full(bases.size, 0xABCD, np.uint16)
+        got, st, err, rc = gpu.query_pml_packed(bases, offs, want_err=True, out=out)
+        assert rc == 0 and (out == exp).all() and not err.any()
+        assert (st.bases, st.fast_forwards, st.scans, st.repositions) == (est.bases, est.fast_forwards, est.scans, est.repositions)
+    zout, _ = gpu.query_zml_packed(bases, offs)
+    assert (zout == expz).all()
+    out[:] = 0                                              # still writable, still ours
+    gpu.close()
