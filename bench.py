@@ -744,8 +744,9 @@ def main():
         try:
             from movi_amd._lib import QueryStatsC, check, lib
             hp = {"unit": "Gbases/s", "note": "movi_pml_host, host buffers in and out (1 B up + 2 B down per base over PCIe), "
-                                              "best of 3 calls after a warm-up call; the two paths checked against each other and against "
-                                              "the cpu_baseline's oracle sample"}
+                                              "best of 3 calls after a warm-up call; pageable_synchronous = host_autopin off (upload, walk, download one after the "
+                                              "other), pageable = the default (a big call page-locks the caller's buffers for its duration and overlaps the three), "
+                                              "page_locked = caller-allocated page-locked buffers; all checked against each other and the cpu_baseline's oracle sample"}
             h_offs = np.ascontiguousarray(offs, np.uint64)
             stq = QueryStatsC()
             torch.cuda.synchronize()
