@@ -1390,6 +1390,28 @@ int movi_host_unregister(void *p) {
     return MOVI_OK;
 }
 
+// Page-locks a caller's pageable range for the duration of one big *_host call ("host_autopin"); releases it on scope exit.
+struct AutoPin {
+    void *p = nullptr;
+    bool pin(void *q, size_t bytes) {                        // true: the range is page-locked now (by us or already)
+        if (!q || !bytes) return false;
+        if (is_pinned(q)) return true;
+        if (hipHostRegister(q, bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return false; }
+        p = q;
+        return true;
+    }
+    ~AutoPin() {
+        if (!p) return;
+        const std::string keep = g_err;
+        (void)hipHostUnregister(p);
+        (void)hipGetLastError();
+        g_err = keep;
+    }
+};
+static bool autopin_worthwhile(const movi_index *ix, const uint64_t *h_offsets, uint64_t n_reads) {
+    return ix->host_autopin && h_offsets[n_reads] - h_offsets[0] >= (1ull << 27) && n_reads >= (1ull << 18);
+}
+
 static int ml_host(bool zml, movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_offsets, uint64_t n_reads,
                   uint16_t *h_out_pml, uint8_t *h_read_err, movi_query_stats_t *stats) {
     if (!ix) return fail(MOVI_ERR_ARG, "index handle is NULL");
@@ -1418,30 +1440,11 @@ static int ml_host(bool zml, movi_index_t *ix, const uint8_t *h_bases, const uin
     // 5), so on >= 2^27 bases it is paid back several times over (the synchronous path: 12.4 Gbases/s PCIe-inclusive).
     // "host_autopin" 0 turns it off; anything that fails here falls back to the synchronous path.
     const uint64_t span = h_offsets[n_reads] - h_offsets[0];
-    void *reg_bases = nullptr, *reg_out = nullptr;
-    if (!overlapped && ix->host_autopin && span >= (1ull << 27) && n_reads >= (1ull << 18)) {
-        uint8_t *b0 = const_cast<uint8_t *>(h_bases) + h_offsets[0];
-        bool ok = true;
-        if (!is_pinned(b0)) {
-            ok = hipHostRegister(b0, span, hipHostRegisterDefault) == hipSuccess;
-            if (ok) reg_bases = b0;
-        }
-        if (ok && h_out_pml && !is_pinned(h_out_pml + h_offsets[0])) {
-            ok = hipHostRegister(h_out_pml + h_offsets[0], span * 2, hipHostRegisterDefault) == hipSuccess;
-            if (ok) reg_out = h_out_pml + h_offsets[0];
-        }
-        (void)hipGetLastError();
-        overlapped = ok;
-    }
-    const int rc = run_host(overlapped, ix, h_bases, h_offsets, n_reads, h_read_err, stats, launch, fetch, harvest, 0);
-    if (reg_out || reg_bases) {
-        const std::string keep = g_err;
-        if (reg_out) (void)hipHostUnregister(reg_out);
-        if (reg_bases) (void)hipHostUnregister(reg_bases);
-        (void)hipGetLastError();
-        g_err = keep;
-    }
-    return rc;
+    AutoPin pin_bases, pin_out;
+    if (!overlapped && autopin_worthwhile(ix, h_offsets, n_reads))
+        overlapped = pin_bases.pin(const_cast<uint8_t *>(h_bases) + h_offsets[0], span) &&
+                     (!h_out_pml || pin_out.pin(h_out_pml + h_offsets[0], span * 2));
+    return run_host(overlapped, ix, h_bases, h_offsets, n_reads, h_read_err, stats, launch, fetch, harvest, 0);
 }
 
 int movi_pml_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_offsets, uint64_t n_reads,
@@ -1562,7 +1565,10 @@ int movi_pml_classify_host(movi_index_t *ix, const uint8_t *h_bases, const uint6
         memcpy(h_bins_above + first, h + nr * 8, nr * 4);
         memcpy(h_bins_below + first, h + nr * 12, nr * 4);
     };
-    const bool overlapped = worth_overlapping_small_results(h_offsets, n_reads) && is_pinned(h_bases);
+    bool overlapped = worth_overlapping_small_results(h_offsets, n_reads) && is_pinned(h_bases);
+    AutoPin pin_bases;
+    if (!overlapped && worth_overlapping_small_results(h_offsets, n_reads) && autopin_worthwhile(ix, h_offsets, n_reads))
+        overlapped = pin_bases.pin(const_cast<uint8_t *>(h_bases) + h_offsets[0], h_offsets[n_reads] - h_offsets[0]);
     return run_host(overlapped, ix, h_bases, h_offsets, n_reads, h_read_err, stats, launch, fetch, harvest, 16);
 }
 
@@ -1636,7 +1642,10 @@ int movi_count_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_
         memcpy(h_matched + first, h, nr * 8);
         memcpy(h_count + first, h + nr * 8, nr * 8);
     };
-    const bool overlapped = worth_overlapping_small_results(h_offsets, n_reads) && is_pinned(h_bases);
+    bool overlapped = worth_overlapping_small_results(h_offsets, n_reads) && is_pinned(h_bases);
+    AutoPin pin_bases;
+    if (!overlapped && worth_overlapping_small_results(h_offsets, n_reads) && autopin_worthwhile(ix, h_offsets, n_reads))
+        overlapped = pin_bases.pin(const_cast<uint8_t *>(h_bases) + h_offsets[0], h_offsets[n_reads] - h_offsets[0]);
     return run_host(overlapped, ix, h_bases, h_offsets, n_reads, h_read_err, stats, launch, fetch, harvest, 16);
 }
 

@@ -248,7 +248,12 @@ def test_big_pageable_host_call_page_locks_its_buffers(built_lib):
     gpu.set_option("host_autopin", 0)
     exp, est = gpu.query_pml_packed(bases, offs)
     expz, _ = gpu.query_zml_packed(bases, offs)
+    em, ec, ecst = gpu.query_count_packed(bases, offs)
+    ebins = gpu.classify_packed(bases, offs, 150, 6)
     gpu.set_option("host_autopin", 1)
+    m, c, cst = gpu.query_count_packed(bases, offs)
+    assert (m == em).all() and (c == ec).all() and (cst.fast_forwards, cst.scans) == (ecst.fast_forwards, ecst.scans)
+    assert all((x == y).all() for x, y in zip(gpu.classify_packed(bases, offs, 150, 6), ebins))
     for rep in range(2):
         out = np.full(bases.size, 0xABCD, np.uint16)
         got, st, err, rc = gpu.query_pml_packed(bases, offs, want_err=True, out=out)
