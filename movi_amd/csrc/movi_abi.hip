@@ -1409,7 +1409,7 @@ struct AutoPin {
     }
 };
 static bool autopin_worthwhile(const movi_index *ix, const uint64_t *h_offsets, uint64_t n_reads) {
-    return ix->host_autopin && h_offsets[n_reads] - h_offsets[0] >= (1ull << 27) && n_reads >= (1ull << 18);
+    return ix->host_autopin && h_offsets[n_reads] - h_offsets[0] >= (1ull << 27) && n_reads >= (1ull << 15);
 }
 
 static int ml_host(bool zml, movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_offsets, uint64_t n_reads,
