@@ -193,7 +193,7 @@ int movi_pml_device(movi_index_t *ix, const uint8_t *d_bases, const uint64_t *d_
  * movi_host_register below) the call is overlapped: the reads are cut into chunks that travel through six
  * slots with their own streams -- up to three chunks going up or being walked while one comes down -- so that
  * upload, walks and download run at the same time (results are identical; DESIGN.md has the rates).  Pageable
- * buffers take the synchronous path -- unless the call is big (>= 2^27 bases and >= 2^15 reads): then it page-locks the
+ * buffers take the synchronous path -- unless the call is big (>= 2^27 bases and >= 3 x 2^15 reads): then it page-locks the
  * caller's buffers for its duration (hipHostRegister / hipHostUnregister: practically free for touched memory) and overlaps
  * all the same ("host_autopin" 0 turns that off).  h_out_pml == NULL: the walk runs and its error bytes and counters come back,
  * but no vector crosses PCIe (`movi query --no-output`: the reference computes and discards, src/movi.cpp:268-389). */

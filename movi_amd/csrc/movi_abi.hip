@@ -1409,7 +1409,8 @@ struct AutoPin {
     }
 };
 static bool autopin_worthwhile(const movi_index *ix, const uint64_t *h_offsets, uint64_t n_reads) {
-    return ix->host_autopin && h_offsets[n_reads] - h_offsets[0] >= (1ull << 27) && n_reads >= (1ull << 15);
+    // (the overlapped path cuts a call into pieces of >= 2^15 reads: it needs at least three of them to overlap anything)
+    return ix->host_autopin && h_offsets[n_reads] - h_offsets[0] >= (1ull << 27) && n_reads >= 3 * kPipeMinReads;
 }
 
 static int ml_host(bool zml, movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_offsets, uint64_t n_reads,
