@@ -226,7 +226,8 @@ typedef struct movi_launch_info {
     int32_t waves_per_cu;             /* cap on resident wavefronts per CU that was applied (0 = none)             */
     int32_t segmented;                /* 1 = the segment-parallel plan ran around that kernel                       */
     int32_t idx64;                    /* 1 = the 64-bit row-index instantiation                                     */
-    int32_t staged;                   /* 1 = short-read wavefronts copy their reads into LDS once ("stage_reads")    */
+    int32_t staged;                   /* > 0: wavefronts whose reads all have at most this many bases copy them into LDS once
+                                         ("stage_reads"; 336 at the default occupancy cap); 0: no staging in this launch */
     int32_t reserved_[2];
 } movi_launch_info_t;
 int movi_last_launch(const movi_index_t *ix, movi_launch_info_t *info);
@@ -314,7 +315,8 @@ int movi_host_unregister(void *p);
  * of those K bases -- one 16-byte table lookup replaces the first K row gathers of every read and segment; left alone the
  * first PML query on a DNA *-thresholds index builds the K = 12 table (256 MB, a few ms: that one call waits for it);
  * 0 = no table, 1..12 = build that one now), "stage_reads" (1, the default: in big batches a wavefront whose reads
- * all have at most 256 bases copies them into LDS once instead of re-fetching them 16 bases at a time; 0 = off: A/B),
+ * all have at most ~336 bases (what the cap's LDS padding holds) copies them into LDS once instead of re-fetching them 16 bases
+ * at a time; 0 = off: A/B),
  * "ftab_k" (the count query's interval table -- the backward-search interval after the last K bases of a read by one lookup,
  * the reference's own ftab (src/move_structure_search.cpp:66-167) put to work for --count; left alone the first count query
  * on a DNA index builds the K = 12 table (256 MB); 0 = none, 1..12 = build that one now). */

@@ -857,7 +857,7 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
     uint4 pk = make_uint4(0, 0, 0, 0), pk_old = pk;
     if (CLS) cs.init(len, cls.bin_width);
     // ---- reads staged through LDS (ix.stage_lds: the launcher found the block's dynamic LDS -- the occupancy cap's
-    // padding, 16 KiB per one-wavefront block -- big enough): a wavefront whose reads all have at most ix.stage_lds (256) bases copies
+    // padding, 21 KiB per one-wavefront block at the default cap -- big enough): a wavefront whose reads all have at most ix.stage_lds (336) bases copies
     // them into LDS once, at the start -- each lane its own read, 16 bytes per load from the read's end backwards, so the
     // 64 x 150 contiguous bytes of the wavefront's reads come in as whole cache lines, each fetched ONCE (the lines stay in
     // the CU's L1 over these back-to-back loads) -- and takes every base from there.  The walk's other way to its bases,
@@ -1841,9 +1841,9 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     // reads staged through LDS (pml_kernel_flatp): needs 256 bytes per lane of the one-wavefront block -- what the occupancy
     // cap's padding provides for caps of up to 9 wavefronts per CU (the default cap is kCapWaves = 7).  cfg.stage_reads: 1 = when it fits (default), 0 = never
     DevIndex ixl = ix;
-    // (capacity per lane = what the padding leaves, a multiple of 16 up to 256 bases: a cap of 9 wavefronts per CU pads
-    // with exactly 16 KiB = 256 bases per lane, a cap of 12 with 12 KiB = 192)
-    const uint32_t stage_cap = (uint32_t)std::min<size_t>(256, (dyn_lds / 64) & ~(size_t)15);
+    // (capacity per lane = what the padding leaves, a multiple of 16: the default cap of 7 wavefronts per CU pads with 21 KiB =
+    // 336 bases per lane, a cap of 9 with 16 KiB = 256, a cap of 12 with 12 KiB = 192)
+    const uint32_t stage_cap = (uint32_t)std::min<size_t>(1024, (dyn_lds / 64) & ~(size_t)15);
     ixl.stage_lds = (cfg.stage_reads != 0 && bt == 64 && stage_cap >= 128 && v == 10 && wp) ? stage_cap : 0u;
     const SegArgs no_seg;
     // every kernel that is handed more than 64 KiB of dynamic LDS must opt in first
@@ -1913,7 +1913,7 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
                       ix.sep ? 1 : 0, v == 13 ? 1 : 0, (v == 10 && ixl.stage_lds) ? 1 : 0);
         info->variant = (v == 10 && wp) ? 14 : v;
         info->block_threads = bt; info->waves_per_cu = wpc; info->segmented = 0; info->idx64 = ix.idx32 ? 0 : 1;
-        info->staged = ixl.stage_lds ? 1 : 0;
+        info->staged = (int)ixl.stage_lds;
     }
 #undef MOVI_LAUNCH_PML
 #undef MOVI_LAUNCH_K

@@ -50,7 +50,7 @@ struct DevIndex {
     uint32_t ftab_k;
     uint32_t pad2_;
     const uint4 *ftab;
-    uint32_t stage_lds;           // set per launch by launch_pml: bytes of dynamic LDS per lane for read staging (0 = none, 256)
+    uint32_t stage_lds;           // set per launch by launch_pml: bytes of dynamic LDS per lane for read staging (0 = none; 336 at cap 7)
     uint32_t kmer_k;
     const uint4 *kmer;            // 4^K entries: x = row[31:0]; y = row[35:32] | off << 4 (12 bits) | match mask << 16 (K bits) |
                                   // valid << 31; z = fast-forwards; w = scan rows.  valid = 0: one of the K steps hit one of the
@@ -101,7 +101,7 @@ struct LaunchInfo {
     int waves_per_cu = 0;    // resident-wavefront cap applied (0 = none)
     int segmented = 0;       // 1 = the segment-parallel plan ran (K1 + stitch + finalize around the named kernel)
     int idx64 = 0;           // 1 = the 64-bit row-index instantiation
-    int staged = 0;          // 1 = wavefronts of short reads copy their reads into LDS once (pml_kernel_flatp)
+    int staged = 0;          // > 0: wavefronts whose reads all have at most this many bases copy them into LDS once (pml_kernel_flatp)
 };
 
 // Classifier::classify bins (src/classifier.cpp:99-143) fused into the PML kernels: per read the number of

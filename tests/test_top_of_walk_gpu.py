@@ -142,7 +142,7 @@ def test_top_of_walk_with_corrupt_rows(built_lib, golden_image):
 @pytest.mark.parametrize("mode", [6, 8])
 def test_reads_staged_through_lds_vs_oracle(built_lib, golden_image, mode):
     """Big batches (more reads than ~18 wavefronts per CU) run capped at 9 wavefronts per CU, and the LDS that enforces the
-    cap holds the reads: a wavefront whose 64 reads all have at most 256 bases copies them into LDS once and takes every
+    cap holds the reads: a wavefront whose 64 reads all have at most 336 bases (what the padding holds) copies them into LDS once and takes every
     base from there; wavefronts with a longer read keep fetching 16 bases at a time from global memory.  Both kinds in one
     launch, every length from 0 to 256 and beyond, with and without the top-of-walk table, fused bins included: PMLs, error
     bytes and counters equal the oracle's and those of the unstaged launch."""
@@ -153,9 +153,10 @@ def test_reads_staged_through_lds_vs_oracle(built_lib, golden_image, mode):
     ref = _ref()
     rng = np.random.default_rng(8500 + mode)
     n = 300_000                                           # > 256 CUs x 64 lanes x 18 wavefronts
-    lens = rng.integers(0, 257, n).astype(np.uint64)
-    lens[rng.choice(n, 40, replace=False)] = rng.integers(257, 2000, 40)      # a few wavefronts that cannot stage
-    lens[:64] = 256                                      # one wavefront of reads that fill the staging area exactly
+    CAP = 336                                             # bases per lane the default cap's LDS padding holds (7 wavefronts per CU)
+    lens = rng.integers(0, CAP + 1, n).astype(np.uint64)
+    lens[rng.choice(n, 40, replace=False)] = rng.integers(CAP + 1, 2000, 40)   # a few wavefronts that cannot stage
+    lens[:64] = CAP                                      # one wavefront of reads that fill the staging area exactly
     lens[64:128] = 0
     starts = rng.integers(0, len(ref) - 2000, n)
     offs = np.zeros(n + 1, np.uint64)
@@ -179,7 +180,7 @@ def test_reads_staged_through_lds_vs_oracle(built_lib, golden_image, mode):
         for variant in (-1, 10):
             gpu.set_option("pml_variant", variant)
             out, st = gpu.query_pml_packed(bases, offs)
-            assert gpu.last_launch()["staged"] == (1 if variant == -1 else 0), (K, variant)   # staging: the default kernel only
+            assert gpu.last_launch()["staged"] == (CAP if variant == -1 else 0), (K, variant)   # staging: the default kernel only
             assert (out == exp).all(), (K, variant)
             assert (st.fast_forwards, st.scans, st.repositions, st.errors) == (ff, sc, st0.repositions, 0), (K, variant)
         gpu.set_option("pml_variant", -1)
