@@ -55,11 +55,17 @@ def test_one_billion_row_table_vs_oracle(built_lib, mode):
     if mode == 8:
         assert gpu.desc.n_blocks >= 900                  # ~954 id blocks of 2^20 rows (or more, halved adaptively)
 
-    # ---- PML: the whole batch in one launch (the config-4 shape), then the slices on their own for the counters
+    # ---- PML: the whole batch in one launch (the config-4 shape; "host_autopin" off: with it a call this big would be cut
+    # into overlapped pieces), then the slices on their own for the counters
+    gpu.set_option("host_autopin", 0)
     out, st = gpu.query_pml_packed(bases, offs)
     assert st.errors == 0 and st.bases == bases.size
     li = gpu.last_launch()
     assert li["kernel"].startswith("pml_kernel_flatp<6, unsigned int") and li["idx64"] == 0 and li["waves_per_cu"] == 7
+    gpu.set_option("host_autopin", 1)
+    out2, st2 = gpu.query_pml_packed(bases, offs)          # ... and the same call cut into overlapped pieces: identical
+    assert (out2 == out).all() and (st2.fast_forwards, st2.scans) == (st.fast_forwards, st.scans)
+    del out2
     # ---- count: the config-5 query
     m, c, cst = gpu.query_count_packed(bases, offs)
     assert cst.errors == 0
