@@ -328,6 +328,7 @@ def main():
     ap.add_argument("--kmer-k", type=int, default=-1, help="top-of-walk table: first K bases of every read by one lookup (A/B; -1 = the engine's default)")
     ap.add_argument("--ftab-k", type=int, default=-1, help="count query's interval table: first K bases of the backward search by one lookup (A/B; -1 = the engine's default)")
     ap.add_argument("--stage-reads", type=int, default=-1, help="reads staged through LDS for short-read wavefronts (A/B: 0 off, 1 on; -1 = default)")
+    ap.add_argument("--ahead-rows", type=int, default=-1, help="look-ahead rows: the table's second copy that resolves two bases per gather (A/B: 0 off, 1 on; -1 = the engine's default: on for tables whose copy fits the Infinity Cache)")
     ap.add_argument("--block-threads", type=int, default=0)
     ap.add_argument("--waves-per-cu", type=int, default=-1)
     ap.add_argument("--ragged", type=int, default=0, help="1: log-normal read lengths (mean = read_len); "
@@ -460,6 +461,8 @@ def main():
         index.set_option("kmer_k", args.kmer_k)
     if args.stage_reads >= 0:
         index.set_option("stage_reads", args.stage_reads)
+    if args.ahead_rows >= 0:
+        index.set_option("ahead_rows", args.ahead_rows)
     if args.ftab_k >= 0:
         index.set_option("ftab_k", args.ftab_k)
     if args.block_threads:
@@ -608,7 +611,7 @@ def main():
                    "iterations_per_base": round(st.lane_steps / max(n_bases, 1), 4) if st.wave_steps else None,
                    "algorithmic_bytes_per_base": round(bytes_per_base, 3),
                    "segments": int(st.segments), "rewalked_reads": int(st.rewalked), "seg_len": args.seg_len,
-                   "query": args.query, "fused_classify": args.classify, "matched_bases_per_step": work_bases, "pml_variant": args.variant, "kmer_k": args.kmer_k, "ftab_k": args.ftab_k, "ragged": args.ragged, "waves_per_cu": args.waves_per_cu, "block_threads": args.block_threads, "index_gen_s": round(t_index_gen, 2),
+                   "query": args.query, "fused_classify": args.classify, "matched_bases_per_step": work_bases, "pml_variant": args.variant, "kmer_k": args.kmer_k, "ahead_rows": args.ahead_rows, "ftab_k": args.ftab_k, "ragged": args.ragged, "waves_per_cu": args.waves_per_cu, "block_threads": args.block_threads, "index_gen_s": round(t_index_gen, 2),
                    "index_upload_s": round(t_index_upload, 2), "index_broadcast_s": round(t_bcast, 3),
                    "reads_gen_s": round(t_reads_gen, 2)},
         "rccl_ranks": rccl_ranks, "index_broadcast_s": round(t_bcast, 4),

@@ -228,7 +228,8 @@ typedef struct movi_launch_info {
     int32_t idx64;                    /* 1 = the 64-bit row-index instantiation                                     */
     int32_t staged;                   /* > 0: wavefronts whose reads all have at most this many bases copy them into LDS once
                                          ("stage_reads"; 336 at the default occupancy cap); 0: no staging in this launch */
-    int32_t reserved_[2];
+    int32_t ahead;           /* 1 = the walk ran on the look-ahead rows ("ahead_rows") */
+    int32_t reserved_;
 } movi_launch_info_t;
 int movi_last_launch(const movi_index_t *ix, movi_launch_info_t *info);
 

@@ -62,7 +62,8 @@ class LaunchInfoC(C.Structure):
         ("segmented", C.c_int32),
         ("idx64", C.c_int32),
         ("staged", C.c_int32),
-        ("reserved_", C.c_int32 * 2),
+        ("ahead", C.c_int32),
+        ("reserved_", C.c_int32),
     ]
 
 

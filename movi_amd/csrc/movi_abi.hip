@@ -95,6 +95,8 @@ struct movi_index {
     uint64_t *d_ckpt = nullptr;      // built lazily by the first count query
     uint4 *d_kmer = nullptr;         // top-of-walk table ("kmer_k" option), 16 << 2K bytes
     int kmer_auto = 12;              // K of the table the first PML query builds by itself (0 = none: "kmer_k" 0)
+    uint8_t *d_rows2 = nullptr;      // look-ahead rows ("ahead_rows" option), 16 bytes per row
+    int ahead_auto = 1;              // 1: the first PML query builds them when the table is small enough (ahead_rows_fit)
     uint4 *d_ftab = nullptr;         // the count query's interval table ("ftab_k" option), 16 << 2K bytes
     int ftab_auto = 12;              // K of the table the first count query builds by itself (0 = none)
     DevStats *d_stats = nullptr;
@@ -724,6 +726,7 @@ int movi_index_destroy(movi_index_t *ix) {
     if (ix->d_ckpt) (void)hipFree(ix->d_ckpt);
     if (ix->d_kmer) (void)hipFree(ix->d_kmer);
     if (ix->d_ftab) (void)hipFree(ix->d_ftab);
+    if (ix->d_rows2) (void)hipFree(ix->d_rows2);
     if (ix->d_stats) (void)hipFree(ix->d_stats);
     release_scratch(ix);
     delete ix;
@@ -745,6 +748,24 @@ static int build_kmer(movi_index *ix, uint32_t K, hipStream_t s) {
     if (e != hipSuccess) { (void)hipFree(ix->d_kmer); ix->d_kmer = nullptr; return fail_hip(e, "building the top-of-walk table"); }
     ix->dev.kmer = ix->d_kmer;
     ix->dev.kmer_k = K;
+    return MOVI_OK;
+}
+
+// Look-ahead rows (DevIndex::rows2): a second copy of the table, 16 bytes per row.  Built by itself only where it pays
+// for certain: tables whose doubled copy still sits in the 256 MiB Infinity Cache (kAheadAutoBytes); "ahead_rows" 1 builds
+// them for any table (real reads on an HBM-sized index: half the gathers for twice the footprint).
+constexpr uint64_t kAheadAutoBytes = 240ull << 20;
+static bool ahead_eligible(const movi_index *ix) {
+    return ix->kmode == MOVI_MODE_REGULAR_THRESHOLDS && ix->desc.r >= 8 && (ix->desc.r >> 36) == 0;
+}
+static int build_ahead(movi_index *ix, hipStream_t s) {
+    HIP_TRY(hipMalloc(&ix->d_rows2, ahead_rows_bytes(ix->desc.r)));
+    uint64_t tail = 0;
+    hipError_t e = build_ahead_rows(ix->kmode, ix->dev, ix->d_rows2, &tail, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { (void)hipFree(ix->d_rows2); ix->d_rows2 = nullptr; return fail_hip(e, "building the look-ahead rows"); }
+    ix->dev.rows2 = ix->d_rows2;
+    ix->dev.rows2_tail = tail;
     return MOVI_OK;
 }
 
@@ -863,6 +884,19 @@ int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
             return fail(MOVI_ERR_ARG, "the top-of-walk table serves PML walks on DNA (ACGT) *-thresholds indexes only");
         return build_kmer(ix, (uint32_t)value, nullptr);
     }
+    if (!strcmp(key, "ahead_rows")) {                        // look-ahead rows: 0 = none (freed), 1 = build them now
+        if (value != 0 && value != 1) return fail(MOVI_ERR_ARG, "ahead_rows must be 0 or 1");
+        HIP_TRY(hipSetDevice(ix->device));
+        HIP_TRY(hipDeviceSynchronize());                     // no walk may be reading the copy that goes away
+        ix->dev.rows2 = nullptr;
+        ix->dev.rows2_tail = 0;
+        if (ix->d_rows2) (void)hipFree(ix->d_rows2);
+        ix->d_rows2 = nullptr;
+        ix->ahead_auto = 0;                                  // the caller's choice from here on
+        if (value == 0) return MOVI_OK;
+        if (!ahead_eligible(ix)) return fail(MOVI_ERR_ARG, "look-ahead rows serve PML walks on *-thresholds indexes only");
+        return build_ahead(ix, nullptr);
+    }
     if (!strcmp(key, "ftab_k")) {                            // count query's interval table: 0 = none, K in [1, 12] = build it now
         if (value < 0 || value > 12) return fail(MOVI_ERR_ARG, "ftab_k must be in [0, 12]");
         HIP_TRY(hipSetDevice(ix->device));
@@ -911,6 +945,13 @@ static int ml_device(bool zml, movi_index_t *ix, const uint8_t *d_bases, const u
             ix->kmer_auto = 0;
         }
     }
+    if (!zml && ix->ahead_auto > 0 && !ix->d_rows2 && ahead_eligible(ix) && cls.log_ff == nullptr &&
+        ahead_rows_bytes(ix->desc.r) <= kAheadAutoBytes) {
+        if (build_ahead(ix, s) != MOVI_OK) {
+            (void)hipGetLastError();
+            ix->ahead_auto = 0;
+        }
+    }
     if (zml)
         HIP_TRY(launch_zml(ix->kmode, ix->dev, d_bases, d_offsets, n_reads, n_bases, d_out, d_read_err, d_stats,
                            d_read_order, ix->cfg, s, seg_ws, ragged_hint, seg_verdict, &ix->last_launch));
@@ -943,6 +984,7 @@ int movi_last_launch(const movi_index_t *ix, movi_launch_info_t *info) {
     info->segmented = ix->last_launch.segmented;
     info->idx64 = ix->last_launch.idx64;
     info->staged = ix->last_launch.staged;
+    info->ahead = ix->last_launch.ahead;
     return MOVI_OK;
 }
 

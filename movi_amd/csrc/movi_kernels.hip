@@ -760,7 +760,12 @@ __device__ __forceinline__ uint2 win_sel(const uint2 (&w)[4], uint32_t q) {
 // segment's flag instead of err[] / zero-filling, and adds nothing to the global fast-forward / scan counters: which
 // part of its work belongs to the read's real walk is only known after K2); 2 = whole reads again, but only those in
 // seg.read_fail (K3).
-template <int MODE, typename IdxT, int HA, int CLS, int SEP, int REFILL, int SEG = 0, int STG = 0>
+// AHD (look-ahead rows, DevIndex::rows2; staged wavefronts only): the window comes from the table's second copy, together
+// with the look-ahead entry of the row it was fetched for.  When the step's emitted base is followed by a base that
+// matches at the LF target j = id(row) without a fast-forward -- known from the entry: c(j), n(j) against the offset --
+// the walk emits that PML as well and goes straight on to id(j): two bases for one gather.  Everything else (a moved
+// row, a mismatch, a fast-forward at j, the read's end, an invalid entry) takes the one-base step it always took.
+template <int MODE, typename IdxT, int HA, int CLS, int SEP, int REFILL, int SEG = 0, int STG = 0, int AHD = 0>
 __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8_t *__restrict__ bases,
                                                        const uint64_t *__restrict__ offs, uint64_t n_reads,
                                                        uint16_t *__restrict__ out, uint8_t *__restrict__ err,
@@ -768,6 +773,7 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
                                                        ClsArgs cls, SegArgs seg) {
     static_assert(SEG == 0 || (CLS == 0 && REFILL == 0), "segments: plain PML, no refill");
     static_assert(STG == 0 || (SEG == 0 && REFILL == 0), "reads staged through LDS: whole reads, no refill");
+    static_assert(AHD == 0 || (STG == 1 && HA < 0), "look-ahead rows: staged reads, window-parallel advance");
     enum : uint32_t { sFF = 0, sDown = 1, sUp = 2, sDone = 3, sLoad = 4 };   // sLoad (REFILL): first bases of a new read in flight
     __shared__ uint8_t s_code[256];
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = ix.code_of[i];
@@ -822,8 +828,19 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
         const IdxT wb = nd & ~(IdxT)3;
         return wb < wb_last ? wb : wb_last;
     };
+    uint2 ah = make_uint2(0u, 0u);                        // AHD: look-ahead entry of the row the window was fetched for
     auto fetch = [&](IdxT nd, bool act, uint2 (&w)[4]) {
-        load_window<MODE>(ix.rows, (uint64_t)(act ? win_base(nd) : (IdxT)0), w);
+        if (AHD) {                                        // line = 8 rows + their 8 entries; the last window has a line of its own
+            const IdxT wb = nd & ~(IdxT)3;
+            const bool body = wb < wb_last;
+            uint64_t at = body ? (uint64_t)(wb >> 3) * 128u + (uint64_t)((uint32_t)wb & 4u) * 8u : ix.rows2_tail;
+            uint32_t q = (uint32_t)(nd - (body ? wb : wb_last));
+            if (!act) { at = 0; q = 0; }
+            load_window<MODE>(ix.rows2 + at, 0, w);
+            __builtin_memcpy(&ah, ix.rows2 + at + 64u + 8u * q, 8);
+        } else {
+            load_window<MODE>(ix.rows, (uint64_t)(act ? win_base(nd) : (IdxT)0), w);
+        }
     };
     // end of a read: what the reference's exception / output paths do with it
     ClsState cs;
@@ -936,6 +953,13 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
             a = s_code[(uint32_t)(rb >> (8u * (7u - (K & 7u)))) & 0xFFu];
         }
     }
+    // AHD: the code of the base after the current one (staged wavefronts only; beyond the read's end: never looked at)
+    auto staged_code = [&](uint32_t kk) -> uint32_t {
+        return s_code[s_stage[(kk >> 2) * 256u + (threadIdx.x & 63u) * 4u + (kk & 3u)]];
+    };
+    const uint32_t stage_top = ix.stage_lds - 1u;
+    uint32_t a1 = 0xFFu;
+    if (AHD && staged) a1 = staged_code(k + 1 < stage_top ? k + 1 : stage_top);
     uint2 w[4];
     fetch(need, st != sDone, w);
 
@@ -965,6 +989,7 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
         lane_steps += (uint32_t)act;
         wave_steps += 1;
         const IdxT wbase = win_base(need);
+        const IdxT need0 = need;                          // (AHD: `ah` belongs to this row)
         // cheap hop: a fast-forward or scan step that only moves on (everything that resolves a base,
         // starts a scan, ends one or fails is left to the full step below)
         auto hop = [&]() {
@@ -1060,6 +1085,19 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
         const uint32_t step_back = (mism & (down ^ 1u)) | (scanning & (hit ^ 1u) & isUp);
         IdxT need_next = lf ? (IdxT)j : (IdxT)(need + step_fwd - step_back);
         uint32_t st_next = (emit & (lf ^ 1u)) ? sDone : (lf ? sFF : (mism ? (down ? sDown : sUp) : st));
+        // AHD: the base after this one, resolved at the LF target from the look-ahead entry (read_processor.cpp:188-238 with
+        // match and no fast-forward: ml + 1, then LF_move again) -- the target row itself is never fetched
+        uint32_t dbl = 0, lf2 = 0, off1 = 0;
+        if (AHD) {
+            const uint32_t n1 = ah.y & 0x7FFu, c1 = (ah.y >> 22) & 7u;
+            const uint32_t off_e = (hit ? (isDown ? 0u : n - 1u) : off) + roff;
+            dbl = lf & (ah.y >> 31) & (uint32_t)(need == need0) & (uint32_t)(a1 == c1) & (uint32_t)(off_e < n1) & (uint32_t)staged;
+            lf2 = dbl & (uint32_t)(k + 2 != len);
+            off1 = (ah.y >> 11) & 0x7FFu;
+            const IdxT j2 = (IdxT)((uint64_t)ah.x | ((uint64_t)((ah.y >> 25) & 15u) << 32));
+            need_next = dbl ? (lf2 ? j2 : need) : need_next;
+            st_next = dbl ? (lf2 ? sFF : sDone) : st_next;
+        }
         // The reference's throws: practically never, so which one it was is sorted out off the common path (as one
         // select ladder over need_next / st_next it cost ~45 instructions between a window's arrival and the next
         // gather's issue in every iteration).  An error freezes the lane where it is: no out-of-table window is fetched.
@@ -1121,7 +1159,33 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
                 }
             }
             k += 1;
-            if (lf) {
+            if (AHD && dbl) {                             // the second base of a two-base step: matched, no fast-forward
+                ml += 1;
+                off += lf2 ? off1 : 0u;
+                const uint32_t val2 = ml > 65535u ? 65535u : ml;
+                if (CLS) cs.add(val2, k, len, cls.bin_width, cls.thr);
+                if (CLS == 2) {
+                } else if (k >= packed_end) {
+                    O[k] = (uint16_t)val2;
+                } else {
+                    pk.x = (pk.x >> 16) | (pk.y << 16);
+                    pk.y = (pk.y >> 16) | (pk.z << 16);
+                    pk.z = (pk.z >> 16) | (pk.w << 16);
+                    pk.w = (pk.w >> 16) | (val2 << 16);
+                    if ((k & 15) == 7) {
+                        if (k + 8 < packed_end) pk_old = pk;
+                        else __builtin_memcpy(O + (k - 7), &pk, 16);
+                    } else if ((k & 15) == 15) {
+                        __builtin_memcpy(O + (k - 15), &pk_old, 16);
+                        __builtin_memcpy(O + (k - 7), &pk, 16);
+                    }
+                }
+                k += 1;
+            }
+            if (AHD && staged) {                          // wave-uniform: this base's code and the next one's
+                a = staged_code(k < stage_top ? k : stage_top);
+                a1 = staged_code(k + 1 < stage_top ? k + 1 : stage_top);
+            } else if (lf) {
                 if (STG && staged) {                      // wave-uniform
                     a = s_code[s_stage[(k >> 2) * 256u + (threadIdx.x & 63u) * 4u + (k & 3u)]];
                 } else {
@@ -1294,6 +1358,45 @@ __global__ __launch_bounds__(256) void kmer_table_kernel(DevIndex ix, uint32_t K
     e4.w = scan;
     if (!ok) e4 = make_uint4(0, 0, 0, 0);
     table[t] = e4;
+}
+
+// Look-ahead rows (DevIndex::rows2): thread i copies row i into its line and writes the entry of its LF target next to it.
+template <int MODE>
+__global__ __launch_bounds__(256) void ahead_rows_kernel(DevIndex ix, uint8_t *__restrict__ out, uint64_t tail) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ix.r) return;
+    const uint2 row = load_row<MODE>(ix.rows, i);
+    const uint64_t j = row_id<MODE>(row, i, ix);
+    uint2 e = make_uint2(0u, 0u);
+    if (j < ix.r) {
+        const uint2 rj = load_row<MODE>(ix.rows, j);
+        const uint64_t j2 = row_id<MODE>(rj, j, ix);
+        if (j2 < ix.r) {
+            e.x = (uint32_t)j2;
+            e.y = row_n<MODE>(rj) | (row_off<MODE>(rj) << 11) | (row_c<MODE>(rj) << 22) | ((uint32_t)(j2 >> 32) << 25) | 0x80000000u;
+        }
+    }
+    uint8_t *line = out + (i >> 3) * 128u + (i & 7u) * 8u;
+    __builtin_memcpy(line, &row, 8);
+    __builtin_memcpy(line + 64, &e, 8);
+    if (i + 4 >= ix.r) {                                  // the walk's last window: rows r-4 .. r-1 once more, in a line of their own
+        uint8_t *tl = out + tail + (i + 4 - ix.r) * 8u;
+        __builtin_memcpy(tl, &row, 8);
+        __builtin_memcpy(tl + 64, &e, 8);
+    }
+}
+
+uint64_t ahead_rows_bytes(uint64_t r) { return ((r + 7) / 8 + 1) * 128; }
+
+hipError_t build_ahead_rows(int kmode, const DevIndex &ix, uint8_t *d_rows2, uint64_t *tail, hipStream_t stream) {
+    if (!d_rows2 || !tail || ix.r < 8 || (ix.r >> 36) != 0 || kmode != 6) return hipErrorInvalidValue;
+    *tail = ((ix.r + 7) / 8) * 128;
+    hipError_t e = hipMemsetAsync(d_rows2, 0, ahead_rows_bytes(ix.r), stream);
+    if (e != hipSuccess) return e;
+    const uint64_t blocks = (ix.r + 255) / 256;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ahead_rows_kernel<6>, dim3((unsigned)blocks), dim3(256), 0, stream, ix, d_rows2, *tail);
+    return hipGetLastError();
 }
 
 hipError_t build_kmer_table(const DevIndex &ix, uint32_t K, uint4 *d_table, hipStream_t stream) {
@@ -1810,7 +1913,7 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
                                                    seg_ws, cfg.pml_variant < 0 || cfg.pml_variant == 14, ragged_hint, &declined, cls,
                                                    seg_verdict);
         if (es == hipSuccess && !declined && info) {
-            snprintf(info->kernel, sizeof(info->kernel), "pml_kernel_flatp<6, %s, -1, 0, %d, 0, 1, 0>",
+            snprintf(info->kernel, sizeof(info->kernel), "pml_kernel_flatp<6, %s, -1, 0, %d, 0, 1, 0, 0>",
                      ix.idx32 ? "unsigned int" : "unsigned long", ix.sep ? 1 : 0);
             info->variant = 14; info->block_threads = 64; info->segmented = 1; info->idx64 = ix.idx32 ? 0 : 1;
             info->waves_per_cu = 0;
@@ -1845,6 +1948,7 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     // 336 bases per lane, a cap of 9 with 16 KiB = 256, a cap of 12 with 12 KiB = 192)
     const uint32_t stage_cap = (uint32_t)std::min<size_t>(1024, (dyn_lds / 64) & ~(size_t)15);
     ixl.stage_lds = (cfg.stage_reads != 0 && bt == 64 && stage_cap >= 128 && v == 10 && wp) ? stage_cap : 0u;
+    const bool use_ahead = ixl.stage_lds != 0u && ix.rows2 != nullptr && cfg.ahead != 0 && v != 13;   // look-ahead rows: the staged kernel only
     const SegArgs no_seg;
     // every kernel that is handed more than 64 KiB of dynamic LDS must opt in first
 #define MOVI_SEG_0
@@ -1878,8 +1982,13 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     } while (0)
 #define MOVI_LAUNCH_FLATP_STG(M, C, S)                                                                      \
     do {                                                                                                    \
-        if (ix.idx32) MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint32_t, -1, C, S, 0, 0, 1>);                  \
-        else MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint64_t, -1, C, S, 0, 0, 1>);                           \
+        if (use_ahead) {                                                                                    \
+            if (ix.idx32) MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint32_t, -1, C, S, 0, 0, 1, 1>);           \
+            else MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint64_t, -1, C, S, 0, 0, 1, 1>);                    \
+        } else {                                                                                            \
+            if (ix.idx32) MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint32_t, -1, C, S, 0, 0, 1>);              \
+            else MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint64_t, -1, C, S, 0, 0, 1>);                       \
+        }                                                                                                   \
     } while (0)
 #define MOVI_LAUNCH_FLATP_R(M, C, S, R)                                                                     \
     do {                                                                                                    \
@@ -1909,11 +2018,12 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
         const char *it = ix.idx32 ? "unsigned int" : "unsigned long";
         if (v == 0 || v == 1) snprintf(info->kernel, sizeof(info->kernel), "pml_kernel<6, %d, %d>", v, v == 0 ? 0 : cm);
         else if (v == 7) snprintf(info->kernel, sizeof(info->kernel), "pml_kernel_flat<6, %s, 0>", it);
-        else snprintf(info->kernel, sizeof(info->kernel), "pml_kernel_flatp<6, %s, %d, %d, %d, %d, 0, %d>", it, wp ? -1 : MOVI_HA, cm,
-                      ix.sep ? 1 : 0, v == 13 ? 1 : 0, (v == 10 && ixl.stage_lds) ? 1 : 0);
+        else snprintf(info->kernel, sizeof(info->kernel), "pml_kernel_flatp<6, %s, %d, %d, %d, %d, 0, %d, %d>", it, wp ? -1 : MOVI_HA, cm,
+                      ix.sep ? 1 : 0, v == 13 ? 1 : 0, (v == 10 && ixl.stage_lds) ? 1 : 0, use_ahead ? 1 : 0);
         info->variant = (v == 10 && wp) ? 14 : v;
         info->block_threads = bt; info->waves_per_cu = wpc; info->segmented = 0; info->idx64 = ix.idx32 ? 0 : 1;
         info->staged = (int)ixl.stage_lds;
+        info->ahead = use_ahead ? 1 : 0;
     }
 #undef MOVI_LAUNCH_PML
 #undef MOVI_LAUNCH_K

@@ -55,6 +55,15 @@ struct DevIndex {
     const uint4 *kmer;            // 4^K entries: x = row[31:0]; y = row[35:32] | off << 4 (12 bits) | match mask << 16 (K bits) |
                                   // valid << 31; z = fast-forwards; w = scan rows.  valid = 0: one of the K steps hit one of the
                                   // reference's throws -- such reads take the ordinary walk and report it
+    // Look-ahead rows ("ahead_rows" option; nullptr = none): a second copy of the table in which every row carries, in the
+    // SAME 128-byte line, what the row its LF points to looks like -- so that a step whose next base matches there without a
+    // fast-forward (the common case on real reads) is taken without fetching that row: two bases per gather.
+    // Layout: line L = rows 8L .. 8L+7 (64 bytes) followed by their 8 look-ahead entries (64 bytes); one more line at
+    // byte rows2_tail holds rows r-4 .. r-1 and their entries (the walk's last, pulled-back window).  Entry of row i, with
+    // j = id(i), j2 = id(j): x = j2[31:0]; y = n(j) (11 bits) | offset(j) << 11 (11 bits) | c(j) << 22 (3 bits) |
+    // j2[35:32] << 25 | valid << 31.  valid = 0 when j or j2 is not a row (corrupt table): such steps are taken one by one.
+    const uint8_t *rows2;
+    uint64_t rows2_tail;
 };
 
 // Device counters of one query call.
@@ -89,6 +98,7 @@ struct LaunchCfg {
                            // 2 = no probe and no read-back at all, the caller's seg_verdict decides: the launch stays asynchronous)
     int seg_verdict = 0;   // seg_probe == 2: 1 = cut eligible batches, 0 = one lane per read
     int stage_reads = 1;   // big batches of short reads: reads staged through LDS (0 = off: A/B)
+    int ahead = 1;         // walk on the look-ahead rows when the index has them and the launch stages its reads (0 = off: A/B)
     int refill_blocks = 0; // variant 13: size of the persistent grid in blocks; 0 = num_cus x waves per CU (tests shrink it
                            // so that a few hundred reads already go through many refills per lane)
 };
@@ -101,6 +111,7 @@ struct LaunchInfo {
     int waves_per_cu = 0;    // resident-wavefront cap applied (0 = none)
     int segmented = 0;       // 1 = the segment-parallel plan ran (K1 + stitch + finalize around the named kernel)
     int idx64 = 0;           // 1 = the 64-bit row-index instantiation
+    int ahead = 0;           // 1 = the walk ran on the look-ahead rows (two bases per gather where the next base matches)
     int staged = 0;          // > 0: wavefronts whose reads all have at most this many bases copy them into LDS once (pml_kernel_flatp)
 };
 
@@ -200,6 +211,10 @@ hipError_t widen_rows(const uint8_t *d_packed, uint64_t r, uint32_t *d_wide, hip
 // Fills the 4^K entries of the top-of-walk table (DevIndex::kmer) by walking every K-mer from the start state with the
 // plain base-synchronous automaton.  ix.kmer / ix.kmer_k of `ix` are ignored; K in [1, 12]; thresholds types (kmode 6) only.
 hipError_t build_kmer_table(const DevIndex &ix, uint32_t K, uint4 *d_table, hipStream_t stream);
+// Look-ahead rows (DevIndex::rows2): ahead_rows_bytes(r) bytes at d_rows2, written by one kernel (a gather of id(id(i))
+// per row); *tail = DevIndex::rows2_tail.  Thresholds types (kmode 6: the PML walk's rows), r >= 8.
+uint64_t ahead_rows_bytes(uint64_t r);
+hipError_t build_ahead_rows(int kmode, const DevIndex &ix, uint8_t *d_rows2, uint64_t *tail, hipStream_t stream);
 
 // Fills the 4^K entries of the count query's interval table (DevIndex::ftab); mode = resident layout (6 or 3).
 hipError_t build_ftab(int mode, const DevIndex &ix, uint32_t K, uint4 *d_table, hipStream_t stream);

@@ -296,7 +296,7 @@ class MoveIndex:
         li = LaunchInfoC()
         check(lib().movi_last_launch(self._h, C.byref(li)))
         return {"kernel": li.kernel.decode(), "variant": int(li.variant), "block_threads": int(li.block_threads),
-                "waves_per_cu": int(li.waves_per_cu), "segmented": int(li.segmented), "idx64": int(li.idx64), "staged": int(li.staged)}
+                "waves_per_cu": int(li.waves_per_cu), "segmented": int(li.segmented), "idx64": int(li.idx64), "staged": int(li.staged), "ahead": int(li.ahead)}
 
     def last_stats(self, stream=0):
         st = QueryStatsC()

@@ -1,0 +1,180 @@
+"""GPU suite (-m gpu): look-ahead rows ("ahead_rows" option) -- the table's second copy in which every row carries what
+its LF target looks like, so that a base that matches there without a fast-forward is resolved without fetching the
+target: two bases per gather (reference semantics of the step: src/read_processor.cpp:188-238 match branch + LF_move,
+src/move_structure.cpp:59-87).  Only staged short-read launches walk on them.  PMLs, error bytes, bins and the
+fast-forward / scan / reposition counters must equal the oracle's and those of the same launch without the copy: on every
+index type the PML walk serves, for every read length the staging area holds, next to wavefronts that cannot stage, with
+illegal bases, separators, corrupt rows, both row-index widths and tables whose last window sits differently in its line."""
+import numpy as np
+import pytest
+
+from test_gpu_parity import mutated_reads, pack
+from test_top_of_walk_gpu import _ref
+
+pytestmark = pytest.mark.gpu
+
+CAP = 336          # bases per lane the default occupancy cap's LDS padding holds
+N_BIG = 300_000    # > 256 CUs x 64 lanes x 18 wavefronts: the capped, staged launch
+
+
+def _big_batch(ref, rng, n=N_BIG, max_len=CAP, sub=0.02, n_long=40, alphabet=b"ACGT"):
+    lens = rng.integers(0, max_len + 1, n).astype(np.uint64)
+    if n_long:
+        lens[rng.choice(n, n_long, replace=False)] = rng.integers(CAP + 1, 2000, n_long)   # wavefronts that cannot stage
+    lens[:64] = CAP
+    lens[64:128] = 0
+    lens[128:192] = 1
+    lens[192:256] = 2
+    starts = rng.integers(0, len(ref) - 2000, n)
+    offs = np.zeros(n + 1, np.uint64)
+    np.cumsum(lens, out=offs[1:])
+    refa = np.frombuffer(ref, np.uint8)
+    idx = np.repeat(starts.astype(np.int64) - offs[:-1].astype(np.int64), lens.astype(np.int64)) + np.arange(int(offs[-1]), dtype=np.int64)
+    bases = refa[idx].copy()
+    mut = rng.random(bases.size)
+    bases[mut < sub] = np.frombuffer(alphabet, np.uint8)[rng.integers(0, len(alphabet), int((mut < sub).sum()))]
+    bases[(mut >= sub) & (mut < sub + 0.003)] = ord("N")
+    return bases, offs
+
+
+@pytest.mark.parametrize("mode", [6, 8, 7])
+def test_ahead_rows_vs_oracle(built_lib, golden_image, mode):
+    import movi_amd
+    from oracle import build_index as B
+    from oracle.oracle import Oracle
+    ref = _ref()
+    img = golden_image(mode) if mode != 7 else B.build_index_from_seqs([ref], 7)
+    gpu, cpu = movi_amd.MoveIndex.from_image(img), Oracle(img)
+    bases, offs = _big_batch(ref, np.random.default_rng(9100 + mode))
+    exp, ff, sc = cpu.pml_batch(bases, offs, threads=8)
+    gpu.set_option("ahead_rows", 0)
+    gpu.set_option("kmer_k", 0)
+    out0, st0 = gpu.query_pml_packed(bases, offs)
+    li = gpu.last_launch()
+    assert li["ahead"] == 0 and li["staged"] == CAP and li["kernel"].endswith(", 0, 0, 1, 0>")
+    assert (out0 == exp).all() and (st0.fast_forwards, st0.scans, st0.errors) == (ff, sc, 0)
+    bins0 = gpu.classify_packed(bases, offs, 40, 4)
+    gpu.set_option("ahead_rows", 1)
+    for K in (0, 12):
+        gpu.set_option("kmer_k", K)
+        out, st = gpu.query_pml_packed(bases, offs)
+        li = gpu.last_launch()
+        assert li["ahead"] == 1 and li["staged"] == CAP and li["kernel"].endswith(", 0, 0, 1, 1>")
+        assert (out == exp).all(), (mode, K)
+        assert (st.fast_forwards, st.scans, st.repositions, st.errors) == (ff, sc, st0.repositions, 0), (mode, K)
+        assert st.lane_steps < 0.8 * st0.lane_steps, (mode, K)          # the point of it: most bases ride along
+        bins = gpu.classify_packed(bases, offs, 40, 4)                  # fused bins with the vector ...
+        assert all((x == y).all() for x, y in zip(bins, bins0)), K
+    # ... and a launch that cannot stage (small batch, long reads) never touches the copy
+    small = mutated_reads(np.random.default_rng(9200), ref, 300, 1, 3000)
+    sb, so = pack(small)
+    sexp, sff, ssc = cpu.pml_batch(sb, so, threads=4)
+    sout, sst = gpu.query_pml_packed(sb, so)
+    assert gpu.last_launch()["ahead"] == 0
+    assert (sout == sexp).all() and (sst.fast_forwards, sst.scans) == (sff, ssc)
+    # 64-bit row indexes: the same walk on the other instantiation
+    gpu.set_option("idx64", 1)
+    out, st = gpu.query_pml_packed(bases, offs)
+    assert gpu.last_launch()["ahead"] == 1 and gpu.last_launch()["idx64"] == 1
+    assert (out == exp).all() and (st.fast_forwards, st.scans, st.errors) == (ff, sc, 0)
+    gpu.close()
+    cpu.close()
+
+
+def test_ahead_rows_are_built_by_the_first_pml_query_on_a_small_table(built_lib, golden_image):
+    import movi_amd
+    from oracle.oracle import Oracle
+    img = golden_image(6)
+    gpu, cpu = movi_amd.MoveIndex.from_image(img), Oracle(img)
+    bases, offs = _big_batch(_ref(), np.random.default_rng(9300), n_long=0, max_len=200)
+    exp, ff, sc = cpu.pml_batch(bases, offs, threads=8)
+    out, st = gpu.query_pml_packed(bases, offs)                         # nothing set: table + look-ahead rows by themselves
+    assert gpu.last_launch()["ahead"] == 1
+    assert (out == exp).all() and (st.fast_forwards, st.scans, st.errors) == (ff, sc, 0)
+    m, c, _ = gpu.query_count_packed(bases[: int(offs[1000])], offs[:1001])   # other queries are not affected
+    em, ec = cpu.count_batch(bases[: int(offs[1000])], offs[:1001], threads=4)
+    assert (m == em).all() and (c == ec).all()
+    gpu.set_option("ahead_rows", 0)
+    out, st2 = gpu.query_pml_packed(bases, offs)
+    assert gpu.last_launch()["ahead"] == 0 and (out == exp).all() and st2.lane_steps > st.lane_steps
+    gpu.close()
+    cpu.close()
+
+
+@pytest.mark.parametrize("cut", [0, 1, 2, 3, 4, 5, 6, 7])
+def test_ahead_rows_last_window(built_lib, cut):
+    """The walk's last window is pulled back to rows r-4 .. r-1 and has a line of its own in the copy: tables whose row count
+    leaves every remainder modulo 8 (every read starts in that window, at row r-1)."""
+    import movi_amd
+    from oracle import build_index as B
+    from oracle.oracle import Oracle
+    ref = _ref()
+    extra = {1: 0, 5: 7, 0: 14, 2: 28, 6: 42, 3: 49, 7: 105, 4: 112}[cut]     # prefixes of the reference whose tables have r % 8 == cut
+    img = B.build_index_from_seqs([ref[: 30000 + extra]], 6)
+    assert movi_amd.parse_index_image(img)[1].r % 8 == cut
+    gpu, cpu = movi_amd.MoveIndex.from_image(img), Oracle(img)
+    bases, offs = _big_batch(ref[:30000], np.random.default_rng(9400 + cut), max_len=64, n_long=3)
+    exp, ff, sc = cpu.pml_batch(bases, offs, threads=8)
+    gpu.set_option("ahead_rows", 1)
+    for K in (0, 5):
+        gpu.set_option("kmer_k", K)
+        out, st = gpu.query_pml_packed(bases, offs)
+        assert gpu.last_launch()["ahead"] == 1
+        assert (out == exp).all() and (st.fast_forwards, st.scans, st.errors) == (ff, sc, 0), (cut, K)
+    gpu.close()
+    cpu.close()
+
+
+def test_ahead_rows_on_a_separators_index(built_lib):
+    import movi_amd
+    from oracle import build_index as B
+    from oracle.oracle import Oracle
+    ref = _ref()
+    img = B.build_index_from_seqs([ref[:40000], ref[40000:90000], ref[90000:]], 6, separators=True)
+    gpu, cpu = movi_amd.MoveIndex.from_image(img), Oracle(img)
+    bases, offs = _big_batch(ref, np.random.default_rng(9500), alphabet=b"ACGT%")
+    exp, ff, sc = cpu.pml_batch(bases, offs, threads=8)
+    gpu.set_option("ahead_rows", 1)
+    for K in (0, 9):
+        gpu.set_option("kmer_k", K)
+        out, st = gpu.query_pml_packed(bases, offs)
+        assert gpu.last_launch()["ahead"] == 1 and gpu.last_launch()["kernel"].endswith("0, 1, 0, 0, 1, 1>")
+        assert (out == exp).all() and (st.fast_forwards, st.scans, st.errors) == (ff, sc, 0), K
+    gpu.close()
+    cpu.close()
+
+
+def test_ahead_rows_with_corrupt_rows(built_lib, golden_image):
+    """Rows whose id (or whose target's id) points past the table carry an invalid entry: those steps are taken one by one
+    and run into the reference's throw exactly as without the copy."""
+    import movi_amd
+    img = bytearray(golden_image(6))
+    _, _, off, _ = movi_amd.parse_index_image(bytes(img))
+    rows = np.frombuffer(img, np.uint8, count=118209 * 8, offset=off).reshape(-1, 8).copy()
+    rng = np.random.default_rng(9600)
+    hit = rng.choice(118209, 3000, replace=False)
+    rows[hit, 0:4] = 0xFF
+    img[off: off + rows.size] = rows.tobytes()
+    gpu = movi_amd.MoveIndex.from_image(bytes(img))
+    bases, offs = _big_batch(_ref(), rng, max_len=120)
+    gpu.set_option("ahead_rows", 0)
+    e_out, e_st, e_err, e_rc = gpu.query_pml_packed(bases, offs, want_err=True)
+    assert e_rc == -6 and e_st.errors > 1000
+    gpu.set_option("ahead_rows", 1)
+    for K in (0, 8):
+        gpu.set_option("kmer_k", K)
+        out, st, err, rc = gpu.query_pml_packed(bases, offs, want_err=True)
+        assert gpu.last_launch()["ahead"] == 1
+        assert rc == -6 and (out == e_out).all() and (err == e_err).all() and st.errors == e_st.errors, K
+    gpu.close()
+
+
+def test_ahead_rows_refused_where_they_cannot_serve(built_lib):
+    import movi_amd
+    from oracle import build_index as B
+    gpu = movi_amd.MoveIndex.from_image(B.build_index_from_seqs([_ref()[:20000]], 3))   # no thresholds: no PML walk
+    with pytest.raises(movi_amd.MoviError):
+        gpu.set_option("ahead_rows", 1)
+    with pytest.raises(movi_amd.MoviError):
+        gpu.set_option("ahead_rows", 2)
+    gpu.close()

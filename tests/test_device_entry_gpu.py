@@ -165,7 +165,7 @@ def test_last_launch_reports_the_policy(engine6):
     bases, offs = pack([b"ACGTACGTAC" * 20] * 300)
     gpu.query_pml_packed(bases, offs)
     li = gpu.last_launch()
-    assert li["kernel"] == "pml_kernel_flatp<6, unsigned int, -1, 0, 0, 0, 0, 0>" and li["variant"] == 14
+    assert li["kernel"] == "pml_kernel_flatp<6, unsigned int, -1, 0, 0, 0, 0, 0, 0>" and li["variant"] == 14
     assert li["block_threads"] == 64 and li["waves_per_cu"] == 0 and li["segmented"] == 0
     gpu.set_option("pml_variant", 1)
     gpu.query_pml_packed(bases, offs)
