@@ -760,11 +760,13 @@ __device__ __forceinline__ uint2 win_sel(const uint2 (&w)[4], uint32_t q) {
 // segment's flag instead of err[] / zero-filling, and adds nothing to the global fast-forward / scan counters: which
 // part of its work belongs to the read's real walk is only known after K2); 2 = whole reads again, but only those in
 // seg.read_fail (K3).
-// AHD (look-ahead rows, DevIndex::rows2; staged wavefronts only): the window comes from the table's second copy, together
-// with the look-ahead entry of the row it was fetched for.  When the step's emitted base is followed by a base that
+// AHD (look-ahead rows, DevIndex::rows2; staged kernels only): the window comes from the table's second copy, together
+// with the look-ahead entries of its four rows (the other half of the same 128-byte line).  When the step's emitted base is followed by a base that
 // matches at the LF target j = id(row) without a fast-forward -- known from the entry: c(j), n(j) against the offset --
-// the walk emits that PML as well and goes straight on to id(j): two bases for one gather.  Everything else (a moved
-// row, a mismatch, a fast-forward at j, the read's end, an invalid entry) takes the one-base step it always took.
+// the walk emits that PML as well and goes straight on to id(j): two bases for one gather.  Everything else (a
+// mismatch, a fast-forward at j, the read's end, an invalid entry) takes the one-base step it always took.
+// (Fetching only the entry of the row the window was fetched FOR -- 8 bytes instead of 32 -- misses the steps that end on a
+// neighbour after a fast-forward or scan: 68.5 against 74.4 Gbases/s on c2, 54.1 against 62.8 on the random table.)
 template <int MODE, typename IdxT, int HA, int CLS, int SEP, int REFILL, int SEG = 0, int STG = 0, int AHD = 0>
 __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8_t *__restrict__ bases,
                                                        const uint64_t *__restrict__ offs, uint64_t n_reads,
@@ -828,16 +830,15 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
         const IdxT wb = nd & ~(IdxT)3;
         return wb < wb_last ? wb : wb_last;
     };
-    uint2 ah = make_uint2(0u, 0u);                        // AHD: look-ahead entry of the row the window was fetched for
+    uint2 ahw[4];                                         // AHD: the look-ahead entries of the window's four rows
     auto fetch = [&](IdxT nd, bool act, uint2 (&w)[4]) {
         if (AHD) {                                        // line = 8 rows + their 8 entries; the last window has a line of its own
             const IdxT wb = nd & ~(IdxT)3;
             const bool body = wb < wb_last;
             uint64_t at = body ? (uint64_t)(wb >> 3) * 128u + (uint64_t)((uint32_t)wb & 4u) * 8u : ix.rows2_tail;
-            uint32_t q = (uint32_t)(nd - (body ? wb : wb_last));
-            if (!act) { at = 0; q = 0; }
+            if (!act) at = 0;
             load_window<MODE>(ix.rows2 + at, 0, w);
-            __builtin_memcpy(&ah, ix.rows2 + at + 64u + 8u * q, 8);
+            load_window<MODE>(ix.rows2 + at + 64u, 0, ahw);
         } else {
             load_window<MODE>(ix.rows, (uint64_t)(act ? win_base(nd) : (IdxT)0), w);
         }
@@ -869,43 +870,48 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
         load_pair_at(beg + len, rb, rb2);
         fix_pair(beg + len, rb, rb2);
     }
-    if (len > 16) load_pair_at(beg + len - 16, nx0, nx1);
+    if (!STG && len > 16) load_pair_at(beg + len - 16, nx0, nx1);
     uint32_t a = s_code[(uint32_t)(rb >> 56) & 0xFFu];    // code of the base of step k (k = 0)
     uint4 pk = make_uint4(0, 0, 0, 0), pk_old = pk;
     if (CLS) cs.init(len, cls.bin_width);
-    // ---- reads staged through LDS (ix.stage_lds: the launcher found the block's dynamic LDS -- the occupancy cap's
-    // padding, 21 KiB per one-wavefront block at the default cap -- big enough): a wavefront whose reads all have at most ix.stage_lds (336) bases copies
-    // them into LDS once, at the start -- each lane its own read, 16 bytes per load from the read's end backwards, so the
-    // 64 x 150 contiguous bytes of the wavefront's reads come in as whole cache lines, each fetched ONCE (the lines stay in
-    // the CU's L1 over these back-to-back loads) -- and takes every base from there.  The walk's other way to its bases,
-    // 16 at a time from global memory (below), re-fetches a read's cache line for every 16 bases: its line is evicted
-    // long before the lane comes back (0.0625 lines per base, 6 % of all line fetches of a big batch).  Layout: step k of
-    // lane l at byte (k / 4) * 256 + 4 l + k % 4 -- lanes in step read consecutive banks.  Wavefronts with a longer read
-    // (and segments, and refilled lanes) keep the global path: the choice is wave-uniform.  STG is a template parameter
-    // so that launches that never stage -- long reads, small batches -- run exactly the loop they ran before (as a
-    // run-time flag alone the extra branch cost the 100 k x 10 kbp shape 2 %).
+    // ---- reads staged through LDS (STG; ix.stage_lds = bases per lane, a multiple of 16, >= 128: the block's dynamic LDS --
+    // the occupancy cap's padding, or what the launcher adds for it): every lane copies the next ix.stage_lds bases of its
+    // read into LDS -- 16 bytes per load from the read's end backwards, so the 64 x 150 contiguous bytes of a wavefront of
+    // short reads come in as whole cache lines, each fetched ONCE (the lines stay in the CU's L1 over these back-to-back
+    // loads) -- and takes every base from there.  The other way to the bases, 16 at a time from global memory (STG = 0,
+    // below), re-fetches a read's cache line for every 16 bases: its line is evicted long before the lane comes back
+    // (0.0625 lines per base, 6 % of all line fetches of a big batch).  Longer reads ROLL: when any lane of the wavefront
+    // is about to leave its staged stretch, every lane stages again from where it stands (stage_from in the loop) -- one
+    // extra round trip per >= stage_lds / 2 iterations.  Layout: slot s of lane l at byte (s / 4) * 256 + 4 l + s % 4 --
+    // lanes in step read consecutive banks; slot s holds the base of step kbase + s.
     extern __shared__ __align__(16) uint8_t s_stage[];
-    bool staged = false;
-    if (STG && ix.stage_lds != 0u) {
-        staged = !wave_any(len > ix.stage_lds);
-        if (staged) {
-            uint32_t *S = reinterpret_cast<uint32_t *>(s_stage);
-            const uint32_t sl = threadIdx.x & 63u;
-            for (uint32_t g = 0; wave_any(16u * g < len); ++g) {
-                if (16u * g < len) {
-                    const uint64_t e = beg + len - 16u * g;
-                    uint64_t c0, c1;
-                    load_pair_at(e, c0, c1);
-                    fix_pair(e, c0, c1);
-                    const uint64_t r0 = __builtin_bswap64(c0), r1 = __builtin_bswap64(c1);   // step 16 g in the low byte
-                    S[(4u * g + 0u) * 64u + sl] = (uint32_t)r0;
-                    S[(4u * g + 1u) * 64u + sl] = (uint32_t)(r0 >> 32);
-                    S[(4u * g + 2u) * 64u + sl] = (uint32_t)r1;
-                    S[(4u * g + 3u) * 64u + sl] = (uint32_t)(r1 >> 32);
-                }
+    uint32_t kbase = 0;
+    const uint32_t stage_cap = ix.stage_lds;
+    auto stage_from = [&](uint32_t k0, bool on) {         // every lane of the wavefront makes the call
+        uint32_t *S = reinterpret_cast<uint32_t *>(s_stage);
+        const uint32_t sl = threadIdx.x & 63u;
+        const uint32_t left = (on && len > k0) ? len - k0 : 0u;
+        const uint32_t cnt = left < stage_cap ? left : stage_cap;
+        for (uint32_t g = 0; wave_any(16u * g < cnt); ++g) {
+            if (16u * g < cnt) {
+                const uint64_t e = beg + len - k0 - 16u * g;
+                uint64_t c0, c1;
+                load_pair_at(e, c0, c1);
+                fix_pair(e, c0, c1);
+                const uint64_t r0 = __builtin_bswap64(c0), r1 = __builtin_bswap64(c1);   // step k0 + 16 g in the low byte
+                S[(4u * g + 0u) * 64u + sl] = (uint32_t)r0;
+                S[(4u * g + 1u) * 64u + sl] = (uint32_t)(r0 >> 32);
+                S[(4u * g + 2u) * 64u + sl] = (uint32_t)r1;
+                S[(4u * g + 3u) * 64u + sl] = (uint32_t)(r1 >> 32);
             }
         }
-    }
+        kbase = k0;
+    };
+    auto staged_code = [&](uint32_t slot) -> uint32_t {   // code of the base in `slot` (clamped into the staged stretch)
+        const uint32_t q = slot < stage_cap ? slot : stage_cap - 1u;
+        return s_code[s_stage[(q >> 2) * 256u + (threadIdx.x & 63u) * 4u + (q & 3u)]];
+    };
+    if (STG) stage_from(0u, st != sDone);
     // ---- top of the walk (DevIndex::kmer): the first K bases of the read (segment) by ONE table lookup.  Reads with an
     // illegal base among them, reads of K bases or fewer and K-mers whose walk throws take the ordinary walk.
     if (!REFILL && ix.kmer_k != 0u) {                     // wave-uniform
@@ -953,13 +959,9 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
             a = s_code[(uint32_t)(rb >> (8u * (7u - (K & 7u)))) & 0xFFu];
         }
     }
-    // AHD: the code of the base after the current one (staged wavefronts only; beyond the read's end: never looked at)
-    auto staged_code = [&](uint32_t kk) -> uint32_t {
-        return s_code[s_stage[(kk >> 2) * 256u + (threadIdx.x & 63u) * 4u + (kk & 3u)]];
-    };
-    const uint32_t stage_top = ix.stage_lds - 1u;
+    // AHD: the code of the base after the current one (beyond the read's end: never looked at)
     uint32_t a1 = 0xFFu;
-    if (AHD && staged) a1 = staged_code(k + 1 < stage_top ? k + 1 : stage_top);
+    if (AHD) a1 = staged_code(k + 1);
     uint2 w[4];
     fetch(need, st != sDone, w);
 
@@ -989,7 +991,6 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
         lane_steps += (uint32_t)act;
         wave_steps += 1;
         const IdxT wbase = win_base(need);
-        const IdxT need0 = need;                          // (AHD: `ah` belongs to this row)
         // cheap hop: a fast-forward or scan step that only moves on (everything that resolves a base,
         // starts a scan, ends one or fails is left to the full step below)
         auto hop = [&]() {
@@ -1089,9 +1090,10 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
         // match and no fast-forward: ml + 1, then LF_move again) -- the target row itself is never fetched
         uint32_t dbl = 0, lf2 = 0, off1 = 0;
         if (AHD) {
+            const uint2 ah = win_sel(ahw, qn);            // the entry of the row the base was resolved at
             const uint32_t n1 = ah.y & 0x7FFu, c1 = (ah.y >> 22) & 7u;
             const uint32_t off_e = (hit ? (isDown ? 0u : n - 1u) : off) + roff;
-            dbl = lf & (ah.y >> 31) & (uint32_t)(need == need0) & (uint32_t)(a1 == c1) & (uint32_t)(off_e < n1) & (uint32_t)staged;
+            dbl = lf & (ah.y >> 31) & (uint32_t)(a1 == c1) & (uint32_t)(off_e < n1);
             lf2 = dbl & (uint32_t)(k + 2 != len);
             off1 = (ah.y >> 11) & 0x7FFu;
             const IdxT j2 = (IdxT)((uint64_t)ah.x | ((uint64_t)((ah.y >> 25) & 15u) << 32));
@@ -1182,13 +1184,10 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
                 }
                 k += 1;
             }
-            if (AHD && staged) {                          // wave-uniform: this base's code and the next one's
-                a = staged_code(k < stage_top ? k : stage_top);
-                a1 = staged_code(k + 1 < stage_top ? k + 1 : stage_top);
+            if (STG) {
+                // (the next base's code: after the state update below, where a lane about to leave its staged stretch is seen)
             } else if (lf) {
-                if (STG && staged) {                      // wave-uniform
-                    a = s_code[s_stage[(k >> 2) * 256u + (threadIdx.x & 63u) * 4u + (k & 3u)]];
-                } else {
+                {
                     if ((k & 15) == 8) {
                         rb = rb2;
                     } else if ((k & 15) == 0) {
@@ -1204,6 +1203,15 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
         if (errc) failed = errc;
         need = need_next;
         st = st_next;
+        if (STG) {
+            // a lane whose next bases lie beyond its staged stretch: the whole wavefront stages again, each lane from its own step
+            const uint32_t ahead_of = k - kbase;          // < 2^31: k >= kbase always
+            const uint32_t out_of = (uint32_t)(st != sDone) &
+                                    ((uint32_t)(ahead_of >= stage_cap) | ((uint32_t)(ahead_of + 1u >= stage_cap) & (uint32_t)(k + 1 < len)));
+            if (wave_any(out_of != 0u)) stage_from(k, st != sDone);
+            a = staged_code(k - kbase);
+            if (AHD) a1 = staged_code(k + 1 - kbase);
+        }
         if (REFILL) {
             // ---- lane refill, all of it under the gather's latency.  Order matters for the waits hipcc inserts: every
             // block reads its registers BEFORE any block below it issues a load into them.
@@ -1924,7 +1932,10 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     uint64_t blocks = (n_reads + bt - 1) / bt;
     int wpc = cfg.waves_per_cu;
     if (wpc < 0) wpc = 0;
-    if (cfg.waves_per_cu == 0 && (cfg.pml_variant < 0 || cfg.pml_variant == 14) && v == 10 && big_batch) wpc = kCapWaves;   // the auto policy above
+    const bool stage_ok = cfg.stage_reads != 0 && bt == 64 && v == 10 && wp;       // the staged kernels: one-wavefront blocks of the default walk
+    const bool ahead_ok = stage_ok && ix.rows2 != nullptr && cfg.ahead != 0;       // ... on the look-ahead rows
+    if (cfg.waves_per_cu == 0 && (cfg.pml_variant < 0 || cfg.pml_variant == 14) && v == 10 && big_batch)
+        wpc = ahead_ok ? kCapWavesAhead : kCapWaves;                               // the auto policy above
     if (v == 13) {
         wpc = wpc_refill;
         const uint64_t resident = (refill_blocks * 64u + bt - 1) / bt;
@@ -1941,14 +1952,19 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
         if (bpc < 1) bpc = 1;
         if (bpc < 32) dyn_lds = ((163840u / (unsigned)bpc) & ~1023u) - 1024u;
     }
-    // reads staged through LDS (pml_kernel_flatp): needs 256 bytes per lane of the one-wavefront block -- what the occupancy
-    // cap's padding provides for caps of up to 9 wavefronts per CU (the default cap is kCapWaves = 7).  cfg.stage_reads: 1 = when it fits (default), 0 = never
+    // Reads staged through LDS (pml_kernel_flatp<..., STG = 1>): the block's dynamic LDS holds the next stage_lds bases of each
+    // of its 64 reads.  A capped launch has that LDS anyway (the padding: 21 KiB = 336 bases per lane at the default cap of 7
+    // wavefronts per CU, 16 KiB = 256 at 9); an uncapped one (a batch of at most ~18 wavefronts per CU, one round) gets what
+    // its wavefronts per CU leave of the 160 KiB, so that the round stays one round.  Long reads roll through the same
+    // stretch (stage_from in the kernel).  cfg.stage_reads: 1 = whenever it fits (default), 0 = never.
     DevIndex ixl = ix;
-    // (capacity per lane = what the padding leaves, a multiple of 16: the default cap of 7 wavefronts per CU pads with 21 KiB =
-    // 336 bases per lane, a cap of 9 with 16 KiB = 256, a cap of 12 with 12 KiB = 192)
+    if (stage_ok && wpc == 0) {
+        const uint64_t wn = (blocks + (uint64_t)cfg.num_cus - 1) / (uint64_t)cfg.num_cus;      // wavefronts per CU of this launch
+        if (wn <= 18) dyn_lds = std::min<size_t>(21504, ((163840u / (unsigned)std::max<uint64_t>(wn, 1)) & ~1023u) - 1024u);
+    }
     const uint32_t stage_cap = (uint32_t)std::min<size_t>(1024, (dyn_lds / 64) & ~(size_t)15);
-    ixl.stage_lds = (cfg.stage_reads != 0 && bt == 64 && stage_cap >= 128 && v == 10 && wp) ? stage_cap : 0u;
-    const bool use_ahead = ixl.stage_lds != 0u && ix.rows2 != nullptr && cfg.ahead != 0 && v != 13;   // look-ahead rows: the staged kernel only
+    ixl.stage_lds = (stage_ok && stage_cap >= 96) ? stage_cap : 0u;
+    const bool use_ahead = ahead_ok && ixl.stage_lds != 0u;
     const SegArgs no_seg;
     // every kernel that is handed more than 64 KiB of dynamic LDS must opt in first
 #define MOVI_SEG_0

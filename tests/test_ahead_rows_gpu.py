@@ -13,7 +13,8 @@ from test_top_of_walk_gpu import _ref
 
 pytestmark = pytest.mark.gpu
 
-CAP = 336          # bases per lane the default occupancy cap's LDS padding holds
+CAP = 336          # bases per lane the default occupancy cap's LDS padding holds (7 wavefronts per CU) ...
+CAP_AHEAD = 256    # ... and the cap on the look-ahead rows (9 wavefronts per CU)
 N_BIG = 300_000    # > 256 CUs x 64 lanes x 18 wavefronts: the capped, staged launch
 
 
@@ -59,19 +60,29 @@ def test_ahead_rows_vs_oracle(built_lib, golden_image, mode):
         gpu.set_option("kmer_k", K)
         out, st = gpu.query_pml_packed(bases, offs)
         li = gpu.last_launch()
-        assert li["ahead"] == 1 and li["staged"] == CAP and li["kernel"].endswith(", 0, 0, 1, 1>")
+        assert li["ahead"] == 1 and (li["staged"], li["waves_per_cu"]) == (CAP_AHEAD, 9) and li["kernel"].endswith(", 0, 0, 1, 1>")
         assert (out == exp).all(), (mode, K)
         assert (st.fast_forwards, st.scans, st.repositions, st.errors) == (ff, sc, st0.repositions, 0), (mode, K)
         assert st.lane_steps < 0.8 * st0.lane_steps, (mode, K)          # the point of it: most bases ride along
         bins = gpu.classify_packed(bases, offs, 40, 4)                  # fused bins with the vector ...
         assert all((x == y).all() for x, y in zip(bins, bins0)), K
-    # ... and a launch that cannot stage (small batch, long reads) never touches the copy
+    # ... a small batch of long reads: uncapped, rolling through its staged stretch many times
     small = mutated_reads(np.random.default_rng(9200), ref, 300, 1, 3000)
     sb, so = pack(small)
     sexp, sff, ssc = cpu.pml_batch(sb, so, threads=4)
+    gpu.set_option("seg_len", 0)                                        # (one lane per read: not the segment-parallel plan)
     sout, sst = gpu.query_pml_packed(sb, so)
-    assert gpu.last_launch()["ahead"] == 0
+    li = gpu.last_launch()
+    assert li["ahead"] == 1 and li["waves_per_cu"] == 0 and li["staged"] == CAP and li["segmented"] == 0
     assert (sout == sexp).all() and (sst.fast_forwards, sst.scans) == (sff, ssc)
+    # ... and batches between one and 18 wavefronts per CU, which get what their wavefronts leave of the CU's LDS
+    for n_mid, cap_mid in ((150_000, 240), (280_000, 112)):
+        mb, mo = bases[: int(offs[n_mid])], offs[: n_mid + 1]
+        mout, mst = gpu.query_pml_packed(mb, mo)
+        li = gpu.last_launch()
+        assert li["ahead"] == 1 and li["waves_per_cu"] == 0 and li["staged"] == cap_mid, li
+        assert (mout == exp[: mb.size]).all() and mst.errors == 0
+    gpu.set_option("seg_len", 2048)
     # 64-bit row indexes: the same walk on the other instantiation
     gpu.set_option("idx64", 1)
     out, st = gpu.query_pml_packed(bases, offs)

@@ -56,9 +56,10 @@ def test_top_of_walk_vs_oracle(built_lib, golden_image, mode, K):
         out, st = gpu.query_pml_packed(bases, offs)
         assert (out == exp).all(), (mode, K, variant)
         assert (st.fast_forwards, st.scans, st.repositions, st.errors) == (ff, sc, base_st.repositions, 0), (mode, K, variant)
+        if variant == -1:
+            # fewer iterations than without the table (the point of it; K = 1 only saves the start row's own step)
+            assert K < 8 or st.lane_steps < base_st.lane_steps
     gpu.set_option("pml_variant", -1)
-    # fewer iterations than without the table (the point of it; K = 1 only saves the start row's own step)
-    assert K < 8 or st.lane_steps < base_st.lane_steps
     # fused bins, with and without the PML vector
     exp_bins = None
     gpu.set_option("kmer_k", 0)
@@ -141,11 +142,11 @@ def test_top_of_walk_with_corrupt_rows(built_lib, golden_image):
 
 @pytest.mark.parametrize("mode", [6, 8])
 def test_reads_staged_through_lds_vs_oracle(built_lib, golden_image, mode):
-    """Big batches (more reads than ~18 wavefronts per CU) run capped at 9 wavefronts per CU, and the LDS that enforces the
-    cap holds the reads: a wavefront whose 64 reads all have at most 336 bases (what the padding holds) copies them into LDS once and takes every
-    base from there; wavefronts with a longer read keep fetching 16 bases at a time from global memory.  Both kinds in one
-    launch, every length from 0 to 256 and beyond, with and without the top-of-walk table, fused bins included: PMLs, error
-    bytes and counters equal the oracle's and those of the unstaged launch."""
+    """Big batches (more reads than ~18 wavefronts per CU) run capped at 7 wavefronts per CU, and the LDS that enforces the
+    cap holds the reads: every lane copies the next 336 bases of its read (what the padding holds) into LDS and takes every
+    base from there; a wavefront with a longer read stages again, every lane from where it stands, whenever one of its lanes
+    leaves its stretch.  Both kinds in one launch, every length from 0 to 336 and beyond, with and without the top-of-walk
+    table, fused bins included: PMLs, error bytes and counters equal the oracle's and those of the unstaged launch."""
     import movi_amd
     from oracle.oracle import Oracle
     img = golden_image(mode)
@@ -168,6 +169,7 @@ def test_reads_staged_through_lds_vs_oracle(built_lib, golden_image, mode):
     bases[mut < 0.02] = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, int((mut < 0.02).sum()))]
     bases[(mut >= 0.02) & (mut < 0.023)] = ord("N")
     exp, ff, sc = cpu.pml_batch(bases, offs, threads=8)
+    gpu.set_option("ahead_rows", 0)                       # (tests/test_ahead_rows_gpu.py; with them the cap is 9 and the stretch 256)
     gpu.set_option("stage_reads", 0)
     gpu.set_option("kmer_k", 0)
     out0, st0 = gpu.query_pml_packed(bases, offs)
@@ -181,6 +183,7 @@ def test_reads_staged_through_lds_vs_oracle(built_lib, golden_image, mode):
             gpu.set_option("pml_variant", variant)
             out, st = gpu.query_pml_packed(bases, offs)
             assert gpu.last_launch()["staged"] == (CAP if variant == -1 else 0), (K, variant)   # staging: the default kernel only
+            assert gpu.last_launch()["ahead"] == 0
             assert (out == exp).all(), (K, variant)
             assert (st.fast_forwards, st.scans, st.repositions, st.errors) == (ff, sc, st0.repositions, 0), (K, variant)
         gpu.set_option("pml_variant", -1)
