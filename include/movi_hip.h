@@ -226,9 +226,9 @@ typedef struct movi_launch_info {
     int32_t waves_per_cu;             /* cap on resident wavefronts per CU that was applied (0 = none)             */
     int32_t segmented;                /* 1 = the segment-parallel plan ran around that kernel                       */
     int32_t idx64;                    /* 1 = the 64-bit row-index instantiation                                     */
-    int32_t staged;                   /* > 0: wavefronts whose reads all have at most this many bases copy them into LDS once
-                                         ("stage_reads"; 336 at the default occupancy cap); 0: no staging in this launch */
-    int32_t ahead;           /* 1 = the walk ran on the look-ahead rows ("ahead_rows") */
+    int32_t staged;                   /* > 0: every lane keeps the next `staged` bases of its read in LDS ("stage_reads";
+                                         336 at the default occupancy cap, 256 on the look-ahead rows); 0: no staging */
+    int32_t ahead;                    /* 1 = the walk ran on the look-ahead rows ("ahead_rows")                    */
     int32_t reserved_;
 } movi_launch_info_t;
 int movi_last_launch(const movi_index_t *ix, movi_launch_info_t *info);
@@ -315,9 +315,17 @@ int movi_host_unregister(void *p);
  * (top-of-walk table: every walk starts in the same state, so its state after the last K bases of a read is a function
  * of those K bases -- one 16-byte table lookup replaces the first K row gathers of every read and segment; left alone the
  * first PML query on a DNA *-thresholds index builds the K = 12 table (256 MB, a few ms: that one call waits for it);
- * 0 = no table, 1..12 = build that one now), "stage_reads" (1, the default: in big batches a wavefront whose reads
- * all have at most ~336 bases (what the cap's LDS padding holds) copies them into LDS once instead of re-fetching them 16 bases
- * at a time; 0 = off: A/B),
+ * 0 = no table, 1..12 = build that one now), "stage_reads" (1, the default: every lane of the default walk copies the
+ * next stretch of its read -- 336 bases at the default occupancy cap, 256 on the look-ahead rows -- into the block's LDS and
+ * takes its bases from there instead of re-fetching the read's cache line for every 16 bases; long reads roll through the
+ * stretch; 0 = off: A/B),
+ * "ahead_rows" (look-ahead rows: a second copy of the table, 16 bytes per row, in which each row's 128-byte line also holds
+ * what the rows' LF targets look like -- character, length, offset, their own target --, so that a base that matches at the
+ * target without a fast-forward is resolved, and its PML emitted, without fetching the target: two bases per gather on
+ * real reads (+40 % on the cache-resident pangenome table).  Left alone, the first PML query builds them for tables of up
+ * to 100 M rows (a copy of 1.6 GB); beyond that the wider gathers cost more address translations than they save rows on
+ * the worst-case (uniformly random) table -- measured slower -- so there they are built only on request.  1 = build now,
+ * 0 = none (freed)),
  * "ftab_k" (the count query's interval table -- the backward-search interval after the last K bases of a read by one lookup,
  * the reference's own ftab (src/move_structure_search.cpp:66-167) put to work for --count; left alone the first count query
  * on a DNA index builds the K = 12 table (256 MB); 0 = none, 1..12 = build that one now). */

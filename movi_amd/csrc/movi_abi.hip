@@ -751,10 +751,12 @@ static int build_kmer(movi_index *ix, uint32_t K, hipStream_t s) {
     return MOVI_OK;
 }
 
-// Look-ahead rows (DevIndex::rows2): a second copy of the table, 16 bytes per row.  Built by itself only where it pays
-// for certain: tables whose doubled copy still sits in the 256 MiB Infinity Cache (kAheadAutoBytes); "ahead_rows" 1 builds
-// them for any table (real reads on an HBM-sized index: half the gathers for twice the footprint).
-constexpr uint64_t kAheadAutoBytes = 240ull << 20;
+// Look-ahead rows (DevIndex::rows2): a second copy of the table, 16 bytes per row.  Built by itself where it pays even on
+// the worst case for it, a uniformly random table (short runs: the base after the LF fast-forwards more often than not):
+// +14 % at 20 M rows, +8 % at 100 M, -9 % at 200 M rows (1.6 GB of rows), -37 % at 1 B -- beyond the reach of the TLBs the
+// two extra 16-byte loads per step cost more translation requests than the skipped rows save
+// (profiles/r03_ahead_rows_threshold.txt).  "ahead_rows" 1 builds them for any table.
+constexpr uint64_t kAheadAutoBytes = 1600ull << 20;      // of the copy: up to 100 M rows
 static bool ahead_eligible(const movi_index *ix) {
     return ix->kmode == MOVI_MODE_REGULAR_THRESHOLDS && ix->desc.r >= 8 && (ix->desc.r >> 36) == 0;
 }
