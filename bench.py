@@ -615,7 +615,8 @@ def main():
                    "index_upload_s": round(t_index_upload, 2), "index_broadcast_s": round(t_bcast, 3),
                    "reads_gen_s": round(t_reads_gen, 2)},
         "rccl_ranks": rccl_ranks, "index_broadcast_s": round(t_bcast, 4),
-        "roofline": {"bound": bound_of(wl["rows"] * row_bytes), "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "roofline": {"bound": bound_of(wl["rows"] * (16 if launch.get("ahead") else row_bytes)),   # the bytes the walk gathers from: the look-ahead copy is 16 B per row
+                     "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": traffic_src,
                      "kernel": launch["kernel"], "launch": launch,

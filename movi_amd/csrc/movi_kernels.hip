@@ -1933,7 +1933,7 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     int wpc = cfg.waves_per_cu;
     if (wpc < 0) wpc = 0;
     const bool stage_ok = cfg.stage_reads != 0 && bt == 64 && v == 10 && wp;       // the staged kernels: one-wavefront blocks of the default walk
-    const bool ahead_ok = stage_ok && ix.rows2 != nullptr && cfg.ahead != 0;       // ... on the look-ahead rows
+    const bool ahead_ok = stage_ok && ix.rows2 != nullptr;                            // ... on the look-ahead rows
     if (cfg.waves_per_cu == 0 && (cfg.pml_variant < 0 || cfg.pml_variant == 14) && v == 10 && big_batch)
         wpc = ahead_ok ? kCapWavesAhead : kCapWaves;                               // the auto policy above
     if (v == 13) {

@@ -99,7 +99,6 @@ struct LaunchCfg {
                            // 2 = no probe and no read-back at all, the caller's seg_verdict decides: the launch stays asynchronous)
     int seg_verdict = 0;   // seg_probe == 2: 1 = cut eligible batches, 0 = one lane per read
     int stage_reads = 1;   // big batches of short reads: reads staged through LDS (0 = off: A/B)
-    int ahead = 1;         // walk on the look-ahead rows when the index has them and the launch stages its reads (0 = off: A/B)
     int refill_blocks = 0; // variant 13: size of the persistent grid in blocks; 0 = num_cus x waves per CU (tests shrink it
                            // so that a few hundred reads already go through many refills per lane)
 };
