@@ -774,7 +774,7 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
                                                        DevStats *stats, const uint32_t *__restrict__ order,
                                                        ClsArgs cls, SegArgs seg) {
     static_assert(SEG == 0 || (CLS == 0 && REFILL == 0), "segments: plain PML, no refill");
-    static_assert(STG == 0 || (SEG == 0 && REFILL == 0), "reads staged through LDS: whole reads, no refill");
+    static_assert(STG == 0 || REFILL == 0, "reads staged through LDS: no lane refill");
     static_assert(AHD == 0 || (STG == 1 && HA < 0), "look-ahead rows: staged reads, window-parallel advance");
     enum : uint32_t { sFF = 0, sDown = 1, sUp = 2, sDone = 3, sLoad = 4 };   // sLoad (REFILL): first bases of a new read in flight
     __shared__ uint8_t s_code[256];
@@ -1163,6 +1163,19 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
             k += 1;
             if (AHD && dbl) {                             // the second base of a two-base step: matched, no fast-forward
                 ml += 1;
+                if (SEG == 1) {                           // K1's records: the state a one-base walk has after this base -- at row j, before its LF
+                    if ((k & 31u) == 31u) {
+                        SegCkpt ck;
+                        ck.idx = j; ck.off = off; ck.ml = ml;
+                        ck.ff = ff_total; ck.scan = scan_total; ck.repo = repo_total; ck.pad_ = 0;
+                        seg.ckpt[(obeg + k) >> 5] = ck;
+                    }
+                    if (k + 1 == len) {
+                        SegFin fn;
+                        fn.idx = j; fn.off = off; fn.ml = ml;
+                        seg.fin[rid] = fn;
+                    }
+                }
                 off += lf2 ? off1 : 0u;
                 const uint32_t val2 = ml > 65535u ? 65535u : ml;
                 if (CLS) cs.add(val2, k, len, cls.bin_width, cls.thr);
@@ -1703,7 +1716,7 @@ uint32_t call_seg_len(const LaunchCfg &cfg, uint64_t n_bases, uint64_t waves) {
 static hipError_t launch_pml_segmented(const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
                                        uint64_t n_bases, uint16_t *d_out, uint8_t *d_err, DevStats *d_stats,
                                        const LaunchCfg &cfg, hipStream_t stream, SegWorkspace *ws, bool big_batch_cap,
-                                       int ragged_hint, bool *declined, const ClsArgs &bins, int *verdict) {
+                                       int ragged_hint, bool *declined, const ClsArgs &bins, int *verdict, LaunchInfo *info) {
     // `verdict` (optional, in / out): a caller that cuts one batch into several launches (the overlapped host path) lets
     // the first one probe and hands its verdict to the others -- 1: cut without probing (no read-back, the launch stays
     // asynchronous), 0: do not cut; -1 on entry: not decided yet.
@@ -1815,34 +1828,59 @@ static hipError_t launch_pml_segmented(const DevIndex &ix, const uint8_t *d_base
     auto lds_for = [&](uint64_t lanes) -> size_t {
         int wpc = cfg.waves_per_cu;
         if (wpc < 0) wpc = 0;
-        if (cfg.waves_per_cu == 0 && big_batch_cap && lanes > (uint64_t)cfg.num_cus * 64u * 18u) wpc = kCapWaves;
+        if (cfg.waves_per_cu == 0 && big_batch_cap && lanes > (uint64_t)cfg.num_cus * 64u * 18u)
+            wpc = (ix.rows2 != nullptr && cfg.stage_reads != 0) ? kCapWavesAhead : kCapWaves;
         if (wpc > 0 && wpc < 32) return ((163840u / (unsigned)wpc) & ~1023u) - 1024u;
         return 0;
     };
     const ClsArgs cls;
     const uint32_t *d_order = nullptr;
+    // (segments and re-walked reads stage their bases through LDS and walk on the look-ahead rows like any other launch:
+    // launch_pml's policy -- the cap's padding, or what the launch's wavefronts per CU leave of the CU's LDS)
+    DevIndex ixl = ix;
+    size_t dyn_lds = 0;
+    auto stage_for = [&](uint64_t lanes) {
+        dyn_lds = lds_for(lanes);
+        if (cfg.stage_reads != 0 && dyn_lds == 0) {
+            const uint64_t wn = ((lanes + bt - 1) / bt + (uint64_t)cfg.num_cus - 1) / (uint64_t)cfg.num_cus;
+            if (wn <= 18) dyn_lds = std::min<size_t>(21504, ((163840u / (unsigned)std::max<uint64_t>(wn, 1)) & ~1023u) - 1024u);
+        }
+        const uint32_t cap = (uint32_t)std::min<size_t>(1024, (dyn_lds / 64) & ~(size_t)15);
+        ixl.stage_lds = (cfg.stage_reads != 0 && cap >= 96) ? cap : 0u;
+    };
 #define MOVI_LAUNCH_SEG(SEGV, LANES, ...)                                                                             \
     do {                                                                                                              \
-        const size_t dyn_lds = lds_for(LANES);                                                                        \
         if (dyn_lds > 65536) {                                                                                        \
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(&__VA_ARGS__),                                     \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds);                        \
             if (e != hipSuccess) return e;                                                                            \
         }                                                                                                             \
-        hipLaunchKernelGGL((__VA_ARGS__), dim3((unsigned)(((LANES) + bt - 1) / bt)), dim3(bt), dyn_lds, stream, ix,   \
+        hipLaunchKernelGGL((__VA_ARGS__), dim3((unsigned)(((LANES) + bt - 1) / bt)), dim3(bt), dyn_lds, stream, ixl,  \
                            d_bases, d_offsets, (uint64_t)(LANES), d_out, d_err, d_stats, d_order, cls, seg);          \
+    } while (0)
+#define MOVI_LAUNCH_SEG_S(SEGV, LANES, T, S)                                                                          \
+    do {                                                                                                              \
+        if (ixl.stage_lds != 0u && ix.rows2 != nullptr) MOVI_LAUNCH_SEG(SEGV, LANES, pml_kernel_flatp<6, T, -1, 0, S, 0, SEGV, 1, 1>); \
+        else if (ixl.stage_lds != 0u) MOVI_LAUNCH_SEG(SEGV, LANES, pml_kernel_flatp<6, T, -1, 0, S, 0, SEGV, 1, 0>);  \
+        else MOVI_LAUNCH_SEG(SEGV, LANES, pml_kernel_flatp<6, T, -1, 0, S, 0, SEGV>);                                 \
     } while (0)
 #define MOVI_LAUNCH_SEG_T(SEGV, LANES)                                                                                \
     do {                                                                                                              \
+        stage_for(LANES);                                                                                             \
         if (ix.idx32) {                                                                                               \
-            if (ix.sep) MOVI_LAUNCH_SEG(SEGV, LANES, pml_kernel_flatp<6, uint32_t, -1, 0, 1, 0, SEGV>);               \
-            else MOVI_LAUNCH_SEG(SEGV, LANES, pml_kernel_flatp<6, uint32_t, -1, 0, 0, 0, SEGV>);                      \
+            if (ix.sep) MOVI_LAUNCH_SEG_S(SEGV, LANES, uint32_t, 1); else MOVI_LAUNCH_SEG_S(SEGV, LANES, uint32_t, 0); \
         } else {                                                                                                      \
-            if (ix.sep) MOVI_LAUNCH_SEG(SEGV, LANES, pml_kernel_flatp<6, uint64_t, -1, 0, 1, 0, SEGV>);               \
-            else MOVI_LAUNCH_SEG(SEGV, LANES, pml_kernel_flatp<6, uint64_t, -1, 0, 0, 0, SEGV>);                      \
+            if (ix.sep) MOVI_LAUNCH_SEG_S(SEGV, LANES, uint64_t, 1); else MOVI_LAUNCH_SEG_S(SEGV, LANES, uint64_t, 0); \
         }                                                                                                             \
     } while (0)
     MOVI_LAUNCH_SEG_T(1, max_seg);
+    if (info) {                                           // the dominant kernel: K1
+        const int stg = ixl.stage_lds != 0u ? 1 : 0, ahd = (stg && ix.rows2 != nullptr) ? 1 : 0;
+        snprintf(info->kernel, sizeof(info->kernel), "pml_kernel_flatp<6, %s, -1, 0, %d, 0, 1, %d, %d>",
+                 ix.idx32 ? "unsigned int" : "unsigned long", ix.sep ? 1 : 0, stg, ahd);
+        info->variant = 14; info->block_threads = 64; info->segmented = 1; info->idx64 = ix.idx32 ? 0 : 1;
+        info->waves_per_cu = 0; info->staged = (int)ixl.stage_lds; info->ahead = ahd;
+    }
     // (blocks of one wavefront: a boundary lane that has to walk far holds up only the 63 beside it)
     const uint32_t max_over = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, (uint64_t)cfg.seg_len * (uint64_t)kSegOverrun);
     hipLaunchKernelGGL((seg_stitch_kernel<6, 0>), dim3((unsigned)((max_seg + 63) / 64)), dim3(64), 0, stream, ix, d_bases, seg,
@@ -1853,6 +1891,7 @@ static hipError_t launch_pml_segmented(const DevIndex &ix, const uint8_t *d_base
                        seg_j, seg_rem, max_over, on_chain, d_out, join);
     MOVI_LAUNCH_SEG_T(2, n_reads);
 #undef MOVI_LAUNCH_SEG_T
+#undef MOVI_LAUNCH_SEG_S
 #undef MOVI_LAUNCH_SEG
     e = hipGetLastError();
     if (e == hipSuccess && bins.bin_width)
@@ -1919,13 +1958,7 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
         bool declined = false;
         const hipError_t es = launch_pml_segmented(ix, d_bases, d_offsets, n_reads, n_bases, d_out, d_err, d_stats, cfg, stream,
                                                    seg_ws, cfg.pml_variant < 0 || cfg.pml_variant == 14, ragged_hint, &declined, cls,
-                                                   seg_verdict);
-        if (es == hipSuccess && !declined && info) {
-            snprintf(info->kernel, sizeof(info->kernel), "pml_kernel_flatp<6, %s, -1, 0, %d, 0, 1, 0, 0>",
-                     ix.idx32 ? "unsigned int" : "unsigned long", ix.sep ? 1 : 0);
-            info->variant = 14; info->block_threads = 64; info->segmented = 1; info->idx64 = ix.idx32 ? 0 : 1;
-            info->waves_per_cu = 0;
-        }
+                                                   seg_verdict, info);
         if (es != hipSuccess || !declined) return es;
     }
     const int bt = cfg.block_threads > 0 ? cfg.block_threads : 64;           // one wavefront per block: finest dispatch grain

@@ -189,3 +189,37 @@ def test_ahead_rows_refused_where_they_cannot_serve(built_lib):
     with pytest.raises(movi_amd.MoviError):
         gpu.set_option("ahead_rows", 2)
     gpu.close()
+
+
+@pytest.mark.parametrize("sep", [0, 1])
+def test_segments_walk_on_the_look_ahead_rows(built_lib, golden_image, sep):
+    """Segment-parallel long reads: K1's lanes (one segment each, a checkpoint every 32 bases and the segment's final state
+    recorded -- also when the base in question is the second of a two-base step) and K3's (whole reads again) stage their
+    bases through LDS and walk on the look-ahead rows like any launch.  PMLs, error bytes and counters equal the oracle's
+    for segment lengths that put checkpoints and segment ends on both bases of such steps."""
+    import movi_amd
+    from oracle import build_index as B
+    from oracle.oracle import Oracle
+    ref = _ref()
+    img = B.build_index_from_seqs([ref[:60000], ref[60000:]], 6, separators=True) if sep else golden_image(6)
+    gpu, cpu = movi_amd.MoveIndex.from_image(img), Oracle(img)
+    rng = np.random.default_rng(9700 + sep)
+    reads = mutated_reads(rng, ref, 300, 900, 6000) + [bytes(ref[1000:9000]), bytes(ref[20000:20000 + 4097])]   # clean reads: long runs of two-base steps
+    bases, offs = pack(reads)
+    exp, ff, sc = cpu.pml_batch(bases, offs, threads=8)
+    gpu.set_option("seg_probe", 0)
+    for seg_len in (32, 64, 96, 2048):
+        gpu.set_option("seg_len", seg_len)
+        for ahead in (1, 0):
+            gpu.set_option("ahead_rows", ahead)
+            for stage in (1, 0):
+                gpu.set_option("stage_reads", stage)
+                out, st = gpu.query_pml_packed(bases, offs)
+                li = gpu.last_launch()
+                assert li["segmented"] == 1 and li["ahead"] == (ahead & stage) and (li["staged"] > 0) == bool(stage), (seg_len, li)
+                assert li["kernel"].endswith("0, 1, %d, %d>" % (stage, ahead & stage))
+                assert (out == exp).all(), (seg_len, ahead, stage)
+                assert (st.fast_forwards, st.scans, st.errors) == (ff, sc, 0), (seg_len, ahead, stage)
+                assert st.segments > len(reads)
+    gpu.close()
+    cpu.close()
