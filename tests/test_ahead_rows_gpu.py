@@ -208,7 +208,7 @@ def test_segments_walk_on_the_look_ahead_rows(built_lib, golden_image, sep):
     bases, offs = pack(reads)
     exp, ff, sc = cpu.pml_batch(bases, offs, threads=8)
     gpu.set_option("seg_probe", 0)
-    for seg_len in (32, 64, 96, 2048):
+    for seg_len in (32, 64, 96, 512):
         gpu.set_option("seg_len", seg_len)
         for ahead in (1, 0):
             gpu.set_option("ahead_rows", ahead)
