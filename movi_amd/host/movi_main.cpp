@@ -611,7 +611,7 @@ int run_query(const Options &o) {
     if (o.verbose) {
         const BatchReader::PhaseTimes &pt = reader.phase_times();
         std::cerr << "[movi] Parser phases: newline scan " << pt.prescan << " s, batch cut " << pt.cut << " s, lengths " << pt.lengths
-                  << " s, copy " << pt.copy << " s\n";
+                  << " s, copy " << pt.copy << " s; " << pt.bulk_reads << " of " << pt.reads << " reads cut in bulk\n";
     }
     if (o.verbose)                                                     // the three pipeline stages run side by side: the slowest one bounds the command
         std::cerr << "[movi] Stage times: parse " << parse_seconds << " s, GPU calls " << gpu_seconds << " s, order + write "

@@ -236,16 +236,20 @@ bool LineSource::getline_slow(const char *&p, size_t &n) {
 // reads are covered.  FASTQ: a read is counted every 4 lines with (record bytes)/2 bases;
 // FASTA: a read is counted when the NEXT line starts with '>' with (record bytes) bases.
 // The batch's lines are appended to lines_ from index first_line on.
+bool BatchReader::detect_format() {
+    if (format_ >= 0) return true;
+    if (!src_.good()) return false;
+    int c = src_.peek();
+    if (c == '>') format_ = 0;
+    else if (c == '@') format_ = 1;
+    else if (c == std::char_traits<char>::eof()) return false;
+    else throw std::runtime_error("unrecognized input query file type - expects FASTA or FASTQ.");
+    return true;
+}
+
 bool BatchReader::load_batch(size_t &first_line) {
     first_line = lines_.size();
-    if (format_ < 0) {
-        if (!src_.good()) return false;
-        int c = src_.peek();
-        if (c == '>') format_ = 0;
-        else if (c == '@') format_ = 1;
-        else if (c == std::char_traits<char>::eof()) return false;
-        else throw std::runtime_error("unrecognized input query file type - expects FASTA or FASTQ.");
-    }
+    if (!detect_format()) return false;
     size_t bases = 0, reads = 0, nlines = 0, record = 0;
     const size_t num_bases = 1000;
     bool valid = false;
@@ -257,7 +261,7 @@ bool BatchReader::load_batch(size_t &first_line) {
             if (format_ == 1 && nlines % 4 == 0) return valid || lines_.size() > first_line;
             if (format_ == 0 && nlines % 2 == 0) return valid || lines_.size() > first_line;
             // the reference returns false here and drops the partial batch (:57-63)
-            lines_.resize(first_line);
+            lines_.resize_uninitialized(first_line);
             return false;
         }
         nlines++;
@@ -279,6 +283,117 @@ bool BatchReader::load_batch(size_t &first_line) {
         }
     }
     return valid;
+}
+
+// The batch cut over the lines the scan-ahead has already found, without walking them one by one (memory-mapped input).
+// load_batch + the grabNextRead loop of next_chunk spend ~10 ns per line on a well-formed file deciding what a handful of
+// array operations decide for a whole chunk: where the records start (FASTA: the lines that begin with '>'; FASTQ: every
+// fourth line), how many bytes each has, and -- one running sum over the RECORDS -- where loadBatch's "1000 bases and
+// min_reads reads" rule ends each batch and the chunk's budget ends the chunk.  Workers find the headers and fill lines_ /
+// recs_; only the running sum is sequential (~2 ns per read).
+// Taken only where it provably does what the line-by-line cut does: every line in reach non-empty (an empty header ends a
+// batch early, src/batch_loader.cpp:99) and shorter than 4 GiB, every header longer than 2 characters and -- FASTQ --
+// starting with '@'; whole batches only; the last record in reach (whose end the scan cannot vouch for) and anything
+// irregular are left to the line-by-line cut, which then starts exactly where a batch would start anyway.
+bool BatchReader::cut_ahead(uint64_t max_bases, uint64_t min_reads, uint64_t hard_max_bases, uint64_t &approx_bases) {
+    if (!mem_ || format_ < 0 || no_fast_cut_) return false;
+    const LineSource::Ahead A = src_.ahead();
+    // no further than the chunk can possibly reach (the passes below run over every line considered)
+    const uint64_t budget = approx_bases < max_bases ? max_bases - approx_bases : (approx_bases < hard_max_bases ? hard_max_bases - approx_bases : 0);
+    const size_t reach = A.pos + (size_t)std::min<uint64_t>(budget + (budget >> 2) + (1u << 20), 1ull << 40);
+    const size_t M = (size_t)(std::upper_bound(A.nl, A.nl + A.count, reach) - A.nl);
+    const size_t L0 = lines_.size(), R0 = recs_.size();
+    if (M < 4096 || L0 + M > 0xFFFFFFF0ull) return false;
+    auto beg = [&](size_t t) -> size_t { return t ? A.nl[t - 1] + 1 : A.pos; };
+    auto fc = [&](size_t t) -> int { return t ? (int)A.first[t - 1] : A.first0; };
+    const char head = format_ == 1 ? '@' : '>';
+    if (fc(0) != head) return false;
+    const unsigned T = pool_->size();
+    // ---- workers: the records' header lines, and is everything regular?
+    std::vector<size_t> n_hdr(T + 1, 0);
+    std::vector<char> bad(T, 0);
+    size_t R = 0;                                                      // complete records in reach (the last one is not)
+    if (format_ == 0) {
+        pool_->run(T, [&](unsigned w) {
+            const size_t a = M * w / T, b = M * (w + 1) / T;
+            size_t c = 0;
+            char irregular = 0;
+            for (size_t t = a; t < b; t++) {
+                const size_t len = A.nl[t] - beg(t);
+                if (len == 0 || len > 0xFFFFFFFFull) irregular = 1;
+                if (fc(t) == '>') { c++; if (len <= 2) irregular = 1; }
+            }
+            n_hdr[w + 1] = c;
+            bad[w] = irregular;
+        });
+        for (unsigned w = 0; w < T; w++) { if (bad[w]) return false; n_hdr[w + 1] += n_hdr[w]; }
+        const size_t H = n_hdr[T];
+        if (H < 2) return false;
+        hdr_line_.resize(H);
+        pool_->run(T, [&](unsigned w) {
+            const size_t a = M * w / T, b = M * (w + 1) / T;
+            size_t c = n_hdr[w];
+            for (size_t t = a; t < b; t++)
+                if (fc(t) == '>') hdr_line_[c++] = (uint32_t)t;
+        });
+        R = H - 1;
+    } else {
+        R = M / 4;
+        if (R < 2) return false;
+        pool_->run(T, [&](unsigned w) {
+            const size_t a = R * w / T, b = R * (w + 1) / T;
+            char irregular = 0;
+            for (size_t r = a; r < b; r++) {
+                const size_t t = 4 * r, len = A.nl[t] - beg(t);
+                if (fc(t) != '@' || len <= 2) irregular = 1;
+                for (size_t u = t; u < t + 4; u++)
+                    if (A.nl[u] - beg(u) > 0xFFFFFFFFull) irregular = 1;
+            }
+            bad[w] = irregular;
+        });
+        for (unsigned w = 0; w < T; w++) if (bad[w]) return false;
+        R -= 1;
+    }
+    auto hdr_of = [&](size_t r) -> size_t { return format_ == 0 ? (size_t)hdr_line_[r] : 4 * r; };
+    // ---- the running sum: loadBatch's rule over whole records, the chunk's budget over whole batches
+    rec_batch_.resize(R);
+    uint64_t bases = 0, pending = 0;
+    size_t reads = 0, accepted = 0;
+    uint32_t b = batch_counter_;
+    for (size_t r = 0; r < R; r++) {
+        const size_t h = hdr_of(r), e = hdr_of(r + 1);                 // lines [h, e)
+        const uint64_t bytes = (uint64_t)(A.nl[e - 1] - beg(h)) - (uint64_t)(e - h - 1);   // the lines' lengths, newlines excluded
+        rec_batch_[r] = b;
+        reads++;
+        if (format_ == 0) { bases += bytes; pending += bytes - (uint64_t)(A.nl[h] - beg(h)); }
+        else { bases += bytes / 2; pending += (uint64_t)(A.nl[h + 1] - beg(h + 1)); }
+        if (bases >= 1000 && reads >= min_reads_) {                    // the batch ends behind this record
+            approx_bases += pending;
+            pending = 0; bases = 0; reads = 0;
+            accepted = r + 1;
+            b++;
+            if (!(approx_bases < max_bases || (R0 + accepted < min_reads && approx_bases < hard_max_bases))) break;
+        }
+    }
+    if (accepted == 0) return false;
+    batch_counter_ = b;
+    // ---- workers: lines_ and recs_ of the accepted batches
+    const size_t C = hdr_of(accepted);                                 // lines consumed
+    lines_.resize_uninitialized(L0 + C);
+    recs_.resize_uninitialized(R0 + accepted);
+    pool_->run(T, [&](unsigned w) {
+        for (size_t t = C * w / T, te = C * (w + 1) / T; t < te; t++) {
+            const size_t at = beg(t);
+            lines_[L0 + t] = Span{(uint64_t)at, (uint32_t)(A.nl[t] - at), (uint8_t)(A.nl[t] > at ? fc(t) : 0)};
+        }
+        for (size_t r = accepted * w / T, re = accepted * (w + 1) / T; r < re; r++) {
+            const uint32_t h = (uint32_t)(L0 + hdr_of(r));
+            recs_[R0 + r] = format_ == 0 ? Rec{h, h + 1, (uint32_t)(L0 + hdr_of(r + 1)), rec_batch_[r]} : Rec{h, h + 1, h + 2, rec_batch_[r]};
+        }
+    });
+    src_.consume(C);
+    times_.bulk_reads += accepted;
+    return true;
 }
 
 static size_t rstrip_len(const char *p, size_t n) {
@@ -305,6 +420,9 @@ bool BatchReader::next_chunk(ReadSet &out, uint64_t max_bases, uint64_t min_read
     bool any = false;
     uint64_t approx_bases = 0;                                         // sequence-line bytes, trailing whitespace included
     while (approx_bases < max_bases || (recs_.size() < min_reads && approx_bases < hard_max_bases)) {
+        // whole batches straight from the scanned lines where the input is regular (cut_ahead) ...
+        if (detect_format() && cut_ahead(max_bases, min_reads, hard_max_bases, approx_bases)) { any = true; continue; }
+        // ... else one reference batch, line by line
         size_t p = 0;
         if (!load_batch(p)) break;
         any = true;
@@ -343,6 +461,7 @@ bool BatchReader::next_chunk(ReadSet &out, uint64_t max_bases, uint64_t min_read
     if (!any) return false;
     // ---- phase 2 (parallel): id and stripped sequence lengths, then ids and bases copied to their final offsets
     const size_t n = recs_.size();
+    times_.reads += n;
     out.batch_of.resize(n);
     out.offsets.assign(n + 1, 0);
     out.id_off.assign(n + 1, 0);

@@ -68,6 +68,40 @@ private:
     FreeFn free_ = nullptr;
 };
 
+// A growable array of plain structs whose resize leaves the new elements uninitialised (they are about to be filled by
+// several workers at once: value-initialising 2 M line records first is a single-threaded pass over 32 MB).
+template <typename T>
+class PodVec {
+public:
+    PodVec() = default;
+    PodVec(const PodVec &) = delete;
+    PodVec &operator=(const PodVec &) = delete;
+    ~PodVec() { std::free(p_); }
+    T *data() { return p_; }
+    const T *data() const { return p_; }
+    size_t size() const { return n_; }
+    bool empty() const { return n_ == 0; }
+    void clear() { n_ = 0; }
+    T &operator[](size_t i) { return p_[i]; }
+    const T &operator[](size_t i) const { return p_[i]; }
+    void reserve(size_t n) {
+        if (n <= cap_) return;
+        T *q = static_cast<T *>(std::realloc(p_, n * sizeof(T)));
+        if (!q) throw std::bad_alloc();
+        p_ = q;
+        cap_ = n;
+    }
+    void resize_uninitialized(size_t n) { reserve(n); n_ = n; }   // contents below the old size are kept
+    void push_back(const T &v) {
+        if (n_ == cap_) reserve(cap_ ? cap_ * 2 : 1024);
+        p_[n_++] = v;
+    }
+
+private:
+    T *p_ = nullptr;
+    size_t n_ = 0, cap_ = 0;
+};
+
 // One chunk of reads.  Ids and bases are two byte arenas with offsets: no per-read allocation (a million std::strings
 // per chunk were a quarter of the parser's time, and ids longer than 15 characters -- every SRR id -- an allocation each).
 struct ReadSet {
@@ -134,6 +168,27 @@ public:
         return peek();
     }
     size_t prescanned_lines() const { return cur_.nl.size() - nl_i_; }
+    // memory form: the complete lines the scan has found from the cursor on -- line t (t < count) spans [t ? nl[t-1] + 1 : pos,
+    // nl[t]) and starts with first0 (t = 0; -1: unknown) or first[t-1]; first[t] is what the line behind it starts with (0 at
+    // the end of the input).  Valid until the next getline() / consume().
+    struct Ahead { const size_t *nl; const uint8_t *first; size_t count, pos; int first0; };
+    Ahead ahead() const {
+        Ahead a;
+        a.nl = cur_.nl.data() + nl_i_;
+        a.first = cur_.first.data() + nl_i_;
+        a.count = cur_.nl.size() - nl_i_;
+        a.pos = pos_;
+        a.first0 = (have_next_first_ && pos_ < end_) ? (int)next_first_ : (pos_ < end_ ? (int)(unsigned char)mem_[pos_] : -1);
+        return a;
+    }
+    void consume(size_t lines) {                           // lines <= ahead().count: as many getline() calls
+        if (lines == 0) return;
+        const size_t i = nl_i_ + lines - 1;
+        pos_ = cur_.nl[i] + 1;
+        next_first_ = cur_.first[i];
+        have_next_first_ = true;
+        nl_i_ += lines;
+    }
     ~LineSource();
     // memory form only: newlines are found ahead of the parser, a window of `bytes` bytes at a time -- the first window by
     // all workers of `pool` at once, every later one by a helper thread while the parser cuts, measures and copies the chunk
@@ -183,24 +238,28 @@ public:
     // reads or `hard_max_bases` bases are (one GPU lane walks one read: a chunk needs reads, not bases).
     bool next_chunk(ReadSet &out, uint64_t max_bases, uint64_t min_reads = 0, uint64_t hard_max_bases = 0);
     // seconds spent in the parser's phases so far (movi query --verbose, tools/parse_bench.cpp)
-    struct PhaseTimes { double prescan = 0, cut = 0, lengths = 0, copy = 0; };
+    struct PhaseTimes { double prescan = 0, cut = 0, lengths = 0, copy = 0; uint64_t bulk_reads = 0, reads = 0; };   // bulk_reads: cut by cut_ahead
     const PhaseTimes &phase_times() const { return times_; }
 
 private:
     struct Span { uint64_t off; uint32_t len; uint8_t first; };   // 16 bytes; first = the line's first character (0: empty line)
     struct Rec { uint32_t hdr, seq_first, seq_end, batch; };          // line indexes of one read (a chunk holds < 2^32 lines)
     bool load_batch(size_t &first_line);
+    bool detect_format();
+    bool cut_ahead(uint64_t max_bases, uint64_t min_reads, uint64_t hard_max_bases, uint64_t &approx_bases);
     const char *line(size_t i) const { return (mem_ ? mem_ : arena_.data()) + lines_[i].off; }
     LineSource src_;
     const char *mem_ = nullptr;         // memory-mapped input: spans point into it
     std::string arena_;                 // stream input: the lines of the current CHUNK, back to back
-    std::vector<Span> lines_;           // lines of the current chunk
-    std::vector<Rec> recs_;
+    PodVec<Span> lines_;                // lines of the current chunk
+    PodVec<Rec> recs_;
+    std::vector<uint32_t> hdr_line_, rec_batch_;   // cut_ahead's scratch: header line of each read, its batch
     size_t min_reads_;
     uint64_t size_hint_ = 0;
     unsigned threads_ = 0;              // 0 = hardware concurrency (at most 16)
     std::unique_ptr<WorkerPool> pool_;
     PhaseTimes times_;
+    const bool no_fast_cut_ = std::getenv("MOVI_NO_FAST_CUT") != nullptr;   // every batch line by line (tests: both cuts must agree)
     int format_ = -1;                   // -1 unknown, 0 FASTA, 1 FASTQ
     uint32_t batch_counter_ = 0;
 };

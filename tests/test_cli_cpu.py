@@ -289,3 +289,63 @@ def test_lines_longer_than_the_newline_scan_window(movi_bin, tmp_path):
     assert a.returncode == 0 and a.stdout == b.stdout
     got = [(l.split(b"\t")[1], int(l.rsplit(b"\t", 1)[1])) for l in a.stdout.split(b"\n") if l]
     assert got == [(i + b" ", len(s)) for i, s in recs]
+
+
+def _plan3(path, flags, extra_env=None):
+    """`movi plan` through the three cuts: scanned lines in bulk (default on a mapped file), line by line on the mapped file,
+    line by line on a stream."""
+    env = dict(os.environ, **(extra_env or {}))
+    a = run(["plan", "-r", str(path)] + flags, env=env)
+    b = run(["plan", "-r", str(path)] + flags, env=dict(env, MOVI_NO_FAST_CUT="1"))
+    c = run(["plan", "-r", str(path)] + flags, env=dict(env, MOVI_NO_MMAP="1"))
+    return a, b, c
+
+
+@pytest.mark.parametrize("fmt", ["fa", "fa1", "fq"])
+@pytest.mark.parametrize("flags", [["-s16"], ["-s", "1"], ["-n"]])
+def test_bulk_batch_cut_equals_the_line_by_line_cut(movi_bin, tmp_path, fmt, flags):
+    """The parser cuts the lines its newline scan has found into reads and reference batches in bulk (BatchReader::cut_ahead)
+    where the input is regular, and line by line (loadBatch / grabNextRead as the reference runs them) everywhere else:
+    same batches, ids, lengths and order on well-formed files of every shape, whatever the chunk size -- and on files with
+    an irregular line somewhere in the middle, where the bulk cut must stand back."""
+    rng = np.random.default_rng(400 + len(flags[0]) + len(fmt))
+    n = 30000
+    if fmt == "fa1":                                          # single-line FASTA, short reads: the common case
+        lines = []
+        for i in range(n):
+            lines += [b">read%d" % i, bytes(rng.choice(list(b"ACGT"), size=int(rng.integers(30, 160))).astype(np.uint8))]
+    else:
+        lines = make_reads(rng, n, fmt)
+    variants = {
+        "regular": b"\n".join(lines) + b"\n",
+        "no_final_newline": b"\n".join(lines),
+        "blank_tail": b"\n".join(lines) + b"\n\n\n",
+        "blank_line_inside": b"\n".join(lines[: len(lines) // 2 // 4 * 4] + [b""] + lines[len(lines) // 2 // 4 * 4:]) + b"\n",
+        "crlf": b"\r\n".join(lines) + b"\r\n",
+    }
+    for name, content in variants.items():
+        path = tmp_path / ("%s.%s" % (name, fmt))
+        path.write_bytes(content)
+        for env in ({}, {"MOVI_CHUNK_BASES": "400000"}, {"MOVI_CHUNK_BASES": "400000", "MOVI_NO_AFFINITY": "1"}):
+            a, b, c = _plan3(path, flags, env)
+            assert (a.returncode, a.stdout, a.stderr) == (b.returncode, b.stdout, b.stderr) == (c.returncode, c.stdout, c.stderr), (name, env)
+        if name == "regular":
+            assert a.returncode == 0 and a.stdout.count(b"\n") == n
+
+
+@pytest.mark.parametrize("fmt,bad,message", [("fa1", b">a", b"header line is missing an id"),
+                                             ("fq", b"q_without_at", b"Incorrect FASTQ entry"),
+                                             ("fq", b"@", b"header line is missing an id")])
+def test_bulk_batch_cut_leaves_malformed_records_to_the_reference_path(movi_bin, tmp_path, fmt, bad, message):
+    rng = np.random.default_rng(500 + len(bad))
+    lines = []
+    for i in range(20000):
+        seq = bytes(rng.choice(list(b"ACGT"), size=100).astype(np.uint8))
+        lines += [b"@r%d" % i, seq, b"+", b"I" * 100] if fmt == "fq" else [b">r%d" % i, seq]
+    k = (len(lines) // 2) // 4 * 4
+    lines[k] = bad                                            # a header in the middle of the file
+    path = tmp_path / ("bad." + fmt)
+    path.write_bytes(b"\n".join(lines) + b"\n")
+    a, b, c = _plan3(path, ["-s16"])
+    assert (a.returncode, a.stdout, a.stderr) == (b.returncode, b.stdout, b.stderr) == (c.returncode, c.stdout, c.stderr)
+    assert a.returncode == 1 and message in a.stderr
