@@ -436,6 +436,8 @@ int run_query(const Options &o) {
             for (unsigned u = 0; u < T; u++) std::cout.write(txt[u].data(), (std::streamsize)txt[u].size());
             return;
         }
+        std::string count_txt;
+        if (!o.ml() && o.write_output_allowed()) count_txt.reserve(n * 32);
         for (uint32_t i : order) {
             const uint64_t len = rs.len(i);
             if (o.ml()) {
@@ -470,9 +472,12 @@ int run_query(const Options &o) {
                     }
                 }
             } else if (o.write_output_allowed()) {
-                std::ostream &out = o.write_stdout_enabled() ? static_cast<std::ostream &>(std::cout) : matches_file;
-                write_count_line(out, rs.id(i), len, job.matched[i], job.counts[i]);
+                append_count_line(count_txt, rs.id(i), len, job.matched[i], job.counts[i]);
             }
+        }
+        if (!count_txt.empty()) {                                     // the chunk's count lines in one write
+            std::ostream &out = o.write_stdout_enabled() ? static_cast<std::ostream &>(std::cout) : matches_file;
+            out.write(count_txt.data(), (std::streamsize)count_txt.size());
         }
         if (to_bpf) mls_file.append(bpf);
     };

@@ -1,4 +1,5 @@
 #include "output.hpp"
+#include <charconv>
 
 #include <cerrno>
 #include <cstdio>
@@ -108,6 +109,22 @@ void write_stdout_pmls(std::ostream &out, std::string_view id, const uint16_t *p
 
 void write_count_line(std::ostream &out, std::string_view id, uint64_t query_length, uint64_t matched, uint64_t count) {
     out << id << "\t" << matched << "/" << query_length << "\t" << count << "\n";
+}
+
+void append_count_line(std::string &txt, std::string_view id, uint64_t query_length, uint64_t matched, uint64_t count) {
+    char num[24];
+    auto put = [&](uint64_t v) {
+        const auto r = std::to_chars(num, num + sizeof(num), v);
+        txt.append(num, (size_t)(r.ptr - num));
+    };
+    txt.append(id.data(), id.size());
+    txt.push_back('\t');
+    put(matched);
+    txt.push_back('/');
+    put(query_length);
+    txt.push_back('\t');
+    put(count);
+    txt.push_back('\n');
 }
 
 size_t Classifier::load_null_db(const std::string &index_dir, const std::string &query_type, bool verbose) {

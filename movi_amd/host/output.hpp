@@ -46,6 +46,7 @@ private:
 void write_stdout_pmls(std::ostream &out, std::string_view id, const uint16_t *pml, uint64_t n);
 void append_stdout_pmls(std::string &txt, std::string_view id, const uint16_t *pml, uint64_t n);   // the same text, appended
 void write_count_line(std::ostream &out, std::string_view id, uint64_t query_length, uint64_t matched, uint64_t count);
+void append_count_line(std::string &txt, std::string_view id, uint64_t query_length, uint64_t matched, uint64_t count);   // the same line, appended
 
 class Classifier {
 public:

@@ -146,10 +146,32 @@ void LineSource::scan_ahead() {
     next_.from = cur_.to;
     next_.to = std::min(end_, cur_.to + window_bytes_);
     next_pending_ = true;
-    scan_thread_ = std::thread([this] {
-        next_.nl.reserve((next_.to - next_.from) / 64 + 16);
-        next_.first.reserve((next_.to - next_.from) / 64 + 16);
-        scan_newlines(mem_ + next_.from, mem_ + next_.to, mem_, mem_ + end_, next_.nl, next_.first);
+    // long lines (the window in use has fewer than one per KiB: long reads): four scanners -- there the scan of a GB-sized
+    // chunk by one thread was what the parser waited for (0.09 of 0.13 s on 100 k x 10 kbp) and the few line ends are joined
+    // in no time; short lines: one scanner writes the list in place (2 M entries per window: joining them would cost more
+    // than the scan)
+    const unsigned parts = (cur_.to > cur_.from && cur_.nl.size() * 1024 < cur_.to - cur_.from) ? 4u : 1u;
+    scan_thread_ = std::thread([this, parts] {
+        const size_t from = next_.from, to = next_.to;
+        if (parts == 1) {
+            next_.nl.reserve((to - from) / 64 + 16);
+            next_.first.reserve((to - from) / 64 + 16);
+            scan_newlines(mem_ + from, mem_ + to, mem_, mem_ + end_, next_.nl, next_.first);
+            return;
+        }
+        std::vector<std::vector<size_t>> nl(parts);
+        std::vector<std::vector<uint8_t>> first(parts);
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < parts; t++)
+            th.emplace_back([&, t] {
+                const size_t a = from + (to - from) * t / parts, b = from + (to - from) * (t + 1) / parts;
+                scan_newlines(mem_ + a, mem_ + b, mem_, mem_ + end_, nl[t], first[t]);
+            });
+        for (auto &x : th) x.join();
+        for (unsigned t = 0; t < parts; t++) {
+            next_.nl.insert(next_.nl.end(), nl[t].begin(), nl[t].end());
+            next_.first.insert(next_.first.end(), first[t].begin(), first[t].end());
+        }
     });
 }
 
