@@ -325,6 +325,7 @@ def main():
     ap.add_argument("--zml-variant", type=int, default=-1, help="ZML kernel: 0 base-synchronous, 1 lane state machine (A/B)")
     ap.add_argument("--seg-len", type=int, default=-1, help="PML: segment length of the segment-parallel long-read path "
                     "(-1 = the engine's default of 2048, 0 = off)")
+    ap.add_argument("--seg-probe", type=int, default=-1, help="segment-parallel policy (A/B): 0 = cut every eligible batch, 1 = probe (default)")
     ap.add_argument("--kmer-k", type=int, default=-1, help="top-of-walk table: first K bases of every read by one lookup (A/B; -1 = the engine's default)")
     ap.add_argument("--ftab-k", type=int, default=-1, help="count query's interval table: first K bases of the backward search by one lookup (A/B; -1 = the engine's default)")
     ap.add_argument("--stage-reads", type=int, default=-1, help="reads staged through LDS for short-read wavefronts (A/B: 0 off, 1 on; -1 = default)")
@@ -457,6 +458,8 @@ def main():
         index.set_option("zml_variant", args.zml_variant)
     if args.seg_len >= 0:
         index.set_option("seg_len", args.seg_len)
+    if args.seg_probe >= 0:
+        index.set_option("seg_probe", args.seg_probe)
     if args.kmer_k >= 0:
         index.set_option("kmer_k", args.kmer_k)
     if args.stage_reads >= 0:
