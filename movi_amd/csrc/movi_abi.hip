@@ -1648,6 +1648,9 @@ static int count_device(movi_index_t *ix, const uint8_t *d_bases, const uint64_t
     if (ix->ftab_auto > 0 && !ix->d_ftab && ftab_eligible(ix)) {       // the first count query builds the interval table
         if (build_ftab_table(ix, (uint32_t)ix->ftab_auto, s) != MOVI_OK) { (void)hipGetLastError(); ix->ftab_auto = 0; }
     }
+    if (ix->ahead_auto > 0 && !ix->d_rows2 && ahead_eligible(ix) && ahead_rows_bytes(ix->desc.r) <= kAheadAutoBytes) {
+        if (build_ahead(ix, s) != MOVI_OK) { (void)hipGetLastError(); ix->ahead_auto = 0; }   // ... and the look-ahead rows (as a PML query does)
+    }
     HIP_TRY(hipMemsetAsync(d_stats, 0, sizeof(DevStats), s));
     if (n_reads > 0xFFFFFFFFull) return fail(MOVI_ERR_ARG, "more than 2^32 reads in one call");
     HIP_TRY(launch_count(ix->kmode, ix->dev, d_bases, d_offsets, n_reads, d_matched, d_count,

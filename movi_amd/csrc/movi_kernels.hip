@@ -2095,7 +2095,27 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
 // the start run past the end instead).  So the two searches are independent, each bounded by the OTHER end's original row,
 // and each takes the 4-row window around its next row per trip (window base clamped to r - 4: never outside the table)
 // instead of one row: the trips of this loop -- max over the wave's lanes -- were most of a ZML step on divergent reads.
-template <int MODE>
+// Row / window / look-ahead entry of the table the count query walks on: AH = 0 the plain rows, AH = 1 the look-ahead copy
+// (DevIndex::rows2: 8 rows + their 8 entries per 128-byte line, the last window in a line of its own).
+template <int MODE, int AH>
+__device__ __forceinline__ uint2 tab_row(const DevIndex &ix, uint64_t i) {
+    if (!AH) return load_row<MODE>(ix.rows, i);
+    uint2 v;
+    __builtin_memcpy(&v, ix.rows2 + (i >> 3) * 128u + (i & 7u) * 8u, 8);
+    return v;
+}
+__device__ __forceinline__ uint2 tab_entry(const DevIndex &ix, uint64_t i) {
+    uint2 v;
+    __builtin_memcpy(&v, ix.rows2 + (i >> 3) * 128u + 64u + (i & 7u) * 8u, 8);
+    return v;
+}
+template <int MODE, int AH>
+__device__ __forceinline__ void tab_window(const DevIndex &ix, uint64_t wb, uint2 (&w)[4]) {   // wb: aligned, or r - 4 (the last window)
+    if (!AH) load_window<MODE>(ix.rows, wb, w);
+    else load_window<MODE>(ix.rows2 + (wb < ix.r - 4 ? (wb >> 3) * 128u + (wb & 4u) * 8u : ix.rows2_tail), 0, w);
+}
+
+template <int MODE, int AH = 0>
 __device__ __forceinline__ void shrink_interval(const DevIndex &ix, bool act, uint32_t b, uint64_t &rs, uint32_t &os,
                                                 uint2 &rws, uint64_t &re, uint32_t &oe, uint2 &rwe,
                                                 uint32_t &scan_total) {
@@ -2112,7 +2132,7 @@ __device__ __forceinline__ void shrink_interval(const DevIndex &ix, bool act, ui
                 uint64_t wb = (rs + 1) & ~3ull;
                 if (wb > wb_last) wb = wb_last;
                 uint2 w[4];
-                load_window<MODE>(ix.rows, wb, w);
+                tab_window<MODE, AH>(ix, wb, w);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     if (gs && wb + (uint64_t)t == rs + 1) {
@@ -2131,7 +2151,7 @@ __device__ __forceinline__ void shrink_interval(const DevIndex &ix, bool act, ui
                 uint64_t wb = (re - 1) & ~3ull;
                 if (wb > wb_last) wb = wb_last;
                 uint2 w[4];
-                load_window<MODE>(ix.rows, wb, w);
+                tab_window<MODE, AH>(ix, wb, w);
 #pragma unroll
                 for (int t = 3; t >= 0; --t) {
                     if (ge && wb + (uint64_t)t + 1 == re) {
@@ -2240,7 +2260,53 @@ hipError_t build_ftab(int mode, const DevIndex &ix, uint32_t K, uint4 *d_table, 
     return hipGetLastError();
 }
 
+// The two ends of the interval arrive at their LF targets (ta, tb) with offsets (offa, offb): both row gathers -- on the
+// look-ahead copy with the rows' entries -- and the shared fast-forward loop of lf_step2.  An end that fast-forwards loses
+// its entry (it belongs to the row the gather was aimed at).
 template <int MODE>
+__device__ __forceinline__ uint32_t arrive2_ahead(const DevIndex &ix, bool live, uint64_t ta, uint64_t tb, uint64_t &ia, uint32_t &offa,
+                                                  uint2 &rowa, uint2 &enta, uint64_t &ib, uint32_t &offb, uint2 &rowb, uint2 &entb,
+                                                  uint32_t &ff_total) {
+    uint32_t na = 0, nb = 0, ffa = 0, ffb = 0, ga = 0, gb = 0;
+    uint64_t ja = ia, jb = ib;
+    if (live) {
+        ja = ta; jb = tb;
+        rowa = tab_row<MODE, 1>(ix, ja);
+        rowb = tab_row<MODE, 1>(ix, jb);
+        enta = tab_entry(ix, ja);
+        entb = tab_entry(ix, jb);
+        na = row_n<MODE>(rowa);
+        nb = row_n<MODE>(rowb);
+        ga = (ja < ix.r - 1 && offa >= na) ? 1u : 0u;
+        gb = (jb < ix.r - 1 && offb >= nb) ? 1u : 0u;
+        if (ga) enta = make_uint2(0u, 0u);
+        if (gb) entb = make_uint2(0u, 0u);
+    }
+    while (wave_any((ga | gb) != 0u)) {                 // fast_forward :524-545, both walkers
+        uint2 wa = rowa, wb = rowb;
+        if (ga) wa = tab_row<MODE, 1>(ix, ja + 1);
+        if (gb) wb = tab_row<MODE, 1>(ix, jb + 1);
+        if (ga) {
+            offa -= na; ja += 1; ffa += 1; rowa = wa; na = row_n<MODE>(rowa);
+            ga = (ja < ix.r - 1 && offa >= na && ffa < 65535u) ? 1u : 0u;
+        }
+        if (gb) {
+            offb -= nb; jb += 1; ffb += 1; rowb = wb; nb = row_n<MODE>(rowb);
+            gb = (jb < ix.r - 1 && offb >= nb && ffb < 65535u) ? 1u : 0u;
+        }
+    }
+    ff_total += ffa + ffb;
+    ia = ja; ib = jb;
+    return (ffa >= 65535u || ffb >= 65535u) ? kErrFastForward : kErrNone;   // move_structure.cpp:72-75
+}
+
+// AH = 1 (look-ahead rows, DevIndex::rows2; MODE 6): the search walks on the table's second copy and every end carries the
+// look-ahead entry of its row.  After the interval has been shrunk to the rows of base b, the NEXT base b2 is looked at:
+// if both ends' LF targets hold b2 (neither is the '$' row) and both arrive there without a fast-forward -- all of it in
+// the entries -- the step after this one needs no shrink and no rows: update_interval + two LF moves twice
+// (src/move_structure_search.cpp:311-333 run for b and for b2), two bases for one pair of gathers.  The interval after b --
+// what the reference reports if the one after b2 came out empty -- is known from the entries too.
+template <int MODE, int AH = 0>
 __global__ __launch_bounds__(256) void count_kernel_v0(DevIndex ix, const uint8_t *__restrict__ bases,
                                                        const uint64_t *__restrict__ offs, uint64_t n_reads,
                                                        uint64_t *__restrict__ matched,
@@ -2301,37 +2367,77 @@ __global__ __launch_bounds__(256) void count_kernel_v0(DevIndex ix, const uint8_
     uint32_t empty = have && !run;
     // rows[rs], rows[re]: loaded for the first step, afterwards carried over from the LF moves
     // (lf_step2 leaves the rows of the new ends in rws / rwe), one dependent trip less per base
-    uint2 rws = make_uint2(0, 0), rwe = make_uint2(0, 0);
+    uint2 rws = make_uint2(0, 0), rwe = make_uint2(0, 0), ens = make_uint2(0, 0), ene = make_uint2(0, 0);
     if (run) {
-        rws = load_row<MODE>(ix.rows, rs);
-        rwe = load_row<MODE>(ix.rows, re);
+        rws = tab_row<MODE, AH>(ix, rs);
+        rwe = tab_row<MODE, AH>(ix, re);
+        if (AH) { ens = tab_entry(ix, rs); ene = tab_entry(ix, re); }
     }
     while (wave_any(run != 0u && pos > 0)) {             // backward_search :176
         const bool act = run != 0u && pos > 0;
-        uint32_t b = 0xFFu;
+        uint32_t b = 0xFFu, b2 = 0xFFu;
         if (act) {
             prs = rs; pre = re; pos_ = os; poe = oe;
+            const uint32_t byte2 = (AH && pos > 1) ? (uint32_t)R[pos - 2] : 0u;   // (AH) the base after this one, fetched with it
             b = s_code[R[pos - 1]];
+            if (AH && pos > 1) b2 = s_code[byte2];
             if (b == 0xFFu) { empty = 1; run = 0; }       // backward_search_step :321-324
         }
         const bool legal = act && b != 0xFFu;
+        const uint64_t rs_in = rs, re_in = re;
         // update_interval, src/move_structure_search.cpp:48-61 (get_char: '$' never equals a base)
         // Both ends shrink in ONE wave-uniform loop, one row per end and trip.  When the interval
         // holds no row of character b the two ends cross instead of rs running all the way past re as
         // in the reference; either way the interval is empty and the previous one is reported.
-        if (ix.r >= 8) {
-            shrink_interval<MODE>(ix, legal && rs <= re, b, rs, os, rws, re, oe, rwe, scan_total);
+        if (AH || ix.r >= 8) {                            // (the look-ahead copy exists for tables of 8 rows and more only)
+            shrink_interval<MODE, AH>(ix, legal && rs <= re, b, rs, os, rws, re, oe, rwe, scan_total);
         } else {
             shrink_interval_rows<MODE>(ix, legal && rs <= re, b, rs, os, rws, re, oe, rwe, scan_total);
         }
         bool nonempty = legal && ((rs < re) || (rs == re && os <= oe));
         if (legal && !nonempty) { empty = 1; run = 0; }
-        // backward_search_step :326-330: two LF moves
-        const uint32_t e12 = lf_step2<MODE>(ix, nonempty, rs, os, rws, re, oe, rwe, ff_total);
-        if (e12) { failed = e12; run = 0; nonempty = false; }
-        if (nonempty) {                                   // backward_search :179-182
-            if ((rs < re) || (rs == re && os <= oe)) pos -= 1;
-            else { empty = 1; run = 0; }
+        if (!AH) {
+            // backward_search_step :326-330: two LF moves
+            const uint32_t e12 = lf_step2<MODE>(ix, nonempty, rs, os, rws, re, oe, rwe, ff_total);
+            if (e12) { failed = e12; run = 0; nonempty = false; }
+            if (nonempty) {                               // backward_search :179-182
+                if ((rs < re) || (rs == re && os <= oe)) pos -= 1;
+                else { empty = 1; run = 0; }
+            }
+        } else {
+            if (rs != rs_in) ens = make_uint2(0u, 0u);    // an end that moved: its entry belonged to the row it left
+            if (re != re_in) ene = make_uint2(0u, 0u);    // (the shrink loads rows only)
+            // backward_search_step :326-330: the two LF moves of base b ...
+            uint64_t ta = rs, tb = re;
+            uint32_t two = 0;
+            if (nonempty) {
+                ta = row_id<MODE>(rws, rs, ix);
+                tb = row_id<MODE>(rwe, re, ix);
+                if (ta >= ix.r || tb >= ix.r) {           // move_structure.cpp:63-65
+                    failed = kErrIdRange; run = 0; nonempty = false;
+                } else {
+                    os += row_off<MODE>(rws);
+                    oe += row_off<MODE>(rwe);
+                    // ... and, from the entries, base b2's whole step: both targets hold b2, no fast-forward at either
+                    const uint32_t n1s = ens.y & 0x7FFu, n1e = ene.y & 0x7FFu, c1s = (ens.y >> 22) & 7u, c1e = (ene.y >> 22) & 7u;
+                    two = (ens.y >> 31) & (ene.y >> 31) & (uint32_t)(b2 != 0xFFu) & (uint32_t)(c1s == b2) & (uint32_t)(c1e == b2) &
+                          (uint32_t)(os < n1s) & (uint32_t)(oe < n1e) & (uint32_t)(ta != ix.end_bwt_idx) & (uint32_t)(tb != ix.end_bwt_idx) &
+                          (uint32_t)((ta < tb) || (ta == tb && os <= oe));
+                    if (two) {
+                        prs = ta; pre = tb; pos_ = os; poe = oe;           // the interval after b: reported if b2's comes out empty
+                        os += (ens.y >> 11) & 0x7FFu;
+                        oe += (ene.y >> 11) & 0x7FFu;
+                        ta = (uint64_t)ens.x | ((uint64_t)((ens.y >> 25) & 15u) << 32);
+                        tb = (uint64_t)ene.x | ((uint64_t)((ene.y >> 25) & 15u) << 32);
+                    }
+                }
+            }
+            const uint32_t e12 = arrive2_ahead<MODE>(ix, nonempty, ta, tb, rs, os, rws, ens, re, oe, rwe, ene, ff_total);
+            if (e12) { failed = e12; run = 0; nonempty = false; }
+            if (nonempty) {                               // backward_search :179-182, once or twice
+                if ((rs < re) || (rs == re && os <= oe)) pos -= 1 + (int64_t)two;
+                else { empty = 1; run = 0; pos -= (int64_t)two; }
+            }
         }
     }
     if (valid) {
@@ -2374,15 +2480,20 @@ hipError_t launch_count(int mode, const DevIndex &ix, const uint8_t *d_bases, co
         if (bpc < 1) bpc = 1;
         if (bpc < 32) dyn_lds = std::min<size_t>(65536 - 1024, ((163840u / (unsigned)bpc) & ~1023u) - 1024u);
     }
+    const bool ahead = mode == 6 && ix.rows2 != nullptr;   // the search walks on the look-ahead rows where the index has them
     if (info) {
-        snprintf(info->kernel, sizeof(info->kernel), "count_kernel_v0<%d>", mode);
+        snprintf(info->kernel, sizeof(info->kernel), "count_kernel_v0<%d, %d>", mode, ahead ? 1 : 0);
         info->variant = 0; info->block_threads = bt; info->waves_per_cu = wpc; info->segmented = 0; info->idx64 = 1;
+        info->ahead = ahead ? 1 : 0;
     }
     const uint64_t blocks = (n_reads + bt - 1) / bt;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     dim3 grid((unsigned)blocks), block((unsigned)bt);
     // resident layouts: 6 = regular-thresholds rows, 3 = regular rows (threshold-less types: 12-bit lengths)
-    if (mode == 6)
+    if (mode == 6 && ahead)
+        hipLaunchKernelGGL((count_kernel_v0<6, 1>), grid, block, dyn_lds, stream, ix, d_bases, d_offsets, n_reads,
+                           d_matched, d_count, d_err, d_stats, d_order);
+    else if (mode == 6)
         hipLaunchKernelGGL(count_kernel_v0<6>, grid, block, dyn_lds, stream, ix, d_bases, d_offsets, n_reads,
                            d_matched, d_count, d_err, d_stats, d_order);
     else if (mode == 3)

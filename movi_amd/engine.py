@@ -242,15 +242,20 @@ class MoveIndex:
                                            None, C.byref(st)))
         return a[:n], b[:n], s[:n]
 
-    def query_count_packed(self, bases, offs):
+    def query_count_packed(self, bases, offs, want_err=False):
+        """-> (matched, count, QueryStats[, per-read error bytes, return code])"""
         bases = np.ascontiguousarray(bases, np.uint8)
         offs = np.ascontiguousarray(offs, np.uint64)
         n = offs.size - 1
         m = np.zeros(max(n, 1), np.uint64)
         c = np.zeros(max(n, 1), np.uint64)
+        err = np.zeros(max(n, 1), np.uint8)
         st = QueryStatsC()
-        check(lib().movi_count_host(self._h, bases.ctypes.data, offs.ctypes.data, n, m.ctypes.data,
-                                    c.ctypes.data, None, C.byref(st)))
+        rc = lib().movi_count_host(self._h, bases.ctypes.data, offs.ctypes.data, n, m.ctypes.data,
+                                   c.ctypes.data, err.ctypes.data if want_err else None, C.byref(st))
+        if want_err:
+            return m[:n], c[:n], QueryStats(st), err[:n], rc
+        check(rc)
         return m[:n], c[:n], QueryStats(st)
 
     def query_count(self, reads):

@@ -223,3 +223,84 @@ def test_segments_walk_on_the_look_ahead_rows(built_lib, golden_image, sep):
                 assert st.segments > len(reads)
     gpu.close()
     cpu.close()
+
+
+@pytest.mark.parametrize("mode", [6, 8, 7])
+def test_count_on_the_look_ahead_rows_vs_oracle(built_lib, golden_image, mode):
+    """The count query (backward search, src/move_structure_search.cpp:169-352) on the look-ahead rows: when both ends' LF
+    targets hold the base after the current one and neither fast-forwards there, that base's whole step comes out of the
+    entries.  matched / count, error bytes and the fast-forward / scan counters equal the oracle's and the plain-rows
+    kernel's: reads that match to their first base, reads that stop early, illegal bases next to and inside two-base steps,
+    with and without the interval table."""
+    import movi_amd
+    from oracle import build_index as B
+    from oracle.oracle import Oracle
+    ref = _ref()
+    img = golden_image(mode) if mode != 7 else B.build_index_from_seqs([ref], 7)
+    gpu, cpu = movi_amd.MoveIndex.from_image(img), Oracle(img)
+    rng = np.random.default_rng(9800 + mode)
+    reads = mutated_reads(rng, ref, 3000, 1, 400)
+    reads += [bytes(ref[s: s + L]) for s, L in ((100, 1), (100, 2), (100, 3), (5000, 150), (7000, 1000), (9000, 4000))]   # exact substrings: two-base steps all the way
+    base = bytearray(ref[30000:30200])
+    for pos in (1, 2, 3, 4, 13, 14, 15):                                 # an illegal base at distance pos from the read's end
+        for bad in (b"N", b"a"):
+            r = bytearray(base)
+            r[len(r) - pos: len(r) - pos + 1] = bad
+            reads.append(bytes(r))
+    reads += [b"", b"A", b"ACGT" * 40, bytes(rng.choice(list(b"ACGT"), size=60).astype(np.uint8))]
+    bases, offs = pack(reads)
+    em, ec = cpu.count_batch(bases, offs, threads=8)
+    gpu.set_option("ahead_rows", 0)
+    for K in (0, 12):
+        gpu.set_option("ftab_k", K)
+        gpu.set_option("ahead_rows", 0)
+        m0, c0, st0 = gpu.query_count_packed(bases, offs)
+        assert gpu.last_launch()["ahead"] == 0 and gpu.last_launch()["kernel"] == "count_kernel_v0<6, 0>"
+        assert (m0 == em).all() and (c0 == ec).all()
+        gpu.set_option("ahead_rows", 1)
+        m, c, st = gpu.query_count_packed(bases, offs)
+        assert gpu.last_launch()["ahead"] == 1 and gpu.last_launch()["kernel"] == "count_kernel_v0<6, 1>"
+        assert (m == em).all() and (c == ec).all(), (mode, K)
+        assert (st.fast_forwards, st.scans, st.errors) == (st0.fast_forwards, st0.scans, 0), (mode, K)
+    # a big batch (the capped launch)
+    bb, bo = _big_batch(ref, rng, max_len=200, n_long=20)
+    em, ec = cpu.count_batch(bb, bo, threads=8)
+    m, c, st = gpu.query_count_packed(bb, bo)
+    assert gpu.last_launch()["ahead"] == 1 and (m == em).all() and (c == ec).all() and st.errors == 0
+    gpu.close()
+    cpu.close()
+
+
+def test_count_on_the_look_ahead_rows_separators_and_corrupt_rows(built_lib, golden_image):
+    import movi_amd
+    from oracle import build_index as B
+    from oracle.oracle import Oracle
+    ref = _ref()
+    img = B.build_index_from_seqs([ref[:40000], ref[40000:90000], ref[90000:]], 6, separators=True)
+    gpu, cpu = movi_amd.MoveIndex.from_image(img), Oracle(img)
+    rng = np.random.default_rng(9900)
+    reads = mutated_reads(rng, ref, 2000, 1, 300) + [bytes(ref[39950:40050]), b"ACG%TACGTACGTACGT", bytes(ref[100:1100])]
+    bases, offs = pack(reads)
+    em, ec = cpu.count_batch(bases, offs, threads=8)
+    for ahead in (0, 1):
+        gpu.set_option("ahead_rows", ahead)
+        m, c, st = gpu.query_count_packed(bases, offs)
+        assert gpu.last_launch()["ahead"] == ahead and (m == em).all() and (c == ec).all() and st.errors == 0, ahead
+    gpu.close()
+    cpu.close()
+    # rows pointing past the table: the entries of such rows (and of rows that point AT them) are invalid, the search runs
+    # into the reference's throw exactly where the plain-rows kernel does
+    img = bytearray(golden_image(6))
+    _, _, off, _ = movi_amd.parse_index_image(bytes(img))
+    rows = np.frombuffer(img, np.uint8, count=118209 * 8, offset=off).reshape(-1, 8).copy()
+    rows[rng.choice(118209, 3000, replace=False), 0:4] = 0xFF
+    img[off: off + rows.size] = rows.tobytes()
+    gpu = movi_amd.MoveIndex.from_image(bytes(img))
+    gpu.set_option("ahead_rows", 0)
+    m0, c0, st0, err0, rc0 = gpu.query_count_packed(bases, offs, want_err=True)
+    assert st0.errors > 100
+    gpu.set_option("ahead_rows", 1)
+    m, c, st, err, rc = gpu.query_count_packed(bases, offs, want_err=True)
+    assert gpu.last_launch()["ahead"] == 1
+    assert rc == rc0 and (m == m0).all() and (c == c0).all() and (err == err0).all() and st.errors == st0.errors
+    gpu.close()

@@ -177,7 +177,7 @@ def test_last_launch_reports_the_policy(engine6):
     assert gpu.last_launch()["kernel"] == "pml_kernel<6, 1, 0>"
     gpu.set_option("pml_variant", -1)
     gpu.query_count_packed(bases, offs)
-    assert gpu.last_launch()["kernel"] == "count_kernel_v0<6>"
+    assert gpu.last_launch()["kernel"] == "count_kernel_v0<6, 1>" and gpu.last_launch()["ahead"] == 1   # on the look-ahead rows (a small table)
     gpu.query_zml_packed(bases, offs)
     assert gpu.last_launch()["kernel"] == "zml_kernel_flat<6, unsigned int, 0>"
 
