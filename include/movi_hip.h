@@ -322,7 +322,8 @@ int movi_host_unregister(void *p);
  * "ahead_rows" (look-ahead rows: a second copy of the table, 16 bytes per row, in which each row's 128-byte line also holds
  * what the rows' LF targets look like -- character, length, offset, their own target --, so that a base that matches at the
  * target without a fast-forward is resolved, and its PML emitted, without fetching the target: two bases per gather on
- * real reads (+40 % on the cache-resident pangenome table).  Left alone, the first PML query builds them for tables of up
+ * real reads (+40 % on the cache-resident pangenome table); the count query walks both ends of its interval on them the
+ * same way (+20 %).  Left alone, the first PML or count query builds them for tables of up
  * to 100 M rows (a copy of 1.6 GB); beyond that the wider gathers cost more address translations than they save rows on
  * the worst-case (uniformly random) table -- measured slower -- so there they are built only on request.  1 = build now,
  * 0 = none (freed)),

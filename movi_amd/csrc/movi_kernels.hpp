@@ -57,7 +57,8 @@ struct DevIndex {
                                   // reference's throws -- such reads take the ordinary walk and report it
     // Look-ahead rows ("ahead_rows" option; nullptr = none): a second copy of the table in which every row carries, in the
     // SAME 128-byte line, what the row its LF points to looks like -- so that a step whose next base matches there without a
-    // fast-forward (the common case on real reads) is taken without fetching that row: two bases per gather.
+    // fast-forward (the common case on real reads) is taken without fetching that row: two bases per gather.  The count query's
+    // two interval ends use the same entries (count_kernel_v0<6, 1>).
     // Layout: line L = rows 8L .. 8L+7 (64 bytes) followed by their 8 look-ahead entries (64 bytes); one more line at
     // byte rows2_tail holds rows r-4 .. r-1 and their entries (the walk's last, pulled-back window).  Entry of row i, with
     // j = id(i), j2 = id(j): x = j2[31:0]; y = n(j) (11 bits) | offset(j) << 11 (11 bits) | c(j) << 22 (3 bits) |
