@@ -96,6 +96,7 @@ struct movi_index {
     uint4 *d_kmer = nullptr;         // top-of-walk table ("kmer_k" option), 16 << 2K bytes
     int kmer_auto = 12;              // K of the table the first PML query builds by itself (0 = none: "kmer_k" 0)
     uint8_t *d_rows2 = nullptr;      // look-ahead rows ("ahead_rows" option), 16 bytes per row
+    uint8_t *d_rows3 = nullptr;      // ... in the fat-row layout ("ahead_rows" 2)
     int ahead_auto = 1;              // 1: the first PML query builds them when the table is small enough (ahead_rows_fit)
     uint4 *d_ftab = nullptr;         // the count query's interval table ("ftab_k" option), 16 << 2K bytes
     int ftab_auto = 12;              // K of the table the first count query builds by itself (0 = none)
@@ -727,6 +728,7 @@ int movi_index_destroy(movi_index_t *ix) {
     if (ix->d_kmer) (void)hipFree(ix->d_kmer);
     if (ix->d_ftab) (void)hipFree(ix->d_ftab);
     if (ix->d_rows2) (void)hipFree(ix->d_rows2);
+    if (ix->d_rows3) (void)hipFree(ix->d_rows3);
     if (ix->d_stats) (void)hipFree(ix->d_stats);
     release_scratch(ix);
     delete ix;
@@ -768,6 +770,15 @@ static int build_ahead(movi_index *ix, hipStream_t s) {
     if (e != hipSuccess) { (void)hipFree(ix->d_rows2); ix->d_rows2 = nullptr; return fail_hip(e, "building the look-ahead rows"); }
     ix->dev.rows2 = ix->d_rows2;
     ix->dev.rows2_tail = tail;
+    return MOVI_OK;
+}
+
+static int build_fat(movi_index *ix, hipStream_t s) {
+    HIP_TRY(hipMalloc(&ix->d_rows3, (size_t)ix->desc.r * 16));
+    hipError_t e = build_fat_rows(ix->kmode, ix->dev, ix->d_rows3, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { (void)hipFree(ix->d_rows3); ix->d_rows3 = nullptr; return fail_hip(e, "building the fat rows"); }
+    ix->dev.rows3 = ix->d_rows3;
     return MOVI_OK;
 }
 
@@ -886,18 +897,21 @@ int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
             return fail(MOVI_ERR_ARG, "the top-of-walk table serves PML walks on DNA (ACGT) *-thresholds indexes only");
         return build_kmer(ix, (uint32_t)value, nullptr);
     }
-    if (!strcmp(key, "ahead_rows")) {                        // look-ahead rows: 0 = none (freed), 1 = build them now
-        if (value != 0 && value != 1) return fail(MOVI_ERR_ARG, "ahead_rows must be 0 or 1");
+    if (!strcmp(key, "ahead_rows")) {                        // look-ahead rows: 0 = none (freed), 1 = build them now, 2 = as fat rows
+        if (value < 0 || value > 2) return fail(MOVI_ERR_ARG, "ahead_rows must be 0, 1 or 2");
         HIP_TRY(hipSetDevice(ix->device));
         HIP_TRY(hipDeviceSynchronize());                     // no walk may be reading the copy that goes away
         ix->dev.rows2 = nullptr;
         ix->dev.rows2_tail = 0;
+        ix->dev.rows3 = nullptr;
         if (ix->d_rows2) (void)hipFree(ix->d_rows2);
+        if (ix->d_rows3) (void)hipFree(ix->d_rows3);
         ix->d_rows2 = nullptr;
+        ix->d_rows3 = nullptr;
         ix->ahead_auto = 0;                                  // the caller's choice from here on
         if (value == 0) return MOVI_OK;
         if (!ahead_eligible(ix)) return fail(MOVI_ERR_ARG, "look-ahead rows serve PML walks on *-thresholds indexes only");
-        return build_ahead(ix, nullptr);
+        return value == 1 ? build_ahead(ix, nullptr) : build_fat(ix, nullptr);
     }
     if (!strcmp(key, "ftab_k")) {                            // count query's interval table: 0 = none, K in [1, 12] = build it now
         if (value < 0 || value > 12) return fail(MOVI_ERR_ARG, "ftab_k must be in [0, 12]");

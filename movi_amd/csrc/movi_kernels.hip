@@ -825,14 +825,24 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
     // The 4-row window that holds row nd: aligned, except that the table's last window is pulled back to
     // rows [r-4, r) so that the fetch never leaves the table and needs no special case (r >= 4, checked at
     // launch).  Unpredicated: finished lanes re-read window 0 (a cache hit) instead of branching around the load.
-    const IdxT wb_last = (IdxT)(ix.r - 4);
+    // (AHD == 2, fat rows: the window is the aligned PAIR of rows around the row it needs, with their two entries -- the same
+    // 32 bytes and two loads as the plain 4-row window; the table's last window is rows [r-2, r))
+    constexpr uint32_t WN = AHD == 2 ? 2u : 4u;           // rows per window
+    const IdxT wb_last = (IdxT)(ix.r - WN);
     auto win_base = [&](IdxT nd) -> IdxT {
-        const IdxT wb = nd & ~(IdxT)3;
+        const IdxT wb = nd & ~(IdxT)(WN - 1u);
         return wb < wb_last ? wb : wb_last;
     };
     uint2 ahw[4];                                         // AHD: the look-ahead entries of the window's four rows
     auto fetch = [&](IdxT nd, bool act, uint2 (&w)[4]) {
-        if (AHD) {                                        // line = 8 rows + their 8 entries; the last window has a line of its own
+        if (AHD == 2) {                                   // fat rows: row i and its entry are the 16 bytes at 16 i
+            uint4 p0, p1;
+            const uint8_t *at = ix.rows3 + (uint64_t)(act ? win_base(nd) : (IdxT)0) * 16u;
+            __builtin_memcpy(&p0, at, 16);
+            __builtin_memcpy(&p1, at + 16, 16);
+            w[0] = make_uint2(p0.x, p0.y); ahw[0] = make_uint2(p0.z, p0.w);
+            w[1] = make_uint2(p1.x, p1.y); ahw[1] = make_uint2(p1.z, p1.w);
+        } else if (AHD) {                                 // line = 8 rows + their 8 entries; the last window has a line of its own
             const IdxT wb = nd & ~(IdxT)3;
             const bool body = wb < wb_last;
             uint64_t at = body ? (uint64_t)(wb >> 3) * 128u + (uint64_t)((uint32_t)wb & 4u) * 8u : ix.rows2_tail;
@@ -995,8 +1005,8 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
         // starts a scan, ends one or fails is left to the full step below)
         auto hop = [&]() {
             const uint32_t q = (uint32_t)(need - wbase);
-            const uint32_t inwin = (uint32_t)(q < 4u) & (uint32_t)(st < sDone);
-            const uint2 hr = win_sel(w, q);
+            const uint32_t inwin = (uint32_t)(q < WN) & (uint32_t)(st < sDone);
+            const uint2 hr = AHD == 2 ? ((q & 1u) ? w[1] : w[0]) : win_sel(w, q);
             const uint32_t hn = row_n<MODE>(hr), hc = row_c<MODE>(hr);
             const uint32_t ffh = inwin & (uint32_t)(st == sFF) & (uint32_t)(need < r1) & (uint32_t)(off >= hn) &
                                  (uint32_t)(ff_run + 1 < 65535u);
@@ -1013,6 +1023,25 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
         // the lengths up to and including i (monotone, so the number of rows passed is a sum of four compares); a scan
         // passes the leading run of non-matching rows from its position (a 4-bit mask and a count-trailing / leading-ones).
         // Same state afterwards as four hop() calls -- identical answers and counts -- at a third of the dependency depth.
+        auto pair_advance = [&]() {                       // window_advance on a window of two rows (AHD == 2)
+            const uint32_t q0 = (uint32_t)(need - wbase);
+            const uint32_t inwin = (uint32_t)(q0 < 2u) & (uint32_t)(st < sDone);
+            const uint32_t n0 = row_n<MODE>(w[0]), n1 = row_n<MODE>(w[1]);
+            const uint32_t last_win = (uint32_t)(wbase + 1 == r1), first_win = (uint32_t)(wbase == 0);
+            const uint32_t m0 = q0 == 0u;
+            const uint32_t t1 = m0 ? n0 : 0u, t2 = t1 + n1;
+            const uint32_t isff = inwin & (uint32_t)(st == sFF);
+            const uint32_t p0 = isff & m0 & (uint32_t)(off >= t1), p1 = isff & (uint32_t)(off >= t2) & (last_win ^ 1u);
+            off -= p1 ? t2 : (p0 ? t1 : 0u);
+            ff_run += p0 + p1;
+            const uint32_t nm = (uint32_t)(row_c<MODE>(w[0]) != a) | ((uint32_t)(row_c<MODE>(w[1]) != a) << 1);
+            const uint32_t dmask = (nm & (last_win ? 1u : 3u)) >> (q0 & 1u);               // row r-1 is never passed
+            const uint32_t cd = (inwin & (uint32_t)(st == sDown)) ? ((dmask & 1u) ? ((dmask & 2u) ? 2u : 1u) : 0u) : 0u;
+            const uint32_t umask = ((nm & (first_win ? 2u : 3u)) << (1u - (q0 & 1u))) & 3u;  // row 0 is never passed
+            const uint32_t cu = (inwin & (uint32_t)(st == sUp)) ? ((umask & 2u) ? ((umask & 1u) ? 2u : 1u) : 0u) : 0u;
+            scan_total += cd + cu;
+            need = need + (IdxT)(p0 + p1 + cd) - (IdxT)cu;
+        };
         auto window_advance = [&]() {
             const uint32_t q0 = (uint32_t)(need - wbase);
             const uint32_t inwin = (uint32_t)(q0 < 4u) & (uint32_t)(st < sDone);
@@ -1045,12 +1074,14 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
             for (int h = 0; h < (HA >= 0 ? HA : 0); ++h) hop();
         } else if (wave_any(st == sFF && ff_run >= 65520u)) {
             for (int h = 0; h < 4; ++h) hop();                       // near the reference's fast-forward limit: step by step
+        } else if (AHD == 2) {
+            pair_advance();
         } else {
             window_advance();
         }
         const uint32_t qn = (uint32_t)(need - wbase);
-        const uint32_t inwin = (uint32_t)(qn < 4u) & (uint32_t)act;
-        const uint2 row = win_sel(w, qn);
+        const uint32_t inwin = (uint32_t)(qn < WN) & (uint32_t)act;
+        const uint2 row = AHD == 2 ? ((qn & 1u) ? w[1] : w[0]) : win_sel(w, qn);
         const uint32_t n = row_n<MODE>(row), c = row_c<MODE>(row), roff = row_off<MODE>(row);
         const uint32_t isFF = (uint32_t)(st == sFF) & inwin, isDown = (uint32_t)(st == sDown) & inwin,
                        isUp = (uint32_t)(st == sUp) & inwin;
@@ -1090,7 +1121,7 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
         // match and no fast-forward: ml + 1, then LF_move again) -- the target row itself is never fetched
         uint32_t dbl = 0, lf2 = 0, off1 = 0;
         if (AHD) {
-            const uint2 ah = win_sel(ahw, qn);            // the entry of the row the base was resolved at
+            const uint2 ah = AHD == 2 ? ((qn & 1u) ? ahw[1] : ahw[0]) : win_sel(ahw, qn);   // the entry of the row the base was resolved at
             const uint32_t n1 = ah.y & 0x7FFu, c1 = (ah.y >> 22) & 7u;
             const uint32_t off_e = (hit ? (isDown ? 0u : n - 1u) : off) + roff;
             dbl = lf & (ah.y >> 31) & (uint32_t)(a1 == c1) & (uint32_t)(off_e < n1);
@@ -1382,7 +1413,8 @@ __global__ __launch_bounds__(256) void kmer_table_kernel(DevIndex ix, uint32_t K
 }
 
 // Look-ahead rows (DevIndex::rows2): thread i copies row i into its line and writes the entry of its LF target next to it.
-template <int MODE>
+// FAT = 1: the fat-row layout (DevIndex::rows3) -- row i and its entry are the 16 bytes at 16 i.
+template <int MODE, int FAT = 0>
 __global__ __launch_bounds__(256) void ahead_rows_kernel(DevIndex ix, uint8_t *__restrict__ out, uint64_t tail) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ix.r) return;
@@ -1396,6 +1428,11 @@ __global__ __launch_bounds__(256) void ahead_rows_kernel(DevIndex ix, uint8_t *_
             e.x = (uint32_t)j2;
             e.y = row_n<MODE>(rj) | (row_off<MODE>(rj) << 11) | (row_c<MODE>(rj) << 22) | ((uint32_t)(j2 >> 32) << 25) | 0x80000000u;
         }
+    }
+    if (FAT) {
+        const uint4 both = make_uint4(row.x, row.y, e.x, e.y);
+        __builtin_memcpy(out + i * 16u, &both, 16);
+        return;
     }
     uint8_t *line = out + (i >> 3) * 128u + (i & 7u) * 8u;
     __builtin_memcpy(line, &row, 8);
@@ -1417,6 +1454,14 @@ hipError_t build_ahead_rows(int kmode, const DevIndex &ix, uint8_t *d_rows2, uin
     const uint64_t blocks = (ix.r + 255) / 256;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     hipLaunchKernelGGL(ahead_rows_kernel<6>, dim3((unsigned)blocks), dim3(256), 0, stream, ix, d_rows2, *tail);
+    return hipGetLastError();
+}
+
+hipError_t build_fat_rows(int kmode, const DevIndex &ix, uint8_t *d_rows3, hipStream_t stream) {
+    if (!d_rows3 || ix.r < 8 || (ix.r >> 36) != 0 || kmode != 6) return hipErrorInvalidValue;
+    const uint64_t blocks = (ix.r + 255) / 256;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((ahead_rows_kernel<6, 1>), dim3((unsigned)blocks), dim3(256), 0, stream, ix, d_rows3, (uint64_t)0);
     return hipGetLastError();
 }
 
@@ -1967,6 +2012,7 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     if (wpc < 0) wpc = 0;
     const bool stage_ok = cfg.stage_reads != 0 && bt == 64 && v == 10 && wp;       // the staged kernels: one-wavefront blocks of the default walk
     const bool ahead_ok = stage_ok && ix.rows2 != nullptr;                            // ... on the look-ahead rows
+    const bool fat_ok = stage_ok && ix.rows2 == nullptr && ix.rows3 != nullptr;       // ... or on the fat rows (tables beyond the TLBs' reach)
     if (cfg.waves_per_cu == 0 && (cfg.pml_variant < 0 || cfg.pml_variant == 14) && v == 10 && big_batch)
         wpc = ahead_ok ? kCapWavesAhead : kCapWaves;                               // the auto policy above
     if (v == 13) {
@@ -1998,6 +2044,7 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     const uint32_t stage_cap = (uint32_t)std::min<size_t>(1024, (dyn_lds / 64) & ~(size_t)15);
     ixl.stage_lds = (stage_ok && stage_cap >= 96) ? stage_cap : 0u;
     const bool use_ahead = ahead_ok && ixl.stage_lds != 0u;
+    const bool use_fat = fat_ok && ixl.stage_lds != 0u;
     const SegArgs no_seg;
     // every kernel that is handed more than 64 KiB of dynamic LDS must opt in first
 #define MOVI_SEG_0
@@ -2031,7 +2078,10 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     } while (0)
 #define MOVI_LAUNCH_FLATP_STG(M, C, S)                                                                      \
     do {                                                                                                    \
-        if (use_ahead) {                                                                                    \
+        if (use_fat) {                                                                                      \
+            if (ix.idx32) MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint32_t, -1, C, S, 0, 0, 1, 2>);           \
+            else MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint64_t, -1, C, S, 0, 0, 1, 2>);                    \
+        } else if (use_ahead) {                                                                                    \
             if (ix.idx32) MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint32_t, -1, C, S, 0, 0, 1, 1>);           \
             else MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint64_t, -1, C, S, 0, 0, 1, 1>);                    \
         } else {                                                                                            \
@@ -2068,11 +2118,11 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
         if (v == 0 || v == 1) snprintf(info->kernel, sizeof(info->kernel), "pml_kernel<6, %d, %d>", v, v == 0 ? 0 : cm);
         else if (v == 7) snprintf(info->kernel, sizeof(info->kernel), "pml_kernel_flat<6, %s, 0>", it);
         else snprintf(info->kernel, sizeof(info->kernel), "pml_kernel_flatp<6, %s, %d, %d, %d, %d, 0, %d, %d>", it, wp ? -1 : MOVI_HA, cm,
-                      ix.sep ? 1 : 0, v == 13 ? 1 : 0, (v == 10 && ixl.stage_lds) ? 1 : 0, use_ahead ? 1 : 0);
+                      ix.sep ? 1 : 0, v == 13 ? 1 : 0, (v == 10 && ixl.stage_lds) ? 1 : 0, use_ahead ? 1 : (use_fat ? 2 : 0));
         info->variant = (v == 10 && wp) ? 14 : v;
         info->block_threads = bt; info->waves_per_cu = wpc; info->segmented = 0; info->idx64 = ix.idx32 ? 0 : 1;
         info->staged = (int)ixl.stage_lds;
-        info->ahead = use_ahead ? 1 : 0;
+        info->ahead = use_ahead ? 1 : (use_fat ? 2 : 0);
     }
 #undef MOVI_LAUNCH_PML
 #undef MOVI_LAUNCH_K

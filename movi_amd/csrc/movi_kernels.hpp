@@ -65,6 +65,10 @@ struct DevIndex {
     // j2[35:32] << 25 | valid << 31.  valid = 0 when j or j2 is not a row (corrupt table): such steps are taken one by one.
     const uint8_t *rows2;
     uint64_t rows2_tail;
+    // Fat rows ("ahead_rows" 2; nullptr = none): the same entries for tables beyond the TLBs' reach, where a step must not
+    // cost more loads than it does on the plain rows -- row i and its entry are the 16 bytes at 16 i, and the walk's window is
+    // the aligned PAIR of rows with their entries: 32 bytes, two loads, like the plain 4-row window.
+    const uint8_t *rows3;
 };
 
 // Device counters of one query call.
@@ -216,6 +220,7 @@ hipError_t build_kmer_table(const DevIndex &ix, uint32_t K, uint4 *d_table, hipS
 // per row); *tail = DevIndex::rows2_tail.  Thresholds types (kmode 6: the PML walk's rows), r >= 8.
 uint64_t ahead_rows_bytes(uint64_t r);
 hipError_t build_ahead_rows(int kmode, const DevIndex &ix, uint8_t *d_rows2, uint64_t *tail, hipStream_t stream);
+hipError_t build_fat_rows(int kmode, const DevIndex &ix, uint8_t *d_rows3, hipStream_t stream);   // DevIndex::rows3: 16 r bytes
 
 // Fills the 4^K entries of the count query's interval table (DevIndex::ftab); mode = resident layout (6 or 3).
 hipError_t build_ftab(int mode, const DevIndex &ix, uint32_t K, uint4 *d_table, hipStream_t stream);

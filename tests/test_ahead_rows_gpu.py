@@ -188,6 +188,8 @@ def test_ahead_rows_refused_where_they_cannot_serve(built_lib):
         gpu.set_option("ahead_rows", 1)
     with pytest.raises(movi_amd.MoviError):
         gpu.set_option("ahead_rows", 2)
+    with pytest.raises(movi_amd.MoviError):
+        gpu.set_option("ahead_rows", 3)
     gpu.close()
 
 
@@ -304,3 +306,61 @@ def test_count_on_the_look_ahead_rows_separators_and_corrupt_rows(built_lib, gol
     assert gpu.last_launch()["ahead"] == 1
     assert rc == rc0 and (m == m0).all() and (c == c0).all() and (err == err0).all() and st.errors == st0.errors
     gpu.close()
+
+
+@pytest.mark.parametrize("mode", [6, 8])
+def test_fat_rows_vs_oracle(built_lib, golden_image, mode):
+    """"ahead_rows" 2: the look-ahead entries next to their rows (16 bytes per row), walked with a window of TWO rows -- the
+    layout for tables beyond the TLBs' reach, where a step may not cost more loads than on the plain rows.  Same answers,
+    error bytes and counters as the oracle and the plain rows, for every read length, both index widths, with bins."""
+    import movi_amd
+    from oracle.oracle import Oracle
+    img = golden_image(mode)
+    gpu, cpu = movi_amd.MoveIndex.from_image(img), Oracle(img)
+    ref = _ref()
+    bases, offs = _big_batch(ref, np.random.default_rng(9950 + mode))
+    exp, ff, sc = cpu.pml_batch(bases, offs, threads=8)
+    gpu.set_option("ahead_rows", 0)
+    out0, st0 = gpu.query_pml_packed(bases, offs)
+    bins0 = gpu.classify_packed(bases, offs, 40, 4)
+    gpu.set_option("ahead_rows", 2)
+    for K in (0, 12):
+        gpu.set_option("kmer_k", K)
+        for idx64 in (0, 1):
+            gpu.set_option("idx64", idx64)
+            out, st = gpu.query_pml_packed(bases, offs)
+            li = gpu.last_launch()
+            assert li["ahead"] == 2 and li["kernel"].endswith(", 0, 0, 1, 2>") and li["idx64"] == idx64
+            assert (out == exp).all(), (mode, K, idx64)
+            assert (st.fast_forwards, st.scans, st.repositions, st.errors) == (ff, sc, st0.repositions, 0), (mode, K, idx64)
+        gpu.set_option("idx64", 0)
+        bins = gpu.classify_packed(bases, offs, 40, 4)
+        assert all((x == y).all() for x, y in zip(bins, bins0)), K
+    # long reads rolling through the staged stretch, a small (uncapped) batch
+    small = mutated_reads(np.random.default_rng(9960), ref, 300, 1, 3000)
+    sb, so = pack(small)
+    sexp, sff, ssc = cpu.pml_batch(sb, so, threads=4)
+    gpu.set_option("seg_len", 0)
+    sout, sst = gpu.query_pml_packed(sb, so)
+    assert gpu.last_launch()["ahead"] == 2 and (sout == sexp).all() and (sst.fast_forwards, sst.scans) == (sff, ssc)
+    gpu.close()
+    cpu.close()
+
+
+@pytest.mark.parametrize("cut", [0, 1, 2, 3])
+def test_fat_rows_last_window(built_lib, cut):
+    import movi_amd
+    from oracle import build_index as B
+    from oracle.oracle import Oracle
+    ref = _ref()
+    extra = {1: 0, 5: 7, 0: 14, 2: 28, 6: 42, 3: 49, 7: 105, 4: 112}[cut]
+    img = B.build_index_from_seqs([ref[: 30000 + extra]], 6)
+    gpu, cpu = movi_amd.MoveIndex.from_image(img), Oracle(img)
+    bases, offs = _big_batch(ref[:30000], np.random.default_rng(9970 + cut), max_len=64, n_long=3)
+    exp, ff, sc = cpu.pml_batch(bases, offs, threads=8)
+    gpu.set_option("ahead_rows", 2)
+    out, st = gpu.query_pml_packed(bases, offs)
+    assert gpu.last_launch()["ahead"] == 2
+    assert (out == exp).all() and (st.fast_forwards, st.scans, st.errors) == (ff, sc, 0)
+    gpu.close()
+    cpu.close()
