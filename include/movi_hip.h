@@ -228,7 +228,7 @@ typedef struct movi_launch_info {
     int32_t idx64;                    /* 1 = the 64-bit row-index instantiation                                     */
     int32_t staged;                   /* > 0: every lane keeps the next `staged` bases of its read in LDS ("stage_reads";
                                          336 at the default occupancy cap, 256 on the look-ahead rows); 0: no staging */
-    int32_t ahead;                    /* 1 = the walk ran on the look-ahead rows ("ahead_rows")                    */
+    int32_t ahead;                    /* 1 = the walk ran on the look-ahead rows ("ahead_rows"), 2 = on the fat rows   */
     int32_t reserved_;
 } movi_launch_info_t;
 int movi_last_launch(const movi_index_t *ix, movi_launch_info_t *info);

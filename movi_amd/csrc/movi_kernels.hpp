@@ -103,7 +103,7 @@ struct LaunchCfg {
     int seg_probe = 1;     // ... if a probe of the batch finds that walks started mid-read fall into step quickly (0 = always: tests;
                            // 2 = no probe and no read-back at all, the caller's seg_verdict decides: the launch stays asynchronous)
     int seg_verdict = 0;   // seg_probe == 2: 1 = cut eligible batches, 0 = one lane per read
-    int stage_reads = 1;   // big batches of short reads: reads staged through LDS (0 = off: A/B)
+    int stage_reads = 1;   // every lane keeps the next stretch of its read in the block's LDS (rolling for long reads); 0 = off: A/B
     int refill_blocks = 0; // variant 13: size of the persistent grid in blocks; 0 = num_cus x waves per CU (tests shrink it
                            // so that a few hundred reads already go through many refills per lane)
 };
@@ -116,8 +116,8 @@ struct LaunchInfo {
     int waves_per_cu = 0;    // resident-wavefront cap applied (0 = none)
     int segmented = 0;       // 1 = the segment-parallel plan ran (K1 + stitch + finalize around the named kernel)
     int idx64 = 0;           // 1 = the 64-bit row-index instantiation
-    int ahead = 0;           // 1 = the walk ran on the look-ahead rows (two bases per gather where the next base matches)
-    int staged = 0;          // > 0: wavefronts whose reads all have at most this many bases copy them into LDS once (pml_kernel_flatp)
+    int ahead = 0;           // 1 = the walk ran on the look-ahead rows (two bases per gather where the next base matches), 2 = on the fat rows
+    int staged = 0;          // > 0: every lane keeps the next `staged` bases of its read in LDS (pml_kernel_flatp<..., STG = 1>)
 };
 
 // Classifier::classify bins (src/classifier.cpp:99-143) fused into the PML kernels: per read the number of

@@ -3,7 +3,7 @@ its LF target looks like, so that a base that matches there without a fast-forwa
 target: two bases per gather (reference semantics of the step: src/read_processor.cpp:188-238 match branch + LF_move,
 src/move_structure.cpp:59-87).  Only staged short-read launches walk on them.  PMLs, error bytes, bins and the
 fast-forward / scan / reposition counters must equal the oracle's and those of the same launch without the copy: on every
-index type the PML walk serves, for every read length the staging area holds, next to wavefronts that cannot stage, with
+index type the PML walk serves, for every read length the staging area holds, next to wavefronts whose reads roll through it, with
 illegal bases, separators, corrupt rows, both row-index widths and tables whose last window sits differently in its line."""
 import numpy as np
 import pytest
@@ -21,7 +21,7 @@ N_BIG = 300_000    # > 256 CUs x 64 lanes x 18 wavefronts: the capped, staged la
 def _big_batch(ref, rng, n=N_BIG, max_len=CAP, sub=0.02, n_long=40, alphabet=b"ACGT"):
     lens = rng.integers(0, max_len + 1, n).astype(np.uint64)
     if n_long:
-        lens[rng.choice(n, n_long, replace=False)] = rng.integers(CAP + 1, 2000, n_long)   # wavefronts that cannot stage
+        lens[rng.choice(n, n_long, replace=False)] = rng.integers(CAP + 1, 2000, n_long)   # wavefronts that roll through their staged stretch
     lens[:64] = CAP
     lens[64:128] = 0
     lens[128:192] = 1

@@ -156,7 +156,7 @@ def test_reads_staged_through_lds_vs_oracle(built_lib, golden_image, mode):
     n = 300_000                                           # > 256 CUs x 64 lanes x 18 wavefronts
     CAP = 336                                             # bases per lane the default cap's LDS padding holds (7 wavefronts per CU)
     lens = rng.integers(0, CAP + 1, n).astype(np.uint64)
-    lens[rng.choice(n, 40, replace=False)] = rng.integers(CAP + 1, 2000, 40)   # a few wavefronts that cannot stage
+    lens[rng.choice(n, 40, replace=False)] = rng.integers(CAP + 1, 2000, 40)   # a few wavefronts that roll through their staged stretch
     lens[:64] = CAP                                      # one wavefront of reads that fill the staging area exactly
     lens[64:128] = 0
     starts = rng.integers(0, len(ref) - 2000, n)
