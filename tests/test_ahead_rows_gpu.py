@@ -76,7 +76,7 @@ def test_ahead_rows_vs_oracle(built_lib, golden_image, mode):
     assert li["ahead"] == 1 and li["waves_per_cu"] == 0 and li["staged"] == CAP and li["segmented"] == 0
     assert (sout == sexp).all() and (sst.fast_forwards, sst.scans) == (sff, ssc)
     # ... and batches between one and 18 wavefronts per CU, which get what their wavefronts leave of the CU's LDS
-    for n_mid, cap_mid in ((150_000, 240), (280_000, 112)):
+    for n_mid, cap_mid in ((150_000, 192), (280_000, 96)):
         mb, mo = bases[: int(offs[n_mid])], offs[: n_mid + 1]
         mout, mst = gpu.query_pml_packed(mb, mo)
         li = gpu.last_launch()
