@@ -364,3 +364,49 @@ def test_fat_rows_last_window(built_lib, cut):
     assert (out == exp).all() and (st.fast_forwards, st.scans, st.errors) == (ff, sc, 0)
     gpu.close()
     cpu.close()
+
+
+@pytest.mark.parametrize("kind", ["repeats", "poly", "two_letters", "random", "tandem", "with_n_runs"])
+def test_look_ahead_on_odd_texts(built_lib, kind):
+    """Texts that stress what the entries encode: long runs (offsets near the 11-bit limit, rows split at 2047), two-letter
+    alphabets (no top-of-walk table), tandem repeats (every base rides along for thousands of steps), random text (almost
+    none does).  PML (line copy and fat rows) and count against the oracle, small batches (uncapped, staged launches)."""
+    import movi_amd
+    from oracle import build_index as B
+    from oracle.oracle import Oracle
+    rng = np.random.default_rng(10000 + ["repeats", "poly", "two_letters", "random", "tandem", "with_n_runs"].index(kind))
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    if kind == "repeats":
+        unit = bytes(acgt[rng.integers(0, 4, 300)])
+        text = b"".join(bytes(bytearray(unit)) if rng.random() < 0.7 else bytes(acgt[rng.integers(0, 4, 300)]) for _ in range(120))
+    elif kind == "poly":
+        text = b"".join((b"A" * int(rng.integers(1, 6000))) + bytes(acgt[rng.integers(0, 4, int(rng.integers(1, 40)))]) for _ in range(12))
+    elif kind == "two_letters":
+        text = bytes(np.frombuffer(b"AT", np.uint8)[rng.integers(0, 2, 30000)])
+    elif kind == "random":
+        text = bytes(acgt[rng.integers(0, 4, 40000)])
+    elif kind == "tandem":
+        text = (b"ACGTTGCA" * 3000) + bytes(acgt[rng.integers(0, 4, 2000)]) + (b"GATTACA" * 2000)
+    else:
+        text = bytes(acgt[rng.integers(0, 4, 20000)]) + b"N" * 50 + bytes(acgt[rng.integers(0, 4, 20000)])
+    text = text.replace(b"N", b"")                                        # the index itself is over ACGT
+    img = B.build_index_from_seqs([text], 6)
+    gpu, cpu = movi_amd.MoveIndex.from_image(img), Oracle(img)
+    reads = mutated_reads(rng, text, 1500, 1, 700) + [bytes(text[:5000]), bytes(text[-3000:]), bytes(text[1000:1001])]
+    if kind == "with_n_runs":
+        reads += [bytes(text[100:160]) + b"NNN" + bytes(text[160:260]), b"N" * 40, b"ACGTN" * 30]
+    bases, offs = pack(reads)
+    exp, ff, sc = cpu.pml_batch(bases, offs, threads=8)
+    em, ec = cpu.count_batch(bases, offs, threads=8)
+    gpu.set_option("seg_len", 0)
+    for ahead in (0, 1, 2):
+        gpu.set_option("ahead_rows", ahead)
+        out, st = gpu.query_pml_packed(bases, offs)
+        assert gpu.last_launch()["ahead"] == ahead and gpu.last_launch()["staged"] > 0
+        assert (out == exp).all(), (kind, ahead)
+        assert (st.fast_forwards, st.scans, st.errors) == (ff, sc, 0), (kind, ahead)
+        m, c, cst = gpu.query_count_packed(bases, offs)
+        assert gpu.last_launch()["ahead"] == (1 if ahead == 1 else 0)
+        assert (m == em).all() and (c == ec).all() and cst.errors == 0, (kind, ahead)
+    gpu.close()
+    cpu.close()
