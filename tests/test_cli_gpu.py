@@ -473,3 +473,43 @@ def test_cli_accepts_mmap_flag(movi_bin):
     a, b = run(base), run(base + ["--mmap"])
     assert a.returncode == 0 and b.returncode == 0, (a.stderr, b.stderr)
     assert a.stdout == b.stdout and len(a.stdout) > 0
+
+
+@pytest.mark.parametrize("shape", ["long", "short_with_a_giant"])
+def test_bpf_writer_paths_for_long_records(movi_bin, tmp_path, shape):
+    """The BPF writer copies records into an 8 MiB buffer and writes payloads of a MiB and more straight from the result
+    array: long records only, and a giant one in the middle of a buffer of short ones -- byte for byte against the oracle
+    (file order)."""
+    from oracle import build_index as B
+    from oracle.oracle import Oracle
+    ref = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))[0][1]
+    rng = np.random.default_rng(77 + len(shape))
+    def piece(L):
+        out = bytearray()
+        while len(out) < L:
+            st = int(rng.integers(0, len(ref) - 1000))
+            out += ref[st: st + min(int(rng.integers(500, 50000)), L - len(out))]
+        for k in rng.integers(0, L, max(1, L // 200)):
+            out[k] = b"ACGTN"[rng.integers(0, 5)]
+        return bytes(out)
+    if shape == "long":
+        lens = [int(x) for x in rng.integers(3000, 30000, 150)] + [700_000, 2100, 5]
+    else:
+        lens = [int(x) for x in rng.integers(1, 300, 30000)]
+        lens[12345] = 600_000                                          # 1.2 MB of PMLs in the middle of a slab
+    reads = [piece(L) for L in lens]
+    path = tmp_path / "reads.fa"
+    path.write_bytes(b"".join(b">r%d some comment\n" % i + r + b"\n" for i, r in enumerate(reads)))
+    prefix = str(tmp_path / "o")
+    r = run(["query", "-i", IDX[6], "-r", str(path), "-n", "-o", prefix])
+    assert r.returncode == 0, r.stderr
+    cpu = Oracle(open(os.path.join(IDX[6], "index.movi"), "rb").read())
+    bases, offs = np.frombuffer(b"".join(reads), np.uint8), np.zeros(len(reads) + 1, np.uint64)
+    np.cumsum([len(x) for x in reads], out=offs[1:])
+    pml, _, _ = cpu.pml_batch(bases, offs, threads=8)
+    exp = bytearray(struct.pack("<IBBBBHxx", 0x42504600, 1, 0, 0, 16, 0))
+    for i, rd in enumerate(reads):
+        rid = b"r%d " % i
+        exp += struct.pack("<H", len(rid)) + rid + struct.pack("<Q", len(rd)) + pml[int(offs[i]): int(offs[i + 1])].astype("<u2").tobytes()
+    assert open(prefix + ".pml.bpf", "rb").read() == bytes(exp)
+    cpu.close()
