@@ -2536,7 +2536,7 @@ hipError_t launch_count(int mode, const DevIndex &ix, const uint8_t *d_bases, co
     const bool ahead = mode == 6 && ix.rows2 != nullptr;   // the search walks on the look-ahead rows where the index has them
     if (info) {
         snprintf(info->kernel, sizeof(info->kernel), "count_kernel_v0<%d, %d>", mode, ahead ? 1 : 0);
-        info->variant = 0; info->block_threads = bt; info->waves_per_cu = wpc; info->segmented = 0; info->idx64 = 1;
+        info->variant = 0; info->block_threads = bt; info->waves_per_cu = wpc; info->segmented = 0; info->idx64 = 1; info->staged = 0;
         info->ahead = ahead ? 1 : 0;
     }
     const uint64_t blocks = (n_reads + bt - 1) / bt;
@@ -3263,7 +3263,7 @@ hipError_t launch_zml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
             const bool sm = ix.r <= (3ull << 30) / 8 && ix.r >= 8 && n_bases >= 16;
             if (sm) snprintf(info->kernel, sizeof(info->kernel), "zml_kernel_flat<%d, %s, 1>", mode, ix.idx32 ? "unsigned int" : "unsigned long");
             else snprintf(info->kernel, sizeof(info->kernel), "zml_kernel<%d, 1>", mode);
-            info->variant = sm ? 1 : 0; info->block_threads = sm ? 64 : 256; info->waves_per_cu = 0; info->segmented = 1;
+            info->variant = sm ? 1 : 0; info->block_threads = sm ? 64 : 256; info->waves_per_cu = 0; info->segmented = 1; info->staged = 0; info->ahead = 0;
             info->idx64 = ix.idx32 ? 0 : 1;
         }
         if (es != hipSuccess || !declined) return es;
@@ -3285,7 +3285,7 @@ hipError_t launch_zml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     if (info) {
         if (v == 1) snprintf(info->kernel, sizeof(info->kernel), "zml_kernel_flat<%d, %s, 0>", mode, ix.idx32 ? "unsigned int" : "unsigned long");
         else snprintf(info->kernel, sizeof(info->kernel), "zml_kernel<%d, 0>", mode);
-        info->variant = v; info->block_threads = bt; info->waves_per_cu = cfg.waves_per_cu > 0 ? cfg.waves_per_cu : 0;
+        info->variant = v; info->block_threads = bt; info->waves_per_cu = cfg.waves_per_cu > 0 ? cfg.waves_per_cu : 0; info->staged = 0; info->ahead = 0;
         info->segmented = 0; info->idx64 = ix.idx32 ? 0 : 1;
     }
     size_t dyn_lds = 0;                                  // occupancy cap by LDS padding, as in launch_pml (<= 64 KiB here)
