@@ -28,6 +28,7 @@ const Spec kSpecs[] = {
     {"device", 0, true},         {"type", 0, true},         {"debug", 'd', false},
     {"logs", 0, false},          {"mmap", 0, false},        {"gen-reads", 0, false},
     {"fasta", 'f', true},          {"separators", 0, false},  {"seg-len", 0, true},
+    {"ahead-rows", 0, true},
     // recognised but unsupported query types / features
     {"zml", 0, false},           {"mem", 0, false},         {"rpml", 0, false},
     {"kmer", 0, false},          {"kmer-count", 0, false},  {"sa-entries", 0, false},
@@ -58,7 +59,7 @@ long to_int(const std::string &name, const std::string &v) {
 std::string usage() {
     return "movi (MI355X engine): movi query -i DIR -r FILE|- [-o PREFIX] [--pml|--zml|--count] [--classify] [--filter [-v]]\n"
            "                      [--stdout] [--no-output] [-s N] [-t N] [-n] [--reverse] [--bin-width N]\n"
-           "                      [--ignore-illegal-chars 1] [--gpus N] [--device D] [--seg-len N] [--verbose]\n"
+           "                      [--ignore-illegal-chars 1] [--gpus N] [--device D] [--seg-len N] [--ahead-rows 0|1|2] [--verbose]\n"
            "       movi view --bpf FILE\n"
            "       movi null -i DIR [--gen-reads -f REF.fasta] [--pml|--zml]\n"
            "       movi build -i DIR -f REF.fasta [--type regular-thresholds|blocked-thresholds|sampled-thresholds|regular|blocked|sampled]\n"
@@ -153,6 +154,10 @@ Options parse_args(int argc, char **argv) {
         if (has("gpus")) { o.gpus = (int)to_int("gpus", val("gpus")); o.gpus_given = true; }
         if (has("device")) o.device = (int)to_int("device", val("device"));
         if (has("seg-len")) o.seg_len = (long)to_int("seg-len", val("seg-len"));
+        if (has("ahead-rows")) {
+            o.ahead_rows = (int)to_int("ahead-rows", val("ahead-rows"));
+            if (o.ahead_rows < 0 || o.ahead_rows > 2) throw UsageError("--ahead-rows must be 0, 1 or 2");
+        }
         if (o.gpus < 1) throw UsageError("--gpus must be >= 1");
         if (o.classify && o.count) throw UsageError("--classify needs PML or ZML queries");
     } else if (o.command == "plan") {
