@@ -180,7 +180,9 @@ int movi_index_device_rows(const movi_index_t *ix, const void **d_rows, size_t *
  * qualifies for the segment-parallel walk ("seg_len" below) makes the call wait for a short probe of the batch
  * (under a millisecond, a 4-byte read-back) before it enqueues the walk.  Callers that capture the stream into a
  * graph or pipeline several streams set "seg_probe" = 2 and state the verdict themselves ("seg_verdict"): nothing
- * is read back then and the call never waits.
+ * is read back then and the call never waits.  The FIRST PML (count) query on a handle also builds the handle's derived
+ * tables -- top-of-walk ("kmer_k") / interval ("ftab_k") table, look-ahead rows ("ahead_rows"): allocations, a few ms of
+ * kernels, a wait -- unless those options were set beforehand: make one warm-up call (or set the options) before capturing.
  * One query call per handle at a time: the counters behind movi_last_stats, the segment workspace and what
  * movi_last_launch reports belong to the handle, so two *_device calls on one handle must not be in flight together
  * even on different streams (the *_host entry points pipeline internally with per-chunk copies of all three). */
