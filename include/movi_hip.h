@@ -330,7 +330,7 @@ int movi_host_unregister(void *p);
  * the worst-case (uniformly random) table -- measured slower -- so there they are built only on request.  1 = build now,
  * 0 = none (freed), 2 = build them as FAT ROWS instead: entry next to its row (16 bytes per row) and a walk window of two
  * rows, i.e. no more loads per step than on the plain rows -- the form for tables beyond the TLBs' reach when the reads
- * follow the text (+8 % over the plain rows on the pangenome at equal loads per step; on the uniformly random 1 B-row
+ * follow the text (+17 % over the plain rows on the pangenome at equal loads per step; on the uniformly random 1 B-row
  * table the narrower window costs what the entries save: -6 %; never built by itself; PML only),
  * "ftab_k" (the count query's interval table -- the backward-search interval after the last K bases of a read by one lookup,
  * the reference's own ftab (src/move_structure_search.cpp:66-167) put to work for --count; left alone the first count query

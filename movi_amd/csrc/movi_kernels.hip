@@ -2014,7 +2014,7 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     const bool ahead_ok = stage_ok && ix.rows2 != nullptr;                            // ... on the look-ahead rows
     const bool fat_ok = stage_ok && ix.rows2 == nullptr && ix.rows3 != nullptr;       // ... or on the fat rows (tables beyond the TLBs' reach)
     if (cfg.waves_per_cu == 0 && (cfg.pml_variant < 0 || cfg.pml_variant == 14) && v == 10 && big_batch)
-        wpc = ahead_ok ? kCapWavesAhead : kCapWaves;                               // the auto policy above
+        wpc = (ahead_ok || fat_ok) ? kCapWavesAhead : kCapWaves;                   // the auto policy above
     if (v == 13) {
         wpc = wpc_refill;
         const uint64_t resident = (refill_blocks * 64u + bt - 1) / bt;
