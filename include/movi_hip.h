@@ -325,7 +325,9 @@ int movi_host_unregister(void *p);
  * what the rows' LF targets look like -- character, length, offset, their own target --, so that a base that matches at the
  * target without a fast-forward is resolved, and its PML emitted, without fetching the target: two bases per gather on
  * real reads (+40 % on the cache-resident pangenome table); the count query walks both ends of its interval on them the
- * same way (+20 %).  Left alone, the first PML or count query builds them for tables of up
+ * same way (+20 %; built by itself, the copy serves the count query only on tables whose positions mostly reach their LF
+ * target without a fast-forward -- the builder tallies it --, which BWTs of real text do and random run sequences do
+ * not).  Left alone, the first PML or count query builds them for tables of up
  * to 100 M rows (a copy of 1.6 GB); beyond that the wider gathers cost more address translations than they save rows on
  * the worst-case (uniformly random) table -- measured slower -- so there they are built only on request.  1 = build now,
  * 0 = none (freed), 2 = build them as FAT ROWS instead: entry next to its row (16 bytes per row) and a walk window of two

@@ -97,6 +97,7 @@ struct movi_index {
     int kmer_auto = 12;              // K of the table the first PML query builds by itself (0 = none: "kmer_k" 0)
     uint8_t *d_rows2 = nullptr;      // look-ahead rows ("ahead_rows" option), 16 bytes per row
     uint8_t *d_rows3 = nullptr;      // ... in the fat-row layout ("ahead_rows" 2)
+    double ahead_no_ff = 0.0;        // share of the table's positions that arrive at their LF target without a fast-forward (build_ahead)
     int ahead_auto = 1;              // 1: the first PML query builds them when the table is small enough (ahead_rows_fit)
     uint4 *d_ftab = nullptr;         // the count query's interval table ("ftab_k" option), 16 << 2K bytes
     int ftab_auto = 12;              // K of the table the first count query builds by itself (0 = none)
@@ -762,14 +763,24 @@ constexpr uint64_t kAheadAutoBytes = 1600ull << 20;      // of the copy: up to 1
 static bool ahead_eligible(const movi_index *ix) {
     return ix->kmode == MOVI_MODE_REGULAR_THRESHOLDS && ix->desc.r >= 8 && (ix->desc.r >> 36) == 0;
 }
-static int build_ahead(movi_index *ix, hipStream_t s) {
+// by_itself: built by the size policy, not on request -- then the count query uses the copy only where the table's own
+// statistic says it pays (DevIndex::rows2_count)
+constexpr double kAheadCountRatio = 0.67;
+static int build_ahead(movi_index *ix, hipStream_t s, bool by_itself) {
     HIP_TRY(hipMalloc(&ix->d_rows2, ahead_rows_bytes(ix->desc.r)));
     uint64_t tail = 0;
-    hipError_t e = build_ahead_rows(ix->kmode, ix->dev, ix->d_rows2, &tail, s);
+    unsigned long long *d_tally = nullptr, h_tally[2] = {0, 0};
+    hipError_t e = hipMalloc(&d_tally, 16);
+    if (e == hipSuccess) e = hipMemsetAsync(d_tally, 0, 16, s);
+    if (e == hipSuccess) e = build_ahead_rows(ix->kmode, ix->dev, ix->d_rows2, &tail, s, d_tally);
+    if (e == hipSuccess) e = hipMemcpyAsync(h_tally, d_tally, 16, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (d_tally) (void)hipFree(d_tally);
     if (e != hipSuccess) { (void)hipFree(ix->d_rows2); ix->d_rows2 = nullptr; return fail_hip(e, "building the look-ahead rows"); }
     ix->dev.rows2 = ix->d_rows2;
     ix->dev.rows2_tail = tail;
+    ix->ahead_no_ff = h_tally[1] ? (double)h_tally[0] / (double)h_tally[1] : 0.0;
+    ix->dev.rows2_count = (!by_itself || ix->ahead_no_ff >= kAheadCountRatio) ? 1u : 0u;
     return MOVI_OK;
 }
 
@@ -903,6 +914,7 @@ int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
         HIP_TRY(hipDeviceSynchronize());                     // no walk may be reading the copy that goes away
         ix->dev.rows2 = nullptr;
         ix->dev.rows2_tail = 0;
+        ix->dev.rows2_count = 0;
         ix->dev.rows3 = nullptr;
         if (ix->d_rows2) (void)hipFree(ix->d_rows2);
         if (ix->d_rows3) (void)hipFree(ix->d_rows3);
@@ -911,7 +923,7 @@ int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
         ix->ahead_auto = 0;                                  // the caller's choice from here on
         if (value == 0) return MOVI_OK;
         if (!ahead_eligible(ix)) return fail(MOVI_ERR_ARG, "look-ahead rows serve PML walks on *-thresholds indexes only");
-        return value == 1 ? build_ahead(ix, nullptr) : build_fat(ix, nullptr);
+        return value == 1 ? build_ahead(ix, nullptr, false) : build_fat(ix, nullptr);
     }
     if (!strcmp(key, "ftab_k")) {                            // count query's interval table: 0 = none, K in [1, 12] = build it now
         if (value < 0 || value > 12) return fail(MOVI_ERR_ARG, "ftab_k must be in [0, 12]");
@@ -963,7 +975,7 @@ static int ml_device(bool zml, movi_index_t *ix, const uint8_t *d_bases, const u
     }
     if (!zml && ix->ahead_auto > 0 && !ix->d_rows2 && ahead_eligible(ix) && cls.log_ff == nullptr &&
         ahead_rows_bytes(ix->desc.r) <= kAheadAutoBytes) {
-        if (build_ahead(ix, s) != MOVI_OK) {
+        if (build_ahead(ix, s, true) != MOVI_OK) {
             (void)hipGetLastError();
             ix->ahead_auto = 0;
         }
@@ -1663,7 +1675,7 @@ static int count_device(movi_index_t *ix, const uint8_t *d_bases, const uint64_t
         if (build_ftab_table(ix, (uint32_t)ix->ftab_auto, s) != MOVI_OK) { (void)hipGetLastError(); ix->ftab_auto = 0; }
     }
     if (ix->ahead_auto > 0 && !ix->d_rows2 && ahead_eligible(ix) && ahead_rows_bytes(ix->desc.r) <= kAheadAutoBytes) {
-        if (build_ahead(ix, s) != MOVI_OK) { (void)hipGetLastError(); ix->ahead_auto = 0; }   // ... and the look-ahead rows (as a PML query does)
+        if (build_ahead(ix, s, true) != MOVI_OK) { (void)hipGetLastError(); ix->ahead_auto = 0; }   // ... and the look-ahead rows (as a PML query does)
     }
     HIP_TRY(hipMemsetAsync(d_stats, 0, sizeof(DevStats), s));
     if (n_reads > 0xFFFFFFFFull) return fail(MOVI_ERR_ARG, "more than 2^32 reads in one call");

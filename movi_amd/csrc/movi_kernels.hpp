@@ -65,6 +65,12 @@ struct DevIndex {
     // j2[35:32] << 25 | valid << 31.  valid = 0 when j or j2 is not a row (corrupt table): such steps are taken one by one.
     const uint8_t *rows2;
     uint64_t rows2_tail;
+    // 1: the count query walks on them too.  It gains where walks that follow the text mostly arrive at their LF target
+    // without a fast-forward (pangenome BWTs: 0.83 of the positions, +20 %) and loses where they do not (uniformly random
+    // run sequences: 0.51, -12 %: the copy's lines hold half as many rows for the interval shrink) -- decided from that
+    // ratio, which the builder tallies, when the copy is built by itself; a caller who asks for the copy gets it for both.
+    uint32_t rows2_count;
+    uint32_t pad3_;
     // Fat rows ("ahead_rows" 2; nullptr = none): the same entries for tables beyond the TLBs' reach, where a step must not
     // cost more loads than it does on the plain rows -- row i and its entry are the 16 bytes at 16 i, and the walk's window is
     // the aligned PAIR of rows with their entries: 32 bytes, two loads, like the plain 4-row window.
@@ -219,7 +225,8 @@ hipError_t build_kmer_table(const DevIndex &ix, uint32_t K, uint4 *d_table, hipS
 // Look-ahead rows (DevIndex::rows2): ahead_rows_bytes(r) bytes at d_rows2, written by one kernel (a gather of id(id(i))
 // per row); *tail = DevIndex::rows2_tail.  Thresholds types (kmode 6: the PML walk's rows), r >= 8.
 uint64_t ahead_rows_bytes(uint64_t r);
-hipError_t build_ahead_rows(int kmode, const DevIndex &ix, uint8_t *d_rows2, uint64_t *tail, hipStream_t stream);
+hipError_t build_ahead_rows(int kmode, const DevIndex &ix, uint8_t *d_rows2, uint64_t *tail, hipStream_t stream,
+                            unsigned long long *d_tally = nullptr);   // d_tally: 2 zeroed counters (ahead_rows_kernel), optional
 hipError_t build_fat_rows(int kmode, const DevIndex &ix, uint8_t *d_rows3, hipStream_t stream);   // DevIndex::rows3: 16 r bytes
 
 // Fills the 4^K entries of the count query's interval table (DevIndex::ftab); mode = resident layout (6 or 3).
