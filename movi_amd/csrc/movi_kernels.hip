@@ -2537,14 +2537,15 @@ hipError_t launch_count(int mode, const DevIndex &ix, const uint8_t *d_bases, co
     // table 52.4 -> 54.6; HBM-resident tables lose with any cap (1.6 GB: 47.3 uncapped, 43.2 at 16) or are indifferent (8 GB).
     const int bt = cfg.block_threads > 0 ? cfg.block_threads : 64;
     int wpc = cfg.waves_per_cu > 0 ? cfg.waves_per_cu : 0;
-    if (cfg.waves_per_cu == 0 && ix.r * 8ull <= (256ull << 20) && n_reads > (uint64_t)cfg.num_cus * 64ull * 24ull) wpc = kCountCapWaves;
+    const bool ahead = mode == 6 && ix.rows2 != nullptr && ix.rows2_count != 0u;   // the search walks on the look-ahead rows where they pay
+    if (cfg.waves_per_cu == 0 && ix.r * (ahead ? 16ull : 8ull) <= (256ull << 20) &&   // (the bytes of the table the search walks on)
+        n_reads > (uint64_t)cfg.num_cus * 64ull * 24ull) wpc = kCountCapWaves;
     size_t dyn_lds = 0;
     if (wpc > 0) {
         int bpc = wpc / (bt / 64);
         if (bpc < 1) bpc = 1;
         if (bpc < 32) dyn_lds = std::min<size_t>(65536 - 1024, ((163840u / (unsigned)bpc) & ~1023u) - 1024u);
     }
-    const bool ahead = mode == 6 && ix.rows2 != nullptr && ix.rows2_count != 0u;   // the search walks on the look-ahead rows where they pay
     if (info) {
         snprintf(info->kernel, sizeof(info->kernel), "count_kernel_v0<%d, %d>", mode, ahead ? 1 : 0);
         info->variant = 0; info->block_threads = bt; info->waves_per_cu = wpc; info->segmented = 0; info->idx64 = 1; info->staged = 0;
