@@ -76,6 +76,9 @@ def ensure_pangenome(wl, world, rank, barrier):
             os.rename(tmp, idx_dir)
             open(os.path.join(idx_dir, ".done"), "w").close()
         if not os.path.exists(reads_file):
+            if not os.path.exists(os.path.join(idx_dir, "text.bin")):      # a cache that travelled without its text (seconds to redo)
+                subprocess.check_call([tool, "pangenome", str(PG["anc"]), str(PG["genomes"]), str(PG["snp"]), str(PG["seed"]),
+                                       str(wl["mode"]), idx_dir, "text-only"], stderr=subprocess.DEVNULL)
             subprocess.check_call([tool, "reads", os.path.join(idx_dir, "text.bin"), str(wl["reads"] * world),
                                    str(wl["read_len"]), str(wl["sub"]), str(PG["seed"]), reads_file + ".tmp"])
             os.rename(reads_file + ".tmp", reads_file)
@@ -331,6 +334,8 @@ def main():
     ap.add_argument("--stage-reads", type=int, default=-1, help="reads staged through LDS for short-read wavefronts (A/B: 0 off, 1 on; -1 = default)")
     ap.add_argument("--ahead-rows", type=int, default=-1, help="look-ahead rows: the table's second copy that resolves two bases per gather (A/B: 0 off, 1 on; -1 = the engine's default: on for tables whose copy fits the Infinity Cache)")
     ap.add_argument("--block-threads", type=int, default=0)
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
+                    help="movi_set_option(KEY, VALUE) on the handle before the timed region (A/B sweeps; repeatable)")
     ap.add_argument("--waves-per-cu", type=int, default=-1)
     ap.add_argument("--ragged", type=int, default=0, help="1: log-normal read lengths (mean = read_len); "
                     "2: same, lanes handed out longest-first (d_read_order)")
@@ -472,6 +477,9 @@ def main():
         index.set_option("block_threads", args.block_threads)
     if args.waves_per_cu >= 0:
         index.set_option("waves_per_cu", args.waves_per_cu)
+    for kv in args.opt:
+        key, _, val = kv.partition("=")
+        index.set_option(key, int(val))
     t_index_upload = time.time() - t0
 
     # ---- reads: each rank draws its own shard (seed + rank)

@@ -230,7 +230,7 @@ typedef struct movi_launch_info {
     int32_t idx64;                    /* 1 = the 64-bit row-index instantiation                                     */
     int32_t staged;                   /* > 0: every lane keeps the next `staged` bases of its read in LDS ("stage_reads";
                                          336 at the default occupancy cap, 256 on the look-ahead rows); 0: no staging */
-    int32_t ahead;                    /* 1 = the walk ran on the look-ahead rows ("ahead_rows"), 2 = on the fat rows   */
+    int32_t ahead;                    /* 1 = the walk ran on the look-ahead rows ("ahead_rows"), 2 = on the chain rows */
     int32_t reserved_;
 } movi_launch_info_t;
 int movi_last_launch(const movi_index_t *ix, movi_launch_info_t *info);
@@ -330,10 +330,15 @@ int movi_host_unregister(void *p);
  * not).  Left alone, the first PML or count query builds them for tables of up
  * to 100 M rows (a copy of 1.6 GB); beyond that the wider gathers cost more address translations than they save rows on
  * the worst-case (uniformly random) table -- measured slower -- so there they are built only on request.  1 = build now,
- * 0 = none (freed), 2 = build them as FAT ROWS instead: entry next to its row (16 bytes per row) and a walk window of two
- * rows, i.e. no more loads per step than on the plain rows -- the form for tables beyond the TLBs' reach when the reads
- * follow the text (+17 % over the plain rows on the pangenome at equal loads per step; on the uniformly random 1 B-row
- * table the narrower window costs what the entries save: -6 %; never built by itself; PML only),
+ * 0 = none (freed), 2 = build CHAIN ROWS instead: entries that reach two rows ahead (16 bytes per row, one 128-byte line per
+ * 4-row window) -- up to three bases per gather; PML only.  Bit-exact like the others; it cuts the lane iterations per base by a
+ * fifth on the pangenome (0.65 -> 0.52) and still runs 10 % SLOWER there (twice the table -- 450 MB, out of the Infinity Cache
+ * -- and six 16-byte loads per step: profiles/r04_chain_rows.txt), so it is never built by itself),
+ * "pml_variant" 13 (lane refill: the default walk as a persistent grid whose idle lanes take the next reads of a pool fed from
+ * one global ticket counter, "refill_batch" lanes at a time (default 16): 82 - 87 % of the lane iterations do work instead of
+ * 72 %, at the same speed -- the walk is bound by the fabric's line rate, not by its lanes -- so it is selectable, not the
+ * default), "inwin_repo" (1, the default: a reposition whose target run is one of the row window's other rows is resolved in
+ * the iteration that sees the mismatch; 0 = off: A/B),
  * "ftab_k" (the count query's interval table -- the backward-search interval after the last K bases of a read by one lookup,
  * the reference's own ftab (src/move_structure_search.cpp:66-167) put to work for --count; left alone the first count query
  * on a DNA index builds the K = 12 table (256 MB); 0 = none, 1..12 = build that one now). */

@@ -116,7 +116,8 @@ SYMBOLS = {
 
 
 def lib_path():
-    return os.path.join(_HERE, "lib", "libmovi_hip.so")
+    # MOVI_HIP_LIB: another build of the same C-ABI (A/B measurements against an earlier round's library)
+    return os.environ.get("MOVI_HIP_LIB") or os.path.join(_HERE, "lib", "libmovi_hip.so")
 
 
 _lib = None

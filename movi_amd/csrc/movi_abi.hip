@@ -96,7 +96,7 @@ struct movi_index {
     uint4 *d_kmer = nullptr;         // top-of-walk table ("kmer_k" option), 16 << 2K bytes
     int kmer_auto = 12;              // K of the table the first PML query builds by itself (0 = none: "kmer_k" 0)
     uint8_t *d_rows2 = nullptr;      // look-ahead rows ("ahead_rows" option), 16 bytes per row
-    uint8_t *d_rows3 = nullptr;      // ... in the fat-row layout ("ahead_rows" 2)
+    uint8_t *d_rows3 = nullptr;      // chain rows: entries that look two rows ahead ("ahead_rows" 2)
     double ahead_no_ff = 0.0;        // share of the table's positions that arrive at their LF target without a fast-forward (build_ahead)
     int ahead_auto = 1;              // 1: the first PML query builds them when the table is small enough (ahead_rows_fit)
     uint4 *d_ftab = nullptr;         // the count query's interval table ("ftab_k" option), 16 << 2K bytes
@@ -784,12 +784,14 @@ static int build_ahead(movi_index *ix, hipStream_t s, bool by_itself) {
     return MOVI_OK;
 }
 
-static int build_fat(movi_index *ix, hipStream_t s) {
-    HIP_TRY(hipMalloc(&ix->d_rows3, (size_t)ix->desc.r * 16));
-    hipError_t e = build_fat_rows(ix->kmode, ix->dev, ix->d_rows3, s);
+static int build_chain(movi_index *ix, hipStream_t s) {
+    HIP_TRY(hipMalloc(&ix->d_rows3, chain_rows_bytes(ix->desc.r)));
+    uint64_t tail = 0;
+    hipError_t e = build_chain_rows(ix->kmode, ix->dev, ix->d_rows3, &tail, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (e != hipSuccess) { (void)hipFree(ix->d_rows3); ix->d_rows3 = nullptr; return fail_hip(e, "building the fat rows"); }
+    if (e != hipSuccess) { (void)hipFree(ix->d_rows3); ix->d_rows3 = nullptr; return fail_hip(e, "building the chain rows"); }
     ix->dev.rows3 = ix->d_rows3;
+    ix->dev.rows3_tail = tail;
     return MOVI_OK;
 }
 
@@ -858,6 +860,16 @@ int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
         ix->cfg.refill_blocks = (int)value;
         return MOVI_OK;
     }
+    if (!strcmp(key, "refill_batch")) {                      // tuning: idle lanes of a lane-refill wavefront switch when this many wait
+        if (value < 0 || value > 64) return fail(MOVI_ERR_ARG, "refill_batch must be in [0, 64]");
+        ix->cfg.refill_batch = (int)value;
+        return MOVI_OK;
+    }
+    if (!strcmp(key, "inwin_repo")) {                        // A/B: repositions inside the row window resolved in the same iteration
+        if (value != 0 && value != 1) return fail(MOVI_ERR_ARG, "inwin_repo must be 0 or 1");
+        ix->cfg.inwin = (int)value;
+        return MOVI_OK;
+    }
     if (!strcmp(key, "release_scratch")) {                   // give back the device staging the *_host entry points keep
         (void)hipSetDevice(ix->device);
         release_scratch(ix);
@@ -908,7 +920,7 @@ int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
             return fail(MOVI_ERR_ARG, "the top-of-walk table serves PML walks on DNA (ACGT) *-thresholds indexes only");
         return build_kmer(ix, (uint32_t)value, nullptr);
     }
-    if (!strcmp(key, "ahead_rows")) {                        // look-ahead rows: 0 = none (freed), 1 = build them now, 2 = as fat rows
+    if (!strcmp(key, "ahead_rows")) {                        // look-ahead rows: 0 = none (freed), 1 = build them now, 2 = chain rows (entries two rows deep)
         if (value < 0 || value > 2) return fail(MOVI_ERR_ARG, "ahead_rows must be 0, 1 or 2");
         HIP_TRY(hipSetDevice(ix->device));
         HIP_TRY(hipDeviceSynchronize());                     // no walk may be reading the copy that goes away
@@ -916,6 +928,7 @@ int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
         ix->dev.rows2_tail = 0;
         ix->dev.rows2_count = 0;
         ix->dev.rows3 = nullptr;
+        ix->dev.rows3_tail = 0;
         if (ix->d_rows2) (void)hipFree(ix->d_rows2);
         if (ix->d_rows3) (void)hipFree(ix->d_rows3);
         ix->d_rows2 = nullptr;
@@ -923,7 +936,7 @@ int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
         ix->ahead_auto = 0;                                  // the caller's choice from here on
         if (value == 0) return MOVI_OK;
         if (!ahead_eligible(ix)) return fail(MOVI_ERR_ARG, "look-ahead rows serve PML walks on *-thresholds indexes only");
-        return value == 1 ? build_ahead(ix, nullptr, false) : build_fat(ix, nullptr);
+        return value == 1 ? build_ahead(ix, nullptr, false) : build_chain(ix, nullptr);
     }
     if (!strcmp(key, "ftab_k")) {                            // count query's interval table: 0 = none, K in [1, 12] = build it now
         if (value < 0 || value > 12) return fail(MOVI_ERR_ARG, "ftab_k must be in [0, 12]");

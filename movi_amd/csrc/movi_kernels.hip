@@ -735,24 +735,20 @@ __device__ __forceinline__ uint2 win_sel(const uint2 (&w)[4], uint32_t q) {
 // Measured (100 k x 10 kbp, Gbases/s, pangenome / random table): unpipelined window kernel (variant 8, removed)
 // 36.4 / 33.6; chunk double-buffering alone 35.1 / 32.4; pipelined HA = 1 / 2 / 3: 40.2 / 39.6 / 38.9 (pangenome),
 // 36.3 / 36.6 / 36.2 (random) -> HA = 2 shipped.  Hops after the step (HC > 0) measured slower and are gone.
-// REFILL = 1 ("lane refill", variant 13, the default whenever there are more reads than resident lanes): the same
-// automaton as a PERSISTENT grid of num_cus x waves_per_cu wavefronts whose lanes take a new read the moment they
-// finish one.  Without it a wavefront runs until its slowest lane is done: on 1 M x 150 bp only 80 % of the lane
-// iterations did work (reads differ in fast-forward / scan iterations), on log-normal read lengths 43 %.
-//   * Tickets are wave-local and need no atomics: wave v's t-th read is rid_of(t) -- chunks of 16 consecutive reads
-//     dealt round-robin to the waves -- so a refill is integer arithmetic on a wave-uniform counter (ballot + mbcnt).
-//     Across waves the split is static (each wave walks ~n_reads / n_waves reads, so length differences average out);
-//     inside a wave it is dynamic.  The launcher sizes the grid so that all of it is resident.
-//   * A refill never waits on memory and never makes the compiler wait: when a lane starts read X it also takes the
-//     ticket of its next read and issues the loads of that read's offsets, which are looked at only when X ends.  The
-//     switch is register moves in the bookkeeping half of the iteration in which X ends, under the gather's latency; it
-//     issues the loads of the new read's first 32 bases and parks the lane in `sLoad` for ONE iteration (the bases
-//     land with that iteration's row window, which for a parked lane is the window of row r-1, where every read
-//     starts).  Prefetching those bases as well (so that the lane loses no iteration at all) was tried first: two
-//     blocks that each load into registers the other one reads made hipcc put `s_waitcnt vmcnt(0)` into both --
-//     right behind the row gather -- and the kernel ran 6 % SLOWER than variant 10 despite 92 % instead of 80 %
-//     busy lanes; one parked iteration in ~190 is the cheaper price.
-//   * Results of a read (error byte, bins, zero-fill on failure) are written when it ends, not after the loop.
+// REFILL = 1 ("lane refill", variant 13; staged kernels only): the same automaton as a PERSISTENT grid of
+// num_cus x waves_per_cu wavefronts whose lanes take a new read when they have finished one.  Without it a wavefront runs
+// until its slowest lane is done, and reads differ a lot: a substitution costs a read about a dozen repositions (the walk
+// needs ~15 bases to fall back into step with the text), so on 1 M x 150 bp with 1 % substitutions only 68 % of the lane
+// iterations do work on the look-ahead rows and 61 % on the chain rows (tools/iter_model.c predicts both figures).
+//   * Tickets are wave-local and need no atomics: wave v's t-th read is rid_of(t) -- chunks of 16 consecutive reads dealt
+//     round-robin to the waves -- so a refill is integer arithmetic on a wave-uniform counter (ballot + mbcnt).  Across
+//     waves the split is static (each wave walks ~n_reads / n_waves reads, so length differences average out); inside a
+//     wave it is dynamic.  The launcher sizes the grid so that all of it is resident.
+//   * Refills come in BATCHES: a switch stages the new read's bases into the lane's LDS stretch and takes its first K
+//     bases from the top-of-walk table -- two memory round trips in which the whole wavefront stands still -- so idle lanes
+//     wait until DevIndex::refill_batch of them (or every lane that still has work) can switch together.  The offsets of
+//     a lane's next read are fetched when it starts the read before, i.e. they are there long before the switch.
+//   * Results of a read (error byte, bins, zero-fill on failure) are written when its lane switches (or at the end).
 // `order` is not supported (longest-first ordering is what refill replaces).
 // SEG (segment-parallel long reads, movi_kernels.hpp): 0 = a lane walks a read; 1 = a lane walks one SEGMENT of a read
 // from the state every read starts in (K1: its "read" is the segment -- bases at seg_in, PMLs to seg_out --, it leaves a
@@ -767,6 +763,10 @@ __device__ __forceinline__ uint2 win_sel(const uint2 (&w)[4], uint32_t q) {
 // mismatch, a fast-forward at j, the read's end, an invalid entry) takes the one-base step it always took.
 // (Fetching only the entry of the row the window was fetched FOR -- 8 bytes instead of 32 -- misses the steps that end on a
 // neighbour after a fast-forward or scan: 68.5 against 74.4 Gbases/s on c2, 54.1 against 62.8 on the random table.)
+// AHD = 2 (chain rows, DevIndex::rows3): the same with entries that look TWO rows ahead -- 16 bytes per row: what the walk
+// would read at j = id(row) and at j2 = id(j), and where it goes from there (j3 = id(j2)) -- so that up to THREE bases are
+// resolved per gather while the read follows the text (tools/iter_model.c: lane iterations per base 0.68 -> 0.56 on c2).
+// Line = the 4 rows of an aligned window (32 bytes) + their 4 entries (64 bytes): six 16-byte loads of ONE 128-byte line.
 template <int MODE, typename IdxT, int HA, int CLS, int SEP, int REFILL, int SEG = 0, int STG = 0, int AHD = 0>
 __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8_t *__restrict__ bases,
                                                        const uint64_t *__restrict__ offs, uint64_t n_reads,
@@ -774,9 +774,9 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
                                                        DevStats *stats, const uint32_t *__restrict__ order,
                                                        ClsArgs cls, SegArgs seg) {
     static_assert(SEG == 0 || (CLS == 0 && REFILL == 0), "segments: plain PML, no refill");
-    static_assert(STG == 0 || REFILL == 0, "reads staged through LDS: no lane refill");
+    static_assert(REFILL == 0 || (STG == 1 && HA < 0), "lane refill: staged reads, window-parallel advance");
     static_assert(AHD == 0 || (STG == 1 && HA < 0), "look-ahead rows: staged reads, window-parallel advance");
-    enum : uint32_t { sFF = 0, sDown = 1, sUp = 2, sDone = 3, sLoad = 4 };   // sLoad (REFILL): first bases of a new read in flight
+    enum : uint32_t { sFF = 0, sDown = 1, sUp = 2, sDone = 3 };
     __shared__ uint8_t s_code[256];
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = ix.code_of[i];
     __syncthreads();
@@ -825,23 +825,30 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
     // The 4-row window that holds row nd: aligned, except that the table's last window is pulled back to
     // rows [r-4, r) so that the fetch never leaves the table and needs no special case (r >= 4, checked at
     // launch).  Unpredicated: finished lanes re-read window 0 (a cache hit) instead of branching around the load.
-    // (AHD == 2, fat rows: the window is the aligned PAIR of rows around the row it needs, with their two entries -- the same
-    // 32 bytes and two loads as the plain 4-row window; the table's last window is rows [r-2, r))
-    constexpr uint32_t WN = AHD == 2 ? 2u : 4u;           // rows per window
+    constexpr uint32_t WN = 4u;                           // rows per window
     const IdxT wb_last = (IdxT)(ix.r - WN);
     auto win_base = [&](IdxT nd) -> IdxT {
         const IdxT wb = nd & ~(IdxT)(WN - 1u);
         return wb < wb_last ? wb : wb_last;
     };
-    uint2 ahw[4];                                         // AHD: the look-ahead entries of the window's four rows
+    uint2 ahw[4];                                         // AHD: the look-ahead entries of the window's four rows ...
+    uint2 ahv[4];                                         // ... AHD == 2: and their second halves (the row after the next)
     auto fetch = [&](IdxT nd, bool act, uint2 (&w)[4]) {
-        if (AHD == 2) {                                   // fat rows: row i and its entry are the 16 bytes at 16 i
-            uint4 p0, p1;
-            const uint8_t *at = ix.rows3 + (uint64_t)(act ? win_base(nd) : (IdxT)0) * 16u;
-            __builtin_memcpy(&p0, at, 16);
-            __builtin_memcpy(&p1, at + 16, 16);
-            w[0] = make_uint2(p0.x, p0.y); ahw[0] = make_uint2(p0.z, p0.w);
-            w[1] = make_uint2(p1.x, p1.y); ahw[1] = make_uint2(p1.z, p1.w);
+        if (AHD == 2) {                                   // chain rows: line = the window's 4 rows + their 4 16-byte entries
+            const IdxT wb = nd & ~(IdxT)3;
+            const bool body = wb < wb_last;
+            uint64_t at = body ? (uint64_t)(wb >> 2) * 128u : ix.rows3_tail;
+            if (!act) at = 0;
+            load_window<MODE>(ix.rows3 + at, 0, w);
+            uint4 e0, e1, e2, e3;
+            __builtin_memcpy(&e0, ix.rows3 + at + 32u, 16);
+            __builtin_memcpy(&e1, ix.rows3 + at + 48u, 16);
+            __builtin_memcpy(&e2, ix.rows3 + at + 64u, 16);
+            __builtin_memcpy(&e3, ix.rows3 + at + 80u, 16);
+            ahw[0] = make_uint2(e0.x, e0.y); ahv[0] = make_uint2(e0.z, e0.w);
+            ahw[1] = make_uint2(e1.x, e1.y); ahv[1] = make_uint2(e1.z, e1.w);
+            ahw[2] = make_uint2(e2.x, e2.y); ahv[2] = make_uint2(e2.z, e2.w);
+            ahw[3] = make_uint2(e3.x, e3.y); ahv[3] = make_uint2(e3.z, e3.w);
         } else if (AHD) {                                 // line = 8 rows + their 8 entries; the last window has a line of its own
             const IdxT wb = nd & ~(IdxT)3;
             const bool body = wb < wb_last;
@@ -897,25 +904,39 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
     extern __shared__ __align__(16) uint8_t s_stage[];
     uint32_t kbase = 0;
     const uint32_t stage_cap = ix.stage_lds;
-    auto stage_from = [&](uint32_t k0, bool on) {         // every lane of the wavefront makes the call
+    // (the loads of kStageUnroll groups leave together -- unconditional, lanes without the group re-read the batch's first
+    // bytes -- before the first of them is waited for.  Two at a time: c2 74.6 -> 75.0, c3 54.8 -> 54.9 Gbases/s; four or
+    // eight in flight cost c3 11 % (48.9: profiles/r04_stage_unroll.txt) although the loop then makes a quarter of the trips)
+#ifndef MOVI_STAGE_UNROLL
+#define MOVI_STAGE_UNROLL 2
+#endif
+    constexpr uint32_t kStageUnroll = MOVI_STAGE_UNROLL;
+    auto stage_from = [&](uint32_t k0, bool on) {         // every lane of the wavefront makes the call; lanes with `on` stage
         uint32_t *S = reinterpret_cast<uint32_t *>(s_stage);
         const uint32_t sl = threadIdx.x & 63u;
         const uint32_t left = (on && len > k0) ? len - k0 : 0u;
         const uint32_t cnt = left < stage_cap ? left : stage_cap;
-        for (uint32_t g = 0; wave_any(16u * g < cnt); ++g) {
-            if (16u * g < cnt) {
-                const uint64_t e = beg + len - k0 - 16u * g;
-                uint64_t c0, c1;
-                load_pair_at(e, c0, c1);
-                fix_pair(e, c0, c1);
-                const uint64_t r0 = __builtin_bswap64(c0), r1 = __builtin_bswap64(c1);   // step k0 + 16 g in the low byte
-                S[(4u * g + 0u) * 64u + sl] = (uint32_t)r0;
-                S[(4u * g + 1u) * 64u + sl] = (uint32_t)(r0 >> 32);
-                S[(4u * g + 2u) * 64u + sl] = (uint32_t)r1;
-                S[(4u * g + 3u) * 64u + sl] = (uint32_t)(r1 >> 32);
+        for (uint32_t g = 0; wave_any(16u * g < cnt); g += kStageUnroll) {
+            uint64_t c0[kStageUnroll], c1[kStageUnroll];
+#pragma unroll
+            for (uint32_t u = 0; u < kStageUnroll; ++u) {
+                const uint64_t e = 16u * (g + u) < cnt ? beg + len - k0 - 16u * (g + u) : 16u;
+                load_pair_at(e, c0[u], c1[u]);
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < kStageUnroll; ++u) {
+                if (16u * (g + u) < cnt) {
+                    const uint64_t e = beg + len - k0 - 16u * (g + u);
+                    fix_pair(e, c0[u], c1[u]);
+                    const uint64_t r0 = __builtin_bswap64(c0[u]), r1 = __builtin_bswap64(c1[u]);   // step k0 + 16 (g + u) in the low byte
+                    S[(4u * (g + u) + 0u) * 64u + sl] = (uint32_t)r0;
+                    S[(4u * (g + u) + 1u) * 64u + sl] = (uint32_t)(r0 >> 32);
+                    S[(4u * (g + u) + 2u) * 64u + sl] = (uint32_t)r1;
+                    S[(4u * (g + u) + 3u) * 64u + sl] = (uint32_t)(r1 >> 32);
+                }
             }
         }
-        kbase = k0;
+        if (on) kbase = k0;
     };
     auto staged_code = [&](uint32_t slot) -> uint32_t {   // code of the base in `slot` (clamped into the staged stretch)
         const uint32_t q = slot < stage_cap ? slot : stage_cap - 1u;
@@ -924,19 +945,12 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
     if (STG) stage_from(0u, st != sDone);
     // ---- top of the walk (DevIndex::kmer): the first K bases of the read (segment) by ONE table lookup.  Reads with an
     // illegal base among them, reads of K bases or fewer and K-mers whose walk throws take the ordinary walk.
-    if (!REFILL && ix.kmer_k != 0u) {                     // wave-uniform
+    // cand: lanes whose K-mer `kidx` is to be looked up (k == 0 there); returns the lanes that took the entry.
+    auto top_of_walk = [&](uint32_t cand, uint32_t kidx) -> uint32_t {
         const uint32_t K = ix.kmer_k;
-        uint32_t kidx = 0, bad = 0;
-        for (uint32_t i = 0; i < K; ++i) {
-            const uint64_t src = i < 8u ? rb : rb2;
-            const uint32_t cc = (uint32_t)s_code[(uint32_t)(src >> (8u * (7u - (i & 7u)))) & 0xFFu] - (uint32_t)SEP;
-            bad |= (uint32_t)(cc > 3u);
-            kidx |= (cc & 3u) << (2u * i);
-        }
-        uint32_t use = (uint32_t)(st != sDone) & (uint32_t)(len > K) & (bad ^ 1u);
         uint4 e4 = make_uint4(0, 0, 0, 0);
-        if (use) e4 = ix.kmer[kidx];
-        use &= e4.y >> 31;
+        if (cand) e4 = ix.kmer[kidx];
+        const uint32_t use = cand & (e4.y >> 31);
         if (use) {
             const uint32_t mask = (e4.y >> 16) & 0xFFFu;
             uint16_t *O = out + obeg;
@@ -962,41 +976,145 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
             ml = run;
             need = (IdxT)((uint64_t)e4.x | ((uint64_t)(e4.y & 15u) << 32));
             off = (e4.y >> 4) & 0xFFFu;
-            ff_total = e4.z;
-            scan_total = e4.w;
-            repo_total = K - (uint32_t)__popc(mask);
+            ff_total += e4.z;
+            scan_total += e4.w;
+            repo_total += K - (uint32_t)__popc(mask);
+        }
+        return use;
+    };
+    if (!REFILL && ix.kmer_k != 0u) {                     // wave-uniform
+        const uint32_t K = ix.kmer_k;
+        uint32_t kidx = 0, bad = 0;
+        for (uint32_t i = 0; i < K; ++i) {
+            const uint64_t src = i < 8u ? rb : rb2;
+            const uint32_t cc = (uint32_t)s_code[(uint32_t)(src >> (8u * (7u - (i & 7u)))) & 0xFFu] - (uint32_t)SEP;
+            bad |= (uint32_t)(cc > 3u);
+            kidx |= (cc & 3u) << (2u * i);
+        }
+        if (top_of_walk((uint32_t)(st != sDone) & (uint32_t)(len > K) & (bad ^ 1u), kidx)) {
             if (K >= 8u) rb = rb2;
             a = s_code[(uint32_t)(rb >> (8u * (7u - (K & 7u)))) & 0xFFu];
         }
     }
     // AHD: the code of the base after the current one (beyond the read's end: never looked at)
-    uint32_t a1 = 0xFFu;
+    uint32_t a1 = 0xFFu, a2 = 0xFFu;
     if (AHD) a1 = staged_code(k + 1);
+    if (AHD == 2) a2 = staged_code(k + 2);
     uint2 w[4];
     fetch(need, st != sDone, w);
 
-    // ---- lane refill: wave-local tickets and the prefetched next read
+    // ---- lane refill (REFILL): a POOL of upcoming reads per wavefront, fed in chunks of 16 consecutive reads from one global
+    // ticket counter (DevStats::ticket, zeroed with the counters): pool slot `lane` holds a read's number, where its bases
+    // start and its length; slots are consumed in ring order by whichever lanes are idle when the wavefront switches.  A chunk
+    // takes two switches to arrive -- the ticket is drawn (one atomic) at one switch, the chunk's offsets are requested at the
+    // next and merged into the pool at the one after -- so nothing about the pool ever waits on memory by itself.
     const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t wave = t >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    auto rid_of = [&](uint32_t tk) -> uint64_t {
-        return (uint64_t)(tk >> 4) * (n_waves << 4) + (wave << 4) + (uint64_t)(tk & 15u);
+    uint32_t cur_valid = 0;
+    uint64_t P_beg = 0, N_beg = 0;                        // pool slot / chunk in flight: byte offset of the read's bases ...
+    uint32_t P_len = 0, P_rid = 0, N_end = 0;             // ... its length and number (in flight: low half of the next offset)
+    uint32_t p_head = 0, p_count = 0;                     // ring of 64 slots (wave-uniform)
+    uint32_t ld_on = 0, tk_on = 0, no_more = 0;           // a chunk's offsets in flight / a ticket in flight / the counter ran past n_reads
+    uint64_t ld_base = 0;
+    unsigned long long T = 0;                             // lane 0: the ticket drawn
+    auto draw_ticket = [&]() {
+        if (lane == 0u) T = atomicAdd(&stats->ticket, 16ull);
+        tk_on = 1;
     };
-    uint32_t tnext = 64, has_next = 0, nend_lo = 0;
-    uint64_t rid_n = 0, nbeg = 0;
-    // the offsets of the lane's next read: an 8-byte and a 4-byte load (reads are shorter than 2^32), NOT one 16-byte
-    // load -- hipcc reused the dead top dword of that tuple for another variable and waited for the load to do so
-    auto load_next_offsets = [&]() {
-        nbeg = offs[rid_n];
-        nend_lo = *reinterpret_cast<const uint32_t *>(offs + rid_n + 1);
-    };
-    if (REFILL) {
-        rid_n = rid_of(lane);
-        has_next = rid_n < n_reads;
-        if (has_next) load_next_offsets();
+    if (REFILL) {                                         // the first four chunks at once
+        if (lane == 0u) T = atomicAdd(&stats->ticket, 64ull);
+        const uint64_t base = __builtin_amdgcn_readfirstlane((uint32_t)T) | ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(T >> 32)) << 32);
+        if (base < n_reads) {
+            const uint64_t left = n_reads - base;
+            p_count = left < 64u ? (uint32_t)left : 64u;
+            const uint64_t rr = base + lane < n_reads ? base + lane : n_reads - 1;
+            P_beg = offs[rr];
+            P_len = (uint32_t)offs[rr + 1] - (uint32_t)P_beg;
+            P_rid = (uint32_t)rr;
+            if (p_count == 64u) draw_ticket(); else no_more = 1;
+        } else {
+            no_more = 1;
+        }
     }
 
     uint32_t lane_steps = 0, wave_steps = 0;
-    while (wave_any(st != sDone || (REFILL && has_next))) {
+    while (wave_any(st != sDone) || (REFILL && (p_count != 0u || ld_on != 0u || tk_on != 0u))) {
+        if (REFILL) {
+            // ---- idle lanes take the pool's next reads -- in batches, when ix.refill_batch lanes (or every lane that still has
+            // work) wait for one: the switch stages the new reads' bases and looks their first K bases up in the top-of-walk
+            // table, memory round trips during which the whole wavefront stands still.
+            const uint32_t idle = (uint32_t)(st == sDone);
+            const uint64_t idm = __ballot(idle != 0u);
+            const uint32_t n_idle = (uint32_t)__popcll(idm);
+            if (idm == ~0ull || (n_idle >= ix.refill_batch && (p_count != 0u || ld_on != 0u || tk_on != 0u))) {
+                // (a) the chunk whose offsets were requested at the last switch joins the pool
+                if (ld_on) {
+                    const uint64_t left = n_reads - ld_base;
+                    const uint32_t cnt = left < 16u ? (uint32_t)left : 16u;
+                    const uint32_t tail = (p_head + p_count) & 63u;           // a multiple of 16: every chunk but the last is full
+                    if ((lane & 48u) == tail) {
+                        P_beg = N_beg;
+                        P_len = N_end - (uint32_t)N_beg;
+                        P_rid = (uint32_t)ld_base + (lane & 15u);
+                    }
+                    p_count += cnt;
+                    ld_on = 0;
+                    if (cnt < 16u) no_more = 1;
+                }
+                // (b) the ticket drawn at the last switch: its chunk's offsets are requested now
+                if (tk_on) {
+                    const uint64_t base = __builtin_amdgcn_readfirstlane((uint32_t)T) | ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(T >> 32)) << 32);
+                    tk_on = 0;
+                    if (base < n_reads) {
+                        ld_base = base;
+                        const uint64_t rr = base + (lane & 15u) < n_reads ? base + (lane & 15u) : n_reads - 1;
+                        N_beg = offs[rr];
+                        N_end = *reinterpret_cast<const uint32_t *>(offs + rr + 1);
+                        ld_on = 1;
+                    } else {
+                        no_more = 1;
+                    }
+                }
+                // (c) room for another chunk: draw its ticket
+                if (!no_more && !tk_on && p_count + (ld_on ? 16u : 0u) <= 16u) draw_ticket();
+                // (d) the switch: the first min(idle lanes, pool) idle lanes take the pool's next reads, in ring order
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idm, 0u));
+                const uint32_t take = n_idle < p_count ? n_idle : p_count;
+                const uint32_t src = (p_head + rank) & 63u;
+                const uint32_t g_lo = __shfl((uint32_t)P_beg, (int)src, 64), g_hi = __shfl((uint32_t)(P_beg >> 32), (int)src, 64),
+                               g_len = __shfl(P_len, (int)src, 64), g_rid = __shfl(P_rid, (int)src, 64);
+                const uint32_t sw = idle & (uint32_t)(rank < take);
+                p_head = (p_head + take) & 63u;
+                p_count -= take;
+                if (idle && cur_valid) {                  // the read that ended: error byte, bins, zero-fill on failure
+                    finish_read();
+                    cur_valid = 0;
+                }
+                if (sw) {
+                    rid = g_rid; beg = (uint64_t)g_lo | ((uint64_t)g_hi << 32); obeg = beg; len = g_len; packed_end = len & ~7u;
+                    k = 0; ml = 0; ff_run = 0; off = off0; need = r1; failed = 0; cur_valid = 1;
+                    if (CLS) { cs = ClsState(); cs.init(len, cls.bin_width); }
+                    st = len > 0 ? sFF : sDone;
+                }
+                const uint32_t fresh = sw & (uint32_t)(st != sDone);
+                stage_from(0u, fresh != 0u);
+                if (ix.kmer_k != 0u) {
+                    const uint32_t K = ix.kmer_k;
+                    uint32_t kidx = 0, bad = 0;
+                    for (uint32_t i = 0; i < K; ++i) {
+                        const uint32_t cc = staged_code(i) - (uint32_t)SEP;
+                        bad |= (uint32_t)(cc > 3u);
+                        kidx |= (cc & 3u) << (2u * i);
+                    }
+                    top_of_walk(fresh & (uint32_t)(len > K) & (bad ^ 1u), kidx);
+                }
+                if (fresh) {
+                    a = staged_code(k);
+                    if (AHD) a1 = staged_code(k + 1);
+                    if (AHD == 2) a2 = staged_code(k + 2);
+                    fetch(need, true, w);
+                }
+            }
+        }
         const bool act = st < sDone;
         lane_steps += (uint32_t)act;
         wave_steps += 1;
@@ -1006,7 +1124,7 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
         auto hop = [&]() {
             const uint32_t q = (uint32_t)(need - wbase);
             const uint32_t inwin = (uint32_t)(q < WN) & (uint32_t)(st < sDone);
-            const uint2 hr = AHD == 2 ? ((q & 1u) ? w[1] : w[0]) : win_sel(w, q);
+            const uint2 hr = win_sel(w, q);
             const uint32_t hn = row_n<MODE>(hr), hc = row_c<MODE>(hr);
             const uint32_t ffh = inwin & (uint32_t)(st == sFF) & (uint32_t)(need < r1) & (uint32_t)(off >= hn) &
                                  (uint32_t)(ff_run + 1 < 65535u);
@@ -1023,31 +1141,15 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
         // the lengths up to and including i (monotone, so the number of rows passed is a sum of four compares); a scan
         // passes the leading run of non-matching rows from its position (a 4-bit mask and a count-trailing / leading-ones).
         // Same state afterwards as four hop() calls -- identical answers and counts -- at a third of the dependency depth.
-        auto pair_advance = [&]() {                       // window_advance on a window of two rows (AHD == 2)
-            const uint32_t q0 = (uint32_t)(need - wbase);
-            const uint32_t inwin = (uint32_t)(q0 < 2u) & (uint32_t)(st < sDone);
-            const uint32_t n0 = row_n<MODE>(w[0]), n1 = row_n<MODE>(w[1]);
-            const uint32_t last_win = (uint32_t)(wbase + 1 == r1), first_win = (uint32_t)(wbase == 0);
-            const uint32_t m0 = q0 == 0u;
-            const uint32_t t1 = m0 ? n0 : 0u, t2 = t1 + n1;
-            const uint32_t isff = inwin & (uint32_t)(st == sFF);
-            const uint32_t p0 = isff & m0 & (uint32_t)(off >= t1), p1 = isff & (uint32_t)(off >= t2) & (last_win ^ 1u);
-            off -= p1 ? t2 : (p0 ? t1 : 0u);
-            ff_run += p0 + p1;
-            const uint32_t nm = (uint32_t)(row_c<MODE>(w[0]) != a) | ((uint32_t)(row_c<MODE>(w[1]) != a) << 1);
-            const uint32_t dmask = (nm & (last_win ? 1u : 3u)) >> (q0 & 1u);               // row r-1 is never passed
-            const uint32_t cd = (inwin & (uint32_t)(st == sDown)) ? ((dmask & 1u) ? ((dmask & 2u) ? 2u : 1u) : 0u) : 0u;
-            const uint32_t umask = ((nm & (first_win ? 2u : 3u)) << (1u - (q0 & 1u))) & 3u;  // row 0 is never passed
-            const uint32_t cu = (inwin & (uint32_t)(st == sUp)) ? ((umask & 2u) ? ((umask & 1u) ? 2u : 1u) : 0u) : 0u;
-            scan_total += cd + cu;
-            need = need + (IdxT)(p0 + p1 + cd) - (IdxT)cu;
-        };
+        // bit i of nm = row i of the window does not hold the base of step k
+        const uint32_t nm = (uint32_t)(row_c<MODE>(w[0]) != a) | ((uint32_t)(row_c<MODE>(w[1]) != a) << 1) |
+                            ((uint32_t)(row_c<MODE>(w[2]) != a) << 2) | ((uint32_t)(row_c<MODE>(w[3]) != a) << 3);
+        const uint32_t last_win = (uint32_t)(wbase + 3 == r1);             // the table ends inside (at the end of) this window
+        const uint32_t first_win = (uint32_t)(wbase == 0);
         auto window_advance = [&]() {
             const uint32_t q0 = (uint32_t)(need - wbase);
             const uint32_t inwin = (uint32_t)(q0 < 4u) & (uint32_t)(st < sDone);
             const uint32_t n0 = row_n<MODE>(w[0]), n1 = row_n<MODE>(w[1]), n2 = row_n<MODE>(w[2]), n3 = row_n<MODE>(w[3]);
-            const uint32_t last_win = (uint32_t)(wbase + 3 == r1);         // the table ends inside (at the end of) this window
-            const uint32_t first_win = (uint32_t)(wbase == 0);
             // ---- fast-forward: rows q0 .. 3 (need < r1 can only fail at index 3 of the last window)
             const uint32_t m0 = q0 == 0u, m1 = q0 <= 1u, m2 = q0 <= 2u;   // row i takes part (i >= q0); row 3 always does
             const uint32_t t1 = m0 ? n0 : 0u, t2 = t1 + (m1 ? n1 : 0u), t3 = t2 + (m2 ? n2 : 0u), t4 = t3 + n3;
@@ -1057,9 +1159,7 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
             const uint32_t cf = p0 + p1 + p2 + p3;
             off -= (p3 ? t4 : (p2 ? t3 : (p1 ? t2 : (p0 ? t1 : 0u))));
             ff_run += cf;
-            // ---- scans: bit i of nm = row i does not hold the base
-            const uint32_t nm = (uint32_t)(row_c<MODE>(w[0]) != a) | ((uint32_t)(row_c<MODE>(w[1]) != a) << 1) |
-                                ((uint32_t)(row_c<MODE>(w[2]) != a) << 2) | ((uint32_t)(row_c<MODE>(w[3]) != a) << 3);
+            // ---- scans
             // down: leading run of 1s from bit q0 upwards; row r-1 is never passed (need < r1)
             const uint32_t dmask = (nm & (last_win ? 7u : 15u)) >> (q0 & 3u);
             const uint32_t cd = (inwin & (uint32_t)(st == sDown)) ? (uint32_t)__builtin_ctz(~dmask | 16u) : 0u;
@@ -1074,15 +1174,13 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
             for (int h = 0; h < (HA >= 0 ? HA : 0); ++h) hop();
         } else if (wave_any(st == sFF && ff_run >= 65520u)) {
             for (int h = 0; h < 4; ++h) hop();                       // near the reference's fast-forward limit: step by step
-        } else if (AHD == 2) {
-            pair_advance();
         } else {
             window_advance();
         }
         const uint32_t qn = (uint32_t)(need - wbase);
         const uint32_t inwin = (uint32_t)(qn < WN) & (uint32_t)act;
-        const uint2 row = AHD == 2 ? ((qn & 1u) ? w[1] : w[0]) : win_sel(w, qn);
-        const uint32_t n = row_n<MODE>(row), c = row_c<MODE>(row), roff = row_off<MODE>(row);
+        const uint2 row = win_sel(w, qn);
+        const uint32_t n = row_n<MODE>(row), c = row_c<MODE>(row);
         const uint32_t isFF = (uint32_t)(st == sFF) & inwin, isDown = (uint32_t)(st == sDown) & inwin,
                        isUp = (uint32_t)(st == sUp) & inwin;
         // fast_forward, move_structure.cpp:524-545
@@ -1103,33 +1201,57 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
         const uint32_t down = (uint32_t)(off >= ((need == end_row) ? end_threshold(SEP, ethr, a) : thr));
         const uint32_t at_last = need >= r1, at_first = need == 0;
         const uint32_t repo_edge = mism & (down ? at_last : at_first);
-        // reposition_down :211-232 / reposition_up :188-209, one row per iteration
+        // reposition_down :211-232 / reposition_up :188-209.  A run of the base among the window's OTHER rows is found in
+        // this very iteration (the nearest one in the scan's direction: what the row-by-row scan stops at) -- a reposition
+        // whose target shares the window costs no round trip of its own (tools/iter_model.c: half of all repositions; lane
+        // iterations per base -5 % on 150 bp reads with 1 % substitutions, -15 % on 10 kbp reads with 8 %).  Anything
+        // further away is scanned for one window per iteration, as before.
+        const uint32_t has = (nm ^ 15u) & (down ? (14u << (qn & 3u)) & 15u : (1u << (qn & 3u)) - 1u);   // rows that hold the base, beyond row qn
+        const uint32_t found = mism & (uint32_t)(has != 0u) & ix.inwin;
+        const uint32_t qf = found ? (down ? (uint32_t)__builtin_ctz(has | 16u) : 31u - (uint32_t)__builtin_clz(has | 1u)) : qn;
+        const uint32_t far = mism & (found ^ 1u);                          // the scan leaves the window
+        const uint2 rowf = win_sel(w, qf);                                 // the row the base is resolved at, if it is resolved now
+        const uint32_t nf = row_n<MODE>(rowf), rofff = row_off<MODE>(rowf);
+        const IdxT needf = (IdxT)(wbase + qf);
         const uint32_t scanning = isDown | isUp;
         const uint32_t hit = scanning & match;
+        const uint32_t landed = hit | found;                               // a scan ended at this row: offset 0 / n - 1 (read_processor.cpp:223)
+        const uint32_t landed_down = hit ? isDown : down;
         const uint32_t scan_edge = scanning & (hit ^ 1u) & (isDown ? at_last : at_first);
-        const uint32_t emit = (resolved & (illegal | match)) | hit;
+        const uint32_t emit = (resolved & (illegal | match)) | landed;
         // LF_move of the emitted base, move_structure.cpp:59-67 (emit and the error cases are exclusive)
         const uint32_t lf = emit & (uint32_t)(k + 1 != len);
         uint64_t j = 0;
-        if (MODE == 6 || lf) j = row_id<MODE>(row, need, ix);
+        if (MODE == 6 || lf) j = row_id<MODE>(rowf, needf, ix);
         const uint32_t lf_bad = lf & (uint32_t)(j >= ix.r);
-        const uint32_t step_fwd = ffm | (mism & down) | (scanning & (hit ^ 1u) & isDown);
-        const uint32_t step_back = (mism & (down ^ 1u)) | (scanning & (hit ^ 1u) & isUp);
+        const uint32_t step_fwd = ffm | (far & down) | (scanning & (hit ^ 1u) & isDown);
+        const uint32_t step_back = (far & (down ^ 1u)) | (scanning & (hit ^ 1u) & isUp);
         IdxT need_next = lf ? (IdxT)j : (IdxT)(need + step_fwd - step_back);
-        uint32_t st_next = (emit & (lf ^ 1u)) ? sDone : (lf ? sFF : (mism ? (down ? sDown : sUp) : st));
+        uint32_t st_next = (emit & (lf ^ 1u)) ? sDone : (lf ? sFF : (far ? (down ? sDown : sUp) : st));
         // AHD: the base after this one, resolved at the LF target from the look-ahead entry (read_processor.cpp:188-238 with
         // match and no fast-forward: ml + 1, then LF_move again) -- the target row itself is never fetched
-        uint32_t dbl = 0, lf2 = 0, off1 = 0;
+        uint32_t dbl = 0, lf2 = 0, off1 = 0, tri = 0, lf3 = 0, off2 = 0;
+        IdxT j2 = 0;
         if (AHD) {
-            const uint2 ah = AHD == 2 ? ((qn & 1u) ? ahw[1] : ahw[0]) : win_sel(ahw, qn);   // the entry of the row the base was resolved at
+            const uint2 ah = win_sel(ahw, qf);            // the entry of the row the base was resolved at
             const uint32_t n1 = ah.y & 0x7FFu, c1 = (ah.y >> 22) & 7u;
-            const uint32_t off_e = (hit ? (isDown ? 0u : n - 1u) : off) + roff;
+            const uint32_t off_e = (landed ? (landed_down ? 0u : nf - 1u) : off) + rofff;
             dbl = lf & (ah.y >> 31) & (uint32_t)(a1 == c1) & (uint32_t)(off_e < n1);
             lf2 = dbl & (uint32_t)(k + 2 != len);
             off1 = (ah.y >> 11) & 0x7FFu;
-            const IdxT j2 = (IdxT)((uint64_t)ah.x | ((uint64_t)((ah.y >> 25) & 15u) << 32));
+            j2 = (IdxT)((uint64_t)ah.x | ((uint64_t)((ah.y >> 25) & 15u) << 32));
             need_next = dbl ? (lf2 ? j2 : need) : need_next;
             st_next = dbl ? (lf2 ? sFF : sDone) : st_next;
+            if (AHD == 2) {                               // ... and the base after that one at j2 = id(j), the same way
+                const uint2 av = win_sel(ahv, qf);
+                const uint32_t n2 = av.y & 0x7FFu, c2 = (av.y >> 22) & 7u;
+                tri = lf2 & (av.y >> 31) & (uint32_t)(a2 == c2) & (uint32_t)(off_e + off1 < n2);
+                lf3 = tri & (uint32_t)(k + 3 != len);
+                off2 = (av.y >> 11) & 0x7FFu;
+                const IdxT j3 = (IdxT)((uint64_t)av.x | ((uint64_t)((av.y >> 25) & 15u) << 32));
+                need_next = tri ? (lf3 ? j3 : need) : need_next;
+                st_next = tri ? (lf3 ? sFF : sDone) : st_next;
+            }
         }
         // The reference's throws: practically never, so which one it was is sorted out off the common path (as one
         // select ladder over need_next / st_next it cost ~45 instructions between a window's arrival and the next
@@ -1152,72 +1274,26 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
         ff_total += resolved ? ff_run : 0u;
         ff_run = lf ? 0u : ff_run + ffm;
         repo_total += mism;
-        scan_total += scanning;
-        off = ffm ? off - n : (hit ? (isDown ? 0u : n - 1) : off);        // read_processor.cpp:223
+        scan_total += scanning + (found ? (down ? qf - qn : qn - qf) : 0u);
+        off = ffm ? off - n : (landed ? (landed_down ? 0u : nf - 1) : off);   // read_processor.cpp:223
         const uint32_t off_pre = off;                                     // (before the LF to the next base: what K1 records)
-        off += lf ? roff : 0u;
+        off += lf ? rofff : 0u;
         if (emit) {
-            const uint32_t val = ml > 65535u ? 65535u : ml;               // MoveQuery::add_ml
             uint16_t *O = out + obeg;
-            if (SEG == 1) {
-                if ((k & 31u) == 31u) {
-                    SegCkpt ck;
-                    ck.idx = (uint64_t)need; ck.off = off_pre; ck.ml = ml;
-                    ck.ff = ff_total; ck.scan = scan_total; ck.repo = repo_total; ck.pad_ = 0;
-                    seg.ckpt[(obeg + k) >> 5] = ck;
-                }
-                if (k + 1 == len) {
-                    SegFin fn;
-                    fn.idx = (uint64_t)need; fn.off = off_pre; fn.ml = ml;
-                    seg.fin[rid] = fn;
-                }
-            }
-            if (CLS) cs.add(val, k, len, cls.bin_width, cls.thr);
-            if (CLS == 2) {
-                // verdict bins only
-            } else if (k >= packed_end) {
-                O[k] = (uint16_t)val;
-            } else {
-                pk.x = (pk.x >> 16) | (pk.y << 16);
-                pk.y = (pk.y >> 16) | (pk.z << 16);
-                pk.z = (pk.z >> 16) | (pk.w << 16);
-                pk.w = (pk.w >> 16) | (val << 16);
-                // 16 PMLs leave together as two adjacent 16-byte stores; an odd group of 8 before the tail on its own
-                if ((k & 15) == 7) {
-                    if (k + 8 < packed_end) pk_old = pk;
-                    else __builtin_memcpy(O + (k - 7), &pk, 16);
-                } else if ((k & 15) == 15) {
-                    __builtin_memcpy(O + (k - 15), &pk_old, 16);
-                    __builtin_memcpy(O + (k - 7), &pk, 16);
-                }
-            }
-            k += 1;
-            if (AHD && dbl) {                             // the second base of a two-base step: matched, no fast-forward
-                ml += 1;
-                if (SEG == 1) {                           // K1's records: the state a one-base walk has after this base -- at row j, before its LF
-                    if ((k & 31u) == 31u) {
-                        SegCkpt ck;
-                        ck.idx = j; ck.off = off; ck.ml = ml;
-                        ck.ff = ff_total; ck.scan = scan_total; ck.repo = repo_total; ck.pad_ = 0;
-                        seg.ckpt[(obeg + k) >> 5] = ck;
-                    }
-                    if (k + 1 == len) {
-                        SegFin fn;
-                        fn.idx = j; fn.off = off; fn.ml = ml;
-                        seg.fin[rid] = fn;
-                    }
-                }
-                off += lf2 ? off1 : 0u;
-                const uint32_t val2 = ml > 65535u ? 65535u : ml;
-                if (CLS) cs.add(val2, k, len, cls.bin_width, cls.thr);
+            // MoveQuery::add_ml for the base of step k (u16 clamp), through the bins and the 16-byte packer: 16 PMLs leave
+            // together as two adjacent 16-byte stores; an odd group of 8 before the tail on its own
+            auto emit_pml = [&](uint32_t mlv) {
+                const uint32_t val = mlv > 65535u ? 65535u : mlv;
+                if (CLS) cs.add(val, k, len, cls.bin_width, cls.thr);
                 if (CLS == 2) {
+                    // verdict bins only
                 } else if (k >= packed_end) {
-                    O[k] = (uint16_t)val2;
+                    O[k] = (uint16_t)val;
                 } else {
                     pk.x = (pk.x >> 16) | (pk.y << 16);
                     pk.y = (pk.y >> 16) | (pk.z << 16);
                     pk.z = (pk.z >> 16) | (pk.w << 16);
-                    pk.w = (pk.w >> 16) | (val2 << 16);
+                    pk.w = (pk.w >> 16) | (val << 16);
                     if ((k & 15) == 7) {
                         if (k + 8 < packed_end) pk_old = pk;
                         else __builtin_memcpy(O + (k - 7), &pk, 16);
@@ -1227,6 +1303,34 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
                     }
                 }
                 k += 1;
+            };
+            // K1's records (SEG == 1): the state a one-base walk has after the base of step k -- at row `at`, before its LF
+            auto seg_record = [&](uint64_t at, uint32_t off_at) {
+                if ((k & 31u) == 31u) {
+                    SegCkpt ck;
+                    ck.idx = at; ck.off = off_at; ck.ml = ml;
+                    ck.ff = ff_total; ck.scan = scan_total; ck.repo = repo_total; ck.pad_ = 0;
+                    seg.ckpt[(obeg + k) >> 5] = ck;
+                }
+                if (k + 1 == len) {
+                    SegFin fn;
+                    fn.idx = at; fn.off = off_at; fn.ml = ml;
+                    seg.fin[rid] = fn;
+                }
+            };
+            if (SEG == 1) seg_record((uint64_t)needf, off_pre);
+            emit_pml(ml);
+            if (AHD && dbl) {                             // the second base of a multi-base step: matched, no fast-forward
+                ml += 1;
+                if (SEG == 1) seg_record(j, off);
+                off += lf2 ? off1 : 0u;
+                emit_pml(ml);
+                if (AHD == 2 && tri) {                    // the third: matched at j2 = id(j), no fast-forward
+                    ml += 1;
+                    if (SEG == 1) seg_record((uint64_t)j2, off);
+                    off += lf3 ? off2 : 0u;
+                    emit_pml(ml);
+                }
             }
             if (STG) {
                 // (the next base's code: after the state update below, where a lane about to leave its staged stretch is seen)
@@ -1251,57 +1355,19 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
             // a lane whose next bases lie beyond its staged stretch: the whole wavefront stages again, each lane from its own step
             const uint32_t ahead_of = k - kbase;          // < 2^31: k >= kbase always
             const uint32_t out_of = (uint32_t)(st != sDone) &
-                                    ((uint32_t)(ahead_of >= stage_cap) | ((uint32_t)(ahead_of + 1u >= stage_cap) & (uint32_t)(k + 1 < len)));
+                                    ((uint32_t)(ahead_of >= stage_cap) | ((uint32_t)(ahead_of + 1u >= stage_cap) & (uint32_t)(k + 1 < len)) |
+                                     ((uint32_t)(AHD == 2) & (uint32_t)(ahead_of + 2u >= stage_cap) & (uint32_t)(k + 2 < len)));
             if (wave_any(out_of != 0u)) stage_from(k, st != sDone);
             a = staged_code(k - kbase);
             if (AHD) a1 = staged_code(k + 1 - kbase);
-        }
-        if (REFILL) {
-            // ---- lane refill, all of it under the gather's latency.  Order matters for the waits hipcc inserts: every
-            // block reads its registers BEFORE any block below it issues a load into them.
-            // (A) parked lanes: the first bases arrived with this iteration's window
-            if (wave_any(st == sLoad)) {
-                if (st == sLoad) {
-                    fix_pair(beg + len, rb, rb2);
-                    a = s_code[(uint32_t)(rb >> 56) & 0xFFu];
-                    st = sFF;
-                }
-            }
-            // (B) reads that ended in this iteration
-            const uint32_t fin = (uint32_t)act & (uint32_t)(st == sDone);
-            if (wave_any(fin != 0u)) {
-                if (fin) finish_read();
-            }
-            // (C) idle lanes with a next read switch to it
-            const uint32_t sw = (uint32_t)(st == sDone) & has_next;
-            const uint64_t swm = __ballot(sw != 0u);
-            if (swm != 0ull) {
-                if (sw) {
-                    rid = rid_n; beg = nbeg; obeg = nbeg; len = nend_lo - (uint32_t)nbeg; packed_end = len & ~7u;
-                    k = 0; ml = 0; ff_run = 0; off = off0; need = r1; failed = 0;
-                    if (CLS) { cs = ClsState(); cs.init(len, cls.bin_width); }
-                    if (len > 0) {
-                        load_pair_at(beg + len, rb, rb2);
-                        if (len > 16) { want_nx = 1; nx_e = beg + len - 16; }
-                        st = sLoad;
-                    } else {
-                        finish_read();
-                    }
-                    const uint32_t tk = tnext + __builtin_amdgcn_mbcnt_hi((uint32_t)(swm >> 32),
-                                                                         __builtin_amdgcn_mbcnt_lo((uint32_t)swm, 0u));
-                    rid_n = rid_of(tk);
-                    has_next = rid_n < n_reads;
-                    if (has_next) load_next_offsets();
-                }
-                tnext += (uint32_t)__popcll(swm);
-            }
+            if (AHD == 2) a2 = staged_code(k + 2 - kbase);
         }
         // ONE load site per prefetch register set and iteration, behind every read of those registers: a second site (or
         // a temporary that the register allocator parks in them where they are dead) costs an `s_waitcnt` on a load
         // in flight, i.e. on the row gather issued above
         if (want_nx) load_pair_at(nx_e, nx0, nx1);
     }
-    if (!REFILL && valid) finish_read();
+    if (REFILL ? cur_valid != 0u : valid) finish_read();
     if (SEG != 1) {
         const uint32_t ffw = wave_sum(ff_total), scw = wave_sum(scan_total), rpw = wave_sum(repo_total),
                        erw = wave_sum(err_total);
@@ -1413,11 +1479,14 @@ __global__ __launch_bounds__(256) void kmer_table_kernel(DevIndex ix, uint32_t K
 }
 
 // Look-ahead rows (DevIndex::rows2): thread i copies row i into its line and writes the entry of its LF target next to it.
-// FAT = 1: the fat-row layout (DevIndex::rows3) -- row i and its entry are the 16 bytes at 16 i.
 // tally (optional): [0] += the positions of row i that arrive at its LF target below the target's length (no fast-forward
 // there), [1] += n(i): their ratio says how often a walk that follows the text can use an entry -- 0.83 on pangenome BWTs,
 // 0.51 on uniformly random run sequences (tools/lf_chain_stats.py).
-template <int MODE, int FAT = 0>
+// What the walk would read at row j and where it goes from there (j2 = id(j)): one 8-byte half of an entry.
+__device__ __forceinline__ uint2 ahead_half(uint2 rj, uint64_t j2) {
+    return make_uint2((uint32_t)j2, row_n<6>(rj) | (row_off<6>(rj) << 11) | (row_c<6>(rj) << 22) | ((uint32_t)(j2 >> 32) << 25) | 0x80000000u);
+}
+template <int MODE>
 __global__ __launch_bounds__(256) void ahead_rows_kernel(DevIndex ix, uint8_t *__restrict__ out, uint64_t tail, unsigned long long *tally) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool in = i < ix.r;
@@ -1430,21 +1499,13 @@ __global__ __launch_bounds__(256) void ahead_rows_kernel(DevIndex ix, uint8_t *_
         const uint64_t j2 = row_id<MODE>(rj, j, ix);
         const uint32_t nj = row_n<MODE>(rj), ni = row_n<MODE>(row), oi = row_off<MODE>(row);
         no_ff = nj > oi ? (nj - oi < ni ? nj - oi : ni) : 0u;
-        if (j2 < ix.r) {
-            e.x = (uint32_t)j2;
-            e.y = row_n<MODE>(rj) | (row_off<MODE>(rj) << 11) | (row_c<MODE>(rj) << 22) | ((uint32_t)(j2 >> 32) << 25) | 0x80000000u;
-        }
+        if (j2 < ix.r) e = ahead_half(rj, j2);
     }
     if (tally) {                                          // every lane of the wavefront is here
         const uint32_t a = wave_sum(no_ff), b = wave_sum(in ? row_n<MODE>(row) : 0u);
         if ((threadIdx.x & 63) == 0) { atomicAdd(tally, (unsigned long long)a); atomicAdd(tally + 1, (unsigned long long)b); }
     }
     if (!in) return;
-    if (FAT) {
-        const uint4 both = make_uint4(row.x, row.y, e.x, e.y);
-        __builtin_memcpy(out + i * 16u, &both, 16);
-        return;
-    }
     uint8_t *line = out + (i >> 3) * 128u + (i & 7u) * 8u;
     __builtin_memcpy(line, &row, 8);
     __builtin_memcpy(line + 64, &e, 8);
@@ -1455,7 +1516,51 @@ __global__ __launch_bounds__(256) void ahead_rows_kernel(DevIndex ix, uint8_t *_
     }
 }
 
+// Chain rows (DevIndex::rows3): line L = rows 4L .. 4L+3 (32 bytes) + their four 16-byte entries (64 bytes; the last 32
+// bytes of the line are unused); one more line at byte `tail` holds rows r-4 .. r-1.  Entry of row i, with j = id(i),
+// j2 = id(j), j3 = id(j2): first half = the look-ahead rows' entry (what the walk reads at j, and j2), second half the
+// same one row further (what it reads at j2, and j3); a half is invalid (0) when one of the rows it names is not a row.
+template <int MODE>
+__global__ __launch_bounds__(256) void chain_rows_kernel(DevIndex ix, uint8_t *__restrict__ out, uint64_t tail, unsigned long long *tally) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in = i < ix.r;
+    const uint2 row = in ? load_row<MODE>(ix.rows, i) : make_uint2(0u, 0u);
+    const uint64_t j = in ? row_id<MODE>(row, i, ix) : ix.r;
+    uint4 e = make_uint4(0u, 0u, 0u, 0u);
+    uint32_t no_ff = 0;
+    if (j < ix.r) {
+        const uint2 rj = load_row<MODE>(ix.rows, j);
+        const uint64_t j2 = row_id<MODE>(rj, j, ix);
+        const uint32_t nj = row_n<MODE>(rj), ni = row_n<MODE>(row), oi = row_off<MODE>(row);
+        no_ff = nj > oi ? (nj - oi < ni ? nj - oi : ni) : 0u;
+        if (j2 < ix.r) {
+            const uint2 h1 = ahead_half(rj, j2);
+            e.x = h1.x; e.y = h1.y;
+            const uint2 rj2 = load_row<MODE>(ix.rows, j2);
+            const uint64_t j3 = row_id<MODE>(rj2, j2, ix);
+            if (j3 < ix.r) {
+                const uint2 h2 = ahead_half(rj2, j3);
+                e.z = h2.x; e.w = h2.y;
+            }
+        }
+    }
+    if (tally) {
+        const uint32_t a = wave_sum(no_ff), b = wave_sum(in ? row_n<MODE>(row) : 0u);
+        if ((threadIdx.x & 63) == 0) { atomicAdd(tally, (unsigned long long)a); atomicAdd(tally + 1, (unsigned long long)b); }
+    }
+    if (!in) return;
+    uint8_t *line = out + (i >> 2) * 128u;
+    __builtin_memcpy(line + (i & 3u) * 8u, &row, 8);
+    __builtin_memcpy(line + 32u + (i & 3u) * 16u, &e, 16);
+    if (i + 4 >= ix.r) {
+        uint8_t *tl = out + tail;
+        __builtin_memcpy(tl + (i + 4 - ix.r) * 8u, &row, 8);
+        __builtin_memcpy(tl + 32u + (i + 4 - ix.r) * 16u, &e, 16);
+    }
+}
+
 uint64_t ahead_rows_bytes(uint64_t r) { return ((r + 7) / 8 + 1) * 128; }
+uint64_t chain_rows_bytes(uint64_t r) { return ((r + 3) / 4 + 1) * 128; }
 
 hipError_t build_ahead_rows(int kmode, const DevIndex &ix, uint8_t *d_rows2, uint64_t *tail, hipStream_t stream, unsigned long long *d_tally) {
     if (!d_rows2 || !tail || ix.r < 8 || (ix.r >> 36) != 0 || kmode != 6) return hipErrorInvalidValue;
@@ -1468,11 +1573,14 @@ hipError_t build_ahead_rows(int kmode, const DevIndex &ix, uint8_t *d_rows2, uin
     return hipGetLastError();
 }
 
-hipError_t build_fat_rows(int kmode, const DevIndex &ix, uint8_t *d_rows3, hipStream_t stream) {
-    if (!d_rows3 || ix.r < 8 || (ix.r >> 36) != 0 || kmode != 6) return hipErrorInvalidValue;
+hipError_t build_chain_rows(int kmode, const DevIndex &ix, uint8_t *d_rows3, uint64_t *tail, hipStream_t stream, unsigned long long *d_tally) {
+    if (!d_rows3 || !tail || ix.r < 8 || (ix.r >> 36) != 0 || kmode != 6) return hipErrorInvalidValue;
+    *tail = ((ix.r + 3) / 4) * 128;
+    hipError_t e = hipMemsetAsync(d_rows3, 0, chain_rows_bytes(ix.r), stream);
+    if (e != hipSuccess) return e;
     const uint64_t blocks = (ix.r + 255) / 256;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((ahead_rows_kernel<6, 1>), dim3((unsigned)blocks), dim3(256), 0, stream, ix, d_rows3, (uint64_t)0, (unsigned long long *)nullptr);
+    hipLaunchKernelGGL(chain_rows_kernel<6>, dim3((unsigned)blocks), dim3(256), 0, stream, ix, d_rows3, *tail, d_tally);
     return hipGetLastError();
 }
 
@@ -1885,7 +1993,7 @@ static hipError_t launch_pml_segmented(const DevIndex &ix, const uint8_t *d_base
         int wpc = cfg.waves_per_cu;
         if (wpc < 0) wpc = 0;
         if (cfg.waves_per_cu == 0 && big_batch_cap && lanes > (uint64_t)cfg.num_cus * 64u * 18u)
-            wpc = (ix.rows2 != nullptr && cfg.stage_reads != 0) ? kCapWavesAhead : kCapWaves;
+            wpc = ((ix.rows2 != nullptr || ix.rows3 != nullptr) && cfg.stage_reads != 0) ? kCapWavesAhead : kCapWaves;
         if (wpc > 0 && wpc < 32) return ((163840u / (unsigned)wpc) & ~1023u) - 1024u;
         return 0;
     };
@@ -1894,6 +2002,7 @@ static hipError_t launch_pml_segmented(const DevIndex &ix, const uint8_t *d_base
     // (segments and re-walked reads stage their bases through LDS and walk on the look-ahead rows like any other launch:
     // launch_pml's policy -- the cap's padding, or what the launch's wavefronts per CU leave of the CU's LDS)
     DevIndex ixl = ix;
+    ixl.inwin = cfg.inwin ? 1u : 0u;
     size_t dyn_lds = 0;
     auto stage_for = [&](uint64_t lanes) {
         dyn_lds = lds_for(lanes);
@@ -1916,7 +2025,8 @@ static hipError_t launch_pml_segmented(const DevIndex &ix, const uint8_t *d_base
     } while (0)
 #define MOVI_LAUNCH_SEG_S(SEGV, LANES, T, S)                                                                          \
     do {                                                                                                              \
-        if (ixl.stage_lds != 0u && ix.rows2 != nullptr) MOVI_LAUNCH_SEG(SEGV, LANES, pml_kernel_flatp<6, T, -1, 0, S, 0, SEGV, 1, 1>); \
+        if (ixl.stage_lds != 0u && ix.rows3 != nullptr) MOVI_LAUNCH_SEG(SEGV, LANES, pml_kernel_flatp<6, T, -1, 0, S, 0, SEGV, 1, 2>); \
+        else if (ixl.stage_lds != 0u && ix.rows2 != nullptr) MOVI_LAUNCH_SEG(SEGV, LANES, pml_kernel_flatp<6, T, -1, 0, S, 0, SEGV, 1, 1>); \
         else if (ixl.stage_lds != 0u) MOVI_LAUNCH_SEG(SEGV, LANES, pml_kernel_flatp<6, T, -1, 0, S, 0, SEGV, 1, 0>);  \
         else MOVI_LAUNCH_SEG(SEGV, LANES, pml_kernel_flatp<6, T, -1, 0, S, 0, SEGV>);                                 \
     } while (0)
@@ -1931,7 +2041,7 @@ static hipError_t launch_pml_segmented(const DevIndex &ix, const uint8_t *d_base
     } while (0)
     MOVI_LAUNCH_SEG_T(1, max_seg);
     if (info) {                                           // the dominant kernel: K1
-        const int stg = ixl.stage_lds != 0u ? 1 : 0, ahd = (stg && ix.rows2 != nullptr) ? 1 : 0;
+        const int stg = ixl.stage_lds != 0u ? 1 : 0, ahd = (stg && ix.rows3 != nullptr) ? 2 : ((stg && ix.rows2 != nullptr) ? 1 : 0);
         snprintf(info->kernel, sizeof(info->kernel), "pml_kernel_flatp<6, %s, -1, 0, %d, 0, 1, %d, %d>",
                  ix.idx32 ? "unsigned int" : "unsigned long", ix.sep ? 1 : 0, stg, ahd);
         info->variant = 14; info->block_threads = 64; info->segmented = 1; info->idx64 = ix.idx32 ? 0 : 1;
@@ -1993,12 +2103,12 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     if (v < 0) v = 14;
     // variant 14 = variant 10 with the window-parallel advance instead of two sequential hops: +2.5 % on long reads,
     // +5.5 % on the 8 GB table, neutral on the fabric-bound big batches (profiles/r02_window_parallel.txt) -> the default
-    const bool wp = v == 14;
+    bool wp = v == 14;
     if (wp) v = 10;
     const int wpc_refill = cfg.waves_per_cu > 0 ? cfg.waves_per_cu : kCapWaves;
     uint64_t refill_blocks = cfg.refill_blocks > 0 ? (uint64_t)cfg.refill_blocks
                                                    : (uint64_t)cfg.num_cus * (uint64_t)wpc_refill;   // in wavefronts (blocks of 64)
-    if (v == 13 && (d_order || n_reads <= refill_blocks * 64u)) v = 10;      // nothing to refill
+    if (v == 13 && (d_order || n_reads <= refill_blocks * 64u)) { v = 10; wp = true; }   // nothing to refill: the default walk
     if ((v == 10 || v == 13) && (ix.r < 8 || n_bases < 16)) v = 7;           // the clamped window needs >= 4 rows, the
                                                                              // 16-base fetches >= 16 bytes of bases
     if (cm != 0 && (v == 0 || v == 7)) v = (v == 0 || ix.r < 8 || n_bases < 16) ? 1 : 10;   // the A/B kernels carry no fused bins
@@ -2021,13 +2131,15 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     uint64_t blocks = (n_reads + bt - 1) / bt;
     int wpc = cfg.waves_per_cu;
     if (wpc < 0) wpc = 0;
-    const bool stage_ok = cfg.stage_reads != 0 && bt == 64 && v == 10 && wp;       // the staged kernels: one-wavefront blocks of the default walk
-    const bool ahead_ok = stage_ok && ix.rows2 != nullptr;                            // ... on the look-ahead rows
-    const bool fat_ok = stage_ok && ix.rows2 == nullptr && ix.rows3 != nullptr;       // ... or on the fat rows (tables beyond the TLBs' reach)
+    if (v == 13 && (cfg.stage_reads == 0 || bt != 64)) { v = 10; wp = true; }         // lane refill: staged one-wavefront blocks only
+    const bool stage_ok = cfg.stage_reads != 0 && bt == 64 && ((v == 10 && wp) || v == 13);   // the staged kernels: one-wavefront blocks of the default walk
+    const bool chain_ok = stage_ok && ix.rows3 != nullptr;                              // ... on the chain rows (three bases per gather) where they exist
+    const bool ahead_ok = stage_ok && !chain_ok && ix.rows2 != nullptr;                 // ... or on the look-ahead rows (two)
     if (cfg.waves_per_cu == 0 && (cfg.pml_variant < 0 || cfg.pml_variant == 14) && v == 10 && big_batch)
-        wpc = (ahead_ok || fat_ok) ? kCapWavesAhead : kCapWaves;                   // the auto policy above
+        wpc = (ahead_ok || chain_ok) ? kCapWavesAhead : kCapWaves;                   // the auto policy above
     if (v == 13) {
-        wpc = wpc_refill;
+        wpc = cfg.waves_per_cu > 0 ? cfg.waves_per_cu : ((ahead_ok || chain_ok) ? kCapWavesAhead : kCapWaves);
+        if (cfg.refill_blocks == 0) refill_blocks = (uint64_t)cfg.num_cus * (uint64_t)wpc;
         const uint64_t resident = (refill_blocks * 64u + bt - 1) / bt;
         if (blocks > resident) blocks = resident;
     }
@@ -2057,8 +2169,11 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     }
     const uint32_t stage_cap = (uint32_t)std::min<size_t>(1024, (dyn_lds / 64) & ~(size_t)15);
     ixl.stage_lds = (stage_ok && stage_cap >= 96) ? stage_cap : 0u;
+    ixl.refill_batch = cfg.refill_batch > 0 ? (uint32_t)cfg.refill_batch : 16u;
+    ixl.inwin = cfg.inwin ? 1u : 0u;
+    if (v == 13 && ixl.stage_lds == 0u) return hipErrorInvalidValue;                  // (cannot happen: the refill launch is capped)
     const bool use_ahead = ahead_ok && ixl.stage_lds != 0u;
-    const bool use_fat = fat_ok && ixl.stage_lds != 0u;
+    const bool use_chain = chain_ok && ixl.stage_lds != 0u;
     const SegArgs no_seg;
     // every kernel that is handed more than 64 KiB of dynamic LDS must opt in first
 #define MOVI_SEG_0
@@ -2090,23 +2205,24 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
         if (ix.idx32) MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint32_t, H, C, S, R>);                         \
         else MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint64_t, H, C, S, R>);                                  \
     } while (0)
-#define MOVI_LAUNCH_FLATP_STG(M, C, S)                                                                      \
+#define MOVI_LAUNCH_FLATP_STG(M, C, S, R)                                                                   \
     do {                                                                                                    \
-        if (use_fat) {                                                                                      \
-            if (ix.idx32) MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint32_t, -1, C, S, 0, 0, 1, 2>);           \
-            else MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint64_t, -1, C, S, 0, 0, 1, 2>);                    \
-        } else if (use_ahead) {                                                                                    \
-            if (ix.idx32) MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint32_t, -1, C, S, 0, 0, 1, 1>);           \
-            else MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint64_t, -1, C, S, 0, 0, 1, 1>);                    \
+        if (use_chain) {                                                                                    \
+            if (ix.idx32) MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint32_t, -1, C, S, R, 0, 1, 2>);           \
+            else MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint64_t, -1, C, S, R, 0, 1, 2>);                    \
+        } else if (use_ahead) {                                                                             \
+            if (ix.idx32) MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint32_t, -1, C, S, R, 0, 1, 1>);           \
+            else MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint64_t, -1, C, S, R, 0, 1, 1>);                    \
         } else {                                                                                            \
-            if (ix.idx32) MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint32_t, -1, C, S, 0, 0, 1>);              \
-            else MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint64_t, -1, C, S, 0, 0, 1>);                       \
+            if (ix.idx32) MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint32_t, -1, C, S, R, 0, 1>);              \
+            else MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint64_t, -1, C, S, R, 0, 1>);                       \
         }                                                                                                   \
     } while (0)
 #define MOVI_LAUNCH_FLATP_R(M, C, S, R)                                                                     \
     do {                                                                                                    \
-        if (wp && R == 0 && ixl.stage_lds) MOVI_LAUNCH_FLATP_STG(M, C, S);                                  \
-        else if (wp) MOVI_LAUNCH_FLATP_H(M, -1, C, S, R); else MOVI_LAUNCH_FLATP_H(M, MOVI_HA, C, S, R);    \
+        if (R == 1) MOVI_LAUNCH_FLATP_STG(M, C, S, 1);                                                      \
+        else if (wp && ixl.stage_lds) MOVI_LAUNCH_FLATP_STG(M, C, S, 0);                                    \
+        else if (wp) MOVI_LAUNCH_FLATP_H(M, -1, C, S, 0); else MOVI_LAUNCH_FLATP_H(M, MOVI_HA, C, S, 0);    \
     } while (0)
 #define MOVI_LAUNCH_FLATP_S(M, C, S)                                                                        \
     do {                                                                                                    \
@@ -2131,12 +2247,12 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
         const char *it = ix.idx32 ? "unsigned int" : "unsigned long";
         if (v == 0 || v == 1) snprintf(info->kernel, sizeof(info->kernel), "pml_kernel<6, %d, %d>", v, v == 0 ? 0 : cm);
         else if (v == 7) snprintf(info->kernel, sizeof(info->kernel), "pml_kernel_flat<6, %s, 0>", it);
-        else snprintf(info->kernel, sizeof(info->kernel), "pml_kernel_flatp<6, %s, %d, %d, %d, %d, 0, %d, %d>", it, wp ? -1 : MOVI_HA, cm,
-                      ix.sep ? 1 : 0, v == 13 ? 1 : 0, (v == 10 && ixl.stage_lds) ? 1 : 0, use_ahead ? 1 : (use_fat ? 2 : 0));
+        else snprintf(info->kernel, sizeof(info->kernel), "pml_kernel_flatp<6, %s, %d, %d, %d, %d, 0, %d, %d>", it, (wp || v == 13) ? -1 : MOVI_HA, cm,
+                      ix.sep ? 1 : 0, v == 13 ? 1 : 0, ixl.stage_lds ? 1 : 0, use_ahead ? 1 : (use_chain ? 2 : 0));
         info->variant = (v == 10 && wp) ? 14 : v;
         info->block_threads = bt; info->waves_per_cu = wpc; info->segmented = 0; info->idx64 = ix.idx32 ? 0 : 1;
         info->staged = (int)ixl.stage_lds;
-        info->ahead = use_ahead ? 1 : (use_fat ? 2 : 0);
+        info->ahead = use_ahead ? 1 : (use_chain ? 2 : 0);
     }
 #undef MOVI_LAUNCH_PML
 #undef MOVI_LAUNCH_K

@@ -51,6 +51,8 @@ struct DevIndex {
     uint32_t pad2_;
     const uint4 *ftab;
     uint32_t stage_lds;           // set per launch by launch_pml: bytes of dynamic LDS per lane for read staging (0 = none; 336 at cap 7)
+    uint32_t refill_batch;        // set per launch: idle lanes of a lane-refill wavefront switch when this many wait (pml_kernel_flatp<..., REFILL = 1>)
+    uint32_t inwin;               // set per launch: 1 = a reposition whose target is one of the window's rows is resolved in the same iteration
     uint32_t kmer_k;
     const uint4 *kmer;            // 4^K entries: x = row[31:0]; y = row[35:32] | off << 4 (12 bits) | match mask << 16 (K bits) |
                                   // valid << 31; z = fast-forwards; w = scan rows.  valid = 0: one of the K steps hit one of the
@@ -71,10 +73,13 @@ struct DevIndex {
     // ratio, which the builder tallies, when the copy is built by itself; a caller who asks for the copy gets it for both.
     uint32_t rows2_count;
     uint32_t pad3_;
-    // Fat rows ("ahead_rows" 2; nullptr = none): the same entries for tables beyond the TLBs' reach, where a step must not
-    // cost more loads than it does on the plain rows -- row i and its entry are the 16 bytes at 16 i, and the walk's window is
-    // the aligned PAIR of rows with their entries: 32 bytes, two loads, like the plain 4-row window.
+    // Chain rows ("ahead_rows" 2; nullptr = none): look-ahead entries that reach TWO rows ahead, 16 bytes per row -- up to
+    // three bases per gather.  Line L = rows 4L .. 4L+3 (32 bytes) + their 4 entries (64 bytes; 32 bytes unused); one more
+    // line at byte rows3_tail holds rows r-4 .. r-1.  Entry of row i, with j = id(i), j2 = id(j), j3 = id(j2):
+    // x, y = the look-ahead rows' entry (j2; n, offset, c of row j; valid); z, w = the same one row further (j3; n, offset,
+    // c of row j2; valid).
     const uint8_t *rows3;
+    uint64_t rows3_tail;
 };
 
 // Device counters of one query call.
@@ -112,6 +117,8 @@ struct LaunchCfg {
     int stage_reads = 1;   // every lane keeps the next stretch of its read in the block's LDS (rolling for long reads); 0 = off: A/B
     int refill_blocks = 0; // variant 13: size of the persistent grid in blocks; 0 = num_cus x waves per CU (tests shrink it
                            // so that a few hundred reads already go through many refills per lane)
+    int refill_batch = 0;  // variant 13: idle lanes switch to their next reads when this many wait (0 = 16)
+    int inwin = 1;         // repositions inside the window resolved in the same iteration (0 = off: A/B)
 };
 
 // What a launch_* call actually launched (movi_last_launch): the policy lives in the launchers, so they say what they picked.
@@ -122,7 +129,7 @@ struct LaunchInfo {
     int waves_per_cu = 0;    // resident-wavefront cap applied (0 = none)
     int segmented = 0;       // 1 = the segment-parallel plan ran (K1 + stitch + finalize around the named kernel)
     int idx64 = 0;           // 1 = the 64-bit row-index instantiation
-    int ahead = 0;           // 1 = the walk ran on the look-ahead rows (two bases per gather where the next base matches), 2 = on the fat rows
+    int ahead = 0;           // 1 = the walk ran on the look-ahead rows (two bases per gather where the next base matches), 2 = on the chain rows (three)
     int staged = 0;          // > 0: every lane keeps the next `staged` bases of its read in LDS (pml_kernel_flatp<..., STG = 1>)
 };
 
@@ -227,7 +234,9 @@ hipError_t build_kmer_table(const DevIndex &ix, uint32_t K, uint4 *d_table, hipS
 uint64_t ahead_rows_bytes(uint64_t r);
 hipError_t build_ahead_rows(int kmode, const DevIndex &ix, uint8_t *d_rows2, uint64_t *tail, hipStream_t stream,
                             unsigned long long *d_tally = nullptr);   // d_tally: 2 zeroed counters (ahead_rows_kernel), optional
-hipError_t build_fat_rows(int kmode, const DevIndex &ix, uint8_t *d_rows3, hipStream_t stream);   // DevIndex::rows3: 16 r bytes
+uint64_t chain_rows_bytes(uint64_t r);
+hipError_t build_chain_rows(int kmode, const DevIndex &ix, uint8_t *d_rows3, uint64_t *tail, hipStream_t stream,
+                            unsigned long long *d_tally = nullptr);   // DevIndex::rows3 (chain_rows_kernel)
 
 // Fills the 4^K entries of the count query's interval table (DevIndex::ftab); mode = resident layout (6 or 3).
 hipError_t build_ftab(int mode, const DevIndex &ix, uint32_t K, uint4 *d_table, hipStream_t stream);

@@ -309,10 +309,10 @@ def test_count_on_the_look_ahead_rows_separators_and_corrupt_rows(built_lib, gol
 
 
 @pytest.mark.parametrize("mode", [6, 8])
-def test_fat_rows_vs_oracle(built_lib, golden_image, mode):
-    """"ahead_rows" 2: the look-ahead entries next to their rows (16 bytes per row), walked with a window of TWO rows -- the
-    layout for tables beyond the TLBs' reach, where a step may not cost more loads than on the plain rows.  Same answers,
-    error bytes and counters as the oracle and the plain rows, for every read length, both index widths, with bins."""
+def test_chain_rows_vs_oracle(built_lib, golden_image, mode):
+    """"ahead_rows" 2: chain rows -- look-ahead entries that reach TWO rows ahead (16 bytes per row next to the 4-row window:
+    up to three bases per gather).  Same answers, error bytes and counters as the oracle and the plain rows, for every read
+    length, both index widths, with bins."""
     import movi_amd
     from oracle.oracle import Oracle
     img = golden_image(mode)
@@ -348,7 +348,7 @@ def test_fat_rows_vs_oracle(built_lib, golden_image, mode):
 
 
 @pytest.mark.parametrize("cut", [0, 1, 2, 3])
-def test_fat_rows_last_window(built_lib, cut):
+def test_chain_rows_last_window(built_lib, cut):
     import movi_amd
     from oracle import build_index as B
     from oracle.oracle import Oracle
@@ -370,7 +370,7 @@ def test_fat_rows_last_window(built_lib, cut):
 def test_look_ahead_on_odd_texts(built_lib, kind):
     """Texts that stress what the entries encode: long runs (offsets near the 11-bit limit, rows split at 2047), two-letter
     alphabets (no top-of-walk table), tandem repeats (every base rides along for thousands of steps), random text (almost
-    none does).  PML (line copy and fat rows) and count against the oracle, small batches (uncapped, staged launches)."""
+    none does).  PML (line copy and chain rows) and count against the oracle, small batches (uncapped, staged launches)."""
     import movi_amd
     from oracle import build_index as B
     from oracle.oracle import Oracle

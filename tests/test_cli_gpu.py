@@ -516,8 +516,8 @@ def test_bpf_writer_paths_for_long_records(movi_bin, tmp_path, shape):
 
 
 def test_ahead_rows_flag(movi_bin, oracles, tmp_path):
-    """`movi query --ahead-rows 0|1|2` (extension): the look-ahead rows off, built whatever the table's size, or as fat
-    rows -- the same BPF bytes and count lines either way."""
+    """`movi query --ahead-rows 0|1|2` (extension): the look-ahead rows off, built whatever the table's size, or as chain
+    rows (entries two rows deep) -- the same BPF bytes and count lines either way."""
     from oracle import build_index as B
     ref = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))[0][1]
     reads_path = str(tmp_path / "mixed.fa")

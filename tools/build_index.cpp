@@ -22,6 +22,7 @@
 //            (also writes <out_dir>/text.bin and reads.bin (and reads2.bin): fixed-length substrings of the text
 //            with substitutions)
 //        build_index reads <text.bin> <n_reads> <read_len> <sub_rate> <seed> <out_file>
+//        build_index pangenome <ancestor_len> <n_genomes> <snp_rate> <seed> <mode> <out_dir> text-only     (writes text.bin only)
 #include <algorithm>
 #include <array>
 #include <cstdint>
@@ -554,6 +555,10 @@ int main(int argc, char **argv) {
     }
     if (mode != 2 && mode != 3 && mode != 5 && mode != 6 && mode != 7 && mode != 8) { fprintf(stderr, "mode must be 2, 3, 5, 6, 7 or 8\n"); return 1; }
     mkdir(out_dir.c_str(), 0777);
+    if (cmd == "pangenome" && argc == 9 && std::string(argv[8]) == "text-only") {   // only <out_dir>/text.bin (seconds): lets `reads` draw from a cached index's text
+        write_file(out_dir + "/text.bin", text);
+        return 0;
+    }
     if (cmd == "pangenome") write_file(out_dir + "/text.bin", text);       // lets `reads` draw more reads later
     for (int set = 0; set < 2; set++) {                                    // optional second read set: argv[11..13] -> reads2.bin
         if (set == 1) {
