@@ -24,7 +24,8 @@ if ROOT not in sys.path:
 
 import numpy as np
 
-PG = dict(anc=5_000_000, genomes=64, snp=0.001, seed=11)       # 64 x 5 Mbp (+ reverse complements) = 640 Mbp, ~14 M rows
+PG_C2 = dict(anc=5_000_000, genomes=64, snp=0.001, seed=11)    # 64 x 5 Mbp (+ reverse complements) = 640 Mbp, ~14 M rows
+PG = PG_C2
 WORKLOADS = {
     # "pangenome": real BWT of a synthetic 64-genome pangenome built by tools/build_index,
     # cached under /tmp after the first ~90 s build.  "synth": random move table of tools/synth.c (8(d)(ii)).
@@ -49,16 +50,34 @@ WORKLOADS = {
     "c5": dict(kind="synth", rows=1_000_000_000, mode=8, reads=1_250_000, read_len=150, sub=0.01,
                desc="random 1B-row blocked-thresholds table (6 GB), 1.25M x 150bp reads per GPU (BASELINE config 5 shard; "
                     "use with --query count)"),
+    "c4real": dict(kind="pangenome", pg="big", mode=6, reads=1_250_000, read_len=150, sub=0.01,
+                   desc="real BWT beyond the Infinity Cache and the TLBs' reach: synthetic 64-genome pangenome, 8.5 Mbp ancestor, 1 % "
+                        "SNPs (1.09 Gbp text, ~102 M rows = 0.8 GB, built on first use: ~10 min), 1.25M x 150bp reads per GPU"),
+    "c4real2": dict(kind="pangenome", pg="big2", mode=6, reads=1_250_000, read_len=150, sub=0.01,
+                    desc="the same with a 16.5 Mbp ancestor: 2.11 Gbp text, ~220 M rows = 1.8 GB (look-ahead copy 3.5 GB), ~6 min to build"),
     "tiny": dict(kind="synth", rows=200_000, mode=6, reads=20_000, read_len=150, sub=0.01,
                  desc="tiny plumbing workload"),
+    "tinypg": dict(kind="pangenome", pg="tiny", mode=6, reads=20_000, read_len=150, sub=0.01,
+                   desc="tiny plumbing workload on a real BWT (8 x 60 kbp pangenome): runs the default line's legs in tests"),
 }
-CACHE = os.environ.get("MOVI_BENCH_CACHE", "/tmp/movi_bench_cache")
+PG_BIG = dict(anc=8_500_000, genomes=64, snp=0.01, seed=12)   # ~102 M rows (n / r = 10.7): tools/build_index, ~10 min, ~16 GB of host memory
+PG_BIG2 = dict(anc=16_500_000, genomes=64, snp=0.01, seed=14)  # ~220 M rows: the largest text the 32-bit suffix array takes (2.11 Gbp), ~35 GB of host memory
+PG_TINY = dict(anc=60_000, genomes=8, snp=0.002, seed=13)     # tests: built in a second
+
+
+def pg_of(wl):
+    return {"big": PG_BIG, "big2": PG_BIG2, "tiny": PG_TINY}.get(wl.get("pg"), PG_C2)
+# where built pangenome indexes and their reads are kept: $MOVI_BENCH_CACHE, else a .bench_cache/ beside this file if one
+# travelled with the tree (a prebuilt c2 index saves the ~2 min single-threaded build per fresh box), else /tmp
+CACHE = os.environ.get("MOVI_BENCH_CACHE") or (os.path.join(ROOT, ".bench_cache") if os.path.isdir(os.path.join(ROOT, ".bench_cache"))
+                                                 else "/tmp/movi_bench_cache")
 
 
 def ensure_pangenome(wl, world, rank, barrier):
     """Rank 0 builds (once per box) the pangenome index and this workload's reads; returns the directory."""
     import subprocess
     tool = os.path.join(ROOT, "tools", "build_index")
+    PG = pg_of(wl)
     idx_dir = os.path.join(CACHE, "pg_%d_%d_%g_%d_m%d" % (PG["anc"], PG["genomes"], PG["snp"], PG["seed"], wl["mode"]))
     reads_file = os.path.join(idx_dir, "reads_%dx%d_%g.bin" % (wl["reads"] * world, wl["read_len"], wl["sub"]))
     if rank == 0:
@@ -108,26 +127,135 @@ def lookup_traffic(workload, rows, reads, read_len, kernel):
     return None, None
 
 
-def big_table_leg(torch, dev, stream, synth, movi_amd, cores, rows=1_000_000_000, steps=10, warmup=2):
-    """c4 on one GPU: tools/synth.c's 1 B-row regular-thresholds table (8 GB), 1.25 M x 150 bp reads.  Returns the
-    `big_table` object of the bench line.  The oracle is the checker here, never the thing measured."""
+def timed_steps(torch, dist, world, dev, stream, run, steps):
+    """Exactly `steps` calls of run() bracketed by barrier + synchronize on both sides.  Returns (seconds between the
+    barriers: the max over ranks, [every rank's own seconds up to its synchronize], this rank's mean kernel seconds from HIP
+    events recorded on the launch stream)."""
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for a, b in evs:
+        a.record(stream)
+        run()
+        b.record(stream)
+    torch.cuda.synchronize()
+    own = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    per = [own]
+    if world > 1:
+        t = torch.tensor([el, own], dtype=torch.float64, device=dev)
+        lst = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(lst, t)
+        el = max(float(x[0]) for x in lst)
+        per = [float(x[1]) for x in lst]
+    return el, per, sum(a.elapsed_time(b) for a, b in evs) / steps / 1e3
+
+
+def sum_over_ranks(torch, dist, world, dev, x):
+    if world == 1:
+        return float(x)
+    t = torch.tensor([float(x)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def pml_roofline(table_bytes, row_bytes, st, n_bases, kern_s, launch, traffic=None, tsrc=None):
+    """The `roofline` object of a PML leg: algorithmic bytes (row_bytes x (1 + f + s) + 1 + 2 per base) over the
+    kernel's mean launch time, against the HBM peak."""
+    f_bar, s_bar = st.fast_forwards / max(n_bases, 1), st.scans / max(n_bases, 1)
+    bpb = row_bytes * (1.0 + f_bar + s_bar) + 1 + 2
+    ach = bpb * n_bases / kern_s / 1e9
+    return {"bound": bound_of(table_bytes), "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_source": tsrc, "algorithmic_bytes_per_base": round(bpb, 3),
+            "kernel": launch["kernel"], "launch": launch, "kernel_ms_avg": kern_s * 1e3,
+            "lane_iterations_per_s": st.lane_steps / kern_s if st.wave_steps else None,
+            "rows_read_per_s": (1.0 + f_bar + s_bar) * n_bases / kern_s}
+
+
+def count_roofline(table_bytes, row_bytes, st, matched_bases, kern_s, launch):
+    """The same for the count query: B_count = 2 x row_bytes x (1 + f) + row_bytes x u + 1 per base the search extends over
+    (two LF walkers, u interval-shrink rows, one base in)."""
+    wb = max(int(matched_bases), 1)
+    f_bar, u_bar = st.fast_forwards / wb / 2.0, st.scans / wb
+    bpb = 2 * row_bytes * (1.0 + f_bar) + row_bytes * u_bar + 1
+    ach = bpb * wb / kern_s / 1e9
+    return {"bound": bound_of(table_bytes), "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "traffic": None, "algorithmic_bytes_per_base": round(bpb, 3), "matched_bases_per_step": wb,
+            "kernel": launch["kernel"], "launch": launch, "kernel_ms_avg": kern_s * 1e3}
+
+
+def table_bytes_walked(rows, row_bytes, launch):
+    """Bytes of the table the launch gathered from: the look-ahead copy is 16 B per row, the chain rows 32."""
+    return rows * {0: row_bytes, 1: 16, 2: 32}.get(int(launch.get("ahead") or 0), row_bytes)
+
+
+def send_to_rank(torch, dist, world, rank, dev, arr, dst):
+    """Rank 0 hands numpy array `arr` to rank `dst` (one broadcast per hand-over: works on every backend); returns it there."""
+    meta = [(arr.shape, str(arr.dtype)) if rank == 0 else None]
+    dist.broadcast_object_list(meta, src=0)
+    shape, dt = meta[0]
+    t = torch.from_numpy(arr.view(np.uint8).reshape(-1)).to(dev) if rank == 0 else \
+        torch.empty(int(np.prod(shape)) * np.dtype(dt).itemsize, dtype=torch.uint8, device=dev)
+    dist.broadcast(t, src=0)
+    return t.cpu().numpy().view(dt).reshape(shape) if rank == dst else None
+
+
+def draw_synth_reads(torch, dist, world, rank, dev, synth, six, n_reads, read_len, seed, sub, lens_of=None):
+    """Reads for a tools/synth.c table: rank 0 (the only rank that holds the table's host structure) draws every rank's
+    shard -- seed + rank -- and hands it over; no other rank synthesises anything."""
+    mine = None
+    for p in range(world):
+        if rank == 0:
+            lens = lens_of(p) if lens_of else None
+            b, o = synth.synth_reads(six, n_reads, read_len, seed=seed + p, sub_rate=sub, n_rate=0.001, lens=lens)
+        if world == 1:
+            return b, o
+        bb = send_to_rank(torch, dist, world, rank, dev, b if rank == 0 else None, p)
+        oo = send_to_rank(torch, dist, world, rank, dev, o if rank == 0 else None, p)
+        if rank == p:
+            mine = (bb, oo)
+    return mine
+
+
+def big_table_leg(torch, dist, world, rank, dev, local_rank, stream, synth, movi_amd, cores, rows=1_000_000_000, steps=10, warmup=2):
+    """c4: tools/synth.c's 1 B-row regular-thresholds table (8 GB), 1.25 M x 150 bp reads per GPU.  Rank 0 synthesises the
+    table and draws every rank's reads; the rows reach the other GPUs through ONE broadcast (RCCL).  Returns the `big_table`
+    object of the bench line on rank 0 (None elsewhere).  The oracle is the checker here, never the thing measured."""
     from oracle.oracle import Oracle
+    from movi_amd._lib import IndexDescC
     w = WORKLOADS["c4"]
+    n_reads, L = w["reads"], w["read_len"]
     t0 = time.time()
-    six = synth.synth_index(rows, mode=6, seed=SEED)
-    img = six.image()
+    six = img = meta = d_rows = None
+    if rank == 0:
+        six = synth.synth_index(rows, mode=6, seed=SEED)
+        img = six.image()
+        _, cdesc0, roff, rbytes = movi_amd.parse_index_image(img)
+        meta = {"cdesc": bytes(cdesc0)}
     t_gen = time.time() - t0
-    _, cdesc, roff, rbytes = movi_amd.parse_index_image(img)
     t0 = time.time()
-    d_rows = torch.from_numpy(img[roff: roff + rbytes]).to(dev)
+    if rank == 0:
+        d_rows = torch.from_numpy(img[roff: roff + rbytes]).to(dev)
+    torch.cuda.synchronize()
+    t_up = time.time() - t0
+    t_bc = 0.0
+    if world > 1:
+        from movi_amd import dist as md
+        tb = time.time()
+        meta, d_rows = md.broadcast_index(meta, d_rows, src=0, device=dev)       # the one collective of this path
+        torch.cuda.synchronize()
+        t_bc = time.time() - tb
+    cdesc = IndexDescC.from_buffer_copy(meta["cdesc"])
     cdesc.id_blocks = None
     cdesc.tally_ids = None
     cdesc.separator_thresholds, cdesc.separator_map = None, None
-    index = movi_amd.MoveIndex.from_device_rows(cdesc, d_rows.data_ptr(), device=dev.index or 0, keepalive=d_rows)
-    torch.cuda.synchronize()
-    t_up = time.time() - t0
-    n_reads, L = w["reads"], w["read_len"]
-    bases, offs = synth.synth_reads(six, n_reads, L, seed=SEED + 1, sub_rate=w["sub"], n_rate=0.001)
+    rbytes = int(d_rows.numel())
+    index = movi_amd.MoveIndex.from_device_rows(cdesc, d_rows.data_ptr(), device=local_rank, keepalive=d_rows)
+    bases, offs = draw_synth_reads(torch, dist, world, rank, dev, synth, six, n_reads, L, SEED + 1, w["sub"])
     n_bases = int(bases.size)
     d_bases = torch.from_numpy(bases).to(dev)
     d_offs = torch.from_numpy(offs.view(np.int64)).to(dev)
@@ -139,78 +267,151 @@ def big_table_leg(torch, dev, stream, synth, movi_amd, cores, rows=1_000_000_000
         run()
     torch.cuda.synchronize()
     st = index.last_stats(stream.cuda_stream)
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-    t0 = time.perf_counter()
-    for a, b in evs:
-        a.record(stream)
-        run()
-        b.record(stream)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    kern_s = sum(a.elapsed_time(b) for a, b in evs) / steps / 1e3
+    dt, per, kern_s = timed_steps(torch, dist, world, dev, stream, run, steps)
+    total = sum_over_ranks(torch, dist, world, dev, n_bases)
     launch = index.last_launch()
-    f_bar, s_bar = st.fast_forwards / n_bases, st.scans / n_bases
-    bpb = 8 * (1.0 + f_bar + s_bar) + 1 + 2
-    achieved = bpb * n_bases / kern_s / 1e9
     traffic, tsrc = lookup_traffic("c4", rows, n_reads, L, launch["kernel"])
-    out = {"workload": "c4", "description": w["desc"], "value": n_bases * steps / dt / 1e9, "unit": "Gbases/s", "steps": steps,
-           "warmup": warmup, "ms_per_step": dt / steps * 1e3, "rows": rows, "table_bytes": int(rbytes), "reads_per_gpu": n_reads,
-           "read_len": L, "fast_forwards_per_base": round(f_bar, 4), "scans_per_base": round(s_bar, 4),
-           "algorithmic_bytes_per_base": round(bpb, 3), "errors": int(st.errors),
-           "index_gen_s": round(t_gen, 1), "index_upload_s": round(t_up, 2),
-           "roofline": {"bound": bound_of(rbytes), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
-                        "kernel": launch["kernel"], "launch": launch, "kernel_ms_avg": kern_s * 1e3,
-                        "gathers_per_s": (1.0 + f_bar + s_bar) * n_bases / kern_s,
-                        "dram_frac_of_peak": (traffic / kern_s / 1e9 / HBM_PEAK_GBS) if traffic else None}}
-    # parity: three slices of the batch against the oracle on the same 8 GB image, PMLs and counters
-    t0 = time.time()
-    cpu = Oracle(img)
-    got_all = d_out.cpu().numpy().view(np.uint16)
-    ok, checked = True, 0
-    for lo in (0, n_reads // 2 - 1000, n_reads - 2000):
-        hi = lo + 2000
-        sb = bases[int(offs[lo]): int(offs[hi])]
-        so = offs[lo: hi + 1] - offs[lo]
-        exp, eff, esc = cpu.pml_batch(sb, so, threads=cores)
-        ok = ok and bool((got_all[int(offs[lo]): int(offs[hi])] == exp).all())
-        # the same slice alone through the engine: its fast-forward / scan counters must equal the oracle's
-        sl = torch.from_numpy(np.ascontiguousarray(so).view(np.int64)).to(dev)
-        index.pml_device(d_bases.data_ptr() + int(offs[lo]), sl.data_ptr(), 2000, int(sb.size), d_out.data_ptr(), d_err.data_ptr(),
-                         stream.cuda_stream, 0)
-        sst = index.last_stats(stream.cuda_stream)
-        ok = ok and sst.fast_forwards == eff and sst.scans == esc and sst.errors == 0
-        ok = ok and bool((d_out[: sb.size].cpu().numpy().view(np.uint16) == exp).all())
-        checked += 2000
+    roof = pml_roofline(table_bytes_walked(rows, 8, launch), 8, st, n_bases, kern_s, launch, traffic, tsrc)
+    roof["dram_frac_of_peak"] = (traffic / kern_s / 1e9 / HBM_PEAK_GBS) if traffic else None
+    out = {"workload": "c4", "description": w["desc"], "value": total * steps / dt / 1e9, "unit": "Gbases/s", "n_gpus": world, "steps": steps,
+           "warmup": warmup, "ms_per_step": dt / steps * 1e3, "rank_seconds": [round(x, 4) for x in per],
+           "rows": rows, "table_bytes": int(rbytes), "reads_per_gpu": n_reads,
+           "read_len": L, "fast_forwards_per_base": round(st.fast_forwards / n_bases, 4), "scans_per_base": round(st.scans / n_bases, 4),
+           "simt_efficiency": round(st.lane_steps / (64.0 * st.wave_steps), 4) if st.wave_steps else None,
+           "iterations_per_base": round(st.lane_steps / n_bases, 4) if st.wave_steps else None,
+           "algorithmic_bytes_per_base": roof["algorithmic_bytes_per_base"], "errors": int(st.errors),
+           "index_gen_s": round(t_gen, 1), "index_upload_s": round(t_up, 2), "index_broadcast_s": round(t_bc, 3),
+           "roofline": roof}
     # BASELINE config 5's query on the same resident rows (a blocked-thresholds file of this table expands to exactly them at
-    # upload: tests/test_big_table_gpu.py runs that form): --count, timed and checked on the same three slices
+    # upload: tests/test_big_table_gpu.py runs that form): --count
     d_m = torch.zeros(n_reads, dtype=torch.int64, device=dev)
     d_c = torch.zeros(n_reads, dtype=torch.int64, device=dev)
     runc = lambda: index.count_device(d_bases.data_ptr(), d_offs.data_ptr(), n_reads, n_bases, d_m.data_ptr(), d_c.data_ptr(),
                                       d_err.data_ptr(), stream.cuda_stream, 0)
     runc()
     torch.cuda.synchronize()
-    tc0 = time.perf_counter()
-    for _ in range(5):
-        runc()
-    torch.cuda.synchronize()
-    dtc = time.perf_counter() - tc0
-    gm, gc = d_m.cpu().numpy().view(np.uint64), d_c.cpu().numpy().view(np.uint64)
-    cok = True
-    for lo in (0, n_reads // 2 - 1000, n_reads - 2000):
-        hi = lo + 2000
-        em, ec = cpu.count_batch(bases[int(offs[lo]): int(offs[hi])], offs[lo: hi + 1] - offs[lo], threads=cores)
-        cok = cok and bool((gm[lo:hi] == em).all() and (gc[lo:hi] == ec).all())
-    out["count"] = {"value": n_bases * 5 / dtc / 1e9, "unit": "Gbases/s (read bases)", "steps": 5, "ms_per_step": dtc / 5 * 1e3,
-                    "kernel": index.last_launch()["kernel"], "matched_bases_per_read": round(float(gm.mean()), 2),
-                    "parity_sample_ok": cok}
-    ok = ok and cok
-    out["parity_sample_ok"] = ok
-    out["parity_sample"] = "reads [0,2000), [%d,%d), [%d,%d) vs oracle/movi_oracle.c on the same image: PMLs bit-exact, fast-forward and scan counters equal; count: matched lengths and counts equal (%.1f s)" % (
-        n_reads // 2 - 1000, n_reads // 2 + 1000, n_reads - 2000, n_reads, time.time() - t0)
-    cpu.close()
+    stc = index.last_stats(stream.cuda_stream)
+    dtc, perc, kern_c = timed_steps(torch, dist, world, dev, stream, runc, 5)
+    claunch = index.last_launch()
+    out["count"] = {"value": total * 5 / dtc / 1e9, "unit": "Gbases/s (read bases)", "steps": 5, "ms_per_step": dtc / 5 * 1e3,
+                    "rank_seconds": [round(x, 4) for x in perc], "kernel": claunch["kernel"],
+                    "roofline": count_roofline(table_bytes_walked(rows, 8, claunch), 8, stc, int(d_m.sum().item()), kern_c, claunch)}
+    if rank == 0:
+        # parity: three slices of rank 0's batch against the oracle on the same image, PMLs, counters and counts
+        t0 = time.time()
+        cpu = Oracle(img)
+        run()
+        torch.cuda.synchronize()
+        got_all = d_out.cpu().numpy().view(np.uint16)
+        gm, gc = d_m.cpu().numpy().view(np.uint64), d_c.cpu().numpy().view(np.uint64)
+        ok, cok = True, True
+        for lo in (0, n_reads // 2 - 1000, n_reads - 2000):
+            hi = lo + 2000
+            sb = bases[int(offs[lo]): int(offs[hi])]
+            so = offs[lo: hi + 1] - offs[lo]
+            exp, eff, esc = cpu.pml_batch(sb, so, threads=cores)
+            ok = ok and bool((got_all[int(offs[lo]): int(offs[hi])] == exp).all())
+            # the same slice alone through the engine: its fast-forward / scan counters must equal the oracle's
+            sl = torch.from_numpy(np.ascontiguousarray(so).view(np.int64)).to(dev)
+            index.pml_device(d_bases.data_ptr() + int(offs[lo]), sl.data_ptr(), 2000, int(sb.size), d_out.data_ptr(), d_err.data_ptr(),
+                             stream.cuda_stream, 0)
+            sst = index.last_stats(stream.cuda_stream)
+            ok = ok and sst.fast_forwards == eff and sst.scans == esc and sst.errors == 0
+            ok = ok and bool((d_out[: sb.size].cpu().numpy().view(np.uint16) == exp).all())
+            em, ec = cpu.count_batch(sb, so, threads=cores)
+            cok = cok and bool((gm[lo:hi] == em).all() and (gc[lo:hi] == ec).all())
+        out["count"]["matched_bases_per_read"] = round(float(gm.mean()), 2)
+        out["count"]["parity_sample_ok"] = cok
+        out["parity_sample_ok"] = ok and cok
+        out["parity_sample"] = "rank 0's reads [0,2000), [%d,%d), [%d,%d) vs oracle/movi_oracle.c on the same image: PMLs bit-exact, fast-forward and scan counters equal; count: matched lengths and counts equal (%.1f s)" % (
+            n_reads // 2 - 1000, n_reads // 2 + 1000, n_reads - 2000, n_reads, time.time() - t0)
+        cpu.close()
     index.close()
-    return out
+    return out if rank == 0 else None
+
+
+def long_reads_leg(torch, dist, world, rank, dev, stream, index, idx_dir, rows, row_bytes, n3, with_few, PG):
+    """c3 on the resident index: n3 x 10 kbp reads per GPU (8 % substitutions; every rank draws its own from the text), plain PML
+    and -- BASELINE config 3 is "PML + --classify" -- with the classification bins fused into the walk (vector + bins, bins
+    only), each with its roofline object.  Returns the `long_reads` (and `few_long_reads`) objects on rank 0."""
+    import subprocess
+    w3 = WORKLOADS["c3"]
+    L3 = w3["read_len"]
+    tool = os.path.join(ROOT, "tools", "build_index")
+    text = os.path.join(idx_dir, "text.bin")
+    if rank == 0 and not os.path.exists(text):
+        subprocess.check_call([tool, "pangenome", str(PG["anc"]), str(PG["genomes"]), str(PG["snp"]), str(PG["seed"]), "6",
+                               idx_dir, "text-only"], stderr=subprocess.DEVNULL)
+    if world > 1:
+        dist.barrier()
+    rf = os.path.join(idx_dir, "reads_%dx%d_%g%s.bin" % (n3, L3, w3["sub"], "" if rank == 0 else "_rank%d" % rank))
+    if not os.path.exists(rf):
+        subprocess.check_call([tool, "reads", text, str(n3), str(L3), str(w3["sub"]), str(PG["seed"] + 1000 * rank), rf + ".tmp%d" % rank])
+        os.rename(rf + ".tmp%d" % rank, rf)
+    b3 = torch.from_numpy(np.fromfile(rf, np.uint8, count=n3 * L3)).to(dev)
+    if rank != 0:
+        os.remove(rf)
+    o3 = torch.from_numpy((np.arange(n3 + 1, dtype=np.uint64) * np.uint64(L3)).view(np.int64)).to(dev)
+    out3 = torch.empty(n3 * L3, dtype=torch.int16, device=dev)
+    err3 = torch.zeros(n3, dtype=torch.uint8, device=dev)
+    d_a = torch.zeros(n3, dtype=torch.int32, device=dev)
+    d_b = torch.zeros(n3, dtype=torch.int32, device=dev)
+    d_s = torch.zeros(n3, dtype=torch.int64, device=dev)
+    total = sum_over_ranks(torch, dist, world, dev, n3 * L3)
+    k3 = 3
+    res, verdicts = {}, {}
+    for cm in (0, 1, 2):
+        if cm == 0:
+            run3 = lambda: index.pml_device(b3.data_ptr(), o3.data_ptr(), n3, n3 * L3, out3.data_ptr(), err3.data_ptr(), stream.cuda_stream, 0)
+        else:
+            run3 = lambda cm=cm: index.pml_classify_device(b3.data_ptr(), o3.data_ptr(), n3, n3 * L3, 150, 8, out3.data_ptr() if cm == 1 else 0,
+                                                           d_a.data_ptr(), d_b.data_ptr(), d_s.data_ptr(), err3.data_ptr(), stream.cuda_stream, 0)
+        run3()
+        torch.cuda.synchronize()
+        st3 = index.last_stats(stream.cuda_stream)
+        dt3, per3, kern3 = timed_steps(torch, dist, world, dev, stream, run3, k3)
+        launch = index.last_launch()
+        leg = {"value": total * k3 / dt3 / 1e9, "unit": "Gbases/s", "steps": k3, "ms_per_step": dt3 / k3 * 1e3,
+               "rank_seconds": [round(x, 4) for x in per3], "fused_classify": cm,
+               "simt_efficiency": round(st3.lane_steps / (64.0 * st3.wave_steps), 4) if st3.wave_steps else None,
+               "iterations_per_base": round(st3.lane_steps / (n3 * L3), 4) if st3.wave_steps else None,
+               "fast_forwards_per_base": round(st3.fast_forwards / (n3 * L3), 4), "scans_per_base": round(st3.scans / (n3 * L3), 4),
+               "errors": int(st3.errors), "segments": int(st3.segments), "rewalked_reads": int(st3.rewalked),
+               "roofline": pml_roofline(table_bytes_walked(rows, row_bytes, launch), row_bytes, st3, n3 * L3, kern3, launch)}
+        if cm:
+            verdicts[cm] = (d_a.clone(), d_b.clone(), d_s.clone())
+        res[cm] = leg
+    lr = dict(res[0])
+    lr.update({"workload": "c3", "description": w3["desc"], "n_gpus": world, "reads_per_gpu": n3, "read_len": L3,
+               "kernel": res[0]["roofline"]["kernel"], "launch": res[0]["roofline"]["launch"],
+               "classify_vector_and_bins": res[1], "classify_bins_only": res[2],
+               "classify_bins_agree": bool(all(torch.equal(x, y) for x, y in zip(verdicts[1], verdicts[2])))})
+    few = None
+    if with_few and world == 1:
+        # the same reads, a quarter of them: too few walks to fill the GPU with one lane per read -- the shape the
+        # segment-parallel walk is for (DESIGN.md section 3); both ways, same launch otherwise
+        n4 = n3 // 4
+        few = {"workload": "first %d of the c3 reads" % n4, "unit": "Gbases/s"}
+        for name, sl in (("one_lane_per_read", 0), ("segment_parallel", 2048)):
+            index.set_option("seg_len", sl)
+            run4 = lambda: index.pml_device(b3.data_ptr(), o3.data_ptr(), n4, n4 * L3, out3.data_ptr(), err3.data_ptr(),
+                                            stream.cuda_stream, 0)
+            run4()
+            torch.cuda.synchronize()
+            st4 = index.last_stats(stream.cuda_stream)
+            t0 = time.perf_counter()
+            for _ in range(k3):
+                run4()
+            torch.cuda.synchronize()
+            few[name] = round(n4 * L3 * k3 / (time.perf_counter() - t0) / 1e9, 2)
+            few[name + "_segments"] = int(st4.segments)
+            if sl == 0:
+                keep4 = out3[: n4 * L3].clone()
+            else:
+                few["identical"] = bool(torch.equal(keep4, out3[: n4 * L3]))
+                del keep4
+        index.set_option("seg_len", 2048)
+    return (lr, few) if rank == 0 else (None, None)
 
 
 def write_fasta(path, reads2d):
@@ -351,6 +552,8 @@ def main():
     ap.add_argument("--no-big-table", action="store_true", help="skip the 1 B-row (8 GB, HBM-resident) leg that the default run "
                     "(c2, N=1) appends as `big_table` (BASELINE config 4's per-GPU shard, oracle-checked)")
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 5 s of back-to-back steps appended as `sustained`")
+    ap.add_argument("--big-rows", type=int, default=1_000_000_000, help="rows of the `big_table` leg's table (tests shrink it)")
+    ap.add_argument("--long-reads", type=int, default=0, help="reads per GPU of the `long_reads` leg (default: c3's 100 000; tests shrink it)")
     ap.add_argument("--quick", action="store_true", help="the timed region only: no cpu_baseline, long_reads, host_path, sustained, big_table (A/B sweeps)")
     args = ap.parse_args()
     if args.quick:
@@ -425,8 +628,8 @@ def main():
             fdesc = movi_amd.parse_index_image(file_img)[0]
             mode, row_bytes = fdesc.mode, fdesc.row_bytes
             wl["rows"], wl["mode"] = fdesc.r, fdesc.mode
-    else:
-        six = synth.synth_index(wl["rows"], mode=mode, seed=SEED)
+    elif rank == 0:
+        six = synth.synth_index(wl["rows"], mode=mode, seed=SEED)      # rank 0 only: the other ranks get the rows by broadcast, their reads from rank 0
     t_index_gen = time.time() - t0
     t0 = time.time()
     meta, d_rows = None, None
@@ -492,11 +695,13 @@ def main():
         bases = np.fromfile(reads_path, np.uint8, count=per * L, offset=rank * per * L)
         offs = (np.arange(per + 1, dtype=np.uint64) * np.uint64(L))
     else:
+        def lens_of(p):
+            g = np.random.default_rng(SEED + 77 + p)
+            return np.clip(g.lognormal(np.log(wl["read_len"]) - 0.08, 0.4, size=wl["reads"]), 20, 5 * wl["read_len"]).astype(np.uint64)
+        bases, offs = draw_synth_reads(torch, dist, world, rank, dev, synth, six, wl["reads"], wl["read_len"], SEED + 1, wl["sub"],
+                                       lens_of if args.ragged else None)
         if args.ragged:
-            g = np.random.default_rng(SEED + 77 + rank)
-            lens = np.clip(g.lognormal(np.log(wl["read_len"]) - 0.08, 0.4, size=wl["reads"]), 20, 5 * wl["read_len"]).astype(np.uint64)
-        bases, offs = synth.synth_reads(six, wl["reads"], wl["read_len"], seed=SEED + 1 + rank,
-                                        sub_rate=wl["sub"], n_rate=0.001, lens=lens)
+            lens = (offs[1:] - offs[:-1]).astype(np.uint64)
     t_reads_gen = time.time() - t0
     n_reads, n_bases = wl["reads"], int(bases.size)
     d_bases = torch.from_numpy(bases).to(dev)
@@ -541,30 +746,9 @@ def main():
     if st.errors:
         raise SystemExit("kernel flagged %d reads with invariant violations" % st.errors)
 
-    # ---- timed region: exactly K steps, barrier + synchronize on both sides
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t_start = time.perf_counter()
-    for a, b in evs:
-        a.record(stream)
-        step()
-        b.record(stream)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t_start
-    kern_ms = [a.elapsed_time(b) for a, b in evs]
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        tot = torch.tensor([float(n_bases)], dtype=torch.float64, device=dev)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        total_bases_per_step = float(tot.item())
-    else:
-        total_bases_per_step = float(n_bases)
+    # ---- timed region: exactly K steps, barrier + synchronize on both sides, max over ranks
+    elapsed, rank_seconds, avg_kern_s = timed_steps(torch, dist, world, dev, stream, step, args.steps)
+    total_bases_per_step = sum_over_ranks(torch, dist, world, dev, n_bases)
 
     # which kernel the library's launch policy picked for this batch, and with which shape: asked, not assumed
     launch = index.last_launch()
@@ -581,7 +765,6 @@ def main():
         # every base: two LF walkers (fast-forwards counted over both) + interval-shrink rows + 1 base in + 2 out
         f_bar, s_bar = st.fast_forwards / max(n_bases, 1) / 2.0, st.scans / max(n_bases, 1)
         bytes_per_base = 2 * row_bytes * (1.0 + f_bar) + row_bytes * s_bar + 1 + 2
-    avg_kern_s = (sum(kern_ms) / len(kern_ms)) / 1e3
     achieved_gbs = bytes_per_base * work_bases / avg_kern_s / 1e9
     value = total_bases_per_step * args.steps / elapsed / 1e9       # Gbases/s, whole job
     # ---- >= 5 s of the same step back to back (default run only, after the timed region, never part of `value`): the
@@ -611,7 +794,8 @@ def main():
         "metric": {"pml": "PML", "count": "count", "zml": "ZML"}[args.query] + " query Gbases/s on " +
                   {6: "regular-thresholds", 8: "blocked-thresholds", 7: "sampled-thresholds"}[mode] + " index",
         "value": value, "unit": "Gbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": elapsed / args.steps * 1e3, "rank_seconds": [round(x, 4) for x in rank_seconds],
+        "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": args.workload, "description": wl["desc"], "rows": wl["rows"], "mode": mode,
                    "reads_per_gpu": n_reads, "read_len": wl["read_len"], "bases_per_step_per_gpu": n_bases,
@@ -624,16 +808,22 @@ def main():
                    "segments": int(st.segments), "rewalked_reads": int(st.rewalked), "seg_len": args.seg_len,
                    "query": args.query, "fused_classify": args.classify, "matched_bases_per_step": work_bases, "pml_variant": args.variant, "kmer_k": args.kmer_k, "ahead_rows": args.ahead_rows, "ftab_k": args.ftab_k, "ragged": args.ragged, "waves_per_cu": args.waves_per_cu, "block_threads": args.block_threads, "index_gen_s": round(t_index_gen, 2),
                    "index_upload_s": round(t_index_upload, 2), "index_broadcast_s": round(t_bcast, 3),
-                   "reads_gen_s": round(t_reads_gen, 2)},
+                   "reads_gen_s": round(t_reads_gen, 2),
+                   "no_ff_share": round(index.info("ahead_no_ff"), 4), "derived_table_bytes": int(index.info("derived_bytes"))},
         "rccl_ranks": rccl_ranks, "index_broadcast_s": round(t_bcast, 4),
-        "roofline": {"bound": bound_of(wl["rows"] * (16 if launch.get("ahead") else row_bytes)),   # the bytes the walk gathers from: the look-ahead copy is 16 B per row
+        # bound: by the bytes the walk gathers from -- the look-ahead copy is 16 B per row -- plus the 256 MB top-of-walk /
+        # interval table every read looks up once (together they do NOT fit the 256 MiB Infinity Cache on c2: "hbm")
+        "roofline": {"bound": bound_of(table_bytes_walked(wl["rows"], row_bytes, launch) + ((16 << 24) if args.query != "zml" and args.kmer_k != 0 else 0)),
+                     "working_set_bytes": table_bytes_walked(wl["rows"], row_bytes, launch) + ((16 << 24) if args.query != "zml" and args.kmer_k != 0 else 0),
                      "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": traffic_src,
                      "kernel": launch["kernel"], "launch": launch,
                      "kernel_ms_avg": avg_kern_s * 1e3,
-                     "gathers_per_s": ((1.0 + f_bar + s_bar) * n_bases if args.query == "pml"
-                                       else (2.0 * (1.0 + f_bar) + s_bar) * work_bases) / avg_kern_s},
+                     # iterations of the lane automata (each one gather of a row window) and table rows the reference's walk reads
+                     "lane_iterations_per_s": st.lane_steps / avg_kern_s if st.wave_steps else None,
+                     "rows_read_per_s": ((1.0 + f_bar + s_bar) * n_bases if args.query == "pml"
+                                         else (2.0 * (1.0 + f_bar) + s_bar) * work_bases) / avg_kern_s},
     }
 
     if sustained is not None:
@@ -689,67 +879,22 @@ def main():
         oracle_sample = exp
         if not result["parity_sample_ok"]:
             print("PARITY FAILURE on the cpu_baseline sample", file=sys.stderr)
-    # ---- secondary figure, default run only (N == 1, after the timed region, never part of `value`): BASELINE config 3,
-    # 100 k x 10 kbp reads on the same resident index -- the latency-bound shape, served by the lane state machine
-    if (rank == 0 and world == 1 and args.workload == "c2" and args.query == "pml" and not args.classify
-            and not args.no_long_reads and not args.from_dir and reads_path and args.variant < 0):
+    # ---- secondary figure, default run (any N, after the timed region, never part of `value`): BASELINE config 3,
+    # 100 k x 10 kbp reads per GPU on the same resident index, plain and with --classify fused into the walk
+    legs_run = (args.workload in ("c2", "tinypg") and args.query == "pml" and not args.classify and not args.from_dir and args.variant < 0)
+    if legs_run and not args.no_long_reads and reads_path:
         try:
-            import subprocess
-            w3 = WORKLOADS["c3"]
-            rf = os.path.join(idx_dir, "reads_%dx%d_%g.bin" % (w3["reads"], w3["read_len"], w3["sub"]))
-            if not os.path.exists(rf):
-                subprocess.check_call([os.path.join(ROOT, "tools", "build_index"), "reads", os.path.join(idx_dir, "text.bin"),
-                                       str(w3["reads"]), str(w3["read_len"]), str(w3["sub"]), str(PG["seed"]), rf + ".tmp"])
-                os.rename(rf + ".tmp", rf)
             del d_out, d_bases
             torch.cuda.empty_cache()
-            L3, n3 = w3["read_len"], w3["reads"]
-            b3 = torch.from_numpy(np.fromfile(rf, np.uint8, count=n3 * L3)).to(dev)
-            o3 = torch.from_numpy((np.arange(n3 + 1, dtype=np.uint64) * np.uint64(L3)).view(np.int64)).to(dev)
-            out3 = torch.empty(n3 * L3, dtype=torch.int16, device=dev)
-            err3 = torch.zeros(n3, dtype=torch.uint8, device=dev)
-            run3 = lambda: index.pml_device(b3.data_ptr(), o3.data_ptr(), n3, n3 * L3, out3.data_ptr(), err3.data_ptr(),
-                                            stream.cuda_stream, 0)
-            run3()
-            torch.cuda.synchronize()
-            st3 = index.last_stats(stream.cuda_stream)
-            k3 = 3
-            t0 = time.perf_counter()
-            for _ in range(k3):
-                run3()
-            torch.cuda.synchronize()
-            dt3 = time.perf_counter() - t0
-            result["long_reads"] = {"workload": "c3", "description": w3["desc"], "value": n3 * L3 * k3 / dt3 / 1e9,
-                                    "unit": "Gbases/s", "steps": k3, "ms_per_step": dt3 / k3 * 1e3, "reads_per_gpu": n3,
-                                    "read_len": L3, "kernel": index.last_launch()["kernel"], "launch": index.last_launch(),
-                                    "fast_forwards_per_base": round(st3.fast_forwards / (n3 * L3), 4),
-                                    "scans_per_base": round(st3.scans / (n3 * L3), 4), "errors": int(st3.errors),
-                                    "segments": int(st3.segments), "rewalked_reads": int(st3.rewalked)}
-            # the same reads, a quarter of them: too few walks to fill the GPU with one lane per read -- the shape the
-            # segment-parallel walk is for; both ways, same launch otherwise
-            n4 = n3 // 4
-            few = {"workload": "first %d of the c3 reads" % n4, "unit": "Gbases/s"}
-            for name, sl in (("one_lane_per_read", 0), ("segment_parallel", 2048)):
-                index.set_option("seg_len", sl)
-                run4 = lambda: index.pml_device(b3.data_ptr(), o3.data_ptr(), n4, n4 * L3, out3.data_ptr(), err3.data_ptr(),
-                                                stream.cuda_stream, 0)
-                run4()
-                torch.cuda.synchronize()
-                st4 = index.last_stats(stream.cuda_stream)
-                t0 = time.perf_counter()
-                for _ in range(k3):
-                    run4()
-                torch.cuda.synchronize()
-                few[name] = round(n4 * L3 * k3 / (time.perf_counter() - t0) / 1e9, 2)
-                few[name + "_segments"] = int(st4.segments)
-                if sl == 0:
-                    keep4 = out3[: n4 * L3].clone()
-                else:
-                    few["identical"] = bool(torch.equal(keep4, out3[: n4 * L3]))
-                    del keep4
-            index.set_option("seg_len", 2048 if args.seg_len < 0 else args.seg_len)
-            result["few_long_reads"] = few
+            lr, few = long_reads_leg(torch, dist, world, rank, dev, stream, index, idx_dir, wl["rows"], row_bytes,
+                                     args.long_reads or WORKLOADS["c3"]["reads"], with_few=not args.long_reads, PG=pg_of(wl))
+            if rank == 0:
+                result["long_reads"] = lr
+                if few:
+                    result["few_long_reads"] = few
         except Exception as e:                            # noqa: BLE001 -- never lose the headline line to the extra
+            if world > 1:
+                raise
             result["long_reads"] = {"error": repr(e)[:200]}
     # ---- PCIe-inclusive rate of the boundary's host entry point ("pre-parsed reads in pinned host memory to
     # PMLs in pinned host memory"), default run only, after the timed region, never part of `value`: the same batch
@@ -797,23 +942,27 @@ def main():
     if default_run and not args.no_cpu_baseline and reads_path:
         try:
             w3 = WORKLOADS["c3"]
-            rf = os.path.join(idx_dir, "reads_%dx%d_%g.bin" % (w3["reads"], w3["read_len"], w3["sub"]))
-            r10k = (np.fromfile(rf, np.uint8, count=w3["reads"] * w3["read_len"]), w3["read_len"]) if os.path.exists(rf) else (None, 0)
+            rf = os.path.join(idx_dir, "reads_%dx%d_%g.bin" % (args.long_reads or w3["reads"], w3["read_len"], w3["sub"]))
+            r10k = (np.fromfile(rf, np.uint8), w3["read_len"]) if os.path.exists(rf) else (None, 0)
             result["cli_path"] = cli_path_leg(idx_dir, (bases, wl["read_len"]), r10k)
         except Exception as e:                            # noqa: BLE001
             result["cli_path"] = {"error": repr(e)[:300]}
     # ---- BASELINE config 4's per-GPU shard (default run only, after the timed region, never part of `value`): the walk on
     # a 1 B-row / 8 GB table -- HBM-resident, 30-bit row ids, byte offsets beyond 2^32 -- with its own roofline, and three
     # slices of the batch (first / middle / last 2000 reads) compared with the oracle bit for bit, counters included
-    if default_run and not args.no_big_table:
+    if legs_run and not args.no_big_table:
         try:
             del index, d_rows
             torch.cuda.empty_cache()
-            result["big_table"] = big_table_leg(torch, dev, stream, synth, movi_amd, usable_cores())
-            if result["big_table"].get("parity_sample_ok") is False:
-                result["parity_sample_ok"] = False
-                print("PARITY FAILURE on the big_table oracle slices", file=sys.stderr)
+            bt = big_table_leg(torch, dist, world, rank, dev, local_rank, stream, synth, movi_amd, usable_cores(), rows=args.big_rows)
+            if rank == 0:
+                result["big_table"] = bt
+                if bt.get("parity_sample_ok") is False:
+                    result["parity_sample_ok"] = False
+                    print("PARITY FAILURE on the big_table oracle slices", file=sys.stderr)
         except Exception as e:                            # noqa: BLE001 -- an extra, never worth the headline line
+            if world > 1:
+                raise
             result["big_table"] = {"error": repr(e)[:300]}
     parity_failed = rank == 0 and result.get("parity_sample_ok") is False
     if parity_failed:

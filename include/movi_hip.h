@@ -235,6 +235,14 @@ typedef struct movi_launch_info {
 } movi_launch_info_t;
 int movi_last_launch(const movi_index_t *ix, movi_launch_info_t *info);
 
+/* What the handle holds in HBM besides the row table, and what its builders measured (no reference counterpart; the
+ * derived tables of "kmer_k" / "ahead_rows" / "ftab_k" are built by the first query that can use them, so this is how a
+ * caller sees their cost).  Keys: "rows_bytes" (the resident row table), "kmer_bytes", "ftab_bytes", "ahead_rows_bytes",
+ * "chain_rows_bytes", "ckpt_bytes" (0 = not built), "derived_bytes" (their sum), "ahead_no_ff" (share of the table's BWT
+ * positions that reach their LF target without a fast-forward, tallied when the look-ahead rows are built: 0.83 on the
+ * pangenome BWT, 0.51 on a uniformly random run sequence; -1 = not tallied yet).  Unknown key: MOVI_ERR_ARG. */
+int movi_index_info(const movi_index_t *ix, const char *key, double *value);
+
 /* ---- binary classification bins ------------------------------------------------ */
 
 /* The per-read reduction of Classifier::classify (src/classifier.cpp:99-143) over PML vectors

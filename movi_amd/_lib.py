@@ -96,6 +96,7 @@ SYMBOLS = {
                                 C.POINTER(QueryStatsC)]),
     "movi_last_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(QueryStatsC)]),
     "movi_last_launch": (C.c_int, [C.c_void_p, C.POINTER(LaunchInfoC)]),
+    "movi_index_info": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]),
     "movi_count_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "movi_count_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,

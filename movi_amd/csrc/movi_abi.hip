@@ -98,6 +98,8 @@ struct movi_index {
     uint8_t *d_rows2 = nullptr;      // look-ahead rows ("ahead_rows" option), 16 bytes per row
     uint8_t *d_rows3 = nullptr;      // chain rows: entries that look two rows ahead ("ahead_rows" 2)
     double ahead_no_ff = 0.0;        // share of the table's positions that arrive at their LF target without a fast-forward (build_ahead)
+    bool ahead_tallied = false;
+    bool count_declined_ahead = false;   // the count query's auto-build found the copy not worth keeping (rows2_count == 0): do not build it per call
     int ahead_auto = 1;              // 1: the first PML query builds them when the table is small enough (ahead_rows_fit)
     uint4 *d_ftab = nullptr;         // the count query's interval table ("ftab_k" option), 16 << 2K bytes
     int ftab_auto = 12;              // K of the table the first count query builds by itself (0 = none)
@@ -760,8 +762,37 @@ static int build_kmer(movi_index *ix, uint32_t K, hipStream_t s) {
 // two extra 16-byte loads per step cost more translation requests than the skipped rows save
 // (profiles/r03_ahead_rows_threshold.txt).  "ahead_rows" 1 builds them for any table.
 constexpr uint64_t kAheadAutoBytes = 1600ull << 20;      // of the copy: up to 100 M rows
+// Round 4: the size rule was set on the worst case.  On the BWT of real text most positions reach their LF target without
+// a fast-forward (0.83 on the 14 M-row pangenome, 0.75 on a 113 M-row one with 1 % divergence, 0.51 on a uniformly random
+// run sequence), entries are used far more often, and the copy pays well beyond 100 M rows: 113.5 M rows (1.8 GB copy)
+// 42.3 -> 53.5 Gbases/s (profiles/r04_real_100M.txt).  So above kAheadAutoBytes the table's own statistic decides -- tallied
+// over a sample of its rows before anything is built -- up to the size a real table was measured at.
+constexpr double kAheadShare = 0.67;                     // (the count query's line, kAheadCountRatio: same statistic)
+constexpr uint64_t kAheadStatBytes = 4096ull << 20;      // of the copy: up to 256 M rows
 static bool ahead_eligible(const movi_index *ix) {
     return ix->kmode == MOVI_MODE_REGULAR_THRESHOLDS && ix->desc.r >= 8 && (ix->desc.r >> 36) == 0;
+}
+// Should the first query build the look-ahead rows by itself?
+static bool ahead_wanted(movi_index *ix, hipStream_t s) {
+    const uint64_t bytes = ahead_rows_bytes(ix->desc.r);
+    if (bytes <= kAheadAutoBytes) return true;
+    if (bytes > kAheadStatBytes) return false;
+    if (!ix->ahead_tallied) {
+        unsigned long long *d_tally = nullptr, h_tally[2] = {0, 0};
+        hipError_t e = hipMalloc(&d_tally, 16);
+        if (e == hipSuccess) e = hipMemsetAsync(d_tally, 0, 16, s);
+        if (e == hipSuccess) e = tally_no_ff_share(ix->kmode, ix->dev, 16, d_tally, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(h_tally, d_tally, 16, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (d_tally) (void)hipFree(d_tally);
+        if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+        ix->ahead_no_ff = h_tally[1] ? (double)h_tally[0] / (double)h_tally[1] : 0.0;
+        ix->ahead_tallied = true;
+    }
+    if (ix->ahead_no_ff < kAheadShare) return false;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return free_b > bytes + (2ull << 30);                   // (room for the copy and the query's own buffers)
 }
 // by_itself: built by the size policy, not on request -- then the count query uses the copy only where the table's own
 // statistic says it pays (DevIndex::rows2_count)
@@ -780,6 +811,7 @@ static int build_ahead(movi_index *ix, hipStream_t s, bool by_itself) {
     ix->dev.rows2 = ix->d_rows2;
     ix->dev.rows2_tail = tail;
     ix->ahead_no_ff = h_tally[1] ? (double)h_tally[0] / (double)h_tally[1] : 0.0;
+    ix->ahead_tallied = true;
     ix->dev.rows2_count = (!by_itself || ix->ahead_no_ff >= kAheadCountRatio) ? 1u : 0u;
     return MOVI_OK;
 }
@@ -986,8 +1018,7 @@ static int ml_device(bool zml, movi_index_t *ix, const uint8_t *d_bases, const u
             ix->kmer_auto = 0;
         }
     }
-    if (!zml && ix->ahead_auto > 0 && !ix->d_rows2 && ahead_eligible(ix) && cls.log_ff == nullptr &&
-        ahead_rows_bytes(ix->desc.r) <= kAheadAutoBytes) {
+    if (!zml && ix->ahead_auto > 0 && !ix->d_rows2 && ahead_eligible(ix) && cls.log_ff == nullptr && ahead_wanted(ix, s)) {
         if (build_ahead(ix, s, true) != MOVI_OK) {
             (void)hipGetLastError();
             ix->ahead_auto = 0;
@@ -1026,6 +1057,26 @@ int movi_last_launch(const movi_index_t *ix, movi_launch_info_t *info) {
     info->idx64 = ix->last_launch.idx64;
     info->staged = ix->last_launch.staged;
     info->ahead = ix->last_launch.ahead;
+    return MOVI_OK;
+}
+
+int movi_index_info(const movi_index_t *ix, const char *key, double *value) {
+    if (!ix || !key || !value) return fail(MOVI_ERR_ARG, "NULL argument");
+    const double rows = ix->kmode != (int)ix->desc.mode ? (double)ix->desc.r * 8.0 : (double)ix->rows_bytes;
+    const double kmer = ix->d_kmer ? (double)((size_t)16 << (2 * ix->dev.kmer_k)) : 0.0;
+    const double ftab = ix->d_ftab ? (double)((size_t)16 << (2 * ix->dev.ftab_k)) : 0.0;
+    const double ahead = ix->d_rows2 ? (double)ahead_rows_bytes(ix->desc.r) : 0.0;
+    const double chain = ix->d_rows3 ? (double)chain_rows_bytes(ix->desc.r) : 0.0;
+    const double ckpt = ix->d_ckpt ? (double)((ix->desc.r >> kPrefixShift) + 2) * 8.0 : 0.0;
+    if (!strcmp(key, "rows_bytes")) *value = rows;
+    else if (!strcmp(key, "kmer_bytes")) *value = kmer;
+    else if (!strcmp(key, "ftab_bytes")) *value = ftab;
+    else if (!strcmp(key, "ahead_rows_bytes")) *value = ahead;
+    else if (!strcmp(key, "chain_rows_bytes")) *value = chain;
+    else if (!strcmp(key, "ckpt_bytes")) *value = ckpt;
+    else if (!strcmp(key, "derived_bytes")) *value = kmer + ftab + ahead + chain + ckpt;
+    else if (!strcmp(key, "ahead_no_ff")) *value = ix->ahead_tallied ? ix->ahead_no_ff : -1.0;
+    else return fail(MOVI_ERR_ARG, std::string("unknown info key: ") + key);
     return MOVI_OK;
 }
 
@@ -1478,7 +1529,11 @@ struct AutoPin {
     void *p = nullptr;
     bool pin(void *q, size_t bytes) {                        // true: the range is page-locked now (by us or already)
         if (!q || !bytes) return false;
-        if (is_pinned(q)) return true;
+        // page-locked already only if BOTH ends are (a caller -- or another thread's call on an adjacent slice of the same
+        // buffer -- may have registered part of the span); a partly registered span cannot be registered again: synchronous path
+        const bool first = is_pinned(q), last = is_pinned(static_cast<char *>(q) + bytes - 1);
+        if (first && last) return true;
+        if (first || last) return false;
         if (hipHostRegister(q, bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return false; }
         p = q;
         return true;
@@ -1687,8 +1742,17 @@ static int count_device(movi_index_t *ix, const uint8_t *d_bases, const uint64_t
     if (ix->ftab_auto > 0 && !ix->d_ftab && ftab_eligible(ix)) {       // the first count query builds the interval table
         if (build_ftab_table(ix, (uint32_t)ix->ftab_auto, s) != MOVI_OK) { (void)hipGetLastError(); ix->ftab_auto = 0; }
     }
-    if (ix->ahead_auto > 0 && !ix->d_rows2 && ahead_eligible(ix) && ahead_rows_bytes(ix->desc.r) <= kAheadAutoBytes) {
+    if (ix->ahead_auto > 0 && !ix->d_rows2 && !ix->count_declined_ahead && ahead_eligible(ix) && ahead_wanted(ix, s)) {
         if (build_ahead(ix, s, true) != MOVI_OK) { (void)hipGetLastError(); ix->ahead_auto = 0; }   // ... and the look-ahead rows (as a PML query does)
+        else if (ix->dev.rows2_count == 0u) {
+            // the table's own statistic says the count query is better off on the plain rows: the copy (16 B per row) is not
+            // kept for a caller who may never ask for PMLs -- the first PML query builds it again (85 us per 14 M rows)
+            ix->dev.rows2 = nullptr;
+            ix->dev.rows2_tail = 0;
+            (void)hipFree(ix->d_rows2);
+            ix->d_rows2 = nullptr;
+            ix->count_declined_ahead = true;
+        }
     }
     HIP_TRY(hipMemsetAsync(d_stats, 0, sizeof(DevStats), s));
     if (n_reads > 0xFFFFFFFFull) return fail(MOVI_ERR_ARG, "more than 2^32 reads in one call");

@@ -1559,6 +1559,33 @@ __global__ __launch_bounds__(256) void chain_rows_kernel(DevIndex ix, uint8_t *_
     }
 }
 
+// The tally alone, over every `stride`-th row: what share of the table's BWT positions reaches its LF target without a
+// fast-forward -- the statistic that says whether look-ahead entries will be used (launch policy, movi_abi.hip) -- without
+// building anything (two gathers per sampled row).
+template <int MODE>
+__global__ __launch_bounds__(256) void no_ff_share_kernel(DevIndex ix, uint64_t stride, unsigned long long *tally) {
+    const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * stride;
+    uint32_t no_ff = 0, ni = 0;
+    if (i < ix.r) {
+        const uint2 row = load_row<MODE>(ix.rows, i);
+        const uint64_t j = row_id<MODE>(row, i, ix);
+        ni = row_n<MODE>(row);
+        if (j < ix.r) {
+            const uint32_t nj = row_n<MODE>(load_row<MODE>(ix.rows, j)), oi = row_off<MODE>(row);
+            no_ff = nj > oi ? (nj - oi < ni ? nj - oi : ni) : 0u;
+        }
+    }
+    const uint32_t a = wave_sum(no_ff), b = wave_sum(ni);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(tally, (unsigned long long)a); atomicAdd(tally + 1, (unsigned long long)b); }
+}
+hipError_t tally_no_ff_share(int kmode, const DevIndex &ix, uint64_t stride, unsigned long long *d_tally, hipStream_t stream) {
+    if (kmode != 6 || !d_tally || stride == 0) return hipErrorInvalidValue;
+    const uint64_t n = (ix.r + stride - 1) / stride, blocks = (n + 255) / 256;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(no_ff_share_kernel<6>, dim3((unsigned)blocks), dim3(256), 0, stream, ix, stride, d_tally);
+    return hipGetLastError();
+}
+
 uint64_t ahead_rows_bytes(uint64_t r) { return ((r + 7) / 8 + 1) * 128; }
 uint64_t chain_rows_bytes(uint64_t r) { return ((r + 3) / 4 + 1) * 128; }
 

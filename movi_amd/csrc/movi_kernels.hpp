@@ -234,6 +234,9 @@ hipError_t build_kmer_table(const DevIndex &ix, uint32_t K, uint4 *d_table, hipS
 uint64_t ahead_rows_bytes(uint64_t r);
 hipError_t build_ahead_rows(int kmode, const DevIndex &ix, uint8_t *d_rows2, uint64_t *tail, hipStream_t stream,
                             unsigned long long *d_tally = nullptr);   // d_tally: 2 zeroed counters (ahead_rows_kernel), optional
+// d_tally[0] / d_tally[1] (two zeroed counters) = share of the BWT positions of every stride-th row that reach their LF
+// target without a fast-forward (no_ff_share_kernel): the launch policy's statistic, without building the copy
+hipError_t tally_no_ff_share(int kmode, const DevIndex &ix, uint64_t stride, unsigned long long *d_tally, hipStream_t stream);
 uint64_t chain_rows_bytes(uint64_t r);
 hipError_t build_chain_rows(int kmode, const DevIndex &ix, uint8_t *d_rows3, uint64_t *tail, hipStream_t stream,
                             unsigned long long *d_tally = nullptr);   // DevIndex::rows3 (chain_rows_kernel)

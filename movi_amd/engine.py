@@ -303,6 +303,12 @@ class MoveIndex:
         return {"kernel": li.kernel.decode(), "variant": int(li.variant), "block_threads": int(li.block_threads),
                 "waves_per_cu": int(li.waves_per_cu), "segmented": int(li.segmented), "idx64": int(li.idx64), "staged": int(li.staged), "ahead": int(li.ahead)}
 
+    def info(self, key):
+        """movi_index_info: bytes of the derived tables the handle holds, statistics their builders tallied."""
+        v = C.c_double()
+        check(lib().movi_index_info(self._h, key.encode(), C.byref(v)))
+        return v.value
+
     def last_stats(self, stream=0):
         st = QueryStatsC()
         check(lib().movi_last_stats(self._h, C.c_void_p(stream) if stream else None, C.byref(st)))

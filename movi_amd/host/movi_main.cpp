@@ -528,7 +528,9 @@ int run_query(const Options &o) {
         for (auto *hd : handles) {                                     // (errors here are not the query's: the real calls report)
             if (o.pml && o.classify && !o.write_output_allowed())
                 (void)movi_pml_classify_host(hd, wb, wo, 1, (uint32_t)o.bin_width, classifier.max_value_thr, &wa, &wbl, &wsum, &we, nullptr);
-            else if (o.pml) (void)movi_pml_host(hd, wb, wo, 1, wp, &we, nullptr);
+            else if (o.pml && o.logs) {
+                // --logs runs on the first kernel, which uses none of the derived tables: nothing to build ahead of it
+            } else if (o.pml) (void)movi_pml_host(hd, wb, wo, 1, wp, &we, nullptr);
             else if (o.zml) (void)movi_zml_host(hd, wb, wo, 1, wp, &we, nullptr);
             else (void)movi_count_host(hd, wb, wo, 1, &wm, &wc, &we, nullptr);
         }

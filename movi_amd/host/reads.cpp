@@ -47,13 +47,20 @@ static std::vector<int> llc_siblings() {
 WorkerPool::WorkerPool(unsigned threads) {
     std::vector<int> cpus;
     if (threads > 1 && !getenv("MOVI_NO_AFFINITY")) cpus = llc_siblings();
+    // only the CPUs this thread may run on anyway (a cpuset may grant fewer than the cache domain lists); the owner's own
+    // mask is put back when the pool goes (an embedder's main thread -- `movi plan`, tools/parse_bench -- must not stay
+    // confined to one cache domain, nor hand that mask down to every thread it starts later)
+    have_owner_mask_ = pthread_getaffinity_np(pthread_self(), sizeof(owner_mask_), &owner_mask_) == 0;
     cpu_set_t set;
     CPU_ZERO(&set);
-    for (int c : cpus) CPU_SET(c, &set);
-    const bool pin = cpus.size() >= 2;
+    size_t usable = 0;
+    for (int c : cpus)
+        if (!have_owner_mask_ || CPU_ISSET(c, &owner_mask_)) { CPU_SET(c, &set); usable++; }
+    const bool pin = usable >= 2;
     if (pin) {
-        (void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
-        if (threads > cpus.size()) threads = (unsigned)cpus.size();
+        owner_ = pthread_self();
+        pinned_owner_ = pthread_setaffinity_np(owner_, sizeof(set), &set) == 0 && have_owner_mask_;
+        if (threads > usable) threads = (unsigned)usable;
     }
     for (unsigned t = 1; t < threads; t++) {
         th_.emplace_back([this] { loop(); });
@@ -65,6 +72,7 @@ WorkerPool::~WorkerPool() {
     { std::lock_guard<std::mutex> g(m_); stop_ = true; }
     cv_.notify_all();
     for (auto &t : th_) t.join();
+    if (pinned_owner_) (void)pthread_setaffinity_np(owner_, sizeof(owner_mask_), &owner_mask_);
 }
 
 void WorkerPool::loop() {
@@ -317,13 +325,18 @@ bool BatchReader::load_batch(size_t &first_line) {
 // batch early, src/batch_loader.cpp:99) and shorter than 4 GiB, every header longer than 2 characters and -- FASTQ --
 // starting with '@'; whole batches only; the last record in reach (whose end the scan cannot vouch for) and anything
 // irregular are left to the line-by-line cut, which then starts exactly where a batch would start anyway.
+// An irregular line does not send everything in reach to the line-by-line cut (which takes ~7 reads per call: the check
+// would run over the same million lines again for every batch, 0.011 -> 0.39 s per chunk with ONE trailing blank line): the
+// records before it are cut in bulk, the cut goes line by line across it -- no pass is made while the input position is
+// within 4096 lines of it (skip_until_) -- and in bulk again behind it.
 bool BatchReader::cut_ahead(uint64_t max_bases, uint64_t min_reads, uint64_t hard_max_bases, uint64_t &approx_bases) {
     if (!mem_ || format_ < 0 || no_fast_cut_) return false;
     const LineSource::Ahead A = src_.ahead();
+    if (A.pos < skip_until_) return false;
     // no further than the chunk can possibly reach (the passes below run over every line considered)
     const uint64_t budget = approx_bases < max_bases ? max_bases - approx_bases : (approx_bases < hard_max_bases ? hard_max_bases - approx_bases : 0);
     const size_t reach = A.pos + (size_t)std::min<uint64_t>(budget + (budget >> 2) + (1u << 20), 1ull << 40);
-    const size_t M = (size_t)(std::upper_bound(A.nl, A.nl + A.count, reach) - A.nl);
+    size_t M = (size_t)(std::upper_bound(A.nl, A.nl + A.count, reach) - A.nl);
     const size_t L0 = lines_.size(), R0 = recs_.size();
     if (M < 4096 || L0 + M > 0xFFFFFFF0ull) return false;
     auto beg = [&](size_t t) -> size_t { return t ? A.nl[t - 1] + 1 : A.pos; };
@@ -333,27 +346,40 @@ bool BatchReader::cut_ahead(uint64_t max_bases, uint64_t min_reads, uint64_t har
     const unsigned T = pool_->size();
     // ---- workers: the records' header lines, and is everything regular?
     std::vector<size_t> n_hdr(T + 1, 0);
-    std::vector<char> bad(T, 0);
+    std::vector<size_t> stop(T, 0);                                    // first irregular line of each worker's share (its end: none)
     size_t R = 0;                                                      // complete records in reach (the last one is not)
+    // the regular prefix ends at line `first_bad`: no pass again until the line-by-line cut has crossed it
+    auto cut_short = [&](size_t first_bad) {
+        skip_until_ = first_bad >= 4096 ? (size_t)0 : A.nl[first_bad] + 1;    // (a long prefix is cut now; the next call sees the line close by)
+        M = first_bad;
+        return M >= 4096;
+    };
     if (format_ == 0) {
+        const size_t M0 = M;
         pool_->run(T, [&](unsigned w) {
-            const size_t a = M * w / T, b = M * (w + 1) / T;
-            size_t c = 0;
-            char irregular = 0;
-            for (size_t t = a; t < b; t++) {
+            const size_t a = M0 * w / T, b = M0 * (w + 1) / T;
+            size_t c = 0, t = a;
+            for (; t < b; t++) {
                 const size_t len = A.nl[t] - beg(t);
-                if (len == 0 || len > 0xFFFFFFFFull) irregular = 1;
-                if (fc(t) == '>') { c++; if (len <= 2) irregular = 1; }
+                if (len == 0 || len > 0xFFFFFFFFull) break;
+                if (fc(t) == '>') { if (len <= 2) break; c++; }
             }
             n_hdr[w + 1] = c;
-            bad[w] = irregular;
+            stop[w] = t;
         });
-        for (unsigned w = 0; w < T; w++) { if (bad[w]) return false; n_hdr[w + 1] += n_hdr[w]; }
+        for (unsigned w = 0; w < T; w++) {
+            n_hdr[w + 1] += n_hdr[w];
+            if (stop[w] < M0 * (w + 1) / T) {                          // the first irregular line in reach
+                for (unsigned v = w + 1; v < T; v++) n_hdr[v + 1] = n_hdr[w + 1];
+                if (!cut_short(stop[w])) return false;
+                break;
+            }
+        }
         const size_t H = n_hdr[T];
         if (H < 2) return false;
         hdr_line_.resize(H);
         pool_->run(T, [&](unsigned w) {
-            const size_t a = M * w / T, b = M * (w + 1) / T;
+            const size_t a = M0 * w / T, b = std::min(M, M0 * (w + 1) / T);
             size_t c = n_hdr[w];
             for (size_t t = a; t < b; t++)
                 if (fc(t) == '>') hdr_line_[c++] = (uint32_t)t;
@@ -362,18 +388,25 @@ bool BatchReader::cut_ahead(uint64_t max_bases, uint64_t min_reads, uint64_t har
     } else {
         R = M / 4;
         if (R < 2) return false;
+        const size_t Rr = R;
         pool_->run(T, [&](unsigned w) {
-            const size_t a = R * w / T, b = R * (w + 1) / T;
-            char irregular = 0;
-            for (size_t r = a; r < b; r++) {
+            const size_t a = Rr * w / T, b = Rr * (w + 1) / T;
+            size_t r = a;
+            for (; r < b; r++) {
                 const size_t t = 4 * r, len = A.nl[t] - beg(t);
-                if (fc(t) != '@' || len <= 2) irregular = 1;
+                bool irregular = fc(t) != '@' || len <= 2;
                 for (size_t u = t; u < t + 4; u++)
-                    if (A.nl[u] - beg(u) > 0xFFFFFFFFull) irregular = 1;
+                    if (A.nl[u] - beg(u) > 0xFFFFFFFFull) irregular = true;
+                if (irregular) break;
             }
-            bad[w] = irregular;
+            stop[w] = r;
         });
-        for (unsigned w = 0; w < T; w++) if (bad[w]) return false;
+        for (unsigned w = 0; w < T; w++)
+            if (stop[w] < Rr * (w + 1) / T) {                          // the first irregular record in reach
+                if (!cut_short(4 * stop[w])) return false;
+                R = M / 4;
+                break;
+            }
         R -= 1;
     }
     auto hdr_of = [&](size_t r) -> size_t { return format_ == 0 ? (size_t)hdr_line_[r] : 4 * r; };

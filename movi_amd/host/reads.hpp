@@ -14,6 +14,8 @@
 #include <condition_variable>
 #include <functional>
 #include <mutex>
+#include <pthread.h>
+#include <sched.h>
 #include <new>
 #include <string>
 #include <string_view>
@@ -134,6 +136,9 @@ private:
     unsigned parts_ = 0, next_ = 0, pending_ = 0;
     uint64_t gen_ = 0;
     bool stop_ = false;
+    cpu_set_t owner_mask_;                // the owning thread's affinity before the pool narrowed it (restored by ~WorkerPool)
+    pthread_t owner_{};
+    bool have_owner_mask_ = false, pinned_owner_ = false;
 };
 
 // Line source with std::istream's good()/peek()/getline() state semantics (the batch cut of the reference depends
@@ -259,6 +264,7 @@ private:
     unsigned threads_ = 0;              // 0 = hardware concurrency (at most 16)
     std::unique_ptr<WorkerPool> pool_;
     PhaseTimes times_;
+    size_t skip_until_ = 0;   // cut_ahead makes no pass while the input position is before this byte (an irregular line close ahead)
     const bool no_fast_cut_ = std::getenv("MOVI_NO_FAST_CUT") != nullptr;   // every batch line by line (tests: both cuts must agree)
     int format_ = -1;                   // -1 unknown, 0 FASTA, 1 FASTQ
     uint32_t batch_counter_ = 0;

@@ -29,7 +29,8 @@ def test_bench_single_gpu_contract():
     for k in REQUIRED:
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "weak"
-    assert d["roofline"]["bound"].startswith("fabric") and 0 < d["roofline"]["frac"] < 1      # a 1.6 MB table never reaches DRAM
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1      # 1.6 MB of rows + the 256 MB top-of-walk table: not Infinity-Cache-resident
+    assert d["roofline"]["lane_iterations_per_s"] > 0 and d["roofline"]["rows_read_per_s"] > 0
     assert d["roofline"]["kernel"].startswith("pml_kernel_flatp<6, unsigned int, -1") and d["rccl_ranks"] == 0
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and d["parity_sample_ok"] is True
 
@@ -59,3 +60,38 @@ def test_bench_launches_its_own_ranks():
     d = _line(r.stdout)
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["bases_per_step_per_gpu"] == 20000 * 150
     assert d["rccl_ranks"] == 0 and "index_broadcast_s" in d      # shared-GPU hook: gloo; under RCCL rccl_ranks == n_gpus
+
+
+def test_bench_two_ranks_print_all_three_legs():
+    """The N > 1 line carries, next to the headline, the long-read leg (plain and with --classify fused) and the big-table leg
+    (rank 0 synthesises the table and draws every rank's reads; the rows reach the other rank by broadcast), each with
+    per-rank seconds and a roofline object.  Shrunk: an 8 x 60 kbp pangenome, 2 M random rows, 256 long reads."""
+    env = dict(os.environ, MOVI_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "tinypg", "--steps", "3",
+                        "--warmup", "1", "--big-rows", "2000000", "--long-reads", "256", "--no-sustained"],
+                       capture_output=True, timeout=1200, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _line(r.stdout)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and len(d["rank_seconds"]) == 2
+    lr, bt = d["long_reads"], d["big_table"]
+    assert lr["n_gpus"] == 2 and lr["value"] > 0 and len(lr["rank_seconds"]) == 2 and lr["errors"] == 0
+    assert lr["roofline"]["frac"] > 0 and lr["classify_bins_only"]["roofline"]["frac"] > 0 and lr["classify_bins_agree"] is True
+    assert lr["classify_vector_and_bins"]["fused_classify"] == 1 and lr["classify_bins_only"]["fused_classify"] == 2
+    assert bt["n_gpus"] == 2 and bt["rows"] == 2000000 and bt["value"] > 0 and bt["parity_sample_ok"] is True
+    assert bt["roofline"]["frac"] > 0 and bt["count"]["roofline"]["frac"] > 0 and bt["index_broadcast_s"] >= 0
+    assert "cpu_baseline" not in d
+
+
+def test_bench_c4_two_ranks_share_one_gpu():
+    """--workload c4 at N = 2: only rank 0 synthesises the table (and draws both shards of reads)."""
+    env = dict(os.environ, MOVI_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c4", "--rows", "20000000",
+                        "--reads", "100000", "--steps", "3", "--warmup", "1"], capture_output=True, timeout=1200, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _line(r.stdout)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["rows"] == 20000000
+    assert d["config"]["bases_per_step_per_gpu"] == 100000 * 150

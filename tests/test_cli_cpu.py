@@ -324,6 +324,9 @@ def test_bulk_batch_cut_equals_the_line_by_line_cut(movi_bin, tmp_path, fmt, fla
         "blank_tail": b"\n".join(lines) + b"\n\n\n",
         "blank_line_inside": b"\n".join(lines[: len(lines) // 2 // 4 * 4] + [b""] + lines[len(lines) // 2 // 4 * 4:]) + b"\n",
         "crlf": b"\r\n".join(lines) + b"\r\n",
+        # several irregular lines: the bulk cut takes the records before each, stands back across it, and resumes behind it
+        "blank_lines_every_few_thousand": b"\n".join(l + b"\n" if i % 9000 == 8999 and (fmt != "fq" or i % 4 == 3) else l
+                                                     for i, l in enumerate(lines)) + b"\n",
     }
     for name, content in variants.items():
         path = tmp_path / ("%s.%s" % (name, fmt))

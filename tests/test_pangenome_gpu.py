@@ -1,0 +1,130 @@
+"""GPU suite (-m gpu): the bench's own workloads at their size, held to the oracle.
+
+* c2: the 14 M-row real-BWT pangenome index of `bench.py` (built once per box by tools/build_index and cached -- or found in a
+  .bench_cache/ that travelled with the tree), 1 M x 150 bp reads through movi_pml_device: 20 000 reads of the batch against
+  the oracle, PMLs and counters, on every table layout the walk can run on.
+* c3 as BASELINE.json words it -- "100 k x 10 kbp ... PML + --classify": the fused classification kernels at that size
+  (movi_pml_classify_device with and without the PML vector: CLS = 1 / 2), bins against Classifier::classify restated over the
+  oracle's PMLs on slices (src/classifier.cpp:99-143, src/read_processor.cpp:565-578), the bins-only launch against the
+  vector launch on all 100 000 reads.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, classify_py
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pangenome(built_lib):
+    """(index directory, c2 reads file): bench.py's c2 workload, built on first use (~2 min on a fresh box)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    wl = dict(bench.WORKLOADS["c2"])
+    idx_dir, reads_file = bench.ensure_pangenome(wl, 1, 0, lambda: None)
+    return idx_dir, reads_file
+
+
+def _load(idx_dir):
+    import movi_amd
+    from oracle.oracle import Oracle
+    img = np.fromfile(os.path.join(idx_dir, "index.movi"), np.uint8)
+    return movi_amd.MoveIndex.from_image(img), Oracle(img)
+
+
+@pytest.mark.timeout(1800)
+def test_c2_pangenome_batch_vs_oracle(pangenome):
+    import torch
+    idx_dir, reads_file = pangenome
+    gpu, cpu = _load(idx_dir)
+    n, L = 1_000_000, 150
+    bases = np.fromfile(reads_file, np.uint8, count=n * L)
+    offs = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+    dev = torch.device("cuda", 0)
+    d_bases = torch.from_numpy(bases).to(dev)
+    d_offs = torch.from_numpy(offs.view(np.int64)).to(dev)
+    d_out = torch.empty(n * L, dtype=torch.int16, device=dev)
+    d_err = torch.zeros(n, dtype=torch.uint8, device=dev)
+    lo, cnt = 490_000, 20_000                                  # 20 k reads from the middle of the batch
+    sb, so = bases[lo * L: (lo + cnt) * L], offs[: cnt + 1]
+    exp, eff, esc = cpu.pml_batch(sb, so, threads=8)
+    for ahead, variant in ((1, -1), (0, -1), (2, -1), (1, 13)):
+        gpu.set_option("ahead_rows", ahead)
+        gpu.set_option("pml_variant", variant)
+        gpu.pml_device(d_bases.data_ptr(), d_offs.data_ptr(), n, n * L, d_out.data_ptr(), d_err.data_ptr())
+        torch.cuda.synchronize()
+        li = gpu.last_launch()
+        assert li["ahead"] == ahead and li["variant"] == (13 if variant == 13 else 14), li
+        got = d_out[lo * L: (lo + cnt) * L].cpu().numpy().view(np.uint16)
+        assert (got == exp).all(), (ahead, variant)
+        assert int(d_err.sum().item()) == 0
+        # the slice alone: its counters equal the oracle's
+        d_so = torch.from_numpy(so.view(np.int64).copy()).to(dev)
+        gpu.pml_device(d_bases.data_ptr() + lo * L, d_so.data_ptr(), cnt, cnt * L, d_out.data_ptr(), d_err.data_ptr())
+        st = gpu.last_stats()
+        assert (st.fast_forwards, st.scans, st.errors) == (eff, esc, 0), (ahead, variant)
+        assert (d_out[: cnt * L].cpu().numpy().view(np.uint16) == exp).all()
+    gpu.set_option("pml_variant", -1)
+    gpu.close()
+    cpu.close()
+
+
+@pytest.mark.timeout(2400)
+def test_c3_classify_at_size(pangenome):
+    """BASELINE config 3: 100 k x 10 kbp, PML + --classify."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    idx_dir, _ = pangenome
+    gpu, cpu = _load(idx_dir)
+    n, L = 100_000, 10_000
+    tool = os.path.join(ROOT, "tools", "build_index")
+    text = os.path.join(idx_dir, "text.bin")
+    PG = bench.PG_C2
+    if not os.path.exists(text):
+        subprocess.check_call([tool, "pangenome", str(PG["anc"]), str(PG["genomes"]), str(PG["snp"]), str(PG["seed"]), "6", idx_dir,
+                               "text-only"], stderr=subprocess.DEVNULL)
+    rf = os.path.join(idx_dir, "reads_%dx%d_%g.bin" % (n, L, 0.08))
+    if not os.path.exists(rf):
+        subprocess.check_call([tool, "reads", text, str(n), str(L), "0.08", str(PG["seed"]), rf + ".tmp"])
+        os.rename(rf + ".tmp", rf)
+    bases = np.fromfile(rf, np.uint8, count=n * L)
+    dev = torch.device("cuda", 0)
+    d_bases = torch.from_numpy(bases).to(dev)
+    d_offs = torch.from_numpy((np.arange(n + 1, dtype=np.uint64) * np.uint64(L)).view(np.int64)).to(dev)
+    d_out = torch.zeros(n * L, dtype=torch.int16, device=dev)
+    d_err = torch.zeros(n, dtype=torch.uint8, device=dev)
+    bin_width, thr = 150, 8
+    res = {}
+    for with_vector in (True, False):
+        d_a = torch.full((n,), -1, dtype=torch.int32, device=dev)
+        d_b = torch.full((n,), -1, dtype=torch.int32, device=dev)
+        d_s = torch.full((n,), -1, dtype=torch.int64, device=dev)
+        gpu.pml_classify_device(d_bases.data_ptr(), d_offs.data_ptr(), n, n * L, bin_width, thr,
+                                d_out.data_ptr() if with_vector else 0, d_a.data_ptr(), d_b.data_ptr(), d_s.data_ptr(), d_err.data_ptr())
+        torch.cuda.synchronize()
+        assert gpu.last_launch()["kernel"].startswith("pml_kernel_flatp<6, unsigned int, -1, %d," % (1 if with_vector else 2))
+        assert int(d_err.sum().item()) == 0
+        res[with_vector] = (d_a.cpu().numpy(), d_b.cpu().numpy(), d_s.cpu().numpy())
+    # the verdict-only launch (no PML vector written) against the vector launch: all 100 000 reads
+    for x, y in zip(res[True], res[False]):
+        assert (x == y).all()
+    a, b, sm = res[True]
+    assert ((a + b) == L // bin_width).all()                   # 66 bins of 150, the last one absorbs the remainder (classifier.cpp:110-115)
+    # bins of slices against Classifier::classify over the ORACLE's PMLs, and the vectors themselves
+    got = d_out.cpu().numpy().view(np.uint16)
+    for lo in (0, 49_950, n - 100):
+        sb = bases[lo * L: (lo + 100) * L]
+        so = np.arange(101, dtype=np.uint64) * np.uint64(L)
+        exp, _, _ = cpu.pml_batch(sb, so, threads=8)
+        assert (got[lo * L: (lo + 100) * L] == exp).all(), lo
+        for i in range(100):
+            found, avg, ea, eb = classify_py(exp[i * L: (i + 1) * L], thr, bin_width)
+            assert (int(a[lo + i]), int(b[lo + i])) == (ea, eb) and int(sm[lo + i]) == round(avg * (ea + eb)), (lo, i)
+    gpu.close()
+    cpu.close()

@@ -7,6 +7,8 @@
 //     every further window costs an iteration;
 //   * mismatch: the step that sees it emits nothing; the scan then costs one iteration per window visited
 //     (with the scan side-array, option A: ONE iteration whatever the distance, up to `sa_reach` rows);
+//   * in-window repositions (inwin): a reposition whose target is a row of the window already held costs nothing;
+//   * own = 1: only the gather's own row carries an entry (a step that ends on a neighbour cannot ride);
 //   * look-ahead chains, depth S: after a base is resolved at row i, up to S following bases ride along while
 //     they match c(j_s) and arrive without a fast-forward (entry of row i holds the chain j_1 .. j_S).
 // Output: lane iterations per base, the share of iterations by kind, SIMT efficiency for waves of 64 consecutive
@@ -126,8 +128,9 @@ int main(int argc, char **argv) {
     uint8_t *reads = malloc(n_reads * L);
     if (fread(reads, 1, n_reads * L, f) != n_reads * L) return 1;
     fclose(f);
-    const Design designs[] = {
-        {0, 4, 0, 0, 0, 0}, {1, 4, 0, 0, 0, 0}, {1, 4, 0, 0, 1, 0}, {2, 4, 0, 0, 0, 0}, {2, 4, 0, 0, 1, 0}, {1, 4, 1, 64, 1, 0}, {2, 4, 1, 64, 1, 0}, {1, 8, 0, 0, 1, 0},
+    const Design designs[] = {          // S, W, side, side_reach, inwin, own
+        {0, 4, 0, 0, 0, 0}, {1, 4, 0, 0, 0, 0}, {1, 4, 0, 0, 0, 1}, {1, 4, 0, 0, 1, 0}, {2, 4, 0, 0, 0, 0}, {2, 4, 0, 0, 1, 0}, {3, 4, 0, 0, 1, 0},
+        {7, 4, 0, 0, 1, 0}, {1, 4, 1, 64, 1, 0}, {2, 4, 1, 64, 1, 0}, {1, 2, 0, 0, 1, 0}, {1, 8, 0, 0, 1, 0}, {2, 8, 0, 0, 1, 0},
     };
     printf("r = %llu rows, %llu reads x %u, top-of-walk K = %u\n", (unsigned long long)r, (unsigned long long)n_reads, L, top_k);
     printf("%-36s %9s %9s | %7s %7s %7s %7s | %7s | %6s %6s %6s\n", "design", "iter/base", "SIMT", "arrive", "ff-win", "mismat", "scanwin",

@@ -2,7 +2,7 @@
 # usage: tools/r04_pmc.sh <outdir> "<bench args>"   -- kernel trace + 5 PMC passes of `bench.py --quick <args>`
 OUT=$1; ARGS=$2
 cd "$(dirname "$0")/.." || exit 1
-export MOVI_BENCH_CACHE=$PWD/.bench_cache
+export MOVI_BENCH_CACHE=${MOVI_BENCH_CACHE:-$PWD/.bench_cache}
 R=$PWD
 cd /tmp && export TMPDIR=/tmp && cd "$R"
 mkdir -p "$OUT"
