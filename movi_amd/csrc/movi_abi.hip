@@ -897,6 +897,11 @@ int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
         ix->cfg.refill_batch = (int)value;
         return MOVI_OK;
     }
+    if (!strcmp(key, "zml_ahead")) {                         // 1: the ZML state machine walks on the look-ahead rows where they exist (A/B: measured no faster)
+        if (value != 0 && value != 1) return fail(MOVI_ERR_ARG, "zml_ahead must be 0 or 1");
+        ix->cfg.zml_ahead = (int)value;
+        return MOVI_OK;
+    }
     if (!strcmp(key, "inwin_repo")) {                        // A/B: repositions inside the row window resolved in the same iteration
         if (value != 0 && value != 1) return fail(MOVI_ERR_ARG, "inwin_repo must be 0 or 1");
         ix->cfg.inwin = (int)value;

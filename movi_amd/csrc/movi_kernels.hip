@@ -2991,11 +2991,12 @@ __global__ __launch_bounds__(256) void zml_probe_kernel(DevIndex ix, const uint8
 // The end-by-end order inside an iteration (start end first, whole window; then the end end) is the order of
 // shrink_interval's trips, so answers AND scan / fast-forward counts equal the base-synchronous kernel's.
 // SEG = 1: a lane parses one SEGMENT of a read (K1 of launch_zml_segmented), as zml_kernel<MODE, 1>.
-template <int MODE, typename IdxT, int SEG = 0>
+template <int MODE, typename IdxT, int SEG = 0, int AH = 0>
 __global__ __launch_bounds__(256) void zml_kernel_flat(DevIndex ix, const uint8_t *__restrict__ bases,
                                                        const uint64_t *__restrict__ offs, uint64_t n_reads,
                                                        uint16_t *__restrict__ out, uint8_t *__restrict__ err,
                                                        DevStats *stats, const uint32_t *__restrict__ order, ZSegArgs seg) {
+    static_assert(AH == 0 || (MODE == 6 && SEG == 0), "look-ahead rows: regular-thresholds rows, whole reads");
     enum : uint32_t { phStart = 0, phScan = 1, phLF = 2, phInit = 3, phDone = 4 };
     enum : uint32_t { pNone = 0, pScan = 1, pFF = 2 };       // what an interval end is waiting for
     __shared__ uint8_t s_code[256];
@@ -3039,6 +3040,7 @@ __global__ __launch_bounds__(256) void zml_kernel_flat(DevIndex ix, const uint8_
     IdxT rs = 0, re = 0, lo = 0, hi = 0;
     uint32_t os = 0, oe = 0, open = 0, dead = 0;
     uint2 rws = make_uint2(0, 0), rwe = make_uint2(0, 0);
+    uint2 ens = make_uint2(0, 0), ene = make_uint2(0, 0);   // AH: the look-ahead entries of the rows the two ends stand on (0 = none)
     uint32_t ps = pNone, pe = pNone, ffs = 0, ffe = 0;
     uint32_t ph = len > 0 ? phStart : phDone;
     uint32_t k = 0, ml = 0;
@@ -3048,14 +3050,30 @@ __global__ __launch_bounds__(256) void zml_kernel_flat(DevIndex ix, const uint8_
         fix_pair(beg + len, rb, rb2);
     }
     if (len > 16) load_pair_at(beg + len - 16, nx0, nx1);
-    // b = code of the base of step k, bn = of step k + 1: M2 -> M0 chains two bases inside one iteration, so the next
-    // base must be decoded one step ahead (rb always holds the 8-group of step k + 1)
+    // b = code of the base of step k, bn = of step k + 1, bn2 = of step k + 2: M2 -> M0 chains two bases inside one
+    // iteration (three on the look-ahead rows), so the next bases are decoded ahead (rb always holds the 8-group of step
+    // k + 2, the furthest one decoded)
     uint32_t b = s_code[(uint32_t)(rb >> 56) & 0xFFu];
     uint32_t bn = len > 1 ? s_code[(uint32_t)(rb >> 48) & 0xFFu] : 0xFFu;
+    uint32_t bn2 = len > 2 ? s_code[(uint32_t)(rb >> 40) & 0xFFu] : 0xFFu;
     uint4 pk = make_uint4(0, 0, 0, 0), pk_old = pk;
-    uint2 ws[4], we[4];
-    load_window<MODE>(ix.rows, 0, ws);
-    load_window<MODE>(ix.rows, 0, we);
+    uint2 ws[4], we[4], es[4], ee[4];                         // AH: es / ee = the look-ahead entries of the windows' rows
+    // a window of the table the parse walks on: the plain rows, or (AH) the look-ahead copy with its rows' entries
+    auto fetch_win = [&](IdxT wb, uint2 (&wr)[4], uint2 (&en)[4]) {
+        if (AH) {
+            const uint64_t at = wb < wb_last ? (uint64_t)(wb >> 3) * 128u + (uint64_t)((uint32_t)wb & 4u) * 8u : ix.rows2_tail;
+            load_window<MODE>(ix.rows2 + at, 0, wr);
+            load_window<MODE>(ix.rows2 + at + 64u, 0, en);
+        } else {
+            load_window<MODE>(ix.rows, (uint64_t)wb, wr);
+        }
+    };
+    // (AH) the row j as the walk needs it -- id, length, offset, character -- from the entry of a row whose LF target it is
+    auto row_of_entry = [&](uint2 e) -> uint2 {
+        return make_uint2(e.x, (e.y & 0x7FFu) | (((e.y >> 22) & 7u) << 13) | (((e.y >> 11) & 0x7FFu) << 16) | (((e.y >> 25) & 15u) << 28));
+    };
+    fetch_win(0, ws, es);
+    fetch_win(0, we, ee);
     IdxT wbs = 0, wbe = 0;                                   // bases of the two windows in flight
 
     uint32_t lane_steps = 0, wave_steps = 0;
@@ -3082,7 +3100,7 @@ __global__ __launch_bounds__(256) void zml_kernel_flat(DevIndex ix, const uint8_
                         scan_total += h - qf + 1;
                         rs = wbs + (IdxT)h;
                         os = 0;
-                        if (cand) { rws = win_sel(ws, h); ps = pNone; }
+                        if (cand) { rws = win_sel(ws, h); if (AH) ens = win_sel(es, h); ps = pNone; }
                         else if (rs >= hi) { dead = 1; ps = pNone; pe = pNone; }
                     }
                 }
@@ -3101,7 +3119,7 @@ __global__ __launch_bounds__(256) void zml_kernel_flat(DevIndex ix, const uint8_
                     os -= (q == 0u ? 0u : (q == 1u ? t1 : (q == 2u ? t2 : (q == 3u ? t3 : t4))));
                     ffs += cnt;
                     rs += (IdxT)cnt;
-                    if (q < 4u) { rws = win_sel(ws, q); ps = pNone; }
+                    if (q < 4u) { rws = win_sel(ws, q); if (AH) ens = win_sel(es, q); ps = pNone; }
                 }
             }
         }
@@ -3120,7 +3138,7 @@ __global__ __launch_bounds__(256) void zml_kernel_flat(DevIndex ix, const uint8_
                         const uint32_t h = cand ? 31u - (uint32_t)__builtin_clz(cand) : first;
                         scan_total += qf - h + 1;
                         re = wbe + (IdxT)h;
-                        if (cand) { rwe = win_sel(we, h); oe = row_n<MODE>(rwe) - 1; pe = pNone; }
+                        if (cand) { rwe = win_sel(we, h); if (AH) ene = win_sel(ee, h); oe = row_n<MODE>(rwe) - 1; pe = pNone; }
                         else if (re <= lo) { dead = 1; ps = pNone; pe = pNone; }
                     }
                 }
@@ -3139,65 +3157,93 @@ __global__ __launch_bounds__(256) void zml_kernel_flat(DevIndex ix, const uint8_
                     oe -= (q == 0u ? 0u : (q == 1u ? t1 : (q == 2u ? t2 : (q == 3u ? t3 : t4))));
                     ffe += cnt;
                     re += (IdxT)cnt;
-                    if (q < 4u) { rwe = win_sel(we, q); pe = pNone; }
+                    if (q < 4u) { rwe = win_sel(we, q); if (AH) ene = win_sel(ee, q); pe = pNone; }
                 }
             }
         }
-        // ---- 2. micro-steps, as far as they go without new rows
-        const bool ready = act && ps == pNone && pe == pNone;
-        uint32_t fail = 0, do_emit = 0, ek = 0, errc = kErrNone;
-        if (ready && ph == phLF) {                           // M2: both jumps and their fast-forwards are done
-            ff_total += ffs + ffe;
-            if (ffs >= 65535u || ffe >= 65535u) errc = kErrFastForward;   // move_structure.cpp:72-75
-            else if ((rs < re) || (rs == re && os <= oe)) {  // query_zml :717-720
-                ml += 1;
-                do_emit = 1; ek = k;
-                if (SEG == 1) { cap_rs = rs; cap_re = re; cap_os = os; cap_oe = oe; cap_ml = ml; cap_open = open; cap_ff = ff_total; cap_scan = scan_total; }
-                k += 1;
-                b = bn;
-                ph = k == len ? phDone : phStart;
-            } else fail = 1;
-        } else if (ready && ph == phInit) {                  // the rows of a new phrase's ends have arrived
-            ph = phStart;
-        }
-        if (ph == phStart && do_emit == 0 && act && b == 0xFFu) fail = 1;       // illegal base: no phrase
-        if (ph == phStart && do_emit == 0 && act && open == 0u) fail = 1;       // no phrase to extend
-        if (ph == phStart && act && fail == 0u && open != 0u && b != 0xFFu) {   // M0: update_interval begins
-            ps = (rs == end_row || row_c<MODE>(rws) != b) ? pScan : pNone;
-            pe = (re == end_row || row_c<MODE>(rwe) != b) ? pScan : pNone;
-            lo = rs; hi = re; dead = 0;
-            ph = phScan;
-        }
-        if (ph == phScan && act && ps == pNone && pe == pNone && errc == kErrNone) {   // M1: scans done (or none needed)
-            if (dead == 0u && ((rs < re) || (rs == re && os <= oe))) {
-                const uint64_t ja = row_id<MODE>(rws, (uint64_t)rs, ix), jb = row_id<MODE>(rwe, (uint64_t)re, ix);
-                if (ja >= ix.r || jb >= ix.r) errc = kErrIdRange;       // move_structure.cpp:63-65
-                else {
-                    os += row_off<MODE>(rws);
-                    oe += row_off<MODE>(rwe);
-                    rs = (IdxT)ja; re = (IdxT)jb;
-                    ps = pFF; pe = pFF; ffs = 0; ffe = 0;
-                    ph = phLF;
-                }
-            } else if (do_emit == 0u) {
-                fail = 1;                                    // (with an emission already made in this iteration: decided again
-            }                                                // in the next one -- ph stays phScan)
-        }
-        if (fail) {                                          // :750-760 / :696-704: the base opens the next phrase
-            ml = 0;
-            open = 0;
-            ph = phStart;
-            if (b != 0xFFu) {                                // initialize_backward_search :284-291
-                rs = (IdxT)ix.first_runs[b + 1]; re = (IdxT)ix.last_runs[b + 1];
-                os = (uint32_t)ix.first_offsets[b + 1]; oe = (uint32_t)ix.last_offsets[b + 1];
-                open = ((rs < re) || (rs == re && os <= oe)) ? 1u : 0u;
-                if (open) { ps = pFF; pe = pFF; ffs = 65535u; ffe = 65535u; ph = phInit; }   // rows only: no fast-forward
-            }
-            do_emit = 1; ek = k;
+        // ---- 2. micro-steps, as far as they go without new rows.  Up to two emissions per iteration: A (the base whose rows
+        // have arrived, or a phrase's end) and, on the look-ahead rows, B (a base both of whose LF moves are known from the ends'
+        // entries to land without a fast-forward: nothing to fetch for it).
+        uint32_t fail = 0, n_emit = 0, ekA = 0, valA = 0, ekB = 0, valB = 0, errc = kErrNone, la_taken = 0;
+        auto book = [&]() {                                  // MoveQuery::add_ml of step k (u16 clamp), then on to the next base
+            const uint32_t val = ml > 65535u ? 65535u : ml;
+            if (n_emit == 0u) { ekA = k; valA = val; } else { ekB = k; valB = val; }
+            n_emit += 1;
             if (SEG == 1) { cap_rs = rs; cap_re = re; cap_os = os; cap_oe = oe; cap_ml = ml; cap_open = open; cap_ff = ff_total; cap_scan = scan_total; }
             k += 1;
-            b = bn;
-            if (k == len) ph = phDone;
+            b = bn; bn = bn2;
+        };
+        auto micro = [&](bool first) {
+            const bool ready = act && ph != phDone && ps == pNone && pe == pNone;
+            fail = 0;
+            if (first && ready && ph == phLF) {              // M2: both jumps and their fast-forwards are done
+                ff_total += ffs + ffe;
+                if (ffs >= 65535u || ffe >= 65535u) errc = kErrFastForward;   // move_structure.cpp:72-75
+                else if ((rs < re) || (rs == re && os <= oe)) {  // query_zml :717-720
+                    ml += 1;
+                    book();
+                    ph = k == len ? phDone : phStart;
+                } else fail = 1;
+            } else if (first && ready && ph == phInit) {     // the rows of a new phrase's ends have arrived
+                ph = phStart;
+            }
+            if (ph == phStart && n_emit == 0u && act && b == 0xFFu) fail = 1;       // illegal base: no phrase
+            if (ph == phStart && n_emit == 0u && act && open == 0u) fail = 1;       // no phrase to extend
+            if (ph == phStart && act && fail == 0u && open != 0u && b != 0xFFu) {   // M0: update_interval begins
+                ps = (rs == end_row || row_c<MODE>(rws) != b) ? pScan : pNone;
+                pe = (re == end_row || row_c<MODE>(rwe) != b) ? pScan : pNone;
+                lo = rs; hi = re; dead = 0;
+                ph = phScan;
+            }
+            if (ph == phScan && act && ps == pNone && pe == pNone && errc == kErrNone) {   // M1: scans done (or none needed)
+                if (dead == 0u && ((rs < re) || (rs == re && os <= oe))) {
+                    const uint64_t ja = row_id<MODE>(rws, (uint64_t)rs, ix), jb = row_id<MODE>(rwe, (uint64_t)re, ix);
+                    if (ja >= ix.r || jb >= ix.r) errc = kErrIdRange;       // move_structure.cpp:63-65
+                    else {
+                        os += row_off<MODE>(rws);
+                        oe += row_off<MODE>(rwe);
+                        rs = (IdxT)ja; re = (IdxT)jb;
+                        // (AH) both targets are reached below their lengths -- known from the entries -- and the interval they
+                        // span is not empty: the step is complete without their rows (query_zml :717-720: ml + 1), and what
+                        // the next base needs of them -- character, offset, their own targets -- is in the entries too
+                        const uint32_t la = AH ? (uint32_t)first & (ens.y >> 31) & (ene.y >> 31) & (uint32_t)(os < (ens.y & 0x7FFu)) &
+                                                 (uint32_t)(oe < (ene.y & 0x7FFu)) & (uint32_t)((rs < re) || (rs == re && os <= oe))
+                                               : 0u;
+                        if (la) {
+                            ml += 1;
+                            book();
+                            rws = row_of_entry(ens); rwe = row_of_entry(ene);
+                            ens = make_uint2(0u, 0u); ene = make_uint2(0u, 0u);
+                            ph = k == len ? phDone : phStart;
+                            la_taken = 1;
+                        } else {
+                            ps = pFF; pe = pFF; ffs = 0; ffe = 0;
+                            ph = phLF;
+                        }
+                    }
+                } else if (n_emit == 0u) {
+                    fail = 1;                                // (with an emission already made in this iteration: decided again
+                }                                            // in the next one -- ph stays phScan)
+            }
+            if (fail) {                                      // :750-760 / :696-704: the base opens the next phrase
+                ml = 0;
+                open = 0;
+                ph = phStart;
+                if (b != 0xFFu) {                            // initialize_backward_search :284-291
+                    rs = (IdxT)ix.first_runs[b + 1]; re = (IdxT)ix.last_runs[b + 1];
+                    os = (uint32_t)ix.first_offsets[b + 1]; oe = (uint32_t)ix.last_offsets[b + 1];
+                    open = ((rs < re) || (rs == re && os <= oe)) ? 1u : 0u;
+                    if (open) { ps = pFF; pe = pFF; ffs = 65535u; ffe = 65535u; ph = phInit; }   // rows only: no fast-forward
+                }
+                book();
+                if (k == len) ph = phDone;
+            }
+        };
+        micro(true);
+        if (AH) {
+            if (wave_any(la_taken != 0u)) {                  // the base after a look-ahead step: its shrink begins, or its LF moves leave
+                if (la_taken && errc == kErrNone) micro(false);
+            }
         }
         if (errc) { failed = errc; ph = phDone; ps = pNone; pe = pNone; }
         // ---- 3. the next two windows leave now; everything below runs under their latency
@@ -3205,14 +3251,13 @@ __global__ __launch_bounds__(256) void zml_kernel_flat(DevIndex ix, const uint8_
             const IdxT ns = ps == pScan ? (IdxT)(rs + 1) : rs, ne = pe == pScan ? (IdxT)(re - (re > 0 ? 1 : 0)) : re;
             wbs = ps != pNone ? win_base(ns) : (IdxT)0;
             wbe = pe != pNone ? win_base(ne) : (IdxT)0;
-            load_window<MODE>(ix.rows, (uint64_t)wbs, ws);
-            load_window<MODE>(ix.rows, (uint64_t)wbe, we);
+            fetch_win(wbs, ws, es);
+            fetch_win(wbe, we, ee);
         }
-        // ---- 4. bookkeeping: emission and the next base
+        // ---- 4. bookkeeping: the emissions and the next bases
         uint32_t want_nx = 0;
         uint64_t nx_e = 0;
-        if (do_emit) {
-            const uint32_t val = ml > 65535u ? 65535u : ml;               // MoveQuery::add_ml
+        auto emit_at = [&](uint32_t ek, uint32_t val) {
             if (SEG == 1) {
                 if ((ek & 31u) == 31u) {
                     ZSegCkpt ck;
@@ -3241,7 +3286,10 @@ __global__ __launch_bounds__(256) void zml_kernel_flat(DevIndex ix, const uint8_
                     __builtin_memcpy(O + (ek - 7), &pk, 16);
                 }
             }
-            const uint32_t j = k + 1;                        // k = ek + 1 is decoded already: look one step further
+        };
+        // one more base decoded ahead per emission: step j = (step of the emission) + 3 moves into the last place of (b, bn, bn2)
+        auto decode_ahead = [&](uint32_t j, uint32_t &dst) {
+            dst = 0xFFu;
             if (j < len) {
                 if ((j & 15) == 8) {
                     rb = rb2;
@@ -3251,7 +3299,17 @@ __global__ __launch_bounds__(256) void zml_kernel_flat(DevIndex ix, const uint8_
                     fix_pair(beg + len - j, rb, rb2);
                     if (j + 16 < len) { want_nx = 1; nx_e = beg + len - j - 16; }
                 }
-                bn = s_code[(uint32_t)(rb >> (8 * (7 - (j & 7)))) & 0xFFu];
+                dst = s_code[(uint32_t)(rb >> (8 * (7 - (j & 7)))) & 0xFFu];
+            }
+        };
+        if (n_emit) {
+            emit_at(ekA, valA);
+            if (n_emit == 2u) {
+                emit_at(ekB, valB);
+                decode_ahead(ekA + 3u, bn);                   // (b, bn, bn2) were shifted twice: two places to fill
+                decode_ahead(ekB + 3u, bn2);
+            } else {
+                decode_ahead(ekA + 3u, bn2);
             }
         }
         if (want_nx) load_pair_at(nx_e, nx0, nx1);
@@ -3437,10 +3495,15 @@ hipError_t launch_zml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     const uint64_t blocks = (n_reads + bt - 1) / bt;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     dim3 grid((unsigned)blocks), block((unsigned)bt);
+    // The state machine on the look-ahead rows (round 4; "zml_ahead" 1, where the copy exists): a base both of whose LF moves
+    // land without a fast-forward is complete without the target rows.  Lane iterations per base on c2 1.45 -> 0.98 -- and 37.3
+    // instead of 38.2 Gbases/s (eight 16-byte loads per iteration instead of four, SIMT 0.72 -> 0.64; random 10 M-row table 35.9 ->
+    // 35.0: profiles/r04_zml_ahead.txt), so it is an option, not the default.
+    const bool ahead = cfg.zml_ahead != 0 && v == 1 && mode == 6 && ix.rows2 != nullptr;
     if (info) {
-        if (v == 1) snprintf(info->kernel, sizeof(info->kernel), "zml_kernel_flat<%d, %s, 0>", mode, ix.idx32 ? "unsigned int" : "unsigned long");
+        if (v == 1) snprintf(info->kernel, sizeof(info->kernel), "zml_kernel_flat<%d, %s, 0%s>", mode, ix.idx32 ? "unsigned int" : "unsigned long", ahead ? ", 1" : "");
         else snprintf(info->kernel, sizeof(info->kernel), "zml_kernel<%d, 0>", mode);
-        info->variant = v; info->block_threads = bt; info->waves_per_cu = cfg.waves_per_cu > 0 ? cfg.waves_per_cu : 0; info->staged = 0; info->ahead = 0;
+        info->variant = v; info->block_threads = bt; info->waves_per_cu = cfg.waves_per_cu > 0 ? cfg.waves_per_cu : 0; info->staged = 0; info->ahead = ahead ? 1 : 0;
         info->segmented = 0; info->idx64 = ix.idx32 ? 0 : 1;
     }
     size_t dyn_lds = 0;                                  // occupancy cap by LDS padding, as in launch_pml (<= 64 KiB here)
@@ -3462,7 +3525,14 @@ hipError_t launch_zml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
                                d_offsets, n_reads, d_out, d_err, d_stats, d_order, ZSegArgs());                \
     } while (0)
     // resident layouts: 6 = regular-thresholds rows, 3 = regular rows (threshold-less types: 12-bit lengths)
-    if (mode == 6) MOVI_LAUNCH_ZML(6);
+    if (mode == 6 && ahead) {
+        if (ix.idx32)
+            hipLaunchKernelGGL((zml_kernel_flat<6, uint32_t, 0, 1>), grid, block, dyn_lds, stream, ix, d_bases, d_offsets, n_reads, d_out,
+                               d_err, d_stats, d_order, ZSegArgs());
+        else
+            hipLaunchKernelGGL((zml_kernel_flat<6, uint64_t, 0, 1>), grid, block, dyn_lds, stream, ix, d_bases, d_offsets, n_reads, d_out,
+                               d_err, d_stats, d_order, ZSegArgs());
+    } else if (mode == 6) MOVI_LAUNCH_ZML(6);
     else if (mode == 3) MOVI_LAUNCH_ZML(3);
     else return hipErrorInvalidValue;
 #undef MOVI_LAUNCH_ZML

@@ -119,6 +119,7 @@ struct LaunchCfg {
                            // so that a few hundred reads already go through many refills per lane)
     int refill_batch = 0;  // variant 13: idle lanes switch to their next reads when this many wait (0 = 16)
     int inwin = 1;         // repositions inside the window resolved in the same iteration (0 = off: A/B)
+    int zml_ahead = 0;     // 1: zml_kernel_flat<6, T, 0, 1> on the look-ahead rows where they exist (a third fewer iterations, no faster: opt-in)
 };
 
 // What a launch_* call actually launched (movi_last_launch): the policy lives in the launchers, so they say what they picked.

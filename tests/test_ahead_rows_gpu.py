@@ -273,6 +273,58 @@ def test_count_on_the_look_ahead_rows_vs_oracle(built_lib, golden_image, mode):
     cpu.close()
 
 
+@pytest.mark.parametrize("mode", [6, 8, 7])
+def test_zml_on_the_look_ahead_rows_vs_oracle(built_lib, golden_image, mode):
+    """The ZML parse (query_zml, src/move_structure_query.cpp:690-785) as a lane state machine on the look-ahead rows: a base
+    both of whose LF moves land without a fast-forward -- known from the entries of the interval's two ends -- is complete
+    without the target rows, and the next base starts from what the entries say about them (zml_kernel_flat<6, T, 0, 1>).
+    Match lengths, error bytes and the fast-forward / scan counters equal the oracle's and the plain-rows kernel's: exact
+    substrings (look-ahead steps all the way), reads with substitutions and illegal bases next to and inside such steps,
+    every read length around the 8- / 16-base groups of the packed I/O, both index widths, small and big batches."""
+    import movi_amd
+    from oracle import build_index as B
+    from oracle.oracle import Oracle
+    ref = _ref()
+    img = golden_image(mode) if mode != 7 else B.build_index_from_seqs([ref], 7)
+    gpu, cpu = movi_amd.MoveIndex.from_image(img), Oracle(img)
+    rng = np.random.default_rng(9900 + mode)
+    reads = mutated_reads(rng, ref, 2500, 1, 400)
+    reads += [bytes(ref[s: s + L]) for s, L in ((100, 1), (100, 2), (100, 3), (200, 7), (200, 8), (200, 9), (300, 15), (300, 16), (300, 17),
+                                                (400, 31), (400, 32), (400, 33), (5000, 150), (7000, 1000), (9000, 4000))]
+    base = bytearray(ref[30000:30200])
+    for pos in (1, 2, 3, 4, 5, 13, 14, 15, 16, 17, 18):                  # an illegal base at distance pos from the read's end
+        for bad in (b"N", b"a"):
+            r = bytearray(base)
+            r[len(r) - pos: len(r) - pos + 1] = bad
+            reads.append(bytes(r))
+    reads += [b"", b"A", b"N", b"ACGT" * 40, bytes(rng.choice(list(b"ACGT"), size=60).astype(np.uint8))]
+    bases, offs = pack(reads)
+    exp = cpu.zml_batch(bases, offs, threads=8)
+    gpu.set_option("seg_len", 0)
+    gpu.set_option("zml_variant", 1)
+    gpu.set_option("zml_ahead", 1)                                        # (opt-in: a third fewer iterations, no faster)
+    for idx64 in (0, 1):
+        gpu.set_option("idx64", idx64)
+        gpu.set_option("ahead_rows", 0)
+        out0, st0 = gpu.query_zml_packed(bases, offs)
+        li = gpu.last_launch()
+        assert li["ahead"] == 0 and li["kernel"].startswith("zml_kernel_flat<6, ") and li["kernel"].endswith(", 0>")
+        assert (out0 == exp).all() and st0.errors == 0
+        gpu.set_option("ahead_rows", 1)
+        out, st = gpu.query_zml_packed(bases, offs)
+        li = gpu.last_launch()
+        assert li["ahead"] == 1 and li["kernel"].endswith(", 0, 1>") and li["idx64"] == idx64
+        assert (out == exp).all(), (mode, idx64)
+        assert (st.fast_forwards, st.scans, st.errors) == (st0.fast_forwards, st0.scans, 0), (mode, idx64)
+    gpu.set_option("idx64", 0)
+    bb, bo = _big_batch(ref, rng, max_len=200, n_long=20)
+    bexp = cpu.zml_batch(bb, bo, threads=8)
+    bout, bst = gpu.query_zml_packed(bb, bo)
+    assert gpu.last_launch()["ahead"] == 1 and (bout == bexp).all() and bst.errors == 0
+    gpu.close()
+    cpu.close()
+
+
 def test_count_on_the_look_ahead_rows_separators_and_corrupt_rows(built_lib, golden_image):
     import movi_amd
     from oracle import build_index as B
