@@ -72,7 +72,9 @@ WorkerPool::~WorkerPool() {
     { std::lock_guard<std::mutex> g(m_); stop_ = true; }
     cv_.notify_all();
     for (auto &t : th_) t.join();
-    if (pinned_owner_) (void)pthread_setaffinity_np(owner_, sizeof(owner_mask_), &owner_mask_);
+    // (only from the owner itself: in `movi query` the owner is the parser thread, which is gone by the time the reader is
+    // destroyed -- its handle must not be touched)
+    if (pinned_owner_ && pthread_equal(pthread_self(), owner_)) (void)pthread_setaffinity_np(owner_, sizeof(owner_mask_), &owner_mask_);
 }
 
 void WorkerPool::loop() {
