@@ -601,7 +601,10 @@ int replicate(const movi_index_desc_t *desc, const void *h_rows, const int *devi
         for (int j = 0; j < i; j++)
             if (devices[j] == devices[i]) return fail(MOVI_ERR_ARG, "the devices of a replicated index must be distinct");
     }
-    if (!g_rccl.load()) return fail(MOVI_ERR_HIP, g_rccl.err);
+    // One GPU: nothing crosses xGMI, so a missing librccl is no reason to fail (`movi query --gpus 1`); when the library is
+    // there the one-rank communicator still runs -- the same calls as N ranks, which is how 1-GPU boxes test this path.
+    const bool have_rccl = g_rccl.load();
+    if (!have_rccl && n > 1) return fail(MOVI_ERR_HIP, g_rccl.err);
     const size_t rows_bytes = (size_t)desc->r * mode_row_bytes(desc->mode);
     std::vector<uint8_t *> d_rows((size_t)n, nullptr);
     std::vector<hipStream_t> streams((size_t)n, nullptr);
@@ -645,22 +648,24 @@ int replicate(const movi_index_desc_t *desc, const void *h_rows, const int *devi
         StdoutToStderr() { fflush(stdout); saved = dup(1); if (saved >= 0) dup2(2, 1); }
         ~StdoutToStderr() { fflush(stdout); if (saved >= 0) { dup2(saved, 1); close(saved); } }
     };
-    ncclResult_t r;
-    {
-        StdoutToStderr quiet;
-        r = g_rccl.CommInitAll(comms.data(), n, devices);
+    if (have_rccl) {
+        ncclResult_t r;
+        {
+            StdoutToStderr quiet;
+            r = g_rccl.CommInitAll(comms.data(), n, devices);
+        }
+        if (r != ncclSuccess) return nccl_fail(r, "ncclCommInitAll");
+        comms_up = true;
+        r = g_rccl.GroupStart();
+        if (r != ncclSuccess) return nccl_fail(r, "ncclGroupStart");
+        for (int i = 0; i < n && r == ncclSuccess; i++) {
+            (void)hipSetDevice(devices[i]);
+            r = g_rccl.Broadcast(d_rows[i], d_rows[i], rows_bytes, ncclUint8, 0, comms[i], streams[i]);
+        }
+        const ncclResult_t rg = g_rccl.GroupEnd();
+        if (r != ncclSuccess) return nccl_fail(r, "ncclBroadcast");
+        if (rg != ncclSuccess) return nccl_fail(rg, "ncclGroupEnd");
     }
-    if (r != ncclSuccess) return nccl_fail(r, "ncclCommInitAll");
-    comms_up = true;
-    r = g_rccl.GroupStart();
-    if (r != ncclSuccess) return nccl_fail(r, "ncclGroupStart");
-    for (int i = 0; i < n && r == ncclSuccess; i++) {
-        (void)hipSetDevice(devices[i]);
-        r = g_rccl.Broadcast(d_rows[i], d_rows[i], rows_bytes, ncclUint8, 0, comms[i], streams[i]);
-    }
-    const ncclResult_t rg = g_rccl.GroupEnd();
-    if (r != ncclSuccess) return nccl_fail(r, "ncclBroadcast");
-    if (rg != ncclSuccess) return nccl_fail(rg, "ncclGroupEnd");
     for (int i = 0; i < n; i++) {
         hipError_t e = hipSetDevice(devices[i]);
         if (e == hipSuccess) e = hipStreamSynchronize(streams[i]);
@@ -895,6 +900,11 @@ int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
     if (!strcmp(key, "refill_batch")) {                      // tuning: idle lanes of a lane-refill wavefront switch when this many wait
         if (value < 0 || value > 64) return fail(MOVI_ERR_ARG, "refill_batch must be in [0, 64]");
         ix->cfg.refill_batch = (int)value;
+        return MOVI_OK;
+    }
+    if (!strcmp(key, "classify_fused")) {                    // -1 auto, 1: vector + bins in one kernel, 0: walk, then a streaming pass over the vectors
+        if (value < -1 || value > 1) return fail(MOVI_ERR_ARG, "classify_fused must be -1, 0 or 1");
+        ix->cfg.classify_fused = (int)value;
         return MOVI_OK;
     }
     if (!strcmp(key, "zml_ahead")) {                         // 1: the ZML state machine walks on the look-ahead rows where they exist (A/B: measured no faster)
@@ -1649,6 +1659,7 @@ int movi_classify_device(movi_index_t *ix, const uint16_t *d_pml, const uint64_t
     return MOVI_OK;
 }
 
+constexpr uint64_t kClassifyTwoPassLen = 1024;          // mean read length from which vector + bins run as walk + pass (short reads: fused 71.5 against 63.5 on c2)
 static int pml_classify_device(movi_index_t *ix, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
                                uint64_t n_bases, uint32_t bin_width, uint32_t max_value_thr, uint16_t *d_out_pml,
                                uint32_t *d_bins_above, uint32_t *d_bins_below, uint64_t *d_sum_max, uint8_t *d_read_err,
@@ -1662,6 +1673,22 @@ static int pml_classify_device(movi_index_t *ix, const uint8_t *d_bases, const u
     cls.above = d_bins_above;
     cls.below = d_bins_below;
     cls.sum_max = d_sum_max;
+    // When the PML vector is wanted anyway, the bins are cheaper as a second, streaming pass over the resident vectors
+    // (classify_kernel: 2 B per base at HBM speed) than fused into the walk: the running bins cost the latency-bound walk
+    // ~20 instructions per emission and eight registers -- 100 k x 10 kbp: fused 46.9, walk + pass 53.6 Gbases/s
+    // (profiles/r04_classify.txt).  Bins WITHOUT the vector (--classify --filter, --no-output) stay fused: nothing is
+    // written at all (60.7).  "classify_fused" 1 / 0 forces either; the pass needs the error bytes (failed reads report
+    // no bins), so without d_read_err the fused kernel runs.
+    const bool two_pass = d_out_pml != nullptr && d_read_err != nullptr && n_reads != 0 &&
+                          (ix ? (ix->cfg.classify_fused == 0 || (ix->cfg.classify_fused < 0 && n_bases / n_reads >= kClassifyTwoPassLen)) : false);
+    if (two_pass) {
+        const int rc = ml_device(false, ix, d_bases, d_offsets, n_reads, n_bases, d_out_pml, d_read_err, d_read_order, stream, ClsArgs(),
+                                 d_stats, seg_ws, ragged_hint, seg_verdict);
+        if (rc != MOVI_OK) return rc;
+        HIP_TRY(launch_classify(d_out_pml, d_offsets, n_reads, bin_width, max_value_thr, d_bins_above, d_bins_below, d_sum_max,
+                                static_cast<hipStream_t>(stream), d_read_err, n_bases));
+        return MOVI_OK;
+    }
     // (a chunk in flight of the overlapped host path brings its own segment workspace, length hint and the call's probe
     // verdict: without them every chunk fell back to the handle's workspace -- shared by chunks on different streams --
     // and probed again)

@@ -736,18 +736,21 @@ __device__ __forceinline__ uint2 win_sel(const uint2 (&w)[4], uint32_t q) {
 // 36.4 / 33.6; chunk double-buffering alone 35.1 / 32.4; pipelined HA = 1 / 2 / 3: 40.2 / 39.6 / 38.9 (pangenome),
 // 36.3 / 36.6 / 36.2 (random) -> HA = 2 shipped.  Hops after the step (HC > 0) measured slower and are gone.
 // REFILL = 1 ("lane refill", variant 13; staged kernels only): the same automaton as a PERSISTENT grid of
-// num_cus x waves_per_cu wavefronts whose lanes take a new read when they have finished one.  Without it a wavefront runs
+// num_cus x waves_per_cu wavefronts (any grid works: blocks that start late find the counter further on) whose lanes take a
+// new read when they have finished one.  Without it a wavefront runs
 // until its slowest lane is done, and reads differ a lot: a substitution costs a read about a dozen repositions (the walk
 // needs ~15 bases to fall back into step with the text), so on 1 M x 150 bp with 1 % substitutions only 68 % of the lane
 // iterations do work on the look-ahead rows and 61 % on the chain rows (tools/iter_model.c predicts both figures).
-//   * Tickets are wave-local and need no atomics: wave v's t-th read is rid_of(t) -- chunks of 16 consecutive reads dealt
-//     round-robin to the waves -- so a refill is integer arithmetic on a wave-uniform counter (ballot + mbcnt).  Across
-//     waves the split is static (each wave walks ~n_reads / n_waves reads, so length differences average out); inside a
-//     wave it is dynamic.  The launcher sizes the grid so that all of it is resident.
+//   * Reads come from ONE global ticket counter (DevStats::ticket) in chunks of 16 consecutive reads -- an atomic per chunk --
+//     into a POOL of upcoming reads per wavefront: 64 slots across the lanes (read number, where its bases start, its
+//     length), consumed in ring order by whichever lanes are idle at a switch (ds_bpermute).  A chunk takes two switches to
+//     arrive -- its ticket is drawn at one, its offsets are requested at the next, they join the pool at the one after -- so
+//     nothing about the pool waits on memory by itself.  (The first version dealt the reads to the wavefronts statically and
+//     let every lane hold its next read: the slowest wavefront ended 9 - 22 % behind the mean, and busy lanes sat on
+//     reservations idle lanes could have used: profiles/r04_lane_refill.txt.)
 //   * Refills come in BATCHES: a switch stages the new read's bases into the lane's LDS stretch and takes its first K
-//     bases from the top-of-walk table -- two memory round trips in which the whole wavefront stands still -- so idle lanes
-//     wait until DevIndex::refill_batch of them (or every lane that still has work) can switch together.  The offsets of
-//     a lane's next read are fetched when it starts the read before, i.e. they are there long before the switch.
+//     bases from the top-of-walk table -- memory round trips in which the whole wavefront stands still -- so idle lanes
+//     wait until DevIndex::refill_batch of them (or every lane that still has work) can switch together.
 //   * Results of a read (error byte, bins, zero-fill on failure) are written when its lane switches (or at the end).
 // `order` is not supported (longest-first ordering is what refill replaces).
 // SEG (segment-parallel long reads, movi_kernels.hpp): 0 = a lane walks a read; 1 = a lane walks one SEGMENT of a read
@@ -3588,10 +3591,78 @@ __global__ __launch_bounds__(256) void classify_kernel(const uint16_t *__restric
     sum_max[t] = sum;
 }
 
+// The same reduction with a WAVEFRONT per read (long reads): lane l takes bins l, l + 64, ... -- a bin is bin_width contiguous
+// values, so a wavefront streams 64 x bin_width x 2 contiguous bytes per round, every byte of every line used -- and the
+// per-lane tallies are summed across the wavefront.  (One lane per read walks 16 bytes at a time through its own 20 KB:
+// 100 k x 10 kbp in 1.35 ms = 1.5 TB/s; this form: see profiles/r04_classify.txt.)
+__global__ __launch_bounds__(64) void classify_wave_kernel(const uint16_t *__restrict__ pml, const uint64_t *__restrict__ offs,
+                                                           uint64_t n_reads, uint32_t bin_width, uint32_t thr,
+                                                           uint32_t *__restrict__ above, uint32_t *__restrict__ below,
+                                                           uint64_t *__restrict__ sum_max, const uint8_t *__restrict__ err) {
+    const uint64_t t = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    if (t >= n_reads) return;
+    if (err && err[t]) {
+        if (lane == 0) { above[t] = 0; below[t] = 0; sum_max[t] = 0; }
+        return;
+    }
+    const uint64_t beg = offs[t], n = offs[t + 1] - beg;
+    const uint16_t *P = pml + beg;
+    uint64_t nb = n / bin_width;                          // bins: [iW, (i+1)W) for i < nb-1, last = [(nb-1)W, n)
+    if (nb == 0) nb = 1;
+    uint32_t a = 0, b = 0, s_lo = 0, s_hi = 0;            // (the sum of a lane's bin maxima: < 2^16 x bins, carried in two halves)
+    if (n > 0) {
+        for (uint64_t bin = lane; bin < nb; bin += 64) {
+            const uint64_t s = bin * bin_width, e = (bin + 1 < nb) ? s + bin_width : n;
+            uint32_t cur = 0;
+            uint64_t k = s;
+            auto max8 = [](uint4 v) -> uint32_t {
+                const uint32_t m0 = max(v.x & 0xFFFFu, v.x >> 16), m1 = max(v.y & 0xFFFFu, v.y >> 16),
+                               m2 = max(v.z & 0xFFFFu, v.z >> 16), m3 = max(v.w & 0xFFFFu, v.w >> 16);
+                return max(max(m0, m1), max(m2, m3));
+            };
+            for (; k + 64 <= e; k += 64) {                    // eight 16-byte loads in flight per lane
+                uint4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) __builtin_memcpy(&v[u], P + k + 8 * u, 16);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) cur = max(cur, max8(v[u]));
+            }
+            for (; k + 8 <= e; k += 8) {
+                uint4 v;
+                __builtin_memcpy(&v, P + k, 16);
+                cur = max(cur, max8(v));
+            }
+            for (; k < e; ++k) cur = max(cur, (uint32_t)P[k]);
+            a += cur >= thr ? 1u : 0u;
+            b += cur >= thr ? 0u : 1u;
+            const uint32_t lo = s_lo + cur;
+            s_hi += lo < s_lo ? 1u : 0u;
+            s_lo = lo;
+        }
+    }
+    a = wave_sum(a);
+    b = wave_sum(b);
+    // 64-bit sum across the wavefront from two 32-bit halves (each lane's low half < 2^32; sum the halves as 64-bit values)
+    uint64_t tot = (uint64_t)s_lo | ((uint64_t)s_hi << 32);
+#pragma unroll
+    for (int sh = 32; sh > 0; sh >>= 1) {
+        const uint32_t olo = __shfl_xor((uint32_t)tot, sh, 64), ohi = __shfl_xor((uint32_t)(tot >> 32), sh, 64);
+        tot += (uint64_t)olo | ((uint64_t)ohi << 32);
+    }
+    if (lane == 0) { above[t] = a; below[t] = b; sum_max[t] = tot; }
+}
+
 hipError_t launch_classify(const uint16_t *d_pml, const uint64_t *d_offsets, uint64_t n_reads, uint32_t bin_width,
                            uint32_t thr, uint32_t *d_above, uint32_t *d_below, uint64_t *d_sum, hipStream_t stream,
-                           const uint8_t *d_err) {
+                           const uint8_t *d_err, uint64_t n_bases) {
     if (n_reads == 0) return hipSuccess;
+    // long reads (a caller that knows the batch's size says so): a wavefront per read
+    if (n_bases / n_reads >= 1024 && n_reads <= 0x7FFFFFFFull && bin_width > 0) {
+        hipLaunchKernelGGL(classify_wave_kernel, dim3((unsigned)n_reads), dim3(64), 0, stream, d_pml, d_offsets, n_reads, bin_width,
+                           thr, d_above, d_below, d_sum, d_err);
+        return hipGetLastError();
+    }
     const unsigned bt = 256;
     const uint64_t blocks = (n_reads + bt - 1) / bt;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;

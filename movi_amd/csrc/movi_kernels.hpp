@@ -119,6 +119,7 @@ struct LaunchCfg {
                            // so that a few hundred reads already go through many refills per lane)
     int refill_batch = 0;  // variant 13: idle lanes switch to their next reads when this many wait (0 = 16)
     int inwin = 1;         // repositions inside the window resolved in the same iteration (0 = off: A/B)
+    int classify_fused = -1; // movi_pml_classify_*: -1 auto, 1 = vector + bins fused into the walk, 0 = the walk, then classify_kernel over the vectors
     int zml_ahead = 0;     // 1: zml_kernel_flat<6, T, 0, 1> on the look-ahead rows where they exist (a third fewer iterations, no faster: opt-in)
 };
 
@@ -214,9 +215,10 @@ hipError_t launch_zml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
                       LaunchInfo *info = nullptr);
 
 // d_err (optional): reads flagged there report no bins (0, 0, 0), like the fused kernels.
+// n_bases (optional): the batch's size, if the caller knows it -- batches of long reads (mean >= 1024) take a wavefront per read.
 hipError_t launch_classify(const uint16_t *d_pml, const uint64_t *d_offsets, uint64_t n_reads, uint32_t bin_width,
                            uint32_t thr, uint32_t *d_above, uint32_t *d_below, uint64_t *d_sum, hipStream_t stream,
-                           const uint8_t *d_err = nullptr);
+                           const uint8_t *d_err = nullptr, uint64_t n_bases = 0);
 
 // Mode 7: ix = a mode-7 view (widened rows + tally table); writes r mode-6 rows (8 bytes each) with the ids recovered by get_id.
 hipError_t expand_sampled_rows(int mode, const DevIndex &ix, void *d_rows6, hipStream_t stream);   // mode 7 or 5

@@ -101,23 +101,32 @@ def test_c3_classify_at_size(pangenome):
     d_err = torch.zeros(n, dtype=torch.uint8, device=dev)
     bin_width, thr = 150, 8
     res = {}
-    for with_vector in (True, False):
+    # vector + bins fused into the walk (CLS = 1), the walk followed by the streaming pass over the vectors (what the policy
+    # picks for long reads: classify_wave_kernel), and bins without the vector (CLS = 2)
+    for name, with_vector, fused, cls in (("fused", True, 1, 1), ("two_pass", True, -1, 0), ("bins_only", False, -1, 2)):
+        gpu.set_option("classify_fused", fused)
         d_a = torch.full((n,), -1, dtype=torch.int32, device=dev)
         d_b = torch.full((n,), -1, dtype=torch.int32, device=dev)
         d_s = torch.full((n,), -1, dtype=torch.int64, device=dev)
+        d_out.zero_()
         gpu.pml_classify_device(d_bases.data_ptr(), d_offs.data_ptr(), n, n * L, bin_width, thr,
                                 d_out.data_ptr() if with_vector else 0, d_a.data_ptr(), d_b.data_ptr(), d_s.data_ptr(), d_err.data_ptr())
         torch.cuda.synchronize()
-        assert gpu.last_launch()["kernel"].startswith("pml_kernel_flatp<6, unsigned int, -1, %d," % (1 if with_vector else 2))
+        assert gpu.last_launch()["kernel"].startswith("pml_kernel_flatp<6, unsigned int, -1, %d," % cls), name
         assert int(d_err.sum().item()) == 0
-        res[with_vector] = (d_a.cpu().numpy(), d_b.cpu().numpy(), d_s.cpu().numpy())
-    # the verdict-only launch (no PML vector written) against the vector launch: all 100 000 reads
-    for x, y in zip(res[True], res[False]):
-        assert (x == y).all()
-    a, b, sm = res[True]
+        res[name] = (d_a.cpu().numpy(), d_b.cpu().numpy(), d_s.cpu().numpy())
+        if name == "fused":
+            got_fused = d_out.cpu().numpy().view(np.uint16).copy()
+        elif name == "two_pass":
+            assert (got_fused == d_out.cpu().numpy().view(np.uint16)).all()
+    # all 100 000 reads: the three launches agree
+    for other in ("two_pass", "bins_only"):
+        for x, y in zip(res["fused"], res[other]):
+            assert (x == y).all(), other
+    a, b, sm = res["fused"]
     assert ((a + b) == L // bin_width).all()                   # 66 bins of 150, the last one absorbs the remainder (classifier.cpp:110-115)
     # bins of slices against Classifier::classify over the ORACLE's PMLs, and the vectors themselves
-    got = d_out.cpu().numpy().view(np.uint16)
+    got = got_fused
     for lo in (0, 49_950, n - 100):
         sb = bases[lo * L: (lo + 100) * L]
         so = np.arange(101, dtype=np.uint64) * np.uint64(L)
