@@ -169,7 +169,9 @@ def pml_roofline(table_bytes, row_bytes, st, n_bases, kern_s, launch, traffic=No
     f_bar, s_bar = st.fast_forwards / max(n_bases, 1), st.scans / max(n_bases, 1)
     bpb = row_bytes * (1.0 + f_bar + s_bar) + 1 + 2
     ach = bpb * n_bases / kern_s / 1e9
-    return {"bound": bound_of(table_bytes), "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+    # (working set: the table the walk gathers from + the 256 MB top-of-walk table every read looks up once)
+    return {"bound": bound_of(table_bytes + (16 << 24)), "working_set_bytes": table_bytes + (16 << 24),
+            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": tsrc, "algorithmic_bytes_per_base": round(bpb, 3),
             "kernel": launch["kernel"], "launch": launch, "kernel_ms_avg": kern_s * 1e3,
             "lane_iterations_per_s": st.lane_steps / kern_s if st.wave_steps else None,
@@ -183,7 +185,8 @@ def count_roofline(table_bytes, row_bytes, st, matched_bases, kern_s, launch):
     f_bar, u_bar = st.fast_forwards / wb / 2.0, st.scans / wb
     bpb = 2 * row_bytes * (1.0 + f_bar) + row_bytes * u_bar + 1
     ach = bpb * wb / kern_s / 1e9
-    return {"bound": bound_of(table_bytes), "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+    return {"bound": bound_of(table_bytes + (16 << 24)), "working_set_bytes": table_bytes + (16 << 24),
+            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
             "traffic": None, "algorithmic_bytes_per_base": round(bpb, 3), "matched_bases_per_step": wb,
             "kernel": launch["kernel"], "launch": launch, "kernel_ms_avg": kern_s * 1e3}
 
@@ -377,7 +380,8 @@ def long_reads_leg(torch, dist, world, rank, dev, stream, index, idx_dir, rows, 
                "iterations_per_base": round(st3.lane_steps / (n3 * L3), 4) if st3.wave_steps else None,
                "fast_forwards_per_base": round(st3.fast_forwards / (n3 * L3), 4), "scans_per_base": round(st3.scans / (n3 * L3), 4),
                "errors": int(st3.errors), "segments": int(st3.segments), "rewalked_reads": int(st3.rewalked),
-               "roofline": pml_roofline(table_bytes_walked(rows, row_bytes, launch), row_bytes, st3, n3 * L3, kern3, launch)}
+               "roofline": pml_roofline(table_bytes_walked(rows, row_bytes, launch), row_bytes, st3, n3 * L3, kern3, launch,
+                                        *(lookup_traffic("c3", rows, n3, L3, launch["kernel"]) if cm == 0 else (None, None)))}
         if cm:
             verdicts[cm] = (d_a.clone(), d_b.clone(), d_s.clone())
         res[cm] = leg

@@ -279,6 +279,7 @@ static int finish_create(movi_index *ix) {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, ix->device));
     ix->cfg.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (const char *pl = getenv("MOVI_PAIR_LOADS")) ix->cfg.pair_loads = atoi(pl) > 0 ? 1 : (atoi(pl) < 0 ? -1 : 0);   // A/B and test hook: every handle's default for "pair_loads"
     HIP_TRY(hipMalloc(&ix->d_stats, sizeof(DevStats)));
     HIP_TRY(hipMemset(ix->d_stats, 0, sizeof(DevStats)));
     DevIndex &v = ix->dev;
@@ -905,6 +906,11 @@ int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
     if (!strcmp(key, "classify_fused")) {                    // -1 auto, 1: vector + bins in one kernel, 0: walk, then a streaming pass over the vectors
         if (value < -1 || value > 1) return fail(MOVI_ERR_ARG, "classify_fused must be -1, 0 or 1");
         ix->cfg.classify_fused = (int)value;
+        return MOVI_OK;
+    }
+    if (!strcmp(key, "pair_loads")) {                        // the lanes of a pair fetch their row windows together (A/B)
+        if (value < -1 || value > 1) return fail(MOVI_ERR_ARG, "pair_loads must be -1 (auto), 0 or 1");
+        ix->cfg.pair_loads = (int)value;
         return MOVI_OK;
     }
     if (!strcmp(key, "zml_ahead")) {                         // 1: the ZML state machine walks on the look-ahead rows where they exist (A/B: measured no faster)

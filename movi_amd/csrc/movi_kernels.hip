@@ -770,7 +770,27 @@ __device__ __forceinline__ uint2 win_sel(const uint2 (&w)[4], uint32_t q) {
 // would read at j = id(row) and at j2 = id(j), and where it goes from there (j3 = id(j2)) -- so that up to THREE bases are
 // resolved per gather while the read follows the text (tools/iter_model.c: lane iterations per base 0.68 -> 0.56 on c2).
 // Line = the 4 rows of an aligned window (32 bytes) + their 4 entries (64 bytes): six 16-byte loads of ONE 128-byte line.
-template <int MODE, typename IdxT, int HA, int CLS, int SEP, int REFILL, int SEG = 0, int STG = 0, int AHD = 0>
+// PSH = 1 (round 4: "pair-shared gathers"; staged kernels, plain and look-ahead rows): the two lanes of a pair (2i, 2i + 1) fetch
+// their windows TOGETHER -- one load instruction brings the even lane's window (each lane one 16-byte half), the next the odd
+// lane's, and one exchange across the pair (DPP quad_perm) hands every lane the half it is missing.  Same loads per lane,
+// same bytes -- but the two lanes' requests for adjacent bytes of a page are ONE address translation and ONE 32-byte access,
+// where a lane's two 16-byte loads are two of each: tools/tlb_bench (profiles/r04_pair_shared_gather_microbench.txt), 32-byte
+// window per chain step: 8 GB table 27.3 -> 49.4 G/s (the 8-byte gather rate), 2 GB 44.3 -> 54.8, 134 MB 52.0 -> 59.5.
+__device__ __forceinline__ uint32_t pair_swap(uint32_t v) {      // the other lane's value: lanes 2i <-> 2i + 1
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);   // quad_perm [1, 0, 3, 2]
+}
+// What lanes 2i / 2i+1 loaded as (r1: their half of the EVEN lane's 32 bytes, r2: of the ODD lane's) -> this lane's own 32 bytes
+__device__ __forceinline__ void pair_assemble(uint32_t odd, const uint4 &r1, const uint4 &r2, uint2 (&w)[4]) {
+    // even: first half = own r1, second = the odd lane's r1;  odd: first half = the even lane's r2, second = own r2.
+    // (Every lane makes every exchange -- a DPP read of a lane that sits out a branch returns nothing --, then selects.)
+    const uint32_t give_x = odd ? r1.x : r2.x, give_y = odd ? r1.y : r2.y, give_z = odd ? r1.z : r2.z, give_w = odd ? r1.w : r2.w;
+    const uint32_t got_x = pair_swap(give_x), got_y = pair_swap(give_y), got_z = pair_swap(give_z), got_w = pair_swap(give_w);
+    w[0] = odd ? make_uint2(got_x, got_y) : make_uint2(r1.x, r1.y);
+    w[1] = odd ? make_uint2(got_z, got_w) : make_uint2(r1.z, r1.w);
+    w[2] = odd ? make_uint2(r2.x, r2.y) : make_uint2(got_x, got_y);
+    w[3] = odd ? make_uint2(r2.z, r2.w) : make_uint2(got_z, got_w);
+}
+template <int MODE, typename IdxT, int HA, int CLS, int SEP, int REFILL, int SEG = 0, int STG = 0, int AHD = 0, int PSH = 0>
 __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8_t *__restrict__ bases,
                                                        const uint64_t *__restrict__ offs, uint64_t n_reads,
                                                        uint16_t *__restrict__ out, uint8_t *__restrict__ err,
@@ -779,6 +799,7 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
     static_assert(SEG == 0 || (CLS == 0 && REFILL == 0), "segments: plain PML, no refill");
     static_assert(REFILL == 0 || (STG == 1 && HA < 0), "lane refill: staged reads, window-parallel advance");
     static_assert(AHD == 0 || (STG == 1 && HA < 0), "look-ahead rows: staged reads, window-parallel advance");
+    static_assert(PSH == 0 || (STG == 1 && REFILL == 0 && AHD != 2), "pair-shared gathers: staged kernels without refill, plain or look-ahead rows");
     enum : uint32_t { sFF = 0, sDown = 1, sUp = 2, sDone = 3 };
     __shared__ uint8_t s_code[256];
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = ix.code_of[i];
@@ -836,7 +857,29 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
     };
     uint2 ahw[4];                                         // AHD: the look-ahead entries of the window's four rows ...
     uint2 ahv[4];                                         // ... AHD == 2: and their second halves (the row after the next)
+    uint4 raw[4];                                         // PSH: what this lane loaded for its pair (rows: 0, 1; entries: 2, 3), assembled at the loop's top
+    const uint32_t odd_lane = threadIdx.x & 1u;
     auto fetch = [&](IdxT nd, bool act, uint2 (&w)[4]) {
+        if (PSH) {
+            // byte offset of this lane's window in the table it walks on (AHD: the look-ahead copy, entries 64 bytes further on)
+            uint64_t at;
+            if (AHD) {
+                const IdxT wb = nd & ~(IdxT)3;
+                at = wb < wb_last ? (uint64_t)(wb >> 3) * 128u + (uint64_t)((uint32_t)wb & 4u) * 8u : ix.rows2_tail;
+            } else {
+                at = (uint64_t)win_base(nd) * 8u;
+            }
+            if (!act) at = 0;
+            const uint64_t pat = (uint64_t)pair_swap((uint32_t)at) | ((uint64_t)pair_swap((uint32_t)(at >> 32)) << 32);
+            const uint8_t *tab = AHD ? ix.rows2 : ix.rows;
+            const uint8_t *pe = tab + (odd_lane ? pat : at) + 16u * odd_lane;    // this lane's half of the even lane's window
+            const uint8_t *po = tab + (odd_lane ? at : pat) + 16u * odd_lane;    // ... and of the odd lane's
+            __builtin_memcpy(&raw[0], pe, 16);
+            if (AHD) __builtin_memcpy(&raw[2], pe + 64u, 16);
+            __builtin_memcpy(&raw[1], po, 16);
+            if (AHD) __builtin_memcpy(&raw[3], po + 64u, 16);
+            return;
+        }
         if (AHD == 2) {                                   // chain rows: line = the window's 4 rows + their 4 16-byte entries
             const IdxT wb = nd & ~(IdxT)3;
             const bool body = wb < wb_last;
@@ -1121,6 +1164,10 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
         const bool act = st < sDone;
         lane_steps += (uint32_t)act;
         wave_steps += 1;
+        if (PSH) {                                        // the halves the pair loaded for each other change hands
+            pair_assemble(odd_lane, raw[0], raw[1], w);
+            if (AHD) pair_assemble(odd_lane, raw[2], raw[3], ahw);
+        }
         const IdxT wbase = win_base(need);
         // cheap hop: a fast-forward or scan step that only moves on (everything that resolves a base,
         // starts a scan, ends one or fails is left to the full step below)
@@ -2204,6 +2251,13 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     if (v == 13 && ixl.stage_lds == 0u) return hipErrorInvalidValue;                  // (cannot happen: the refill launch is capped)
     const bool use_ahead = ahead_ok && ixl.stage_lds != 0u;
     const bool use_chain = chain_ok && ixl.stage_lds != 0u;
+    // pair-shared gathers (pml_kernel_flatp<..., PSH = 1>): the staged default walk on the plain or the look-ahead rows
+    // Where: on tables beyond the reach of the per-CU TLBs (~2 GB), where a lane's two (four) 16-byte loads are as many
+    // translation requests and the L2 TLB's request rate bounds the walk -- real BWT of 226 M rows on the look-ahead rows (3.6 GB
+    // copy) 39.4 -> 50.8 Gbases/s, the random 8 GB table 32.6 -> 34.7; below that the exchange costs more than the merged
+    // accesses give (113 M rows +1.5 %, c2 -2.5 %, c3 -9 %: profiles/r04_pair_shared_gathers.txt).  "pair_loads" 1 / 0 forces it.
+    const uint64_t walked_bytes = ix.r * (use_ahead ? 16ull : 8ull);
+    const bool use_pair = (cfg.pair_loads > 0 || (cfg.pair_loads < 0 && walked_bytes >= (2ull << 30))) && ixl.stage_lds != 0u && v == 10 && !use_chain;
     const SegArgs no_seg;
     // every kernel that is handed more than 64 KiB of dynamic LDS must opt in first
 #define MOVI_SEG_0
@@ -2237,7 +2291,13 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     } while (0)
 #define MOVI_LAUNCH_FLATP_STG(M, C, S, R)                                                                   \
     do {                                                                                                    \
-        if (use_chain) {                                                                                    \
+        if (use_pair && R == 0 && use_ahead) {                                                              \
+            if (ix.idx32) MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint32_t, -1, C, S, 0, 0, 1, 1, 1>);        \
+            else MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint64_t, -1, C, S, 0, 0, 1, 1, 1>);                 \
+        } else if (use_pair && R == 0) {                                                                    \
+            if (ix.idx32) MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint32_t, -1, C, S, 0, 0, 1, 0, 1>);        \
+            else MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint64_t, -1, C, S, 0, 0, 1, 0, 1>);                 \
+        } else if (use_chain) {                                                                             \
             if (ix.idx32) MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint32_t, -1, C, S, R, 0, 1, 2>);           \
             else MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint64_t, -1, C, S, R, 0, 1, 2>);                    \
         } else if (use_ahead) {                                                                             \
@@ -2277,8 +2337,8 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
         const char *it = ix.idx32 ? "unsigned int" : "unsigned long";
         if (v == 0 || v == 1) snprintf(info->kernel, sizeof(info->kernel), "pml_kernel<6, %d, %d>", v, v == 0 ? 0 : cm);
         else if (v == 7) snprintf(info->kernel, sizeof(info->kernel), "pml_kernel_flat<6, %s, 0>", it);
-        else snprintf(info->kernel, sizeof(info->kernel), "pml_kernel_flatp<6, %s, %d, %d, %d, %d, 0, %d, %d>", it, (wp || v == 13) ? -1 : MOVI_HA, cm,
-                      ix.sep ? 1 : 0, v == 13 ? 1 : 0, ixl.stage_lds ? 1 : 0, use_ahead ? 1 : (use_chain ? 2 : 0));
+        else snprintf(info->kernel, sizeof(info->kernel), "pml_kernel_flatp<6, %s, %d, %d, %d, %d, 0, %d, %d%s>", it, (wp || v == 13) ? -1 : MOVI_HA, cm,
+                      ix.sep ? 1 : 0, v == 13 ? 1 : 0, ixl.stage_lds ? 1 : 0, use_ahead ? 1 : (use_chain ? 2 : 0), use_pair ? ", 1" : "");
         info->variant = (v == 10 && wp) ? 14 : v;
         info->block_threads = bt; info->waves_per_cu = wpc; info->segmented = 0; info->idx64 = ix.idx32 ? 0 : 1;
         info->staged = (int)ixl.stage_lds;

@@ -120,6 +120,7 @@ struct LaunchCfg {
     int refill_batch = 0;  // variant 13: idle lanes switch to their next reads when this many wait (0 = 16)
     int inwin = 1;         // repositions inside the window resolved in the same iteration (0 = off: A/B)
     int classify_fused = -1; // movi_pml_classify_*: -1 auto, 1 = vector + bins fused into the walk, 0 = the walk, then classify_kernel over the vectors
+    int pair_loads = -1;   // the lanes of a pair fetch their row windows together (pml_kernel_flatp<..., PSH = 1>): -1 auto (tables of 2 GB and more), 0 never, 1 always
     int zml_ahead = 0;     // 1: zml_kernel_flat<6, T, 0, 1> on the look-ahead rows where they exist (a third fewer iterations, no faster: opt-in)
 };
 

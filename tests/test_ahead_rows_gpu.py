@@ -488,3 +488,46 @@ def test_count_uses_the_copy_where_the_table_says_it_pays(built_lib):
     assert gpu.last_launch()["ahead"] == 1 and (m == em).all() and (c == ec).all()
     gpu.close()
     cpu.close()
+
+
+@pytest.mark.parametrize("mode", [6, 8])
+def test_pair_shared_gathers_vs_oracle(built_lib, golden_image, mode):
+    """"pair_loads" 1 (pml_kernel_flatp<..., PSH = 1>): the two lanes of a pair fetch their row windows together -- one load
+    instruction per lane of the pair, each lane one 16-byte half, halves exchanged across the pair -- on the plain rows and on the
+    look-ahead rows.  Same PMLs, error bytes, counters and bins as the oracle and as the lane-private loads: odd numbers of
+    reads (a lane whose partner has no read), reads that end while their partner walks on, long reads rolling through the
+    staged stretch, both index widths, the table's last window."""
+    import movi_amd
+    from oracle.oracle import Oracle
+    img = golden_image(mode)
+    gpu, cpu = movi_amd.MoveIndex.from_image(img), Oracle(img)
+    ref = _ref()
+    rng = np.random.default_rng(9990 + mode)
+    bases, offs = _big_batch(ref, rng)
+    exp, ff, sc = cpu.pml_batch(bases, offs, threads=8)
+    small = mutated_reads(rng, ref, 301, 1, 3000) + [b"", b"A", b"N" * 5, bytes(ref[-200:]), bytes(ref[:200])]
+    sb, so = pack(small)
+    sexp, sff, ssc = cpu.pml_batch(sb, so, threads=4)
+    gpu.set_option("seg_len", 0)
+    for ahead in (0, 1):
+        gpu.set_option("ahead_rows", ahead)
+        gpu.set_option("pair_loads", 0)
+        bins0 = gpu.classify_packed(bases, offs, 40, 4)
+        gpu.set_option("pair_loads", 1)
+        for K in (0, 12):
+            gpu.set_option("kmer_k", K)
+            for idx64 in (0, 1):
+                gpu.set_option("idx64", idx64)
+                out, st = gpu.query_pml_packed(bases, offs)
+                li = gpu.last_launch()
+                assert li["ahead"] == ahead and li["kernel"].endswith(", 0, 0, 1, %d, 1>" % ahead) and li["idx64"] == idx64, li
+                assert (out == exp).all(), (mode, ahead, K, idx64)
+                assert (st.fast_forwards, st.scans, st.errors) == (ff, sc, 0), (mode, ahead, K, idx64)
+            gpu.set_option("idx64", 0)
+        bins = gpu.classify_packed(bases, offs, 40, 4)
+        assert all((x == y).all() for x, y in zip(bins, bins0)), ahead
+        sout, sst = gpu.query_pml_packed(sb, so)
+        assert gpu.last_launch()["kernel"].endswith(", 1>") and (sout == sexp).all() and (sst.fast_forwards, sst.scans) == (sff, ssc)
+    gpu.set_option("pair_loads", 0)
+    gpu.close()
+    cpu.close()

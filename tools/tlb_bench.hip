@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void chase(const uint64_t *__restrict__ table,
                                              uint64_t n_lanes, uint64_t *__restrict__ sink) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_lanes) return;
-    uint32_t idx = next_idx(mix(t), n_rows);
+    uint32_t idx = next_idx(mix(VAR == 6 ? t >> 1 : (VAR == 7 ? t >> 2 : t)), n_rows);   // (6 / 7: the lanes of a pair / quad walk one chain)
     uint64_t acc = 0;
     for (int k = 0; k < steps; ++k) {
         uint64_t v;
@@ -65,6 +65,42 @@ __global__ __launch_bounds__(256) void chase(const uint64_t *__restrict__ table,
             const uint64_t lo = (idx & 1) ? a1 : a0, hi = (idx & 1) ? a3 : a2;
             v = (idx & 2) ? hi : lo;
             acc += (uint32_t)a0 ^ (uint32_t)a2;
+        } else if (VAR == 6) {
+            // round 4: the aligned quad fetched by a PAIR of lanes in ONE instruction -- lanes 2i and 2i+1 walk the same chain
+            // (same idx), each loads one 16-byte half, the halves are exchanged across the pair -- to see whether the two
+            // lanes' translation requests for the same page are one request
+            const uint4 *p = reinterpret_cast<const uint4 *>(table + (idx & ~3u)) + (threadIdx.x & 1u);
+            const uint4 mine = p[0];
+            uint4 other;
+            other.x = __shfl_xor(mine.x, 1, 64); other.y = __shfl_xor(mine.y, 1, 64);
+            other.z = __shfl_xor(mine.z, 1, 64); other.w = __shfl_xor(mine.w, 1, 64);
+            const uint4 q0 = (threadIdx.x & 1u) ? other : mine, q1 = (threadIdx.x & 1u) ? mine : other;
+            const uint4 q = (idx & 2) ? q1 : q0;
+            v = (idx & 1) ? ((uint64_t)q.w << 32 | q.z) : ((uint64_t)q.y << 32 | q.x);
+            acc += q0.x ^ q1.z;
+        } else if (VAR == 7) {
+            // the same by FOUR lanes with 8-byte loads (one instruction covers the quad)
+            const uint64_t mine = table[(idx & ~3u) + (threadIdx.x & 3u)];
+            const uint32_t lo = (uint32_t)mine, hi = (uint32_t)(mine >> 32);
+            const int src = (int)((threadIdx.x & ~3u) | (idx & 3u));
+            v = (uint64_t)__shfl(lo, src, 64) | ((uint64_t)__shfl(hi, src, 64) << 32);
+            acc += __shfl_xor(lo, 2, 64);
+        } else if (VAR == 8) {
+            // every lane walks its OWN chain, the two lanes of a pair SHARE their loads: instruction 1 fetches the even lane's
+            // quad (each lane one 16-byte half), instruction 2 the odd lane's; one exchange hands every lane its missing half
+            const uint32_t odd = threadIdx.x & 1u;
+            const uint32_t pidx = __shfl_xor(idx, 1, 64);
+            const uint32_t ie = odd ? pidx : idx, io = odd ? idx : pidx;
+            const uint4 r1 = *(reinterpret_cast<const uint4 *>(table + (ie & ~3u)) + odd);
+            const uint4 r2 = *(reinterpret_cast<const uint4 *>(table + (io & ~3u)) + odd);
+            const uint4 send = odd ? r1 : r2;
+            uint4 recv;
+            recv.x = __shfl_xor(send.x, 1, 64); recv.y = __shfl_xor(send.y, 1, 64);
+            recv.z = __shfl_xor(send.z, 1, 64); recv.w = __shfl_xor(send.w, 1, 64);
+            const uint4 q0 = odd ? recv : r1, q1 = odd ? r2 : recv;
+            const uint4 q = (idx & 2) ? q1 : q0;
+            v = (idx & 1) ? ((uint64_t)q.w << 32 | q.z) : ((uint64_t)q.y << 32 | q.x);
+            acc += q0.x ^ q1.z;
         } else {
             const uint4 *p = reinterpret_cast<const uint4 *>(table + (idx & ~3u));
             const uint4 q0 = p[0], q1 = p[1];
@@ -102,7 +138,9 @@ int main(int argc, char **argv) {
     uint64_t *sink;
     CHECK(hipMalloc(&sink, 64));
     const char *alloc_names[3] = {"hipMalloc", "hipExtMallocWithFlags(hipDeviceMallocContiguous)", "hipMemCreate+hipMemMap (one handle)"};
-    const char *names[6] = {"8B row", "16B pair", "32B quad", "8B row + dependent neighbour", "pair as 2 x 8B loads", "quad as 4 x 8B loads"};
+    const char *names[9] = {"8B row", "16B pair", "32B quad", "8B row + dependent neighbour", "pair as 2 x 8B loads", "quad as 4 x 8B loads",
+                             "32B quad by a lane PAIR (2 x 16B, one instr; steps = lanes / 2)", "32B quad by FOUR lanes (4 x 8B, one instr; steps = lanes / 4)",
+                             "32B quad, own chain per lane, loads SHARED by the pair (2 instr)"};
     const char *only_var = getenv("TLB_VAR");               // e.g. TLB_VAR=4: that variant only (PMC passes)
     for (int si = 0; si < ns; si++) {
         const uint64_t n = 1ull << sizes[si];
@@ -143,7 +181,7 @@ int main(int argc, char **argv) {
             CHECK(hipDeviceSynchronize());
             const uint32_t n_rows = (uint32_t)(n - 8);
             for (uint64_t lanes : {(uint64_t)1 << 19, (uint64_t)1 << 20}) {
-                double ms[6] = {0, 0, 0, 0, 0, 0};
+                double ms[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
                 auto want = [&](int v) { return !only_var || atoi(only_var) == v; };
                 if (want(0)) ms[0] = run<0>(table, n_rows, steps, lanes, sink, 4);
                 if (want(1)) ms[1] = run<1>(table, n_rows, steps, lanes, sink, 4);
@@ -151,9 +189,12 @@ int main(int argc, char **argv) {
                 if (want(3)) ms[3] = run<3>(table, n_rows, steps, lanes, sink, 4);
                 if (want(4)) ms[4] = run<4>(table, n_rows, steps, lanes, sink, 4);
                 if (want(5)) ms[5] = run<5>(table, n_rows, steps, lanes, sink, 4);
-                for (int v = 0; v < 6; v++)
+                if (want(6)) ms[6] = run<6>(table, n_rows, steps, 2 * lanes, sink, 4);      // the same number of CHAINS: twice / four times the lanes
+                if (want(7)) ms[7] = run<7>(table, n_rows, steps, 4 * lanes, sink, 4);
+                if (want(8)) ms[8] = run<8>(table, n_rows, steps, lanes, sink, 4);
+                for (int v = 0; v < 9; v++)
                     if (want(v))
-                        printf("  lanes=%8llu  %-30s %8.3f ms  %7.2f Gsteps/s\n", (unsigned long long)lanes, names[v], ms[v],
+                        printf("  chains=%8llu  %-64s %8.3f ms  %7.2f Gsteps/s\n", (unsigned long long)lanes, names[v], ms[v],
                                lanes * (double)steps / ms[v] / 1e6);
             }
             if (which == 2) {
