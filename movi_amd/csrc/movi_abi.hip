@@ -762,43 +762,41 @@ static int build_kmer(movi_index *ix, uint32_t K, hipStream_t s) {
     return MOVI_OK;
 }
 
-// Look-ahead rows (DevIndex::rows2): a second copy of the table, 16 bytes per row.  Built by itself where it pays even on
-// the worst case for it, a uniformly random table (short runs: the base after the LF fast-forwards more often than not):
-// +14 % at 20 M rows, +8 % at 100 M, -9 % at 200 M rows (1.6 GB of rows), -37 % at 1 B -- beyond the reach of the TLBs the
-// two extra 16-byte loads per step cost more translation requests than the skipped rows save
-// (profiles/r03_ahead_rows_threshold.txt).  "ahead_rows" 1 builds them for any table.
-constexpr uint64_t kAheadAutoBytes = 1600ull << 20;      // of the copy: up to 100 M rows
-// Round 4: the size rule was set on the worst case.  On the BWT of real text most positions reach their LF target without
-// a fast-forward (0.83 on the 14 M-row pangenome, 0.75 on a 113 M-row one with 1 % divergence, 0.51 on a uniformly random
-// run sequence), entries are used far more often, and the copy pays well beyond 100 M rows: 113.5 M rows (1.8 GB copy)
-// 42.3 -> 53.5 Gbases/s (profiles/r04_real_100M.txt).  So above kAheadAutoBytes the table's own statistic decides -- tallied
-// over a sample of its rows before anything is built -- up to the size a real table was measured at.
-constexpr double kAheadShare = 0.67;                     // (the count query's line, kAheadCountRatio: same statistic)
-constexpr uint64_t kAheadStatBytes = 4096ull << 20;      // of the copy: up to 256 M rows
+// Look-ahead rows (DevIndex::rows2): a second copy of the table, 16 bytes per row, built by itself by the first PML query
+// wherever the device has room for it.  History of the rule: round 3 built it up to 100 M rows only -- on a uniformly random
+// table, the worst case for it (the base after the LF fast-forwards more often than not), it was +14 % at 20 M rows, +8 % at
+// 100 M, -9 % at 200 M and -37 % at 1 B, where the two extra 16-byte loads per step cost more translation requests than the
+// skipped rows save (profiles/r03_ahead_rows_threshold.txt); round 4 first let the table's own statistic (share of positions
+// that arrive at their LF target without a fast-forward: 0.83 / 0.75 on real BWTs, 0.51 on random ones) extend it to 256 M
+// rows of real text (113 M rows: 42.3 -> 53.5 Gbases/s, profiles/r04_real_100M.txt).  The pair-shared gathers then removed
+// the translation cost the size rule was about (launch_pml: on for walked tables of 2 GB and more): on the look-ahead rows
+// the random table now runs 45.4 against 38.5 Gbases/s at 200 M rows, 43.4 / 36.3 at 350 M, 44.4 / 34.8 at 700 M and
+// 42.0 - 44.2 / 34.6 at 1 B (without the pairs: 21.4), the real 226 M-row BWT 50.8 / 38.6
+// (profiles/r04_pair_shared_gathers.txt) -- so the copy pays at every size measured, and only memory decides.
+// The statistic still steers the count query (kAheadCountRatio below) and is reported (movi_index_info "ahead_no_ff").
 static bool ahead_eligible(const movi_index *ix) {
     return ix->kmode == MOVI_MODE_REGULAR_THRESHOLDS && ix->desc.r >= 8 && (ix->desc.r >> 36) == 0;
 }
-// Should the first query build the look-ahead rows by itself?
-static bool ahead_wanted(movi_index *ix, hipStream_t s) {
+// The statistic over a sample of the table's rows (every 16th), before anything is built.
+static void sample_no_ff(movi_index *ix, hipStream_t s) {
+    if (ix->ahead_tallied) return;
+    unsigned long long *d_tally = nullptr, h_tally[2] = {0, 0};
+    hipError_t e = hipMalloc(&d_tally, 16);
+    if (e == hipSuccess) e = hipMemsetAsync(d_tally, 0, 16, s);
+    if (e == hipSuccess) e = tally_no_ff_share(ix->kmode, ix->dev, 16, d_tally, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(h_tally, d_tally, 16, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (d_tally) (void)hipFree(d_tally);
+    if (e != hipSuccess) { (void)hipGetLastError(); return; }
+    ix->ahead_no_ff = h_tally[1] ? (double)h_tally[0] / (double)h_tally[1] : 0.0;
+    ix->ahead_tallied = true;
+}
+// Should the first query build the look-ahead rows by itself?  Yes, if they leave room for the query's own buffers.
+static bool ahead_wanted(movi_index *ix) {
     const uint64_t bytes = ahead_rows_bytes(ix->desc.r);
-    if (bytes <= kAheadAutoBytes) return true;
-    if (bytes > kAheadStatBytes) return false;
-    if (!ix->ahead_tallied) {
-        unsigned long long *d_tally = nullptr, h_tally[2] = {0, 0};
-        hipError_t e = hipMalloc(&d_tally, 16);
-        if (e == hipSuccess) e = hipMemsetAsync(d_tally, 0, 16, s);
-        if (e == hipSuccess) e = tally_no_ff_share(ix->kmode, ix->dev, 16, d_tally, s);
-        if (e == hipSuccess) e = hipMemcpyAsync(h_tally, d_tally, 16, hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
-        if (d_tally) (void)hipFree(d_tally);
-        if (e != hipSuccess) { (void)hipGetLastError(); return false; }
-        ix->ahead_no_ff = h_tally[1] ? (double)h_tally[0] / (double)h_tally[1] : 0.0;
-        ix->ahead_tallied = true;
-    }
-    if (ix->ahead_no_ff < kAheadShare) return false;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return false; }
-    return free_b > bytes + (2ull << 30);                   // (room for the copy and the query's own buffers)
+    return free_b > bytes + std::max<uint64_t>(2ull << 30, bytes / 2);
 }
 // by_itself: built by the size policy, not on request -- then the count query uses the copy only where the table's own
 // statistic says it pays (DevIndex::rows2_count)
@@ -1039,7 +1037,7 @@ static int ml_device(bool zml, movi_index_t *ix, const uint8_t *d_bases, const u
             ix->kmer_auto = 0;
         }
     }
-    if (!zml && ix->ahead_auto > 0 && !ix->d_rows2 && ahead_eligible(ix) && cls.log_ff == nullptr && ahead_wanted(ix, s)) {
+    if (!zml && ix->ahead_auto > 0 && !ix->d_rows2 && ahead_eligible(ix) && cls.log_ff == nullptr && ahead_wanted(ix)) {
         if (build_ahead(ix, s, true) != MOVI_OK) {
             (void)hipGetLastError();
             ix->ahead_auto = 0;
@@ -1780,8 +1778,12 @@ static int count_device(movi_index_t *ix, const uint8_t *d_bases, const uint64_t
     if (ix->ftab_auto > 0 && !ix->d_ftab && ftab_eligible(ix)) {       // the first count query builds the interval table
         if (build_ftab_table(ix, (uint32_t)ix->ftab_auto, s) != MOVI_OK) { (void)hipGetLastError(); ix->ftab_auto = 0; }
     }
-    if (ix->ahead_auto > 0 && !ix->d_rows2 && !ix->count_declined_ahead && ahead_eligible(ix) && ahead_wanted(ix, s)) {
-        if (build_ahead(ix, s, true) != MOVI_OK) { (void)hipGetLastError(); ix->ahead_auto = 0; }   // ... and the look-ahead rows (as a PML query does)
+    if (ix->ahead_auto > 0 && !ix->d_rows2 && !ix->count_declined_ahead && ahead_eligible(ix)) {
+        // ... and the look-ahead rows (as a PML query does), where the table's own statistic says the search will use them:
+        // sampled first, so that a table that will not is not copied (16 B per row) to find out
+        sample_no_ff(ix, s);
+        if (!ix->ahead_tallied || ix->ahead_no_ff < kAheadCountRatio || !ahead_wanted(ix)) ix->count_declined_ahead = true;
+        else if (build_ahead(ix, s, true) != MOVI_OK) { (void)hipGetLastError(); ix->ahead_auto = 0; }
         else if (ix->dev.rows2_count == 0u) {
             // the table's own statistic says the count query is better off on the plain rows: the copy (16 B per row) is not
             // kept for a caller who may never ask for PMLs -- the first PML query builds it again (85 us per 14 M rows)

@@ -2080,6 +2080,9 @@ static hipError_t launch_pml_segmented(const DevIndex &ix, const uint8_t *d_base
     // launch_pml's policy -- the cap's padding, or what the launch's wavefronts per CU leave of the CU's LDS)
     DevIndex ixl = ix;
     ixl.inwin = cfg.inwin ? 1u : 0u;
+    // (pair-shared gathers on tables beyond the TLBs' reach: launch_pml's rule)
+    const bool seg_pair = ix.rows3 == nullptr &&
+                          (cfg.pair_loads > 0 || (cfg.pair_loads < 0 && ix.r * (ix.rows2 != nullptr ? 16ull : 8ull) >= kPairLoadBytes));
     size_t dyn_lds = 0;
     auto stage_for = [&](uint64_t lanes) {
         dyn_lds = lds_for(lanes);
@@ -2102,7 +2105,9 @@ static hipError_t launch_pml_segmented(const DevIndex &ix, const uint8_t *d_base
     } while (0)
 #define MOVI_LAUNCH_SEG_S(SEGV, LANES, T, S)                                                                          \
     do {                                                                                                              \
-        if (ixl.stage_lds != 0u && ix.rows3 != nullptr) MOVI_LAUNCH_SEG(SEGV, LANES, pml_kernel_flatp<6, T, -1, 0, S, 0, SEGV, 1, 2>); \
+        if (seg_pair && ixl.stage_lds != 0u && ix.rows2 != nullptr) MOVI_LAUNCH_SEG(SEGV, LANES, pml_kernel_flatp<6, T, -1, 0, S, 0, SEGV, 1, 1, 1>); \
+        else if (seg_pair && ixl.stage_lds != 0u) MOVI_LAUNCH_SEG(SEGV, LANES, pml_kernel_flatp<6, T, -1, 0, S, 0, SEGV, 1, 0, 1>); \
+        else if (ixl.stage_lds != 0u && ix.rows3 != nullptr) MOVI_LAUNCH_SEG(SEGV, LANES, pml_kernel_flatp<6, T, -1, 0, S, 0, SEGV, 1, 2>); \
         else if (ixl.stage_lds != 0u && ix.rows2 != nullptr) MOVI_LAUNCH_SEG(SEGV, LANES, pml_kernel_flatp<6, T, -1, 0, S, 0, SEGV, 1, 1>); \
         else if (ixl.stage_lds != 0u) MOVI_LAUNCH_SEG(SEGV, LANES, pml_kernel_flatp<6, T, -1, 0, S, 0, SEGV, 1, 0>);  \
         else MOVI_LAUNCH_SEG(SEGV, LANES, pml_kernel_flatp<6, T, -1, 0, S, 0, SEGV>);                                 \
@@ -2119,8 +2124,8 @@ static hipError_t launch_pml_segmented(const DevIndex &ix, const uint8_t *d_base
     MOVI_LAUNCH_SEG_T(1, max_seg);
     if (info) {                                           // the dominant kernel: K1
         const int stg = ixl.stage_lds != 0u ? 1 : 0, ahd = (stg && ix.rows3 != nullptr) ? 2 : ((stg && ix.rows2 != nullptr) ? 1 : 0);
-        snprintf(info->kernel, sizeof(info->kernel), "pml_kernel_flatp<6, %s, -1, 0, %d, 0, 1, %d, %d>",
-                 ix.idx32 ? "unsigned int" : "unsigned long", ix.sep ? 1 : 0, stg, ahd);
+        snprintf(info->kernel, sizeof(info->kernel), "pml_kernel_flatp<6, %s, -1, 0, %d, 0, 1, %d, %d%s>",
+                 ix.idx32 ? "unsigned int" : "unsigned long", ix.sep ? 1 : 0, stg, ahd, (seg_pair && stg) ? ", 1" : "");
         info->variant = 14; info->block_threads = 64; info->segmented = 1; info->idx64 = ix.idx32 ? 0 : 1;
         info->waves_per_cu = 0; info->staged = (int)ixl.stage_lds; info->ahead = ahd;
     }
@@ -2254,10 +2259,11 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     // pair-shared gathers (pml_kernel_flatp<..., PSH = 1>): the staged default walk on the plain or the look-ahead rows
     // Where: on tables beyond the reach of the per-CU TLBs (~2 GB), where a lane's two (four) 16-byte loads are as many
     // translation requests and the L2 TLB's request rate bounds the walk -- real BWT of 226 M rows on the look-ahead rows (3.6 GB
-    // copy) 39.4 -> 50.8 Gbases/s, the random 8 GB table 32.6 -> 34.7; below that the exchange costs more than the merged
-    // accesses give (113 M rows +1.5 %, c2 -2.5 %, c3 -9 %: profiles/r04_pair_shared_gathers.txt).  "pair_loads" 1 / 0 forces it.
+    // copy) 39.4 -> 50.8 Gbases/s, the random 1 B-row table 32.6 -> 34.7 on its plain rows and 21.4 -> 44.2 on the look-ahead
+    // copy (16 GB); below that the exchange costs about what the merged accesses give (random 25 / 50 / 100 M rows +4 / +5 / -2 %,
+    // real 113 M rows +1.5 %, c2 -2.5 %, c3 -9 %: profiles/r04_pair_shared_gathers.txt).  "pair_loads" 1 / 0 forces it.
     const uint64_t walked_bytes = ix.r * (use_ahead ? 16ull : 8ull);
-    const bool use_pair = (cfg.pair_loads > 0 || (cfg.pair_loads < 0 && walked_bytes >= (2ull << 30))) && ixl.stage_lds != 0u && v == 10 && !use_chain;
+    const bool use_pair = (cfg.pair_loads > 0 || (cfg.pair_loads < 0 && walked_bytes >= kPairLoadBytes)) && ixl.stage_lds != 0u && v == 10 && !use_chain;
     const SegArgs no_seg;
     // every kernel that is handed more than 64 KiB of dynamic LDS must opt in first
 #define MOVI_SEG_0

@@ -100,6 +100,7 @@ struct DevStats {
 constexpr int kCountCapWaves = 16;   // the count kernel's cap on cache-resident tables (launch_count)
 constexpr int kCapWaves = 7;   // resident wavefronts per CU of the lane state machine on big batches (round 2: 9, optimum 8-10; round 3, with the reads staged in LDS and the top-of-walk table: 6-8, profiles/r03_occupancy_sweep.txt)
 constexpr int kCapWavesAhead = 9;    // ... when the walk runs on the look-ahead rows: fewer lines per base, more walks in flight pay (profiles/r03_ahead_rows_ab.txt)
+constexpr uint64_t kPairLoadBytes = 2ull << 30;   // walked tables of this size and more: pair-shared gathers (launch_pml)
 
 struct LaunchCfg {
     int block_threads = 0;   // 0 = auto: 64 for the PML and count kernels and the ZML state machine (finest dispatch grain), 256 for the base-synchronous ZML kernel
