@@ -777,15 +777,24 @@ static int build_kmer(movi_index *ix, uint32_t K, hipStream_t s) {
 static bool ahead_eligible(const movi_index *ix) {
     return ix->kmode == MOVI_MODE_REGULAR_THRESHOLDS && ix->desc.r >= 8 && (ix->desc.r >> 36) == 0;
 }
+// A builder's tally: kTallySlots pairs of counters on the device (movi_kernels.hip: tally_add), added up here.
+constexpr size_t kTallyBytes = 2u * kTallySlots * sizeof(unsigned long long);
+static hipError_t read_tally(const unsigned long long *d_tally, unsigned long long (&sum)[2], hipStream_t s) {
+    std::vector<unsigned long long> h(2u * kTallySlots);
+    hipError_t e = hipMemcpyAsync(h.data(), d_tally, kTallyBytes, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    sum[0] = sum[1] = 0;
+    if (e == hipSuccess) for (uint32_t i = 0; i < kTallySlots; ++i) { sum[0] += h[2 * i]; sum[1] += h[2 * i + 1]; }
+    return e;
+}
 // The statistic over a sample of the table's rows (every 16th), before anything is built.
 static void sample_no_ff(movi_index *ix, hipStream_t s) {
     if (ix->ahead_tallied) return;
     unsigned long long *d_tally = nullptr, h_tally[2] = {0, 0};
-    hipError_t e = hipMalloc(&d_tally, 16);
-    if (e == hipSuccess) e = hipMemsetAsync(d_tally, 0, 16, s);
+    hipError_t e = hipMalloc(&d_tally, kTallyBytes);
+    if (e == hipSuccess) e = hipMemsetAsync(d_tally, 0, kTallyBytes, s);
     if (e == hipSuccess) e = tally_no_ff_share(ix->kmode, ix->dev, 16, d_tally, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(h_tally, d_tally, 16, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = read_tally(d_tally, h_tally, s);
     if (d_tally) (void)hipFree(d_tally);
     if (e != hipSuccess) { (void)hipGetLastError(); return; }
     ix->ahead_no_ff = h_tally[1] ? (double)h_tally[0] / (double)h_tally[1] : 0.0;
@@ -805,11 +814,10 @@ static int build_ahead(movi_index *ix, hipStream_t s, bool by_itself) {
     HIP_TRY(hipMalloc(&ix->d_rows2, ahead_rows_bytes(ix->desc.r)));
     uint64_t tail = 0;
     unsigned long long *d_tally = nullptr, h_tally[2] = {0, 0};
-    hipError_t e = hipMalloc(&d_tally, 16);
-    if (e == hipSuccess) e = hipMemsetAsync(d_tally, 0, 16, s);
+    hipError_t e = hipMalloc(&d_tally, kTallyBytes);
+    if (e == hipSuccess) e = hipMemsetAsync(d_tally, 0, kTallyBytes, s);
     if (e == hipSuccess) e = build_ahead_rows(ix->kmode, ix->dev, ix->d_rows2, &tail, s, d_tally);
-    if (e == hipSuccess) e = hipMemcpyAsync(h_tally, d_tally, 16, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = read_tally(d_tally, h_tally, s);
     if (d_tally) (void)hipFree(d_tally);
     if (e != hipSuccess) { (void)hipFree(ix->d_rows2); ix->d_rows2 = nullptr; return fail_hip(e, "building the look-ahead rows"); }
     ix->dev.rows2 = ix->d_rows2;
@@ -914,6 +922,11 @@ int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
     if (!strcmp(key, "zml_ahead")) {                         // 1: the ZML state machine walks on the look-ahead rows where they exist (A/B: measured no faster)
         if (value != 0 && value != 1) return fail(MOVI_ERR_ARG, "zml_ahead must be 0 or 1");
         ix->cfg.zml_ahead = (int)value;
+        return MOVI_OK;
+    }
+    if (!strcmp(key, "out_ring")) {                          // A/B: the PML kernels' output ring in LDS (-1 = the launch policy)
+        if (value < -1 || value > 1) return fail(MOVI_ERR_ARG, "out_ring must be -1, 0 or 1");
+        ix->cfg.out_ring = (int)value;
         return MOVI_OK;
     }
     if (!strcmp(key, "inwin_repo")) {                        // A/B: repositions inside the row window resolved in the same iteration

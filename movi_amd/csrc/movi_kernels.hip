@@ -790,7 +790,7 @@ __device__ __forceinline__ void pair_assemble(uint32_t odd, const uint4 &r1, con
     w[2] = odd ? make_uint2(r2.x, r2.y) : make_uint2(got_x, got_y);
     w[3] = odd ? make_uint2(r2.z, r2.w) : make_uint2(got_z, got_w);
 }
-template <int MODE, typename IdxT, int HA, int CLS, int SEP, int REFILL, int SEG = 0, int STG = 0, int AHD = 0, int PSH = 0>
+template <int MODE, typename IdxT, int HA, int CLS, int SEP, int REFILL, int SEG = 0, int STG = 0, int AHD = 0, int PSH = 0, int RING = 0>
 __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8_t *__restrict__ bases,
                                                        const uint64_t *__restrict__ offs, uint64_t n_reads,
                                                        uint16_t *__restrict__ out, uint8_t *__restrict__ err,
@@ -800,6 +800,7 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
     static_assert(REFILL == 0 || (STG == 1 && HA < 0), "lane refill: staged reads, window-parallel advance");
     static_assert(AHD == 0 || (STG == 1 && HA < 0), "look-ahead rows: staged reads, window-parallel advance");
     static_assert(PSH == 0 || (STG == 1 && REFILL == 0 && AHD != 2), "pair-shared gathers: staged kernels without refill, plain or look-ahead rows");
+    static_assert(RING == 0 || (STG == 1 && REFILL == 0 && AHD != 2), "PMLs out through the LDS ring: staged kernels without refill, plain or look-ahead rows");
     enum : uint32_t { sFF = 0, sDown = 1, sUp = 2, sDone = 3 };
     __shared__ uint8_t s_code[256];
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = ix.code_of[i];
@@ -818,7 +819,8 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
     uint64_t beg = valid ? (SEG == 1 ? seg.seg_in[rid] : offs[rid]) : 0;
     uint32_t len = valid ? (SEG == 1 ? seg.seg_len[rid] : (uint32_t)(offs[rid + 1] - beg)) : 0;   // reads are shorter than 2^32 (checked on the host)
     uint64_t obeg = (SEG == 1 && valid) ? seg.seg_out[rid] : beg;   // where the read's (segment's) PMLs go
-    uint32_t packed_end = len & ~7u;
+    constexpr bool ring = RING != 0;                      // PMLs leave through the ring in LDS (below) instead of the register packer
+    uint32_t packed_end = len & (ring ? ~15u : ~7u);      // PMLs of steps >= this are stored one by one
 
     // The 16 bases of steps kk .. kk+15 of the read (b, l) are the bytes [b + l - kk - 16, b + l - kk) of `bases`, last
     // step first: ONE unconditional 16-byte load -- c0 = steps kk .. kk+7 (step kk in the top byte), c1 = steps kk+8 ..
@@ -947,7 +949,31 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
     // is about to leave its staged stretch, every lane stages again from where it stands (stage_from in the loop) -- one
     // extra round trip per >= stage_lds / 2 iterations.  Layout: slot s of lane l at byte (s / 4) * 256 + 4 l + s % 4 --
     // lanes in step read consecutive banks; slot s holds the base of step kbase + s.
+    //
+    // PMLs out (RING = 1: launches of long reads, launch_pml): behind the staged bases the same dynamic LDS holds a ring of 32
+    // PMLs per lane (kOutRingBytes) -- entry e of lane l at byte (e / 8) * 1024 + 16 l + 2 (e % 8): a lane's 8 consecutive PMLs are
+    // 16 contiguous bytes, 64 lanes' 16 bytes a conflict-free kilobyte.  An emission is one ds_write_b16; when a lane's k crosses a
+    // multiple of 16 the finished group leaves as two adjacent 16-byte stores (two ds_read_b128) -- at most three emissions per
+    // iteration, so the ring's other half is always free.  The register packer it stands in for (four v_perm per PML, a saved
+    // copy of the first 8 of each 16, three nested divergent branches) is 81 of the loop's ~400 VALU instructions, the ring 35.
+    // Where it pays: 100 k x 10 kbp reads -- 6 wavefronts per CU, where a wavefront's own instruction stream is most of an
+    // iteration -- 54.7 -> 57.5 Gbases/s; big batches of short reads are bound by the fabric's line rate and lose 1 % (c2 75.1 ->
+    // 74.5, the 113 M-row table 53.2 -> 52.6) and the LDS the ring takes (profiles/r04_valu.txt).  The stores must leave where the
+    // packer's did, right behind the gather: at the iteration's end c3 drops to 45.3, at the top of the next to 55.1 (c4 -12 %).
     extern __shared__ __align__(16) uint8_t s_stage[];
+    uint8_t *const s_ring = s_stage + ix.stage_lds * 64u;
+    const uint32_t ring_lane = (threadIdx.x & 63u) * 16u;
+    auto ring_put = [&](uint32_t kk, uint32_t val) {
+        *reinterpret_cast<uint16_t *>(s_ring + ((kk >> 3) & 3u) * 1024u + ring_lane + (kk & 7u) * 2u) = (uint16_t)val;
+    };
+    auto ring_flush = [&](uint32_t k0) {                  // the group of 16 that step k0 lies in: complete, and all of it below packed_end
+        const uint32_t g = (k0 >> 4) & 1u;
+        const uint4 lo = *reinterpret_cast<const uint4 *>(s_ring + (2u * g) * 1024u + ring_lane);
+        const uint4 hi = *reinterpret_cast<const uint4 *>(s_ring + (2u * g + 1u) * 1024u + ring_lane);
+        uint16_t *dst = out + obeg + (k0 & ~15u);
+        __builtin_memcpy(dst, &lo, 16);                   // unaligned 16-byte stores
+        __builtin_memcpy(dst + 8, &hi, 16);
+    };
     uint32_t kbase = 0;
     const uint32_t stage_cap = ix.stage_lds;
     // (the loads of kStageUnroll groups leave together -- unconditional, lanes without the group re-read the batch's first
@@ -1007,6 +1033,8 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
                 if (CLS == 2) {
                 } else if (k >= packed_end) {
                     O[k] = (uint16_t)run;
+                } else if (STG && ring) {
+                    ring_put(k, run);                     // (K <= 12: no group of 16 is completed here)
                 } else {
                     pk.x = (pk.x >> 16) | (pk.y << 16);
                     pk.y = (pk.y >> 16) | (pk.z << 16);
@@ -1136,7 +1164,7 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
                     cur_valid = 0;
                 }
                 if (sw) {
-                    rid = g_rid; beg = (uint64_t)g_lo | ((uint64_t)g_hi << 32); obeg = beg; len = g_len; packed_end = len & ~7u;
+                    rid = g_rid; beg = (uint64_t)g_lo | ((uint64_t)g_hi << 32); obeg = beg; len = g_len; packed_end = len & (ring ? ~15u : ~7u);
                     k = 0; ml = 0; ff_run = 0; off = off0; need = r1; failed = 0; cur_valid = 1;
                     if (CLS) { cs = ClsState(); cs.init(len, cls.bin_width); }
                     st = len > 0 ? sFF : sDone;
@@ -1164,6 +1192,13 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
         const bool act = st < sDone;
         lane_steps += (uint32_t)act;
         wave_steps += 1;
+#if defined(MOVI_PAD_PRE) && MOVI_PAD_PRE > 0
+        {   // experiment (profiles/r04_valu.txt): MOVI_PAD_PRE dependent VALU instructions between the window's arrival and the next gather
+            uint32_t pad = wave_steps;
+#pragma unroll
+            for (int i = 0; i < MOVI_PAD_PRE; ++i) asm volatile("v_add_u32 %0, %0, %0" : "+v"(pad));
+        }
+#endif
         if (PSH) {                                        // the halves the pair loaded for each other change hands
             pair_assemble(odd_lane, raw[0], raw[1], w);
             if (AHD) pair_assemble(odd_lane, raw[2], raw[3], ahw);
@@ -1317,6 +1352,13 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
         // ---- the next gather leaves now; everything below runs under its latency
         // (`row` is not touched below, so the new window can land in the old one's registers)
         fetch(need_next, st_next != sDone, w);
+#if defined(MOVI_PAD_POST) && MOVI_PAD_POST > 0
+        {   // ... and MOVI_PAD_POST of them under the gather's latency
+            uint32_t pad = wave_steps;
+#pragma unroll
+            for (int i = 0; i < MOVI_PAD_POST; ++i) asm volatile("v_add_u32 %0, %0, %0" : "+v"(pad));
+        }
+#endif
         // ---- bookkeeping, all selects
         uint32_t want_nx = 0;                             // this lane asks for the 16 bases that end at byte nx_e
         uint64_t nx_e = 0;
@@ -1339,6 +1381,8 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
                     // verdict bins only
                 } else if (k >= packed_end) {
                     O[k] = (uint16_t)val;
+                } else if (STG && ring) {
+                    ring_put(k, val);
                 } else {
                     pk.x = (pk.x >> 16) | (pk.y << 16);
                     pk.y = (pk.y >> 16) | (pk.z << 16);
@@ -1368,6 +1412,7 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
                     seg.fin[rid] = fn;
                 }
             };
+            const uint32_t k_in = k;
             if (SEG == 1) seg_record((uint64_t)needf, off_pre);
             emit_pml(ml);
             if (AHD && dbl) {                             // the second base of a multi-base step: matched, no fast-forward
@@ -1382,6 +1427,7 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
                     emit_pml(ml);
                 }
             }
+            if (STG && CLS != 2 && ring && ((k ^ k_in) & 16u) != 0u) ring_flush(k_in);   // a group of 16 PMLs is complete
             if (STG) {
                 // (the next base's code: after the state update below, where a lane about to leave its staged stretch is seen)
             } else if (lf) {
@@ -1528,6 +1574,14 @@ __global__ __launch_bounds__(256) void kmer_table_kernel(DevIndex ix, uint32_t K
     table[t] = e4;
 }
 
+// The builders' tallies go to kTallySlots pairs of counters, a block to the pair of its index (the host adds them up): one
+// pair for all took the look-ahead rows of a 1 B-row table 375 ms -- 31 M atomics on one address, ~12 ns each -- instead of
+// the ~45 ms its 16 GB of writes take.
+__device__ __forceinline__ void tally_add(unsigned long long *tally, uint32_t a, uint32_t b) {
+    unsigned long long *t = tally + 2u * (blockIdx.x & (kTallySlots - 1u));
+    atomicAdd(t, (unsigned long long)a);
+    atomicAdd(t + 1, (unsigned long long)b);
+}
 // Look-ahead rows (DevIndex::rows2): thread i copies row i into its line and writes the entry of its LF target next to it.
 // tally (optional): [0] += the positions of row i that arrive at its LF target below the target's length (no fast-forward
 // there), [1] += n(i): their ratio says how often a walk that follows the text can use an entry -- 0.83 on pangenome BWTs,
@@ -1553,7 +1607,7 @@ __global__ __launch_bounds__(256) void ahead_rows_kernel(DevIndex ix, uint8_t *_
     }
     if (tally) {                                          // every lane of the wavefront is here
         const uint32_t a = wave_sum(no_ff), b = wave_sum(in ? row_n<MODE>(row) : 0u);
-        if ((threadIdx.x & 63) == 0) { atomicAdd(tally, (unsigned long long)a); atomicAdd(tally + 1, (unsigned long long)b); }
+        if ((threadIdx.x & 63) == 0) tally_add(tally, a, b);
     }
     if (!in) return;
     uint8_t *line = out + (i >> 3) * 128u + (i & 7u) * 8u;
@@ -1596,7 +1650,7 @@ __global__ __launch_bounds__(256) void chain_rows_kernel(DevIndex ix, uint8_t *_
     }
     if (tally) {
         const uint32_t a = wave_sum(no_ff), b = wave_sum(in ? row_n<MODE>(row) : 0u);
-        if ((threadIdx.x & 63) == 0) { atomicAdd(tally, (unsigned long long)a); atomicAdd(tally + 1, (unsigned long long)b); }
+        if ((threadIdx.x & 63) == 0) tally_add(tally, a, b);
     }
     if (!in) return;
     uint8_t *line = out + (i >> 2) * 128u;
@@ -1626,7 +1680,7 @@ __global__ __launch_bounds__(256) void no_ff_share_kernel(DevIndex ix, uint64_t 
         }
     }
     const uint32_t a = wave_sum(no_ff), b = wave_sum(ni);
-    if ((threadIdx.x & 63) == 0) { atomicAdd(tally, (unsigned long long)a); atomicAdd(tally + 1, (unsigned long long)b); }
+    if ((threadIdx.x & 63) == 0) tally_add(tally, a, b);
 }
 hipError_t tally_no_ff_share(int kmode, const DevIndex &ix, uint64_t stride, unsigned long long *d_tally, hipStream_t stream) {
     if (kmode != 6 || !d_tally || stride == 0) return hipErrorInvalidValue;
@@ -2084,14 +2138,18 @@ static hipError_t launch_pml_segmented(const DevIndex &ix, const uint8_t *d_base
     const bool seg_pair = ix.rows3 == nullptr &&
                           (cfg.pair_loads > 0 || (cfg.pair_loads < 0 && ix.r * (ix.rows2 != nullptr ? 16ull : 8ull) >= kPairLoadBytes));
     size_t dyn_lds = 0;
+    bool seg_ring = false;
     auto stage_for = [&](uint64_t lanes) {
         dyn_lds = lds_for(lanes);
         if (cfg.stage_reads != 0 && dyn_lds == 0) {
             const uint64_t wn = ((lanes + bt - 1) / bt + (uint64_t)cfg.num_cus - 1) / (uint64_t)cfg.num_cus;
-            if (wn <= 18) dyn_lds = std::min<size_t>(21504, ((163840u / (unsigned)(wn + std::max<uint64_t>(2, wn / 4))) & ~1023u) - 1024u);
+            if (wn <= 18) dyn_lds = std::min<size_t>(21504 + (cfg.out_ring != 0 ? kOutRingBytes : 0u), ((163840u / (unsigned)(wn + std::max<uint64_t>(2, wn / 4))) & ~1023u) - 1024u);
         }
-        const uint32_t cap = (uint32_t)std::min<size_t>(1024, (dyn_lds / 64) & ~(size_t)15);
+        // (segments are long reads: their PMLs leave through the ring in LDS where the block has room for it -- launch_pml)
+        const size_t ring_b = (cfg.out_ring != 0 && cfg.stage_reads != 0 && ix.rows3 == nullptr && dyn_lds >= kOutRingBytes + 96u * 64u) ? kOutRingBytes : 0;
+        const uint32_t cap = (uint32_t)std::min<size_t>(1024, ((dyn_lds - ring_b) / 64) & ~(size_t)15);
         ixl.stage_lds = (cfg.stage_reads != 0 && cap >= 96) ? cap : 0u;
+        seg_ring = ring_b != 0 && ixl.stage_lds != 0u;
     };
 #define MOVI_LAUNCH_SEG(SEGV, LANES, ...)                                                                             \
     do {                                                                                                              \
@@ -2105,7 +2163,11 @@ static hipError_t launch_pml_segmented(const DevIndex &ix, const uint8_t *d_base
     } while (0)
 #define MOVI_LAUNCH_SEG_S(SEGV, LANES, T, S)                                                                          \
     do {                                                                                                              \
-        if (seg_pair && ixl.stage_lds != 0u && ix.rows2 != nullptr) MOVI_LAUNCH_SEG(SEGV, LANES, pml_kernel_flatp<6, T, -1, 0, S, 0, SEGV, 1, 1, 1>); \
+        if (seg_ring && seg_pair && ix.rows2 != nullptr) MOVI_LAUNCH_SEG(SEGV, LANES, pml_kernel_flatp<6, T, -1, 0, S, 0, SEGV, 1, 1, 1, 1>); \
+        else if (seg_ring && seg_pair) MOVI_LAUNCH_SEG(SEGV, LANES, pml_kernel_flatp<6, T, -1, 0, S, 0, SEGV, 1, 0, 1, 1>);   \
+        else if (seg_ring && ix.rows2 != nullptr) MOVI_LAUNCH_SEG(SEGV, LANES, pml_kernel_flatp<6, T, -1, 0, S, 0, SEGV, 1, 1, 0, 1>); \
+        else if (seg_ring) MOVI_LAUNCH_SEG(SEGV, LANES, pml_kernel_flatp<6, T, -1, 0, S, 0, SEGV, 1, 0, 0, 1>);               \
+        else if (seg_pair && ixl.stage_lds != 0u && ix.rows2 != nullptr) MOVI_LAUNCH_SEG(SEGV, LANES, pml_kernel_flatp<6, T, -1, 0, S, 0, SEGV, 1, 1, 1>); \
         else if (seg_pair && ixl.stage_lds != 0u) MOVI_LAUNCH_SEG(SEGV, LANES, pml_kernel_flatp<6, T, -1, 0, S, 0, SEGV, 1, 0, 1>); \
         else if (ixl.stage_lds != 0u && ix.rows3 != nullptr) MOVI_LAUNCH_SEG(SEGV, LANES, pml_kernel_flatp<6, T, -1, 0, S, 0, SEGV, 1, 2>); \
         else if (ixl.stage_lds != 0u && ix.rows2 != nullptr) MOVI_LAUNCH_SEG(SEGV, LANES, pml_kernel_flatp<6, T, -1, 0, S, 0, SEGV, 1, 1>); \
@@ -2125,7 +2187,8 @@ static hipError_t launch_pml_segmented(const DevIndex &ix, const uint8_t *d_base
     if (info) {                                           // the dominant kernel: K1
         const int stg = ixl.stage_lds != 0u ? 1 : 0, ahd = (stg && ix.rows3 != nullptr) ? 2 : ((stg && ix.rows2 != nullptr) ? 1 : 0);
         snprintf(info->kernel, sizeof(info->kernel), "pml_kernel_flatp<6, %s, -1, 0, %d, 0, 1, %d, %d%s>",
-                 ix.idx32 ? "unsigned int" : "unsigned long", ix.sep ? 1 : 0, stg, ahd, (seg_pair && stg) ? ", 1" : "");
+                 ix.idx32 ? "unsigned int" : "unsigned long", ix.sep ? 1 : 0, stg, ahd,
+                 seg_ring ? (seg_pair ? ", 1, 1" : ", 0, 1") : ((seg_pair && stg) ? ", 1" : ""));
         info->variant = 14; info->block_threads = 64; info->segmented = 1; info->idx64 = ix.idx32 ? 0 : 1;
         info->waves_per_cu = 0; info->staged = (int)ixl.stage_lds; info->ahead = ahd;
     }
@@ -2242,15 +2305,21 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     // its wavefronts per CU leave of the 160 KiB, so that the round stays one round.  Long reads roll through the same
     // stretch (stage_from in the kernel).  cfg.stage_reads: 1 = whenever it fits (default), 0 = never.
     DevIndex ixl = ix;
+    // PMLs out through a ring in LDS (ix.out_ring; the kernel has the numbers): launches of long reads -- few wavefronts, each
+    // one's own instruction stream most of an iteration -- where the block's LDS holds the ring beside 96 staged bases.
+    // cfg.out_ring: -1 = this policy, 0 / 1 = never / wherever it fits (A/B).
+    const bool ring_wanted = stage_ok && v == 10 && !chain_ok && (cfg.out_ring > 0 || (cfg.out_ring < 0 && n_bases / n_reads >= kOutRingReadLen));
     if (stage_ok && wpc == 0) {
         const uint64_t wn = (blocks + (uint64_t)cfg.num_cus - 1) / (uint64_t)cfg.num_cus;      // wavefronts per CU of this launch
         // (room for a quarter more: the dispatcher does not deal the blocks out evenly, and a CU that may hold no more than the
         // average leaves its surplus queued -- 150 k reads, 9.2 wavefronts per CU: 41.2 Gbases/s with room for 10, 45.8 for 12)
         const uint64_t room = wn + std::max<uint64_t>(2, wn / 4);
-        if (wn <= 18) dyn_lds = std::min<size_t>(21504, ((163840u / (unsigned)room) & ~1023u) - 1024u);
+        if (wn <= 18) dyn_lds = std::min<size_t>(21504 + (ring_wanted ? kOutRingBytes : 0u), ((163840u / (unsigned)room) & ~1023u) - 1024u);
     }
-    const uint32_t stage_cap = (uint32_t)std::min<size_t>(1024, (dyn_lds / 64) & ~(size_t)15);
+    const size_t ring_b = (ring_wanted && dyn_lds >= kOutRingBytes + 96u * 64u) ? kOutRingBytes : 0;
+    const uint32_t stage_cap = (uint32_t)std::min<size_t>(1024, ((dyn_lds - ring_b) / 64) & ~(size_t)15);
     ixl.stage_lds = (stage_ok && stage_cap >= 96) ? stage_cap : 0u;
+    const bool use_ring = ring_b != 0 && ixl.stage_lds != 0u;
     ixl.refill_batch = cfg.refill_batch > 0 ? (uint32_t)cfg.refill_batch : 16u;
     ixl.inwin = cfg.inwin ? 1u : 0u;
     if (v == 13 && ixl.stage_lds == 0u) return hipErrorInvalidValue;                  // (cannot happen: the refill launch is capped)
@@ -2295,9 +2364,19 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
         if (ix.idx32) MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint32_t, H, C, S, R>);                         \
         else MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint64_t, H, C, S, R>);                                  \
     } while (0)
+#define MOVI_LAUNCH_FLATP_G(M, C, S, A, P)                                                                  \
+    do {                                                                                                    \
+        if (ix.idx32) MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint32_t, -1, C, S, 0, 0, 1, A, P, 1>);         \
+        else MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint64_t, -1, C, S, 0, 0, 1, A, P, 1>);                  \
+    } while (0)
 #define MOVI_LAUNCH_FLATP_STG(M, C, S, R)                                                                   \
     do {                                                                                                    \
-        if (use_pair && R == 0 && use_ahead) {                                                              \
+        if (use_ring && R == 0) {                                                                           \
+            if (use_pair && use_ahead) MOVI_LAUNCH_FLATP_G(M, C, S, 1, 1);                                  \
+            else if (use_pair) MOVI_LAUNCH_FLATP_G(M, C, S, 0, 1);                                          \
+            else if (use_ahead) MOVI_LAUNCH_FLATP_G(M, C, S, 1, 0);                                         \
+            else MOVI_LAUNCH_FLATP_G(M, C, S, 0, 0);                                                        \
+        } else if (use_pair && R == 0 && use_ahead) {                                                       \
             if (ix.idx32) MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint32_t, -1, C, S, 0, 0, 1, 1, 1>);        \
             else MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint64_t, -1, C, S, 0, 0, 1, 1, 1>);                 \
         } else if (use_pair && R == 0) {                                                                    \
@@ -2344,7 +2423,8 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
         if (v == 0 || v == 1) snprintf(info->kernel, sizeof(info->kernel), "pml_kernel<6, %d, %d>", v, v == 0 ? 0 : cm);
         else if (v == 7) snprintf(info->kernel, sizeof(info->kernel), "pml_kernel_flat<6, %s, 0>", it);
         else snprintf(info->kernel, sizeof(info->kernel), "pml_kernel_flatp<6, %s, %d, %d, %d, %d, 0, %d, %d%s>", it, (wp || v == 13) ? -1 : MOVI_HA, cm,
-                      ix.sep ? 1 : 0, v == 13 ? 1 : 0, ixl.stage_lds ? 1 : 0, use_ahead ? 1 : (use_chain ? 2 : 0), use_pair ? ", 1" : "");
+                      ix.sep ? 1 : 0, v == 13 ? 1 : 0, ixl.stage_lds ? 1 : 0, use_ahead ? 1 : (use_chain ? 2 : 0),
+                      use_ring ? (use_pair ? ", 1, 1" : ", 0, 1") : (use_pair ? ", 1" : ""));
         info->variant = (v == 10 && wp) ? 14 : v;
         info->block_threads = bt; info->waves_per_cu = wpc; info->segmented = 0; info->idx64 = ix.idx32 ? 0 : 1;
         info->staged = (int)ixl.stage_lds;
@@ -2360,6 +2440,7 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
 #undef MOVI_LAUNCH_FLATP_S
 #undef MOVI_LAUNCH_FLATP_R
 #undef MOVI_LAUNCH_FLATP_STG
+#undef MOVI_LAUNCH_FLATP_G
 #undef MOVI_LAUNCH_FLATP_H
 #undef MOVI_BY_CLS
     return hipGetLastError();

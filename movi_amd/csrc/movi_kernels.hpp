@@ -100,6 +100,9 @@ struct DevStats {
 constexpr int kCountCapWaves = 16;   // the count kernel's cap on cache-resident tables (launch_count)
 constexpr int kCapWaves = 7;   // resident wavefronts per CU of the lane state machine on big batches (round 2: 9, optimum 8-10; round 3, with the reads staged in LDS and the top-of-walk table: 6-8, profiles/r03_occupancy_sweep.txt)
 constexpr int kCapWavesAhead = 9;    // ... when the walk runs on the look-ahead rows: fewer lines per base, more walks in flight pay (profiles/r03_ahead_rows_ab.txt)
+constexpr uint32_t kOutRingBytes = 4096;          // pml_kernel_flatp<..., RING = 1>: the ring in the block's dynamic LDS its PMLs leave through (32 per lane)
+constexpr uint64_t kOutRingReadLen = 1024;        // ... on by itself for batches whose mean read length is at least this (launch_pml)
+constexpr uint32_t kTallySlots = 512;             // pairs of u64 counters a builder's tally is spread over (d_tally: 2 * kTallySlots u64, zeroed)
 constexpr uint64_t kPairLoadBytes = 2ull << 30;   // walked tables of this size and more: pair-shared gathers (launch_pml)
 
 struct LaunchCfg {
@@ -120,6 +123,7 @@ struct LaunchCfg {
                            // so that a few hundred reads already go through many refills per lane)
     int refill_batch = 0;  // variant 13: idle lanes switch to their next reads when this many wait (0 = 16)
     int inwin = 1;         // repositions inside the window resolved in the same iteration (0 = off: A/B)
+    int out_ring = -1;     // PMLs out through a ring in LDS: -1 = batches of long reads (launch_pml), 0 / 1 = never / wherever it fits (A/B)
     int classify_fused = -1; // movi_pml_classify_*: -1 auto, 1 = vector + bins fused into the walk, 0 = the walk, then classify_kernel over the vectors
     int pair_loads = -1;   // the lanes of a pair fetch their row windows together (pml_kernel_flatp<..., PSH = 1>): -1 auto (tables of 2 GB and more), 0 never, 1 always
     int zml_ahead = 0;     // 1: zml_kernel_flat<6, T, 0, 1> on the look-ahead rows where they exist (a third fewer iterations, no faster: opt-in)

@@ -219,7 +219,8 @@ def test_segments_walk_on_the_look_ahead_rows(built_lib, golden_image, sep):
                 out, st = gpu.query_pml_packed(bases, offs)
                 li = gpu.last_launch()
                 assert li["segmented"] == 1 and li["ahead"] == (ahead & stage) and (li["staged"] > 0) == bool(stage), (seg_len, li)
-                assert li["kernel"].endswith("0, 1, %d, %d>" % (stage, ahead & stage))
+                # (staged segments: their PMLs leave through the LDS ring -- RING = 1, the last template argument)
+                assert li["kernel"].endswith("0, 1, %d, %d%s>" % (stage, ahead & stage, ", 0, 1" if stage else ""))
                 assert (out == exp).all(), (seg_len, ahead, stage)
                 assert (st.fast_forwards, st.scans, st.errors) == (ff, sc, 0), (seg_len, ahead, stage)
                 assert st.segments > len(reads)
@@ -529,5 +530,67 @@ def test_pair_shared_gathers_vs_oracle(built_lib, golden_image, mode):
         sout, sst = gpu.query_pml_packed(sb, so)
         assert gpu.last_launch()["kernel"].endswith(", 1>") and (sout == sexp).all() and (sst.fast_forwards, sst.scans) == (sff, ssc)
     gpu.set_option("pair_loads", 0)
+    gpu.close()
+    cpu.close()
+
+
+@pytest.mark.parametrize("mode", [6, 8])
+def test_pml_out_ring_vs_oracle(built_lib, golden_image, mode):
+    """"out_ring" (pml_kernel_flatp<..., RING = 1>): the staged PML kernels' PMLs leave through a ring of 32 per lane in LDS -- one 2-byte LDS
+    write per PML, a finished group of 16 as two 16-byte stores -- instead of the register packer.  On by itself for batches of
+    long reads, "out_ring" 1 wherever the block's LDS holds it.  Same PML vectors, error bytes, counters and bins: reads of every
+    length from 0 up (tails of 0 .. 15 PMLs stored one by one, reads shorter than a group), failing reads (zero-filled), long
+    reads rolling through the staged stretch, lane refill, pair-shared gathers, segments."""
+    import movi_amd
+    from oracle.oracle import Oracle
+    img = golden_image(mode)
+    gpu, cpu = movi_amd.MoveIndex.from_image(img), Oracle(img)
+    ref = _ref()
+    rng = np.random.default_rng(9890 + mode)
+    bases, offs = _big_batch(ref, rng)
+    exp, ff, sc = cpu.pml_batch(bases, offs, threads=8)
+    long_reads = mutated_reads(rng, ref, 301, 1, 3000) + [bytes(ref[-2500:]), bytes(ref[:2100])]
+    lb, lo = pack(long_reads)
+    lexp, lff, lsc = cpu.pml_batch(lb, lo, threads=4)
+    ragged = [bytes(ref[s: s + n]) for n in range(0, 70) for s in (11, 1234)] + [b"", b"N" * 40, b"ACGTN" * 9]
+    rb, ro = pack(ragged)
+    rexp, rff, rsc = cpu.pml_batch(rb, ro, threads=2)
+    gpu.set_option("out_ring", 0)
+    bins0 = gpu.classify_packed(bases, offs, 40, 4)
+    lbins0 = gpu.classify_packed(lb, lo, 150, 8)
+    gpu.set_option("out_ring", 1)
+    for ahead, pair, variant in ((1, 0, -1), (0, 0, -1), (1, 1, -1), (0, 1, -1), (1, 0, 13), (2, 0, -1)):
+        gpu.set_option("ahead_rows", ahead)
+        gpu.set_option("pair_loads", pair)
+        gpu.set_option("pml_variant", variant)
+        out, st = gpu.query_pml_packed(bases, offs)
+        li = gpu.last_launch()
+        ringed = variant == -1 and ahead < 2              # (lane refill and the chain rows keep the packer)
+        assert li["ahead"] == ahead and li["staged"] == (CAP if ahead == 0 else CAP_AHEAD) - (64 if ringed else 0), li   # the ring takes 4 KB of the block's LDS
+        assert li["kernel"].endswith(", %d, 1>" % pair) == ringed, li
+        assert (out == exp).all(), (mode, ahead, pair, variant)
+        assert (st.fast_forwards, st.scans, st.errors) == (ff, sc, 0), (mode, ahead, pair, variant)
+        rout, rst = gpu.query_pml_packed(rb, ro)
+        assert (rout == rexp).all() and (rst.fast_forwards, rst.scans) == (rff, rsc), (mode, ahead, pair, variant)
+        if variant == -1 and ahead < 2:
+            bins = gpu.classify_packed(bases, offs, 40, 4)
+            assert all((x == y).all() for x, y in zip(bins, bins0)), (ahead, pair)
+    gpu.set_option("pml_variant", -1)
+    gpu.set_option("pair_loads", -1)
+    gpu.set_option("ahead_rows", 1)
+    # long reads: the policy picks the ring by itself -- one lane per read, and cut into segments
+    gpu.set_option("out_ring", -1)
+    for seg_len in (0, 512):
+        gpu.set_option("seg_len", seg_len)
+        gpu.set_option("seg_probe", 0)
+        lout, lst = gpu.query_pml_packed(lb, lo)
+        assert gpu.last_launch()["segmented"] == (1 if seg_len else 0) and gpu.last_launch()["kernel"].endswith(", 1, 0, 1>")
+        assert (lout == lexp).all() and (lst.fast_forwards, lst.scans, lst.errors) == (lff, lsc, 0), seg_len
+    gpu.set_option("seg_len", 0)
+    lbins = gpu.classify_packed(lb, lo, 150, 8)
+    assert all((x == y).all() for x, y in zip(lbins, lbins0))
+    # ... and not for short ones: same staging as ever
+    out, st = gpu.query_pml_packed(bases, offs)
+    assert gpu.last_launch()["staged"] == CAP_AHEAD and (out == exp).all()
     gpu.close()
     cpu.close()

@@ -1,7 +1,8 @@
 #!/bin/bash
 # round 4, final tree: kernel trace + PMC passes (own runs, never combined with tracing) of the default launches of c2, c3 and c4
-# usage: tools/r04_final.sh <outdir>
+# usage: tools/r04_final.sh <outdir> [workloads: "c2 c3 c2_count c4"]
 OUT=${1:-gpurun_out/r04_final}
+WLS=${2:-c2 c3 c2_count c4}
 cd "$(dirname "$0")/.." || exit 1
 export MOVI_BENCH_CACHE=${MOVI_BENCH_CACHE:-$PWD/.bench_cache}
 R=$PWD
@@ -20,9 +21,12 @@ one() {  # name, bench args
   find "$d" -name "*.db" -delete
   grep -o '"value": [0-9.]*\|"iterations_per_base": [0-9.]*\|"simt_efficiency": [0-9.]*\|"fast_forwards_per_base": [0-9.]*\|"scans_per_base": [0-9.]*' "$d/kt.log" | tr '\n' ' ' > "$d/bench_line.txt"
 }
-one c2 --workload c2
-one c3 --workload c3
-one c2_count --workload c2 --query count
-one c4 --workload c4
-{ for n in c2 c3 c2_count c4; do echo "==== $n: bench.py --quick --workload ... under rocprofv3 ($(cat $OUT/$n/bench_line.txt))"; grep -h "KERNEL\|PMC" $OUT/$n/summary.txt | grep "pml_kernel_flatp\|count_kernel\|kmer_table\|ahead_rows\|ftab_kernel" | sed 's/void movi:://' | cut -c1-250; done; } > $OUT/r04_final_kernels.txt
+for w in $WLS; do
+  case $w in
+    c2_count) one c2_count --workload c2 --query count;;
+    c4_plain) one c4_plain --workload c4 --ahead-rows 0;;
+    *) one $w --workload $w;;
+  esac
+done
+{ for n in $WLS; do echo "==== $n: bench.py --quick --workload ... under rocprofv3 ($(cat $OUT/$n/bench_line.txt))"; grep -h "KERNEL\|PMC" $OUT/$n/summary.txt | grep "pml_kernel_flatp\|count_kernel\|kmer_table\|ahead_rows\|ftab_kernel" | sed 's/void movi:://' | cut -c1-250; done; } > $OUT/r04_final_kernels.txt
 tail -5 $OUT/r04_final_kernels.txt
