@@ -326,7 +326,7 @@ int movi_host_unregister(void *p);
  * of those K bases -- one 16-byte table lookup replaces the first K row gathers of every read and segment; left alone the
  * first PML query on a DNA *-thresholds index builds the K = 12 table (256 MB, a few ms: that one call waits for it);
  * 0 = no table, 1..12 = build that one now), "stage_reads" (1, the default: every lane of the default walk copies the
- * next stretch of its read -- 336 bases at the default occupancy cap, 256 on the look-ahead rows -- into the block's LDS and
+ * next stretch of its read -- 256 bases at the occupancy cap of the look-ahead rows, 336 in small launches -- into the block's LDS and
  * takes its bases from there instead of re-fetching the read's cache line for every 16 bases; long reads roll through the
  * stretch; 0 = off: A/B),
  * "ahead_rows" (look-ahead rows: a second copy of the table, 16 bytes per row, in which each row's 128-byte line also holds
@@ -335,9 +335,9 @@ int movi_host_unregister(void *p);
  * real reads (+40 % on the cache-resident pangenome table); the count query walks both ends of its interval on them the
  * same way (+20 %; built by itself, the copy serves the count query only on tables whose positions mostly reach their LF
  * target without a fast-forward -- the builder tallies it --, which BWTs of real text do and random run sequences do
- * not).  Left alone, the first PML or count query builds them for tables of up
- * to 100 M rows (a copy of 1.6 GB); beyond that the wider gathers cost more address translations than they save rows on
- * the worst-case (uniformly random) table -- measured slower -- so there they are built only on request.  1 = build now,
+ * not).  Left alone, the first PML query builds them wherever the device has room for the copy and half as much again
+ * (with the pair-shared gathers below they pay at every table size measured, 14 M to 1 B rows), the first count query where
+ * a sample of the table says its search will use them.  1 = build now,
  * 0 = none (freed), 2 = build CHAIN ROWS instead: entries that reach two rows ahead (16 bytes per row, one 128-byte line per
  * 4-row window) -- up to three bases per gather; PML only.  Bit-exact like the others; it cuts the lane iterations per base by a
  * fifth on the pangenome (0.65 -> 0.52) and still runs 10 % SLOWER there (twice the table -- 450 MB, out of the Infinity Cache
@@ -347,6 +347,19 @@ int movi_host_unregister(void *p);
  * 72 %, at the same speed -- the walk is bound by the fabric's line rate, not by its lanes -- so it is selectable, not the
  * default), "inwin_repo" (1, the default: a reposition whose target run is one of the row window's other rows is resolved in
  * the iteration that sees the mismatch; 0 = off: A/B),
+ * "pair_loads" (pair-shared gathers: the two lanes of a pair fetch each row window together, each lane one 16-byte half of
+ * it in the same load instruction, halves exchanged through DPP -- one translation request and one 32-byte access where a
+ * lane's own two loads are two of each; -1, the default: on for walked tables of 2 GB and more, where translation requests
+ * bound the walk -- 1 B rows 32 -> 44 Gbases/s together with the look-ahead rows --; 1 / 0 = always / never: A/B),
+ * "out_ring" (the PML kernels' PMLs leave through a ring in LDS -- one 2-byte LDS write per PML, a finished group of 16 as
+ * two 16-byte stores -- instead of being packed in registers: a ninth fewer vector instructions per iteration; -1, the
+ * default: batches whose mean read length is at least 1024, the shape that is bound by its own instruction stream (100 k x
+ * 10 kbp: +5.7 %); 1 / 0 = wherever the block's LDS holds it / never: A/B),
+ * "classify_fused" (movi_pml_classify_device with a PML vector: -1, the default: reads of mean length >= 1024 are walked
+ * first and their bins reduced from the resident vectors by a wavefront per read -- faster than bins fused into the walk
+ * there --, shorter ones fused; 1 = always fused, 0 = always two passes),
+ * "zml_ahead" (1: the ZML parse walks on the look-ahead rows where they exist -- a third fewer iterations, no faster: off
+ * by default),
  * "ftab_k" (the count query's interval table -- the backward-search interval after the last K bases of a read by one lookup,
  * the reference's own ftab (src/move_structure_search.cpp:66-167) put to work for --count; left alone the first count query
  * on a DNA index builds the K = 12 table (256 MB); 0 = none, 1..12 = build that one now). */
