@@ -2472,25 +2472,7 @@ __device__ __forceinline__ void tab_window(const DevIndex &ix, uint64_t wb, uint
     else load_window<MODE>(ix.rows2 + (wb < ix.r - 4 ? (wb >> 3) * 128u + (wb & 4u) * 8u : ix.rows2_tail), 0, w);
 }
 
-// The window by a PAIR of lanes (pair-shared gathers, as in pml_kernel_flatp<..., PSH = 1>): every lane of the wavefront makes the
-// call; lanes 2i / 2i + 1 each load one 16-byte half of the even lane's window and of the odd lane's, in the same two
-// instructions, and exchange halves -- one translation request and one 32-byte access per window instead of two of each.
-// on = this lane wants window wb (the others fetch the table's first bytes for their partner's sake).
-template <int MODE, int AH>
-__device__ __forceinline__ void pair_tab_window(const DevIndex &ix, uint64_t wb, bool on, uint2 (&w)[4]) {
-    static_assert(MODE == 6 || MODE == 3, "8-byte rows");
-    uint64_t at = 0;
-    if (on) at = AH ? (wb < ix.r - 4 ? (wb >> 3) * 128u + (wb & 4u) * 8u : ix.rows2_tail) : wb * 8u;
-    const uint32_t odd = threadIdx.x & 1u;
-    const uint64_t pat = (uint64_t)pair_swap((uint32_t)at) | ((uint64_t)pair_swap((uint32_t)(at >> 32)) << 32);
-    const uint8_t *tab = AH ? ix.rows2 : ix.rows;
-    uint4 r1, r2;
-    __builtin_memcpy(&r1, tab + (odd ? pat : at) + 16u * odd, 16);       // this lane's half of the even lane's window
-    __builtin_memcpy(&r2, tab + (odd ? at : pat) + 16u * odd, 16);       // ... and of the odd lane's
-    pair_assemble(odd, r1, r2, w);
-}
-
-template <int MODE, int AH = 0, int PSH = 0>
+template <int MODE, int AH = 0>
 __device__ __forceinline__ void shrink_interval(const DevIndex &ix, bool act, uint32_t b, uint64_t &rs, uint32_t &os,
                                                 uint2 &rws, uint64_t &re, uint32_t &oe, uint2 &rwe,
                                                 uint32_t &scan_total) {
@@ -2501,41 +2483,6 @@ __device__ __forceinline__ void shrink_interval(const DevIndex &ix, bool act, ui
     }
     const uint64_t lo = rs, hi = re, wb_last = ix.r - 4;
     while (wave_any((gs | ge) != 0u)) {
-        if (PSH) {                                                       // both ends' windows, each by a pair of lanes
-            // (the same order of events as below -- the counters are part of the answer: start end first, then the other end's)
-            if (gs && rs >= hi) { dead = 1; gs = 0; ge = 0; }            // no row of b in [lo, hi]
-            uint64_t wbs = (rs + 1) & ~3ull, wbe = (re - 1) & ~3ull;
-            if (wbs > wb_last) wbs = wb_last;
-            if (wbe > wb_last) wbe = wb_last;
-            uint2 ws[4], we[4];
-            pair_tab_window<MODE, AH>(ix, wbs, gs != 0u, ws);
-            pair_tab_window<MODE, AH>(ix, wbe, ge != 0u && re > lo, we);
-            if (gs) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    if (gs && wbs + (uint64_t)t == rs + 1) {
-                        rs += 1;
-                        scan_total += 1;
-                        if (rs != ix.end_bwt_idx && row_c<MODE>(ws[t]) == b) { rws = ws[t]; gs = 0; }
-                        else if (rs >= hi) { dead = 1; gs = 0; ge = 0; }
-                    }
-                }
-                os = 0;
-            }
-            if (ge && re <= lo) { dead = 1; gs = 0; ge = 0; }
-            if (ge) {
-#pragma unroll
-                for (int t = 3; t >= 0; --t) {
-                    if (ge && wbe + (uint64_t)t + 1 == re) {
-                        re -= 1;
-                        scan_total += 1;
-                        if (re != ix.end_bwt_idx && row_c<MODE>(we[t]) == b) { rwe = we[t]; oe = row_n<MODE>(we[t]) - 1; ge = 0; }
-                        else if (re <= lo) { dead = 1; gs = 0; ge = 0; }
-                    }
-                }
-            }
-            continue;
-        }
         if (gs) {
             if (rs >= hi) { dead = 1; gs = 0; ge = 0; }                  // no row of b in [lo, hi]
             else {
@@ -2716,7 +2663,7 @@ __device__ __forceinline__ uint32_t arrive2_ahead(const DevIndex &ix, bool live,
 // the entries -- the step after this one needs no shrink and no rows: update_interval + two LF moves twice
 // (src/move_structure_search.cpp:311-333 run for b and for b2), two bases for one pair of gathers.  The interval after b --
 // what the reference reports if the one after b2 came out empty -- is known from the entries too.
-template <int MODE, int AH = 0, int PSH = 0>
+template <int MODE, int AH = 0>
 __global__ __launch_bounds__(256) void count_kernel_v0(DevIndex ix, const uint8_t *__restrict__ bases,
                                                        const uint64_t *__restrict__ offs, uint64_t n_reads,
                                                        uint64_t *__restrict__ matched,
@@ -2800,7 +2747,7 @@ __global__ __launch_bounds__(256) void count_kernel_v0(DevIndex ix, const uint8_
         // holds no row of character b the two ends cross instead of rs running all the way past re as
         // in the reference; either way the interval is empty and the previous one is reported.
         if (AH || ix.r >= 8) {                            // (the look-ahead copy exists for tables of 8 rows and more only)
-            shrink_interval<MODE, AH, PSH>(ix, legal && rs <= re, b, rs, os, rws, re, oe, rwe, scan_total);
+            shrink_interval<MODE, AH>(ix, legal && rs <= re, b, rs, os, rws, re, oe, rwe, scan_total);
         } else {
             shrink_interval_rows<MODE>(ix, legal && rs <= re, b, rs, os, rws, re, oe, rwe, scan_total);
         }
@@ -2892,11 +2839,8 @@ hipError_t launch_count(int mode, const DevIndex &ix, const uint8_t *d_bases, co
         if (bpc < 1) bpc = 1;
         if (bpc < 32) dyn_lds = std::min<size_t>(65536 - 1024, ((163840u / (unsigned)bpc) & ~1023u) - 1024u);
     }
-    // Pair-shared gathers for the interval shrink's windows (count_kernel_v0<..., PSH = 1>): launch_pml's rule -- tables beyond the
-    // per-CU TLBs' reach, where translation requests bound the search.  "pair_loads" 1 / 0 forces it.
-    const bool pair = ix.r >= 8 && (cfg.pair_loads > 0 || (cfg.pair_loads < 0 && ix.r * (ahead ? 16ull : 8ull) >= kPairLoadBytes));
     if (info) {
-        snprintf(info->kernel, sizeof(info->kernel), pair ? "count_kernel_v0<%d, %d, 1>" : "count_kernel_v0<%d, %d>", mode, ahead ? 1 : 0);
+        snprintf(info->kernel, sizeof(info->kernel), "count_kernel_v0<%d, %d>", mode, ahead ? 1 : 0);
         info->variant = 0; info->block_threads = bt; info->waves_per_cu = wpc; info->segmented = 0; info->idx64 = 1; info->staged = 0;
         info->ahead = ahead ? 1 : 0;
     }
@@ -2904,16 +2848,7 @@ hipError_t launch_count(int mode, const DevIndex &ix, const uint8_t *d_bases, co
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     dim3 grid((unsigned)blocks), block((unsigned)bt);
     // resident layouts: 6 = regular-thresholds rows, 3 = regular rows (threshold-less types: 12-bit lengths)
-    if (mode == 6 && ahead && pair)
-        hipLaunchKernelGGL((count_kernel_v0<6, 1, 1>), grid, block, dyn_lds, stream, ix, d_bases, d_offsets, n_reads,
-                           d_matched, d_count, d_err, d_stats, d_order);
-    else if (mode == 6 && pair)
-        hipLaunchKernelGGL((count_kernel_v0<6, 0, 1>), grid, block, dyn_lds, stream, ix, d_bases, d_offsets, n_reads,
-                           d_matched, d_count, d_err, d_stats, d_order);
-    else if (mode == 3 && pair)
-        hipLaunchKernelGGL((count_kernel_v0<3, 0, 1>), grid, block, dyn_lds, stream, ix, d_bases, d_offsets, n_reads,
-                           d_matched, d_count, d_err, d_stats, d_order);
-    else if (mode == 6 && ahead)
+    if (mode == 6 && ahead)
         hipLaunchKernelGGL((count_kernel_v0<6, 1>), grid, block, dyn_lds, stream, ix, d_bases, d_offsets, n_reads,
                            d_matched, d_count, d_err, d_stats, d_order);
     else if (mode == 6)

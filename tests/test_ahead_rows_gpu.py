@@ -594,37 +594,3 @@ def test_pml_out_ring_vs_oracle(built_lib, golden_image, mode):
     assert gpu.last_launch()["staged"] == CAP_AHEAD and (out == exp).all()
     gpu.close()
     cpu.close()
-
-
-@pytest.mark.parametrize("mode", [6, 3, 8])
-def test_count_pair_shared_gathers_vs_oracle(built_lib, golden_image, mode):
-    """"pair_loads" 1 on the count query (count_kernel_v0<..., PSH = 1>): the 4-row windows of the interval shrink are fetched by
-    pairs of lanes, on the plain rows and on the look-ahead copy.  matched / count, error bytes and the fast-forward / scan
-    counters equal the oracle's: ends that shrink over several windows, intervals that come out empty (the two ends' events
-    keep their order: the counters are part of the answer), odd numbers of reads, reads that end while their partner goes on."""
-    import movi_amd
-    from oracle.oracle import Oracle
-    img = golden_image(mode)
-    gpu, cpu = movi_amd.MoveIndex.from_image(img), Oracle(img)
-    ref = _ref()
-    rng = np.random.default_rng(9950 + mode)
-    reads = mutated_reads(rng, ref, 4001, 1, 400)
-    reads += [bytes(ref[s: s + L]) for s, L in ((100, 1), (100, 2), (5000, 150), (7000, 1000))] + [b"", b"A", b"N", b"ACGT" * 40]
-    reads += [bytes(rng.choice(list(b"ACGT"), size=int(n)).astype(np.uint8)) for n in rng.integers(5, 40, 300)]   # random text: intervals that shrink far and die
-    bases, offs = pack(reads)
-    em, ec = cpu.count_batch(bases, offs, threads=8)
-    for ahead in ((0, 1) if mode != 3 else (0,)):
-        gpu.set_option("ahead_rows", ahead)
-        for K in (0, 12):
-            gpu.set_option("ftab_k", K)
-            gpu.set_option("pair_loads", 0)
-            m0, c0, st0 = gpu.query_count_packed(bases, offs)
-            gpu.set_option("pair_loads", 1)
-            m, c, st = gpu.query_count_packed(bases, offs)
-            li = gpu.last_launch()
-            assert li["ahead"] == ahead and li["kernel"] == "count_kernel_v0<%d, %d, 1>" % (3 if mode == 3 else 6, ahead), li
-            assert (m == em).all() and (c == ec).all(), (mode, ahead, K)
-            assert (m0 == em).all() and (c0 == ec).all()
-            assert (st.fast_forwards, st.scans, st.errors) == (st0.fast_forwards, st0.scans, st0.errors), (mode, ahead, K)
-    gpu.close()
-    cpu.close()
