@@ -101,6 +101,34 @@ __global__ __launch_bounds__(256) void chase(const uint64_t *__restrict__ table,
             const uint4 q = (idx & 2) ? q1 : q0;
             v = (idx & 1) ? ((uint64_t)q.w << 32 | q.z) : ((uint64_t)q.y << 32 | q.x);
             acc += q0.x ^ q1.z;
+        } else if (VAR >= 9 && VAR <= 12) {
+            // round 4: the look-ahead rows' fetch -- 64 bytes per step out of one 128-byte line: a 32-byte window (at +0 or +32) and
+            // its 32 bytes of entries (64 bytes further on).  9: one lane, four 16-byte loads; 10: a PAIR of lanes shares the loads
+            // (four instructions, each covering one lane's window or entries: the kernel's PSH = 1); 11: FOUR lanes share them
+            // (four instructions, each covering ONE lane's window AND entries: lanes 0 / 1 the window's halves, 2 / 3 the entries');
+            // 12: the same with the 64 bytes contiguous (line = rows|entries|rows|entries).  Every lane walks its own chain; the next
+            // index depends on what the lane itself loaded (no exchange: this measures the memory side only).
+            const uint32_t lane = threadIdx.x;
+            auto piece = [&](uint32_t i, uint32_t q) -> const uint4 * {   // 16-byte piece q (0..3) of the 64 bytes of index i
+                const uint64_t *line = table + (i & ~15u);
+                if (VAR == 12) return reinterpret_cast<const uint4 *>(line + ((i & 4u) ? 8u : 0u)) + q;
+                return reinterpret_cast<const uint4 *>(line + ((i & 4u) ? 4u : 0u) + (q >> 1) * 8u) + (q & 1u);
+            };
+            uint4 r0, r1, r2, r3;
+            if (VAR == 9) {
+                r0 = *piece(idx, 0); r1 = *piece(idx, 1); r2 = *piece(idx, 2); r3 = *piece(idx, 3);
+            } else if (VAR == 10) {
+                const uint32_t odd = lane & 1u, pidx = __shfl_xor(idx, 1, 64);
+                const uint32_t ie = odd ? pidx : idx, io = odd ? idx : pidx;
+                r0 = *piece(ie, odd); r1 = *piece(ie, 2u + odd); r2 = *piece(io, odd); r3 = *piece(io, 2u + odd);
+            } else {
+                const uint32_t q = lane & 3u, b = lane & ~3u;
+                const uint32_t i0 = __shfl(idx, (int)b, 64), i1 = __shfl(idx, (int)(b | 1u), 64), i2 = __shfl(idx, (int)(b | 2u), 64),
+                               i3 = __shfl(idx, (int)(b | 3u), 64);
+                r0 = *piece(i0, q); r1 = *piece(i1, q); r2 = *piece(i2, q); r3 = *piece(i3, q);
+            }
+            v = ((uint64_t)(r0.x ^ r1.y ^ r2.z ^ r3.w) << 32) | (uint64_t)(r0.y ^ r1.z ^ r2.w ^ r3.x);
+            acc += r0.z ^ r3.y;
         } else {
             const uint4 *p = reinterpret_cast<const uint4 *>(table + (idx & ~3u));
             const uint4 q0 = p[0], q1 = p[1];
@@ -138,9 +166,11 @@ int main(int argc, char **argv) {
     uint64_t *sink;
     CHECK(hipMalloc(&sink, 64));
     const char *alloc_names[3] = {"hipMalloc", "hipExtMallocWithFlags(hipDeviceMallocContiguous)", "hipMemCreate+hipMemMap (one handle)"};
-    const char *names[9] = {"8B row", "16B pair", "32B quad", "8B row + dependent neighbour", "pair as 2 x 8B loads", "quad as 4 x 8B loads",
+    const char *names[13] = {"8B row", "16B pair", "32B quad", "8B row + dependent neighbour", "pair as 2 x 8B loads", "quad as 4 x 8B loads",
                              "32B quad by a lane PAIR (2 x 16B, one instr; steps = lanes / 2)", "32B quad by FOUR lanes (4 x 8B, one instr; steps = lanes / 4)",
-                             "32B quad, own chain per lane, loads SHARED by the pair (2 instr)"};
+                             "32B quad, own chain per lane, loads SHARED by the pair (2 instr)",
+                             "64B of a line (32B window + 32B entries at +64): one lane, 4 x 16B", "... loads shared by a lane PAIR (4 instr)",
+                             "... loads shared by FOUR lanes (4 instr, each one lane's 64B)", "... by FOUR lanes, the 64B contiguous"};
     const char *only_var = getenv("TLB_VAR");               // e.g. TLB_VAR=4: that variant only (PMC passes)
     for (int si = 0; si < ns; si++) {
         const uint64_t n = 1ull << sizes[si];
@@ -179,10 +209,10 @@ int main(int argc, char **argv) {
             if (ea != hipSuccess) { printf("  allocation failed: %s\n", hipGetErrorString(ea)); (void)hipGetLastError(); continue; }
             hipLaunchKernelGGL(fill_table, dim3(4096), dim3(256), 0, 0, table, n);
             CHECK(hipDeviceSynchronize());
-            const uint32_t n_rows = (uint32_t)(n - 8);
+            const uint32_t n_rows = (uint32_t)(n - 16);
             for (uint64_t lanes : {(uint64_t)1 << 19, (uint64_t)1 << 20}) {
-                double ms[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-                auto want = [&](int v) { return !only_var || atoi(only_var) == v; };
+                double ms[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                auto want = [&](int v) { return !only_var || atoi(only_var) == v || (only_var[0] == '>' && v >= atoi(only_var + 1)); };   // TLB_VAR=4, or ">9": from 9 on
                 if (want(0)) ms[0] = run<0>(table, n_rows, steps, lanes, sink, 4);
                 if (want(1)) ms[1] = run<1>(table, n_rows, steps, lanes, sink, 4);
                 if (want(2)) ms[2] = run<2>(table, n_rows, steps, lanes, sink, 4);
@@ -192,7 +222,11 @@ int main(int argc, char **argv) {
                 if (want(6)) ms[6] = run<6>(table, n_rows, steps, 2 * lanes, sink, 4);      // the same number of CHAINS: twice / four times the lanes
                 if (want(7)) ms[7] = run<7>(table, n_rows, steps, 4 * lanes, sink, 4);
                 if (want(8)) ms[8] = run<8>(table, n_rows, steps, lanes, sink, 4);
-                for (int v = 0; v < 9; v++)
+                if (want(9)) ms[9] = run<9>(table, n_rows, steps, lanes, sink, 4);
+                if (want(10)) ms[10] = run<10>(table, n_rows, steps, lanes, sink, 4);
+                if (want(11)) ms[11] = run<11>(table, n_rows, steps, lanes, sink, 4);
+                if (want(12)) ms[12] = run<12>(table, n_rows, steps, lanes, sink, 4);
+                for (int v = 0; v < 13; v++)
                     if (want(v))
                         printf("  chains=%8llu  %-64s %8.3f ms  %7.2f Gsteps/s\n", (unsigned long long)lanes, names[v], ms[v],
                                lanes * (double)steps / ms[v] / 1e6);
