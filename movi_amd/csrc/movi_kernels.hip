@@ -1576,7 +1576,7 @@ __global__ __launch_bounds__(256) void kmer_table_kernel(DevIndex ix, uint32_t K
 
 // The builders' tallies go to kTallySlots pairs of counters, a block to the pair of its index (the host adds them up): one
 // pair for all took the look-ahead rows of a 1 B-row table 375 ms -- 31 M atomics on one address, ~12 ns each -- instead of
-// the ~45 ms its 16 GB of writes take.
+// the 6.8 ms its 16 GB of writes take (measured after the change: gpurun_out -> profiles/r04_c4_pair_shared_pmc.txt header).
 __device__ __forceinline__ void tally_add(unsigned long long *tally, uint32_t a, uint32_t b) {
     unsigned long long *t = tally + 2u * (blockIdx.x & (kTallySlots - 1u));
     atomicAdd(t, (unsigned long long)a);
