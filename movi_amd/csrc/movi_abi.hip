@@ -805,7 +805,9 @@ static bool ahead_wanted(movi_index *ix) {
     const uint64_t bytes = ahead_rows_bytes(ix->desc.r);
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return false; }
-    return free_b > bytes + std::max<uint64_t>(2ull << 30, bytes / 2);
+    // (never more than a quarter of the device by itself: a handle's derived tables are the caller's HBM too -- "ahead_rows" 1
+    // builds them whatever their size, movi_index_info reports them)
+    return bytes <= total_b / 4 && free_b > bytes + std::max<uint64_t>(2ull << 30, bytes / 2);
 }
 // by_itself: built by the size policy, not on request -- then the count query uses the copy only where the table's own
 // statistic says it pays (DevIndex::rows2_count)
