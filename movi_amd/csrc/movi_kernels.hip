@@ -3141,12 +3141,14 @@ __global__ __launch_bounds__(256) void zml_probe_kernel(DevIndex ix, const uint8
 // The end-by-end order inside an iteration (start end first, whole window; then the end end) is the order of
 // shrink_interval's trips, so answers AND scan / fast-forward counts equal the base-synchronous kernel's.
 // SEG = 1: a lane parses one SEGMENT of a read (K1 of launch_zml_segmented), as zml_kernel<MODE, 1>.
-template <int MODE, typename IdxT, int SEG = 0, int AH = 0>
+// PSH = 1 (round 4; plain rows, whole reads): the two windows of an iteration by pairs of lanes, as pml_kernel_flatp<..., PSH = 1>.
+template <int MODE, typename IdxT, int SEG = 0, int AH = 0, int PSH = 0>
 __global__ __launch_bounds__(256) void zml_kernel_flat(DevIndex ix, const uint8_t *__restrict__ bases,
                                                        const uint64_t *__restrict__ offs, uint64_t n_reads,
                                                        uint16_t *__restrict__ out, uint8_t *__restrict__ err,
                                                        DevStats *stats, const uint32_t *__restrict__ order, ZSegArgs seg) {
     static_assert(AH == 0 || (MODE == 6 && SEG == 0), "look-ahead rows: regular-thresholds rows, whole reads");
+    static_assert(PSH == 0 || (AH == 0 && SEG == 0 && (MODE == 6 || MODE == 3)), "pair-shared gathers: plain 8-byte rows, whole reads");
     enum : uint32_t { phStart = 0, phScan = 1, phLF = 2, phInit = 3, phDone = 4 };
     enum : uint32_t { pNone = 0, pScan = 1, pFF = 2 };       // what an interval end is waiting for
     __shared__ uint8_t s_code[256];
@@ -3209,8 +3211,15 @@ __global__ __launch_bounds__(256) void zml_kernel_flat(DevIndex ix, const uint8_
     uint4 pk = make_uint4(0, 0, 0, 0), pk_old = pk;
     uint2 ws[4], we[4], es[4], ee[4];                         // AH: es / ee = the look-ahead entries of the windows' rows
     // a window of the table the parse walks on: the plain rows, or (AH) the look-ahead copy with its rows' entries
-    auto fetch_win = [&](IdxT wb, uint2 (&wr)[4], uint2 (&en)[4]) {
-        if (AH) {
+    uint4 raw_s[2], raw_e[2];                                 // PSH: what this lane loaded for its pair, assembled at the loop's top
+    const uint32_t odd_lane = threadIdx.x & 1u;
+    auto fetch_win = [&](IdxT wb, uint2 (&wr)[4], uint2 (&en)[4], uint4 (&raw)[2]) {
+        if (PSH) {                                           // each lane one 16-byte half of the even lane's window and of the odd lane's
+            const uint64_t at = (uint64_t)wb * 8u;
+            const uint64_t pat = (uint64_t)pair_swap((uint32_t)at) | ((uint64_t)pair_swap((uint32_t)(at >> 32)) << 32);
+            __builtin_memcpy(&raw[0], ix.rows + (odd_lane ? pat : at) + 16u * odd_lane, 16);
+            __builtin_memcpy(&raw[1], ix.rows + (odd_lane ? at : pat) + 16u * odd_lane, 16);
+        } else if (AH) {
             const uint64_t at = wb < wb_last ? (uint64_t)(wb >> 3) * 128u + (uint64_t)((uint32_t)wb & 4u) * 8u : ix.rows2_tail;
             load_window<MODE>(ix.rows2 + at, 0, wr);
             load_window<MODE>(ix.rows2 + at + 64u, 0, en);
@@ -3222,8 +3231,8 @@ __global__ __launch_bounds__(256) void zml_kernel_flat(DevIndex ix, const uint8_
     auto row_of_entry = [&](uint2 e) -> uint2 {
         return make_uint2(e.x, (e.y & 0x7FFu) | (((e.y >> 22) & 7u) << 13) | (((e.y >> 11) & 0x7FFu) << 16) | (((e.y >> 25) & 15u) << 28));
     };
-    fetch_win(0, ws, es);
-    fetch_win(0, we, ee);
+    fetch_win(0, ws, es, raw_s);
+    fetch_win(0, we, ee, raw_e);
     IdxT wbs = 0, wbe = 0;                                   // bases of the two windows in flight
 
     uint32_t lane_steps = 0, wave_steps = 0;
@@ -3231,6 +3240,10 @@ __global__ __launch_bounds__(256) void zml_kernel_flat(DevIndex ix, const uint8_
         const bool act = ph != phDone;
         lane_steps += (uint32_t)act;
         wave_steps += 1;
+        if (PSH) {                                           // the halves the pair loaded for each other change hands
+            pair_assemble(odd_lane, raw_s[0], raw_s[1], ws);
+            pair_assemble(odd_lane, raw_e[0], raw_e[1], we);
+        }
         // ---- 1. walk each end as far as its window reaches (start end first: shrink_interval's order), in closed form as
         // pml_kernel_flatp's window_advance: a fast-forward passes row i iff the offset covers the running sum of the
         // lengths up to i; a scan passes the leading run of rows that are not its target (a 4-bit mask + count zeros).
@@ -3401,8 +3414,8 @@ __global__ __launch_bounds__(256) void zml_kernel_flat(DevIndex ix, const uint8_
             const IdxT ns = ps == pScan ? (IdxT)(rs + 1) : rs, ne = pe == pScan ? (IdxT)(re - (re > 0 ? 1 : 0)) : re;
             wbs = ps != pNone ? win_base(ns) : (IdxT)0;
             wbe = pe != pNone ? win_base(ne) : (IdxT)0;
-            fetch_win(wbs, ws, es);
-            fetch_win(wbe, we, ee);
+            fetch_win(wbs, ws, es, raw_s);
+            fetch_win(wbe, we, ee, raw_e);
         }
         // ---- 4. bookkeeping: the emissions and the next bases
         uint32_t want_nx = 0;
@@ -3638,8 +3651,13 @@ hipError_t launch_zml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     // beyond the ~1.7 GB reach of a CU's TLB that costs more than the base-synchronous kernel's dependent trips, so auto
     // picks it for tables up to 3 GB.  (Its first form walked the windows with eight sequential hops and was no faster
     // than kernel 0 anywhere: 12.4 on the long reads, 32.6 on the short ones; the closed-form window walk made it.)
+    // Round 4: with the two windows fetched by PAIRS of lanes (zml_kernel_flat<..., PSH = 1>: half the translation requests) the
+    // state machine serves the tables beyond 3 GB too: 1 B rows 16.8 (kernel 0) / 13.9 (kernel 1) -> 25.0 Gbases/s; below 2 GB the
+    // exchange costs more than it gives (c2: 38.2 -> 36.6), so there the lanes keep their own loads (profiles/r04_zml_ahead.txt;
+    // "pair_loads" 0: the old policy, 1: pairs everywhere).
     int v = cfg.zml_variant;
-    if (v < 0) v = ix.r <= (3ull << 30) / 8 ? 1 : 0;
+    const bool big = ix.r * 8ull >= kPairLoadBytes;
+    if (v < 0) v = (ix.r <= (3ull << 30) / 8 || (big && cfg.pair_loads != 0)) ? 1 : 0;
     if (v == 1 && (ix.r < 8 || n_bases < 16)) v = 0;     // the clamped windows need >= 4 rows, the 16-base fetches 16 bytes
     const int bt = cfg.block_threads > 0 ? cfg.block_threads : (v == 1 ? 64 : 256);
     const uint64_t blocks = (n_reads + bt - 1) / bt;
@@ -3650,8 +3668,10 @@ hipError_t launch_zml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     // instead of 38.2 Gbases/s (eight 16-byte loads per iteration instead of four, SIMT 0.72 -> 0.64; random 10 M-row table 35.9 ->
     // 35.0: profiles/r04_zml_ahead.txt), so it is an option, not the default.
     const bool ahead = cfg.zml_ahead != 0 && v == 1 && mode == 6 && ix.rows2 != nullptr;
+    const bool pair = v == 1 && !ahead && (cfg.pair_loads > 0 || (cfg.pair_loads < 0 && big));
     if (info) {
-        if (v == 1) snprintf(info->kernel, sizeof(info->kernel), "zml_kernel_flat<%d, %s, 0%s>", mode, ix.idx32 ? "unsigned int" : "unsigned long", ahead ? ", 1" : "");
+        if (v == 1) snprintf(info->kernel, sizeof(info->kernel), "zml_kernel_flat<%d, %s, 0%s>", mode, ix.idx32 ? "unsigned int" : "unsigned long",
+                             ahead ? ", 1" : (pair ? ", 0, 1" : ""));
         else snprintf(info->kernel, sizeof(info->kernel), "zml_kernel<%d, 0>", mode);
         info->variant = v; info->block_threads = bt; info->waves_per_cu = cfg.waves_per_cu > 0 ? cfg.waves_per_cu : 0; info->staged = 0; info->ahead = ahead ? 1 : 0;
         info->segmented = 0; info->idx64 = ix.idx32 ? 0 : 1;
@@ -3667,6 +3687,12 @@ hipError_t launch_zml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
         if (v == 0)                                                                                            \
             hipLaunchKernelGGL(zml_kernel<M>, grid, block, dyn_lds, stream, ix, d_bases, d_offsets, n_reads,   \
                                d_out, d_err, d_stats, d_order, ZSegArgs());                                    \
+        else if (pair && ix.idx32)                                                                             \
+            hipLaunchKernelGGL((zml_kernel_flat<M, uint32_t, 0, 0, 1>), grid, block, dyn_lds, stream, ix,      \
+                               d_bases, d_offsets, n_reads, d_out, d_err, d_stats, d_order, ZSegArgs());       \
+        else if (pair)                                                                                         \
+            hipLaunchKernelGGL((zml_kernel_flat<M, uint64_t, 0, 0, 1>), grid, block, dyn_lds, stream, ix,      \
+                               d_bases, d_offsets, n_reads, d_out, d_err, d_stats, d_order, ZSegArgs());       \
         else if (ix.idx32)                                                                                     \
             hipLaunchKernelGGL((zml_kernel_flat<M, uint32_t>), grid, block, dyn_lds, stream, ix, d_bases,      \
                                d_offsets, n_reads, d_out, d_err, d_stats, d_order, ZSegArgs());                \

@@ -594,3 +594,42 @@ def test_pml_out_ring_vs_oracle(built_lib, golden_image, mode):
     assert gpu.last_launch()["staged"] == CAP_AHEAD and (out == exp).all()
     gpu.close()
     cpu.close()
+
+
+@pytest.mark.parametrize("mode", [6, 3, 8])
+def test_zml_pair_shared_gathers_vs_oracle(built_lib, golden_image, mode):
+    """"pair_loads" 1 on the ZML parse (zml_kernel_flat<..., PSH = 1>): the two windows of an iteration are fetched by pairs of
+    lanes (what the policy does by itself for tables of 2 GB and more).  Same ZML vectors, error bytes and counters as the
+    oracle and as the lane-private loads: odd numbers of reads, reads that end while their partner parses on, both widths."""
+    import movi_amd
+    from oracle import build_index as B
+    from oracle.oracle import Oracle
+    ref = _ref()
+    img = golden_image(mode) if mode != 3 else B.build_index_from_seqs([ref], 3)     # (3: a threshold-less `regular` index)
+    gpu, cpu = movi_amd.MoveIndex.from_image(img), Oracle(img)
+    rng = np.random.default_rng(9970 + mode)
+    reads = mutated_reads(rng, ref, 2501, 1, 400) + [bytes(ref[s: s + L]) for s, L in ((100, 1), (200, 8), (300, 17), (5000, 150), (9000, 4000))]
+    reads += [b"", b"A", b"N", b"ACGT" * 40, bytes(ref[-300:]), bytes(ref[:300])]
+    bases, offs = pack(reads)
+    exp = cpu.zml_batch(bases, offs, threads=8)
+    gpu.set_option("seg_len", 0)
+    gpu.set_option("zml_variant", 1)
+    kmode = 3 if mode == 3 else 6
+    for idx64 in (0, 1):
+        gpu.set_option("idx64", idx64)
+        gpu.set_option("pair_loads", 0)
+        out0, st0 = gpu.query_zml_packed(bases, offs)
+        assert gpu.last_launch()["kernel"].endswith(", 0>") and (out0 == exp).all() and st0.errors == 0
+        gpu.set_option("pair_loads", 1)
+        out, st = gpu.query_zml_packed(bases, offs)
+        li = gpu.last_launch()
+        assert li["kernel"].startswith("zml_kernel_flat<%d, " % kmode) and li["kernel"].endswith(", 0, 0, 1>") and li["idx64"] == idx64, li
+        assert (out == exp).all(), (mode, idx64)
+        assert (st.fast_forwards, st.scans, st.errors) == (st0.fast_forwards, st0.scans, 0), (mode, idx64)
+    gpu.set_option("idx64", 0)
+    bb, bo = _big_batch(ref, rng, max_len=200, n_long=20)
+    bexp = cpu.zml_batch(bb, bo, threads=8)
+    bout, bst = gpu.query_zml_packed(bb, bo)
+    assert gpu.last_launch()["kernel"].endswith(", 0, 0, 1>") and (bout == bexp).all() and bst.errors == 0
+    gpu.close()
+    cpu.close()
