@@ -350,7 +350,8 @@ int movi_host_unregister(void *p);
  * "pair_loads" (pair-shared gathers: the two lanes of a pair fetch each row window together, each lane one 16-byte half of
  * it in the same load instruction, halves exchanged through DPP -- one translation request and one 32-byte access where a
  * lane's own two loads are two of each; -1, the default: on for walked tables of 2 GB and more, where translation requests
- * bound the walk -- 1 B rows 32 -> 44 Gbases/s together with the look-ahead rows --; 1 / 0 = always / never: A/B),
+ * bound the walk -- 1 B rows 32 -> 44 Gbases/s together with the look-ahead rows; the ZML parse fetches its two windows per
+ * iteration the same way there: 16.8 -> 25.0 --; 1 / 0 = always / never: A/B),
  * "out_ring" (the PML kernels' PMLs leave through a ring in LDS -- one 2-byte LDS write per PML, a finished group of 16 as
  * two 16-byte stores -- instead of being packed in registers: a ninth fewer vector instructions per iteration; -1, the
  * default: batches whose mean read length is at least 1024, the shape that is bound by its own instruction stream (100 k x
