@@ -192,8 +192,8 @@ def count_roofline(table_bytes, row_bytes, st, matched_bases, kern_s, launch):
 
 
 def table_bytes_walked(rows, row_bytes, launch):
-    """Bytes of the table the launch gathered from: the look-ahead copy is 16 B per row, the chain rows 32."""
-    return rows * {0: row_bytes, 1: 16, 2: 32}.get(int(launch.get("ahead") or 0), row_bytes)
+    """Bytes of the table the launch gathered from: the look-ahead copy is 16 B per row."""
+    return rows * {0: row_bytes, 1: 16}.get(int(launch.get("ahead") or 0), row_bytes)
 
 
 def send_to_rank(torch, dist, world, rank, dev, arr, dst):

@@ -230,7 +230,7 @@ typedef struct movi_launch_info {
     int32_t idx64;                    /* 1 = the 64-bit row-index instantiation                                     */
     int32_t staged;                   /* > 0: every lane keeps the next `staged` bases of its read in LDS ("stage_reads";
                                          336 at the default occupancy cap, 256 on the look-ahead rows); 0: no staging */
-    int32_t ahead;                    /* 1 = the walk ran on the look-ahead rows ("ahead_rows"), 2 = on the chain rows */
+    int32_t ahead;                    /* 1 = the walk ran on the look-ahead rows ("ahead_rows") */
     int32_t reserved_;
 } movi_launch_info_t;
 int movi_last_launch(const movi_index_t *ix, movi_launch_info_t *info);
@@ -238,7 +238,7 @@ int movi_last_launch(const movi_index_t *ix, movi_launch_info_t *info);
 /* What the handle holds in HBM besides the row table, and what its builders measured (no reference counterpart; the
  * derived tables of "kmer_k" / "ahead_rows" / "ftab_k" are built by the first query that can use them, so this is how a
  * caller sees their cost).  Keys: "rows_bytes" (the resident row table), "kmer_bytes", "ftab_bytes", "ahead_rows_bytes",
- * "chain_rows_bytes", "ckpt_bytes" (0 = not built), "derived_bytes" (their sum), "ahead_no_ff" (share of the table's BWT
+ * "ckpt_bytes" (0 = not built), "derived_bytes" (their sum), "ahead_no_ff" (share of the table's BWT
  * positions that reach their LF target without a fast-forward, tallied when the look-ahead rows are built: 0.83 on the
  * pangenome BWT, 0.51 on a uniformly random run sequence; -1 = not tallied yet).  Unknown key: MOVI_ERR_ARG. */
 int movi_index_info(const movi_index_t *ix, const char *key, double *value);
@@ -338,10 +338,8 @@ int movi_host_unregister(void *p);
  * not).  Left alone, the first PML query builds them wherever the device has room for the copy and half as much again
  * (with the pair-shared gathers below they pay at every table size measured, 14 M to 1 B rows), the first count query where
  * a sample of the table says its search will use them.  1 = build now,
- * 0 = none (freed), 2 = build CHAIN ROWS instead: entries that reach two rows ahead (16 bytes per row, one 128-byte line per
- * 4-row window) -- up to three bases per gather; PML only.  Bit-exact like the others; it cuts the lane iterations per base by a
- * fifth on the pangenome (0.65 -> 0.52) and still runs 10 % SLOWER there (twice the table -- 450 MB, out of the Infinity Cache
- * -- and six 16-byte loads per step: profiles/r04_chain_rows.txt), so it is never built by itself),
+ * 0 = none (freed).  (Entries two rows deep -- "chain rows", three bases per gather -- were built in round 4, bit-exact, and
+ * measured 10 - 38 % slower: profiles/r04_chain_rows.txt; removed),
  * "pml_variant" 13 (lane refill: the default walk as a persistent grid whose idle lanes take the next reads of a pool fed from
  * one global ticket counter, "refill_batch" lanes at a time (default 16): 82 - 87 % of the lane iterations do work instead of
  * 72 %, at the same speed -- the walk is bound by the fabric's line rate, not by its lanes -- so it is selectable, not the

@@ -96,7 +96,6 @@ struct movi_index {
     uint4 *d_kmer = nullptr;         // top-of-walk table ("kmer_k" option), 16 << 2K bytes
     int kmer_auto = 12;              // K of the table the first PML query builds by itself (0 = none: "kmer_k" 0)
     uint8_t *d_rows2 = nullptr;      // look-ahead rows ("ahead_rows" option), 16 bytes per row
-    uint8_t *d_rows3 = nullptr;      // chain rows: entries that look two rows ahead ("ahead_rows" 2)
     double ahead_no_ff = 0.0;        // share of the table's positions that arrive at their LF target without a fast-forward (build_ahead)
     bool ahead_tallied = false;
     bool count_declined_ahead = false;   // the count query's auto-build found the copy not worth keeping (rows2_count == 0): do not build it per call
@@ -737,7 +736,6 @@ int movi_index_destroy(movi_index_t *ix) {
     if (ix->d_kmer) (void)hipFree(ix->d_kmer);
     if (ix->d_ftab) (void)hipFree(ix->d_ftab);
     if (ix->d_rows2) (void)hipFree(ix->d_rows2);
-    if (ix->d_rows3) (void)hipFree(ix->d_rows3);
     if (ix->d_stats) (void)hipFree(ix->d_stats);
     release_scratch(ix);
     delete ix;
@@ -827,17 +825,6 @@ static int build_ahead(movi_index *ix, hipStream_t s, bool by_itself) {
     ix->ahead_no_ff = h_tally[1] ? (double)h_tally[0] / (double)h_tally[1] : 0.0;
     ix->ahead_tallied = true;
     ix->dev.rows2_count = (!by_itself || ix->ahead_no_ff >= kAheadCountRatio) ? 1u : 0u;
-    return MOVI_OK;
-}
-
-static int build_chain(movi_index *ix, hipStream_t s) {
-    HIP_TRY(hipMalloc(&ix->d_rows3, chain_rows_bytes(ix->desc.r)));
-    uint64_t tail = 0;
-    hipError_t e = build_chain_rows(ix->kmode, ix->dev, ix->d_rows3, &tail, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (e != hipSuccess) { (void)hipFree(ix->d_rows3); ix->d_rows3 = nullptr; return fail_hip(e, "building the chain rows"); }
-    ix->dev.rows3 = ix->d_rows3;
-    ix->dev.rows3_tail = tail;
     return MOVI_OK;
 }
 
@@ -986,23 +973,19 @@ int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
             return fail(MOVI_ERR_ARG, "the top-of-walk table serves PML walks on DNA (ACGT) *-thresholds indexes only");
         return build_kmer(ix, (uint32_t)value, nullptr);
     }
-    if (!strcmp(key, "ahead_rows")) {                        // look-ahead rows: 0 = none (freed), 1 = build them now, 2 = chain rows (entries two rows deep)
-        if (value < 0 || value > 2) return fail(MOVI_ERR_ARG, "ahead_rows must be 0, 1 or 2");
+    if (!strcmp(key, "ahead_rows")) {                        // look-ahead rows: 0 = none (freed), 1 = build them now
+        if (value < 0 || value > 1) return fail(MOVI_ERR_ARG, "ahead_rows must be 0 or 1");
         HIP_TRY(hipSetDevice(ix->device));
         HIP_TRY(hipDeviceSynchronize());                     // no walk may be reading the copy that goes away
         ix->dev.rows2 = nullptr;
         ix->dev.rows2_tail = 0;
         ix->dev.rows2_count = 0;
-        ix->dev.rows3 = nullptr;
-        ix->dev.rows3_tail = 0;
         if (ix->d_rows2) (void)hipFree(ix->d_rows2);
-        if (ix->d_rows3) (void)hipFree(ix->d_rows3);
-        ix->d_rows2 = nullptr;
-        ix->d_rows3 = nullptr;
+            ix->d_rows2 = nullptr;
         ix->ahead_auto = 0;                                  // the caller's choice from here on
         if (value == 0) return MOVI_OK;
         if (!ahead_eligible(ix)) return fail(MOVI_ERR_ARG, "look-ahead rows serve PML walks on *-thresholds indexes only");
-        return value == 1 ? build_ahead(ix, nullptr, false) : build_chain(ix, nullptr);
+        return build_ahead(ix, nullptr, false);
     }
     if (!strcmp(key, "ftab_k")) {                            // count query's interval table: 0 = none, K in [1, 12] = build it now
         if (value < 0 || value > 12) return fail(MOVI_ERR_ARG, "ftab_k must be in [0, 12]");
@@ -1100,15 +1083,13 @@ int movi_index_info(const movi_index_t *ix, const char *key, double *value) {
     const double kmer = ix->d_kmer ? (double)((size_t)16 << (2 * ix->dev.kmer_k)) : 0.0;
     const double ftab = ix->d_ftab ? (double)((size_t)16 << (2 * ix->dev.ftab_k)) : 0.0;
     const double ahead = ix->d_rows2 ? (double)ahead_rows_bytes(ix->desc.r) : 0.0;
-    const double chain = ix->d_rows3 ? (double)chain_rows_bytes(ix->desc.r) : 0.0;
     const double ckpt = ix->d_ckpt ? (double)((ix->desc.r >> kPrefixShift) + 2) * 8.0 : 0.0;
     if (!strcmp(key, "rows_bytes")) *value = rows;
     else if (!strcmp(key, "kmer_bytes")) *value = kmer;
     else if (!strcmp(key, "ftab_bytes")) *value = ftab;
     else if (!strcmp(key, "ahead_rows_bytes")) *value = ahead;
-    else if (!strcmp(key, "chain_rows_bytes")) *value = chain;
     else if (!strcmp(key, "ckpt_bytes")) *value = ckpt;
-    else if (!strcmp(key, "derived_bytes")) *value = kmer + ftab + ahead + chain + ckpt;
+    else if (!strcmp(key, "derived_bytes")) *value = kmer + ftab + ahead + ckpt;
     else if (!strcmp(key, "ahead_no_ff")) *value = ix->ahead_tallied ? ix->ahead_no_ff : -1.0;
     else return fail(MOVI_ERR_ARG, std::string("unknown info key: ") + key);
     return MOVI_OK;

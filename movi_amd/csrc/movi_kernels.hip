@@ -740,7 +740,7 @@ __device__ __forceinline__ uint2 win_sel(const uint2 (&w)[4], uint32_t q) {
 // new read when they have finished one.  Without it a wavefront runs
 // until its slowest lane is done, and reads differ a lot: a substitution costs a read about a dozen repositions (the walk
 // needs ~15 bases to fall back into step with the text), so on 1 M x 150 bp with 1 % substitutions only 68 % of the lane
-// iterations do work on the look-ahead rows and 61 % on the chain rows (tools/iter_model.c predicts both figures).
+// iterations do work on the look-ahead rows (tools/iter_model.c predicts the figure).
 //   * Reads come from ONE global ticket counter (DevStats::ticket) in chunks of 16 consecutive reads -- an atomic per chunk --
 //     into a POOL of upcoming reads per wavefront: 64 slots across the lanes (read number, where its bases start, its
 //     length), consumed in ring order by whichever lanes are idle at a switch (ds_bpermute).  A chunk takes two switches to
@@ -766,10 +766,10 @@ __device__ __forceinline__ uint2 win_sel(const uint2 (&w)[4], uint32_t q) {
 // mismatch, a fast-forward at j, the read's end, an invalid entry) takes the one-base step it always took.
 // (Fetching only the entry of the row the window was fetched FOR -- 8 bytes instead of 32 -- misses the steps that end on a
 // neighbour after a fast-forward or scan: 68.5 against 74.4 Gbases/s on c2, 54.1 against 62.8 on the random table.)
-// AHD = 2 (chain rows, DevIndex::rows3): the same with entries that look TWO rows ahead -- 16 bytes per row: what the walk
-// would read at j = id(row) and at j2 = id(j), and where it goes from there (j3 = id(j2)) -- so that up to THREE bases are
-// resolved per gather while the read follows the text (tools/iter_model.c: lane iterations per base 0.68 -> 0.56 on c2).
-// Line = the 4 rows of an aligned window (32 bytes) + their 4 entries (64 bytes): six 16-byte loads of ONE 128-byte line.
+// (Round 4 built the same with entries that look TWO rows ahead -- "chain rows", 16 bytes per row, up to three bases per gather:
+// bit-exact, lane iterations per base 0.68 -> 0.56 on c2 as tools/iter_model.c predicts, and 10 % SLOWER there, 38 % slower on a
+// 113 M-row real BWT: twice the bytes, six loads and 18 % more instructions per iteration.  Measured with PMC
+// (profiles/r04_chain_rows.txt) and removed again; the code is in the history: commit b8d3f4e.)
 // PSH = 1 (round 4: "pair-shared gathers"; staged kernels, plain and look-ahead rows): the two lanes of a pair (2i, 2i + 1) fetch
 // their windows TOGETHER -- one load instruction brings the even lane's window (each lane one 16-byte half), the next the odd
 // lane's, and one exchange across the pair (DPP quad_perm) hands every lane the half it is missing.  Same loads per lane,
@@ -799,8 +799,9 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
     static_assert(SEG == 0 || (CLS == 0 && REFILL == 0), "segments: plain PML, no refill");
     static_assert(REFILL == 0 || (STG == 1 && HA < 0), "lane refill: staged reads, window-parallel advance");
     static_assert(AHD == 0 || (STG == 1 && HA < 0), "look-ahead rows: staged reads, window-parallel advance");
-    static_assert(PSH == 0 || (STG == 1 && REFILL == 0 && AHD != 2), "pair-shared gathers: staged kernels without refill, plain or look-ahead rows");
-    static_assert(RING == 0 || (STG == 1 && REFILL == 0 && AHD != 2), "PMLs out through the LDS ring: staged kernels without refill, plain or look-ahead rows");
+    static_assert(AHD == 0 || AHD == 1, "plain rows or look-ahead rows");
+    static_assert(PSH == 0 || (STG == 1 && REFILL == 0), "pair-shared gathers: staged kernels without refill");
+    static_assert(RING == 0 || (STG == 1 && REFILL == 0), "PMLs out through the LDS ring: staged kernels without refill");
     enum : uint32_t { sFF = 0, sDown = 1, sUp = 2, sDone = 3 };
     __shared__ uint8_t s_code[256];
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = ix.code_of[i];
@@ -858,7 +859,6 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
         return wb < wb_last ? wb : wb_last;
     };
     uint2 ahw[4];                                         // AHD: the look-ahead entries of the window's four rows ...
-    uint2 ahv[4];                                         // ... AHD == 2: and their second halves (the row after the next)
     uint4 raw[4];                                         // PSH: what this lane loaded for its pair (rows: 0, 1; entries: 2, 3), assembled at the loop's top
     const uint32_t odd_lane = threadIdx.x & 1u;
     auto fetch = [&](IdxT nd, bool act, uint2 (&w)[4]) {
@@ -882,22 +882,7 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
             if (AHD) __builtin_memcpy(&raw[3], po + 64u, 16);
             return;
         }
-        if (AHD == 2) {                                   // chain rows: line = the window's 4 rows + their 4 16-byte entries
-            const IdxT wb = nd & ~(IdxT)3;
-            const bool body = wb < wb_last;
-            uint64_t at = body ? (uint64_t)(wb >> 2) * 128u : ix.rows3_tail;
-            if (!act) at = 0;
-            load_window<MODE>(ix.rows3 + at, 0, w);
-            uint4 e0, e1, e2, e3;
-            __builtin_memcpy(&e0, ix.rows3 + at + 32u, 16);
-            __builtin_memcpy(&e1, ix.rows3 + at + 48u, 16);
-            __builtin_memcpy(&e2, ix.rows3 + at + 64u, 16);
-            __builtin_memcpy(&e3, ix.rows3 + at + 80u, 16);
-            ahw[0] = make_uint2(e0.x, e0.y); ahv[0] = make_uint2(e0.z, e0.w);
-            ahw[1] = make_uint2(e1.x, e1.y); ahv[1] = make_uint2(e1.z, e1.w);
-            ahw[2] = make_uint2(e2.x, e2.y); ahv[2] = make_uint2(e2.z, e2.w);
-            ahw[3] = make_uint2(e3.x, e3.y); ahv[3] = make_uint2(e3.z, e3.w);
-        } else if (AHD) {                                 // line = 8 rows + their 8 entries; the last window has a line of its own
+        if (AHD) {                                        // line = 8 rows + their 8 entries; the last window has a line of its own
             const IdxT wb = nd & ~(IdxT)3;
             const bool body = wb < wb_last;
             uint64_t at = body ? (uint64_t)(wb >> 3) * 128u + (uint64_t)((uint32_t)wb & 4u) * 8u : ix.rows2_tail;
@@ -1071,9 +1056,8 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
         }
     }
     // AHD: the code of the base after the current one (beyond the read's end: never looked at)
-    uint32_t a1 = 0xFFu, a2 = 0xFFu;
+    uint32_t a1 = 0xFFu;
     if (AHD) a1 = staged_code(k + 1);
-    if (AHD == 2) a2 = staged_code(k + 2);
     uint2 w[4];
     fetch(need, st != sDone, w);
 
@@ -1184,7 +1168,6 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
                 if (fresh) {
                     a = staged_code(k);
                     if (AHD) a1 = staged_code(k + 1);
-                    if (AHD == 2) a2 = staged_code(k + 2);
                     fetch(need, true, w);
                 }
             }
@@ -1315,7 +1298,7 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
         uint32_t st_next = (emit & (lf ^ 1u)) ? sDone : (lf ? sFF : (far ? (down ? sDown : sUp) : st));
         // AHD: the base after this one, resolved at the LF target from the look-ahead entry (read_processor.cpp:188-238 with
         // match and no fast-forward: ml + 1, then LF_move again) -- the target row itself is never fetched
-        uint32_t dbl = 0, lf2 = 0, off1 = 0, tri = 0, lf3 = 0, off2 = 0;
+        uint32_t dbl = 0, lf2 = 0, off1 = 0;
         IdxT j2 = 0;
         if (AHD) {
             const uint2 ah = win_sel(ahw, qf);            // the entry of the row the base was resolved at
@@ -1327,16 +1310,6 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
             j2 = (IdxT)((uint64_t)ah.x | ((uint64_t)((ah.y >> 25) & 15u) << 32));
             need_next = dbl ? (lf2 ? j2 : need) : need_next;
             st_next = dbl ? (lf2 ? sFF : sDone) : st_next;
-            if (AHD == 2) {                               // ... and the base after that one at j2 = id(j), the same way
-                const uint2 av = win_sel(ahv, qf);
-                const uint32_t n2 = av.y & 0x7FFu, c2 = (av.y >> 22) & 7u;
-                tri = lf2 & (av.y >> 31) & (uint32_t)(a2 == c2) & (uint32_t)(off_e + off1 < n2);
-                lf3 = tri & (uint32_t)(k + 3 != len);
-                off2 = (av.y >> 11) & 0x7FFu;
-                const IdxT j3 = (IdxT)((uint64_t)av.x | ((uint64_t)((av.y >> 25) & 15u) << 32));
-                need_next = tri ? (lf3 ? j3 : need) : need_next;
-                st_next = tri ? (lf3 ? sFF : sDone) : st_next;
-            }
         }
         // The reference's throws: practically never, so which one it was is sorted out off the common path (as one
         // select ladder over need_next / st_next it cost ~45 instructions between a window's arrival and the next
@@ -1420,12 +1393,6 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
                 if (SEG == 1) seg_record(j, off);
                 off += lf2 ? off1 : 0u;
                 emit_pml(ml);
-                if (AHD == 2 && tri) {                    // the third: matched at j2 = id(j), no fast-forward
-                    ml += 1;
-                    if (SEG == 1) seg_record((uint64_t)j2, off);
-                    off += lf3 ? off2 : 0u;
-                    emit_pml(ml);
-                }
             }
             if (STG && CLS != 2 && ring && ((k ^ k_in) & 16u) != 0u) ring_flush(k_in);   // a group of 16 PMLs is complete
             if (STG) {
@@ -1451,12 +1418,10 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
             // a lane whose next bases lie beyond its staged stretch: the whole wavefront stages again, each lane from its own step
             const uint32_t ahead_of = k - kbase;          // < 2^31: k >= kbase always
             const uint32_t out_of = (uint32_t)(st != sDone) &
-                                    ((uint32_t)(ahead_of >= stage_cap) | ((uint32_t)(ahead_of + 1u >= stage_cap) & (uint32_t)(k + 1 < len)) |
-                                     ((uint32_t)(AHD == 2) & (uint32_t)(ahead_of + 2u >= stage_cap) & (uint32_t)(k + 2 < len)));
+                                    ((uint32_t)(ahead_of >= stage_cap) | ((uint32_t)(ahead_of + 1u >= stage_cap) & (uint32_t)(k + 1 < len)));
             if (wave_any(out_of != 0u)) stage_from(k, st != sDone);
             a = staged_code(k - kbase);
             if (AHD) a1 = staged_code(k + 1 - kbase);
-            if (AHD == 2) a2 = staged_code(k + 2 - kbase);
         }
         // ONE load site per prefetch register set and iteration, behind every read of those registers: a second site (or
         // a temporary that the register allocator parks in them where they are dead) costs an `s_waitcnt` on a load
@@ -1620,49 +1585,6 @@ __global__ __launch_bounds__(256) void ahead_rows_kernel(DevIndex ix, uint8_t *_
     }
 }
 
-// Chain rows (DevIndex::rows3): line L = rows 4L .. 4L+3 (32 bytes) + their four 16-byte entries (64 bytes; the last 32
-// bytes of the line are unused); one more line at byte `tail` holds rows r-4 .. r-1.  Entry of row i, with j = id(i),
-// j2 = id(j), j3 = id(j2): first half = the look-ahead rows' entry (what the walk reads at j, and j2), second half the
-// same one row further (what it reads at j2, and j3); a half is invalid (0) when one of the rows it names is not a row.
-template <int MODE>
-__global__ __launch_bounds__(256) void chain_rows_kernel(DevIndex ix, uint8_t *__restrict__ out, uint64_t tail, unsigned long long *tally) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool in = i < ix.r;
-    const uint2 row = in ? load_row<MODE>(ix.rows, i) : make_uint2(0u, 0u);
-    const uint64_t j = in ? row_id<MODE>(row, i, ix) : ix.r;
-    uint4 e = make_uint4(0u, 0u, 0u, 0u);
-    uint32_t no_ff = 0;
-    if (j < ix.r) {
-        const uint2 rj = load_row<MODE>(ix.rows, j);
-        const uint64_t j2 = row_id<MODE>(rj, j, ix);
-        const uint32_t nj = row_n<MODE>(rj), ni = row_n<MODE>(row), oi = row_off<MODE>(row);
-        no_ff = nj > oi ? (nj - oi < ni ? nj - oi : ni) : 0u;
-        if (j2 < ix.r) {
-            const uint2 h1 = ahead_half(rj, j2);
-            e.x = h1.x; e.y = h1.y;
-            const uint2 rj2 = load_row<MODE>(ix.rows, j2);
-            const uint64_t j3 = row_id<MODE>(rj2, j2, ix);
-            if (j3 < ix.r) {
-                const uint2 h2 = ahead_half(rj2, j3);
-                e.z = h2.x; e.w = h2.y;
-            }
-        }
-    }
-    if (tally) {
-        const uint32_t a = wave_sum(no_ff), b = wave_sum(in ? row_n<MODE>(row) : 0u);
-        if ((threadIdx.x & 63) == 0) tally_add(tally, a, b);
-    }
-    if (!in) return;
-    uint8_t *line = out + (i >> 2) * 128u;
-    __builtin_memcpy(line + (i & 3u) * 8u, &row, 8);
-    __builtin_memcpy(line + 32u + (i & 3u) * 16u, &e, 16);
-    if (i + 4 >= ix.r) {
-        uint8_t *tl = out + tail;
-        __builtin_memcpy(tl + (i + 4 - ix.r) * 8u, &row, 8);
-        __builtin_memcpy(tl + 32u + (i + 4 - ix.r) * 16u, &e, 16);
-    }
-}
-
 // The tally alone, over every `stride`-th row: what share of the table's BWT positions reaches its LF target without a
 // fast-forward -- the statistic that says whether look-ahead entries will be used (launch policy, movi_abi.hip) -- without
 // building anything (two gathers per sampled row).
@@ -1691,7 +1613,6 @@ hipError_t tally_no_ff_share(int kmode, const DevIndex &ix, uint64_t stride, uns
 }
 
 uint64_t ahead_rows_bytes(uint64_t r) { return ((r + 7) / 8 + 1) * 128; }
-uint64_t chain_rows_bytes(uint64_t r) { return ((r + 3) / 4 + 1) * 128; }
 
 hipError_t build_ahead_rows(int kmode, const DevIndex &ix, uint8_t *d_rows2, uint64_t *tail, hipStream_t stream, unsigned long long *d_tally) {
     if (!d_rows2 || !tail || ix.r < 8 || (ix.r >> 36) != 0 || kmode != 6) return hipErrorInvalidValue;
@@ -1701,17 +1622,6 @@ hipError_t build_ahead_rows(int kmode, const DevIndex &ix, uint8_t *d_rows2, uin
     const uint64_t blocks = (ix.r + 255) / 256;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     hipLaunchKernelGGL(ahead_rows_kernel<6>, dim3((unsigned)blocks), dim3(256), 0, stream, ix, d_rows2, *tail, d_tally);
-    return hipGetLastError();
-}
-
-hipError_t build_chain_rows(int kmode, const DevIndex &ix, uint8_t *d_rows3, uint64_t *tail, hipStream_t stream, unsigned long long *d_tally) {
-    if (!d_rows3 || !tail || ix.r < 8 || (ix.r >> 36) != 0 || kmode != 6) return hipErrorInvalidValue;
-    *tail = ((ix.r + 3) / 4) * 128;
-    hipError_t e = hipMemsetAsync(d_rows3, 0, chain_rows_bytes(ix.r), stream);
-    if (e != hipSuccess) return e;
-    const uint64_t blocks = (ix.r + 255) / 256;
-    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(chain_rows_kernel<6>, dim3((unsigned)blocks), dim3(256), 0, stream, ix, d_rows3, *tail, d_tally);
     return hipGetLastError();
 }
 
@@ -2124,7 +2034,7 @@ static hipError_t launch_pml_segmented(const DevIndex &ix, const uint8_t *d_base
         int wpc = cfg.waves_per_cu;
         if (wpc < 0) wpc = 0;
         if (cfg.waves_per_cu == 0 && big_batch_cap && lanes > (uint64_t)cfg.num_cus * 64u * 18u)
-            wpc = ((ix.rows2 != nullptr || ix.rows3 != nullptr) && cfg.stage_reads != 0) ? kCapWavesAhead : kCapWaves;
+            wpc = (ix.rows2 != nullptr && cfg.stage_reads != 0) ? kCapWavesAhead : kCapWaves;
         if (wpc > 0 && wpc < 32) return ((163840u / (unsigned)wpc) & ~1023u) - 1024u;
         return 0;
     };
@@ -2135,8 +2045,7 @@ static hipError_t launch_pml_segmented(const DevIndex &ix, const uint8_t *d_base
     DevIndex ixl = ix;
     ixl.inwin = cfg.inwin ? 1u : 0u;
     // (pair-shared gathers on tables beyond the TLBs' reach: launch_pml's rule)
-    const bool seg_pair = ix.rows3 == nullptr &&
-                          (cfg.pair_loads > 0 || (cfg.pair_loads < 0 && ix.r * (ix.rows2 != nullptr ? 16ull : 8ull) >= kPairLoadBytes));
+    const bool seg_pair = (cfg.pair_loads > 0 || (cfg.pair_loads < 0 && ix.r * (ix.rows2 != nullptr ? 16ull : 8ull) >= kPairLoadBytes));
     size_t dyn_lds = 0;
     bool seg_ring = false;
     auto stage_for = [&](uint64_t lanes) {
@@ -2146,7 +2055,7 @@ static hipError_t launch_pml_segmented(const DevIndex &ix, const uint8_t *d_base
             if (wn <= 18) dyn_lds = std::min<size_t>(21504 + (cfg.out_ring != 0 ? kOutRingBytes : 0u), ((163840u / (unsigned)(wn + std::max<uint64_t>(2, wn / 4))) & ~1023u) - 1024u);
         }
         // (segments are long reads: their PMLs leave through the ring in LDS where the block has room for it -- launch_pml)
-        const size_t ring_b = (cfg.out_ring != 0 && cfg.stage_reads != 0 && ix.rows3 == nullptr && dyn_lds >= kOutRingBytes + 96u * 64u) ? kOutRingBytes : 0;
+        const size_t ring_b = (cfg.out_ring != 0 && cfg.stage_reads != 0 && dyn_lds >= kOutRingBytes + 96u * 64u) ? kOutRingBytes : 0;
         const uint32_t cap = (uint32_t)std::min<size_t>(1024, ((dyn_lds - ring_b) / 64) & ~(size_t)15);
         ixl.stage_lds = (cfg.stage_reads != 0 && cap >= 96) ? cap : 0u;
         seg_ring = ring_b != 0 && ixl.stage_lds != 0u;
@@ -2169,7 +2078,6 @@ static hipError_t launch_pml_segmented(const DevIndex &ix, const uint8_t *d_base
         else if (seg_ring) MOVI_LAUNCH_SEG(SEGV, LANES, pml_kernel_flatp<6, T, -1, 0, S, 0, SEGV, 1, 0, 0, 1>);               \
         else if (seg_pair && ixl.stage_lds != 0u && ix.rows2 != nullptr) MOVI_LAUNCH_SEG(SEGV, LANES, pml_kernel_flatp<6, T, -1, 0, S, 0, SEGV, 1, 1, 1>); \
         else if (seg_pair && ixl.stage_lds != 0u) MOVI_LAUNCH_SEG(SEGV, LANES, pml_kernel_flatp<6, T, -1, 0, S, 0, SEGV, 1, 0, 1>); \
-        else if (ixl.stage_lds != 0u && ix.rows3 != nullptr) MOVI_LAUNCH_SEG(SEGV, LANES, pml_kernel_flatp<6, T, -1, 0, S, 0, SEGV, 1, 2>); \
         else if (ixl.stage_lds != 0u && ix.rows2 != nullptr) MOVI_LAUNCH_SEG(SEGV, LANES, pml_kernel_flatp<6, T, -1, 0, S, 0, SEGV, 1, 1>); \
         else if (ixl.stage_lds != 0u) MOVI_LAUNCH_SEG(SEGV, LANES, pml_kernel_flatp<6, T, -1, 0, S, 0, SEGV, 1, 0>);  \
         else MOVI_LAUNCH_SEG(SEGV, LANES, pml_kernel_flatp<6, T, -1, 0, S, 0, SEGV>);                                 \
@@ -2185,7 +2093,7 @@ static hipError_t launch_pml_segmented(const DevIndex &ix, const uint8_t *d_base
     } while (0)
     MOVI_LAUNCH_SEG_T(1, max_seg);
     if (info) {                                           // the dominant kernel: K1
-        const int stg = ixl.stage_lds != 0u ? 1 : 0, ahd = (stg && ix.rows3 != nullptr) ? 2 : ((stg && ix.rows2 != nullptr) ? 1 : 0);
+        const int stg = ixl.stage_lds != 0u ? 1 : 0, ahd = (stg && ix.rows2 != nullptr) ? 1 : 0;
         snprintf(info->kernel, sizeof(info->kernel), "pml_kernel_flatp<6, %s, -1, 0, %d, 0, 1, %d, %d%s>",
                  ix.idx32 ? "unsigned int" : "unsigned long", ix.sep ? 1 : 0, stg, ahd,
                  seg_ring ? (seg_pair ? ", 1, 1" : ", 0, 1") : ((seg_pair && stg) ? ", 1" : ""));
@@ -2278,12 +2186,11 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     if (wpc < 0) wpc = 0;
     if (v == 13 && (cfg.stage_reads == 0 || bt != 64)) { v = 10; wp = true; }         // lane refill: staged one-wavefront blocks only
     const bool stage_ok = cfg.stage_reads != 0 && bt == 64 && ((v == 10 && wp) || v == 13);   // the staged kernels: one-wavefront blocks of the default walk
-    const bool chain_ok = stage_ok && ix.rows3 != nullptr;                              // ... on the chain rows (three bases per gather) where they exist
-    const bool ahead_ok = stage_ok && !chain_ok && ix.rows2 != nullptr;                 // ... or on the look-ahead rows (two)
+    const bool ahead_ok = stage_ok && ix.rows2 != nullptr;                              // ... on the look-ahead rows where they exist
     if (cfg.waves_per_cu == 0 && (cfg.pml_variant < 0 || cfg.pml_variant == 14) && v == 10 && big_batch)
-        wpc = (ahead_ok || chain_ok) ? kCapWavesAhead : kCapWaves;                   // the auto policy above
+        wpc = ahead_ok ? kCapWavesAhead : kCapWaves;                                 // the auto policy above
     if (v == 13) {
-        wpc = cfg.waves_per_cu > 0 ? cfg.waves_per_cu : ((ahead_ok || chain_ok) ? kCapWavesAhead : kCapWaves);
+        wpc = cfg.waves_per_cu > 0 ? cfg.waves_per_cu : (ahead_ok ? kCapWavesAhead : kCapWaves);
         if (cfg.refill_blocks == 0) refill_blocks = (uint64_t)cfg.num_cus * (uint64_t)wpc;
         const uint64_t resident = (refill_blocks * 64u + bt - 1) / bt;
         if (blocks > resident) blocks = resident;
@@ -2308,7 +2215,7 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     // PMLs out through a ring in LDS (ix.out_ring; the kernel has the numbers): launches of long reads -- few wavefronts, each
     // one's own instruction stream most of an iteration -- where the block's LDS holds the ring beside 96 staged bases.
     // cfg.out_ring: -1 = this policy, 0 / 1 = never / wherever it fits (A/B).
-    const bool ring_wanted = stage_ok && v == 10 && !chain_ok && (cfg.out_ring > 0 || (cfg.out_ring < 0 && n_bases / n_reads >= kOutRingReadLen));
+    const bool ring_wanted = stage_ok && v == 10 && (cfg.out_ring > 0 || (cfg.out_ring < 0 && n_bases / n_reads >= kOutRingReadLen));
     if (stage_ok && wpc == 0) {
         const uint64_t wn = (blocks + (uint64_t)cfg.num_cus - 1) / (uint64_t)cfg.num_cus;      // wavefronts per CU of this launch
         // (room for a quarter more: the dispatcher does not deal the blocks out evenly, and a CU that may hold no more than the
@@ -2324,7 +2231,6 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     ixl.inwin = cfg.inwin ? 1u : 0u;
     if (v == 13 && ixl.stage_lds == 0u) return hipErrorInvalidValue;                  // (cannot happen: the refill launch is capped)
     const bool use_ahead = ahead_ok && ixl.stage_lds != 0u;
-    const bool use_chain = chain_ok && ixl.stage_lds != 0u;
     // pair-shared gathers (pml_kernel_flatp<..., PSH = 1>): the staged default walk on the plain or the look-ahead rows
     // Where: on tables beyond the reach of the per-CU TLBs (~2 GB), where a lane's two (four) 16-byte loads are as many
     // translation requests and the L2 TLB's request rate bounds the walk -- real BWT of 226 M rows on the look-ahead rows (3.6 GB
@@ -2332,7 +2238,7 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     // copy (16 GB); below that the exchange costs about what the merged accesses give (random 25 / 50 / 100 M rows +4 / +5 / -2 %,
     // real 113 M rows +1.5 %, c2 -2.5 %, c3 -9 %: profiles/r04_pair_shared_gathers.txt).  "pair_loads" 1 / 0 forces it.
     const uint64_t walked_bytes = ix.r * (use_ahead ? 16ull : 8ull);
-    const bool use_pair = (cfg.pair_loads > 0 || (cfg.pair_loads < 0 && walked_bytes >= kPairLoadBytes)) && ixl.stage_lds != 0u && v == 10 && !use_chain;
+    const bool use_pair = (cfg.pair_loads > 0 || (cfg.pair_loads < 0 && walked_bytes >= kPairLoadBytes)) && ixl.stage_lds != 0u && v == 10;
     const SegArgs no_seg;
     // every kernel that is handed more than 64 KiB of dynamic LDS must opt in first
 #define MOVI_SEG_0
@@ -2382,9 +2288,6 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
         } else if (use_pair && R == 0) {                                                                    \
             if (ix.idx32) MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint32_t, -1, C, S, 0, 0, 1, 0, 1>);        \
             else MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint64_t, -1, C, S, 0, 0, 1, 0, 1>);                 \
-        } else if (use_chain) {                                                                             \
-            if (ix.idx32) MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint32_t, -1, C, S, R, 0, 1, 2>);           \
-            else MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint64_t, -1, C, S, R, 0, 1, 2>);                    \
         } else if (use_ahead) {                                                                             \
             if (ix.idx32) MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint32_t, -1, C, S, R, 0, 1, 1>);           \
             else MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint64_t, -1, C, S, R, 0, 1, 1>);                    \
@@ -2423,12 +2326,12 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
         if (v == 0 || v == 1) snprintf(info->kernel, sizeof(info->kernel), "pml_kernel<6, %d, %d>", v, v == 0 ? 0 : cm);
         else if (v == 7) snprintf(info->kernel, sizeof(info->kernel), "pml_kernel_flat<6, %s, 0>", it);
         else snprintf(info->kernel, sizeof(info->kernel), "pml_kernel_flatp<6, %s, %d, %d, %d, %d, 0, %d, %d%s>", it, (wp || v == 13) ? -1 : MOVI_HA, cm,
-                      ix.sep ? 1 : 0, v == 13 ? 1 : 0, ixl.stage_lds ? 1 : 0, use_ahead ? 1 : (use_chain ? 2 : 0),
+                      ix.sep ? 1 : 0, v == 13 ? 1 : 0, ixl.stage_lds ? 1 : 0, use_ahead ? 1 : 0,
                       use_ring ? (use_pair ? ", 1, 1" : ", 0, 1") : (use_pair ? ", 1" : ""));
         info->variant = (v == 10 && wp) ? 14 : v;
         info->block_threads = bt; info->waves_per_cu = wpc; info->segmented = 0; info->idx64 = ix.idx32 ? 0 : 1;
         info->staged = (int)ixl.stage_lds;
-        info->ahead = use_ahead ? 1 : (use_chain ? 2 : 0);
+        info->ahead = use_ahead ? 1 : 0;
     }
 #undef MOVI_LAUNCH_PML
 #undef MOVI_LAUNCH_K

@@ -73,13 +73,6 @@ struct DevIndex {
     // ratio, which the builder tallies, when the copy is built by itself; a caller who asks for the copy gets it for both.
     uint32_t rows2_count;
     uint32_t pad3_;
-    // Chain rows ("ahead_rows" 2; nullptr = none): look-ahead entries that reach TWO rows ahead, 16 bytes per row -- up to
-    // three bases per gather.  Line L = rows 4L .. 4L+3 (32 bytes) + their 4 entries (64 bytes; 32 bytes unused); one more
-    // line at byte rows3_tail holds rows r-4 .. r-1.  Entry of row i, with j = id(i), j2 = id(j), j3 = id(j2):
-    // x, y = the look-ahead rows' entry (j2; n, offset, c of row j; valid); z, w = the same one row further (j3; n, offset,
-    // c of row j2; valid).
-    const uint8_t *rows3;
-    uint64_t rows3_tail;
 };
 
 // Device counters of one query call.
@@ -137,7 +130,7 @@ struct LaunchInfo {
     int waves_per_cu = 0;    // resident-wavefront cap applied (0 = none)
     int segmented = 0;       // 1 = the segment-parallel plan ran (K1 + stitch + finalize around the named kernel)
     int idx64 = 0;           // 1 = the 64-bit row-index instantiation
-    int ahead = 0;           // 1 = the walk ran on the look-ahead rows (two bases per gather where the next base matches), 2 = on the chain rows (three)
+    int ahead = 0;           // 1 = the walk ran on the look-ahead rows (two bases per gather where the next base matches)
     int staged = 0;          // > 0: every lane keeps the next `staged` bases of its read in LDS (pml_kernel_flatp<..., STG = 1>)
 };
 
@@ -246,9 +239,6 @@ hipError_t build_ahead_rows(int kmode, const DevIndex &ix, uint8_t *d_rows2, uin
 // d_tally[0] / d_tally[1] (two zeroed counters) = share of the BWT positions of every stride-th row that reach their LF
 // target without a fast-forward (no_ff_share_kernel): the launch policy's statistic, without building the copy
 hipError_t tally_no_ff_share(int kmode, const DevIndex &ix, uint64_t stride, unsigned long long *d_tally, hipStream_t stream);
-uint64_t chain_rows_bytes(uint64_t r);
-hipError_t build_chain_rows(int kmode, const DevIndex &ix, uint8_t *d_rows3, uint64_t *tail, hipStream_t stream,
-                            unsigned long long *d_tally = nullptr);   // DevIndex::rows3 (chain_rows_kernel)
 
 // Fills the 4^K entries of the count query's interval table (DevIndex::ftab); mode = resident layout (6 or 3).
 hipError_t build_ftab(int mode, const DevIndex &ix, uint32_t K, uint4 *d_table, hipStream_t stream);

@@ -59,7 +59,7 @@ long to_int(const std::string &name, const std::string &v) {
 std::string usage() {
     return "movi (MI355X engine): movi query -i DIR -r FILE|- [-o PREFIX] [--pml|--zml|--count] [--classify] [--filter [-v]]\n"
            "                      [--stdout] [--no-output] [-s N] [-t N] [-n] [--reverse] [--bin-width N]\n"
-           "                      [--ignore-illegal-chars 1] [--gpus N] [--device D] [--seg-len N] [--ahead-rows 0|1|2] [--verbose]\n"
+           "                      [--ignore-illegal-chars 1] [--gpus N] [--device D] [--seg-len N] [--ahead-rows 0|1] [--verbose]\n"
            "       movi view --bpf FILE\n"
            "       movi null -i DIR [--gen-reads -f REF.fasta] [--pml|--zml]\n"
            "       movi build -i DIR -f REF.fasta [--type regular-thresholds|blocked-thresholds|sampled-thresholds|regular|blocked|sampled]\n"
@@ -156,7 +156,7 @@ Options parse_args(int argc, char **argv) {
         if (has("seg-len")) o.seg_len = (long)to_int("seg-len", val("seg-len"));
         if (has("ahead-rows")) {
             o.ahead_rows = (int)to_int("ahead-rows", val("ahead-rows"));
-            if (o.ahead_rows < 0 || o.ahead_rows > 2) throw UsageError("--ahead-rows must be 0, 1 or 2");
+            if (o.ahead_rows < 0 || o.ahead_rows > 1) throw UsageError("--ahead-rows must be 0 or 1");
         }
         if (o.gpus < 1) throw UsageError("--gpus must be >= 1");
         if (o.classify && o.count) throw UsageError("--classify needs PML or ZML queries");

@@ -40,7 +40,7 @@ struct Options {
     bool logs = false;            // --logs: <prefix>.costs / .scans / .fastforwards next to the PML output (src/utils.cpp:376-382)
     bool gpus_given = false;      //   (given explicitly, N == 1 included: the index goes through the RCCL replication path)
     int device = 0;               // extension: --device D
-    int ahead_rows = -1;          // extension: --ahead-rows 0|1|2: look-ahead rows off / built for any table / as fat rows (default: the engine's size policy)
+    int ahead_rows = -1;          // extension: --ahead-rows 0|1: look-ahead rows off / built whatever the device's free memory says (default: the engine's policy)
     long seg_len = -1;            // extension: --seg-len N: segment length of the segment-parallel long-read walk (0 = off; default: the engine's)
 
     // derived predicates, same names as the reference (movi_options.hpp:57-58)

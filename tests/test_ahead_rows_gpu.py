@@ -187,9 +187,7 @@ def test_ahead_rows_refused_where_they_cannot_serve(built_lib):
     with pytest.raises(movi_amd.MoviError):
         gpu.set_option("ahead_rows", 1)
     with pytest.raises(movi_amd.MoviError):
-        gpu.set_option("ahead_rows", 2)
-    with pytest.raises(movi_amd.MoviError):
-        gpu.set_option("ahead_rows", 3)
+        gpu.set_option("ahead_rows", 2)                  # (round 4's chain rows: measured slower, removed)
     gpu.close()
 
 
@@ -361,69 +359,11 @@ def test_count_on_the_look_ahead_rows_separators_and_corrupt_rows(built_lib, gol
     gpu.close()
 
 
-@pytest.mark.parametrize("mode", [6, 8])
-def test_chain_rows_vs_oracle(built_lib, golden_image, mode):
-    """"ahead_rows" 2: chain rows -- look-ahead entries that reach TWO rows ahead (16 bytes per row next to the 4-row window:
-    up to three bases per gather).  Same answers, error bytes and counters as the oracle and the plain rows, for every read
-    length, both index widths, with bins."""
-    import movi_amd
-    from oracle.oracle import Oracle
-    img = golden_image(mode)
-    gpu, cpu = movi_amd.MoveIndex.from_image(img), Oracle(img)
-    ref = _ref()
-    bases, offs = _big_batch(ref, np.random.default_rng(9950 + mode))
-    exp, ff, sc = cpu.pml_batch(bases, offs, threads=8)
-    gpu.set_option("ahead_rows", 0)
-    out0, st0 = gpu.query_pml_packed(bases, offs)
-    bins0 = gpu.classify_packed(bases, offs, 40, 4)
-    gpu.set_option("ahead_rows", 2)
-    for K in (0, 12):
-        gpu.set_option("kmer_k", K)
-        for idx64 in (0, 1):
-            gpu.set_option("idx64", idx64)
-            out, st = gpu.query_pml_packed(bases, offs)
-            li = gpu.last_launch()
-            assert li["ahead"] == 2 and li["kernel"].endswith(", 0, 0, 1, 2>") and li["idx64"] == idx64
-            assert (out == exp).all(), (mode, K, idx64)
-            assert (st.fast_forwards, st.scans, st.repositions, st.errors) == (ff, sc, st0.repositions, 0), (mode, K, idx64)
-        gpu.set_option("idx64", 0)
-        bins = gpu.classify_packed(bases, offs, 40, 4)
-        assert all((x == y).all() for x, y in zip(bins, bins0)), K
-    # long reads rolling through the staged stretch, a small (uncapped) batch
-    small = mutated_reads(np.random.default_rng(9960), ref, 300, 1, 3000)
-    sb, so = pack(small)
-    sexp, sff, ssc = cpu.pml_batch(sb, so, threads=4)
-    gpu.set_option("seg_len", 0)
-    sout, sst = gpu.query_pml_packed(sb, so)
-    assert gpu.last_launch()["ahead"] == 2 and (sout == sexp).all() and (sst.fast_forwards, sst.scans) == (sff, ssc)
-    gpu.close()
-    cpu.close()
-
-
-@pytest.mark.parametrize("cut", [0, 1, 2, 3])
-def test_chain_rows_last_window(built_lib, cut):
-    import movi_amd
-    from oracle import build_index as B
-    from oracle.oracle import Oracle
-    ref = _ref()
-    extra = {1: 0, 5: 7, 0: 14, 2: 28, 6: 42, 3: 49, 7: 105, 4: 112}[cut]
-    img = B.build_index_from_seqs([ref[: 30000 + extra]], 6)
-    gpu, cpu = movi_amd.MoveIndex.from_image(img), Oracle(img)
-    bases, offs = _big_batch(ref[:30000], np.random.default_rng(9970 + cut), max_len=64, n_long=3)
-    exp, ff, sc = cpu.pml_batch(bases, offs, threads=8)
-    gpu.set_option("ahead_rows", 2)
-    out, st = gpu.query_pml_packed(bases, offs)
-    assert gpu.last_launch()["ahead"] == 2
-    assert (out == exp).all() and (st.fast_forwards, st.scans, st.errors) == (ff, sc, 0)
-    gpu.close()
-    cpu.close()
-
-
 @pytest.mark.parametrize("kind", ["repeats", "poly", "two_letters", "random", "tandem", "with_n_runs"])
 def test_look_ahead_on_odd_texts(built_lib, kind):
     """Texts that stress what the entries encode: long runs (offsets near the 11-bit limit, rows split at 2047), two-letter
     alphabets (no top-of-walk table), tandem repeats (every base rides along for thousands of steps), random text (almost
-    none does).  PML (line copy and chain rows) and count against the oracle, small batches (uncapped, staged launches)."""
+    none does).  PML and count against the oracle, small batches (uncapped, staged launches)."""
     import movi_amd
     from oracle import build_index as B
     from oracle.oracle import Oracle
@@ -452,7 +392,7 @@ def test_look_ahead_on_odd_texts(built_lib, kind):
     exp, ff, sc = cpu.pml_batch(bases, offs, threads=8)
     em, ec = cpu.count_batch(bases, offs, threads=8)
     gpu.set_option("seg_len", 0)
-    for ahead in (0, 1, 2):
+    for ahead in (0, 1):
         gpu.set_option("ahead_rows", ahead)
         out, st = gpu.query_pml_packed(bases, offs)
         assert gpu.last_launch()["ahead"] == ahead and gpu.last_launch()["staged"] > 0
@@ -559,20 +499,20 @@ def test_pml_out_ring_vs_oracle(built_lib, golden_image, mode):
     bins0 = gpu.classify_packed(bases, offs, 40, 4)
     lbins0 = gpu.classify_packed(lb, lo, 150, 8)
     gpu.set_option("out_ring", 1)
-    for ahead, pair, variant in ((1, 0, -1), (0, 0, -1), (1, 1, -1), (0, 1, -1), (1, 0, 13), (2, 0, -1)):
+    for ahead, pair, variant in ((1, 0, -1), (0, 0, -1), (1, 1, -1), (0, 1, -1), (1, 0, 13)):
         gpu.set_option("ahead_rows", ahead)
         gpu.set_option("pair_loads", pair)
         gpu.set_option("pml_variant", variant)
         out, st = gpu.query_pml_packed(bases, offs)
         li = gpu.last_launch()
-        ringed = variant == -1 and ahead < 2              # (lane refill and the chain rows keep the packer)
+        ringed = variant == -1                            # (lane refill keeps the packer)
         assert li["ahead"] == ahead and li["staged"] == (CAP if ahead == 0 else CAP_AHEAD) - (64 if ringed else 0), li   # the ring takes 4 KB of the block's LDS
         assert li["kernel"].endswith(", %d, 1>" % pair) == ringed, li
         assert (out == exp).all(), (mode, ahead, pair, variant)
         assert (st.fast_forwards, st.scans, st.errors) == (ff, sc, 0), (mode, ahead, pair, variant)
         rout, rst = gpu.query_pml_packed(rb, ro)
         assert (rout == rexp).all() and (rst.fast_forwards, rst.scans) == (rff, rsc), (mode, ahead, pair, variant)
-        if variant == -1 and ahead < 2:
+        if variant == -1:
             bins = gpu.classify_packed(bases, offs, 40, 4)
             assert all((x == y).all() for x, y in zip(bins, bins0)), (ahead, pair)
     gpu.set_option("pml_variant", -1)

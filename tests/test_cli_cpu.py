@@ -48,7 +48,7 @@ def test_argument_errors(movi_bin):
     r = run(["query", "-i", "x", "-r", "y", "--seg-len", "abc"])
     assert r.returncode == 1 and b"failed to parse for option 'seg-len'" in r.stderr
     r = run(["query", "-i", "x", "-r", "y", "--ahead-rows", "3"])
-    assert r.returncode == 1 and b"--ahead-rows must be 0, 1 or 2" in r.stderr
+    assert r.returncode == 1 and b"--ahead-rows must be 0 or 1" in r.stderr
     r = run(["query", "-i", "x", "-r", "y", "--mmap", "--seg-len", "64"])
     assert r.returncode == 1 and b"not supported" not in r.stderr and b"Error parsing command line" not in r.stderr
 
