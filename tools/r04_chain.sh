@@ -1,4 +1,5 @@
 #!/bin/bash
+# (historical: "ahead_rows" 2 exists only up to the commit before "chain rows removed"; kept as the record of how profiles/r04_chain_rows.txt was produced)
 # round 4: chain rows (look-ahead entries two rows deep, "ahead_rows" 2) against the look-ahead rows ("ahead_rows" 1) on c2
 cd "$(dirname "$0")/.." || exit 1
 export MOVI_BENCH_CACHE=$PWD/.bench_cache
