@@ -16,7 +16,7 @@ PY
 {
 run a0 --ahead-rows 0
 run a1 --ahead-rows 1
-run a2 --ahead-rows 2
+run a2 --ahead-rows 2    # (historical: chain rows, removed since)
 run auto
 run a1_v13 --ahead-rows 1 --variant 13
 run a0_w0 --ahead-rows 0 --waves-per-cu 0

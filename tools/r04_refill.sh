@@ -18,7 +18,7 @@ PY
 }
 {
 run a1_v14 --ahead-rows 1
-run a2_v14 --ahead-rows 2
+run a2_v14 --ahead-rows 2    # (historical: chain rows, removed since)
 for a in 1 2; do
   for b in 8 16 32; do run a${a}_v13_b$b --ahead-rows $a --variant 13 --opt refill_batch=$b; done
   for w in 7 11 13; do run a${a}_v13_b16_w$w --ahead-rows $a --variant 13 --opt refill_batch=16 --waves-per-cu $w; done
