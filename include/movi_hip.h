@@ -223,7 +223,7 @@ int movi_last_stats(movi_index_t *ix, void *stream, movi_query_stats_t *stats);
  * asks instead of assuming (bench.py's roofline.kernel). */
 typedef struct movi_launch_info {
     char kernel[96];
-    int32_t variant;                  /* PML: 0, 1, 7, 10, 13, 14 ("pml_variant"); ZML: 0, 1; count: 0             */
+    int32_t variant;                  /* PML: 0, 1, 14 ("pml_variant"); ZML: 0, 1; count: 0                        */
     int32_t block_threads;
     int32_t waves_per_cu;             /* cap on resident wavefronts per CU that was applied (0 = none)             */
     int32_t segmented;                /* 1 = the segment-parallel plan ran around that kernel                       */
@@ -304,13 +304,12 @@ int movi_host_unregister(void *p);
 /* ---- tuning ------------------------------------------------------------------- */
 
 /* Kernel variant / launch knobs, for A/B measurement (bench.py --variant).
- * Unknown keys return MOVI_ERR_ARG.  Keys: "pml_variant" (-1 = auto by batch size, 0 = first
- * kernel, 1 = base-synchronous packed I/O, 7 = flat lane state machine, 10 = 7 + row window,
- * software-pipelined, 13 = 10 as a persistent grid whose lanes take a new read when they finish one, 14 = 10 with all
- * in-window fast-forward / scan steps resolved at once: what auto selects),
- * "refill_blocks" (variant 13: wavefronts in the persistent grid, 0 = CUs x waves per CU),
+ * Unknown keys return MOVI_ERR_ARG.  Keys: "pml_variant" (-1 = auto, 0 = first kernel (the one `--logs` runs on),
+ * 1 = base-synchronous packed I/O, 14 = the lane state machine over row windows, software-pipelined: what auto
+ * selects.  7 / 10 / 13 -- the row-at-a-time state machine, the hop-by-hop advance, lane refill -- were A/B variants that
+ * never earned a default and were removed in round 5: DESIGN.md section 3),
  * "block_threads" (0 = auto, 64, 128, 192 or 256: the kernels' launch bound), "waves_per_cu"
- * (0 = uncapped; variant 13: 0 = its default of 9), "idx64" (1 = run the kernel instantiations for
+ * (0 = the launch policy's cap, else at most this many wavefronts resident per CU), "idx64" (1 = run the kernel instantiations for
  * tables of 2^32 rows and more, whatever the size: a test hook), "release_scratch" (any value: frees the
  * device staging buffers that the *_host entry points keep, grow-only, across calls), "pipe_chunk_bases"
  * (bases per chunk of the overlapped host path, 0 = its own policy: a test hook), "seg_len" (PML: batches whose mean
@@ -340,10 +339,7 @@ int movi_host_unregister(void *p);
  * a sample of the table says its search will use them.  1 = build now,
  * 0 = none (freed).  (Entries two rows deep -- "chain rows", three bases per gather -- were built in round 4, bit-exact, and
  * measured 10 - 38 % slower: profiles/r04_chain_rows.txt; removed),
- * "pml_variant" 13 (lane refill: the default walk as a persistent grid whose idle lanes take the next reads of a pool fed from
- * one global ticket counter, "refill_batch" lanes at a time (default 16): 82 - 87 % of the lane iterations do work instead of
- * 72 %, at the same speed -- the walk is bound by the fabric's line rate, not by its lanes -- so it is selectable, not the
- * default), "inwin_repo" (1, the default: a reposition whose target run is one of the row window's other rows is resolved in
+ * "inwin_repo" (1, the default: a reposition whose target run is one of the row window's other rows is resolved in
  * the iteration that sees the mismatch; 0 = off: A/B),
  * "pair_loads" (pair-shared gathers: the two lanes of a pair fetch each row window together, each lane one 16-byte half of
  * it in the same load instruction, halves exchanged through DPP -- one translation request and one 32-byte access where a

@@ -866,8 +866,8 @@ int movi_index_device_rows(const movi_index_t *ix, const void **d_rows, size_t *
 int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
     if (!ix || !key) return fail(MOVI_ERR_ARG, "NULL argument");
     if (!strcmp(key, "pml_variant")) {
-        if (value != -1 && value != 0 && value != 1 && value != 7 && value != 10 && value != 13 && value != 14)
-            return fail(MOVI_ERR_ARG, "pml_variant must be -1 (auto), 0, 1, 7, 10, 13 or 14");
+        if (value != -1 && value != 0 && value != 1 && value != 14)
+            return fail(MOVI_ERR_ARG, "pml_variant must be -1 (auto), 0, 1 or 14");
         ix->cfg.pml_variant = (int)value;
         return MOVI_OK;
     }
@@ -886,16 +886,6 @@ int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
         if (value != 0 && value != 64 && value != 128 && value != 192 && value != 256)
             return fail(MOVI_ERR_ARG, "block_threads must be 0 (auto), 64, 128, 192 or 256");
         ix->cfg.block_threads = (int)value;
-        return MOVI_OK;
-    }
-    if (!strcmp(key, "refill_blocks")) {                     // test hook / tuning: persistent grid of the lane-refill kernel
-        if (value < 0 || value > (1 << 20)) return fail(MOVI_ERR_ARG, "refill_blocks must be in [0, 2^20]");
-        ix->cfg.refill_blocks = (int)value;
-        return MOVI_OK;
-    }
-    if (!strcmp(key, "refill_batch")) {                      // tuning: idle lanes of a lane-refill wavefront switch when this many wait
-        if (value < 0 || value > 64) return fail(MOVI_ERR_ARG, "refill_batch must be in [0, 64]");
-        ix->cfg.refill_batch = (int)value;
         return MOVI_OK;
     }
     if (!strcmp(key, "classify_fused")) {                    // -1 auto, 1: vector + bins in one kernel, 0: walk, then a streaming pass over the vectors

@@ -13,7 +13,7 @@
 // Shape of the work: integer pointer chasing.  One wavefront lane owns one read;
 // every step is one dependent random 8-byte (mode 6) / 6-byte (mode 8) row gather
 // plus a few sequential neighbour rows.  No MFMA: there is no contraction here.
-#include "movi_kernels.hpp"
+#include "movi_device.hpp"
 
 #include <hipcub/hipcub.hpp>
 
@@ -21,367 +21,6 @@
 #include <cstdio>
 
 namespace movi {
-
-
-// ------------------------------------------------------------------ row decode
-// A row is carried in registers as two dwords.
-//   mode 6 (8 B, include/move_row.hpp:131-142; masks move_row_configs.hpp:34-51):
-//     x = id[31:0]            y = n16 | offset16 << 16
-//     n16:  [10:0] n, [11] thr1, [12] thr2, [15:13] c
-//     off16:[10:0] offset, [11] thr0, [15:12] id[35:32]
-//   mode 8 (6 B, move_row.hpp:128-142; masks move_row_configs.hpp:76-104):
-//     x = id16 | n16 << 16    y = offset16
-//     n16:  [9:0] n, [15:10] id[21:16]
-//     off16:[9:0] offset, [12:10] c, [13] thr0, [14] thr1, [15] thr2
-//   mode 7 (3 B, sampled-thresholds; move_row.hpp:122-127, masks move_row_configs.hpp:120-136): no id in the row
-//     x = n8 | offset8 << 8 | cbyte << 16     cbyte: [0] offset bit 8, [1] n bit 8, [4:2] c, [5] thr0, [6] thr1, [7] thr2
-//     (widened to one dword per row at upload, then expanded to mode-6 rows: expand_sampled_kernel)
-template <int MODE>
-__device__ __forceinline__ uint2 load_row(const uint8_t *rows, uint64_t i) {
-    if (MODE == 6 || MODE == 3) {
-        return *reinterpret_cast<const uint2 *>(rows + i * 8);
-    } else if (MODE == 8 || MODE == 2) {
-        // 6-byte rows: ONE unaligned 8-byte load of the bytes [6i-2, 6i+6) (for row 0: [0, 8)), shifted into
-        // place -- never reads outside the table -- instead of three 2-byte loads
-        const uint32_t lead = i ? 2u : 0u;
-        unsigned long long v;
-        __builtin_memcpy(&v, rows + i * 6 - lead, 8);
-        v >>= 8u * lead;
-        return make_uint2((uint32_t)v, (uint32_t)(v >> 32) & 0xFFFFu);
-    } else {
-        // 3-byte rows, widened to one aligned dword per row when the index is uploaded (widen_rows_kernel); only
-        // expand_sampled_kernel reads them: queries run on the mode-6 rows it writes
-        return make_uint2(*reinterpret_cast<const uint32_t *>(rows + i * 4), 0u);
-    }
-}
-template <int MODE> __device__ __forceinline__ uint32_t row_n(uint2 w) {
-    if (MODE == 5) return (w.x & 0xFFu) | (((w.x >> 18) & 3u) << 8);      // sampled, no thresholds: configs :107-118
-    if (MODE == 7) return (w.x & 0xFFu) | (((w.x >> 17) & 1u) << 8);
-    if (MODE == 3) return w.y & 0xFFFu;                                    // regular, no thresholds: 12 bits (configs :21-32)
-    return MODE == 6 ? (w.y & 0x7FFu) : ((w.x >> 16) & 0x3FFu);           // modes 8 and 2: 10 bits
-}
-template <int MODE> __device__ __forceinline__ uint32_t row_off(uint2 w) {
-    if (MODE == 5) return ((w.x >> 8) & 0xFFu) | (((w.x >> 16) & 3u) << 8);
-    if (MODE == 7) return ((w.x >> 8) & 0xFFu) | (((w.x >> 16) & 1u) << 8);
-    if (MODE == 3) return (w.y >> 16) & 0xFFFu;
-    return MODE == 6 ? ((w.y >> 16) & 0x7FFu) : (w.y & 0x3FFu);
-}
-template <int MODE> __device__ __forceinline__ uint32_t row_c(uint2 w) {
-    if (MODE == 5) return (w.x >> 20) & 15u;
-    if (MODE == 7) return (w.x >> 18) & 7u;
-    return (MODE == 6 || MODE == 3) ? ((w.y >> 13) & 7u) : ((w.y >> 10) & 7u);
-}
-// threshold bit k in {0,1,2} (MoveRow::get_threshold, move_row.hpp:304-347)
-template <int MODE> __device__ __forceinline__ uint32_t row_thr(uint2 w, uint32_t k) {
-    if (MODE == 5 || MODE == 3 || MODE == 2) return 0u;   // no thresholds in these index types
-    if (MODE == 6) {
-        // k=0 -> off16 bit 11 (y bit 27); k=1 -> n16 bit 11; k=2 -> n16 bit 12
-        uint32_t sh = (k == 0) ? 27u : (10u + k);
-        return (w.y >> sh) & 1u;
-    } else if (MODE == 8) {
-        return (w.y >> (13u + k)) & 1u;
-    } else {
-        return (w.x >> (21u + k)) & 1u;
-    }
-}
-// MoveStructure::get_id, src/move_structure.cpp:91-102
-template <int MODE>
-__device__ __forceinline__ uint64_t row_id(uint2 w, uint64_t idx, const DevIndex &ix) {
-    static_assert(MODE == 6 || MODE == 8 || MODE == 3 || MODE == 2, "the sampled modes have no id in the row: tally_id()");
-    if (MODE == 6 || MODE == 3) {
-        return (uint64_t)w.x | ((uint64_t)(w.y >> 28) << 32);
-    } else {
-        uint64_t bid = (uint64_t)(w.x & 0xFFFFu) | ((uint64_t)(w.x >> 26) << 16);
-        if (MODE == 2) bid |= (uint64_t)((w.y >> 14) & 3u) << 22;          // two more id bits in `offset` (move_row.hpp:274-280)
-        if (idx == ix.end_bwt_idx) return bid;
-        uint32_t c = row_c<MODE>(w);
-        const uint64_t blk = ix.block_shift != 0xFFFFFFFFu ? (idx >> ix.block_shift) : idx / ix.block_size;
-        const uint64_t slot = (uint64_t)c * ix.n_blocks + blk;
-        const uint32_t base = ix.id_blocks[slot];                           // check point of (character, block)
-        return bid + (uint64_t)base + ix.first_runs[c + 1];
-    }
-}
-
-// ---- reposition_thresholds, src/move_structure_query.cpp:513-601: which threshold applies.
-// Read base code a and row code c are alphamap values: 0..3, or 1..4 on a separators index (code 0 = '%').
-// Slot of a DNA row: alphamap_3[c - sep][a - sep] (src/utils.cpp:5-8) = (a - sep) - (a > c) for a != c.
-__device__ __forceinline__ uint32_t thr_slot(uint32_t sep, uint32_t a, uint32_t c) {
-    return (a - sep - (uint32_t)(a > c)) & 3u;
-}
-// end_bwt_idx_thresholds[a - sep] (:534-535).  The four values are clamped to 32 bits once per kernel (offsets
-// are < 2^11, so `off >= t` is unchanged) and picked with selects: written as a ladder over the kernel-argument
-// array, hipcc turned the pick into an indexed LOAD from the kernarg segment plus `s_waitcnt vmcnt(0)` -- one
-// more memory round trip in every iteration of the latency-bound state machine (c3: 39.6 -> 32.2 Gbases/s).
-struct EndThr { uint32_t e0, e1, e2, e3; };
-__device__ __forceinline__ EndThr end_thresholds(const DevIndex &ix) {
-    auto clamp = [](uint64_t v) { return v > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)v; };
-    return EndThr{clamp(ix.end_thr[0]), clamp(ix.end_thr[1]), clamp(ix.end_thr[2]), clamp(ix.end_thr[3])};
-}
-__device__ __forceinline__ uint32_t end_threshold(uint32_t sep, const EndThr &e, uint32_t a) {
-    const uint32_t k = a - sep;
-    const uint32_t lo = (k & 1u) ? e.e1 : e.e0, hi = (k & 1u) ? e.e3 : e.e2;
-    return (k & 2u) ? hi : lo;
-}
-// separators_thresholds[separators_thresholds_map[idx]].values[a - 1] (:540-541) for a row of the separator;
-// a missing key reads entry 0 of an empty-initialised map in the reference: 0 here.  Rare path: binary search.
-__device__ __forceinline__ uint32_t separator_threshold(const DevIndex &ix, uint64_t idx, uint32_t a) {
-    uint32_t lo = 0, hi = ix.n_sep;
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (ix.sep_rows[mid] < idx) lo = mid + 1; else hi = mid;
-    }
-    if (lo >= ix.n_sep || ix.sep_rows[lo] != idx) return 0u;
-    const uint2 v = ix.sep_vals[lo];
-    const uint32_t k = a - 1u;
-    const uint32_t w = (k & 2u) ? v.y : v.x;
-    return (k & 1u) ? (w >> 16) : (w & 0xFFFFu);
-}
-
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-    for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s, 64);
-    return v;
-}
-
-// Per-read error codes (the reference throws in each of these cases).
-enum : uint32_t {
-    kErrNone = 0,
-    kErrIdRange = 1,       // LF destination >= r              (move_structure.cpp:63-65)
-    kErrFastForward = 2,   // >= 65535 fast-forward steps      (move_structure.cpp:72-75)
-    kErrNoRunBelow = 3,    // reposition_down found no run     (move_structure_query.cpp:582-586)
-    kErrNoRunAbove = 4,    // reposition_up found no run       (move_structure_query.cpp:594-598)
-};
-
-// Control-flow note (ROCm 7.2 / gfx950): every data-dependent loop below is written
-// as a WAVE-UNIFORM loop (`while (__any(pred))`) with a predicated body and all
-// loop-carried state in integer VGPRs.  A divergent `while` whose result is consumed
-// as a boolean after the loop (`found = (c == a)`) was miscompiled by hipcc: the exit
-// compare of the LAST iteration (vcc) was reused for lanes that had left the loop
-// earlier.  Uniform loops are also the cheaper form on a 64-wide wavefront.
-__device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
-
-// MoveStructure::get_id for the sampled ("tally") mode 7, src/move_structure.cpp:104-283, forward branch (the
-// reference fixes forward_direciton = true, :146): the row holds no id; every tally_cp rows the id of the latest
-// run of each character is kept.  The id of row idx = the id stored at the next checkpoint for idx's character,
-// walked back over the destination rows by the BWT positions of that character between idx and the stored run.
-// Wave-uniform loops, predicated per lane (see the control-flow note above).  Returns r on the reference's throws.
-// IdxT = uint32_t when the table has fewer than 2^32 rows.  Rows are read four at a time as the aligned 16-byte
-// group that holds them (the widened table has 16 bytes of slack, so the last group may be read whole).
-template <int TM, typename IdxT>                          // TM: 7 = sampled-thresholds rows, 5 = sampled rows
-__device__ __forceinline__ uint64_t tally_id_t(const DevIndex &ix, bool live, uint64_t idx64, uint2 row) {
-    const IdxT idx = (IdxT)idx64, r = (IdxT)ix.r, end_row = (IdxT)ix.end_bwt_idx;
-    const uint32_t ci = row_c<TM>(row);
-    const IdxT cp = (IdxT)ix.tally_cp;
-    IdxT id = live ? 0 : idx;                            // lanes that take no step keep their row (callers store the result)
-    uint32_t walk = 0;                                   // 1 while the lane still scans / walks
-    uint32_t bad = 0;                                    // one of the reference's throws (or an id >= r): returns r
-    IdxT next_cp = idx;
-    uint32_t rows_until = 0;                             // <= tally_cp rows of <= 511 positions
-    uint32_t last_n = 0, last_off = 0, last_is_idx = 1;
-    if (live && idx != end_row) {                        // '$' goes to row 0 (:106-108)
-        const IdxT ta = idx / cp;
-        const uint64_t *tl = ix.tally + (uint64_t)ci * ix.tally_len;
-        uint64_t raw;
-        if (idx == r - 1) raw = tl[ix.tally_len - 1];    // :114-117
-        else if (ta * cp == idx) raw = tl[ta];           // :121-124
-        else {
-            next_cp = (ta + 1) * cp;
-            if (next_cp >= r) next_cp = r - 1;           // :137-139
-            raw = tl[ta + 1];
-            walk = 1;
-        }
-        id = (IdxT)raw;
-        if (raw >= ix.r) { bad = 1; walk = 0; }          // LF_move throws on it (move_structure.cpp:63-65)
-    }
-    // rows of idx's character in [idx, next_cp) (:168-174) -- row idx itself is one of them -- and the row at
-    // next_cp, group by group
-    uint32_t scan = walk;
-    IdxT g = idx & ~(IdxT)3;
-    uint32_t wn = 0;                                     // the row at next_cp
-    while (wave_any(scan != 0u)) {
-        if (scan) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(ix.rows + (uint64_t)g * 4);
-            const uint32_t x[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const uint2 w = make_uint2(x[t], 0u);
-                const IdxT it = g + (IdxT)t;
-                if (it >= idx && it < next_cp && it != end_row && row_c<TM>(w) == ci) {
-                    rows_until += row_n<TM>(w);
-                    last_n = row_n<TM>(w);
-                    last_off = row_off<TM>(w);
-                    last_is_idx = (it == idx) ? 1u : 0u;
-                }
-                wn = (it == next_cp) ? x[t] : wn;
-            }
-            g += 4;
-            scan = (g <= next_cp) ? 1u : 0u;
-        }
-    }
-    // the stored id is idx's own (:178-180), or the walk starts at row id with `offset` positions to spare (:186-209)
-    uint32_t back = 0, offset = 0;
-    if (walk) {
-        const uint2 wnr = make_uint2(wn, 0u);
-        const uint32_t same = (next_cp != end_row && row_c<TM>(wnr) == ci) ? 1u : 0u;
-        if (!(last_is_idx && !same)) {
-            offset = row_off<TM>(wnr);
-            if (!same) { rows_until -= last_n; offset = last_off; }       // :194-197
-            back = 1;
-        }
-    }
-    // :200-219: row id first (offset >= n(id) throws; offset >= rows_until: id it is; else rows_until -= offset + 1
-    // and on to id - 1), then `while (rows_until) { rows_until >= n(id) ? (rows_until -= n(id), id--) : rows_until = 0 }`
-    uint32_t first = 1;
-    while (wave_any(back != 0u)) {
-        if (back) {
-            const IdxT gb = id & ~(IdxT)3;
-            const uint4 v = *reinterpret_cast<const uint4 *>(ix.rows + (uint64_t)gb * 4);
-            const uint32_t x[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int t = 3; t >= 0; --t) {
-                const uint32_t nrow = row_n<TM>(make_uint2(x[t], 0u));
-                if (back && (gb + (IdxT)t) == id) {
-                    uint32_t step_down = 0;
-                    if (first) {
-                        first = 0;
-                        if (offset >= nrow) { bad = 1; back = 0; }
-                        else if (offset >= rows_until) back = 0;
-                        else { rows_until -= offset + 1; step_down = 1; }
-                    } else if (rows_until == 0) {
-                        back = 0;
-                    } else if (rows_until >= nrow) {
-                        rows_until -= nrow;
-                        step_down = 1;
-                    } else {
-                        rows_until = 0;
-                        back = 0;
-                    }
-                    if (step_down) { if (id == 0) { bad = 1; back = 0; } else id -= 1; }
-                }
-            }
-        }
-    }
-    return bad ? ix.r : (uint64_t)id;
-}
-template <int TM>
-__device__ __forceinline__ uint64_t tally_id(const DevIndex &ix, bool live, uint64_t idx, uint2 row) {
-    if (ix.idx32) return tally_id_t<TM, uint32_t>(ix, live, idx, row);           // wave-uniform choice
-    return tally_id_t<TM, uint64_t>(ix, live, idx, row);
-}
-
-// LF_move + fast_forward.  On entry `row` is rows[idx]; on exit it is the row of
-// the new idx.  `live` lanes take the step; returns a kErr* code (0 = ok) per lane.
-template <int MODE>
-__device__ __forceinline__ uint32_t lf_step(const DevIndex &ix, bool live, uint64_t &idx, uint32_t &off,
-                                            uint2 &row, uint32_t &ff_total) {
-    uint32_t errc = kErrNone;
-    uint64_t j = idx;
-    uint32_t n = 0, ff = 0;
-    uint32_t going = 0;
-    if (live) {
-        j = row_id<MODE>(row, idx, ix);
-        if (j >= ix.r) {                                // move_structure.cpp:63-65
-            errc = kErrIdRange;
-            j = idx;
-        } else {
-            off += row_off<MODE>(row);
-            row = load_row<MODE>(ix.rows, j);           // THE dependent random gather
-            n = row_n<MODE>(row);
-            going = (j < ix.r - 1 && off >= n) ? 1u : 0u;
-        }
-    }
-    // fast_forward :524-545: the next row sits in the line the gather just brought in (L2 hit)
-    while (wave_any(going != 0u)) {
-        if (going) {
-            const uint64_t jj = j + 1;
-            const uint2 w = load_row<MODE>(ix.rows, jj < ix.r ? jj : ix.r - 1);
-            off -= n;
-            j += 1;
-            ff += 1;
-            row = w;
-            n = row_n<MODE>(row);
-            going = (j < ix.r - 1 && off >= n && ff < 65535u) ? 1u : 0u;
-        }
-    }
-    if (ff >= 65535u) errc = kErrFastForward;           // move_structure.cpp:72-75
-    ff_total += ff;
-    idx = j;
-    return errc;
-}
-
-// Two independent LF_moves (the two ends of a backward-search interval) advanced together:
-// both gathers are issued before either result is needed and the two fast-forwards share one
-// wave-uniform loop, so an interval step costs the trips of ONE walker.
-template <int MODE>
-__device__ __forceinline__ uint32_t lf_step2(const DevIndex &ix, bool live, uint64_t &ia, uint32_t &offa, uint2 &rowa,
-                                             uint64_t &ib, uint32_t &offb, uint2 &rowb, uint32_t &ff_total) {
-    uint32_t errc = kErrNone;
-    uint64_t ja = ia, jb = ib;
-    uint32_t na = 0, nb = 0, ffa = 0, ffb = 0, ga = 0, gb = 0;
-    if (live) {
-        ja = row_id<MODE>(rowa, ia, ix);
-        jb = row_id<MODE>(rowb, ib, ix);
-        if (ja >= ix.r || jb >= ix.r) {                 // move_structure.cpp:63-65
-            errc = kErrIdRange;
-            ja = ia; jb = ib;
-        } else {
-            offa += row_off<MODE>(rowa);
-            offb += row_off<MODE>(rowb);
-            rowa = load_row<MODE>(ix.rows, ja);
-            rowb = load_row<MODE>(ix.rows, jb);
-            na = row_n<MODE>(rowa);
-            nb = row_n<MODE>(rowb);
-            ga = (ja < ix.r - 1 && offa >= na) ? 1u : 0u;
-            gb = (jb < ix.r - 1 && offb >= nb) ? 1u : 0u;
-        }
-    }
-    while (wave_any((ga | gb) != 0u)) {                 // fast_forward :524-545, both walkers
-        uint2 wa = rowa, wb = rowb;
-        if (ga) wa = load_row<MODE>(ix.rows, ja + 1);
-        if (gb) wb = load_row<MODE>(ix.rows, jb + 1);
-        if (ga) {
-            offa -= na; ja += 1; ffa += 1; rowa = wa; na = row_n<MODE>(rowa);
-            ga = (ja < ix.r - 1 && offa >= na && ffa < 65535u) ? 1u : 0u;
-        }
-        if (gb) {
-            offb -= nb; jb += 1; ffb += 1; rowb = wb; nb = row_n<MODE>(rowb);
-            gb = (jb < ix.r - 1 && offb >= nb && ffb < 65535u) ? 1u : 0u;
-        }
-    }
-    if (ffa >= 65535u || ffb >= 65535u) errc = kErrFastForward;   // move_structure.cpp:72-75
-    ff_total += ffa + ffb;
-    ia = ja; ib = jb;
-    return errc;
-}
-
-// Classifier::classify (src/classifier.cpp:99-143) as a running reduction over the values a lane emits:
-// bins of bin_width in emission order, the last bin absorbing a remainder shorter than bin_width.
-// CLS template parameter of the PML kernels: 0 = PML vector only, 1 = vector + bins, 2 = bins only.
-struct ClsState {
-    uint32_t cur = 0, above = 0, below = 0, bin = 0, nb = 1, next_cut = 0;
-    uint64_t sum = 0;
-    __device__ __forceinline__ void init(uint32_t len, uint32_t w) {
-        nb = w ? len / w : 0;
-        if (nb == 0) nb = 1;
-        next_cut = nb > 1 ? w : len;
-    }
-    __device__ __forceinline__ void add(uint32_t val, uint32_t k, uint32_t len, uint32_t w, uint32_t thr) {
-        cur = val > cur ? val : cur;
-        if (k + 1 == next_cut) {
-            above += cur >= thr ? 1u : 0u;
-            below += cur >= thr ? 0u : 1u;
-            sum += cur;
-            cur = 0;
-            bin += 1;
-            next_cut = (bin + 1 < nb) ? next_cut + w : len;
-        }
-    }
-    __device__ __forceinline__ void store(const ClsArgs &c, uint64_t rid, bool failed) const {
-        c.above[rid] = failed ? 0u : above;
-        c.below[rid] = failed ? 0u : below;
-        c.sum_max[rid] = failed ? 0ull : sum;
-    }
-};
 
 // ------------------------------------------------------------------------- PML
 // One lane per read; wave-uniform step loop, predicated per lane.
@@ -553,958 +192,6 @@ __global__ __launch_bounds__(256) void pml_kernel(DevIndex ix, const uint8_t *__
     }
 }
 
-// VARIANT 7 ("flat lane state machine"): the SIMT-friendly form of the walk for batches with few
-// reads.  In variants 0/1 all 64 lanes advance base by base, so every step costs the wave
-// 1 + max_lanes(fast-forwards) + max_lanes(scan rows) dependent memory round trips.  Here each lane
-// runs its own little automaton (states: fast-forwarding to / resolving a base, scanning down,
-// scanning up, done) and every iteration of the wave-uniform loop issues exactly ONE row load per
-// lane for whatever that lane needs next; a lane that needs three extra rows falls three
-// iterations behind its neighbours instead of stalling them.  The first version of this kernel used
-// ordinary nested branches (variant 2, removed: 11-12 % slower -- latency-bound at 1-2 waves per
-// SIMD it spent ~37 % of its wave cycles issuing ~270 instructions per iteration, many of them
-// exec-mask bookkeeping and phi copies); this one is straight-line predicated code: every state
-// update is a select, the only branches guard memory side effects, and the base code of step k
-// is looked up in LDS when k advances -- the lookup then overlaps the next row gather instead of
-// sitting between the row's arrival and the compare.
-// IdxT = uint32_t when the table has fewer than 2^32 rows (half the index arithmetic).
-template <int MODE, typename IdxT, int CLS>
-__global__ __launch_bounds__(256) void pml_kernel_flat(DevIndex ix, const uint8_t *__restrict__ bases,
-                                                       const uint64_t *__restrict__ offs, uint64_t n_reads,
-                                                       uint16_t *__restrict__ out, uint8_t *__restrict__ err,
-                                                       DevStats *stats, const uint32_t *__restrict__ order,
-                                                       ClsArgs cls) {
-    enum : uint32_t { sFF = 0, sDown = 1, sUp = 2, sDone = 3 };
-    __shared__ uint8_t s_code[256];
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = ix.code_of[i];
-    __syncthreads();
-
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t ff_total = 0, scan_total = 0, repo_total = 0, failed = 0;
-    const EndThr ethr = end_thresholds(ix);
-    const bool valid = t < n_reads;
-    const uint64_t rid = (valid && order) ? order[t] : t;
-    const uint64_t beg = valid ? offs[rid] : 0;
-    const uint32_t len = valid ? (uint32_t)(offs[rid + 1] - beg) : 0;   // reads are shorter than 2^32 (checked on the host)
-    const uint8_t *R = bases + beg;
-    uint16_t *O = out + beg;
-    const uint32_t packed_end = len & ~7u;
-    const IdxT r1 = (IdxT)(ix.r - 1), end_row = (IdxT)ix.end_bwt_idx;
-
-    auto load_chunk = [&](uint32_t kk) -> uint64_t {
-        uint64_t v = 0;
-        if (beg + len >= (uint64_t)kk + 8) {
-            __builtin_memcpy(&v, R + len - kk - 8, 8);    // may start before R: still inside `bases`
-        } else {
-            for (uint32_t i = 0; i < len - kk; ++i) v |= (uint64_t)R[len - 1 - kk - i] << (8 * (7 - i));
-        }
-        return v;
-    };
-
-    uint32_t st = len > 0 ? sFF : sDone;
-    IdxT need = r1;                                       // ReadProcessor::reset_process :69-70
-    uint32_t k = 0;
-    uint32_t ml = 0, ff_run = 0;
-    uint32_t off = row_n<MODE>(load_row<MODE>(ix.rows, r1)) - 1;
-    uint64_t rb = st != sDone ? load_chunk(0) : 0;
-    uint32_t a = s_code[(uint32_t)(rb >> 56) & 0xFFu];    // code of the base of step k (k = 0)
-    uint4 pk = make_uint4(0, 0, 0, 0);
-    ClsState cs;
-    if (CLS) cs.init(len, cls.bin_width);
-
-    while (wave_any(st != sDone)) {
-        uint2 row = make_uint2(0, 0);
-        if (st != sDone) row = load_row<MODE>(ix.rows, need);
-        const uint32_t n = row_n<MODE>(row), c = row_c<MODE>(row);
-        // predicates as 0/1 integers combined with & | (no short-circuit control flow)
-        const uint32_t isFF = st == sFF, isDown = st == sDown, isUp = st == sUp;
-        // fast_forward, move_structure.cpp:524-545
-        const uint32_t ffm = isFF & (uint32_t)(need < r1) & (uint32_t)(off >= n);
-        const uint32_t ff_over = ffm & (uint32_t)(ff_run + 1 >= 65535u);  // :72-75
-        const uint32_t resolved = isFF & (ffm ^ 1u);
-        // the base of step k against the row (read_processor.cpp:188-238)
-        const uint32_t illegal = a == 0xFFu, match = c == a;
-        const uint32_t mism = resolved & (illegal ^ 1u) & (match ^ 1u);
-        // reposition_thresholds, src/move_structure_query.cpp:513-601
-        const uint32_t kk = thr_slot(ix.sep, a, c);                       // alphamap_3[c][a]
-        uint32_t thr = row_thr<MODE>(row, kk > 2u ? 2u : kk) ? n : 0u;
-        if (ix.sep) {                                                     // a row of the separator: side table
-            if (mism & (uint32_t)(c == 0u) & (uint32_t)(need != end_row)) thr = separator_threshold(ix, (uint64_t)need, a);
-        }
-        const uint32_t down = (uint32_t)(off >= ((need == end_row) ? end_threshold(ix.sep, ethr, a) : thr));
-        const uint32_t at_last = need >= r1, at_first = need == 0;
-        const uint32_t repo_edge = mism & (down ? at_last : at_first);
-        // reposition_down :211-232 / reposition_up :188-209, one row per iteration
-        const uint32_t scanning = isDown | isUp;
-        const uint32_t hit = scanning & match;
-        const uint32_t scan_edge = scanning & (hit ^ 1u) & (isDown ? at_last : at_first);
-        const uint32_t emit = (resolved & (illegal | match)) | hit;
-        const uint32_t errc = ff_over ? kErrFastForward
-                              : (repo_edge ? (down ? kErrNoRunBelow : kErrNoRunAbove)
-                                 : (scan_edge ? (isDown ? kErrNoRunBelow : kErrNoRunAbove) : kErrNone));
-        // ---- state update, all selects
-        ml = resolved ? (match ? ml + 1 : 0u) : ml;
-        ff_total += resolved ? ff_run : 0u;
-        ff_run += ffm;
-        repo_total += mism;
-        scan_total += scanning;
-        off = ffm ? off - n : (hit ? (isDown ? 0u : n - 1) : off);        // read_processor.cpp:223
-        const uint32_t step_fwd = ffm | (mism & down) | (scanning & (hit ^ 1u) & isDown);
-        const uint32_t step_back = (mism & (down ^ 1u)) | (scanning & (hit ^ 1u) & isUp);
-        IdxT need_next = need + step_fwd - step_back;
-        uint32_t st_next = mism ? (down ? sDown : sUp) : st;
-        if (emit) {
-            const uint32_t val = ml > 65535u ? 65535u : ml;               // MoveQuery::add_ml
-            if (CLS) cs.add(val, k, len, cls.bin_width, cls.thr);
-            if (CLS == 2) {
-                // verdict bins only
-            } else if (k >= packed_end) {
-                O[k] = (uint16_t)val;
-            } else {
-                pk.x = (pk.x >> 16) | (pk.y << 16);
-                pk.y = (pk.y >> 16) | (pk.z << 16);
-                pk.z = (pk.z >> 16) | (pk.w << 16);
-                pk.w = (pk.w >> 16) | (val << 16);
-                if ((k & 7) == 7) __builtin_memcpy(O + (k - 7), &pk, 16);
-            }
-            k += 1;
-            if (k == len) {
-                st_next = sDone;
-            } else {
-                const uint64_t j = row_id<MODE>(row, need, ix);      // LF_move, move_structure.cpp:59-67
-                if (j >= ix.r) {
-                    failed = kErrIdRange;
-                    st_next = sDone;
-                } else {
-                    off += row_off<MODE>(row);
-                    need_next = (IdxT)j;
-                    ff_run = 0;
-                    st_next = sFF;
-                    if ((k & 7) == 0) rb = load_chunk(k);
-                    a = s_code[(uint32_t)(rb >> (8 * (7 - (k & 7)))) & 0xFFu];
-                }
-            }
-        }
-        if (errc) { failed = errc; st_next = sDone; }
-        need = need_next;
-        st = st_next;
-    }
-    if (failed && CLS != 2) {
-        for (uint32_t i = 0; i < len; ++i) O[i] = 0;
-    }
-    if (CLS && valid) cs.store(cls, rid, failed != 0u);
-    if (valid && err) err[rid] = (uint8_t)failed;
-    const uint32_t ffw = wave_sum(ff_total), scw = wave_sum(scan_total), rpw = wave_sum(repo_total),
-                   erw = wave_sum(failed ? 1u : 0u);
-    if ((threadIdx.x & 63) == 0 && stats) {
-        if (ffw) atomicAdd(&stats->fast_forwards, (unsigned long long)ffw);
-        if (scw) atomicAdd(&stats->scans, (unsigned long long)scw);
-        if (rpw) atomicAdd(&stats->repositions, (unsigned long long)rpw);
-        if (erw) atomicAdd(&stats->errors, (unsigned long long)erw);
-    }
-}
-
-template <int MODE>
-__device__ __forceinline__ void load_window(const uint8_t *rows, uint64_t wbase, uint2 (&w)[4]) {
-    static_assert(MODE == 6 || MODE == 3, "queries run on 8-byte regular(-thresholds) rows only (the other types are expanded at upload)");
-    uint4 p0, p1;
-    __builtin_memcpy(&p0, rows + wbase * 8, 16);
-    __builtin_memcpy(&p1, rows + wbase * 8 + 16, 16);
-    w[0] = make_uint2(p0.x, p0.y); w[1] = make_uint2(p0.z, p0.w);
-    w[2] = make_uint2(p1.x, p1.y); w[3] = make_uint2(p1.z, p1.w);
-}
-__device__ __forceinline__ uint2 win_sel(const uint2 (&w)[4], uint32_t q) {
-    const uint2 lo = (q & 1u) ? w[1] : w[0];
-    const uint2 hi = (q & 1u) ? w[3] : w[2];
-    return (q & 2u) ? hi : lo;
-}
-
-// VARIANT 10 ("flat state machine + row window, software-pipelined"; with HA < 0 = variant 14, the default everywhere):
-// variant 7 with
-//   * the 4-row WINDOW around the row it needs fetched instead of the row (32 B / 24 B of the same cache line,
-//     the same single L2 request) and up to HA cheap fast-forward / scan hops taken inside it before the full
-//     automaton step, so most neighbour rows cost no memory round trip (+6 % on the pangenome, +16-19 % on
-//     random tables over variant 7);
-//   * the next window's address computed from the row alone (all selects) and its load issued BEFORE the
-//     step's bookkeeping (PML packing and stores, bins, counters, base decode), which then runs under the
-//     gather's latency; the load is unpredicated and branch-free (the table's last window is pulled back to
-//     rows [r-4, r); finished lanes re-read window 0) -- with a predicated two-path fetch hipcc parked a
-//     `s_waitcnt vmcnt(0)` right behind the load and the overlap was gone;
-//   * read chunks double-buffered, 16 bases per fetch: the 16 bases after the current ones are fetched when a
-//     16-group is entered, so the chunk load (always an L2 miss: its line was evicted long ago) overlaps sixteen row
-//     gathers and costs 1/16 instead of 1/8 line per base; PMLs leave as paired 16-byte stores.
-// Measured (100 k x 10 kbp, Gbases/s, pangenome / random table): unpipelined window kernel (variant 8, removed)
-// 36.4 / 33.6; chunk double-buffering alone 35.1 / 32.4; pipelined HA = 1 / 2 / 3: 40.2 / 39.6 / 38.9 (pangenome),
-// 36.3 / 36.6 / 36.2 (random) -> HA = 2 shipped.  Hops after the step (HC > 0) measured slower and are gone.
-// REFILL = 1 ("lane refill", variant 13; staged kernels only): the same automaton as a PERSISTENT grid of
-// num_cus x waves_per_cu wavefronts (any grid works: blocks that start late find the counter further on) whose lanes take a
-// new read when they have finished one.  Without it a wavefront runs
-// until its slowest lane is done, and reads differ a lot: a substitution costs a read about a dozen repositions (the walk
-// needs ~15 bases to fall back into step with the text), so on 1 M x 150 bp with 1 % substitutions only 68 % of the lane
-// iterations do work on the look-ahead rows (tools/iter_model.c predicts the figure).
-//   * Reads come from ONE global ticket counter (DevStats::ticket) in chunks of 16 consecutive reads -- an atomic per chunk --
-//     into a POOL of upcoming reads per wavefront: 64 slots across the lanes (read number, where its bases start, its
-//     length), consumed in ring order by whichever lanes are idle at a switch (ds_bpermute).  A chunk takes two switches to
-//     arrive -- its ticket is drawn at one, its offsets are requested at the next, they join the pool at the one after -- so
-//     nothing about the pool waits on memory by itself.  (The first version dealt the reads to the wavefronts statically and
-//     let every lane hold its next read: the slowest wavefront ended 9 - 22 % behind the mean, and busy lanes sat on
-//     reservations idle lanes could have used: profiles/r04_lane_refill.txt.)
-//   * Refills come in BATCHES: a switch stages the new read's bases into the lane's LDS stretch and takes its first K
-//     bases from the top-of-walk table -- memory round trips in which the whole wavefront stands still -- so idle lanes
-//     wait until DevIndex::refill_batch of them (or every lane that still has work) can switch together.
-//   * Results of a read (error byte, bins, zero-fill on failure) are written when its lane switches (or at the end).
-// `order` is not supported (longest-first ordering is what refill replaces).
-// SEG (segment-parallel long reads, movi_kernels.hpp): 0 = a lane walks a read; 1 = a lane walks one SEGMENT of a read
-// from the state every read starts in (K1: its "read" is the segment -- bases at seg_in, PMLs to seg_out --, it leaves a
-// checkpoint of its state and counters every 32 bases and its final state, reports an invariant violation in its
-// segment's flag instead of err[] / zero-filling, and adds nothing to the global fast-forward / scan counters: which
-// part of its work belongs to the read's real walk is only known after K2); 2 = whole reads again, but only those in
-// seg.read_fail (K3).
-// AHD (look-ahead rows, DevIndex::rows2; staged kernels only): the window comes from the table's second copy, together
-// with the look-ahead entries of its four rows (the other half of the same 128-byte line).  When the step's emitted base is followed by a base that
-// matches at the LF target j = id(row) without a fast-forward -- known from the entry: c(j), n(j) against the offset --
-// the walk emits that PML as well and goes straight on to id(j): two bases for one gather.  Everything else (a
-// mismatch, a fast-forward at j, the read's end, an invalid entry) takes the one-base step it always took.
-// (Fetching only the entry of the row the window was fetched FOR -- 8 bytes instead of 32 -- misses the steps that end on a
-// neighbour after a fast-forward or scan: 68.5 against 74.4 Gbases/s on c2, 54.1 against 62.8 on the random table.)
-// (Round 4 built the same with entries that look TWO rows ahead -- "chain rows", 16 bytes per row, up to three bases per gather:
-// bit-exact, lane iterations per base 0.68 -> 0.56 on c2 as tools/iter_model.c predicts, and 10 % SLOWER there, 38 % slower on a
-// 113 M-row real BWT: twice the bytes, six loads and 18 % more instructions per iteration.  Measured with PMC
-// (profiles/r04_chain_rows.txt) and removed again; the code is in the history: commit b8d3f4e.)
-// PSH = 1 (round 4: "pair-shared gathers"; staged kernels, plain and look-ahead rows): the two lanes of a pair (2i, 2i + 1) fetch
-// their windows TOGETHER -- one load instruction brings the even lane's window (each lane one 16-byte half), the next the odd
-// lane's, and one exchange across the pair (DPP quad_perm) hands every lane the half it is missing.  Same loads per lane,
-// same bytes -- but the two lanes' requests for adjacent bytes of a page are ONE address translation and ONE 32-byte access,
-// where a lane's two 16-byte loads are two of each: tools/tlb_bench (profiles/r04_pair_shared_gather_microbench.txt), 32-byte
-// window per chain step: 8 GB table 27.3 -> 49.4 G/s (the 8-byte gather rate), 2 GB 44.3 -> 54.8, 134 MB 52.0 -> 59.5.
-__device__ __forceinline__ uint32_t pair_swap(uint32_t v) {      // the other lane's value: lanes 2i <-> 2i + 1
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);   // quad_perm [1, 0, 3, 2]
-}
-// What lanes 2i / 2i+1 loaded as (r1: their half of the EVEN lane's 32 bytes, r2: of the ODD lane's) -> this lane's own 32 bytes
-__device__ __forceinline__ void pair_assemble(uint32_t odd, const uint4 &r1, const uint4 &r2, uint2 (&w)[4]) {
-    // even: first half = own r1, second = the odd lane's r1;  odd: first half = the even lane's r2, second = own r2.
-    // (Every lane makes every exchange -- a DPP read of a lane that sits out a branch returns nothing --, then selects.)
-    const uint32_t give_x = odd ? r1.x : r2.x, give_y = odd ? r1.y : r2.y, give_z = odd ? r1.z : r2.z, give_w = odd ? r1.w : r2.w;
-    const uint32_t got_x = pair_swap(give_x), got_y = pair_swap(give_y), got_z = pair_swap(give_z), got_w = pair_swap(give_w);
-    w[0] = odd ? make_uint2(got_x, got_y) : make_uint2(r1.x, r1.y);
-    w[1] = odd ? make_uint2(got_z, got_w) : make_uint2(r1.z, r1.w);
-    w[2] = odd ? make_uint2(r2.x, r2.y) : make_uint2(got_x, got_y);
-    w[3] = odd ? make_uint2(r2.z, r2.w) : make_uint2(got_z, got_w);
-}
-template <int MODE, typename IdxT, int HA, int CLS, int SEP, int REFILL, int SEG = 0, int STG = 0, int AHD = 0, int PSH = 0, int RING = 0>
-__global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8_t *__restrict__ bases,
-                                                       const uint64_t *__restrict__ offs, uint64_t n_reads,
-                                                       uint16_t *__restrict__ out, uint8_t *__restrict__ err,
-                                                       DevStats *stats, const uint32_t *__restrict__ order,
-                                                       ClsArgs cls, SegArgs seg) {
-    static_assert(SEG == 0 || (CLS == 0 && REFILL == 0), "segments: plain PML, no refill");
-    static_assert(REFILL == 0 || (STG == 1 && HA < 0), "lane refill: staged reads, window-parallel advance");
-    static_assert(AHD == 0 || (STG == 1 && HA < 0), "look-ahead rows: staged reads, window-parallel advance");
-    static_assert(AHD == 0 || AHD == 1, "plain rows or look-ahead rows");
-    static_assert(PSH == 0 || (STG == 1 && REFILL == 0), "pair-shared gathers: staged kernels without refill");
-    static_assert(RING == 0 || (STG == 1 && REFILL == 0), "PMLs out through the LDS ring: staged kernels without refill");
-    enum : uint32_t { sFF = 0, sDown = 1, sUp = 2, sDone = 3 };
-    __shared__ uint8_t s_code[256];
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = ix.code_of[i];
-    __syncthreads();
-
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t ff_total = 0, scan_total = 0, repo_total = 0, failed = 0, err_total = 0;
-    const EndThr ethr = end_thresholds(ix);
-    const IdxT r1 = (IdxT)(ix.r - 1), end_row = (IdxT)ix.end_bwt_idx;
-    const uint2 row_r1 = load_row<MODE>(ix.rows, r1);       // ReadProcessor::reset_process :69-70: every read starts here
-    const uint32_t off0 = row_n<MODE>(row_r1) - 1;
-
-    // ---- the lane's current read
-    const bool valid = !REFILL && (SEG == 1 ? (*seg.go != 0u && t < *seg.n_seg) : (t < n_reads && (SEG != 2 || seg.read_fail[t] != 0)));
-    uint64_t rid = (valid && order && SEG == 0) ? order[t] : t;
-    uint64_t beg = valid ? (SEG == 1 ? seg.seg_in[rid] : offs[rid]) : 0;
-    uint32_t len = valid ? (SEG == 1 ? seg.seg_len[rid] : (uint32_t)(offs[rid + 1] - beg)) : 0;   // reads are shorter than 2^32 (checked on the host)
-    uint64_t obeg = (SEG == 1 && valid) ? seg.seg_out[rid] : beg;   // where the read's (segment's) PMLs go
-    constexpr bool ring = RING != 0;                      // PMLs leave through the ring in LDS (below) instead of the register packer
-    uint32_t packed_end = len & (ring ? ~15u : ~7u);      // PMLs of steps >= this are stored one by one
-
-    // The 16 bases of steps kk .. kk+15 of the read (b, l) are the bytes [b + l - kk - 16, b + l - kk) of `bases`, last
-    // step first: ONE unconditional 16-byte load -- c0 = steps kk .. kk+7 (step kk in the top byte), c1 = steps kk+8 ..
-    // kk+15.  Bytes that belong to steps >= l are never looked at, so a read's last, partial group needs no special
-    // case; it merely reaches back into the previous read.  Only a read that starts in the first 16 bytes of the
-    // batch can reach back past the buffer: its address is clamped to 0 and fix_pair() shifts the bytes into place
-    // WHEN THEY ARE USED.  (Every read-chunk fetch is a 128-byte line from the fabric -- its line is evicted long
-    // before the lane comes back -- so 8-base fetches cost 0.125 lines per base, 11 % of all line fetches on c3.)
-    // No branch, no select and no zero-fill may touch c0 / c1 at the load: the prefetched groups are consumed 16 steps later,
-    // and anything that reads or overwrites the registers of a load in flight makes hipcc park an `s_waitcnt vmcnt(0)`
-    // behind it -- i.e. behind the row gather issued just before -- which un-pipelines the iteration (the byte-wise
-    // tail variants of the first version did exactly that once per read and lane: every third iteration of a wave).
-    // The launcher guarantees >= 16 bytes of bases in the batch.
-    // (e = b + l - kk: one past the byte of step kk)
-    auto load_pair_at = [&](uint64_t e, uint64_t &c0, uint64_t &c1) {
-        uint64_t two[2];
-        __builtin_memcpy(two, bases + (e >= 16 ? e - 16 : 0), 16);
-        c0 = two[1];
-        c1 = two[0];
-    };
-    auto fix_pair = [&](uint64_t e, uint64_t &c0, uint64_t &c1) {
-        if (e < 16) {                                     // the 128-bit value (c0:c1) << 8 * (16 - e); e >= 1
-            const uint32_t sh = 8u * (uint32_t)(16 - e);  // 8 .. 120
-            if (sh >= 64) { c0 = c1 << (sh - 64); c1 = 0; }
-            else { c0 = (c0 << sh) | (c1 >> (64 - sh)); c1 <<= sh; }
-        }
-    };
-    // The 4-row window that holds row nd: aligned, except that the table's last window is pulled back to
-    // rows [r-4, r) so that the fetch never leaves the table and needs no special case (r >= 4, checked at
-    // launch).  Unpredicated: finished lanes re-read window 0 (a cache hit) instead of branching around the load.
-    constexpr uint32_t WN = 4u;                           // rows per window
-    const IdxT wb_last = (IdxT)(ix.r - WN);
-    auto win_base = [&](IdxT nd) -> IdxT {
-        const IdxT wb = nd & ~(IdxT)(WN - 1u);
-        return wb < wb_last ? wb : wb_last;
-    };
-    uint2 ahw[4];                                         // AHD: the look-ahead entries of the window's four rows ...
-    uint4 raw[4];                                         // PSH: what this lane loaded for its pair (rows: 0, 1; entries: 2, 3), assembled at the loop's top
-    const uint32_t odd_lane = threadIdx.x & 1u;
-    auto fetch = [&](IdxT nd, bool act, uint2 (&w)[4]) {
-        if (PSH) {
-            // byte offset of this lane's window in the table it walks on (AHD: the look-ahead copy, entries 64 bytes further on)
-            uint64_t at;
-            if (AHD) {
-                const IdxT wb = nd & ~(IdxT)3;
-                at = wb < wb_last ? (uint64_t)(wb >> 3) * 128u + (uint64_t)((uint32_t)wb & 4u) * 8u : ix.rows2_tail;
-            } else {
-                at = (uint64_t)win_base(nd) * 8u;
-            }
-            if (!act) at = 0;
-            const uint64_t pat = (uint64_t)pair_swap((uint32_t)at) | ((uint64_t)pair_swap((uint32_t)(at >> 32)) << 32);
-            const uint8_t *tab = AHD ? ix.rows2 : ix.rows;
-            const uint8_t *pe = tab + (odd_lane ? pat : at) + 16u * odd_lane;    // this lane's half of the even lane's window
-            const uint8_t *po = tab + (odd_lane ? at : pat) + 16u * odd_lane;    // ... and of the odd lane's
-            __builtin_memcpy(&raw[0], pe, 16);
-            if (AHD) __builtin_memcpy(&raw[2], pe + 64u, 16);
-            __builtin_memcpy(&raw[1], po, 16);
-            if (AHD) __builtin_memcpy(&raw[3], po + 64u, 16);
-            return;
-        }
-        if (AHD) {                                        // line = 8 rows + their 8 entries; the last window has a line of its own
-            const IdxT wb = nd & ~(IdxT)3;
-            const bool body = wb < wb_last;
-            uint64_t at = body ? (uint64_t)(wb >> 3) * 128u + (uint64_t)((uint32_t)wb & 4u) * 8u : ix.rows2_tail;
-            if (!act) at = 0;
-            load_window<MODE>(ix.rows2 + at, 0, w);
-            load_window<MODE>(ix.rows2 + at + 64u, 0, ahw);
-        } else {
-            load_window<MODE>(ix.rows, (uint64_t)(act ? win_base(nd) : (IdxT)0), w);
-        }
-    };
-    // end of a read: what the reference's exception / output paths do with it
-    ClsState cs;
-    auto finish_read = [&]() {
-        if (SEG == 1) {                                   // K1: the segment's counters and how its walk ended
-            SegTot tt;
-            tt.ff = ff_total; tt.scan = scan_total; tt.repo = repo_total; tt.flag = failed;
-            seg.tot[rid] = tt;
-            return;
-        }
-        if (failed && CLS != 2) {
-            for (uint32_t i = 0; i < len; ++i) out[obeg + i] = 0;
-        }
-        if (CLS) cs.store(cls, rid, failed != 0u);
-        if (err) err[rid] = (uint8_t)failed;
-        err_total += failed ? 1u : 0u;
-    };
-
-    uint32_t st = len > 0 ? sFF : sDone;
-    IdxT need = r1;
-    uint32_t k = 0;
-    uint32_t ml = 0, ff_run = 0;
-    uint32_t off = off0;
-    uint64_t rb = 0, rb2 = 0, nx0 = 0, nx1 = 0;           // current 8 bases, the 8 after them, and the next 16 (in flight)
-    if (st != sDone) {
-        load_pair_at(beg + len, rb, rb2);
-        fix_pair(beg + len, rb, rb2);
-    }
-    if (!STG && len > 16) load_pair_at(beg + len - 16, nx0, nx1);
-    uint32_t a = s_code[(uint32_t)(rb >> 56) & 0xFFu];    // code of the base of step k (k = 0)
-    uint4 pk = make_uint4(0, 0, 0, 0), pk_old = pk;
-    if (CLS) cs.init(len, cls.bin_width);
-    // ---- reads staged through LDS (STG; ix.stage_lds = bases per lane, a multiple of 16, >= 128: the block's dynamic LDS --
-    // the occupancy cap's padding, or what the launcher adds for it): every lane copies the next ix.stage_lds bases of its
-    // read into LDS -- 16 bytes per load from the read's end backwards, so the 64 x 150 contiguous bytes of a wavefront of
-    // short reads come in as whole cache lines, each fetched ONCE (the lines stay in the CU's L1 over these back-to-back
-    // loads) -- and takes every base from there.  The other way to the bases, 16 at a time from global memory (STG = 0,
-    // below), re-fetches a read's cache line for every 16 bases: its line is evicted long before the lane comes back
-    // (0.0625 lines per base, 6 % of all line fetches of a big batch).  Longer reads ROLL: when any lane of the wavefront
-    // is about to leave its staged stretch, every lane stages again from where it stands (stage_from in the loop) -- one
-    // extra round trip per >= stage_lds / 2 iterations.  Layout: slot s of lane l at byte (s / 4) * 256 + 4 l + s % 4 --
-    // lanes in step read consecutive banks; slot s holds the base of step kbase + s.
-    //
-    // PMLs out (RING = 1: launches of long reads, launch_pml): behind the staged bases the same dynamic LDS holds a ring of 32
-    // PMLs per lane (kOutRingBytes) -- entry e of lane l at byte (e / 8) * 1024 + 16 l + 2 (e % 8): a lane's 8 consecutive PMLs are
-    // 16 contiguous bytes, 64 lanes' 16 bytes a conflict-free kilobyte.  An emission is one ds_write_b16; when a lane's k crosses a
-    // multiple of 16 the finished group leaves as two adjacent 16-byte stores (two ds_read_b128) -- at most three emissions per
-    // iteration, so the ring's other half is always free.  The register packer it stands in for (four v_perm per PML, a saved
-    // copy of the first 8 of each 16, three nested divergent branches) is 81 of the loop's ~400 VALU instructions, the ring 35.
-    // Where it pays: 100 k x 10 kbp reads -- 6 wavefronts per CU, where a wavefront's own instruction stream is most of an
-    // iteration -- 54.7 -> 57.5 Gbases/s; big batches of short reads are bound by the fabric's line rate and lose 1 % (c2 75.1 ->
-    // 74.5, the 113 M-row table 53.2 -> 52.6) and the LDS the ring takes (profiles/r04_valu.txt).  The stores must leave where the
-    // packer's did, right behind the gather: at the iteration's end c3 drops to 45.3, at the top of the next to 55.1 (c4 -12 %).
-    extern __shared__ __align__(16) uint8_t s_stage[];
-    uint8_t *const s_ring = s_stage + ix.stage_lds * 64u;
-    const uint32_t ring_lane = (threadIdx.x & 63u) * 16u;
-    auto ring_put = [&](uint32_t kk, uint32_t val) {
-        *reinterpret_cast<uint16_t *>(s_ring + ((kk >> 3) & 3u) * 1024u + ring_lane + (kk & 7u) * 2u) = (uint16_t)val;
-    };
-    auto ring_flush = [&](uint32_t k0) {                  // the group of 16 that step k0 lies in: complete, and all of it below packed_end
-        const uint32_t g = (k0 >> 4) & 1u;
-        const uint4 lo = *reinterpret_cast<const uint4 *>(s_ring + (2u * g) * 1024u + ring_lane);
-        const uint4 hi = *reinterpret_cast<const uint4 *>(s_ring + (2u * g + 1u) * 1024u + ring_lane);
-        uint16_t *dst = out + obeg + (k0 & ~15u);
-        __builtin_memcpy(dst, &lo, 16);                   // unaligned 16-byte stores
-        __builtin_memcpy(dst + 8, &hi, 16);
-    };
-    uint32_t kbase = 0;
-    const uint32_t stage_cap = ix.stage_lds;
-    // (the loads of kStageUnroll groups leave together -- unconditional, lanes without the group re-read the batch's first
-    // bytes -- before the first of them is waited for.  Two at a time: c2 74.6 -> 75.0, c3 54.8 -> 54.9 Gbases/s; four or
-    // eight in flight cost c3 11 % (48.9: profiles/r04_stage_unroll.txt) although the loop then makes a quarter of the trips)
-#ifndef MOVI_STAGE_UNROLL
-#define MOVI_STAGE_UNROLL 2
-#endif
-    constexpr uint32_t kStageUnroll = MOVI_STAGE_UNROLL;
-    auto stage_from = [&](uint32_t k0, bool on) {         // every lane of the wavefront makes the call; lanes with `on` stage
-        uint32_t *S = reinterpret_cast<uint32_t *>(s_stage);
-        const uint32_t sl = threadIdx.x & 63u;
-        const uint32_t left = (on && len > k0) ? len - k0 : 0u;
-        const uint32_t cnt = left < stage_cap ? left : stage_cap;
-        for (uint32_t g = 0; wave_any(16u * g < cnt); g += kStageUnroll) {
-            uint64_t c0[kStageUnroll], c1[kStageUnroll];
-#pragma unroll
-            for (uint32_t u = 0; u < kStageUnroll; ++u) {
-                const uint64_t e = 16u * (g + u) < cnt ? beg + len - k0 - 16u * (g + u) : 16u;
-                load_pair_at(e, c0[u], c1[u]);
-            }
-#pragma unroll
-            for (uint32_t u = 0; u < kStageUnroll; ++u) {
-                if (16u * (g + u) < cnt) {
-                    const uint64_t e = beg + len - k0 - 16u * (g + u);
-                    fix_pair(e, c0[u], c1[u]);
-                    const uint64_t r0 = __builtin_bswap64(c0[u]), r1 = __builtin_bswap64(c1[u]);   // step k0 + 16 (g + u) in the low byte
-                    S[(4u * (g + u) + 0u) * 64u + sl] = (uint32_t)r0;
-                    S[(4u * (g + u) + 1u) * 64u + sl] = (uint32_t)(r0 >> 32);
-                    S[(4u * (g + u) + 2u) * 64u + sl] = (uint32_t)r1;
-                    S[(4u * (g + u) + 3u) * 64u + sl] = (uint32_t)(r1 >> 32);
-                }
-            }
-        }
-        if (on) kbase = k0;
-    };
-    auto staged_code = [&](uint32_t slot) -> uint32_t {   // code of the base in `slot` (clamped into the staged stretch)
-        const uint32_t q = slot < stage_cap ? slot : stage_cap - 1u;
-        return s_code[s_stage[(q >> 2) * 256u + (threadIdx.x & 63u) * 4u + (q & 3u)]];
-    };
-    if (STG) stage_from(0u, st != sDone);
-    // ---- top of the walk (DevIndex::kmer): the first K bases of the read (segment) by ONE table lookup.  Reads with an
-    // illegal base among them, reads of K bases or fewer and K-mers whose walk throws take the ordinary walk.
-    // cand: lanes whose K-mer `kidx` is to be looked up (k == 0 there); returns the lanes that took the entry.
-    auto top_of_walk = [&](uint32_t cand, uint32_t kidx) -> uint32_t {
-        const uint32_t K = ix.kmer_k;
-        uint4 e4 = make_uint4(0, 0, 0, 0);
-        if (cand) e4 = ix.kmer[kidx];
-        const uint32_t use = cand & (e4.y >> 31);
-        if (use) {
-            const uint32_t mask = (e4.y >> 16) & 0xFFFu;
-            uint16_t *O = out + obeg;
-            uint32_t run = 0;
-            for (uint32_t i = 0; i < K; ++i) {            // the K PMLs, through the same packing as the loop's emissions
-                run = ((mask >> i) & 1u) ? run + 1u : 0u;
-                if (CLS) cs.add(run, k, len, cls.bin_width, cls.thr);
-                if (CLS == 2) {
-                } else if (k >= packed_end) {
-                    O[k] = (uint16_t)run;
-                } else if (STG && ring) {
-                    ring_put(k, run);                     // (K <= 12: no group of 16 is completed here)
-                } else {
-                    pk.x = (pk.x >> 16) | (pk.y << 16);
-                    pk.y = (pk.y >> 16) | (pk.z << 16);
-                    pk.z = (pk.z >> 16) | (pk.w << 16);
-                    pk.w = (pk.w >> 16) | (run << 16);
-                    if ((k & 15) == 7) {
-                        if (k + 8 < packed_end) pk_old = pk;
-                        else __builtin_memcpy(O + (k - 7), &pk, 16);
-                    }
-                }
-                k += 1;
-            }
-            ml = run;
-            need = (IdxT)((uint64_t)e4.x | ((uint64_t)(e4.y & 15u) << 32));
-            off = (e4.y >> 4) & 0xFFFu;
-            ff_total += e4.z;
-            scan_total += e4.w;
-            repo_total += K - (uint32_t)__popc(mask);
-        }
-        return use;
-    };
-    if (!REFILL && ix.kmer_k != 0u) {                     // wave-uniform
-        const uint32_t K = ix.kmer_k;
-        uint32_t kidx = 0, bad = 0;
-        for (uint32_t i = 0; i < K; ++i) {
-            const uint64_t src = i < 8u ? rb : rb2;
-            const uint32_t cc = (uint32_t)s_code[(uint32_t)(src >> (8u * (7u - (i & 7u)))) & 0xFFu] - (uint32_t)SEP;
-            bad |= (uint32_t)(cc > 3u);
-            kidx |= (cc & 3u) << (2u * i);
-        }
-        if (top_of_walk((uint32_t)(st != sDone) & (uint32_t)(len > K) & (bad ^ 1u), kidx)) {
-            if (K >= 8u) rb = rb2;
-            a = s_code[(uint32_t)(rb >> (8u * (7u - (K & 7u)))) & 0xFFu];
-        }
-    }
-    // AHD: the code of the base after the current one (beyond the read's end: never looked at)
-    uint32_t a1 = 0xFFu;
-    if (AHD) a1 = staged_code(k + 1);
-    uint2 w[4];
-    fetch(need, st != sDone, w);
-
-    // ---- lane refill (REFILL): a POOL of upcoming reads per wavefront, fed in chunks of 16 consecutive reads from one global
-    // ticket counter (DevStats::ticket, zeroed with the counters): pool slot `lane` holds a read's number, where its bases
-    // start and its length; slots are consumed in ring order by whichever lanes are idle when the wavefront switches.  A chunk
-    // takes two switches to arrive -- the ticket is drawn (one atomic) at one switch, the chunk's offsets are requested at the
-    // next and merged into the pool at the one after -- so nothing about the pool ever waits on memory by itself.
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t cur_valid = 0;
-    uint64_t P_beg = 0, N_beg = 0;                        // pool slot / chunk in flight: byte offset of the read's bases ...
-    uint32_t P_len = 0, P_rid = 0, N_end = 0;             // ... its length and number (in flight: low half of the next offset)
-    uint32_t p_head = 0, p_count = 0;                     // ring of 64 slots (wave-uniform)
-    uint32_t ld_on = 0, tk_on = 0, no_more = 0;           // a chunk's offsets in flight / a ticket in flight / the counter ran past n_reads
-    uint64_t ld_base = 0;
-    unsigned long long T = 0;                             // lane 0: the ticket drawn
-    auto draw_ticket = [&]() {
-        if (lane == 0u) T = atomicAdd(&stats->ticket, 16ull);
-        tk_on = 1;
-    };
-    if (REFILL) {                                         // the first four chunks at once
-        if (lane == 0u) T = atomicAdd(&stats->ticket, 64ull);
-        const uint64_t base = __builtin_amdgcn_readfirstlane((uint32_t)T) | ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(T >> 32)) << 32);
-        if (base < n_reads) {
-            const uint64_t left = n_reads - base;
-            p_count = left < 64u ? (uint32_t)left : 64u;
-            const uint64_t rr = base + lane < n_reads ? base + lane : n_reads - 1;
-            P_beg = offs[rr];
-            P_len = (uint32_t)offs[rr + 1] - (uint32_t)P_beg;
-            P_rid = (uint32_t)rr;
-            if (p_count == 64u) draw_ticket(); else no_more = 1;
-        } else {
-            no_more = 1;
-        }
-    }
-
-    uint32_t lane_steps = 0, wave_steps = 0;
-    while (wave_any(st != sDone) || (REFILL && (p_count != 0u || ld_on != 0u || tk_on != 0u))) {
-        if (REFILL) {
-            // ---- idle lanes take the pool's next reads -- in batches, when ix.refill_batch lanes (or every lane that still has
-            // work) wait for one: the switch stages the new reads' bases and looks their first K bases up in the top-of-walk
-            // table, memory round trips during which the whole wavefront stands still.
-            const uint32_t idle = (uint32_t)(st == sDone);
-            const uint64_t idm = __ballot(idle != 0u);
-            const uint32_t n_idle = (uint32_t)__popcll(idm);
-            if (idm == ~0ull || (n_idle >= ix.refill_batch && (p_count != 0u || ld_on != 0u || tk_on != 0u))) {
-                // (a) the chunk whose offsets were requested at the last switch joins the pool
-                if (ld_on) {
-                    const uint64_t left = n_reads - ld_base;
-                    const uint32_t cnt = left < 16u ? (uint32_t)left : 16u;
-                    const uint32_t tail = (p_head + p_count) & 63u;           // a multiple of 16: every chunk but the last is full
-                    if ((lane & 48u) == tail) {
-                        P_beg = N_beg;
-                        P_len = N_end - (uint32_t)N_beg;
-                        P_rid = (uint32_t)ld_base + (lane & 15u);
-                    }
-                    p_count += cnt;
-                    ld_on = 0;
-                    if (cnt < 16u) no_more = 1;
-                }
-                // (b) the ticket drawn at the last switch: its chunk's offsets are requested now
-                if (tk_on) {
-                    const uint64_t base = __builtin_amdgcn_readfirstlane((uint32_t)T) | ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(T >> 32)) << 32);
-                    tk_on = 0;
-                    if (base < n_reads) {
-                        ld_base = base;
-                        const uint64_t rr = base + (lane & 15u) < n_reads ? base + (lane & 15u) : n_reads - 1;
-                        N_beg = offs[rr];
-                        N_end = *reinterpret_cast<const uint32_t *>(offs + rr + 1);
-                        ld_on = 1;
-                    } else {
-                        no_more = 1;
-                    }
-                }
-                // (c) room for another chunk: draw its ticket
-                if (!no_more && !tk_on && p_count + (ld_on ? 16u : 0u) <= 16u) draw_ticket();
-                // (d) the switch: the first min(idle lanes, pool) idle lanes take the pool's next reads, in ring order
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idm, 0u));
-                const uint32_t take = n_idle < p_count ? n_idle : p_count;
-                const uint32_t src = (p_head + rank) & 63u;
-                const uint32_t g_lo = __shfl((uint32_t)P_beg, (int)src, 64), g_hi = __shfl((uint32_t)(P_beg >> 32), (int)src, 64),
-                               g_len = __shfl(P_len, (int)src, 64), g_rid = __shfl(P_rid, (int)src, 64);
-                const uint32_t sw = idle & (uint32_t)(rank < take);
-                p_head = (p_head + take) & 63u;
-                p_count -= take;
-                if (idle && cur_valid) {                  // the read that ended: error byte, bins, zero-fill on failure
-                    finish_read();
-                    cur_valid = 0;
-                }
-                if (sw) {
-                    rid = g_rid; beg = (uint64_t)g_lo | ((uint64_t)g_hi << 32); obeg = beg; len = g_len; packed_end = len & (ring ? ~15u : ~7u);
-                    k = 0; ml = 0; ff_run = 0; off = off0; need = r1; failed = 0; cur_valid = 1;
-                    if (CLS) { cs = ClsState(); cs.init(len, cls.bin_width); }
-                    st = len > 0 ? sFF : sDone;
-                }
-                const uint32_t fresh = sw & (uint32_t)(st != sDone);
-                stage_from(0u, fresh != 0u);
-                if (ix.kmer_k != 0u) {
-                    const uint32_t K = ix.kmer_k;
-                    uint32_t kidx = 0, bad = 0;
-                    for (uint32_t i = 0; i < K; ++i) {
-                        const uint32_t cc = staged_code(i) - (uint32_t)SEP;
-                        bad |= (uint32_t)(cc > 3u);
-                        kidx |= (cc & 3u) << (2u * i);
-                    }
-                    top_of_walk(fresh & (uint32_t)(len > K) & (bad ^ 1u), kidx);
-                }
-                if (fresh) {
-                    a = staged_code(k);
-                    if (AHD) a1 = staged_code(k + 1);
-                    fetch(need, true, w);
-                }
-            }
-        }
-        const bool act = st < sDone;
-        lane_steps += (uint32_t)act;
-        wave_steps += 1;
-#if defined(MOVI_PAD_PRE) && MOVI_PAD_PRE > 0
-        {   // experiment (profiles/r04_valu.txt): MOVI_PAD_PRE dependent VALU instructions between the window's arrival and the next gather
-            uint32_t pad = wave_steps;
-#pragma unroll
-            for (int i = 0; i < MOVI_PAD_PRE; ++i) asm volatile("v_add_u32 %0, %0, %0" : "+v"(pad));
-        }
-#endif
-        if (PSH) {                                        // the halves the pair loaded for each other change hands
-            pair_assemble(odd_lane, raw[0], raw[1], w);
-            if (AHD) pair_assemble(odd_lane, raw[2], raw[3], ahw);
-        }
-        const IdxT wbase = win_base(need);
-        // cheap hop: a fast-forward or scan step that only moves on (everything that resolves a base,
-        // starts a scan, ends one or fails is left to the full step below)
-        auto hop = [&]() {
-            const uint32_t q = (uint32_t)(need - wbase);
-            const uint32_t inwin = (uint32_t)(q < WN) & (uint32_t)(st < sDone);
-            const uint2 hr = win_sel(w, q);
-            const uint32_t hn = row_n<MODE>(hr), hc = row_c<MODE>(hr);
-            const uint32_t ffh = inwin & (uint32_t)(st == sFF) & (uint32_t)(need < r1) & (uint32_t)(off >= hn) &
-                                 (uint32_t)(ff_run + 1 < 65535u);
-            const uint32_t nomatch = hc != a;
-            const uint32_t dnh = inwin & (uint32_t)(st == sDown) & nomatch & (uint32_t)(need < r1);
-            const uint32_t uph = inwin & (uint32_t)(st == sUp) & nomatch & (uint32_t)(need != 0);
-            off = ffh ? off - hn : off;
-            ff_run += ffh;
-            scan_total += dnh | uph;
-            need = need + (IdxT)(ffh + dnh) - (IdxT)uph;
-        };
-        // HA < 0 ("window-parallel", variant 14): everything the hops could do inside this window, in closed form instead
-        // of one dependent select-compare-update round per hop.  A fast-forward passes row i iff off >= the running sum of
-        // the lengths up to and including i (monotone, so the number of rows passed is a sum of four compares); a scan
-        // passes the leading run of non-matching rows from its position (a 4-bit mask and a count-trailing / leading-ones).
-        // Same state afterwards as four hop() calls -- identical answers and counts -- at a third of the dependency depth.
-        // bit i of nm = row i of the window does not hold the base of step k
-        const uint32_t nm = (uint32_t)(row_c<MODE>(w[0]) != a) | ((uint32_t)(row_c<MODE>(w[1]) != a) << 1) |
-                            ((uint32_t)(row_c<MODE>(w[2]) != a) << 2) | ((uint32_t)(row_c<MODE>(w[3]) != a) << 3);
-        const uint32_t last_win = (uint32_t)(wbase + 3 == r1);             // the table ends inside (at the end of) this window
-        const uint32_t first_win = (uint32_t)(wbase == 0);
-        auto window_advance = [&]() {
-            const uint32_t q0 = (uint32_t)(need - wbase);
-            const uint32_t inwin = (uint32_t)(q0 < 4u) & (uint32_t)(st < sDone);
-            const uint32_t n0 = row_n<MODE>(w[0]), n1 = row_n<MODE>(w[1]), n2 = row_n<MODE>(w[2]), n3 = row_n<MODE>(w[3]);
-            // ---- fast-forward: rows q0 .. 3 (need < r1 can only fail at index 3 of the last window)
-            const uint32_t m0 = q0 == 0u, m1 = q0 <= 1u, m2 = q0 <= 2u;   // row i takes part (i >= q0); row 3 always does
-            const uint32_t t1 = m0 ? n0 : 0u, t2 = t1 + (m1 ? n1 : 0u), t3 = t2 + (m2 ? n2 : 0u), t4 = t3 + n3;
-            const uint32_t isff = inwin & (uint32_t)(st == sFF);
-            const uint32_t p0 = isff & m0 & (uint32_t)(off >= t1), p1 = isff & m1 & (uint32_t)(off >= t2),
-                           p2 = isff & m2 & (uint32_t)(off >= t3), p3 = isff & (uint32_t)(off >= t4) & (last_win ^ 1u);
-            const uint32_t cf = p0 + p1 + p2 + p3;
-            off -= (p3 ? t4 : (p2 ? t3 : (p1 ? t2 : (p0 ? t1 : 0u))));
-            ff_run += cf;
-            // ---- scans
-            // down: leading run of 1s from bit q0 upwards; row r-1 is never passed (need < r1)
-            const uint32_t dmask = (nm & (last_win ? 7u : 15u)) >> (q0 & 3u);
-            const uint32_t cd = (inwin & (uint32_t)(st == sDown)) ? (uint32_t)__builtin_ctz(~dmask | 16u) : 0u;
-            // up: leading run of 1s from bit q0 downwards; row 0 is never passed (need != 0)
-            const uint32_t umask = ((nm & (first_win ? 14u : 15u)) << (3u - (q0 & 3u))) & 15u;
-            const uint32_t cu = (inwin & (uint32_t)(st == sUp)) ? (uint32_t)__builtin_clz(((~umask) & 15u) << 28 | 0x08000000u) : 0u;
-            scan_total += cd + cu;
-            need = need + (IdxT)(cf + cd) - (IdxT)cu;
-        };
-        if (HA >= 0) {
-#pragma unroll
-            for (int h = 0; h < (HA >= 0 ? HA : 0); ++h) hop();
-        } else if (wave_any(st == sFF && ff_run >= 65520u)) {
-            for (int h = 0; h < 4; ++h) hop();                       // near the reference's fast-forward limit: step by step
-        } else {
-            window_advance();
-        }
-        const uint32_t qn = (uint32_t)(need - wbase);
-        const uint32_t inwin = (uint32_t)(qn < WN) & (uint32_t)act;
-        const uint2 row = win_sel(w, qn);
-        const uint32_t n = row_n<MODE>(row), c = row_c<MODE>(row);
-        const uint32_t isFF = (uint32_t)(st == sFF) & inwin, isDown = (uint32_t)(st == sDown) & inwin,
-                       isUp = (uint32_t)(st == sUp) & inwin;
-        // fast_forward, move_structure.cpp:524-545
-        const uint32_t ffm = isFF & (uint32_t)(need < r1) & (uint32_t)(off >= n);
-        const uint32_t ff_over = ffm & (uint32_t)(ff_run + 1 >= 65535u);  // :72-75
-        const uint32_t resolved = isFF & (ffm ^ 1u);
-        // the base of step k against the row (read_processor.cpp:188-238)
-        const uint32_t illegal = a == 0xFFu, match = c == a;
-        const uint32_t mism = resolved & (illegal ^ 1u) & (match ^ 1u);
-        // reposition_thresholds, src/move_structure_query.cpp:513-601
-        // (SEP is a template parameter here: the separator branch and its selects sit on the critical path
-        // between the window's arrival and the next gather, and cost 4 % on c3 as a run-time flag)
-        const uint32_t kk = thr_slot(SEP, a, c);                          // alphamap_3[c][a]
-        uint32_t thr = row_thr<MODE>(row, kk > 2u ? 2u : kk) ? n : 0u;
-        if (SEP) {                                                        // a row of the separator: side table
-            if (mism & (uint32_t)(c == 0u) & (uint32_t)(need != end_row)) thr = separator_threshold(ix, (uint64_t)need, a);
-        }
-        const uint32_t down = (uint32_t)(off >= ((need == end_row) ? end_threshold(SEP, ethr, a) : thr));
-        const uint32_t at_last = need >= r1, at_first = need == 0;
-        const uint32_t repo_edge = mism & (down ? at_last : at_first);
-        // reposition_down :211-232 / reposition_up :188-209.  A run of the base among the window's OTHER rows is found in
-        // this very iteration (the nearest one in the scan's direction: what the row-by-row scan stops at) -- a reposition
-        // whose target shares the window costs no round trip of its own (tools/iter_model.c: half of all repositions; lane
-        // iterations per base -5 % on 150 bp reads with 1 % substitutions, -15 % on 10 kbp reads with 8 %).  Anything
-        // further away is scanned for one window per iteration, as before.
-        const uint32_t has = (nm ^ 15u) & (down ? (14u << (qn & 3u)) & 15u : (1u << (qn & 3u)) - 1u);   // rows that hold the base, beyond row qn
-        const uint32_t found = mism & (uint32_t)(has != 0u) & ix.inwin;
-        const uint32_t qf = found ? (down ? (uint32_t)__builtin_ctz(has | 16u) : 31u - (uint32_t)__builtin_clz(has | 1u)) : qn;
-        const uint32_t far = mism & (found ^ 1u);                          // the scan leaves the window
-        const uint2 rowf = win_sel(w, qf);                                 // the row the base is resolved at, if it is resolved now
-        const uint32_t nf = row_n<MODE>(rowf), rofff = row_off<MODE>(rowf);
-        const IdxT needf = (IdxT)(wbase + qf);
-        const uint32_t scanning = isDown | isUp;
-        const uint32_t hit = scanning & match;
-        const uint32_t landed = hit | found;                               // a scan ended at this row: offset 0 / n - 1 (read_processor.cpp:223)
-        const uint32_t landed_down = hit ? isDown : down;
-        const uint32_t scan_edge = scanning & (hit ^ 1u) & (isDown ? at_last : at_first);
-        const uint32_t emit = (resolved & (illegal | match)) | landed;
-        // LF_move of the emitted base, move_structure.cpp:59-67 (emit and the error cases are exclusive)
-        const uint32_t lf = emit & (uint32_t)(k + 1 != len);
-        uint64_t j = 0;
-        if (MODE == 6 || lf) j = row_id<MODE>(rowf, needf, ix);
-        const uint32_t lf_bad = lf & (uint32_t)(j >= ix.r);
-        const uint32_t step_fwd = ffm | (far & down) | (scanning & (hit ^ 1u) & isDown);
-        const uint32_t step_back = (far & (down ^ 1u)) | (scanning & (hit ^ 1u) & isUp);
-        IdxT need_next = lf ? (IdxT)j : (IdxT)(need + step_fwd - step_back);
-        uint32_t st_next = (emit & (lf ^ 1u)) ? sDone : (lf ? sFF : (far ? (down ? sDown : sUp) : st));
-        // AHD: the base after this one, resolved at the LF target from the look-ahead entry (read_processor.cpp:188-238 with
-        // match and no fast-forward: ml + 1, then LF_move again) -- the target row itself is never fetched
-        uint32_t dbl = 0, lf2 = 0, off1 = 0;
-        IdxT j2 = 0;
-        if (AHD) {
-            const uint2 ah = win_sel(ahw, qf);            // the entry of the row the base was resolved at
-            const uint32_t n1 = ah.y & 0x7FFu, c1 = (ah.y >> 22) & 7u;
-            const uint32_t off_e = (landed ? (landed_down ? 0u : nf - 1u) : off) + rofff;
-            dbl = lf & (ah.y >> 31) & (uint32_t)(a1 == c1) & (uint32_t)(off_e < n1);
-            lf2 = dbl & (uint32_t)(k + 2 != len);
-            off1 = (ah.y >> 11) & 0x7FFu;
-            j2 = (IdxT)((uint64_t)ah.x | ((uint64_t)((ah.y >> 25) & 15u) << 32));
-            need_next = dbl ? (lf2 ? j2 : need) : need_next;
-            st_next = dbl ? (lf2 ? sFF : sDone) : st_next;
-        }
-        // The reference's throws: practically never, so which one it was is sorted out off the common path (as one
-        // select ladder over need_next / st_next it cost ~45 instructions between a window's arrival and the next
-        // gather's issue in every iteration).  An error freezes the lane where it is: no out-of-table window is fetched.
-        uint32_t errc = kErrNone;
-        if (wave_any((ff_over | repo_edge | scan_edge | lf_bad) != 0u)) {
-            errc = ff_over ? kErrFastForward
-                           : (repo_edge ? (down ? kErrNoRunBelow : kErrNoRunAbove)
-                              : (scan_edge ? (isDown ? kErrNoRunBelow : kErrNoRunAbove)
-                                 : (lf_bad ? kErrIdRange : kErrNone)));
-            if (errc) { need_next = need; st_next = sDone; }
-        }
-        // ---- the next gather leaves now; everything below runs under its latency
-        // (`row` is not touched below, so the new window can land in the old one's registers)
-        fetch(need_next, st_next != sDone, w);
-#if defined(MOVI_PAD_POST) && MOVI_PAD_POST > 0
-        {   // ... and MOVI_PAD_POST of them under the gather's latency
-            uint32_t pad = wave_steps;
-#pragma unroll
-            for (int i = 0; i < MOVI_PAD_POST; ++i) asm volatile("v_add_u32 %0, %0, %0" : "+v"(pad));
-        }
-#endif
-        // ---- bookkeeping, all selects
-        uint32_t want_nx = 0;                             // this lane asks for the 16 bases that end at byte nx_e
-        uint64_t nx_e = 0;
-        ml = resolved ? (match ? ml + 1 : 0u) : ml;
-        ff_total += resolved ? ff_run : 0u;
-        ff_run = lf ? 0u : ff_run + ffm;
-        repo_total += mism;
-        scan_total += scanning + (found ? (down ? qf - qn : qn - qf) : 0u);
-        off = ffm ? off - n : (landed ? (landed_down ? 0u : nf - 1) : off);   // read_processor.cpp:223
-        const uint32_t off_pre = off;                                     // (before the LF to the next base: what K1 records)
-        off += lf ? rofff : 0u;
-        if (emit) {
-            uint16_t *O = out + obeg;
-            // MoveQuery::add_ml for the base of step k (u16 clamp), through the bins and the 16-byte packer: 16 PMLs leave
-            // together as two adjacent 16-byte stores; an odd group of 8 before the tail on its own
-            auto emit_pml = [&](uint32_t mlv) {
-                const uint32_t val = mlv > 65535u ? 65535u : mlv;
-                if (CLS) cs.add(val, k, len, cls.bin_width, cls.thr);
-                if (CLS == 2) {
-                    // verdict bins only
-                } else if (k >= packed_end) {
-                    O[k] = (uint16_t)val;
-                } else if (STG && ring) {
-                    ring_put(k, val);
-                } else {
-                    pk.x = (pk.x >> 16) | (pk.y << 16);
-                    pk.y = (pk.y >> 16) | (pk.z << 16);
-                    pk.z = (pk.z >> 16) | (pk.w << 16);
-                    pk.w = (pk.w >> 16) | (val << 16);
-                    if ((k & 15) == 7) {
-                        if (k + 8 < packed_end) pk_old = pk;
-                        else __builtin_memcpy(O + (k - 7), &pk, 16);
-                    } else if ((k & 15) == 15) {
-                        __builtin_memcpy(O + (k - 15), &pk_old, 16);
-                        __builtin_memcpy(O + (k - 7), &pk, 16);
-                    }
-                }
-                k += 1;
-            };
-            // K1's records (SEG == 1): the state a one-base walk has after the base of step k -- at row `at`, before its LF
-            auto seg_record = [&](uint64_t at, uint32_t off_at) {
-                if ((k & 31u) == 31u) {
-                    SegCkpt ck;
-                    ck.idx = at; ck.off = off_at; ck.ml = ml;
-                    ck.ff = ff_total; ck.scan = scan_total; ck.repo = repo_total; ck.pad_ = 0;
-                    seg.ckpt[(obeg + k) >> 5] = ck;
-                }
-                if (k + 1 == len) {
-                    SegFin fn;
-                    fn.idx = at; fn.off = off_at; fn.ml = ml;
-                    seg.fin[rid] = fn;
-                }
-            };
-            const uint32_t k_in = k;
-            if (SEG == 1) seg_record((uint64_t)needf, off_pre);
-            emit_pml(ml);
-            if (AHD && dbl) {                             // the second base of a multi-base step: matched, no fast-forward
-                ml += 1;
-                if (SEG == 1) seg_record(j, off);
-                off += lf2 ? off1 : 0u;
-                emit_pml(ml);
-            }
-            if (STG && CLS != 2 && ring && ((k ^ k_in) & 16u) != 0u) ring_flush(k_in);   // a group of 16 PMLs is complete
-            if (STG) {
-                // (the next base's code: after the state update below, where a lane about to leave its staged stretch is seen)
-            } else if (lf) {
-                {
-                    if ((k & 15) == 8) {
-                        rb = rb2;
-                    } else if ((k & 15) == 0) {
-                        rb = nx0;
-                        rb2 = nx1;
-                        fix_pair(beg + len - k, rb, rb2);
-                        if (k + 16 < len) { want_nx = 1; nx_e = beg + len - k - 16; }
-                    }
-                    a = s_code[(uint32_t)(rb >> (8 * (7 - (k & 7)))) & 0xFFu];
-                }
-            }
-        }
-        if (errc) failed = errc;
-        need = need_next;
-        st = st_next;
-        if (STG) {
-            // a lane whose next bases lie beyond its staged stretch: the whole wavefront stages again, each lane from its own step
-            const uint32_t ahead_of = k - kbase;          // < 2^31: k >= kbase always
-            const uint32_t out_of = (uint32_t)(st != sDone) &
-                                    ((uint32_t)(ahead_of >= stage_cap) | ((uint32_t)(ahead_of + 1u >= stage_cap) & (uint32_t)(k + 1 < len)));
-            if (wave_any(out_of != 0u)) stage_from(k, st != sDone);
-            a = staged_code(k - kbase);
-            if (AHD) a1 = staged_code(k + 1 - kbase);
-        }
-        // ONE load site per prefetch register set and iteration, behind every read of those registers: a second site (or
-        // a temporary that the register allocator parks in them where they are dead) costs an `s_waitcnt` on a load
-        // in flight, i.e. on the row gather issued above
-        if (want_nx) load_pair_at(nx_e, nx0, nx1);
-    }
-    if (REFILL ? cur_valid != 0u : valid) finish_read();
-    if (SEG != 1) {
-        const uint32_t ffw = wave_sum(ff_total), scw = wave_sum(scan_total), rpw = wave_sum(repo_total),
-                       erw = wave_sum(err_total);
-        if ((threadIdx.x & 63) == 0 && stats) {
-            if (ffw) atomicAdd(&stats->fast_forwards, (unsigned long long)ffw);
-            if (scw) atomicAdd(&stats->scans, (unsigned long long)scw);
-            if (rpw) atomicAdd(&stats->repositions, (unsigned long long)rpw);
-            if (erw) atomicAdd(&stats->errors, (unsigned long long)erw);
-        }
-    }
-    const uint32_t lsw = wave_sum(lane_steps);
-    if ((threadIdx.x & 63) == 0 && stats) {
-        atomicAdd(&stats->lane_steps, (unsigned long long)lsw);
-        atomicAdd(&stats->wave_steps, (unsigned long long)wave_steps);
-    }
-}
-
-// ------------------------------------------------------------- segment-parallel long reads (movi_kernels.hpp)
-
-// One base of the plain base-synchronous automaton (pml_kernel<MODE, 0>) for the lanes with `live`: the LF from the
-// base before (unless this is the walk's first base), then match / illegal / reposition_thresholds + scan against base
-// code `a`.  Wave-uniform loops inside: every lane of the wavefront must make the call.  Returns a kErr* code.
-template <int MODE>
-__device__ __forceinline__ uint32_t walk_base(const DevIndex &ix, const EndThr &ethr, bool live, bool lf, uint32_t a, uint64_t &idx,
-                                              uint32_t &off, uint2 &row, uint32_t &ml, uint32_t &ff_total, uint32_t &scan_total,
-                                              uint32_t &repo_total) {
-    uint32_t failed = lf_step<MODE>(ix, live && lf, idx, off, row, ff_total);
-    if (failed) live = false;
-    const uint32_t rc = row_c<MODE>(row);
-    uint32_t dir = 0;
-    if (live) {
-        if (a == 0xFFu) {
-            ml = 0;
-        } else if (rc == a) {
-            ml += 1;
-        } else {                                          // reposition_thresholds, as in pml_kernel
-            repo_total += 1;
-            ml = 0;
-            uint32_t down;
-            if (idx == ix.end_bwt_idx) {
-                down = (off >= end_threshold(ix.sep, ethr, a)) ? 1u : 0u;
-            } else if (ix.sep && rc == 0u) {
-                down = (off >= separator_threshold(ix, idx, a)) ? 1u : 0u;
-            } else {
-                const uint32_t kk = thr_slot(ix.sep, a, rc);
-                const uint32_t thr = row_thr<MODE>(row, kk > 2u ? 2u : kk) ? row_n<MODE>(row) : 0u;
-                down = (off >= thr) ? 1u : 0u;
-            }
-            dir = down ? 1u : 2u;
-            if (down && idx == ix.r - 1) { failed = kErrNoRunBelow; dir = 0; }
-            if (!down && idx == 0) { failed = kErrNoRunAbove; dir = 0; }
-        }
-    }
-    uint32_t scanning = dir;
-    while (wave_any(scanning != 0u)) {
-        if (scanning) {
-            uint64_t jj = (scanning == 1u) ? idx + 1 : idx - 1;
-            if (scanning == 1u) { if (jj >= ix.r) jj = ix.r - 1; }
-            else if (jj > idx) jj = 0;
-            const uint2 w = load_row<MODE>(ix.rows, jj);
-            scan_total += 1;
-            idx = (scanning == 1u) ? idx + 1 : idx - 1;
-            row = w;
-            const uint32_t c = row_c<MODE>(row);
-            if (c == a) {
-                scanning = 0;
-            } else if (scanning == 1u ? (idx >= ix.r - 1) : (idx == 0)) {
-                failed = scanning == 1u ? kErrNoRunBelow : kErrNoRunAbove;
-                scanning = 0;
-            }
-        }
-    }
-    if (failed == 0u && dir == 1u) off = 0;
-    if (failed == 0u && dir == 2u) off = row_n<MODE>(row) - 1;
-    return failed;
-}
 
 // Top-of-walk table (DevIndex::kmer): lane t walks the K-mer whose step-i base has code (t >> 2 i) & 3 (+ 1 on a
 // separators index) from the state every read starts in -- exactly pml_kernel<MODE, 0>'s automaton -- and records where
@@ -2060,45 +747,21 @@ static hipError_t launch_pml_segmented(const DevIndex &ix, const uint8_t *d_base
         ixl.stage_lds = (cfg.stage_reads != 0 && cap >= 96) ? cap : 0u;
         seg_ring = ring_b != 0 && ixl.stage_lds != 0u;
     };
-#define MOVI_LAUNCH_SEG(SEGV, LANES, ...)                                                                             \
-    do {                                                                                                              \
-        if (dyn_lds > 65536) {                                                                                        \
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&__VA_ARGS__),                                     \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds);                        \
-            if (e != hipSuccess) return e;                                                                            \
-        }                                                                                                             \
-        hipLaunchKernelGGL((__VA_ARGS__), dim3((unsigned)(((LANES) + bt - 1) / bt)), dim3(bt), dyn_lds, stream, ixl,  \
-                           d_bases, d_offsets, (uint64_t)(LANES), d_out, d_err, d_stats, d_order, cls, seg);          \
-    } while (0)
-#define MOVI_LAUNCH_SEG_S(SEGV, LANES, T, S)                                                                          \
-    do {                                                                                                              \
-        if (seg_ring && seg_pair && ix.rows2 != nullptr) MOVI_LAUNCH_SEG(SEGV, LANES, pml_kernel_flatp<6, T, -1, 0, S, 0, SEGV, 1, 1, 1, 1>); \
-        else if (seg_ring && seg_pair) MOVI_LAUNCH_SEG(SEGV, LANES, pml_kernel_flatp<6, T, -1, 0, S, 0, SEGV, 1, 0, 1, 1>);   \
-        else if (seg_ring && ix.rows2 != nullptr) MOVI_LAUNCH_SEG(SEGV, LANES, pml_kernel_flatp<6, T, -1, 0, S, 0, SEGV, 1, 1, 0, 1>); \
-        else if (seg_ring) MOVI_LAUNCH_SEG(SEGV, LANES, pml_kernel_flatp<6, T, -1, 0, S, 0, SEGV, 1, 0, 0, 1>);               \
-        else if (seg_pair && ixl.stage_lds != 0u && ix.rows2 != nullptr) MOVI_LAUNCH_SEG(SEGV, LANES, pml_kernel_flatp<6, T, -1, 0, S, 0, SEGV, 1, 1, 1>); \
-        else if (seg_pair && ixl.stage_lds != 0u) MOVI_LAUNCH_SEG(SEGV, LANES, pml_kernel_flatp<6, T, -1, 0, S, 0, SEGV, 1, 0, 1>); \
-        else if (ixl.stage_lds != 0u && ix.rows2 != nullptr) MOVI_LAUNCH_SEG(SEGV, LANES, pml_kernel_flatp<6, T, -1, 0, S, 0, SEGV, 1, 1>); \
-        else if (ixl.stage_lds != 0u) MOVI_LAUNCH_SEG(SEGV, LANES, pml_kernel_flatp<6, T, -1, 0, S, 0, SEGV, 1, 0>);  \
-        else MOVI_LAUNCH_SEG(SEGV, LANES, pml_kernel_flatp<6, T, -1, 0, S, 0, SEGV>);                                 \
-    } while (0)
-#define MOVI_LAUNCH_SEG_T(SEGV, LANES)                                                                                \
-    do {                                                                                                              \
-        stage_for(LANES);                                                                                             \
-        if (ix.idx32) {                                                                                               \
-            if (ix.sep) MOVI_LAUNCH_SEG_S(SEGV, LANES, uint32_t, 1); else MOVI_LAUNCH_SEG_S(SEGV, LANES, uint32_t, 0); \
-        } else {                                                                                                      \
-            if (ix.sep) MOVI_LAUNCH_SEG_S(SEGV, LANES, uint64_t, 1); else MOVI_LAUNCH_SEG_S(SEGV, LANES, uint64_t, 0); \
-        }                                                                                                             \
-    } while (0)
-    MOVI_LAUNCH_SEG_T(1, max_seg);
+    auto launch_seg = [&](int segv, uint64_t lanes, LaunchInfo *li) -> hipError_t {
+        stage_for(lanes);
+        WalkLaunch L;
+        L.grid = dim3((unsigned)((lanes + bt - 1) / bt)); L.block = dim3(bt); L.dyn_lds = dyn_lds; L.stream = stream;
+        L.ix = ixl; L.bases = d_bases; L.offs = d_offsets; L.n = lanes; L.out = d_out; L.err = d_err; L.stats = d_stats;
+        L.order = d_order; L.cls = cls; L.seg = seg;
+        L.cls_mode = 0; L.sep = ix.sep ? 1 : 0; L.stg = ixl.stage_lds != 0u ? 1 : 0;
+        L.ahd = (L.stg && ix.rows2 != nullptr) ? 1 : 0; L.psh = (L.stg && seg_pair) ? 1 : 0; L.ring = seg_ring ? 1 : 0;
+        return ix.idx32 ? launch_walkseg_u32(segv, L, li) : launch_walkseg_u64(segv, L, li);
+    };
+    e = launch_seg(1, max_seg, info);
+    if (e != hipSuccess) return e;
     if (info) {                                           // the dominant kernel: K1
-        const int stg = ixl.stage_lds != 0u ? 1 : 0, ahd = (stg && ix.rows2 != nullptr) ? 1 : 0;
-        snprintf(info->kernel, sizeof(info->kernel), "pml_kernel_flatp<6, %s, -1, 0, %d, 0, 1, %d, %d%s>",
-                 ix.idx32 ? "unsigned int" : "unsigned long", ix.sep ? 1 : 0, stg, ahd,
-                 seg_ring ? (seg_pair ? ", 1, 1" : ", 0, 1") : ((seg_pair && stg) ? ", 1" : ""));
         info->variant = 14; info->block_threads = 64; info->segmented = 1; info->idx64 = ix.idx32 ? 0 : 1;
-        info->waves_per_cu = 0; info->staged = (int)ixl.stage_lds; info->ahead = ahd;
+        info->waves_per_cu = 0; info->staged = (int)ixl.stage_lds; info->ahead = (ixl.stage_lds != 0u && ix.rows2 != nullptr) ? 1 : 0;
     }
     // (blocks of one wavefront: a boundary lane that has to walk far holds up only the 63 beside it)
     const uint32_t max_over = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, (uint64_t)cfg.seg_len * (uint64_t)kSegOverrun);
@@ -2108,11 +771,8 @@ static hipError_t launch_pml_segmented(const DevIndex &ix, const uint8_t *d_base
                        seg.tot, join, seg_l, seg_rem, on_chain, read_fail, d_err, d_stats);
     hipLaunchKernelGGL((seg_stitch_kernel<6, 1>), dim3((unsigned)((max_seg + 63) / 64)), dim3(64), 0, stream, ix, d_bases, seg,
                        seg_j, seg_rem, max_over, on_chain, d_out, join);
-    MOVI_LAUNCH_SEG_T(2, n_reads);
-#undef MOVI_LAUNCH_SEG_T
-#undef MOVI_LAUNCH_SEG_S
-#undef MOVI_LAUNCH_SEG
-    e = hipGetLastError();
+    e = launch_seg(2, n_reads, nullptr);
+    if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess && bins.bin_width)
         e = launch_classify(d_out, d_offsets, n_reads, bins.bin_width, bins.thr, bins.above, bins.below, bins.sum_max, stream, d_err);
     return e;
@@ -2130,23 +790,18 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     // One resident row layout: blocked- and sampled-thresholds tables are expanded to regular-thresholds rows at upload
     // (expand_blocked_kernel / expand_sampled_kernel), so the query kernels exist for MODE 6 only.
     if (mode != 6) return hipErrorInvalidValue;
-    // Variants: 0 first correct kernel, 1 base-synchronous packed I/O, 7 flat lane state machine,
-    // 10 = 7 + row window + software pipelining, 13 = 10 as a persistent grid with lane refill, 14 = 10 with every in-window
-    // fast-forward / scan step resolved in closed form (window_advance; the default).  (2-6, 8, 9, 11, 12 were
-    // experiments -- branchy state machine, 2/4-row neighbour windows, the unpipelined window kernel, other hop counts --
-    // measured slower and removed; numbers in DESIGN.md section 3.)
-    // Auto selection (measured on MI355X, profiles/r02_*): variant 10 in blocks of ONE wavefront, and -- when there are
+    // Variants: 0 first correct kernel (serves --logs), 1 base-synchronous packed I/O (tables of fewer than 8 rows, batches of
+    // fewer than 16 bases; A/B), 14 = the lane state machine over row windows (pml_kernel_flatp, movi_walk.hpp; the default).
+    // (2-13 were experiments -- branchy / row-at-a-time state machines, 2/4-row neighbour windows, the unpipelined window
+    // kernel, hop-by-hop advances, lane refill -- measured slower or no faster and removed; numbers in DESIGN.md section 3.)
+    // Auto selection (measured on MI355X, profiles/r02_*): the state machine in blocks of ONE wavefront, and -- when there are
     // more reads than ~18 waves per CU -- at most kCapWaves wavefronts resident per CU.  Why a cap: between two
     // iterations of a lane its cache lines (the row window's neighbours, its read, its output) must survive in the
     // 4 MiB L2 of its XCD; with all 32 wave slots of a CU walking, 8 MiB of lines are in flight per XCD and neighbour
-    // rows are refetched from the fabric.  1 M x 150 bp, Gbases/s, variant 10 uncapped / capped at 8-10 waves per CU /
+    // rows are refetched from the fabric.  1 M x 150 bp, Gbases/s, uncapped / capped at 8-10 waves per CU /
     // variant 1 (base-synchronous: its neighbour loads follow the gather at once, so it wants all the occupancy it can
     // get): pangenome 14 M rows 43.2 / 48.2 / 46.4; random tables of 10 M rows 40.0 / 47.5 / 43.6, 60 M 35.7 / 40.8 /
     // 36.3, 250 M (2 GB) 29.1 / 32.8 / 29.2, 500 M 27.9 / 30.3 / 27.7, 1 B (8 GB) 27.4 / 27.7 / 28.3.
-    // Variant 13 (lane refill) lifts the share of busy lanes from 80 % to 92 % but runs every rare-per-lane block
-    // (chunk fetch, PML stores, refill) in every iteration because its lanes are never in step: 46.1 on the pangenome
-    // (variant 10 capped: 47.7), 43.5 on the random table; on log-normal read lengths 36.5 against 35.8.  Selectable,
-    // not the default.
     int v = cfg.pml_variant;
     const bool logging = cls.log_ff != nullptr || cls.log_scan != nullptr;
     // (batches of up to ~18 waves per CU run in ONE round, uncapped: with the cap, 224 k reads = 13.7 waves per CU run as
@@ -2154,17 +809,9 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     // reads on the cap wins: 43.9 against 41.7.  profiles/r02_occupancy_cap_sweeps.txt)
     const bool big_batch = n_reads > (uint64_t)cfg.num_cus * 64u * 18u;
     if (v < 0) v = 14;
-    // variant 14 = variant 10 with the window-parallel advance instead of two sequential hops: +2.5 % on long reads,
-    // +5.5 % on the 8 GB table, neutral on the fabric-bound big batches (profiles/r02_window_parallel.txt) -> the default
-    bool wp = v == 14;
-    if (wp) v = 10;
-    const int wpc_refill = cfg.waves_per_cu > 0 ? cfg.waves_per_cu : kCapWaves;
-    uint64_t refill_blocks = cfg.refill_blocks > 0 ? (uint64_t)cfg.refill_blocks
-                                                   : (uint64_t)cfg.num_cus * (uint64_t)wpc_refill;   // in wavefronts (blocks of 64)
-    if (v == 13 && (d_order || n_reads <= refill_blocks * 64u)) { v = 10; wp = true; }   // nothing to refill: the default walk
-    if ((v == 10 || v == 13) && (ix.r < 8 || n_bases < 16)) v = 7;           // the clamped window needs >= 4 rows, the
+    if (v == 14 && (ix.r < 8 || n_bases < 16)) v = 1;                        // the clamped window needs >= 4 rows (r >= 8: two windows), the
                                                                              // 16-base fetches >= 16 bytes of bases
-    if (cm != 0 && (v == 0 || v == 7)) v = (v == 0 || ix.r < 8 || n_bases < 16) ? 1 : 10;   // the A/B kernels carry no fused bins
+    if (cm != 0 && v == 0) v = 1;                                            // the first kernel carries no fused bins
     if (logging) {                                                           // per-base logs: the first kernel keeps them
         if (cm != 0) return hipErrorInvalidValue;
         v = 0;
@@ -2172,7 +819,7 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     // Batches of long reads: segment-parallel (plain PML through the default kernel only).  One lane per read leaves the
     // GPU short of walks -- 100 k reads are 6 wavefronts per CU, and a single 1 Mbp read holds its lane for 2 s --;
     // cut into segments the same batch fills it like a batch of short reads.
-    if (seg_ws && !logging && cfg.seg_len >= 32 && !d_order && wp && v == 10 && cfg.block_threads <= 64 &&
+    if (seg_ws && !logging && cfg.seg_len >= 32 && !d_order && v == 14 && cfg.block_threads <= 64 &&
         n_bases / n_reads >= 2ull * (uint64_t)cfg.seg_len && n_reads + n_bases / (uint64_t)cfg.seg_len < 0x7FFFFFF0ull) {
         bool declined = false;
         const hipError_t es = launch_pml_segmented(ix, d_bases, d_offsets, n_reads, n_bases, d_out, d_err, d_stats, cfg, stream,
@@ -2181,25 +828,17 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
         if (es != hipSuccess || !declined) return es;
     }
     const int bt = cfg.block_threads > 0 ? cfg.block_threads : 64;           // one wavefront per block: finest dispatch grain
-    uint64_t blocks = (n_reads + bt - 1) / bt;
+    const uint64_t blocks = (n_reads + bt - 1) / bt;
     int wpc = cfg.waves_per_cu;
     if (wpc < 0) wpc = 0;
-    if (v == 13 && (cfg.stage_reads == 0 || bt != 64)) { v = 10; wp = true; }         // lane refill: staged one-wavefront blocks only
-    const bool stage_ok = cfg.stage_reads != 0 && bt == 64 && ((v == 10 && wp) || v == 13);   // the staged kernels: one-wavefront blocks of the default walk
+    const bool stage_ok = cfg.stage_reads != 0 && bt == 64 && v == 14;                  // the staged kernels: one-wavefront blocks of the default walk
     const bool ahead_ok = stage_ok && ix.rows2 != nullptr;                              // ... on the look-ahead rows where they exist
-    if (cfg.waves_per_cu == 0 && (cfg.pml_variant < 0 || cfg.pml_variant == 14) && v == 10 && big_batch)
+    if (cfg.waves_per_cu == 0 && v == 14 && big_batch)
         wpc = ahead_ok ? kCapWavesAhead : kCapWaves;                                 // the auto policy above
-    if (v == 13) {
-        wpc = cfg.waves_per_cu > 0 ? cfg.waves_per_cu : (ahead_ok ? kCapWavesAhead : kCapWaves);
-        if (cfg.refill_blocks == 0) refill_blocks = (uint64_t)cfg.num_cus * (uint64_t)wpc;
-        const uint64_t resident = (refill_blocks * 64u + bt - 1) / bt;
-        if (blocks > resident) blocks = resident;
-    }
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     dim3 grid((unsigned)blocks), block((unsigned)bt);
     // Occupancy cap: enforced by the dispatcher through the block's LDS allocation (160 KiB per CU); blocks beyond
-    // the cap queue and start as resident ones retire.  For the persistent grid of variant 13 the same padding makes
-    // the dispatcher spread the blocks evenly: exactly wpc wavefronts on every CU.
+    // the cap queue and start as resident ones retire.
     size_t dyn_lds = 0;
     if (wpc > 0) {
         int bpc = wpc / (bt / 64);
@@ -2212,10 +851,10 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     // its wavefronts per CU leave of the 160 KiB, so that the round stays one round.  Long reads roll through the same
     // stretch (stage_from in the kernel).  cfg.stage_reads: 1 = whenever it fits (default), 0 = never.
     DevIndex ixl = ix;
-    // PMLs out through a ring in LDS (ix.out_ring; the kernel has the numbers): launches of long reads -- few wavefronts, each
+    // PMLs out through a ring in LDS (the kernel has the numbers): launches of long reads -- few wavefronts, each
     // one's own instruction stream most of an iteration -- where the block's LDS holds the ring beside 96 staged bases.
     // cfg.out_ring: -1 = this policy, 0 / 1 = never / wherever it fits (A/B).
-    const bool ring_wanted = stage_ok && v == 10 && (cfg.out_ring > 0 || (cfg.out_ring < 0 && n_bases / n_reads >= kOutRingReadLen));
+    const bool ring_wanted = stage_ok && (cfg.out_ring > 0 || (cfg.out_ring < 0 && n_bases / n_reads >= kOutRingReadLen));
     if (stage_ok && wpc == 0) {
         const uint64_t wn = (blocks + (uint64_t)cfg.num_cus - 1) / (uint64_t)cfg.num_cus;      // wavefronts per CU of this launch
         // (room for a quarter more: the dispatcher does not deal the blocks out evenly, and a CU that may hold no more than the
@@ -2227,9 +866,7 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     const uint32_t stage_cap = (uint32_t)std::min<size_t>(1024, ((dyn_lds - ring_b) / 64) & ~(size_t)15);
     ixl.stage_lds = (stage_ok && stage_cap >= 96) ? stage_cap : 0u;
     const bool use_ring = ring_b != 0 && ixl.stage_lds != 0u;
-    ixl.refill_batch = cfg.refill_batch > 0 ? (uint32_t)cfg.refill_batch : 16u;
     ixl.inwin = cfg.inwin ? 1u : 0u;
-    if (v == 13 && ixl.stage_lds == 0u) return hipErrorInvalidValue;                  // (cannot happen: the refill launch is capped)
     const bool use_ahead = ahead_ok && ixl.stage_lds != 0u;
     // pair-shared gathers (pml_kernel_flatp<..., PSH = 1>): the staged default walk on the plain or the look-ahead rows
     // Where: on tables beyond the reach of the per-CU TLBs (~2 GB), where a lane's two (four) 16-byte loads are as many
@@ -2238,115 +875,35 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     // copy (16 GB); below that the exchange costs about what the merged accesses give (random 25 / 50 / 100 M rows +4 / +5 / -2 %,
     // real 113 M rows +1.5 %, c2 -2.5 %, c3 -9 %: profiles/r04_pair_shared_gathers.txt).  "pair_loads" 1 / 0 forces it.
     const uint64_t walked_bytes = ix.r * (use_ahead ? 16ull : 8ull);
-    const bool use_pair = (cfg.pair_loads > 0 || (cfg.pair_loads < 0 && walked_bytes >= kPairLoadBytes)) && ixl.stage_lds != 0u && v == 10;
-    const SegArgs no_seg;
-    // every kernel that is handed more than 64 KiB of dynamic LDS must opt in first
-#define MOVI_SEG_0
-#define MOVI_SEG_1 , no_seg
-#define MOVI_LAUNCH_K(...) MOVI_LAUNCH_KX(0, __VA_ARGS__)
-#define MOVI_LAUNCH_KX(X, ...)                                                                              \
-    do {                                                                                                    \
-        if (dyn_lds > 65536) {                                                                              \
-            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&__VA_ARGS__),               \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds);  \
-            if (ea != hipSuccess) return ea;                                                                \
-        }                                                                                                   \
-        if (v == 13 && cfg.refill_blocks == 0) {                                                            \
-            /* the persistent grid must be resident as a whole: reads are dealt to its waves statically */   \
-            int mb = 0;                                                                                     \
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&mb, __VA_ARGS__, bt, dyn_lds) == hipSuccess && \
-                mb > 0 && (uint64_t)grid.x > (uint64_t)mb * (uint64_t)cfg.num_cus)                          \
-                grid.x = (unsigned)((uint64_t)mb * (uint64_t)cfg.num_cus);                                  \
-        }                                                                                                   \
-        hipLaunchKernelGGL((__VA_ARGS__), grid, block, dyn_lds, stream, ixl, d_bases, d_offsets, n_reads,   \
-                           d_out, d_err, d_stats, d_order, cls MOVI_SEG_##X);                               \
-    } while (0)
-#define MOVI_LAUNCH_PML(M, V, C) MOVI_LAUNCH_K(pml_kernel<M, V, C>)
-#ifndef MOVI_HA
-#define MOVI_HA 2
-#endif
-#define MOVI_LAUNCH_FLATP_H(M, H, C, S, R)                                                                  \
-    do {                                                                                                    \
-        if (ix.idx32) MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint32_t, H, C, S, R>);                         \
-        else MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint64_t, H, C, S, R>);                                  \
-    } while (0)
-#define MOVI_LAUNCH_FLATP_G(M, C, S, A, P)                                                                  \
-    do {                                                                                                    \
-        if (ix.idx32) MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint32_t, -1, C, S, 0, 0, 1, A, P, 1>);         \
-        else MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint64_t, -1, C, S, 0, 0, 1, A, P, 1>);                  \
-    } while (0)
-#define MOVI_LAUNCH_FLATP_STG(M, C, S, R)                                                                   \
-    do {                                                                                                    \
-        if (use_ring && R == 0) {                                                                           \
-            if (use_pair && use_ahead) MOVI_LAUNCH_FLATP_G(M, C, S, 1, 1);                                  \
-            else if (use_pair) MOVI_LAUNCH_FLATP_G(M, C, S, 0, 1);                                          \
-            else if (use_ahead) MOVI_LAUNCH_FLATP_G(M, C, S, 1, 0);                                         \
-            else MOVI_LAUNCH_FLATP_G(M, C, S, 0, 0);                                                        \
-        } else if (use_pair && R == 0 && use_ahead) {                                                       \
-            if (ix.idx32) MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint32_t, -1, C, S, 0, 0, 1, 1, 1>);        \
-            else MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint64_t, -1, C, S, 0, 0, 1, 1, 1>);                 \
-        } else if (use_pair && R == 0) {                                                                    \
-            if (ix.idx32) MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint32_t, -1, C, S, 0, 0, 1, 0, 1>);        \
-            else MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint64_t, -1, C, S, 0, 0, 1, 0, 1>);                 \
-        } else if (use_ahead) {                                                                             \
-            if (ix.idx32) MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint32_t, -1, C, S, R, 0, 1, 1>);           \
-            else MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint64_t, -1, C, S, R, 0, 1, 1>);                    \
-        } else {                                                                                            \
-            if (ix.idx32) MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint32_t, -1, C, S, R, 0, 1>);              \
-            else MOVI_LAUNCH_KX(1, pml_kernel_flatp<M, uint64_t, -1, C, S, R, 0, 1>);                       \
-        }                                                                                                   \
-    } while (0)
-#define MOVI_LAUNCH_FLATP_R(M, C, S, R)                                                                     \
-    do {                                                                                                    \
-        if (R == 1) MOVI_LAUNCH_FLATP_STG(M, C, S, 1);                                                      \
-        else if (wp && ixl.stage_lds) MOVI_LAUNCH_FLATP_STG(M, C, S, 0);                                    \
-        else if (wp) MOVI_LAUNCH_FLATP_H(M, -1, C, S, 0); else MOVI_LAUNCH_FLATP_H(M, MOVI_HA, C, S, 0);    \
-    } while (0)
-#define MOVI_LAUNCH_FLATP_S(M, C, S)                                                                        \
-    do {                                                                                                    \
-        if (v == 13) MOVI_LAUNCH_FLATP_R(M, C, S, 1); else MOVI_LAUNCH_FLATP_R(M, C, S, 0);                 \
-    } while (0)
-#define MOVI_LAUNCH_FLATP(M, C)                                                                             \
-    do {                                                                                                    \
-        if (ix.sep) MOVI_LAUNCH_FLATP_S(M, C, 1); else MOVI_LAUNCH_FLATP_S(M, C, 0);                        \
-    } while (0)
-#define MOVI_LAUNCH_FLAT(M)                                                                                 \
-    do {                                                                                                    \
-        if (ix.idx32) MOVI_LAUNCH_K(pml_kernel_flat<M, uint32_t, 0>);                                       \
-        else MOVI_LAUNCH_K(pml_kernel_flat<M, uint64_t, 0>);                                                \
-    } while (0)
-#define MOVI_BY_CLS(LAUNCH, ...)                                                                            \
-    do {                                                                                                    \
-        if (cm == 0) LAUNCH(__VA_ARGS__, 0); else if (cm == 1) LAUNCH(__VA_ARGS__, 1); else LAUNCH(__VA_ARGS__, 2); \
-    } while (0)
-    if (v == 0) MOVI_LAUNCH_PML(6, 0, 0); else if (v == 1) MOVI_BY_CLS(MOVI_LAUNCH_PML, 6, 1);
-    else if (v == 7) MOVI_LAUNCH_FLAT(6); else MOVI_BY_CLS(MOVI_LAUNCH_FLATP, 6);
+    const bool use_pair = (cfg.pair_loads > 0 || (cfg.pair_loads < 0 && walked_bytes >= kPairLoadBytes)) && ixl.stage_lds != 0u && v == 14;
+    hipError_t e = hipSuccess;
+    if (v == 14) {
+        WalkLaunch L;
+        L.grid = grid; L.block = block; L.dyn_lds = dyn_lds; L.stream = stream;
+        L.ix = ixl; L.bases = d_bases; L.offs = d_offsets; L.n = n_reads; L.out = d_out; L.err = d_err; L.stats = d_stats;
+        L.order = d_order; L.cls = cls;
+        L.cls_mode = cm; L.sep = ix.sep ? 1 : 0; L.stg = ixl.stage_lds != 0u ? 1 : 0;
+        L.ahd = use_ahead ? 1 : 0; L.psh = use_pair ? 1 : 0; L.ring = use_ring ? 1 : 0;
+        e = ix.idx32 ? launch_walk_u32(L, info) : launch_walk_u64(L, info);
+    } else {
+        // the base-synchronous kernels (every one takes at most 64 KiB of dynamic LDS: the cap's padding)
+        if (dyn_lds > 65536) dyn_lds = 65536 - 1024;
+#define MOVI_LAUNCH_PML(V, C) hipLaunchKernelGGL((pml_kernel<6, V, C>), grid, block, dyn_lds, stream, ixl, d_bases, d_offsets, n_reads, d_out, d_err, d_stats, d_order, cls)
+        if (v == 0) MOVI_LAUNCH_PML(0, 0);
+        else if (cm == 0) MOVI_LAUNCH_PML(1, 0);
+        else if (cm == 1) MOVI_LAUNCH_PML(1, 1);
+        else MOVI_LAUNCH_PML(1, 2);
+#undef MOVI_LAUNCH_PML
+        if (info) snprintf(info->kernel, sizeof(info->kernel), "pml_kernel<6, %d, %d>", v, v == 0 ? 0 : cm);
+        e = hipGetLastError();
+    }
     if (info) {
-        const char *it = ix.idx32 ? "unsigned int" : "unsigned long";
-        if (v == 0 || v == 1) snprintf(info->kernel, sizeof(info->kernel), "pml_kernel<6, %d, %d>", v, v == 0 ? 0 : cm);
-        else if (v == 7) snprintf(info->kernel, sizeof(info->kernel), "pml_kernel_flat<6, %s, 0>", it);
-        else snprintf(info->kernel, sizeof(info->kernel), "pml_kernel_flatp<6, %s, %d, %d, %d, %d, 0, %d, %d%s>", it, (wp || v == 13) ? -1 : MOVI_HA, cm,
-                      ix.sep ? 1 : 0, v == 13 ? 1 : 0, ixl.stage_lds ? 1 : 0, use_ahead ? 1 : 0,
-                      use_ring ? (use_pair ? ", 1, 1" : ", 0, 1") : (use_pair ? ", 1" : ""));
-        info->variant = (v == 10 && wp) ? 14 : v;
+        info->variant = v;
         info->block_threads = bt; info->waves_per_cu = wpc; info->segmented = 0; info->idx64 = ix.idx32 ? 0 : 1;
         info->staged = (int)ixl.stage_lds;
         info->ahead = use_ahead ? 1 : 0;
     }
-#undef MOVI_LAUNCH_PML
-#undef MOVI_LAUNCH_K
-#undef MOVI_LAUNCH_KX
-#undef MOVI_SEG_0
-#undef MOVI_SEG_1
-#undef MOVI_LAUNCH_FLAT
-#undef MOVI_LAUNCH_FLATP
-#undef MOVI_LAUNCH_FLATP_S
-#undef MOVI_LAUNCH_FLATP_R
-#undef MOVI_LAUNCH_FLATP_STG
-#undef MOVI_LAUNCH_FLATP_G
-#undef MOVI_LAUNCH_FLATP_H
-#undef MOVI_BY_CLS
-    return hipGetLastError();
+    return e;
 }
 
 // update_interval, src/move_structure_search.cpp:48-61 (get_char: the '$' row never equals a base): move the interval's
@@ -3540,7 +2097,7 @@ hipError_t launch_zml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
                                                                   stream, seg_ws, ragged_hint, &declined, seg_verdict);
         if (es == hipSuccess && !declined && info) {
             const bool sm = ix.r <= (3ull << 30) / 8 && ix.r >= 8 && n_bases >= 16;
-            if (sm) snprintf(info->kernel, sizeof(info->kernel), "zml_kernel_flat<%d, %s, 1>", mode, ix.idx32 ? "unsigned int" : "unsigned long");
+            if (sm) snprintf(info->kernel, sizeof(info->kernel), "zml_kernel_flat<%d, %s, 1, 0, 0>", mode, ix.idx32 ? "unsigned int" : "unsigned long");
             else snprintf(info->kernel, sizeof(info->kernel), "zml_kernel<%d, 1>", mode);
             info->variant = sm ? 1 : 0; info->block_threads = sm ? 64 : 256; info->waves_per_cu = 0; info->segmented = 1; info->staged = 0; info->ahead = 0;
             info->idx64 = ix.idx32 ? 0 : 1;
@@ -3558,9 +2115,13 @@ hipError_t launch_zml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     // state machine serves the tables beyond 3 GB too: 1 B rows 16.8 (kernel 0) / 13.9 (kernel 1) -> 25.0 Gbases/s; below 2 GB the
     // exchange costs more than it gives (c2: 38.2 -> 36.6), so there the lanes keep their own loads (profiles/r04_zml_ahead.txt;
     // "pair_loads" 0: the old policy, 1: pairs everywhere).
+    // (`ahead` and `pair` are settled BEFORE the kernel is picked: a caller who asks for the look-ahead rows forgoes the pairs, and
+    // beyond 3 GB the unpaired state machine is the slowest of the three -- 13.9 against kernel 0's 16.8 Gbases/s at 1 B rows)
     int v = cfg.zml_variant;
     const bool big = ix.r * 8ull >= kPairLoadBytes;
-    if (v < 0) v = (ix.r <= (3ull << 30) / 8 || (big && cfg.pair_loads != 0)) ? 1 : 0;
+    const bool want_ahead = cfg.zml_ahead != 0 && mode == 6 && ix.rows2 != nullptr;
+    const bool can_pair = !want_ahead && (cfg.pair_loads > 0 || (cfg.pair_loads < 0 && big));
+    if (v < 0) v = (ix.r <= (3ull << 30) / 8 || can_pair) ? 1 : 0;
     if (v == 1 && (ix.r < 8 || n_bases < 16)) v = 0;     // the clamped windows need >= 4 rows, the 16-base fetches 16 bytes
     const int bt = cfg.block_threads > 0 ? cfg.block_threads : (v == 1 ? 64 : 256);
     const uint64_t blocks = (n_reads + bt - 1) / bt;
@@ -3570,11 +2131,11 @@ hipError_t launch_zml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     // land without a fast-forward is complete without the target rows.  Lane iterations per base on c2 1.45 -> 0.98 -- and 37.3
     // instead of 38.2 Gbases/s (eight 16-byte loads per iteration instead of four, SIMT 0.72 -> 0.64; random 10 M-row table 35.9 ->
     // 35.0: profiles/r04_zml_ahead.txt), so it is an option, not the default.
-    const bool ahead = cfg.zml_ahead != 0 && v == 1 && mode == 6 && ix.rows2 != nullptr;
-    const bool pair = v == 1 && !ahead && (cfg.pair_loads > 0 || (cfg.pair_loads < 0 && big));
+    const bool ahead = want_ahead && v == 1;
+    const bool pair = v == 1 && can_pair;
     if (info) {
-        if (v == 1) snprintf(info->kernel, sizeof(info->kernel), "zml_kernel_flat<%d, %s, 0%s>", mode, ix.idx32 ? "unsigned int" : "unsigned long",
-                             ahead ? ", 1" : (pair ? ", 0, 1" : ""));
+        if (v == 1) snprintf(info->kernel, sizeof(info->kernel), "zml_kernel_flat<%d, %s, 0, %d, %d>", mode, ix.idx32 ? "unsigned int" : "unsigned long",
+                             ahead ? 1 : 0, pair ? 1 : 0);
         else snprintf(info->kernel, sizeof(info->kernel), "zml_kernel<%d, 0>", mode);
         info->variant = v; info->block_threads = bt; info->waves_per_cu = cfg.waves_per_cu > 0 ? cfg.waves_per_cu : 0; info->staged = 0; info->ahead = ahead ? 1 : 0;
         info->segmented = 0; info->idx64 = ix.idx32 ? 0 : 1;

@@ -51,7 +51,7 @@ struct DevIndex {
     uint32_t pad2_;
     const uint4 *ftab;
     uint32_t stage_lds;           // set per launch by launch_pml: bytes of dynamic LDS per lane for read staging (0 = none; 336 at cap 7)
-    uint32_t refill_batch;        // set per launch: idle lanes of a lane-refill wavefront switch when this many wait (pml_kernel_flatp<..., REFILL = 1>)
+    uint32_t pad4_;
     uint32_t inwin;               // set per launch: 1 = a reposition whose target is one of the window's rows is resolved in the same iteration
     uint32_t kmer_k;
     const uint4 *kmer;            // 4^K entries: x = row[31:0]; y = row[35:32] | off << 4 (12 bits) | match mask << 16 (K bits) |
@@ -84,7 +84,7 @@ struct DevStats {
     // SIMT efficiency of the lane state machines: iterations in which a lane had work / 64 x wave iterations
     unsigned long long lane_steps;
     unsigned long long wave_steps;
-    unsigned long long ticket;         // next unassigned read of the lane-refill kernels (zeroed with the counters)
+    unsigned long long pad0_;
     unsigned long long segments;       // segment-parallel PML: segments walked, reads walked again
     unsigned long long rewalked;
     unsigned long long pad_;
@@ -100,21 +100,18 @@ constexpr uint64_t kPairLoadBytes = 2ull << 30;   // walked tables of this size 
 
 struct LaunchCfg {
     int block_threads = 0;   // 0 = auto: 64 for the PML and count kernels and the ZML state machine (finest dispatch grain), 256 for the base-synchronous ZML kernel
-    // -1 auto; 0 first kernel (plain I/O), 1 base-synchronous packed I/O, 7 flat lane state machine,
-    // 10 flat lane state machine + row window, software-pipelined, 13 = 10 as a persistent grid with lane refill,
-    // 14 = 10 with the window-parallel advance (what auto picks)
+    // -1 auto; 0 first kernel (plain I/O; serves --logs), 1 base-synchronous packed I/O, 14 = the lane state machine over
+    // row windows, software-pipelined (what auto picks).  (7 / 10 / 13 -- the row-at-a-time state machine, the hop-by-hop
+    // advance, lane refill -- were A/B variants that never earned a default; removed in round 5.)
     int pml_variant = -1;
     int zml_variant = -1;  // -1 auto; 0 base-synchronous kernel, 1 lane state machine
     int num_cus = 256;
-    int waves_per_cu = 0;  // 0 = auto (variant 10 on big batches and variant 13: kCapWaves; else no cap); else cap resident waves per CU by padding the block's LDS allocation
+    int waves_per_cu = 0;  // 0 = auto (the state machine on big batches: kCapWaves; else no cap); else cap resident waves per CU by padding the block's LDS allocation
     int seg_len = 2048;    // PML: batches whose mean read length is >= 2 x seg_len are walked segment-parallel (0 = never) ...
     int seg_probe = 1;     // ... if a probe of the batch finds that walks started mid-read fall into step quickly (0 = always: tests;
                            // 2 = no probe and no read-back at all, the caller's seg_verdict decides: the launch stays asynchronous)
     int seg_verdict = 0;   // seg_probe == 2: 1 = cut eligible batches, 0 = one lane per read
     int stage_reads = 1;   // every lane keeps the next stretch of its read in the block's LDS (rolling for long reads); 0 = off: A/B
-    int refill_blocks = 0; // variant 13: size of the persistent grid in blocks; 0 = num_cus x waves per CU (tests shrink it
-                           // so that a few hundred reads already go through many refills per lane)
-    int refill_batch = 0;  // variant 13: idle lanes switch to their next reads when this many wait (0 = 16)
     int inwin = 1;         // repositions inside the window resolved in the same iteration (0 = off: A/B)
     int out_ring = -1;     // PMLs out through a ring in LDS: -1 = batches of long reads (launch_pml), 0 / 1 = never / wherever it fits (A/B)
     int classify_fused = -1; // movi_pml_classify_*: -1 auto, 1 = vector + bins fused into the walk, 0 = the walk, then classify_kernel over the vectors
@@ -125,7 +122,7 @@ struct LaunchCfg {
 // What a launch_* call actually launched (movi_last_launch): the policy lives in the launchers, so they say what they picked.
 struct LaunchInfo {
     char kernel[96] = {0};   // the dominant kernel's name as rocprofv3 prints it (template arguments included)
-    int variant = -1;        // PML: 0, 1, 7, 10, 13, 14; ZML: 0, 1; count: 0
+    int variant = -1;        // PML: 0, 1, 14; ZML: 0, 1; count: 0
     int block_threads = 0;
     int waves_per_cu = 0;    // resident-wavefront cap applied (0 = none)
     int segmented = 0;       // 1 = the segment-parallel plan ran (K1 + stitch + finalize around the named kernel)
@@ -186,6 +183,31 @@ struct ZSegArgs {
     SegTot *tot = nullptr;
     const uint8_t *read_fail = nullptr;
 };
+
+// One launch of the walk kernel (pml_kernel_flatp, movi_walk.hpp): its arguments plus the run-time choices that pick the
+// instantiation.  The launchers (launch_pml, launch_pml_segmented) fill it; the movi_walk*_u32 / _u64 translation units turn
+// it into a launch and name the kernel (every template argument) in `info`.
+struct WalkLaunch {
+    dim3 grid, block;
+    size_t dyn_lds = 0;
+    hipStream_t stream = nullptr;
+    DevIndex ix;
+    const uint8_t *bases = nullptr;
+    const uint64_t *offs = nullptr;
+    uint64_t n = 0;                       // reads (SEG 0 / 2) or an upper bound of the segments (SEG 1: the kernel reads the count)
+    uint16_t *out = nullptr;
+    uint8_t *err = nullptr;
+    DevStats *stats = nullptr;
+    const uint32_t *order = nullptr;
+    ClsArgs cls;
+    SegArgs seg;
+    int cls_mode = 0;                     // 0 = PML vector, 1 = vector + classification bins, 2 = bins only
+    int sep = 0, stg = 0, ahd = 0, psh = 0, ring = 0;   // separators index / reads staged through LDS / look-ahead rows / pair-shared gathers / PMLs out through the LDS ring
+};
+hipError_t launch_walk_u32(const WalkLaunch &L, LaunchInfo *info);
+hipError_t launch_walk_u64(const WalkLaunch &L, LaunchInfo *info);
+hipError_t launch_walkseg_u32(int seg, const WalkLaunch &L, LaunchInfo *info);   // seg: 1 = segments (K1), 2 = re-walked reads (K3)
+hipError_t launch_walkseg_u64(int seg, const WalkLaunch &L, LaunchInfo *info);
 
 // Device workspace of the segmented path, owned by whoever owns the stream (the handle; a pipeline slot): grow-only.
 struct SegWorkspace {

@@ -1,0 +1,11 @@
+// movi_walkseg_u32.hip -- the walk kernel's instantiations for 32-bit row indexes, segments (K1) and re-walked reads (K3) of the segment-parallel plan
+// (one translation unit per (index width, segment class): they compile in parallel; movi_walk.hpp has the kernel).
+#include "movi_walk.hpp"
+
+namespace movi {
+
+hipError_t launch_walkseg_u32(int seg, const WalkLaunch &L, LaunchInfo *info) {
+    return seg == 1 ? walk_dispatch<uint32_t, 1>(L, info) : (seg == 2 ? walk_dispatch<uint32_t, 2>(L, info) : hipErrorInvalidValue);
+}
+
+}  // namespace movi

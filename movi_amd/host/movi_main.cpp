@@ -271,7 +271,8 @@ int run_query(const Options &o) {
     }
     if (o.seg_len >= 0)
         for (auto *hd : handles) check(movi_set_option(hd, "seg_len", o.seg_len), "--seg-len");
-    if (o.ahead_rows >= 0)
+    // (the ZML parse does not walk on the look-ahead rows unless "zml_ahead" asks for it: `--zml --ahead-rows 1` builds nothing)
+    if (o.ahead_rows >= 0 && !(o.zml && o.ahead_rows == 1))
         for (auto *hd : handles) check(movi_set_option(hd, "ahead_rows", o.ahead_rows), "--ahead-rows");
     movi_index_desc_t desc;
     check(movi_index_get_desc(handles[0], &desc), "index description");

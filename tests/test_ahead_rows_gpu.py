@@ -52,7 +52,7 @@ def test_ahead_rows_vs_oracle(built_lib, golden_image, mode):
     gpu.set_option("kmer_k", 0)
     out0, st0 = gpu.query_pml_packed(bases, offs)
     li = gpu.last_launch()
-    assert li["ahead"] == 0 and li["staged"] == CAP and li["kernel"].endswith(", 0, 0, 1, 0>")
+    assert li["ahead"] == 0 and li["staged"] == CAP and li["kernel"].endswith(", 0, 1, 0, 0, 0>")
     assert (out0 == exp).all() and (st0.fast_forwards, st0.scans, st0.errors) == (ff, sc, 0)
     bins0 = gpu.classify_packed(bases, offs, 40, 4)
     gpu.set_option("ahead_rows", 1)
@@ -60,7 +60,7 @@ def test_ahead_rows_vs_oracle(built_lib, golden_image, mode):
         gpu.set_option("kmer_k", K)
         out, st = gpu.query_pml_packed(bases, offs)
         li = gpu.last_launch()
-        assert li["ahead"] == 1 and (li["staged"], li["waves_per_cu"]) == (CAP_AHEAD, 9) and li["kernel"].endswith(", 0, 0, 1, 1>")
+        assert li["ahead"] == 1 and (li["staged"], li["waves_per_cu"]) == (CAP_AHEAD, 9) and li["kernel"].endswith(", 0, 1, 1, 0, 0>")
         assert (out == exp).all(), (mode, K)
         assert (st.fast_forwards, st.scans, st.repositions, st.errors) == (ff, sc, st0.repositions, 0), (mode, K)
         assert st.lane_steps < 0.8 * st0.lane_steps, (mode, K)          # the point of it: most bases ride along
@@ -149,7 +149,7 @@ def test_ahead_rows_on_a_separators_index(built_lib):
     for K in (0, 9):
         gpu.set_option("kmer_k", K)
         out, st = gpu.query_pml_packed(bases, offs)
-        assert gpu.last_launch()["ahead"] == 1 and gpu.last_launch()["kernel"].endswith("0, 1, 0, 0, 1, 1>")
+        assert gpu.last_launch()["ahead"] == 1 and gpu.last_launch()["kernel"].endswith(", 0, 1, 0, 1, 1, 0, 0>")
         assert (out == exp).all() and (st.fast_forwards, st.scans, st.errors) == (ff, sc, 0), K
     gpu.close()
     cpu.close()
@@ -218,7 +218,7 @@ def test_segments_walk_on_the_look_ahead_rows(built_lib, golden_image, sep):
                 li = gpu.last_launch()
                 assert li["segmented"] == 1 and li["ahead"] == (ahead & stage) and (li["staged"] > 0) == bool(stage), (seg_len, li)
                 # (staged segments: their PMLs leave through the LDS ring -- RING = 1, the last template argument)
-                assert li["kernel"].endswith("0, 1, %d, %d%s>" % (stage, ahead & stage, ", 0, 1" if stage else ""))
+                assert li["kernel"].endswith(", 1, %d, %d, 0, %d>" % (stage, ahead & stage, stage))   # SEG, STG, AHD, PSH, RING
                 assert (out == exp).all(), (seg_len, ahead, stage)
                 assert (st.fast_forwards, st.scans, st.errors) == (ff, sc, 0), (seg_len, ahead, stage)
                 assert st.segments > len(reads)
@@ -312,7 +312,7 @@ def test_zml_on_the_look_ahead_rows_vs_oracle(built_lib, golden_image, mode):
         gpu.set_option("ahead_rows", 1)
         out, st = gpu.query_zml_packed(bases, offs)
         li = gpu.last_launch()
-        assert li["ahead"] == 1 and li["kernel"].endswith(", 0, 1>") and li["idx64"] == idx64
+        assert li["ahead"] == 1 and li["kernel"].endswith(", 0, 1, 0>") and li["idx64"] == idx64
         assert (out == exp).all(), (mode, idx64)
         assert (st.fast_forwards, st.scans, st.errors) == (st0.fast_forwards, st0.scans, 0), (mode, idx64)
     gpu.set_option("idx64", 0)
@@ -461,7 +461,7 @@ def test_pair_shared_gathers_vs_oracle(built_lib, golden_image, mode):
                 gpu.set_option("idx64", idx64)
                 out, st = gpu.query_pml_packed(bases, offs)
                 li = gpu.last_launch()
-                assert li["ahead"] == ahead and li["kernel"].endswith(", 0, 0, 1, %d, 1>" % ahead) and li["idx64"] == idx64, li
+                assert li["ahead"] == ahead and li["kernel"].endswith(", 0, 1, %d, 1, 0>" % ahead) and li["idx64"] == idx64, li
                 assert (out == exp).all(), (mode, ahead, K, idx64)
                 assert (st.fast_forwards, st.scans, st.errors) == (ff, sc, 0), (mode, ahead, K, idx64)
             gpu.set_option("idx64", 0)
@@ -480,7 +480,7 @@ def test_pml_out_ring_vs_oracle(built_lib, golden_image, mode):
     write per PML, a finished group of 16 as two 16-byte stores -- instead of the register packer.  On by itself for batches of
     long reads, "out_ring" 1 wherever the block's LDS holds it.  Same PML vectors, error bytes, counters and bins: reads of every
     length from 0 up (tails of 0 .. 15 PMLs stored one by one, reads shorter than a group), failing reads (zero-filled), long
-    reads rolling through the staged stretch, lane refill, pair-shared gathers, segments."""
+    reads rolling through the staged stretch, pair-shared gathers, segments."""
     import movi_amd
     from oracle.oracle import Oracle
     img = golden_image(mode)
@@ -499,13 +499,13 @@ def test_pml_out_ring_vs_oracle(built_lib, golden_image, mode):
     bins0 = gpu.classify_packed(bases, offs, 40, 4)
     lbins0 = gpu.classify_packed(lb, lo, 150, 8)
     gpu.set_option("out_ring", 1)
-    for ahead, pair, variant in ((1, 0, -1), (0, 0, -1), (1, 1, -1), (0, 1, -1), (1, 0, 13)):
+    for ahead, pair, variant in ((1, 0, -1), (0, 0, -1), (1, 1, -1), (0, 1, -1), (1, 0, 14)):
         gpu.set_option("ahead_rows", ahead)
         gpu.set_option("pair_loads", pair)
         gpu.set_option("pml_variant", variant)
         out, st = gpu.query_pml_packed(bases, offs)
         li = gpu.last_launch()
-        ringed = variant == -1                            # (lane refill keeps the packer)
+        ringed = True
         assert li["ahead"] == ahead and li["staged"] == (CAP if ahead == 0 else CAP_AHEAD) - (64 if ringed else 0), li   # the ring takes 4 KB of the block's LDS
         assert li["kernel"].endswith(", %d, 1>" % pair) == ringed, li
         assert (out == exp).all(), (mode, ahead, pair, variant)

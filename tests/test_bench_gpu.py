@@ -31,7 +31,7 @@ def test_bench_single_gpu_contract():
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "weak"
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1      # 1.6 MB of rows + the 256 MB top-of-walk table: not Infinity-Cache-resident
     assert d["roofline"]["lane_iterations_per_s"] > 0 and d["roofline"]["rows_read_per_s"] > 0
-    assert d["roofline"]["kernel"].startswith("pml_kernel_flatp<6, unsigned int, -1") and d["rccl_ranks"] == 0
+    assert d["roofline"]["kernel"].startswith("pml_kernel_flatp<6, unsigned int, 0, 0, 0, 1, 1,") and d["rccl_ranks"] == 0
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and d["parity_sample_ok"] is True
 
 

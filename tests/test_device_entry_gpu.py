@@ -166,11 +166,11 @@ def test_last_launch_reports_the_policy(engine6):
     gpu.query_pml_packed(bases, offs)
     li = gpu.last_launch()
     # the default walk: reads staged through LDS (a small batch: uncapped, 336 bases per lane) on the look-ahead rows (a small table)
-    assert li["kernel"] == "pml_kernel_flatp<6, unsigned int, -1, 0, 0, 0, 0, 1, 1>" and li["variant"] == 14
+    assert li["kernel"] == "pml_kernel_flatp<6, unsigned int, 0, 0, 0, 1, 1, 0, 0>" and li["variant"] == 14
     assert li["block_threads"] == 64 and li["waves_per_cu"] == 0 and li["segmented"] == 0 and li["staged"] == 336 and li["ahead"] == 1
     gpu.set_option("stage_reads", 0)
     gpu.query_pml_packed(bases, offs)
-    assert gpu.last_launch()["kernel"] == "pml_kernel_flatp<6, unsigned int, -1, 0, 0, 0, 0, 0, 0>" and gpu.last_launch()["staged"] == 0
+    assert gpu.last_launch()["kernel"] == "pml_kernel_flatp<6, unsigned int, 0, 0, 0, 0, 0, 0, 0>" and gpu.last_launch()["staged"] == 0
     gpu.set_option("stage_reads", 1)
     gpu.set_option("pml_variant", 1)
     gpu.query_pml_packed(bases, offs)
@@ -179,7 +179,7 @@ def test_last_launch_reports_the_policy(engine6):
     gpu.query_count_packed(bases, offs)
     assert gpu.last_launch()["kernel"] == "count_kernel_v0<6, 1>" and gpu.last_launch()["ahead"] == 1   # on the look-ahead rows (a small table)
     gpu.query_zml_packed(bases, offs)
-    assert gpu.last_launch()["kernel"] == "zml_kernel_flat<6, unsigned int, 0>"
+    assert gpu.last_launch()["kernel"] == "zml_kernel_flat<6, unsigned int, 0, 0, 0>"
 
 
 @pytest.mark.parametrize("mode", [6, 8, 7])

@@ -101,7 +101,7 @@ def test_pml_ragged_reads_vs_oracle(engines, mode):
 
 
 @pytest.mark.parametrize("mode", [6, 8])
-@pytest.mark.parametrize("variant", [0, 1, 7, 10, 13, 14])
+@pytest.mark.parametrize("variant", [0, 1, 14])
 def test_pml_kernel_variants_vs_oracle(engines, mode, variant):
     """Every selectable kernel variant is held to the same bit-exact bar, including
     reads whose length is not a multiple of the 8-step packing and unaligned offsets."""
@@ -113,23 +113,20 @@ def test_pml_kernel_variants_vs_oracle(engines, mode, variant):
     reads += [b"", b"A", b"AC", b"ACGTACG", b"ACGTACGT", b"ACGTACGTA", b"N" * 9, b"T" * 15, b"G" * 16, b"C" * 17]
     bases, offs = pack(reads)
     gpu.set_option("pml_variant", variant)
-    gpu.set_option("refill_blocks", 2)            # variant 13: 128 lanes for 610 reads, i.e. ~5 refills per lane
     try:
         out, st = gpu.query_pml_packed(bases, offs)
     finally:
         gpu.set_option("pml_variant", -1)
-        gpu.set_option("refill_blocks", 0)
     exp, ff, sc = cpu.pml_batch(bases, offs, threads=4)
     assert (out == exp).all()
     assert (st.fast_forwards, st.scans, st.errors) == (ff, sc, 0)
-    if variant == 13:                             # the refill path really ran: 2 wavefronts did all the work
-        assert st.wave_steps > 0 and st.lane_steps > 0.5 * 64 * st.wave_steps
 
 
 @pytest.mark.parametrize("blocks", [1, 3, 7])
-def test_lane_refill_ragged_batches_vs_oracle(engines, blocks):
-    """The lane-refill kernel (variant 13) on batches built to stress the refill: empty reads between long ones, a run of
-    empty reads longer than a wavefront, one-base reads, fewer reads than lanes in the last round, illegal bases."""
+def test_ragged_batches_vs_oracle(engines, blocks):
+    """Batches built to stress lanes that start and finish out of step (written for the lane-refill kernel, which round 5
+    removed; kept for the default walk): empty reads between long ones, a run of empty reads longer than a wavefront, one-base
+    reads, fewer reads than lanes in the last wavefront, illegal bases."""
     from oracle import build_index as B
     gpu, cpu = engines[6]
     ref = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))[0][1]
@@ -140,13 +137,11 @@ def test_lane_refill_ragged_batches_vs_oracle(engines, blocks):
     reads = [reads[i] for i in order[:900]] + [b""] * 70 + [reads[i] for i in order[900:]]
     bases, offs = pack(reads)
     exp, ff, sc = cpu.pml_batch(bases, offs, threads=4)
-    gpu.set_option("pml_variant", 13)
-    gpu.set_option("refill_blocks", blocks)
+    gpu.set_option("waves_per_cu", blocks)        # (also: the occupancy cap at 1 / 3 / 7 wavefronts per CU)
     try:
         out, st, err, rc = gpu.query_pml_packed(bases, offs, want_err=True)
     finally:
-        gpu.set_option("pml_variant", -1)
-        gpu.set_option("refill_blocks", 0)
+        gpu.set_option("waves_per_cu", 0)
     assert rc == 0 and not err.any()
     assert (out == exp).all()
     assert (st.fast_forwards, st.scans, st.errors) == (ff, sc, 0)
@@ -306,7 +301,7 @@ def test_launch_options_are_bounded(engines):
             gpu.set_option("block_threads", bt)
             for wpc in (1, 2, 4):                             # 159 KiB / 79 KiB / 39 KiB of dynamic LDS per block of 64
                 gpu.set_option("waves_per_cu", wpc)
-                for variant in (1, 7, 10, 14):
+                for variant in (1, 14):
                     gpu.set_option("pml_variant", variant)
                     out, st = gpu.query_pml_packed(bases, offs)
                     assert (out == exp).all() and st.errors == 0, (bt, wpc, variant)
@@ -469,7 +464,7 @@ def test_classification_bins_on_device(engines, bin_width, thr):
 
 
 @pytest.mark.parametrize("mode", [6, 8])
-@pytest.mark.parametrize("variant", [1, 10, 13, 14])
+@pytest.mark.parametrize("variant", [1, 14])
 def test_fused_classification_kernels(engines, mode, variant):
     """movi_pml_classify_device: the bins fused into the PML walk, with and without the PML vector, in both
     shipped kernels, against the bins of the oracle's PML vectors and against the standalone
@@ -490,7 +485,6 @@ def test_fused_classification_kernels(engines, mode, variant):
     d_offs = torch.from_numpy(offs.view(np.int64).copy()).to(dev)
     exp_pml, _, _ = cpu.pml_batch(bases, offs, threads=4)
     gpu.set_option("pml_variant", variant)
-    gpu.set_option("refill_blocks", 3)
     try:
         for bin_width, thr in ((150, 7), (40, 3), (1, 1)):
             exp = [classify_py(exp_pml[int(offs[i]):int(offs[i + 1])], thr, bin_width) if len(r) else None
@@ -527,7 +521,6 @@ def test_fused_classification_kernels(engines, mode, variant):
                     assert int(d_out.abs().sum().item()) == 0          # nothing was written
     finally:
         gpu.set_option("pml_variant", -1)
-        gpu.set_option("refill_blocks", 0)
 
 
 @pytest.mark.parametrize("alphabet", [b"ACGT", b"ACG", b"AT", b"GT", b"C"])
@@ -566,7 +559,7 @@ def test_fuzz_small_indexes(built_lib, tmp_path, alphabet):
             subprocess.check_call([tool, "fasta", str(fa), str(mode), out_dir], stderr=subprocess.DEVNULL)
             img = open(os.path.join(out_dir, "index.movi"), "rb").read()
             gpu, cpu = movi_amd.MoveIndex.from_image(img), Oracle(img)
-            for variant in (1, 7, 10, 14):
+            for variant in (1, 14):
                 gpu.set_option("pml_variant", variant)
                 out, st = gpu.query_pml_packed(bases, offs)
                 exp, ff, sc = cpu.pml_batch(bases, offs, threads=2)
@@ -601,7 +594,7 @@ def test_real_bwt_pangenome_vs_oracle(built_lib, tmp_path, mode):
     bases = np.fromfile(os.path.join(out, "reads.bin"), np.uint8)
     offs = (np.arange(20001, dtype=np.uint64) * np.uint64(150))
     exp, ff, sc = cpu.pml_batch(bases, offs, threads=8)
-    for variant in (1, 7, 10, 14):
+    for variant in (1, 14):
         gpu.set_option("pml_variant", variant)
         got, st = gpu.query_pml_packed(bases, offs)
         assert (got == exp).all() and (st.fast_forwards, st.scans, st.errors) == (ff, sc, 0)
@@ -635,7 +628,7 @@ def test_separators_reference_index_vs_oracle(built_lib, mode):
     reads += [s for _, s in read_fastx(os.path.join(GOLDEN, "sample.fastq"))]
     bases, offs = pack(reads)
     exp, ff, sc = cpu.pml_batch(bases, offs, threads=4)
-    for variant in (0, 1, 7, 10, 14):
+    for variant in (0, 1, 14):
         gpu.set_option("pml_variant", variant)
         out, st = gpu.query_pml_packed(bases, offs)
         assert (out == exp).all(), variant
@@ -665,7 +658,7 @@ def test_separators_fuzz_many_sequences(built_lib, seed):
         img = B.serialize(B.build_rows(bwt, thr, mode))
         gpu, cpu = movi_amd.MoveIndex.from_image(img), Oracle(img)
         exp, ff, sc = cpu.pml_batch(bases, offs, threads=2)
-        for variant in (0, 1, 7, 10, 14):
+        for variant in (0, 1, 14):
             gpu.set_option("pml_variant", variant)
             out, st = gpu.query_pml_packed(bases, offs)
             assert (out == exp).all(), (seed, mode, variant)
@@ -765,7 +758,7 @@ def test_64bit_index_instantiations(built_lib, golden_image, mode):
     bases, offs = pack(reads)
     exp, ff, sc = cpu.pml_batch(bases, offs, threads=4)
     gpu.set_option("idx64", 1)
-    for variant in ((7, 10, 14) if mode != 7 else (-1,)):
+    for variant in ((1, 14) if mode != 7 else (-1,)):
         gpu.set_option("pml_variant", variant)
         out, st = gpu.query_pml_packed(bases, offs)
         assert (out == exp).all(), (mode, variant)

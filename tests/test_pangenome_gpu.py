@@ -53,13 +53,13 @@ def test_c2_pangenome_batch_vs_oracle(pangenome):
     lo, cnt = 490_000, 20_000                                  # 20 k reads from the middle of the batch
     sb, so = bases[lo * L: (lo + cnt) * L], offs[: cnt + 1]
     exp, eff, esc = cpu.pml_batch(sb, so, threads=8)
-    for ahead, variant in ((1, -1), (0, -1), (1, 13)):
+    for ahead, variant in ((1, -1), (0, -1), (1, 14)):
         gpu.set_option("ahead_rows", ahead)
         gpu.set_option("pml_variant", variant)
         gpu.pml_device(d_bases.data_ptr(), d_offs.data_ptr(), n, n * L, d_out.data_ptr(), d_err.data_ptr())
         torch.cuda.synchronize()
         li = gpu.last_launch()
-        assert li["ahead"] == ahead and li["variant"] == (13 if variant == 13 else 14), li
+        assert li["ahead"] == ahead and li["variant"] == 14, li
         got = d_out[lo * L: (lo + cnt) * L].cpu().numpy().view(np.uint16)
         assert (got == exp).all(), (ahead, variant)
         assert int(d_err.sum().item()) == 0
@@ -112,7 +112,7 @@ def test_c3_classify_at_size(pangenome):
         gpu.pml_classify_device(d_bases.data_ptr(), d_offs.data_ptr(), n, n * L, bin_width, thr,
                                 d_out.data_ptr() if with_vector else 0, d_a.data_ptr(), d_b.data_ptr(), d_s.data_ptr(), d_err.data_ptr())
         torch.cuda.synchronize()
-        assert gpu.last_launch()["kernel"].startswith("pml_kernel_flatp<6, unsigned int, -1, %d," % cls), name
+        assert gpu.last_launch()["kernel"].startswith("pml_kernel_flatp<6, unsigned int, %d," % cls), name
         assert int(d_err.sum().item()) == 0
         res[name] = (d_a.cpu().numpy(), d_b.cpu().numpy(), d_s.cpu().numpy())
         if name == "fused":

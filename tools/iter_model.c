@@ -91,7 +91,10 @@ static uint32_t walk(const uint8_t *rd, uint32_t len, uint32_t top_k, const Desi
                 // the target sits in the window already held: resolved in the arrival iteration itself
             } else {
             it++; t->it_mism++;                      // the scan's first window (the mismatch step itself emitted nothing: it was the arrival iteration)
-            if (d->side && sc <= (uint32_t)d->side_reach) {
+            // side = 2: the hint counts the rows BEYOND the window's edge (1 .. side_reach), so that its reach does not depend on where in the window the row sits
+            const uint64_t edge = down ? (from / W) * W + (W - 1) : (from / W) * W;
+            const uint64_t beyond = down ? idx - edge : edge - idx;
+            if (d->side == 2 ? beyond <= (uint64_t)d->side_reach : (d->side && sc <= (uint32_t)d->side_reach)) {
                 // side array told the distance: the one iteration above fetched the target's window directly
             } else {
                 const uint64_t first = down ? from + 1 : from - 1;
@@ -131,6 +134,7 @@ int main(int argc, char **argv) {
     const Design designs[] = {          // S, W, side, side_reach, inwin, own
         {0, 4, 0, 0, 0, 0}, {1, 4, 0, 0, 0, 0}, {1, 4, 0, 0, 0, 1}, {1, 4, 0, 0, 1, 0}, {2, 4, 0, 0, 0, 0}, {2, 4, 0, 0, 1, 0}, {3, 4, 0, 0, 1, 0},
         {7, 4, 0, 0, 1, 0}, {1, 4, 1, 64, 1, 0}, {2, 4, 1, 64, 1, 0}, {1, 2, 0, 0, 1, 0}, {1, 8, 0, 0, 1, 0}, {2, 8, 0, 0, 1, 0},
+        {1, 4, 1, 7, 1, 0}, {1, 4, 1, 15, 1, 0}, {1, 4, 1, 31, 1, 0}, {1, 4, 1, 63, 1, 0}, {1, 4, 2, 7, 1, 0}, {1, 4, 2, 15, 1, 0},  // round 5: reposition hints of 3 .. 6 bits in the rows' spare bits
     };
     printf("r = %llu rows, %llu reads x %u, top-of-walk K = %u\n", (unsigned long long)r, (unsigned long long)n_reads, L, top_k);
     printf("%-36s %9s %9s | %7s %7s %7s %7s | %7s | %6s %6s %6s\n", "design", "iter/base", "SIMT", "arrive", "ff-win", "mismat", "scanwin",
