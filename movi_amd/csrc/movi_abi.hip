@@ -822,6 +822,7 @@ static int build_ahead(movi_index *ix, hipStream_t s, bool by_itself) {
     if (e != hipSuccess) { (void)hipFree(ix->d_rows2); ix->d_rows2 = nullptr; return fail_hip(e, "building the look-ahead rows"); }
     ix->dev.rows2 = ix->d_rows2;
     ix->dev.rows2_tail = tail;
+    ix->dev.hints = ahead_rows_hinted(ix->desc.r) ? 1u : 0u;   // (the copy's ids are 32 bits wide and its spare bits hold reposition hints)
     ix->ahead_no_ff = h_tally[1] ? (double)h_tally[0] / (double)h_tally[1] : 0.0;
     ix->ahead_tallied = true;
     ix->dev.rows2_count = (!by_itself || ix->ahead_no_ff >= kAheadCountRatio) ? 1u : 0u;
@@ -908,6 +909,11 @@ int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
         ix->cfg.out_ring = (int)value;
         return MOVI_OK;
     }
+    if (!strcmp(key, "repo_hints")) {                        // A/B: mismatches whose scan leaves the row window jump by the look-ahead rows' reposition hints
+        if (value != 0 && value != 1) return fail(MOVI_ERR_ARG, "repo_hints must be 0 or 1");
+        ix->cfg.hints = (int)value;
+        return MOVI_OK;
+    }
     if (!strcmp(key, "inwin_repo")) {                        // A/B: repositions inside the row window resolved in the same iteration
         if (value != 0 && value != 1) return fail(MOVI_ERR_ARG, "inwin_repo must be 0 or 1");
         ix->cfg.inwin = (int)value;
@@ -970,6 +976,7 @@ int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
         ix->dev.rows2 = nullptr;
         ix->dev.rows2_tail = 0;
         ix->dev.rows2_count = 0;
+        ix->dev.hints = 0;
         if (ix->d_rows2) (void)hipFree(ix->d_rows2);
             ix->d_rows2 = nullptr;
         ix->ahead_auto = 0;                                  // the caller's choice from here on
@@ -1775,6 +1782,7 @@ static int count_device(movi_index_t *ix, const uint8_t *d_bases, const uint64_t
             // kept for a caller who may never ask for PMLs -- the first PML query builds it again (85 us per 14 M rows)
             ix->dev.rows2 = nullptr;
             ix->dev.rows2_tail = 0;
+            ix->dev.hints = 0;
             (void)hipFree(ix->d_rows2);
             ix->d_rows2 = nullptr;
             ix->count_declined_ahead = true;

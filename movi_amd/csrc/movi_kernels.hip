@@ -242,11 +242,13 @@ __device__ __forceinline__ void tally_add(unsigned long long *tally, uint32_t a,
 __device__ __forceinline__ uint2 ahead_half(uint2 rj, uint64_t j2) {
     return make_uint2((uint32_t)j2, row_n<6>(rj) | (row_off<6>(rj) << 11) | (row_c<6>(rj) << 22) | ((uint32_t)(j2 >> 32) << 25) | 0x80000000u);
 }
-template <int MODE>
+// Round 5: HINTS = 1 (tables of fewer than 2^32 - 1 rows: DevIndex::hints has the layout) -- the row's copy and its entry also carry
+// the row's three reposition hints, and ids are stored 32 bits wide (an id that is not a row as 0xFFFFFFFF).
+template <int MODE, int HINTS>
 __global__ __launch_bounds__(256) void ahead_rows_kernel(DevIndex ix, uint8_t *__restrict__ out, uint64_t tail, unsigned long long *tally) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool in = i < ix.r;
-    const uint2 row = in ? load_row<MODE>(ix.rows, i) : make_uint2(0u, 0u);
+    uint2 row = in ? load_row<MODE>(ix.rows, i) : make_uint2(0u, 0u);
     const uint64_t j = in ? row_id<MODE>(row, i, ix) : ix.r;
     uint2 e = make_uint2(0u, 0u);
     uint32_t no_ff = 0;
@@ -262,6 +264,38 @@ __global__ __launch_bounds__(256) void ahead_rows_kernel(DevIndex ix, uint8_t *_
         if ((threadIdx.x & 63) == 0) tally_add(tally, a, b);
     }
     if (!in) return;
+    if (HINTS) {
+        // the window the walk sees row i in (pml_kernel_flatp: win_base) and the nearest run of each other base beyond its edges
+        const uint64_t wb_last = ix.r - 4;
+        const uint64_t wb = (i & ~3ull) < wb_last ? (i & ~3ull) : wb_last;
+        const uint32_t c = row_c<MODE>(row);
+        uint32_t h = 0;
+        if (ix.sep == 0u && ix.sigma == 4u && i != ix.end_bwt_idx) {
+            for (uint32_t k = 0; k < 3u; ++k) {
+                const uint32_t a = k < c ? k : k + 1u;    // the base whose slot is k: alphamap_3[c][a] = a - (a > c), src/utils.cpp:5-8
+                if (a > 3u) continue;
+                uint32_t d = 0;
+                if (row_thr<MODE>(row, k) == 0u) {        // threshold 0 <= offset: reposition_down
+                    const uint64_t edge = wb + 3;
+                    bool inside = false;
+                    for (uint64_t t = i + 1; t <= edge && t < ix.r; ++t) inside = inside || row_c<MODE>(load_row<MODE>(ix.rows, t)) == a;
+                    if (!inside)
+                        for (uint64_t t = edge + 1; t <= edge + 7 && t < ix.r; ++t)
+                            if (row_c<MODE>(load_row<MODE>(ix.rows, t)) == a) { d = (uint32_t)(t - edge); break; }
+                } else {                                  // threshold n > offset: reposition_up
+                    bool inside = false;
+                    for (uint64_t t = wb; t < i; ++t) inside = inside || row_c<MODE>(load_row<MODE>(ix.rows, t)) == a;
+                    if (!inside)
+                        for (uint64_t s = 1; s <= 7 && s <= wb; ++s)
+                            if (row_c<MODE>(load_row<MODE>(ix.rows, wb - s)) == a) { d = (uint32_t)s; break; }
+                }
+                h |= d << (3u * k);
+            }
+        }
+        if (j >= ix.r) row.x = 0xFFFFFFFFu;               // (r < 2^32 - 1: still "not a row", move_structure.cpp:63-65)
+        row.y = (row.y & 0x0FFFFFFFu) | (h << 28);
+        e.y = (e.y & ~(0x3Fu << 25)) | (((h >> 4) & 0x3Fu) << 25);
+    }
     uint8_t *line = out + (i >> 3) * 128u + (i & 7u) * 8u;
     __builtin_memcpy(line, &row, 8);
     __builtin_memcpy(line + 64, &e, 8);
@@ -301,6 +335,8 @@ hipError_t tally_no_ff_share(int kmode, const DevIndex &ix, uint64_t stride, uns
 
 uint64_t ahead_rows_bytes(uint64_t r) { return ((r + 7) / 8 + 1) * 128; }
 
+bool ahead_rows_hinted(uint64_t r) { return r >= 8 && r < 0xFFFFFFFFull; }
+
 hipError_t build_ahead_rows(int kmode, const DevIndex &ix, uint8_t *d_rows2, uint64_t *tail, hipStream_t stream, unsigned long long *d_tally) {
     if (!d_rows2 || !tail || ix.r < 8 || (ix.r >> 36) != 0 || kmode != 6) return hipErrorInvalidValue;
     *tail = ((ix.r + 7) / 8) * 128;
@@ -308,7 +344,8 @@ hipError_t build_ahead_rows(int kmode, const DevIndex &ix, uint8_t *d_rows2, uin
     if (e != hipSuccess) return e;
     const uint64_t blocks = (ix.r + 255) / 256;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(ahead_rows_kernel<6>, dim3((unsigned)blocks), dim3(256), 0, stream, ix, d_rows2, *tail, d_tally);
+    if (ahead_rows_hinted(ix.r)) hipLaunchKernelGGL((ahead_rows_kernel<6, 1>), dim3((unsigned)blocks), dim3(256), 0, stream, ix, d_rows2, *tail, d_tally);
+    else hipLaunchKernelGGL((ahead_rows_kernel<6, 0>), dim3((unsigned)blocks), dim3(256), 0, stream, ix, d_rows2, *tail, d_tally);
     return hipGetLastError();
 }
 
@@ -731,6 +768,7 @@ static hipError_t launch_pml_segmented(const DevIndex &ix, const uint8_t *d_base
     // launch_pml's policy -- the cap's padding, or what the launch's wavefronts per CU leave of the CU's LDS)
     DevIndex ixl = ix;
     ixl.inwin = cfg.inwin ? 1u : 0u;
+    ixl.hint_w = (cfg.hints != 0 && ix.hints != 0u && ix.rows2 != nullptr) ? 3u : 0u;
     // (pair-shared gathers on tables beyond the TLBs' reach: launch_pml's rule)
     const bool seg_pair = (cfg.pair_loads > 0 || (cfg.pair_loads < 0 && ix.r * (ix.rows2 != nullptr ? 16ull : 8ull) >= kPairLoadBytes));
     size_t dyn_lds = 0;
@@ -867,6 +905,7 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     ixl.stage_lds = (stage_ok && stage_cap >= 96) ? stage_cap : 0u;
     const bool use_ring = ring_b != 0 && ixl.stage_lds != 0u;
     ixl.inwin = cfg.inwin ? 1u : 0u;
+    ixl.hint_w = (cfg.hints != 0 && ix.hints != 0u && ix.rows2 != nullptr) ? 3u : 0u;
     const bool use_ahead = ahead_ok && ixl.stage_lds != 0u;
     // pair-shared gathers (pml_kernel_flatp<..., PSH = 1>): the staged default walk on the plain or the look-ahead rows
     // Where: on tables beyond the reach of the per-CU TLBs (~2 GB), where a lane's two (four) 16-byte loads are as many
@@ -914,22 +953,29 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
 // instead of one row: the trips of this loop -- max over the wave's lanes -- were most of a ZML step on divergent reads.
 // Row / window / look-ahead entry of the table the count query walks on: AH = 0 the plain rows, AH = 1 the look-ahead copy
 // (DevIndex::rows2: 8 rows + their 8 entries per 128-byte line, the last window in a line of its own).
+// (The copy's reposition hints -- DevIndex::hints: y[31:28] of a row, y[30:25] of an entry -- are the PML walk's business: masked
+// off here, which leaves the 32-bit ids of that form as they are.)
 template <int MODE, int AH>
 __device__ __forceinline__ uint2 tab_row(const DevIndex &ix, uint64_t i) {
     if (!AH) return load_row<MODE>(ix.rows, i);
     uint2 v;
     __builtin_memcpy(&v, ix.rows2 + (i >> 3) * 128u + (i & 7u) * 8u, 8);
+    v.y &= ix.hints ? 0x0FFFFFFFu : 0xFFFFFFFFu;
     return v;
 }
 __device__ __forceinline__ uint2 tab_entry(const DevIndex &ix, uint64_t i) {
     uint2 v;
     __builtin_memcpy(&v, ix.rows2 + (i >> 3) * 128u + 64u + (i & 7u) * 8u, 8);
+    v.y &= ix.hints ? ~(0x3Fu << 25) : 0xFFFFFFFFu;
     return v;
 }
 template <int MODE, int AH>
 __device__ __forceinline__ void tab_window(const DevIndex &ix, uint64_t wb, uint2 (&w)[4]) {   // wb: aligned, or r - 4 (the last window)
-    if (!AH) load_window<MODE>(ix.rows, wb, w);
-    else load_window<MODE>(ix.rows2 + (wb < ix.r - 4 ? (wb >> 3) * 128u + (wb & 4u) * 8u : ix.rows2_tail), 0, w);
+    if (!AH) { load_window<MODE>(ix.rows, wb, w); return; }
+    load_window<MODE>(ix.rows2 + (wb < ix.r - 4 ? (wb >> 3) * 128u + (wb & 4u) * 8u : ix.rows2_tail), 0, w);
+    const uint32_t ym = ix.hints ? 0x0FFFFFFFu : 0xFFFFFFFFu;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) w[t].y &= ym;
 }
 
 template <int MODE, int AH = 0>
@@ -1703,6 +1749,11 @@ __global__ __launch_bounds__(256) void zml_kernel_flat(DevIndex ix, const uint8_
         if (PSH) {                                           // the halves the pair loaded for each other change hands
             pair_assemble(odd_lane, raw_s[0], raw_s[1], ws);
             pair_assemble(odd_lane, raw_e[0], raw_e[1], we);
+        }
+        if (AH) {                                            // the copy's reposition hints (DevIndex::hints) are the walk's business: masked off
+            const uint32_t ym = ix.hints ? 0x0FFFFFFFu : 0xFFFFFFFFu, em = ix.hints ? ~(0x3Fu << 25) : 0xFFFFFFFFu;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { ws[t].y &= ym; we[t].y &= ym; es[t].y &= em; ee[t].y &= em; }
         }
         // ---- 1. walk each end as far as its window reaches (start end first: shrink_interval's order), in closed form as
         // pml_kernel_flatp's window_advance: a fast-forward passes row i iff the offset covers the running sum of the

@@ -72,7 +72,20 @@ struct DevIndex {
     // run sequences: 0.51, -12 %: the copy's lines hold half as many rows for the interval shrink) -- decided from that
     // ratio, which the builder tallies, when the copy is built by itself; a caller who asks for the copy gets it for both.
     uint32_t rows2_count;
-    uint32_t pad3_;
+    // Round 5 -- REPOSITION HINTS in the look-ahead copy of a table with fewer than 2^32 - 1 rows (hints = 1).  There the four
+    // high id bits of a row (y[31:28]) and of its entry (y[28:25]) are zero and two entry bits (y[30:29]) were free: ten spare
+    // bits per row.  Nine of them hold, for each of the row's three threshold slots k (= alphamap_3[c(row)][a], the same slot
+    // that holds the threshold bit of read base a): how many rows BEYOND THE EDGE OF THE ROW'S WINDOW, in the direction the
+    // threshold bit gives (0 = down, 1 = up: get_thresholds is n or 0 and offset < n, src/move_structure.cpp:295-309), the
+    // nearest run of base a lies -- 1 .. 7, or 0 for "inside the window, further than 7 rows, nowhere, or this is the '$' row
+    // (whose direction depends on the offset)".  A mismatch whose scan (reposition_up / _down, src/move_structure_query.cpp:188-232)
+    // would leave the window then gathers the TARGET's window in its next iteration instead of walking there window by window.
+    // hint of slot k = (h >> 3 k) & 7 with h = row.y >> 28 | (entry.y >> 25 & 0x3F) << 4.
+    // In this form ids in rows2 are 32 bits wide: x alone (a row whose id is not a row reads x = 0xFFFFFFFF), and every
+    // reader of rows2 masks the hint bits off (tab_row / tab_entry / the walk kernel).
+    uint32_t hints;
+    // set per launch: width of a hint field the walk looks at -- 3 = use the hints, 0 = ignore them ("repo_hints" 0: A/B)
+    uint32_t hint_w;
 };
 
 // Device counters of one query call.
@@ -116,6 +129,7 @@ struct LaunchCfg {
     int out_ring = -1;     // PMLs out through a ring in LDS: -1 = batches of long reads (launch_pml), 0 / 1 = never / wherever it fits (A/B)
     int classify_fused = -1; // movi_pml_classify_*: -1 auto, 1 = vector + bins fused into the walk, 0 = the walk, then classify_kernel over the vectors
     int pair_loads = -1;   // the lanes of a pair fetch their row windows together (pml_kernel_flatp<..., PSH = 1>): -1 auto (tables of 2 GB and more), 0 never, 1 always
+    int hints = 1;         // 1: mismatches whose scan leaves the row window jump by the reposition hints of the look-ahead rows (DevIndex::hints); 0 = off: A/B
     int zml_ahead = 0;     // 1: zml_kernel_flat<6, T, 0, 1> on the look-ahead rows where they exist (a third fewer iterations, no faster: opt-in)
 };
 
@@ -256,9 +270,10 @@ hipError_t build_kmer_table(const DevIndex &ix, uint32_t K, uint4 *d_table, hipS
 // Look-ahead rows (DevIndex::rows2): ahead_rows_bytes(r) bytes at d_rows2, written by one kernel (a gather of id(id(i))
 // per row); *tail = DevIndex::rows2_tail.  Thresholds types (kmode 6: the PML walk's rows), r >= 8.
 uint64_t ahead_rows_bytes(uint64_t r);
+bool ahead_rows_hinted(uint64_t r);    // the copy of a table of r rows carries reposition hints and 32-bit ids (DevIndex::hints)
 hipError_t build_ahead_rows(int kmode, const DevIndex &ix, uint8_t *d_rows2, uint64_t *tail, hipStream_t stream,
-                            unsigned long long *d_tally = nullptr);   // d_tally: 2 zeroed counters (ahead_rows_kernel), optional
-// d_tally[0] / d_tally[1] (two zeroed counters) = share of the BWT positions of every stride-th row that reach their LF
+                            unsigned long long *d_tally = nullptr);   // d_tally: 2 * kTallySlots zeroed u64 (tally_add spreads the atomics by block; the caller sums the pairs), optional
+// sum of d_tally[2 s] / sum of d_tally[2 s + 1] over the kTallySlots pairs (2 * kTallySlots zeroed u64) = share of the BWT positions of every stride-th row that reach their LF
 // target without a fast-forward (no_ff_share_kernel): the launch policy's statistic, without building the copy
 hipError_t tally_no_ff_share(int kmode, const DevIndex &ix, uint64_t stride, unsigned long long *d_tally, hipStream_t stream);
 

@@ -573,3 +573,84 @@ def test_zml_pair_shared_gathers_vs_oracle(built_lib, golden_image, mode):
     assert gpu.last_launch()["kernel"].endswith(", 0, 0, 1>") and (bout == bexp).all() and bst.errors == 0
     gpu.close()
     cpu.close()
+
+
+@pytest.mark.parametrize("mode", [6, 8, 7])
+def test_reposition_hints_vs_oracle(built_lib, golden_image, mode):
+    """Round 5 -- reposition hints in the look-ahead rows' spare bits (DevIndex::hints, "repo_hints"): a mismatch whose scan leaves
+    the row window jumps to where the scan ends (reposition_up / _down, src/move_structure_query.cpp:188-232) when that is within
+    7 rows of the window's edge.  Same PML vectors, error bytes and fast-forward / scan / reposition counters as the oracle and
+    as the same launch without the hints -- on noisy reads (every few bases a mismatch: many scans that leave their window),
+    on poly-base reads (scans that run far, past the hints' reach, and into the table's ends), with both row-index widths, the
+    pair-shared gathers, in-window repositions off (every reposition then depends on the hints declining in-window targets),
+    segments -- and fewer lane iterations."""
+    import movi_amd
+    from oracle import build_index as B
+    from oracle.oracle import Oracle
+    ref = _ref()
+    img = golden_image(mode) if mode != 7 else B.build_index_from_seqs([ref], 7)
+    gpu, cpu = movi_amd.MoveIndex.from_image(img), Oracle(img)
+    rng = np.random.default_rng(5150 + mode)
+    refa = np.frombuffer(ref, np.uint8)
+    reads = []
+    for sub in (0.08, 0.2, 0.5):                                 # noisy to nearly random
+        for _ in range(400):
+            L = int(rng.integers(1, 700))
+            s = int(rng.integers(0, len(ref) - L))
+            r = refa[s:s + L].copy()
+            m = rng.random(L) < sub
+            r[m] = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, int(m.sum()))]
+            reads.append(r.tobytes())
+    reads += [b"A" * 300, b"C" * 300, b"G" * 300, b"T" * 300, b"ACGT" * 100, b"TTTTTTTTGGGGGGGGCCCCCCCCAAAAAAAA" * 12, b"TG" * 200]
+    reads += [bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), 400)) for _ in range(200)]      # random reads: a reposition per base
+    bases, offs = pack(reads)
+    exp, ff, sc = cpu.pml_batch(bases, offs, threads=8)
+    gpu.set_option("ahead_rows", 1)
+    steps = {}
+    for hints in (1, 0):
+        gpu.set_option("repo_hints", hints)
+        for idx64, pair, inwin in ((0, 0, 1), (1, 0, 1), (0, 1, 1), (0, 0, 0), (1, 1, 0)):
+            gpu.set_option("idx64", idx64)
+            gpu.set_option("pair_loads", pair)
+            gpu.set_option("inwin_repo", inwin)
+            out, st, err, rc = gpu.query_pml_packed(bases, offs, want_err=True)
+            li = gpu.last_launch()
+            assert li["ahead"] == 1 and li["idx64"] == idx64, li
+            assert rc == 0 and not err.any()
+            assert (out == exp).all(), (mode, hints, idx64, pair, inwin)
+            assert (st.fast_forwards, st.scans, st.errors) == (ff, sc, 0), (mode, hints, idx64, pair, inwin)
+            steps[(hints, idx64, pair, inwin)] = st.lane_steps
+    gpu.set_option("idx64", 0)
+    gpu.set_option("pair_loads", -1)
+    gpu.set_option("inwin_repo", 1)
+    # the jumps are taken: fewer lane iterations with the hints than without, in every configuration
+    for key in ((0, 0, 1), (1, 0, 1), (0, 1, 1), (0, 0, 0), (1, 1, 0)):
+        assert steps[(1,) + key] < 0.97 * steps[(0,) + key], (key, steps)
+    # segments (K1 / K3 walk on the hinted rows too; the stitch kernels on the plain ones)
+    long_reads = []
+    for _ in range(24):
+        s = int(rng.integers(0, len(ref) - 9000))
+        r = refa[s:s + 9000].copy()
+        m = rng.random(9000) < 0.08
+        r[m] = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, int(m.sum()))]
+        long_reads.append(r.tobytes())
+    lb, lo = pack(long_reads)
+    lexp, lff, lsc = cpu.pml_batch(lb, lo, threads=4)
+    gpu.set_option("seg_probe", 0)
+    for hints in (1, 0):
+        gpu.set_option("repo_hints", hints)
+        lout, lst = gpu.query_pml_packed(lb, lo)
+        assert gpu.last_launch()["segmented"] == 1 and lst.segments > len(long_reads)
+        assert (lout == lexp).all() and (lst.fast_forwards, lst.scans, lst.errors) == (lff, lsc, 0), hints
+    gpu.set_option("seg_probe", 1)
+    gpu.set_option("repo_hints", 1)
+    # count and ZML read the same copy: its hint bits are not theirs
+    creads = [bytes(ref[s:s + 120]) for s in range(10, 40010, 400)] + reads[:200]
+    assert gpu.query_count(creads) == [cpu.count(r) for r in creads]
+    assert gpu.last_launch()["kernel"] == "count_kernel_v0<6, 1>"
+    gpu.set_option("zml_ahead", 1)
+    for r, g in zip(creads[:150], gpu.query_zml(creads[:150])):
+        assert (g == cpu.zml(r)).all()
+    assert gpu.last_launch()["ahead"] == 1
+    gpu.close()
+    cpu.close()

@@ -51,7 +51,7 @@ def test_top_of_walk_vs_oracle(built_lib, golden_image, mode, K):
     base_out, base_st = gpu.query_pml_packed(bases, offs)
     assert (base_out == exp).all()
     gpu.set_option("kmer_k", K)
-    for variant in (-1, 10):                                      # window-parallel (default) and the two-hop pipeline
+    for variant in (-1, 1):                                       # the default walk and the base-synchronous kernel (no table there)
         gpu.set_option("pml_variant", variant)
         out, st = gpu.query_pml_packed(bases, offs)
         assert (out == exp).all(), (mode, K, variant)
@@ -179,10 +179,10 @@ def test_reads_staged_through_lds_vs_oracle(built_lib, golden_image, mode):
     gpu.set_option("stage_reads", 1)
     for K in (0, 10):
         gpu.set_option("kmer_k", K)
-        for variant in (-1, 10):
+        for variant in (-1, 14):
             gpu.set_option("pml_variant", variant)
             out, st = gpu.query_pml_packed(bases, offs)
-            assert gpu.last_launch()["staged"] == (CAP if variant == -1 else 0), (K, variant)   # staging: the default kernel only
+            assert gpu.last_launch()["staged"] == CAP, (K, variant)
             assert gpu.last_launch()["ahead"] == 0
             assert (out == exp).all(), (K, variant)
             assert (st.fast_forwards, st.scans, st.repositions, st.errors) == (ff, sc, st0.repositions, 0), (K, variant)
