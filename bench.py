@@ -105,23 +105,24 @@ def ensure_pangenome(wl, world, rank, barrier):
     return idx_dir, reads_file
 
 
-def bound_of(table_bytes):
-    """What the walk's gathers are served from: a table that fits the 256 MiB Infinity Cache never reaches DRAM in steady
-    state (the line rate of the L2 <-> fabric path bounds it, not HBM); anything bigger is HBM-bound.  `peak` stays the
-    HBM peak either way (the contract's roofline)."""
-    return "hbm" if table_bytes > INFINITY_CACHE_BYTES else "fabric (Infinity-Cache-resident table)"
+def served_from(table_bytes):
+    """Where the walk's row gathers are served from in steady state: a table (as walked) that fits the 256 MiB Infinity Cache
+    hardly reaches DRAM -- the line rate of the L2 <-> fabric path bounds it -- anything bigger comes from HBM.  Reported
+    beside the roofline; `bound` itself stays "hbm" (the contract's label: an HBM-bandwidth roofline, `peak` = the HBM peak)."""
+    return "hbm" if table_bytes > INFINITY_CACHE_BYTES else "infinity cache (fabric line rate)"
 
 
-def lookup_traffic(workload, rows, reads, read_len, kernel):
+def lookup_traffic(key, rows, reads, read_len, kernel):
     """roofline.traffic: bytes per launch from profiles/traffic.json -- rocprofv3 PMC passes of an EARLIER run of this very
-    workload and kernel (counters cannot be collected inside a plain bench run), not a measurement of this run; null when
-    the shape or the kernel differs from what was profiled."""
+    launch (counters cannot be collected inside a plain bench run), not a measurement of this run; null when the shape or
+    the kernel differs from what was profiled.  `key` names the launch ("c2", "c3", "c3_classify1", "c4", "c4_count", ...);
+    `kernel` is the library's name for it with EVERY template argument (movi_last_launch), and it must equal the entry's."""
     tf = os.path.join(ROOT, "profiles", "traffic.json")
     try:
-        ent = json.load(open(tf)).get(workload)
+        ent = json.load(open(tf)).get(key)
         if ent and ent.get("rows") == rows and ent.get("reads") == reads and ent.get("read_len") == read_len \
-                and ent.get("kernel_name", kernel) == kernel:
-            return ent.get("hbm_bytes_per_launch"), "static: %s (PMC passes of an earlier run of this workload; not measured in this run)" % ent.get("source")
+                and ent.get("kernel_name") == kernel:
+            return ent.get("hbm_bytes_per_launch"), "static: %s (PMC passes of an earlier run of this launch; not measured in this run)" % ent.get("source")
     except Exception:
         pass
     return None, None
@@ -163,32 +164,38 @@ def sum_over_ranks(torch, dist, world, dev, x):
     return float(t.item())
 
 
+SIDE_TABLE_BYTES = 16 << 24       # the 4^12 x 16 B top-of-walk / interval table: one lookup per read (~0.1 B per base), reported beside the roofline
+
+
 def pml_roofline(table_bytes, row_bytes, st, n_bases, kern_s, launch, traffic=None, tsrc=None):
-    """The `roofline` object of a PML leg: algorithmic bytes (row_bytes x (1 + f + s) + 1 + 2 per base) over the
-    kernel's mean launch time, against the HBM peak."""
+    """The `roofline` object of a PML leg: algorithmic bytes (row_bytes x (1 + f + s) + 1 + 2 per base, with the
+    REFERENCE's row size -- the look-ahead copy's 16 B per row are this engine's layout, not the algorithm's) over the kernel's
+    mean launch time, against the HBM peak.  `bound` follows the bytes the row gathers walk (`table_bytes`: the look-ahead copy
+    where the launch walked on it); the side table is reported separately."""
     f_bar, s_bar = st.fast_forwards / max(n_bases, 1), st.scans / max(n_bases, 1)
     bpb = row_bytes * (1.0 + f_bar + s_bar) + 1 + 2
     ach = bpb * n_bases / kern_s / 1e9
-    # (working set: the table the walk gathers from + the 256 MB top-of-walk table every read looks up once)
-    return {"bound": bound_of(table_bytes + (16 << 24)), "working_set_bytes": table_bytes + (16 << 24),
+    return {"bound": "hbm", "gathers_served_from": served_from(table_bytes), "working_set_bytes": table_bytes, "side_table_bytes": SIDE_TABLE_BYTES,
             "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": tsrc, "algorithmic_bytes_per_base": round(bpb, 3),
+            "algorithmic_model": "SURVEY 8(d): %d B (the reference's row) x rows the reference's walk reads per base + 3" % row_bytes,
             "kernel": launch["kernel"], "launch": launch, "kernel_ms_avg": kern_s * 1e3,
             "lane_iterations_per_s": st.lane_steps / kern_s if st.wave_steps else None,
             "rows_read_per_s": (1.0 + f_bar + s_bar) * n_bases / kern_s}
 
 
-def count_roofline(table_bytes, row_bytes, st, matched_bases, kern_s, launch):
+def count_roofline(table_bytes, row_bytes, st, matched_bases, kern_s, launch, traffic=None, tsrc=None):
     """The same for the count query: B_count = 2 x row_bytes x (1 + f) + row_bytes x u + 1 per base the search extends over
     (two LF walkers, u interval-shrink rows, one base in)."""
     wb = max(int(matched_bases), 1)
     f_bar, u_bar = st.fast_forwards / wb / 2.0, st.scans / wb
     bpb = 2 * row_bytes * (1.0 + f_bar) + row_bytes * u_bar + 1
     ach = bpb * wb / kern_s / 1e9
-    return {"bound": bound_of(table_bytes + (16 << 24)), "working_set_bytes": table_bytes + (16 << 24),
+    return {"bound": "hbm", "gathers_served_from": served_from(table_bytes), "working_set_bytes": table_bytes, "side_table_bytes": SIDE_TABLE_BYTES,
             "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-            "traffic": None, "algorithmic_bytes_per_base": round(bpb, 3), "matched_bases_per_step": wb,
-            "kernel": launch["kernel"], "launch": launch, "kernel_ms_avg": kern_s * 1e3}
+            "traffic": traffic, "traffic_source": tsrc, "algorithmic_bytes_per_base": round(bpb, 3), "matched_bases_per_step": wb,
+            "kernel": launch["kernel"], "launch": launch, "kernel_ms_avg": kern_s * 1e3,
+            "lane_iterations_per_s": st.lane_steps / kern_s if st.wave_steps else None}
 
 
 def table_bytes_walked(rows, row_bytes, launch):
@@ -296,9 +303,11 @@ def big_table_leg(torch, dist, world, rank, dev, local_rank, stream, synth, movi
     stc = index.last_stats(stream.cuda_stream)
     dtc, perc, kern_c = timed_steps(torch, dist, world, dev, stream, runc, 5)
     claunch = index.last_launch()
+    ctraffic, ctsrc = lookup_traffic("c4_count", rows, n_reads, L, claunch["kernel"])
     out["count"] = {"value": total * 5 / dtc / 1e9, "unit": "Gbases/s (read bases)", "steps": 5, "ms_per_step": dtc / 5 * 1e3,
                     "rank_seconds": [round(x, 4) for x in perc], "kernel": claunch["kernel"],
-                    "roofline": count_roofline(table_bytes_walked(rows, 8, claunch), 8, stc, int(d_m.sum().item()), kern_c, claunch)}
+                    "roofline": count_roofline(table_bytes_walked(rows, 8, claunch), 8, stc, int(d_m.sum().item()), kern_c, claunch, ctraffic, ctsrc)}
+    out["count"]["roofline"]["dram_frac_of_peak"] = (ctraffic / kern_c / 1e9 / HBM_PEAK_GBS) if ctraffic else None
     if rank == 0:
         # parity: three slices of rank 0's batch against the oracle on the same image, PMLs, counters and counts
         t0 = time.time()
@@ -381,7 +390,7 @@ def long_reads_leg(torch, dist, world, rank, dev, stream, index, idx_dir, rows, 
                "fast_forwards_per_base": round(st3.fast_forwards / (n3 * L3), 4), "scans_per_base": round(st3.scans / (n3 * L3), 4),
                "errors": int(st3.errors), "segments": int(st3.segments), "rewalked_reads": int(st3.rewalked),
                "roofline": pml_roofline(table_bytes_walked(rows, row_bytes, launch), row_bytes, st3, n3 * L3, kern3, launch,
-                                        *(lookup_traffic("c3", rows, n3, L3, launch["kernel"]) if cm == 0 else (None, None)))}
+                                        *lookup_traffic("c3" if cm == 0 else "c3_classify%d" % cm, rows, n3, L3, launch["kernel"]))}
         if cm:
             verdicts[cm] = (d_a.clone(), d_b.clone(), d_s.clone())
         res[cm] = leg
@@ -477,7 +486,7 @@ def cli_path_leg(idx_dir, reads_150, reads_10k):
 def usable_cores():
     """Host threads this process can really run: the CPU affinity mask capped by the cgroup CPU quota (the GPU boxes
     show 256 logical CPUs but grant 16 CPUs of quota: 256 OpenMP threads then run at 0.15-0.2 Gbases/s, 16 at 0.39;
-    tests/cpu_threads_sweep.py, profiles/r02_cpu_port_thread_sweep.txt)."""
+    tests/studies/cpu_threads_sweep.py, profiles/r02_cpu_port_thread_sweep.txt)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:
         q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]                  # cgroup v2
@@ -688,6 +697,11 @@ def main():
         key, _, val = kv.partition("=")
         index.set_option(key, int(val))
     t_index_upload = time.time() - t0
+    # the handle's derived tables (top-of-walk / interval table, look-ahead rows, checkpoints) are built here, by name, not inside
+    # the first warm-up step (movi_index_prepare, round 5)
+    t0 = time.time()
+    derived_bytes = index.prepare({"pml": index.PREPARE_PML, "count": index.PREPARE_COUNT, "zml": index.PREPARE_ZML}[args.query])
+    t_prepare = time.time() - t0
 
     # ---- reads: each rank draws its own shard (seed + rank)
     t0 = time.time()
@@ -791,8 +805,8 @@ def main():
         except Exception as e:                            # noqa: BLE001
             sustained = {"error": repr(e)[:200]}
 
-    traffic, traffic_src = lookup_traffic(args.workload, wl["rows"], wl["reads"], wl["read_len"], launch["kernel"]) \
-        if args.query == "pml" and not args.classify else (None, None)
+    tkey = args.workload + ("" if args.query == "pml" else "_" + args.query) + ("_classify%d" % args.classify if args.classify else "")
+    traffic, traffic_src = lookup_traffic(tkey, wl["rows"], wl["reads"], wl["read_len"], launch["kernel"])
 
     result = {
         "metric": {"pml": "PML", "count": "count", "zml": "ZML"}[args.query] + " query Gbases/s on " +
@@ -810,15 +824,17 @@ def main():
                    "iterations_per_base": round(st.lane_steps / max(n_bases, 1), 4) if st.wave_steps else None,
                    "algorithmic_bytes_per_base": round(bytes_per_base, 3),
                    "segments": int(st.segments), "rewalked_reads": int(st.rewalked), "seg_len": args.seg_len,
-                   "query": args.query, "fused_classify": args.classify, "matched_bases_per_step": work_bases, "pml_variant": args.variant, "kmer_k": args.kmer_k, "ahead_rows": args.ahead_rows, "ftab_k": args.ftab_k, "ragged": args.ragged, "waves_per_cu": args.waves_per_cu, "block_threads": args.block_threads, "index_gen_s": round(t_index_gen, 2),
+                   "query": args.query, "fused_classify": args.classify, "matched_bases_per_step": work_bases, "pml_variant": args.variant, "kmer_k": args.kmer_k, "ahead_rows": args.ahead_rows, "ftab_k": args.ftab_k, "ragged": args.ragged, "waves_per_cu": args.waves_per_cu, "block_threads": args.block_threads, "index_gen_s": round(t_index_gen, 2), "prepare_s": round(t_prepare, 3), "derived_bytes": derived_bytes,
                    "index_upload_s": round(t_index_upload, 2), "index_broadcast_s": round(t_bcast, 3),
                    "reads_gen_s": round(t_reads_gen, 2),
                    "no_ff_share": round(index.info("ahead_no_ff"), 4), "derived_table_bytes": int(index.info("derived_bytes"))},
         "rccl_ranks": rccl_ranks, "index_broadcast_s": round(t_bcast, 4),
-        # bound: by the bytes the walk gathers from -- the look-ahead copy is 16 B per row -- plus the 256 MB top-of-walk /
-        # interval table every read looks up once (together they do NOT fit the 256 MiB Infinity Cache on c2: "hbm")
-        "roofline": {"bound": bound_of(table_bytes_walked(wl["rows"], row_bytes, launch) + ((16 << 24) if args.query != "zml" and args.kmer_k != 0 else 0)),
-                     "working_set_bytes": table_bytes_walked(wl["rows"], row_bytes, launch) + ((16 << 24) if args.query != "zml" and args.kmer_k != 0 else 0),
+        # bound: by the bytes the row gathers walk -- the look-ahead copy is 16 B per row; the 256 MB top-of-walk / interval table,
+        # one lookup per read (~0.1 B per base), is reported beside it ("side_table_bytes"), not folded into the label.  `achieved`
+        # prices the REFERENCE's 8-byte rows, whichever layout the launch walked on.
+        "roofline": {"bound": "hbm", "gathers_served_from": served_from(table_bytes_walked(wl["rows"], row_bytes, launch)),
+                     "working_set_bytes": table_bytes_walked(wl["rows"], row_bytes, launch),
+                     "side_table_bytes": SIDE_TABLE_BYTES if args.query != "zml" and args.kmer_k != 0 else 0,
                      "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": traffic_src,

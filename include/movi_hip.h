@@ -152,6 +152,20 @@ int movi_index_replicate(const movi_index_desc_t *desc, const void *h_rows, cons
                          movi_index_t **out);
 int movi_index_load_replicated(const char *index_dir_or_file, const int *devices, int n, movi_index_t **out);
 
+/* Build the handle's derived tables NOW instead of inside the first query: `what` = MOVI_PREPARE_PML (top-of-walk table,
+ * 256 MB at K = 12; look-ahead rows, 16 bytes per row, where the device has room for them and half as much again, never more
+ * than a quarter of the device by itself) | MOVI_PREPARE_COUNT (row-start checkpoints, 8 bytes per 32 rows; interval table,
+ * 256 MB; the look-ahead rows where a sample of the table says the search will use them) | MOVI_PREPARE_ZML (nothing: accepted
+ * for symmetry).  Honours the options set before it ("kmer_k", "ftab_k", "ahead_rows": a table the caller built or switched
+ * off is left alone).  Waits for the builders; *derived_bytes (optional) = bytes of device memory the handle's derived tables
+ * hold afterwards (movi_index_info "derived_bytes").  After it the *_device entry points of those queries allocate nothing
+ * and build nothing on this handle (batches of long reads still grow the segment workspace on their first call): they can be
+ * captured into a HIP graph without a warm-up call.  Not calling it is fine: the first query does the same, lazily. */
+#define MOVI_PREPARE_PML 1u
+#define MOVI_PREPARE_COUNT 2u
+#define MOVI_PREPARE_ZML 4u
+int movi_index_prepare(movi_index_t *ix, uint32_t what, void *stream, uint64_t *derived_bytes);
+
 int movi_index_destroy(movi_index_t *ix);
 int movi_index_get_desc(const movi_index_t *ix, movi_index_desc_t *desc);   /* id_blocks = NULL */
 /* Device pointer + size of the resident row table.  Mode 6: the file's bytes.  Modes 7 / 8: the expanded table, r x 8
@@ -223,7 +237,7 @@ int movi_last_stats(movi_index_t *ix, void *stream, movi_query_stats_t *stats);
  * asks instead of assuming (bench.py's roofline.kernel). */
 typedef struct movi_launch_info {
     char kernel[96];
-    int32_t variant;                  /* PML: 0, 1, 14 ("pml_variant"); ZML: 0, 1; count: 0                        */
+    int32_t variant;                  /* PML: 0, 1, 14 ("pml_variant"); ZML: 0, 1; count: 0, 1 ("count_variant")     */
     int32_t block_threads;
     int32_t waves_per_cu;             /* cap on resident wavefronts per CU that was applied (0 = none)             */
     int32_t segmented;                /* 1 = the segment-parallel plan ran around that kernel                       */
@@ -234,6 +248,12 @@ typedef struct movi_launch_info {
     int32_t reserved_;
 } movi_launch_info_t;
 int movi_last_launch(const movi_index_t *ix, movi_launch_info_t *info);
+/* Diagnostic (process-wide): the first call switches a log of the walk kernel's launches on; every call copies the DISTINCT
+ * kernel names launched since the previous call into buf (one per line, NUL-terminated, truncated to cap) and clears the
+ * log; *needed (optional) = bytes a complete copy takes.  Unlike movi_last_launch it sees the K1 / K3 launches of the
+ * segment-parallel plan too: tests/test_kernel_coverage_gpu.py holds every instantiation the library was built with to the
+ * oracle through it. */
+int movi_launch_log(char *buf, size_t cap, size_t *needed);
 
 /* What the handle holds in HBM besides the row table, and what its builders measured (no reference counterpart; the
  * derived tables of "kmer_k" / "ahead_rows" / "ftab_k" are built by the first query that can use them, so this is how a
@@ -339,6 +359,13 @@ int movi_host_unregister(void *p);
  * a sample of the table says its search will use them.  1 = build now,
  * 0 = none (freed).  (Entries two rows deep -- "chain rows", three bases per gather -- were built in round 4, bit-exact, and
  * measured 10 - 38 % slower: profiles/r04_chain_rows.txt; removed),
+ * "repo_hints" (1, the default: in the look-ahead copy of a table of fewer than 2^32 - 1 rows the rows' spare bits hold, per
+ * threshold slot, how many rows beyond its window's edge the nearest run of that base lies -- a mismatch whose scan leaves the
+ * window then gathers the scan's END in its next iteration instead of walking there window by window; 0 = ignore them: A/B),
+ * "count_variant" (-1, the default: the count query runs as a lane state machine over row windows -- zml_kernel_flat<..., CNT = 1>,
+ * by pairs of lanes on tables of 2 GB and more ("pair_loads") -- wherever it can: tables of 8 rows and more, batches of 16 bases
+ * and more; 0 = count_kernel_v0, the base-synchronous kernel of rounds 1 - 4 (on the look-ahead rows where the table's statistic
+ * admits them); 1 = the state machine or an error),
  * "inwin_repo" (1, the default: a reposition whose target run is one of the row window's other rows is resolved in
  * the iteration that sees the mismatch; 0 = off: A/B),
  * "pair_loads" (pair-shared gathers: the two lanes of a pair fetch each row window together, each lane one 16-byte half of

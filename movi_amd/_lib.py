@@ -81,6 +81,7 @@ SYMBOLS = {
     "movi_index_replicate": (C.c_int, [C.POINTER(IndexDescC), C.c_void_p, C.POINTER(C.c_int), C.c_int,
                                        C.POINTER(C.c_void_p)]),
     "movi_index_load_replicated": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
+    "movi_index_prepare": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64)]),
     "movi_index_destroy": (C.c_int, [C.c_void_p]),
     "movi_index_get_desc": (C.c_int, [C.c_void_p, C.POINTER(IndexDescC)]),
     "movi_index_device_rows": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
@@ -96,6 +97,7 @@ SYMBOLS = {
                                 C.POINTER(QueryStatsC)]),
     "movi_last_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(QueryStatsC)]),
     "movi_last_launch": (C.c_int, [C.c_void_p, C.POINTER(LaunchInfoC)]),
+    "movi_launch_log": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "movi_index_info": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]),
     "movi_count_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -99,7 +99,8 @@ struct movi_index {
     double ahead_no_ff = 0.0;        // share of the table's positions that arrive at their LF target without a fast-forward (build_ahead)
     bool ahead_tallied = false;
     bool count_declined_ahead = false;   // the count query's auto-build found the copy not worth keeping (rows2_count == 0): do not build it per call
-    int ahead_auto = 1;              // 1: the first PML query builds them when the table is small enough (ahead_rows_fit)
+    int ahead_auto = 1;              // 1: the first PML query builds them when the device has room for them (ahead_wanted)
+    int ahead_retry_in = 0;          // the copy was declined for lack of device memory: calls until the device is asked again (not every call)
     uint4 *d_ftab = nullptr;         // the count query's interval table ("ftab_k" option), 16 << 2K bytes
     int ftab_auto = 12;              // K of the table the first count query builds by itself (0 = none)
     DevStats *d_stats = nullptr;
@@ -844,6 +845,28 @@ static int build_ftab_table(movi_index *ix, uint32_t K, hipStream_t s) {
     return MOVI_OK;
 }
 
+// The derived tables of the PML walk -- top-of-walk table (256 MB at K = 12, a few ms), look-ahead rows (16 B per row) --:
+// built by movi_index_prepare, or by the first PML query on the handle.  Nothing here fails the query: a table there is no room
+// for (or a device in trouble, which the walk's own launch will report) is done without.
+static void ensure_pml_tables(movi_index *ix, hipStream_t s) {
+    if (ix->kmer_auto > 0 && !ix->d_kmer && kmer_eligible(ix)) {
+        if (build_kmer(ix, (uint32_t)ix->kmer_auto, s) != MOVI_OK) {
+            (void)hipGetLastError();
+            ix->kmer_auto = 0;
+        }
+    }
+    if (ix->ahead_auto > 0 && !ix->d_rows2 && ahead_eligible(ix)) {
+        // (declined for lack of memory: the device is asked again after 64 calls, not in every one -- hipMemGetInfo per chunk of
+        // a streaming run -- and two processes sharing a GPU that both pass the check and then collide switch the auto-build off)
+        if (ix->ahead_retry_in > 0) ix->ahead_retry_in -= 1;
+        else if (!ahead_wanted(ix)) ix->ahead_retry_in = 63;
+        else if (build_ahead(ix, s, true) != MOVI_OK) {
+            (void)hipGetLastError();
+            ix->ahead_auto = 0;
+        }
+    }
+}
+
 extern "C" {
 
 int movi_index_get_desc(const movi_index_t *ix, movi_index_desc_t *desc) {
@@ -875,6 +898,11 @@ int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
     if (!strcmp(key, "zml_variant")) {
         if (value < -1 || value > 1) return fail(MOVI_ERR_ARG, "zml_variant must be -1 (auto), 0 or 1");
         ix->cfg.zml_variant = (int)value;
+        return MOVI_OK;
+    }
+    if (!strcmp(key, "count_variant")) {                     // A/B: -1 = the launch policy, 0 = count_kernel_v0, 1 = the lane state machine
+        if (value < -1 || value > 1) return fail(MOVI_ERR_ARG, "count_variant must be -1 (auto), 0 or 1");
+        ix->cfg.count_variant = (int)value;
         return MOVI_OK;
     }
     if (!strcmp(key, "idx64")) {                             // test hook: run the 64-bit-index kernel instantiations
@@ -1025,19 +1053,9 @@ static int ml_device(bool zml, movi_index_t *ix, const uint8_t *d_bases, const u
     hipStream_t s = static_cast<hipStream_t>(stream);
     HIP_TRY(hipMemsetAsync(d_stats, 0, sizeof(DevStats), s));
     if (n_reads > 0xFFFFFFFFull) return fail(MOVI_ERR_ARG, "more than 2^32 reads in one call");
-    // the first PML query on an index that can have one builds the top-of-walk table (256 MB at K = 12, a few ms)
-    if (!zml && ix->kmer_auto > 0 && !ix->d_kmer && kmer_eligible(ix) && cls.log_ff == nullptr) {
-        if (build_kmer(ix, (uint32_t)ix->kmer_auto, s) != MOVI_OK) {   // no room for it (or the device is in trouble, which the
-            (void)hipGetLastError();                                  // walk's own launch will report): walk without a table
-            ix->kmer_auto = 0;
-        }
-    }
-    if (!zml && ix->ahead_auto > 0 && !ix->d_rows2 && ahead_eligible(ix) && cls.log_ff == nullptr && ahead_wanted(ix)) {
-        if (build_ahead(ix, s, true) != MOVI_OK) {
-            (void)hipGetLastError();
-            ix->ahead_auto = 0;
-        }
-    }
+    // the first PML query on a handle builds its derived tables -- unless movi_index_prepare did (--logs runs on the first
+    // kernel, which uses none of them)
+    if (!zml && cls.log_ff == nullptr) ensure_pml_tables(ix, s);
     if (zml)
         HIP_TRY(launch_zml(ix->kmode, ix->dev, d_bases, d_offsets, n_reads, n_bases, d_out, d_read_err, d_stats,
                            d_read_order, ix->cfg, s, seg_ws, ragged_hint, seg_verdict, &ix->last_launch));
@@ -1071,6 +1089,12 @@ int movi_last_launch(const movi_index_t *ix, movi_launch_info_t *info) {
     info->idx64 = ix->last_launch.idx64;
     info->staged = ix->last_launch.staged;
     info->ahead = ix->last_launch.ahead;
+    return MOVI_OK;
+}
+
+int movi_launch_log(char *buf, size_t cap, size_t *needed) {
+    const size_t n = take_launch_log(buf, cap);
+    if (needed) *needed = n + 1;
     return MOVI_OK;
 }
 
@@ -1757,6 +1781,39 @@ static int ensure_ckpt(movi_index *ix, hipStream_t s) {
     return MOVI_OK;
 }
 
+// The derived tables of the count query -- row-start checkpoints, interval table, and the look-ahead rows where the table's own
+// statistic says the search will use them --: built by movi_index_prepare, or by the first count query on the handle.
+static int ensure_count_tables(movi_index *ix, hipStream_t s) {
+    int rc = ensure_ckpt(ix, s);
+    if (rc) return rc;
+    if (ix->ftab_auto > 0 && !ix->d_ftab && ftab_eligible(ix)) {       // the interval table (256 MB at K = 12)
+        if (build_ftab_table(ix, (uint32_t)ix->ftab_auto, s) != MOVI_OK) { (void)hipGetLastError(); ix->ftab_auto = 0; }
+    }
+    // (round 5: the count query's default is the lane state machine on the PLAIN rows, launch_count; the look-ahead copy serves
+    // count_kernel_v0 only, i.e. "count_variant" 0)
+    if (ix->cfg.count_variant == 0 && ix->ahead_auto > 0 && !ix->d_rows2 && !ix->count_declined_ahead && ahead_eligible(ix)) {
+        // sampled first, so that a table that will not use the copy is not copied (16 B per row) to find out.  Only the table's
+        // statistic declines for good; a device short of memory is asked again later (ahead_retry_in).
+        sample_no_ff(ix, s);
+        if (!ix->ahead_tallied) { /* the sample failed: the next call tries again */ }
+        else if (ix->ahead_no_ff < kAheadCountRatio) ix->count_declined_ahead = true;
+        else if (ix->ahead_retry_in > 0) ix->ahead_retry_in -= 1;
+        else if (!ahead_wanted(ix)) ix->ahead_retry_in = 63;
+        else if (build_ahead(ix, s, true) != MOVI_OK) { (void)hipGetLastError(); ix->ahead_auto = 0; }
+        else if (ix->dev.rows2_count == 0u) {
+            // (the copy's own tally -- every row, not a sample -- says the count query is better off on the plain rows: the copy
+            // is not kept for a caller who may never ask for PMLs; the first PML query builds it again, 85 us per 14 M rows)
+            ix->dev.rows2 = nullptr;
+            ix->dev.rows2_tail = 0;
+            ix->dev.hints = 0;
+            (void)hipFree(ix->d_rows2);
+            ix->d_rows2 = nullptr;
+            ix->count_declined_ahead = true;
+        }
+    }
+    return MOVI_OK;
+}
+
 static int count_device(movi_index_t *ix, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
                         uint64_t n_bases, uint64_t *d_matched, uint64_t *d_count, uint8_t *d_read_err,
                         const uint32_t *d_read_order, void *stream, DevStats *d_stats) {
@@ -1766,32 +1823,12 @@ static int count_device(movi_index_t *ix, const uint8_t *d_bases, const uint64_t
     if (!d_stats) d_stats = ix->d_stats;
     HIP_TRY(hipSetDevice(ix->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    int rc = ensure_ckpt(ix, s);
+    int rc = ensure_count_tables(ix, s);
     if (rc) return rc;
-    if (ix->ftab_auto > 0 && !ix->d_ftab && ftab_eligible(ix)) {       // the first count query builds the interval table
-        if (build_ftab_table(ix, (uint32_t)ix->ftab_auto, s) != MOVI_OK) { (void)hipGetLastError(); ix->ftab_auto = 0; }
-    }
-    if (ix->ahead_auto > 0 && !ix->d_rows2 && !ix->count_declined_ahead && ahead_eligible(ix)) {
-        // ... and the look-ahead rows (as a PML query does), where the table's own statistic says the search will use them:
-        // sampled first, so that a table that will not is not copied (16 B per row) to find out
-        sample_no_ff(ix, s);
-        if (!ix->ahead_tallied || ix->ahead_no_ff < kAheadCountRatio || !ahead_wanted(ix)) ix->count_declined_ahead = true;
-        else if (build_ahead(ix, s, true) != MOVI_OK) { (void)hipGetLastError(); ix->ahead_auto = 0; }
-        else if (ix->dev.rows2_count == 0u) {
-            // the table's own statistic says the count query is better off on the plain rows: the copy (16 B per row) is not
-            // kept for a caller who may never ask for PMLs -- the first PML query builds it again (85 us per 14 M rows)
-            ix->dev.rows2 = nullptr;
-            ix->dev.rows2_tail = 0;
-            ix->dev.hints = 0;
-            (void)hipFree(ix->d_rows2);
-            ix->d_rows2 = nullptr;
-            ix->count_declined_ahead = true;
-        }
-    }
     HIP_TRY(hipMemsetAsync(d_stats, 0, sizeof(DevStats), s));
     if (n_reads > 0xFFFFFFFFull) return fail(MOVI_ERR_ARG, "more than 2^32 reads in one call");
     HIP_TRY(launch_count(ix->kmode, ix->dev, d_bases, d_offsets, n_reads, d_matched, d_count,
-                         d_read_err, d_stats, d_read_order, ix->cfg, s, &ix->last_launch));
+                         d_read_err, d_stats, d_read_order, ix->cfg, s, &ix->last_launch, n_bases));
     return MOVI_OK;
 }
 
@@ -1800,6 +1837,27 @@ int movi_count_device(movi_index_t *ix, const uint8_t *d_bases, const uint64_t *
                       const uint32_t *d_read_order, void *stream) {
     return count_device(ix, d_bases, d_offsets, n_reads, n_bases, d_matched, d_count, d_read_err, d_read_order, stream,
                         nullptr);
+}
+
+int movi_index_prepare(movi_index_t *ix, uint32_t what, void *stream, uint64_t *derived_bytes) {
+    if (!ix) return fail(MOVI_ERR_ARG, "index handle is NULL");
+    if (what & ~(uint32_t)(MOVI_PREPARE_PML | MOVI_PREPARE_COUNT | MOVI_PREPARE_ZML)) return fail(MOVI_ERR_ARG, "unknown MOVI_PREPARE_* bit");
+    HIP_TRY(hipSetDevice(ix->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ix->ahead_retry_in = 0;                                           // an explicit call asks the device now
+    if ((what & MOVI_PREPARE_PML) && mode_has_thresholds(ix->desc.mode)) ensure_pml_tables(ix, s);
+    if (what & MOVI_PREPARE_COUNT) {
+        const int rc = ensure_count_tables(ix, s);
+        if (rc) return rc;
+    }
+    // (MOVI_PREPARE_ZML: the parse walks on the plain rows and derives nothing -- accepted so that callers need not know)
+    HIP_TRY(hipStreamSynchronize(s));
+    if (derived_bytes) {
+        double v = 0.0;
+        (void)movi_index_info(ix, "derived_bytes", &v);
+        *derived_bytes = (uint64_t)v;
+    }
+    return MOVI_OK;
 }
 
 int movi_count_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_offsets, uint64_t n_reads,

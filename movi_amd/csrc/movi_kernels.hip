@@ -18,7 +18,12 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <set>
+#include <string>
 
 namespace movi {
 
@@ -816,6 +821,29 @@ static hipError_t launch_pml_segmented(const DevIndex &ix, const uint8_t *d_base
     return e;
 }
 
+// ---- launch log (diagnostic; movi_launch_log): the distinct walk kernels launched since it was switched on / last read
+static std::atomic<bool> g_launch_log_on{false};
+static std::mutex g_launch_log_m;
+static std::set<std::string> g_launch_log;
+void note_walk_launch(const char *kernel_name) {
+    if (!g_launch_log_on.load(std::memory_order_relaxed)) return;
+    std::lock_guard<std::mutex> g(g_launch_log_m);
+    g_launch_log.insert(kernel_name);
+}
+size_t take_launch_log(char *buf, size_t cap) {
+    g_launch_log_on.store(true, std::memory_order_relaxed);
+    std::lock_guard<std::mutex> g(g_launch_log_m);
+    std::string all;
+    for (const auto &k : g_launch_log) { all += k; all += '\n'; }
+    g_launch_log.clear();
+    if (buf && cap) {
+        const size_t n = all.size() < cap - 1 ? all.size() : cap - 1;
+        memcpy(buf, all.data(), n);
+        buf[n] = 0;
+    }
+    return all.size();
+}
+
 hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets,
                       uint64_t n_reads, uint64_t n_bases, uint16_t *d_out, uint8_t *d_err, DevStats *d_stats,
                       const uint32_t *d_order, const LaunchCfg &cfg, hipStream_t stream, const ClsArgs &cls,
@@ -1324,10 +1352,15 @@ __global__ __launch_bounds__(256) void count_kernel_v0(DevIndex ix, const uint8_
     }
 }
 
+// the count query as a lane state machine (zml_kernel_flat<..., CNT = 1>, with the ZML kernels below)
+static hipError_t launch_count_flat(int mode, const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
+                                    uint64_t *d_matched, uint64_t *d_count, uint8_t *d_err, DevStats *d_stats, const uint32_t *d_order,
+                                    const LaunchCfg &cfg, hipStream_t stream, LaunchInfo *info, bool pair);
+
 hipError_t launch_count(int mode, const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets,
                         uint64_t n_reads, uint64_t *d_matched, uint64_t *d_count, uint8_t *d_err,
                         DevStats *d_stats, const uint32_t *d_order, const LaunchCfg &cfg, hipStream_t stream,
-                        LaunchInfo *info) {
+                        LaunchInfo *info, uint64_t n_bases) {
     if (n_reads == 0) return hipSuccess;
     // Blocks of one wavefront; on a cache-resident table (up to the 256 MiB of the Infinity Cache) and a batch of more than
     // ~24 wavefronts of reads per CU at most kCountCapWaves wavefronts resident per CU -- the same L2-retention effect as in
@@ -1337,6 +1370,18 @@ hipError_t launch_count(int mode, const DevIndex &ix, const uint8_t *d_bases, co
     const int bt = cfg.block_threads > 0 ? cfg.block_threads : 64;
     int wpc = cfg.waves_per_cu > 0 ? cfg.waves_per_cu : 0;
     const bool ahead = mode == 6 && ix.rows2 != nullptr && ix.rows2_count != 0u;   // the search walks on the look-ahead rows where they pay
+    // Round 5 -- the search as a LANE STATE MACHINE over row windows (zml_kernel_flat<..., CNT = 1>; by pairs of lanes on plain rows of
+    // 2 GB and more) wherever it can run: tables of 8 rows and more, batches of 16 bases and more, one-wavefront blocks.  Gbases/s of
+    // read bases, count_kernel_v0 -> the state machine (profiles/r05_c5_count_pmc.txt): the 1 B-row blocked-thresholds table of BASELINE
+    // config 5 37.2 -> 56.4 - 56.9 (without the pairs 32.3), random 200 M rows 46.6 -> 68.0, the c2 pangenome 71.4 (on its look-ahead
+    // rows) -> 84.0 (on the plain rows).  cfg.count_variant: -1 = this policy, 0 = count_kernel_v0 (A/B; tiny tables and batches), 1 = the
+    // state machine or nothing.
+    const bool flat_ok = (mode == 6 || mode == 3) && ix.r >= 8 && n_bases >= 16 && bt == 64;
+    const bool big = ix.r * 8ull >= kPairLoadBytes;
+    if (flat_ok && cfg.count_variant != 0)
+        return launch_count_flat(mode, ix, d_bases, d_offsets, n_reads, d_matched, d_count, d_err, d_stats, d_order, cfg, stream, info,
+                                 cfg.pair_loads > 0 || (cfg.pair_loads < 0 && big));
+    if (cfg.count_variant > 0) return hipErrorInvalidValue;
     if (cfg.waves_per_cu == 0 && ix.r * (ahead ? 16ull : 8ull) <= (256ull << 20) &&   // (the bytes of the table the search walks on)
         n_reads > (uint64_t)cfg.num_cus * 64ull * 24ull) wpc = kCountCapWaves;
     size_t dyn_lds = 0;
@@ -1648,13 +1693,23 @@ __global__ __launch_bounds__(256) void zml_probe_kernel(DevIndex ix, const uint8
 // shrink_interval's trips, so answers AND scan / fast-forward counts equal the base-synchronous kernel's.
 // SEG = 1: a lane parses one SEGMENT of a read (K1 of launch_zml_segmented), as zml_kernel<MODE, 1>.
 // PSH = 1 (round 4; plain rows, whole reads): the two windows of an iteration by pairs of lanes, as pml_kernel_flatp<..., PSH = 1>.
-template <int MODE, typename IdxT, int SEG = 0, int AH = 0, int PSH = 0>
+// CNT = 1 (round 5): the COUNT query (query_backward_search, src/move_structure_search.cpp:340-352) on the same machine.  A
+// backward search is the parse's first phrase: the search ends where the phrase would (the interval comes out empty, or the
+// base is illegal) and reports the last non-empty interval and how many bases it matched, instead of opening the next phrase;
+// nothing is emitted per base.  The first K bases come from the interval table (DevIndex::ftab) like count_kernel_v0's.  Why: on
+// tables beyond the TLBs' reach the base-synchronous count_kernel_v0 pays max-over-the-wavefront dependent round trips per base
+// (interval shrink, two LF gathers, a fast-forward loop that takes one row per trip: 0.91 fast-forwards per LF on the random
+// 1 B-row table); here every lane fetches two row windows per iteration -- by pairs of lanes (PSH) -- and resolves the
+// fast-forwards and scans inside them in closed form.  `matched` / `count`: per read, as count_kernel_v0 writes them.
+template <int MODE, typename IdxT, int SEG = 0, int AH = 0, int PSH = 0, int CNT = 0>
 __global__ __launch_bounds__(256) void zml_kernel_flat(DevIndex ix, const uint8_t *__restrict__ bases,
                                                        const uint64_t *__restrict__ offs, uint64_t n_reads,
                                                        uint16_t *__restrict__ out, uint8_t *__restrict__ err,
-                                                       DevStats *stats, const uint32_t *__restrict__ order, ZSegArgs seg) {
+                                                       DevStats *stats, const uint32_t *__restrict__ order, ZSegArgs seg,
+                                                       uint64_t *__restrict__ matched, uint64_t *__restrict__ count) {
     static_assert(AH == 0 || (MODE == 6 && SEG == 0), "look-ahead rows: regular-thresholds rows, whole reads");
     static_assert(PSH == 0 || (AH == 0 && SEG == 0 && (MODE == 6 || MODE == 3)), "pair-shared gathers: plain 8-byte rows, whole reads");
+    static_assert(CNT == 0 || (SEG == 0 && AH == 0), "the count query: whole reads on the plain rows");
     enum : uint32_t { phStart = 0, phScan = 1, phLF = 2, phInit = 3, phDone = 4 };
     enum : uint32_t { pNone = 0, pScan = 1, pFF = 2 };       // what an interval end is waiting for
     __shared__ uint8_t s_code[256];
@@ -1668,7 +1723,7 @@ __global__ __launch_bounds__(256) void zml_kernel_flat(DevIndex ix, const uint8_
     const uint64_t beg = valid ? (SEG == 1 ? seg.seg_in[rid] : offs[rid]) : 0;
     const uint32_t len = valid ? (SEG == 1 ? seg.seg_len[rid] : (uint32_t)(offs[rid + 1] - beg)) : 0;
     const uint64_t obeg = (SEG == 1 && valid) ? seg.seg_out[rid] : beg;
-    uint16_t *O = out + obeg;
+    uint16_t *O = CNT ? nullptr : out + obeg;
     const uint32_t packed_end = len & ~7u;
     const IdxT r1 = (IdxT)(ix.r - 1), end_row = (IdxT)ix.end_bwt_idx, wb_last = (IdxT)(ix.r - 4);
     // K1: the state right after the base just emitted (the machine may already be moving on to the next base when the
@@ -1715,6 +1770,42 @@ __global__ __launch_bounds__(256) void zml_kernel_flat(DevIndex ix, const uint8_
     uint32_t bn = len > 1 ? s_code[(uint32_t)(rb >> 48) & 0xFFu] : 0xFFu;
     uint32_t bn2 = len > 2 ? s_code[(uint32_t)(rb >> 40) & 0xFFu] : 0xFFu;
     uint4 pk = make_uint4(0, 0, 0, 0), pk_old = pk;
+    // CNT: the last non-empty interval (what the search reports: backward_search :176-199) and whether the search has begun
+    IdxT prs = 0, pre = 0;
+    uint32_t pos_ = 0, poe = 0, have = 0;
+    if (CNT && ix.ftab_k != 0u) {                             // the first K bases by one lookup (count_kernel_v0 has the table's story)
+        const uint32_t K = ix.ftab_k;
+        uint32_t kidx = 0, bad = (uint32_t)(len < K);
+        for (uint32_t i = 0; i < K; ++i) {
+            const uint64_t src = i < 8u ? rb : rb2;
+            const uint32_t cc = (bad ? 0xFFu : (uint32_t)s_code[(uint32_t)(src >> (8u * (7u - (i & 7u)))) & 0xFFu]) - ix.sep;
+            bad |= (uint32_t)(cc > 3u);
+            kidx |= (cc & 3u) << (2u * i);
+        }
+        uint4 e4 = make_uint4(0, 0, 0, 0);
+        if (!bad) e4 = ix.ftab[kidx];
+        if (e4.w >> 31) {
+            rs = (IdxT)((uint64_t)e4.x | ((uint64_t)(e4.z & 15u) << 32));
+            re = (IdxT)((uint64_t)e4.y | ((uint64_t)((e4.z >> 4) & 15u) << 32));
+            os = (e4.z >> 8) & 0xFFFu;
+            oe = e4.z >> 20;
+            ff_total = e4.w & 0x7FFFu;
+            scan_total = (e4.w >> 15) & 0xFFFFu;
+            prs = rs; pre = re; pos_ = os; poe = oe; have = 1;
+            k = K;
+            open = 1;
+            if (k == len) ph = phDone;
+            else { ps = pFF; pe = pFF; ffs = 65535u; ffe = 65535u; ph = phInit; }   // the rows of the two ends: no fast-forward
+            // the decoder's state for step K: b, bn, bn2 = steps K .. K + 2 (K <= 12: all inside the first 16 bases), rb = the
+            // 8-group of step K + 2
+            auto code_at = [&](uint32_t j) -> uint32_t {
+                const uint64_t src = j < 8u ? rb : rb2;
+                return j < len ? (uint32_t)s_code[(uint32_t)(src >> (8u * (7u - (j & 7u)))) & 0xFFu] : 0xFFu;
+            };
+            b = code_at(K); bn = code_at(K + 1u); bn2 = code_at(K + 2u);
+            if (K + 2u >= 8u) rb = rb2;
+        }
+    }
     uint2 ws[4], we[4], es[4], ee[4];                         // AH: es / ee = the look-ahead entries of the windows' rows
     // a window of the table the parse walks on: the plain rows, or (AH) the look-ahead copy with its rows' entries
     uint4 raw_s[2], raw_e[2];                                 // PSH: what this lane loaded for its pair, assembled at the loop's top
@@ -1856,6 +1947,7 @@ __global__ __launch_bounds__(256) void zml_kernel_flat(DevIndex ix, const uint8_
                 else if ((rs < re) || (rs == re && os <= oe)) {  // query_zml :717-720
                     ml += 1;
                     book();
+                    if (CNT) { prs = rs; pre = re; pos_ = os; poe = oe; }
                     ph = k == len ? phDone : phStart;
                 } else fail = 1;
             } else if (first && ready && ph == phInit) {     // the rows of a new phrase's ends have arrived
@@ -1899,7 +1991,10 @@ __global__ __launch_bounds__(256) void zml_kernel_flat(DevIndex ix, const uint8_
                     fail = 1;                                // (with an emission already made in this iteration: decided again
                 }                                            // in the next one -- ph stays phScan)
             }
-            if (fail) {                                      // :750-760 / :696-704: the base opens the next phrase
+            if (fail && CNT && k != 0u) {                    // the search ends here (backward_search :176-199): the last non-empty
+                ph = phDone;                                 // interval is reported, this base is not matched
+                ps = pNone; pe = pNone;
+            } else if (fail) {                               // :750-760 / :696-704: the base opens the next phrase
                 ml = 0;
                 open = 0;
                 ph = phStart;
@@ -1908,9 +2003,15 @@ __global__ __launch_bounds__(256) void zml_kernel_flat(DevIndex ix, const uint8_
                     os = (uint32_t)ix.first_offsets[b + 1]; oe = (uint32_t)ix.last_offsets[b + 1];
                     open = ((rs < re) || (rs == re && os <= oe)) ? 1u : 0u;
                     if (open) { ps = pFF; pe = pFF; ffs = 65535u; ffe = 65535u; ph = phInit; }   // rows only: no fast-forward
+                    if (CNT) { prs = rs; pre = re; pos_ = os; poe = oe; have = 1; }
                 }
-                book();
-                if (k == len) ph = phDone;
+                if (CNT && (b == 0xFFu || open == 0u)) {     // query_backward_search :344-347: an illegal last base matches nothing ("0/len");
+                    if (b != 0xFFu) k = 1;                   // a base that does not occur: itself, with its (empty) interval
+                    ph = phDone;
+                } else {
+                    book();
+                    if (k == len) ph = phDone;
+                }
             }
         };
         micro(true);
@@ -1977,9 +2078,9 @@ __global__ __launch_bounds__(256) void zml_kernel_flat(DevIndex ix, const uint8_
             }
         };
         if (n_emit) {
-            emit_at(ekA, valA);
+            if (!CNT) emit_at(ekA, valA);
             if (n_emit == 2u) {
-                emit_at(ekB, valB);
+                if (!CNT) emit_at(ekB, valB);
                 decode_ahead(ekA + 3u, bn);                   // (b, bn, bn2) were shifted twice: two places to fill
                 decode_ahead(ekB + 3u, bn2);
             } else {
@@ -1995,7 +2096,19 @@ __global__ __launch_bounds__(256) void zml_kernel_flat(DevIndex ix, const uint8_
             seg.tot[rid] = tt;
         }
     } else {
-        if (failed) {
+        if (CNT) {
+            if (valid) {
+                uint64_t m_out = 0, c_out = 0;
+                if (have && !failed) {
+                    m_out = (uint64_t)k;
+                    // MoveInterval::count, include/move_intervals.hpp:47-58, via the row-start checkpoints
+                    if (prs == pre) c_out = (uint64_t)poe - pos_ + 1;
+                    else c_out = (row_start<MODE>(ix, (uint64_t)pre) + poe) - (row_start<MODE>(ix, (uint64_t)prs) + pos_) + 1;
+                }
+                matched[rid] = m_out;
+                count[rid] = c_out;
+            }
+        } else if (failed) {
             for (uint32_t i = 0; i < len; ++i) O[i] = 0;
         }
         if (valid && err) err[rid] = (uint8_t)failed;
@@ -2113,10 +2226,10 @@ static hipError_t launch_zml_segmented(const DevIndex &ix, const uint8_t *d_base
     if (ix.r <= (3ull << 30) / 8 && ix.r >= 8 && n_bases >= 16) {
         if (ix.idx32)
             hipLaunchKernelGGL((zml_kernel_flat<MODE, uint32_t, 1>), dim3((unsigned)((max_seg + 63) / 64)), dim3(64), 0, stream, ix,
-                               d_bases, d_offsets, max_seg, d_out, d_err, d_stats, d_order, seg);
+                               d_bases, d_offsets, max_seg, d_out, d_err, d_stats, d_order, seg, nullptr, nullptr);
         else
             hipLaunchKernelGGL((zml_kernel_flat<MODE, uint64_t, 1>), dim3((unsigned)((max_seg + 63) / 64)), dim3(64), 0, stream, ix,
-                               d_bases, d_offsets, max_seg, d_out, d_err, d_stats, d_order, seg);
+                               d_bases, d_offsets, max_seg, d_out, d_err, d_stats, d_order, seg, nullptr, nullptr);
     } else {
         hipLaunchKernelGGL((zml_kernel<MODE, 1>), dim3((unsigned)((max_seg + bt256 - 1) / bt256)), dim3(bt256), 0, stream, ix, d_bases,
                            d_offsets, max_seg, d_out, d_err, d_stats, d_order, seg);
@@ -2130,6 +2243,39 @@ static hipError_t launch_zml_segmented(const DevIndex &ix, const uint8_t *d_base
                        seg_j, seg_rem, max_over, on_chain, d_out, join);
     hipLaunchKernelGGL((zml_kernel<MODE, 2>), dim3((unsigned)((n_reads + bt256 - 1) / bt256)), dim3(bt256), 0, stream, ix, d_bases,
                        d_offsets, n_reads, d_out, d_err, d_stats, d_order, seg);
+    return hipGetLastError();
+}
+
+static hipError_t launch_count_flat(int mode, const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
+                                    uint64_t *d_matched, uint64_t *d_count, uint8_t *d_err, DevStats *d_stats, const uint32_t *d_order,
+                                    const LaunchCfg &cfg, hipStream_t stream, LaunchInfo *info, bool pair) {
+    const uint64_t blocks = (n_reads + 63) / 64;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)blocks), block(64);
+    const int wpc = cfg.waves_per_cu > 0 ? cfg.waves_per_cu : 0;     // "waves_per_cu": occupancy cap by LDS padding (<= 64 KiB here), as launch_zml
+    size_t dyn_lds = 0;
+    if (wpc > 0) {
+        const int bpc = wpc < 3 ? 3 : wpc;
+        if (bpc < 32) dyn_lds = ((163840u / (unsigned)bpc) & ~1023u) - 1024u;
+    }
+    if (info) {
+        snprintf(info->kernel, sizeof(info->kernel), "zml_kernel_flat<%d, %s, 0, 0, %d, 1>", mode, ix.idx32 ? "unsigned int" : "unsigned long", pair ? 1 : 0);
+        info->variant = 1; info->block_threads = 64; info->waves_per_cu = wpc; info->segmented = 0; info->idx64 = ix.idx32 ? 0 : 1; info->staged = 0;
+        info->ahead = 0;
+    }
+#define MOVI_LAUNCH_CNT(M, T, P)                                                                                          \
+    hipLaunchKernelGGL((zml_kernel_flat<M, T, 0, 0, P, 1>), grid, block, dyn_lds, stream, ix, d_bases, d_offsets, n_reads, \
+                       (uint16_t *)nullptr, d_err, d_stats, d_order, ZSegArgs(), d_matched, d_count)
+#define MOVI_LAUNCH_CNT_M(M)                                                                                              \
+    do {                                                                                                                  \
+        if (ix.idx32) { if (pair) MOVI_LAUNCH_CNT(M, uint32_t, 1); else MOVI_LAUNCH_CNT(M, uint32_t, 0); }                \
+        else { if (pair) MOVI_LAUNCH_CNT(M, uint64_t, 1); else MOVI_LAUNCH_CNT(M, uint64_t, 0); }                         \
+    } while (0)
+    if (mode == 6) MOVI_LAUNCH_CNT_M(6);
+    else if (mode == 3) MOVI_LAUNCH_CNT_M(3);
+    else return hipErrorInvalidValue;
+#undef MOVI_LAUNCH_CNT_M
+#undef MOVI_LAUNCH_CNT
     return hipGetLastError();
 }
 
@@ -2204,25 +2350,25 @@ hipError_t launch_zml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
                                d_out, d_err, d_stats, d_order, ZSegArgs());                                    \
         else if (pair && ix.idx32)                                                                             \
             hipLaunchKernelGGL((zml_kernel_flat<M, uint32_t, 0, 0, 1>), grid, block, dyn_lds, stream, ix,      \
-                               d_bases, d_offsets, n_reads, d_out, d_err, d_stats, d_order, ZSegArgs());       \
+                               d_bases, d_offsets, n_reads, d_out, d_err, d_stats, d_order, ZSegArgs(), nullptr, nullptr); \
         else if (pair)                                                                                         \
             hipLaunchKernelGGL((zml_kernel_flat<M, uint64_t, 0, 0, 1>), grid, block, dyn_lds, stream, ix,      \
-                               d_bases, d_offsets, n_reads, d_out, d_err, d_stats, d_order, ZSegArgs());       \
+                               d_bases, d_offsets, n_reads, d_out, d_err, d_stats, d_order, ZSegArgs(), nullptr, nullptr); \
         else if (ix.idx32)                                                                                     \
             hipLaunchKernelGGL((zml_kernel_flat<M, uint32_t>), grid, block, dyn_lds, stream, ix, d_bases,      \
-                               d_offsets, n_reads, d_out, d_err, d_stats, d_order, ZSegArgs());                \
+                               d_offsets, n_reads, d_out, d_err, d_stats, d_order, ZSegArgs(), nullptr, nullptr); \
         else                                                                                                   \
             hipLaunchKernelGGL((zml_kernel_flat<M, uint64_t>), grid, block, dyn_lds, stream, ix, d_bases,      \
-                               d_offsets, n_reads, d_out, d_err, d_stats, d_order, ZSegArgs());                \
+                               d_offsets, n_reads, d_out, d_err, d_stats, d_order, ZSegArgs(), nullptr, nullptr); \
     } while (0)
     // resident layouts: 6 = regular-thresholds rows, 3 = regular rows (threshold-less types: 12-bit lengths)
     if (mode == 6 && ahead) {
         if (ix.idx32)
             hipLaunchKernelGGL((zml_kernel_flat<6, uint32_t, 0, 1>), grid, block, dyn_lds, stream, ix, d_bases, d_offsets, n_reads, d_out,
-                               d_err, d_stats, d_order, ZSegArgs());
+                               d_err, d_stats, d_order, ZSegArgs(), nullptr, nullptr);
         else
             hipLaunchKernelGGL((zml_kernel_flat<6, uint64_t, 0, 1>), grid, block, dyn_lds, stream, ix, d_bases, d_offsets, n_reads, d_out,
-                               d_err, d_stats, d_order, ZSegArgs());
+                               d_err, d_stats, d_order, ZSegArgs(), nullptr, nullptr);
     } else if (mode == 6) MOVI_LAUNCH_ZML(6);
     else if (mode == 3) MOVI_LAUNCH_ZML(3);
     else return hipErrorInvalidValue;

@@ -118,6 +118,7 @@ struct LaunchCfg {
     // advance, lane refill -- were A/B variants that never earned a default; removed in round 5.)
     int pml_variant = -1;
     int zml_variant = -1;  // -1 auto; 0 base-synchronous kernel, 1 lane state machine
+    int count_variant = -1; // -1 auto (launch_count); 0 count_kernel_v0 (base-synchronous), 1 the lane state machine (zml_kernel_flat<..., CNT = 1>)
     int num_cus = 256;
     int waves_per_cu = 0;  // 0 = auto (the state machine on big batches: kCapWaves; else no cap); else cap resident waves per CU by padding the block's LDS allocation
     int seg_len = 2048;    // PML: batches whose mean read length is >= 2 x seg_len are walked segment-parallel (0 = never) ...
@@ -166,7 +167,7 @@ struct ClsArgs {
 // read starts in (K1); then one lane per segment BOUNDARY continues the walk of the segment before across the
 // boundary until it is in step -- same row, offset and match length at one of the checkpoints the speculative lane
 // left every 32 bases -- with what that lane did (K2): from there on the two walks are the same walk.  A read all of
-// whose boundaries fell into step is exact; any other is walked again from end to end (K3).  tests/sync_study.py: on
+// whose boundaries fell into step is exact; any other is walked again from end to end (K3).  tests/studies/sync_study.py: on
 // 10 kbp reads with 8 % / 1 % / 0.1 % substitutions a walk started mid-read is in step after a median of 11 / 80 / 607
 // bases (maximum 107 / 665 / 4540).
 struct SegCkpt { uint64_t idx; uint32_t off, ml, ff, scan, repo, pad_; };   // state after a base (before the LF to the next) + the segment's counters so far
@@ -218,6 +219,10 @@ struct WalkLaunch {
     int cls_mode = 0;                     // 0 = PML vector, 1 = vector + classification bins, 2 = bins only
     int sep = 0, stg = 0, ahd = 0, psh = 0, ring = 0;   // separators index / reads staged through LDS / look-ahead rows / pair-shared gathers / PMLs out through the LDS ring
 };
+// Diagnostic: when switched on (movi_launch_log), every launch of the walk kernel notes its name -- the K1 / K3 launches of the
+// segment plan included, which LaunchInfo (the dominant kernel only) does not show.
+void note_walk_launch(const char *kernel_name);
+size_t take_launch_log(char *buf, size_t cap);   // switches the log on; returns the bytes the names (one per line) take; clears it
 hipError_t launch_walk_u32(const WalkLaunch &L, LaunchInfo *info);
 hipError_t launch_walk_u64(const WalkLaunch &L, LaunchInfo *info);
 hipError_t launch_walkseg_u32(int seg, const WalkLaunch &L, LaunchInfo *info);   // seg: 1 = segments (K1), 2 = re-walked reads (K3)
@@ -241,7 +246,7 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
 hipError_t launch_count(int mode, const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets,
                         uint64_t n_reads, uint64_t *d_matched, uint64_t *d_count, uint8_t *d_err,
                         DevStats *d_stats, const uint32_t *d_order, const LaunchCfg &cfg, hipStream_t stream,
-                        LaunchInfo *info = nullptr);
+                        LaunchInfo *info = nullptr, uint64_t n_bases = 0);   // n_bases: the batch's size if the caller knows it (the state machine needs >= 16)
 
 hipError_t launch_zml(int mode, const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets,
                       uint64_t n_reads, uint64_t n_bases, uint16_t *d_out, uint8_t *d_err, DevStats *d_stats,

@@ -619,9 +619,11 @@ static hipError_t walk_go(const WalkLaunch &L, LaunchInfo *info) {
         if (ea != hipSuccess) return ea;
     }
     hipLaunchKernelGGL(kern, L.grid, L.block, L.dyn_lds, L.stream, L.ix, L.bases, L.offs, L.n, L.out, L.err, L.stats, L.order, L.cls, L.seg);
-    if (info)                                              // the name as rocprofv3 prints it: every template argument, none dropped
-        snprintf(info->kernel, sizeof(info->kernel), "pml_kernel_flatp<6, %s, %d, %d, %d, %d, %d, %d, %d>",
-                 sizeof(IdxT) == 4 ? "unsigned int" : "unsigned long", CLS, SEP, SEG, STG, AHD, PSH, RING);
+    char name[96];                                         // the name as rocprofv3 prints it: every template argument, none dropped
+    snprintf(name, sizeof(name), "pml_kernel_flatp<6, %s, %d, %d, %d, %d, %d, %d, %d>", sizeof(IdxT) == 4 ? "unsigned int" : "unsigned long",
+             CLS, SEP, SEG, STG, AHD, PSH, RING);
+    if (info) snprintf(info->kernel, sizeof(info->kernel), "%s", name);
+    note_walk_launch(name);
     return hipGetLastError();
 }
 template <typename IdxT, int SEG, int CLS, int SEP>

@@ -296,6 +296,14 @@ class MoveIndex:
                                       C.c_void_p(d_order) if d_order else None,
                                       C.c_void_p(stream) if stream else None))
 
+    PREPARE_PML, PREPARE_COUNT, PREPARE_ZML = 1, 2, 4
+
+    def prepare(self, what=1 | 2 | 4, stream=0):
+        """movi_index_prepare: build the handle's derived tables now (not inside the first query); returns their bytes."""
+        n = C.c_uint64(0)
+        check(lib().movi_index_prepare(self._h, int(what), C.c_void_p(stream) if stream else None, C.byref(n)))
+        return int(n.value)
+
     def last_launch(self):
         """movi_last_launch: dict(kernel=..., variant=..., block_threads=..., waves_per_cu=..., segmented=..., idx64=...)."""
         li = LaunchInfoC()

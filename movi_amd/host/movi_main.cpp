@@ -514,27 +514,14 @@ int run_query(const Options &o) {
         }
     } joiner{free_q, done_q, parser, writer};
 
-    // ---- warm-up, while the parser works on the first chunk: a one-read query of the same kind on every handle, so that what
-    // a handle does once -- building the top-of-walk / interval table (256 MB, ~4 ms), the row-start checkpoints, loading the
-    // kernels' code objects, the first staging allocations -- is not paid inside the first chunk's call (1 M x 150 bp: 24 ms
-    // of the command's 30 ms of GPU calls were that first call; a steady-state call on a 2^25-base chunk takes 1.8 - 2.9 ms)
-    {
-        const uint8_t wb[32] = {'A','C','G','T','A','C','G','T','A','C','G','T','A','C','G','T','A','C','G','T','A','C','G','T','A','C','G','T','A','C','G','T'};
-        const uint64_t wo[2] = {0, 32};
-        uint16_t wp[32];
-        uint64_t wm = 0, wc = 0;
-        uint32_t wa = 0, wbl = 0;
-        uint64_t wsum = 0;
-        uint8_t we = 0;
-        for (auto *hd : handles) {                                     // (errors here are not the query's: the real calls report)
-            if (o.pml && o.classify && !o.write_output_allowed())
-                (void)movi_pml_classify_host(hd, wb, wo, 1, (uint32_t)o.bin_width, classifier.max_value_thr, &wa, &wbl, &wsum, &we, nullptr);
-            else if (o.pml && o.logs) {
-                // --logs runs on the first kernel, which uses none of the derived tables: nothing to build ahead of it
-            } else if (o.pml) (void)movi_pml_host(hd, wb, wo, 1, wp, &we, nullptr);
-            else if (o.zml) (void)movi_zml_host(hd, wb, wo, 1, wp, &we, nullptr);
-            else (void)movi_count_host(hd, wb, wo, 1, &wm, &wc, &we, nullptr);
-        }
+    // ---- preparation, while the parser works on the first chunk: what a handle does once -- building the top-of-walk / interval
+    // table (256 MB, ~4 ms), the look-ahead rows, the row-start checkpoints, loading the kernels' code object (the builders' launches
+    // do) -- is not paid inside the first chunk's call (1 M x 150 bp: 24 ms of the command's 30 ms of GPU calls were that first
+    // call; a steady-state call on a 2^25-base chunk takes 1.8 - 2.9 ms).  movi_index_prepare (round 5) replaces the one-read
+    // warm-up query of rounds 3 - 4.
+    for (auto *hd : handles) {                                         // (errors here are not the query's: the real calls report)
+        if (o.pml && o.logs) continue;                                 // --logs runs on the first kernel, which uses none of the derived tables
+        (void)movi_index_prepare(hd, o.pml ? MOVI_PREPARE_PML : (o.zml ? MOVI_PREPARE_ZML : MOVI_PREPARE_COUNT), nullptr, nullptr);
     }
 
     // ---- stage 2: the GPU calls, in input order

@@ -14,6 +14,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: builds a 113 M-row real BWT first (~10 min of host time): deselected unless "
+                                       "MOVI_SLOW_TESTS=1 (tools/r05_real_bwt.sh runs them; the log is committed under profiles/)")
 
 
 def _have_gpu():
@@ -25,6 +27,11 @@ def _have_gpu():
 
 
 def pytest_collection_modifyitems(config, items):
+    if os.environ.get("MOVI_SLOW_TESTS") != "1":            # (deselected, not skipped: they are not part of the default suites)
+        slow = [it for it in items if "slow" in it.keywords]
+        if slow:
+            config.hook.pytest_deselected(items=slow)
+            items[:] = [it for it in items if "slow" not in it.keywords]
     if _have_gpu():
         return
     skip = pytest.mark.skip(reason="no GPU in this container")
@@ -37,10 +44,10 @@ def pytest_collection_modifyitems(config, items):
 def built_lib():
     """libmovi_hip.so, (re)built if stale.  hipcc cross-compiles without a GPU."""
     so = os.path.join(ROOT, "movi_amd", "lib", "libmovi_hip.so")
-    srcs = [os.path.join(ROOT, "movi_amd", "csrc", f) for f in
-            ("movi_kernels.hip", "movi_abi.hip", "movi_kernels.hpp")] + [os.path.join(ROOT, "include", "movi_hip.h")]
+    csrc = os.path.join(ROOT, "movi_amd", "csrc")
+    srcs = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".hpp"))] + [os.path.join(ROOT, "include", "movi_hip.h")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "movi_amd", "csrc")], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-j8", "-C", csrc], stdout=subprocess.DEVNULL)
     return so
 
 

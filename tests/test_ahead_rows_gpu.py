@@ -251,6 +251,7 @@ def test_count_on_the_look_ahead_rows_vs_oracle(built_lib, golden_image, mode):
     reads += [b"", b"A", b"ACGT" * 40, bytes(rng.choice(list(b"ACGT"), size=60).astype(np.uint8))]
     bases, offs = pack(reads)
     em, ec = cpu.count_batch(bases, offs, threads=8)
+    gpu.set_option("count_variant", 0)                                   # count_kernel_v0 (round 5: the default is the lane state machine on the plain rows)
     gpu.set_option("ahead_rows", 0)
     for K in (0, 12):
         gpu.set_option("ftab_k", K)
@@ -335,6 +336,7 @@ def test_count_on_the_look_ahead_rows_separators_and_corrupt_rows(built_lib, gol
     reads = mutated_reads(rng, ref, 2000, 1, 300) + [bytes(ref[39950:40050]), b"ACG%TACGTACGTACGT", bytes(ref[100:1100])]
     bases, offs = pack(reads)
     em, ec = cpu.count_batch(bases, offs, threads=8)
+    gpu.set_option("count_variant", 0)
     for ahead in (0, 1):
         gpu.set_option("ahead_rows", ahead)
         m, c, st = gpu.query_count_packed(bases, offs)
@@ -349,6 +351,7 @@ def test_count_on_the_look_ahead_rows_separators_and_corrupt_rows(built_lib, gol
     rows[rng.choice(118209, 3000, replace=False), 0:4] = 0xFF
     img[off: off + rows.size] = rows.tobytes()
     gpu = movi_amd.MoveIndex.from_image(bytes(img))
+    gpu.set_option("count_variant", 0)
     gpu.set_option("ahead_rows", 0)
     m0, c0, st0, err0, rc0 = gpu.query_count_packed(bases, offs, want_err=True)
     assert st0.errors > 100
@@ -421,6 +424,10 @@ def test_count_uses_the_copy_where_the_table_says_it_pays(built_lib):
     exp, ff, sc = cpu.pml_batch(bases, offs, threads=8)
     out, st = gpu.query_pml_packed(bases, offs)                        # builds the copy (a small table)
     assert gpu.last_launch()["ahead"] == 1 and (out == exp).all() and (st.fast_forwards, st.scans) == (ff, sc)
+    m, c, _ = gpu.query_count_packed(bases, offs)                      # the default: the state machine, on the plain rows
+    assert gpu.last_launch()["ahead"] == 0 and gpu.last_launch()["kernel"] == "zml_kernel_flat<6, unsigned int, 0, 0, 0, 1>"
+    assert (m == em).all() and (c == ec).all()
+    gpu.set_option("count_variant", 0)                                 # count_kernel_v0: the copy only where the table says it pays
     m, c, _ = gpu.query_count_packed(bases, offs)
     assert gpu.last_launch()["ahead"] == 0 and gpu.last_launch()["kernel"] == "count_kernel_v0<6, 0>"   # a random table: plain rows
     assert (m == em).all() and (c == ec).all()
@@ -646,6 +653,7 @@ def test_reposition_hints_vs_oracle(built_lib, golden_image, mode):
     gpu.set_option("repo_hints", 1)
     # count and ZML read the same copy: its hint bits are not theirs
     creads = [bytes(ref[s:s + 120]) for s in range(10, 40010, 400)] + reads[:200]
+    gpu.set_option("count_variant", 0)
     assert gpu.query_count(creads) == [cpu.count(r) for r in creads]
     assert gpu.last_launch()["kernel"] == "count_kernel_v0<6, 1>"
     gpu.set_option("zml_ahead", 1)

@@ -29,7 +29,9 @@ def test_bench_single_gpu_contract():
     for k in REQUIRED:
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "weak"
-    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1      # 1.6 MB of rows + the 256 MB top-of-walk table: not Infinity-Cache-resident
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1                   # the contract's label (an HBM-bandwidth roofline) ...
+    assert d["roofline"]["gathers_served_from"].startswith("infinity cache")                  # ... 1.6 MB of rows (3.2 MB as walked): where the gathers are served from follows the rows they walk
+    assert d["roofline"]["side_table_bytes"] == 256 << 20                                      # ... the top-of-walk table is reported beside it
     assert d["roofline"]["lane_iterations_per_s"] > 0 and d["roofline"]["rows_read_per_s"] > 0
     assert d["roofline"]["kernel"].startswith("pml_kernel_flatp<6, unsigned int, 0, 0, 0, 1, 1,") and d["rccl_ranks"] == 0
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and d["parity_sample_ok"] is True

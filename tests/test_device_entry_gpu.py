@@ -177,7 +177,7 @@ def test_last_launch_reports_the_policy(engine6):
     assert gpu.last_launch()["kernel"] == "pml_kernel<6, 1, 0>"
     gpu.set_option("pml_variant", -1)
     gpu.query_count_packed(bases, offs)
-    assert gpu.last_launch()["kernel"] == "count_kernel_v0<6, 1>" and gpu.last_launch()["ahead"] == 1   # on the look-ahead rows (a small table)
+    assert gpu.last_launch()["kernel"] == "zml_kernel_flat<6, unsigned int, 0, 0, 0, 1>" and gpu.last_launch()["ahead"] == 0   # the lane state machine, on the plain rows (round 5); (a small table)
     gpu.query_zml_packed(bases, offs)
     assert gpu.last_launch()["kernel"] == "zml_kernel_flat<6, unsigned int, 0, 0, 0>"
 
@@ -268,3 +268,58 @@ def test_big_pageable_host_call_page_locks_its_buffers(built_lib):
     assert (zout == expz).all()
     out[:] = 0                                              # still writable, still ours
     gpu.close()
+
+
+def test_prepared_handle_queries_build_nothing_and_can_be_captured(built_lib, golden_image):
+    """movi_index_prepare (round 5): the derived tables -- top-of-walk table, look-ahead rows, interval table, row-start
+    checkpoints -- are built by the call, not inside the first query: afterwards the first movi_pml_device / movi_count_device
+    on the handle leave the device's free memory where it was and can be captured into a HIP graph with no warm-up call before
+    them (a hipMalloc or a stream synchronise inside would fail the capture); the replayed graphs give the oracle's answers."""
+    import torch
+    import movi_amd
+    from oracle.oracle import Oracle
+    img = golden_image(6)
+    cpu = Oracle(img)
+    rng = np.random.default_rng(9700)
+    reads = mutated_reads(rng, _ref(), 900, 1, 300)
+    bases, offs = pack(reads)
+    n = len(reads)
+    exp, ff, sc = cpu.pml_batch(bases, offs, threads=4)
+    em, ec = cpu.count_batch(bases, offs, threads=4)
+    dev = torch.device("cuda", 0)
+    d_bases = torch.from_numpy(bases.copy()).to(dev)
+    d_offs = torch.from_numpy(offs.view(np.int64).copy()).to(dev)
+    d_out = torch.zeros(bases.size, dtype=torch.int16, device=dev)
+    d_m = torch.zeros(n, dtype=torch.int64, device=dev)
+    d_c = torch.zeros(n, dtype=torch.int64, device=dev)
+    gpu = movi_amd.MoveIndex.from_image(img)
+    assert gpu.info("derived_bytes") == 0
+    with pytest.raises(movi_amd.MoviError):
+        gpu.prepare(8)                                         # not a MOVI_PREPARE_* bit
+    got = gpu.prepare(gpu.PREPARE_PML | gpu.PREPARE_COUNT | gpu.PREPARE_ZML)
+    assert got == gpu.info("derived_bytes") and got > 2 * (256 << 20)
+    assert gpu.info("kmer_bytes") == 256 << 20 and gpu.info("ftab_bytes") == 256 << 20
+    assert gpu.info("ahead_rows_bytes") > 0 and gpu.info("ckpt_bytes") > 0
+    assert gpu.prepare() == got                                # idempotent
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    s = torch.cuda.Stream()
+    g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        g1.capture_begin(capture_error_mode="relaxed")
+        gpu.pml_device(d_bases.data_ptr(), d_offs.data_ptr(), n, bases.size, d_out.data_ptr(), 0, s.cuda_stream)
+        g1.capture_end()
+        g2.capture_begin(capture_error_mode="relaxed")
+        gpu.count_device(d_bases.data_ptr(), d_offs.data_ptr(), n, bases.size, d_m.data_ptr(), d_c.data_ptr(), 0, s.cuda_stream)
+        g2.capture_end()
+    assert int(d_out.abs().sum().item()) == 0 and int(d_m.sum().item()) == 0      # captured, not run
+    assert gpu.info("derived_bytes") == got
+    g1.replay()
+    g2.replay()
+    torch.cuda.synchronize()
+    assert (d_out.cpu().numpy().view(np.uint16) == exp).all()
+    assert (d_m.cpu().numpy().view(np.uint64) == em).all() and (d_c.cpu().numpy().view(np.uint64) == ec).all()
+    assert torch.cuda.mem_get_info()[0] >= free0 - (8 << 20)  # (the graphs' own bookkeeping aside)
+    assert gpu.last_launch()["kernel"] == "zml_kernel_flat<6, unsigned int, 0, 0, 0, 1>"   # the count query's state machine
+    gpu.close()
+    cpu.close()

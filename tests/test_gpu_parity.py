@@ -163,6 +163,65 @@ def test_count_vs_oracle(engines, mode):
 
 
 @pytest.mark.parametrize("mode", [6, 8])
+def test_count_state_machine_vs_oracle(engines, mode):
+    """"count_variant" 1 (round 5): the backward search as a lane state machine over row windows (zml_kernel_flat<..., CNT = 1>;
+    by itself on tables beyond the TLBs' reach) against the oracle and against count_kernel_v0 -- matched lengths, counts, error
+    bytes and the fast-forward / scan counters -- with and without the interval table (every K the table can have: the search
+    then starts at base K), the pair-shared gathers, the 64-bit row indexes; reads of every length from 0, illegal bases at every
+    distance from the read's end, bases that do not extend, exact substrings."""
+    from oracle import build_index as B
+    gpu, cpu = engines[mode]
+    ref = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))[0][1]
+    rng = np.random.default_rng(2200 + mode)
+    reads = mutated_reads(rng, ref, 700, 1, 400)
+    reads += [b"", b"A", b"N", b"AN", b"NA", b"ACGTN", b"NACGT", b"C" * 40, b"T" * 300, ref[1000:1300], ref[5:6], ref[:700], ref[-700:]]
+    reads += [ref[3000:3000 + L] for L in range(0, 41)]
+    for pos in range(0, 20):                                   # an illegal base at distance pos from the read's end
+        r = bytearray(ref[5000:5060]); r[59 - pos] = ord("N"); reads.append(bytes(r))
+        r = bytearray(ref[5000:5060]); r[59 - pos] = ord("a"); reads.append(bytes(r))
+    bases, offs = pack(reads)
+    em, ec = cpu.count_batch(bases, offs, threads=4)
+    try:
+        for K in (12, 0, 1, 5, 7):
+            gpu.set_option("ftab_k", K)
+            gpu.set_option("count_variant", 0)
+            m0, c0, st0 = gpu.query_count_packed(bases, offs)
+            assert gpu.last_launch()["kernel"].startswith("count_kernel_v0<")
+            assert (m0 == em).all() and (c0 == ec).all() and st0.errors == 0, K
+            gpu.set_option("count_variant", 1)
+            for idx64, pair in ((0, 0), (0, 1), (1, 0), (1, 1)):
+                gpu.set_option("idx64", idx64)
+                gpu.set_option("pair_loads", pair)
+                m, c, st, err, rc = gpu.query_count_packed(bases, offs, want_err=True)
+                li = gpu.last_launch()
+                assert li["kernel"] == "zml_kernel_flat<6, %s, 0, 0, %d, 1>" % ("unsigned long" if idx64 else "unsigned int", pair), li
+                assert rc == 0 and not err.any()
+                assert (m == em).all() and (c == ec).all(), (K, idx64, pair)
+                assert (st.fast_forwards, st.scans, st.errors) == (st0.fast_forwards, st0.scans, 0), (K, idx64, pair)
+            gpu.set_option("idx64", 0)
+    finally:
+        gpu.set_option("idx64", 0)
+        gpu.set_option("pair_loads", -1)
+        gpu.set_option("count_variant", -1)
+        gpu.set_option("ftab_k", 12)
+    if mode == 6:                                              # the threshold-less layouts (`regular`, `blocked` -> kmode 3) run it too
+        import movi_amd
+        from oracle.oracle import Oracle
+        for tmode in (3, 2):
+            img = B.build_index_from_seqs([ref], tmode)
+            g3, c3 = movi_amd.MoveIndex.from_image(img), Oracle(img)
+            em3, ec3 = c3.count_batch(bases, offs, threads=4)
+            g3.set_option("count_variant", 1)
+            for pair in (0, 1):
+                g3.set_option("pair_loads", pair)
+                m, c, st = g3.query_count_packed(bases, offs)
+                assert g3.last_launch()["kernel"] == "zml_kernel_flat<3, unsigned int, 0, 0, %d, 1>" % pair
+                assert (m == em3).all() and (c == ec3).all() and st.errors == 0, (tmode, pair)
+            g3.close()
+            c3.close()
+
+
+@pytest.mark.parametrize("mode", [6, 8])
 @pytest.mark.parametrize("variant", [0, 1])
 def test_zml_vs_oracle(engines, mode, variant):
     """MoveStructure::query_zml (src/move_structure_query.cpp:690-785): ragged reads with substitutions
