@@ -401,9 +401,11 @@ def test_look_ahead_on_odd_texts(built_lib, kind):
         assert gpu.last_launch()["ahead"] == ahead and gpu.last_launch()["staged"] > 0
         assert (out == exp).all(), (kind, ahead)
         assert (st.fast_forwards, st.scans, st.errors) == (ff, sc, 0), (kind, ahead)
-        m, c, cst = gpu.query_count_packed(bases, offs)
-        assert gpu.last_launch()["ahead"] == (1 if ahead == 1 else 0)
-        assert (m == em).all() and (c == ec).all() and cst.errors == 0, (kind, ahead)
+        for cv in (0, -1):                                 # count_kernel_v0 (on the copy where it is there) and the default state machine (plain rows)
+            gpu.set_option("count_variant", cv)
+            m, c, cst = gpu.query_count_packed(bases, offs)
+            assert gpu.last_launch()["ahead"] == (1 if ahead == 1 and cv == 0 else 0)
+            assert (m == em).all() and (c == ec).all() and cst.errors == 0, (kind, ahead, cv)
     gpu.close()
     cpu.close()
 
