@@ -55,6 +55,9 @@ WORKLOADS = {
                         "SNPs (1.09 Gbp text, ~102 M rows = 0.8 GB, built on first use: ~10 min), 1.25M x 150bp reads per GPU"),
     "c4real2": dict(kind="pangenome", pg="big2", mode=6, reads=1_250_000, read_len=150, sub=0.01,
                     desc="the same with a 16.5 Mbp ancestor: 2.11 Gbp text, ~220 M rows = 1.8 GB (look-ahead copy 3.5 GB), ~6 min to build"),
+    "c4big": dict(kind="pangenome", pg="big3", mode=6, reads=1_250_000, read_len=150, sub=0.01,
+                  desc="a real BWT of about half a billion rows (round 5): the 2.11 Gbp pangenome with 4 % SNPs between its 64 genomes (n / r ~ 3.8: "
+                       "~0.55 B rows = 4.4 GB, look-ahead copy 8.9 GB), ~7 min to build, 1.25M x 150bp reads per GPU"),
     "tiny": dict(kind="synth", rows=200_000, mode=6, reads=20_000, read_len=150, sub=0.01,
                  desc="tiny plumbing workload"),
     "tinypg": dict(kind="pangenome", pg="tiny", mode=6, reads=20_000, read_len=150, sub=0.01,
@@ -62,11 +65,12 @@ WORKLOADS = {
 }
 PG_BIG = dict(anc=8_500_000, genomes=64, snp=0.01, seed=12)   # ~102 M rows (n / r = 10.7): tools/build_index, ~10 min, ~16 GB of host memory
 PG_BIG2 = dict(anc=16_500_000, genomes=64, snp=0.01, seed=14)  # ~220 M rows: the largest text the 32-bit suffix array takes (2.11 Gbp), ~35 GB of host memory
+PG_BIG3 = dict(anc=16_500_000, genomes=64, snp=0.04, seed=15)  # the same 2.11 Gbp with 4 % SNPs: n / r ~ 3.8 (small-scale calibration: 1 % 11.1, 3 % 4.6, 5 % 3.1, 8 % 2.3) -> ~0.55 B rows: a REAL BWT at the size of the BASELINE target's table
 PG_TINY = dict(anc=60_000, genomes=8, snp=0.002, seed=13)     # tests: built in a second
 
 
 def pg_of(wl):
-    return {"big": PG_BIG, "big2": PG_BIG2, "tiny": PG_TINY}.get(wl.get("pg"), PG_C2)
+    return {"big": PG_BIG, "big2": PG_BIG2, "big3": PG_BIG3, "tiny": PG_TINY}.get(wl.get("pg"), PG_C2)
 # where built pangenome indexes and their reads are kept: $MOVI_BENCH_CACHE, else a .bench_cache/ beside this file if one
 # travelled with the tree (a prebuilt c2 index saves the ~2 min single-threaded build per fresh box), else /tmp
 CACHE = os.environ.get("MOVI_BENCH_CACHE") or (os.path.join(ROOT, ".bench_cache") if os.path.isdir(os.path.join(ROOT, ".bench_cache"))

@@ -346,9 +346,11 @@ int run_query(const Options &o) {
     // resident) -- but the host stages (text parsing ~1.4 GB/s, BPF writing) are what bounds the command, and they only overlap
     // the GPU calls and each other across chunks: better several half-filled launches than one full one
     uint64_t chunk_bases = 1ull << 25, chunk_min_reads = 1ull << 15, chunk_hard_max = 1ull << 30;
+    bool ramp_chunks = std::getenv("MOVI_NO_CHUNK_RAMP") == nullptr;   // (A/B hook)
     if (const char *e = std::getenv("MOVI_CHUNK_BASES")) {             // test hook: many small chunks
         chunk_bases = std::max<uint64_t>(1, std::strtoull(e, nullptr, 10));
         chunk_min_reads = 1;
+        ramp_chunks = false;
     }
     uint64_t reads_done = 0, bases_done = 0;
     double gpu_seconds = 0;
@@ -378,9 +380,16 @@ int run_query(const Options &o) {
     std::thread parser([&] {
         try {
             Job *j = nullptr;
+            // (round 5) the first chunks are SMALLER -- a quarter, then half of the steady size: nothing downstream runs while the
+            // first chunk is parsed and nothing upstream while the last one is walked and written, so a run of a few chunks (1 M x
+            // 150 bp = 4.5 chunks of 2^25 bases) paid a full chunk's parse time before its first GPU call.  Chunk boundaries are
+            // reference batch boundaries either way: the output does not depend on them (tests: MOVI_CHUNK_BASES).
+            unsigned chunk_no = 0;
             while (free_q.pop(j)) {
                 const auto tp = std::chrono::steady_clock::now();
-                const bool more = reader.next_chunk(j->rs, chunk_bases, chunk_min_reads, chunk_hard_max);
+                const unsigned down = ramp_chunks && chunk_no < 2 ? 2 - chunk_no : 0;
+                chunk_no++;
+                const bool more = reader.next_chunk(j->rs, std::max<uint64_t>(1, chunk_bases >> down), std::max<uint64_t>(1, chunk_min_reads >> down), chunk_hard_max);
                 parse_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - tp).count();
                 if (!more) break;
                 parsed_q.push(j);

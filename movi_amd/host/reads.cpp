@@ -467,7 +467,11 @@ bool BatchReader::next_chunk(ReadSet &out, uint64_t max_bases, uint64_t min_read
     recs_.clear();
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_begin = now();
-    if (!pool_) pool_.reset(new WorkerPool(threads_ ? threads_ : std::min(16u, std::max(1u, std::thread::hardware_concurrency()))));
+    if (!pool_) {
+        unsigned want = threads_ ? threads_ : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+        if (const char *e = std::getenv("MOVI_PARSE_THREADS")) want = (unsigned)std::max(1, std::atoi(e));   // (tuning hook: tools/r05_cli.sh)
+        pool_.reset(new WorkerPool(want));
+    }
     // the newlines of about a chunk's worth of input, found by all workers at once (the rest, if the chunk turns out
     // longer, line by line as before)
     if (mem_) src_.prescan((size_t)std::min<uint64_t>(max_bases + (max_bases >> 2) + (1u << 20), 1ull << 32), *pool_);

@@ -1,5 +1,5 @@
 """GPU suite, slow part (-m gpu with MOVI_SLOW_TESTS=1; tools/r05_real_bwt.sh): the real BWTs behind README's / DESIGN's
-"c4real" and "c4real2" numbers -- 113 M and 226 M rows, beyond the Infinity Cache (and, for the second one's look-ahead copy,
+"c4real", "c4real2" and "c4big" numbers -- 113 M, 226 M and ~550 M rows, beyond the Infinity Cache (and, for the second one's look-ahead copy,
 beyond the TLBs' reach) -- against the oracle AT THEIR SIZE.  bench.py's own workloads: the index is built on first use by
 tools/build_index (3 - 10 min of host time, 16 - 35 GB of host memory; cached under $MOVI_BENCH_CACHE), which is why these
 tests are not part of the default suite: the driver's GPU step has 20 minutes for everything.
@@ -21,7 +21,7 @@ def _slices(n, k=20_000):
     return [(0, k), (n // 2 - k // 2, n // 2 + k // 2), (n - k, n)]
 
 
-@pytest.mark.parametrize("workload", ["c4real", "c4real2"])
+@pytest.mark.parametrize("workload", ["c4real", "c4real2", "c4big"])
 def test_real_bwt_at_size_vs_oracle(built_lib, workload):
     import movi_amd
     import bench
@@ -34,7 +34,7 @@ def test_real_bwt_at_size_vs_oracle(built_lib, workload):
     offs = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
     gpu = movi_amd.MoveIndex.from_image(img)
     rows = int(gpu.desc.r)
-    assert rows > (100_000_000 if workload == "c4real" else 200_000_000)
+    assert rows > {"c4real": 100_000_000, "c4real2": 200_000_000, "c4big": 400_000_000}[workload]
     gpu.prepare(gpu.PREPARE_PML | gpu.PREPARE_COUNT)
     gpu.set_option("host_autopin", 0)                    # the whole batch in one launch (the bench's shape)
     out, st = gpu.query_pml_packed(bases, offs)
@@ -44,8 +44,10 @@ def test_real_bwt_at_size_vs_oracle(built_lib, workload):
     assert li["kernel"] == "pml_kernel_flatp<6, unsigned int, 0, 0, 0, 1, 1, %d, 0>" % pair and li["ahead"] == 1 and li["waves_per_cu"] == 9, li
     m, c, cst = gpu.query_count_packed(bases, offs)
     cli = gpu.last_launch()
-    assert cst.errors == 0 and cli["kernel"] == "zml_kernel_flat<6, unsigned int, 0, 0, 0, 1>", cli   # plain rows below 2 GB: no pairs
-    assert gpu.info("ahead_no_ff") >= 0.67               # (a real BWT: count_kernel_v0 would be admitted to the copy)
+    cpair = 1 if rows * 8 >= 2 << 30 else 0             # the count query's state machine: pairs on plain rows of 2 GB and more
+    assert cst.errors == 0 and cli["kernel"] == "zml_kernel_flat<6, unsigned int, 0, 0, %d, 1>" % cpair, cli
+    no_ff = gpu.info("ahead_no_ff")
+    assert no_ff >= (0.67 if workload != "c4big" else 0.4), no_ff   # (0.83 on the c2 pangenome, 0.75 at 1 % SNPs; 0.51 on random run sequences)
     cpu = Oracle(img)
     for lo, hi in _slices(n):
         sb, so = bases[lo * L: hi * L], offs[: hi - lo + 1]
@@ -59,6 +61,6 @@ def test_real_bwt_at_size_vs_oracle(built_lib, workload):
     gpu.set_option("count_variant", 0)
     lo, hi = _slices(n)[1]
     sm, sc, _ = gpu.query_count_packed(bases[lo * L: hi * L], offs[: hi - lo + 1])
-    assert gpu.last_launch()["kernel"] == "count_kernel_v0<6, 1>" and (sm == m[lo:hi]).all() and (sc == c[lo:hi]).all()
+    assert gpu.last_launch()["kernel"].startswith("count_kernel_v0<6, ") and (sm == m[lo:hi]).all() and (sc == c[lo:hi]).all()
     gpu.close()
     cpu.close()
