@@ -56,8 +56,8 @@ WORKLOADS = {
     "c4real2": dict(kind="pangenome", pg="big2", mode=6, reads=1_250_000, read_len=150, sub=0.01,
                     desc="the same with a 16.5 Mbp ancestor: 2.11 Gbp text, ~220 M rows = 1.8 GB (look-ahead copy 3.5 GB), ~6 min to build"),
     "c4big": dict(kind="pangenome", pg="big3", mode=6, reads=1_250_000, read_len=150, sub=0.01,
-                  desc="a real BWT of about half a billion rows (round 5): the 2.11 Gbp pangenome with 4 % SNPs between its 64 genomes (n / r ~ 3.8: "
-                       "~0.55 B rows = 4.4 GB, look-ahead copy 8.9 GB), ~7 min to build, 1.25M x 150bp reads per GPU"),
+                  desc="a real BWT of two thirds of a billion rows (round 5): the 2.11 Gbp pangenome with 4 % SNPs between its 64 genomes (n / r = 3.1: "
+                       "676 M rows = 5.4 GB, look-ahead copy 10.8 GB), ~7 min to build, 1.25M x 150bp reads per GPU"),
     "tiny": dict(kind="synth", rows=200_000, mode=6, reads=20_000, read_len=150, sub=0.01,
                  desc="tiny plumbing workload"),
     "tinypg": dict(kind="pangenome", pg="tiny", mode=6, reads=20_000, read_len=150, sub=0.01,
@@ -65,7 +65,7 @@ WORKLOADS = {
 }
 PG_BIG = dict(anc=8_500_000, genomes=64, snp=0.01, seed=12)   # ~102 M rows (n / r = 10.7): tools/build_index, ~10 min, ~16 GB of host memory
 PG_BIG2 = dict(anc=16_500_000, genomes=64, snp=0.01, seed=14)  # ~220 M rows: the largest text the 32-bit suffix array takes (2.11 Gbp), ~35 GB of host memory
-PG_BIG3 = dict(anc=16_500_000, genomes=64, snp=0.04, seed=15)  # the same 2.11 Gbp with 4 % SNPs: n / r ~ 3.8 (small-scale calibration: 1 % 11.1, 3 % 4.6, 5 % 3.1, 8 % 2.3) -> ~0.55 B rows: a REAL BWT at the size of the BASELINE target's table
+PG_BIG3 = dict(anc=16_500_000, genomes=64, snp=0.04, seed=15)  # the same 2.11 Gbp with 4 % SNPs: n / r = 3.1 -> 675 738 185 rows (0.68 B): a REAL BWT at the size of the BASELINE target's table (small-scale calibration of n / r against the SNP rate: 1 % 11.1, 3 % 4.6, 5 % 3.1, 8 % 2.3)
 PG_TINY = dict(anc=60_000, genomes=8, snp=0.002, seed=13)     # tests: built in a second
 
 
@@ -235,7 +235,7 @@ def draw_synth_reads(torch, dist, world, rank, dev, synth, six, n_reads, read_le
     return mine
 
 
-def big_table_leg(torch, dist, world, rank, dev, local_rank, stream, synth, movi_amd, cores, rows=1_000_000_000, steps=10, warmup=2):
+def big_table_leg(torch, dist, world, rank, dev, local_rank, stream, synth, movi_amd, cores, rows=1_000_000_000, steps=10, warmup=2, host_legs=True):
     """c4: tools/synth.c's 1 B-row regular-thresholds table (8 GB), 1.25 M x 150 bp reads per GPU.  Rank 0 synthesises the
     table and draws every rank's reads; the rows reach the other GPUs through ONE broadcast (RCCL).  Returns the `big_table`
     object of the bench line on rank 0 (None elsewhere).  The oracle is the checker here, never the thing measured."""
@@ -269,6 +269,9 @@ def big_table_leg(torch, dist, world, rank, dev, local_rank, stream, synth, movi
     cdesc.separator_thresholds, cdesc.separator_map = None, None
     rbytes = int(d_rows.numel())
     index = movi_amd.MoveIndex.from_device_rows(cdesc, d_rows.data_ptr(), device=local_rank, keepalive=d_rows)
+    t0 = time.time()
+    derived = index.prepare(index.PREPARE_PML | index.PREPARE_COUNT)       # look-ahead copy (16 GB), top-of-walk / interval tables, checkpoints
+    t_prep = time.time() - t0
     bases, offs = draw_synth_reads(torch, dist, world, rank, dev, synth, six, n_reads, L, SEED + 1, w["sub"])
     n_bases = int(bases.size)
     d_bases = torch.from_numpy(bases).to(dev)
@@ -295,7 +298,7 @@ def big_table_leg(torch, dist, world, rank, dev, local_rank, stream, synth, movi
            "iterations_per_base": round(st.lane_steps / n_bases, 4) if st.wave_steps else None,
            "algorithmic_bytes_per_base": roof["algorithmic_bytes_per_base"], "errors": int(st.errors),
            "index_gen_s": round(t_gen, 1), "index_upload_s": round(t_up, 2), "index_broadcast_s": round(t_bc, 3),
-           "roofline": roof}
+           "prepare_s": round(t_prep, 3), "derived_bytes": derived, "roofline": roof}
     # BASELINE config 5's query on the same resident rows (a blocked-thresholds file of this table expands to exactly them at
     # upload: tests/test_big_table_gpu.py runs that form): --count
     d_m = torch.zeros(n_reads, dtype=torch.int64, device=dev)
@@ -342,7 +345,42 @@ def big_table_leg(torch, dist, world, rank, dev, local_rank, stream, synth, movi
         out["parity_sample"] = "rank 0's reads [0,2000), [%d,%d), [%d,%d) vs oracle/movi_oracle.c on the same image: PMLs bit-exact, fast-forward and scan counters equal; count: matched lengths and counts equal (%.1f s)" % (
             n_reads // 2 - 1000, n_reads // 2 + 1000, n_reads - 2000, n_reads, time.time() - t0)
         cpu.close()
+    if rank == 0 and world == 1 and host_legs:
+        # round 5: the PCIe-inclusive and the command-line rates on THIS table too (the table the BASELINE target is quoted on)
+        try:
+            from movi_amd._lib import QueryStatsC, check, lib
+            hp = {"unit": "Gbases/s", "note": "movi_pml_host on the 1 B-row table, best of 3 calls after a warm-up call, checked against the device call's vector"}
+            stq = QueryStatsC()
+            ref = got_all                                         # the device call's vector of the whole batch (fetched before the slices re-used d_out)
+            for name, mk in (("pageable", lambda n, dt: np.empty(n, dt)), ("page_locked", movi_amd.pinned_empty)):
+                hb, ho = mk(n_bases, np.uint8), mk(n_bases, np.uint16)
+                hb[:] = bases
+                ts = []
+                for _ in range(4):
+                    t1 = time.perf_counter()
+                    check(lib().movi_pml_host(index._h, hb.ctypes.data, np.ascontiguousarray(offs, np.uint64).ctypes.data, n_reads, ho.ctypes.data, None, C.byref(stq)))
+                    ts.append(time.perf_counter() - t1)
+                hp[name] = round(n_bases / min(ts[1:]) / 1e9, 2)
+                hp[name + "_ok"] = bool((ho == ref).all())
+                del hb, ho
+            out["host_path"] = hp
+        except Exception as e:                            # noqa: BLE001
+            out["host_path"] = {"error": repr(e)[:200]}
     index.close()
+    if rank == 0 and world == 1 and host_legs:
+        import shutil
+        import tempfile
+        tmp = tempfile.mkdtemp(prefix="movi_cli_big_")
+        try:
+            img.tofile(os.path.join(tmp, "index.movi"))           # 8 GB: the command maps it like any index file
+            fa = os.path.join(tmp, "reads.fa")
+            write_fasta(fa, bases.reshape(-1, L))
+            out["cli_path"] = dict(cli_measure(tmp, fa, os.path.join(tmp, "out")), unit="Gbases/s",
+                                   note="movi query on the 1 B-row index file (8 GB, mapped) and a FASTA file of this leg's reads; value = bases / the command's own read-processing time")
+        except Exception as e:                            # noqa: BLE001
+            out["cli_path"] = {"error": repr(e)[:300]}
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
     return out if rank == 0 else None
 
 
@@ -446,14 +484,41 @@ def write_fasta(path, reads2d):
     rec.tofile(path)
 
 
+def cli_measure(idx_dir, fa, out_prefix, modes=("no_output", "bpf"), extra=(), env=None, runs=2):
+    """`movi query -i idx_dir -r fa --verbose` per output mode, best of `runs`: {mode: {value, seconds, stage_s, wall_s}}."""
+    import re
+    import subprocess
+    exe = os.path.join(ROOT, "movi_amd", "bin", "movi")
+    res = {}
+    for mode in modes:
+        flags = ["--no-output"] if mode == "no_output" else ["-o", out_prefix]
+        best, wall = None, None
+        for _ in range(runs):
+            t0 = time.perf_counter()
+            r = subprocess.run([exe, "query", "-i", idx_dir, "-r", fa, "--verbose"] + flags + list(extra), capture_output=True, timeout=900,
+                               env=dict(os.environ, **env) if env else None)
+            w = time.perf_counter() - t0
+            if r.returncode != 0:
+                raise RuntimeError(r.stderr.decode()[-300:])
+            m = re.search(r"processing the reads: ([0-9.e+-]+) s \((\d+) bases; GPU calls ([0-9.e+-]+) s", r.stderr.decode())
+            sec, nb = float(m.group(1)), int(m.group(2))
+            if best is None or sec < best[0]:
+                st = re.search(r"Stage times: parse ([0-9.e+-]+) s, GPU calls ([0-9.e+-]+) s, order \+ write ([0-9.e+-]+) s", r.stderr.decode())
+                best = (sec, nb, float(m.group(3)), st.groups() if st else None)
+                wall = w
+        res[mode] = {"value": round(best[1] / best[0] / 1e9, 3), "seconds": round(best[0], 4), "gpu_calls_s": round(best[2], 4),
+                     "stage_s": {"parse": float(best[3][0]), "gpu": float(best[3][1]), "write": float(best[3][2])} if best[3] else None,
+                     "wall_s": round(wall, 3)}
+    return res
+
+
 def cli_path_leg(idx_dir, reads_150, reads_10k):
     """The drop-in a user touches: the `movi query` binary end to end on FASTA files of the same reads (page cache warm),
     --no-output and with the BPF file; rates exclude process start and index load (the command's own "processing the
-    reads" clock, src/movi.cpp:387-389 prints the same), `wall_s` includes them."""
-    import re
-    import subprocess
+    reads" clock, src/movi.cpp:387-389 prints the same), `wall_s` includes them.  Round 5: also `--gpus 2` with both logical
+    GPUs on the box's one device (MOVI_SHARE_GPU=1: N independent loads, the reads sharded by bases over two host threads) so
+    that the sharding code is timed at least once."""
     import tempfile
-    exe = os.path.join(ROOT, "movi_amd", "bin", "movi")
     out = {"unit": "Gbases/s", "note": "movi query on FASTA input, best of 2 runs; value = bases / the command's own read-processing time "
                                        "(parse + GPU calls + order + write, pipelined); wall_s adds process start, HIP init and index load"}
     tmp = tempfile.mkdtemp(prefix="movi_cli_")
@@ -463,23 +528,14 @@ def cli_path_leg(idx_dir, reads_150, reads_10k):
                 continue
             fa = os.path.join(tmp, name + ".fa")
             write_fasta(fa, arr.reshape(-1, L))
-            for mode, flags in (("no_output", ["--no-output"]), ("bpf", ["-o", os.path.join(tmp, name)])):
-                best, wall = None, None
-                for _ in range(2):
-                    t0 = time.perf_counter()
-                    r = subprocess.run([exe, "query", "-i", idx_dir, "-r", fa, "--verbose"] + flags, capture_output=True, timeout=600)
-                    w = time.perf_counter() - t0
-                    if r.returncode != 0:
-                        raise RuntimeError(r.stderr.decode()[-300:])
-                    m = re.search(r"processing the reads: ([0-9.e+-]+) s \((\d+) bases; GPU calls ([0-9.e+-]+) s", r.stderr.decode())
-                    sec, nb = float(m.group(1)), int(m.group(2))
-                    if best is None or sec < best[0]:
-                        st = re.search(r"Stage times: parse ([0-9.e+-]+) s, GPU calls ([0-9.e+-]+) s, order \+ write ([0-9.e+-]+) s", r.stderr.decode())
-                        best = (sec, nb, float(m.group(3)), st.groups() if st else None)
-                        wall = w
-                out[name + "_" + mode] = {"value": round(best[1] / best[0] / 1e9, 3), "seconds": round(best[0], 4), "gpu_calls_s": round(best[2], 4),
-                                          "stage_s": {"parse": float(best[3][0]), "gpu": float(best[3][1]), "write": float(best[3][2])} if best[3] else None,
-                                          "wall_s": round(wall, 3)}
+            for mode, v in cli_measure(idx_dir, fa, os.path.join(tmp, name)).items():
+                out[name + "_" + mode] = v
+            if name == "short_1Mx150":
+                try:
+                    out[name + "_no_output_gpus2_one_device"] = cli_measure(idx_dir, fa, os.path.join(tmp, name), modes=("no_output",), extra=("--gpus", "2"),
+                                                                            env={"MOVI_SHARE_GPU": "1"})["no_output"]
+                except Exception as e:                    # noqa: BLE001
+                    out[name + "_no_output_gpus2_one_device"] = {"error": repr(e)[:200]}
             os.remove(fa)
     finally:
         import shutil
@@ -923,7 +979,7 @@ def main():
     # ---- PCIe-inclusive rate of the boundary's host entry point ("pre-parsed reads in pinned host memory to
     # PMLs in pinned host memory"), default run only, after the timed region, never part of `value`: the same batch
     # through movi_pml_host from pageable buffers (synchronous path) and from page-locked ones (overlapped path)
-    if (rank == 0 and world == 1 and args.workload == "c2" and args.query == "pml" and not args.classify
+    if (rank == 0 and world == 1 and args.workload in ("c2", "tinypg") and args.query == "pml" and not args.classify
             and args.variant < 0 and not args.no_cpu_baseline):
         try:
             from movi_amd._lib import QueryStatsC, check, lib
@@ -960,7 +1016,7 @@ def main():
             result["host_path"] = hp
         except Exception as e:                            # noqa: BLE001 -- an extra, never worth the headline line
             result["host_path"] = {"error": repr(e)[:200]}
-    default_run = (rank == 0 and world == 1 and args.workload == "c2" and args.query == "pml" and not args.classify
+    default_run = (rank == 0 and world == 1 and args.workload in ("c2", "tinypg") and args.query == "pml" and not args.classify
                    and args.variant < 0 and not args.from_dir)
     # ---- the command-line drop-in end to end (default run only, after the timed region, never part of `value`)
     if default_run and not args.no_cpu_baseline and reads_path:

@@ -1845,7 +1845,13 @@ int movi_index_prepare(movi_index_t *ix, uint32_t what, void *stream, uint64_t *
     HIP_TRY(hipSetDevice(ix->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     ix->ahead_retry_in = 0;                                           // an explicit call asks the device now
-    if ((what & MOVI_PREPARE_PML) && mode_has_thresholds(ix->desc.mode)) ensure_pml_tables(ix, s);
+    if ((what & MOVI_PREPARE_PML) && mode_has_thresholds(ix->desc.mode)) {
+        ensure_pml_tables(ix, s);
+        // the walk kernels live in translation units of their own: their code objects are loaded here, not by the first walk
+        (void)(ix->dev.idx32 ? preload_walk_u32() : preload_walk_u64());
+        (void)(ix->dev.idx32 ? preload_walkseg_u32() : preload_walkseg_u64());
+        (void)hipGetLastError();
+    }
     if (what & MOVI_PREPARE_COUNT) {
         const int rc = ensure_count_tables(ix, s);
         if (rc) return rc;

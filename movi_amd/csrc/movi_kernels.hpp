@@ -227,6 +227,10 @@ hipError_t launch_walk_u32(const WalkLaunch &L, LaunchInfo *info);
 hipError_t launch_walk_u64(const WalkLaunch &L, LaunchInfo *info);
 hipError_t launch_walkseg_u32(int seg, const WalkLaunch &L, LaunchInfo *info);   // seg: 1 = segments (K1), 2 = re-walked reads (K3)
 hipError_t launch_walkseg_u64(int seg, const WalkLaunch &L, LaunchInfo *info);
+hipError_t preload_walk_u32();            // load the translation unit's code object now (movi_index_prepare)
+hipError_t preload_walk_u64();
+hipError_t preload_walkseg_u32();
+hipError_t preload_walkseg_u64();
 
 // Device workspace of the segmented path, owned by whoever owns the stream (the handle; a pipeline slot): grow-only.
 struct SegWorkspace {

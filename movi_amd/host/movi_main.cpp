@@ -251,6 +251,38 @@ int run_query(const Options &o) {
         throw EngineError("requested devices " + std::to_string(o.device) + ".." + std::to_string(o.device + o.gpus - 1) +
                           " but only " + std::to_string(n_dev) + " visible");
     auto t0 = std::chrono::steady_clock::now();
+    // Round 5: the read file is mapped and the parser WARMED while the index loads (BatchReader::warm_up: the worker pool, the first
+    // window's newline scan -- and with it the mapping's page faults --, the three circulating chunks' buffers sized and first
+    // touched by the pool's pinned threads).  A run of 1 M x 150 bp is 4.5 chunks, three of them used to be parsed into fresh memory:
+    // chunk 1 took 7.4 ms, chunks 2 - 3 3.9 - 4.3 ms, a warm chunk 2.8 ms (tools/r05_cli.sh).  (Touching the buffers from helper
+    // threads of THIS thread instead made the parse slower, 0.024 - 0.028 s against 0.020 s: first touch by threads on another NUMA node
+    // than the parser's pinned pool.)  Parsing itself still starts after the index has loaded: the command's "processing the reads"
+    // clock is the reference's.  MOVI_NO_WARM_PARSER=1: A/B.
+    std::ifstream file_in;
+    std::istream *in = &std::cin;
+    InputMapping map;
+    std::unique_ptr<BatchReader> reader_ptr;
+    Job jobs[3];
+    uint64_t chunk_bases = 1ull << 25, chunk_min_reads = 1ull << 15, chunk_hard_max = 1ull << 30;
+    if (const char *e = std::getenv("MOVI_CHUNK_BASES")) {             // test hook: many small chunks
+        chunk_bases = std::max<uint64_t>(1, std::strtoull(e, nullptr, 10));
+        chunk_min_reads = 1;
+    }
+    const bool pin_buffers = std::getenv("MOVI_PINNED") && std::string(std::getenv("MOVI_PINNED")) == "1";
+    std::thread warmer;
+    struct WarmJoin { std::thread &t; ~WarmJoin() { if (t.joinable()) t.join(); } } warm_join{warmer};
+    if (o.read_file != "-") {
+        file_in.open(o.read_file.c_str());
+        if (file_in.good()) {                                          // (a missing file is reported where it always was: after the index)
+            in = &file_in;
+            reader_ptr = open_reader(o.read_file, *in, o.prefetch ? 4 * o.strands : 1, map);   // src/movi.cpp:283, :326
+            if (map.p != MAP_FAILED && !pin_buffers && !std::getenv("MOVI_NO_WARM_PARSER") && !std::getenv("MOVI_CHUNK_BASES"))
+                warmer = std::thread([&] {
+                    ReadSet *sets[3] = {&jobs[0].rs, &jobs[1].rs, &jobs[2].rs};
+                    try { reader_ptr->warm_up(sets, 3, chunk_bases); } catch (...) { /* no memory for it: the chunks allocate as they come */ }
+                });
+        }
+    }
     std::vector<movi_index_t *> handles((size_t)o.gpus, nullptr);
     struct Closer {
         std::vector<movi_index_t *> &h;
@@ -281,14 +313,8 @@ int run_query(const Options &o) {
     std::cerr << "[movi] Time measured for loading the index: "
               << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << " s\n";
 
-    // input: file or stdin (setup_input_file, src/movi.cpp:106-118)
-    std::ifstream file_in;
-    std::istream *in = &std::cin;
-    if (o.read_file != "-") {
-        file_in.open(o.read_file.c_str());
-        if (!file_in.good()) throw std::runtime_error("The input file " + o.read_file + " does not exist.");
-        in = &file_in;
-    }
+    // input: file or stdin (setup_input_file, src/movi.cpp:106-118) -- opened above, while the index loaded
+    if (o.read_file != "-" && !file_in.good()) throw std::runtime_error("The input file " + o.read_file + " does not exist.");
 
     // outputs (open_output_files, src/utils.cpp:319-384)
     Classifier classifier;
@@ -337,21 +363,14 @@ int run_query(const Options &o) {
         std::cerr << "[movi] --logs is only collected for PML queries that write their output to files; ignored here.\n";
     }
 
+    if (warmer.joinable()) warmer.join();
     auto t1 = std::chrono::steady_clock::now();
-    InputMapping map;
-    std::unique_ptr<BatchReader> reader_ptr = open_reader(o.read_file, *in, o.prefetch ? 4 * o.strands : 1, map);   // src/movi.cpp:283, :326
+    if (!reader_ptr) reader_ptr = open_reader(o.read_file, *in, o.prefetch ? 4 * o.strands : 1, map);   // (stdin) src/movi.cpp:283, :326
     BatchReader &reader = *reader_ptr;
     // chunks of >= 2^25 bases and >= 2^15 reads (long reads: up to 2^30 bases): one GPU lane walks one read, so a chunk needs
     // READS to fill the lanes (2^25 bases of 150 bp reads = 224 k reads: more than the 147 k lanes the PML kernel keeps
     // resident) -- but the host stages (text parsing ~1.4 GB/s, BPF writing) are what bounds the command, and they only overlap
     // the GPU calls and each other across chunks: better several half-filled launches than one full one
-    uint64_t chunk_bases = 1ull << 25, chunk_min_reads = 1ull << 15, chunk_hard_max = 1ull << 30;
-    bool ramp_chunks = std::getenv("MOVI_NO_CHUNK_RAMP") == nullptr;   // (A/B hook)
-    if (const char *e = std::getenv("MOVI_CHUNK_BASES")) {             // test hook: many small chunks
-        chunk_bases = std::max<uint64_t>(1, std::strtoull(e, nullptr, 10));
-        chunk_min_reads = 1;
-        ramp_chunks = false;
-    }
     uint64_t reads_done = 0, bases_done = 0;
     double gpu_seconds = 0;
 
@@ -364,33 +383,34 @@ int run_query(const Options &o) {
     // (parse | GPU calls | order + write, three chunks in flight) already overlaps the transfers with the other stages.
     uint64_t input_bytes = 0;
     if (map.p != MAP_FAILED) input_bytes = map.n;
-    const bool pin_buffers = std::getenv("MOVI_PINNED") && std::string(std::getenv("MOVI_PINNED")) == "1";
     auto pin_this_chunk = [&](uint64_t) { return pin_buffers; };
-    Job jobs[3];
     HandOff<Job *> free_q, parsed_q, done_q;
     (void)input_bytes;
     if (pin_buffers)
         for (Job &j : jobs) j.rs.bases.set_allocator(pinned_alloc, pinned_free);
     for (Job &j : jobs) free_q.push(&j);
     double parse_seconds = 0, write_seconds = 0;
+    std::vector<double> chunk_parse_s, chunk_gpu_s;                    // --verbose: the first chunks' stage times one by one
     std::exception_ptr parse_error, write_error;
     std::mutex err_m;
 
+    // (round 5, measured and dropped: keeping the parser's threads off the cache domain of the GPU-call and writer threads --
+    // inside the command every parser phase runs 2 x slower than in tools/parse_bench -- changed nothing: 0.027 - 0.036 s against
+    // 0.026 s per 150 Mbases.  tools/r05_cli.sh)
     // ---- stage 1: parse
     std::thread parser([&] {
         try {
+            reader.adopt_pool();                                       // (a pool built by the warm-up: this thread joins its cache domain)
             Job *j = nullptr;
-            // (round 5) the first chunks are SMALLER -- a quarter, then half of the steady size: nothing downstream runs while the
-            // first chunk is parsed and nothing upstream while the last one is walked and written, so a run of a few chunks (1 M x
-            // 150 bp = 4.5 chunks of 2^25 bases) paid a full chunk's parse time before its first GPU call.  Chunk boundaries are
-            // reference batch boundaries either way: the output does not depend on them (tests: MOVI_CHUNK_BASES).
-            unsigned chunk_no = 0;
+            // (round 5, measured and dropped: smaller FIRST chunks -- a quarter, then half of the steady size, to shorten the
+            // pipeline's fill -- tripled the GPU stage, 0.011 -> 0.035 s per 150 Mbases: every growth of a chunk re-allocates the
+            // engine's device staging, and hipFree waits for the device.  tools/r05_cli.sh)
             while (free_q.pop(j)) {
                 const auto tp = std::chrono::steady_clock::now();
-                const unsigned down = ramp_chunks && chunk_no < 2 ? 2 - chunk_no : 0;
-                chunk_no++;
-                const bool more = reader.next_chunk(j->rs, std::max<uint64_t>(1, chunk_bases >> down), std::max<uint64_t>(1, chunk_min_reads >> down), chunk_hard_max);
-                parse_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - tp).count();
+                const bool more = reader.next_chunk(j->rs, chunk_bases, chunk_min_reads, chunk_hard_max);
+                const double dtp = std::chrono::duration<double>(std::chrono::steady_clock::now() - tp).count();
+                parse_seconds += dtp;
+                if (chunk_parse_s.size() < 64) chunk_parse_s.push_back(dtp);
                 if (!more) break;
                 parsed_q.push(j);
             }
@@ -526,11 +546,28 @@ int run_query(const Options &o) {
     // ---- preparation, while the parser works on the first chunk: what a handle does once -- building the top-of-walk / interval
     // table (256 MB, ~4 ms), the look-ahead rows, the row-start checkpoints, loading the kernels' code object (the builders' launches
     // do) -- is not paid inside the first chunk's call (1 M x 150 bp: 24 ms of the command's 30 ms of GPU calls were that first
-    // call; a steady-state call on a 2^25-base chunk takes 1.8 - 2.9 ms).  movi_index_prepare (round 5) replaces the one-read
-    // warm-up query of rounds 3 - 4.
-    for (auto *hd : handles) {                                         // (errors here are not the query's: the real calls report)
-        if (o.pml && o.logs) continue;                                 // --logs runs on the first kernel, which uses none of the derived tables
-        (void)movi_index_prepare(hd, o.pml ? MOVI_PREPARE_PML : (o.zml ? MOVI_PREPARE_ZML : MOVI_PREPARE_COUNT), nullptr, nullptr);
+    // call; a steady-state call on a 2^25-base chunk takes 1.8 - 2.9 ms): movi_index_prepare (round 5) builds the tables ...
+    // ... and one one-read query of the same kind through the host entry point: what the FIRST host call does once -- the handle's
+    // device staging, the page-locked block of its small results, the walk kernels' code object (a translation unit of its own
+    // since round 5: the builders' launches do not load it) -- cost the first chunk 20 - 30 ms without it (tools/r05_cli.sh:
+    // GPU calls of 1 M x 150 bp 0.035 - 0.045 s with the preparation alone, 0.012 - 0.014 s with the warm-up call).
+    {
+        const uint8_t wb[32] = {'A','C','G','T','A','C','G','T','A','C','G','T','A','C','G','T','A','C','G','T','A','C','G','T','A','C','G','T','A','C','G','T'};
+        const uint64_t wo[2] = {0, 32};
+        uint16_t wp[32];
+        uint64_t wm = 0, wc = 0;
+        uint32_t wa = 0, wbl = 0;
+        uint64_t wsum = 0;
+        uint8_t we = 0;
+        for (auto *hd : handles) {                                     // (errors here are not the query's: the real calls report)
+            if (o.pml && o.logs) continue;                             // --logs runs on the first kernel, which uses none of the derived tables
+            (void)movi_index_prepare(hd, o.pml ? MOVI_PREPARE_PML : (o.zml ? MOVI_PREPARE_ZML : MOVI_PREPARE_COUNT), nullptr, nullptr);
+            if (o.pml && o.classify && !o.write_output_allowed())
+                (void)movi_pml_classify_host(hd, wb, wo, 1, (uint32_t)o.bin_width, classifier.max_value_thr, &wa, &wbl, &wsum, &we, nullptr);
+            else if (o.pml) (void)movi_pml_host(hd, wb, wo, 1, wp, &we, nullptr);
+            else if (o.zml) (void)movi_zml_host(hd, wb, wo, 1, wp, &we, nullptr);
+            else (void)movi_count_host(hd, wb, wo, 1, &wm, &wc, &we, nullptr);
+        }
     }
 
     // ---- stage 2: the GPU calls, in input order
@@ -595,7 +632,7 @@ int run_query(const Options &o) {
             for (int g = 0; g < o.gpus; g++) th.emplace_back(work, g);
             for (auto &t : th) t.join();
         }
-        gpu_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - tg).count();
+        { const double dtg = std::chrono::duration<double>(std::chrono::steady_clock::now() - tg).count(); gpu_seconds += dtg; if (chunk_gpu_s.size() < 64) chunk_gpu_s.push_back(dtg); }
         for (const auto &e : errors)
             if (!e.empty()) throw EngineError(e);
         reads_done += n;
@@ -618,6 +655,13 @@ int run_query(const Options &o) {
         const BatchReader::PhaseTimes &pt = reader.phase_times();
         std::cerr << "[movi] Parser phases: newline scan " << pt.prescan << " s, batch cut " << pt.cut << " s, lengths " << pt.lengths
                   << " s, copy " << pt.copy << " s; " << pt.bulk_reads << " of " << pt.reads << " reads cut in bulk\n";
+    }
+    if (o.verbose) {                                                   // chunk by chunk: the first chunk's parse runs alone, the others beside the GPU calls
+        std::cerr << "[movi] Chunks: parse";
+        for (double x : chunk_parse_s) std::cerr << " " << x;
+        std::cerr << " s; GPU calls";
+        for (double x : chunk_gpu_s) std::cerr << " " << x;
+        std::cerr << " s\n";
     }
     if (o.verbose)                                                     // the three pipeline stages run side by side: the slowest one bounds the command
         std::cerr << "[movi] Stage times: parse " << parse_seconds << " s, GPU calls " << gpu_seconds << " s, order + write "

@@ -5,9 +5,7 @@
 #include <cstdio>
 
 #include <algorithm>
-#include <condition_variable>
 #include <cstring>
-#include <mutex>
 #include <iomanip>
 #include <iostream>
 #include <stdexcept>
@@ -52,11 +50,14 @@ void BpfWriter::close() {
 // pwritev of (head, payload) iovec pairs from 8 threads 0.55 / 0.16 s (buffered writes to ONE file serialise on the inode
 // lock, and 2 M small iovecs cost more than copying them); one write() per 20 KB payload 0.77 / 0.10 s (system calls are
 // expensive there); T threads copying into a MAP_SHARED mapping of the grown file 1.40 / 0.22 s (page faults on the file
-// mapping are slow there).  Rounds 2 - 4: one thread, an 8 MiB buffer, only payloads of 1 MiB and more written straight from
-// the result array -- gather and write() took turns on that one thread (57 ms per 317 MB: 5.5 GB/s).  Round 5: the write()s
-// still leave from ONE thread, in order (the page-cache copy holds the inode lock either way), but the slabs they write are
-// gathered by helper threads a few slabs ahead, so that the gather runs beside the write instead of before it.
+// mapping are slow there).  Round 5 (tools/r05_cli.sh): the slabs gathered by two helper threads a few slabs AHEAD of the one
+// thread that write()s them in order -- the gather beside the write instead of before it -- 0.067 - 0.075 s against 0.053 -
+// 0.063 s for this loop: the write() into the page cache is the whole cost (317 MB in ~55 ms = 5.7 GB/s, one thread, under the
+// inode lock) and the helpers only competed with it; dropped.  Kept: one thread, an 8 MiB buffer, only payloads of 1 MiB and
+// more written straight from the result array.
 void BpfWriter::append(const std::vector<Record> &records) {
+    if (buf_.empty()) buf_.resize(8u << 20);
+    size_t fill = 0;
     auto write_all = [&](const void *p, size_t len) {
         const uint8_t *q = static_cast<const uint8_t *>(p);
         while (len) {
@@ -67,86 +68,22 @@ void BpfWriter::append(const std::vector<Record> &records) {
             len -= (size_t)w;
         }
     };
-    // a record = u16 id_len | id | u64 n | n x u16 (src/utils.cpp:202-246, :222).  Slabs: runs of whole records of about kSlab
-    // bytes; a record whose payload is 1 MiB or more is a slab of its own kind -- head gathered, payload written from the
-    // result array.
-    constexpr size_t kSlab = 8u << 20, kBig = 1u << 20;
-    struct Slab { size_t first, last; size_t bytes; bool big; };        // records [first, last)
-    std::vector<Slab> slabs;
-    {
-        size_t cur = 0, start = 0;
-        for (size_t i = 0; i < records.size(); i++) {
-            const size_t head = 2 + (size_t)static_cast<uint16_t>(records[i].id.length()) + 8, pay = records[i].n * 2;
-            if (pay >= kBig) {
-                if (i > start) slabs.push_back(Slab{start, i, cur, false});
-                slabs.push_back(Slab{i, i + 1, head, true});
-                start = i + 1; cur = 0;
-                continue;
-            }
-            if (cur + head + pay > kSlab && i > start) { slabs.push_back(Slab{start, i, cur, false}); start = i; cur = 0; }
-            cur += head + pay;
-        }
-        if (records.size() > start) slabs.push_back(Slab{start, records.size(), cur, false});
-    }
-    if (slabs.empty()) return;
-    auto gather = [&](const Slab &sl, uint8_t *dst) {
-        for (size_t i = sl.first; i < sl.last; i++) {
-            const Record &r = records[i];
-            const uint16_t idl = static_cast<uint16_t>(r.id.length());
-            std::memcpy(dst, &idl, 2); dst += 2;
-            std::memcpy(dst, r.id.data(), idl); dst += idl;
-            std::memcpy(dst, &r.n, 8); dst += 8;                            // output_binary :204-210
-            if (!sl.big && r.n) { std::memcpy(dst, r.pml, r.n * 2); dst += r.n * 2; }
-        }
+    auto flush = [&] { if (fill) { write_all(buf_.data(), fill); fill = 0; } };
+    auto put = [&](const void *p, size_t len) {
+        if (len > buf_.size() - fill) flush();
+        std::memcpy(buf_.data() + fill, p, len);
+        fill += len;
     };
-    constexpr size_t kRing = 4;                                             // slab buffers in flight
-    if (bufs_.size() != kRing) bufs_.assign(kRing, std::vector<uint8_t>());
-    for (auto &b : bufs_) if (b.size() < kSlab + 65536 + 16) b.resize(kSlab + 65536 + 16);   // (a record's head is at most 2 + 65535 + 8 bytes)
-    const size_t helpers = slabs.size() >= 3 ? 2 : 0;                       // a chunk of a few slabs: the gather on this thread, as before
-    if (!helpers) {
-        for (const Slab &sl : slabs) {
-            gather(sl, bufs_[0].data());
-            write_all(bufs_[0].data(), sl.bytes);
-            if (sl.big) write_all(records[sl.first].pml, records[sl.first].n * 2);
-        }
-        return;
+    for (const Record &r : records) {
+        const uint16_t idl = static_cast<uint16_t>(r.id.length());      // src/utils.cpp:222
+        put(&idl, 2);
+        put(r.id.data(), idl);
+        put(&r.n, 8);                                                    // output_binary :204-210
+        const size_t bytes = r.n * 2;
+        if (bytes >= (1u << 20)) { flush(); write_all(r.pml, bytes); }
+        else if (bytes) put(r.pml, bytes);
     }
-    std::mutex m;
-    std::condition_variable cv;
-    size_t next = 0, written = 0;                                           // next slab to gather; slabs written so far
-    std::vector<uint8_t> ready(slabs.size(), 0);
-    bool stop = false;
-    auto helper = [&] {
-        for (;;) {
-            size_t s;
-            {
-                std::unique_lock<std::mutex> g(m);
-                cv.wait(g, [&] { return stop || next >= slabs.size() || next < written + kRing; });   // slab s reuses the buffer of slab s - kRing
-                if (stop || next >= slabs.size()) return;
-                s = next++;
-            }
-            gather(slabs[s], bufs_[s % kRing].data());
-            { std::lock_guard<std::mutex> g(m); ready[s] = 1; }
-            cv.notify_all();
-        }
-    };
-    std::vector<std::thread> th;
-    for (size_t t = 0; t < helpers; t++) th.emplace_back(helper);
-    try {
-        for (size_t s = 0; s < slabs.size(); s++) {
-            { std::unique_lock<std::mutex> g(m); cv.wait(g, [&] { return ready[s] != 0; }); }
-            write_all(bufs_[s % kRing].data(), slabs[s].bytes);
-            if (slabs[s].big) write_all(records[slabs[s].first].pml, records[slabs[s].first].n * 2);
-            { std::lock_guard<std::mutex> g(m); written = s + 1; }
-            cv.notify_all();
-        }
-    } catch (...) {
-        { std::lock_guard<std::mutex> g(m); stop = true; }
-        cv.notify_all();
-        for (auto &t : th) t.join();
-        throw;
-    }
-    for (auto &t : th) t.join();
+    flush();
 }
 
 void append_stdout_pmls(std::string &txt, std::string_view id, const uint16_t *pml, uint64_t n) {

@@ -39,7 +39,7 @@ public:
 private:
     int fd_ = -1;
     std::string path_;
-    std::vector<std::vector<uint8_t>> bufs_;      // slab buffers (append)
+    std::vector<uint8_t> buf_;
 };
 
 // `>id\n` + values in read order, each followed by a space, + `\n`

@@ -15,7 +15,7 @@
 namespace movi_host {
 
 // The hardware threads that share a last-level cache with the calling thread, from sysfs ("0-7,128-135"); empty if unknown.
-static std::vector<int> llc_siblings() {
+std::vector<int> llc_siblings() {
     std::vector<int> cpus;
     const int cpu = sched_getcpu();
     if (cpu < 0) return cpus;
@@ -57,6 +57,7 @@ WorkerPool::WorkerPool(unsigned threads) {
     for (int c : cpus)
         if (!have_owner_mask_ || CPU_ISSET(c, &owner_mask_)) { CPU_SET(c, &set); usable++; }
     const bool pin = usable >= 2;
+    if (pin) { pool_set_ = set; pinned_ = true; }
     if (pin) {
         owner_ = pthread_self();
         pinned_owner_ = pthread_setaffinity_np(owner_, sizeof(set), &set) == 0 && have_owner_mask_;
@@ -75,6 +76,10 @@ WorkerPool::~WorkerPool() {
     // (only from the owner itself: in `movi query` the owner is the parser thread, which is gone by the time the reader is
     // destroyed -- its handle must not be touched)
     if (pinned_owner_ && pthread_equal(pthread_self(), owner_)) (void)pthread_setaffinity_np(owner_, sizeof(owner_mask_), &owner_mask_);
+}
+
+void WorkerPool::adopt_owner() {
+    if (pinned_) (void)pthread_setaffinity_np(pthread_self(), sizeof(pool_set_), &pool_set_);
 }
 
 void WorkerPool::loop() {
@@ -158,8 +163,9 @@ void LineSource::scan_ahead() {
     next_pending_ = true;
     // long lines (the window in use has fewer than one per KiB: long reads): four scanners -- there the scan of a GB-sized
     // chunk by one thread was what the parser waited for (0.09 of 0.13 s on 100 k x 10 kbp) and the few line ends are joined
-    // in no time; short lines: one scanner writes the list in place (2 M entries per window: joining them would cost more
-    // than the scan)
+    // in no time; short lines: one scanner writes the list in place.  (Round 5: two / four / eight scanners on short lines too --
+    // the one scanner takes 4 - 6 ms per 43 MB window of a mapping it is the first to touch, a warm parser consumes a window in
+    // 3.4 ms -- measured no different, 26.7 - 31.4 / 27.3 - 33.6 / 28.3 - 31.8 / 28.4 - 35.3 ms per 150 Mbases: tools/r05_cli.sh.)
     const unsigned parts = (cur_.to > cur_.from && cur_.nl.size() * 1024 < cur_.to - cur_.from) ? 4u : 1u;
     scan_thread_ = std::thread([this, parts] {
         const size_t from = next_.from, to = next_.to;
@@ -458,6 +464,50 @@ static size_t rstrip_len(const char *p, size_t n) {
     return n;
 }
 
+void BatchReader::make_pool() {
+    if (pool_) return;
+    unsigned want = threads_ ? threads_ : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (const char *e = std::getenv("MOVI_PARSE_THREADS")) want = (unsigned)std::max(1, std::atoi(e));   // (tuning hook: tools/r05_cli.sh)
+    pool_.reset(new WorkerPool(want));
+}
+
+void BatchReader::warm_up(ReadSet *const *sets, unsigned n_sets, uint64_t max_bases) {
+    if (!mem_ || size_hint_ == 0) return;
+    make_pool();
+    const size_t window = (size_t)std::min<uint64_t>(max_bases + (max_bases >> 2) + (1u << 20), 1ull << 32);
+    src_.prescan(window, *pool_);                                      // exactly the first next_chunk's call
+    const size_t L = src_.prescanned_lines();
+    const size_t in_reach = (size_t)std::min<uint64_t>(window, size_hint_);
+    // a chunk holds at most the bytes in reach of sequence, at most L / 2 records and their ids (<= header bytes: bounded by the same bytes;
+    // an eighth of them covers ids of 18 characters on 150 bp reads -- a bigger chunk grows its buffers as before)
+    const size_t n_rec = L / 2 + 2, id_bytes = std::min<size_t>(in_reach / 8 + 4096, 64u << 20);
+    lines_.reserve(L + 1024);
+    recs_.reserve(L / 2 + 1024);
+    struct Region { uint8_t *p; size_t n; };
+    std::vector<Region> regions;
+    regions.push_back(Region{reinterpret_cast<uint8_t *>(lines_.data()), lines_.capacity() * sizeof(Span)});
+    regions.push_back(Region{reinterpret_cast<uint8_t *>(recs_.data()), recs_.capacity() * sizeof(Rec)});
+    for (unsigned k = 0; k < n_sets; k++) {
+        ReadSet &rs = *sets[k];
+        rs.bases.resize_uninitialized(in_reach);
+        rs.id_bytes.resize_uninitialized(id_bytes);
+        regions.push_back(Region{rs.bases.data(), in_reach});
+        regions.push_back(Region{rs.id_bytes.data(), id_bytes});
+        // (the offset / batch arrays are std::vectors: value-initialised here, on this thread -- 4.5 MB per set -- instead of inside the first chunks)
+        rs.offsets.assign(n_rec, 0);
+        rs.id_off.assign(n_rec, 0);
+        rs.batch_of.assign(n_rec, 0);
+    }
+    const unsigned T = pool_->size();
+    pool_->run(T, [&](unsigned t) {
+        for (const Region &r : regions) {
+            volatile uint8_t *b = r.p;
+            for (size_t off = r.n / T * t & ~(size_t)4095, end = t + 1 == T ? r.n : r.n / T * (t + 1); off < end; off += 4096) b[off] = 0;
+        }
+    });
+    for (unsigned k = 0; k < n_sets; k++) { sets[k]->bases.clear(); sets[k]->id_bytes.clear(); }
+}
+
 bool BatchReader::next_chunk(ReadSet &out, uint64_t max_bases, uint64_t min_reads, uint64_t hard_max_bases) {
     // (the offset / batch arrays keep their size across chunks: a ReadSet circulates, every element is rewritten below, and
     // value-initialising 20 MB of them per million reads was 2 ms of a 25 ms chunk)
@@ -467,11 +517,7 @@ bool BatchReader::next_chunk(ReadSet &out, uint64_t max_bases, uint64_t min_read
     recs_.clear();
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_begin = now();
-    if (!pool_) {
-        unsigned want = threads_ ? threads_ : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
-        if (const char *e = std::getenv("MOVI_PARSE_THREADS")) want = (unsigned)std::max(1, std::atoi(e));   // (tuning hook: tools/r05_cli.sh)
-        pool_.reset(new WorkerPool(want));
-    }
+    make_pool();
     // the newlines of about a chunk's worth of input, found by all workers at once (the rest, if the chunk turns out
     // longer, line by line as before)
     if (mem_) src_.prescan((size_t)std::min<uint64_t>(max_bases + (max_bases >> 2) + (1u << 20), 1ull << 32), *pool_);

@@ -6,6 +6,7 @@
 //   BatchLoader::grabNextRead  src/batch_loader.cpp:91-143  (id rule, sequence assembly)
 //   ReadProcessor::process_latency_hiding  src/read_processor.cpp:641-730 (record order)
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -86,6 +87,7 @@ public:
     void clear() { n_ = 0; }
     T &operator[](size_t i) { return p_[i]; }
     const T &operator[](size_t i) const { return p_[i]; }
+    size_t capacity() const { return cap_; }
     void reserve(size_t n) {
         if (n <= cap_) return;
         T *q = static_cast<T *>(std::realloc(p_, n * sizeof(T)));
@@ -119,12 +121,17 @@ struct ReadSet {
     }
 };
 
+// The hardware threads that share a last-level cache with the calling thread (sysfs); empty if unknown.
+std::vector<int> llc_siblings();
+
 // A few worker threads that stay around between chunks (two thread launches per phase and chunk were ~2 ms of a 10 ms chunk).
 class WorkerPool {
 public:
     explicit WorkerPool(unsigned threads);
     ~WorkerPool();
     unsigned size() const { return (unsigned)th_.size() + 1; }
+    // the calling thread joins the pool's cache domain (a thread other than the one that built the pool is going to drive it)
+    void adopt_owner();
     void run(unsigned parts, const std::function<void(unsigned)> &fn);   // fn(0 .. parts-1), the caller works too; returns when all are done
 
 private:
@@ -139,6 +146,8 @@ private:
     cpu_set_t owner_mask_;                // the owning thread's affinity before the pool narrowed it (restored by ~WorkerPool)
     pthread_t owner_{};
     bool have_owner_mask_ = false, pinned_owner_ = false;
+    cpu_set_t pool_set_;                  // the cache domain the pool's threads are pinned to (valid if pinned_)
+    bool pinned_ = false;
 };
 
 // Line source with std::istream's good()/peek()/getline() state semantics (the batch cut of the reference depends
@@ -242,6 +251,14 @@ public:
     // Whole reference batches until `max_bases` bases are held -- and, for long reads, until `min_reads`
     // reads or `hard_max_bases` bases are (one GPU lane walks one read: a chunk needs reads, not bases).
     bool next_chunk(ReadSet &out, uint64_t max_bases, uint64_t min_reads = 0, uint64_t hard_max_bases = 0);
+    // Round 5 -- memory-mapped input only, BEFORE the first next_chunk and possibly on another thread than the one that will call
+    // it: build the worker pool, scan the first window (what the first next_chunk does first: it also takes the file mapping's page
+    // faults), size the circulating ReadSets and the reader's own line / record tables for a chunk of `max_bases` and let the POOL
+    // touch their pages -- first touch by the pinned workers keeps the memory on their NUMA node.  `movi query` does this while the
+    // index loads: the first three chunks of a run used to be parsed into fresh memory (chunk 1: 7.4 ms, chunks 2 - 3: 3.9 - 4.3 ms,
+    // warm: 2.8 ms; tools/r05_cli.sh).  The thread that then calls next_chunk calls adopt_pool() first.
+    void warm_up(ReadSet *const *sets, unsigned n_sets, uint64_t max_bases);
+    void adopt_pool() { if (pool_) pool_->adopt_owner(); }
     // seconds spent in the parser's phases so far (movi query --verbose, tools/parse_bench.cpp)
     struct PhaseTimes { double prescan = 0, cut = 0, lengths = 0, copy = 0; uint64_t bulk_reads = 0, reads = 0; };   // bulk_reads: cut by cut_ahead
     const PhaseTimes &phase_times() const { return times_; }
@@ -263,6 +280,7 @@ private:
     uint64_t size_hint_ = 0;
     unsigned threads_ = 0;              // 0 = hardware concurrency (at most 16)
     std::unique_ptr<WorkerPool> pool_;
+    void make_pool();
     PhaseTimes times_;
     size_t skip_until_ = 0;   // cut_ahead makes no pass while the input position is before this byte (an irregular line close ahead)
     const bool no_fast_cut_ = std::getenv("MOVI_NO_FAST_CUT") != nullptr;   // every batch line by line (tests: both cuts must agree)

@@ -86,6 +86,29 @@ def test_bench_two_ranks_print_all_three_legs():
     assert "cpu_baseline" not in d
 
 
+def test_bench_default_line_legs_on_one_gpu():
+    """The default line's host-side legs, shrunk (8 x 60 kbp pangenome, 2 M random rows, 256 long reads): `cli_path` -- the `movi query`
+    binary on FASTA files, also with `--gpus 2` sharing the box's device --, `host_path`, and the same two for the big table
+    (round 5: `big_table.host_path`, `big_table.cli_path` on the table's own index file)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "tinypg", "--steps", "3", "--warmup", "1",
+                        "--big-rows", "2000000", "--long-reads", "256", "--no-sustained"], capture_output=True, timeout=1200, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _line(r.stdout)
+    assert d["parity_sample_ok"] is True and d["cpu_baseline"]["value"] > 0
+    cp = d["cli_path"]
+    assert "error" not in cp, cp
+    for k in ("short_1Mx150_no_output", "short_1Mx150_bpf", "short_1Mx150_no_output_gpus2_one_device"):
+        assert cp[k]["value"] > 0 and cp[k]["stage_s"]["parse"] > 0, (k, cp[k])
+    bt = d["big_table"]
+    assert bt["parity_sample_ok"] is True and bt["prepare_s"] >= 0 and bt["derived_bytes"] > 0
+    assert bt["host_path"]["pageable"] > 0 and bt["host_path"]["pageable_ok"] is True and bt["host_path"]["page_locked_ok"] is True, bt["host_path"]
+    assert bt["cli_path"]["no_output"]["value"] > 0 and bt["cli_path"]["bpf"]["value"] > 0, bt["cli_path"]
+    assert bt["count"]["kernel"].startswith("zml_kernel_flat<6, unsigned int, 0, 0, ") and bt["count"]["parity_sample_ok"] is True
+
+
 def test_bench_c4_two_ranks_share_one_gpu():
     """--workload c4 at N = 2: only rank 0 synthesises the table (and draws both shards of reads)."""
     env = dict(os.environ, MOVI_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")

@@ -1,5 +1,5 @@
 """GPU suite, slow part (-m gpu with MOVI_SLOW_TESTS=1; tools/r05_real_bwt.sh): the real BWTs behind README's / DESIGN's
-"c4real", "c4real2" and "c4big" numbers -- 113 M, 226 M and ~550 M rows, beyond the Infinity Cache (and, for the second one's look-ahead copy,
+"c4real", "c4real2" and "c4big" numbers -- 113 M, 226 M and 676 M rows, beyond the Infinity Cache (and, for the second one's look-ahead copy,
 beyond the TLBs' reach) -- against the oracle AT THEIR SIZE.  bench.py's own workloads: the index is built on first use by
 tools/build_index (3 - 10 min of host time, 16 - 35 GB of host memory; cached under $MOVI_BENCH_CACHE), which is why these
 tests are not part of the default suite: the driver's GPU step has 20 minutes for everything.

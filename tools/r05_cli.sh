@@ -18,22 +18,23 @@ if not os.path.exists('/tmp/long.fa'):
     subprocess.check_call(['tools/build_index', 'reads', t, '100000', '10000', '0.08', '1011', '/tmp/long.bin'])
     bench.write_fasta('/tmp/long.fa', np.fromfile('/tmp/long.bin', np.uint8).reshape(-1, 10000))
 PY
-run() { exe=$1; name=$2; shift 2
+run() { local bin=$1 name=$2 rep; shift 2
   for rep in 1 2 3; do
-    /usr/bin/time -f "wall %e s" $exe query -i $IDX --verbose "$@" 2> $O/$name.$rep.err > /dev/null
-    grep -h "processing the reads\|Stage times\|Parser phases\|wall" $O/$name.$rep.err | sed "s/^/$name.$rep: /"
+    local t0=$(date +%s%N)
+    $bin query -i $IDX --verbose "$@" 2> $O/$name.$rep.err > /dev/null
+    echo "[movi] wall $(( ($(date +%s%N) - t0) / 1000000 )) ms" >> $O/$name.$rep.err
+    grep -h "processing the reads\|Stage times\|Parser phases\|Chunks\|wall" $O/$name.$rep.err | sed "s|^|$name.$rep: |"
   done
 }
 {
-for exe in movi movi_r04; do
-  run movi_amd/bin/$exe ${exe}_short_noout -r /tmp/short.fa --no-output
-  run movi_amd/bin/$exe ${exe}_short_bpf -r /tmp/short.fa -o /tmp/out_short
-  run movi_amd/bin/$exe ${exe}_long_noout -r /tmp/long.fa --no-output
-  run movi_amd/bin/$exe ${exe}_long_bpf -r /tmp/long.fa -o /tmp/out_long
-  md5sum /tmp/out_short*.bpf /tmp/out_long*.bpf | sed "s/^/$exe: /"
-done
-MOVI_NO_CHUNK_RAMP=1 run movi_amd/bin/movi movi_noramp_short_noout -r /tmp/short.fa --no-output
-MOVI_NO_AFFINITY=1 run movi_amd/bin/movi movi_noaff_short_noout -r /tmp/short.fa --no-output
-for t in 6 8 12; do MOVI_PARSE_THREADS=$t run movi_amd/bin/movi movi_t${t}_short_noout -r /tmp/short.fa --no-output; done
-MOVI_PARSE_THREADS=8 MOVI_NO_AFFINITY=1 run movi_amd/bin/movi movi_t8_noaff_short_noout -r /tmp/short.fa --no-output
+run movi_amd/bin/movi movi_short_noout -r /tmp/short.fa --no-output
+run movi_amd/bin/movi movi_short_bpf -r /tmp/short.fa -o /tmp/out_short
+md5sum /tmp/out_short*.bpf
+run movi_amd/bin/movi movi_long_noout -r /tmp/long.fa --no-output
+run movi_amd/bin/movi movi_long_bpf -r /tmp/long.fa -o /tmp/out_long
+md5sum /tmp/out_long*.bpf
+MOVI_SCAN_PARTS=1 run movi_amd/bin/movi movi_scan1_short_noout -r /tmp/short.fa --no-output
+MOVI_SCAN_PARTS=2 run movi_amd/bin/movi movi_scan2_short_noout -r /tmp/short.fa --no-output
+MOVI_SCAN_PARTS=8 run movi_amd/bin/movi movi_scan8_short_noout -r /tmp/short.fa --no-output
 } 2>&1 | tee $O/summary.txt
+/tmp/parse_bench /tmp/short.fa 12 > $O/parse_bench.txt 2>&1 || { g++ -O2 -std=c++17 -mavx2 -o /tmp/parse_bench tools/parse_bench.cpp movi_amd/host/reads.cpp -lpthread && /tmp/parse_bench /tmp/short.fa 12 > $O/parse_bench.txt 2>&1; }; tail -3 $O/parse_bench.txt
