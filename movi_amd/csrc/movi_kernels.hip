@@ -2294,7 +2294,7 @@ hipError_t launch_zml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
                                                                   stream, seg_ws, ragged_hint, &declined, seg_verdict);
         if (es == hipSuccess && !declined && info) {
             const bool sm = ix.r <= (3ull << 30) / 8 && ix.r >= 8 && n_bases >= 16;
-            if (sm) snprintf(info->kernel, sizeof(info->kernel), "zml_kernel_flat<%d, %s, 1, 0, 0>", mode, ix.idx32 ? "unsigned int" : "unsigned long");
+            if (sm) snprintf(info->kernel, sizeof(info->kernel), "zml_kernel_flat<%d, %s, 1, 0, 0, 0>", mode, ix.idx32 ? "unsigned int" : "unsigned long");
             else snprintf(info->kernel, sizeof(info->kernel), "zml_kernel<%d, 1>", mode);
             info->variant = sm ? 1 : 0; info->block_threads = sm ? 64 : 256; info->waves_per_cu = 0; info->segmented = 1; info->staged = 0; info->ahead = 0;
             info->idx64 = ix.idx32 ? 0 : 1;
@@ -2331,7 +2331,7 @@ hipError_t launch_zml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     const bool ahead = want_ahead && v == 1;
     const bool pair = v == 1 && can_pair;
     if (info) {
-        if (v == 1) snprintf(info->kernel, sizeof(info->kernel), "zml_kernel_flat<%d, %s, 0, %d, %d>", mode, ix.idx32 ? "unsigned int" : "unsigned long",
+        if (v == 1) snprintf(info->kernel, sizeof(info->kernel), "zml_kernel_flat<%d, %s, 0, %d, %d, 0>", mode, ix.idx32 ? "unsigned int" : "unsigned long",
                              ahead ? 1 : 0, pair ? 1 : 0);
         else snprintf(info->kernel, sizeof(info->kernel), "zml_kernel<%d, 0>", mode);
         info->variant = v; info->block_threads = bt; info->waves_per_cu = cfg.waves_per_cu > 0 ? cfg.waves_per_cu : 0; info->staged = 0; info->ahead = ahead ? 1 : 0;

@@ -313,7 +313,7 @@ def test_zml_on_the_look_ahead_rows_vs_oracle(built_lib, golden_image, mode):
         gpu.set_option("ahead_rows", 1)
         out, st = gpu.query_zml_packed(bases, offs)
         li = gpu.last_launch()
-        assert li["ahead"] == 1 and li["kernel"].endswith(", 0, 1, 0>") and li["idx64"] == idx64
+        assert li["ahead"] == 1 and li["kernel"].endswith(", 0, 1, 0, 0>") and li["idx64"] == idx64
         assert (out == exp).all(), (mode, idx64)
         assert (st.fast_forwards, st.scans, st.errors) == (st0.fast_forwards, st0.scans, 0), (mode, idx64)
     gpu.set_option("idx64", 0)
@@ -572,14 +572,14 @@ def test_zml_pair_shared_gathers_vs_oracle(built_lib, golden_image, mode):
         gpu.set_option("pair_loads", 1)
         out, st = gpu.query_zml_packed(bases, offs)
         li = gpu.last_launch()
-        assert li["kernel"].startswith("zml_kernel_flat<%d, " % kmode) and li["kernel"].endswith(", 0, 0, 1>") and li["idx64"] == idx64, li
+        assert li["kernel"].startswith("zml_kernel_flat<%d, " % kmode) and li["kernel"].endswith(", 0, 0, 1, 0>") and li["idx64"] == idx64, li
         assert (out == exp).all(), (mode, idx64)
         assert (st.fast_forwards, st.scans, st.errors) == (st0.fast_forwards, st0.scans, 0), (mode, idx64)
     gpu.set_option("idx64", 0)
     bb, bo = _big_batch(ref, rng, max_len=200, n_long=20)
     bexp = cpu.zml_batch(bb, bo, threads=8)
     bout, bst = gpu.query_zml_packed(bb, bo)
-    assert gpu.last_launch()["kernel"].endswith(", 0, 0, 1>") and (bout == bexp).all() and bst.errors == 0
+    assert gpu.last_launch()["kernel"].endswith(", 0, 0, 1, 0>") and (bout == bexp).all() and bst.errors == 0
     gpu.close()
     cpu.close()
 

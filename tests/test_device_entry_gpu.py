@@ -179,7 +179,7 @@ def test_last_launch_reports_the_policy(engine6):
     gpu.query_count_packed(bases, offs)
     assert gpu.last_launch()["kernel"] == "zml_kernel_flat<6, unsigned int, 0, 0, 0, 1>" and gpu.last_launch()["ahead"] == 0   # the lane state machine, on the plain rows (round 5); (a small table)
     gpu.query_zml_packed(bases, offs)
-    assert gpu.last_launch()["kernel"] == "zml_kernel_flat<6, unsigned int, 0, 0, 0>"
+    assert gpu.last_launch()["kernel"] == "zml_kernel_flat<6, unsigned int, 0, 0, 0, 0>"
 
 
 @pytest.mark.parametrize("mode", [6, 8, 7])
