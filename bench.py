@@ -486,6 +486,7 @@ def write_fasta(path, reads2d):
 
 def cli_measure(idx_dir, fa, out_prefix, modes=("no_output", "bpf"), extra=(), env=None, runs=2):
     """`movi query -i idx_dir -r fa --verbose` per output mode, best of `runs`: {mode: {value, seconds, stage_s, wall_s}}."""
+    import glob
     import re
     import subprocess
     exe = os.path.join(ROOT, "movi_amd", "bin", "movi")
@@ -494,6 +495,8 @@ def cli_measure(idx_dir, fa, out_prefix, modes=("no_output", "bpf"), extra=(), e
         flags = ["--no-output"] if mode == "no_output" else ["-o", out_prefix]
         best, wall = None, None
         for _ in range(runs):
+            for old in glob.glob(out_prefix + "*.bpf"):       # a fresh output file every run: ext4 flushes a truncated-and-rewritten file in close()
+                os.remove(old)                                # (+30 ms inside the command's clock; profiles/r05_cli_path.txt)
             t0 = time.perf_counter()
             r = subprocess.run([exe, "query", "-i", idx_dir, "-r", fa, "--verbose"] + flags + list(extra), capture_output=True, timeout=900,
                                env=dict(os.environ, **env) if env else None)

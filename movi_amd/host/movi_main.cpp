@@ -329,6 +329,7 @@ int run_query(const Options &o) {
     // stream buffers first: they must outlive the streams that flush through them on destruction
     std::vector<char> out_buf2(1u << 20);
     std::ofstream report_file, matches_file;
+    std::unique_ptr<WorkerPool> bpf_pool;                             // the writer stage's helper threads (record order, BPF gather; built by the writer thread, outlives mls_file)
     BpfWriter mls_file;
     matches_file.rdbuf()->pubsetbuf(out_buf2.data(), (std::streamsize)out_buf2.size());
     std::ostream *report = nullptr;
@@ -430,6 +431,9 @@ int run_query(const Options &o) {
     });
 
     // ---- stage 3: record order + writers (everything that touches the output streams lives on this thread)
+    const bool bpf_serial = std::getenv("MOVI_BPF_SERIAL") != nullptr;  // A/B: the one-thread gather-and-write loop (BpfWriter::append(records))
+    unsigned bpf_threads = 4;                                          // (8 measured the same: the stage is bound by its write()s)
+    if (const char *e = std::getenv("MOVI_BPF_THREADS")) bpf_threads = (unsigned)std::max(1, std::atoi(e));
     auto write_job = [&](Job &job) {
         ReadSet &rs = job.rs;
         const size_t n = rs.size();
@@ -437,20 +441,34 @@ int run_query(const Options &o) {
         // nothing to write for this chunk (`--no-output` without a report or a filter): no record order needed either
         if (!o.write_output_allowed() && !(o.classify && (o.filter || report))) return;
         // record order: strand scheduler emulation in prefetch mode, file order otherwise
+        if (!bpf_pool && n >= 4096) bpf_pool.reset(new WorkerPool(bpf_threads));   // this stage's helpers (order, BPF gather)
         std::vector<uint32_t> order;
         if (o.prefetch) {
             std::vector<uint64_t> cost(n);
-            for (size_t i = 0; i < n; i++)
-                cost[i] = o.pml ? rs.len(i)
-                        : o.zml ? zml_rounds(rs, i, job.pml.data() + rs.offsets[i], desc.code_of)
-                                : count_rounds(rs, i, job.matched[i], desc.code_of);
-            order = strand_order(rs, cost, o.strands);
+            auto cost_of = [&](size_t i) -> uint64_t {
+                return o.pml ? rs.len(i)
+                     : o.zml ? zml_rounds(rs, i, job.pml.data() + rs.offsets[i], desc.code_of)
+                             : count_rounds(rs, i, job.matched[i], desc.code_of);
+            };
+            if (bpf_pool) {
+                const unsigned P = bpf_pool->size() * 2u;
+                bpf_pool->run(P, [&](unsigned p) { for (size_t i = n * p / P, e = n * (p + 1) / P; i < e; i++) cost[i] = cost_of(i); });
+            } else {
+                for (size_t i = 0; i < n; i++) cost[i] = cost_of(i);
+            }
+            order = strand_order(rs, cost, o.strands, bpf_pool.get());
         } else {
             order.resize(n);
             for (size_t i = 0; i < n; i++) order[i] = (uint32_t)i;
         }
         std::vector<BpfWriter::Record> bpf;                           // the chunk's records, in emission order
         const bool to_bpf = o.ml() && o.write_output_allowed() && !o.write_stdout_enabled();
+        if (to_bpf && !o.classify && !logs && !bpf_serial) {
+            // the plain BPF file: records gathered from the chunk's arrays by a pool of this thread's, written behind it (output.cpp)
+            if (!bpf_pool) bpf_pool.reset(new WorkerPool(bpf_threads));
+            mls_file.append(BpfWriter::Chunk{order.data(), n, rs.offsets.data(), job.pml.data(), rs.id_off.data(), rs.id_bytes.data()}, *bpf_pool);
+            return;
+        }
         if (to_bpf) bpf.reserve(n);
         if (o.ml() && !o.classify && o.write_output_allowed() && o.write_stdout_enabled() && rs.bases.size() >= (1u << 22)) {
             // plain `--stdout`: the text of a chunk is formatted by worker threads (ranges balanced by bases), written in order
@@ -667,6 +685,11 @@ int run_query(const Options &o) {
         for (double x : chunk_gpu_s) std::cerr << " " << x;
         std::cerr << " s\n";
     }
+    if (o.verbose && bpf_pool) {
+        const BpfWriter::Times bt = mls_file.times();
+        std::cerr << "[movi] BPF writer: gather " << bt.gather << " s, waiting for a free slab " << bt.wait << " s (" << bpf_pool->size()
+                  << " threads); write() " << bt.write << " s on its own thread\n";
+    }
     if (o.verbose)                                                     // the three pipeline stages run side by side: the slowest one bounds the command
         std::cerr << "[movi] Stage times: parse " << parse_seconds << " s, GPU calls " << gpu_seconds << " s, order + write "
                   << write_seconds << " s (page-locked chunk buffers: " << (pin_buffers ? "yes" : "no") << ")\n";
@@ -721,11 +744,13 @@ int run_plan(const Options &o) {
     ReadSet rs;
     uint64_t plan_chunk = 1ull << 28;
     if (const char *e = std::getenv("MOVI_CHUNK_BASES")) plan_chunk = std::max<uint64_t>(1, std::strtoull(e, nullptr, 10));   // test hook
+    std::unique_ptr<WorkerPool> plan_pool;                             // test hook: the record order by a pool, as `movi query`'s writer stage computes it
+    if (const char *e = std::getenv("MOVI_PLAN_THREADS")) plan_pool.reset(new WorkerPool((unsigned)std::max(1, std::atoi(e))));
     while (reader.next_chunk(rs, plan_chunk)) {
         std::vector<uint64_t> cost(rs.size());
         for (size_t i = 0; i < rs.size(); i++) cost[i] = rs.len(i);
         std::vector<uint32_t> order;
-        if (o.prefetch) order = strand_order(rs, cost, o.strands);
+        if (o.prefetch) order = strand_order(rs, cost, o.strands, plan_pool.get());
         else for (size_t i = 0; i < rs.size(); i++) order.push_back((uint32_t)i);
         for (uint32_t i : order) std::cout << rs.batch_of[i] << "\t" << rs.id(i) << "\t" << rs.len(i) << "\n";
     }

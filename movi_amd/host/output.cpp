@@ -1,13 +1,19 @@
 #include "output.hpp"
+#include "reads.hpp"
 #include <charconv>
 
 #include <cerrno>
 #include <cstdio>
+#include <cstdlib>
 
 #include <algorithm>
 #include <cstring>
 #include <iomanip>
 #include <iostream>
+#include <chrono>
+#include <condition_variable>
+#include <exception>
+#include <mutex>
 #include <stdexcept>
 #include <thread>
 
@@ -18,7 +24,30 @@
 
 namespace movi_host {
 
+// append(Chunk)'s other half: a ring of slabs, filled by the caller's pool, written in order by one thread
+struct BpfWriter::Async {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    enum { kMaxSlabs = 16 };
+    RawBytes slab[kMaxSlabs];
+    bool full[kMaxSlabs] = {false};
+    unsigned n_slabs = 4, fill_next = 0, write_next = 0, queued = 0;
+    uint64_t reserved_to = 0, written_to = 0;                          // fallocate()d / written file offsets (reserve_ahead)
+    bool reserve = true;
+    bool stop = false;
+    std::exception_ptr err;
+    double write_s = 0;
+};
+
 BpfWriter::~BpfWriter() {
+    if (async_) {                                                      // (an exception is unwinding: what is queued is dropped)
+        { std::lock_guard<std::mutex> g(async_->m); async_->stop = true; }
+        async_->cv.notify_all();
+        if (async_->th.joinable()) async_->th.join();
+        delete async_;
+        async_ = nullptr;
+    }
     // reached with the descriptor still open only when an exception is unwinding past the writer (close() is the normal
     // way out and throws on error); a close() error here cannot be thrown, so it is at least said
     if (fd_ >= 0 && ::close(fd_) != 0) std::fprintf(stderr, "[movi] Failed to write the output file: %s\n", path_.c_str());
@@ -40,9 +69,175 @@ void BpfWriter::open(const std::string &path, uint8_t entry_size) {
     if (w != 12) throw std::runtime_error("Failed to write the output file: " + path);
 }
 
+// every slab handed over so far is in the file (or its error is thrown here)
+void BpfWriter::drain() {
+    if (!async_) return;
+    std::unique_lock<std::mutex> g(async_->m);
+    async_->cv.wait(g, [&] { return async_->queued == 0 || async_->err; });
+    if (async_->err) { std::exception_ptr e = async_->err; async_->err = nullptr; std::rethrow_exception(e); }
+}
+
 void BpfWriter::close() {
+    if (async_) {
+        drain();
+        { std::lock_guard<std::mutex> g(async_->m); async_->stop = true; }
+        async_->cv.notify_all();
+        async_->th.join();
+    }
+    if (fd_ >= 0 && async_ && async_->reserved_to > async_->written_to && ::ftruncate(fd_, (off_t)async_->written_to) != 0) {   // blocks reserved past the end go back
+        ::close(fd_);
+        fd_ = -1;
+        throw std::runtime_error("Failed to write the output file: " + path_);
+    }
     if (fd_ >= 0 && ::close(fd_) != 0) { fd_ = -1; throw std::runtime_error("Failed to write the output file: " + path_); }
     fd_ = -1;
+}
+
+BpfWriter::Times BpfWriter::times() const {
+    Times t;
+    t.gather = gather_s_;
+    t.wait = wait_s_;
+    if (async_) { std::lock_guard<std::mutex> g(async_->m); t.write = async_->write_s; }
+    return t;
+}
+
+// Round 5, second pass.  tools/io_bench.cpp on the GPU box: `write()` of 320 MB into the page cache of /tmp 31 ms = 10.8 GB/s from one
+// thread; N threads pwrite()-ing large disjoint ranges 31 - 37 ms, 26 - 28 ms into fallocate()d blocks -- the inode lock: no scaling --;
+// a shared mapping 46 - 153 ms; O_DIRECT 42 - 57 ms.  So the write() is 30 ms of the 54 ms this stage took for 1 M x 150 bp reads; the
+// other 24 were the record order, the vector of Records and the gather, all on the writing thread.  Here the gather is the pool's (a
+// chunk's records cut into slabs, each slab into byte-balanced parts), the write() another thread's, and the stage costs what the
+// write()s cost -- which depends on WHERE the slab is when it is written (tools/r05_bpf.sh, write() seconds for 317 MB / 2 GB):
+//   ring of 2 x 32 MiB 0.029 / 0.20, 4 x 8 MiB 0.028 - 0.030 / 0.18, 8 x 4 MiB 0.028 / 0.18 | 4 x 4 MiB 0.021 - 0.023 / 0.13 - 0.14,
+//   8 x 2 MiB 0.021 - 0.026 / 0.13 - 0.14, 16 x 1 MiB 0.022 - 0.025: a ring of 16 MiB stays in the last-level cache of the pool's
+// domain (32 MB on that host; the writing thread joins the domain) and write() copies from there.  Blocks reserved ahead (below): another
+// 10 %.  The command, fresh output file, three runs each: 1 M x 150 bp 0.054 - 0.063 -> 0.032 - 0.035 s (2.4 - 2.8 -> 4.3 - 4.7 Gbases/s),
+// 100 k x 10 kbp 0.253 - 0.255 -> 0.194 - 0.213 s; pool of 4 threads as good as 8.  (What round 5's first attempt -- two unpinned helper
+// threads gathering 8 MiB slabs ahead of the writer, slower than the loop above -- got wrong: where its threads and its slabs were.)
+// Re-opening an EXISTING output file costs another 30 ms in close(): ext4 flushes a file that was truncated and rewritten when it is
+// closed (auto_da_alloc) -- the reference pays the same; the measurements above write fresh files.
+void BpfWriter::append(const Chunk &c, WorkerPool &pool) {
+    using clk = std::chrono::steady_clock;
+    static const size_t kSlabBytes = [] {                              // (MOVI_BPF_SLAB_BYTES: the tests cut slabs smaller than a record)
+        const char *e = std::getenv("MOVI_BPF_SLAB_BYTES");
+        const long long v = e ? std::atoll(e) : 0;
+        return v > 0 ? (size_t)v : (size_t)(4u << 20);
+    }();
+    if (c.n == 0) return;
+    if (!async_) {
+        async_ = new Async();
+        Async *a = async_;
+        if (const char *e = std::getenv("MOVI_BPF_SLABS")) a->n_slabs = (unsigned)std::min<long>(Async::kMaxSlabs, std::max<long>(2, std::atol(e)));
+        a->reserve = std::getenv("MOVI_BPF_NO_RESERVE") == nullptr;
+        a->written_to = (uint64_t)::lseek(fd_, 0, SEEK_CUR);
+        a->th = std::thread([this, a, &pool] {
+            pool.adopt_owner();
+            std::unique_lock<std::mutex> g(a->m);
+            for (;;) {
+                a->cv.wait(g, [&] { return a->stop || a->full[a->write_next]; });
+                if (!a->full[a->write_next]) return;                   // stop, nothing queued
+                const unsigned s = a->write_next;
+                g.unlock();
+                const auto t0 = clk::now();
+                std::exception_ptr err;
+                const uint8_t *q = a->slab[s].data();
+                size_t len = a->slab[s].size();
+                // blocks reserved ahead of the writes, 256 MiB at a time, the file's size left alone (what is left over goes back in
+                // close()): a write() into reserved blocks skips the per-page delayed-allocation bookkeeping -- 320 MB in 26 instead of
+                // 31 ms (tools/io_bench.cpp).  A file system that cannot do it is not asked again.
+                if (a->reserve && a->written_to + len > a->reserved_to) {
+                    const uint64_t from = std::max(a->reserved_to, a->written_to), more = std::max<uint64_t>(256u << 20, len);
+                    if (::fallocate(fd_, FALLOC_FL_KEEP_SIZE, (off_t)from, (off_t)more) == 0) a->reserved_to = from + more;
+                    else a->reserve = false;
+                }
+                a->written_to += len;
+                while (len) {
+                    const ssize_t w = ::write(fd_, q, len);
+                    if (w < 0 && errno == EINTR) continue;
+                    if (w < 0) { err = std::make_exception_ptr(std::runtime_error("Failed to write the output file: " + path_)); break; }
+                    q += w;
+                    len -= (size_t)w;
+                }
+                const double dt = std::chrono::duration<double>(clk::now() - t0).count();
+                g.lock();
+                a->write_s += dt;
+                if (err && !a->err) a->err = err;
+                a->full[s] = false;
+                a->queued -= 1;
+                a->write_next = (a->write_next + 1u) % a->n_slabs;
+                a->cv.notify_all();
+            }
+        });
+    }
+    Async *a = async_;
+    auto rec_bytes = [&](size_t k) -> uint64_t {
+        const uint32_t i = c.order[k];
+        return 10u + (uint64_t)(uint16_t)(c.id_off[i + 1] - c.id_off[i]) + 2u * (c.offsets[i + 1] - c.offsets[i]);
+    };
+    // byte offset of every record in the chunk's image (two-pass prefix sum by the pool)
+    std::vector<uint64_t> at(c.n + 1);
+    const unsigned P = std::max(1u, std::min<unsigned>(pool.size() * 2u, (unsigned)std::min<size_t>(c.n, 1u << 16)));
+    std::vector<uint64_t> part_sum(P + 1, 0);
+    const auto tg0 = clk::now();
+    pool.run(P, [&](unsigned p) {
+        uint64_t sum = 0;
+        for (size_t k = c.n * p / P, e = c.n * (p + 1) / P; k < e; k++) { at[k] = sum; sum += rec_bytes(k); }
+        part_sum[p + 1] = sum;
+    });
+    for (unsigned p = 0; p < P; p++) part_sum[p + 1] += part_sum[p];
+    pool.run(P, [&](unsigned p) {
+        const uint64_t base = part_sum[p];
+        if (base) for (size_t k = c.n * p / P, e = c.n * (p + 1) / P; k < e; k++) at[k] += base;
+    });
+    at[c.n] = part_sum[P];
+    gather_s_ += std::chrono::duration<double>(clk::now() - tg0).count();
+    size_t k0 = 0;
+    while (k0 < c.n) {
+        // the slab: records k0 .. k1 - 1, at least one, up to kSlabBytes
+        size_t k1 = (size_t)(std::upper_bound(at.begin() + (ptrdiff_t)k0, at.end(), at[k0] + kSlabBytes) - at.begin());
+        if (k1 > 0) k1 -= 1;
+        if (k1 <= k0) k1 = k0 + 1;
+        if (k1 > c.n) k1 = c.n;
+        const uint64_t lo = at[k0], bytes = at[k1] - lo;
+        const unsigned s = a->fill_next;
+        {
+            const auto tw0 = clk::now();
+            std::unique_lock<std::mutex> g(a->m);
+            a->cv.wait(g, [&] { return !a->full[s] || a->err; });
+            if (a->err) { std::exception_ptr e = a->err; a->err = nullptr; std::rethrow_exception(e); }
+            wait_s_ += std::chrono::duration<double>(clk::now() - tw0).count();
+        }
+        const auto t0 = clk::now();
+        a->slab[s].resize_uninitialized((size_t)bytes);
+        uint8_t *dst = a->slab[s].data();
+        const unsigned Q = std::max(1u, std::min<unsigned>(pool.size() * 2u, (unsigned)std::min<size_t>(k1 - k0, 1u << 16)));
+        pool.run(Q, [&](unsigned p) {
+            // parts balanced by bytes: part p takes the records that START in its share of the slab
+            auto cut = [&](unsigned j) -> size_t {
+                if (j == 0) return k0;
+                if (j >= Q) return k1;
+                return (size_t)(std::lower_bound(at.begin() + (ptrdiff_t)k0, at.begin() + (ptrdiff_t)k1, lo + bytes * j / Q) - at.begin());
+            };
+            for (size_t k = cut(p), e = cut(p + 1); k < e; k++) {
+                const uint32_t i = c.order[k];
+                uint8_t *q = dst + (at[k] - lo);
+                const uint16_t idl = (uint16_t)(c.id_off[i + 1] - c.id_off[i]);      // src/utils.cpp:222
+                const uint64_t n = c.offsets[i + 1] - c.offsets[i];
+                std::memcpy(q, &idl, 2);
+                std::memcpy(q + 2, c.id_bytes + c.id_off[i], idl);
+                std::memcpy(q + 2 + idl, &n, 8);                                      // output_binary :204-210
+                if (n) std::memcpy(q + 10 + idl, c.pml + c.offsets[i], n * 2);
+            }
+        });
+        gather_s_ += std::chrono::duration<double>(clk::now() - t0).count();
+        {
+            std::lock_guard<std::mutex> g(a->m);
+            a->full[s] = true;
+            a->queued += 1;
+            a->fill_next = (a->fill_next + 1u) % a->n_slabs;
+        }
+        a->cv.notify_all();
+        k0 = k1;
+    }
 }
 
 // Measured on the GPU box (2 GB of PMLs for 100 k x 10 kbp reads / 317 MB for 1 M x 150 bp; processing time of the whole
@@ -56,6 +251,7 @@ void BpfWriter::close() {
 // inode lock) and the helpers only competed with it; dropped.  Kept: one thread, an 8 MiB buffer, only payloads of 1 MiB and
 // more written straight from the result array.
 void BpfWriter::append(const std::vector<Record> &records) {
+    drain();                                                           // (slabs of append(Chunk) still on their way come first)
     if (buf_.empty()) buf_.resize(8u << 20);
     size_t fill = 0;
     auto write_all = [&](const void *p, size_t len) {
@@ -84,6 +280,7 @@ void BpfWriter::append(const std::vector<Record> &records) {
         else if (bytes) put(r.pml, bytes);
     }
     flush();
+    if (async_) async_->written_to = (uint64_t)::lseek(fd_, 0, SEEK_CUR);   // (nothing is queued: drain() above)
 }
 
 void append_stdout_pmls(std::string &txt, std::string_view id, const uint16_t *pml, uint64_t n) {

@@ -19,6 +19,8 @@
 
 namespace movi_host {
 
+class WorkerPool;                            // reads.hpp
+
 const uint32_t kBpfMagic = 0x42504600u;      // "BPF\0", include/utils.hpp:26
 
 // BPF file: 12-byte header, then per read u16 id_len | id | u64 n | n x u16 (emission order = last base first).
@@ -34,12 +36,25 @@ public:
     bool is_open() const { return fd_ >= 0; }
     struct Record { std::string_view id; const uint16_t *pml; uint64_t n; };
     void append(const std::vector<Record> &records);                  // in the given order
+    // A chunk's records straight from its arrays (ReadSet's and the result vector): record k is read order[k], its id
+    // id_bytes[id_off[i] .. id_off[i + 1]), its values pml[offsets[i] .. offsets[i + 1]).  The same bytes as append(records); the
+    // records are gathered into slabs by the pool's threads while a thread of the writer's own write()s the slab before
+    // (output.cpp has the measurements).  Returns once the last slab is handed over: errors of the write surface in the next
+    // call or in close().
+    struct Chunk { const uint32_t *order; size_t n; const uint64_t *offsets; const uint16_t *pml; const uint64_t *id_off; const uint8_t *id_bytes; };
+    void append(const Chunk &c, WorkerPool &pool);
     void close();
+    struct Times { double gather = 0, wait = 0, write = 0; };         // append(Chunk): gathering, waiting for a free slab; the write()s
+    Times times() const;
 
 private:
+    struct Async;
+    void drain();
     int fd_ = -1;
     std::string path_;
     std::vector<uint8_t> buf_;
+    Async *async_ = nullptr;
+    double gather_s_ = 0, wait_s_ = 0;
 };
 
 // `>id\n` + values in read order, each followed by a space, + `\n`

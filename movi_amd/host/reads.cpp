@@ -640,35 +640,47 @@ bool BatchReader::next_chunk(ReadSet &out, uint64_t max_bases, uint64_t min_read
     return true;
 }
 
-std::vector<uint32_t> strand_order(const ReadSet &rs, const std::vector<uint64_t> &cost, size_t strands) {
-    std::vector<uint32_t> order;
-    order.reserve(rs.size());
-    size_t i = 0;
+std::vector<uint32_t> strand_order(const ReadSet &rs, const std::vector<uint64_t> &cost, size_t strands, WorkerPool *pool) {
     const size_t n = rs.size();
-    typedef std::pair<uint64_t, uint32_t> Ev;                          // (finish round, strand)
-    while (i < n) {
-        size_t j = i;
-        while (j < n && rs.batch_of[j] == rs.batch_of[i]) j++;
-        // batch = reads [i, j)
-        std::priority_queue<Ev, std::vector<Ev>, std::greater<Ev>> pq;
+    std::vector<uint32_t> order(n);
+    // the records of batch [i, j) fill order[i .. j): the batches are independent of each other, so a pool takes ranges of them
+    // (1 M x 150 bp: 3 ms of a 12 ms chunk on one thread -- while the writer behind it sat idle)
+    auto range = [&](size_t lo, size_t hi) {                           // reads [lo, hi), both on batch boundaries
+        typedef std::pair<uint64_t, uint32_t> Ev;                      // (finish round, strand)
+        std::priority_queue<Ev, std::vector<Ev>, std::greater<Ev>> pq;  // (empty again after every batch)
         std::vector<uint32_t> cur(strands, 0);
-        size_t next = i;
-        for (uint32_t s = 0; s < strands && next < j; s++, next++) {
-            cur[s] = (uint32_t)next;
-            pq.push(Ev(cost[next] ? cost[next] : 1, s));
-        }
-        while (!pq.empty()) {
-            Ev e = pq.top();
-            pq.pop();
-            order.push_back(cur[e.second]);
-            if (next < j) {
-                cur[e.second] = (uint32_t)next;
-                pq.push(Ev(e.first + (cost[next] ? cost[next] : 1), e.second));
-                next++;
+        size_t i = lo;
+        while (i < hi) {
+            size_t j = i;
+            while (j < hi && rs.batch_of[j] == rs.batch_of[i]) j++;
+            size_t next = i, at = i;
+            for (uint32_t s = 0; s < strands && next < j; s++, next++) {
+                cur[s] = (uint32_t)next;
+                pq.push(Ev(cost[next] ? cost[next] : 1, s));
             }
+            while (!pq.empty()) {
+                const Ev e = pq.top();
+                pq.pop();
+                order[at++] = cur[e.second];
+                if (next < j) {
+                    cur[e.second] = (uint32_t)next;
+                    pq.push(Ev(e.first + (cost[next] ? cost[next] : 1), e.second));
+                    next++;
+                }
+            }
+            i = j;
         }
-        i = j;
+    };
+    const unsigned P = pool && n >= 4096 ? pool->size() * 2u : 1u;
+    if (P == 1) { range(0, n); return order; }
+    std::vector<size_t> cut(P + 1, n);                                 // part boundaries moved up to the next batch boundary
+    cut[0] = 0;
+    for (unsigned p = 1; p < P; p++) {
+        size_t k = std::max(cut[p - 1], n * p / P);
+        while (k > 0 && k < n && rs.batch_of[k] == rs.batch_of[k - 1]) k++;
+        cut[p] = k;
     }
+    pool->run(P, [&](unsigned p) { range(cut[p], cut[p + 1]); });
     return order;
 }
 

@@ -292,6 +292,6 @@ private:
 // thread: within each reference batch, strands 0..S-1 take the first S reads; every round
 // each live strand consumes `1` unit of its read; a strand that finishes writes its record at
 // once and takes the batch's next read.  `cost[i]` = rounds read i needs (its length for PML).
-std::vector<uint32_t> strand_order(const ReadSet &rs, const std::vector<uint64_t> &cost, size_t strands);
+std::vector<uint32_t> strand_order(const ReadSet &rs, const std::vector<uint64_t> &cost, size_t strands, WorkerPool *pool = nullptr);
 
 }  // namespace movi_host

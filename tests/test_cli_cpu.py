@@ -168,7 +168,9 @@ def test_parallel_mmap_parser_equals_stream_parser(movi_bin, tmp_path, fmt):
     assert a.stdout == b.stdout == c.stdout and a.stdout.count(b"\n") == 14000
     # the same file cut into many small chunks: the parallel newline scan then covers ~1 MB windows, so chunks, reference
     # batches and lines straddle its windows (lines beyond a window are found the slow way) -- same plan, worker count or not
-    for env in (dict(MOVI_CHUNK_BASES="50000"), dict(MOVI_CHUNK_BASES="50000", MOVI_NO_AFFINITY="1"), dict(MOVI_CHUNK_BASES="7")):
+    # (MOVI_PLAN_THREADS: the strand-scheduler emulation by ranges of batches on a pool, as the writer stage of `movi query` runs it)
+    for env in (dict(MOVI_CHUNK_BASES="50000"), dict(MOVI_CHUNK_BASES="50000", MOVI_NO_AFFINITY="1"), dict(MOVI_CHUNK_BASES="7"),
+                dict(MOVI_PLAN_THREADS="5"), dict(MOVI_PLAN_THREADS="3", MOVI_CHUNK_BASES="500000")):
         d = run(["plan", "-r", str(path), "-s16"], env=dict(os.environ, **env))
         assert d.returncode == 0 and d.stdout == a.stdout, env
     clean = [l[:-1] if l.endswith(b"\r") and not l.startswith((b">", b"@")) else l for l in lines]
