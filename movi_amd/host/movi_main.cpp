@@ -388,7 +388,9 @@ int run_query(const Options &o) {
     // in this command and NOT the default (profiles/r03_cli_path.txt): its chunks (2^25 bases of short reads, 2^15 long
     // reads) are a quarter of what the overlapped path needs to pay -- each piece must still fill the GPU -- and a run makes
     // a handful of calls, so the path's one-time set-up (six streams with staging) is never earned back: GPU calls of
-    // 1 M x 150 bp 0.021 s pageable, 0.084 s page-locked; 100 k x 10 kbp 0.15 s / 0.31 s.  The command's own pipeline
+    // 1 M x 150 bp 0.021 s pageable, 0.084 s page-locked; 100 k x 10 kbp 0.15 s / 0.31 s.  (Round 5: page-locked read buffers with
+    // the calls NOT cut into pieces -- one direct upload per chunk -- 8.1 - 9.5 against 8.6 - 9.9 ms of GPU calls per 150 Mbases, the
+    // command 12.0 - 13.1 against 12.5 - 12.6 ms, and with the BPF file 50 - 57 against 32 - 36 ms: dropped.  tools/r05_scan.sh)  The command's own pipeline
     // (parse | GPU calls | order + write, three chunks in flight) already overlaps the transfers with the other stages.
     uint64_t input_bytes = 0;
     if (map.p != MAP_FAILED) input_bytes = map.n;
@@ -400,6 +402,7 @@ int run_query(const Options &o) {
     for (Job &j : jobs) free_q.push(&j);
     double parse_seconds = 0, write_seconds = 0;
     std::vector<double> chunk_parse_s, chunk_gpu_s;                    // --verbose: the first chunks' stage times one by one
+    std::vector<BatchReader::PhaseTimes> chunk_phases;                 // (cumulative parser phases after each chunk)
     std::exception_ptr parse_error, write_error;
     std::mutex err_m;
 
@@ -419,7 +422,7 @@ int run_query(const Options &o) {
                 const bool more = reader.next_chunk(j->rs, chunk_bases, chunk_min_reads, chunk_hard_max);
                 const double dtp = std::chrono::duration<double>(std::chrono::steady_clock::now() - tp).count();
                 parse_seconds += dtp;
-                if (chunk_parse_s.size() < 64) chunk_parse_s.push_back(dtp);
+                if (chunk_parse_s.size() < 64) { chunk_parse_s.push_back(dtp); chunk_phases.push_back(reader.phase_times()); }
                 if (!more) break;
                 parsed_q.push(j);
             }
@@ -674,7 +677,7 @@ int run_query(const Options &o) {
     std::cerr << "[movi] Time measured for processing the reads: " << total << " s (" << bases_done << " bases; GPU calls "
               << gpu_seconds << " s)\n";
     if (o.verbose) {
-        const BatchReader::PhaseTimes &pt = reader.phase_times();
+        const BatchReader::PhaseTimes pt = reader.phase_times();
         std::cerr << "[movi] Parser phases: newline scan " << pt.prescan << " s, batch cut " << pt.cut << " s, lengths " << pt.lengths
                   << " s, copy " << pt.copy << " s; " << pt.bulk_reads << " of " << pt.reads << " reads cut in bulk\n";
     }
@@ -684,6 +687,14 @@ int run_query(const Options &o) {
         std::cerr << " s; GPU calls";
         for (double x : chunk_gpu_s) std::cerr << " " << x;
         std::cerr << " s\n";
+        std::cerr << "[movi] Chunk phases (cut [of which waiting for the scan-ahead] / lengths / copy | the scan-ahead helper's own time, ms):";
+        BatchReader::PhaseTimes prev;
+        for (const auto &p : chunk_phases) {
+            std::cerr << " " << (p.cut - prev.cut) * 1e3 << "[" << (p.scan_wait - prev.scan_wait) * 1e3 << "]/" << (p.lengths - prev.lengths) * 1e3 << "/"
+                      << (p.copy - prev.copy) * 1e3 << "|" << (p.scan_busy - prev.scan_busy) * 1e3;
+            prev = p;
+        }
+        std::cerr << "\n";
     }
     if (o.verbose && bpf_pool) {
         const BpfWriter::Times bt = mls_file.times();

@@ -150,52 +150,70 @@ static void scan_newlines(const char *p, const char *e, const char *base, const 
 }
 
 LineSource::~LineSource() {
-    if (scan_thread_.joinable()) scan_thread_.join();
+    for (auto &p : ahead_)
+        if (p->th.joinable()) p->th.join();
 }
 
-// Start the helper on the window behind cur_ (one thread: a window is ~40 MB, 2 - 3 ms of AVX2 compares, and it has the whole
-// cut + copy of the chunk before it to finish).
+// Keep scan_depth_ windows in flight behind cur_, one helper thread each (a window is ~40 MB).  One scanner takes 5 - 6.5 ms per
+// window of a mapping it is the first to touch; a warm parser consumes a window in ~3 ms, so with ONE window in flight the cut of
+// the third and fourth chunk of a 1 M x 150 bp run waited 2 - 3 and 1 - 2 ms for it (tools/r05_scan.sh: the wait and the helper's own
+// time are in --verbose's per-chunk line).  More scanners on the same window did not help -- four take 3.7 - 4.5 ms, not 1.4:
+// their page faults queue up behind the GPU-call thread's page pinning on the address-space lock -- but two windows scanned side
+// by side do: each helper still needs its 5 - 6 ms, started one window earlier.
 void LineSource::scan_ahead() {
-    if (next_pending_ || cur_.to >= end_ || window_bytes_ == 0) return;
-    next_ = Window();
-    next_.from = cur_.to;
-    next_.to = std::min(end_, cur_.to + window_bytes_);
-    next_pending_ = true;
-    // long lines (the window in use has fewer than one per KiB: long reads): four scanners -- there the scan of a GB-sized
-    // chunk by one thread was what the parser waited for (0.09 of 0.13 s on 100 k x 10 kbp) and the few line ends are joined
-    // in no time; short lines: one scanner writes the list in place.  (Round 5: two / four / eight scanners on short lines too --
-    // the one scanner takes 4 - 6 ms per 43 MB window of a mapping it is the first to touch, a warm parser consumes a window in
-    // 3.4 ms -- measured no different, 26.7 - 31.4 / 27.3 - 33.6 / 28.3 - 31.8 / 28.4 - 35.3 ms per 150 Mbases: tools/r05_cli.sh.)
-    const unsigned parts = (cur_.to > cur_.from && cur_.nl.size() * 1024 < cur_.to - cur_.from) ? 4u : 1u;
-    scan_thread_ = std::thread([this, parts] {
-        const size_t from = next_.from, to = next_.to;
-        if (parts == 1) {
-            next_.nl.reserve((to - from) / 64 + 16);
-            next_.first.reserve((to - from) / 64 + 16);
-            scan_newlines(mem_ + from, mem_ + to, mem_, mem_ + end_, next_.nl, next_.first);
-            return;
-        }
-        std::vector<std::vector<size_t>> nl(parts);
-        std::vector<std::vector<uint8_t>> first(parts);
-        std::vector<std::thread> th;
-        for (unsigned t = 0; t < parts; t++)
-            th.emplace_back([&, t] {
-                const size_t a = from + (to - from) * t / parts, b = from + (to - from) * (t + 1) / parts;
-                scan_newlines(mem_ + a, mem_ + b, mem_, mem_ + end_, nl[t], first[t]);
-            });
-        for (auto &x : th) x.join();
-        for (unsigned t = 0; t < parts; t++) {
-            next_.nl.insert(next_.nl.end(), nl[t].begin(), nl[t].end());
-            next_.first.insert(next_.first.end(), first[t].begin(), first[t].end());
-        }
-    });
+    if (window_bytes_ == 0) return;
+    if (ahead_.empty()) ahead_to_ = cur_.to;
+    while (ahead_.size() < scan_depth_ && ahead_to_ < end_) {
+        std::unique_ptr<Pending> p(new Pending());
+        p->w.from = ahead_to_;
+        p->w.to = std::min(end_, ahead_to_ + window_bytes_);
+        ahead_to_ = p->w.to;
+        // long lines (the window in use has fewer than one per KiB: long reads): four scanners -- there the scan of a GB-sized
+        // chunk by one thread was what the parser waited for (0.09 of 0.13 s on 100 k x 10 kbp) and the few line ends are joined
+        // in no time; short lines: one scanner writes the list in place
+        unsigned parts = (cur_.to > cur_.from && cur_.nl.size() * 1024 < cur_.to - cur_.from) ? 4u : 1u;
+        static const unsigned forced = [] { const char *e = std::getenv("MOVI_SCAN_PARTS"); return e ? (unsigned)std::max(1, std::atoi(e)) : 0u; }();
+        if (forced) parts = forced;
+        Pending *q = p.get();
+        q->th = std::thread([this, q, parts] {
+            const auto t0 = std::chrono::steady_clock::now();
+            Window &w = q->w;
+            const size_t from = w.from, to = w.to;
+            if (parts == 1) {
+                w.nl.reserve((to - from) / 64 + 16);
+                w.first.reserve((to - from) / 64 + 16);
+                scan_newlines(mem_ + from, mem_ + to, mem_, mem_ + end_, w.nl, w.first);
+            } else {
+                std::vector<std::vector<size_t>> nl(parts);
+                std::vector<std::vector<uint8_t>> first(parts);
+                std::vector<std::thread> th;
+                for (unsigned t = 0; t < parts; t++)
+                    th.emplace_back([&, t] {
+                        const size_t a = from + (to - from) * t / parts, b = from + (to - from) * (t + 1) / parts;
+                        scan_newlines(mem_ + a, mem_ + b, mem_, mem_ + end_, nl[t], first[t]);
+                    });
+                for (auto &x : th) x.join();
+                for (unsigned t = 0; t < parts; t++) {
+                    w.nl.insert(w.nl.end(), nl[t].begin(), nl[t].end());
+                    w.first.insert(w.first.end(), first[t].begin(), first[t].end());
+                }
+            }
+            q->busy_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        });
+        ahead_.push_back(std::move(p));
+    }
 }
 
 bool LineSource::next_window() {
-    if (!next_pending_) return false;
-    scan_thread_.join();
-    next_pending_ = false;
-    cur_ = std::move(next_);
+    if (ahead_.empty()) return false;
+    {
+        const auto tw = std::chrono::steady_clock::now();
+        ahead_.front()->th.join();
+        scan_wait_s_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
+    }
+    scan_busy_s_ += ahead_.front()->busy_s;
+    cur_ = std::move(ahead_.front()->w);
+    ahead_.pop_front();
     nl_i_ = 0;
     while (nl_i_ < cur_.nl.size() && cur_.nl[nl_i_] < pos_) nl_i_++;   // (a line longer than a window was finished the slow way)
     scan_ahead();
@@ -205,7 +223,7 @@ bool LineSource::next_window() {
 void LineSource::prescan(size_t bytes, WorkerPool &pool) {
     if (!mem_) return;
     window_bytes_ = bytes;
-    if (cur_.to == 0 && cur_.nl.empty() && !next_pending_) {          // the first window: all workers, now
+    if (cur_.to == 0 && cur_.nl.empty() && ahead_.empty()) {          // the first window: all workers, now
         const size_t from = pos_, to = std::min(end_, pos_ + bytes);
         if (to > from) {
             const unsigned T = (to - from) >= (1u << 22) ? pool.size() : 1;
@@ -226,7 +244,13 @@ void LineSource::prescan(size_t bytes, WorkerPool &pool) {
             nl_i_ = 0;
         }
     }
-    scan_ahead();                                                      // keep one window in flight behind the current one
+    else {
+        // (every later call: the parser is running -- from now on two windows in flight; the first call, which may be the warm-up's
+        // while the index still loads, starts one: nothing more of the input is read ahead of the clock than before)
+        static const unsigned depth = [] { const char *e = std::getenv("MOVI_SCAN_DEPTH"); return e ? (unsigned)std::min(8, std::max(1, std::atoi(e))) : 2u; }();
+        scan_depth_ = depth;
+    }
+    scan_ahead();                                                      // keep the windows behind the current one in flight
 }
 
 bool LineSource::fill() {

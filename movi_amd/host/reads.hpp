@@ -8,6 +8,8 @@
 #pragma once
 #include <algorithm>
 #include <cstdint>
+#include <deque>
+#include <memory>
 #include <cstdlib>
 #include <cstring>
 #include <istream>
@@ -224,11 +226,18 @@ private:
     // of the input): with those the sequential batch cut never touches the input itself -- reading one byte per line
     // streamed most of the file through one core (15 ms per 160 MB).
     struct Window { std::vector<size_t> nl; std::vector<uint8_t> first; size_t from = 0, to = 0; };
+public:
+    double scan_busy_s() const { return scan_busy_s_; }
+    double scan_wait_s() const { return scan_wait_s_; }
+private:
     bool next_window();                 // cur_ is used up: adopt the window scanned ahead (waits for it), scan the one after
     void scan_ahead();
-    Window cur_, next_;
-    std::thread scan_thread_;
-    bool next_pending_ = false;
+    struct Pending { Window w; std::thread th; double busy_s = 0; };
+    Window cur_;
+    std::deque<std::unique_ptr<Pending>> ahead_;   // windows being scanned behind cur_, oldest first
+    size_t ahead_to_ = 0;               // where the last window handed to a helper ends
+    unsigned scan_depth_ = 1;           // windows kept in flight (prescan() raises it once the parser is running)
+    double scan_busy_s_ = 0, scan_wait_s_ = 0;   // the helper's own time per window, summed; what next_window() waited for it
     size_t window_bytes_ = 0;
     size_t nl_i_ = 0;                   // next unused entry of cur_
     uint8_t next_first_ = 0;
@@ -260,8 +269,8 @@ public:
     void warm_up(ReadSet *const *sets, unsigned n_sets, uint64_t max_bases);
     void adopt_pool() { if (pool_) pool_->adopt_owner(); }
     // seconds spent in the parser's phases so far (movi query --verbose, tools/parse_bench.cpp)
-    struct PhaseTimes { double prescan = 0, cut = 0, lengths = 0, copy = 0; uint64_t bulk_reads = 0, reads = 0; };   // bulk_reads: cut by cut_ahead
-    const PhaseTimes &phase_times() const { return times_; }
+    struct PhaseTimes { double prescan = 0, cut = 0, lengths = 0, copy = 0, scan_busy = 0, scan_wait = 0; uint64_t bulk_reads = 0, reads = 0; };   // scan_*: the scan-ahead helper's own time / what the cut waited for it (inside `cut`)   // bulk_reads: cut by cut_ahead
+    PhaseTimes phase_times() const { PhaseTimes t = times_; t.scan_busy = src_.scan_busy_s(); t.scan_wait = src_.scan_wait_s(); return t; }
 
 private:
     struct Span { uint64_t off; uint32_t len; uint8_t first; };   // 16 bytes; first = the line's first character (0: empty line)
