@@ -4,6 +4,7 @@
 #include "../movi_amd/host/reads.hpp"
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -18,6 +19,7 @@ int main(int argc, char **argv) {
     std::vector<unsigned> ts;
     for (int i = 2; i < argc; i++) ts.push_back((unsigned)atoi(argv[i]));
     if (ts.empty()) ts = {1, 4, 8, 16};
+    const uint64_t chunk = getenv("MOVI_CHUNK_BASES") ? strtoull(getenv("MOVI_CHUNK_BASES"), nullptr, 10) : 1ull << 25;   // (small chunks: many scan-ahead windows)
     ReadSet rs[3];                                        // circulating, as in the command: warm after the first pass
     for (unsigned T : ts)
         for (int rep = 0; rep < 3; rep++) {
@@ -25,7 +27,7 @@ int main(int argc, char **argv) {
             int k = 0;
             uint64_t bases = 0, reads = 0;
             auto t0 = std::chrono::steady_clock::now();
-            while (rd.next_chunk(rs[k % 3], 1ull << 25, 1ull << 15, 1ull << 30)) { bases += rs[k % 3].bases.size(); reads += rs[k % 3].size(); k++; }
+            while (rd.next_chunk(rs[k % 3], chunk, chunk < (1ull << 25) ? 1 : 1ull << 15, 1ull << 30)) { bases += rs[k % 3].bases.size(); reads += rs[k % 3].size(); k++; }
             const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             const BatchReader::PhaseTimes &pt = rd.phase_times();
             printf("T=%-2u chunks %d reads %lu bases %lu: %.4f s = %.2f Gbases/s  (newline scan %.4f, batch cut %.4f, lengths %.4f, copy %.4f; %lu reads cut in bulk)\n",
