@@ -369,8 +369,18 @@ bool BatchReader::cut_ahead(uint64_t max_bases, uint64_t min_reads, uint64_t har
     const uint64_t budget = approx_bases < max_bases ? max_bases - approx_bases : (approx_bases < hard_max_bases ? hard_max_bases - approx_bases : 0);
     const size_t reach = A.pos + (size_t)std::min<uint64_t>(budget + (budget >> 2) + (1u << 20), 1ull << 40);
     size_t M = (size_t)(std::upper_bound(A.nl, A.nl + A.count, reach) - A.nl);
+    // an irregular line a pass has already found (bad_at_ = the byte behind it) bounds this one too: the passes below run over
+    // every line considered, and a batch that ended well short of that line would otherwise send them over the same lines up to it
+    // -- and beyond -- again; after an irregular line the reach starts small and doubles with every clean pass (lines_cap_), so the
+    // passes over an input with an irregular line every few thousand lines cost what lies between those lines, not the chunk
+    if (bad_at_ && A.pos >= bad_at_) bad_at_ = 0;
+    if (bad_at_) M = std::min(M, (size_t)(std::lower_bound(A.nl, A.nl + M, bad_at_ - 1) - A.nl));
+    if (lines_cap_) M = std::min(M, lines_cap_);
     const size_t L0 = lines_.size(), R0 = recs_.size();
-    if (M < 4096 || L0 + M > 0xFFFFFFF0ull) return false;
+    if (M < 4096 || L0 + M > 0xFFFFFFF0ull) {
+        if (bad_at_ && M < 4096) skip_until_ = bad_at_;                // the known line is close by: line by line across it
+        return false;
+    }
     auto beg = [&](size_t t) -> size_t { return t ? A.nl[t - 1] + 1 : A.pos; };
     auto fc = [&](size_t t) -> int { return t ? (int)A.first[t - 1] : A.first0; };
     const char head = format_ == 1 ? '@' : '>';
@@ -381,8 +391,12 @@ bool BatchReader::cut_ahead(uint64_t max_bases, uint64_t min_reads, uint64_t har
     std::vector<size_t> stop(T, 0);                                    // first irregular line of each worker's share (its end: none)
     size_t R = 0;                                                      // complete records in reach (the last one is not)
     // the regular prefix ends at line `first_bad`: no pass again until the line-by-line cut has crossed it
+    bool clean = true;
     auto cut_short = [&](size_t first_bad) {
         skip_until_ = first_bad >= 4096 ? (size_t)0 : A.nl[first_bad] + 1;    // (a long prefix is cut now; the next call sees the line close by)
+        bad_at_ = A.nl[first_bad] + 1;
+        lines_cap_ = 16384;
+        clean = false;
         M = first_bad;
         return M >= 4096;
     };
@@ -441,6 +455,7 @@ bool BatchReader::cut_ahead(uint64_t max_bases, uint64_t min_reads, uint64_t har
             }
         R -= 1;
     }
+    if (clean && lines_cap_) lines_cap_ = lines_cap_ >= (1u << 26) ? 0 : lines_cap_ * 2;   // a clean pass: the next one may look further
     auto hdr_of = [&](size_t r) -> size_t { return format_ == 0 ? (size_t)hdr_line_[r] : 4 * r; };
     // ---- the running sum: loadBatch's rule over whole records, the chunk's budget over whole batches
     rec_batch_.resize(R);

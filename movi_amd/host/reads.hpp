@@ -292,6 +292,8 @@ private:
     void make_pool();
     PhaseTimes times_;
     size_t skip_until_ = 0;   // cut_ahead makes no pass while the input position is before this byte (an irregular line close ahead)
+    size_t bad_at_ = 0;       // the byte behind an irregular line a pass has found and the cut has not crossed yet (0: none known)
+    size_t lines_cap_ = 0;    // lines a pass may consider (0: the chunk's reach): small behind an irregular line, doubling with clean passes
     const bool no_fast_cut_ = std::getenv("MOVI_NO_FAST_CUT") != nullptr;   // every batch line by line (tests: both cuts must agree)
     int format_ = -1;                   // -1 unknown, 0 FASTA, 1 FASTQ
     uint32_t batch_counter_ = 0;
