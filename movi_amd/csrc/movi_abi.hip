@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -1308,6 +1309,10 @@ int run_chunked(movi_index *ix, const uint8_t *h_bases, const uint64_t *h_offset
         const uint64_t nr = last - first;
         const uint64_t b0 = h_offsets[first], nb = h_offsets[last] - b0;
         struct { void *p; } d_bases{}, d_offs{}, d_err{};
+        static const bool trace = getenv("MOVI_TRACE_HOST_CALLS") != nullptr;   // diagnostic: where a synchronous host call's time goes, to stderr
+        double tr[8] = {0};
+        auto stamp = [&](int k) { if (trace) tr[k] = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        stamp(0);
         HIP_TRY(ctx.alloc(movi_index::kBases, nb, &d_bases.p));
         HIP_TRY(ctx.alloc(movi_index::kOffs, (nr + 1) * 8, &d_offs.p));
         HIP_TRY(ctx.alloc(movi_index::kErr, nr, &d_err.p));
@@ -1321,17 +1326,28 @@ int run_chunked(movi_index *ix, const uint8_t *h_bases, const uint64_t *h_offset
         // No length sort here: on ragged batches handing the lanes out longest-first measured
         // slightly SLOWER (31.1 vs 32.8 Gbases/s, log-normal lengths) -- the walk is bound by the
         // memory system, not by lane occupancy, and the dispatcher already refills whole blocks.
+        stamp(1);
         if (nb) HIP_TRY(hipMemcpy(d_bases.p, h_bases + b0, nb, hipMemcpyHostToDevice));
+        stamp(2);
         HIP_TRY(hipMemcpy(d_offs.p, rel.data(), (nr + 1) * 8, hipMemcpyHostToDevice));
+        stamp(3);
         int rc = launch(ctx, static_cast<const uint8_t *>(d_bases.p), static_cast<const uint64_t *>(d_offs.p), nr, nb,
                         static_cast<uint8_t *>(d_err.p));
         if (rc) return rc;
+        stamp(4);
         movi_query_stats_t st{};
         rc = movi_last_stats(ix, nullptr, &st);
         if (rc) return rc;
+        stamp(5);
         rc = fetch(ctx, first, nr, b0, nb);
         if (rc) return rc;
+        stamp(6);
         if (h_read_err) HIP_TRY(hipMemcpy(h_read_err + first, d_err.p, nr, hipMemcpyDeviceToHost));
+        stamp(7);
+        if (trace)
+            fprintf(stderr, "[movi_hip] host call: %llu reads %llu bases | staging + offsets %.3f | bases up %.3f | offsets up %.3f | launch %.3f | walk + counters %.3f | "
+                            "results down %.3f | error bytes down %.3f ms\n", (unsigned long long)nr, (unsigned long long)nb, (tr[1] - tr[0]) * 1e3, (tr[2] - tr[1]) * 1e3,
+                    (tr[3] - tr[2]) * 1e3, (tr[4] - tr[3]) * 1e3, (tr[5] - tr[4]) * 1e3, (tr[6] - tr[5]) * 1e3, (tr[7] - tr[6]) * 1e3);
         if (stats) {
             stats->bases += nb;
             stats->fast_forwards += st.fast_forwards;
