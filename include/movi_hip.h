@@ -331,7 +331,12 @@ int movi_host_unregister(void *p);
  * "block_threads" (0 = auto, 64, 128, 192 or 256: the kernels' launch bound), "waves_per_cu"
  * (0 = the launch policy's cap, else at most this many wavefronts resident per CU), "idx64" (1 = run the kernel instantiations for
  * tables of 2^32 rows and more, whatever the size: a test hook), "release_scratch" (any value: frees the
- * device staging buffers that the *_host entry points keep, grow-only, across calls), "pipe_chunk_bases"
+ * device staging buffers that the *_host entry points keep, grow-only, across calls), "host_overlap" (0: a *_host call is never cut into overlapped pieces, whatever memory
+ * its buffers are in -- one upload, the walk, one download; for a caller that pipelines chunk-sized calls itself and keeps its reads in page-locked
+ * memory for the direct upload, as `movi query` does; default 1), "reserve_host_bases" / "reserve_host_results" /
+ * "reserve_host_reads" (that staging reserved up front instead of inside the first big call: the reads of a synchronous *_host call of
+ * up to this many bases, its u16 result vector, the per-read buffers of up to this many reads; movi_index_info "host_staging_bytes"
+ * tells what is held), "pipe_chunk_bases"
  * (bases per chunk of the overlapped host path, 0 = its own policy: a test hook), "seg_len" (PML: batches whose mean
  * read length is at least twice this many bases are walked segment-parallel -- every read cut into segments of about
  * seg_len bases walked by their own lanes, stitched where the walks fall into step, reads that do not walked again:

@@ -114,6 +114,8 @@ struct movi_index {
     void *scratch[kScratchSlots] = {};
     size_t scratch_cap[kScratchSlots] = {};
     SegWorkspace seg_ws;             // segment-parallel long reads (launch_pml): device workspace of the handle's own calls
+    uint64_t *h_rel = nullptr;       // synchronous path: a chunk's relative offsets, page-locked and kept (a fresh 2 MB vector per call was page
+    size_t h_rel_cap = 0;            // faults + a staged copy: ~0.3 ms of a 2 ms call); entries
     // the overlapped form of the *_host entry points (page-locked caller buffers, movi_host_alloc): kPipeSlots chunks in
     // flight, each on its own stream with its own device staging, counters and a small page-locked block for what
     // travels with a chunk (relative offsets up; error bytes, per-read results and counters down)
@@ -134,10 +136,12 @@ struct movi_index {
     uint64_t pipe_chunk_bases = 0;   // test hook ("pipe_chunk_bases"): chunk size of the overlapped path, 0 = its policy
     LaunchInfo last_launch;          // what the last query call launched (movi_last_launch)
     bool host_autopin = true;        // big *_host calls on pageable buffers page-lock them for the call ("host_autopin")
+    bool host_overlap = true;        // page-locked buffers take the overlapped path ("host_overlap" 0: one upload, the walk, one download)
     bool seg_seen = false;           // the last PML / ZML host call on long reads was walked segment-parallel (chunk policy below)
 };
 
 static void release_scratch(movi_index *ix);
+namespace { hipError_t grow(void **p, size_t *cap, size_t bytes); }   // grow-only device staging (defined with the host paths)
 
 extern "C" {
 
@@ -953,6 +957,30 @@ int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
         release_scratch(ix);
         return MOVI_OK;
     }
+    // device staging of the synchronous *_host calls reserved up front (it is grow-only and otherwise grows inside the first big call:
+    // three hipMallocs, ~1.2 ms of a 3 ms call of 2^25 bases): the reads of a call of up to `value` bases / its u16 result vector /
+    // the per-read buffers of up to `value` reads
+    if (!strcmp(key, "reserve_host_bases") || !strcmp(key, "reserve_host_results") || !strcmp(key, "reserve_host_reads")) {
+        if (value < 0 || (uint64_t)value > (1ull << 40)) return fail(MOVI_ERR_ARG, std::string(key) + " out of range");
+        HIP_TRY(hipSetDevice(ix->device));
+        const size_t v = (size_t)value;
+        if (!strcmp(key, "reserve_host_bases")) {
+            HIP_TRY(grow(&ix->scratch[movi_index::kBases], &ix->scratch_cap[movi_index::kBases], v));
+        } else if (!strcmp(key, "reserve_host_results")) {
+            HIP_TRY(grow(&ix->scratch[movi_index::kOut], &ix->scratch_cap[movi_index::kOut], v * 2));
+        } else {                                             // "reserve_host_reads"
+            HIP_TRY(grow(&ix->scratch[movi_index::kOffs], &ix->scratch_cap[movi_index::kOffs], (v + 1) * 8));
+            HIP_TRY(grow(&ix->scratch[movi_index::kErr], &ix->scratch_cap[movi_index::kErr], v));
+            if (ix->h_rel_cap < v + 1) {
+                if (ix->h_rel) (void)hipHostFree(ix->h_rel);
+                ix->h_rel = nullptr;
+                ix->h_rel_cap = 0;
+                HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ix->h_rel), (v + 1) * 8, hipHostMallocDefault));
+                ix->h_rel_cap = v + 1;
+            }
+        }
+        return MOVI_OK;
+    }
     if (!strcmp(key, "pipe_chunk_bases")) {                  // test hook: many small chunks through the overlapped host path
         if (value < 0) return fail(MOVI_ERR_ARG, "pipe_chunk_bases must be >= 0");
         ix->pipe_chunk_bases = (uint64_t)value;
@@ -977,6 +1005,11 @@ int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
     if (!strcmp(key, "host_autopin")) {                      // 0: pageable buffers always take the synchronous path (A/B)
         if (value != 0 && value != 1) return fail(MOVI_ERR_ARG, "host_autopin must be 0 or 1");
         ix->host_autopin = value != 0;
+        return MOVI_OK;
+    }
+    if (!strcmp(key, "host_overlap")) {                      // 0: the *_host calls never cut themselves into overlapped pieces (a caller
+        if (value != 0 && value != 1) return fail(MOVI_ERR_ARG, "host_overlap must be 0 or 1");   // that pipelines chunk-sized calls itself)
+        ix->host_overlap = value != 0;
         return MOVI_OK;
     }
     if (!strcmp(key, "stage_reads")) {                       // A/B: reads of short-read wavefronts staged through LDS
@@ -1113,6 +1146,11 @@ int movi_index_info(const movi_index_t *ix, const char *key, double *value) {
     else if (!strcmp(key, "ckpt_bytes")) *value = ckpt;
     else if (!strcmp(key, "derived_bytes")) *value = kmer + ftab + ahead + ckpt;
     else if (!strcmp(key, "ahead_no_ff")) *value = ix->ahead_tallied ? ix->ahead_no_ff : -1.0;
+    else if (!strcmp(key, "host_staging_bytes")) {           // device staging the synchronous *_host calls hold at the moment
+        double b = 0.0;
+        for (int k = 0; k < movi_index::kScratchSlots; k++) b += (double)ix->scratch_cap[k];
+        *value = b;
+    }
     else return fail(MOVI_ERR_ARG, std::string("unknown info key: ") + key);
     return MOVI_OK;
 }
@@ -1228,6 +1266,9 @@ static void release_scratch(movi_index *ix) {
     }
     if (ix->seg_ws.buf) (void)hipFree(ix->seg_ws.buf);
     ix->seg_ws = SegWorkspace();
+    if (ix->h_rel) (void)hipHostFree(ix->h_rel);
+    ix->h_rel = nullptr;
+    ix->h_rel_cap = 0;
     for (auto &sl : ix->pipe) {
         if (sl.s) (void)hipStreamSynchronize(sl.s);
         if (sl.seg_ws.buf) (void)hipFree(sl.seg_ws.buf);
@@ -1316,7 +1357,15 @@ int run_chunked(movi_index *ix, const uint8_t *h_bases, const uint64_t *h_offset
         HIP_TRY(ctx.alloc(movi_index::kBases, nb, &d_bases.p));
         HIP_TRY(ctx.alloc(movi_index::kOffs, (nr + 1) * 8, &d_offs.p));
         HIP_TRY(ctx.alloc(movi_index::kErr, nr, &d_err.p));
-        std::vector<uint64_t> rel(nr + 1);
+        if (ix->h_rel_cap < nr + 1) {
+            if (ix->h_rel) (void)hipHostFree(ix->h_rel);
+            ix->h_rel = nullptr;
+            ix->h_rel_cap = 0;
+            const size_t want = (size_t)(nr + 1) + (size_t)((nr + 1) >> 3);
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ix->h_rel), want * 8, hipHostMallocDefault));
+            ix->h_rel_cap = want;
+        }
+        uint64_t *rel = ix->h_rel;                            // (read by the copy below before the call returns: hipMemcpy is synchronous)
         uint64_t longest = 0;
         for (uint64_t i = 0; i <= nr; i++) {
             rel[i] = h_offsets[first + i] - b0;
@@ -1329,7 +1378,7 @@ int run_chunked(movi_index *ix, const uint8_t *h_bases, const uint64_t *h_offset
         stamp(1);
         if (nb) HIP_TRY(hipMemcpy(d_bases.p, h_bases + b0, nb, hipMemcpyHostToDevice));
         stamp(2);
-        HIP_TRY(hipMemcpy(d_offs.p, rel.data(), (nr + 1) * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_offs.p, rel, (nr + 1) * 8, hipMemcpyHostToDevice));
         stamp(3);
         int rc = launch(ctx, static_cast<const uint8_t *>(d_bases.p), static_cast<const uint64_t *>(d_offs.p), nr, nb,
                         static_cast<uint8_t *>(d_err.p));
@@ -1535,6 +1584,7 @@ int run_host(bool overlapped, movi_index *ix, const uint8_t *h_bases, const uint
              uint8_t *h_read_err, movi_query_stats_t *stats, Launch launch, Fetch fetch, Harvest harvest,
              size_t small_bytes) {
     movi_query_stats_t local{};
+    overlapped = overlapped && ix->host_overlap;
     int rc = overlapped ? run_pipelined(ix, h_bases, h_offsets, n_reads, h_read_err, &local, launch, fetch, harvest, small_bytes)
                         : run_chunked(ix, h_bases, h_offsets, n_reads, h_read_err, &local, launch, fetch, harvest, small_bytes);
     if (stats) *stats = local;
@@ -1600,7 +1650,7 @@ struct AutoPin {
 };
 static bool autopin_worthwhile(const movi_index *ix, const uint64_t *h_offsets, uint64_t n_reads) {
     // (the overlapped path cuts a call into pieces of >= 2^15 reads: it needs at least three of them to overlap anything)
-    return ix->host_autopin && h_offsets[n_reads] - h_offsets[0] >= (1ull << 27) && n_reads >= 3 * kPipeMinReads;
+    return ix->host_autopin && ix->host_overlap && h_offsets[n_reads] - h_offsets[0] >= (1ull << 27) && n_reads >= 3 * kPipeMinReads;
 }
 
 static int ml_host(bool zml, movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_offsets, uint64_t n_reads,

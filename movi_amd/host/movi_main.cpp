@@ -172,6 +172,33 @@ void *pinned_alloc(size_t bytes) {
 }
 void pinned_free(void *q) { movi_host_free(q); }
 
+// The chunks' read buffers: page-locked up to the size of an ordinary chunk -- allocated by the parser's warm-up while the index loads --,
+// plain memory beyond it (a chunk of long reads grows to a GB: page-locking that much inside the run costs more than it gives).
+// Why (tools/r05_stall.sh, the engine's MOVI_TRACE_HOST_CALLS=1): the upload of a chunk's 33.5 MB from PAGEABLE memory takes 0.6 ms when
+// nothing else runs, 1.1 - 2.9 ms beside the parser's threads, and now and then 20 - 30 ms (one run in five on some boxes: the runtime's
+// pageable path against the parser's page faults); from page-locked memory it is one direct DMA.  25 runs each on one box, ms per
+// 150 Mbases: --no-output 14.6 - 38.7 (median 18.4) -> 12.4 - 19.9 (13.5); with the BPF file 32.0 - 69.8 (35.7) -> 31.0 - 44.9 (32.8).
+// The calls are kept whole ("host_overlap" 0: the engine would otherwise cut a call on page-locked buffers into overlapped pieces,
+// which chunk-sized calls never earn back -- the MOVI_PINNED=1 measurement above).  MOVI_PINNED=0: pageable buffers (A/B).
+constexpr size_t kPinnedChunkLimit = 96u << 20;
+std::mutex g_pinned_m;
+std::vector<void *> g_pinned_ptrs;
+void *chunk_alloc(size_t bytes) {
+    if (bytes <= kPinnedChunkLimit) {
+        void *q = pinned_alloc(bytes);
+        if (q) { std::lock_guard<std::mutex> g(g_pinned_m); g_pinned_ptrs.push_back(q); return q; }
+    }
+    return std::malloc(bytes);
+}
+void chunk_free(void *q) {
+    {
+        std::lock_guard<std::mutex> g(g_pinned_m);
+        auto it = std::find(g_pinned_ptrs.begin(), g_pinned_ptrs.end(), q);
+        if (it != g_pinned_ptrs.end()) { g_pinned_ptrs.erase(it); movi_host_free(q); return; }
+    }
+    std::free(q);
+}
+
 struct Job {
     ReadSet rs;
     MlBuf pml;                                                        // PML / ZML values, emission order per read
@@ -268,7 +295,9 @@ int run_query(const Options &o) {
         chunk_bases = std::max<uint64_t>(1, std::strtoull(e, nullptr, 10));
         chunk_min_reads = 1;
     }
-    const bool pin_buffers = std::getenv("MOVI_PINNED") && std::string(std::getenv("MOVI_PINNED")) == "1";
+    const std::string pinned_env = std::getenv("MOVI_PINNED") ? std::getenv("MOVI_PINNED") : "";
+    const bool pin_buffers = pinned_env == "1";
+    bool pin_chunks = false;                                           // read buffers page-locked at warm-up, one direct upload per chunk (chunk_alloc)
     std::thread warmer;
     struct WarmJoin { std::thread &t; ~WarmJoin() { if (t.joinable()) t.join(); } } warm_join{warmer};
     if (o.read_file != "-") {
@@ -276,7 +305,11 @@ int run_query(const Options &o) {
         if (file_in.good()) {                                          // (a missing file is reported where it always was: after the index)
             in = &file_in;
             reader_ptr = open_reader(o.read_file, *in, o.prefetch ? 4 * o.strands : 1, map);   // src/movi.cpp:283, :326
-            if (map.p != MAP_FAILED && !pin_buffers && !std::getenv("MOVI_NO_WARM_PARSER") && !std::getenv("MOVI_CHUNK_BASES"))
+            const bool warm = map.p != MAP_FAILED && !pin_buffers && !std::getenv("MOVI_NO_WARM_PARSER") && !std::getenv("MOVI_CHUNK_BASES");
+            pin_chunks = warm && pinned_env != "0";                    // (only where the warm-up allocates them, outside the run)
+            if (pin_chunks)
+                for (Job &j : jobs) j.rs.bases.set_allocator(chunk_alloc, chunk_free);
+            if (warm)
                 warmer = std::thread([&] {
                     ReadSet *sets[3] = {&jobs[0].rs, &jobs[1].rs, &jobs[2].rs};
                     try { reader_ptr->warm_up(sets, 3, chunk_bases); } catch (...) { /* no memory for it: the chunks allocate as they come */ }
@@ -306,6 +339,8 @@ int run_query(const Options &o) {
     // (the ZML parse does not walk on the look-ahead rows unless "zml_ahead" asks for it: `--zml --ahead-rows 1` builds nothing)
     if (o.ahead_rows >= 0 && !(o.zml && o.ahead_rows == 1))
         for (auto *hd : handles) check(movi_set_option(hd, "ahead_rows", o.ahead_rows), "--ahead-rows");
+    if (pin_chunks)
+        for (auto *hd : handles) check(movi_set_option(hd, "host_overlap", 0), "host_overlap");
     // Round 5: the handles' derived tables -- top-of-walk / interval table, look-ahead rows (16 bytes per row: 16 GB and ~0.3 s of
     // allocation + build for a 1 B-row index), row-start checkpoints -- are part of LOADING THE INDEX (movi_index_prepare), not of the
     // first chunk's GPU call: rounds 3 - 4 built them inside the read-processing clock, behind the first chunk's parse, which a
@@ -313,6 +348,13 @@ int run_query(const Options &o) {
     for (auto *hd : handles) {                                         // (errors here are not the query's: the real calls report)
         if (o.pml && o.logs) continue;                                 // --logs runs on the first kernel, which uses none of the derived tables
         (void)movi_index_prepare(hd, o.pml ? MOVI_PREPARE_PML : (o.zml ? MOVI_PREPARE_ZML : MOVI_PREPARE_COUNT), nullptr, nullptr);
+        // ... and so is the device staging of a chunk's host call (three hipMallocs: 1.2 ms of the first chunk's 3 ms call otherwise):
+        // a chunk's bases with the slack of its last batch, its result vector when one comes back, reads down to 64 bases long
+        const int64_t cb = (int64_t)std::min<uint64_t>(chunk_bases + (chunk_bases >> 3), 1ull << 31) / (o.gpus > 0 ? o.gpus : 1);
+        (void)movi_set_option(hd, "reserve_host_bases", cb);
+        (void)movi_set_option(hd, "reserve_host_reads", cb / 64);
+        if (o.ml() && (o.write_output_allowed() || o.classify) && !(o.pml && o.classify && !o.write_output_allowed()))
+            (void)movi_set_option(hd, "reserve_host_results", cb);
     }
     movi_index_desc_t desc;
     check(movi_index_get_desc(handles[0], &desc), "index description");
@@ -703,7 +745,7 @@ int run_query(const Options &o) {
     }
     if (o.verbose)                                                     // the three pipeline stages run side by side: the slowest one bounds the command
         std::cerr << "[movi] Stage times: parse " << parse_seconds << " s, GPU calls " << gpu_seconds << " s, order + write "
-                  << write_seconds << " s (page-locked chunk buffers: " << (pin_buffers ? "yes" : "no") << ")\n";
+                  << write_seconds << " s (page-locked chunk buffers: " << (pin_buffers ? "yes" : (pin_chunks ? "reads" : "no")) << ")\n";
     std::cout.flush();
     return 0;
 }

@@ -323,3 +323,44 @@ def test_prepared_handle_queries_build_nothing_and_can_be_captured(built_lib, go
     assert gpu.last_launch()["kernel"] == "zml_kernel_flat<6, unsigned int, 0, 0, 0, 1>"   # the count query's state machine
     gpu.close()
     cpu.close()
+
+
+def test_host_staging_reserved_up_front(built_lib, golden_image):
+    """"reserve_host_bases" / "reserve_host_results" / "reserve_host_reads" (round 5): the device staging of the synchronous *_host
+    calls is allocated by the options, a host call within those sizes allocates nothing more (movi_index_info "host_staging_bytes"
+    and the device's free memory stay where they were), its answers are the oracle's, and "release_scratch" gives it all back."""
+    import torch
+    import movi_amd
+    from oracle.oracle import Oracle
+    img = golden_image(6)
+    cpu = Oracle(img)
+    rng = np.random.default_rng(9800)
+    reads = mutated_reads(rng, _ref(), 700, 1, 300)
+    bases, offs = pack(reads)
+    exp, _, _ = cpu.pml_batch(bases, offs, threads=4)
+    em, ec = cpu.count_batch(bases, offs, threads=4)
+    gpu = movi_amd.MoveIndex.from_image(img)
+    gpu.prepare()
+    assert gpu.info("host_staging_bytes") == 0
+    with pytest.raises(movi_amd.MoviError):
+        gpu.set_option("reserve_host_bases", -1)
+    gpu.set_option("reserve_host_bases", 1 << 20)
+    gpu.set_option("reserve_host_results", 1 << 20)
+    gpu.set_option("reserve_host_reads", 4096)
+    held = gpu.info("host_staging_bytes")
+    assert held >= (1 << 20) * 3 + 4097 * 8 + 4096
+    gpu.set_option("reserve_host_bases", 1 << 10)              # grow-only: a smaller request changes nothing
+    assert gpu.info("host_staging_bytes") == held
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    got, _ = gpu.query_pml_packed(bases, offs)
+    assert (got == exp).all()
+    assert gpu.info("host_staging_bytes") == held and torch.cuda.mem_get_info()[0] >= free0 - (1 << 20)
+    m, c, _ = gpu.query_count_packed(bases, offs)               # (the count call's two per-read result buffers are its own)
+    assert (m == em).all() and (c == ec).all()
+    gpu.set_option("release_scratch", 1)
+    assert gpu.info("host_staging_bytes") == 0
+    got, _ = gpu.query_pml_packed(bases, offs)                  # ... and the lazy path still serves
+    assert (got == exp).all() and gpu.info("host_staging_bytes") > 0
+    gpu.close()
+    cpu.close()

@@ -1082,6 +1082,19 @@ def test_overlapped_host_path_equals_synchronous(engines, mode, chunk_bases):
     # page-locked reads with a pageable result vector: PML / ZML fall back to the synchronous path, same answers
     out2, _ = gpu.query_pml_packed(pb, offs)
     assert (out2 == exp_out).all()
+    # "host_overlap" 0 (round 5; what `movi query` sets): page-locked buffers, the call kept whole -- one direct upload, the walk, one download
+    gpu.set_option("host_overlap", 0)
+    try:
+        out3 = movi_amd.pinned_empty(bases.size, np.uint16)
+        out3[:] = 0xABCD
+        _, st3 = gpu.query_pml_packed(pb, offs, out=out3)
+        assert (out3 == exp_out).all() and (st3.fast_forwards, st3.scans) == (ff, sc)
+        m3, c3, _ = gpu.query_count_packed(pb, offs)
+        assert (m3 == exp_m).all() and (c3 == exp_c).all()
+        with pytest.raises(movi_amd.MoviError):
+            gpu.set_option("host_overlap", 2)
+    finally:
+        gpu.set_option("host_overlap", 1)
 
 
 def test_overlapped_host_path_reports_invariant_violations(built_lib, golden_image):
