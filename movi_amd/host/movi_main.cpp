@@ -306,7 +306,18 @@ int run_query(const Options &o) {
             in = &file_in;
             reader_ptr = open_reader(o.read_file, *in, o.prefetch ? 4 * o.strands : 1, map);   // src/movi.cpp:283, :326
             const bool warm = map.p != MAP_FAILED && !pin_buffers && !std::getenv("MOVI_NO_WARM_PARSER") && !std::getenv("MOVI_CHUNK_BASES");
-            pin_chunks = warm && pinned_env != "0";                    // (only where the warm-up allocates them, outside the run)
+            // (only where the warm-up allocates them, outside the run -- and only for short lines: a chunk of long reads outgrows the
+            // warmed buffers at once, and giving page-locked memory back inside the run cost 100 k x 10 kbp 20 %: 0.094 - 0.135 -> 0.134 - 0.159 s,
+            // tools/r05_pin_ab.sh)
+            bool short_lines = false;
+            if (warm) {
+                const char *m = static_cast<const char *>(map.p);
+                const size_t probe = std::min<size_t>(map.n, 1u << 20);
+                size_t nl = 0;
+                for (const char *q = m; (q = static_cast<const char *>(std::memchr(q, '\n', (size_t)(m + probe - q)))) != nullptr; ++q) nl++;
+                short_lines = nl * 1024 >= probe;                      // at least a line per KiB (the scan-ahead's own test for long reads)
+            }
+            pin_chunks = warm && short_lines && pinned_env != "0";
             if (pin_chunks)
                 for (Job &j : jobs) j.rs.bases.set_allocator(chunk_alloc, chunk_free);
             if (warm)
