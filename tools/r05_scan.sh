@@ -14,15 +14,14 @@ PY
 run() { local name=$1 rep; shift
   for rep in 1 2 3 4 5; do
     movi_amd/bin/movi query -i $IDX --verbose "$@" 2> $O/$name.$rep.err > /dev/null
-    grep -h "processing the reads\|Chunks:" $O/$name.$rep.err | sed "s|^|$name.$rep: |; s/\[movi\] //"
+    grep -h "processing the reads\|Chunk phases" $O/$name.$rep.err | sed "s|^|$name.$rep: |; s/\[movi\] //"
   done
 }
 {
-run pageable -r /tmp/short.fa --no-output
-MOVI_PINNED=2 run pinned2 -r /tmp/short.fa --no-output
-MOVI_PINNED=1 run pinned1 -r /tmp/short.fa --no-output
-run pageable_again -r /tmp/short.fa --no-output
-MOVI_PINNED=2 run pinned2_again -r /tmp/short.fa --no-output
-MOVI_PINNED=2 run pinned2_bpf -r /tmp/short.fa -o /tmp/o_pinned2; rm -f /tmp/o_pinned2*
-run pageable_bpf -r /tmp/short.fa -o /tmp/o_pageable; rm -f /tmp/o_pageable*
+for round in 1 2; do
+run parts1_r$round -r /tmp/short.fa --no-output
+MOVI_SCAN_PARTS=2 run parts2_r$round -r /tmp/short.fa --no-output
+MOVI_SCAN_PARTS=4 run parts4_r$round -r /tmp/short.fa --no-output
+MOVI_SCAN_DEPTH=3 run depth3_r$round -r /tmp/short.fa --no-output
+done
 } 2>&1 | tee $O/summary.txt
