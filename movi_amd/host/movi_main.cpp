@@ -469,7 +469,9 @@ int run_query(const Options &o) {
             Job *j = nullptr;
             // (round 5, measured and dropped: smaller FIRST chunks -- a quarter, then half of the steady size, to shorten the
             // pipeline's fill -- tripled the GPU stage, 0.011 -> 0.035 s per 150 Mbases: every growth of a chunk re-allocates the
-            // engine's device staging, and hipFree waits for the device.  tools/r05_cli.sh)
+            // engine's device staging, and hipFree waits for the device.  tools/r05_cli.sh.  Tried again with the staging reserved up
+            // front ("reserve_host_*"): nothing to see through the box's own noise, 15 runs each, BPF 30 - 40 against 30 - 39 and 32 - 35
+            // against 34 - 37 ms, --no-output worse in one round and better in the other)
             while (free_q.pop(j)) {
                 const auto tp = std::chrono::steady_clock::now();
                 const bool more = reader.next_chunk(j->rs, chunk_bases, chunk_min_reads, chunk_hard_max);
