@@ -734,7 +734,7 @@ int run_query(const Options &o) {
     if (o.verbose) {
         const BatchReader::PhaseTimes pt = reader.phase_times();
         std::cerr << "[movi] Parser phases: newline scan " << pt.prescan << " s, batch cut " << pt.cut << " s, lengths " << pt.lengths
-                  << " s, copy " << pt.copy << " s; " << pt.bulk_reads << " of " << pt.reads << " reads cut in bulk\n";
+                  << " s, copy " << pt.copy << " s; " << pt.bulk_reads << " of " << pt.reads << " reads cut in bulk (" << pt.closed_reads << " by the closed form)\n";
     }
     if (o.verbose) {                                                   // chunk by chunk: the first chunk's parse runs alone, the others beside the GPU calls
         std::cerr << "[movi] Chunks: parse";

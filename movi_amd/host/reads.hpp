@@ -269,7 +269,7 @@ public:
     void warm_up(ReadSet *const *sets, unsigned n_sets, uint64_t max_bases);
     void adopt_pool() { if (pool_) pool_->adopt_owner(); }
     // seconds spent in the parser's phases so far (movi query --verbose, tools/parse_bench.cpp)
-    struct PhaseTimes { double prescan = 0, cut = 0, lengths = 0, copy = 0, scan_busy = 0, scan_wait = 0; uint64_t bulk_reads = 0, reads = 0; };   // scan_*: the scan-ahead helper's own time / what the cut waited for it (inside `cut`)   // bulk_reads: cut by cut_ahead
+    struct PhaseTimes { double prescan = 0, cut = 0, lengths = 0, copy = 0, scan_busy = 0, scan_wait = 0; uint64_t bulk_reads = 0, closed_reads = 0, reads = 0; };   // scan_*: the scan-ahead helper's own time / what the cut waited for it (inside `cut`)   // bulk_reads: cut by cut_ahead (closed_reads of them: batches by the closed form)
     PhaseTimes phase_times() const { PhaseTimes t = times_; t.scan_busy = src_.scan_busy_s(); t.scan_wait = src_.scan_wait_s(); return t; }
 
 private:
@@ -285,6 +285,7 @@ private:
     PodVec<Span> lines_;                // lines of the current chunk
     PodVec<Rec> recs_;
     std::vector<uint32_t> hdr_line_, rec_batch_;   // cut_ahead's scratch: header line of each read, its batch
+    std::vector<uint64_t> batch_pending_;          // ... and, closed-form cut, the sequence bytes of each batch
     size_t min_reads_;
     uint64_t size_hint_ = 0;
     unsigned threads_ = 0;              // 0 = hardware concurrency (at most 16)

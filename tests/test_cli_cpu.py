@@ -356,3 +356,33 @@ def test_bulk_batch_cut_leaves_malformed_records_to_the_reference_path(movi_bin,
     a, b, c = _plan3(path, ["-s16"])
     assert (a.returncode, a.stdout, a.stderr) == (b.returncode, b.stdout, b.stderr) == (c.returncode, c.stdout, c.stderr)
     assert a.returncode == 1 and message in a.stderr
+
+
+@pytest.mark.parametrize("fmt", ["fa", "fq"])
+@pytest.mark.parametrize("strands", [16, 4, 1])
+def test_closed_form_batch_cut_equals_the_running_sum(movi_bin, tmp_path, fmt, strands):
+    """Round 5: where every record in reach counts for at least ceil(1000 / min_reads) "bases", loadBatch's rule ends every batch
+    after exactly min_reads records and the bulk cut says so in closed form; a record too short for that sends the pass back to
+    the running sum.  Three files -- regular 150 bp reads, tiny reads (1 - 8 bases, one-letter ids: far below the bound), and
+    stretches of both -- must give the plan of the running sum (MOVI_NO_CLOSED_CUT=1) and of the line-by-line cut
+    (MOVI_NO_FAST_CUT=1), chunked or not."""
+    rng = np.random.default_rng(50 + strands + (fmt == "fq"))
+
+    def rec(i, L, short_id):
+        s = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), L))
+        name = (b"%c" % (97 + i % 26)) * 2 if short_id else b"read%d" % i
+        return [b"@" + name, s, b"+", b"I" * L] if fmt == "fq" else [b">" + name, s]
+
+    files = {"regular": [l for i in range(12000) for l in rec(i, 150, False)],
+             "tiny": [l for i in range(30000) for l in rec(i, int(rng.integers(1, 9)), True)],
+             "mixed": [l for i in range(30000) for l in rec(i, 150 if (i // 3000) % 2 == 0 else int(rng.integers(1, 9)), (i // 3000) % 2 == 1)]}
+    for name, lines in files.items():
+        path = tmp_path / ("%s.%s" % (name, fmt))
+        path.write_bytes(b"\n".join(lines) + b"\n")
+        flags = ["plan", "-r", str(path), "-s%d" % strands]
+        a = run(flags)
+        b = run(flags, env=dict(os.environ, MOVI_NO_CLOSED_CUT="1"))
+        c = run(flags, env=dict(os.environ, MOVI_NO_FAST_CUT="1"))
+        d = run(flags, env=dict(os.environ, MOVI_CHUNK_BASES="200000"))
+        assert a.returncode == b.returncode == c.returncode == d.returncode == 0, (name, a.stderr, b.stderr, c.stderr, d.stderr)
+        assert a.stdout == b.stdout == c.stdout == d.stdout and a.stdout.count(b"\n") == len(lines) // (4 if fmt == "fq" else 2), name

@@ -30,8 +30,8 @@ int main(int argc, char **argv) {
             while (rd.next_chunk(rs[k % 3], chunk, chunk < (1ull << 25) ? 1 : 1ull << 15, 1ull << 30)) { bases += rs[k % 3].bases.size(); reads += rs[k % 3].size(); k++; }
             const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             const BatchReader::PhaseTimes &pt = rd.phase_times();
-            printf("T=%-2u chunks %d reads %lu bases %lu: %.4f s = %.2f Gbases/s  (newline scan %.4f, batch cut %.4f, lengths %.4f, copy %.4f; %lu reads cut in bulk)\n",
-                   T, k, (unsigned long)reads, (unsigned long)bases, dt, bases / dt / 1e9, pt.prescan, pt.cut, pt.lengths, pt.copy, (unsigned long)pt.bulk_reads);
+            printf("T=%-2u chunks %d reads %lu bases %lu: %.4f s = %.2f Gbases/s  (newline scan %.4f, batch cut %.4f, lengths %.4f, copy %.4f; %lu reads cut in bulk, %lu in closed form)\n",
+                   T, k, (unsigned long)reads, (unsigned long)bases, dt, bases / dt / 1e9, pt.prescan, pt.cut, pt.lengths, pt.copy, (unsigned long)pt.bulk_reads, (unsigned long)pt.closed_reads);
         }
     return 0;
 }
