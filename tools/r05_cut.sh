@@ -13,7 +13,7 @@ PY
 run() { local name=$1 n=$2 rep; shift 2
   for rep in $(seq 1 $n); do movi_amd/bin/movi query -i $IDX --verbose "$@" 2> $O/$name.$rep.err > /dev/null; done
   echo -n "$name: "; grep -h "processing the reads" $O/$name.*.err | awk '{print $8}' | sort -n | tr '\n' ' '; echo
-  grep -h "Parser phases" $O/$name.*.err | awk '{c += $8; n++} END {printf "   batch cut, mean of %d runs: %.2f ms\n", n, c / n * 1e3}'
+  grep -h "Parser phases" $O/$name.*.err | sed 's/.*batch cut \([0-9.e-]*\) s, lengths \([0-9.e-]*\) s, copy \([0-9.e-]*\) s.*/\1 \2 \3/' | awk '{c += $1; l += $2; k += $3; n++} END {printf "   mean of %d runs: batch cut %.2f, lengths %.2f, copy %.2f ms\n", n, c / n * 1e3, l / n * 1e3, k / n * 1e3}'
 }
 {
 for round in 1 2 3; do
