@@ -56,6 +56,12 @@ def test_reference_cli_golden(movi_bin, mode, flags, reads):
     assert got == open(os.path.join(GOLDEN, "sample.fastq.pmls.sorted"), "rb").read()
 
 
+def pack(reads):
+    offs = np.zeros(len(reads) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(r) for r in reads])
+    return np.frombuffer(b"".join(reads), np.uint8).copy(), offs
+
+
 def write_mixed_reads(path, rng, ref, n=300):
     recs = []
     with open(path, "wb") as f:
@@ -101,6 +107,33 @@ def test_bpf_bytes_view_and_order(movi_bin, oracles, tmp_path, mode):
     s = run(["query", "-i", IDX[mode], "-r", reads_path, "-n", "--stdout"])
     assert v.returncode == 0 and s.returncode == 0 and v.stdout == s.stdout
     assert s.stdout == b"".join(b">" + rid + b"\n" + stdout_line(oracles[mode].pml(seq)).encode() + b"\n" for rid, seq in recs)
+
+
+def test_bpf_bytes_with_pooled_order_and_many_slabs(movi_bin, oracles, tmp_path):
+    """Round 5: 9 000 ragged reads -- enough for the writer stage's pool to compute the strand-scheduler order by ranges of batches --
+    and slabs of 64 KiB, so that the BPF file leaves through hundreds of ring slots: the bytes are the oracle's PMLs in `movi plan`'s
+    order, and the one-thread loop (MOVI_BPF_SERIAL=1) writes the same file."""
+    from oracle import build_index as B
+    ref = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))[0][1]
+    reads_path = str(tmp_path / "many.fa")
+    recs = write_mixed_reads(reads_path, np.random.default_rng(77), ref, n=9000)
+    by_id = dict(recs)
+    assert len(by_id) == 9000
+    prefix = str(tmp_path / "out")
+    r = run(["query", "-i", IDX[6], "-r", reads_path, "-o", prefix, "-s16", "-t1"], env=dict(os.environ, MOVI_BPF_SLAB_BYTES="65536"))
+    assert r.returncode == 0, r.stderr
+    blob = open(prefix + ".pml.bpf", "rb").read()
+    order = plan_order(reads_path, ["-s16"])
+    assert order == [x for x in plan_order(reads_path, ["-s16"])] and sorted(order) == sorted(by_id)
+    bases, offs = pack([by_id[rid] for rid in order])
+    pml, _, _ = oracles[6].pml_batch(bases, offs, threads=4)
+    exp = [struct.pack("<IBBBBHxx", 0x42504600, 1, 0, 0, 16, 0)]
+    for k, rid in enumerate(order):
+        p = pml[int(offs[k]):int(offs[k + 1])]
+        exp.append(struct.pack("<H", len(rid)) + rid + struct.pack("<Q", len(p)) + p.astype("<u2").tobytes())
+    assert blob == b"".join(exp)
+    r2 = run(["query", "-i", IDX[6], "-r", reads_path, "-o", prefix + "2", "-s16", "-t1"], env=dict(os.environ, MOVI_BPF_SERIAL="1"))
+    assert r2.returncode == 0 and open(prefix + "2.pml.bpf", "rb").read() == blob
 
 
 @pytest.mark.parametrize("mode", [6, 8])
