@@ -523,7 +523,10 @@ def cli_path_leg(idx_dir, reads_150, reads_10k):
     that the sharding code is timed at least once."""
     import tempfile
     out = {"unit": "Gbases/s", "note": "movi query on FASTA input, best of 2 runs; value = bases / the command's own read-processing time "
-                                       "(parse + GPU calls + order + write, pipelined); wall_s adds process start, HIP init and index load"}
+                                       "(parse + GPU calls + order + write, pipelined -- and, since round 6, the seconds of the parser's warm-up, "
+                                       "which reads the input while the index loads: the clock excludes no work on the reads); wall_s adds process "
+                                       "start, HIP init and index load",
+           "clock_includes_parser_warmup": True}
     tmp = tempfile.mkdtemp(prefix="movi_cli_")
     try:
         for name, (arr, L) in (("short_1Mx150", reads_150), ("long_100kx10k", reads_10k)):
@@ -868,6 +871,37 @@ def main():
         except Exception as e:                            # noqa: BLE001
             sustained = {"error": repr(e)[:200]}
 
+    # ---- the same batch as RESET MASKS (round 6; default run only, never part of `value`): the walk that writes one bit per base
+    # (movi_pml_mask_device), and pml_expand_kernel turning the words back into the u16 vector -- each timed with HIP events
+    mask_path = None
+    if default_run:
+        try:
+            from movi_amd.engine import mask_words
+            d_words = torch.zeros(mask_words(n_reads, n_bases), dtype=torch.int32, device=dev)
+            d_out2 = torch.empty(n_bases, dtype=torch.int16, device=dev)
+            def mask_step():
+                index.pml_mask_device(d_bases.data_ptr(), d_offs.data_ptr(), n_reads, n_bases, d_words.data_ptr(), 0, d_err.data_ptr(), stream.cuda_stream)
+            def expand_step():
+                index.pml_expand_device(d_words.data_ptr(), d_offs.data_ptr(), n_reads, n_bases, d_out2.data_ptr(), 0, stream.cuda_stream)
+            for _ in range(2):
+                mask_step(); expand_step()
+            torch.cuda.synchronize()
+            mlaunch = index.last_launch()
+            _, _, mk_s = timed_steps(torch, dist, 1, dev, stream, mask_step, args.steps)
+            _, _, ex_s = timed_steps(torch, dist, 1, dev, stream, expand_step, args.steps)
+            same = bool(torch.equal(d_out2, d_out))
+            mask_path = {"walk_kernel": mlaunch["kernel"], "walk_ms": mk_s * 1e3, "expand_ms": ex_s * 1e3,
+                         "masks_gbases_s": n_bases / mk_s / 1e9, "masks_plus_expand_gbases_s": n_bases / (mk_s + ex_s) / 1e9,
+                         "expand_write_gb_s": 2.0 * n_bases / ex_s / 1e9, "bytes_out_per_base": 4.0 * d_words.numel() / n_bases,
+                         "expanded_equals_vector_walk": same}
+            if not same:
+                print("PARITY FAILURE: masks + expand differ from the vector walk", file=sys.stderr)
+            del d_words, d_out2
+            index.pml_device(d_bases.data_ptr(), d_offs.data_ptr(), n_reads, n_bases, d_out.data_ptr(), d_err.data_ptr(), stream.cuda_stream, d_order)
+            torch.cuda.synchronize()
+        except Exception as e:                            # noqa: BLE001
+            mask_path = {"error": repr(e)[:200]}
+
     tkey = args.workload + ("" if args.query == "pml" else "_" + args.query) + ("_classify%d" % args.classify if args.classify else "")
     traffic, traffic_src = lookup_traffic(tkey, wl["rows"], wl["reads"], wl["read_len"], launch["kernel"])
 
@@ -911,6 +945,10 @@ def main():
 
     if sustained is not None:
         result["sustained"] = sustained
+    if mask_path is not None:
+        result["mask_path"] = mask_path
+        if mask_path.get("expanded_equals_vector_walk") is False:
+            result["parity_sample_ok"] = False
     oracle_sample = None
     # ---- CPU baseline: the oracle restatement (scalar port, 16 strands/thread + prefetch,
     # OpenMP over read groups) on a bounded sample of the same reads, rank 0, N == 1 only.
@@ -986,28 +1024,44 @@ def main():
             and args.variant < 0 and not args.no_cpu_baseline):
         try:
             from movi_amd._lib import QueryStatsC, check, lib
-            hp = {"unit": "Gbases/s", "note": "movi_pml_host, host buffers in and out (1 B up + 2 B down per base over PCIe), "
-                                              "best of 3 calls after a warm-up call; pageable_synchronous = host_autopin off (upload, walk, download one after the "
-                                              "other), pageable = the default (a big call page-locks the caller's buffers for its duration and overlaps the three), "
-                                              "page_locked = caller-allocated page-locked buffers; all checked against each other and the cpu_baseline's oracle sample"}
+            hp = {"unit": "Gbases/s", "note": "movi_pml_host, host buffers in and out, best of 3 calls after a warm-up call.  Round 6: by default only "
+                                              "RESET MASKS cross PCIe on the way back (1 B up + 1/8 B down per base) and the u16 vector is expanded into the caller's "
+                                              "buffer by host worker threads beside the walks (`pml_via_mask`); *_vector = `pml_via_mask` 0, the vector itself comes "
+                                              "down (1 B up + 2 B down: rounds 1-5); masks_only = movi_pml_mask_host (the masks are the result).  pageable_synchronous = "
+                                              "host_autopin off (upload, walk, download one after the other), pageable = the default (a big call page-locks the caller's "
+                                              "reads for its duration and overlaps), page_locked = caller-allocated page-locked buffers; all checked against each other "
+                                              "and the cpu_baseline's oracle sample",
+                  "host_threads": usable_cores()}
             h_offs = np.ascontiguousarray(offs, np.uint64)
             stq = QueryStatsC()
             torch.cuda.synchronize()
             ref_out = None
-            for name, mk in (("pageable_synchronous", lambda n, dt: np.empty(n, dt)), ("pageable", lambda n, dt: np.empty(n, dt)),
-                             ("page_locked", movi_amd.pinned_empty)):
+            for name, mk, via in (("pageable_synchronous", lambda n, dt: np.empty(n, dt), -1), ("pageable", lambda n, dt: np.empty(n, dt), -1),
+                                  ("page_locked", movi_amd.pinned_empty, -1), ("page_locked_vector", movi_amd.pinned_empty, 0),
+                                  ("pageable_vector", lambda n, dt: np.empty(n, dt), 0), ("masks_only", movi_amd.pinned_empty, -1)):
                 # pageable_synchronous: "host_autopin" 0 = upload, walk, download one after the other; pageable: the default --
                 # a big call page-locks the caller's buffers for its duration and overlaps the three
                 index.set_option("host_autopin", 0 if name == "pageable_synchronous" else 1)
-                hb, ho = mk(n_bases, np.uint8), mk(n_bases, np.uint16)
+                index.set_option("pml_via_mask", via)
+                hb = mk(n_bases, np.uint8)
                 hb[:] = bases
-                ho[:] = 0xFFFF
+                if name == "masks_only":
+                    from movi_amd.engine import expand_masks_host, mask_words
+                    ho = np.zeros(mask_words(n_reads, n_bases), np.uint32)
+                    call = lambda: check(lib().movi_pml_mask_host(index._h, hb.ctypes.data, h_offs.ctypes.data, n_reads, ho.ctypes.data, None, C.byref(stq)))
+                else:
+                    ho = mk(n_bases, np.uint16)
+                    ho[:] = 0xFFFF
+                    call = lambda: check(lib().movi_pml_host(index._h, hb.ctypes.data, h_offs.ctypes.data, n_reads, ho.ctypes.data, None, C.byref(stq)))
                 ts = []
                 for _ in range(4):
                     t0 = time.perf_counter()
-                    check(lib().movi_pml_host(index._h, hb.ctypes.data, h_offs.ctypes.data, n_reads, ho.ctypes.data, None,
-                                              C.byref(stq)))
+                    call()
                     ts.append(time.perf_counter() - t0)
+                if name == "masks_only":                   # (their expansion, timed on its own: what a consumer of the vector pays on the host)
+                    t0 = time.perf_counter()
+                    ho = expand_masks_host(ho, h_offs, threads=0)
+                    hp["masks_only_host_expand_gbases_s"] = round(n_bases / (time.perf_counter() - t0) / 1e9, 2)
                 if ref_out is None:
                     ref_out = ho.copy()
                 hp[name] = round(n_bases / min(ts[1:]) / 1e9, 2)
@@ -1016,6 +1070,8 @@ def main():
                     ok = ok and bool((ho[: oracle_sample.size] == oracle_sample).all())
                 hp[name + "_ok"] = ok
                 del hb, ho
+            index.set_option("pml_via_mask", -1)
+            index.set_option("host_autopin", 1)
             result["host_path"] = hp
         except Exception as e:                            # noqa: BLE001 -- an extra, never worth the headline line
             result["host_path"] = {"error": repr(e)[:200]}

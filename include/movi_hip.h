@@ -16,6 +16,9 @@
  *   ReadProcessor::backward_search + compute_match_count  src/read_processor.cpp:610-620,1096-1175   movi_count_host / movi_count_device
  *   Classifier::classify (bins)     src/classifier.cpp:99-143           movi_classify_device / movi_pml_classify_device / movi_pml_classify_host
  *   MoveStructure::query_zml        src/move_structure_query.cpp:690-785  movi_zml_host / movi_zml_device
+ *   MoveQuery::add_ml / matching_lens  include/move_query.hpp:26-38 (filled by process_char, src/read_processor.cpp:193-215)
+ *                                                                       movi_pml_mask_device / movi_pml_mask_host (one reset bit per base)
+ *                                                                       + movi_pml_expand_device / movi_pml_expand_host (bits -> u16 vector)
  *
  * Conventions: every entry point returns an int status (MOVI_OK == 0) and never
  * throws; movi_last_error() gives the message for the calling thread.  One
@@ -155,12 +158,15 @@ int movi_index_load_replicated(const char *index_dir_or_file, const int *devices
 /* Build the handle's derived tables NOW instead of inside the first query: `what` = MOVI_PREPARE_PML (top-of-walk table,
  * 256 MB at K = 12; look-ahead rows, 16 bytes per row, where the device has room for them and half as much again, never more
  * than a quarter of the device by itself) | MOVI_PREPARE_COUNT (row-start checkpoints, 8 bytes per 32 rows; interval table,
- * 256 MB; the look-ahead rows where a sample of the table says the search will use them) | MOVI_PREPARE_ZML (nothing: accepted
- * for symmetry).  Honours the options set before it ("kmer_k", "ftab_k", "ahead_rows": a table the caller built or switched
+ * 256 MB; nothing else: since round 5 the count query's default is the lane state machine on the PLAIN rows -- the look-ahead rows
+ * are built for it only under "count_variant" 0, the base-synchronous kernel of rounds 1 - 4, and then where a sample of the table
+ * says the search will use them) | MOVI_PREPARE_ZML (nothing: accepted for symmetry).  Honours the options set before it ("kmer_k", "ftab_k", "ahead_rows": a table the caller built or switched
  * off is left alone).  Waits for the builders; *derived_bytes (optional) = bytes of device memory the handle's derived tables
  * hold afterwards (movi_index_info "derived_bytes").  After it the *_device entry points of those queries allocate nothing
  * and build nothing on this handle (batches of long reads still grow the segment workspace on their first call): they can be
- * captured into a HIP graph without a warm-up call.  Not calling it is fine: the first query does the same, lazily. */
+ * captured into a HIP graph without a warm-up call -- a look-ahead copy that was declined for lack of device memory is asked for
+ * again by the next movi_index_prepare call only, never from inside a query.  Not calling it is fine: the first query does the
+ * same, lazily (and then retries a declined copy every 64 calls). */
 #define MOVI_PREPARE_PML 1u
 #define MOVI_PREPARE_COUNT 2u
 #define MOVI_PREPARE_ZML 4u
@@ -262,6 +268,43 @@ int movi_launch_log(char *buf, size_t cap, size_t *needed);
  * positions that reach their LF target without a fast-forward, tallied when the look-ahead rows are built: 0.83 on the
  * pangenome BWT, 0.51 on a uniformly random run sequence; -1 = not tallied yet).  Unknown key: MOVI_ERR_ARG. */
 int movi_index_info(const movi_index_t *ix, const char *key, double *value);
+
+/* ---- PML as reset masks (round 6) ----------------------------------------------- */
+
+/* What the PML path PRODUCES is one bit per base.  process_char either increments match_len or zeroes it
+ * (src/read_processor.cpp:193-215: match -> match_len + 1; mismatch + reposition or illegal character -> 0) and
+ * MoveQuery::add_ml (include/move_query.hpp:26-38) records min(match_len, 65535): PML[k] = reset(k) ? 0 : PML[k - 1] + 1,
+ * the run length since the last reset.  These entry points hand over the reset bits instead of the u16 vector -- 1/16 of
+ * the bytes over PCIe and into host memory -- and the two expanders turn them back into exactly the vector movi_pml_* write
+ * (u16 clamp included; MoveQuery::matching_lens is filled from them: INTEGRATION.md).
+ *
+ * Layout: 32-bit words.  Bit (k % 32) of word  W(i) + k / 32,  W(i) = ((first_base + offsets[i]) >> 5) - (first_base >> 5) + i,
+ * belongs to emission step k of read i (k = 0: the read's LAST base, as in movi_pml_device); 1 = its PML is 0.  Every read
+ * starts a word of its own and no prefix sum over the reads is needed (floor((o + l) / 32) + 1 >= floor(o / 32) + ceil(l / 32));
+ * bits of a read's last word beyond its length are 0; words between two reads' ranges ("gap words") are unspecified.
+ * first_base = position of this batch's first base in the caller's whole read set (0 for a stand-alone batch): consecutive
+ * sub-batches of one read set then write word for word what one call over the whole set would -- sub-batch (first read f, first
+ * base b) starts at word (b >> 5) + f of the whole.  movi_pml_mask_words: words the batch's array must hold.
+ * A read that hit one of the reference's throws (d_read_err) reports every base as a reset, i.e. all-zero PMLs.
+ * The default walk writes the words itself (one 4-byte store per 32 bases); batches it hands to another path -- long reads walked
+ * segment-parallel, tables of fewer than 8 rows, "stage_reads" 0 -- write their vector to device scratch of the handle (2 bytes per
+ * base, grow-only: those calls may allocate) and pack it.  Other arguments and conventions as movi_pml_device. */
+int movi_pml_mask_words(uint64_t n_reads, uint64_t n_bases, uint64_t first_base, uint64_t *n_words);
+int movi_pml_mask_device(movi_index_t *ix, const uint8_t *d_bases, const uint64_t *d_offsets,
+                         uint64_t n_reads, uint64_t n_bases, uint64_t first_base, uint32_t *d_mask_words,
+                         uint8_t *d_read_err, const uint32_t *d_read_order, void *stream);
+/* masks -> the u16 vector of movi_pml_device, on the device (streaming: 2 bytes written per base) */
+int movi_pml_expand_device(movi_index_t *ix, const uint32_t *d_mask_words, const uint64_t *d_offsets,
+                           uint64_t n_reads, uint64_t n_bases, uint64_t first_base, uint16_t *d_out_pml, void *stream);
+/* Host buffers in, masks out: h_mask_words holds movi_pml_mask_words(n_reads, offsets[n_reads] - offsets[0], 0) words, laid out
+ * with first_base = 0 relative to offsets[0].  Only 1/8 byte per base comes back over PCIe. */
+int movi_pml_mask_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_offsets,
+                       uint64_t n_reads, uint32_t *h_mask_words, uint8_t *h_read_err, movi_query_stats_t *stats);
+/* masks -> u16 vector on the HOST: pure CPU code (no device needed), n_threads worker threads (0 = as many as the process may
+ * run on, at most 32).  h_out_pml[offsets[i] + k] as movi_pml_host writes it; offsets need not start at 0 (the masks are laid out
+ * relative to offsets[0], as movi_pml_mask_host writes them). */
+int movi_pml_expand_host(const uint32_t *h_mask_words, const uint64_t *h_offsets, uint64_t n_reads,
+                         uint16_t *h_out_pml, int n_threads);
 
 /* ---- binary classification bins ------------------------------------------------ */
 
@@ -387,6 +430,11 @@ int movi_host_unregister(void *p);
  * there --, shorter ones fused; 1 = always fused, 0 = always two passes),
  * "zml_ahead" (1: the ZML parse walks on the look-ahead rows where they exist -- a third fewer iterations, no faster: off
  * by default),
+ * "pml_via_mask" (movi_pml_host: 1 = the walk writes reset masks, only they cross PCIe and the u16 vector is expanded into the
+ * caller's buffer by host threads (movi_pml_expand_host's code) while later chunks are walked; 0 = the vector itself comes down;
+ * -1, the default: masks for calls of 2^22 bases and more.  movi_pml_device: 1 = mask walk + pml_expand_kernel, 0 / -1 = the walk
+ * writes the vector itself (measured faster on the device: DESIGN.md)), "host_threads" (worker threads of the host-side
+ * expansion, 0 = as many as the process may run on, at most 32),
  * "ftab_k" (the count query's interval table -- the backward-search interval after the last K bases of a read by one lookup,
  * the reference's own ftab (src/move_structure_search.cpp:66-167) put to work for --count; left alone the first count query
  * on a DNA index builds the K = 12 table (256 MB); 0 = none, 1..12 = build that one now). */

@@ -89,6 +89,14 @@ SYMBOLS = {
                                   C.c_void_p, C.c_void_p, C.c_void_p]),
     "movi_pml_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                 C.POINTER(QueryStatsC)]),
+    "movi_pml_mask_words": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "movi_pml_mask_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]),
+    "movi_pml_expand_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p,
+                                         C.c_void_p]),
+    "movi_pml_mask_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
+                                     C.POINTER(QueryStatsC)]),
+    "movi_pml_expand_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]),
     "movi_pml_logs_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.POINTER(QueryStatsC)]),
     "movi_zml_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p,

@@ -4,6 +4,7 @@
 // query entry point fails with MOVI_ERR_NO_DEVICE / MOVI_ERR_HIP.
 #include "../../include/movi_hip.h"
 #include "movi_kernels.hpp"
+#include "movi_expand_host.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -33,6 +34,9 @@ int fail(int code, const std::string &msg) {
 }
 int fail_hip(hipError_t e, const char *what) {
     g_err = std::string(what) + ": " + hipGetErrorString(e) + " (hipError " + std::to_string((int)e) + ")";
+    // the failure is REPORTED here: the thread's sticky last-error is cleared so that a later launch on this thread (callers may
+    // tolerate this failure -- e.g. a staging reservation that did not fit) does not read it back as its own (hipGetLastError)
+    (void)hipGetLastError();
     return (e == hipErrorNoDevice || e == hipErrorInvalidDevice) ? MOVI_ERR_NO_DEVICE : MOVI_ERR_HIP;
 }
 #define HIP_TRY(expr)                                            \
@@ -102,6 +106,7 @@ struct movi_index {
     bool count_declined_ahead = false;   // the count query's auto-build found the copy not worth keeping (rows2_count == 0): do not build it per call
     int ahead_auto = 1;              // 1: the first PML query builds them when the device has room for them (ahead_wanted)
     int ahead_retry_in = 0;          // the copy was declined for lack of device memory: calls until the device is asked again (not every call)
+    bool prepared = false;           // movi_index_prepare has run: query calls build and allocate nothing any more (a declined copy is retried by movi_index_prepare only)
     uint4 *d_ftab = nullptr;         // the count query's interval table ("ftab_k" option), 16 << 2K bytes
     int ftab_auto = 12;              // K of the table the first count query builds by itself (0 = none)
     DevStats *d_stats = nullptr;
@@ -110,7 +115,7 @@ struct movi_index {
     LaunchCfg cfg;
     // device staging of the *_host entry points: grow-only, kept across calls (a hipMalloc / hipFree pair per call and
     // buffer cost more than the copies themselves); released by movi_index_destroy or movi_set_option("release_scratch")
-    enum { kBases = 0, kOffs, kErr, kOut, kA, kB, kS, kScratchSlots };
+    enum { kBases = 0, kOffs, kErr, kOut, kA, kB, kS, kMask, kTmp, kScratchSlots };   // (kMask: a chunk's reset-mask words; kTmp: the u16 vector of a mask call whose path has no mask output of its own)
     void *scratch[kScratchSlots] = {};
     size_t scratch_cap[kScratchSlots] = {};
     SegWorkspace seg_ws;             // segment-parallel long reads (launch_pml): device workspace of the handle's own calls
@@ -138,6 +143,8 @@ struct movi_index {
     bool host_autopin = true;        // big *_host calls on pageable buffers page-lock them for the call ("host_autopin")
     bool host_overlap = true;        // page-locked buffers take the overlapped path ("host_overlap" 0: one upload, the walk, one download)
     bool seg_seen = false;           // the last PML / ZML host call on long reads was walked segment-parallel (chunk policy below)
+    int pml_via_mask = -1;           // "pml_via_mask": movi_pml_host brings reset masks down and expands them on the host (-1: calls of >= 2^22 bases)
+    int host_threads = 0;            // "host_threads": workers of the host-side expansion (0 = host_threads_default())
 };
 
 static void release_scratch(movi_index *ix);
@@ -403,6 +410,11 @@ static movi_index *new_handle(int device, const movi_index_desc_t *desc) {
     }
     ix->desc.tally_ids = nullptr;
     ix->rows_bytes = (size_t)desc->r * mode_row_bytes(desc->mode);
+    // MOVI_PML_VIA_MASK = 0 / 1: the handle's initial "pml_via_mask" (the test suite re-runs its PML parity files with 1: every PML
+    // vector then comes from reset masks, expanded on the device or by the host's worker threads)
+    if (const char *e = getenv("MOVI_PML_VIA_MASK")) {
+        if (e[0] == '0' || e[0] == '1') ix->pml_via_mask = e[0] - '0';
+    }
     return ix;
 }
 
@@ -853,14 +865,17 @@ static int build_ftab_table(movi_index *ix, uint32_t K, hipStream_t s) {
 // The derived tables of the PML walk -- top-of-walk table (256 MB at K = 12, a few ms), look-ahead rows (16 B per row) --:
 // built by movi_index_prepare, or by the first PML query on the handle.  Nothing here fails the query: a table there is no room
 // for (or a device in trouble, which the walk's own launch will report) is done without.
-static void ensure_pml_tables(movi_index *ix, hipStream_t s) {
+static void ensure_pml_tables(movi_index *ix, hipStream_t s, bool from_prepare = false) {
     if (ix->kmer_auto > 0 && !ix->d_kmer && kmer_eligible(ix)) {
         if (build_kmer(ix, (uint32_t)ix->kmer_auto, s) != MOVI_OK) {
             (void)hipGetLastError();
             ix->kmer_auto = 0;
         }
     }
-    if (ix->ahead_auto > 0 && !ix->d_rows2 && ahead_eligible(ix)) {
+    // (after movi_index_prepare the header's promise holds: query calls allocate nothing and build nothing -- a copy that was declined
+    // for lack of memory is asked for again by the next explicit movi_index_prepare, never from inside a query, which may be under
+    // stream capture or in the middle of a streaming run)
+    if (ix->ahead_auto > 0 && !ix->d_rows2 && ahead_eligible(ix) && (from_prepare || !ix->prepared)) {
         // (declined for lack of memory: the device is asked again after 64 calls, not in every one -- hipMemGetInfo per chunk of
         // a streaming run -- and two processes sharing a GPU that both pass the check and then collide switch the auto-build off)
         if (ix->ahead_retry_in > 0) ix->ahead_retry_in -= 1;
@@ -1002,6 +1017,16 @@ int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
         ix->cfg.seg_verdict = (int)value;
         return MOVI_OK;
     }
+    if (!strcmp(key, "pml_via_mask")) {                      // movi_pml_host / movi_pml_device through reset masks (-1: the policy)
+        if (value < -1 || value > 1) return fail(MOVI_ERR_ARG, "pml_via_mask must be -1, 0 or 1");
+        ix->pml_via_mask = (int)value;
+        return MOVI_OK;
+    }
+    if (!strcmp(key, "host_threads")) {                      // workers of the host-side mask expansion (0 = as many as the process may run on)
+        if (value < 0 || value > 256) return fail(MOVI_ERR_ARG, "host_threads must be 0 .. 256");
+        ix->host_threads = (int)value;
+        return MOVI_OK;
+    }
     if (!strcmp(key, "host_autopin")) {                      // 0: pageable buffers always take the synchronous path (A/B)
         if (value != 0 && value != 1) return fail(MOVI_ERR_ARG, "host_autopin must be 0 or 1");
         ix->host_autopin = value != 0;
@@ -1069,10 +1094,13 @@ int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
 
 // ---------------------------------------------------------------------------- PML
 
+// mask (optional; PML only): reset masks out instead of the vector -- mask->words / phase from the caller; a path without a mask output
+// of its own writes its vector to *tmp_p first (grow-only device scratch: the handle's, or a pipeline slot's).
 static int ml_device(bool zml, movi_index_t *ix, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
                      uint64_t n_bases, uint16_t *d_out, uint8_t *d_read_err, const uint32_t *d_read_order, void *stream,
                      const ClsArgs &cls = ClsArgs(), DevStats *d_stats = nullptr, SegWorkspace *seg_ws = nullptr,
-                     int ragged_hint = -1, int *seg_verdict = nullptr) {
+                     int ragged_hint = -1, int *seg_verdict = nullptr, const MaskArgs *mask = nullptr, void **tmp_p = nullptr,
+                     size_t *tmp_cap = nullptr) {
     if (!ix) return fail(MOVI_ERR_ARG, "index handle is NULL");
     if (!d_stats) d_stats = ix->d_stats;                     // (the pipelined host path counts per chunk in flight ...
     if (!seg_ws) seg_ws = &ix->seg_ws;                       //  ... and keeps a segment workspace per chunk in flight)
@@ -1082,7 +1110,9 @@ static int ml_device(bool zml, movi_index_t *ix, const uint8_t *d_bases, const u
                                   "*-thresholds index");
     if (n_reads == 0) return MOVI_OK;
     const bool bins_only = cls.bin_width != 0 && !d_out;
-    if (!d_offsets || (n_bases && (!d_bases || (!d_out && !bins_only)))) return fail(MOVI_ERR_ARG, "NULL device buffer");
+    const bool masks = mask && mask->words;
+    if (masks && (zml || cls.bin_width != 0 || cls.log_ff)) return fail(MOVI_ERR_ARG, "reset masks: plain PML queries only");
+    if (!d_offsets || (n_bases && (!d_bases || (!d_out && !bins_only && !masks)))) return fail(MOVI_ERR_ARG, "NULL device buffer");
     HIP_TRY(hipSetDevice(ix->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     HIP_TRY(hipMemsetAsync(d_stats, 0, sizeof(DevStats), s));
@@ -1093,16 +1123,62 @@ static int ml_device(bool zml, movi_index_t *ix, const uint8_t *d_bases, const u
     if (zml)
         HIP_TRY(launch_zml(ix->kmode, ix->dev, d_bases, d_offsets, n_reads, n_bases, d_out, d_read_err, d_stats,
                            d_read_order, ix->cfg, s, seg_ws, ragged_hint, seg_verdict, &ix->last_launch));
-    else
+    else {
+        MaskArgs m;
+        if (masks) {
+            m = *mask;
+            if (pml_mask_needs_tmp(ix->dev, ix->cfg, n_reads, n_bases, seg_ws != nullptr)) {
+                if (!tmp_p) { tmp_p = &ix->scratch[movi_index::kTmp]; tmp_cap = &ix->scratch_cap[movi_index::kTmp]; }
+                HIP_TRY(grow(tmp_p, tmp_cap, n_bases * 2));
+                m.tmp_pml = static_cast<uint16_t *>(*tmp_p);
+            }
+        }
         HIP_TRY(launch_pml(ix->kmode, ix->dev, d_bases, d_offsets, n_reads, n_bases, d_out, d_read_err, d_stats,
-                           d_read_order, ix->cfg, s, cls, seg_ws, ragged_hint, seg_verdict, &ix->last_launch));
+                           d_read_order, ix->cfg, s, cls, seg_ws, ragged_hint, seg_verdict, &ix->last_launch, m));
+    }
     return MOVI_OK;
 }
 
 int movi_pml_device(movi_index_t *ix, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
                     uint64_t n_bases, uint16_t *d_out_pml, uint8_t *d_read_err, const uint32_t *d_read_order,
                     void *stream) {
+    if (ix && ix->pml_via_mask == 1 && n_reads && d_out_pml && mode_has_thresholds(ix->desc.mode)) {
+        // "pml_via_mask" 1: the walk writes reset masks (device scratch of the handle, grow-only), pml_expand_kernel the vector
+        HIP_TRY(hipSetDevice(ix->device));
+        HIP_TRY(grow(&ix->scratch[movi_index::kMask], &ix->scratch_cap[movi_index::kMask], (size_t)pml_mask_words(n_reads, n_bases, 0) * 4));
+        uint32_t *words = static_cast<uint32_t *>(ix->scratch[movi_index::kMask]);
+        if (int rc = movi_pml_mask_device(ix, d_bases, d_offsets, n_reads, n_bases, 0, words, d_read_err, d_read_order, stream)) return rc;
+        return movi_pml_expand_device(ix, words, d_offsets, n_reads, n_bases, 0, d_out_pml, stream);
+    }
     return ml_device(false, ix, d_bases, d_offsets, n_reads, n_bases, d_out_pml, d_read_err, d_read_order, stream);
+}
+
+int movi_pml_mask_words(uint64_t n_reads, uint64_t n_bases, uint64_t first_base, uint64_t *n_words) {
+    if (!n_words) return fail(MOVI_ERR_ARG, "n_words is NULL");
+    *n_words = pml_mask_words(n_reads, n_bases, (uint32_t)(first_base & 31u));
+    return MOVI_OK;
+}
+
+int movi_pml_mask_device(movi_index_t *ix, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
+                         uint64_t n_bases, uint64_t first_base, uint32_t *d_mask_words, uint8_t *d_read_err,
+                         const uint32_t *d_read_order, void *stream) {
+    if (n_reads && !d_mask_words) return fail(MOVI_ERR_ARG, "NULL device buffer");
+    MaskArgs m;
+    m.words = d_mask_words;
+    m.phase = (uint32_t)(first_base & 31u);
+    return ml_device(false, ix, d_bases, d_offsets, n_reads, n_bases, nullptr, d_read_err, d_read_order, stream, ClsArgs(), nullptr,
+                     nullptr, -1, nullptr, &m);
+}
+
+int movi_pml_expand_device(movi_index_t *ix, const uint32_t *d_mask_words, const uint64_t *d_offsets, uint64_t n_reads,
+                           uint64_t n_bases, uint64_t first_base, uint16_t *d_out_pml, void *stream) {
+    if (!ix) return fail(MOVI_ERR_ARG, "index handle is NULL");
+    if (n_reads == 0) return MOVI_OK;
+    if (!d_mask_words || !d_offsets || (n_bases && !d_out_pml)) return fail(MOVI_ERR_ARG, "NULL device buffer");
+    HIP_TRY(hipSetDevice(ix->device));
+    HIP_TRY(launch_pml_expand(d_mask_words, d_offsets, n_reads, n_bases, (uint32_t)(first_base & 31u), d_out_pml,
+                              static_cast<hipStream_t>(stream)));
+    return MOVI_OK;
 }
 
 int movi_zml_device(movi_index_t *ix, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
@@ -1221,6 +1297,7 @@ struct ChunkCtx {
     SegWorkspace *seg_ws = nullptr;
     int ragged_hint = -1;            // the chunk's longest read is (1) / is not (0) more than 1.5 x its mean: launch_pml's segment policy
     int *seg_verdict = nullptr;      // one probe per call: the first chunk's verdict serves the others (launch_pml_segmented)
+    uint64_t first = 0, b0 = 0;      // the chunk: its first read and the position of its first base in the caller's arrays
     bool async = false;
     hipError_t alloc(int slot, size_t bytes, void **out) {
         hipError_t e = grow(&d[slot], &cap[slot], bytes);
@@ -1324,12 +1401,12 @@ void add_stats(movi_query_stats_t *acc, uint64_t nb, const DevStats &h) {
 // One kind of query behind a *_host entry point:
 //   launch(ctx, d_bases, d_offs, nr, nb, d_err)  allocates the chunk's result staging from ctx and enqueues the kernel;
 //   fetch(ctx, first, nr, b0, nb)                enqueues the results' way back (ctx.down / ctx.down_small);
-//   harvest(h_small, first, nr)                  overlapped path only, after the chunk's stream has drained: per-read
+//   harvest(h_small, first, nr, group)           overlapped path only, after the chunk's stream has drained: per-read
 //                                                results from the page-locked block to the caller's arrays;
 //   small_bytes                                  page-locked bytes per read that fetch / harvest use.
 template <typename Launch, typename Fetch, typename Harvest>
 int run_chunked(movi_index *ix, const uint8_t *h_bases, const uint64_t *h_offsets, uint64_t n_reads,
-                uint8_t *h_read_err, movi_query_stats_t *stats, Launch launch, Fetch fetch, Harvest, size_t) {
+                uint8_t *h_read_err, movi_query_stats_t *stats, Launch launch, Fetch fetch, Harvest, size_t, size_t) {
     if (stats) memset(stats, 0, sizeof(*stats));
     int seg_verdict = -1;
     ChunkCtx ctx;
@@ -1380,6 +1457,8 @@ int run_chunked(movi_index *ix, const uint8_t *h_bases, const uint64_t *h_offset
         stamp(2);
         HIP_TRY(hipMemcpy(d_offs.p, rel, (nr + 1) * 8, hipMemcpyHostToDevice));
         stamp(3);
+        ctx.first = first;
+        ctx.b0 = b0;
         int rc = launch(ctx, static_cast<const uint8_t *>(d_bases.p), static_cast<const uint64_t *>(d_offs.p), nr, nb,
                         static_cast<uint8_t *>(d_err.p));
         if (rc) return rc;
@@ -1424,7 +1503,7 @@ int run_chunked(movi_index *ix, const uint8_t *h_bases, const uint64_t *h_offset
 template <typename Launch, typename Fetch, typename Harvest>
 int run_pipelined(movi_index *ix, const uint8_t *h_bases, const uint64_t *h_offsets, uint64_t n_reads,
                   uint8_t *h_read_err, movi_query_stats_t *stats, Launch launch, Fetch fetch, Harvest harvest,
-                  size_t small_bytes) {
+                  size_t small_bytes, size_t mask_word_bytes) {
     if (stats) memset(stats, 0, sizeof(*stats));
     movi_query_stats_t acc{};
     const uint64_t total = h_offsets[n_reads] - h_offsets[0];
@@ -1458,10 +1537,14 @@ int run_pipelined(movi_index *ix, const uint8_t *h_bases, const uint64_t *h_offs
     }
     constexpr int S = movi_index::kPipeSlots;
     struct InFlight { int stage = 0; Chunk c{}; } fl[S];       // 0 free, 1 walking (upload + kernel enqueued), 2 coming down
+    HostPool::Group grp[S];                                    // host-side work a slot's harvest has handed to the worker pool (it reads the slot's page-locked block)
     // layout of a slot's page-locked block
     auto off_err = [](uint64_t nr) { return (size_t)(nr + 1) * 8; };
     auto off_small = [&](uint64_t nr) { return (off_err(nr) + (size_t)nr + 15) & ~(size_t)15; };
-    auto off_stats = [&](uint64_t nr) { return (off_small(nr) + (size_t)nr * small_bytes + 15) & ~(size_t)15; };
+    // (mask_word_bytes = 4: the block also holds the chunk's reset-mask words, behind the per-read results)
+    auto off_stats = [&](uint64_t nr, uint64_t nb) {
+        return (off_small(nr) + (size_t)nr * small_bytes + (mask_word_bytes ? (size_t)pml_mask_words(nr, nb, 31u) * mask_word_bytes : 0) + 15) & ~(size_t)15;
+    };
     int seg_verdict = -1;
     auto ctx_of = [&](int k, uint64_t nr) {
         movi_index::PipeSlot &sl = ix->pipe[k];
@@ -1475,6 +1558,8 @@ int run_pipelined(movi_index *ix, const uint8_t *h_bases, const uint64_t *h_offs
         ctx.h_small = sl.h + off_small(nr);
         ctx.seg_ws = &sl.seg_ws;
         ctx.async = true;
+        ctx.first = fl[k].c.first;
+        ctx.b0 = fl[k].c.b0;
         return ctx;
     };
     // a chunk's stream has drained: counters, error bytes, per-read results
@@ -1485,22 +1570,23 @@ int run_pipelined(movi_index *ix, const uint8_t *h_bases, const uint64_t *h_offs
         f.stage = 0;
         HIP_TRY(hipStreamSynchronize(sl.s));
         DevStats h;
-        memcpy(&h, sl.h + off_stats(f.c.nr), sizeof(h));
+        memcpy(&h, sl.h + off_stats(f.c.nr, f.c.nb), sizeof(h));
         add_stats(&acc, f.c.nb, h);
         if (h_read_err) memcpy(h_read_err + f.c.first, sl.h + off_err(f.c.nr), f.c.nr);
-        harvest(sl.h + off_small(f.c.nr), f.c.first, f.c.nr);
+        harvest(sl.h + off_small(f.c.nr), f.c.first, f.c.nr, &grp[k]);
         return MOVI_OK;
     };
     // chunk c goes up into slot k and is walked
     auto up = [&](const Chunk &c, int k) -> int {
         movi_index::PipeSlot &sl = ix->pipe[k];
         if (int rc = finish(k)) return rc;
+        HostPool::get().wait(&grp[k]);                       // (the slot's block is about to be rewritten)
         if (!sl.s) HIP_TRY(hipStreamCreateWithFlags(&sl.s, hipStreamNonBlocking));
         if (!sl.ev) HIP_TRY(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
         if (!sl.ev_up) HIP_TRY(hipEventCreateWithFlags(&sl.ev_up, hipEventDisableTiming));
         if (!ix->pipe_up) HIP_TRY(hipStreamCreateWithFlags(&ix->pipe_up, hipStreamNonBlocking));
         if (!sl.d_stats) HIP_TRY(hipMalloc(&sl.d_stats, sizeof(DevStats)));
-        const size_t hb = off_stats(c.nr) + sizeof(DevStats);
+        const size_t hb = off_stats(c.nr, c.nb) + sizeof(DevStats);
         if (sl.h_cap < hb) {
             if (sl.h) (void)hipHostFree(sl.h);
             sl.h = nullptr;
@@ -1509,6 +1595,7 @@ int run_pipelined(movi_index *ix, const uint8_t *h_bases, const uint64_t *h_offs
             HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sl.h), want, hipHostMallocDefault));
             sl.h_cap = want;
         }
+        fl[k].c = c;
         ChunkCtx ctx = ctx_of(k, c.nr);
         struct { void *p; } d_bases{}, d_offs{}, d_err{};
         HIP_TRY(ctx.alloc(movi_index::kBases, c.nb, &d_bases.p));
@@ -1541,8 +1628,19 @@ int run_pipelined(movi_index *ix, const uint8_t *h_bases, const uint64_t *h_offs
         ChunkCtx ctx = ctx_of(k, c.nr);
         if (int rc = fetch(ctx, c.first, c.nr, c.b0, c.nb)) return rc;
         HIP_TRY(hipMemcpyAsync(sl.h + off_err(c.nr), sl.d[movi_index::kErr], c.nr, hipMemcpyDeviceToHost, sl.s));
-        HIP_TRY(hipMemcpyAsync(sl.h + off_stats(c.nr), sl.d_stats, sizeof(DevStats), hipMemcpyDeviceToHost, sl.s));
+        HIP_TRY(hipMemcpyAsync(sl.h + off_stats(c.nr, c.nb), sl.d_stats, sizeof(DevStats), hipMemcpyDeviceToHost, sl.s));
         fl[k].stage = 2;
+        return MOVI_OK;
+    };
+    // chunks that have arrived on the host are harvested as soon as the loop comes by, not when their slot is needed again:
+    // a harvest may have real work to hand on (the mask path's expansion runs on the host's worker threads beside the next walks)
+    auto finish_arrived = [&]() -> int {
+        for (int k = 0; k < S; k++) {
+            if (fl[k].stage != 2) continue;
+            const hipError_t q = hipStreamQuery(ix->pipe[k].s);
+            if (q == hipErrorNotReady) { (void)hipGetLastError(); continue; }
+            if (int rc = finish(k)) return rc;
+        }
         return MOVI_OK;
     };
     // kPipeAhead chunks going up or being walked (their kernels share the GPU: the lanes in flight are the sum of
@@ -1555,8 +1653,10 @@ int run_pipelined(movi_index *ix, const uint8_t *h_bases, const uint64_t *h_offs
     for (size_t i = 0; i < n && rc == MOVI_OK; i++) {
         for (; next_up < n && next_up < i + (size_t)movi_index::kPipeAhead && rc == MOVI_OK; next_up++) rc = up(chunks[next_up], (int)(next_up % S));
         if (rc == MOVI_OK) rc = down((int)(i % S));
+        if (rc == MOVI_OK) rc = finish_arrived();
     }
     for (size_t j = 0; j < (size_t)S && rc == MOVI_OK; j++) rc = finish((int)((n + j) % S));   // oldest first
+    for (int k = 0; k < S; k++) HostPool::get().wait(&grp[k]);                                 // (also on errors: the workers write caller memory)
     if (rc != MOVI_OK) {
         // whatever happened, nothing may still be reading or writing the caller's buffers when the call returns
         const std::string keep = g_err;
@@ -1582,11 +1682,11 @@ bool worth_overlapping_small_results(const uint64_t *h_offsets, uint64_t n_reads
 template <typename Launch, typename Fetch, typename Harvest>
 int run_host(bool overlapped, movi_index *ix, const uint8_t *h_bases, const uint64_t *h_offsets, uint64_t n_reads,
              uint8_t *h_read_err, movi_query_stats_t *stats, Launch launch, Fetch fetch, Harvest harvest,
-             size_t small_bytes) {
+             size_t small_bytes, size_t mask_word_bytes = 0) {
     movi_query_stats_t local{};
     overlapped = overlapped && ix->host_overlap;
-    int rc = overlapped ? run_pipelined(ix, h_bases, h_offsets, n_reads, h_read_err, &local, launch, fetch, harvest, small_bytes)
-                        : run_chunked(ix, h_bases, h_offsets, n_reads, h_read_err, &local, launch, fetch, harvest, small_bytes);
+    int rc = overlapped ? run_pipelined(ix, h_bases, h_offsets, n_reads, h_read_err, &local, launch, fetch, harvest, small_bytes, mask_word_bytes)
+                        : run_chunked(ix, h_bases, h_offsets, n_reads, h_read_err, &local, launch, fetch, harvest, small_bytes, mask_word_bytes);
     if (stats) *stats = local;
     if (rc) return rc;
     if (local.errors)
@@ -1653,8 +1753,11 @@ static bool autopin_worthwhile(const movi_index *ix, const uint64_t *h_offsets, 
     return ix->host_autopin && ix->host_overlap && h_offsets[n_reads] - h_offsets[0] >= (1ull << 27) && n_reads >= 3 * kPipeMinReads;
 }
 
+// h_mask_words != NULL: the reset masks themselves are the result (movi_pml_mask_host).  Otherwise, PML with "pml_via_mask": the
+// walk writes masks, only they cross PCIe (1/8 byte per base instead of 2) and the u16 vector is expanded into the caller's buffer
+// by the host's worker threads (movi_expand_host.cpp) -- in the overlapped path beside the walks of the chunks that follow.
 static int ml_host(bool zml, movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_offsets, uint64_t n_reads,
-                  uint16_t *h_out_pml, uint8_t *h_read_err, movi_query_stats_t *stats) {
+                  uint16_t *h_out_pml, uint8_t *h_read_err, movi_query_stats_t *stats, uint32_t *h_mask_words = nullptr) {
     if (!ix) return fail(MOVI_ERR_ARG, "index handle is NULL");
     if (n_reads == 0) { if (stats) memset(stats, 0, sizeof(*stats)); return MOVI_OK; }
     // h_out_pml == NULL: the walk runs, error bytes and counters come back, the vectors stay on the device and are dropped
@@ -1662,30 +1765,92 @@ static int ml_host(bool zml, movi_index_t *ix, const uint8_t *h_bases, const uin
     if (!h_offsets || (h_offsets[n_reads] != h_offsets[0] && !h_bases)) return fail(MOVI_ERR_ARG, "NULL host buffer");
     if (int rc0 = check_offsets(h_offsets, n_reads)) return rc0;
     HIP_TRY(hipSetDevice(ix->device));
+    const uint64_t o0 = h_offsets[0], span = h_offsets[n_reads] - o0;
+    const bool via_mask = !zml && (h_mask_words != nullptr ||
+                                   (h_out_pml != nullptr && (ix->pml_via_mask > 0 || (ix->pml_via_mask < 0 && span >= (1ull << 22)))));
+    const int threads = ix->host_threads > 0 ? ix->host_threads : host_threads_default();
     struct { void *p; } d_out{};
+    auto phase_of = [&](uint64_t b0) { return (uint32_t)((b0 - o0) & 31u); };
     auto launch = [&](ChunkCtx &c, const uint8_t *db, const uint64_t *dof, uint64_t nr, uint64_t nb, uint8_t *derr) -> int {
+        if (via_mask) {
+            MaskArgs m;
+            m.phase = phase_of(c.b0);
+            HIP_TRY(c.alloc(movi_index::kMask, (size_t)pml_mask_words(nr, nb, m.phase) * 4, &d_out.p));
+            m.words = static_cast<uint32_t *>(d_out.p);
+            return ml_device(false, ix, db, dof, nr, nb, nullptr, derr, nullptr, c.s, ClsArgs(), c.d_stats, c.seg_ws, c.ragged_hint,
+                             c.seg_verdict, &m, &c.d[movi_index::kTmp], &c.cap[movi_index::kTmp]);
+        }
         HIP_TRY(c.alloc(movi_index::kOut, nb * 2, &d_out.p));
         return ml_device(zml, ix, db, dof, nr, nb, static_cast<uint16_t *>(d_out.p), derr, nullptr, c.s, ClsArgs(), c.d_stats,
                          c.seg_ws, c.ragged_hint, c.seg_verdict);
     };
+    // what a chunk's masks are to the host: the words land in `words`; they are the result, or the vector is expanded from them
+    auto deliver = [&](const uint32_t *words, uint64_t first, uint64_t nr, HostPool::Group *g) {
+        const uint64_t b0 = h_offsets[first], nb = h_offsets[first + nr] - b0;
+        const uint32_t ph = phase_of(b0);
+        if (h_mask_words) memcpy(h_mask_words + ((b0 - o0) >> 5) + first, words, (size_t)(((nb + ph) >> 5) + nr) * 4);
+        if (h_out_pml) {
+            ExpandJob j;
+            j.words = words; j.offs = h_offsets; j.o0 = b0; j.phase = ph; j.ibase = first; j.i0 = first; j.i1 = first + nr;
+            j.out = h_out_pml;
+            expand_parallel(j, threads, g);
+        }
+    };
     // (the results are found through the chunk's own staging: with chunks in flight, launch() of the next chunk has
     // run before fetch() of this one)
-    auto fetch = [&](ChunkCtx &c, uint64_t, uint64_t, uint64_t b0, uint64_t nb) -> int {
+    std::vector<uint32_t> sync_words;                        // synchronous path: a chunk's words on their way through the host
+    auto fetch = [&](ChunkCtx &c, uint64_t first, uint64_t nr, uint64_t b0, uint64_t nb) -> int {
+        if (via_mask) {
+            const size_t nw = (size_t)(((nb + phase_of(b0)) >> 5) + nr);
+            if (c.async) {                                    // into the slot's page-locked block; harvest() takes it from there
+                HIP_TRY(c.down_small(nullptr, 0, c.d[movi_index::kMask], nw * 4));
+                return MOVI_OK;
+            }
+            if (h_mask_words && !h_out_pml) {                 // straight to where they belong
+                HIP_TRY(hipMemcpy(h_mask_words + ((b0 - o0) >> 5) + first, c.d[movi_index::kMask], nw * 4, hipMemcpyDeviceToHost));
+                return MOVI_OK;
+            }
+            sync_words.resize(nw);
+            HIP_TRY(hipMemcpy(sync_words.data(), c.d[movi_index::kMask], nw * 4, hipMemcpyDeviceToHost));
+            deliver(sync_words.data(), first, nr, nullptr);
+            return MOVI_OK;
+        }
         if (h_out_pml) HIP_TRY(c.down(h_out_pml + b0, c.d[movi_index::kOut], nb * 2));
         return MOVI_OK;
     };
-    auto harvest = [](const uint8_t *, uint64_t, uint64_t) {};
-    bool overlapped = h_offsets[n_reads] != h_offsets[0] && is_pinned(h_bases) && (!h_out_pml || is_pinned(h_out_pml));
+    auto harvest = [&](const uint8_t *h_small, uint64_t first, uint64_t nr, HostPool::Group *g) {
+        if (via_mask) deliver(reinterpret_cast<const uint32_t *>(h_small), first, nr, g);
+    };
+    // masks: only the reads have to be page-locked for the overlapped path (the vector is written by host threads)
+    bool overlapped = span != 0 && is_pinned(h_bases) && (via_mask || !h_out_pml || is_pinned(h_out_pml));
     // A big call on PAGEABLE buffers (what a std::vector-holding caller passes: INTEGRATION.md's stub): page-lock them for the
     // duration of the call and take the overlapped path.  Registering touched memory runs at hundreds of GB/s (DESIGN.md section
     // 5), so on >= 2^27 bases it is paid back several times over (the synchronous path: 12.4 Gbases/s PCIe-inclusive).
     // "host_autopin" 0 turns it off; anything that fails here falls back to the synchronous path.
-    const uint64_t span = h_offsets[n_reads] - h_offsets[0];
     AutoPin pin_bases, pin_out;
     if (!overlapped && autopin_worthwhile(ix, h_offsets, n_reads))
         overlapped = pin_bases.pin(const_cast<uint8_t *>(h_bases) + h_offsets[0], span) &&
-                     (!h_out_pml || pin_out.pin(h_out_pml + h_offsets[0], span * 2));
-    return run_host(overlapped, ix, h_bases, h_offsets, n_reads, h_read_err, stats, launch, fetch, harvest, 0);
+                     (via_mask || !h_out_pml || pin_out.pin(h_out_pml + h_offsets[0], span * 2));
+    return run_host(overlapped, ix, h_bases, h_offsets, n_reads, h_read_err, stats, launch, fetch, harvest, 0, via_mask ? 4 : 0);
+}
+
+int movi_pml_mask_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_offsets, uint64_t n_reads,
+                       uint32_t *h_mask_words, uint8_t *h_read_err, movi_query_stats_t *stats) {
+    if (n_reads && !h_mask_words) return fail(MOVI_ERR_ARG, "NULL host buffer");
+    return ml_host(false, ix, h_bases, h_offsets, n_reads, nullptr, h_read_err, stats, h_mask_words);
+}
+
+// Pure host code: no device is touched.
+int movi_pml_expand_host(const uint32_t *h_mask_words, const uint64_t *h_offsets, uint64_t n_reads, uint16_t *h_out_pml,
+                         int n_threads) {
+    if (n_reads == 0) return MOVI_OK;
+    if (!h_mask_words || !h_offsets || (h_offsets[n_reads] != h_offsets[0] && !h_out_pml)) return fail(MOVI_ERR_ARG, "NULL host buffer");
+    if (int rc0 = check_offsets(h_offsets, n_reads)) return rc0;
+    ExpandJob j;
+    j.words = h_mask_words; j.offs = h_offsets; j.o0 = h_offsets[0]; j.phase = 0; j.ibase = 0; j.i0 = 0; j.i1 = n_reads;
+    j.out = h_out_pml;
+    expand_parallel(j, n_threads, nullptr);
+    return MOVI_OK;
 }
 
 int movi_pml_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_offsets, uint64_t n_reads,
@@ -1722,7 +1887,7 @@ int movi_pml_logs_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t 
         HIP_TRY(c.down(h_scans + b0, c.d[movi_index::kS], nb * 2));
         return MOVI_OK;
     };
-    auto harvest = [](const uint8_t *, uint64_t, uint64_t) {};
+    auto harvest = [](const uint8_t *, uint64_t, uint64_t, HostPool::Group *) {};
     return run_host(false, ix, h_bases, h_offsets, n_reads, h_read_err, stats, launch, fetch, harvest, 0);
 }
 
@@ -1818,7 +1983,7 @@ int movi_pml_classify_host(movi_index_t *ix, const uint8_t *h_bases, const uint6
         HIP_TRY(c.down_small(h_bins_below + first, nr * 12, c.d[movi_index::kB], nr * 4));
         return MOVI_OK;
     };
-    auto harvest = [&](const uint8_t *h, uint64_t first, uint64_t nr) {
+    auto harvest = [&](const uint8_t *h, uint64_t first, uint64_t nr, HostPool::Group *) {
         memcpy(h_sum_max + first, h, nr * 8);
         memcpy(h_bins_above + first, h + nr * 8, nr * 4);
         memcpy(h_bins_below + first, h + nr * 12, nr * 4);
@@ -1849,7 +2014,7 @@ static int ensure_ckpt(movi_index *ix, hipStream_t s) {
 
 // The derived tables of the count query -- row-start checkpoints, interval table, and the look-ahead rows where the table's own
 // statistic says the search will use them --: built by movi_index_prepare, or by the first count query on the handle.
-static int ensure_count_tables(movi_index *ix, hipStream_t s) {
+static int ensure_count_tables(movi_index *ix, hipStream_t s, bool from_prepare = false) {
     int rc = ensure_ckpt(ix, s);
     if (rc) return rc;
     if (ix->ftab_auto > 0 && !ix->d_ftab && ftab_eligible(ix)) {       // the interval table (256 MB at K = 12)
@@ -1857,7 +2022,8 @@ static int ensure_count_tables(movi_index *ix, hipStream_t s) {
     }
     // (round 5: the count query's default is the lane state machine on the PLAIN rows, launch_count; the look-ahead copy serves
     // count_kernel_v0 only, i.e. "count_variant" 0)
-    if (ix->cfg.count_variant == 0 && ix->ahead_auto > 0 && !ix->d_rows2 && !ix->count_declined_ahead && ahead_eligible(ix)) {
+    if (ix->cfg.count_variant == 0 && ix->ahead_auto > 0 && !ix->d_rows2 && !ix->count_declined_ahead && ahead_eligible(ix) &&
+        (from_prepare || !ix->prepared)) {
         // sampled first, so that a table that will not use the copy is not copied (16 B per row) to find out.  Only the table's
         // statistic declines for good; a device short of memory is asked again later (ahead_retry_in).
         sample_no_ff(ix, s);
@@ -1912,16 +2078,17 @@ int movi_index_prepare(movi_index_t *ix, uint32_t what, void *stream, uint64_t *
     hipStream_t s = static_cast<hipStream_t>(stream);
     ix->ahead_retry_in = 0;                                           // an explicit call asks the device now
     if ((what & MOVI_PREPARE_PML) && mode_has_thresholds(ix->desc.mode)) {
-        ensure_pml_tables(ix, s);
+        ensure_pml_tables(ix, s, true);
         // the walk kernels live in translation units of their own: their code objects are loaded here, not by the first walk
         (void)(ix->dev.idx32 ? preload_walk_u32() : preload_walk_u64());
         (void)(ix->dev.idx32 ? preload_walkseg_u32() : preload_walkseg_u64());
         (void)hipGetLastError();
     }
     if (what & MOVI_PREPARE_COUNT) {
-        const int rc = ensure_count_tables(ix, s);
+        const int rc = ensure_count_tables(ix, s, true);
         if (rc) return rc;
     }
+    ix->prepared = true;
     // (MOVI_PREPARE_ZML: the parse walks on the plain rows and derives nothing -- accepted so that callers need not know)
     HIP_TRY(hipStreamSynchronize(s));
     if (derived_bytes) {
@@ -1953,7 +2120,7 @@ int movi_count_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_
         HIP_TRY(c.down_small(h_count + first, nr * 8, c.d[movi_index::kS], nr * 8));
         return MOVI_OK;
     };
-    auto harvest = [&](const uint8_t *h, uint64_t first, uint64_t nr) {
+    auto harvest = [&](const uint8_t *h, uint64_t first, uint64_t nr, HostPool::Group *) {
         memcpy(h_matched + first, h, nr * 8);
         memcpy(h_count + first, h + nr * 8, nr * 8);
     };

@@ -844,18 +844,20 @@ size_t take_launch_log(char *buf, size_t cap) {
     return all.size();
 }
 
-hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets,
-                      uint64_t n_reads, uint64_t n_bases, uint16_t *d_out, uint8_t *d_err, DevStats *d_stats,
-                      const uint32_t *d_order, const LaunchCfg &cfg, hipStream_t stream, const ClsArgs &cls,
-                      SegWorkspace *seg_ws, int ragged_hint, int *seg_verdict, LaunchInfo *info) {
-    if (n_reads == 0) return hipSuccess;
-    // 0 = PML vector only, 1 = vector + classification bins, 2 = bins only
-    const int cm = cls.bin_width == 0 ? 0 : (d_out ? 1 : 2);
-    if (cm == 0 && !d_out) return hipErrorInvalidValue;
-    if (cm != 0 && (!cls.above || !cls.below || !cls.sum_max)) return hipErrorInvalidValue;
-    // One resident row layout: blocked- and sampled-thresholds tables are expanded to regular-thresholds rows at upload
-    // (expand_blocked_kernel / expand_sampled_kernel), so the query kernels exist for MODE 6 only.
-    if (mode != 6) return hipErrorInvalidValue;
+// The launch policy of one PML call, apart from the segment plan's own decisions (launch_pml_segmented): which kernel, which block,
+// how much dynamic LDS and what it holds.  launch_pml acts on it; pml_mask_needs_tmp asks it whether the reset-mask output can
+// come straight from the walk.
+namespace {
+struct PmlPlan {
+    int v = 14, bt = 64, wpc = 0;
+    bool seg_eligible = false;       // a batch of long reads: the segment plan gets the first say (it may decline)
+    size_t dyn_lds = 0;
+    uint32_t stage_lds = 0;
+    bool use_ring = false, use_ahead = false, use_pair = false;
+};
+PmlPlan plan_pml(const DevIndex &ix, const LaunchCfg &cfg, uint64_t n_reads, uint64_t n_bases, int cm, bool logging, bool have_seg_ws,
+                 bool ordered, bool want_mask) {
+    PmlPlan P;
     // Variants: 0 first correct kernel (serves --logs), 1 base-synchronous packed I/O (tables of fewer than 8 rows, batches of
     // fewer than 16 bases; A/B), 14 = the lane state machine over row windows (pml_kernel_flatp, movi_walk.hpp; the default).
     // (2-13 were experiments -- branchy / row-at-a-time state machines, 2/4-row neighbour windows, the unpipelined window
@@ -869,7 +871,6 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     // get): pangenome 14 M rows 43.2 / 48.2 / 46.4; random tables of 10 M rows 40.0 / 47.5 / 43.6, 60 M 35.7 / 40.8 /
     // 36.3, 250 M (2 GB) 29.1 / 32.8 / 29.2, 500 M 27.9 / 30.3 / 27.7, 1 B (8 GB) 27.4 / 27.7 / 28.3.
     int v = cfg.pml_variant;
-    const bool logging = cls.log_ff != nullptr || cls.log_scan != nullptr;
     // (batches of up to ~18 waves per CU run in ONE round, uncapped: with the cap, 224 k reads = 13.7 waves per CU run as
     // a full round of 9 and a half-empty one -- 38.3 against 39.2 Gbases/s; 300 k reads: 38.2 against 41.2; from 400 k
     // reads on the cap wins: 43.9 against 41.7.  profiles/r02_occupancy_cap_sweeps.txt)
@@ -878,22 +879,15 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     if (v == 14 && (ix.r < 8 || n_bases < 16)) v = 1;                        // the clamped window needs >= 4 rows (r >= 8: two windows), the
                                                                              // 16-base fetches >= 16 bytes of bases
     if (cm != 0 && v == 0) v = 1;                                            // the first kernel carries no fused bins
-    if (logging) {                                                           // per-base logs: the first kernel keeps them
-        if (cm != 0) return hipErrorInvalidValue;
-        v = 0;
-    }
+    if (logging) v = 0;                                                      // per-base logs: the first kernel keeps them
+    P.v = v;
     // Batches of long reads: segment-parallel (plain PML through the default kernel only).  One lane per read leaves the
     // GPU short of walks -- 100 k reads are 6 wavefronts per CU, and a single 1 Mbp read holds its lane for 2 s --;
     // cut into segments the same batch fills it like a batch of short reads.
-    if (seg_ws && !logging && cfg.seg_len >= 32 && !d_order && v == 14 && cfg.block_threads <= 64 &&
-        n_bases / n_reads >= 2ull * (uint64_t)cfg.seg_len && n_reads + n_bases / (uint64_t)cfg.seg_len < 0x7FFFFFF0ull) {
-        bool declined = false;
-        const hipError_t es = launch_pml_segmented(ix, d_bases, d_offsets, n_reads, n_bases, d_out, d_err, d_stats, cfg, stream,
-                                                   seg_ws, cfg.pml_variant < 0 || cfg.pml_variant == 14, ragged_hint, &declined, cls,
-                                                   seg_verdict, info);
-        if (es != hipSuccess || !declined) return es;
-    }
+    P.seg_eligible = have_seg_ws && !logging && cfg.seg_len >= 32 && !ordered && v == 14 && cfg.block_threads <= 64 &&
+                     n_bases / n_reads >= 2ull * (uint64_t)cfg.seg_len && n_reads + n_bases / (uint64_t)cfg.seg_len < 0x7FFFFFF0ull;
     const int bt = cfg.block_threads > 0 ? cfg.block_threads : 64;           // one wavefront per block: finest dispatch grain
+    P.bt = bt;
     const uint64_t blocks = (n_reads + bt - 1) / bt;
     int wpc = cfg.waves_per_cu;
     if (wpc < 0) wpc = 0;
@@ -901,8 +895,7 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     const bool ahead_ok = stage_ok && ix.rows2 != nullptr;                              // ... on the look-ahead rows where they exist
     if (cfg.waves_per_cu == 0 && v == 14 && big_batch)
         wpc = ahead_ok ? kCapWavesAhead : kCapWaves;                                 // the auto policy above
-    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    dim3 grid((unsigned)blocks), block((unsigned)bt);
+    P.wpc = wpc;
     // Occupancy cap: enforced by the dispatcher through the block's LDS allocation (160 KiB per CU); blocks beyond
     // the cap queue and start as resident ones retire.
     size_t dyn_lds = 0;
@@ -916,11 +909,10 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     // wavefronts per CU, 16 KiB = 256 at 9); an uncapped one (a batch of at most ~18 wavefronts per CU, one round) gets what
     // its wavefronts per CU leave of the 160 KiB, so that the round stays one round.  Long reads roll through the same
     // stretch (stage_from in the kernel).  cfg.stage_reads: 1 = whenever it fits (default), 0 = never.
-    DevIndex ixl = ix;
     // PMLs out through a ring in LDS (the kernel has the numbers): launches of long reads -- few wavefronts, each
     // one's own instruction stream most of an iteration -- where the block's LDS holds the ring beside 96 staged bases.
-    // cfg.out_ring: -1 = this policy, 0 / 1 = never / wherever it fits (A/B).
-    const bool ring_wanted = stage_ok && (cfg.out_ring > 0 || (cfg.out_ring < 0 && n_bases / n_reads >= kOutRingReadLen));
+    // cfg.out_ring: -1 = this policy, 0 / 1 = never / wherever it fits (A/B).  (Reset masks out: no PML leaves, no ring.)
+    const bool ring_wanted = stage_ok && !want_mask && (cfg.out_ring > 0 || (cfg.out_ring < 0 && n_bases / n_reads >= kOutRingReadLen));
     if (stage_ok && wpc == 0) {
         const uint64_t wn = (blocks + (uint64_t)cfg.num_cus - 1) / (uint64_t)cfg.num_cus;      // wavefronts per CU of this launch
         // (room for a quarter more: the dispatcher does not deal the blocks out evenly, and a CU that may hold no more than the
@@ -930,27 +922,75 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     }
     const size_t ring_b = (ring_wanted && dyn_lds >= kOutRingBytes + 96u * 64u) ? kOutRingBytes : 0;
     const uint32_t stage_cap = (uint32_t)std::min<size_t>(1024, ((dyn_lds - ring_b) / 64) & ~(size_t)15);
-    ixl.stage_lds = (stage_ok && stage_cap >= 96) ? stage_cap : 0u;
-    const bool use_ring = ring_b != 0 && ixl.stage_lds != 0u;
-    ixl.inwin = cfg.inwin ? 1u : 0u;
-    ixl.hint_w = (cfg.hints != 0 && ix.hints != 0u && ix.rows2 != nullptr) ? 3u : 0u;
-    const bool use_ahead = ahead_ok && ixl.stage_lds != 0u;
+    P.dyn_lds = dyn_lds;
+    P.stage_lds = (stage_ok && stage_cap >= 96) ? stage_cap : 0u;
+    P.use_ring = ring_b != 0 && P.stage_lds != 0u;
+    P.use_ahead = ahead_ok && P.stage_lds != 0u;
     // pair-shared gathers (pml_kernel_flatp<..., PSH = 1>): the staged default walk on the plain or the look-ahead rows
     // Where: on tables beyond the reach of the per-CU TLBs (~2 GB), where a lane's two (four) 16-byte loads are as many
     // translation requests and the L2 TLB's request rate bounds the walk -- real BWT of 226 M rows on the look-ahead rows (3.6 GB
     // copy) 39.4 -> 50.8 Gbases/s, the random 1 B-row table 32.6 -> 34.7 on its plain rows and 21.4 -> 44.2 on the look-ahead
     // copy (16 GB); below that the exchange costs about what the merged accesses give (random 25 / 50 / 100 M rows +4 / +5 / -2 %,
     // real 113 M rows +1.5 %, c2 -2.5 %, c3 -9 %: profiles/r04_pair_shared_gathers.txt).  "pair_loads" 1 / 0 forces it.
-    const uint64_t walked_bytes = ix.r * (use_ahead ? 16ull : 8ull);
-    const bool use_pair = (cfg.pair_loads > 0 || (cfg.pair_loads < 0 && walked_bytes >= kPairLoadBytes)) && ixl.stage_lds != 0u && v == 14;
+    const uint64_t walked_bytes = ix.r * (P.use_ahead ? 16ull : 8ull);
+    P.use_pair = (cfg.pair_loads > 0 || (cfg.pair_loads < 0 && walked_bytes >= kPairLoadBytes)) && P.stage_lds != 0u && v == 14;
+    return P;
+}
+}  // namespace
+
+bool pml_mask_needs_tmp(const DevIndex &ix, const LaunchCfg &cfg, uint64_t n_reads, uint64_t n_bases, bool have_seg_ws) {
+    if (n_reads == 0) return false;
+    const PmlPlan P = plan_pml(ix, cfg, n_reads, n_bases, 0, false, have_seg_ws, false, true);
+    return P.seg_eligible || P.v != 14 || P.stage_lds == 0u;
+}
+
+hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets,
+                      uint64_t n_reads, uint64_t n_bases, uint16_t *d_out, uint8_t *d_err, DevStats *d_stats,
+                      const uint32_t *d_order, const LaunchCfg &cfg, hipStream_t stream, const ClsArgs &cls,
+                      SegWorkspace *seg_ws, int ragged_hint, int *seg_verdict, LaunchInfo *info, const MaskArgs &mask) {
+    if (n_reads == 0) return hipSuccess;
+    // 0 = PML vector only, 1 = vector + classification bins, 2 = bins only
+    const bool want_mask = mask.words != nullptr;          // reset masks out instead of the vector (MaskArgs)
+    if (want_mask) d_out = mask.tmp_pml;                   // (the paths without a mask output of their own write here first)
+    const int cm = cls.bin_width == 0 ? 0 : (d_out ? 1 : 2);
+    if (cm == 0 && !d_out && !want_mask) return hipErrorInvalidValue;
+    if (cm != 0 && (!cls.above || !cls.below || !cls.sum_max || want_mask)) return hipErrorInvalidValue;
+    // One resident row layout: blocked- and sampled-thresholds tables are expanded to regular-thresholds rows at upload
+    // (expand_blocked_kernel / expand_sampled_kernel), so the query kernels exist for MODE 6 only.
+    if (mode != 6) return hipErrorInvalidValue;
+    const bool logging = cls.log_ff != nullptr || cls.log_scan != nullptr;
+    if (logging && (cm != 0 || want_mask)) return hipErrorInvalidValue;
+    const PmlPlan P = plan_pml(ix, cfg, n_reads, n_bases, cm, logging, seg_ws != nullptr, d_order != nullptr, want_mask);
+    const int v = P.v;
+    if (P.seg_eligible && (!want_mask || d_out)) {
+        bool declined = false;
+        const hipError_t es = launch_pml_segmented(ix, d_bases, d_offsets, n_reads, n_bases, d_out, d_err, d_stats, cfg, stream,
+                                                   seg_ws, cfg.pml_variant < 0 || cfg.pml_variant == 14, ragged_hint, &declined, cls,
+                                                   seg_verdict, info);
+        if (es != hipSuccess) return es;
+        if (!declined) return want_mask ? launch_pml_to_mask(d_out, d_offsets, n_reads, n_bases, mask.phase, mask.words, stream) : hipSuccess;
+    }
+    const int bt = P.bt;
+    const uint64_t blocks = (n_reads + bt - 1) / bt;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    dim3 grid((unsigned)blocks), block((unsigned)bt);
+    size_t dyn_lds = P.dyn_lds;
+    DevIndex ixl = ix;
+    ixl.stage_lds = P.stage_lds;
+    ixl.inwin = cfg.inwin ? 1u : 0u;
+    ixl.hint_w = (cfg.hints != 0 && ix.hints != 0u && ix.rows2 != nullptr) ? 3u : 0u;
+    ixl.mask_phase = mask.phase & 31u;
+    const bool mask_native = want_mask && v == 14 && P.stage_lds != 0u;
+    if (want_mask && !mask_native && !d_out) return hipErrorInvalidValue;     // (pml_mask_needs_tmp told the caller)
     hipError_t e = hipSuccess;
     if (v == 14) {
         WalkLaunch L;
         L.grid = grid; L.block = block; L.dyn_lds = dyn_lds; L.stream = stream;
-        L.ix = ixl; L.bases = d_bases; L.offs = d_offsets; L.n = n_reads; L.out = d_out; L.err = d_err; L.stats = d_stats;
+        L.ix = ixl; L.bases = d_bases; L.offs = d_offsets; L.n = n_reads; L.out = mask_native ? reinterpret_cast<uint16_t *>(mask.words) : d_out;
+        L.err = d_err; L.stats = d_stats;
         L.order = d_order; L.cls = cls;
         L.cls_mode = cm; L.sep = ix.sep ? 1 : 0; L.stg = ixl.stage_lds != 0u ? 1 : 0;
-        L.ahd = use_ahead ? 1 : 0; L.psh = use_pair ? 1 : 0; L.ring = use_ring ? 1 : 0;
+        L.ahd = P.use_ahead ? 1 : 0; L.psh = P.use_pair ? 1 : 0; L.ring = mask_native ? 2 : (P.use_ring ? 1 : 0);
         e = ix.idx32 ? launch_walk_u32(L, info) : launch_walk_u64(L, info);
     } else {
         // the base-synchronous kernels (every one takes at most 64 KiB of dynamic LDS: the cap's padding)
@@ -966,10 +1006,11 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     }
     if (info) {
         info->variant = v;
-        info->block_threads = bt; info->waves_per_cu = wpc; info->segmented = 0; info->idx64 = ix.idx32 ? 0 : 1;
+        info->block_threads = bt; info->waves_per_cu = P.wpc; info->segmented = 0; info->idx64 = ix.idx32 ? 0 : 1;
         info->staged = (int)ixl.stage_lds;
-        info->ahead = use_ahead ? 1 : 0;
+        info->ahead = P.use_ahead ? 1 : 0;
     }
+    if (e == hipSuccess && want_mask && !mask_native) e = launch_pml_to_mask(d_out, d_offsets, n_reads, n_bases, mask.phase, mask.words, stream);
     return e;
 }
 
@@ -2504,6 +2545,156 @@ hipError_t launch_classify(const uint16_t *d_pml, const uint64_t *d_offsets, uin
                        thr, d_above, d_below, d_sum, d_err);
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------ reset masks <-> PML vectors (round 6)
+// PML[k] = reset(k) ? 0 : PML[k - 1] + 1 (process_char either increments match_len or zeroes it, src/read_processor.cpp:193-215;
+// MoveQuery::add_ml clamps to u16, include/move_query.hpp:26-38): the vector is the run length since the last reset.  The walk can
+// write the reset bits alone (pml_kernel_flatp<..., RING = 2>; layout: MaskArgs, movi_kernels.hpp); these two streaming kernels
+// turn masks into vectors and vectors (of the paths that have no mask output of their own) into masks.
+
+// One 32-bit mask word -> 32 PMLs (16 packed pairs), `run` = match_len before the word's first base.
+__device__ __forceinline__ void expand_word(uint32_t m, uint32_t &run, uint4 (&g)[4]) {
+    uint32_t v[16];
+#pragma unroll
+    for (int b = 0; b < 32; b += 2) {
+        run = ((m >> b) & 1u) ? 0u : run + 1u;
+        const uint32_t lo = run > 65535u ? 65535u : run;
+        run = ((m >> (b + 1)) & 1u) ? 0u : run + 1u;
+        const uint32_t hi = run > 65535u ? 65535u : run;
+        v[b / 2] = lo | (hi << 16);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) g[q] = make_uint4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+}
+// the first cnt (1 .. 32) of a word's 32 PMLs to O: whole groups of 8 as 16-byte stores, the rest one by one
+__device__ __forceinline__ void store_word(uint16_t *O, const uint4 (&g)[4], uint32_t cnt) {
+    if (cnt >= 8u) __builtin_memcpy(O, &g[0], 16);
+    if (cnt >= 16u) __builtin_memcpy(O + 8, &g[1], 16);
+    if (cnt >= 24u) __builtin_memcpy(O + 16, &g[2], 16);
+    if (cnt >= 32u) { __builtin_memcpy(O + 24, &g[3], 16); return; }
+    const uint32_t q = cnt >> 3;
+    const uint4 t = q == 0u ? g[0] : (q == 1u ? g[1] : (q == 2u ? g[2] : g[3]));
+    const uint32_t x[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (uint32_t i = 0; i < 8u; ++i)
+        if (8u * q + i < cnt) O[8u * q + i] = (uint16_t)(x[i >> 1] >> (16u * (i & 1u)));
+}
+
+// One lane per read: the words of a read one after the other, match_len carried in a register.
+__global__ __launch_bounds__(256) void pml_expand_kernel(const uint32_t *__restrict__ words, const uint64_t *__restrict__ offs,
+                                                         uint64_t n_reads, uint32_t phase, uint16_t *__restrict__ out) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_reads) return;
+    const uint64_t beg = offs[t];
+    const uint32_t len = (uint32_t)(offs[t + 1] - beg);
+    const uint32_t *M = words + ((beg + phase) >> 5) + t;
+    uint16_t *O = out + beg;
+    uint32_t run = 0;
+    for (uint32_t k = 0; k < len; k += 32u) {
+        uint4 g[4];
+        expand_word(M[k >> 5], run, g);
+        store_word(O + k, g, len - k < 32u ? len - k : 32u);
+    }
+}
+
+// A wavefront per read (long reads): lane l takes word 64 i + l of round i -- the wavefront streams 4 KB of contiguous PMLs per
+// round -- and match_len at the start of every word comes from a scan over (has a reset, bases after the last one) across the
+// wavefront plus the carry of the rounds before.
+__global__ __launch_bounds__(64) void pml_expand_wave_kernel(const uint32_t *__restrict__ words, const uint64_t *__restrict__ offs,
+                                                             uint64_t n_reads, uint32_t phase, uint16_t *__restrict__ out) {
+    const uint64_t t = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    if (t >= n_reads) return;
+    const uint64_t beg = offs[t];
+    const uint32_t len = (uint32_t)(offs[t + 1] - beg);
+    const uint32_t *M = words + ((beg + phase) >> 5) + t;
+    uint16_t *O = out + beg;
+    uint32_t carry = 0;
+    for (uint64_t w0 = 0; w0 * 32u < len; w0 += 64u) {
+        const uint64_t k = (w0 + lane) * 32u;
+        const bool live = k < len;
+        const uint32_t m = live ? M[w0 + lane] : 0u;
+        const uint32_t cnt = live ? (len - k < 32u ? (uint32_t)(len - k) : 32u) : 0u;
+        // (h, tl): the word holds a reset / bases after its last reset (all of them if it holds none); bits beyond cnt are 0
+        uint32_t h = m != 0u, tl = m ? cnt - 32u + (uint32_t)__builtin_clz(m) : cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t ph = __shfl_up(h, d, 64), pt = __shfl_up(tl, d, 64);
+            if ((int)lane >= d) { tl = h ? tl : pt + tl; h |= ph; }
+        }
+        const uint32_t ph = __shfl_up(h, 1, 64), pt = __shfl_up(tl, 1, 64);
+        uint32_t run = lane == 0u ? carry : (ph ? pt : carry + pt);
+        const uint32_t h63 = __shfl(h, 63, 64), t63 = __shfl(tl, 63, 64);
+        carry = h63 ? t63 : carry + t63;
+        if (live) {
+            uint4 g[4];
+            expand_word(m, run, g);
+            store_word(O + k, g, cnt);
+        }
+    }
+}
+
+hipError_t launch_pml_expand(const uint32_t *d_words, const uint64_t *d_offsets, uint64_t n_reads, uint64_t n_bases, uint32_t phase,
+                             uint16_t *d_out, hipStream_t stream) {
+    if (n_reads == 0) return hipSuccess;
+    if (n_bases / n_reads >= 2048 && n_reads <= 0x7FFFFFFFull) {
+        hipLaunchKernelGGL(pml_expand_wave_kernel, dim3((unsigned)n_reads), dim3(64), 0, stream, d_words, d_offsets, n_reads, phase & 31u, d_out);
+        return hipGetLastError();
+    }
+    const uint64_t blocks = (n_reads + 255) / 256;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(pml_expand_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d_words, d_offsets, n_reads, phase & 31u, d_out);
+    return hipGetLastError();
+}
+
+// PML vector -> masks: bit = (PML == 0).  WAVE = 0: one lane per read; 1: a wavefront per read, lane l on words l, l + 64, ...
+template <int WAVE>
+__global__ __launch_bounds__(256) void pml_to_mask_kernel(const uint16_t *__restrict__ pml, const uint64_t *__restrict__ offs,
+                                                          uint64_t n_reads, uint32_t phase, uint32_t *__restrict__ words) {
+    const uint64_t t = WAVE ? (uint64_t)blockIdx.x : (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_reads) return;
+    const uint64_t beg = offs[t];
+    const uint32_t len = (uint32_t)(offs[t + 1] - beg);
+    uint32_t *M = words + ((beg + phase) >> 5) + t;
+    const uint16_t *P = pml + beg;
+    for (uint64_t w = WAVE ? threadIdx.x : 0u; w * 32u < len; w += WAVE ? 64u : 1u) {
+        const uint64_t k = w * 32u;
+        const uint32_t cnt = len - k < 32u ? (uint32_t)(len - k) : 32u;
+        uint32_t m = 0;
+        if (cnt == 32u) {
+            uint4 g[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) __builtin_memcpy(&g[q], P + k + 8 * q, 16);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t x[4] = {g[q].x, g[q].y, g[q].z, g[q].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    m |= (uint32_t)((x[i] & 0xFFFFu) == 0u) << (8 * q + 2 * i);
+                    m |= (uint32_t)((x[i] >> 16) == 0u) << (8 * q + 2 * i + 1);
+                }
+            }
+        } else {
+            for (uint32_t b = 0; b < cnt; ++b) m |= (uint32_t)(P[k + b] == 0) << b;
+        }
+        M[w] = m;
+    }
+}
+
+hipError_t launch_pml_to_mask(const uint16_t *d_pml, const uint64_t *d_offsets, uint64_t n_reads, uint64_t n_bases, uint32_t phase,
+                              uint32_t *d_words, hipStream_t stream) {
+    if (n_reads == 0) return hipSuccess;
+    if (n_bases / n_reads >= 2048 && n_reads <= 0x7FFFFFFFull) {
+        hipLaunchKernelGGL(pml_to_mask_kernel<1>, dim3((unsigned)n_reads), dim3(64), 0, stream, d_pml, d_offsets, n_reads, phase & 31u, d_words);
+        return hipGetLastError();
+    }
+    const uint64_t blocks = (n_reads + 255) / 256;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(pml_to_mask_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, stream, d_pml, d_offsets, n_reads, phase & 31u, d_words);
+    return hipGetLastError();
+}
+
+uint64_t pml_mask_words(uint64_t n_reads, uint64_t n_bases, uint32_t phase) { return ((n_bases + (phase & 31u)) >> 5) + n_reads + 1; }
 
 // ------------------------------------------------- row-start checkpoints (setup)
 

@@ -51,7 +51,7 @@ struct DevIndex {
     uint32_t pad2_;
     const uint4 *ftab;
     uint32_t stage_lds;           // set per launch by launch_pml: bytes of dynamic LDS per lane for read staging (0 = none; 336 at cap 7)
-    uint32_t pad4_;
+    uint32_t mask_phase;          // set per launch, reset-mask output (pml_kernel_flatp<..., RING = 2>): the low 5 bits of the position of the batch's first base in the caller's whole read set (0 for a whole call)
     uint32_t inwin;               // set per launch: 1 = a reposition whose target is one of the window's rows is resolved in the same iteration
     uint32_t kmer_k;
     const uint4 *kmer;            // 4^K entries: x = row[31:0]; y = row[35:32] | off << 4 (12 bits) | match mask << 16 (K bits) |
@@ -217,7 +217,7 @@ struct WalkLaunch {
     ClsArgs cls;
     SegArgs seg;
     int cls_mode = 0;                     // 0 = PML vector, 1 = vector + classification bins, 2 = bins only
-    int sep = 0, stg = 0, ahd = 0, psh = 0, ring = 0;   // separators index / reads staged through LDS / look-ahead rows / pair-shared gathers / PMLs out through the LDS ring
+    int sep = 0, stg = 0, ahd = 0, psh = 0, ring = 0;   // separators index / reads staged through LDS / look-ahead rows / pair-shared gathers / PMLs out through the LDS ring (1) or as reset masks (2: `out` holds 32-bit words)
 };
 // Diagnostic: when switched on (movi_launch_log), every launch of the walk kernel notes its name -- the K1 / K3 launches of the
 // segment plan included, which LaunchInfo (the dominant kernel only) does not show.
@@ -238,6 +238,25 @@ struct SegWorkspace {
     size_t cap = 0;
 };
 
+// Reset masks instead of the PML vector (round 6; movi_pml_mask_device): PML[k] = reset(k) ? 0 : PML[k - 1] + 1, so one bit per base
+// says everything the u16 vector does.  words: bit k % 32 of word ((offsets[i] + phase) >> 5) + i + k / 32 = 1 iff step k of read i
+// reset match_len (its PML is 0); phase = the low five bits of the batch's first base's position in the caller's whole read set
+// (sub-batches of one call then concatenate word for word).  The default walk writes them natively (pml_kernel_flatp<..., RING = 2>);
+// every other path (segment-parallel long reads, the base-synchronous kernels) writes its vector to tmp_pml (n_bases u16, which the
+// caller provides whenever pml_mask_needs_tmp says so) and pml_to_mask_kernel packs it.
+struct MaskArgs {
+    uint32_t *words = nullptr;
+    uint32_t phase = 0;
+    uint16_t *tmp_pml = nullptr;
+};
+uint64_t pml_mask_words(uint64_t n_reads, uint64_t n_bases, uint32_t phase);          // words a batch's masks take (gap words included)
+bool pml_mask_needs_tmp(const DevIndex &ix, const LaunchCfg &cfg, uint64_t n_reads, uint64_t n_bases, bool have_seg_ws);
+// u16 vector <-> masks, streaming (one lane per read; a wavefront per read from a mean length of 2048 bases)
+hipError_t launch_pml_expand(const uint32_t *d_words, const uint64_t *d_offsets, uint64_t n_reads, uint64_t n_bases, uint32_t phase,
+                             uint16_t *d_out, hipStream_t stream);
+hipError_t launch_pml_to_mask(const uint16_t *d_pml, const uint64_t *d_offsets, uint64_t n_reads, uint64_t n_bases, uint32_t phase,
+                              uint32_t *d_words, hipStream_t stream);
+
 // d_out == nullptr is allowed when cls.bin_width != 0: verdict bins only, no PML vector is written.
 // seg_ws != nullptr allows the segment-parallel path for batches of long reads (cfg.seg_len); ragged_hint: 1 / 0 = the
 // caller knows that the longest read is / is not more than 1.5 x the mean, -1 = it does not know (device offsets only).
@@ -245,7 +264,7 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
                       uint64_t n_reads, uint64_t n_bases, uint16_t *d_out, uint8_t *d_err, DevStats *d_stats,
                       const uint32_t *d_order, const LaunchCfg &cfg, hipStream_t stream,
                       const ClsArgs &cls = ClsArgs(), SegWorkspace *seg_ws = nullptr, int ragged_hint = -1,
-                      int *seg_verdict = nullptr, LaunchInfo *info = nullptr);
+                      int *seg_verdict = nullptr, LaunchInfo *info = nullptr, const MaskArgs &mask = MaskArgs());
 
 hipError_t launch_count(int mode, const DevIndex &ix, const uint8_t *d_bases, const uint64_t *d_offsets,
                         uint64_t n_reads, uint64_t *d_matched, uint64_t *d_count, uint8_t *d_err,

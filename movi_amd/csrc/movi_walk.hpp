@@ -56,7 +56,8 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
     static_assert(AHD == 0 || STG == 1, "look-ahead rows: staged reads");
     static_assert(AHD == 0 || AHD == 1, "plain rows or look-ahead rows");
     static_assert(PSH == 0 || STG == 1, "pair-shared gathers: staged kernels");
-    static_assert(RING == 0 || STG == 1, "PMLs out through the LDS ring: staged kernels");
+    static_assert(RING == 0 || STG == 1, "PMLs out through the LDS ring / as reset masks: staged kernels");
+    static_assert(RING != 2 || (CLS == 0 && SEG == 0), "reset masks: plain PML of whole reads");
     enum : uint32_t { sFF = 0, sDown = 1, sUp = 2, sDone = 3 };
     __shared__ uint8_t s_code[256];
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = ix.code_of[i];
@@ -75,7 +76,17 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
     const uint64_t beg = valid ? (SEG == 1 ? seg.seg_in[rid] : offs[rid]) : 0;
     const uint32_t len = valid ? (SEG == 1 ? seg.seg_len[rid] : (uint32_t)(offs[rid + 1] - beg)) : 0;   // reads are shorter than 2^32 (checked on the host)
     const uint64_t obeg = (SEG == 1 && valid) ? seg.seg_out[rid] : beg;   // where the read's (segment's) PMLs go
-    constexpr bool ring = RING != 0;                      // PMLs leave through the ring in LDS (below) instead of the register packer
+    constexpr bool ring = RING == 1;                      // PMLs leave through the ring in LDS (below) instead of the register packer
+    // RING == 2 (round 6): RESET MASKS out instead of PMLs.  PML[k] = reset(k) ? 0 : PML[k - 1] + 1 (MoveQuery::add_ml of a match_len
+    // that process_char either increments or zeroes, src/read_processor.cpp:193-215, include/move_query.hpp:26-38), so the vector is
+    // a function of one bit per base: 1 = match_len was reset at this base (mismatch or illegal character).  `out` is then an array
+    // of 32-bit words: bit k % 32 of word ((beg + ix.mask_phase) >> 5) + rid + k / 32 belongs to step k of read rid -- every read
+    // starts a word of its own without a prefix sum over the reads (floor((o + l) / 32) + 1 >= floor(o / 32) + ceil(l / 32)).  An
+    // emission is one v_lshl_or_b32, a finished word one 4-byte store; pml_expand_kernel / movi_pml_expand_host turn the words back
+    // into the u16 vector (u16 clamp included).  1/16 of the bytes of the vector.
+    constexpr bool msk = RING == 2;
+    uint32_t *const M = msk ? reinterpret_cast<uint32_t *>(out) + (((beg + ix.mask_phase) >> 5) + rid) : nullptr;
+    uint32_t mk = 0;
     const uint32_t packed_end = len & (ring ? ~15u : ~7u);      // PMLs of steps >= this are stored one by one
 
     // The 16 bases of steps kk .. kk+15 of the read (b, l) are the bytes [b + l - kk - 16, b + l - kk) of `bases`, last
@@ -157,7 +168,13 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
             seg.tot[rid] = tt;
             return;
         }
-        if (failed && CLS != 2) {
+        if (msk) {                                        // a failed read reports all-zero PMLs: every base a reset
+            if (failed) {
+                for (uint32_t wd = 0; wd * 32u < len; ++wd) M[wd] = (len - wd * 32u >= 32u) ? 0xFFFFFFFFu : ((1u << (len & 31u)) - 1u);
+            } else if (len & 31u) {
+                M[len >> 5] = mk;                         // the read's last, partial word
+            }
+        } else if (failed && CLS != 2) {
             for (uint32_t i = 0; i < len; ++i) out[obeg + i] = 0;
         }
         if (CLS) cs.store(cls, rid, failed != 0u);
@@ -263,7 +280,19 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
         uint4 e4 = make_uint4(0, 0, 0, 0);
         if (cand) e4 = ix.kmer[kidx];
         const uint32_t use = cand & (e4.y >> 31);
-        if (use) {
+        if (msk) {
+            if (use) {                                    // K <= 12 bases: the match mask's complement is the word so far
+                const uint32_t mask = (e4.y >> 16) & 0xFFFu;
+                mk = ~mask & ((1u << K) - 1u);
+                k = K;
+                ml = (uint32_t)__builtin_clz(~(mask << (32u - K)));      // the run of matches that ends at base K - 1
+                need = (IdxT)((uint64_t)e4.x | ((uint64_t)(e4.y & 15u) << 32));
+                off = (e4.y >> 4) & 0xFFFu;
+                ff_total += e4.z;
+                scan_total += e4.w;
+                repo_total += K - (uint32_t)__popc(mask);
+            }
+        } else if (use) {
             const uint32_t mask = (e4.y >> 16) & 0xFFFu;
             uint16_t *O = out + obeg;
             uint32_t run = 0;
@@ -514,6 +543,9 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
                 if (CLS) cs.add(val, k, len, cls.bin_width, cls.thr);
                 if (CLS == 2) {
                     // verdict bins only
+                } else if (msk) {
+                    mk |= (uint32_t)(mlv == 0u) << (k & 31u);
+                    if ((k & 31u) == 31u) { M[k >> 5] = mk; mk = 0u; }
                 } else if (k >= packed_end) {
                     O[k] = (uint16_t)val;
                 } else if (STG && ring) {
@@ -629,6 +661,18 @@ static hipError_t walk_go(const WalkLaunch &L, LaunchInfo *info) {
 template <typename IdxT, int SEG, int CLS, int SEP>
 static hipError_t walk_pick(const WalkLaunch &L, LaunchInfo *info) {
     if (!L.stg) return walk_go<IdxT, SEG, CLS, SEP, 0, 0, 0, 0>(L, info);
+    if (L.ring == 2) {                                     // reset masks out (plain PML of whole reads: launch_pml sees to it)
+        if constexpr (SEG == 0 && CLS == 0) {
+            switch ((L.ahd ? 2 : 0) | (L.psh ? 1 : 0)) {
+            case 0: return walk_go<IdxT, 0, 0, SEP, 1, 0, 0, 2>(L, info);
+            case 1: return walk_go<IdxT, 0, 0, SEP, 1, 0, 1, 2>(L, info);
+            case 2: return walk_go<IdxT, 0, 0, SEP, 1, 1, 0, 2>(L, info);
+            default: return walk_go<IdxT, 0, 0, SEP, 1, 1, 1, 2>(L, info);
+            }
+        } else {
+            return hipErrorInvalidValue;
+        }
+    }
     switch ((L.ahd ? 4 : 0) | (L.psh ? 2 : 0) | (L.ring ? 1 : 0)) {
     case 0: return walk_go<IdxT, SEG, CLS, SEP, 1, 0, 0, 0>(L, info);
     case 1: return walk_go<IdxT, SEG, CLS, SEP, 1, 0, 0, 1>(L, info);

@@ -82,6 +82,44 @@ def pinned_empty(n, dtype):
     return np.asarray(blk)[: int(n) * dt.itemsize].view(dt)
 
 
+def mask_words(n_reads, n_bases, first_base=0):
+    """movi_pml_mask_words: 32-bit words the reset masks of a batch take."""
+    n = C.c_uint64(0)
+    check(lib().movi_pml_mask_words(int(n_reads), int(n_bases), int(first_base), C.byref(n)))
+    return int(n.value)
+
+
+def expand_masks_host(words, offs, threads=0, out=None):
+    """movi_pml_expand_host: reset-mask words -> the u16 PML vector (pure host code, worker threads)."""
+    words = np.ascontiguousarray(words, np.uint32)
+    offs = np.ascontiguousarray(offs, np.uint64)
+    if out is None:
+        out = np.zeros(int(offs[-1]), np.uint16)
+    check(lib().movi_pml_expand_host(words.ctypes.data, offs.ctypes.data, offs.size - 1, out.ctypes.data, int(threads)))
+    return out
+
+
+def masks_of_pml(pml, offs, first_base=0):
+    """The reset-mask words of a PML vector (numpy; test helper): bit = (PML == 0), layout of include/movi_hip.h.
+    Returns (words, valid) -- valid marks the words that belong to a read (gap words are unspecified)."""
+    offs = np.asarray(offs, np.uint64).astype(np.int64)
+    n = offs.size - 1
+    rel = offs - offs[0]
+    words = np.zeros(mask_words(n, int(rel[-1]), first_base), np.uint32)
+    valid = np.zeros(words.size, bool)
+    lens = np.diff(rel)
+    if n == 0 or rel[-1] == 0:
+        return words, valid
+    w0 = ((first_base + rel[:-1]) >> 5) - (first_base >> 5) + np.arange(n)
+    read_of = np.repeat(np.arange(n), lens)
+    k = np.arange(int(rel[-1])) - np.repeat(rel[:-1], lens)
+    z = np.asarray(pml[int(offs[0]):int(offs[-1])]) == 0
+    widx = w0[read_of] + (k >> 5)
+    np.bitwise_or.at(words, widx[z], (np.uint32(1) << (k[z] & 31).astype(np.uint32)))
+    valid[widx] = True
+    return words, valid
+
+
 class QueryStats:
     def __init__(self, c):
         self.bases = int(c.bases)
@@ -190,6 +228,21 @@ class MoveIndex:
         check(rc)
         return out, QueryStats(st)
 
+    def query_pml_mask_packed(self, bases, offs, want_err=False):
+        """movi_pml_mask_host: (u32 reset-mask words laid out as include/movi_hip.h says, QueryStats[, err, rc])."""
+        bases = np.ascontiguousarray(bases, np.uint8)
+        offs = np.ascontiguousarray(offs, np.uint64)
+        n = offs.size - 1
+        words = np.zeros(mask_words(n, int(offs[-1] - offs[0])), np.uint32)
+        err = np.zeros(max(n, 1), np.uint8)
+        st = QueryStatsC()
+        rc = lib().movi_pml_mask_host(self._h, bases.ctypes.data, offs.ctypes.data, n, words.ctypes.data, err.ctypes.data,
+                                      C.byref(st))
+        if want_err:
+            return words, QueryStats(st), err[:n], rc
+        check(rc)
+        return words, QueryStats(st)
+
     def query_pml_logs_packed(self, bases, offs):
         """movi_pml_logs_host: (PMLs, per-base fast-forwards, per-base scan rows, QueryStats), all in emission order."""
         bases = np.ascontiguousarray(bases, np.uint8)
@@ -271,6 +324,16 @@ class MoveIndex:
                                     C.c_void_p(d_out), C.c_void_p(d_err) if d_err else None,
                                     C.c_void_p(d_order) if d_order else None,
                                     C.c_void_p(stream) if stream else None))
+
+    def pml_mask_device(self, d_bases, d_offs, n_reads, n_bases, d_words, first_base=0, d_err=0, stream=0, d_order=0):
+        check(lib().movi_pml_mask_device(self._h, C.c_void_p(d_bases), C.c_void_p(d_offs), n_reads, n_bases, int(first_base),
+                                         C.c_void_p(d_words), C.c_void_p(d_err) if d_err else None,
+                                         C.c_void_p(d_order) if d_order else None,
+                                         C.c_void_p(stream) if stream else None))
+
+    def pml_expand_device(self, d_words, d_offs, n_reads, n_bases, d_out, first_base=0, stream=0):
+        check(lib().movi_pml_expand_device(self._h, C.c_void_p(d_words), C.c_void_p(d_offs), n_reads, n_bases, int(first_base),
+                                           C.c_void_p(d_out), C.c_void_p(stream) if stream else None))
 
     def pml_classify_device(self, d_bases, d_offs, n_reads, n_bases, bin_width, max_value_thr, d_out, d_above,
                             d_below, d_sum, d_err=0, stream=0, d_order=0):

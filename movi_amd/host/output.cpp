@@ -36,15 +36,19 @@ struct BpfWriter::Async {
     uint64_t reserved_to = 0, written_to = 0;                          // fallocate()d / written file offsets (reserve_ahead)
     bool reserve = true;
     bool stop = false;
+    bool abort = false;                                                // the destructor during unwinding: queued slabs are dropped, not written
+    bool failed = false;                                               // a write() has failed: later slabs are handed back unwritten
     std::exception_ptr err;
     double write_s = 0;
 };
 
 BpfWriter::~BpfWriter() {
-    if (async_) {                                                      // (an exception is unwinding: what is queued is dropped)
-        { std::lock_guard<std::mutex> g(async_->m); async_->stop = true; }
+    if (async_) {                                                      // (an exception is unwinding: what is queued is dropped -- the thread leaves at once)
+        { std::lock_guard<std::mutex> g(async_->m); async_->stop = true; async_->abort = true; }
         async_->cv.notify_all();
         if (async_->th.joinable()) async_->th.join();
+        // blocks reserved ahead of the writes go back (best effort: the file is known to be incomplete)
+        if (fd_ >= 0 && async_->reserved_to > async_->written_to && ::ftruncate(fd_, (off_t)async_->written_to) != 0) { /* nothing more to do */ }
         delete async_;
         async_ = nullptr;
     }
@@ -134,8 +138,15 @@ void BpfWriter::append(const Chunk &c, WorkerPool &pool) {
             std::unique_lock<std::mutex> g(a->m);
             for (;;) {
                 a->cv.wait(g, [&] { return a->stop || a->full[a->write_next]; });
-                if (!a->full[a->write_next]) return;                   // stop, nothing queued
+                if (a->abort || !a->full[a->write_next]) return;       // stop with nothing queued -- or the destructor during unwinding: whatever is queued is dropped
                 const unsigned s = a->write_next;
+                if (a->failed) {                                       // a write() has failed: nothing more goes into a file known to be bad
+                    a->full[s] = false;
+                    a->queued -= 1;
+                    a->write_next = (a->write_next + 1u) % a->n_slabs;
+                    a->cv.notify_all();
+                    continue;
+                }
                 g.unlock();
                 const auto t0 = clk::now();
                 std::exception_ptr err;
@@ -153,7 +164,11 @@ void BpfWriter::append(const Chunk &c, WorkerPool &pool) {
                 while (len) {
                     const ssize_t w = ::write(fd_, q, len);
                     if (w < 0 && errno == EINTR) continue;
-                    if (w < 0) { err = std::make_exception_ptr(std::runtime_error("Failed to write the output file: " + path_)); break; }
+                    if (w < 0) {
+                        err = std::make_exception_ptr(std::runtime_error("Failed to write the output file: " + path_));
+                        a->written_to -= len;                          // (what did not reach the file)
+                        break;
+                    }
                     q += w;
                     len -= (size_t)w;
                 }
@@ -161,6 +176,7 @@ void BpfWriter::append(const Chunk &c, WorkerPool &pool) {
                 g.lock();
                 a->write_s += dt;
                 if (err && !a->err) a->err = err;
+                if (err) a->failed = true;
                 a->full[s] = false;
                 a->queued -= 1;
                 a->write_next = (a->write_next + 1u) % a->n_slabs;

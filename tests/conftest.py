@@ -45,7 +45,7 @@ def built_lib():
     """libmovi_hip.so, (re)built if stale.  hipcc cross-compiles without a GPU."""
     so = os.path.join(ROOT, "movi_amd", "lib", "libmovi_hip.so")
     csrc = os.path.join(ROOT, "movi_amd", "csrc")
-    srcs = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".hpp"))] + [os.path.join(ROOT, "include", "movi_hip.h")]
+    srcs = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".hpp", ".cpp"))] + [os.path.join(ROOT, "include", "movi_hip.h")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-j8", "-C", csrc], stdout=subprocess.DEVNULL)
     return so

@@ -16,5 +16,5 @@ for mode in (2, 3, 5, 6, 7, 8):
         open("%s/m%d%s.movi" % (w, mode, "s" if sep else ""), "wb").write(B.build_index_from_seqs([ref], mode, separators=sep))
 PY
 /opt/rocm/bin/hipcc -O1 -g -std=c++17 -fsanitize=address,undefined -fno-omit-frame-pointer --offload-arch=gfx950 \
-    -o "$W/fuzz_parse" "$ROOT/tests/fuzz/fuzz_parse.cpp" "$ROOT"/movi_amd/csrc/movi_abi.hip "$ROOT"/movi_amd/csrc/movi_kernels.hip "$ROOT"/movi_amd/csrc/movi_walk*.hip
+    -o "$W/fuzz_parse" "$ROOT/tests/fuzz/fuzz_parse.cpp" "$ROOT"/movi_amd/csrc/movi_abi.hip "$ROOT"/movi_amd/csrc/movi_kernels.hip "$ROOT"/movi_amd/csrc/movi_walk*.hip "$ROOT"/movi_amd/csrc/movi_expand_host.cpp
 ASAN_OPTIONS=detect_leaks=0 "$W/fuzz_parse" "$IT" "$W"/m*.movi

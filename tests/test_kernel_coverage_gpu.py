@@ -1,7 +1,8 @@
 """GPU suite (-m gpu): every instantiation of the walk kernel the library was BUILT with is reachable through the options of
 the C-ABI, and each one is held to the oracle once.
 
-pml_kernel_flatp<6, IdxT, CLS, SEP, SEG, STG, AHD, PSH, RING> (movi_amd/csrc/movi_walk.hpp) has 180 instantiations; the launch
+pml_kernel_flatp<6, IdxT, CLS, SEP, SEG, STG, AHD, PSH, RING> (movi_amd/csrc/movi_walk.hpp) has 196 instantiations (round 6: + 16 with
+RING = 2, reset masks out: index width x separators x look-ahead rows x pair-shared gathers); the launch
 policy picks among them from the table (separators, size), the batch (read lengths, size) and a dozen option knobs.  This test
 walks the knobs -- index with / without separators x row-index width x reads staged through LDS or not x look-ahead rows x
 pair-shared gathers x PMLs out through the LDS ring x {PML vector, vector + fused bins, bins only} and, for batches of long
@@ -19,6 +20,7 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN, classify_py
+from movi_amd.engine import masks_of_pml
 from test_gpu_parity import mutated_reads, pack
 
 pytestmark = pytest.mark.gpu
@@ -78,7 +80,7 @@ def test_every_built_walk_kernel_is_reachable_and_equals_the_oracle(built_lib, g
     from oracle import build_index as B
     from oracle.oracle import Oracle
     built = built_walk_kernels()
-    assert len(built) == 180, len(built)                        # DESIGN.md section 3 states the count
+    assert len(built) == 196, len(built)                        # DESIGN.md section 3 states the count
     ref = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))[0][1]
     rng = np.random.default_rng(31337)
     short = mutated_reads(rng, ref, 1900, 1, 420) + [b"", b"A", b"N" * 17, ref[:16], ref[100:117], b"ACGT" * 40] + \
@@ -93,6 +95,7 @@ def test_every_built_walk_kernel_is_reachable_and_equals_the_oracle(built_lib, g
         sb, so = pack(short)
         lb, lo = pack(long_reads)
         sexp, sff, ssc = cpu.pml_batch(sb, so, threads=8)
+        mexp, mvalid = masks_of_pml(sexp, so)
         lexp, lff, lsc = cpu.pml_batch(lb, lo, threads=8)
         BW, THR = 40, 4
         bins_exp = [classify_py(sexp[int(so[i]):int(so[i + 1])], THR, BW) if len(r) else None for i, r in enumerate(short)]
@@ -112,6 +115,10 @@ def test_every_built_walk_kernel_is_reachable_and_equals_the_oracle(built_lib, g
                     # CLS 0: the PML vector
                     out, st = gpu.query_pml_packed(sb, so)
                     assert (out == sexp).all() and (st.fast_forwards, st.scans, st.errors) == (sff, ssc, 0), tag
+                    # RING 2: reset masks out (the staged walk writes them itself; ring = 1 changes nothing for it)
+                    if stage and not ring:
+                        words, mst = gpu.query_pml_mask_packed(sb, so)
+                        assert (words[mvalid] == mexp[mvalid]).all() and (mst.fast_forwards, mst.scans, mst.errors) == (sff, ssc, 0), tag
                     # CLS 1 / 2: vector + fused bins, bins only
                     for with_vector in (True, False):
                         d_out = torch.zeros(max(sb.size, 1), dtype=torch.int16, device=dev)

@@ -37,17 +37,20 @@ static inline uint32_t rthr(uint64_t i, uint32_t k) {
 }
 static int code_of(uint8_t ch) { return ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : -1; }
 
-typedef struct { int S, W, side, side_reach, inwin, own; } Design;
+typedef struct { int S, W, side, side_reach, inwin, own, rpl; } Design;   // rpl: rows per 128-byte line of the walked layout (round 6: fabric lines per base)
 typedef struct {
     uint64_t iters, bases, it_arrive, it_ffwin, it_mism, it_scanwin, chained, waves_iters, lanes_iters;
     uint64_t ff_rows, scan_rows, repos;
+    uint64_t lines;                                  // window fetches that touch another 128-byte line than the lane's previous fetch
 } Tally;
 
 // One read under one design; returns its lane iterations.
 static uint32_t walk(const uint8_t *rd, uint32_t len, uint32_t top_k, const Design *d, Tally *t) {
     uint64_t idx = r - 1;
     uint32_t off = rn(idx) - 1, it = 0;
-    const uint64_t W = (uint64_t)d->W;
+    const uint64_t W = (uint64_t)d->W, RPL = (uint64_t)(d->rpl ? d->rpl : 8);
+    uint64_t last_line = ~0ull;
+#define FETCH(row) do { const uint64_t ln_ = (uint64_t)(row) / RPL; if (ln_ != last_line) { t->lines++; last_line = ln_; } } while (0)
     int chain_left = 0;                              // bases that may still ride on the current entry
     for (uint32_t k = 0; k < len; k++) {
         const int a = code_of(rd[len - 1 - k]);
@@ -66,9 +69,10 @@ static uint32_t walk(const uint8_t *rd, uint32_t len, uint32_t top_k, const Desi
                 it++; t->it_arrive++;
                 const uint64_t w0 = j / W, w1 = jj / W;
                 it += (uint32_t)(w1 - w0); t->it_ffwin += w1 - w0;
+                for (uint64_t w = w0; w <= w1; w++) FETCH(w * W);
             }
             idx = jj;
-        } else if (top_k == 0) { it++; t->it_arrive++; }
+        } else if (top_k == 0) { it++; t->it_arrive++; FETCH(idx); }
         if (rode) { t->chained++; continue; }        // matched by construction
         if (a < 0) { chain_left = (k >= top_k && !(d->own && arr_ff)) ? d->S : 0; continue; }
         if ((int)rc(idx) == a) { chain_left = (k >= top_k && !(d->own && arr_ff)) ? d->S : 0; continue; }
@@ -96,11 +100,14 @@ static uint32_t walk(const uint8_t *rd, uint32_t len, uint32_t top_k, const Desi
             const uint64_t beyond = down ? idx - edge : edge - idx;
             if (d->side == 2 ? beyond <= (uint64_t)d->side_reach : (d->side && sc <= (uint32_t)d->side_reach)) {
                 // side array told the distance: the one iteration above fetched the target's window directly
+                FETCH((idx / W) * W);
             } else {
                 const uint64_t first = down ? from + 1 : from - 1;
                 const uint64_t wa = first / W, wb = idx / W;
                 const uint64_t extra = wa > wb ? wa - wb : wb - wa;
                 it += (uint32_t)extra; t->it_scanwin += extra;
+                if (wa <= wb) { for (uint64_t w = wa; w <= wb; w++) FETCH(w * W); }
+                else { for (uint64_t w = wa + 1; w-- > wb;) FETCH(w * W); }
             }
             }
         }
@@ -135,10 +142,13 @@ int main(int argc, char **argv) {
         {0, 4, 0, 0, 0, 0}, {1, 4, 0, 0, 0, 0}, {1, 4, 0, 0, 0, 1}, {1, 4, 0, 0, 1, 0}, {2, 4, 0, 0, 0, 0}, {2, 4, 0, 0, 1, 0}, {3, 4, 0, 0, 1, 0},
         {7, 4, 0, 0, 1, 0}, {1, 4, 1, 64, 1, 0}, {2, 4, 1, 64, 1, 0}, {1, 2, 0, 0, 1, 0}, {1, 8, 0, 0, 1, 0}, {2, 8, 0, 0, 1, 0},
         {1, 4, 1, 7, 1, 0}, {1, 4, 1, 15, 1, 0}, {1, 4, 1, 31, 1, 0}, {1, 4, 1, 63, 1, 0}, {1, 4, 2, 7, 1, 0}, {1, 4, 2, 15, 1, 0},  // round 5: reposition hints of 3 .. 6 bits in the rows' spare bits
+        // round 6: entries TWO rows deep packed to 21.33 bytes per row (6 rows per 128-byte line, windows of 3 rows = half a line), with / without hints;
+        // beside them what ships (S = 1, W = 4, 8 rows per line) and round 4's chain rows (S = 2, W = 4, 4 rows per line) with hints
+        {1, 4, 2, 7, 1, 0, 8}, {2, 4, 2, 7, 1, 0, 4}, {2, 3, 0, 0, 1, 0, 6}, {2, 3, 2, 7, 1, 0, 6}, {2, 3, 2, 3, 1, 0, 6}, {2, 6, 2, 7, 1, 0, 6}, {3, 3, 2, 7, 1, 0, 6},
     };
     printf("r = %llu rows, %llu reads x %u, top-of-walk K = %u\n", (unsigned long long)r, (unsigned long long)n_reads, L, top_k);
-    printf("%-36s %9s %9s | %7s %7s %7s %7s | %7s | %6s %6s %6s\n", "design", "iter/base", "SIMT", "arrive", "ff-win", "mismat", "scanwin",
-           "chained", "ff/b", "scan/b", "repo/b");
+    printf("%-40s %9s %9s | %7s %7s %7s %7s | %7s | %6s %6s %6s | %7s\n", "design", "iter/base", "SIMT", "arrive", "ff-win", "mismat", "scanwin",
+           "chained", "ff/b", "scan/b", "repo/b", "lines/b");
     for (size_t di = 0; di < sizeof designs / sizeof designs[0]; di++) {
         Tally t; memset(&t, 0, sizeof t);
         uint32_t wave_max = 0;
@@ -152,11 +162,11 @@ int main(int argc, char **argv) {
             if ((i & 63) == 63 || i + 1 == n_reads) { t.waves_iters += (uint64_t)wave_max * 64; wave_max = 0; }
         }
         if (df) fclose(df);
-        char name[64];
-        snprintf(name, sizeof name, "S=%d W=%d side=%d(%d) inwin=%d own=%d", designs[di].S, designs[di].W, designs[di].side, designs[di].side_reach, designs[di].inwin, designs[di].own);
+        char name[96];
+        snprintf(name, sizeof name, "S=%d W=%d side=%d(%d) inwin=%d own=%d rpl=%d", designs[di].S, designs[di].W, designs[di].side, designs[di].side_reach, designs[di].inwin, designs[di].own, designs[di].rpl ? designs[di].rpl : 8);
         const double b = (double)t.bases;
-        printf("%-36s %9.4f %9.3f | %7.4f %7.4f %7.4f %7.4f | %7.4f | %6.3f %6.3f %6.4f\n", name, t.iters / b, (double)t.iters / t.waves_iters,
-               t.it_arrive / b, t.it_ffwin / b, t.it_mism / b, t.it_scanwin / b, t.chained / b, t.ff_rows / b, t.scan_rows / b, t.repos / b);
+        printf("%-40s %9.4f %9.3f | %7.4f %7.4f %7.4f %7.4f | %7.4f | %6.3f %6.3f %6.4f | %7.4f\n", name, t.iters / b, (double)t.iters / t.waves_iters,
+               t.it_arrive / b, t.it_ffwin / b, t.it_mism / b, t.it_scanwin / b, t.chained / b, t.ff_rows / b, t.scan_rows / b, t.repos / b, t.lines / b);
     }
     return 0;
 }
