@@ -203,8 +203,8 @@ def count_roofline(table_bytes, row_bytes, st, matched_bases, kern_s, launch, tr
 
 
 def table_bytes_walked(rows, row_bytes, launch):
-    """Bytes of the table the launch gathered from: the look-ahead copy is 16 B per row."""
-    return rows * {0: row_bytes, 1: 16}.get(int(launch.get("ahead") or 0), row_bytes)
+    """Bytes of the table the launch gathered from: the look-ahead copy is 16 B per row, the deep rows 64 B per three rows."""
+    return int(rows * {0: row_bytes, 1: 16, 2: 64.0 / 3.0}.get(int(launch.get("ahead") or 0), row_bytes))
 
 
 def send_to_rank(torch, dist, world, rank, dev, arr, dst):
@@ -315,6 +315,12 @@ def big_table_leg(torch, dist, world, rank, dev, local_rank, stream, synth, movi
                     "rank_seconds": [round(x, 4) for x in perc], "kernel": claunch["kernel"],
                     "roofline": count_roofline(table_bytes_walked(rows, 8, claunch), 8, stc, int(d_m.sum().item()), kern_c, claunch, ctraffic, ctsrc)}
     out["count"]["roofline"]["dram_frac_of_peak"] = (ctraffic / kern_c / 1e9 / HBM_PEAK_GBS) if ctraffic else None
+    if getattr(index, "dry", False):
+        out["dry_run"] = True
+        out["index_broadcast_gb_s"] = round(rbytes / t_bc / 1e9, 2) if t_bc > 0 else None
+        index.close()
+        return out if rank == 0 else None
+    out["index_broadcast_gb_s"] = round(rbytes / t_bc / 1e9, 2) if t_bc > 0 else None
     if rank == 0:
         # parity: three slices of rank 0's batch against the oracle on the same image, PMLs, counters and counts
         t0 = time.time()
@@ -441,6 +447,8 @@ def long_reads_leg(torch, dist, world, rank, dev, stream, index, idx_dir, rows, 
                "kernel": res[0]["roofline"]["kernel"], "launch": res[0]["roofline"]["launch"],
                "classify_vector_and_bins": res[1], "classify_bins_only": res[2],
                "classify_bins_agree": bool(all(torch.equal(x, y) for x, y in zip(verdicts[1], verdicts[2])))})
+    if getattr(index, "dry", False):
+        lr["dry_run"] = True
     few = None
     if with_few and world == 1:
         # the same reads, a quarter of them: too few walks to fill the GPU with one lane per read -- the shape the
@@ -574,6 +582,74 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 INFINITY_CACHE_BYTES = 256 << 20   # MI355X_MICROARCH.md: 256 MiB Infinity Cache (MALL) in front of HBM
 
 
+# ---- `--dry-run`: the whole N-rank flow of this file on the CPU, over gloo, WITHOUT a GPU call (round 6) -------------------------
+# No 8-GPU node has ever run this build, so everything around the kernels -- the self-spawn under torch.distributed.run, rank 0's
+# synthesis of the tables, the one broadcast of the rows, the per-rank read hand-over, the barrier / max-over-ranks timing and the
+# assembly of rank 0's JSON line -- is exercised here with the engine replaced by a stand-in whose calls do nothing (and say so:
+# "dry_run": true, value = null).  tests/test_dist_cpu.py runs `--gpus 8 --dry-run` and holds its peak resident memory and wall time
+# to the driver's limits.  What it cannot cover is RCCL itself (`dist.broadcast` on the nccl backend, ncclCommInitAll).
+class _DryStats:
+    bases = fast_forwards = scans = repositions = errors = lane_steps = wave_steps = segments = rewalked = 0
+
+
+class DryIndex:
+    """Stand-in for movi_amd.MoveIndex: same calls, no device, no results."""
+    PREPARE_PML, PREPARE_COUNT, PREPARE_ZML = 1, 2, 4
+    dry = True
+    _h = None
+
+    def __init__(self, rows_bytes=0):
+        self.rows_bytes = rows_bytes
+
+    @classmethod
+    def from_device_rows(cls, cdesc, d_rows_ptr, device=0, keepalive=None):
+        ix = cls(int(keepalive.numel()) if keepalive is not None else 0)
+        ix._keep = keepalive
+        return ix
+
+    def set_option(self, key, value): pass
+    def prepare(self, what=7, stream=0): return 0
+    def pml_device(self, *a, **k): pass
+    def pml_mask_device(self, *a, **k): pass
+    def pml_expand_device(self, *a, **k): pass
+    def pml_classify_device(self, *a, **k): pass
+    def zml_device(self, *a, **k): pass
+    def count_device(self, *a, **k): pass
+    def last_stats(self, stream=0): return _DryStats()
+    def last_launch(self): return {"kernel": "(dry run: no kernel was launched)", "variant": -1, "block_threads": 0, "waves_per_cu": 0, "segmented": 0, "idx64": 0, "staged": 0, "ahead": 0}
+    def info(self, key): return 0.0
+    def close(self): pass
+
+
+class _DryEvent:
+    def __init__(self, enable_timing=True): self.t = 0.0
+    def record(self, stream=None): self.t = time.perf_counter()
+    def elapsed_time(self, other): return (other.t - self.t) * 1e3 + 1e-6
+
+
+class _DryStream:
+    cuda_stream = 0
+
+
+def install_dry_run(torch, movi_amd):
+    """Replace what touches a device: torch.cuda.* used by this file, and the engine's handle class.  Returns the engine stand-in."""
+    import types
+    torch.cuda.is_available = lambda: True
+    torch.cuda.set_device = lambda d: None
+    torch.cuda.synchronize = lambda *a: None
+    torch.cuda.empty_cache = lambda: None
+    torch.cuda.current_stream = lambda *a: _DryStream()
+    torch.cuda.Event = _DryEvent
+    shim = types.SimpleNamespace(MoveIndex=DryIndex, parse_index_image=movi_amd.parse_index_image,
+                                 pinned_empty=lambda n, dt: np.empty(n, dt), MoviError=movi_amd.MoviError)
+    return shim
+
+
+def peak_rss_mb():
+    import resource
+    return resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` started by hand (no torchrun): this process -- which has not touched the GPU, nor even
     imported torch -- starts N ranks under torch.distributed.run as a CHILD and relays its exit code; rank 0's JSON
@@ -634,7 +710,12 @@ def main():
     ap.add_argument("--big-rows", type=int, default=1_000_000_000, help="rows of the `big_table` leg's table (tests shrink it)")
     ap.add_argument("--long-reads", type=int, default=0, help="reads per GPU of the `long_reads` leg (default: c3's 100 000; tests shrink it)")
     ap.add_argument("--quick", action="store_true", help="the timed region only: no cpu_baseline, long_reads, host_path, sustained, big_table (A/B sweeps)")
+    ap.add_argument("--dry-run", action="store_true", help="the N-rank flow on the CPU over gloo with a stand-in engine: no GPU call, no result (value null); "
+                    "spawn, rank 0's synthesis, the broadcast, the read hand-over, timing and JSON assembly are real (tests/test_dist_cpu.py)")
     args = ap.parse_args()
+    t_wall0 = time.time()
+    if args.dry_run:
+        args.no_cpu_baseline = args.no_sustained = True
     if args.quick:
         args.no_cpu_baseline = args.no_long_reads = args.no_big_table = args.no_sustained = True
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -646,6 +727,8 @@ def main():
     from movi_amd._lib import IndexDescC
     from tools import synth
 
+    if args.dry_run:
+        movi_amd = install_dry_run(torch, movi_amd)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -660,11 +743,11 @@ def main():
     if share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cpu") if args.dry_run else torch.device("cuda", local_rank)
     rccl_ranks = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if share_gpu:
+        if share_gpu or args.dry_run:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)          # backend "nccl" IS RCCL on ROCm
@@ -856,7 +939,7 @@ def main():
     # 1 Hz utilisation sampler to see the GPU busy at all; this leg is the sustained figure
     sustained = None
     default_run = (rank == 0 and world == 1 and args.workload == "c2" and args.query == "pml" and not args.classify
-                   and args.variant < 0 and not args.from_dir)
+                   and args.variant < 0 and not args.from_dir and not args.dry_run)
     if default_run and not args.no_sustained:
         try:
             n_sus = max(args.steps, int(5.5 / max(avg_kern_s, 1e-6)))
@@ -926,6 +1009,8 @@ def main():
                    "reads_gen_s": round(t_reads_gen, 2),
                    "no_ff_share": round(index.info("ahead_no_ff"), 4), "derived_table_bytes": int(index.info("derived_bytes"))},
         "rccl_ranks": rccl_ranks, "index_broadcast_s": round(t_bcast, 4),
+        "index_broadcast_gb_s": round(int(d_rows.numel()) / t_bcast / 1e9, 2) if t_bcast > 0 else None,
+        "index_broadcast_bytes": int(d_rows.numel()),
         # bound: by the bytes the row gathers walk -- the look-ahead copy is 16 B per row; the 256 MB top-of-walk / interval table,
         # one lookup per read (~0.1 B per base), is reported beside it ("side_table_bytes"), not folded into the label.  `achieved`
         # prices the REFERENCE's 8-byte rows, whichever layout the launch walked on.
@@ -1103,6 +1188,18 @@ def main():
             if world > 1:
                 raise
             result["big_table"] = {"error": repr(e)[:300]}
+    # every rank's peak resident memory and this process's wall time (the driver allows 1800 s per bench run)
+    rss = [peak_rss_mb()]
+    if world > 1:
+        box = [None] * world
+        dist.all_gather_object(box, rss[0])
+        rss = box
+    result["host_peak_rss_mb"] = [round(x, 1) for x in rss]
+    result["wall_s"] = round(time.time() - t_wall0, 1)
+    if args.dry_run:
+        result["dry_run"] = True
+        result["value_dry_run_meaningless"], result["value"] = result["value"], None
+        result["data"] = "synthetic (DRY RUN: no GPU call was made, no result was computed)"
     parity_failed = rank == 0 and result.get("parity_sample_ok") is False
     if parity_failed:
         # a kernel that disagrees with the oracle has no throughput: the record keeps the measurement under

@@ -101,6 +101,8 @@ struct movi_index {
     uint4 *d_kmer = nullptr;         // top-of-walk table ("kmer_k" option), 16 << 2K bytes
     int kmer_auto = 12;              // K of the table the first PML query builds by itself (0 = none: "kmer_k" 0)
     uint8_t *d_rows2 = nullptr;      // look-ahead rows ("ahead_rows" option), 16 bytes per row
+    uint8_t *d_rows3 = nullptr;      // deep rows ("deep_rows" option), 21.33 bytes per row: what the PML walk runs on where the policy builds them
+    int deep_auto = 1;               // 1: the first PML query builds them for tables of at most kDeepAutoRows rows (instead of the look-ahead rows)
     double ahead_no_ff = 0.0;        // share of the table's positions that arrive at their LF target without a fast-forward (build_ahead)
     bool ahead_tallied = false;
     bool count_declined_ahead = false;   // the count query's auto-build found the copy not worth keeping (rows2_count == 0): do not build it per call
@@ -754,6 +756,7 @@ int movi_index_destroy(movi_index_t *ix) {
     if (ix->d_kmer) (void)hipFree(ix->d_kmer);
     if (ix->d_ftab) (void)hipFree(ix->d_ftab);
     if (ix->d_rows2) (void)hipFree(ix->d_rows2);
+    if (ix->d_rows3) (void)hipFree(ix->d_rows3);
     if (ix->d_stats) (void)hipFree(ix->d_stats);
     release_scratch(ix);
     delete ix;
@@ -847,6 +850,23 @@ static int build_ahead(movi_index *ix, hipStream_t s, bool by_itself) {
     return MOVI_OK;
 }
 
+// Deep rows (DevIndex::rows3; round 6): the PML walk's layout for tables of fewer than 2^28 - 1 rows -- 1.33 x the bytes of the look-ahead
+// rows for three bases per gather instead of two.  Built by itself up to kDeepAutoRows rows (the copy then stays within reach of the
+// Infinity Cache and the per-CU TLBs: profiles/r06_deep_rows.txt has the sizes measured), instead of the look-ahead rows, which the PML
+// walk no longer needs then; "deep_rows" 1 / 0 builds / frees them at any eligible size.
+constexpr uint64_t kDeepAutoRows = 48ull << 20;             // 50 M rows: a copy of 1 GiB
+static bool deep_eligible(const movi_index *ix) {
+    return ix->kmode == MOVI_MODE_REGULAR_THRESHOLDS && deep_rows_eligible(ix->desc.r);
+}
+static int build_deep(movi_index *ix, hipStream_t s) {
+    HIP_TRY(hipMalloc(&ix->d_rows3, deep_rows_bytes(ix->desc.r)));
+    hipError_t e = build_deep_rows(ix->kmode, ix->dev, ix->d_rows3, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { (void)hipFree(ix->d_rows3); ix->d_rows3 = nullptr; return fail_hip(e, "building the deep rows"); }
+    ix->dev.rows3 = ix->d_rows3;
+    return MOVI_OK;
+}
+
 // The count query's interval table (DevIndex::ftab): any DNA index, thresholds or not.
 static bool ftab_eligible(const movi_index *ix) {
     return (ix->kmode == MOVI_MODE_REGULAR_THRESHOLDS || ix->kmode == MOVI_MODE_REGULAR) && ix->dev.sigma - ix->dev.sep == 4;
@@ -883,6 +903,21 @@ static void ensure_pml_tables(movi_index *ix, hipStream_t s, bool from_prepare =
         else if (build_ahead(ix, s, true) != MOVI_OK) {
             (void)hipGetLastError();
             ix->ahead_auto = 0;
+        }
+    }
+    // The deep rows, beside the look-ahead rows (batches of short reads walk on the one, long reads on the other: launch_pml): tables of up
+    // to kDeepAutoRows rows whose positions mostly reach their LF target without a fast-forward -- real text: the builder of the
+    // look-ahead rows has tallied it, else a sample does -- three bases per gather need two such arrivals in a row (uniformly random
+    // run sequences, 0.51: 62.4 -> 61.2 Gbases/s; the pangenome BWT, 0.83: 80.3 -> 89.6 with reset masks out)
+    if (ix->deep_auto > 0 && !ix->d_rows3 && deep_eligible(ix) && ix->desc.r <= kDeepAutoRows && (from_prepare || !ix->prepared)) {
+        if (!ix->ahead_tallied) sample_no_ff(ix, s);
+        size_t free_b = 0, total_b = 0;
+        const uint64_t bytes = deep_rows_bytes(ix->desc.r);
+        if (ix->ahead_tallied && ix->ahead_no_ff < kAheadCountRatio) {
+            ix->deep_auto = 0;                                 // (the table's own statistic declines, for good)
+        } else if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + (2ull << 30) || build_deep(ix, s) != MOVI_OK) {
+            (void)hipGetLastError();
+            ix->deep_auto = 0;                                 // (no room, or a device in trouble: the walk stays on the look-ahead rows)
         }
     }
 }
@@ -1065,11 +1100,32 @@ int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
         ix->dev.rows2_count = 0;
         ix->dev.hints = 0;
         if (ix->d_rows2) (void)hipFree(ix->d_rows2);
-            ix->d_rows2 = nullptr;
-        ix->ahead_auto = 0;                                  // the caller's choice from here on
+        ix->d_rows2 = nullptr;
+        ix->ahead_auto = 0;                                  // the caller's choice from here on ...
+        ix->dev.rows3 = nullptr;                             // ... and it is about what the PML walk runs on: the deep rows, which would take
+        if (ix->d_rows3) (void)hipFree(ix->d_rows3);         // precedence over either answer, go (and are not built by themselves any more;
+        ix->d_rows3 = nullptr;                               // "deep_rows" 1 brings them back)
+        ix->deep_auto = 0;
         if (value == 0) return MOVI_OK;
         if (!ahead_eligible(ix)) return fail(MOVI_ERR_ARG, "look-ahead rows serve PML walks on *-thresholds indexes only");
         return build_ahead(ix, nullptr, false);
+    }
+    if (!strcmp(key, "deep_rows")) {                         // deep rows: 0 = none (freed), 1 = build them now
+        if (value < 0 || value > 1) return fail(MOVI_ERR_ARG, "deep_rows must be 0 or 1");
+        HIP_TRY(hipSetDevice(ix->device));
+        HIP_TRY(hipDeviceSynchronize());                     // no walk may be reading the copy that goes away
+        ix->dev.rows3 = nullptr;
+        if (ix->d_rows3) (void)hipFree(ix->d_rows3);
+        ix->d_rows3 = nullptr;
+        ix->deep_auto = 0;                                   // the caller's choice from here on
+        if (value == 0) return MOVI_OK;
+        if (!deep_eligible(ix)) return fail(MOVI_ERR_ARG, "deep rows serve PML walks on *-thresholds indexes of fewer than 2^28 - 1 rows only");
+        return build_deep(ix, nullptr);
+    }
+    if (!strcmp(key, "deep")) {                              // the walk on the deep rows the handle holds: -1 = batches of short reads, 0 never, 1 always (A/B)
+        if (value < -1 || value > 1) return fail(MOVI_ERR_ARG, "deep must be -1, 0 or 1");
+        ix->cfg.deep = (int)value;
+        return MOVI_OK;
     }
     if (!strcmp(key, "ftab_k")) {                            // count query's interval table: 0 = none, K in [1, 12] = build it now
         if (value < 0 || value > 12) return fail(MOVI_ERR_ARG, "ftab_k must be in [0, 12]");
@@ -1214,13 +1270,15 @@ int movi_index_info(const movi_index_t *ix, const char *key, double *value) {
     const double kmer = ix->d_kmer ? (double)((size_t)16 << (2 * ix->dev.kmer_k)) : 0.0;
     const double ftab = ix->d_ftab ? (double)((size_t)16 << (2 * ix->dev.ftab_k)) : 0.0;
     const double ahead = ix->d_rows2 ? (double)ahead_rows_bytes(ix->desc.r) : 0.0;
+    const double deep = ix->d_rows3 ? (double)deep_rows_bytes(ix->desc.r) : 0.0;
     const double ckpt = ix->d_ckpt ? (double)((ix->desc.r >> kPrefixShift) + 2) * 8.0 : 0.0;
     if (!strcmp(key, "rows_bytes")) *value = rows;
     else if (!strcmp(key, "kmer_bytes")) *value = kmer;
     else if (!strcmp(key, "ftab_bytes")) *value = ftab;
     else if (!strcmp(key, "ahead_rows_bytes")) *value = ahead;
+    else if (!strcmp(key, "deep_rows_bytes")) *value = deep;
     else if (!strcmp(key, "ckpt_bytes")) *value = ckpt;
-    else if (!strcmp(key, "derived_bytes")) *value = kmer + ftab + ahead + ckpt;
+    else if (!strcmp(key, "derived_bytes")) *value = kmer + ftab + ahead + deep + ckpt;
     else if (!strcmp(key, "ahead_no_ff")) *value = ix->ahead_tallied ? ix->ahead_no_ff : -1.0;
     else if (!strcmp(key, "host_staging_bytes")) {           // device staging the synchronous *_host calls hold at the moment
         double b = 0.0;

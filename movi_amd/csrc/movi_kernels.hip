@@ -354,6 +354,87 @@ hipError_t build_ahead_rows(int kmode, const DevIndex &ix, uint8_t *d_rows2, uin
     return hipGetLastError();
 }
 
+// ---- deep rows (DevIndex::rows3, round 6): thread i writes row i of the copy -- the row, what the walk reads at j = id(i) and at
+// j2 = id(j), and j3 = id(j2) (three dependent gathers) -- and its reposition hints for windows of three rows.
+__global__ __launch_bounds__(256) void deep_rows_kernel(DevIndex ix, uint32_t *__restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t padded = ((ix.r + 2) / 3) * 3;
+    if (i >= padded) return;
+    uint32_t *W = out + (i / 3) * 16u;
+    const uint32_t s = (uint32_t)(i % 3);
+    uint32_t d0 = 0x0FFFFFFFu, d1 = (7u << 22) | (7u << 25) | (7u << 28), d2 = 0x0FFFFFFFu, d3 = 0, d4 = 0x0FFFFFFFu, x = 0;
+    if (i < ix.r) {
+        const uint2 row = load_row<6>(ix.rows, i);
+        const uint64_t j = row_id<6>(row, i, ix);
+        const uint32_t c = row_c<6>(row);
+        d0 = (j < ix.r ? (uint32_t)j : 0x0FFFFFFFu) | (row_thr<6>(row, 0) << 28) | (row_thr<6>(row, 1) << 29) | (row_thr<6>(row, 2) << 30);
+        d1 = row_n<6>(row) | (row_off<6>(row) << 11) | (c << 22) | (7u << 25) | (7u << 28);
+        if (j < ix.r) {
+            const uint2 rj = load_row<6>(ix.rows, j);
+            const uint64_t j2 = row_id<6>(rj, j, ix);
+            if (j2 < ix.r) {
+                const uint2 rj2 = load_row<6>(ix.rows, j2);
+                const uint64_t j3 = row_id<6>(rj2, j2, ix);
+                d1 = (d1 & ~(7u << 25)) | (row_c<6>(rj) << 25);
+                d2 = (uint32_t)j2;
+                d3 = row_n<6>(rj) | (row_off<6>(rj) << 11);
+                if (j3 < ix.r) {
+                    const uint32_t n2 = row_n<6>(rj2), o2 = row_off<6>(rj2);
+                    d1 = (d1 & ~(7u << 28)) | (row_c<6>(rj2) << 28);
+                    d3 |= (n2 & 0x3FFu) << 22;
+                    d4 = (uint32_t)j3 | ((n2 >> 10) << 28) | ((o2 & 7u) << 29);
+                    x = o2 >> 3;
+                }
+            }
+        }
+        // hints: the nearest run of each other base beyond the edges of the window the walk sees row i in (ahead_rows_kernel's rule, three-row windows, reach 3)
+        uint32_t h = 0;
+        if (ix.sep == 0u && ix.sigma == 4u && i != ix.end_bwt_idx) {
+            const uint64_t wb = (i / 3) * 3;
+            for (uint32_t k = 0; k < 3u; ++k) {
+                const uint32_t a = k < c ? k : k + 1u;    // the base whose slot is k: alphamap_3[c][a] = a - (a > c), src/utils.cpp:5-8
+                if (a > 3u) continue;
+                uint32_t d = 0;
+                if (row_thr<6>(row, k) == 0u) {           // threshold 0 <= offset: reposition_down
+                    const uint64_t edge = wb + 2;
+                    bool inside = false;
+                    for (uint64_t t = i + 1; t <= edge && t < ix.r; ++t) inside = inside || row_c<6>(load_row<6>(ix.rows, t)) == a;
+                    if (!inside)
+                        for (uint64_t t = edge + 1; t <= edge + 3 && t < ix.r; ++t)
+                            if (row_c<6>(load_row<6>(ix.rows, t)) == a) { d = (uint32_t)(t - edge); break; }
+                } else {                                  // threshold n > offset: reposition_up
+                    bool inside = false;
+                    for (uint64_t t = wb; t < i; ++t) inside = inside || row_c<6>(load_row<6>(ix.rows, t)) == a;
+                    if (!inside)
+                        for (uint64_t t = 1; t <= 3 && t <= wb; ++t)
+                            if (row_c<6>(load_row<6>(ix.rows, wb - t)) == a) { d = (uint32_t)t; break; }
+                }
+                h |= d << (2u * k);
+            }
+        }
+        d2 |= (h & 15u) << 28;
+        x |= (h >> 4) << 8;
+    }
+    W[5u * s + 0u] = d0;
+    W[5u * s + 1u] = d1;
+    W[5u * s + 2u] = d2;
+    W[5u * s + 3u] = d3;
+    W[5u * s + 4u] = d4;
+    atomicOr(&W[15], x << (10u * s));                     // (the table is zeroed first; three rows share the dword)
+}
+
+uint64_t deep_rows_bytes(uint64_t r) { return ((r + 2) / 3) * 64; }
+bool deep_rows_eligible(uint64_t r) { return r >= 8 && r < 0x0FFFFFFFull; }
+
+hipError_t build_deep_rows(int kmode, const DevIndex &ix, uint8_t *d_rows3, hipStream_t stream) {
+    if (!d_rows3 || !deep_rows_eligible(ix.r) || kmode != 6) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(d_rows3, 0, deep_rows_bytes(ix.r), stream);
+    if (e != hipSuccess) return e;
+    const uint64_t blocks = (ix.r + 2 + 255) / 256;
+    hipLaunchKernelGGL(deep_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, ix, reinterpret_cast<uint32_t *>(d_rows3));
+    return hipGetLastError();
+}
+
 hipError_t build_kmer_table(const DevIndex &ix, uint32_t K, uint4 *d_table, hipStream_t stream) {
     if (K < 1 || K > 12 || !d_table || ix.sigma - ix.sep != 4) return hipErrorInvalidValue;
     const uint64_t n = 1ull << (2 * K);
@@ -759,11 +840,12 @@ static hipError_t launch_pml_segmented(const DevIndex &ix, const uint8_t *d_base
                        n_reads, S, first, seg_in, seg_out, seg_l, seg_j, seg_rem);
     // K1 and K3b: the window-parallel lane state machine in blocks of one wavefront, capped like any big batch
     const int bt = 64;
+    const bool seg_deep = ix.rows3 != nullptr && ix.idx32 != 0u && cfg.deep > 0 && cfg.stage_reads != 0;   // K1 / K3 on the deep rows only on request ("deep" 1): segments are long reads (launch_pml's rule)
     auto lds_for = [&](uint64_t lanes) -> size_t {
         int wpc = cfg.waves_per_cu;
         if (wpc < 0) wpc = 0;
         if (cfg.waves_per_cu == 0 && big_batch_cap && lanes > (uint64_t)cfg.num_cus * 64u * 18u)
-            wpc = (ix.rows2 != nullptr && cfg.stage_reads != 0) ? kCapWavesAhead : kCapWaves;
+            wpc = ((ix.rows2 != nullptr || seg_deep) && cfg.stage_reads != 0) ? kCapWavesAhead : kCapWaves;
         if (wpc > 0 && wpc < 32) return ((163840u / (unsigned)wpc) & ~1023u) - 1024u;
         return 0;
     };
@@ -773,9 +855,9 @@ static hipError_t launch_pml_segmented(const DevIndex &ix, const uint8_t *d_base
     // launch_pml's policy -- the cap's padding, or what the launch's wavefronts per CU leave of the CU's LDS)
     DevIndex ixl = ix;
     ixl.inwin = cfg.inwin ? 1u : 0u;
-    ixl.hint_w = (cfg.hints != 0 && ix.hints != 0u && ix.rows2 != nullptr) ? 3u : 0u;
+    ixl.hint_w = seg_deep ? (cfg.hints != 0 ? 2u : 0u) : ((cfg.hints != 0 && ix.hints != 0u && ix.rows2 != nullptr) ? 3u : 0u);
     // (pair-shared gathers on tables beyond the TLBs' reach: launch_pml's rule)
-    const bool seg_pair = (cfg.pair_loads > 0 || (cfg.pair_loads < 0 && ix.r * (ix.rows2 != nullptr ? 16ull : 8ull) >= kPairLoadBytes));
+    const bool seg_pair = !seg_deep && (cfg.pair_loads > 0 || (cfg.pair_loads < 0 && ix.r * (ix.rows2 != nullptr ? 16ull : 8ull) >= kPairLoadBytes));
     size_t dyn_lds = 0;
     bool seg_ring = false;
     auto stage_for = [&](uint64_t lanes) {
@@ -797,14 +879,14 @@ static hipError_t launch_pml_segmented(const DevIndex &ix, const uint8_t *d_base
         L.ix = ixl; L.bases = d_bases; L.offs = d_offsets; L.n = lanes; L.out = d_out; L.err = d_err; L.stats = d_stats;
         L.order = d_order; L.cls = cls; L.seg = seg;
         L.cls_mode = 0; L.sep = ix.sep ? 1 : 0; L.stg = ixl.stage_lds != 0u ? 1 : 0;
-        L.ahd = (L.stg && ix.rows2 != nullptr) ? 1 : 0; L.psh = (L.stg && seg_pair) ? 1 : 0; L.ring = seg_ring ? 1 : 0;
+        L.ahd = (L.stg && seg_deep) ? 2 : ((L.stg && ix.rows2 != nullptr) ? 1 : 0); L.psh = (L.stg && seg_pair) ? 1 : 0; L.ring = seg_ring ? 1 : 0;
         return ix.idx32 ? launch_walkseg_u32(segv, L, li) : launch_walkseg_u64(segv, L, li);
     };
     e = launch_seg(1, max_seg, info);
     if (e != hipSuccess) return e;
     if (info) {                                           // the dominant kernel: K1
         info->variant = 14; info->block_threads = 64; info->segmented = 1; info->idx64 = ix.idx32 ? 0 : 1;
-        info->waves_per_cu = 0; info->staged = (int)ixl.stage_lds; info->ahead = (ixl.stage_lds != 0u && ix.rows2 != nullptr) ? 1 : 0;
+        info->waves_per_cu = 0; info->staged = (int)ixl.stage_lds; info->ahead = ixl.stage_lds == 0u ? 0 : (seg_deep ? 2 : (ix.rows2 != nullptr ? 1 : 0));
     }
     // (blocks of one wavefront: a boundary lane that has to walk far holds up only the 63 beside it)
     const uint32_t max_over = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, (uint64_t)cfg.seg_len * (uint64_t)kSegOverrun);
@@ -854,6 +936,7 @@ struct PmlPlan {
     size_t dyn_lds = 0;
     uint32_t stage_lds = 0;
     bool use_ring = false, use_ahead = false, use_pair = false;
+    bool use_deep = false;           // the walk runs on the deep rows (DevIndex::rows3: three bases per gather)
 };
 PmlPlan plan_pml(const DevIndex &ix, const LaunchCfg &cfg, uint64_t n_reads, uint64_t n_bases, int cm, bool logging, bool have_seg_ws,
                  bool ordered, bool want_mask) {
@@ -892,9 +975,14 @@ PmlPlan plan_pml(const DevIndex &ix, const LaunchCfg &cfg, uint64_t n_reads, uin
     int wpc = cfg.waves_per_cu;
     if (wpc < 0) wpc = 0;
     const bool stage_ok = cfg.stage_reads != 0 && bt == 64 && v == 14;                  // the staged kernels: one-wavefront blocks of the default walk
-    const bool ahead_ok = stage_ok && ix.rows2 != nullptr;                              // ... on the look-ahead rows where they exist
+    // ... on the deep rows where the handle holds them and the batch is one of short reads: three bases per gather pay where reads follow the
+    // text (c2: fabric lines per base 0.584 -> 0.477, 80.3 -> 89.6 Gbases/s with reset masks out); 10 kbp reads with 8 % substitutions spend
+    // their iterations on repositions, which three-row windows serve worse than four-row ones (59.3 -> 44.4): profiles/r06_deep_rows.txt
+    const bool deep_ok = stage_ok && ix.rows3 != nullptr && ix.idx32 != 0u &&
+                         (cfg.deep > 0 || (cfg.deep < 0 && n_bases / n_reads < kDeepReadLen));
+    const bool ahead_ok = stage_ok && (ix.rows2 != nullptr || deep_ok);                 // ... or on the look-ahead rows
     if (cfg.waves_per_cu == 0 && v == 14 && big_batch)
-        wpc = ahead_ok ? kCapWavesAhead : kCapWaves;                                 // the auto policy above
+        wpc = deep_ok ? kCapWavesDeep : (ahead_ok ? kCapWavesAhead : kCapWaves);     // the auto policy above
     P.wpc = wpc;
     // Occupancy cap: enforced by the dispatcher through the block's LDS allocation (160 KiB per CU); blocks beyond
     // the cap queue and start as resident ones retire.
@@ -925,6 +1013,7 @@ PmlPlan plan_pml(const DevIndex &ix, const LaunchCfg &cfg, uint64_t n_reads, uin
     P.dyn_lds = dyn_lds;
     P.stage_lds = (stage_ok && stage_cap >= 96) ? stage_cap : 0u;
     P.use_ring = ring_b != 0 && P.stage_lds != 0u;
+    P.use_deep = deep_ok && P.stage_lds != 0u;
     P.use_ahead = ahead_ok && P.stage_lds != 0u;
     // pair-shared gathers (pml_kernel_flatp<..., PSH = 1>): the staged default walk on the plain or the look-ahead rows
     // Where: on tables beyond the reach of the per-CU TLBs (~2 GB), where a lane's two (four) 16-byte loads are as many
@@ -933,7 +1022,7 @@ PmlPlan plan_pml(const DevIndex &ix, const LaunchCfg &cfg, uint64_t n_reads, uin
     // copy (16 GB); below that the exchange costs about what the merged accesses give (random 25 / 50 / 100 M rows +4 / +5 / -2 %,
     // real 113 M rows +1.5 %, c2 -2.5 %, c3 -9 %: profiles/r04_pair_shared_gathers.txt).  "pair_loads" 1 / 0 forces it.
     const uint64_t walked_bytes = ix.r * (P.use_ahead ? 16ull : 8ull);
-    P.use_pair = (cfg.pair_loads > 0 || (cfg.pair_loads < 0 && walked_bytes >= kPairLoadBytes)) && P.stage_lds != 0u && v == 14;
+    P.use_pair = (cfg.pair_loads > 0 || (cfg.pair_loads < 0 && walked_bytes >= kPairLoadBytes)) && P.stage_lds != 0u && v == 14 && !P.use_deep;
     return P;
 }
 }  // namespace
@@ -978,7 +1067,7 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     DevIndex ixl = ix;
     ixl.stage_lds = P.stage_lds;
     ixl.inwin = cfg.inwin ? 1u : 0u;
-    ixl.hint_w = (cfg.hints != 0 && ix.hints != 0u && ix.rows2 != nullptr) ? 3u : 0u;
+    ixl.hint_w = P.use_deep ? (cfg.hints != 0 ? 2u : 0u) : ((cfg.hints != 0 && ix.hints != 0u && ix.rows2 != nullptr) ? 3u : 0u);
     ixl.mask_phase = mask.phase & 31u;
     const bool mask_native = want_mask && v == 14 && P.stage_lds != 0u;
     if (want_mask && !mask_native && !d_out) return hipErrorInvalidValue;     // (pml_mask_needs_tmp told the caller)
@@ -990,7 +1079,7 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
         L.err = d_err; L.stats = d_stats;
         L.order = d_order; L.cls = cls;
         L.cls_mode = cm; L.sep = ix.sep ? 1 : 0; L.stg = ixl.stage_lds != 0u ? 1 : 0;
-        L.ahd = P.use_ahead ? 1 : 0; L.psh = P.use_pair ? 1 : 0; L.ring = mask_native ? 2 : (P.use_ring ? 1 : 0);
+        L.ahd = P.use_deep ? 2 : (P.use_ahead ? 1 : 0); L.psh = P.use_pair ? 1 : 0; L.ring = mask_native ? 2 : (P.use_ring ? 1 : 0);
         e = ix.idx32 ? launch_walk_u32(L, info) : launch_walk_u64(L, info);
     } else {
         // the base-synchronous kernels (every one takes at most 64 KiB of dynamic LDS: the cap's padding)
@@ -1008,7 +1097,7 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
         info->variant = v;
         info->block_threads = bt; info->waves_per_cu = P.wpc; info->segmented = 0; info->idx64 = ix.idx32 ? 0 : 1;
         info->staged = (int)ixl.stage_lds;
-        info->ahead = P.use_ahead ? 1 : 0;
+        info->ahead = P.use_deep ? 2 : (P.use_ahead ? 1 : 0);
     }
     if (e == hipSuccess && want_mask && !mask_native) e = launch_pml_to_mask(d_out, d_offsets, n_reads, n_bases, mask.phase, mask.words, stream);
     return e;
@@ -2264,6 +2353,14 @@ static hipError_t launch_zml_segmented(const DevIndex &ix, const uint8_t *d_base
                        n_reads, S, first, seg_in, seg_out, seg_l, seg_j, seg_rem);
     const uint32_t *d_order = nullptr;
     // K1: the lane state machine where the plain query would use it (tables up to 3 GB), else the base-synchronous kernel
+    {   // (movi_launch_log: the plan's K1 and K3 kernels by name, like the walk kernel's)
+        char nm[96];
+        if (ix.r <= (3ull << 30) / 8 && ix.r >= 8 && n_bases >= 16) snprintf(nm, sizeof(nm), "zml_kernel_flat<%d, %s, 1, 0, 0, 0>", MODE, ix.idx32 ? "unsigned int" : "unsigned long");
+        else snprintf(nm, sizeof(nm), "zml_kernel<%d, 1>", MODE);
+        note_walk_launch(nm);
+        snprintf(nm, sizeof(nm), "zml_kernel<%d, 2>", MODE);
+        note_walk_launch(nm);
+    }
     if (ix.r <= (3ull << 30) / 8 && ix.r >= 8 && n_bases >= 16) {
         if (ix.idx32)
             hipLaunchKernelGGL((zml_kernel_flat<MODE, uint32_t, 1>), dim3((unsigned)((max_seg + 63) / 64)), dim3(64), 0, stream, ix,
@@ -2298,6 +2395,11 @@ static hipError_t launch_count_flat(int mode, const DevIndex &ix, const uint8_t 
     if (wpc > 0) {
         const int bpc = wpc < 3 ? 3 : wpc;
         if (bpc < 32) dyn_lds = ((163840u / (unsigned)bpc) & ~1023u) - 1024u;
+    }
+    {
+        char nm[96];
+        snprintf(nm, sizeof(nm), "zml_kernel_flat<%d, %s, 0, 0, %d, 1>", mode, ix.idx32 ? "unsigned int" : "unsigned long", pair ? 1 : 0);
+        note_walk_launch(nm);
     }
     if (info) {
         snprintf(info->kernel, sizeof(info->kernel), "zml_kernel_flat<%d, %s, 0, 0, %d, 1>", mode, ix.idx32 ? "unsigned int" : "unsigned long", pair ? 1 : 0);
@@ -2371,6 +2473,12 @@ hipError_t launch_zml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     // 35.0: profiles/r04_zml_ahead.txt), so it is an option, not the default.
     const bool ahead = want_ahead && v == 1;
     const bool pair = v == 1 && can_pair;
+    {
+        char nm[96];
+        if (v == 1) snprintf(nm, sizeof(nm), "zml_kernel_flat<%d, %s, 0, %d, %d, 0>", mode, ix.idx32 ? "unsigned int" : "unsigned long", ahead ? 1 : 0, pair ? 1 : 0);
+        else snprintf(nm, sizeof(nm), "zml_kernel<%d, 0>", mode);
+        note_walk_launch(nm);
+    }
     if (info) {
         if (v == 1) snprintf(info->kernel, sizeof(info->kernel), "zml_kernel_flat<%d, %s, 0, %d, %d, 0>", mode, ix.idx32 ? "unsigned int" : "unsigned long",
                              ahead ? 1 : 0, pair ? 1 : 0);
@@ -2580,20 +2688,81 @@ __device__ __forceinline__ void store_word(uint16_t *O, const uint4 (&g)[4], uin
         if (8u * q + i < cnt) O[8u * q + i] = (uint16_t)(x[i >> 1] >> (16u * (i & 1u)));
 }
 
-// One lane per read: the words of a read one after the other, match_len carried in a register.
+// Short reads: a block of 256 threads takes kExpandReads consecutive reads -- their vectors are ONE contiguous stretch of the output --
+// and its threads share the stretch by groups of EIGHT CONSECUTIVE OUTPUT ELEMENTS aligned to 16 bytes: one 16-byte store per group, a
+// wavefront's stores a contiguous kilobyte.  The reads' offsets sit in LDS (the read a group starts in: a binary search over 65
+// entries); match_len before a group's first position comes from the bits below it in its mask word, or from the words before (as
+// many as the run of matches is long: long reads take the wavefront-per-read kernel below).  Groups that straddle the stretch's
+// ends are written element by element by the block that owns each element.
+// (Round 6's first two versions -- one lane per read, four 16-byte stores per word at a stride of a read: 0.81 TB/s; one thread per
+// group with the reads found by binary searches over the whole batch, two of them serial per block: 0.68 TB/s.  profiles/r06_mask_path.txt)
+constexpr uint32_t kExpandReads = 64;
 __global__ __launch_bounds__(256) void pml_expand_kernel(const uint32_t *__restrict__ words, const uint64_t *__restrict__ offs,
                                                          uint64_t n_reads, uint32_t phase, uint16_t *__restrict__ out) {
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_reads) return;
-    const uint64_t beg = offs[t];
-    const uint32_t len = (uint32_t)(offs[t + 1] - beg);
-    const uint32_t *M = words + ((beg + phase) >> 5) + t;
-    uint16_t *O = out + beg;
-    uint32_t run = 0;
-    for (uint32_t k = 0; k < len; k += 32u) {
-        uint4 g[4];
-        expand_word(M[k >> 5], run, g);
-        store_word(O + k, g, len - k < 32u ? len - k : 32u);
+    __shared__ uint64_t s_off[kExpandReads + 1];
+    const uint64_t R0 = (uint64_t)blockIdx.x * kExpandReads;
+    const uint32_t nr = (uint32_t)(n_reads - R0 < kExpandReads ? n_reads - R0 : kExpandReads);
+    for (uint32_t t = threadIdx.x; t <= nr; t += blockDim.x) s_off[t] = offs[R0 + t];
+    __syncthreads();
+    const uint64_t B0 = s_off[0], B1 = s_off[nr];
+    if (B1 == B0) return;
+    const float reads_per_pos = (float)nr / (float)(B1 - B0);                           // where a position's read is EXPECTED (exact for equal lengths)
+    for (uint64_t g = (B0 >> 3) + threadIdx.x; g * 8u < B1; g += blockDim.x) {
+        const uint64_t p0 = g * 8u > B0 ? g * 8u : B0;                                  // this block's first element of the group ...
+        const uint64_t p1 = g * 8u + 8u < B1 ? g * 8u + 8u : B1;                        // ... and one past its last
+        // the read that holds p0: the largest i with s_off[i] <= p0 (empty reads are skipped by construction) -- from the expected
+        // place, a step or two either way
+        uint32_t i = (uint32_t)((float)(p0 - B0) * reads_per_pos);
+        i = i < nr - 1u ? i : nr - 1u;
+        while (s_off[i] > p0) i -= 1;
+        while (i + 1u < nr && s_off[i + 1] <= p0) i += 1;
+        uint64_t beg = s_off[i], end = s_off[i + 1];
+        const uint32_t *M = words + ((beg + phase) >> 5) + (R0 + i);
+        uint32_t k = (uint32_t)(p0 - beg);
+        uint32_t w = k >> 5, cur = M[w];
+        uint32_t run;                                                                   // match_len before step k of read i
+        {
+            const uint32_t b = k & 31u, below = cur & ((1u << b) - 1u);
+            if (below) {
+                run = b - (32u - (uint32_t)__builtin_clz(below));
+            } else {
+                run = b;
+                uint32_t ww = w;
+                while (ww > 0) {
+                    const uint32_t m = M[--ww];
+                    if (m) { run += (uint32_t)__builtin_clz(m); break; }
+                    run += 32u;
+                }
+            }
+        }
+        uint16_t *O = out + g * 8u;
+        if (p1 - p0 == 8u && p0 + 8u <= end) {
+            // the common case: a whole group inside one read -- its eight bits from the word (and the one after it: the array has a
+            // spare word at its end), straight-line code, one aligned 16-byte store
+            const uint32_t nxt = M[w + 1];
+            const uint32_t bits = (uint32_t)((((uint64_t)nxt << 32) | cur) >> (k & 31u)) & 0xFFu;
+            uint32_t v[8];
+#pragma unroll
+            for (uint32_t e = 0; e < 8u; ++e) {
+                run = ((bits >> e) & 1u) ? 0u : run + 1u;
+                v[e] = run > 65535u ? 65535u : run;
+            }
+            *reinterpret_cast<uint4 *>(O) = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));   // (out is 16-byte aligned: the launcher's check)
+            continue;
+        }
+        // a group that crosses into the next read(s), or that straddles the stretch's ends: element by element
+        for (uint64_t p = p0; p < p1; ++p) {
+            while (p >= end) {                                                          // the next read (empty ones have no positions)
+                i += 1;
+                beg = end;
+                end = s_off[i + 1];
+                M = words + ((beg + phase) >> 5) + (R0 + i);
+                k = 0; run = 0;
+            }
+            run = ((M[k >> 5] >> (k & 31u)) & 1u) ? 0u : run + 1u;
+            O[p - g * 8u] = (uint16_t)(run > 65535u ? 65535u : run);
+            k += 1;
+        }
     }
 }
 
@@ -2641,8 +2810,12 @@ hipError_t launch_pml_expand(const uint32_t *d_words, const uint64_t *d_offsets,
         hipLaunchKernelGGL(pml_expand_wave_kernel, dim3((unsigned)n_reads), dim3(64), 0, stream, d_words, d_offsets, n_reads, phase & 31u, d_out);
         return hipGetLastError();
     }
-    const uint64_t blocks = (n_reads + 255) / 256;
+    const uint64_t blocks = (n_reads + kExpandReads - 1) / kExpandReads;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    if ((reinterpret_cast<uintptr_t>(d_out) & 15u) != 0) {  // the group kernel stores 16 aligned bytes at a time: an odd vector takes the other kernel
+        hipLaunchKernelGGL(pml_expand_wave_kernel, dim3((unsigned)n_reads), dim3(64), 0, stream, d_words, d_offsets, n_reads, phase & 31u, d_out);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(pml_expand_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d_words, d_offsets, n_reads, phase & 31u, d_out);
     return hipGetLastError();
 }

@@ -84,8 +84,23 @@ struct DevIndex {
     // In this form ids in rows2 are 32 bits wide: x alone (a row whose id is not a row reads x = 0xFFFFFFFF), and every
     // reader of rows2 masks the hint bits off (tab_row / tab_entry / the walk kernel).
     uint32_t hints;
-    // set per launch: width of a hint field the walk looks at -- 3 = use the hints, 0 = ignore them ("repo_hints" 0: A/B)
+    // set per launch: width of a hint field the walk looks at -- 3 = use the hints (2 on the deep rows), 0 = ignore them ("repo_hints" 0: A/B)
     uint32_t hint_w;
+    // Round 6 -- DEEP ROWS ("deep_rows" option; nullptr = none; tables of fewer than 2^28 - 1 rows): a copy of the table in which every row
+    // carries what the walk reads at its LF target j = id(i) AND at j2 = id(j) -- up to three bases per gather -- packed to 21.33 bytes
+    // per row (round 4's chain rows held the same in 32 bytes per row and fell out of the Infinity Cache: profiles/r04_chain_rows.txt).
+    // Window q = rows 3q .. 3q + 2 = 64 bytes at byte 64 q (two windows per 128-byte line, six rows per line); 16 dwords: row s at
+    // dwords 5s .. 5s + 4, its ten extra bits at [10s + 9 : 10s] of dword 15.  Row i, with j = id(i), j2 = id(j), j3 = id(j2):
+    //   D0 = j (28 bits; 0x0FFFFFFF = not a row) | thr0 << 28 | thr1 << 29 | thr2 << 30
+    //   D1 = n(i) | off(i) << 11 | c(i) << 22 | c(j) << 25 | c(j2) << 28          (c(j) = 7: no entry for j -- j or j2 is not a row; c(j2) = 7 likewise for j2 / j3)
+    //   D2 = j2 (28 bits) | hints[3:0] << 28
+    //   D3 = n(j) | off(j) << 11 | n(j2)[9:0] << 22
+    //   D4 = j3 (28 bits) | n(j2)[10] << 28 | off(j2)[2:0] << 29
+    //   X  = off(j2)[10:3] | hints[5:4] << 8
+    // hints: two bits per threshold slot k (bits 2k + 1 : 2k): rows beyond the edge of the row's three-row window at which the nearest run
+    // of the slot's base lies in the direction the threshold bit gives, 1 .. 3; 0 = inside the window, further, nowhere, or the '$' row.
+    // The rows of the last window beyond r - 1 are padding (c = 7, n = 0, never reached).
+    const uint8_t *rows3;
 };
 
 // Device counters of one query call.
@@ -106,9 +121,11 @@ struct DevStats {
 constexpr int kCountCapWaves = 16;   // the count kernel's cap on cache-resident tables (launch_count)
 constexpr int kCapWaves = 7;   // resident wavefronts per CU of the lane state machine on big batches (round 2: 9, optimum 8-10; round 3, with the reads staged in LDS and the top-of-walk table: 6-8, profiles/r03_occupancy_sweep.txt)
 constexpr int kCapWavesAhead = 9;    // ... when the walk runs on the look-ahead rows: fewer lines per base, more walks in flight pay (profiles/r03_ahead_rows_ab.txt)
+constexpr int kCapWavesDeep = 13;    // ... on the deep rows: fewer lines per base again and more instructions per iteration (c2, cap 9 / 11 / 13 / 14 / 16: vector out 71.8 / 75.7 / 78.4 / 78.7 / 77.9, reset masks out 87.3 / 89.9 / 89.4 / 89.5 / 87.8 Gbases/s: profiles/r06_deep_rows.txt)
 constexpr uint32_t kOutRingBytes = 4096;          // pml_kernel_flatp<..., RING = 1>: the ring in the block's dynamic LDS its PMLs leave through (32 per lane)
 constexpr uint64_t kOutRingReadLen = 1024;        // ... on by itself for batches whose mean read length is at least this (launch_pml)
 constexpr uint32_t kTallySlots = 512;             // pairs of u64 counters a builder's tally is spread over (d_tally: 2 * kTallySlots u64, zeroed)
+constexpr uint64_t kDeepReadLen = 1024;           // launch_pml: batches whose mean read length is below this walk on the deep rows (where the handle holds them)
 constexpr uint64_t kPairLoadBytes = 2ull << 30;   // walked tables of this size and more: pair-shared gathers (launch_pml)
 
 struct LaunchCfg {
@@ -132,6 +149,7 @@ struct LaunchCfg {
     int pair_loads = -1;   // the lanes of a pair fetch their row windows together (pml_kernel_flatp<..., PSH = 1>): -1 auto (tables of 2 GB and more), 0 never, 1 always
     int hints = 1;         // 1: mismatches whose scan leaves the row window jump by the reposition hints of the look-ahead rows (DevIndex::hints); 0 = off: A/B
     int zml_ahead = 0;     // 1: zml_kernel_flat<6, T, 0, 1> on the look-ahead rows where they exist (a third fewer iterations, no faster: opt-in)
+    int deep = -1;         // the PML walk on the deep rows (DevIndex::rows3) where the handle holds them: -1 = batches of short reads (mean length < kDeepReadLen), 0 never, 1 always
 };
 
 // What a launch_* call actually launched (movi_last_launch): the policy lives in the launchers, so they say what they picked.
@@ -298,6 +316,11 @@ hipError_t build_kmer_table(const DevIndex &ix, uint32_t K, uint4 *d_table, hipS
 // Look-ahead rows (DevIndex::rows2): ahead_rows_bytes(r) bytes at d_rows2, written by one kernel (a gather of id(id(i))
 // per row); *tail = DevIndex::rows2_tail.  Thresholds types (kmode 6: the PML walk's rows), r >= 8.
 uint64_t ahead_rows_bytes(uint64_t r);
+// Deep rows (DevIndex::rows3): deep_rows_bytes(r) bytes at d_rows3 (zeroed by the call), one kernel (three dependent gathers per row).
+// Thresholds types (kmode 6), 8 <= r < 2^28 - 1.
+uint64_t deep_rows_bytes(uint64_t r);
+bool deep_rows_eligible(uint64_t r);
+hipError_t build_deep_rows(int kmode, const DevIndex &ix, uint8_t *d_rows3, hipStream_t stream);
 bool ahead_rows_hinted(uint64_t r);    // the copy of a table of r rows carries reposition hints and 32-bit ids (DevIndex::hints)
 hipError_t build_ahead_rows(int kmode, const DevIndex &ix, uint8_t *d_rows2, uint64_t *tail, hipStream_t stream,
                             unsigned long long *d_tally = nullptr);   // d_tally: 2 * kTallySlots zeroed u64 (tally_add spreads the atomics by block; the caller sums the pairs), optional

@@ -54,7 +54,8 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
                                                        ClsArgs cls, SegArgs seg) {
     static_assert(SEG == 0 || CLS == 0, "segments: plain PML");
     static_assert(AHD == 0 || STG == 1, "look-ahead rows: staged reads");
-    static_assert(AHD == 0 || AHD == 1, "plain rows or look-ahead rows");
+    static_assert(AHD == 0 || AHD == 1 || AHD == 2, "plain rows, look-ahead rows or deep rows");
+    static_assert(AHD != 2 || (PSH == 0 && sizeof(IdxT) == 4), "deep rows: tables of fewer than 2^28 rows, no pair-shared gathers");
     static_assert(PSH == 0 || STG == 1, "pair-shared gathers: staged kernels");
     static_assert(RING == 0 || STG == 1, "PMLs out through the LDS ring / as reset masks: staged kernels");
     static_assert(RING != 2 || (CLS == 0 && SEG == 0), "reset masks: plain PML of whole reads");
@@ -126,8 +127,18 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
     };
     uint2 ahw[4];                                         // AHD: the look-ahead entries of the window's four rows ...
     uint4 raw[4];                                         // PSH: what this lane loaded for its pair (rows: 0, 1; entries: 2, 3), assembled at the loop's top
+    uint4 dq[4];                                          // AHD == 2: the 64-byte window of the deep rows (three rows of 5 dwords + their 10 extra bits each in dword 15)
     const uint32_t odd_lane = threadIdx.x & 1u;
     auto fetch = [&](IdxT nd, bool act, uint2 (&w)[4]) {
+        if (AHD == 2) {                                   // window q = rows 3q .. 3q + 2 at byte 64 q (DevIndex::rows3); the last window is padded
+            const uint32_t q3 = __umulhi((uint32_t)nd, 0xAAAAAAABu) >> 1;
+            const uint8_t *at = ix.rows3 + (act ? (uint64_t)q3 * 64u : 0u);
+            __builtin_memcpy(&dq[0], at, 16);
+            __builtin_memcpy(&dq[1], at + 16, 16);
+            __builtin_memcpy(&dq[2], at + 32, 16);
+            __builtin_memcpy(&dq[3], at + 48, 16);
+            return;
+        }
         if (PSH) {
             // byte offset of this lane's window in the table it walks on (AHD: the look-ahead copy, entries 64 bytes further on)
             uint64_t at;
@@ -340,8 +351,9 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
         }
     }
     // AHD: the code of the base after the current one (beyond the read's end: never looked at)
-    uint32_t a1 = 0xFFu;
+    uint32_t a1 = 0xFFu, a2 = 0xFFu;
     if (AHD) a1 = staged_code(k + 1);
+    if (AHD == 2) a2 = staged_code(k + 2);
     uint2 w[4];
     fetch(need, st != sDone, w);
 
@@ -357,162 +369,297 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
             for (int i = 0; i < MOVI_PAD_PRE; ++i) asm volatile("v_add_u32 %0, %0, %0" : "+v"(pad));
         }
 #endif
-        if (PSH) {                                        // the halves the pair loaded for each other change hands
-            pair_assemble(odd_lane, raw[0], raw[1], w);
-            if (AHD) pair_assemble(odd_lane, raw[2], raw[3], ahw);
-        }
-        const IdxT wbase = win_base(need);
-        // cheap hop: a fast-forward or scan step that only moves on (everything that resolves a base,
-        // starts a scan, ends one or fails is left to the full step below)
-        auto hop = [&]() {
-            const uint32_t q = (uint32_t)(need - wbase);
-            const uint32_t inwin = (uint32_t)(q < WN) & (uint32_t)(st < sDone);
-            const uint2 hr = win_sel(w, q);
-            const uint32_t hn = row_n<MODE>(hr), hc = row_c<MODE>(hr);
-            const uint32_t ffh = inwin & (uint32_t)(st == sFF) & (uint32_t)(need < r1) & (uint32_t)(off >= hn) &
-                                 (uint32_t)(ff_run + 1 < 65535u);
-            const uint32_t nomatch = hc != a;
-            const uint32_t dnh = inwin & (uint32_t)(st == sDown) & nomatch & (uint32_t)(need < r1);
-            const uint32_t uph = inwin & (uint32_t)(st == sUp) & nomatch & (uint32_t)(need != 0);
-            off = ffh ? off - hn : off;
-            ff_run += ffh;
-            scan_total += dnh | uph;
-            need = need + (IdxT)(ffh + dnh) - (IdxT)uph;
-        };
-        // "window-parallel" advance: everything the hops could do inside this window, in closed form instead
-        // of one dependent select-compare-update round per hop.  A fast-forward passes row i iff off >= the running sum of
-        // the lengths up to and including i (monotone, so the number of rows passed is a sum of four compares); a scan
-        // passes the leading run of non-matching rows from its position (a 4-bit mask and a count-trailing / leading-ones).
-        // Same state afterwards as four hop() calls -- identical answers and counts -- at a third of the dependency depth.
-        // bit i of nm = row i of the window does not hold the base of step k
-        const uint32_t nm = (uint32_t)(row_c<MODE>(w[0]) != a) | ((uint32_t)(row_c<MODE>(w[1]) != a) << 1) |
-                            ((uint32_t)(row_c<MODE>(w[2]) != a) << 2) | ((uint32_t)(row_c<MODE>(w[3]) != a) << 3);
-        const uint32_t last_win = (uint32_t)(wbase + 3 == r1);             // the table ends inside (at the end of) this window
-        const uint32_t first_win = (uint32_t)(wbase == 0);
-        auto window_advance = [&]() {
-            const uint32_t q0 = (uint32_t)(need - wbase);
-            const uint32_t inwin = (uint32_t)(q0 < 4u) & (uint32_t)(st < sDone);
-            const uint32_t n0 = row_n<MODE>(w[0]), n1 = row_n<MODE>(w[1]), n2 = row_n<MODE>(w[2]), n3 = row_n<MODE>(w[3]);
-            // ---- fast-forward: rows q0 .. 3 (need < r1 can only fail at index 3 of the last window)
-            const uint32_t m0 = q0 == 0u, m1 = q0 <= 1u, m2 = q0 <= 2u;   // row i takes part (i >= q0); row 3 always does
-            const uint32_t t1 = m0 ? n0 : 0u, t2 = t1 + (m1 ? n1 : 0u), t3 = t2 + (m2 ? n2 : 0u), t4 = t3 + n3;
-            const uint32_t isff = inwin & (uint32_t)(st == sFF);
-            const uint32_t p0 = isff & m0 & (uint32_t)(off >= t1), p1 = isff & m1 & (uint32_t)(off >= t2),
-                           p2 = isff & m2 & (uint32_t)(off >= t3), p3 = isff & (uint32_t)(off >= t4) & (last_win ^ 1u);
-            const uint32_t cf = p0 + p1 + p2 + p3;
-            off -= (p3 ? t4 : (p2 ? t3 : (p1 ? t2 : (p0 ? t1 : 0u))));
-            ff_run += cf;
-            // ---- scans
-            // down: leading run of 1s from bit q0 upwards; row r-1 is never passed (need < r1)
-            const uint32_t dmask = (nm & (last_win ? 7u : 15u)) >> (q0 & 3u);
-            const uint32_t cd = (inwin & (uint32_t)(st == sDown)) ? (uint32_t)__builtin_ctz(~dmask | 16u) : 0u;
-            // up: leading run of 1s from bit q0 downwards; row 0 is never passed (need != 0)
-            const uint32_t umask = ((nm & (first_win ? 14u : 15u)) << (3u - (q0 & 3u))) & 15u;
-            const uint32_t cu = (inwin & (uint32_t)(st == sUp)) ? (uint32_t)__builtin_clz(((~umask) & 15u) << 28 | 0x08000000u) : 0u;
-            scan_total += cd + cu;
-            need = need + (IdxT)(cf + cd) - (IdxT)cu;
-        };
-        if (wave_any(st == sFF && ff_run >= 65520u)) {
-            for (int h = 0; h < 4; ++h) hop();                       // near the reference's fast-forward limit: step by step
-        } else {
-            window_advance();
-        }
-        const uint32_t qn = (uint32_t)(need - wbase);
-        const uint32_t inwin = (uint32_t)(qn < WN) & (uint32_t)act;
-        const uint2 row = win_sel(w, qn);
-        const uint32_t n = row_n<MODE>(row), c = row_c<MODE>(row);
-        const uint32_t isFF = (uint32_t)(st == sFF) & inwin, isDown = (uint32_t)(st == sDown) & inwin,
-                       isUp = (uint32_t)(st == sUp) & inwin;
-        // fast_forward, move_structure.cpp:524-545
-        const uint32_t ffm = isFF & (uint32_t)(need < r1) & (uint32_t)(off >= n);
-        const uint32_t ff_over = ffm & (uint32_t)(ff_run + 1 >= 65535u);  // :72-75
-        const uint32_t resolved = isFF & (ffm ^ 1u);
-        // the base of step k against the row (read_processor.cpp:188-238)
-        const uint32_t illegal = a == 0xFFu, match = c == a;
-        const uint32_t mism = resolved & (illegal ^ 1u) & (match ^ 1u);
-        // reposition_thresholds, src/move_structure_query.cpp:513-601
-        // (SEP is a template parameter here: the separator branch and its selects sit on the critical path
-        // between the window's arrival and the next gather, and cost 4 % on c3 as a run-time flag)
-        const uint32_t kk = thr_slot(SEP, a, c);                          // alphamap_3[c][a]
-        uint32_t thr = row_thr<MODE>(row, kk > 2u ? 2u : kk) ? n : 0u;
-        if (SEP) {                                                        // a row of the separator: side table
-            if (mism & (uint32_t)(c == 0u) & (uint32_t)(need != end_row)) thr = separator_threshold(ix, (uint64_t)need, a);
-        }
-        const uint32_t down = (uint32_t)(off >= ((need == end_row) ? end_threshold(SEP, ethr, a) : thr));
-        const uint32_t at_last = need >= r1, at_first = need == 0;
-        const uint32_t repo_edge = mism & (down ? at_last : at_first);
-        // reposition_down :211-232 / reposition_up :188-209.  A run of the base among the window's OTHER rows is found in
-        // this very iteration (the nearest one in the scan's direction: what the row-by-row scan stops at) -- a reposition
-        // whose target shares the window costs no round trip of its own (tools/iter_model.c: half of all repositions; lane
-        // iterations per base -5 % on 150 bp reads with 1 % substitutions, -15 % on 10 kbp reads with 8 %).  Anything
-        // further away is scanned for one window per iteration, as before.
-        const uint32_t has = (nm ^ 15u) & (down ? (14u << (qn & 3u)) & 15u : (1u << (qn & 3u)) - 1u);   // rows that hold the base, beyond row qn
-        const uint32_t found = mism & (uint32_t)(has != 0u) & ix.inwin;
-        const uint32_t qf = found ? (down ? (uint32_t)__builtin_ctz(has | 16u) : 31u - (uint32_t)__builtin_clz(has | 1u)) : qn;
-        const uint32_t far = mism & (found ^ 1u);                          // the scan leaves the window
-        const uint2 rowf = win_sel(w, qf);                                 // the row the base is resolved at, if it is resolved now
-        const uint32_t nf = row_n<MODE>(rowf), rofff = row_off<MODE>(rowf);
-        const IdxT needf = (IdxT)(wbase + qf);
-        const uint32_t scanning = isDown | isUp;
-        const uint32_t hit = scanning & match;
-        const uint32_t landed = hit | found;                               // a scan ended at this row: offset 0 / n - 1 (read_processor.cpp:223)
-        const uint32_t landed_down = hit ? isDown : down;
-        const uint32_t scan_edge = scanning & (hit ^ 1u) & (isDown ? at_last : at_first);
-        const uint32_t emit = (resolved & (illegal | match)) | landed;
-        // LF_move of the emitted base, move_structure.cpp:59-67 (emit and the error cases are exclusive)
-        const uint32_t lf = emit & (uint32_t)(k + 1 != len);
-        // (ids in the look-ahead copy of a table of fewer than 2^32 - 1 rows are 32 bits wide: DevIndex::hints)
-        constexpr bool id32 = AHD != 0 && sizeof(IdxT) == 4;
-        uint64_t j = 0;
-        if (id32) j = (uint64_t)rowf.x;
-        else if (MODE == 6 || lf) j = (AHD && ix.hints) ? (uint64_t)rowf.x : row_id<MODE>(rowf, needf, ix);
-        const uint32_t lf_bad = lf & (uint32_t)(j >= ix.r);
-        // AHD: the entry of the row the base is resolved at -- or, on a mismatch that is not resolved here, of the row it was seen at
-        uint2 ah = make_uint2(0u, 0u);
-        if (AHD) ah = win_sel(ahw, qf);
-        // Reposition hints (DevIndex::hints): a mismatch whose scan leaves the window knows, for scans of up to 7 rows beyond the
-        // window's edge, WHERE the scan ends -- the next iteration gathers that row's window (in the scanning state: the row
-        // matches, the scan lands there) instead of the neighbouring window, and the ones after it.  tools/iter_model.c: lane
-        // iterations per base 1.123 -> 0.987 on 10 kbp reads with 8 % substitutions, 0.649 -> 0.626 on 150 bp reads with 1 %.
-        uint32_t jump = 0, jdist = 0;
-        IdxT jtgt = 0;
-        if (AHD) {
-            const uint32_t hbits = (rowf.y >> 28) | ((ah.y >> 21) & 0x3F0u);
+        // What the analysis of this iteration's window hands to the bookkeeping below (the two layouts -- four-row windows of 8-byte rows
+        // with or without look-ahead entries; three-row windows of deep rows -- analyse their windows in their own code and meet here).
+        struct StepOut {
+            uint32_t resolved, match, ffm, lf, mism, scanning, found, down, qf, qn, jump, jdist, landed, landed_down, nf, n, rofff, emit;
+            uint32_t dbl, lf2, off1, tpl, lf3, off2, errc, st_next;
+            uint64_t j;
+            IdxT needf, need_next, j2, j3;
+        } R;
+        R.tpl = 0; R.lf3 = 0; R.off2 = 0; R.j3 = 0;
+        if (AHD == 2) {
+            // ---- DEEP ROWS (round 6; DevIndex::rows3): the window is the aligned group of THREE rows that holds `need` (64 bytes: half a
+            // cache line), and every row carries what the walk reads at its LF target j AND at j's target j2 -- so that up to THREE
+            // bases are resolved per gather: base k here; base k + 1 at j if it is c(j) and the offset arrives below n(j); base k + 2 at
+            // j2 likewise; then the gather goes to j3 = id(j2).  Same automaton, same answers as the four-row code in the other branch.
+            const uint32_t need32 = (uint32_t)need;
+            const uint32_t wbase = (__umulhi(need32, 0xAAAAAAABu) >> 1) * 3u;
+            const uint32_t r1u = (uint32_t)r1;
+            const uint32_t d1a = dq[0].y, d1b = dq[1].z, d1c = dq[2].w;                   // dword 1 of rows 0, 1, 2: n | off << 11 | c << 22 | ...
+            const uint32_t n0 = d1a & 0x7FFu, n1w = d1b & 0x7FFu, n2w = d1c & 0x7FFu;
+            const uint32_t nm = (uint32_t)(((d1a >> 22) & 7u) != a) | ((uint32_t)(((d1b >> 22) & 7u) != a) << 1) | ((uint32_t)(((d1c >> 22) & 7u) != a) << 2);
+            const uint32_t lim = r1u - wbase;                                              // rows of the window before row r - 1 (>= 3 everywhere but in the last window)
+            const uint32_t first_win = (uint32_t)(wbase == 0u);
+            uint32_t nd = need32;
+            {   // window_advance for three rows, in closed form (near the reference's fast-forward limit the count is clamped: `room`)
+                const uint32_t q0 = nd - wbase;
+                const uint32_t inw = (uint32_t)(q0 < 3u) & (uint32_t)(st < sDone);
+                const uint32_t m0 = q0 == 0u, m1 = q0 <= 1u;
+                const uint32_t t1 = m0 ? n0 : 0u, t2 = t1 + (m1 ? n1w : 0u), t3 = t2 + n2w;
+                const uint32_t isff = inw & (uint32_t)(st == sFF);
+                const uint32_t room = 65534u - (ff_run < 65534u ? ff_run : 65534u);       // fast-forwards left before the reference throws (:72-75): the throw itself is the full step's
+                uint32_t p0 = isff & m0 & (uint32_t)(off >= t1) & (uint32_t)(0u < lim), p1 = isff & m1 & (uint32_t)(off >= t2) & (uint32_t)(1u < lim),
+                         p2 = isff & (uint32_t)(off >= t3) & (uint32_t)(2u < lim);
+                uint32_t cf = p0 + p1 + p2;
+                if (cf > room) {                                                           // (practically never) stop where the limit is: rows are passed in order
+                    cf = room;
+                    const uint32_t first = m0 ? 0u : (m1 ? 1u : 2u);                       // first row that takes part
+                    p0 = p0 & (uint32_t)(first + cf > 0u);
+                    p1 = p1 & (uint32_t)(first + cf > 1u);
+                    p2 = p2 & (uint32_t)(first + cf > 2u);
+                }
+                off -= (p2 ? t3 : (p1 ? t2 : (p0 ? t1 : 0u)));
+                ff_run += cf;
+                const uint32_t dmask = (nm & (lim >= 3u ? 7u : ((1u << lim) - 1u))) >> q0;    // row r - 1 is never passed
+                const uint32_t cd = (inw & (uint32_t)(st == sDown)) ? (uint32_t)__builtin_ctz(~dmask | 8u) : 0u;
+                const uint32_t umask = ((nm & (first_win ? 6u : 7u)) << (2u - (q0 < 3u ? q0 : 2u))) & 7u;   // row 0 is never passed
+                const uint32_t cu = (inw & (uint32_t)(st == sUp)) ? (uint32_t)__builtin_clz(((~umask) & 7u) << 29 | 0x10000000u) : 0u;
+                scan_total += cd + cu;
+                nd = nd + cf + cd - cu;
+            }
+            need = (IdxT)nd;
+            const uint32_t qn = nd - wbase;
+            const uint32_t inwin = (uint32_t)(qn < 3u) & (uint32_t)act;
+            auto sel3 = [](uint32_t x0, uint32_t x1, uint32_t x2, uint32_t q) { return q == 0u ? x0 : (q == 1u ? x1 : x2); };
+            const uint32_t rD0 = sel3(dq[0].x, dq[1].y, dq[2].z, qn), rD1 = sel3(d1a, d1b, d1c, qn);
+            const uint32_t n = rD1 & 0x7FFu, c = (rD1 >> 22) & 7u;
+            const uint32_t isFF = (uint32_t)(st == sFF) & inwin, isDown = (uint32_t)(st == sDown) & inwin, isUp = (uint32_t)(st == sUp) & inwin;
+            const uint32_t ffm = isFF & (uint32_t)(nd < r1u) & (uint32_t)(off >= n);       // fast_forward, move_structure.cpp:524-545
+            const uint32_t ff_over = ffm & (uint32_t)(ff_run + 1 >= 65535u);               // :72-75
+            const uint32_t resolved = isFF & (ffm ^ 1u);
+            const uint32_t illegal = a == 0xFFu, match = c == a;
+            const uint32_t mism = resolved & (illegal ^ 1u) & (match ^ 1u);
+            const uint32_t kk = thr_slot(SEP, a, c);                                       // alphamap_3[c][a]
             const uint32_t kc = kk > 2u ? 2u : kk;
-            const uint32_t hd = __builtin_amdgcn_ubfe(hbits, kc + 2u * kc, ix.hint_w);          // (hint_w: 3, or 0 = no hints / switched off)
-            jump = far & (uint32_t)(hd != 0u);
-            jtgt = down ? (IdxT)(wbase + 3u + hd) : (IdxT)(wbase - hd);
-            jdist = down ? (uint32_t)(jtgt - need) : (uint32_t)(need - jtgt);
-        }
-        const uint32_t step_fwd = ffm | (far & down) | (scanning & (hit ^ 1u) & isDown);
-        const uint32_t step_back = (far & (down ^ 1u)) | (scanning & (hit ^ 1u) & isUp);
-        IdxT need_next = lf ? (IdxT)j : (jump ? jtgt : (IdxT)(need + step_fwd - step_back));
-        uint32_t st_next = (emit & (lf ^ 1u)) ? sDone : (lf ? sFF : (far ? (down ? sDown : sUp) : st));
-        // AHD: the base after this one, resolved at the LF target from the look-ahead entry (read_processor.cpp:188-238 with
-        // match and no fast-forward: ml + 1, then LF_move again) -- the target row itself is never fetched
-        uint32_t dbl = 0, lf2 = 0, off1 = 0;
-        IdxT j2 = 0;
-        if (AHD) {
-            const uint32_t n1 = ah.y & 0x7FFu, c1 = (ah.y >> 22) & 7u;
+            uint32_t thr = ((rD0 >> (28u + kc)) & 1u) ? n : 0u;
+            if (SEP) {
+                if (mism & (uint32_t)(c == 0u) & (uint32_t)(need != end_row)) thr = separator_threshold(ix, (uint64_t)need, a);
+            }
+            const uint32_t down = (uint32_t)(off >= ((need == end_row) ? end_threshold(SEP, ethr, a) : thr));
+            const uint32_t at_last = nd >= r1u, at_first = nd == 0u;
+            const uint32_t repo_edge = mism & (down ? at_last : at_first);
+            const uint32_t has = (nm ^ 7u) & (down ? (6u << qn) & 7u : (1u << qn) - 1u);   // rows of the window that hold the base, beyond row qn
+            const uint32_t found = mism & (uint32_t)(has != 0u) & ix.inwin;
+            const uint32_t qf = found ? (down ? (uint32_t)__builtin_ctz(has | 8u) : 31u - (uint32_t)__builtin_clz(has | 1u)) : qn;
+            const uint32_t far = mism & (found ^ 1u);
+            // the row the base is resolved at (qf): its five dwords and ten extra bits
+            const uint32_t f0 = sel3(dq[0].x, dq[1].y, dq[2].z, qf), f1 = sel3(d1a, d1b, d1c, qf), f2 = sel3(dq[0].z, dq[1].w, dq[3].x, qf),
+                           f3 = sel3(dq[0].w, dq[2].x, dq[3].y, qf), f4 = sel3(dq[1].x, dq[2].y, dq[3].z, qf);
+            const uint32_t fx = (dq[3].w >> (10u * (qf < 3u ? qf : 0u))) & 0x3FFu;
+            const uint32_t nf = f1 & 0x7FFu, rofff = (f1 >> 11) & 0x7FFu;
+            const uint32_t scanning = isDown | isUp;
+            const uint32_t hit = scanning & match;
+            const uint32_t landed = hit | found;
+            const uint32_t landed_down = hit ? isDown : down;
+            const uint32_t scan_edge = scanning & (hit ^ 1u) & (isDown ? at_last : at_first);
+            const uint32_t emit = (resolved & (illegal | match)) | landed;
+            const uint32_t lf = emit & (uint32_t)(k + 1 != len);
+            const uint32_t jj = f0 & 0x0FFFFFFFu;                                           // id(row): 28 bits; 0x0FFFFFFF = not a row (r < 2^28)
+            const uint32_t lf_bad = lf & (uint32_t)(jj >= (uint32_t)ix.r);
+            // reposition hints: two bits per threshold slot (rows beyond the window's edge: 1 .. 3)
+            const uint32_t h6 = (f2 >> 28) | ((fx >> 8) << 4);
+            const uint32_t hd = __builtin_amdgcn_ubfe(h6, kc + kc, ix.hint_w);            // (hint_w: 2 here, or 0 = switched off)
+            const uint32_t jump = far & (uint32_t)(hd != 0u);
+            const uint32_t jtgt = down ? wbase + 2u + hd : wbase - hd;
+            const uint32_t jdist = down ? jtgt - nd : nd - jtgt;
+            const uint32_t step_fwd = ffm | (far & down) | (scanning & (hit ^ 1u) & isDown);
+            const uint32_t step_back = (far & (down ^ 1u)) | (scanning & (hit ^ 1u) & isUp);
+            uint32_t need_next = lf ? jj : (jump ? jtgt : nd + step_fwd - step_back);
+            uint32_t st_next = (emit & (lf ^ 1u)) ? sDone : (lf ? sFF : (far ? (down ? sDown : sUp) : st));
+            // the two bases after this one, at j and at j2 (read_processor.cpp:188-238 with match and no fast-forward: ml + 1, LF_move again)
+            const uint32_t e1n = f3 & 0x7FFu, e1off = (f3 >> 11) & 0x7FFu, e1c = (f1 >> 25) & 7u, jj2 = f2 & 0x0FFFFFFFu;
+            const uint32_t e2n = (f3 >> 22) | (((f4 >> 28) & 1u) << 10), e2off = ((f4 >> 29) & 7u) | ((fx & 0xFFu) << 3), e2c = (f1 >> 28) & 7u,
+                           jj3 = f4 & 0x0FFFFFFFu;
             const uint32_t off_e = (landed ? (landed_down ? 0u : nf - 1u) : off) + rofff;
-            dbl = lf & (ah.y >> 31) & (uint32_t)(a1 == c1) & (uint32_t)(off_e < n1);
-            lf2 = dbl & (uint32_t)(k + 2 != len);
-            off1 = (ah.y >> 11) & 0x7FFu;
-            j2 = (id32 || ix.hints) ? (IdxT)ah.x : (IdxT)((uint64_t)ah.x | ((uint64_t)((ah.y >> 25) & 15u) << 32));
-            need_next = dbl ? (lf2 ? j2 : need) : need_next;
-            st_next = dbl ? (lf2 ? sFF : sDone) : st_next;
+            const uint32_t dbl = lf & (uint32_t)(a1 == e1c) & (uint32_t)(off_e < e1n);    // (an invalid entry has c = 7: no base code equals it)
+            const uint32_t lf2 = dbl & (uint32_t)(k + 2 != len);
+            const uint32_t off_e2 = off_e + e1off;
+            const uint32_t tpl = lf2 & (uint32_t)(a2 == e2c) & (uint32_t)(off_e2 < e2n);
+            const uint32_t lf3 = tpl & (uint32_t)(k + 3 != len);
+            need_next = tpl ? (lf3 ? jj3 : nd) : (dbl ? (lf2 ? jj2 : nd) : need_next);
+            st_next = tpl ? (lf3 ? sFF : sDone) : (dbl ? (lf2 ? sFF : sDone) : st_next);
+            uint32_t errc = kErrNone;
+            if (wave_any((ff_over | repo_edge | scan_edge | lf_bad) != 0u)) {
+                errc = ff_over ? kErrFastForward
+                               : (repo_edge ? (down ? kErrNoRunBelow : kErrNoRunAbove)
+                                  : (scan_edge ? (isDown ? kErrNoRunBelow : kErrNoRunAbove)
+                                     : (lf_bad ? kErrIdRange : kErrNone)));
+                if (errc) { need_next = nd; st_next = sDone; }
+            }
+            R.resolved = resolved; R.match = match; R.ffm = ffm; R.lf = lf; R.mism = mism; R.scanning = scanning; R.found = found; R.down = down;
+            R.qf = qf; R.qn = qn; R.jump = jump; R.jdist = jdist; R.landed = landed; R.landed_down = landed_down; R.nf = nf; R.n = n; R.rofff = rofff;
+            R.emit = emit; R.dbl = dbl; R.lf2 = lf2; R.off1 = e1off; R.tpl = tpl; R.lf3 = lf3; R.off2 = e2off; R.errc = errc; R.st_next = st_next;
+            R.j = jj; R.needf = (IdxT)(wbase + qf); R.need_next = (IdxT)need_next; R.j2 = (IdxT)jj2; R.j3 = (IdxT)jj3;
+        } else {
+            if (PSH) {                                        // the halves the pair loaded for each other change hands
+                pair_assemble(odd_lane, raw[0], raw[1], w);
+                if (AHD) pair_assemble(odd_lane, raw[2], raw[3], ahw);
+            }
+            const IdxT wbase = win_base(need);
+            // cheap hop: a fast-forward or scan step that only moves on (everything that resolves a base,
+            // starts a scan, ends one or fails is left to the full step below)
+            auto hop = [&]() {
+                const uint32_t q = (uint32_t)(need - wbase);
+                const uint32_t inwin = (uint32_t)(q < WN) & (uint32_t)(st < sDone);
+                const uint2 hr = win_sel(w, q);
+                const uint32_t hn = row_n<MODE>(hr), hc = row_c<MODE>(hr);
+                const uint32_t ffh = inwin & (uint32_t)(st == sFF) & (uint32_t)(need < r1) & (uint32_t)(off >= hn) &
+                                     (uint32_t)(ff_run + 1 < 65535u);
+                const uint32_t nomatch = hc != a;
+                const uint32_t dnh = inwin & (uint32_t)(st == sDown) & nomatch & (uint32_t)(need < r1);
+                const uint32_t uph = inwin & (uint32_t)(st == sUp) & nomatch & (uint32_t)(need != 0);
+                off = ffh ? off - hn : off;
+                ff_run += ffh;
+                scan_total += dnh | uph;
+                need = need + (IdxT)(ffh + dnh) - (IdxT)uph;
+            };
+            // "window-parallel" advance: everything the hops could do inside this window, in closed form instead
+            // of one dependent select-compare-update round per hop.  A fast-forward passes row i iff off >= the running sum of
+            // the lengths up to and including i (monotone, so the number of rows passed is a sum of four compares); a scan
+            // passes the leading run of non-matching rows from its position (a 4-bit mask and a count-trailing / leading-ones).
+            // Same state afterwards as four hop() calls -- identical answers and counts -- at a third of the dependency depth.
+            // bit i of nm = row i of the window does not hold the base of step k
+            const uint32_t nm = (uint32_t)(row_c<MODE>(w[0]) != a) | ((uint32_t)(row_c<MODE>(w[1]) != a) << 1) |
+                                ((uint32_t)(row_c<MODE>(w[2]) != a) << 2) | ((uint32_t)(row_c<MODE>(w[3]) != a) << 3);
+            const uint32_t last_win = (uint32_t)(wbase + 3 == r1);             // the table ends inside (at the end of) this window
+            const uint32_t first_win = (uint32_t)(wbase == 0);
+            auto window_advance = [&]() {
+                const uint32_t q0 = (uint32_t)(need - wbase);
+                const uint32_t inwin = (uint32_t)(q0 < 4u) & (uint32_t)(st < sDone);
+                const uint32_t n0 = row_n<MODE>(w[0]), n1 = row_n<MODE>(w[1]), n2 = row_n<MODE>(w[2]), n3 = row_n<MODE>(w[3]);
+                // ---- fast-forward: rows q0 .. 3 (need < r1 can only fail at index 3 of the last window)
+                const uint32_t m0 = q0 == 0u, m1 = q0 <= 1u, m2 = q0 <= 2u;   // row i takes part (i >= q0); row 3 always does
+                const uint32_t t1 = m0 ? n0 : 0u, t2 = t1 + (m1 ? n1 : 0u), t3 = t2 + (m2 ? n2 : 0u), t4 = t3 + n3;
+                const uint32_t isff = inwin & (uint32_t)(st == sFF);
+                const uint32_t p0 = isff & m0 & (uint32_t)(off >= t1), p1 = isff & m1 & (uint32_t)(off >= t2),
+                               p2 = isff & m2 & (uint32_t)(off >= t3), p3 = isff & (uint32_t)(off >= t4) & (last_win ^ 1u);
+                const uint32_t cf = p0 + p1 + p2 + p3;
+                off -= (p3 ? t4 : (p2 ? t3 : (p1 ? t2 : (p0 ? t1 : 0u))));
+                ff_run += cf;
+                // ---- scans
+                // down: leading run of 1s from bit q0 upwards; row r-1 is never passed (need < r1)
+                const uint32_t dmask = (nm & (last_win ? 7u : 15u)) >> (q0 & 3u);
+                const uint32_t cd = (inwin & (uint32_t)(st == sDown)) ? (uint32_t)__builtin_ctz(~dmask | 16u) : 0u;
+                // up: leading run of 1s from bit q0 downwards; row 0 is never passed (need != 0)
+                const uint32_t umask = ((nm & (first_win ? 14u : 15u)) << (3u - (q0 & 3u))) & 15u;
+                const uint32_t cu = (inwin & (uint32_t)(st == sUp)) ? (uint32_t)__builtin_clz(((~umask) & 15u) << 28 | 0x08000000u) : 0u;
+                scan_total += cd + cu;
+                need = need + (IdxT)(cf + cd) - (IdxT)cu;
+            };
+            if (wave_any(st == sFF && ff_run >= 65520u)) {
+                for (int h = 0; h < 4; ++h) hop();                       // near the reference's fast-forward limit: step by step
+            } else {
+                window_advance();
+            }
+            const uint32_t qn = (uint32_t)(need - wbase);
+            const uint32_t inwin = (uint32_t)(qn < WN) & (uint32_t)act;
+            const uint2 row = win_sel(w, qn);
+            const uint32_t n = row_n<MODE>(row), c = row_c<MODE>(row);
+            const uint32_t isFF = (uint32_t)(st == sFF) & inwin, isDown = (uint32_t)(st == sDown) & inwin,
+                           isUp = (uint32_t)(st == sUp) & inwin;
+            // fast_forward, move_structure.cpp:524-545
+            const uint32_t ffm = isFF & (uint32_t)(need < r1) & (uint32_t)(off >= n);
+            const uint32_t ff_over = ffm & (uint32_t)(ff_run + 1 >= 65535u);  // :72-75
+            const uint32_t resolved = isFF & (ffm ^ 1u);
+            // the base of step k against the row (read_processor.cpp:188-238)
+            const uint32_t illegal = a == 0xFFu, match = c == a;
+            const uint32_t mism = resolved & (illegal ^ 1u) & (match ^ 1u);
+            // reposition_thresholds, src/move_structure_query.cpp:513-601
+            // (SEP is a template parameter here: the separator branch and its selects sit on the critical path
+            // between the window's arrival and the next gather, and cost 4 % on c3 as a run-time flag)
+            const uint32_t kk = thr_slot(SEP, a, c);                          // alphamap_3[c][a]
+            uint32_t thr = row_thr<MODE>(row, kk > 2u ? 2u : kk) ? n : 0u;
+            if (SEP) {                                                        // a row of the separator: side table
+                if (mism & (uint32_t)(c == 0u) & (uint32_t)(need != end_row)) thr = separator_threshold(ix, (uint64_t)need, a);
+            }
+            const uint32_t down = (uint32_t)(off >= ((need == end_row) ? end_threshold(SEP, ethr, a) : thr));
+            const uint32_t at_last = need >= r1, at_first = need == 0;
+            const uint32_t repo_edge = mism & (down ? at_last : at_first);
+            // reposition_down :211-232 / reposition_up :188-209.  A run of the base among the window's OTHER rows is found in
+            // this very iteration (the nearest one in the scan's direction: what the row-by-row scan stops at) -- a reposition
+            // whose target shares the window costs no round trip of its own (tools/iter_model.c: half of all repositions; lane
+            // iterations per base -5 % on 150 bp reads with 1 % substitutions, -15 % on 10 kbp reads with 8 %).  Anything
+            // further away is scanned for one window per iteration, as before.
+            const uint32_t has = (nm ^ 15u) & (down ? (14u << (qn & 3u)) & 15u : (1u << (qn & 3u)) - 1u);   // rows that hold the base, beyond row qn
+            const uint32_t found = mism & (uint32_t)(has != 0u) & ix.inwin;
+            const uint32_t qf = found ? (down ? (uint32_t)__builtin_ctz(has | 16u) : 31u - (uint32_t)__builtin_clz(has | 1u)) : qn;
+            const uint32_t far = mism & (found ^ 1u);                          // the scan leaves the window
+            const uint2 rowf = win_sel(w, qf);                                 // the row the base is resolved at, if it is resolved now
+            const uint32_t nf = row_n<MODE>(rowf), rofff = row_off<MODE>(rowf);
+            const IdxT needf = (IdxT)(wbase + qf);
+            const uint32_t scanning = isDown | isUp;
+            const uint32_t hit = scanning & match;
+            const uint32_t landed = hit | found;                               // a scan ended at this row: offset 0 / n - 1 (read_processor.cpp:223)
+            const uint32_t landed_down = hit ? isDown : down;
+            const uint32_t scan_edge = scanning & (hit ^ 1u) & (isDown ? at_last : at_first);
+            const uint32_t emit = (resolved & (illegal | match)) | landed;
+            // LF_move of the emitted base, move_structure.cpp:59-67 (emit and the error cases are exclusive)
+            const uint32_t lf = emit & (uint32_t)(k + 1 != len);
+            // (ids in the look-ahead copy of a table of fewer than 2^32 - 1 rows are 32 bits wide: DevIndex::hints)
+            constexpr bool id32 = AHD != 0 && sizeof(IdxT) == 4;
+            uint64_t j = 0;
+            if (id32) j = (uint64_t)rowf.x;
+            else if (MODE == 6 || lf) j = (AHD && ix.hints) ? (uint64_t)rowf.x : row_id<MODE>(rowf, needf, ix);
+            const uint32_t lf_bad = lf & (uint32_t)(j >= ix.r);
+            // AHD: the entry of the row the base is resolved at -- or, on a mismatch that is not resolved here, of the row it was seen at
+            uint2 ah = make_uint2(0u, 0u);
+            if (AHD) ah = win_sel(ahw, qf);
+            // Reposition hints (DevIndex::hints): a mismatch whose scan leaves the window knows, for scans of up to 7 rows beyond the
+            // window's edge, WHERE the scan ends -- the next iteration gathers that row's window (in the scanning state: the row
+            // matches, the scan lands there) instead of the neighbouring window, and the ones after it.  tools/iter_model.c: lane
+            // iterations per base 1.123 -> 0.987 on 10 kbp reads with 8 % substitutions, 0.649 -> 0.626 on 150 bp reads with 1 %.
+            uint32_t jump = 0, jdist = 0;
+            IdxT jtgt = 0;
+            if (AHD) {
+                const uint32_t hbits = (rowf.y >> 28) | ((ah.y >> 21) & 0x3F0u);
+                const uint32_t kc = kk > 2u ? 2u : kk;
+                const uint32_t hd = __builtin_amdgcn_ubfe(hbits, kc + 2u * kc, ix.hint_w);          // (hint_w: 3, or 0 = no hints / switched off)
+                jump = far & (uint32_t)(hd != 0u);
+                jtgt = down ? (IdxT)(wbase + 3u + hd) : (IdxT)(wbase - hd);
+                jdist = down ? (uint32_t)(jtgt - need) : (uint32_t)(need - jtgt);
+            }
+            const uint32_t step_fwd = ffm | (far & down) | (scanning & (hit ^ 1u) & isDown);
+            const uint32_t step_back = (far & (down ^ 1u)) | (scanning & (hit ^ 1u) & isUp);
+            IdxT need_next = lf ? (IdxT)j : (jump ? jtgt : (IdxT)(need + step_fwd - step_back));
+            uint32_t st_next = (emit & (lf ^ 1u)) ? sDone : (lf ? sFF : (far ? (down ? sDown : sUp) : st));
+            // AHD: the base after this one, resolved at the LF target from the look-ahead entry (read_processor.cpp:188-238 with
+            // match and no fast-forward: ml + 1, then LF_move again) -- the target row itself is never fetched
+            uint32_t dbl = 0, lf2 = 0, off1 = 0;
+            IdxT j2 = 0;
+            if (AHD) {
+                const uint32_t n1 = ah.y & 0x7FFu, c1 = (ah.y >> 22) & 7u;
+                const uint32_t off_e = (landed ? (landed_down ? 0u : nf - 1u) : off) + rofff;
+                dbl = lf & (ah.y >> 31) & (uint32_t)(a1 == c1) & (uint32_t)(off_e < n1);
+                lf2 = dbl & (uint32_t)(k + 2 != len);
+                off1 = (ah.y >> 11) & 0x7FFu;
+                j2 = (id32 || ix.hints) ? (IdxT)ah.x : (IdxT)((uint64_t)ah.x | ((uint64_t)((ah.y >> 25) & 15u) << 32));
+                need_next = dbl ? (lf2 ? j2 : need) : need_next;
+                st_next = dbl ? (lf2 ? sFF : sDone) : st_next;
+            }
+            // The reference's throws: practically never, so which one it was is sorted out off the common path (as one
+            // select ladder over need_next / st_next it cost ~45 instructions between a window's arrival and the next
+            // gather's issue in every iteration).  An error freezes the lane where it is: no out-of-table window is fetched.
+            uint32_t errc = kErrNone;
+            if (wave_any((ff_over | repo_edge | scan_edge | lf_bad) != 0u)) {
+                errc = ff_over ? kErrFastForward
+                               : (repo_edge ? (down ? kErrNoRunBelow : kErrNoRunAbove)
+                                  : (scan_edge ? (isDown ? kErrNoRunBelow : kErrNoRunAbove)
+                                     : (lf_bad ? kErrIdRange : kErrNone)));
+                if (errc) { need_next = need; st_next = sDone; }
+            }
+            R.resolved = resolved; R.match = match; R.ffm = ffm; R.lf = lf; R.mism = mism; R.scanning = scanning; R.found = found; R.down = down;
+            R.qf = qf; R.qn = qn; R.jump = jump; R.jdist = jdist; R.landed = landed; R.landed_down = landed_down; R.nf = nf; R.n = n; R.rofff = rofff;
+            R.emit = emit; R.dbl = dbl; R.lf2 = lf2; R.off1 = off1; R.errc = errc; R.st_next = st_next;
+            R.j = j; R.needf = needf; R.need_next = need_next; R.j2 = j2;
         }
-        // The reference's throws: practically never, so which one it was is sorted out off the common path (as one
-        // select ladder over need_next / st_next it cost ~45 instructions between a window's arrival and the next
-        // gather's issue in every iteration).  An error freezes the lane where it is: no out-of-table window is fetched.
-        uint32_t errc = kErrNone;
-        if (wave_any((ff_over | repo_edge | scan_edge | lf_bad) != 0u)) {
-            errc = ff_over ? kErrFastForward
-                           : (repo_edge ? (down ? kErrNoRunBelow : kErrNoRunAbove)
-                              : (scan_edge ? (isDown ? kErrNoRunBelow : kErrNoRunAbove)
-                                 : (lf_bad ? kErrIdRange : kErrNone)));
-            if (errc) { need_next = need; st_next = sDone; }
-        }
+        const uint32_t resolved = R.resolved, match = R.match, ffm = R.ffm, lf = R.lf, mism = R.mism, scanning = R.scanning, found = R.found,
+                       down = R.down, qf = R.qf, qn = R.qn, jump = R.jump, jdist = R.jdist, landed = R.landed, landed_down = R.landed_down,
+                       nf = R.nf, n = R.n, rofff = R.rofff, emit = R.emit, dbl = R.dbl, lf2 = R.lf2, off1 = R.off1, tpl = R.tpl, lf3 = R.lf3,
+                       off2 = R.off2, errc = R.errc, st_next = R.st_next;
+        const uint64_t j = R.j;
+        const IdxT needf = R.needf, need_next = R.need_next, j2 = R.j2, j3 = R.j3;
+        (void)j3; (void)tpl; (void)lf3; (void)off2;
         // ---- the next gather leaves now; everything below runs under its latency
         // (`row` is not touched below, so the new window can land in the old one's registers)
         fetch(need_next, st_next != sDone, w);
@@ -588,6 +735,12 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
                 off += lf2 ? off1 : 0u;
                 emit_pml(ml);
             }
+            if (AHD == 2 && tpl) {                        // ... and the third (deep rows): at j2
+                ml += 1;
+                if (SEG == 1) seg_record((uint64_t)j2, off);
+                off += lf3 ? off2 : 0u;
+                emit_pml(ml);
+            }
             if (STG && CLS != 2 && ring && ((k ^ k_in) & 16u) != 0u) ring_flush(k_in);   // a group of 16 PMLs is complete
             if (STG) {
                 // (the next base's code: after the state update below, where a lane about to leave its staged stretch is seen)
@@ -612,10 +765,12 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
             // a lane whose next bases lie beyond its staged stretch: the whole wavefront stages again, each lane from its own step
             const uint32_t ahead_of = k - kbase;          // < 2^31: k >= kbase always
             const uint32_t out_of = (uint32_t)(st != sDone) &
-                                    ((uint32_t)(ahead_of >= stage_cap) | ((uint32_t)(ahead_of + 1u >= stage_cap) & (uint32_t)(k + 1 < len)));
+                                    ((uint32_t)(ahead_of >= stage_cap) | ((uint32_t)(ahead_of + 1u >= stage_cap) & (uint32_t)(k + 1 < len)) |
+                                     (AHD == 2 ? ((uint32_t)(ahead_of + 2u >= stage_cap) & (uint32_t)(k + 2 < len)) : 0u));
             if (wave_any(out_of != 0u)) stage_from(k, st != sDone);
             a = staged_code(k - kbase);
             if (AHD) a1 = staged_code(k + 1 - kbase);
+            if (AHD == 2) a2 = staged_code(k + 2 - kbase);
         }
         // ONE load site per prefetch register set and iteration, behind every read of those registers: a second site (or
         // a temporary that the register allocator parks in them where they are dead) costs an `s_waitcnt` on a load
@@ -661,6 +816,17 @@ static hipError_t walk_go(const WalkLaunch &L, LaunchInfo *info) {
 template <typename IdxT, int SEG, int CLS, int SEP>
 static hipError_t walk_pick(const WalkLaunch &L, LaunchInfo *info) {
     if (!L.stg) return walk_go<IdxT, SEG, CLS, SEP, 0, 0, 0, 0>(L, info);
+    if (L.ahd == 2) {                                      // deep rows: 32-bit row indexes, no pair-shared gathers (launch_pml sees to both)
+        if constexpr (sizeof(IdxT) == 4) {
+            if (L.ring == 2) {
+                if constexpr (SEG == 0 && CLS == 0) return walk_go<IdxT, 0, 0, SEP, 1, 2, 0, 2>(L, info);
+                else return hipErrorInvalidValue;
+            }
+            return L.ring ? walk_go<IdxT, SEG, CLS, SEP, 1, 2, 0, 1>(L, info) : walk_go<IdxT, SEG, CLS, SEP, 1, 2, 0, 0>(L, info);
+        } else {
+            return hipErrorInvalidValue;
+        }
+    }
     if (L.ring == 2) {                                     // reset masks out (plain PML of whole reads: launch_pml sees to it)
         if constexpr (SEG == 0 && CLS == 0) {
             switch ((L.ahd ? 2 : 0) | (L.psh ? 1 : 0)) {

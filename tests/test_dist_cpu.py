@@ -86,3 +86,31 @@ def test_shard_bounds_properties():
             b = shard_bounds(offs, parts)
             assert b[0] == 0 and b[-1] == len(lens) and all(x <= y for x, y in zip(b, b[1:]))
     assert shard_bounds(np.zeros(1, np.uint64), 4) == [0, 0, 0, 0, 0]     # empty batch
+
+
+def test_bench_dry_run_eight_ranks(built_lib):
+    """`bench.py --gpus 8 --dry-run`: the whole 8-rank flow of the bench -- self-spawn under torch.distributed.run, rank 0's synthesis,
+    the index broadcast, the per-rank read hand-over, barrier / max-over-ranks timing, every leg's assembly into rank 0's ONE JSON
+    line -- on the CPU over gloo with a stand-in engine (no GPU call, value null).  The first real 8-GPU run then only adds RCCL.
+    Tables are shrunk (the container has 64 GB for 8 ranks); resident memory and wall time are held to what the driver allows."""
+    import json
+    import subprocess
+    import time
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run", "--workload", "tinypg", "--big-rows", "300000",
+                        "--long-reads", "64", "--steps", "3", "--warmup", "1"], capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    wall = time.time() - t0
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                   # ONE JSON line, rank 0's
+    d = json.loads(lines[0])
+    assert d["dry_run"] is True and d["value"] is None and d["n_gpus"] == 8 and d["rccl_ranks"] == 0 and d["scaling"] == "weak"
+    assert len(d["rank_seconds"]) == 8 and len(d["host_peak_rss_mb"]) == 8
+    assert d["index_broadcast_s"] > 0 and d["index_broadcast_gb_s"] > 0 and d["index_broadcast_bytes"] == d["config"]["rows"] * 8
+    for leg in ("long_reads", "big_table"):
+        assert d[leg]["dry_run"] is True and d[leg]["n_gpus"] == 8 and len(d[leg]["rank_seconds"]) == 8, leg
+    assert d["big_table"]["index_broadcast_gb_s"] > 0 and len(d["big_table"]["count"]["rank_seconds"]) == 8
+    assert d["long_reads"]["classify_bins_agree"] is True
+    # the driver's limits: 1800 s per bench run; rank 0 holds every rank's synthetic reads in turn, the others only their own shard
+    assert wall < 1500 and d["wall_s"] < 1500
+    assert max(d["host_peak_rss_mb"]) < 6000 and max(d["host_peak_rss_mb"][1:]) <= d["host_peak_rss_mb"][0] + 200
