@@ -50,6 +50,9 @@ WORKLOADS = {
     "c5": dict(kind="synth", rows=1_000_000_000, mode=8, reads=1_250_000, read_len=150, sub=0.01,
                desc="random 1B-row blocked-thresholds table (6 GB), 1.25M x 150bp reads per GPU (BASELINE config 5 shard; "
                     "use with --query count)"),
+    "c2mid": dict(kind="pangenome", pg="mid", mode=6, reads=1_000_000, read_len=150, sub=0.01,
+                  desc="a real BWT that fits NO cache and still builds in minutes (round 6): the c2 pangenome with 0.5 % SNPs between its 64 genomes "
+                       "(640 Mbp text, 37.8 M rows = 302 MB; look-ahead copy 604 MB, deep rows 805 MB: beyond the 256 MB Infinity Cache), 1M x 150bp reads per GPU"),
     "c4real": dict(kind="pangenome", pg="big", mode=6, reads=1_250_000, read_len=150, sub=0.01,
                    desc="real BWT beyond the Infinity Cache and the TLBs' reach: synthetic 64-genome pangenome, 8.5 Mbp ancestor, 1 % "
                         "SNPs (1.09 Gbp text, ~102 M rows = 0.8 GB, built on first use: ~10 min), 1.25M x 150bp reads per GPU"),
@@ -67,10 +70,11 @@ PG_BIG = dict(anc=8_500_000, genomes=64, snp=0.01, seed=12)   # ~102 M rows (n /
 PG_BIG2 = dict(anc=16_500_000, genomes=64, snp=0.01, seed=14)  # ~220 M rows: the largest text the 32-bit suffix array takes (2.11 Gbp), ~35 GB of host memory
 PG_BIG3 = dict(anc=16_500_000, genomes=64, snp=0.04, seed=15)  # the same 2.11 Gbp with 4 % SNPs: n / r = 3.1 -> 675 738 185 rows (0.68 B): a REAL BWT at the size of the BASELINE target's table (small-scale calibration of n / r against the SNP rate: 1 % 11.1, 3 % 4.6, 5 % 3.1, 8 % 2.3)
 PG_TINY = dict(anc=60_000, genomes=8, snp=0.002, seed=13)     # tests: built in a second
+PG_MID = dict(anc=5_000_000, genomes=64, snp=0.005, seed=16)  # 37 755 947 rows (n / r = 16.95): tools/build_index in 2 - 5 min, ~8 GB of host memory
 
 
 def pg_of(wl):
-    return {"big": PG_BIG, "big2": PG_BIG2, "big3": PG_BIG3, "tiny": PG_TINY}.get(wl.get("pg"), PG_C2)
+    return {"big": PG_BIG, "big2": PG_BIG2, "big3": PG_BIG3, "tiny": PG_TINY, "mid": PG_MID}.get(wl.get("pg"), PG_C2)
 # where built pangenome indexes and their reads are kept: $MOVI_BENCH_CACHE, else a .bench_cache/ beside this file if one
 # travelled with the tree (a prebuilt c2 index saves the ~2 min single-threaded build per fresh box), else /tmp
 CACHE = os.environ.get("MOVI_BENCH_CACHE") or (os.path.join(ROOT, ".bench_cache") if os.path.isdir(os.path.join(ROOT, ".bench_cache"))
@@ -311,14 +315,20 @@ def big_table_leg(torch, dist, world, rank, dev, local_rank, stream, synth, movi
     dtc, perc, kern_c = timed_steps(torch, dist, world, dev, stream, runc, 5)
     claunch = index.last_launch()
     ctraffic, ctsrc = lookup_traffic("c4_count", rows, n_reads, L, claunch["kernel"])
-    out["count"] = {"value": total * 5 / dtc / 1e9, "unit": "Gbases/s (read bases)", "steps": 5, "ms_per_step": dtc / 5 * 1e3,
+    out["count"] = {"config": {"mode": 6, "note": "--count on the regular-thresholds (8-byte) rows of this leg's table; BASELINE config 5 as worded -- the "
+                                                   "blocked-thresholds file, 6-byte rows expanded on the GPU -- is `count_blocked_thresholds` below"},
+                    "value": total * 5 / dtc / 1e9, "unit": "Gbases/s (read bases)", "steps": 5, "ms_per_step": dtc / 5 * 1e3,
                     "rank_seconds": [round(x, 4) for x in perc], "kernel": claunch["kernel"],
                     "roofline": count_roofline(table_bytes_walked(rows, 8, claunch), 8, stc, int(d_m.sum().item()), kern_c, claunch, ctraffic, ctsrc)}
     out["count"]["roofline"]["dram_frac_of_peak"] = (ctraffic / kern_c / 1e9 / HBM_PEAK_GBS) if ctraffic else None
+    out["zml"] = zml_leg(torch, dist, world, dev, stream, index, rows, 8, d_bases, d_offs, n_reads, n_bases, d_out, d_err, "c4_zml", L)
     if getattr(index, "dry", False):
         out["dry_run"] = True
         out["index_broadcast_gb_s"] = round(rbytes / t_bc / 1e9, 2) if t_bc > 0 else None
         index.close()
+        c8 = count_mode8_leg(torch, dist, world, rank, dev, local_rank, stream, synth, movi_amd, cores, rows)
+        if rank == 0:
+            out["count_blocked_thresholds"] = c8
         return out if rank == 0 else None
     out["index_broadcast_gb_s"] = round(rbytes / t_bc / 1e9, 2) if t_bc > 0 else None
     if rank == 0:
@@ -387,6 +397,145 @@ def big_table_leg(torch, dist, world, rank, dev, local_rank, stream, synth, movi
             out["cli_path"] = {"error": repr(e)[:300]}
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
+    # ---- config 5 as worded: the blocked-thresholds form of the table (6 GB of file rows up, expanded on the GPU), --count
+    del six, img
+    torch.cuda.empty_cache()
+    try:
+        c8 = count_mode8_leg(torch, dist, world, rank, dev, local_rank, stream, synth, movi_amd, cores, rows)
+        if rank == 0:
+            out["count_blocked_thresholds"] = c8
+            if c8.get("parity_sample_ok") is False:
+                out["parity_sample_ok"] = False
+    except Exception as e:                                # noqa: BLE001
+        if world > 1:
+            raise
+        out["count_blocked_thresholds"] = {"error": repr(e)[:300]}
+    return out if rank == 0 else None
+
+
+def zml_roofline(table_bytes, row_bytes, st, n_bases, kern_s, launch, traffic=None, tsrc=None):
+    """The `roofline` object of a ZML leg: every base costs the two LF walkers of the interval's ends (fast-forwards counted over both), the
+    interval-shrink rows, one base in and one u16 out: B_zml = 2 x row_bytes x (1 + f) + row_bytes x u + 1 + 2 (as B_count + the output)."""
+    f_bar, u_bar = st.fast_forwards / max(n_bases, 1) / 2.0, st.scans / max(n_bases, 1)
+    bpb = 2 * row_bytes * (1.0 + f_bar) + row_bytes * u_bar + 1 + 2
+    ach = bpb * n_bases / kern_s / 1e9
+    return {"bound": "hbm", "gathers_served_from": served_from(table_bytes), "working_set_bytes": table_bytes, "side_table_bytes": 0,
+            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_source": tsrc, "algorithmic_bytes_per_base": round(bpb, 3),
+            "kernel": launch["kernel"], "launch": launch, "kernel_ms_avg": kern_s * 1e3,
+            "lane_iterations_per_s": st.lane_steps / kern_s if st.wave_steps else None}
+
+
+def zml_leg(torch, dist, world, dev, stream, index, rows, row_bytes, d_bases, d_offs, n_reads, n_bases, d_out, d_err, key, read_len, steps=5):
+    """`--zml` (MoveStructure::query_zml, src/move_structure_query.cpp:690-785) on a batch that is already resident, with its roofline
+    object (round 6: the ZML parse measured in the default line like the PML walk and the count query)."""
+    run = lambda: index.zml_device(d_bases.data_ptr(), d_offs.data_ptr(), n_reads, n_bases, d_out.data_ptr(), d_err.data_ptr(), stream.cuda_stream, 0)
+    run()
+    torch.cuda.synchronize()
+    st = index.last_stats(stream.cuda_stream)
+    dt, per, kern_s = timed_steps(torch, dist, world, dev, stream, run, steps)
+    total = sum_over_ranks(torch, dist, world, dev, n_bases)
+    launch = index.last_launch()
+    traffic, tsrc = lookup_traffic(key, rows, n_reads, read_len, launch["kernel"])
+    roof = zml_roofline(table_bytes_walked(rows, row_bytes, launch), row_bytes, st, n_bases, kern_s, launch, traffic, tsrc)
+    roof["dram_frac_of_peak"] = (traffic / kern_s / 1e9 / HBM_PEAK_GBS) if traffic else None
+    return {"value": total * steps / dt / 1e9, "unit": "Gbases/s", "steps": steps, "ms_per_step": dt / steps * 1e3, "rank_seconds": [round(x, 4) for x in per],
+            "kernel": launch["kernel"], "errors": int(st.errors),
+            "simt_efficiency": round(st.lane_steps / (64.0 * st.wave_steps), 4) if st.wave_steps else None,
+            "iterations_per_base": round(st.lane_steps / max(n_bases, 1), 4) if st.wave_steps else None, "roofline": roof}
+
+
+def count_mode8_leg(torch, dist, world, rank, dev, local_rank, stream, synth, movi_amd, cores, rows, steps=5):
+    """BASELINE config 5 AS WORDED (round 6): "the same 1 B-run reference built as blocked-thresholds (6 B/row) ... --count".  The run
+    structure of the c4 table as a blocked-thresholds FILE -- 6-byte rows + id blocks (include/move_row.hpp:128-142, src/move_structure.cpp:91-102)
+    -- goes up as it is stored (6 GB), is expanded on the GPU to the resident 8-byte layout (`expand_s`), and the count query runs on that.
+    `roofline` prices the reference's 6-byte row (B_count); the 8-byte figure of the resident layout is beside it."""
+    from oracle.oracle import Oracle
+    from movi_amd._lib import IndexDescC
+    w = WORKLOADS["c5"]
+    n_reads, L = w["reads"], w["read_len"]
+    t0 = time.time()
+    six = img = meta = d_rows = None
+    if rank == 0:
+        six = synth.synth_index(rows, mode=8, seed=SEED)
+        img = six.image()
+        _, cdesc0, roff, rbytes = movi_amd.parse_index_image(img)
+        id_blocks = np.ctypeslib.as_array(C.cast(cdesc0.id_blocks, C.POINTER(C.c_uint32)), shape=(int(cdesc0.n_blocks) * int(cdesc0.alphabet_size),)).copy()
+        meta = {"cdesc": bytes(cdesc0), "id_blocks": id_blocks}
+    t_gen = time.time() - t0
+    t0 = time.time()
+    if rank == 0:
+        d_rows = torch.from_numpy(img[roff: roff + rbytes]).to(dev)
+    torch.cuda.synchronize()
+    t_up = time.time() - t0
+    t_bc = 0.0
+    if world > 1:
+        from movi_amd import dist as md
+        tb = time.time()
+        meta, d_rows = md.broadcast_index(meta, d_rows, src=0, device=dev)
+        torch.cuda.synchronize()
+        t_bc = time.time() - tb
+    cdesc = IndexDescC.from_buffer_copy(meta["cdesc"])
+    id_blocks = meta["id_blocks"]
+    cdesc.id_blocks = id_blocks.ctypes.data
+    cdesc.tally_ids = None
+    cdesc.separator_thresholds, cdesc.separator_map = None, None
+    file_bytes = int(d_rows.numel())
+    t0 = time.time()
+    index = movi_amd.MoveIndex.from_device_rows(cdesc, d_rows.data_ptr(), device=local_rank, keepalive=d_rows)   # get_id per row, once: 6 B -> 8 B rows
+    torch.cuda.synchronize()
+    t_expand = time.time() - t0
+    del d_rows                                              # (modes 7 / 8: the file rows may be released after the call)
+    index._keep = None
+    torch.cuda.empty_cache()
+    t0 = time.time()
+    derived = index.prepare(index.PREPARE_COUNT)
+    t_prep = time.time() - t0
+    bases, offs = draw_synth_reads(torch, dist, world, rank, dev, synth, six, n_reads, L, SEED + 1, w["sub"])
+    n_bases = int(bases.size)
+    d_bases = torch.from_numpy(bases).to(dev)
+    d_offs = torch.from_numpy(offs.view(np.int64)).to(dev)
+    d_err = torch.zeros(n_reads, dtype=torch.uint8, device=dev)
+    d_m = torch.zeros(n_reads, dtype=torch.int64, device=dev)
+    d_c = torch.zeros(n_reads, dtype=torch.int64, device=dev)
+    runc = lambda: index.count_device(d_bases.data_ptr(), d_offs.data_ptr(), n_reads, n_bases, d_m.data_ptr(), d_c.data_ptr(),
+                                      d_err.data_ptr(), stream.cuda_stream, 0)
+    runc()
+    torch.cuda.synchronize()
+    stc = index.last_stats(stream.cuda_stream)
+    dtc, perc, kern_c = timed_steps(torch, dist, world, dev, stream, runc, steps)
+    total = sum_over_ranks(torch, dist, world, dev, n_bases)
+    claunch = index.last_launch()
+    matched = int(d_m.sum().item())
+    ctraffic, ctsrc = lookup_traffic("c4_count", rows, n_reads, L, claunch["kernel"])
+    roof6 = count_roofline(rows * 8, 6, stc, matched, kern_c, claunch, ctraffic, ctsrc)
+    roof8 = count_roofline(rows * 8, 8, stc, matched, kern_c, claunch, ctraffic, ctsrc)
+    roof6["algorithmic_model"] = "SURVEY 8(d) B_count with the reference's 6-byte blocked-thresholds row; the walk itself runs on the 8-byte rows the upload expanded them to"
+    roof6["resident_layout"] = {"row_bytes": 8, "algorithmic_bytes_per_base": roof8["algorithmic_bytes_per_base"], "achieved": roof8["achieved"], "frac": roof8["frac"]}
+    roof6["dram_frac_of_peak"] = (ctraffic / kern_c / 1e9 / HBM_PEAK_GBS) if ctraffic else None
+    out = {"workload": "c5", "description": w["desc"], "config": {"mode": 8, "rows": rows, "file_row_bytes": 6, "file_table_bytes": file_bytes, "resident_row_bytes": 8,
+                                                                   "id_blocks": int(id_blocks.size), "reads_per_gpu": n_reads, "read_len": L},
+           "value": total * steps / dtc / 1e9, "unit": "Gbases/s (read bases)", "n_gpus": world, "steps": steps, "ms_per_step": dtc / steps * 1e3,
+           "rank_seconds": [round(x, 4) for x in perc], "kernel": claunch["kernel"], "matched_bases_per_read": round(matched / n_reads, 2),
+           "index_gen_s": round(t_gen, 1), "index_upload_s": round(t_up, 2), "index_broadcast_s": round(t_bc, 3), "expand_s": round(t_expand, 3),
+           "expand_gb_s": round(file_bytes / max(t_expand, 1e-9) / 1e9, 1), "prepare_s": round(t_prep, 3), "derived_bytes": derived, "errors": int(stc.errors),
+           "roofline": roof6}
+    if getattr(index, "dry", False):
+        out["dry_run"] = True
+    elif rank == 0:
+        cpu = Oracle(img)                                    # (the oracle walks the blocked ids as stored: get_id per step)
+        gm, gc = d_m.cpu().numpy().view(np.uint64), d_c.cpu().numpy().view(np.uint64)
+        ok = True
+        for lo in (0, n_reads // 2 - 1000, n_reads - 2000):
+            hi = lo + 2000
+            sb = bases[int(offs[lo]): int(offs[hi])]
+            so = offs[lo: hi + 1] - offs[lo]
+            em, ec = cpu.count_batch(sb, so, threads=cores)
+            ok = ok and bool((gm[lo:hi] == em).all() and (gc[lo:hi] == ec).all())
+        out["parity_sample_ok"] = ok
+        out["parity_sample"] = "rank 0's reads [0,2000), middle 2000, last 2000 vs oracle/movi_oracle.c on the blocked-thresholds image: matched lengths and counts equal"
+        cpu.close()
+    index.close()
     return out if rank == 0 else None
 
 
@@ -716,6 +865,7 @@ def main():
     t_wall0 = time.time()
     if args.dry_run:
         args.no_cpu_baseline = args.no_sustained = True
+    args.quick_only_walk = bool(args.quick)
     if args.quick:
         args.no_cpu_baseline = args.no_long_reads = args.no_big_table = args.no_sustained = True
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -985,6 +1135,30 @@ def main():
         except Exception as e:                            # noqa: BLE001
             mask_path = {"error": repr(e)[:200]}
 
+    # ---- the ZML parse and the count query of the same batch on the same resident index (default run only, never part of `value`)
+    zml_c2 = count_c2 = None
+    if default_run and not args.quick_only_walk:
+        try:
+            zml_c2 = zml_leg(torch, dist, 1, dev, stream, index, wl["rows"], row_bytes, d_bases, d_offs, n_reads, n_bases, d_out, d_err, "c2_zml", wl["read_len"])
+            d_m2 = torch.zeros(n_reads, dtype=torch.int64, device=dev)
+            d_c2 = torch.zeros(n_reads, dtype=torch.int64, device=dev)
+            index.prepare(index.PREPARE_COUNT)
+            runc = lambda: index.count_device(d_bases.data_ptr(), d_offs.data_ptr(), n_reads, n_bases, d_m2.data_ptr(), d_c2.data_ptr(), d_err.data_ptr(), stream.cuda_stream, 0)
+            runc()
+            torch.cuda.synchronize()
+            stc = index.last_stats(stream.cuda_stream)
+            dtc, _, kern_c = timed_steps(torch, dist, 1, dev, stream, runc, 5)
+            cl = index.last_launch()
+            ctr, ctsrc = lookup_traffic("c2_count", wl["rows"], n_reads, wl["read_len"], cl["kernel"])
+            count_c2 = {"value": n_bases * 5 / dtc / 1e9, "unit": "Gbases/s (read bases)", "steps": 5, "ms_per_step": dtc / 5 * 1e3, "kernel": cl["kernel"],
+                        "matched_bases_per_read": round(float(d_m2.sum().item()) / n_reads, 2),
+                        "roofline": count_roofline(table_bytes_walked(wl["rows"], row_bytes, cl), row_bytes, stc, int(d_m2.sum().item()), kern_c, cl, ctr, ctsrc)}
+            del d_m2, d_c2
+            index.pml_device(d_bases.data_ptr(), d_offs.data_ptr(), n_reads, n_bases, d_out.data_ptr(), d_err.data_ptr(), stream.cuda_stream, d_order)
+            torch.cuda.synchronize()
+        except Exception as e:                            # noqa: BLE001
+            zml_c2 = {"error": repr(e)[:200]}
+
     tkey = args.workload + ("" if args.query == "pml" else "_" + args.query) + ("_classify%d" % args.classify if args.classify else "")
     traffic, traffic_src = lookup_traffic(tkey, wl["rows"], wl["reads"], wl["read_len"], launch["kernel"])
 
@@ -1030,6 +1204,10 @@ def main():
 
     if sustained is not None:
         result["sustained"] = sustained
+    if zml_c2 is not None:
+        result["zml"] = zml_c2
+    if count_c2 is not None:
+        result["count"] = count_c2
     if mask_path is not None:
         result["mask_path"] = mask_path
         if mask_path.get("expanded_equals_vector_walk") is False:

@@ -145,6 +145,7 @@ struct movi_index {
     bool host_autopin = true;        // big *_host calls on pageable buffers page-lock them for the call ("host_autopin")
     bool host_overlap = true;        // page-locked buffers take the overlapped path ("host_overlap" 0: one upload, the walk, one download)
     bool seg_seen = false;           // the last PML / ZML host call on long reads was walked segment-parallel (chunk policy below)
+    uint64_t reserved_result_bases = 0, reserved_reads = 0;   // "reserve_host_results" / "reserve_host_reads": what the mask words' scratch is reserved for
     int pml_via_mask = -1;           // "pml_via_mask": movi_pml_host brings reset masks down and expands them on the host (-1: calls of >= 2^22 bases)
     int host_threads = 0;            // "host_threads": workers of the host-side expansion (0 = host_threads_default())
 };
@@ -1018,7 +1019,15 @@ int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
             HIP_TRY(grow(&ix->scratch[movi_index::kBases], &ix->scratch_cap[movi_index::kBases], v));
         } else if (!strcmp(key, "reserve_host_results")) {
             HIP_TRY(grow(&ix->scratch[movi_index::kOut], &ix->scratch_cap[movi_index::kOut], v * 2));
+            // (round 6: a PML vector is written through reset masks on the device -- their words, for as many reads as "reserve_host_reads" says)
+            ix->reserved_result_bases = std::max<uint64_t>(ix->reserved_result_bases, v);
+            HIP_TRY(grow(&ix->scratch[movi_index::kMask], &ix->scratch_cap[movi_index::kMask],
+                         (size_t)pml_mask_words(ix->reserved_reads, ix->reserved_result_bases, 31u) * 4));
         } else {                                             // "reserve_host_reads"
+            ix->reserved_reads = std::max<uint64_t>(ix->reserved_reads, v);
+            if (ix->reserved_result_bases)
+                HIP_TRY(grow(&ix->scratch[movi_index::kMask], &ix->scratch_cap[movi_index::kMask],
+                             (size_t)pml_mask_words(ix->reserved_reads, ix->reserved_result_bases, 31u) * 4));
             HIP_TRY(grow(&ix->scratch[movi_index::kOffs], &ix->scratch_cap[movi_index::kOffs], (v + 1) * 8));
             HIP_TRY(grow(&ix->scratch[movi_index::kErr], &ix->scratch_cap[movi_index::kErr], v));
             if (ix->h_rel_cap < v + 1) {
@@ -1055,6 +1064,17 @@ int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
     if (!strcmp(key, "pml_via_mask")) {                      // movi_pml_host / movi_pml_device through reset masks (-1: the policy)
         if (value < -1 || value > 1) return fail(MOVI_ERR_ARG, "pml_via_mask must be -1, 0 or 1");
         ix->pml_via_mask = (int)value;
+        return MOVI_OK;
+    }
+    if (!strcmp(key, "fused_expand")) {                      // A/B: 0 = a mask walk whose caller wants the vector leaves the expansion to the pml_expand_* kernels
+        if (value != 0 && value != 1) return fail(MOVI_ERR_ARG, "fused_expand must be 0 or 1");
+        ix->cfg.fused_expand = (int)value;
+        return MOVI_OK;
+    }
+    if (!strcmp(key, "reserve_device_masks")) {              // device scratch for the mask words of movi_pml_device calls of up to `value` bases (and as many reads / 16)
+        if (value < 0 || (uint64_t)value > (1ull << 40)) return fail(MOVI_ERR_ARG, "reserve_device_masks out of range");
+        HIP_TRY(hipSetDevice(ix->device));
+        HIP_TRY(grow(&ix->scratch[movi_index::kMask], &ix->scratch_cap[movi_index::kMask], (size_t)pml_mask_words((uint64_t)value / 16 + 1, (uint64_t)value, 0) * 4));
         return MOVI_OK;
     }
     if (!strcmp(key, "host_threads")) {                      // workers of the host-side mask expansion (0 = as many as the process may run on)
@@ -1183,7 +1203,7 @@ static int ml_device(bool zml, movi_index_t *ix, const uint8_t *d_bases, const u
         MaskArgs m;
         if (masks) {
             m = *mask;
-            if (pml_mask_needs_tmp(ix->dev, ix->cfg, n_reads, n_bases, seg_ws != nullptr)) {
+            if (!m.expand_out && pml_mask_needs_tmp(ix->dev, ix->cfg, n_reads, n_bases, seg_ws != nullptr)) {   // (expand_out: such a batch writes the vector itself)
                 if (!tmp_p) { tmp_p = &ix->scratch[movi_index::kTmp]; tmp_cap = &ix->scratch_cap[movi_index::kTmp]; }
                 HIP_TRY(grow(tmp_p, tmp_cap, n_bases * 2));
                 m.tmp_pml = static_cast<uint16_t *>(*tmp_p);
@@ -1198,13 +1218,27 @@ static int ml_device(bool zml, movi_index_t *ix, const uint8_t *d_bases, const u
 int movi_pml_device(movi_index_t *ix, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
                     uint64_t n_bases, uint16_t *d_out_pml, uint8_t *d_read_err, const uint32_t *d_read_order,
                     void *stream) {
-    if (ix && ix->pml_via_mask == 1 && n_reads && d_out_pml && mode_has_thresholds(ix->desc.mode)) {
-        // "pml_via_mask" 1: the walk writes reset masks (device scratch of the handle, grow-only), pml_expand_kernel the vector
+    if (ix && n_reads && d_out_pml && d_offsets && mode_has_thresholds(ix->desc.mode) && ix->pml_via_mask != 0) {
+        // The vector THROUGH RESET MASKS: the walk writes one bit per base (a ninth fewer vector instructions per iteration than the
+        // u16 packer, a third of the write traffic) and every wavefront, when its 64 walks are over, expands its reads' words into the
+        // vector itself -- the expansion runs under the other wavefronts' gathers (pml_kernel_flatp's tail; "fused_expand" 0: the
+        // pml_expand_* kernels behind the walk).  "pml_via_mask" 1: always; -1, the default: where the walk runs on the deep rows -- three
+        // emissions per iteration: c2 78.4 -> 86.7 Gbases/s; the 1 B-row table 42.3 -> 46.0 --, i.e. batches of short reads; long reads keep
+        // the ring in LDS, which is as good there (c3: 16.76 against 16.66 ms).  The mask words live in device scratch of the handle
+        // (grow-only: "reserve_device_masks" reserves it, and movi_index_prepare's promise of no allocation inside a query holds from the
+        // first call of each size on).
         HIP_TRY(hipSetDevice(ix->device));
-        HIP_TRY(grow(&ix->scratch[movi_index::kMask], &ix->scratch_cap[movi_index::kMask], (size_t)pml_mask_words(n_reads, n_bases, 0) * 4));
-        uint32_t *words = static_cast<uint32_t *>(ix->scratch[movi_index::kMask]);
-        if (int rc = movi_pml_mask_device(ix, d_bases, d_offsets, n_reads, n_bases, 0, words, d_read_err, d_read_order, stream)) return rc;
-        return movi_pml_expand_device(ix, words, d_offsets, n_reads, n_bases, 0, d_out_pml, stream);
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        ensure_pml_tables(ix, s);
+        if (ix->pml_via_mask > 0 || pml_vector_via_masks(ix->dev, ix->cfg, n_reads, n_bases, true, d_read_order != nullptr)) {
+            HIP_TRY(grow(&ix->scratch[movi_index::kMask], &ix->scratch_cap[movi_index::kMask], (size_t)pml_mask_words(n_reads, n_bases, 0) * 4));
+            MaskArgs m;
+            m.words = static_cast<uint32_t *>(ix->scratch[movi_index::kMask]);
+            m.phase = 0;
+            m.expand_out = d_out_pml;
+            return ml_device(false, ix, d_bases, d_offsets, n_reads, n_bases, nullptr, d_read_err, d_read_order, stream, ClsArgs(), nullptr, nullptr,
+                             -1, nullptr, &m);
+        }
     }
     return ml_device(false, ix, d_bases, d_offsets, n_reads, n_bases, d_out_pml, d_read_err, d_read_order, stream);
 }
@@ -1824,8 +1858,10 @@ static int ml_host(bool zml, movi_index_t *ix, const uint8_t *h_bases, const uin
     if (int rc0 = check_offsets(h_offsets, n_reads)) return rc0;
     HIP_TRY(hipSetDevice(ix->device));
     const uint64_t o0 = h_offsets[0], span = h_offsets[n_reads] - o0;
+    // ("pml_via_mask" -1: masks down + host expansion for big calls whose result vector is PAGEABLE -- no page-locking of 2 bytes per base,
+    // 1/16 of the bytes over PCIe: 23.4 -> 25.4 Gbases/s on 1 M x 150 bp; a page-locked vector comes down as it is, at the same rate)
     const bool via_mask = !zml && (h_mask_words != nullptr ||
-                                   (h_out_pml != nullptr && (ix->pml_via_mask > 0 || (ix->pml_via_mask < 0 && span >= (1ull << 22)))));
+                                   (h_out_pml != nullptr && (ix->pml_via_mask > 0 || (ix->pml_via_mask < 0 && span >= (1ull << 22) && !is_pinned(h_out_pml)))));
     const int threads = ix->host_threads > 0 ? ix->host_threads : host_threads_default();
     struct { void *p; } d_out{};
     auto phase_of = [&](uint64_t b0) { return (uint32_t)((b0 - o0) & 31u); };
@@ -1839,6 +1875,16 @@ static int ml_host(bool zml, movi_index_t *ix, const uint8_t *h_bases, const uin
                              c.seg_verdict, &m, &c.d[movi_index::kTmp], &c.cap[movi_index::kTmp]);
         }
         HIP_TRY(c.alloc(movi_index::kOut, nb * 2, &d_out.p));
+        // (the vector itself comes down: on the device it is written through reset masks where movi_pml_device's policy says so)
+        if (!zml && ix->pml_via_mask != 0 && (ix->pml_via_mask > 0 || pml_vector_via_masks(ix->dev, ix->cfg, nr, nb, true, false))) {
+            void *mw = nullptr;
+            HIP_TRY(c.alloc(movi_index::kMask, (size_t)pml_mask_words(nr, nb, 0) * 4, &mw));
+            MaskArgs m;
+            m.words = static_cast<uint32_t *>(mw);
+            m.expand_out = static_cast<uint16_t *>(d_out.p);
+            return ml_device(false, ix, db, dof, nr, nb, nullptr, derr, nullptr, c.s, ClsArgs(), c.d_stats, c.seg_ws, c.ragged_hint,
+                             c.seg_verdict, &m);
+        }
         return ml_device(zml, ix, db, dof, nr, nb, static_cast<uint16_t *>(d_out.p), derr, nullptr, c.s, ClsArgs(), c.d_stats,
                          c.seg_ws, c.ragged_hint, c.seg_verdict);
     };

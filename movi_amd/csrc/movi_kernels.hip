@@ -1027,6 +1027,16 @@ PmlPlan plan_pml(const DevIndex &ix, const LaunchCfg &cfg, uint64_t n_reads, uin
 }
 }  // namespace
 
+// movi_pml_device's own choice ("pml_via_mask" -1): the vector through reset masks wherever the default walk writes the masks itself and
+// the register packer would otherwise write the vector -- batches of short reads (mean length below kOutRingReadLen; long reads keep the
+// ring in LDS, which is as good there: c3 16.76 against 16.66 ms).  Measured, vector out, packer -> fused masks: c2 on the deep rows 78.4
+// -> 86.7 Gbases/s, the random 10 M-row table 62.4 -> 64.8, the 1 B-row table 42.3 -> 46.0 (profiles/r06_mask_path.txt).
+bool pml_vector_via_masks(const DevIndex &ix, const LaunchCfg &cfg, uint64_t n_reads, uint64_t n_bases, bool have_seg_ws, bool ordered) {
+    if (n_reads == 0) return false;
+    const PmlPlan P = plan_pml(ix, cfg, n_reads, n_bases, 0, false, have_seg_ws, ordered, true);
+    return !P.seg_eligible && P.v == 14 && P.stage_lds != 0u && n_bases / n_reads < kOutRingReadLen;
+}
+
 bool pml_mask_needs_tmp(const DevIndex &ix, const LaunchCfg &cfg, uint64_t n_reads, uint64_t n_bases, bool have_seg_ws) {
     if (n_reads == 0) return false;
     const PmlPlan P = plan_pml(ix, cfg, n_reads, n_bases, 0, false, have_seg_ws, false, true);
@@ -1039,7 +1049,16 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
                       SegWorkspace *seg_ws, int ragged_hint, int *seg_verdict, LaunchInfo *info, const MaskArgs &mask) {
     if (n_reads == 0) return hipSuccess;
     // 0 = PML vector only, 1 = vector + classification bins, 2 = bins only
-    const bool want_mask = mask.words != nullptr;          // reset masks out instead of the vector (MaskArgs)
+    bool want_mask = mask.words != nullptr;                // reset masks out instead of the vector (MaskArgs)
+    const bool logging0 = cls.log_ff != nullptr || cls.log_scan != nullptr;
+    if (want_mask && mask.expand_out) {
+        // the caller wants the VECTOR and lends scratch for masks: through masks only where the walk writes them itself
+        const PmlPlan P0 = plan_pml(ix, cfg, n_reads, n_bases, 0, logging0, seg_ws != nullptr, d_order != nullptr, true);
+        if (P0.seg_eligible || P0.v != 14 || P0.stage_lds == 0u || cls.bin_width != 0) {
+            want_mask = false;
+            d_out = mask.expand_out;
+        }
+    }
     if (want_mask) d_out = mask.tmp_pml;                   // (the paths without a mask output of their own write here first)
     const int cm = cls.bin_width == 0 ? 0 : (d_out ? 1 : 2);
     if (cm == 0 && !d_out && !want_mask) return hipErrorInvalidValue;
@@ -1070,6 +1089,10 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
     ixl.hint_w = P.use_deep ? (cfg.hints != 0 ? 2u : 0u) : ((cfg.hints != 0 && ix.hints != 0u && ix.rows2 != nullptr) ? 3u : 0u);
     ixl.mask_phase = mask.phase & 31u;
     const bool mask_native = want_mask && v == 14 && P.stage_lds != 0u;
+    // the vector from the mask walk itself: one-wavefront blocks whose 64 reads are one contiguous, 16-byte aligned stretch of it
+    const bool fused_expand = mask_native && mask.expand_out != nullptr && bt == 64 && d_order == nullptr &&
+                              (reinterpret_cast<uintptr_t>(mask.expand_out) & 15u) == 0 && cfg.fused_expand != 0;
+    ixl.expand_out = fused_expand ? mask.expand_out : nullptr;
     if (want_mask && !mask_native && !d_out) return hipErrorInvalidValue;     // (pml_mask_needs_tmp told the caller)
     hipError_t e = hipSuccess;
     if (v == 14) {
@@ -1100,6 +1123,8 @@ hipError_t launch_pml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
         info->ahead = P.use_deep ? 2 : (P.use_ahead ? 1 : 0);
     }
     if (e == hipSuccess && want_mask && !mask_native) e = launch_pml_to_mask(d_out, d_offsets, n_reads, n_bases, mask.phase, mask.words, stream);
+    if (e == hipSuccess && mask_native && mask.expand_out != nullptr && !fused_expand)
+        e = launch_pml_expand(mask.words, d_offsets, n_reads, n_bases, mask.phase, mask.expand_out, stream);
     return e;
 }
 
@@ -2688,34 +2713,98 @@ __device__ __forceinline__ void store_word(uint16_t *O, const uint4 (&g)[4], uin
         if (8u * q + i < cnt) O[8u * q + i] = (uint16_t)(x[i >> 1] >> (16u * (i & 1u)));
 }
 
-// Short reads: a block of 256 threads takes kExpandReads consecutive reads -- their vectors are ONE contiguous stretch of the output --
-// and its threads share the stretch by groups of EIGHT CONSECUTIVE OUTPUT ELEMENTS aligned to 16 bytes: one 16-byte store per group, a
-// wavefront's stores a contiguous kilobyte.  The reads' offsets sit in LDS (the read a group starts in: a binary search over 65
-// entries); match_len before a group's first position comes from the bits below it in its mask word, or from the words before (as
-// many as the run of matches is long: long reads take the wavefront-per-read kernel below).  Groups that straddle the stretch's
-// ends are written element by element by the block that owns each element.
-// (Round 6's first two versions -- one lane per read, four 16-byte stores per word at a stride of a read: 0.81 TB/s; one thread per
-// group with the reads found by binary searches over the whole batch, two of them serial per block: 0.68 TB/s.  profiles/r06_mask_path.txt)
+// SHORT reads (mean length below kExpandTileLen): ONE WAVEFRONT takes 64 consecutive reads -- their vectors are one contiguous stretch
+// of the output -- and every lane expands ITS OWN read, sequentially (match_len carried in a register: no search for the read, no
+// look-back over words), eight bases per step, into a tile of the stretch in LDS; the wavefront then copies the tile out as aligned
+// 16-byte stores, a contiguous kilobyte per instruction.  Long stretches slide the tile along (a lane resumes where it stopped).
+// ~0.09 vector instructions per element, where one thread per group of eight (pml_expand_group_kernel below: a search for the read and
+// a look-back per group) spends 0.33: profiles/r06_mask_path.txt has the four versions measured (0.81 / 0.68 / 1.65 TB/s / this one).
+constexpr uint32_t kExpandTileElems = 8192;               // 16 KB of LDS per wavefront
+constexpr uint64_t kExpandTileLen = 512;                  // launch_pml_expand: batches whose mean read length is below this
+__global__ __launch_bounds__(64) void pml_expand_tile_kernel(const uint32_t *__restrict__ words, const uint64_t *__restrict__ offs,
+                                                             uint64_t n_reads, uint32_t phase, uint16_t *__restrict__ out) {
+    __shared__ __align__(16) uint16_t tile[kExpandTileElems];
+    const uint32_t lane = threadIdx.x;
+    const uint64_t R0 = (uint64_t)blockIdx.x * 64u;
+    const uint64_t R1 = R0 + 64u < n_reads ? R0 + 64u : n_reads;
+    const uint64_t rid = R0 + lane;
+    const bool have = rid < n_reads;
+    const uint64_t beg = have ? offs[rid] : 0, end = have ? offs[rid + 1] : 0;
+    const uint32_t len = (uint32_t)(end - beg);
+    const uint32_t *M = words + ((beg + phase) >> 5) + rid;
+    const uint64_t B0 = offs[R0], B1 = offs[R1];           // uniform: the stretch
+    uint32_t k = 0, run = 0;
+    uint32_t wcur = 0, w0 = 0, w1 = 0;
+    if (len) { w0 = M[0]; w1 = M[1]; }                     // (the array has a spare word at its end: M[w + 1] is always readable)
+    auto one = [&](uint32_t o) {                           // one base: step k of this lane's read to tile[o]
+        if ((k >> 5) != wcur) { wcur = k >> 5; w0 = w1; w1 = M[wcur + 1]; }
+        run = ((w0 >> (k & 31u)) & 1u) ? 0u : run + 1u;
+        tile[o] = (uint16_t)(run > 65535u ? 65535u : run);
+        k += 1;
+    };
+    for (uint64_t A = B0 & ~7ull; A < B1; A += kExpandTileElems) {
+        const uint64_t hi = A + kExpandTileElems < B1 ? A + kExpandTileElems : B1;
+        if (k < len && beg + k < hi) {                      // this lane's bases inside the tile (beg + k >= A: the tiles advance in order)
+            uint32_t o = (uint32_t)(beg + k - A);
+            const uint32_t stop = (uint32_t)((end < hi ? end : hi) - A);
+            while (o < stop && (o & 7u)) one(o++);
+            while (o + 8u <= stop) {                        // eight bases: their bits from the word pair, one 16-byte LDS store
+                if ((k >> 5) != wcur) { wcur = k >> 5; w0 = w1; w1 = M[wcur + 1]; }
+                const uint32_t bits = (uint32_t)((((uint64_t)w1 << 32) | w0) >> (k & 31u)) & 0xFFu;
+                uint32_t v[8];
+#pragma unroll
+                for (uint32_t e = 0; e < 8u; ++e) {
+                    run = ((bits >> e) & 1u) ? 0u : run + 1u;
+                    v[e] = run > 65535u ? 65535u : run;
+                }
+                *reinterpret_cast<uint4 *>(&tile[o]) = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
+                o += 8u;
+                k += 8u;
+            }
+            while (o < stop) one(o++);
+        }
+        __syncthreads();
+        const uint32_t nelem = (uint32_t)(hi - A);
+        for (uint32_t g = lane; g * 8u < nelem; g += 64u) {
+            const uint64_t p = A + (uint64_t)g * 8u;
+            const uint4 q = *reinterpret_cast<const uint4 *>(&tile[g * 8u]);
+            if (p >= B0 && p + 8u <= hi) {
+                *reinterpret_cast<uint4 *>(out + p) = q;    // (out is 16-byte aligned: the launcher's check; p is a multiple of 8)
+            } else {                                        // the stretch's first / last group: shared with the neighbouring wavefront's
+                const uint32_t x[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (uint32_t e = 0; e < 8u; ++e)
+                    if (p + e >= B0 && p + e < hi) out[p + e] = (uint16_t)(x[e >> 1] >> (16u * (e & 1u)));
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Reads of a few hundred to two thousand bases: a block of 256 threads takes kExpandReads consecutive reads and its threads share
+// their stretch of the output by groups of EIGHT CONSECUTIVE ELEMENTS aligned to 16 bytes: one 16-byte store per group.  The reads'
+// offsets sit in LDS (the read a group starts in: a binary search over 65 entries); match_len before a group's first position comes
+// from the bits below it in its mask word, or from the words before (as many as the run of matches is long: reads of 2048 bases and
+// more take the wavefront-per-read kernel below).  Groups that straddle the stretch's ends are written element by element.
 constexpr uint32_t kExpandReads = 64;
-__global__ __launch_bounds__(256) void pml_expand_kernel(const uint32_t *__restrict__ words, const uint64_t *__restrict__ offs,
-                                                         uint64_t n_reads, uint32_t phase, uint16_t *__restrict__ out) {
+__global__ __launch_bounds__(256) void pml_expand_group_kernel(const uint32_t *__restrict__ words, const uint64_t *__restrict__ offs,
+                                                               uint64_t n_reads, uint32_t phase, uint16_t *__restrict__ out) {
     __shared__ uint64_t s_off[kExpandReads + 1];
     const uint64_t R0 = (uint64_t)blockIdx.x * kExpandReads;
     const uint32_t nr = (uint32_t)(n_reads - R0 < kExpandReads ? n_reads - R0 : kExpandReads);
     for (uint32_t t = threadIdx.x; t <= nr; t += blockDim.x) s_off[t] = offs[R0 + t];
     __syncthreads();
     const uint64_t B0 = s_off[0], B1 = s_off[nr];
-    if (B1 == B0) return;
-    const float reads_per_pos = (float)nr / (float)(B1 - B0);                           // where a position's read is EXPECTED (exact for equal lengths)
     for (uint64_t g = (B0 >> 3) + threadIdx.x; g * 8u < B1; g += blockDim.x) {
         const uint64_t p0 = g * 8u > B0 ? g * 8u : B0;                                  // this block's first element of the group ...
         const uint64_t p1 = g * 8u + 8u < B1 ? g * 8u + 8u : B1;                        // ... and one past its last
-        // the read that holds p0: the largest i with s_off[i] <= p0 (empty reads are skipped by construction) -- from the expected
-        // place, a step or two either way
-        uint32_t i = (uint32_t)((float)(p0 - B0) * reads_per_pos);
-        i = i < nr - 1u ? i : nr - 1u;
-        while (s_off[i] > p0) i -= 1;
-        while (i + 1u < nr && s_off[i + 1] <= p0) i += 1;
+        // the read that holds p0: the largest i with s_off[i] <= p0 (empty reads are skipped by construction)
+        uint32_t lo = 0, hi = nr - 1u;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi + 1u) >> 1;
+            if (s_off[mid] <= p0) lo = mid; else hi = mid - 1u;
+        }
+        uint32_t i = lo;
         uint64_t beg = s_off[i], end = s_off[i + 1];
         const uint32_t *M = words + ((beg + phase) >> 5) + (R0 + i);
         uint32_t k = (uint32_t)(p0 - beg);
@@ -2735,33 +2824,32 @@ __global__ __launch_bounds__(256) void pml_expand_kernel(const uint32_t *__restr
                 }
             }
         }
-        uint16_t *O = out + g * 8u;
-        if (p1 - p0 == 8u && p0 + 8u <= end) {
-            // the common case: a whole group inside one read -- its eight bits from the word (and the one after it: the array has a
-            // spare word at its end), straight-line code, one aligned 16-byte store
-            const uint32_t nxt = M[w + 1];
-            const uint32_t bits = (uint32_t)((((uint64_t)nxt << 32) | cur) >> (k & 31u)) & 0xFFu;
-            uint32_t v[8];
+        uint32_t v[8];
+        const uint32_t e0 = (uint32_t)(p0 - g * 8u), e1 = (uint32_t)(p1 - g * 8u);
 #pragma unroll
-            for (uint32_t e = 0; e < 8u; ++e) {
-                run = ((bits >> e) & 1u) ? 0u : run + 1u;
+        for (uint32_t e = 0; e < 8u; ++e) {
+            v[e] = 0;
+            if (e >= e0 && e < e1) {
+                while (g * 8u + e >= end) {                                             // the next read (empty ones have no positions)
+                    i += 1;
+                    beg = end;
+                    end = s_off[i + 1];
+                    M = words + ((beg + phase) >> 5) + (R0 + i);
+                    k = 0; run = 0; w = 0; cur = M[0];
+                }
+                if ((k >> 5) != w) { w = k >> 5; cur = M[w]; }
+                run = ((cur >> (k & 31u)) & 1u) ? 0u : run + 1u;
                 v[e] = run > 65535u ? 65535u : run;
+                k += 1;
             }
-            *reinterpret_cast<uint4 *>(O) = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));   // (out is 16-byte aligned: the launcher's check)
-            continue;
         }
-        // a group that crosses into the next read(s), or that straddles the stretch's ends: element by element
-        for (uint64_t p = p0; p < p1; ++p) {
-            while (p >= end) {                                                          // the next read (empty ones have no positions)
-                i += 1;
-                beg = end;
-                end = s_off[i + 1];
-                M = words + ((beg + phase) >> 5) + (R0 + i);
-                k = 0; run = 0;
-            }
-            run = ((M[k >> 5] >> (k & 31u)) & 1u) ? 0u : run + 1u;
-            O[p - g * 8u] = (uint16_t)(run > 65535u ? 65535u : run);
-            k += 1;
+        uint16_t *O = out + g * 8u;
+        if (e0 == 0u && e1 == 8u) {
+            *reinterpret_cast<uint4 *>(O) = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));   // (out is 16-byte aligned: the launcher's check)
+        } else {
+#pragma unroll
+            for (uint32_t e = 0; e < 8u; ++e)
+                if (e >= e0 && e < e1) O[e] = (uint16_t)v[e];
         }
     }
 }
@@ -2816,7 +2904,12 @@ hipError_t launch_pml_expand(const uint32_t *d_words, const uint64_t *d_offsets,
         hipLaunchKernelGGL(pml_expand_wave_kernel, dim3((unsigned)n_reads), dim3(64), 0, stream, d_words, d_offsets, n_reads, phase & 31u, d_out);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(pml_expand_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d_words, d_offsets, n_reads, phase & 31u, d_out);
+    if (n_bases / n_reads < kExpandTileLen) {               // short reads: a wavefront per 64 reads, lanes on their own reads, out through an LDS tile
+        const uint64_t wblocks = (n_reads + 63) / 64;
+        hipLaunchKernelGGL(pml_expand_tile_kernel, dim3((unsigned)wblocks), dim3(64), 0, stream, d_words, d_offsets, n_reads, phase & 31u, d_out);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(pml_expand_group_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d_words, d_offsets, n_reads, phase & 31u, d_out);
     return hipGetLastError();
 }
 

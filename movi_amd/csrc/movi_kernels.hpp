@@ -101,6 +101,10 @@ struct DevIndex {
     // of the slot's base lies in the direction the threshold bit gives, 1 .. 3; 0 = inside the window, further, nowhere, or the '$' row.
     // The rows of the last window beyond r - 1 are padding (c = 7, n = 0, never reached).
     const uint8_t *rows3;
+    // set per launch, reset-mask output (RING = 2) in blocks of one wavefront: non-null = every wavefront, when its 64 walks are over, turns
+    // its reads' mask words into their u16 PML vectors here (through a tile in the LDS its reads were staged in: pml_kernel_flatp's tail)
+    // -- the vector output at the mask walk's instruction count, the expansion hidden under the other wavefronts' gathers
+    uint16_t *expand_out;
 };
 
 // Device counters of one query call.
@@ -149,6 +153,7 @@ struct LaunchCfg {
     int pair_loads = -1;   // the lanes of a pair fetch their row windows together (pml_kernel_flatp<..., PSH = 1>): -1 auto (tables of 2 GB and more), 0 never, 1 always
     int hints = 1;         // 1: mismatches whose scan leaves the row window jump by the reposition hints of the look-ahead rows (DevIndex::hints); 0 = off: A/B
     int zml_ahead = 0;     // 1: zml_kernel_flat<6, T, 0, 1> on the look-ahead rows where they exist (a third fewer iterations, no faster: opt-in)
+    int fused_expand = 1;  // 1: a mask walk whose caller wants the vector expands its wavefronts' reads itself (DevIndex::expand_out); 0 = pml_expand_* kernels behind the walk: A/B
     int deep = -1;         // the PML walk on the deep rows (DevIndex::rows3) where the handle holds them: -1 = batches of short reads (mean length < kDeepReadLen), 0 never, 1 always
 };
 
@@ -266,9 +271,14 @@ struct MaskArgs {
     uint32_t *words = nullptr;
     uint32_t phase = 0;
     uint16_t *tmp_pml = nullptr;
+    // non-null: the caller wants the u16 VECTOR here and `words` is scratch (movi_pml_device through masks): the mask walk expands its
+    // wavefronts' reads itself where it can (one-wavefront blocks, reads in order, a 16-byte aligned vector), pml_expand_* kernels do
+    // it behind the walk otherwise; a batch whose path has no mask output of its own simply writes the vector (no masks at all)
+    uint16_t *expand_out = nullptr;
 };
 uint64_t pml_mask_words(uint64_t n_reads, uint64_t n_bases, uint32_t phase);          // words a batch's masks take (gap words included)
 bool pml_mask_needs_tmp(const DevIndex &ix, const LaunchCfg &cfg, uint64_t n_reads, uint64_t n_bases, bool have_seg_ws);
+bool pml_vector_via_masks(const DevIndex &ix, const LaunchCfg &cfg, uint64_t n_reads, uint64_t n_bases, bool have_seg_ws, bool ordered);   // movi_pml_device's policy: the vector of this batch through reset masks
 // u16 vector <-> masks, streaming (one lane per read; a wavefront per read from a mean length of 2048 bases)
 hipError_t launch_pml_expand(const uint32_t *d_words, const uint64_t *d_offsets, uint64_t n_reads, uint64_t n_bases, uint32_t phase,
                              uint16_t *d_out, hipStream_t stream);

@@ -778,6 +778,71 @@ __global__ __launch_bounds__(256) void pml_kernel_flatp(DevIndex ix, const uint8
         if (want_nx) load_pair_at(nx_e, nx0, nx1);
     }
     if (valid) finish_read();
+    if (msk && ix.expand_out != nullptr) {
+        // ---- the wavefront's walks are over: its reads' reset masks -> their u16 PML vectors (round 6).  The 64 reads of a one-wavefront
+        // block (reads in order) are ONE contiguous stretch of the vector: every lane expands its own read -- match_len carried in a register,
+        // eight bases per step -- into a tile of the stretch in the LDS its bases were staged in, and the wavefront copies the tile out as
+        // aligned 16-byte stores, a contiguous kilobyte per instruction (pml_expand_tile_kernel is the same code as a kernel of its own).
+        // The other wavefronts of the CU are still waiting on their gathers: the expansion costs the launch next to nothing.
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");            // this lane's own word stores before its loads of them
+        __syncthreads();
+        uint16_t *tile = reinterpret_cast<uint16_t *>(s_stage);
+        const uint32_t tile_elems = ix.stage_lds * 32u;                   // (stage_lds bytes per lane x 64 lanes / 2; a multiple of 8)
+        const uint32_t ln = threadIdx.x & 63u;
+        const unsigned long long vb = __ballot(valid);
+        if (vb != 0ull) {
+            const uint64_t B0 = __shfl(beg, 0, 64);                        // lane 0 is valid whenever any lane is
+            const uint64_t B1 = __shfl(beg + len, 63 - __builtin_clzll(vb), 64);
+            const uint32_t *Mx = reinterpret_cast<const uint32_t *>(out) + (((beg + ix.mask_phase) >> 5) + rid);
+            uint16_t *vec = ix.expand_out;
+            uint32_t kx = 0, run = 0, wcur = 0, w0 = 0, w1 = 0;
+            const uint64_t endx = beg + len;
+            if (valid && len) { w0 = Mx[0]; w1 = Mx[1]; }                 // (the array has a spare word at its end)
+            auto one = [&](uint32_t o) {
+                if ((kx >> 5) != wcur) { wcur = kx >> 5; w0 = w1; w1 = Mx[wcur + 1]; }
+                run = ((w0 >> (kx & 31u)) & 1u) ? 0u : run + 1u;
+                tile[o] = (uint16_t)(run > 65535u ? 65535u : run);
+                kx += 1;
+            };
+            for (uint64_t A = B0 & ~7ull; A < B1; A += tile_elems) {
+                const uint64_t hi = A + tile_elems < B1 ? A + tile_elems : B1;
+                if (valid && kx < len && beg + kx < hi) {
+                    uint32_t o = (uint32_t)(beg + kx - A);
+                    const uint32_t stop = (uint32_t)((endx < hi ? endx : hi) - A);
+                    while (o < stop && (o & 7u)) one(o++);
+                    while (o + 8u <= stop) {
+                        if ((kx >> 5) != wcur) { wcur = kx >> 5; w0 = w1; w1 = Mx[wcur + 1]; }
+                        const uint32_t bits = (uint32_t)((((uint64_t)w1 << 32) | w0) >> (kx & 31u)) & 0xFFu;
+                        uint32_t v[8];
+#pragma unroll
+                        for (uint32_t e = 0; e < 8u; ++e) {
+                            run = ((bits >> e) & 1u) ? 0u : run + 1u;
+                            v[e] = run > 65535u ? 65535u : run;
+                        }
+                        *reinterpret_cast<uint4 *>(&tile[o]) = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
+                        o += 8u;
+                        kx += 8u;
+                    }
+                    while (o < stop) one(o++);
+                }
+                __syncthreads();
+                const uint32_t nelem = (uint32_t)(hi - A);
+                for (uint32_t g = ln; g * 8u < nelem; g += 64u) {
+                    const uint64_t p = A + (uint64_t)g * 8u;
+                    const uint4 q = *reinterpret_cast<const uint4 *>(&tile[g * 8u]);
+                    if (p >= B0 && p + 8u <= hi) {
+                        *reinterpret_cast<uint4 *>(vec + p) = q;
+                    } else {
+                        const uint32_t x[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                        for (uint32_t e = 0; e < 8u; ++e)
+                            if (p + e >= B0 && p + e < hi) vec[p + e] = (uint16_t)(x[e >> 1] >> (16u * (e & 1u)));
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
     if (SEG != 1) {
         const uint32_t ffw = wave_sum(ff_total), scw = wave_sum(scan_total), rpw = wave_sum(repo_total),
                        erw = wave_sum(err_total);

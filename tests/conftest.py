@@ -121,3 +121,23 @@ def classify_py(pml, thr, bin_width=150):
         start = end
     found = above / (above + below + 0.0) > 0.5
     return found, s / bins, above, below
+
+
+def vector_kernel(name):
+    """A walk kernel's name with the reset-mask instantiation (RING = 2: the vector through masks, movi_pml_device's default on batches
+    of short reads) read as the one that writes the vector itself (RING = 0): for asserts that are about the table layout the launch
+    policy picked, not about how the PMLs left the kernel."""
+    return name[:-3] + "0>" if name.startswith("pml_kernel_flatp<") and name.endswith(", 2>") else name
+
+
+@pytest.fixture
+def packer_paths():
+    """Handles created inside the test write PML vectors straight from the walk ("pml_via_mask" 0: register packer / LDS ring) --
+    for the tests that are about those output paths, or that assert their kernels by name."""
+    old = os.environ.get("MOVI_PML_VIA_MASK")
+    os.environ["MOVI_PML_VIA_MASK"] = "0"
+    yield
+    if old is None:
+        os.environ.pop("MOVI_PML_VIA_MASK", None)
+    else:
+        os.environ["MOVI_PML_VIA_MASK"] = old

@@ -13,6 +13,14 @@ from test_top_of_walk_gpu import _ref
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def _vectors_straight_from_the_walk(packer_paths):
+    """This module is about the look-ahead rows AND the walk's own output paths (register packer, LDS ring), asserted by kernel name:
+    its handles write the vector themselves ("pml_via_mask" 0).  The mask output on every layout: tests/test_mask_gpu.py,
+    tests/test_deep_rows_gpu.py, tests/test_kernel_coverage_gpu.py."""
+    yield
+
 CAP = 336          # bases per lane the default occupancy cap's LDS padding holds (7 wavefronts per CU) ...
 CAP_AHEAD = 256    # ... and the cap on the look-ahead rows (9 wavefronts per CU)
 N_BIG = 300_000    # > 256 CUs x 64 lanes x 18 wavefronts: the capped, staged launch
@@ -99,7 +107,11 @@ def test_ahead_rows_are_built_by_the_first_pml_query_on_a_small_table(built_lib,
     gpu, cpu = movi_amd.MoveIndex.from_image(img), Oracle(img)
     bases, offs = _big_batch(_ref(), np.random.default_rng(9300), n_long=0, max_len=200)
     exp, ff, sc = cpu.pml_batch(bases, offs, threads=8)
-    out, st = gpu.query_pml_packed(bases, offs)                         # nothing set: table + look-ahead rows by themselves
+    out, st = gpu.query_pml_packed(bases, offs)                         # nothing set: table + look-ahead rows (+ round 6: deep rows) by themselves
+    assert gpu.last_launch()["ahead"] == 2 and gpu.info("ahead_rows_bytes") > 0 and gpu.info("deep_rows_bytes") > 0   # short reads on a small table of real text: the deep rows
+    assert (out == exp).all() and (st.fast_forwards, st.scans, st.errors) == (ff, sc, 0)
+    gpu.set_option("deep", 0)                                           # ... without them: the look-ahead rows the same query built
+    out, st = gpu.query_pml_packed(bases, offs)
     assert gpu.last_launch()["ahead"] == 1
     assert (out == exp).all() and (st.fast_forwards, st.scans, st.errors) == (ff, sc, 0)
     m, c, _ = gpu.query_count_packed(bases[: int(offs[1000])], offs[:1001])   # other queries are not affected

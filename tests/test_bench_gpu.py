@@ -33,7 +33,7 @@ def test_bench_single_gpu_contract():
     assert d["roofline"]["gathers_served_from"].startswith("infinity cache")                  # ... 1.6 MB of rows (3.2 MB as walked): where the gathers are served from follows the rows they walk
     assert d["roofline"]["side_table_bytes"] == 256 << 20                                      # ... the top-of-walk table is reported beside it
     assert d["roofline"]["lane_iterations_per_s"] > 0 and d["roofline"]["rows_read_per_s"] > 0
-    assert d["roofline"]["kernel"].startswith("pml_kernel_flatp<6, unsigned int, 0, 0, 0, 1, 1,") and d["rccl_ranks"] == 0
+    assert d["roofline"]["kernel"].startswith("pml_kernel_flatp<6, unsigned int, 0, 0, 0, 1, ") and d["rccl_ranks"] == 0
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and d["parity_sample_ok"] is True
 
 

@@ -165,9 +165,14 @@ def test_last_launch_reports_the_policy(engine6):
     bases, offs = pack([b"ACGTACGTAC" * 20] * 300)
     gpu.query_pml_packed(bases, offs)
     li = gpu.last_launch()
-    # the default walk: reads staged through LDS (a small batch: uncapped, 336 bases per lane) on the look-ahead rows (a small table)
-    assert li["kernel"] == "pml_kernel_flatp<6, unsigned int, 0, 0, 0, 1, 1, 0, 0>" and li["variant"] == 14
-    assert li["block_threads"] == 64 and li["waves_per_cu"] == 0 and li["segmented"] == 0 and li["staged"] == 336 and li["ahead"] == 1
+    # the default walk of a batch of short reads (round 6): reads staged through LDS (a small batch: uncapped, 336 bases per lane), on the
+    # DEEP rows (a small table of real text), the vector through reset masks that every wavefront expands itself (RING = 2)
+    assert li["kernel"] == "pml_kernel_flatp<6, unsigned int, 0, 0, 0, 1, 2, 0, 2>" and li["variant"] == 14
+    assert li["block_threads"] == 64 and li["waves_per_cu"] == 0 and li["segmented"] == 0 and li["staged"] == 336 and li["ahead"] == 2
+    gpu.set_option("pml_via_mask", 0)
+    gpu.query_pml_packed(bases, offs)
+    assert gpu.last_launch()["kernel"] == "pml_kernel_flatp<6, unsigned int, 0, 0, 0, 1, 2, 0, 0>"        # ... by the register packer
+    gpu.set_option("pml_via_mask", -1)
     gpu.set_option("stage_reads", 0)
     gpu.query_pml_packed(bases, offs)
     assert gpu.last_launch()["kernel"] == "pml_kernel_flatp<6, unsigned int, 0, 0, 0, 0, 0, 0, 0>" and gpu.last_launch()["staged"] == 0

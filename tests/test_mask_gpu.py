@@ -254,7 +254,9 @@ def test_parity_files_through_masks(built_lib):
     """The PML parity files of this suite once more with MOVI_PML_VIA_MASK=1: every handle then answers movi_pml_host and
     movi_pml_device from reset masks (host worker threads / pml_expand_kernel) -- same oracle comparisons, same goldens."""
     env = dict(os.environ, MOVI_PML_VIA_MASK="1")
-    files = ["tests/test_gpu_parity.py", "tests/test_ahead_rows_gpu.py", "tests/test_top_of_walk_gpu.py", "tests/test_device_entry_gpu.py"]
+    # (tests/test_ahead_rows_gpu.py is about the walk's own output paths and pins them; the CLI's goldens go through masks too: the binary's
+    # handles read the same variable)
+    files = ["tests/test_gpu_parity.py", "tests/test_top_of_walk_gpu.py", "tests/test_device_entry_gpu.py", "tests/test_cli_gpu.py"]
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + files, cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

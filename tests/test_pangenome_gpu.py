@@ -137,3 +137,67 @@ def test_c3_classify_at_size(pangenome):
             assert (int(a[lo + i]), int(b[lo + i])) == (ea, eb) and int(sm[lo + i]) == round(avg * (ea + eb)), (lo, i)
     gpu.close()
     cpu.close()
+
+
+@pytest.mark.timeout(1800)
+def test_real_bwt_beyond_every_cache_vs_oracle(built_lib):
+    """A REAL BWT that fits no cache, under the driver's eye (round 6): bench.py's `c2mid` -- the c2 pangenome with 0.5 % SNPs, 37.8 M rows
+    = 302 MB, its look-ahead copy 604 MB and its deep rows 805 MB, all beyond the 256 MB Infinity Cache (built by tools/build_index in
+    2 - 5 minutes where no cache travelled with the tree).  The DEFAULT policy's launches of the whole 1 M x 150 bp batch -- device entry
+    point: deep rows, vector through fused reset masks; the same with the walk's own packer; on the look-ahead rows; the count query --
+    with 20 000-read slices from the start, the middle and the end held to the oracle: PMLs, fast-forward / scan counters, matched
+    lengths and counts; the kernels the policy picked asserted by name.
+    Reference: src/move_structure.cpp:59-87 (LF_move), src/move_structure_query.cpp:513-601, src/move_structure_search.cpp:340-352."""
+    import torch
+    import movi_amd
+    sys.path.insert(0, ROOT)
+    import bench
+    from oracle.oracle import Oracle
+    wl = dict(bench.WORKLOADS["c2mid"])
+    idx_dir, reads_file = bench.ensure_pangenome(wl, 1, 0, lambda: None)
+    img = np.fromfile(os.path.join(idx_dir, "index.movi"), np.uint8)
+    n, L = wl["reads"], wl["read_len"]
+    bases = np.fromfile(reads_file, np.uint8, count=n * L)
+    offs = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+    gpu, cpu = movi_amd.MoveIndex.from_image(img), Oracle(img)
+    rows = int(gpu.desc.r)
+    assert 30_000_000 < rows < 48_000_000, rows
+    gpu.prepare(gpu.PREPARE_PML | gpu.PREPARE_COUNT)
+    assert gpu.info("deep_rows_bytes") > 700e6 and gpu.info("ahead_rows_bytes") > 500e6 and gpu.info("ahead_no_ff") >= 0.67
+    dev = torch.device("cuda", 0)
+    d_bases = torch.from_numpy(bases).to(dev)
+    d_offs = torch.from_numpy(offs.view(np.int64)).to(dev)
+    d_out = torch.empty(n * L, dtype=torch.int16, device=dev)
+    d_err = torch.zeros(n, dtype=torch.uint8, device=dev)
+    slices = [(0, 20_000), (n // 2 - 10_000, n // 2 + 10_000), (n - 20_000, n)]
+    expected = []
+    for lo, hi in slices:
+        expected.append(cpu.pml_batch(bases[lo * L: hi * L], offs[: hi - lo + 1], threads=16))
+    for name, opts, kernel, ahead in (("default", {}, "pml_kernel_flatp<6, unsigned int, 0, 0, 0, 1, 2, 0, 2>", 2),
+                                      ("packer", {"pml_via_mask": 0}, "pml_kernel_flatp<6, unsigned int, 0, 0, 0, 1, 2, 0, 0>", 2),
+                                      ("look-ahead rows", {"deep": 0}, "pml_kernel_flatp<6, unsigned int, 0, 0, 0, 1, 1, 0, 2>", 1)):
+        for k, v in opts.items():
+            gpu.set_option(k, v)
+        d_out.fill_(-1)
+        gpu.pml_device(d_bases.data_ptr(), d_offs.data_ptr(), n, n * L, d_out.data_ptr(), d_err.data_ptr())
+        torch.cuda.synchronize()
+        li = gpu.last_launch()
+        assert li["kernel"] == kernel and li["ahead"] == ahead and li["waves_per_cu"] == (13 if ahead == 2 else 9), (name, li)
+        assert int(d_err.sum().item()) == 0
+        for (lo, hi), (exp, eff, esc) in zip(slices, expected):
+            got = d_out[lo * L: hi * L].cpu().numpy().view(np.uint16)
+            assert (got == exp).all(), (name, lo)
+            d_so = torch.from_numpy(offs[: hi - lo + 1].view(np.int64).copy()).to(dev)
+            gpu.pml_device(d_bases.data_ptr() + lo * L, d_so.data_ptr(), hi - lo, (hi - lo) * L, d_out.data_ptr(), d_err.data_ptr())
+            st = gpu.last_stats()
+            assert (st.fast_forwards, st.scans, st.errors) == (eff, esc, 0), (name, lo)
+        for k in opts:
+            gpu.set_option(k, -1)
+    # the count query (the state machine on the plain rows: 302 MB)
+    m, c, cst = gpu.query_count_packed(bases, offs)
+    assert cst.errors == 0 and gpu.last_launch()["kernel"] == "zml_kernel_flat<6, unsigned int, 0, 0, 0, 1>"
+    for lo, hi in slices:
+        em, ec = cpu.count_batch(bases[lo * L: hi * L], offs[: hi - lo + 1], threads=16)
+        assert (m[lo:hi] == em).all() and (c[lo:hi] == ec).all(), lo
+    gpu.close()
+    cpu.close()
