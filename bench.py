@@ -51,8 +51,8 @@ WORKLOADS = {
                desc="random 1B-row blocked-thresholds table (6 GB), 1.25M x 150bp reads per GPU (BASELINE config 5 shard; "
                     "use with --query count)"),
     "c2mid": dict(kind="pangenome", pg="mid", mode=6, reads=1_000_000, read_len=150, sub=0.01,
-                  desc="a real BWT that fits NO cache and still builds in minutes (round 6): the c2 pangenome with 0.5 % SNPs between its 64 genomes "
-                       "(640 Mbp text, 37.8 M rows = 302 MB; look-ahead copy 604 MB, deep rows 805 MB: beyond the 256 MB Infinity Cache), 1M x 150bp reads per GPU"),
+                  desc="a real BWT that fits NO cache and still builds in a minute or two (round 6): 64 genomes of a 2.5 Mbp ancestor, 1.3 % SNPs "
+                       "(320 Mbp text, 39.5 M rows = 316 MB; look-ahead copy 632 MB, deep rows 842 MB: beyond the 256 MB Infinity Cache), 1M x 150bp reads per GPU"),
     "c4real": dict(kind="pangenome", pg="big", mode=6, reads=1_250_000, read_len=150, sub=0.01,
                    desc="real BWT beyond the Infinity Cache and the TLBs' reach: synthetic 64-genome pangenome, 8.5 Mbp ancestor, 1 % "
                         "SNPs (1.09 Gbp text, ~102 M rows = 0.8 GB, built on first use: ~10 min), 1.25M x 150bp reads per GPU"),
@@ -70,7 +70,7 @@ PG_BIG = dict(anc=8_500_000, genomes=64, snp=0.01, seed=12)   # ~102 M rows (n /
 PG_BIG2 = dict(anc=16_500_000, genomes=64, snp=0.01, seed=14)  # ~220 M rows: the largest text the 32-bit suffix array takes (2.11 Gbp), ~35 GB of host memory
 PG_BIG3 = dict(anc=16_500_000, genomes=64, snp=0.04, seed=15)  # the same 2.11 Gbp with 4 % SNPs: n / r = 3.1 -> 675 738 185 rows (0.68 B): a REAL BWT at the size of the BASELINE target's table (small-scale calibration of n / r against the SNP rate: 1 % 11.1, 3 % 4.6, 5 % 3.1, 8 % 2.3)
 PG_TINY = dict(anc=60_000, genomes=8, snp=0.002, seed=13)     # tests: built in a second
-PG_MID = dict(anc=5_000_000, genomes=64, snp=0.005, seed=16)  # 37 755 947 rows (n / r = 16.95): tools/build_index in 2 - 5 min, ~8 GB of host memory
+PG_MID = dict(anc=2_500_000, genomes=64, snp=0.013, seed=16)  # 39 493 027 rows (n / r = 8.1; 320 Mbp of text): tools/build_index in 1 - 3 min, ~5 GB of host memory
 
 
 def pg_of(wl):
@@ -859,6 +859,7 @@ def main():
     ap.add_argument("--big-rows", type=int, default=1_000_000_000, help="rows of the `big_table` leg's table (tests shrink it)")
     ap.add_argument("--long-reads", type=int, default=0, help="reads per GPU of the `long_reads` leg (default: c3's 100 000; tests shrink it)")
     ap.add_argument("--quick", action="store_true", help="the timed region only: no cpu_baseline, long_reads, host_path, sustained, big_table (A/B sweeps)")
+    ap.add_argument("--with-mask-leg", action="store_true", help="with --quick: keep the `mask_path` leg (the mask walk and the expand kernel timed on their own)")
     ap.add_argument("--dry-run", action="store_true", help="the N-rank flow on the CPU over gloo with a stand-in engine: no GPU call, no result (value null); "
                     "spawn, rank 0's synthesis, the broadcast, the read hand-over, timing and JSON assembly are real (tests/test_dist_cpu.py)")
     args = ap.parse_args()
@@ -1107,7 +1108,7 @@ def main():
     # ---- the same batch as RESET MASKS (round 6; default run only, never part of `value`): the walk that writes one bit per base
     # (movi_pml_mask_device), and pml_expand_kernel turning the words back into the u16 vector -- each timed with HIP events
     mask_path = None
-    if default_run:
+    if default_run and (not args.quick_only_walk or args.with_mask_leg):
         try:
             from movi_amd.engine import mask_words
             d_words = torch.zeros(mask_words(n_reads, n_bases), dtype=torch.int32, device=dev)

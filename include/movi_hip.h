@@ -157,7 +157,8 @@ int movi_index_load_replicated(const char *index_dir_or_file, const int *devices
 
 /* Build the handle's derived tables NOW instead of inside the first query: `what` = MOVI_PREPARE_PML (top-of-walk table,
  * 256 MB at K = 12; look-ahead rows, 16 bytes per row, where the device has room for them and half as much again, never more
- * than a quarter of the device by itself) | MOVI_PREPARE_COUNT (row-start checkpoints, 8 bytes per 32 rows; interval table,
+ * than a quarter of the device by itself; round 6: the deep rows, 21.33 bytes per row, beside them for real-text tables of at most
+ * 50 M rows -- "deep_rows") | MOVI_PREPARE_COUNT (row-start checkpoints, 8 bytes per 32 rows; interval table,
  * 256 MB; nothing else: since round 5 the count query's default is the lane state machine on the PLAIN rows -- the look-ahead rows
  * are built for it only under "count_variant" 0, the base-synchronous kernel of rounds 1 - 4, and then where a sample of the table
  * says the search will use them) | MOVI_PREPARE_ZML (nothing: accepted for symmetry).  Honours the options set before it ("kmer_k", "ftab_k", "ahead_rows": a table the caller built or switched
@@ -300,8 +301,8 @@ int movi_pml_expand_device(movi_index_t *ix, const uint32_t *d_mask_words, const
  * with first_base = 0 relative to offsets[0].  Only 1/8 byte per base comes back over PCIe. */
 int movi_pml_mask_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_offsets,
                        uint64_t n_reads, uint32_t *h_mask_words, uint8_t *h_read_err, movi_query_stats_t *stats);
-/* masks -> u16 vector on the HOST: pure CPU code (no device needed), n_threads worker threads (0 = as many as the process may
- * run on, at most 32).  h_out_pml[offsets[i] + k] as movi_pml_host writes it; offsets need not start at 0 (the masks are laid out
+/* masks -> u16 vector on the HOST: pure CPU code (no device needed), n_threads worker threads (0 = three quarters of
+ * the CPUs the process may use -- its affinity mask capped by the cgroup's CPU quota --, at most 24).  h_out_pml[offsets[i] + k] as movi_pml_host writes it; offsets need not start at 0 (the masks are laid out
  * relative to offsets[0], as movi_pml_mask_host writes them). */
 int movi_pml_expand_host(const uint32_t *h_mask_words, const uint64_t *h_offsets, uint64_t n_reads,
                          uint16_t *h_out_pml, int n_threads);
@@ -430,11 +431,20 @@ int movi_host_unregister(void *p);
  * there --, shorter ones fused; 1 = always fused, 0 = always two passes),
  * "zml_ahead" (1: the ZML parse walks on the look-ahead rows where they exist -- a third fewer iterations, no faster: off
  * by default),
- * "pml_via_mask" (movi_pml_host: 1 = the walk writes reset masks, only they cross PCIe and the u16 vector is expanded into the
- * caller's buffer by host threads (movi_pml_expand_host's code) while later chunks are walked; 0 = the vector itself comes down;
- * -1, the default: masks for calls of 2^22 bases and more.  movi_pml_device: 1 = mask walk + pml_expand_kernel, 0 / -1 = the walk
- * writes the vector itself (measured faster on the device: DESIGN.md)), "host_threads" (worker threads of the host-side
- * expansion, 0 = as many as the process may run on, at most 32),
+ * "pml_via_mask" (round 6; PML as reset masks.  movi_pml_device: the walk writes one bit per base and every wavefront expands its reads'
+ * words into the u16 vector itself when its walks are over -- -1, the default: batches of short reads (mean length < 1024: c2 78.4 ->
+ * 86.7 Gbases/s, 1 B rows 42.3 -> 46.0); 1 = wherever the walk can write masks; 0 = the walk writes the vector itself (register packer /
+ * LDS ring).  movi_pml_host: besides, with -1 a call of >= 2^22 bases whose result vector is PAGEABLE brings only the masks down and
+ * expands them into the caller's vector on host worker threads beside the walks of the later chunks (1 = every call, 0 = never),
+ * "fused_expand" (1, the default; 0 = the expansion by kernels of their own behind the walk: A/B), "reserve_device_masks" (device scratch
+ * for the mask words of movi_pml_device calls of up to this many bases, reserved now instead of inside the first such call),
+ * "host_threads" (worker threads of the host-side expansion, 0 = three quarters of the CPUs the process may use -- affinity mask capped by the cgroup's quota --, at most 24),
+ * "deep_rows" (round 6: a third layout of the table for the PML walk of short reads -- 21.33 bytes per row, windows of three rows, every
+ * row with what the walk reads at its LF target AND at that row's target: up to three bases per gather.  Left alone, the first PML query
+ * (or movi_index_prepare) builds them, beside the look-ahead rows, for tables of at most 50 M rows whose positions mostly reach their LF
+ * target without a fast-forward (real text); 1 = build now (tables of fewer than 2^28 - 1 rows), 0 = none (freed).  "ahead_rows" 0 / 1
+ * frees them too: it is a statement about what the walk runs on), "deep" (-1, the default: batches whose mean read length is below
+ * 1024 walk on the deep rows where the handle holds them; 0 = never, 1 = always, the segment plan's launches included: A/B),
  * "ftab_k" (the count query's interval table -- the backward-search interval after the last K bases of a read by one lookup,
  * the reference's own ftab (src/move_structure_search.cpp:66-167) put to work for --count; left alone the first count query
  * on a DNA index builds the K = 12 table (256 MB); 0 = none, 1..12 = build that one now). */

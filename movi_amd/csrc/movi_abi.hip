@@ -145,6 +145,10 @@ struct movi_index {
     bool host_autopin = true;        // big *_host calls on pageable buffers page-lock them for the call ("host_autopin")
     bool host_overlap = true;        // page-locked buffers take the overlapped path ("host_overlap" 0: one upload, the walk, one download)
     bool seg_seen = false;           // the last PML / ZML host call on long reads was walked segment-parallel (chunk policy below)
+    // the segment plan's probe verdict of the last batch of long reads, kept for the next calls on batches of the same shape (a stream of
+    // batches of one kind of reads): the probe is a 0.4 ms read-back in front of a 5 ms walk (profiles/r06_few_long_reads.txt)
+    int seg_cache_verdict = -1, seg_cache_left = 0;
+    uint32_t seg_cache_key = 0;
     uint64_t reserved_result_bases = 0, reserved_reads = 0;   // "reserve_host_results" / "reserve_host_reads": what the mask words' scratch is reserved for
     int pml_via_mask = -1;           // "pml_via_mask": movi_pml_host brings reset masks down and expands them on the host (-1: calls of >= 2^22 bases)
     int host_threads = 0;            // "host_threads": workers of the host-side expansion (0 = host_threads_default())
@@ -1209,8 +1213,20 @@ static int ml_device(bool zml, movi_index_t *ix, const uint8_t *d_bases, const u
                 m.tmp_pml = static_cast<uint16_t *>(*tmp_p);
             }
         }
+        // (device-pointer calls: the probe's verdict is remembered for the next 15 calls on batches of the same shape -- mean read length
+        // and read count to a factor of two --: such calls then enqueue the walk without the probe and its read-back.  Either verdict
+        // gives the same answers; a stale one costs speed for at most those calls.  "seg_probe" 0 / 2 never probe anyway.)
+        int cached = -1;
+        const bool use_cache = seg_verdict == nullptr && ix->cfg.seg_probe == 1 && n_bases / n_reads >= 2ull * (uint64_t)std::max(ix->cfg.seg_len, 1);
+        const uint32_t key = use_cache ? ((uint32_t)(63 - __builtin_clzll(n_bases / n_reads)) << 8) | (uint32_t)(63 - __builtin_clzll(n_reads)) : 0u;
+        if (use_cache) {
+            if (ix->seg_cache_left > 0 && ix->seg_cache_key == key) { cached = ix->seg_cache_verdict; ix->seg_cache_left -= 1; }
+            seg_verdict = &cached;
+        }
+        const int before = cached;
         HIP_TRY(launch_pml(ix->kmode, ix->dev, d_bases, d_offsets, n_reads, n_bases, d_out, d_read_err, d_stats,
                            d_read_order, ix->cfg, s, cls, seg_ws, ragged_hint, seg_verdict, &ix->last_launch, m));
+        if (use_cache && before < 0 && cached >= 0) { ix->seg_cache_verdict = cached; ix->seg_cache_key = key; ix->seg_cache_left = 15; }
     }
     return MOVI_OK;
 }

@@ -1917,13 +1917,54 @@ __global__ __launch_bounds__(256) void zml_kernel_flat(DevIndex ix, const uint8_
         load_pair_at(beg + len, rb, rb2);
         fix_pair(beg + len, rb, rb2);
     }
-    if (len > 16) load_pair_at(beg + len - 16, nx0, nx1);
+    if (len > 16 && (SEG != 0 || ix.stage_lds == 0u)) load_pair_at(beg + len - 16, nx0, nx1);   // (staged reads: the bases come from LDS)
     // b = code of the base of step k, bn = of step k + 1, bn2 = of step k + 2: M2 -> M0 chains two bases inside one
     // iteration (three on the look-ahead rows), so the next bases are decoded ahead (rb always holds the 8-group of step
     // k + 2, the furthest one decoded)
     uint32_t b = s_code[(uint32_t)(rb >> 56) & 0xFFu];
     uint32_t bn = len > 1 ? s_code[(uint32_t)(rb >> 48) & 0xFFu] : 0xFFu;
     uint32_t bn2 = len > 2 ? s_code[(uint32_t)(rb >> 40) & 0xFFu] : 0xFFu;
+    // READS STAGED THROUGH LDS (round 6; ix.stage_lds = bases per lane in the block's dynamic LDS, set by the launchers for blocks of one
+    // wavefront, 0 = none): every lane copies the next stretch of its read into LDS -- 16 bytes per load from the read's end backwards,
+    // so a wavefront's contiguous reads arrive as whole cache lines, each fetched once -- and the bases of steps k, k + 1, k + 2 come
+    // from there (pml_kernel_flatp's staging: same layout, slot s of lane l at byte (s / 4) * 256 + 4 l + s % 4).  Without it a lane
+    // fetches its read 16 bases at a time and every fetch is a line from the fabric: 0.0625 lines per base.  Longer reads roll.
+    extern __shared__ __align__(16) uint8_t z_stage[];
+    const uint32_t zcap = (SEG == 0) ? ix.stage_lds : 0u;
+    uint32_t zbase = 0;
+    auto zstage_from = [&](uint32_t k0, bool on) {        // every lane of the wavefront makes the call; lanes with `on` stage
+        uint32_t *S = reinterpret_cast<uint32_t *>(z_stage);
+        const uint32_t sl = threadIdx.x & 63u;
+        const uint32_t left = (on && len > k0) ? len - k0 : 0u;
+        const uint32_t cnt = left < zcap ? left : zcap;
+        for (uint32_t g = 0; wave_any(16u * g < cnt); g += 2u) {
+            uint64_t c0[2], c1[2];
+#pragma unroll
+            for (uint32_t u = 0; u < 2u; ++u) {
+                const uint64_t e = 16u * (g + u) < cnt ? beg + len - k0 - 16u * (g + u) : 16u;
+                load_pair_at(e, c0[u], c1[u]);
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 2u; ++u) {
+                if (16u * (g + u) < cnt) {
+                    const uint64_t e = beg + len - k0 - 16u * (g + u);
+                    fix_pair(e, c0[u], c1[u]);
+                    const uint64_t r0 = __builtin_bswap64(c0[u]), r1x = __builtin_bswap64(c1[u]);
+                    S[(4u * (g + u) + 0u) * 64u + sl] = (uint32_t)r0;
+                    S[(4u * (g + u) + 1u) * 64u + sl] = (uint32_t)(r0 >> 32);
+                    S[(4u * (g + u) + 2u) * 64u + sl] = (uint32_t)r1x;
+                    S[(4u * (g + u) + 3u) * 64u + sl] = (uint32_t)(r1x >> 32);
+                }
+            }
+        }
+        if (on) zbase = k0;
+    };
+    auto zcode = [&](uint32_t j) -> uint32_t {            // code of the base of step j (inside the staged stretch: the rolls see to it), 0xFF beyond the read
+        const uint32_t q0 = j - zbase, q = q0 < zcap ? q0 : zcap - 1u;
+        const uint32_t c = s_code[z_stage[(q >> 2) * 256u + (threadIdx.x & 63u) * 4u + (q & 3u)]];
+        return j < len ? c : 0xFFu;
+    };
+    if (zcap) zstage_from(0u, len > 0);
     uint4 pk = make_uint4(0, 0, 0, 0), pk_old = pk;
     // CNT: the last non-empty interval (what the search reports: backward_search :176-199) and whether the search has begun
     IdxT prs = 0, pre = 0;
@@ -2234,8 +2275,16 @@ __global__ __launch_bounds__(256) void zml_kernel_flat(DevIndex ix, const uint8_
         };
         if (n_emit) {
             if (!CNT) emit_at(ekA, valA);
+            if (n_emit == 2u && !CNT) emit_at(ekB, valB);
+        }
+        if (zcap) {
+            // the bases of steps k .. k + 2 from the staged stretch; a lane about to leave it makes the whole wavefront stage again
+            const uint32_t far = k + 2u < len ? k + 2u : len - 1u;                     // the furthest step decoded ahead that is still a base of the read
+            const uint32_t out_of = (uint32_t)(ph != phDone) & (uint32_t)(k < len) & (uint32_t)(far - zbase >= zcap);
+            if (wave_any(out_of != 0u)) zstage_from(k, ph != phDone);
+            if (n_emit) { b = zcode(k); bn = zcode(k + 1u); bn2 = zcode(k + 2u); }
+        } else if (n_emit) {
             if (n_emit == 2u) {
-                if (!CNT) emit_at(ekB, valB);
                 decode_ahead(ekA + 3u, bn);                   // (b, bn, bn2) were shifted twice: two places to fill
                 decode_ahead(ekB + 3u, bn2);
             } else {
@@ -2421,6 +2470,12 @@ static hipError_t launch_count_flat(int mode, const DevIndex &ix, const uint8_t 
         const int bpc = wpc < 3 ? 3 : wpc;
         if (bpc < 32) dyn_lds = ((163840u / (unsigned)bpc) & ~1023u) - 1024u;
     }
+    // reads staged through LDS (round 6; blocks of one wavefront): the cap's padding, or kZmlStageBytes of their own (16 wavefronts per CU)
+    DevIndex ixl = ix;
+    if (cfg.stage_reads != 0) {
+        if (dyn_lds < kZmlStageBytes) dyn_lds = kZmlStageBytes;
+        ixl.stage_lds = (uint32_t)std::min<size_t>(1024, (dyn_lds / 64) & ~(size_t)15);
+    }
     {
         char nm[96];
         snprintf(nm, sizeof(nm), "zml_kernel_flat<%d, %s, 0, 0, %d, 1>", mode, ix.idx32 ? "unsigned int" : "unsigned long", pair ? 1 : 0);
@@ -2432,7 +2487,7 @@ static hipError_t launch_count_flat(int mode, const DevIndex &ix, const uint8_t 
         info->ahead = 0;
     }
 #define MOVI_LAUNCH_CNT(M, T, P)                                                                                          \
-    hipLaunchKernelGGL((zml_kernel_flat<M, T, 0, 0, P, 1>), grid, block, dyn_lds, stream, ix, d_bases, d_offsets, n_reads, \
+    hipLaunchKernelGGL((zml_kernel_flat<M, T, 0, 0, P, 1>), grid, block, dyn_lds, stream, ixl, d_bases, d_offsets, n_reads, \
                        (uint16_t *)nullptr, d_err, d_stats, d_order, ZSegArgs(), d_matched, d_count)
 #define MOVI_LAUNCH_CNT_M(M)                                                                                              \
     do {                                                                                                                  \
@@ -2517,31 +2572,36 @@ hipError_t launch_zml(int mode, const DevIndex &ix, const uint8_t *d_bases, cons
         if (bpc < 3) bpc = 3;
         if (bpc < 32) dyn_lds = ((163840u / (unsigned)bpc) & ~1023u) - 1024u;
     }
+    DevIndex ixl = ix;                                   // reads staged through LDS (round 6): the state machine in blocks of one wavefront
+    if (v == 1 && bt == 64 && cfg.stage_reads != 0) {
+        if (dyn_lds < kZmlStageBytes) dyn_lds = kZmlStageBytes;
+        ixl.stage_lds = (uint32_t)std::min<size_t>(1024, (dyn_lds / 64) & ~(size_t)15);
+    }
 #define MOVI_LAUNCH_ZML(M)                                                                                     \
     do {                                                                                                       \
         if (v == 0)                                                                                            \
-            hipLaunchKernelGGL(zml_kernel<M>, grid, block, dyn_lds, stream, ix, d_bases, d_offsets, n_reads,   \
+            hipLaunchKernelGGL(zml_kernel<M>, grid, block, dyn_lds, stream, ixl, d_bases, d_offsets, n_reads,   \
                                d_out, d_err, d_stats, d_order, ZSegArgs());                                    \
         else if (pair && ix.idx32)                                                                             \
-            hipLaunchKernelGGL((zml_kernel_flat<M, uint32_t, 0, 0, 1>), grid, block, dyn_lds, stream, ix,      \
+            hipLaunchKernelGGL((zml_kernel_flat<M, uint32_t, 0, 0, 1>), grid, block, dyn_lds, stream, ixl,     \
                                d_bases, d_offsets, n_reads, d_out, d_err, d_stats, d_order, ZSegArgs(), nullptr, nullptr); \
         else if (pair)                                                                                         \
-            hipLaunchKernelGGL((zml_kernel_flat<M, uint64_t, 0, 0, 1>), grid, block, dyn_lds, stream, ix,      \
+            hipLaunchKernelGGL((zml_kernel_flat<M, uint64_t, 0, 0, 1>), grid, block, dyn_lds, stream, ixl,     \
                                d_bases, d_offsets, n_reads, d_out, d_err, d_stats, d_order, ZSegArgs(), nullptr, nullptr); \
         else if (ix.idx32)                                                                                     \
-            hipLaunchKernelGGL((zml_kernel_flat<M, uint32_t>), grid, block, dyn_lds, stream, ix, d_bases,      \
+            hipLaunchKernelGGL((zml_kernel_flat<M, uint32_t>), grid, block, dyn_lds, stream, ixl, d_bases,      \
                                d_offsets, n_reads, d_out, d_err, d_stats, d_order, ZSegArgs(), nullptr, nullptr); \
         else                                                                                                   \
-            hipLaunchKernelGGL((zml_kernel_flat<M, uint64_t>), grid, block, dyn_lds, stream, ix, d_bases,      \
+            hipLaunchKernelGGL((zml_kernel_flat<M, uint64_t>), grid, block, dyn_lds, stream, ixl, d_bases,      \
                                d_offsets, n_reads, d_out, d_err, d_stats, d_order, ZSegArgs(), nullptr, nullptr); \
     } while (0)
     // resident layouts: 6 = regular-thresholds rows, 3 = regular rows (threshold-less types: 12-bit lengths)
     if (mode == 6 && ahead) {
         if (ix.idx32)
-            hipLaunchKernelGGL((zml_kernel_flat<6, uint32_t, 0, 1>), grid, block, dyn_lds, stream, ix, d_bases, d_offsets, n_reads, d_out,
+            hipLaunchKernelGGL((zml_kernel_flat<6, uint32_t, 0, 1>), grid, block, dyn_lds, stream, ixl, d_bases, d_offsets, n_reads, d_out,
                                d_err, d_stats, d_order, ZSegArgs(), nullptr, nullptr);
         else
-            hipLaunchKernelGGL((zml_kernel_flat<6, uint64_t, 0, 1>), grid, block, dyn_lds, stream, ix, d_bases, d_offsets, n_reads, d_out,
+            hipLaunchKernelGGL((zml_kernel_flat<6, uint64_t, 0, 1>), grid, block, dyn_lds, stream, ixl, d_bases, d_offsets, n_reads, d_out,
                                d_err, d_stats, d_order, ZSegArgs(), nullptr, nullptr);
     } else if (mode == 6) MOVI_LAUNCH_ZML(6);
     else if (mode == 3) MOVI_LAUNCH_ZML(3);

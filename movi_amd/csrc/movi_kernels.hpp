@@ -129,6 +129,7 @@ constexpr int kCapWavesDeep = 13;    // ... on the deep rows: fewer lines per ba
 constexpr uint32_t kOutRingBytes = 4096;          // pml_kernel_flatp<..., RING = 1>: the ring in the block's dynamic LDS its PMLs leave through (32 per lane)
 constexpr uint64_t kOutRingReadLen = 1024;        // ... on by itself for batches whose mean read length is at least this (launch_pml)
 constexpr uint32_t kTallySlots = 512;             // pairs of u64 counters a builder's tally is spread over (d_tally: 2 * kTallySlots u64, zeroed)
+constexpr size_t kZmlStageBytes = 10240;          // zml_kernel_flat: dynamic LDS per one-wavefront block for its staged reads (160 bases per lane; 16 wavefronts per CU)
 constexpr uint64_t kDeepReadLen = 1024;           // launch_pml: batches whose mean read length is below this walk on the deep rows (where the handle holds them)
 constexpr uint64_t kPairLoadBytes = 2ull << 30;   // walked tables of this size and more: pair-shared gathers (launch_pml)
 

@@ -127,7 +127,7 @@ def vector_kernel(name):
     """A walk kernel's name with the reset-mask instantiation (RING = 2: the vector through masks, movi_pml_device's default on batches
     of short reads) read as the one that writes the vector itself (RING = 0): for asserts that are about the table layout the launch
     policy picked, not about how the PMLs left the kernel."""
-    return name[:-3] + "0>" if name.startswith("pml_kernel_flatp<") and name.endswith(", 2>") else name
+    return name[:-2] + "0>" if name.startswith("pml_kernel_flatp<") and name.endswith(", 2>") else name
 
 
 @pytest.fixture

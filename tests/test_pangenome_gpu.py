@@ -141,9 +141,9 @@ def test_c3_classify_at_size(pangenome):
 
 @pytest.mark.timeout(1800)
 def test_real_bwt_beyond_every_cache_vs_oracle(built_lib):
-    """A REAL BWT that fits no cache, under the driver's eye (round 6): bench.py's `c2mid` -- the c2 pangenome with 0.5 % SNPs, 37.8 M rows
-    = 302 MB, its look-ahead copy 604 MB and its deep rows 805 MB, all beyond the 256 MB Infinity Cache (built by tools/build_index in
-    2 - 5 minutes where no cache travelled with the tree).  The DEFAULT policy's launches of the whole 1 M x 150 bp batch -- device entry
+    """A REAL BWT that fits no cache, under the driver's eye (round 6): bench.py's `c2mid` -- 64 genomes of a 2.5 Mbp ancestor with 1.3 %
+    SNPs, 39.5 M rows = 316 MB, its look-ahead copy 632 MB and its deep rows 842 MB, all beyond the 256 MB Infinity Cache (built by
+    tools/build_index in a minute or two: an index of this size does not fit the 512 MB a tree may carry to the GPU box).  The DEFAULT policy's launches of the whole 1 M x 150 bp batch -- device entry
     point: deep rows, vector through fused reset masks; the same with the walk's own packer; on the look-ahead rows; the count query --
     with 20 000-read slices from the start, the middle and the end held to the oracle: PMLs, fast-forward / scan counters, matched
     lengths and counts; the kernels the policy picked asserted by name.
