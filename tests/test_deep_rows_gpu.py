@@ -41,6 +41,7 @@ def test_deep_rows_vs_oracle(built_lib, golden_image, mode):
         for hints in (1, 0):
             gpu.set_option("repo_hints", hints)
             gpu.set_option("pml_via_mask", hints - 1)              # (the vector itself / the default: masks down, expanded on the host)
+            gpu.set_option("host_masks", hints - 1)
             out, st = gpu.query_pml_packed(bases, offs)
             li = gpu.last_launch()
             # (a host call of this size brings reset masks down: RING = 2; "pml_via_mask" 0 below: the vector itself)

@@ -170,9 +170,11 @@ def test_last_launch_reports_the_policy(engine6):
     assert li["kernel"] == "pml_kernel_flatp<6, unsigned int, 0, 0, 0, 1, 2, 0, 2>" and li["variant"] == 14
     assert li["block_threads"] == 64 and li["waves_per_cu"] == 0 and li["segmented"] == 0 and li["staged"] == 336 and li["ahead"] == 2
     gpu.set_option("pml_via_mask", 0)
+    gpu.set_option("host_masks", 0)
     gpu.query_pml_packed(bases, offs)
     assert gpu.last_launch()["kernel"] == "pml_kernel_flatp<6, unsigned int, 0, 0, 0, 1, 2, 0, 0>"        # ... by the register packer
     gpu.set_option("pml_via_mask", -1)
+    gpu.set_option("host_masks", -1)
     gpu.set_option("stage_reads", 0)
     gpu.query_pml_packed(bases, offs)
     assert gpu.last_launch()["kernel"] == "pml_kernel_flatp<6, unsigned int, 0, 0, 0, 0, 0, 0, 0>" and gpu.last_launch()["staged"] == 0

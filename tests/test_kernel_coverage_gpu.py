@@ -104,6 +104,7 @@ def test_every_built_walk_kernel_is_reachable_and_equals_the_oracle(built_lib, g
         d_offs = torch.from_numpy(so.view(np.int64).copy()).to(dev)
         gpu.set_option("classify_fused", 1)
         gpu.set_option("pml_via_mask", 0)                       # (vector launches by the walk's own output paths; the mask launches are asked for by name)
+        gpu.set_option("host_masks", 0)
         def check_launches(tag, with_masks):
             """PML vector; reset masks; vector + fused bins, bins only; the segment plan's K1 / K3 -- each against the oracle."""
             nonlocal seen

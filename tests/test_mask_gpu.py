@@ -163,6 +163,7 @@ def test_u16_clamp_through_masks(built_lib):
     words, _ = gpu.query_pml_mask_packed(bases, offs)
     assert (E.expand_masks_host(words, offs, threads=2) == exp).all()
     gpu.set_option("pml_via_mask", 1)
+    gpu.set_option("host_masks", 1)
     assert (gpu.query_pml_packed(bases, offs)[0] == exp).all()                     # host path: masks down, expanded by worker threads
     gpu.close()
 
@@ -205,6 +206,7 @@ def test_overlapped_host_path_through_masks(engines, chunk_bases):
     pb = _pinned_copy(bases)
     gpu.set_option("pipe_chunk_bases", chunk_bases)
     gpu.set_option("pml_via_mask", 1)
+    gpu.set_option("host_masks", 1)
     try:
         for rep in range(2):
             out = np.full(bases.size, 0xABCD, np.uint16)                          # pageable: host threads write it
@@ -218,6 +220,7 @@ def test_overlapped_host_path_through_masks(engines, chunk_bases):
     finally:
         gpu.set_option("pipe_chunk_bases", 0)
         gpu.set_option("pml_via_mask", -1)
+        gpu.set_option("host_masks", -1)
 
 
 def test_large_batch_through_masks(built_lib):
@@ -230,8 +233,10 @@ def test_large_batch_through_masks(built_lib):
     gpu = movi_amd.MoveIndex.from_image(six.image())
     bases, offs = synth.synth_reads(six, 1_000_000, 150, seed=6, sub_rate=0.01, n_rate=0.001)
     gpu.set_option("pml_via_mask", 0)
+    gpu.set_option("host_masks", 0)
     exp, est = gpu.query_pml_packed(bases, offs)
     gpu.set_option("pml_via_mask", -1)
+    gpu.set_option("host_masks", -1)
     got, st = gpu.query_pml_packed(bases, offs)
     assert (got == exp).all() and (st.fast_forwards, st.scans, st.repositions) == (est.fast_forwards, est.scans, est.repositions)
     assert gpu.last_launch()["kernel"].endswith(", 2>")
@@ -244,6 +249,7 @@ def test_large_batch_through_masks(built_lib):
     d_offs = torch.from_numpy(offs.view(np.int64).copy()).to(dev)
     d_out = torch.zeros(bases.size, dtype=torch.int16, device=dev)
     gpu.set_option("pml_via_mask", 1)
+    gpu.set_option("host_masks", 1)
     gpu.pml_device(d_bases.data_ptr(), d_offs.data_ptr(), offs.size - 1, bases.size, d_out.data_ptr())
     torch.cuda.synchronize()
     assert (d_out.cpu().numpy().view(np.uint16) == exp).all()

@@ -3,7 +3,7 @@ PSH, CNT> (the lane state machine: ZML parses, the count query, the segment plan
 inputs, A/B, K1 on tables beyond 3 GB, K3) -- is reachable through the options of the C-ABI, and each one is held to the oracle once
 (query_zml: /root/reference/src/move_structure_query.cpp:690-785; query_backward_search: src/move_structure_search.cpp:340-352).
 The library reports every such launch by name (movi_launch_log); the set seen must EQUAL the set of symbols in the shipped code object
-(tests/test_kernel_coverage_gpu.py does the same for the PML walk's 218)."""
+(tests/test_kernel_coverage_gpu.py does the same for the PML walk's 218).  30 kernels: 24 zml_kernel_flat + 6 zml_kernel."""
 import os
 import struct
 import subprocess
@@ -55,7 +55,7 @@ def test_every_built_zml_and_count_kernel_is_reachable_and_equals_the_oracle(bui
     from oracle import build_index as B
     from oracle.oracle import Oracle
     built = built_zml_kernels()
-    assert len(built) == 28, sorted(built)                      # 22 zml_kernel_flat + 6 zml_kernel
+    assert len(built) == 30, sorted(built)                      # 24 zml_kernel_flat + 6 zml_kernel
     ref = B.read_fasta(os.path.join(GOLDEN, "ref.fasta"))[0][1]
     rng = np.random.default_rng(4242)
     short = mutated_reads(rng, ref, 900, 1, 400) + [b"", b"A", b"N" * 17, ref[:16], ref[100:117], b"ACGT" * 40, ref[2000:2300]]
@@ -103,6 +103,14 @@ def test_every_built_zml_and_count_kernel_is_reachable_and_equals_the_oracle(bui
                 m, c, st = gpu.query_count_packed(sb, so)
                 assert gpu.last_launch()["kernel"] == "zml_kernel_flat<%d, %s, 0, 0, %d, 1>" % (kmode, T, pair)
                 assert (m == em).all() and (c == ec).all() and st.errors == 0, (kmode, idx64, pair)
+            if kmode == 6:                                      # ... and on the look-ahead rows ("zml_ahead" 1; round 6)
+                gpu.set_option("pair_loads", 0)
+                gpu.set_option("ahead_rows", 1)
+                gpu.set_option("zml_ahead", 1)
+                m, c, st = gpu.query_count_packed(sb, so)
+                assert gpu.last_launch()["kernel"] == "zml_kernel_flat<6, %s, 0, 1, 0, 1>" % T and gpu.last_launch()["ahead"] == 1
+                assert (m == em).all() and (c == ec).all() and st.errors == 0, (kmode, idx64, "ahead")
+                gpu.set_option("zml_ahead", 0)
             gpu.set_option("count_variant", -1)
             gpu.set_option("pair_loads", -1)
             seen |= read_log()
