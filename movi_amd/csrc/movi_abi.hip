@@ -12,6 +12,7 @@
 #include <chrono>
 #include <cstring>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include <dlfcn.h>
@@ -151,6 +152,7 @@ struct movi_index {
     uint32_t seg_cache_key = 0;
     uint64_t reserved_result_bases = 0, reserved_reads = 0;   // "reserve_host_results" / "reserve_host_reads": what the mask words' scratch is reserved for
     int pml_via_mask = -1;           // "pml_via_mask": the walk's u16 vector through reset masks that its wavefronts expand themselves (-1: batches of short reads)
+    int host_mask_share = 40;        // "host_mask_share": percent of a mixed call's bases that come down as masks (the rest as the vector itself)
     int host_masks = -1;             // "host_masks": movi_pml_host brings reset masks down and expands them on host worker threads (-1: calls of >= 2^22 bases into a pageable vector)
     int host_threads = 0;            // "host_threads": workers of the host-side expansion (0 = host_threads_default())
 };
@@ -1072,8 +1074,13 @@ int movi_set_option(movi_index_t *ix, const char *key, int64_t value) {
         return MOVI_OK;
     }
     if (!strcmp(key, "host_masks")) {                        // movi_pml_host: masks down + expansion on host worker threads (-1: the policy)
-        if (value < -1 || value > 1) return fail(MOVI_ERR_ARG, "host_masks must be -1, 0 or 1");
+        if (value < -1 || value > 2) return fail(MOVI_ERR_ARG, "host_masks must be -1, 0, 1 or 2");
         ix->host_masks = (int)value;
+        return MOVI_OK;
+    }
+    if (!strcmp(key, "host_mask_share")) {                   // mixed calls of movi_pml_host: percent of the bases that take the mask route
+        if (value < 0 || value > 100) return fail(MOVI_ERR_ARG, "host_mask_share must be 0 .. 100");
+        ix->host_mask_share = (int)value;
         return MOVI_OK;
     }
     if (!strcmp(key, "fused_expand")) {                      // A/B: 0 = a mask walk whose caller wants the vector leaves the expansion to the pml_expand_* kernels
@@ -1867,7 +1874,7 @@ static bool autopin_worthwhile(const movi_index *ix, const uint64_t *h_offsets, 
     return ix->host_autopin && ix->host_overlap && h_offsets[n_reads] - h_offsets[0] >= (1ull << 27) && n_reads >= 3 * kPipeMinReads;
 }
 
-// h_mask_words != NULL: the reset masks themselves are the result (movi_pml_mask_host).  Otherwise, PML with "pml_via_mask": the
+// h_mask_words != NULL: the reset masks themselves are the result (movi_pml_mask_host).  Otherwise, PML with "host_masks": the
 // walk writes masks, only they cross PCIe (1/8 byte per base instead of 2) and the u16 vector is expanded into the caller's buffer
 // by the host's worker threads (movi_expand_host.cpp) -- in the overlapped path beside the walks of the chunks that follow.
 static int ml_host(bool zml, movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_offsets, uint64_t n_reads,
@@ -1880,17 +1887,42 @@ static int ml_host(bool zml, movi_index_t *ix, const uint8_t *h_bases, const uin
     if (int rc0 = check_offsets(h_offsets, n_reads)) return rc0;
     HIP_TRY(hipSetDevice(ix->device));
     const uint64_t o0 = h_offsets[0], span = h_offsets[n_reads] - o0;
-    // ("host_masks" -1: masks down + host expansion for big calls whose result vector is PAGEABLE -- no page-locking of 2 bytes per base,
-    // 1/16 of the bytes over PCIe: 23.4 -> 25.4 Gbases/s on 1 M x 150 bp; a page-locked vector comes down as it is, at the same rate)
-    const bool via_mask = !zml && (h_mask_words != nullptr ||
-                                   (h_out_pml != nullptr && (ix->host_masks > 0 || (ix->host_masks < 0 && span >= (1ull << 22) && !is_pinned(h_out_pml)))));
+    // The way down of the u16 vector, chunk by chunk: as it is (2 bytes per base over PCIe, no host work where the caller's vector is
+    // page-locked) or as reset masks (1/8 byte per base) that the host's worker threads expand into the caller's vector.  The DMA engine
+    // and the host's cores are two resources: a call whose vector is page-locked uses BOTH ("mixed": `host_mask_share` percent of the
+    // bases take the mask route, the rest come down as they are, side by side); a pageable vector takes masks only (no page-locking
+    // of 2 bytes per base).  "host_masks": -1 this policy for calls of >= 2^22 bases, 0 never masks, 1 masks only, 2 mixed.
+    enum { kVector = 0, kMasks = 1, kMixed = 2 };
+    int route = kVector;
+    if (h_mask_words) route = kMasks;
+    else if (!zml && h_out_pml) {
+        if (ix->host_masks > 0) route = ix->host_masks >= 2 ? kMixed : kMasks;
+        else if (ix->host_masks < 0 && span >= (1ull << 22))     // (a pageable vector of a call big enough to page-lock its buffers for: both ways too)
+            route = (is_pinned(h_out_pml) || autopin_worthwhile(ix, h_offsets, n_reads)) ? kMixed : kMasks;
+    }
+    // A chunk's way down: `masks` = reset masks + host expansion, else the vector by DMA; a mixed call deals its chunks by `host_mask_share`.
+    // (Tried: walks that leave both on the device and a choice at download time by the pool's backlog -- 28.1 against 29.9 Gbases/s for
+    // the plain deal; a call's tail cut into halving chunks -- 27.3 against 28.1: profiles/r06_host_path.txt.)
+    struct Way { bool masks = false; uint32_t phase = 0; };
+    uint64_t acc_all = 0, acc_mask = 0;                       // bases launched so far / of them by the mask route
+    std::unordered_map<uint64_t, Way> way_of;                 // first read of a chunk -> its way (launch, fetch and harvest run on the calling thread)
     const int threads = ix->host_threads > 0 ? ix->host_threads : host_threads_default();
     struct { void *p; } d_out{};
     auto phase_of = [&](uint64_t b0) { return (uint32_t)((b0 - o0) & 31u); };
     auto launch = [&](ChunkCtx &c, const uint8_t *db, const uint64_t *dof, uint64_t nr, uint64_t nb, uint8_t *derr) -> int {
-        if (via_mask) {
+        Way w;
+        w.phase = phase_of(c.b0);
+        const bool through_masks = !zml && ix->pml_via_mask != 0 && pml_vector_via_masks(ix->dev, ix->cfg, nr, nb, true, false);
+        if (route == kMasks) w.masks = true;
+        else if (route == kMixed) {                           // (the first chunk comes down as it is: its DMA starts when its walk ends)
+            w.masks = (acc_mask + nb) * 100 <= (uint64_t)ix->host_mask_share * (acc_all + nb);
+            acc_all += nb;
+            if (w.masks) acc_mask += nb;
+        }
+        way_of[c.first] = w;
+        if (w.masks) {
             MaskArgs m;
-            m.phase = phase_of(c.b0);
+            m.phase = w.phase;
             HIP_TRY(c.alloc(movi_index::kMask, (size_t)pml_mask_words(nr, nb, m.phase) * 4, &d_out.p));
             m.words = static_cast<uint32_t *>(d_out.p);
             return ml_device(false, ix, db, dof, nr, nb, nullptr, derr, nullptr, c.s, ClsArgs(), c.d_stats, c.seg_ws, c.ragged_hint,
@@ -1898,7 +1930,7 @@ static int ml_host(bool zml, movi_index_t *ix, const uint8_t *h_bases, const uin
         }
         HIP_TRY(c.alloc(movi_index::kOut, nb * 2, &d_out.p));
         // (the vector itself comes down: on the device it is written through reset masks where movi_pml_device's policy says so)
-        if (!zml && ix->pml_via_mask != 0 && (ix->pml_via_mask > 0 || pml_vector_via_masks(ix->dev, ix->cfg, nr, nb, true, false))) {
+        if (through_masks || (!zml && ix->pml_via_mask > 0)) {
             void *mw = nullptr;
             HIP_TRY(c.alloc(movi_index::kMask, (size_t)pml_mask_words(nr, nb, 0) * 4, &mw));
             MaskArgs m;
@@ -1911,9 +1943,8 @@ static int ml_host(bool zml, movi_index_t *ix, const uint8_t *h_bases, const uin
                          c.seg_ws, c.ragged_hint, c.seg_verdict);
     };
     // what a chunk's masks are to the host: the words land in `words`; they are the result, or the vector is expanded from them
-    auto deliver = [&](const uint32_t *words, uint64_t first, uint64_t nr, HostPool::Group *g) {
+    auto deliver = [&](const uint32_t *words, uint64_t first, uint64_t nr, uint32_t ph, HostPool::Group *g) {
         const uint64_t b0 = h_offsets[first], nb = h_offsets[first + nr] - b0;
-        const uint32_t ph = phase_of(b0);
         if (h_mask_words) memcpy(h_mask_words + ((b0 - o0) >> 5) + first, words, (size_t)(((nb + ph) >> 5) + nr) * 4);
         if (h_out_pml) {
             ExpandJob j;
@@ -1926,8 +1957,9 @@ static int ml_host(bool zml, movi_index_t *ix, const uint8_t *h_bases, const uin
     // run before fetch() of this one)
     std::vector<uint32_t> sync_words;                        // synchronous path: a chunk's words on their way through the host
     auto fetch = [&](ChunkCtx &c, uint64_t first, uint64_t nr, uint64_t b0, uint64_t nb) -> int {
-        if (via_mask) {
-            const size_t nw = (size_t)(((nb + phase_of(b0)) >> 5) + nr);
+        const Way w = way_of[first];
+        if (w.masks) {
+            const size_t nw = (size_t)(((nb + w.phase) >> 5) + nr);
             if (c.async) {                                    // into the slot's page-locked block; harvest() takes it from there
                 HIP_TRY(c.down_small(nullptr, 0, c.d[movi_index::kMask], nw * 4));
                 return MOVI_OK;
@@ -1938,17 +1970,19 @@ static int ml_host(bool zml, movi_index_t *ix, const uint8_t *h_bases, const uin
             }
             sync_words.resize(nw);
             HIP_TRY(hipMemcpy(sync_words.data(), c.d[movi_index::kMask], nw * 4, hipMemcpyDeviceToHost));
-            deliver(sync_words.data(), first, nr, nullptr);
+            deliver(sync_words.data(), first, nr, w.phase, nullptr);
             return MOVI_OK;
         }
         if (h_out_pml) HIP_TRY(c.down(h_out_pml + b0, c.d[movi_index::kOut], nb * 2));
         return MOVI_OK;
     };
     auto harvest = [&](const uint8_t *h_small, uint64_t first, uint64_t nr, HostPool::Group *g) {
-        if (via_mask) deliver(reinterpret_cast<const uint32_t *>(h_small), first, nr, g);
+        const Way w = way_of[first];
+        if (!w.masks) return;
+        deliver(reinterpret_cast<const uint32_t *>(h_small), first, nr, w.phase, g);
     };
     // masks: only the reads have to be page-locked for the overlapped path (the vector is written by host threads)
-    bool overlapped = span != 0 && is_pinned(h_bases) && (via_mask || !h_out_pml || is_pinned(h_out_pml));
+    bool overlapped = span != 0 && is_pinned(h_bases) && (route == kMasks || !h_out_pml || is_pinned(h_out_pml));
     // A big call on PAGEABLE buffers (what a std::vector-holding caller passes: INTEGRATION.md's stub): page-lock them for the
     // duration of the call and take the overlapped path.  Registering touched memory runs at hundreds of GB/s (DESIGN.md section
     // 5), so on >= 2^27 bases it is paid back several times over (the synchronous path: 12.4 Gbases/s PCIe-inclusive).
@@ -1956,8 +1990,9 @@ static int ml_host(bool zml, movi_index_t *ix, const uint8_t *h_bases, const uin
     AutoPin pin_bases, pin_out;
     if (!overlapped && autopin_worthwhile(ix, h_offsets, n_reads))
         overlapped = pin_bases.pin(const_cast<uint8_t *>(h_bases) + h_offsets[0], span) &&
-                     (via_mask || !h_out_pml || pin_out.pin(h_out_pml + h_offsets[0], span * 2));
-    return run_host(overlapped, ix, h_bases, h_offsets, n_reads, h_read_err, stats, launch, fetch, harvest, 0, via_mask ? 4 : 0);
+                     (route == kMasks || !h_out_pml || pin_out.pin(h_out_pml + h_offsets[0], span * 2));
+    if (route == kMixed && !overlapped) route = kMasks;       // (the synchronous path: one way down for the whole call)
+    return run_host(overlapped, ix, h_bases, h_offsets, n_reads, h_read_err, stats, launch, fetch, harvest, 0, route != kVector ? 4 : 0);
 }
 
 int movi_pml_mask_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_offsets, uint64_t n_reads,

@@ -575,6 +575,7 @@ struct SegJoin {
 // -- a lane whose start state turns out not to be real would write rubbish over a stretch that belongs to another --;
 // once K3 has followed the chains, PASS 1 walks the stretches of the lanes that count again (a few dozen bases each, as
 // a rule) and writes their PMLs: those stretches are disjoint.
+constexpr uint32_t kStitchLanes = 16;
 template <int MODE, int PASS>
 __global__ __launch_bounds__(256) void seg_stitch_kernel(DevIndex ix, const uint8_t *__restrict__ bases, SegArgs seg,
                                                         const uint32_t *__restrict__ seg_j, const uint32_t *__restrict__ seg_rem,
@@ -583,8 +584,11 @@ __global__ __launch_bounds__(256) void seg_stitch_kernel(DevIndex ix, const uint
     __shared__ uint8_t s_code[256];
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = ix.code_of[i];
     __syncthreads();
-    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool mine = *seg.go != 0u && s < *seg.n_seg && seg_j[s] != 0 && (PASS == 0 || on_chain[s] == 2);
+    // kStitchLanes boundaries per wavefront (the other lanes idle): a wavefront walks until the LAST of its lanes has met its
+    // checkpoint, and the meeting points are spread like lock-on + the wait for the next substitution -- the maximum over 16 lanes lies
+    // a checkpoint or two nearer than the maximum over 64, and the launch has wavefront slots to spare (profiles/r06_few_long_reads.txt)
+    const uint64_t s = (uint64_t)blockIdx.x * kStitchLanes + threadIdx.x;
+    const bool mine = threadIdx.x < kStitchLanes && *seg.go != 0u && s < *seg.n_seg && seg_j[s] != 0 && (PASS == 0 || on_chain[s] == 2);
     const EndThr ethr = end_thresholds(ix);
     uint32_t ff_total = 0, scan_total = 0, repo_total = 0, failed = 0, how = 0;
     bool live0 = mine;
@@ -596,7 +600,7 @@ __global__ __launch_bounds__(256) void seg_stitch_kernel(DevIndex ix, const uint
     const uint8_t *R = bases + (live0 ? seg.seg_in[s] + T : 0);          // one past this segment's first base
     const uint64_t obeg = live0 ? seg.seg_out[s] : 0;
     uint16_t *O = out + obeg;
-    uint64_t idx = 0;
+    uint64_t idx = 0, rb8 = 0;
     uint32_t off = 0, ml = 0, kend = 0;
     SegJoin res{};
     if (live0) {
@@ -607,7 +611,14 @@ __global__ __launch_bounds__(256) void seg_stitch_kernel(DevIndex ix, const uint
     for (uint64_t k = 0; wave_any(k < len && failed == 0u && how == 0u); ++k) {
         bool live = k < len && failed == 0u && how == 0u;
         uint32_t a = 0xFFu;
-        if (live) a = s_code[*(R - 1 - (int64_t)k)];
+        if (live && (k & 7ull) == 0ull) {                                // the next eight bases by one load (off the walk's dependent chain)
+            if (k + 8 <= len) __builtin_memcpy(&rb8, R - 8 - (int64_t)k, 8);
+            else {
+                rb8 = 0;
+                for (uint64_t i = 0; k + i < len; ++i) rb8 |= (uint64_t)*(R - 1 - (int64_t)(k + i)) << (8u * (7u - (uint32_t)i));
+            }
+        }
+        if (live) a = s_code[(uint32_t)(rb8 >> (8u * (7u - (uint32_t)(k & 7ull)))) & 0xFFu];
         const uint32_t e = walk_base<MODE>(ix, ethr, live, true, a, idx, off, row, ml, ff_total, scan_total, repo_total);
         if (e) { failed = e; live = false; }
         if (PASS == 1) {
@@ -890,11 +901,11 @@ static hipError_t launch_pml_segmented(const DevIndex &ix, const uint8_t *d_base
     }
     // (blocks of one wavefront: a boundary lane that has to walk far holds up only the 63 beside it)
     const uint32_t max_over = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, (uint64_t)cfg.seg_len * (uint64_t)kSegOverrun);
-    hipLaunchKernelGGL((seg_stitch_kernel<6, 0>), dim3((unsigned)((max_seg + 63) / 64)), dim3(64), 0, stream, ix, d_bases, seg,
+    hipLaunchKernelGGL((seg_stitch_kernel<6, 0>), dim3((unsigned)((max_seg + kStitchLanes - 1) / kStitchLanes)), dim3(64), 0, stream, ix, d_bases, seg,
                        seg_j, seg_rem, max_over, on_chain, d_out, join);
     hipLaunchKernelGGL(seg_finalize_kernel, dim3((unsigned)((n_reads + bt256 - 1) / bt256)), dim3(bt256), 0, stream, go, first, n_reads,
                        seg.tot, join, seg_l, seg_rem, on_chain, read_fail, d_err, d_stats);
-    hipLaunchKernelGGL((seg_stitch_kernel<6, 1>), dim3((unsigned)((max_seg + 63) / 64)), dim3(64), 0, stream, ix, d_bases, seg,
+    hipLaunchKernelGGL((seg_stitch_kernel<6, 1>), dim3((unsigned)((max_seg + kStitchLanes - 1) / kStitchLanes)), dim3(64), 0, stream, ix, d_bases, seg,
                        seg_j, seg_rem, max_over, on_chain, d_out, join);
     e = launch_seg(2, n_reads, nullptr);
     if (e == hipSuccess) e = hipGetLastError();

@@ -223,6 +223,36 @@ def test_overlapped_host_path_through_masks(engines, chunk_bases):
         gpu.set_option("host_masks", -1)
 
 
+@pytest.mark.parametrize("share", [0, 40, 100])
+def test_overlapped_host_path_both_ways_down(engines, share):
+    """movi_pml_host, reads AND vector page-locked ("host_masks" 2 = what -1 picks for big calls on such buffers): some chunks come down as
+    the vector itself by DMA, the others as reset masks that the worker pool expands -- into the same caller vector, side by side."""
+    import movi_amd
+    gpu, cpu = engines[6]
+    rng = np.random.default_rng(7600 + share)
+    reads = mutated_reads(rng, ref_text(), 400, 1, 900) + [b"", b"N", b""] + mutated_reads(rng, ref_text(), 300, 100, 200)
+    bases, offs = pack(reads)
+    exp, ff, sc = cpu.pml_batch(bases, offs, threads=4)
+    pb = _pinned_copy(bases)
+    gpu.set_option("pipe_chunk_bases", 5000)
+    gpu.set_option("host_masks", 2)
+    gpu.set_option("host_mask_share", share)
+    try:
+        for rep in range(2):
+            out = movi_amd.pinned_empty(bases.size, np.uint16)
+            out[:] = 0xABCD
+            got, st, err, rc = gpu.query_pml_packed(pb, offs, want_err=True, out=out)
+            assert rc == 0 and (out == exp).all() and not err.any()
+            assert (st.bases, st.fast_forwards, st.scans, st.errors) == (bases.size, ff, sc, 0)
+        out2 = np.full(bases.size, 0xABCD, np.uint16)                             # pageable vector, pageable reads: one way down (masks), synchronous
+        gpu.query_pml_packed(bases, offs, out=out2)
+        assert (out2 == exp).all()
+    finally:
+        gpu.set_option("pipe_chunk_bases", 0)
+        gpu.set_option("host_masks", -1)
+        gpu.set_option("host_mask_share", 40)
+
+
 def test_large_batch_through_masks(built_lib):
     """1 M x 150 bp: the default policy of movi_pml_host brings masks down (>= 2^22 bases); equal to the vector path, and the device
     entry point with "pml_via_mask" 1 (mask walk + pml_expand_kernel) equal to the walk that writes the vector itself."""
