@@ -26,7 +26,7 @@ struct ExpandJob {
 void expand_reads(const ExpandJob &job);          // on the calling thread (AVX2 where the CPU has it)
 void expand_reads_scalar(const ExpandJob &job);   // the plain loop (what the tests hold the vector code to)
 
-int host_threads_default();                       // CPUs the process may run on, at most 32
+int host_threads_default();                       // three quarters of the CPUs the process may use (affinity, cgroup quota), at most 24
 
 // A small persistent pool: tasks are submitted in groups, a group can be waited for.  One pool per process, grown on demand.
 class HostPool {
