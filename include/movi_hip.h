@@ -437,7 +437,7 @@ int movi_host_unregister(void *p);
  * LDS ring), "host_masks" (movi_pml_host: -1, the default: a call of >= 2^22 bases whose result vector is PAGEABLE brings only the
  * masks down and expands them into the caller's vector on host worker threads beside the walks of the later chunks -- 1/16 of the
  * bytes over PCIe, no page-locking of the vector --, and such a call whose vector is PAGE-LOCKED takes both ways down side by side:
- * "host_mask_share" percent (default 40) of its bases as masks for the host's cores, the rest as the vector itself by DMA; 1 = masks for
+ * "host_mask_share" percent (default 60) of its bases as masks for the host's cores, the rest as the vector itself by DMA; 1 = masks for
  * every call, 2 = both ways for every call the overlapped path takes, 0 = never masks: a caller whose own threads are busy, like `movi query`),
  * "fused_expand" (1, the default; 0 = the expansion by kernels of their own behind the walk: A/B), "reserve_device_masks" (device scratch
  * for the mask words of movi_pml_device calls of up to this many bases, reserved now instead of inside the first such call),

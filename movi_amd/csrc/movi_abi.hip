@@ -152,7 +152,7 @@ struct movi_index {
     uint32_t seg_cache_key = 0;
     uint64_t reserved_result_bases = 0, reserved_reads = 0;   // "reserve_host_results" / "reserve_host_reads": what the mask words' scratch is reserved for
     int pml_via_mask = -1;           // "pml_via_mask": the walk's u16 vector through reset masks that its wavefronts expand themselves (-1: batches of short reads)
-    int host_mask_share = 40;        // "host_mask_share": percent of a mixed call's bases that come down as masks (the rest as the vector itself)
+    int host_mask_share = 60;        // "host_mask_share": percent of a mixed call's bases that come down as masks (the rest as the vector itself)
     int host_masks = -1;             // "host_masks": movi_pml_host brings reset masks down and expands them on host worker threads (-1: calls of >= 2^22 bases into a pageable vector)
     int host_threads = 0;            // "host_threads": workers of the host-side expansion (0 = host_threads_default())
 };
@@ -1391,6 +1391,7 @@ constexpr uint64_t kMaxChunkBases = 1ull << 31;
 constexpr uint64_t kPipeMinBases = 1ull << 22;
 constexpr uint64_t kPipeMinReads = 1ull << 15;
 constexpr uint64_t kPipeTargetChunks = 8;
+constexpr uint64_t kPipeMaskChunks = 16;
 
 hipError_t grow(void **p, size_t *cap, size_t bytes) {
     if (bytes < 8) bytes = 8;
@@ -1628,7 +1629,10 @@ int run_pipelined(movi_index *ix, const uint8_t *h_bases, const uint64_t *h_offs
     if (stats) memset(stats, 0, sizeof(*stats));
     movi_query_stats_t acc{};
     const uint64_t total = h_offsets[n_reads] - h_offsets[0];
-    uint64_t target = total / kPipeTargetChunks;
+    // (calls whose results -- all or part of them -- come down as reset masks for the host's worker pool are cut twice as fine: the pool's
+    // work arrives earlier and more evenly; 1 M x 150 bp: masks alone 22.9 -> 32.4 Gbases/s, both ways down 30 -> 33.9; finer still and
+    // the walks no longer fill the GPU: profiles/r06_host_path.txt)
+    uint64_t target = total / (mask_word_bytes ? kPipeMaskChunks : kPipeTargetChunks);
     target = target < kPipeMinBases ? kPipeMinBases : (target > kChunkBases ? kChunkBases : target);
     uint64_t min_reads = kPipeMinReads;
     // Long reads are cut into few, big chunks because a read takes its time however few lanes walk beside it -- unless the
