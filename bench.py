@@ -1290,9 +1290,10 @@ def main():
             from movi_amd._lib import QueryStatsC, check, lib
             hp = {"unit": "Gbases/s", "note": "movi_pml_host, host buffers in and out, best of 3 calls after a warm-up call.  Round 6: by default only "
                                               "RESET MASKS cross PCIe on the way back (1 B up + 1/8 B down per base) and the u16 vector is expanded into the caller's "
-                                              "buffer by host worker threads beside the walks (`host_masks`): a pageable vector takes that route alone, a PAGE-LOCKED vector takes both ways down side by side "
-                                              "(mixed: `host_mask_share` percent of the bases as masks for the host's cores, the rest as the vector itself by DMA); "
-                                              "*_vector = `host_masks` 0, the vector itself comes down (1 B up + 2 B down: rounds 1-5), *_masks = 1 (masks alone), *_mixed = 2; masks_only = movi_pml_mask_host (the masks are the result).  pageable_synchronous = "
+                                              "buffer by host worker threads beside the walks (`host_masks` -1 = 1 for calls of >= 2^22 bases): a chunk's words go to the "
+                                              "pool by a host function on its stream, sixteen chunks per call.  *_vector = `host_masks` 0, the vector itself comes "
+                                              "down (1 B up + 2 B down: rounds 1-5), *_mixed = 2 (both ways side by side, `host_mask_share` 70 % as masks); masks_only = "
+                                              "movi_pml_mask_host (the masks are the result).  pageable_synchronous = "
                                               "host_autopin off (upload, walk, download one after the other), pageable = the default (a big call page-locks the caller's "
                                               "reads for its duration and overlaps), page_locked = caller-allocated page-locked buffers; all checked against each other "
                                               "and the cpu_baseline's oracle sample",
@@ -1303,8 +1304,7 @@ def main():
             ref_out = None
             for name, mk, via in (("pageable_synchronous", lambda n, dt: np.empty(n, dt), -1), ("pageable", lambda n, dt: np.empty(n, dt), -1),
                                   ("page_locked", movi_amd.pinned_empty, -1), ("page_locked_vector", movi_amd.pinned_empty, 0),
-                                  ("page_locked_masks", movi_amd.pinned_empty, 1), ("pageable_vector", lambda n, dt: np.empty(n, dt), 0),
-                                  ("pageable_mixed", lambda n, dt: np.empty(n, dt), 2), ("masks_only", movi_amd.pinned_empty, -1)):
+                                  ("page_locked_mixed", movi_amd.pinned_empty, 2), ("pageable_vector", lambda n, dt: np.empty(n, dt), 0), ("masks_only", movi_amd.pinned_empty, -1)):
                 # pageable_synchronous: "host_autopin" 0 = upload, walk, download one after the other; pageable: the default --
                 # a big call page-locks the caller's buffers for its duration and overlaps the three
                 index.set_option("host_autopin", 0 if name == "pageable_synchronous" else 1)

@@ -434,11 +434,11 @@ int movi_host_unregister(void *p);
  * "pml_via_mask" (round 6; PML as reset masks.  movi_pml_device: the walk writes one bit per base and every wavefront expands its reads'
  * words into the u16 vector itself when its walks are over -- -1, the default: batches of short reads (mean length < 1024: c2 78.4 ->
  * 86.7 Gbases/s, 1 B rows 42.3 -> 46.0); 1 = wherever the walk can write masks; 0 = the walk writes the vector itself (register packer /
- * LDS ring), "host_masks" (movi_pml_host: -1, the default: a call of >= 2^22 bases whose result vector is PAGEABLE brings only the
- * masks down and expands them into the caller's vector on host worker threads beside the walks of the later chunks -- 1/16 of the
- * bytes over PCIe, no page-locking of the vector --, and such a call whose vector is PAGE-LOCKED takes both ways down side by side:
- * "host_mask_share" percent (default 60) of its bases as masks for the host's cores, the rest as the vector itself by DMA; 1 = masks for
- * every call, 2 = both ways for every call the overlapped path takes, 0 = never masks: a caller whose own threads are busy, like `movi query`),
+ * LDS ring), "host_masks" (movi_pml_host: -1, the default: a call of >= 2^22 bases brings only the masks down and expands them into the
+ * caller's vector on host worker threads beside the walks of the later chunks -- 1/16 of the bytes over PCIe, no page-locking of the
+ * vector: 22.7 -> 33 - 34 Gbases/s on 1 M x 150 bp; 1 = every call; 2 = both ways down side by side, "host_mask_share" percent
+ * (default 70) of the bases as masks, the rest as the vector itself by DMA into a page-locked vector; 0 = never masks: a caller whose
+ * own threads are busy, like `movi query`),
  * "fused_expand" (1, the default; 0 = the expansion by kernels of their own behind the walk: A/B), "reserve_device_masks" (device scratch
  * for the mask words of movi_pml_device calls of up to this many bases, reserved now instead of inside the first such call),
  * "host_threads" (worker threads of the host-side expansion, 0 = three quarters of the CPUs the process may use -- affinity mask capped by the cgroup's quota --, at most 24),

@@ -152,7 +152,7 @@ struct movi_index {
     uint32_t seg_cache_key = 0;
     uint64_t reserved_result_bases = 0, reserved_reads = 0;   // "reserve_host_results" / "reserve_host_reads": what the mask words' scratch is reserved for
     int pml_via_mask = -1;           // "pml_via_mask": the walk's u16 vector through reset masks that its wavefronts expand themselves (-1: batches of short reads)
-    int host_mask_share = 60;        // "host_mask_share": percent of a mixed call's bases that come down as masks (the rest as the vector itself)
+    int host_mask_share = 70;        // "host_mask_share": percent of a mixed call's bases that come down as masks (the rest as the vector itself)
     int host_masks = -1;             // "host_masks": movi_pml_host brings reset masks down and expands them on host worker threads (-1: calls of >= 2^22 bases into a pageable vector)
     int host_threads = 0;            // "host_threads": workers of the host-side expansion (0 = host_threads_default())
 };
@@ -1420,6 +1420,7 @@ struct ChunkCtx {
     int ragged_hint = -1;            // the chunk's longest read is (1) / is not (0) more than 1.5 x its mean: launch_pml's segment policy
     int *seg_verdict = nullptr;      // one probe per call: the first chunk's verdict serves the others (launch_pml_segmented)
     uint64_t first = 0, b0 = 0;      // the chunk: its first read and the position of its first base in the caller's arrays
+    HostPool::Group *grp = nullptr;  // overlapped path: the slot's group of worker-pool tasks (what reads the slot's page-locked block)
     bool async = false;
     hipError_t alloc(int slot, size_t bytes, void **out) {
         hipError_t e = grow(&d[slot], &cap[slot], bytes);
@@ -1649,7 +1650,10 @@ int run_pipelined(movi_index *ix, const uint8_t *h_bases, const uint64_t *h_offs
         // (the first download can only start when the first walk is over: the first two chunks are a quarter and
         // half the size)
         uint64_t tgt = target;
-        if (!ix->pipe_chunk_bases && chunks.size() < 2 && (target >> (2 - chunks.size())) >= kPipeMinBases) tgt = target >> (2 - chunks.size());
+        // (not where masks come down: a chunk's masks are 1/16 of its vector, and sixteen equal chunks ran 8 % faster than the same with a
+        // half-size second one)
+        if (!ix->pipe_chunk_bases && !mask_word_bytes && chunks.size() < 2 && (target >> (2 - chunks.size())) >= kPipeMinBases)
+            tgt = target >> (2 - chunks.size());
         uint64_t last = (uint64_t)(std::upper_bound(lo, end, h_offsets[first] + tgt) - h_offsets) - 1;
         if (last - first < min_reads) {
             const uint64_t cap = (uint64_t)(std::upper_bound(lo, end, h_offsets[first] + kMaxChunkBases) - h_offsets) - 1;
@@ -1685,6 +1689,7 @@ int run_pipelined(movi_index *ix, const uint8_t *h_bases, const uint64_t *h_offs
         ctx.async = true;
         ctx.first = fl[k].c.first;
         ctx.b0 = fl[k].c.b0;
+        ctx.grp = &grp[k];
         return ctx;
     };
     // a chunk's stream has drained: counters, error bytes, per-read results
@@ -1781,7 +1786,6 @@ int run_pipelined(movi_index *ix, const uint8_t *h_bases, const uint64_t *h_offs
         if (rc == MOVI_OK) rc = finish_arrived();
     }
     for (size_t j = 0; j < (size_t)S && rc == MOVI_OK; j++) rc = finish((int)((n + j) % S));   // oldest first
-    for (int k = 0; k < S; k++) HostPool::get().wait(&grp[k]);                                 // (also on errors: the workers write caller memory)
     if (rc != MOVI_OK) {
         // whatever happened, nothing may still be reading or writing the caller's buffers when the call returns
         const std::string keep = g_err;
@@ -1790,6 +1794,8 @@ int run_pipelined(movi_index *ix, const uint8_t *h_bases, const uint64_t *h_offs
             if (ix->pipe[k].s) (void)hipStreamSynchronize(ix->pipe[k].s);
         g_err = keep;
     }
+    // (after the streams have drained: a stream's host function may hand work to the pool; also on errors: the workers write caller memory)
+    for (int k = 0; k < S; k++) HostPool::get().wait(&grp[k]);
     if (stats) *stats = acc;
     if (rc == MOVI_OK && total / n_reads >= 2ull * (uint64_t)(ix->cfg.seg_len > 0 ? ix->cfg.seg_len : 1)) ix->seg_seen = acc.segments != 0;
     return rc;
@@ -1881,6 +1887,23 @@ static bool autopin_worthwhile(const movi_index *ix, const uint64_t *h_offsets, 
 // h_mask_words != NULL: the reset masks themselves are the result (movi_pml_mask_host).  Otherwise, PML with "host_masks": the
 // walk writes masks, only they cross PCIe (1/8 byte per base instead of 2) and the u16 vector is expanded into the caller's buffer
 // by the host's worker threads (movi_expand_host.cpp) -- in the overlapped path beside the walks of the chunks that follow.
+// A chunk's reset-mask words have arrived in its slot's page-locked block (host function on the chunk's stream: no HIP call in here).
+struct DeliverArg {
+    const uint32_t *words = nullptr;
+    uint32_t *mask_dst = nullptr;     // movi_pml_mask_host: where the words belong in the caller's array
+    size_t mask_bytes = 0;
+    bool expand = false;              // movi_pml_host: the worker pool expands them into the caller's vector
+    ExpandJob job;
+    int threads = 0;
+    HostPool::Group *group = nullptr;
+};
+static void deliver_on_stream(void *p) {
+    DeliverArg *a = static_cast<DeliverArg *>(p);
+    if (a->mask_dst) memcpy(a->mask_dst, a->words, a->mask_bytes);
+    if (a->expand) expand_parallel(a->job, a->threads, a->group);
+    delete a;
+}
+
 static int ml_host(bool zml, movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_offsets, uint64_t n_reads,
                   uint16_t *h_out_pml, uint8_t *h_read_err, movi_query_stats_t *stats, uint32_t *h_mask_words = nullptr) {
     if (!ix) return fail(MOVI_ERR_ARG, "index handle is NULL");
@@ -1892,22 +1915,23 @@ static int ml_host(bool zml, movi_index_t *ix, const uint8_t *h_bases, const uin
     HIP_TRY(hipSetDevice(ix->device));
     const uint64_t o0 = h_offsets[0], span = h_offsets[n_reads] - o0;
     // The way down of the u16 vector, chunk by chunk: as it is (2 bytes per base over PCIe, no host work where the caller's vector is
-    // page-locked) or as reset masks (1/8 byte per base) that the host's worker threads expand into the caller's vector.  The DMA engine
-    // and the host's cores are two resources: a call whose vector is page-locked uses BOTH ("mixed": `host_mask_share` percent of the
-    // bases take the mask route, the rest come down as they are, side by side); a pageable vector takes masks only (no page-locking
-    // of 2 bytes per base).  "host_masks": -1 this policy for calls of >= 2^22 bases, 0 never masks, 1 masks only, 2 mixed.
+    // page-locked) or as reset masks (1/8 byte per base) that the host's worker threads expand into the caller's vector -- the DMA engine
+    // and the host's cores are two resources.  "host_masks": -1 = masks for calls of >= 2^22 bases (no page-locking of the vector; with the
+    // words handed to the pool by a host function on the chunk's stream and sixteen chunks per call this way alone runs at 33 - 34 Gbases/s
+    // on 1 M x 150 bp, the vector's at 22.7, the 1 B / base upload's floor is 36.7), 0 = never masks, 1 = masks for every call, 2 = both
+    // ways side by side, `host_mask_share` percent of the bases as masks (31 - 34: no better than masks alone since the host function;
+    // profiles/r06_host_path.txt).
     enum { kVector = 0, kMasks = 1, kMixed = 2 };
     int route = kVector;
     if (h_mask_words) route = kMasks;
     else if (!zml && h_out_pml) {
         if (ix->host_masks > 0) route = ix->host_masks >= 2 ? kMixed : kMasks;
-        else if (ix->host_masks < 0 && span >= (1ull << 22))     // (a pageable vector of a call big enough to page-lock its buffers for: both ways too)
-            route = (is_pinned(h_out_pml) || autopin_worthwhile(ix, h_offsets, n_reads)) ? kMixed : kMasks;
+        else if (ix->host_masks < 0 && span >= (1ull << 22)) route = kMasks;
     }
     // A chunk's way down: `masks` = reset masks + host expansion, else the vector by DMA; a mixed call deals its chunks by `host_mask_share`.
     // (Tried: walks that leave both on the device and a choice at download time by the pool's backlog -- 28.1 against 29.9 Gbases/s for
     // the plain deal; a call's tail cut into halving chunks -- 27.3 against 28.1: profiles/r06_host_path.txt.)
-    struct Way { bool masks = false; uint32_t phase = 0; };
+    struct Way { bool masks = false, delivered = false; uint32_t phase = 0; };
     uint64_t acc_all = 0, acc_mask = 0;                       // bases launched so far / of them by the mask route
     std::unordered_map<uint64_t, Way> way_of;                 // first read of a chunk -> its way (launch, fetch and harvest run on the calling thread)
     const int threads = ix->host_threads > 0 ? ix->host_threads : host_threads_default();
@@ -1964,8 +1988,22 @@ static int ml_host(bool zml, movi_index_t *ix, const uint8_t *h_bases, const uin
         const Way w = way_of[first];
         if (w.masks) {
             const size_t nw = (size_t)(((nb + w.phase) >> 5) + nr);
-            if (c.async) {                                    // into the slot's page-locked block; harvest() takes it from there
+            if (c.async) {
+                // into the slot's page-locked block, and on to the worker pool by a host function on the chunk's stream -- the moment the
+                // words have arrived, not when the calling thread's loop next comes by (with 8 chunks per call the pool ran at 2/3 duty)
                 HIP_TRY(c.down_small(nullptr, 0, c.d[movi_index::kMask], nw * 4));
+                DeliverArg *a = new DeliverArg;
+                a->words = reinterpret_cast<const uint32_t *>(c.h_small);
+                a->mask_dst = h_mask_words ? h_mask_words + ((b0 - o0) >> 5) + first : nullptr;
+                a->mask_bytes = nw * 4;
+                a->expand = h_out_pml != nullptr;
+                a->job.words = a->words; a->job.offs = h_offsets; a->job.o0 = b0; a->job.phase = w.phase; a->job.ibase = first;
+                a->job.i0 = first; a->job.i1 = first + nr; a->job.out = h_out_pml;
+                a->threads = threads;
+                a->group = c.grp;
+                const hipError_t eh = hipLaunchHostFunc(c.s, deliver_on_stream, a);
+                if (eh != hipSuccess) { delete a; (void)hipGetLastError(); return MOVI_OK; }   // harvest() does it instead
+                way_of[first].delivered = true;
                 return MOVI_OK;
             }
             if (h_mask_words && !h_out_pml) {                 // straight to where they belong
@@ -1982,7 +2020,7 @@ static int ml_host(bool zml, movi_index_t *ix, const uint8_t *h_bases, const uin
     };
     auto harvest = [&](const uint8_t *h_small, uint64_t first, uint64_t nr, HostPool::Group *g) {
         const Way w = way_of[first];
-        if (!w.masks) return;
+        if (!w.masks || w.delivered) return;
         deliver(reinterpret_cast<const uint32_t *>(h_small), first, nr, w.phase, g);
     };
     // masks: only the reads have to be page-locked for the overlapped path (the vector is written by host threads)

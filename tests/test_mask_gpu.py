@@ -250,7 +250,7 @@ def test_overlapped_host_path_both_ways_down(engines, share):
     finally:
         gpu.set_option("pipe_chunk_bases", 0)
         gpu.set_option("host_masks", -1)
-        gpu.set_option("host_mask_share", 60)
+        gpu.set_option("host_mask_share", 70)
 
 
 def test_large_batch_through_masks(built_lib):
