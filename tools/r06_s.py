@@ -21,7 +21,7 @@ def run(hm, share, chunk):
         check(lib().movi_pml_host(idx._h, hb.ctypes.data, offs.ctypes.data, n, ho.ctypes.data, None, C.byref(st)))
         ts.append(time.perf_counter() - t0)
     return bases.size / min(ts[1:]) / 1e9, bases.size / sorted(ts[1:])[3] / 1e9
-for rep in range(2):
-    for chunk in (0, 9_375_000, 18_750_000, 25_000_000):
-        print("chunk %9d: vector %.2f | masks %.2f | both 50 %%: %.2f  60 %%: %.2f (median %.2f)  70 %%: %.2f" % (
-            (chunk, run(0, 60, chunk)[0], run(1, 60, chunk)[0], run(2, 50, chunk)[0]) + run(2, 60, chunk) + (run(2, 70, chunk)[0],)), flush=True)
+for rep in range(3):
+    for taper in (0, 1):
+        idx.set_option("pipe_taper", taper)
+        print("taper %d: masks %.2f (median %.2f)" % ((taper,) + run(-1, 70, 0)), flush=True)
