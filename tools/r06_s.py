@@ -21,7 +21,12 @@ def run(hm, share, chunk):
         check(lib().movi_pml_host(idx._h, hb.ctypes.data, offs.ctypes.data, n, ho.ctypes.data, None, C.byref(st)))
         ts.append(time.perf_counter() - t0)
     return bases.size / min(ts[1:]) / 1e9, bases.size / sorted(ts[1:])[3] / 1e9
+from movi_amd.engine import mask_words
+hw = np.zeros(mask_words(n, bases.size), np.uint32)
 for rep in range(3):
-    for taper in (0, 1):
-        idx.set_option("pipe_taper", taper)
-        print("taper %d: masks %.2f (median %.2f)" % ((taper,) + run(-1, 70, 0)), flush=True)
+    ts = []
+    for _ in range(6):
+        t0 = time.perf_counter()
+        check(lib().movi_pml_mask_host(idx._h, hb.ctypes.data, offs.ctypes.data, n, hw.ctypes.data, None, C.byref(st)))
+        ts.append(time.perf_counter() - t0)
+    print("masks only %.2f | vector through masks %.2f (median %.2f) | vector by DMA %.2f" % ((bases.size / min(ts[1:]) / 1e9,) + run(-1, 70, 0) + (run(0, 70, 0)[0],)), flush=True)
