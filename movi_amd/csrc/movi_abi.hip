@@ -138,7 +138,7 @@ struct movi_index {
         uint8_t *h = nullptr;
         size_t h_cap = 0;
     };
-    enum { kPipeSlots = 6, kPipeAhead = 3 };   // slots; chunks going up or being walked while one comes down
+    enum { kPipeSlots = 6, kPipeAhead = 3 };   // slots; chunks going up or being walked while one comes down (2: -14 %, 4: the same)
     PipeSlot pipe[kPipeSlots];
     hipStream_t pipe_up = nullptr;   // every chunk's upload, in order (uploads on separate streams share the link and all arrive late)
     uint64_t pipe_chunk_bases = 0;   // test hook ("pipe_chunk_bases"): chunk size of the overlapped path, 0 = its policy

@@ -3,4 +3,4 @@
 cd "$(dirname "$0")/.." || exit 1
 O=gpurun_out/r06_s; mkdir -p $O
 
-timeout 900 python3 tools/r06_s.py 2>&1 | grep -v amdgpu.ids | tee $O/offsets_on_slot_stream.txt
+timeout 900 python3 tools/r06_s.py 2>&1 | grep -v amdgpu.ids | tee $O/host_threads.txt
