@@ -141,6 +141,7 @@ struct movi_index {
     enum { kPipeSlots = 6, kPipeAhead = 3 };   // slots; chunks going up or being walked while one comes down (2: -14 %, 4: the same)
     PipeSlot pipe[kPipeSlots];
     hipStream_t pipe_up = nullptr;   // every chunk's upload, in order (uploads on separate streams share the link and all arrive late)
+    std::vector<hipEvent_t> pipe_ev; // chunk i of a call has arrived (calls whose reads go up ahead of the loop into scratch[kBases])
     uint64_t pipe_chunk_bases = 0;   // test hook ("pipe_chunk_bases"): chunk size of the overlapped path, 0 = its policy
     LaunchInfo last_launch;          // what the last query call launched (movi_last_launch)
     bool host_autopin = true;        // big *_host calls on pageable buffers page-lock them for the call ("host_autopin")
@@ -158,7 +159,18 @@ struct movi_index {
 };
 
 static void release_scratch(movi_index *ix);
-namespace { hipError_t grow(void **p, size_t *cap, size_t bytes); }   // grow-only device staging (defined with the host paths)
+namespace { hipError_t grow(void **p, size_t *cap, size_t bytes); }
+// The upload stream of the overlapped host paths.  Streams of one priority share a handful of hardware queues, and a chunk's stream that
+// landed on the upload stream's queue had its walk queued behind the copies' completion packets (every sixth chunk waited for uploads that
+// were not its own: 0.1 ms of a dry upload stream each time, profiles/r06_host_path.txt).  A stream of another priority gets a queue of
+// its own kind.
+static hipError_t create_upload_stream(hipStream_t *s) {
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
+        if (hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest) == hipSuccess) return hipSuccess;
+    (void)hipGetLastError();
+    return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}   // grow-only device staging (defined with the host paths)
 
 extern "C" {
 
@@ -1464,6 +1476,8 @@ static void release_scratch(movi_index *ix) {
         (void)hipStreamDestroy(ix->pipe_up);
         ix->pipe_up = nullptr;
     }
+    for (hipEvent_t e : ix->pipe_ev) (void)hipEventDestroy(e);
+    ix->pipe_ev.clear();
     if (ix->seg_ws.buf) (void)hipFree(ix->seg_ws.buf);
     ix->seg_ws = SegWorkspace();
     if (ix->h_rel) (void)hipHostFree(ix->h_rel);
@@ -1664,6 +1678,7 @@ int run_pipelined(movi_index *ix, const uint8_t *h_bases, const uint64_t *h_offs
         chunks.push_back({first, last - first, h_offsets[first], h_offsets[last] - h_offsets[first]});
         first = last;
     }
+    uint8_t *all = nullptr;                                    // the call's reads in one device buffer (set below, ahead of the loop), or chunk by chunk
     constexpr int S = movi_index::kPipeSlots;
     struct InFlight { int stage = 0; Chunk c{}; } fl[S];       // 0 free, 1 walking (upload + kernel enqueued), 2 coming down
     HostPool::Group grp[S];                                    // host-side work a slot's harvest has handed to the worker pool (it reads the slot's page-locked block)
@@ -1707,14 +1722,14 @@ int run_pipelined(movi_index *ix, const uint8_t *h_bases, const uint64_t *h_offs
         return MOVI_OK;
     };
     // chunk c goes up into slot k and is walked
-    auto up = [&](const Chunk &c, int k) -> int {
+    auto up = [&](const Chunk &c, int k, size_t ci) -> int {
         movi_index::PipeSlot &sl = ix->pipe[k];
         if (int rc = finish(k)) return rc;
         HostPool::get().wait(&grp[k]);                       // (the slot's block is about to be rewritten)
         if (!sl.s) HIP_TRY(hipStreamCreateWithFlags(&sl.s, hipStreamNonBlocking));
         if (!sl.ev) HIP_TRY(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
         if (!sl.ev_up) HIP_TRY(hipEventCreateWithFlags(&sl.ev_up, hipEventDisableTiming));
-        if (!ix->pipe_up) HIP_TRY(hipStreamCreateWithFlags(&ix->pipe_up, hipStreamNonBlocking));
+        if (!ix->pipe_up) HIP_TRY(create_upload_stream(&ix->pipe_up));
         if (!sl.d_stats) HIP_TRY(hipMalloc(&sl.d_stats, sizeof(DevStats)));
         const size_t hb = off_stats(c.nr, c.nb) + sizeof(DevStats);
         if (sl.h_cap < hb) {
@@ -1728,7 +1743,8 @@ int run_pipelined(movi_index *ix, const uint8_t *h_bases, const uint64_t *h_offs
         fl[k].c = c;
         ChunkCtx ctx = ctx_of(k, c.nr);
         struct { void *p; } d_bases{}, d_offs{}, d_err{};
-        HIP_TRY(ctx.alloc(movi_index::kBases, c.nb, &d_bases.p));
+        if (all) d_bases.p = all + (c.b0 - chunks[0].b0);
+        else HIP_TRY(ctx.alloc(movi_index::kBases, c.nb, &d_bases.p));
         HIP_TRY(ctx.alloc(movi_index::kOffs, (c.nr + 1) * 8, &d_offs.p));
         HIP_TRY(ctx.alloc(movi_index::kErr, c.nr, &d_err.p));
         uint64_t *rel = reinterpret_cast<uint64_t *>(sl.h);
@@ -1742,10 +1758,15 @@ int run_pipelined(movi_index *ix, const uint8_t *h_bases, const uint64_t *h_offs
         fl[k].stage = 1;                                     // from here on the streams hold work that touches caller memory
         // (the upload stream carries the bases alone, copy behind copy: with the chunk's offsets in between, every chunk left it idle for
         // ~40 us -- a fifth of a 9.4 MB copy; the offsets go up on the chunk's own stream, ahead of its walk: profiles/r06_host_path.txt)
-        if (c.nb) HIP_TRY(hipMemcpyAsync(d_bases.p, h_bases + c.b0, c.nb, hipMemcpyHostToDevice, ix->pipe_up));
-        HIP_TRY(hipEventRecord(sl.ev_up, ix->pipe_up));
-        HIP_TRY(hipMemcpyAsync(d_offs.p, rel, (c.nr + 1) * 8, hipMemcpyHostToDevice, sl.s));
-        HIP_TRY(hipStreamWaitEvent(sl.s, sl.ev_up, 0));
+        if (!all) {
+            if (c.nb) HIP_TRY(hipMemcpyAsync(d_bases.p, h_bases + c.b0, c.nb, hipMemcpyHostToDevice, ix->pipe_up));
+            HIP_TRY(hipEventRecord(sl.ev_up, ix->pipe_up));
+            HIP_TRY(hipMemcpyAsync(d_offs.p, rel, (c.nr + 1) * 8, hipMemcpyHostToDevice, sl.s));
+        } else {
+            // (by a kernel that reads the slot's page-locked block, not by the copy engine: that one has the whole call's reads queued)
+            HIP_TRY(launch_copy_words(static_cast<uint64_t *>(d_offs.p), rel, c.nr + 1, sl.s));
+        }
+        HIP_TRY(hipStreamWaitEvent(sl.s, all ? ix->pipe_ev[ci] : sl.ev_up, 0));
         if (int rc = launch(ctx, static_cast<const uint8_t *>(d_bases.p), static_cast<const uint64_t *>(d_offs.p), c.nr, c.nb,
                             static_cast<uint8_t *>(d_err.p)))
             return rc;
@@ -1782,8 +1803,36 @@ int run_pipelined(movi_index *ix, const uint8_t *h_bases, const uint64_t *h_offs
     int rc = MOVI_OK;
     const size_t n = chunks.size();
     size_t next_up = 0;
+    // ALL THE READS GO UP AHEAD OF THE LOOP (calls of up to 2^31 bases, into the handle's call-wide staging): the copies queued behind one
+    // another, an event behind each, and a chunk's walk waits for its event.  Enqueued chunk by chunk from the loop -- three ahead of the
+    // walk being waited for -- the upload stream ran dry two or three times per call (0.1 ms each), and the upload is what bounds the
+    // call.  (The chunks' offsets then must not travel by the copy engine: they would queue behind the whole call's reads.)
+    if (n > 1 && total <= (1ull << 31)) {
+        hipError_t e = hipSuccess;
+        if (!ix->pipe_up) e = create_upload_stream(&ix->pipe_up);
+        if (e == hipSuccess) e = grow(&ix->scratch[movi_index::kBases], &ix->scratch_cap[movi_index::kBases], total);
+        while (e == hipSuccess && ix->pipe_ev.size() < n) {
+            hipEvent_t ev = nullptr;
+            e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+            if (e == hipSuccess) ix->pipe_ev.push_back(ev);
+        }
+        if (e == hipSuccess) {
+            all = static_cast<uint8_t *>(ix->scratch[movi_index::kBases]);
+            for (size_t i = 0; i < n && e == hipSuccess; i++) {
+                const Chunk &c = chunks[i];
+                if (c.nb) e = hipMemcpyAsync(all + (c.b0 - chunks[0].b0), h_bases + c.b0, c.nb, hipMemcpyHostToDevice, ix->pipe_up);
+                if (e == hipSuccess) e = hipEventRecord(ix->pipe_ev[i], ix->pipe_up);
+            }
+            if (e != hipSuccess) {                            // copies may be in flight: nothing reads the caller's buffers when the call returns
+                (void)hipStreamSynchronize(ix->pipe_up);
+                return fail_hip(e, "uploading the reads");
+            }
+        } else {
+            (void)hipGetLastError();                          // no room for the call-wide staging: chunk by chunk, as before
+        }
+    }
     for (size_t i = 0; i < n && rc == MOVI_OK; i++) {
-        for (; next_up < n && next_up < i + (size_t)movi_index::kPipeAhead && rc == MOVI_OK; next_up++) rc = up(chunks[next_up], (int)(next_up % S));
+        for (; next_up < n && next_up < i + (size_t)movi_index::kPipeAhead && rc == MOVI_OK; next_up++) rc = up(chunks[next_up], (int)(next_up % S), next_up);
         if (rc == MOVI_OK) rc = down((int)(i % S));
         if (rc == MOVI_OK) rc = finish_arrived();
     }

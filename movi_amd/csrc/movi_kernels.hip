@@ -914,6 +914,16 @@ static hipError_t launch_pml_segmented(const DevIndex &ix, const uint8_t *d_base
     return e;
 }
 
+__global__ __launch_bounds__(256) void copy_words_kernel(uint64_t *__restrict__ dst, const uint64_t *__restrict__ src, uint64_t n) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) dst[t] = src[t];
+}
+hipError_t launch_copy_words(uint64_t *d_dst, const uint64_t *src, uint64_t n, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(copy_words_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_dst, src, n);
+    return hipGetLastError();
+}
+
 // ---- launch log (diagnostic; movi_launch_log): the distinct walk kernels launched since it was switched on / last read
 static std::atomic<bool> g_launch_log_on{false};
 static std::mutex g_launch_log_m;

@@ -283,6 +283,9 @@ bool pml_vector_via_masks(const DevIndex &ix, const LaunchCfg &cfg, uint64_t n_r
 // u16 vector <-> masks, streaming (one lane per read; a wavefront per read from a mean length of 2048 bases)
 hipError_t launch_pml_expand(const uint32_t *d_words, const uint64_t *d_offsets, uint64_t n_reads, uint64_t n_bases, uint32_t phase,
                              uint16_t *d_out, hipStream_t stream);
+// n 8-byte words from page-locked host memory (or anywhere the device can read) to the device by a kernel on `stream`: small blocks that
+// must not queue behind bulk transfers on the copy engine (run_pipelined's per-chunk offsets)
+hipError_t launch_copy_words(uint64_t *d_dst, const uint64_t *src, uint64_t n, hipStream_t stream);
 hipError_t launch_pml_to_mask(const uint16_t *d_pml, const uint64_t *d_offsets, uint64_t n_reads, uint64_t n_bases, uint32_t phase,
                               uint32_t *d_words, hipStream_t stream);
 

@@ -30,13 +30,5 @@ def masks_only():
         check(lib().movi_pml_mask_host(idx._h, hb.ctypes.data, offs.ctypes.data, n, hw.ctypes.data, None, C.byref(st)))
         ts.append(time.perf_counter() - t0)
     return bases.size / min(ts[1:]) / 1e9
-def run_thr(thr):
-    idx.set_option("host_masks", -1); idx.set_option("host_threads", thr); idx.set_option("pipe_chunk_bases", 0)
-    ts = []
-    for _ in range(7):
-        t0 = time.perf_counter()
-        check(lib().movi_pml_host(idx._h, hb.ctypes.data, offs.ctypes.data, n, ho.ctypes.data, None, C.byref(st)))
-        ts.append(time.perf_counter() - t0)
-    return bases.size / min(ts[1:]) / 1e9, bases.size / sorted(ts[1:])[3] / 1e9
 for rep in range(3):
-    print("host_threads 8 / 10 / 12 / 14 / 16: " + " | ".join("%.2f (median %.2f)" % run_thr(t) for t in (8, 10, 12, 14, 16)), flush=True)
+    print("masks only %.2f | vector through masks %.2f (median %.2f) | vector by DMA %.2f" % ((masks_only(),) + run(-1, 70, 0) + (run(0, 70, 0)[0],)), flush=True)
