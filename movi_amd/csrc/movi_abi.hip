@@ -1640,7 +1640,7 @@ int run_chunked(movi_index *ix, const uint8_t *h_bases, const uint64_t *h_offset
 template <typename Launch, typename Fetch, typename Harvest>
 int run_pipelined(movi_index *ix, const uint8_t *h_bases, const uint64_t *h_offsets, uint64_t n_reads,
                   uint8_t *h_read_err, movi_query_stats_t *stats, Launch launch, Fetch fetch, Harvest harvest,
-                  size_t small_bytes, size_t mask_word_bytes) {
+                  size_t small_bytes, size_t mask_word_bytes, bool vector_down) {
     if (stats) memset(stats, 0, sizeof(*stats));
     movi_query_stats_t acc{};
     const uint64_t total = h_offsets[n_reads] - h_offsets[0];
@@ -1807,7 +1807,7 @@ int run_pipelined(movi_index *ix, const uint8_t *h_bases, const uint64_t *h_offs
     // another, an event behind each, and a chunk's walk waits for its event.  Enqueued chunk by chunk from the loop -- three ahead of the
     // walk being waited for -- the upload stream ran dry two or three times per call (0.1 ms each), and the upload is what bounds the
     // call.  (The chunks' offsets then must not travel by the copy engine: they would queue behind the whole call's reads.)
-    if (n > 1 && total <= (1ull << 31)) {
+    if (n > 1 && total <= (1ull << 31) && !vector_down) {
         hipError_t e = hipSuccess;
         if (!ix->pipe_up) e = create_upload_stream(&ix->pipe_up);
         if (e == hipSuccess) e = grow(&ix->scratch[movi_index::kBases], &ix->scratch_cap[movi_index::kBases], total);
@@ -1864,10 +1864,10 @@ bool worth_overlapping_small_results(const uint64_t *h_offsets, uint64_t n_reads
 template <typename Launch, typename Fetch, typename Harvest>
 int run_host(bool overlapped, movi_index *ix, const uint8_t *h_bases, const uint64_t *h_offsets, uint64_t n_reads,
              uint8_t *h_read_err, movi_query_stats_t *stats, Launch launch, Fetch fetch, Harvest harvest,
-             size_t small_bytes, size_t mask_word_bytes = 0) {
+             size_t small_bytes, size_t mask_word_bytes = 0, bool vector_down = false) {
     movi_query_stats_t local{};
     overlapped = overlapped && ix->host_overlap;
-    int rc = overlapped ? run_pipelined(ix, h_bases, h_offsets, n_reads, h_read_err, &local, launch, fetch, harvest, small_bytes, mask_word_bytes)
+    int rc = overlapped ? run_pipelined(ix, h_bases, h_offsets, n_reads, h_read_err, &local, launch, fetch, harvest, small_bytes, mask_word_bytes, vector_down)
                         : run_chunked(ix, h_bases, h_offsets, n_reads, h_read_err, &local, launch, fetch, harvest, small_bytes, mask_word_bytes);
     if (stats) *stats = local;
     if (rc) return rc;
@@ -2085,7 +2085,10 @@ static int ml_host(bool zml, movi_index_t *ix, const uint8_t *h_bases, const uin
         overlapped = pin_bases.pin(const_cast<uint8_t *>(h_bases) + h_offsets[0], span) &&
                      (route == kMasks || !h_out_pml || pin_out.pin(h_out_pml + h_offsets[0], span * 2));
     if (route == kMixed && !overlapped) route = kMasks;       // (the synchronous path: one way down for the whole call)
-    return run_host(overlapped, ix, h_bases, h_offsets, n_reads, h_read_err, stats, launch, fetch, harvest, 0, route != kVector ? 4 : 0);
+    // (vector_down: 2 bytes per base come down by DMA -- the way down bounds such a call, and with every read going up at once beside
+    // it the downloads ran 8 % slower: those calls feed their uploads from the loop)
+    return run_host(overlapped, ix, h_bases, h_offsets, n_reads, h_read_err, stats, launch, fetch, harvest, 0, route != kVector ? 4 : 0,
+                    route != kMasks && h_out_pml != nullptr);
 }
 
 int movi_pml_mask_host(movi_index_t *ix, const uint8_t *h_bases, const uint64_t *h_offsets, uint64_t n_reads,
